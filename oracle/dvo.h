@@ -1,0 +1,97 @@
+/*
+ * dvo.h — C API of the CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * The oracle is a dependency-free C++17 restatement of the reference's hot path
+ * (dynamic_vins front-end tracking + sliding-window BA).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product
+ * (dynamic_vins_amd/, libdvins_hip.so) never links, imports or calls anything here.
+ *
+ * PARITY UNPINNED: the reference ships no golden vectors for this path and cannot be
+ * built in this image (needs ROS/OpenCV-CUDA/Ceres/Eigen).  The third-party pieces
+ * (OpenCV 3.4.16 calcOpticalFlowPyrLK / goodFeaturesToTrack / circle, Ceres 1.14
+ * DENSE_SCHUR+DOGLEG) are restated from their published algorithms;
+ * first-party pieces cite the reference file:line they follow.
+ */
+#ifndef DVO_H
+#define DVO_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------- front end ---------------- */
+
+typedef struct dvo_cam {   /* camodocal PinholeCamera parameters (PinholeCamera.cc:292-295) */
+    double fx, fy, cx, cy, k1, k2, p1, p2;
+} dvo_cam;
+
+typedef struct dvo_fe_config {  /* fe_para (front_end_parameters.cpp:18-40) + cfg::is_stereo */
+    int width, height;
+    int max_cnt;       /* fe_para::kMaxCnt  */
+    int min_dist;      /* fe_para::kMinDist */
+    int flow_back;     /* fe_para::is_flow_back */
+    int stereo;        /* cfg::is_stereo */
+    dvo_cam cam0, cam1;
+} dvo_fe_config;
+
+/* one row per tracked feature, left observation always present */
+typedef struct dvo_feat {
+    uint32_t id;
+    int32_t track_cnt;
+    int32_t has_right;
+    int32_t pad_;
+    double left[7];   /* x_n, y_n, 1, u, v, vx, vy  (background_tracker.cpp:347-355) */
+    double right[7];
+} dvo_feat;
+
+/* cv::pyrDown 8U, 5x5 [1 4 6 4 1]^2 /256, BORDER_REFLECT_101; dst is ((w+1)/2)x((h+1)/2) */
+void dvo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst);
+
+/* calcScharrDeriv (OpenCV lkpyramid.cpp): out is int16 interleaved (Ix,Iy), w*h*2 */
+void dvo_scharr(const uint8_t* src, int w, int h, int16_t* out);
+
+/* cv::calcOpticalFlowPyrLK(img_a,img_b,pts_a,pts_b,status,err,Size(21,21),max_level,
+ * TermCriteria(COUNT+EPS,iters,eps), use_initial?OPTFLOW_USE_INITIAL_FLOW:0, 1e-4).
+ * pts are interleaved (x,y) float; pts_b is in/out when use_initial. */
+void dvo_lk(const uint8_t* img_a, const uint8_t* img_b, int w, int h,
+            const float* pts_a, int n, int max_level, int iters, double eps,
+            int use_initial, float* pts_b, uint8_t* status);
+
+/* FeatureTrackByLK (front_end/feature_utils.cpp:35-69); dist_thresh 0.5 there */
+void dvo_track_by_lk(const uint8_t* img1, const uint8_t* img2, int w, int h,
+                     const float* pts1, int n, int flow_back, float dist_thresh,
+                     float* pts2, uint8_t* status);
+
+/* cv::cornerMinEigenVal(img, eig, 3, 3) */
+void dvo_min_eigen(const uint8_t* img, int w, int h, float* eig);
+
+/* cv::goodFeaturesToTrack(img, out, max_n, quality, min_dist, mask) ; mask may be NULL */
+void dvo_gftt(const uint8_t* img, const uint8_t* mask, int w, int h, int max_n,
+              double quality, double min_dist, float* out_xy, int* n_out);
+
+/* cv::circle(mask, Point(cvRound(x),cvRound(y)), radius, 0, -1) for each point */
+void dvo_circle_mask(uint8_t* mask, int w, int h, const float* pts_xy, int n, int radius);
+
+/* cv::erode with k x k rect, anchor centre, border +inf (feature_utils.h:142-146) */
+void dvo_erode(const uint8_t* src, int w, int h, int k, uint8_t* dst);
+
+/* PinholeCamera::liftProjective (PinholeCamera.cc:450-508) -> (x/z, y/z) as float */
+void dvo_lift_projective(const dvo_cam* cam, const float* pts_xy, int n, float* out_xy);
+
+/* FeatureTracker (front_end/background_tracker.cpp) */
+typedef struct dvo_tracker dvo_tracker;
+dvo_tracker* dvo_tracker_create(const dvo_fe_config* cfg);
+void dvo_tracker_destroy(dvo_tracker*);
+/* TrackImage (raw mode, :52-158). mask==NULL. out must hold max_cnt rows. returns n */
+int dvo_tracker_track_image(dvo_tracker*, const uint8_t* gray0, const uint8_t* gray1,
+                            double time, dvo_feat* out);
+/* TrackImageNaive-style (:400-516): mask = inv_merge_mask (0 = object), eroded by caller;
+ * uses the A.1 LK (canonical) with fwd/bwd threshold 1.0 (feature_utils.cpp:126) and
+ * DetectNewFeature's "<10 -> skip" refill rule (instance_feature.cpp:353-356). */
+int dvo_tracker_track_image_naive(dvo_tracker*, const uint8_t* gray0, const uint8_t* gray1,
+                                  const uint8_t* mask, double time, dvo_feat* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

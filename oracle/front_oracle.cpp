@@ -1,0 +1,547 @@
+// front_oracle.cpp — CPU ORACLE (test infrastructure, not the product) for the front end.
+//
+// Restates, dependency-free:
+//   * OpenCV 3.4.16 calcOpticalFlowPyrLK / buildOpticalFlowPyramid / calcSharrDeriv / pyrDown
+//     (modules/video/src/lkpyramid.cpp, modules/imgproc/src/pyramids.cpp) — un-vendored
+//     third-party code, restated from the published algorithm;
+//   * OpenCV 3.4.16 goodFeaturesToTrack / cornerMinEigenVal (featureselect.cpp, corner.cpp),
+//     circle() (drawing.cpp, Circle()), erode (App. A.2 / A.5);
+//   * camodocal PinholeCamera::liftProjective (camera_models/src/camera_models/PinholeCamera.cc:450-508,646-662);
+//   * dynamic_vins FeatureTrackByLK (front_end/feature_utils.cpp:35-69), InBorder / ReduceVector
+//     (feature_utils.h:68-85), SortPoints (feature_utils.cpp:307-328), InstFeat::PtsVelocity
+//     (front_end/instance_feature.cpp:26-85), FeatureTracker::TrackImage / TrackImageNaive /
+//     SetOutputFeats (front_end/background_tracker.cpp:52-158, 340-392, 400-516).
+//
+// PARITY UNPINNED (see dvo.h).  Documented canonical choices where OpenCV itself is
+// platform dependent:
+//   D1  LK window sums (A11,A12,A22,b1,b2) are sums of integers that OpenCV accumulates in
+//       float in a platform-dependent order (scalar / SSE2 4-lane / NEON).  The oracle takes
+//       the exact integer sum (int64) and converts to float once.
+//   D2  boxFilter on the CV_32FC3 covariance image uses double sliding sums in OpenCV; the
+//       oracle sums the 3x3 window in double in a fixed order ((l+c)+r per row, (t+m)+b).
+//   D3  SortPoints uses unstable std::sort on track_cnt (Q11); the oracle uses a stable sort.
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off (no FMA contraction: results must not depend
+// on the host ISA).
+#include "dvo.h"
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <vector>
+
+namespace {
+
+inline int reflect101(int p, int len) {          // cv::borderInterpolate(BORDER_REFLECT_101)
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+inline int cv_round(double v) { return (int)std::nearbyint(v); }   // round-half-even (default FE mode)
+inline int cv_floor(float v) { return (int)std::floor(v); }
+inline int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }   // CV_DESCALE
+
+struct Img { int w = 0, h = 0; std::vector<uint8_t> d; };
+
+void pyr_down(const uint8_t* src, int w, int h, uint8_t* dst) {
+    const int w2 = (w + 1) / 2, h2 = (h + 1) / 2;
+    std::vector<int> rows(5 * (size_t)w2);
+    for (int y = 0; y < h2; ++y) {
+        for (int k = 0; k < 5; ++k) {
+            const uint8_t* s = src + (size_t)reflect101(2 * y + k - 2, h) * w;
+            int* r = rows.data() + (size_t)k * w2;
+            for (int x = 0; x < w2; ++x) {
+                int x0 = reflect101(2 * x - 2, w), x1 = reflect101(2 * x - 1, w), x2 = 2 * x < w ? 2 * x : reflect101(2 * x, w);
+                int x3 = reflect101(2 * x + 1, w), x4 = reflect101(2 * x + 2, w);
+                r[x] = s[x0] + s[x4] + 4 * (s[x1] + s[x3]) + 6 * s[x2];
+            }
+        }
+        for (int x = 0; x < w2; ++x) {
+            int v = rows[x] + rows[4 * (size_t)w2 + x] + 4 * (rows[(size_t)w2 + x] + rows[3 * (size_t)w2 + x]) + 6 * rows[2 * (size_t)w2 + x];
+            dst[(size_t)y * w2 + x] = (uint8_t)((v + 128) >> 8);
+        }
+    }
+}
+
+// calcSharrDeriv: Ix = [3 10 3]^T (vertical smooth) x [-1 0 1]; Iy = [-1 0 1]^T x [3 10 3]; REFLECT_101
+void scharr(const uint8_t* src, int w, int h, int16_t* out) {
+    std::vector<int> t0(w + 2), t1(w + 2);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * w;
+        const uint8_t* r1 = src + (size_t)y * w;
+        const uint8_t* r2 = src + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * w;
+        for (int x = 0; x < w; ++x) {
+            t0[x + 1] = (r0[x] + r2[x]) * 3 + r1[x] * 10;
+            t1[x + 1] = r2[x] - r0[x];
+        }
+        int xl = w > 1 ? 1 : 0, xr = w > 1 ? w - 2 : 0;
+        t0[0] = t0[xl + 1]; t0[w + 1] = t0[xr + 1];
+        t1[0] = t1[xl + 1]; t1[w + 1] = t1[xr + 1];
+        for (int x = 0; x < w; ++x) {
+            out[((size_t)y * w + x) * 2 + 0] = (int16_t)(t0[x + 2] - t0[x]);
+            out[((size_t)y * w + x) * 2 + 1] = (int16_t)((t1[x + 2] + t1[x]) * 3 + t1[x + 1] * 10);
+        }
+    }
+}
+
+constexpr int WIN = 21;     // cv::Size(21,21) at every call site (feature_utils.cpp:44,51)
+constexpr int PAD = WIN;    // buildOpticalFlowPyramid pads each level by winSize
+
+struct Level {
+    int w, h;
+    std::vector<uint8_t> img;     // (w+2*PAD) x (h+2*PAD), REFLECT_101 border
+    std::vector<int16_t> der;     // same size x2, CONSTANT(0) border
+    int stride() const { return w + 2 * PAD; }
+    const uint8_t* I(int x, int y) const { return img.data() + (size_t)(y + PAD) * stride() + (x + PAD); }
+    const int16_t* D(int x, int y) const { return der.data() + ((size_t)(y + PAD) * stride() + (x + PAD)) * 2; }
+};
+
+// buildOpticalFlowPyramid(img, pyr, winSize, maxLevel, false, REFLECT_101, CONSTANT)
+int build_pyramid(const uint8_t* img, int w, int h, int max_level, std::vector<Level>& pyr, bool with_deriv) {
+    pyr.clear();
+    std::vector<uint8_t> cur(img, img + (size_t)w * h);
+    int cw = w, ch = h, level = 0;
+    for (;; ++level) {
+        Level L; L.w = cw; L.h = ch;
+        const int st = L.stride();
+        L.img.resize((size_t)st * (ch + 2 * PAD));
+        for (int y = -PAD; y < ch + PAD; ++y) {
+            const uint8_t* s = cur.data() + (size_t)reflect101(y, ch) * cw;
+            uint8_t* d = L.img.data() + (size_t)(y + PAD) * st;
+            for (int x = -PAD; x < cw + PAD; ++x) d[x + PAD] = s[reflect101(x, cw)];
+        }
+        if (with_deriv) {
+            L.der.assign((size_t)st * (ch + 2 * PAD) * 2, 0);
+            std::vector<int16_t> d((size_t)cw * ch * 2);
+            scharr(cur.data(), cw, ch, d.data());
+            for (int y = 0; y < ch; ++y)
+                std::memcpy(L.der.data() + ((size_t)(y + PAD) * st + PAD) * 2, d.data() + (size_t)y * cw * 2, (size_t)cw * 2 * sizeof(int16_t));
+        }
+        pyr.push_back(std::move(L));
+        if (level == max_level) break;
+        int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+        if (nw <= WIN || nh <= WIN) break;      // lkpyramid.cpp: level too small -> stop, return level
+        std::vector<uint8_t> nxt((size_t)nw * nh);
+        pyr_down(cur.data(), cw, ch, nxt.data());
+        cur.swap(nxt); cw = nw; ch = nh;
+    }
+    return (int)pyr.size() - 1;
+}
+
+struct P2f { float x, y; };
+
+// LKTrackerInvoker::operator() for one level (lkpyramid.cpp)
+void lk_level(const Level& I, const Level& J, int level, int max_level, const P2f* prev_pts, P2f* next_pts,
+              uint8_t* status, int n, int max_count, double eps_sq, bool use_initial) {
+    const float half = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const int W_BITS = 14;
+    int16_t Iw[WIN * WIN], dIw[WIN * WIN * 2];
+    for (int p = 0; p < n; ++p) {
+        P2f prevPt = { prev_pts[p].x * (float)(1. / (1 << level)), prev_pts[p].y * (float)(1. / (1 << level)) };
+        P2f nextPt;
+        if (level == max_level) {
+            if (use_initial) nextPt = { next_pts[p].x * (float)(1. / (1 << level)), next_pts[p].y * (float)(1. / (1 << level)) };
+            else nextPt = prevPt;
+        } else nextPt = { next_pts[p].x * 2.f, next_pts[p].y * 2.f };
+        next_pts[p] = nextPt;
+
+        prevPt.x -= half; prevPt.y -= half;
+        int ipx = cv_floor(prevPt.x), ipy = cv_floor(prevPt.y);
+        if (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h) {
+            if (level == 0) status[p] = 0;
+            continue;
+        }
+        float a = prevPt.x - ipx, b = prevPt.y - ipy;
+        int iw00 = cv_round((1.f - a) * (1.f - b) * (1 << W_BITS));
+        int iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
+        int iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
+        int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        const int st = I.stride();
+        int64_t sA11 = 0, sA12 = 0, sA22 = 0;      // D1: exact integer sums
+        for (int y = 0; y < WIN; ++y) {
+            const uint8_t* src = I.I(ipx, ipy + y);
+            const int16_t* ds = I.D(ipx, ipy + y);
+            for (int x = 0; x < WIN; ++x) {
+                int ival = descale(src[x] * iw00 + src[x + 1] * iw01 + src[x + st] * iw10 + src[x + st + 1] * iw11, W_BITS - 5);
+                int ixval = descale(ds[2 * x] * iw00 + ds[2 * x + 2] * iw01 + ds[2 * (x + st)] * iw10 + ds[2 * (x + st) + 2] * iw11, W_BITS);
+                int iyval = descale(ds[2 * x + 1] * iw00 + ds[2 * x + 3] * iw01 + ds[2 * (x + st) + 1] * iw10 + ds[2 * (x + st) + 3] * iw11, W_BITS);
+                Iw[y * WIN + x] = (int16_t)ival;
+                dIw[(y * WIN + x) * 2] = (int16_t)ixval;
+                dIw[(y * WIN + x) * 2 + 1] = (int16_t)iyval;
+                sA11 += (int64_t)ixval * ixval; sA12 += (int64_t)ixval * iyval; sA22 += (int64_t)iyval * iyval;
+            }
+        }
+        float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        float D = A11 * A22 - A12 * A12;
+        float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * WIN * WIN);
+        if (minEig < 1e-4f || D < FLT_EPSILON) {          // minEigThreshold = 1e-4 (default)
+            if (level == 0) status[p] = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nextPt.x -= half; nextPt.y -= half;
+        P2f prevDelta = { 0.f, 0.f };
+        const int stJ = J.stride();
+        for (int j = 0; j < max_count; ++j) {
+            int inx = cv_floor(nextPt.x), iny = cv_floor(nextPt.y);
+            if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) {
+                if (level == 0) status[p] = 0;
+                break;
+            }
+            a = nextPt.x - inx; b = nextPt.y - iny;
+            iw00 = cv_round((1.f - a) * (1.f - b) * (1 << W_BITS));
+            iw01 = cv_round(a * (1.f - b) * (1 << W_BITS));
+            iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
+            iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+            int64_t sb1 = 0, sb2 = 0;
+            for (int y = 0; y < WIN; ++y) {
+                const uint8_t* Jp = J.I(inx, iny + y);
+                for (int x = 0; x < WIN; ++x) {
+                    int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stJ] * iw10 + Jp[x + stJ + 1] * iw11, W_BITS - 5) - Iw[y * WIN + x];
+                    sb1 += (int64_t)diff * dIw[(y * WIN + x) * 2];
+                    sb2 += (int64_t)diff * dIw[(y * WIN + x) * 2 + 1];
+                }
+            }
+            float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            P2f delta = { (float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D) };
+            nextPt.x += delta.x; nextPt.y += delta.y;
+            next_pts[p] = { nextPt.x + half, nextPt.y + half };
+            if ((double)delta.x * delta.x + (double)delta.y * delta.y <= eps_sq) break;
+            if (j > 0 && std::abs(delta.x + prevDelta.x) < 0.01 && std::abs(delta.y + prevDelta.y) < 0.01) {
+                next_pts[p].x -= delta.x * 0.5f; next_pts[p].y -= delta.y * 0.5f;
+                break;
+            }
+            prevDelta = delta;
+        }
+        // err != NULL at both call sites -> the level-0 re-check of the final point runs
+        if (status[p] && level == 0) {
+            P2f np = { next_pts[p].x - half, next_pts[p].y - half };
+            int ix = cv_floor(np.x), iy = cv_floor(np.y);
+            if (ix < -WIN || ix >= J.w || iy < -WIN || iy >= J.h) status[p] = 0;
+        }
+    }
+}
+
+void lk(const uint8_t* img_a, const uint8_t* img_b, int w, int h, const P2f* pts_a, int n, int max_level,
+        int iters, double eps, bool use_initial, P2f* pts_b, uint8_t* status) {
+    if (n <= 0) return;
+    std::vector<Level> pa, pb;
+    int la = build_pyramid(img_a, w, h, max_level, pa, true);
+    int lb = build_pyramid(img_b, w, h, max_level, pb, false);
+    int ml = std::min(la, lb);
+    iters = std::min(std::max(iters, 0), 100);
+    eps = std::min(std::max(eps, 0.), 10.);
+    double eps_sq = eps * eps;
+    for (int i = 0; i < n; ++i) status[i] = 1;
+    for (int level = ml; level >= 0; --level)
+        lk_level(pa[level], pb[level], level, ml, pts_a, pts_b, status, n, iters, eps_sq, use_initial);
+}
+
+inline bool in_border(P2f pt, int rows, int cols) {      // feature_utils.h:68-74
+    int x = cv_round(pt.x), y = cv_round(pt.y);
+    return 1 <= x && x < cols - 1 && 1 <= y && y < rows - 1;
+}
+
+void track_by_lk(const uint8_t* img1, const uint8_t* img2, int w, int h, const P2f* pts1, int n, bool flow_back,
+                 float dist_thresh, P2f* pts2, uint8_t* status) {   // feature_utils.cpp:35-69
+    lk(img1, img2, w, h, pts1, n, 3, 30, 0.01, false, pts2, status);
+    if (flow_back) {
+        std::vector<uint8_t> rs(n);
+        std::vector<P2f> rp(pts1, pts1 + n);
+        lk(img2, img1, w, h, pts2, n, 1, 30, 0.01, true, rp.data(), rs.data());
+        for (int i = 0; i < n; ++i) {
+            float dx = pts1[i].x - rp[i].x, dy = pts1[i].y - rp[i].y;
+            status[i] = (status[i] && rs[i] && std::sqrt(dx * dx + dy * dy) <= dist_thresh) ? 1 : 0;
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        if (status[i] && !in_border(pts2[i], h, w)) status[i] = 0;
+}
+
+// cornerMinEigenVal(img, eig, blockSize=3, ksize=3), BORDER_DEFAULT (corner.cpp)
+void min_eigen(const uint8_t* img, int w, int h, float* eig) {
+    const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
+    const float k1 = (float)(1.0 * scale_d), k2 = (float)(2.0 * scale_d);     // smoothing kernel [1 2 1]*scale as CV_32F
+    std::vector<float> xx((size_t)w * h), xy((size_t)w * h), yy((size_t)w * h);
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* r0 = img + (size_t)reflect101(y - 1, h) * w;
+        const uint8_t* r1 = img + (size_t)y * w;
+        const uint8_t* r2 = img + (size_t)reflect101(y + 1, h) * w;
+        for (int x = 0; x < w; ++x) {
+            int xl = reflect101(x - 1, w), xr = reflect101(x + 1, w);
+            // Dx: row filter [-1 0 1] (exact), column filter (S0+S2)*k1 + S1*k2
+            float d0 = (float)(r0[xr] - r0[xl]), d1 = (float)(r1[xr] - r1[xl]), d2 = (float)(r2[xr] - r2[xl]);
+            float dx = (d0 + d2) * k1 + d1 * k2;
+            // Dy: row filter ((k1*a + k2*b) + k1*c) per row, column filter S2 - S0
+            float s0 = (k1 * (float)r0[xl] + k2 * (float)r0[x]) + k1 * (float)r0[xr];
+            float s2 = (k1 * (float)r2[xl] + k2 * (float)r2[x]) + k1 * (float)r2[xr];
+            float dy = s2 - s0;
+            size_t i = (size_t)y * w + x;
+            xx[i] = dx * dx; xy[i] = dx * dy; yy[i] = dy * dy;
+        }
+    }
+    auto box = [&](const std::vector<float>& c, int x, int y) -> float {      // D2
+        double rs[3];
+        for (int k = 0; k < 3; ++k) {
+            const float* r = c.data() + (size_t)reflect101(y + k - 1, h) * w;
+            rs[k] = ((double)r[reflect101(x - 1, w)] + (double)r[x]) + (double)r[reflect101(x + 1, w)];
+        }
+        return (float)((rs[0] + rs[1]) + rs[2]);
+    };
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            float a = box(xx, x, y) * 0.5f, b = box(xy, x, y), c = box(yy, x, y) * 0.5f;
+            eig[(size_t)y * w + x] = (float)((a + c) - std::sqrt((a - c) * (a - c) + b * b));
+        }
+}
+
+void gftt(const uint8_t* img, const uint8_t* mask, int w, int h, int max_n, double quality, double min_dist,
+          std::vector<P2f>& out) {           // featureselect.cpp goodFeaturesToTrack
+    out.clear();
+    std::vector<float> eig((size_t)w * h);
+    min_eigen(img, w, h, eig.data());
+    double maxVal = 0; bool any = false;
+    for (size_t i = 0; i < eig.size(); ++i)
+        if (!mask || mask[i]) { if (!any || eig[i] > maxVal) { maxVal = eig[i]; any = true; } }
+    if (!any) maxVal = 0;
+    const float thr = (float)(maxVal * quality);
+    for (auto& v : eig) v = v > thr ? v : 0.f;           // THRESH_TOZERO
+    std::vector<int> cand;
+    for (int y = 1; y < h - 1; ++y)
+        for (int x = 1; x < w - 1; ++x) {
+            float v = eig[(size_t)y * w + x];
+            if (v == 0 || (mask && !mask[(size_t)y * w + x])) continue;
+            float m = v;
+            for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) m = std::max(m, eig[(size_t)(y + dy) * w + x + dx]);
+            if (v == m) cand.push_back(y * w + x);
+        }
+    if (cand.empty()) return;
+    std::sort(cand.begin(), cand.end(), [&](int a, int b) {      // greaterThanPtr: value desc, then address desc
+        return eig[a] > eig[b] ? true : eig[a] < eig[b] ? false : a > b; });
+    if (min_dist >= 1) {
+        const int cell = cv_round(min_dist);
+        const int gw = (w + cell - 1) / cell, gh = (h + cell - 1) / cell;
+        std::vector<std::vector<P2f>> grid((size_t)gw * gh);
+        const float md2 = (float)(min_dist * min_dist);
+        for (int ofs : cand) {
+            int y = ofs / w, x = ofs - y * w;
+            int xc = x / cell, yc = y / cell;
+            int x1 = std::max(0, xc - 1), y1 = std::max(0, yc - 1), x2 = std::min(gw - 1, xc + 1), y2 = std::min(gh - 1, yc + 1);
+            bool good = true;
+            for (int yy = y1; yy <= y2 && good; ++yy)
+                for (int xx = x1; xx <= x2 && good; ++xx)
+                    for (const P2f& m : grid[(size_t)yy * gw + xx]) {
+                        float dx = x - m.x, dy = y - m.y;
+                        if (dx * dx + dy * dy < md2) { good = false; break; }
+                    }
+            if (good) {
+                grid[(size_t)yc * gw + xc].push_back({ (float)x, (float)y });
+                out.push_back({ (float)x, (float)y });
+                if (max_n > 0 && (int)out.size() == max_n) break;
+            }
+        }
+    } else {
+        for (int ofs : cand) {
+            int y = ofs / w, x = ofs - y * w;
+            out.push_back({ (float)x, (float)y });
+            if (max_n > 0 && (int)out.size() == max_n) break;
+        }
+    }
+}
+
+// drawing.cpp Circle(img, center, radius, color, fill=true): midpoint circle, filled by hlines
+void circle_zero(uint8_t* mask, int w, int h, int cx, int cy, int radius) {
+    auto hline = [&](int y, int xa, int xb) {
+        if ((unsigned)y >= (unsigned)h) return;
+        xa = std::max(xa, 0); xb = std::min(xb, w - 1);
+        for (int x = xa; x <= xb; ++x) mask[(size_t)y * w + x] = 0;
+    };
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        hline(cy - dy, cx - dx, cx + dx); hline(cy + dy, cx - dx, cx + dx);
+        hline(cy - dx, cx - dy, cx + dy); hline(cy + dx, cx - dy, cx + dy);
+        dy++; err += plus; plus += 2;
+        int m = (err <= 0) - 1;
+        err -= minus & m; dx += m; minus -= m & 2;
+    }
+}
+
+void lift_projective(const dvo_cam& c, double px, double py, double& ox, double& oy) {   // PinholeCamera.cc:450-508
+    const double ik11 = 1.0 / c.fx, ik13 = -c.cx / c.fx, ik22 = 1.0 / c.fy, ik23 = -c.cy / c.fy;
+    double mx_d = ik11 * px + ik13, my_d = ik22 * py + ik23;
+    auto dist = [&](double ux, double uy, double& dxo, double& dyo) {     // :646-662
+        double mx2 = ux * ux, my2 = uy * uy, mxy = ux * uy, rho2 = mx2 + my2;
+        double rad = c.k1 * rho2 + c.k2 * rho2 * rho2;
+        dxo = ux * rad + 2.0 * c.p1 * mxy + c.p2 * (rho2 + 2.0 * mx2);
+        dyo = uy * rad + 2.0 * c.p2 * mxy + c.p1 * (rho2 + 2.0 * my2);
+    };
+    bool no_dist = (c.k1 == 0.0 && c.k2 == 0.0 && c.p1 == 0.0 && c.p2 == 0.0);   // m_noDistortion
+    double mx_u, my_u;
+    if (no_dist) { mx_u = mx_d; my_u = my_d; }
+    else {
+        double ddx, ddy;
+        dist(mx_d, my_d, ddx, ddy);
+        mx_u = mx_d - ddx; my_u = my_d - ddy;
+        for (int i = 1; i < 8; ++i) { dist(mx_u, my_u, ddx, ddy); mx_u = mx_d - ddx; my_u = my_d - ddy; }
+    }
+    ox = mx_u / 1.0; oy = my_u / 1.0;    // b.x()/b.z() with z = 1
+}
+
+template <class T> void reduce_vector(std::vector<T>& v, const std::vector<uint8_t>& st) {   // feature_utils.h:77-85
+    size_t j = 0;
+    for (size_t i = 0; i < v.size(); ++i) if (st[i]) v[j++] = v[i];
+    v.resize(j);
+}
+
+} // namespace
+
+struct dvo_tracker {
+    dvo_fe_config cfg;
+    Img prev0;
+    double prev_time = 0, cur_time = 0;
+    uint32_t global_id_count = 1;                 // InstFeat::global_id_count (instance_feature.h:137)
+    std::vector<uint32_t> ids, right_ids;
+    std::vector<int> track_cnt;
+    std::vector<P2f> curr_points, curr_un, last_points, right_points, right_un, vel, right_vel;
+    std::map<uint32_t, P2f> prev_id_pts, curr_id_pts, right_prev_id_pts, right_curr_id_pts;
+
+    void undistort(const dvo_cam& cam, const std::vector<P2f>& in, std::vector<P2f>& out) {   // instance_feature.cpp:94-103
+        out.clear();
+        for (auto& p : in) { double x, y; lift_projective(cam, p.x, p.y, x, y); out.push_back({ (float)x, (float)y }); }
+    }
+    static void pts_velocity(double dt, const std::vector<uint32_t>& id, const std::vector<P2f>& un,
+                             std::map<uint32_t, P2f>& cur_map, const std::map<uint32_t, P2f>& prev_map, std::vector<P2f>& v) {
+        v.clear(); cur_map.clear();                                                              // instance_feature.cpp:26-85
+        for (size_t i = 0; i < id.size(); ++i) cur_map.insert({ id[i], un[i] });
+        for (size_t i = 0; i < un.size(); ++i) {
+            auto it = prev_map.find(id[i]);
+            if (!prev_map.empty() && it != prev_map.end()) {
+                double vx = (un[i].x - it->second.x) / dt, vy = (un[i].y - it->second.y) / dt;
+                v.push_back({ (float)vx, (float)vy });
+            } else v.push_back({ 0.f, 0.f });
+        }
+    }
+    int pack(dvo_feat* out) {                                                                    // background_tracker.cpp:340-392
+        std::map<uint32_t, size_t> ridx;
+        for (size_t i = 0; i < right_ids.size(); ++i) ridx[right_ids[i]] = i;
+        for (size_t i = 0; i < ids.size(); ++i) {
+            dvo_feat& f = out[i];
+            std::memset(&f, 0, sizeof(f));
+            f.id = ids[i]; f.track_cnt = track_cnt[i];
+            double l[7] = { curr_un[i].x, curr_un[i].y, 1, curr_points[i].x, curr_points[i].y, vel[i].x, vel[i].y };
+            std::memcpy(f.left, l, sizeof(l));
+            auto it = ridx.find(ids[i]);
+            if (cfg.stereo && it != ridx.end()) {
+                size_t k = it->second; f.has_right = 1;
+                double r[7] = { right_un[k].x, right_un[k].y, 1, right_points[k].x, right_points[k].y, right_vel[k].x, right_vel[k].y };
+                std::memcpy(f.right, r, sizeof(r));
+            }
+        }
+        return (int)ids.size();
+    }
+    int track(const uint8_t* g0, const uint8_t* g1, const uint8_t* in_mask, bool naive, double time, dvo_feat* out) {
+        const int w = cfg.width, h = cfg.height;
+        cur_time = time;
+        std::vector<uint8_t> mask((size_t)w * h, 255);
+        if (in_mask) std::memcpy(mask.data(), in_mask, mask.size());
+        const float dthr = naive ? 1.0f : 0.5f;                     // Q12: feature_utils.cpp:56 vs :126
+        curr_points.clear();
+        if (!last_points.empty()) {
+            curr_points.resize(last_points.size());
+            std::vector<uint8_t> st(last_points.size());
+            track_by_lk(prev0.d.data(), g0, w, h, last_points.data(), (int)last_points.size(), cfg.flow_back, dthr, curr_points.data(), st.data());
+            if (naive && in_mask)                                  // instance_feature.cpp:211-216 (mask.at<uchar>(Point2f) rounds)
+                for (size_t i = 0; i < st.size(); ++i)
+                    if (st[i]) { int x = cv_round(curr_points[i].x), y = cv_round(curr_points[i].y); if (in_mask[(size_t)y * w + x] == 0) st[i] = 0; }
+            reduce_vector(last_points, st); reduce_vector(curr_points, st); reduce_vector(ids, st); reduce_vector(track_cnt, st);
+        }
+        for (auto& c : track_cnt) c++;
+        if (!naive) {                                               // SortPoints (D3: stable)
+            std::vector<size_t> ord(ids.size());
+            for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) { return track_cnt[a] > track_cnt[b]; });
+            std::vector<P2f> cp; std::vector<uint32_t> id2; std::vector<int> tc;
+            for (size_t k : ord) { cp.push_back(curr_points[k]); id2.push_back(ids[k]); tc.push_back(track_cnt[k]); }
+            curr_points.swap(cp); ids.swap(id2); track_cnt.swap(tc);
+        }
+        int n_max = cfg.max_cnt - (int)curr_points.size();
+        bool detect = naive ? (n_max >= 10) : (n_max > 0);          // Q23
+        if (detect) {
+            for (auto& p : curr_points) circle_zero(mask.data(), w, h, cv_round(p.x), cv_round(p.y), cfg.min_dist);
+            std::vector<P2f> npts;
+            gftt(g0, mask.data(), w, h, n_max, 0.01, cfg.min_dist, npts);
+            for (auto& p : npts) { curr_points.push_back(p); ids.push_back(global_id_count++); track_cnt.push_back(1); }
+        }
+        undistort(cfg.cam0, curr_points, curr_un);
+        pts_velocity(cur_time - prev_time, ids, curr_un, curr_id_pts, prev_id_pts, vel);
+        if (cfg.stereo && g1) {
+            right_ids.clear(); right_points.clear(); right_un.clear(); right_vel.clear(); right_curr_id_pts.clear();
+            if (!curr_points.empty()) {
+                right_points.resize(curr_points.size());
+                std::vector<uint8_t> st(curr_points.size());
+                track_by_lk(g0, g1, w, h, curr_points.data(), (int)curr_points.size(), cfg.flow_back, dthr, right_points.data(), st.data());
+                right_ids = ids;
+                reduce_vector(right_points, st); reduce_vector(right_ids, st);
+                undistort(cfg.cam1, right_points, right_un);
+                pts_velocity(cur_time - prev_time, right_ids, right_un, right_curr_id_pts, right_prev_id_pts, right_vel);
+            }
+            right_prev_id_pts = right_curr_id_pts;
+        }
+        prev0.w = w; prev0.h = h; prev0.d.assign(g0, g0 + (size_t)w * h);
+        prev_time = cur_time;
+        last_points = curr_points;             // PostProcess (instance_feature.h:88-101)
+        prev_id_pts = curr_id_pts;
+        right_prev_id_pts = right_curr_id_pts;
+        return pack(out);
+    }
+};
+
+extern "C" {
+
+void dvo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst) { pyr_down(src, w, h, dst); }
+void dvo_scharr(const uint8_t* src, int w, int h, int16_t* out) { scharr(src, w, h, out); }
+void dvo_lk(const uint8_t* a, const uint8_t* b, int w, int h, const float* pa, int n, int max_level, int iters, double eps,
+            int use_initial, float* pb, uint8_t* status) {
+    lk(a, b, w, h, (const P2f*)pa, n, max_level, iters, eps, use_initial != 0, (P2f*)pb, status);
+}
+void dvo_track_by_lk(const uint8_t* i1, const uint8_t* i2, int w, int h, const float* p1, int n, int flow_back, float dist_thresh,
+                     float* p2, uint8_t* status) {
+    track_by_lk(i1, i2, w, h, (const P2f*)p1, n, flow_back != 0, dist_thresh, (P2f*)p2, status);
+}
+void dvo_min_eigen(const uint8_t* img, int w, int h, float* eig) { min_eigen(img, w, h, eig); }
+void dvo_gftt(const uint8_t* img, const uint8_t* mask, int w, int h, int max_n, double quality, double min_dist, float* out_xy, int* n_out) {
+    std::vector<P2f> out; gftt(img, mask, w, h, max_n, quality, min_dist, out);
+    for (size_t i = 0; i < out.size(); ++i) { out_xy[2 * i] = out[i].x; out_xy[2 * i + 1] = out[i].y; }
+    *n_out = (int)out.size();
+}
+void dvo_circle_mask(uint8_t* mask, int w, int h, const float* pts, int n, int radius) {
+    for (int i = 0; i < n; ++i) circle_zero(mask, w, h, cv_round(pts[2 * i]), cv_round(pts[2 * i + 1]), radius);
+}
+void dvo_erode(const uint8_t* src, int w, int h, int k, uint8_t* dst) {
+    const int a = k / 2;                                            // anchor (-1,-1) -> centre = k/2
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        int m = 255;
+        for (int dy = -a; dy < k - a; ++dy) for (int dx = -a; dx < k - a; ++dx) {
+            int yy = y + dy, xx = x + dx;
+            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;  // border = +inf for erode
+            m = std::min(m, (int)src[(size_t)yy * w + xx]);
+        }
+        dst[(size_t)y * w + x] = (uint8_t)m;
+    }
+}
+void dvo_lift_projective(const dvo_cam* cam, const float* pts, int n, float* out) {
+    for (int i = 0; i < n; ++i) { double x, y; lift_projective(*cam, pts[2 * i], pts[2 * i + 1], x, y); out[2 * i] = (float)x; out[2 * i + 1] = (float)y; }
+}
+dvo_tracker* dvo_tracker_create(const dvo_fe_config* cfg) { auto* t = new dvo_tracker(); t->cfg = *cfg; return t; }
+void dvo_tracker_destroy(dvo_tracker* t) { delete t; }
+int dvo_tracker_track_image(dvo_tracker* t, const uint8_t* g0, const uint8_t* g1, double time, dvo_feat* out) {
+    return t->track(g0, g1, nullptr, false, time, out);
+}
+int dvo_tracker_track_image_naive(dvo_tracker* t, const uint8_t* g0, const uint8_t* g1, const uint8_t* mask, double time, dvo_feat* out) {
+    return t->track(g0, g1, mask, true, time, out);
+}
+
+} // extern "C"

@@ -1,0 +1,83 @@
+"""ctypes binding of the C ABI declared in include/dvins.h (libdvins_hip.so).
+
+The product path has NO CPU fallback: if the HIP library is missing or no GPU is present,
+loading / dv_create fails loudly (DvinsError).  Nothing here imports the oracle.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdvins_hip.so")
+
+DV_MEM_HOST, DV_MEM_DEVICE = 0, 1
+DV_MODE_RAW, DV_MODE_NAIVE = 0, 1
+DV_MAX_FEATS = 1024
+
+
+class DvinsError(RuntimeError):
+    pass
+
+
+class dv_cam(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")]
+
+
+class dv_config(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("max_cnt", C.c_int), ("min_dist", C.c_int),
+                ("flow_back", C.c_int), ("stereo", C.c_int), ("cam0", dv_cam), ("cam1", dv_cam),
+                ("device", C.c_int), ("reserved", C.c_int * 7)]
+
+
+class dv_feat(C.Structure):
+    _fields_ = [("id", C.c_uint32), ("track_cnt", C.c_int32), ("has_right", C.c_int32), ("pad_", C.c_int32),
+                ("left", C.c_double * 7), ("right", C.c_double * 7)]
+
+
+_u8p = C.c_void_p      # image / status buffers: host ndarray pointer or device pointer (int)
+_f32p = C.c_void_p
+_ctx = C.c_void_p
+
+# name -> (restype, argtypes).  tests/test_abi.py checks this table against include/dvins.h.
+SIGNATURES = {
+    "dv_create": (_ctx, [C.POINTER(dv_config)]),
+    "dv_destroy": (None, [_ctx]),
+    "dv_last_error": (C.c_char_p, [_ctx]),
+    "dv_reset": (C.c_int, [_ctx]),
+    "dv_sync": (C.c_int, [_ctx]),
+    "dv_track_stereo": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_double, _u8p, C.c_int, C.c_int,
+                                  C.POINTER(dv_feat), C.POINTER(C.c_int)]),
+    "dv_track_stereo_enqueue": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_double, _u8p, C.c_int, C.c_int]),
+    "dv_track_stereo_collect": (C.c_int, [_ctx, C.POINTER(dv_feat), C.POINTER(C.c_int)]),
+    "dv_lk": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                        _f32p, _u8p, C.c_int]),
+    "dv_track_by_lk": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_float,
+                                 _f32p, _u8p, C.c_int]),
+    "dv_gftt": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f32p,
+                          C.POINTER(C.c_int), C.c_int]),
+    "dv_min_eigen": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
+    "dv_pyr_down": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
+    "dv_circle_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]),
+    "dv_erode": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
+    "dv_lift_projective": (C.c_int, [_ctx, C.POINTER(dv_cam), _f32p, C.c_int, _f32p, C.c_int]),
+    "dv_timing_enable": (C.c_int, [_ctx, C.c_int]),
+    "dv_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+}
+
+_lib = None
+
+
+def load():
+    """Loads libdvins_hip.so; raises DvinsError if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DvinsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         "(the HIP path has no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = ABI mismatch, let it propagate
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

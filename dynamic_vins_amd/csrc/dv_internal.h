@@ -1,0 +1,79 @@
+// dv_internal.h — shared declarations of the gfx950 implementation (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/dvins.h"
+
+#define DV_LK_WIN 21          // cv::Size(21,21) at every reference call site
+#define DV_MAX_LEVELS 4       // maxLevel = 3 -> 4 levels
+#define DV_MAX_RADIUS 128     // largest disc radius (min_dist) supported by the mask stamper
+
+struct DvLevel { uint8_t* p; int w, h, pitch; };
+struct DvPyr   { DvLevel L[DV_MAX_LEVELS]; int levels; };   // levels = number of valid entries
+
+// candidate record emitted by the Shi-Tomasi tile kernel
+struct DvCand { unsigned long long key; float min_nb; int pad; };
+
+// device-side tracker state (struct of arrays, capacity DV_MAX_FEATS)
+struct DvTrackState {
+    float2*   last_pts;      // positions in the previous frame
+    float2*   curr_pts;      // positions in the current frame (compacted, sorted, + new corners)
+    float2*   lk_pts;        // raw temporal-LK output (indexed like last_pts)
+    uint8_t*  lk_status;
+    uint32_t* ids;
+    int32_t*  track_cnt;
+    float2*   prev_un;       // undistorted position in the previous frame (prev_id_pts value)
+    float2*   prev_run;      // right_prev_id_pts value
+    uint8_t*  prev_rvalid;   // id present in right_prev_id_pts
+    uint8_t*  tracked;       // 1 = id present in prev_id_pts
+    float2*   right_pts;
+    uint8_t*  right_status;
+    int*      n_feat;        // device scalar: current number of features
+    int*      n_tracked;     // device scalar: features that survived temporal LK
+    uint32_t* next_id;       // InstFeat::global_id_count
+};
+
+struct GfttTileArgs {
+    const uint8_t* img; int w, h, pitch;
+    const uint8_t* in_mask; int mask_pitch;      // optional user mask (0 = excluded)
+    const float2* disc_pts; const int* n_disc;   // tracked points whose discs are excluded (may be null)
+    int radius; const uint8_t* hw;               // disc half widths hw[0..radius]
+    const int* n_feat; int max_cnt;              // skip everything when max_cnt - *n_feat < min_new
+    int min_new;
+    float* eig_out; int eig_pitch;               // optional: write the eigenvalue image (elements)
+    DvCand* cand; int cand_cap; int* n_cand; unsigned* max_ord;
+};
+
+struct GfttSelectArgs {
+    const DvCand* cand; const int* n_cand; int cand_cap; const unsigned* max_ord;
+    int w, h; double quality; double min_dist;
+    int max_n_host; const int* n_feat; int max_cnt; int min_new;   // tracker: max_n = max_cnt - *n_feat (needs >= min_new)
+    float2* out_xy; int* n_out;                                    // operator-level output (dv_gftt), may be null
+    DvTrackState tr; int has_tr;                                   // tracker epilogue: append corners, assign ids
+    int* err_flag;
+};
+
+struct dv_ctx;
+void dv_set_error(dv_ctx* ctx, const std::string& msg);
+
+// ---- kernel launchers (defined in the .hip files) ----
+void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int sh, int spitch,
+                         uint8_t* dst0, uint8_t* dst1, int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch,
+                         hipStream_t s);
+void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters,
+                          double eps_sq, int use_initial, float2* pts_b, uint8_t* status, hipStream_t s);
+void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max,
+                        int flow_back, float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s);
+void dv_launch_gftt_tile(const GfttTileArgs& a, hipStream_t s);
+int  dv_launch_gftt_select(const GfttSelectArgs& a, hipStream_t s);
+void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_pitch, int sort_by_cnt, int* n_cand,
+                       unsigned* max_ord, hipStream_t s);
+void dv_launch_finalize(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max,
+                        dv_feat* out, int* n_out, hipStream_t s);
+void dv_launch_circle_mask(uint8_t* mask, int w, int h, int pitch, const float2* pts, int n, int radius, const uint8_t* hw,
+                           hipStream_t s);
+void dv_launch_erode(const uint8_t* src, int w, int h, int spitch, int k, uint8_t* tmp, int tpitch, uint8_t* dst, int dpitch,
+                     hipStream_t s);
+void dv_launch_lift(const dv_cam& cam, const float2* in, int n, float2* out, hipStream_t s);

@@ -1,0 +1,552 @@
+// dvins_api.hip — C ABI (include/dvins.h) of libdvins_hip.so: context, HBM layout and per-frame
+// orchestration of the front end.  Everything a frame needs lives in HBM inside the ctx:
+//   * three image pyramids (left current, left previous, right), each level pitched to 16 B,
+//     level 0 is a pitched copy of the input written by the first pyrDown launch;
+//   * the tracker state as a struct of arrays (DvTrackState) with its counters in device memory,
+//     so the whole of FeatureTracker::TrackImage is enqueued without a host round trip;
+//   * Shi-Tomasi candidate records + the pinned host staging buffer for the frame's output.
+// One frame = pyrDown x3 (stereo pair per launch) -> LK temporal -> compact/sort -> Shi-Tomasi tile
+// -> select/append -> LK stereo -> finalize -> one D2H copy of <= max_cnt 128-byte rows.
+#include "dv_internal.h"
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+static std::string g_last_error;
+static std::mutex g_err_mutex;
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct PyrSet {
+    DvPyr pyr{}; DevBuf buf; int w = 0, h = 0, ml = -1;
+    hipError_t alloc(int w_, int h_, int max_level) {
+        if (w == w_ && h == h_ && ml == max_level && pyr.levels > 0) return hipSuccess;
+        w = w_; h = h_; ml = max_level;
+        int lw[DV_MAX_LEVELS], lh[DV_MAX_LEVELS], n = 0;
+        int cw = w, ch = h;
+        for (int l = 0; l <= max_level && l < DV_MAX_LEVELS; ++l) {
+            lw[n] = cw; lh[n] = ch; ++n;
+            int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+            if (nw <= DV_LK_WIN || nh <= DV_LK_WIN) break;      // buildOpticalFlowPyramid stop rule
+            cw = nw; ch = nh;
+        }
+        size_t total = 0, off[DV_MAX_LEVELS];
+        for (int l = 0; l < n; ++l) { off[l] = total; total += (size_t)align_up(lw[l], 16) * lh[l]; total = (total + 255) / 256 * 256; }
+        total += 512;                                             // slack for aligned over-reads
+        hipError_t e = buf.ensure(total);
+        if (e != hipSuccess) return e;
+        for (int l = 0; l < n; ++l) pyr.L[l] = DvLevel{ (uint8_t*)buf.p + off[l], lw[l], lh[l], align_up(lw[l], 16) };
+        for (int l = n; l < DV_MAX_LEVELS; ++l) pyr.L[l] = DvLevel{ nullptr, 0, 0, 0 };
+        pyr.levels = n;
+        return hipSuccess;
+    }
+};
+
+struct StageTimer {
+    std::string name; hipEvent_t a = nullptr, b = nullptr; bool armed = false; double total_ms = 0; long long count = 0;
+};
+
+struct dv_ctx {
+    dv_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    PyrSet left[2], right; int cur = 0; bool have_prev = false; double prev_time = 0.0;
+    DevBuf state_block; DvTrackState tr{};
+    DevBuf cand_buf; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
+    DevBuf hw_buf; int hw_radius = -1;
+    DevBuf mask_buf;
+    DevBuf out_buf; dv_feat* out_dev = nullptr; int* nout_dev = nullptr;
+    dv_feat* out_pinned = nullptr; int* nout_pinned = nullptr; int* err_pinned = nullptr;
+    hipEvent_t done = nullptr; bool pending = false;
+    // operator-level scratch
+    PyrSet opA, opB; DevBuf s0, s1, s2, s3, s4;
+    bool timing = false; std::vector<StageTimer> timers;
+};
+
+void dv_set_error(dv_ctx* ctx, const std::string& msg) {
+    if (ctx) ctx->err = msg;
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    g_last_error = msg;
+}
+
+#define DV_CHECK(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            dv_set_error(ctx, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+            return -1;                                                                   \
+        }                                                                                \
+    } while (0)
+#define DV_FAIL(msg) do { dv_set_error(ctx, msg); return -1; } while (0)
+
+// disc half-widths of cv::circle's midpoint rasteriser (drawing.cpp Circle(), fill = true)
+static void circle_half_widths(int radius, std::vector<uint8_t>& hw) {
+    hw.assign(radius + 1, 0);
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        hw[dy] = (uint8_t)std::max<int>(hw[dy], dx);
+        hw[dx] = (uint8_t)std::max<int>(hw[dx], dy);
+        dy++; err += plus; plus += 2;
+        int m = (err <= 0) - 1;
+        err -= minus & m; dx += m; minus -= m & 2;
+    }
+}
+
+static int ensure_hw(dv_ctx* ctx, int radius) {
+    if (radius < 0 || radius > DV_MAX_RADIUS) DV_FAIL("disc radius (min_dist) out of range [0,128]");
+    if (ctx->hw_radius == radius) return 0;
+    std::vector<uint8_t> hw; circle_half_widths(radius, hw);
+    DV_CHECK(ctx->hw_buf.ensure(DV_MAX_RADIUS + 1));
+    DV_CHECK(hipMemcpyAsync(ctx->hw_buf.p, hw.data(), hw.size(), hipMemcpyHostToDevice, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->hw_radius = radius;
+    return 0;
+}
+
+static int ensure_cand(dv_ctx* ctx, int w, int h) {
+    int cap = std::max(4096, (w * h) / 4);
+    if (cap <= ctx->cand_cap) return 0;
+    DV_CHECK(ctx->cand_buf.ensure((size_t)cap * sizeof(DvCand)));
+    ctx->cand_cap = cap;
+    return 0;
+}
+
+static StageTimer* timer_for(dv_ctx* ctx, const char* name) {
+    for (auto& t : ctx->timers) if (t.name == name) return &t;
+    ctx->timers.emplace_back();
+    StageTimer& t = ctx->timers.back();
+    t.name = name;
+    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
+    return &t;
+}
+struct StageScope {
+    dv_ctx* c; StageTimer* t = nullptr;
+    StageScope(dv_ctx* ctx, const char* name) : c(ctx) { if (c->timing) { t = timer_for(c, name); (void)hipEventRecord(t->a, c->stream); } }
+    ~StageScope() { if (t) { (void)hipEventRecord(t->b, c->stream); t->armed = true; } }
+};
+static void harvest_timers(dv_ctx* ctx) {
+    for (auto& t : ctx->timers) if (t.armed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { t.total_ms += ms; t.count++; }
+        t.armed = false;
+    }
+}
+
+// Builds the pyramids of one image (img1 == nullptr) or of a stereo pair with shared launches.
+static int build_pyramids(dv_ctx* ctx, PyrSet& P0, PyrSet* P1, const uint8_t* img0, const uint8_t* img1, int w, int h, int stride,
+                          int mem, int max_level) {
+    DV_CHECK(P0.alloc(w, h, max_level));
+    if (P1) DV_CHECK(P1->alloc(w, h, max_level));
+    const DvPyr& a = P0.pyr;
+    const DvPyr* b = P1 ? &P1->pyr : nullptr;
+    hipStream_t s = ctx->stream;
+    const bool dev = (mem == DV_MEM_DEVICE);
+    if (!dev || a.levels == 1) {
+        hipMemcpyKind k = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+        DV_CHECK(hipMemcpy2DAsync(a.L[0].p, a.L[0].pitch, img0, stride, w, h, k, s));
+        if (b) DV_CHECK(hipMemcpy2DAsync(b->L[0].p, b->L[0].pitch, img1, stride, w, h, k, s));
+    }
+    for (int l = 1; l < a.levels; ++l) {
+        const bool fuse_copy = dev && l == 1;
+        const uint8_t* s0 = fuse_copy ? img0 : a.L[l - 1].p;
+        const uint8_t* s1 = b ? (fuse_copy ? img1 : b->L[l - 1].p) : nullptr;
+        const int sp = fuse_copy ? stride : a.L[l - 1].pitch;
+        dv_launch_pyr_down2(s0, s1, a.L[l - 1].w, a.L[l - 1].h, sp, a.L[l].p, b ? b->L[l].p : nullptr, a.L[l].pitch,
+                            fuse_copy ? a.L[0].p : nullptr, (fuse_copy && b) ? b->L[0].p : nullptr, a.L[0].pitch, s);
+    }
+    DV_CHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" {
+
+const char* dv_last_error(dv_ctx* ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_err_mutex);
+    return g_last_error.c_str();
+}
+
+dv_ctx* dv_create(const dv_config* cfg) {
+    if (!cfg) { dv_set_error(nullptr, "dv_create: null config"); return nullptr; }
+    if (cfg->width <= 0 || cfg->height <= 0) { dv_set_error(nullptr, "dv_create: bad image size"); return nullptr; }
+    if (cfg->max_cnt <= 0 || cfg->max_cnt > DV_MAX_FEATS) { dv_set_error(nullptr, "dv_create: max_cnt must be in [1,1024]"); return nullptr; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { dv_set_error(nullptr, "dv_create: no HIP device (the HIP path has no CPU fallback)"); return nullptr; }
+    if (cfg->device < 0 || cfg->device >= ndev) { dv_set_error(nullptr, "dv_create: bad device ordinal"); return nullptr; }
+    dv_ctx* ctx = new dv_ctx();
+    ctx->cfg = *cfg;
+    auto fail = [&](const char* what, hipError_t e) -> dv_ctx* {
+        dv_set_error(nullptr, std::string("dv_create: ") + what + ": " + hipGetErrorString(e));
+        delete ctx; return nullptr;
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(cfg->device)) != hipSuccess) return fail("hipSetDevice", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    // tracker state: one block, struct of arrays
+    const size_t N = DV_MAX_FEATS;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    size_t o_last = take(N * 8), o_cur = take(N * 8), o_lk = take(N * 8), o_lks = take(N), o_ids = take(N * 4), o_cnt = take(N * 4),
+           o_pun = take(N * 8), o_prun = take(N * 8), o_prv = take(N), o_trk = take(N), o_rp = take(N * 8), o_rs = take(N),
+           o_scal = take(64);
+    if ((e = ctx->state_block.ensure(off)) != hipSuccess) return fail("hipMalloc(state)", e);
+    uint8_t* base = (uint8_t*)ctx->state_block.p;
+    ctx->tr.last_pts = (float2*)(base + o_last); ctx->tr.curr_pts = (float2*)(base + o_cur); ctx->tr.lk_pts = (float2*)(base + o_lk);
+    ctx->tr.lk_status = base + o_lks; ctx->tr.ids = (uint32_t*)(base + o_ids); ctx->tr.track_cnt = (int32_t*)(base + o_cnt);
+    ctx->tr.prev_un = (float2*)(base + o_pun); ctx->tr.prev_run = (float2*)(base + o_prun); ctx->tr.prev_rvalid = base + o_prv;
+    ctx->tr.tracked = base + o_trk; ctx->tr.right_pts = (float2*)(base + o_rp); ctx->tr.right_status = base + o_rs;
+    ctx->tr.n_feat = (int*)(base + o_scal); ctx->tr.n_tracked = ctx->tr.n_feat + 1; ctx->tr.next_id = (uint32_t*)(ctx->tr.n_feat + 2);
+    ctx->n_cand = ctx->tr.n_feat + 3; ctx->max_ord = (unsigned*)(ctx->tr.n_feat + 4); ctx->err_flag = ctx->tr.n_feat + 5;
+    if ((e = ctx->out_buf.ensure(N * sizeof(dv_feat) + 256)) != hipSuccess) return fail("hipMalloc(out)", e);
+    ctx->out_dev = (dv_feat*)ctx->out_buf.p; ctx->nout_dev = (int*)((uint8_t*)ctx->out_buf.p + N * sizeof(dv_feat));
+    void* pinned = nullptr;
+    if ((e = hipHostMalloc(&pinned, N * sizeof(dv_feat) + 256, hipHostMallocDefault)) != hipSuccess) return fail("hipHostMalloc", e);
+    ctx->out_pinned = (dv_feat*)pinned; ctx->nout_pinned = (int*)((uint8_t*)pinned + N * sizeof(dv_feat)); ctx->err_pinned = ctx->nout_pinned + 1;
+    if (dv_reset(ctx) != 0) { std::string m = ctx->err; delete ctx; dv_set_error(nullptr, m); return nullptr; }
+    return ctx;
+}
+
+void dv_destroy(dv_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto& t : ctx->timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+    for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,
+                       &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->opA.buf, &ctx->opB.buf }) b->release();
+    if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
+    if (ctx->done) (void)hipEventDestroy(ctx->done);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int dv_reset(dv_ctx* ctx) {
+    if (!ctx) return -1;
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    DV_CHECK(hipMemsetAsync(ctx->state_block.p, 0, ctx->state_block.bytes, ctx->stream));
+    const uint32_t one = 1;    // InstFeat::global_id_count{1} (front_end/instance_feature.h:137)
+    DV_CHECK(hipMemcpyAsync(ctx->tr.next_id, &one, 4, hipMemcpyHostToDevice, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->have_prev = false; ctx->prev_time = 0.0; ctx->pending = false;
+    return 0;
+}
+
+int dv_sync(dv_ctx* ctx) {
+    if (!ctx) return -1;
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dv_timing_enable(dv_ctx* ctx, int on) { if (!ctx) return -1; ctx->timing = on != 0; return 0; }
+int dv_timing_get(dv_ctx* ctx, const char* name, double* total_ms, long long* count) {
+    if (!ctx || !name) return -1;
+    for (auto& t : ctx->timers) if (t.name == name) { if (total_ms) *total_ms = t.total_ms; if (count) *count = t.count; return 0; }
+    if (total_ms) *total_ms = 0; if (count) *count = 0;
+    return 0;
+}
+
+int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gray1, int w, int h, int stride, double t,
+                            const uint8_t* mask_or_null, int mode, int mem) {
+    if (!ctx) return -1;
+    if (!gray0) DV_FAIL("dv_track_stereo: gray0 is null");
+    if (w != ctx->cfg.width || h != ctx->cfg.height) DV_FAIL("dv_track_stereo: image size differs from config (reference: std::terminate, main.cpp:95-99)");
+    if (ctx->pending) DV_FAIL("dv_track_stereo_enqueue: previous frame not collected");
+    if (mode != DV_MODE_RAW && mode != DV_MODE_NAIVE) DV_FAIL("dv_track_stereo: unknown mode");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    const dv_config& c = ctx->cfg;
+    const bool stereo = c.stereo && gray1;
+    hipStream_t s = ctx->stream;
+    if (ensure_hw(ctx, c.min_dist)) return -1;
+    if (ensure_cand(ctx, w, h)) return -1;
+    StageScope frame(ctx, "frame");
+    ctx->cur ^= 1;
+    PyrSet& L = ctx->left[ctx->cur];
+    PyrSet& Lp = ctx->left[ctx->cur ^ 1];
+    {
+        StageScope sc(ctx, "pyr");
+        if (build_pyramids(ctx, L, stereo ? &ctx->right : nullptr, gray0, stereo ? gray1 : nullptr, w, h, stride, mem, 3)) return -1;
+    }
+    const uint8_t* mask_dev = nullptr; int mask_pitch = 0;
+    if (mask_or_null) {
+        if (mem == DV_MEM_DEVICE) { mask_dev = mask_or_null; mask_pitch = stride; }
+        else {
+            mask_pitch = align_up(w, 16);
+            DV_CHECK(ctx->mask_buf.ensure((size_t)mask_pitch * h));
+            DV_CHECK(hipMemcpy2DAsync(ctx->mask_buf.p, mask_pitch, mask_or_null, stride, w, h, hipMemcpyHostToDevice, s));
+            mask_dev = (const uint8_t*)ctx->mask_buf.p;
+        }
+    }
+    const bool naive = (mode == DV_MODE_NAIVE);
+    const float dist_thresh = naive ? 1.0f : 0.5f;       // feature_utils.cpp:126 vs :56 (Q12)
+    if (ctx->have_prev) {
+        StageScope sc(ctx, "lk_temporal");
+        dv_launch_lk_track(Lp.pyr, L.pyr, ctx->tr.last_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_thresh, ctx->tr.lk_pts,
+                           ctx->tr.lk_status, s);
+    }
+    {
+        StageScope sc(ctx, "compact");
+        dv_launch_compact(ctx->tr, naive ? mask_dev : nullptr, mask_pitch, naive ? 0 : 1, ctx->n_cand, ctx->max_ord, s);
+    }
+    const int min_new = naive ? 10 : 1;                   // Q23: instance_feature.cpp:353-356 vs background_tracker.cpp:82-90
+    {
+        StageScope sc(ctx, "gftt_eig");
+        GfttTileArgs a{};
+        a.img = L.pyr.L[0].p; a.w = w; a.h = h; a.pitch = L.pyr.L[0].pitch;
+        a.in_mask = mask_dev; a.mask_pitch = mask_pitch;
+        a.disc_pts = ctx->tr.curr_pts; a.n_disc = ctx->tr.n_tracked; a.radius = c.min_dist; a.hw = (const uint8_t*)ctx->hw_buf.p;
+        a.n_feat = ctx->tr.n_feat; a.max_cnt = c.max_cnt; a.min_new = min_new;
+        a.eig_out = nullptr; a.eig_pitch = 0;
+        a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord;
+        dv_launch_gftt_tile(a, s);
+    }
+    {
+        StageScope sc(ctx, "gftt_select");
+        GfttSelectArgs a{};
+        a.cand = (const DvCand*)ctx->cand_buf.p; a.n_cand = ctx->n_cand; a.cand_cap = ctx->cand_cap; a.max_ord = ctx->max_ord;
+        a.w = w; a.h = h; a.quality = 0.01; a.min_dist = (double)c.min_dist;
+        a.max_n_host = 0; a.n_feat = ctx->tr.n_feat; a.max_cnt = c.max_cnt; a.min_new = min_new;
+        a.out_xy = nullptr; a.n_out = nullptr; a.tr = ctx->tr; a.has_tr = 1; a.err_flag = ctx->err_flag;
+        if (dv_launch_gftt_select(a, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
+    }
+    if (stereo) {
+        StageScope sc(ctx, "lk_stereo");
+        dv_launch_lk_track(L.pyr, ctx->right.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_thresh,
+                           ctx->tr.right_pts, ctx->tr.right_status, s);
+    }
+    {
+        StageScope sc(ctx, "finalize");
+        dv_launch_finalize(ctx->tr, c.cam0, c.cam1, stereo ? 1 : 0, t - ctx->prev_time, c.max_cnt, ctx->out_dev, ctx->nout_dev, s);
+        DV_CHECK(hipMemcpyAsync(ctx->out_pinned, ctx->out_dev, (size_t)c.max_cnt * sizeof(dv_feat), hipMemcpyDeviceToHost, s));
+        DV_CHECK(hipMemcpyAsync(ctx->nout_pinned, ctx->nout_dev, 4, hipMemcpyDeviceToHost, s));
+        DV_CHECK(hipMemcpyAsync(ctx->err_pinned, ctx->err_flag, 4, hipMemcpyDeviceToHost, s));
+    }
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipEventRecord(ctx->done, s));
+    ctx->prev_time = t; ctx->have_prev = true; ctx->pending = true;
+    return 0;
+}
+
+int dv_track_stereo_collect(dv_ctx* ctx, dv_feat* out, int* n_out) {
+    if (!ctx) return -1;
+    if (!ctx->pending) DV_FAIL("dv_track_stereo_collect: nothing enqueued");
+    DV_CHECK(hipEventSynchronize(ctx->done));
+    ctx->pending = false;
+    if (ctx->timing) harvest_timers(ctx);
+    if (*ctx->err_pinned) {
+        int f = *ctx->err_pinned;
+        DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, ctx->stream));
+        DV_FAIL(std::string("front end device error flags=") + std::to_string(f) +
+                " (1: candidate buffer overflow, 2: min-distance grid too large, 4: value bin overflow)");
+    }
+    const int n = *ctx->nout_pinned;
+    if (n_out) *n_out = n;
+    if (out && n > 0) std::memcpy(out, ctx->out_pinned, (size_t)n * sizeof(dv_feat));
+    return 0;
+}
+
+int dv_track_stereo(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gray1, int w, int h, int stride, double t,
+                    const uint8_t* mask_or_null, int mode, int mem, dv_feat* out, int* n_out) {
+    if (dv_track_stereo_enqueue(ctx, gray0, gray1, w, h, stride, t, mask_or_null, mode, mem)) return -1;
+    return dv_track_stereo_collect(ctx, out, n_out);
+}
+
+// ------------------------------- operator-level entries -------------------------------
+
+// copies `bytes` from user memory (host or device) into a ctx scratch buffer on the device
+static int stage_in(dv_ctx* ctx, DevBuf& b, const void* src, size_t bytes, int mem) {
+    DV_CHECK(b.ensure(bytes ? bytes : 1));
+    if (bytes) DV_CHECK(hipMemcpyAsync(b.p, src, bytes, mem == DV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    return 0;
+}
+static int stage_out(dv_ctx* ctx, void* dst, const void* src, size_t bytes, int mem) {
+    if (bytes) DV_CHECK(hipMemcpyAsync(dst, src, bytes, mem == DV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    return 0;
+}
+
+int dv_lk(dv_ctx* ctx, const uint8_t* img_a, const uint8_t* img_b, int w, int h, int stride, const float* pts_a, int n, int max_level,
+          int iters, double eps, int use_initial, float* pts_b, uint8_t* status, int mem) {
+    if (!ctx) return -1;
+    if (!img_a || !img_b || !pts_a || n <= 0) DV_FAIL("dv_lk: empty input (reference throws std::runtime_error, feature_utils.cpp:39-41)");
+    if (max_level < 0 || max_level > 3) DV_FAIL("dv_lk: max_level must be in [0,3]");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (build_pyramids(ctx, ctx->opA, nullptr, img_a, nullptr, w, h, stride, mem, max_level)) return -1;
+    if (build_pyramids(ctx, ctx->opB, nullptr, img_b, nullptr, w, h, stride, mem, max_level)) return -1;
+    const int ml = std::min(ctx->opA.pyr.levels, ctx->opB.pyr.levels) - 1;
+    if (stage_in(ctx, ctx->s0, pts_a, (size_t)n * 8, mem)) return -1;
+    if (use_initial) { if (stage_in(ctx, ctx->s1, pts_b, (size_t)n * 8, mem)) return -1; }
+    else DV_CHECK(ctx->s1.ensure((size_t)n * 8));
+    DV_CHECK(ctx->s2.ensure(n));
+    iters = std::min(std::max(iters, 0), 100);
+    eps = std::min(std::max(eps, 0.), 10.);
+    dv_launch_lk_generic(ctx->opA.pyr, ctx->opB.pyr, (const float2*)ctx->s0.p, n, ml, iters, eps * eps, use_initial, (float2*)ctx->s1.p,
+                         (uint8_t*)ctx->s2.p, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    if (stage_out(ctx, pts_b, ctx->s1.p, (size_t)n * 8, mem)) return -1;
+    if (stage_out(ctx, status, ctx->s2.p, n, mem)) return -1;
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dv_track_by_lk(dv_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int w, int h, int stride, const float* pts1, int n,
+                   int flow_back, float dist_thresh, float* pts2, uint8_t* status, int mem) {
+    if (!ctx) return -1;
+    if (!img1 || !img2 || !pts1 || n <= 0) DV_FAIL("dv_track_by_lk: FeatureTrackByLK() input wrong, received at least one of parameter are empty");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (build_pyramids(ctx, ctx->opA, &ctx->opB, img1, img2, w, h, stride, mem, 3)) return -1;
+    if (stage_in(ctx, ctx->s0, pts1, (size_t)n * 8, mem)) return -1;
+    DV_CHECK(ctx->s1.ensure((size_t)n * 8));
+    DV_CHECK(ctx->s2.ensure(n));
+    StageScope sc(ctx, "op_lk_track");
+    dv_launch_lk_track(ctx->opA.pyr, ctx->opB.pyr, (const float2*)ctx->s0.p, nullptr, n, flow_back, dist_thresh, (float2*)ctx->s1.p,
+                       (uint8_t*)ctx->s2.p, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    if (stage_out(ctx, pts2, ctx->s1.p, (size_t)n * 8, mem)) return -1;
+    if (stage_out(ctx, status, ctx->s2.p, n, mem)) return -1;
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// stage an image (host or device) into a pitched device buffer; returns pointer/pitch to use
+static int stage_image(dv_ctx* ctx, DevBuf& b, const uint8_t* img, int w, int h, int stride, int mem, const uint8_t** out, int* pitch) {
+    if (mem == DV_MEM_DEVICE) { *out = img; *pitch = stride; return 0; }
+    const int p = align_up(w, 16);
+    DV_CHECK(b.ensure((size_t)p * h + 64));
+    DV_CHECK(hipMemcpy2DAsync(b.p, p, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+    *out = (const uint8_t*)b.p; *pitch = p;
+    return 0;
+}
+
+int dv_min_eigen(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem) {
+    if (!ctx) return -1;
+    if (!img || !eig) DV_FAIL("dv_min_eigen: null argument");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    const uint8_t* d_img; int pitch;
+    if (stage_image(ctx, ctx->s0, img, w, h, stride, mem, &d_img, &pitch)) return -1;
+    if (ensure_cand(ctx, w, h)) return -1;
+    float* d_eig = eig;
+    if (mem != DV_MEM_DEVICE) { DV_CHECK(ctx->s1.ensure((size_t)w * h * 4)); d_eig = (float*)ctx->s1.p; }
+    DV_CHECK(hipMemsetAsync(ctx->n_cand, 0, 8, ctx->stream));     // n_cand + max_ord
+    GfttTileArgs a{};
+    a.img = d_img; a.w = w; a.h = h; a.pitch = pitch; a.eig_out = d_eig; a.eig_pitch = w;
+    a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord;
+    dv_launch_gftt_tile(a, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    if (mem != DV_MEM_DEVICE) DV_CHECK(hipMemcpyAsync(eig, d_eig, (size_t)w * h * 4, hipMemcpyDeviceToHost, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w, int h, int stride, int max_n, double quality,
+            double min_dist, float* out_xy, int* n_out, int mem) {
+    if (!ctx) return -1;
+    if (!img || !out_xy || !n_out) DV_FAIL("dv_gftt: null argument");
+    if (!(quality > 0)) DV_FAIL("dv_gftt: qualityLevel must be > 0");
+    if (min_dist < 0) DV_FAIL("dv_gftt: minDistance must be >= 0");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    const uint8_t *d_img, *d_mask = nullptr; int pitch, mpitch = 0;
+    if (stage_image(ctx, ctx->s0, img, w, h, stride, mem, &d_img, &pitch)) return -1;
+    if (mask_or_null && stage_image(ctx, ctx->s3, mask_or_null, w, h, stride, mem, &d_mask, &mpitch)) return -1;
+    if (ensure_cand(ctx, w, h)) return -1;
+    DV_CHECK(ctx->s1.ensure((size_t)DV_MAX_FEATS * 8 + 16));
+    float2* d_out = (float2*)ctx->s1.p; int* d_n = (int*)((uint8_t*)ctx->s1.p + (size_t)DV_MAX_FEATS * 8);
+    DV_CHECK(hipMemsetAsync(ctx->n_cand, 0, 12, ctx->stream));    // n_cand, max_ord, err_flag
+    GfttTileArgs a{};
+    a.img = d_img; a.w = w; a.h = h; a.pitch = pitch; a.in_mask = d_mask; a.mask_pitch = mpitch;
+    a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord;
+    dv_launch_gftt_tile(a, ctx->stream);
+    GfttSelectArgs sa{};
+    sa.cand = (const DvCand*)ctx->cand_buf.p; sa.n_cand = ctx->n_cand; sa.cand_cap = ctx->cand_cap; sa.max_ord = ctx->max_ord;
+    sa.w = w; sa.h = h; sa.quality = quality; sa.min_dist = min_dist; sa.max_n_host = max_n; sa.n_feat = nullptr;
+    sa.out_xy = d_out; sa.n_out = d_n; sa.has_tr = 0; sa.err_flag = ctx->err_flag;
+    if (dv_launch_gftt_select(sa, ctx->stream)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
+    DV_CHECK(hipGetLastError());
+    int n = 0, ef = 0;
+    DV_CHECK(hipMemcpyAsync(&n, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DV_CHECK(hipMemcpyAsync(&ef, ctx->err_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ef) { DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, ctx->stream)); DV_FAIL("dv_gftt: device error flags=" + std::to_string(ef)); }
+    if (stage_out(ctx, out_xy, d_out, (size_t)n * 8, mem)) return -1;
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    *n_out = n;
+    return 0;
+}
+
+int dv_pyr_down(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, int mem) {
+    if (!ctx) return -1;
+    if (!src || !dst) DV_FAIL("dv_pyr_down: null argument");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    const uint8_t* d_src; int pitch;
+    if (stage_image(ctx, ctx->s0, src, w, h, stride, mem, &d_src, &pitch)) return -1;
+    const int dw = (w + 1) / 2, dh = (h + 1) / 2, dp = align_up(dw, 16);
+    DV_CHECK(ctx->s1.ensure((size_t)dp * dh + 64));
+    dv_launch_pyr_down2(d_src, nullptr, w, h, pitch, (uint8_t*)ctx->s1.p, nullptr, dp, nullptr, nullptr, 0, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipMemcpy2DAsync(dst, dw, ctx->s1.p, dp, dw, dh, mem == DV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dv_circle_mask(dv_ctx* ctx, uint8_t* mask, int w, int h, int stride, const float* pts_xy, int n, int radius, int mem) {
+    if (!ctx) return -1;
+    if (!mask || (n > 0 && !pts_xy)) DV_FAIL("dv_circle_mask: null argument");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (ensure_hw(ctx, radius)) return -1;
+    uint8_t* d_mask = mask; int pitch = stride;
+    if (mem != DV_MEM_DEVICE) {
+        pitch = align_up(w, 16);
+        DV_CHECK(ctx->s0.ensure((size_t)pitch * h));
+        DV_CHECK(hipMemcpy2DAsync(ctx->s0.p, pitch, mask, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
+        d_mask = (uint8_t*)ctx->s0.p;
+    }
+    if (stage_in(ctx, ctx->s1, pts_xy, (size_t)n * 8, mem)) return -1;
+    dv_launch_circle_mask(d_mask, w, h, pitch, (const float2*)ctx->s1.p, n, radius, (const uint8_t*)ctx->hw_buf.p, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    if (mem != DV_MEM_DEVICE) DV_CHECK(hipMemcpy2DAsync(mask, stride, d_mask, pitch, w, h, hipMemcpyDeviceToHost, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dv_erode(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, int k, uint8_t* dst, int mem) {
+    if (!ctx) return -1;
+    if (!src || !dst || k < 1) DV_FAIL("dv_erode: bad argument");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    const uint8_t* d_src; int pitch;
+    if (stage_image(ctx, ctx->s0, src, w, h, stride, mem, &d_src, &pitch)) return -1;
+    const int p = align_up(w, 16);
+    DV_CHECK(ctx->s1.ensure((size_t)p * h)); DV_CHECK(ctx->s2.ensure((size_t)p * h));
+    dv_launch_erode(d_src, w, h, pitch, k, (uint8_t*)ctx->s1.p, p, (uint8_t*)ctx->s2.p, p, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipMemcpy2DAsync(dst, mem == DV_MEM_DEVICE ? stride : w, ctx->s2.p, p, w, h,
+                              mem == DV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int dv_lift_projective(dv_ctx* ctx, const dv_cam* cam, const float* pts_xy, int n, float* out_xy, int mem) {
+    if (!ctx) return -1;
+    if (!cam || (n > 0 && (!pts_xy || !out_xy))) DV_FAIL("dv_lift_projective: null argument");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (stage_in(ctx, ctx->s0, pts_xy, (size_t)n * 8, mem)) return -1;
+    DV_CHECK(ctx->s1.ensure((size_t)std::max(n, 1) * 8));
+    dv_launch_lift(*cam, (const float2*)ctx->s0.p, n, (float2*)ctx->s1.p, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    if (stage_out(ctx, out_xy, ctx->s1.p, (size_t)n * 8, mem)) return -1;
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+} // extern "C"

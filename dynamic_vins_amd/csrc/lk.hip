@@ -1,0 +1,261 @@
+// lk.hip — pyramidal Lucas-Kanade sparse optical flow for gfx950.
+//
+// Semantics: cv::calcOpticalFlowPyrLK (OpenCV 3.4.16, winSize 21x21, 14-bit fixed-point
+// bilinear weights, Scharr derivatives, minEigThreshold 1e-4) as called by the reference's
+// FeatureTrackByLK (dynamic_vins/src/front_end/feature_utils.cpp:35-69).
+//
+// MI355X mapping: ONE 64-lane wavefront per feature point, no workgroup barriers.
+//   * lane -> (window row r = lane/3, 7-pixel segment lane%3): 63 lanes cover the 21x21 window;
+//   * per level the 24x24 I tile (window + 1 px Scharr halo + 1 px bilinear) and a 32x32 J tile
+//     are staged once in LDS with 4-byte aligned dword loads (reflect-101 byte path only for
+//     tiles that touch the image border); the J tile is re-centred only when the iterate
+//     drifts more than 5 px;
+//   * the interpolated patch I, Ix, Iy stays in registers (21 ints/lane) for all iterations;
+//   * A11,A12,A22,b1,b2 are exact integer sums: int32 butterflies over 8 lanes, widened to
+//     int64 for the last three steps -> results are independent of reduction order and
+//     bit-identical to the CPU oracle;
+//   * forward (4 levels) + backward (2 levels, initial flow) + distance test + InBorder test
+//     run in the same wave, so one launch replaces two calcOpticalFlowPyrLK calls and the
+//     host loop at feature_utils.cpp:55-66.
+// Float math is compiled with -ffp-contract=off and uses correctly rounded div/sqrt.
+#include "dv_internal.h"
+#include <cfloat>
+
+#define WIN DV_LK_WIN
+#define IT_ROWS 24
+#define IT_PITCH 28
+#define JT_ROWS 32
+#define JT_PITCH 36
+#define JT_MARGIN 5
+
+__device__ __forceinline__ int lk_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+// Stage rows [y0, y0+rows) x bytes [ax0, ax0+pitch) of level L into LDS (ax0 multiple of 4).
+// need_x0/need_cols describe the columns that are actually consumed; if they and the rows lie
+// inside the image the aligned dword path is taken (over-read bytes are never used).
+__device__ __forceinline__ void lk_stage_tile(uint8_t* lds, int pitch, int rows, const DvLevel& L, int ax0, int y0,
+                                              int need_x0, int need_cols, int lane) {
+    const bool fast = need_x0 >= 0 && need_x0 + need_cols <= L.w && y0 >= 0 && y0 + rows <= L.h;
+    if (fast) {
+        const int ndw = pitch >> 2;
+        uint32_t* l32 = reinterpret_cast<uint32_t*>(lds);
+        for (int i = lane; i < rows * ndw; i += 64) {
+            int r = i / ndw, c = i - r * ndw;
+            l32[i] = *reinterpret_cast<const uint32_t*>(L.p + (size_t)(y0 + r) * L.pitch + ax0 + 4 * c);
+        }
+    } else {
+        for (int i = lane; i < rows * pitch; i += 64) {
+            int r = i / pitch, c = i - r * pitch;
+            lds[i] = L.p[(size_t)lk_reflect101(y0 + r, L.h) * L.pitch + lk_reflect101(ax0 + c, L.w)];
+        }
+    }
+}
+
+__device__ __forceinline__ long long lk_wave_sum(int v) {
+    // |v| * 8 < 2^31 for every quantity summed here (see DESIGN.md "LK exact sums")
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    long long s = v;
+    s += __shfl_xor(s, 8);
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    return s;
+}
+
+__device__ __forceinline__ int lk_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+__device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+    w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+    w01 = __float2int_rn(a * (1.f - b) * 16384.f);
+    w10 = __float2int_rn((1.f - a) * b * 16384.f);
+    w11 = 16384 - w00 - w01 - w10;
+}
+
+// One pyramid level of LKTrackerInvoker for the wave's point.  All control flow is wave-uniform.
+// next is in/out (nextPts[ptidx]); status is cleared only at level 0.
+__device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_level, float2 prev, float2& next,
+                         bool& status, int max_count, double eps_sq, bool use_initial, uint8_t* sI, uint8_t* sJ, int lane) {
+    const float half = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float lscale = (float)(1. / (1 << level));
+    float2 prevPt = make_float2(prev.x * lscale, prev.y * lscale);
+    float2 nextPt;
+    if (level == max_level) nextPt = use_initial ? make_float2(next.x * lscale, next.y * lscale) : prevPt;
+    else nextPt = make_float2(next.x * 2.f, next.y * 2.f);
+    next = nextPt;
+
+    prevPt.x -= half; prevPt.y -= half;
+    const int ipx = (int)floorf(prevPt.x), ipy = (int)floorf(prevPt.y);
+    if (ipx < -WIN || ipx >= I.w || ipy < -WIN || ipy >= I.h) { if (level == 0) status = false; return; }
+    int w00, w01, w10, w11;
+    lk_weights(prevPt.x - ipx, prevPt.y - ipy, w00, w01, w10, w11);
+
+    // ---- stage the I tile: rows ipy-1..ipy+22, cols ipx-1..ipx+22 ----
+    const int itx0 = ipx - 1, iax0 = itx0 & ~3, ioff = itx0 - iax0;
+    lk_stage_tile(sI, IT_PITCH, IT_ROWS, I, iax0, ipy - 1, itx0, 24, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    const bool active = lane < 63;
+    const int r = active ? lane / 3 : 0, c0 = active ? (lane - r * 3) * 7 : 0;
+    int Iv[7], Ixv[7], Iyv[7];
+    {
+        // tile coordinates of window pixel (x=c0, y=r): row r+1, col c0+1+ioff
+        const uint8_t* T = sI + (r + 1) * IT_PITCH + (c0 + 1 + ioff);
+        // column-wise Scharr partials for rows y=r (j=0) and y=r+1 (j=1), cols c0-1..c0+8
+        int t0[2][10], t1[2][10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) {
+            int a = T[-IT_PITCH + k - 1], b = T[k - 1], c = T[IT_PITCH + k - 1], d = T[2 * IT_PITCH + k - 1];
+            t0[0][k] = (a + c) * 3 + b * 10;  t1[0][k] = c - a;
+            t0[1][k] = (b + d) * 3 + c * 10;  t1[1][k] = d - b;
+        }
+        int gx[2][8], gy[2][8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ay = ipy + r + j;
+            const bool yin = ay >= 0 && ay < I.h;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int ax = ipx + c0 + i;
+                const bool in = yin && ax >= 0 && ax < I.w;          // derivative image has a zero border
+                gx[j][i] = in ? t0[j][i + 2] - t0[j][i] : 0;
+                gy[j][i] = in ? (t1[j][i + 2] + t1[j][i]) * 3 + t1[j][i + 1] * 10 : 0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            Iv[i] = lk_descale(T[i] * w00 + T[i + 1] * w01 + T[IT_PITCH + i] * w10 + T[IT_PITCH + i + 1] * w11, 14 - 5);
+            Ixv[i] = lk_descale(gx[0][i] * w00 + gx[0][i + 1] * w01 + gx[1][i] * w10 + gx[1][i + 1] * w11, 14);
+            Iyv[i] = lk_descale(gy[0][i] * w00 + gy[0][i + 1] * w01 + gy[1][i] * w10 + gy[1][i + 1] * w11, 14);
+        }
+    }
+    int pa11 = 0, pa12 = 0, pa22 = 0;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) { pa11 += Ixv[i] * Ixv[i]; pa12 += Ixv[i] * Iyv[i]; pa22 += Iyv[i] * Iyv[i]; }
+    }
+    const float A11 = (float)lk_wave_sum(pa11) * FLT_SCALE;
+    const float A12 = (float)lk_wave_sum(pa12) * FLT_SCALE;
+    const float A22 = (float)lk_wave_sum(pa22) * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * WIN * WIN);
+    if (minEig < 1e-4f || D < FLT_EPSILON) { if (level == 0) status = false; return; }
+    D = 1.f / D;
+
+    nextPt.x -= half; nextPt.y -= half;
+    float2 prevDelta = make_float2(0.f, 0.f);
+    int jx0 = 0, jy0 = 0, jax0 = 0;
+    bool have_tile = false;
+    for (int j = 0; j < max_count; ++j) {
+        const int inx = (int)floorf(nextPt.x), iny = (int)floorf(nextPt.y);
+        if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { if (level == 0) status = false; break; }
+        if (!have_tile || inx < jx0 || inx > jx0 + 2 * JT_MARGIN || iny < jy0 || iny > jy0 + 2 * JT_MARGIN) {
+            jx0 = inx - JT_MARGIN; jy0 = iny - JT_MARGIN; jax0 = jx0 & ~3;
+            __builtin_amdgcn_wave_barrier();
+            lk_stage_tile(sJ, JT_PITCH, JT_ROWS, J, jax0, jy0, jx0, 32, lane);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            have_tile = true;
+        }
+        lk_weights(nextPt.x - inx, nextPt.y - iny, w00, w01, w10, w11);
+        int pb1 = 0, pb2 = 0;
+        {
+            const uint8_t* T = sJ + (iny - jy0 + r) * JT_PITCH + (inx - jax0 + c0);
+            int top[8], bot[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { top[i] = T[i]; bot[i] = T[JT_PITCH + i]; }
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < 7; ++i) {
+                    int diff = lk_descale(top[i] * w00 + top[i + 1] * w01 + bot[i] * w10 + bot[i + 1] * w11, 14 - 5) - Iv[i];
+                    pb1 += diff * Ixv[i];
+                    pb2 += diff * Iyv[i];
+                }
+            }
+        }
+        const float b1 = (float)lk_wave_sum(pb1) * FLT_SCALE;
+        const float b2 = (float)lk_wave_sum(pb2) * FLT_SCALE;
+        const float2 delta = make_float2((A12 * b2 - A22 * b1) * D, (A12 * b1 - A11 * b2) * D);
+        nextPt.x += delta.x; nextPt.y += delta.y;
+        next = make_float2(nextPt.x + half, nextPt.y + half);
+        if ((double)delta.x * (double)delta.x + (double)delta.y * (double)delta.y <= eps_sq) break;
+        if (j > 0 && (double)fabsf(delta.x + prevDelta.x) < 0.01 && (double)fabsf(delta.y + prevDelta.y) < 0.01) {
+            next.x -= delta.x * 0.5f; next.y -= delta.y * 0.5f;
+            break;
+        }
+        prevDelta = delta;
+    }
+    if (status && level == 0) {   // err != NULL at the reference call sites: final in-bounds re-check
+        const int ix = (int)floorf(next.x - half), iy = (int)floorf(next.y - half);
+        if (ix < -WIN || ix >= J.w || iy < -WIN || iy >= J.h) status = false;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ bool lk_in_border(float2 pt, int rows, int cols) {   // feature_utils.h:68-74
+    const int x = __float2int_rn(pt.x), y = __float2int_rn(pt.y);
+    return 1 <= x && x < cols - 1 && 1 <= y && y < rows - 1;
+}
+
+// generic single-direction calcOpticalFlowPyrLK
+__global__ __launch_bounds__(64) void lk_generic_kernel(DvPyr A, DvPyr B, const float2* __restrict__ pts_a, int n, int max_level,
+                                                        int iters, double eps_sq, int use_initial, float2* __restrict__ pts_b,
+                                                        uint8_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t sI[IT_ROWS * IT_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t sJ[JT_ROWS * JT_PITCH];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= n) return;
+    const float2 prev = pts_a[p];
+    float2 next = use_initial ? pts_b[p] : make_float2(0.f, 0.f);
+    bool st = true;
+    for (int level = max_level; level >= 0; --level)
+        lk_level(A.L[level], B.L[level], level, max_level, prev, next, st, iters, eps_sq, use_initial != 0, sI, sJ, lane);
+    if (lane == 0) { pts_b[p] = next; status[p] = st ? 1 : 0; }
+}
+
+// FeatureTrackByLK fused: fwd (maxLevel 3) + bwd (maxLevel 1, initial flow) + distance + InBorder
+__global__ __launch_bounds__(64) void lk_track_kernel(DvPyr A, DvPyr B, const float2* __restrict__ pts_a, const int* __restrict__ n_dev,
+                                                      int n_host, int flow_back, float dist_thresh, double eps_sq,
+                                                      float2* __restrict__ pts_b, uint8_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t sI[IT_ROWS * IT_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t sJ[JT_ROWS * JT_PITCH];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n = n_dev ? *n_dev : n_host;
+    if (p >= n) return;
+    const float2 prev = pts_a[p];
+    float2 next = make_float2(0.f, 0.f);
+    bool st = true;
+    const int mlf = min(3, A.levels - 1);
+    for (int level = mlf; level >= 0; --level)
+        lk_level(A.L[level], B.L[level], level, mlf, prev, next, st, 30, eps_sq, false, sI, sJ, lane);
+    if (flow_back) {
+        float2 rev = prev;
+        bool rst = true;
+        const int mlb = min(1, A.levels - 1);
+        for (int level = mlb; level >= 0; --level)
+            lk_level(B.L[level], A.L[level], level, mlb, next, rev, rst, 30, eps_sq, true, sI, sJ, lane);
+        const float dx = prev.x - rev.x, dy = prev.y - rev.y;
+        st = st && rst && sqrtf(dx * dx + dy * dy) <= dist_thresh;
+    }
+    if (st && !lk_in_border(next, B.L[0].h, B.L[0].w)) st = false;
+    if (lane == 0) { pts_b[p] = next; status[p] = st ? 1 : 0; }
+}
+
+void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters, double eps_sq,
+                          int use_initial, float2* pts_b, uint8_t* status, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(lk_generic_kernel, dim3(n), dim3(64), 0, s, A, B, pts_a, n, max_level, iters, eps_sq, use_initial, pts_b, status);
+}
+
+void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back,
+                        float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s) {
+    if (n_max <= 0) return;
+    const double eps = 0.01;   // TermCriteria default / feature_utils.cpp:52; OpenCV squares it
+    hipLaunchKernelGGL(lk_track_kernel, dim3(n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status);
+}

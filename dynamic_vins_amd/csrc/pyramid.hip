@@ -1,0 +1,94 @@
+// pyramid.hip — cv::pyrDown for CV_8UC1 on gfx950 (used by buildOpticalFlowPyramid inside
+// cv::calcOpticalFlowPyrLK; reference call sites front_end/feature_utils.cpp:43,50).
+// 5x5 separable [1 4 6 4 1], (sum+128)>>8, BORDER_REFLECT_101, dst = ((w+1)/2) x ((h+1)/2).
+// Integer arithmetic -> bit-exact against the oracle.
+//
+// Layout: one 256-thread workgroup per 64x16 output tile.  The 131x35 source tile is staged
+// in LDS with dword global loads (interior tiles) or reflect-indexed byte loads (border
+// tiles); the horizontal pass goes LDS->LDS (int16), the vertical pass writes uchar4.
+// The level-1 launch optionally also writes the source tile's core to a pitched copy of
+// level 0, so the frame is read from HBM once for "copy + first pyrDown".
+// blockIdx.z selects the image of a stereo pair (two images per launch).
+#include "dv_internal.h"
+
+#define PT_W 64
+#define PT_H 16
+#define PS_W (2 * PT_W + 3)   // 131 source columns
+#define PS_H (2 * PT_H + 3)   // 35 source rows
+#define PS_PITCH 136          // 34 dwords per LDS row (covers the 4-byte aligned span)
+
+__device__ __forceinline__ int pyr_reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) p = p < 0 ? -p : 2 * len - 2 - p;
+    return p;
+}
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
+                                                       int sw, int sh, int spitch,
+                                                       uint8_t* __restrict__ dst0, uint8_t* __restrict__ dst1, int dw, int dh, int dpitch,
+                                                       uint8_t* __restrict__ copy0, uint8_t* __restrict__ copy1, int cpitch) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_src[PS_H * PS_PITCH];
+    __shared__ short s_h[PS_H][PT_W];
+    const uint8_t* src = blockIdx.z ? src1 : src0;
+    uint8_t* dst = blockIdx.z ? dst1 : dst0;
+    uint8_t* cpy = blockIdx.z ? copy1 : copy0;
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * PT_W, oy0 = blockIdx.y * PT_H;
+    const int sx0 = 2 * ox0 - 2, sy0 = 2 * oy0 - 2;
+    const int ax0 = sx0 - 2;                                  // 2*ox0-4: multiple of 4
+    const bool interior = (ax0 >= 0) && (ax0 + PS_PITCH <= sw) && (sy0 >= 0) && (sy0 + PS_H <= sh) && ((spitch & 3) == 0)
+                          && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+    if (interior) {
+        uint32_t* s32 = reinterpret_cast<uint32_t*>(s_src);
+        for (int i = tid; i < PS_H * (PS_PITCH / 4); i += 256) {
+            int r = i / (PS_PITCH / 4), c = i - r * (PS_PITCH / 4);
+            s32[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(sy0 + r) * spitch + ax0 + 4 * c);
+        }
+    } else {
+        for (int i = tid; i < PS_H * PS_PITCH; i += 256) {
+            int r = i / PS_PITCH, c = i - r * PS_PITCH;
+            int y = pyr_reflect101(sy0 + r, sh), x = pyr_reflect101(ax0 + c, sw);
+            s_src[i] = src[(size_t)y * spitch + x];
+        }
+    }
+    __syncthreads();
+    if (cpy) {   // level-0 copy: this tile's own 128x32 source pixels
+        for (int i = tid; i < 32 * 32; i += 256) {
+            int r = i >> 5, q = i & 31;
+            int y = 2 * oy0 + r, x = 2 * ox0 + 4 * q;
+            if (y < sh && x < sw) {
+                const uint8_t* p = &s_src[(r + 2) * PS_PITCH + 4 * q + 4];
+                if (x + 3 < sw) *reinterpret_cast<uchar4*>(cpy + (size_t)y * cpitch + x) = make_uchar4(p[0], p[1], p[2], p[3]);
+                else for (int k = 0; x + k < sw; ++k) cpy[(size_t)y * cpitch + x + k] = p[k];
+            }
+        }
+    }
+    for (int i = tid; i < PS_H * PT_W; i += 256) {
+        int r = i / PT_W, c = i - r * PT_W;
+        const uint8_t* p = &s_src[r * PS_PITCH + 2 * c + 2];   // source column sx0 + 2c
+        s_h[r][c] = (short)(p[0] + p[4] + 4 * (p[1] + p[3]) + 6 * p[2]);
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 4, q = tid & 15;
+        const int y = oy0 + r, x = ox0 + 4 * q;
+        if (y < dh && x < dw) {
+            uint8_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int c = 4 * q + k;
+                int v = s_h[2 * r][c] + s_h[2 * r + 4][c] + 4 * (s_h[2 * r + 1][c] + s_h[2 * r + 3][c]) + 6 * s_h[2 * r + 2][c];
+                o[k] = (uint8_t)((v + 128) >> 8);
+            }
+            if (x + 3 < dw) *reinterpret_cast<uchar4*>(dst + (size_t)y * dpitch + x) = make_uchar4(o[0], o[1], o[2], o[3]);
+            else for (int k = 0; x + k < dw; ++k) dst[(size_t)y * dpitch + x + k] = o[k];
+        }
+    }
+}
+
+void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int sh, int spitch, uint8_t* dst0, uint8_t* dst1,
+                         int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch, hipStream_t s) {
+    const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
+    dim3 grid((dw + PT_W - 1) / PT_W, (dh + PT_H - 1) / PT_H, src1 ? 2 : 1);
+    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src0, src1, sw, sh, spitch, dst0, dst1, dw, dh, dpitch, copy0, copy1, cpitch);
+}

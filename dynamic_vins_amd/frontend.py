@@ -1,0 +1,190 @@
+"""Python mirror of the reference's front-end interface, on top of the C ABI (for tests and bench.py;
+the C++ drop-in shim with the reference's class signatures is dynamic_vins_amd/host/feature_tracker.h).
+
+Names follow dynamic_vins/src/front_end/background_tracker.h:41-88 and feature_utils.h.
+"""
+import ctypes as C
+import numpy as np
+
+from . import _abi
+from ._abi import DvinsError, dv_cam, dv_config, dv_feat, DV_MEM_HOST, DV_MEM_DEVICE, DV_MODE_RAW, DV_MODE_NAIVE
+
+FEAT_DTYPE = np.dtype([("id", np.uint32), ("track_cnt", np.int32), ("has_right", np.int32), ("pad_", np.int32),
+                       ("left", np.float64, 7), ("right", np.float64, 7)])
+assert FEAT_DTYPE.itemsize == C.sizeof(dv_feat) == 128
+
+
+def make_cam(fx, fy, cx, cy, k1=0.0, k2=0.0, p1=0.0, p2=0.0):
+    return dv_cam(fx, fy, cx, cy, k1, k2, p1, p2)
+
+
+def _ptr(a):
+    """pointer of a host ndarray, or pass through a raw device pointer (int)."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return C.c_void_p(int(a))
+    return C.c_void_p(a.ctypes.data)
+
+
+class Context:
+    """Owns a dv_ctx (device memory + stream).  One per thread, like the reference's FeatureTracker."""
+
+    def __init__(self, width, height, max_cnt=150, min_dist=30, flow_back=1, stereo=1, cam0=None, cam1=None, device=0):
+        self.lib = _abi.load()
+        cfg = dv_config()
+        cfg.width, cfg.height, cfg.max_cnt, cfg.min_dist = width, height, max_cnt, min_dist
+        cfg.flow_back, cfg.stereo, cfg.device = flow_back, stereo, device
+        cfg.cam0 = cam0 if cam0 is not None else make_cam(1, 1, 0, 0)
+        cfg.cam1 = cam1 if cam1 is not None else cfg.cam0
+        self.cfg = cfg
+        self.h = self.lib.dv_create(C.byref(cfg))
+        if not self.h:
+            raise DvinsError(self.lib.dv_last_error(None).decode())
+        self._out = np.zeros(_abi.DV_MAX_FEATS, FEAT_DTYPE)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dv_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise DvinsError(self.lib.dv_last_error(self.h).decode())
+
+    # ---- whole-frame entries ----
+    def track_stereo(self, gray0, gray1, t, mask=None, mode=DV_MODE_RAW, mem=DV_MEM_HOST, w=None, h=None, stride=None):
+        w = w or self.cfg.width
+        h = h or self.cfg.height
+        stride = stride or w
+        n = C.c_int(0)
+        self._check(self.lib.dv_track_stereo(self.h, _ptr(gray0), _ptr(gray1), w, h, stride, float(t), _ptr(mask), mode, mem,
+                                             self._out.ctypes.data_as(C.POINTER(dv_feat)), C.byref(n)))
+        return self._out[: n.value].copy()
+
+    def track_stereo_enqueue(self, gray0, gray1, t, mask=None, mode=DV_MODE_RAW, mem=DV_MEM_HOST, stride=None):
+        w, h = self.cfg.width, self.cfg.height
+        self._check(self.lib.dv_track_stereo_enqueue(self.h, _ptr(gray0), _ptr(gray1), w, h, stride or w, float(t), _ptr(mask), mode, mem))
+
+    def track_stereo_collect(self):
+        n = C.c_int(0)
+        self._check(self.lib.dv_track_stereo_collect(self.h, self._out.ctypes.data_as(C.POINTER(dv_feat)), C.byref(n)))
+        return self._out[: n.value].copy()
+
+    def reset(self):
+        self._check(self.lib.dv_reset(self.h))
+
+    def sync(self):
+        self._check(self.lib.dv_sync(self.h))
+
+    # ---- operator-level entries (host numpy in / out) ----
+    def lk(self, img_a, img_b, pts_a, max_level=3, iters=30, eps=0.01, initial=None):
+        h, w = img_a.shape
+        pts_a = np.ascontiguousarray(pts_a, np.float32)
+        n = len(pts_a)
+        pts_b = np.ascontiguousarray(initial, np.float32).copy() if initial is not None else np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        self._check(self.lib.dv_lk(self.h, _ptr(img_a), _ptr(img_b), w, h, img_a.strides[0], _ptr(pts_a), n, max_level, iters, float(eps),
+                                   1 if initial is not None else 0, _ptr(pts_b), _ptr(st), DV_MEM_HOST))
+        return pts_b, st
+
+    def track_by_lk(self, img1, img2, pts1, flow_back=True, dist_thresh=0.5):
+        """FeatureTrackByLK (front_end/feature_utils.cpp:35-69)."""
+        h, w = img1.shape
+        pts1 = np.ascontiguousarray(pts1, np.float32)
+        n = len(pts1)
+        pts2 = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        self._check(self.lib.dv_track_by_lk(self.h, _ptr(img1), _ptr(img2), w, h, img1.strides[0], _ptr(pts1), n, int(flow_back),
+                                            float(dist_thresh), _ptr(pts2), _ptr(st), DV_MEM_HOST))
+        return pts2, st
+
+    def gftt(self, img, max_n, quality, min_dist, mask=None):
+        h, w = img.shape
+        out = np.zeros((_abi.DV_MAX_FEATS, 2), np.float32)
+        n = C.c_int(0)
+        self._check(self.lib.dv_gftt(self.h, _ptr(img), _ptr(mask), w, h, img.strides[0], int(max_n), float(quality), float(min_dist),
+                                     _ptr(out), C.byref(n), DV_MEM_HOST))
+        return out[: n.value].copy()
+
+    def min_eigen(self, img):
+        h, w = img.shape
+        eig = np.zeros((h, w), np.float32)
+        self._check(self.lib.dv_min_eigen(self.h, _ptr(img), w, h, img.strides[0], _ptr(eig), DV_MEM_HOST))
+        return eig
+
+    def pyr_down(self, img):
+        h, w = img.shape
+        dst = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self._check(self.lib.dv_pyr_down(self.h, _ptr(img), w, h, img.strides[0], _ptr(dst), DV_MEM_HOST))
+        return dst
+
+    def circle_mask(self, mask, pts, radius):
+        h, w = mask.shape
+        pts = np.ascontiguousarray(pts, np.float32)
+        out = np.ascontiguousarray(mask).copy()
+        self._check(self.lib.dv_circle_mask(self.h, _ptr(out), w, h, out.strides[0], _ptr(pts), len(pts), int(radius), DV_MEM_HOST))
+        return out
+
+    def erode(self, mask, k):
+        h, w = mask.shape
+        out = np.zeros_like(mask)
+        self._check(self.lib.dv_erode(self.h, _ptr(mask), w, h, mask.strides[0], int(k), _ptr(out), DV_MEM_HOST))
+        return out
+
+    def lift_projective(self, cam, pts):
+        pts = np.ascontiguousarray(pts, np.float32)
+        out = np.zeros_like(pts)
+        self._check(self.lib.dv_lift_projective(self.h, C.byref(cam), _ptr(pts), len(pts), _ptr(out), DV_MEM_HOST))
+        return out
+
+    # ---- measurement ----
+    def timing_enable(self, on=True):
+        self._check(self.lib.dv_timing_enable(self.h, 1 if on else 0))
+
+    def timing_get(self, name):
+        ms, cnt = C.c_double(0), C.c_longlong(0)
+        self._check(self.lib.dv_timing_get(self.h, name.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+
+class FeatureTracker:
+    """Mirror of dynamic_vins::FeatureTracker (front_end/background_tracker.h:41-88).
+
+    TrackImage / TrackImageNaive return the FeatureBackground.points map:
+        {id: [(0, [x,y,1,u,v,vx,vy]), (1, [...right...])]}
+    camelCase aliases (VINS-Fusion spelling used by BASELINE.json) are provided.
+    """
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.cur_time = 0.0
+
+    @staticmethod
+    def _to_map(rows):
+        pts = {}
+        for r in rows:
+            obs = [(0, np.array(r["left"]))]
+            if r["has_right"]:
+                obs.append((1, np.array(r["right"])))
+            pts[int(r["id"])] = obs
+        return pts
+
+    def TrackImage(self, gray0, gray1, time0):
+        self.cur_time = time0
+        self.rows = self.ctx.track_stereo(gray0, gray1, time0, None, DV_MODE_RAW)
+        return self._to_map(self.rows)
+
+    def TrackImageNaive(self, gray0, gray1, time0, inv_merge_mask=None):
+        self.cur_time = time0
+        self.rows = self.ctx.track_stereo(gray0, gray1, time0, inv_merge_mask, DV_MODE_NAIVE)
+        return self._to_map(self.rows)
+
+    trackImage = TrackImage
+    trackImageNaive = TrackImageNaive

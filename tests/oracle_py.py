@@ -1,0 +1,166 @@
+"""ctypes wrapper of the CPU oracle (oracle/_build/libdvins_oracle.so).  TEST INFRASTRUCTURE ONLY:
+imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, never by the product."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ODIR = os.path.join(ROOT, "oracle")
+OLIB = os.path.join(ODIR, "_build", "libdvins_oracle.so")
+
+
+class dvo_cam(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2")]
+
+
+class dvo_fe_config(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("max_cnt", C.c_int), ("min_dist", C.c_int),
+                ("flow_back", C.c_int), ("stereo", C.c_int), ("cam0", dvo_cam), ("cam1", dvo_cam)]
+
+
+FEAT_DTYPE = np.dtype([("id", np.uint32), ("track_cnt", np.int32), ("has_right", np.int32), ("pad_", np.int32),
+                       ("left", np.float64, 7), ("right", np.float64, 7)])
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ODIR])
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class Oracle:
+    def __init__(self, lib):
+        self.lib = lib
+        lib.dvo_tracker_create.restype = C.c_void_p
+        lib.dvo_tracker_create.argtypes = [C.POINTER(dvo_fe_config)]
+        lib.dvo_tracker_destroy.argtypes = [C.c_void_p]
+        lib.dvo_tracker_track_image.restype = C.c_int
+        lib.dvo_tracker_track_image.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        lib.dvo_tracker_track_image_naive.restype = C.c_int
+        lib.dvo_tracker_track_image_naive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        lib.dvo_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
+                               C.c_void_p, C.c_void_p]
+        lib.dvo_track_by_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+        lib.dvo_gftt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
+        lib.dvo_min_eigen.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.dvo_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.dvo_scharr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.dvo_circle_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
+        lib.dvo_erode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.dvo_lift_projective.argtypes = [C.POINTER(dvo_cam), C.c_void_p, C.c_int, C.c_void_p]
+
+    def pyr_down(self, img):
+        h, w = img.shape
+        img = np.ascontiguousarray(img)
+        dst = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self.lib.dvo_pyr_down(_p(img), w, h, _p(dst))
+        return dst
+
+    def scharr(self, img):
+        h, w = img.shape
+        img = np.ascontiguousarray(img)
+        out = np.zeros((h, w, 2), np.int16)
+        self.lib.dvo_scharr(_p(img), w, h, _p(out))
+        return out
+
+    def lk(self, a, b, pts_a, max_level=3, iters=30, eps=0.01, initial=None):
+        h, w = a.shape
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        pts_a = np.ascontiguousarray(pts_a, np.float32)
+        n = len(pts_a)
+        pts_b = np.ascontiguousarray(initial, np.float32).copy() if initial is not None else np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        self.lib.dvo_lk(_p(a), _p(b), w, h, _p(pts_a), n, max_level, iters, eps, 1 if initial is not None else 0, _p(pts_b), _p(st))
+        return pts_b, st
+
+    def track_by_lk(self, a, b, pts1, flow_back=True, dist_thresh=0.5):
+        h, w = a.shape
+        a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+        pts1 = np.ascontiguousarray(pts1, np.float32)
+        n = len(pts1)
+        pts2 = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        self.lib.dvo_track_by_lk(_p(a), _p(b), w, h, _p(pts1), n, int(flow_back), dist_thresh, _p(pts2), _p(st))
+        return pts2, st
+
+    def gftt(self, img, max_n, quality, min_dist, mask=None):
+        h, w = img.shape
+        img = np.ascontiguousarray(img)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask)
+        out = np.zeros((max(h * w // 4, 16), 2), np.float32)
+        n = C.c_int(0)
+        self.lib.dvo_gftt(_p(img), _p(mask), w, h, int(max_n), float(quality), float(min_dist), _p(out), C.byref(n))
+        return out[: n.value].copy()
+
+    def min_eigen(self, img):
+        h, w = img.shape
+        img = np.ascontiguousarray(img)
+        eig = np.zeros((h, w), np.float32)
+        self.lib.dvo_min_eigen(_p(img), w, h, _p(eig))
+        return eig
+
+    def circle_mask(self, mask, pts, radius):
+        h, w = mask.shape
+        out = np.ascontiguousarray(mask).copy()
+        pts = np.ascontiguousarray(pts, np.float32)
+        self.lib.dvo_circle_mask(_p(out), w, h, _p(pts), len(pts), int(radius))
+        return out
+
+    def erode(self, mask, k):
+        h, w = mask.shape
+        mask = np.ascontiguousarray(mask)
+        out = np.zeros_like(mask)
+        self.lib.dvo_erode(_p(mask), w, h, int(k), _p(out))
+        return out
+
+    def lift_projective(self, cam, pts):
+        pts = np.ascontiguousarray(pts, np.float32)
+        out = np.zeros_like(pts)
+        c = dvo_cam(*cam)
+        self.lib.dvo_lift_projective(C.byref(c), _p(pts), len(pts), _p(out))
+        return out
+
+    def tracker(self, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1):
+        return OracleTracker(self, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1)
+
+
+class OracleTracker:
+    def __init__(self, o, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1):
+        self.o = o
+        cfg = dvo_fe_config(width, height, max_cnt, min_dist, flow_back, stereo, dvo_cam(*cam0), dvo_cam(*cam1))
+        self.h = o.lib.dvo_tracker_create(C.byref(cfg))
+        self.out = np.zeros(max_cnt + 8, FEAT_DTYPE)
+
+    def track_image(self, g0, g1, t, mask=None, naive=False):
+        g0 = np.ascontiguousarray(g0)
+        g1 = np.ascontiguousarray(g1) if g1 is not None else None
+        if naive:
+            n = self.o.lib.dvo_tracker_track_image_naive(self.h, _p(g0), _p(g1), _p(mask), t, _p(self.out))
+        else:
+            n = self.o.lib.dvo_tracker_track_image(self.h, _p(g0), _p(g1), t, _p(self.out))
+        return self.out[:n].copy()
+
+    def close(self):
+        if self.h:
+            self.o.lib.dvo_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+_inst = None
+
+
+def load():
+    global _inst
+    if _inst is None:
+        if not os.path.exists(OLIB):
+            build()
+        _inst = Oracle(C.CDLL(OLIB))
+    return _inst

@@ -1,0 +1,222 @@
+"""GPU parity tests: HIP front end (through the C ABI) vs the CPU oracle on the same seeded inputs.
+Bar: bit-exact — the path is u8/int16/int32/int64 arithmetic plus a handful of correctly-rounded
+fp32/fp64 operations evaluated in the same order on both sides (no FMA contraction)."""
+import numpy as np
+import pytest
+
+from dynamic_vins_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ZED = (701.406049185687, 700.7199834541797, 663.9703743586792, 362.02045484177154,
+       -0.17198906485492285, 0.024624053031210322, 0.0003391614313509814, -0.00045583634752113735)
+
+
+def _cam(p):
+    from dynamic_vins_amd.frontend import make_cam
+    return make_cam(*p)
+
+
+def _img(h, w, seed):
+    return np.ascontiguousarray((synth.texture(h, w, seed) * 255).astype(np.uint8))
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_ctx_factory):
+    return gpu_ctx_factory(width=320, height=240, max_cnt=150, min_dist=15, cam0=_cam(ZED), cam1=_cam(ZED))
+
+
+@pytest.mark.parametrize("hw", [(240, 320), (480, 752), (375, 1242), (188, 621), (94, 311), (33, 47), (720, 1280)])
+def test_pyr_down_bit_exact(ctx, oracle, hw):
+    img = _img(hw[0], hw[1], 7)
+    got = ctx.pyr_down(img)
+    ref = oracle.pyr_down(img)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+def _pair(h, w, dx, dy, seed=3):
+    seq = synth.PlaneSequence(w, h, seed=seed, margin=64)
+    X, Y = seq.u + seq.m, seq.v + seq.m
+    a = synth.sample(seq.tex, X, Y)
+    b = synth.sample(seq.tex, X - dx, Y - dy)
+    return a, b
+
+
+@pytest.mark.parametrize("hw,shift", [((240, 320), (3.3, -1.7)), ((480, 752), (-9.6, 6.2)), ((375, 1242), (14.2, 0.4)), ((120, 160), (0.6, 0.3))])
+def test_lk_generic_bit_exact(ctx, oracle, hw, shift):
+    a, b = _pair(hw[0], hw[1], *shift)
+    pts = oracle.gftt(a, 200, 0.01, 12)
+    # add points near / beyond the border to exercise the reflect path and status clearing
+    extra = np.array([[1.5, 2.5], [hw[1] - 2.2, hw[0] - 1.7], [0.0, 0.0], [hw[1] - 1.0, 5.0], [hw[1] / 2, 0.4]], np.float32)
+    pts = np.vstack([pts, extra])
+    for ml in (3, 1, 0):
+        gp, gs = ctx.lk(a, b, pts, max_level=ml)
+        rp, rs = oracle.lk(a, b, pts, max_level=ml)
+        assert np.array_equal(gs, rs), f"status differs at max_level {ml}"
+        assert np.array_equal(gp.view(np.uint32), rp.view(np.uint32)), f"positions differ at max_level {ml}"
+    # recovered flow is the true shift (sanity of the oracle itself)
+    rp, rs = oracle.lk(a, b, pts[:-5], max_level=3)
+    d = (rp - pts[:-5])[rs > 0]
+    assert abs(np.median(d[:, 0]) - shift[0]) < 0.1 and abs(np.median(d[:, 1]) - shift[1]) < 0.1
+
+
+def test_lk_initial_flow_bit_exact(ctx, oracle):
+    a, b = _pair(240, 320, 2.4, 1.1)
+    pts = oracle.gftt(a, 120, 0.01, 12)
+    init = pts + np.float32([2.0, 1.0])
+    gp, gs = ctx.lk(a, b, pts, max_level=1, initial=init)
+    rp, rs = oracle.lk(a, b, pts, max_level=1, initial=init)
+    assert np.array_equal(gs, rs)
+    assert np.array_equal(gp.view(np.uint32), rp.view(np.uint32))
+
+
+@pytest.mark.parametrize("hw,shift,thr", [((240, 320), (3.3, -1.7), 0.5), ((480, 752), (-7.6, 4.2), 0.5), ((720, 1280), (11.0, -3.0), 1.0)])
+def test_track_by_lk_bit_exact(ctx, oracle, hw, shift, thr):
+    """FeatureTrackByLK: fwd + bwd + distance + InBorder fused in one launch."""
+    a, b = _pair(hw[0], hw[1], *shift)
+    pts = oracle.gftt(a, 300, 0.01, 15)
+    gp, gs = ctx.track_by_lk(a, b, pts, True, thr)
+    rp, rs = oracle.track_by_lk(a, b, pts, True, thr)
+    assert np.array_equal(gs, rs)
+    assert np.array_equal(gp.view(np.uint32), rp.view(np.uint32))
+    assert gs.sum() > 0.8 * len(pts)
+    gp, gs = ctx.track_by_lk(a, b, pts, False, thr)
+    rp, rs = oracle.track_by_lk(a, b, pts, False, thr)
+    assert np.array_equal(gs, rs) and np.array_equal(gp.view(np.uint32), rp.view(np.uint32))
+
+
+@pytest.mark.parametrize("hw", [(240, 320), (480, 752), (375, 1242), (65, 130), (16, 64), (17, 65)])
+def test_min_eigen_bit_exact(ctx, oracle, hw):
+    img = _img(hw[0], hw[1], 11)
+    got = ctx.min_eigen(img)
+    ref = oracle.min_eigen(img)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("hw,max_n,md", [((240, 320), 150, 15), ((480, 752), 150, 30), ((375, 1242), 250, 25), ((240, 320), 0, 8),
+                                         ((240, 320), 40, 4), ((240, 320), 500, 0)])
+def test_gftt_exact(ctx, oracle, hw, max_n, md):
+    img = _img(hw[0], hw[1], 5)
+    got = ctx.gftt(img, max_n, 0.01, md)
+    ref = oracle.gftt(img, max_n if max_n > 0 else 1024, 0.01, md)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+def test_gftt_masked_and_chunked(ctx, oracle):
+    """720p: > 8192 surviving candidates forces the value-ordered chunk path; mask with discs."""
+    img = _img(720, 1280, 9)
+    rng = np.random.default_rng(2)
+    mask = np.full((720, 1280), 255, np.uint8)
+    mask[100:300, 200:700] = 0
+    pts = rng.uniform([0, 0], [1280, 720], (120, 2)).astype(np.float32)
+    mask_o = oracle.circle_mask(mask, pts, 25)
+    mask_g = ctx.circle_mask(mask, pts, 25)
+    assert np.array_equal(mask_o, mask_g)
+    got = ctx.gftt(img, 1000, 0.001, 6, mask_g)
+    ref = oracle.gftt(img, 1000, 0.001, 6, mask_o)
+    assert np.array_equal(got, ref)
+    assert len(got) == 1000
+
+
+def test_gftt_empty_and_flat(ctx, oracle):
+    flat = np.full((64, 96), 128, np.uint8)
+    assert len(ctx.gftt(flat, 10, 0.01, 5)) == 0 == len(oracle.gftt(flat, 10, 0.01, 5))
+    img = _img(64, 96, 1)
+    zero_mask = np.zeros((64, 96), np.uint8)
+    assert len(ctx.gftt(img, 10, 0.01, 5, zero_mask)) == 0 == len(oracle.gftt(img, 10, 0.01, 5, zero_mask))
+
+
+@pytest.mark.parametrize("radius", [0, 1, 4, 20, 25, 30])
+def test_circle_mask_bit_exact(ctx, oracle, radius):
+    rng = np.random.default_rng(radius)
+    mask = np.full((120, 200), 255, np.uint8)
+    pts = rng.uniform([-10, -10], [210, 130], (40, 2)).astype(np.float32)
+    pts[0] = [0.5, 0.5]
+    pts[1] = [199.5, 119.5]
+    assert np.array_equal(ctx.circle_mask(mask, pts, radius), oracle.circle_mask(mask, pts, radius))
+
+
+@pytest.mark.parametrize("k", [1, 5, 10, 20])
+def test_erode_bit_exact(ctx, oracle, k):
+    rng = np.random.default_rng(k)
+    mask = (rng.uniform(0, 1, (97, 131)) > 0.02).astype(np.uint8) * 255
+    assert np.array_equal(ctx.erode(mask, k), oracle.erode(mask, k))
+
+
+def test_lift_projective_bit_exact(ctx, oracle):
+    rng = np.random.default_rng(0)
+    pts = rng.uniform([0, 0], [1280, 720], (500, 2)).astype(np.float32)
+    got = ctx.lift_projective(_cam(ZED), pts)
+    ref = oracle.lift_projective(ZED, pts)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    nod = ZED[:4] + (0.0, 0.0, 0.0, 0.0)
+    assert np.array_equal(ctx.lift_projective(_cam(nod), pts).view(np.uint32), oracle.lift_projective(nod, pts).view(np.uint32))
+
+
+def _rows_equal(g, r):
+    assert len(g) == len(r), f"feature count {len(g)} vs {len(r)}"
+    for name in ("id", "track_cnt", "has_right"):
+        assert np.array_equal(g[name], r[name]), name
+    assert np.array_equal(g["left"].view(np.uint64), r["left"].view(np.uint64)), "left observation"
+    assert np.array_equal(g["right"].view(np.uint64), r["right"].view(np.uint64)), "right observation"
+
+
+@pytest.mark.parametrize("w,h,max_cnt,min_dist,frames", [(320, 240, 80, 15, 12), (752, 480, 150, 30, 8)])
+def test_track_image_sequence_bit_exact(gpu_ctx_factory, oracle, w, h, max_cnt, min_dist, frames):
+    """FeatureTracker::TrackImage over a sequence: ids, track counts, stereo flags and every Vec7d
+    (undistorted point, pixel, velocity) identical to the oracle, frame after frame."""
+    cam = (w * 0.55, w * 0.55, w / 2 - 3.1, h / 2 + 2.2) + ZED[4:]
+    c = gpu_ctx_factory(width=w, height=h, max_cnt=max_cnt, min_dist=min_dist, cam0=_cam(cam), cam1=_cam(cam))
+    o = oracle.tracker(w, h, max_cnt, min_dist, 1, 1, cam, cam)
+    seq = synth.PlaneSequence(w, h, seed=21, disparity=9.25)
+    total_tracked = 0
+    for k in range(frames):
+        left, right = seq.frame(k)
+        t = 0.05 * k
+        g = c.track_stereo(left, right, t)
+        r = o.track_image(left, right, t)
+        _rows_equal(g, r)
+        if k:
+            total_tracked += int((g["track_cnt"] > 1).sum())
+    assert total_tracked > frames * max_cnt * 0.5      # the sequence really is tracked, not re-detected
+    assert g["has_right"].sum() > 0.5 * len(g)
+
+
+def test_track_image_naive_masked_bit_exact(gpu_ctx_factory, oracle):
+    w, h, max_cnt, min_dist = 320, 240, 90, 12
+    cam = (180.0, 181.0, 158.0, 121.0) + ZED[4:]
+    c = gpu_ctx_factory(width=w, height=h, max_cnt=max_cnt, min_dist=min_dist, cam0=_cam(cam), cam1=_cam(cam))
+    o = oracle.tracker(w, h, max_cnt, min_dist, 1, 1, cam, cam)
+    seq = synth.PlaneSequence(w, h, seed=5, disparity=6.5)
+    from dynamic_vins_amd.frontend import DV_MODE_NAIVE
+    for k in range(8):
+        left, right = seq.frame(k)
+        mask = np.full((h, w), 255, np.uint8)
+        mask[60:140, 100 + 5 * k:190 + 5 * k] = 0       # a moving "object" region
+        g = c.track_stereo(left, right, 0.1 * k, mask, DV_MODE_NAIVE)
+        r = o.track_image(left, right, 0.1 * k, mask, naive=True)
+        _rows_equal(g, r)
+
+
+def test_mono_and_reset(gpu_ctx_factory, oracle):
+    w, h = 320, 240
+    cam = (200.0, 200.0, 160.0, 120.0, 0, 0, 0, 0)
+    c = gpu_ctx_factory(width=w, height=h, max_cnt=60, min_dist=20, stereo=0, cam0=_cam(cam), cam1=_cam(cam))
+    seq = synth.PlaneSequence(w, h, seed=8)
+    for rep in range(2):
+        o = oracle.tracker(w, h, 60, 20, 1, 0, cam, cam)
+        for k in range(4):
+            left, _ = seq.frame(k)
+            _rows_equal(c.track_stereo(left, None, 0.05 * k), o.track_image(left, None, 0.05 * k))
+        c.reset()
+
+
+def test_error_behaviour(ctx):
+    from dynamic_vins_amd import DvinsError
+    img = _img(240, 320, 1)
+    with pytest.raises(DvinsError):
+        ctx.track_by_lk(img, img, np.zeros((0, 2), np.float32))      # reference: std::runtime_error on empty input
+    with pytest.raises(DvinsError):
+        ctx.track_stereo(_img(100, 100, 1), None, 0.0, w=100, h=100)   # size mismatch (reference: std::terminate)

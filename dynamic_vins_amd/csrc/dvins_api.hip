@@ -10,6 +10,7 @@
 #include "dv_internal.h"
 #include <cmath>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 
@@ -74,7 +75,7 @@ struct dv_ctx {
     hipEvent_t done = nullptr; bool pending = false;
     // operator-level scratch
     PyrSet opA, opB; DevBuf s0, s1, s2, s3, s4;
-    bool timing = false; std::vector<StageTimer> timers;
+    bool timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
 };
 
 void dv_set_error(dv_ctx* ctx, const std::string& msg) {

@@ -91,6 +91,47 @@ int dvo_tracker_track_image(dvo_tracker*, const uint8_t* gray0, const uint8_t* g
 int dvo_tracker_track_image_naive(dvo_tracker*, const uint8_t* gray0, const uint8_t* gray1,
                                   const uint8_t* mask, double time, dvo_feat* out);
 
+/* ---------------- back end ---------------- */
+
+/* projection factors: kind 0 = ProjectionTwoFrameOneCamFactor (blocks pose_i,pose_j,ex0,lambda,td),
+ * 1 = ProjectionTwoFrameTwoCamFactor (pose_i,pose_j,ex0,ex1,lambda,td), 2 = ProjectionOneFrameTwoCamFactor
+ * (ex0,ex1,lambda,td).  obs12 = pts_i(3) pts_j(3) vel_i(2) vel_j(2) td_i td_j.  J[k] row-major
+ * 2 x block_size (may be NULL entries / NULL). */
+void dvo_proj_eval(int kind, const double* obs12, const double* const* par, double* res2, double** J);
+
+/* IntegrationBase (estimator/imu/integration_base.h) */
+typedef struct dvo_preint dvo_preint;
+dvo_preint* dvo_preint_create(const double* acc0, const double* gyr0, const double* ba, const double* bg,
+                              const double* noise4 /* acc_n gyr_n acc_w gyr_w */);
+void dvo_preint_destroy(dvo_preint*);
+void dvo_preint_push(dvo_preint*, double dt, const double* acc, const double* gyr);
+void dvo_preint_repropagate(dvo_preint*, const double* ba, const double* bg);
+void dvo_preint_get(const dvo_preint*, double* sum_dt, double* dp, double* dq_xyzw, double* dv, double* jac225, double* cov225);
+/* IMUFactor::Evaluate; par = pose_i(7) sb_i(9) pose_j(7) sb_j(9); J = 15x7,15x9,15x7,15x9 row-major */
+void dvo_imu_eval(const dvo_preint*, double g_norm, const double* const* par, double* res15, double** J);
+
+typedef struct dvo_be_config {       /* para (estimator/vio_parameters.cpp:19-83) + cfg flags + extrinsics */
+    int use_imu, stereo, plane_constraint, max_iters;
+    double keyframe_parallax;        /* pixels; min_parallax = keyframe_parallax / 460 */
+    double init_depth, g_norm, td;
+    double acc_n, gyr_n, acc_w, gyr_w;
+    double ric[2][9], tic[2][3];     /* body_T_cam0 / body_T_cam1 rotation (row-major) and translation */
+} dvo_be_config;
+
+typedef struct dvo_be_state {
+    int frame, nonlinear, margin_old, n_landmarks, n_long, iterations;
+    double initial_cost, final_cost;
+    double window[11][16];           /* per window slot: P(3) Q(xyzw) V(3) Ba(3) Bg(3) */
+} dvo_be_state;
+
+/* Estimator (estimator/estimator.cpp): InputIMU + one ProcessMeasurements iteration per call.
+ * returns 0 = processed, 1 = IMU data does not yet cover t (call again after more InputIMU). */
+typedef struct dvo_estimator dvo_estimator;
+dvo_estimator* dvo_estimator_create(const dvo_be_config*);
+void dvo_estimator_destroy(dvo_estimator*);
+void dvo_estimator_input_imu(dvo_estimator*, double t, const double* acc, const double* gyr);
+int dvo_estimator_process(dvo_estimator*, const dvo_feat* feats, int n, double t, dvo_be_state* out);
+
 #ifdef __cplusplus
 }
 #endif

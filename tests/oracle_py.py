@@ -128,6 +128,9 @@ class Oracle:
     def tracker(self, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1):
         return OracleTracker(self, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1)
 
+    def estimator(self, **kw):
+        return OracleEstimator(self, **kw)
+
 
 class OracleTracker:
     def __init__(self, o, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1):
@@ -148,6 +151,69 @@ class OracleTracker:
     def close(self):
         if self.h:
             self.o.lib.dvo_tracker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
+class dvo_be_config(C.Structure):
+    _fields_ = [("use_imu", C.c_int), ("stereo", C.c_int), ("plane_constraint", C.c_int), ("max_iters", C.c_int),
+                ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),
+                ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
+                ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2)]
+
+
+class dvo_be_state(C.Structure):
+    _fields_ = [("frame", C.c_int), ("nonlinear", C.c_int), ("margin_old", C.c_int), ("n_landmarks", C.c_int),
+                ("n_long", C.c_int), ("iterations", C.c_int), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("window", (C.c_double * 16) * 11)]
+
+
+def make_be_config(cls, use_imu=1, stereo=1, plane_constraint=0, max_iters=8, keyframe_parallax=10.0, init_depth=5.0,
+                   g_norm=9.81, td=0.0, acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None):
+    c = cls()
+    c.use_imu, c.stereo, c.plane_constraint, c.max_iters = use_imu, stereo, plane_constraint, max_iters
+    c.keyframe_parallax, c.init_depth, c.g_norm, c.td = keyframe_parallax, init_depth, g_norm, td
+    c.acc_n, c.gyr_n, c.acc_w, c.gyr_w = acc_n, gyr_n, acc_w, gyr_w
+    for k in range(2):
+        for i in range(9):
+            c.ric[k][i] = float(np.asarray(ric[k]).reshape(-1)[i])
+        for i in range(3):
+            c.tic[k][i] = float(tic[k][i])
+    return c
+
+
+class OracleEstimator:
+    def __init__(self, o, **kw):
+        self.lib = o.lib
+        L = self.lib
+        L.dvo_estimator_create.restype = C.c_void_p
+        L.dvo_estimator_create.argtypes = [C.POINTER(dvo_be_config)]
+        L.dvo_estimator_destroy.argtypes = [C.c_void_p]
+        L.dvo_estimator_input_imu.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        L.dvo_estimator_process.restype = C.c_int
+        L.dvo_estimator_process.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.POINTER(dvo_be_state)]
+        self.cfg = make_be_config(dvo_be_config, **kw)
+        self.h = L.dvo_estimator_create(C.byref(self.cfg))
+        self.state = dvo_be_state()
+
+    def input_imu(self, t, acc, gyr):
+        a = np.ascontiguousarray(acc, np.float64)
+        g = np.ascontiguousarray(gyr, np.float64)
+        self.lib.dvo_estimator_input_imu(self.h, float(t), _p(a), _p(g))
+
+    def process(self, rows, t):
+        rows = np.ascontiguousarray(rows)
+        rc = self.lib.dvo_estimator_process(self.h, _p(rows), len(rows), float(t), C.byref(self.state))
+        return rc, self.state
+
+    def window(self):
+        return np.array([list(r) for r in self.state.window])
+
+    def close(self):
+        if self.h:
+            self.lib.dvo_estimator_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -1,0 +1,115 @@
+"""ctypes mirror of the bundle-adjustment part of include/dvins.h (dv_ba_*), for tests and bench.py."""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import DvinsError
+
+
+class dv_ba_factor(C.Structure):
+    _fields_ = [("pix", C.c_double), ("piy", C.c_double), ("pjx", C.c_double), ("pjy", C.c_double),
+                ("vix", C.c_double), ("viy", C.c_double), ("vjx", C.c_double), ("vjy", C.c_double),
+                ("td_i", C.c_double), ("td_j", C.c_double),
+                ("kind", C.c_int32), ("lm", C.c_int32), ("fi", C.c_int32), ("fj", C.c_int32), ("pad_", C.c_double * 2)]
+
+
+FACTOR_DTYPE = np.dtype([("pix", "f8"), ("piy", "f8"), ("pjx", "f8"), ("pjy", "f8"), ("vix", "f8"), ("viy", "f8"), ("vjx", "f8"), ("vjy", "f8"),
+                         ("td_i", "f8"), ("td_j", "f8"), ("kind", "i4"), ("lm", "i4"), ("fi", "i4"), ("fj", "i4"), ("pad_", "f8", 2)])
+LM_DTYPE = np.dtype([("first", "i4"), ("count", "i4"), ("anchor", "i4"), ("mask", "i4")])
+IMU_DTYPE = np.dtype([("sum_dt", "f8"), ("dp", "f8", 3), ("dq", "f8", 4), ("dv", "f8", 3), ("lin_ba", "f8", 3), ("lin_bg", "f8", 3),
+                      ("jacobian", "f8", 225), ("covariance", "f8", 225), ("fi", "i4"), ("fj", "i4"), ("pad0", "i4"), ("pad1", "i4")])
+assert FACTOR_DTYPE.itemsize == C.sizeof(dv_ba_factor) == 112
+
+
+class dv_ba_prior_block(C.Structure):
+    _fields_ = [("type", C.c_int32), ("idx", C.c_int32), ("off", C.c_int32), ("size_local", C.c_int32)]
+
+
+class dv_ba_prior(C.Structure):
+    _fields_ = [("valid", C.c_int32), ("n", C.c_int32), ("nblocks", C.c_int32), ("pad", C.c_int32), ("c0", C.c_double),
+                ("blocks", dv_ba_prior_block * 16), ("x0", (C.c_double * 9) * 16)]
+
+
+class dv_ba_problem(C.Structure):
+    _fields_ = [("nframes", C.c_int32), ("nlm", C.c_int32), ("nfac", C.c_int32), ("nimu", C.c_int32),
+                ("use_imu", C.c_int32), ("plane_kind", C.c_int32), ("max_iters", C.c_int32), ("reserved", C.c_int32),
+                ("g_norm", C.c_double),
+                ("pose", C.c_void_p), ("speed_bias", C.c_void_p), ("ex_pose", C.c_void_p), ("td", C.c_void_p), ("inv_depth", C.c_void_p),
+                ("factors", C.c_void_p), ("landmarks", C.c_void_p), ("imu", C.c_void_p),
+                ("prior", C.c_void_p), ("prior_A", C.c_void_p), ("prior_b", C.c_void_p)]
+
+
+class dv_ba_summary(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("successful", C.c_int32), ("termination", C.c_int32), ("slots", C.c_int32),
+                ("initial_cost", C.c_double), ("final_cost", C.c_double)]
+
+
+
+
+class WindowProblem:
+    """Owns the numpy buffers of one window problem and exposes them as a dv_ba_problem.
+    The struct layout is shared by the oracle's dvo_ba_problem, so the same object drives both."""
+
+    def __init__(self, pose, speed_bias, ex_pose, td, inv_depth, factors, landmarks, imu, use_imu=1, plane_kind=0, max_iters=8,
+                 g_norm=9.81, prior=None, prior_A=None, prior_b=None):
+        self.pose = np.ascontiguousarray(pose, np.float64).copy()
+        self.speed_bias = np.ascontiguousarray(speed_bias, np.float64).copy()
+        self.ex_pose = np.ascontiguousarray(ex_pose, np.float64).copy()
+        self.td = np.array([td], np.float64)
+        self.inv_depth = np.ascontiguousarray(inv_depth, np.float64).copy()
+        self.factors = np.ascontiguousarray(factors)
+        self.landmarks = np.ascontiguousarray(landmarks)
+        self.imu = np.ascontiguousarray(imu)
+        self.prior, self.prior_A, self.prior_b = prior, None, None
+        if prior is not None:
+            self.prior_A = np.ascontiguousarray(prior_A, np.float64)
+            self.prior_b = np.ascontiguousarray(prior_b, np.float64)
+        p = dv_ba_problem()
+        p.nframes, p.nlm, p.nfac, p.nimu = len(self.pose), len(self.inv_depth), len(self.factors), len(self.imu)
+        p.use_imu, p.plane_kind, p.max_iters, p.g_norm = use_imu, plane_kind, max_iters, g_norm
+        self.c = p
+        self._bind()
+
+    def _bind(self):
+        p = self.c
+        p.pose, p.speed_bias, p.ex_pose = self.pose.ctypes.data, self.speed_bias.ctypes.data, self.ex_pose.ctypes.data
+        p.td, p.inv_depth = self.td.ctypes.data, self.inv_depth.ctypes.data
+        p.factors = self.factors.ctypes.data if len(self.factors) else None
+        p.landmarks = self.landmarks.ctypes.data if len(self.landmarks) else None
+        p.imu = self.imu.ctypes.data if len(self.imu) else None
+        if self.prior is not None:
+            p.prior, p.prior_A, p.prior_b = C.addressof(self.prior), self.prior_A.ctypes.data, self.prior_b.ctypes.data
+        else:
+            p.prior, p.prior_A, p.prior_b = None, None, None
+
+    def clone(self):
+        q = WindowProblem(self.pose, self.speed_bias, self.ex_pose, self.td[0], self.inv_depth, self.factors, self.landmarks, self.imu,
+                          self.c.use_imu, self.c.plane_kind, self.c.max_iters, self.c.g_norm, self.prior, self.prior_A, self.prior_b)
+        return q
+
+
+def ba_solve(ctx, prob: WindowProblem):
+    s = dv_ba_summary()
+    if ctx.lib.dv_ba_solve(ctx.h, C.byref(prob.c), C.byref(s)) != 0:
+        raise DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+    return s
+
+
+def proj_eval(ctx, factors, pose_i, pose_j, ex0, ex1, inv_depth, td):
+    n = len(factors)
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (pose_i, pose_j, ex0, ex1, inv_depth, td)]
+    factors = np.ascontiguousarray(factors)
+    out = np.zeros((n, 54))
+    if ctx.lib.dv_proj_eval(ctx.h, factors.ctypes.data, n, *[a.ctypes.data for a in arrs], out.ctypes.data) != 0:
+        raise DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+    return out
+
+
+def imu_eval(ctx, imu_rec, g_norm, pose_i, sb_i, pose_j, sb_j):
+    arrs = [np.ascontiguousarray(a, np.float64) for a in (pose_i, sb_i, pose_j, sb_j)]
+    rec = np.ascontiguousarray(imu_rec)
+    out = np.zeros(465)
+    if ctx.lib.dv_imu_eval(ctx.h, rec.ctypes.data, float(g_norm), *[a.ctypes.data for a in arrs], out.ctypes.data) != 0:
+        raise DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+    return out[:15], out[15:].reshape(15, 30)

@@ -1,0 +1,211 @@
+// be_eval.hip — residual/Jacobian evaluation of one sliding-window BA problem on gfx950: replaces the
+// per-residual-block ceres::CostFunction::Evaluate() calls of the reference's ceres::Solve
+// (estimator/estimator.cpp:109-214, 314) with one launch per evaluation.
+//
+// Grid: one 64-lane workgroup per landmark, then one per IMU factor, then one for the prior.
+//   landmark block : lane = residual block.  Each lane evaluates its ProjectionFactor (fp64 residual, 2x6
+//                    Jacobians wrt pose_i / pose_j, 2x1 wrt inverse depth), applies the Huber(1.0)
+//                    corrector and parks the 28 numbers in LDS; then lane = output entry: the landmark's
+//                    Hessian pieces (h, g, w[a], gp[a], Ddiag[a], Danch[a]) are summed over its residual
+//                    blocks in a fixed order and written as one 7.4 KB packet.  Nothing is accumulated
+//                    with atomics, so the reduced system is bitwise reproducible.
+//   IMU block      : lane 0 evaluates the raw 15-residual / 15x30 Jacobian, all lanes whiten with the cached
+//                    sqrt-information and form the factor's 30x30 Hessian block and gradient.
+//   prior block    : g = b' + A' dx and cost = c0/2 + b'.dx + dx.A'dx/2 (information form of the
+//                    MarginalizationFactor, factor/marginalization_factor.cpp:350-396).
+// COST-only variant (candidate points of the trust-region loop): residuals only.
+#include <hip/hip_runtime.h>
+#include "be_kernels.h"
+
+using namespace be;
+
+__device__ void be_frame_geom(const BeState* s, int nframes, FrameGeom* fg, m33* ric, d3* tic, int lane) {
+    if (lane < nframes) { fg[lane].R = qR(Q4(s->pose[lane])); fg[lane].P = P3(s->pose[lane]); }
+    if (lane >= 32 && lane < 34) { ric[lane - 32] = qR(Q4(s->ex[lane - 32])); tic[lane - 32] = P3(s->ex[lane - 32]); }
+}
+
+// dx of the prior's kept blocks (MarginalizationFactor::Evaluate, marginalization_factor.cpp:355-378)
+__device__ void be_prior_dx(const BePriorHdr* p, const BeState* s, double* dx, int lane, int nthreads) {
+    for (int b = lane; b < p->nblocks; b += nthreads) {
+        const BePriorBlock pb = p->blocks[b];
+        const double* x0 = p->x0[b];
+        if (pb.type == 0 || pb.type == 2) {
+            const double* x = pb.type == 0 ? s->pose[pb.idx] : s->ex[pb.idx];
+            for (int k = 0; k < 3; ++k) dx[pb.off + k] = x[k] - x0[k];
+            const quat dq = qmul(qinv(Q4(x0)), Q4(x));
+            d3 v = qvec(dq) * 2.0;
+            if (!(dq.w >= 0)) v = -v;
+            dx[pb.off + 3] = v.x; dx[pb.off + 4] = v.y; dx[pb.off + 5] = v.z;
+        } else if (pb.type == 1) {
+            for (int k = 0; k < 9; ++k) dx[pb.off + k] = s->sb[pb.idx][k] - x0[k];
+        } else dx[pb.off] = s->td - x0[0];
+    }
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
+    const BeCtl c = *a.ctl;
+    if (c.done) return;
+    if (FULL && !c.need_eval) return;
+    if (!FULL && (c.chol_fail || !c.step_valid)) return;
+    const BeState* st = FULL ? a.x : a.cand;
+    const int lane = threadIdx.x;
+    const int b = blockIdx.x;
+    const int nlm = a.dims.nlm, nimu = a.dims.nimu;
+    __shared__ FrameGeom fg[BE_NF];
+    __shared__ m33 ric[2];
+    __shared__ d3 tic[2];
+    __shared__ double Jb[BE_MAX_OBS_FACTORS][28];
+    __shared__ int s_fj[BE_MAX_OBS_FACTORS], s_two[BE_MAX_OBS_FACTORS];
+    __shared__ double s_cost[BE_MAX_OBS_FACTORS];
+    __shared__ double s_imu[450 + 450 + 32];
+    if (b < nlm) {
+        // ------------------------------- landmark -------------------------------
+        const BeLm L = a.lm[b];
+        be_frame_geom(st, a.dims.nframes, fg, ric, tic, lane);
+        __syncthreads();
+        const double lambda = st->inv_depth[b];
+        if (lane < L.count) {
+            const BeFactor f = a.fac[L.first + lane];
+            double r[2], Ji[12], Jj[12], Jl[2];
+            proj_factor<FULL, false>(f, fg[f.fi], fg[f.fj], ric[0], tic[0], ric[1], tic[1], lambda, st->td, r, Ji, Jj, Jl, nullptr, nullptr, nullptr);
+            double rho0, sc;
+            huber1(r[0] * r[0] + r[1] * r[1], rho0, sc);
+            s_cost[lane] = 0.5 * rho0;
+            if (FULL) {
+                double* o = Jb[lane];
+                o[0] = r[0] * sc; o[1] = r[1] * sc;
+#pragma unroll
+                for (int k = 0; k < 12; ++k) { o[2 + k] = Ji[k] * sc; o[14 + k] = Jj[k] * sc; }
+                o[26] = Jl[0] * sc; o[27] = Jl[1] * sc;
+                s_fj[lane] = f.fj; s_two[lane] = f.kind != 2;
+            }
+        }
+        __syncthreads();
+        double cost = 0;
+        for (int f = 0; f < L.count; ++f) cost += s_cost[f];      // fixed order
+        if (!FULL) { if (lane == 0) a.cand_cost[b] = cost; return; }
+        double* pk = a.packets + (size_t)b * BE_PK_SIZE;
+        const int anchor = L.anchor, nf = L.count;
+        for (int e = lane; e < BE_PK_SIZE; e += 64) {
+            double v = 0.0;
+            if (e == BE_PK_H) { for (int f = 0; f < nf; ++f) v += Jb[f][26] * Jb[f][26] + Jb[f][27] * Jb[f][27]; }
+            else if (e == BE_PK_G) { for (int f = 0; f < nf; ++f) v += Jb[f][26] * Jb[f][0] + Jb[f][27] * Jb[f][1]; }
+            else if (e == BE_PK_COST) v = cost;
+            else if (e < BE_PK_DD) {
+                const bool is_w = e < BE_PK_GP;
+                const int q = e - (is_w ? BE_PK_W : BE_PK_GP), fa = q / 6, rr = q - fa * 6;
+                for (int f = 0; f < nf; ++f) {
+                    if (!s_two[f]) continue;
+                    const double* J = (fa == anchor) ? &Jb[f][2] : ((s_fj[f] == fa) ? &Jb[f][14] : nullptr);
+                    if (!J) continue;
+                    const double m0 = is_w ? Jb[f][26] : Jb[f][0], m1 = is_w ? Jb[f][27] : Jb[f][1];
+                    v += J[rr] * m0 + J[6 + rr] * m1;
+                }
+            } else if (e < BE_PK_DA) {
+                const int q = e - BE_PK_DD, fa = q / 36, rc = q - fa * 36, rr = rc / 6, cc = rc - rr * 6;
+                for (int f = 0; f < nf; ++f) {
+                    if (!s_two[f]) continue;
+                    const double* J = (fa == anchor) ? &Jb[f][2] : ((s_fj[f] == fa) ? &Jb[f][14] : nullptr);
+                    if (!J) continue;
+                    v += J[rr] * J[cc] + J[6 + rr] * J[6 + cc];
+                }
+            } else if (e < BE_PK_DA + BE_NF * 36) {
+                const int q = e - BE_PK_DA, fa = q / 36, rc = q - fa * 36, rr = rc / 6, cc = rc - rr * 6;
+                if (fa != anchor)
+                    for (int f = 0; f < nf; ++f) {
+                        if (!s_two[f] || s_fj[f] != fa) continue;
+                        v += Jb[f][2 + rr] * Jb[f][14 + cc] + Jb[f][8 + rr] * Jb[f][20 + cc];
+                    }
+            }
+            pk[e] = v;
+        }
+    } else if (b < nlm + nimu) {
+        // ------------------------------- IMU factor -------------------------------
+        const int k = b - nlm;
+        const BeImu* m = &a.imu[k];
+        double* Jraw = s_imu; double* Jw = s_imu + 450; double* rr = s_imu + 900;      // rr[0..14] raw, rr[15..29] whitened
+        for (int i = lane; i < 450; i += 64) Jraw[i] = 0.0;
+        __syncthreads();
+        if (lane == 0) imu_raw<FULL>(*m, a.g_norm, st->pose[m->fi], st->sb[m->fi], st->pose[m->fj], st->sb[m->fj], rr, Jraw);
+        __syncthreads();
+        if (lane < 15) { double s = 0; for (int q = lane; q < 15; ++q) s += m->sqrt_info[lane * 15 + q] * rr[q]; rr[15 + lane] = s; }
+        if (FULL)
+            for (int e = lane; e < 450; e += 64) {
+                const int i = e / 30, cc = e - i * 30; double s = 0;
+                for (int q = i; q < 15; ++q) s += m->sqrt_info[i * 15 + q] * Jraw[q * 30 + cc];
+                Jw[e] = s;
+            }
+        __syncthreads();
+        double cost = 0;
+        for (int i = 0; i < 15; ++i) cost += rr[15 + i] * rr[15 + i];
+        cost *= 0.5;
+        if (!FULL) { if (lane == 0) a.cand_cost[b] = cost; return; }
+        double* o = a.imu_out + (size_t)k * IMU_OUT_STRIDE;
+        if (lane == 0) o[0] = cost;
+        if (lane < 30) { double s = 0; for (int i = 0; i < 15; ++i) s += Jw[i * 30 + lane] * rr[15 + i]; o[1 + lane] = s; }
+        for (int e = lane; e < 900; e += 64) {
+            const int r0 = e / 30, c0 = e - r0 * 30; double s = 0;
+            for (int i = 0; i < 15; ++i) s += Jw[i * 30 + r0] * Jw[i * 30 + c0];
+            o[31 + e] = s;
+        }
+    } else {
+        // ------------------------------- prior -------------------------------
+        const BePriorHdr* p = a.prior;
+        if (!p->valid) { if (lane == 0) { if (FULL) a.prior_out[0] = 0.0; else a.cand_cost[b] = 0.0; } return; }
+        __shared__ double dx[BE_MAX_PRIOR], Adx[BE_MAX_PRIOR];
+        const int n = p->n;
+        be_prior_dx(p, st, dx, lane, 64);
+        __syncthreads();
+        for (int i = lane; i < n; i += 64) { double s = 0; const double* row = a.priorA + (size_t)i * n; for (int j = 0; j < n; ++j) s += row[j] * dx[j]; Adx[i] = s; }
+        __syncthreads();
+        if (lane == 0) {
+            double bd = 0, dAd = 0;
+            for (int i = 0; i < n; ++i) { bd += a.priorb[i] * dx[i]; dAd += dx[i] * Adx[i]; }
+            const double cost = 0.5 * p->c0 + bd + 0.5 * dAd;
+            if (FULL) a.prior_out[0] = cost; else a.cand_cost[b] = cost;
+        }
+        if (FULL) for (int i = lane; i < n; i += 64) a.prior_out[1 + i] = a.priorb[i] + Adx[i];
+    }
+}
+
+void be_launch_eval(const BeEvalArgs& a, bool full, hipStream_t s) {
+    const int grid = a.dims.nlm + a.dims.nimu + 1;
+    if (full) hipLaunchKernelGGL(be_eval_kernel<true>, dim3(grid), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL(be_eval_kernel<false>, dim3(grid), dim3(64), 0, s, a);
+}
+
+// ---- operator-level factor evaluation (parity tests against the oracle's dvo_proj_eval / dvo_imu_eval) ----
+__global__ void be_proj_op_kernel(const BeFactor* fac, int n, const double* pose_i, const double* pose_j, const double* ex0, const double* ex1,
+                                  const double* lambda, const double* td, double* out /* n x 54: r2 Ji12 Jj12 Jex0_12 Jex1_12 Jl2 Jtd2 */) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    FrameGeom Fi, Fj;
+    Fi.R = qR(Q4(pose_i + 7 * i)); Fi.P = P3(pose_i + 7 * i); Fj.R = qR(Q4(pose_j + 7 * i)); Fj.P = P3(pose_j + 7 * i);
+    double* o = out + (size_t)i * 54;
+    for (int k = 0; k < 54; ++k) o[k] = 0.0;
+    proj_factor<true, true>(fac[i], Fi, Fj, qR(Q4(ex0 + 7 * i)), P3(ex0 + 7 * i), qR(Q4(ex1 + 7 * i)), P3(ex1 + 7 * i), lambda[i], td[i],
+                            o, o + 2, o + 14, o + 50, o + 26, o + 38, o + 52);
+}
+void be_launch_proj_op(const BeFactor* fac, int n, const double* pose_i, const double* pose_j, const double* ex0, const double* ex1,
+                       const double* lambda, const double* td, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(be_proj_op_kernel, dim3((n + 63) / 64), dim3(64), 0, s, fac, n, pose_i, pose_j, ex0, ex1, lambda, td, out);
+}
+
+__global__ void be_imu_op_kernel(const BeImu* m, double g_norm, const double* par /* pose_i7 sb_i9 pose_j7 sb_j9 */, double* out /* r15, J 15x30 whitened */) {
+    __shared__ double Jraw[450], rr[15];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 450; i += 64) Jraw[i] = 0.0;
+    __syncthreads();
+    if (lane == 0) imu_raw<true>(*m, g_norm, par, par + 7, par + 16, par + 23, rr, Jraw);
+    __syncthreads();
+    if (lane < 15) { double s = 0; for (int q = lane; q < 15; ++q) s += m->sqrt_info[lane * 15 + q] * rr[q]; out[lane] = s; }
+    for (int e = lane; e < 450; e += 64) {
+        const int i = e / 30, cc = e - i * 30; double s = 0;
+        for (int q = i; q < 15; ++q) s += m->sqrt_info[i * 15 + q] * Jraw[q * 30 + cc];
+        out[15 + e] = s;
+    }
+}
+void be_launch_imu_op(const BeImu* m, double g_norm, const double* par, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(be_imu_op_kernel, dim3(1), dim3(64), 0, s, m, g_norm, par, out);
+}

@@ -1,0 +1,95 @@
+// be_math.h — fixed-size fp64 vector / matrix / quaternion helpers shared by the host estimator and the
+// HIP back-end kernels (__host__ __device__).  Product code; independent of the oracle's la.h.
+#pragma once
+#include <math.h>
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BE_HD __host__ __device__ __forceinline__
+#else
+#define BE_HD inline
+#endif
+
+namespace be {
+
+struct d3 { double x, y, z; };
+BE_HD d3 mk3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+BE_HD d3 operator+(d3 a, d3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+BE_HD d3 operator-(d3 a, d3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+BE_HD d3 operator-(d3 a) { return mk3(-a.x, -a.y, -a.z); }
+BE_HD d3 operator*(d3 a, double s) { return mk3(a.x * s, a.y * s, a.z * s); }
+BE_HD d3 operator*(double s, d3 a) { return mk3(a.x * s, a.y * s, a.z * s); }
+BE_HD d3 operator/(d3 a, double s) { return mk3(a.x / s, a.y / s, a.z / s); }
+BE_HD double dot(d3 a, d3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+BE_HD d3 cross(d3 a, d3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+BE_HD double norm(d3 a) { return sqrt(dot(a, a)); }
+BE_HD double get(d3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+struct m33 { double m[9]; };      // row-major
+BE_HD m33 eye3() { m33 r; for (int i = 0; i < 9; ++i) r.m[i] = 0; r.m[0] = r.m[4] = r.m[8] = 1; return r; }
+BE_HD m33 zero3() { m33 r; for (int i = 0; i < 9; ++i) r.m[i] = 0; return r; }
+BE_HD m33 mul(const m33& a, const m33& b) {
+    m33 r;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = a.m[i * 3] * b.m[j] + a.m[i * 3 + 1] * b.m[3 + j] + a.m[i * 3 + 2] * b.m[6 + j];
+    return r;
+}
+BE_HD d3 mul(const m33& a, d3 v) { return mk3(a.m[0] * v.x + a.m[1] * v.y + a.m[2] * v.z, a.m[3] * v.x + a.m[4] * v.y + a.m[5] * v.z, a.m[6] * v.x + a.m[7] * v.y + a.m[8] * v.z); }
+BE_HD m33 tr(const m33& a) { m33 r; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = a.m[j * 3 + i]; return r; }
+BE_HD m33 scale(const m33& a, double s) { m33 r; for (int i = 0; i < 9; ++i) r.m[i] = a.m[i] * s; return r; }
+BE_HD m33 add(const m33& a, const m33& b) { m33 r; for (int i = 0; i < 9; ++i) r.m[i] = a.m[i] + b.m[i]; return r; }
+BE_HD m33 sub(const m33& a, const m33& b) { m33 r; for (int i = 0; i < 9; ++i) r.m[i] = a.m[i] - b.m[i]; return r; }
+BE_HD m33 skew(d3 q) { m33 r = zero3(); r.m[1] = -q.z; r.m[2] = q.y; r.m[3] = q.z; r.m[5] = -q.x; r.m[6] = -q.y; r.m[7] = q.x; return r; }
+
+struct quat { double w, x, y, z; };
+BE_HD quat mkq(double w, double x, double y, double z) { quat q; q.w = w; q.x = x; q.y = y; q.z = z; return q; }
+BE_HD quat qmul(quat a, quat b) {
+    return mkq(a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+               a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x);
+}
+BE_HD quat qinv(quat q) { double n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z; return mkq(q.w / n, -q.x / n, -q.y / n, -q.z / n); }
+BE_HD quat qnormalized(quat q) { double n = sqrt(q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z); return mkq(q.w / n, q.x / n, q.y / n, q.z / n); }
+BE_HD d3 qvec(quat q) { return mk3(q.x, q.y, q.z); }
+BE_HD d3 qrot(quat q, d3 v) { d3 u = qvec(q); d3 uv = cross(u, v); uv = uv + uv; return v + uv * q.w + cross(u, uv); }
+BE_HD m33 qR(quat q) {
+    m33 r;
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    r.m[0] = 1 - (tyy + tzz); r.m[1] = txy - twz; r.m[2] = txz + twy;
+    r.m[3] = txy + twz; r.m[4] = 1 - (txx + tzz); r.m[5] = tyz - twx;
+    r.m[6] = txz - twy; r.m[7] = tyz + twx; r.m[8] = 1 - (txx + tyy);
+    return r;
+}
+BE_HD quat qfromR(const m33& m) {
+    quat q; double t = m.m[0] + m.m[4] + m.m[8];
+    if (t > 0) { t = sqrt(t + 1.0); q.w = 0.5 * t; t = 0.5 / t; q.x = (m.m[7] - m.m[5]) * t; q.y = (m.m[2] - m.m[6]) * t; q.z = (m.m[3] - m.m[1]) * t; }
+    else {
+        int i = 0; if (m.m[4] > m.m[0]) i = 1; if (m.m[8] > m.m[i * 4]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = sqrt(m.m[i * 4] - m.m[j * 4] - m.m[k * 4] + 1.0);
+        double v[3]; v[i] = 0.5 * t; t = 0.5 / t;
+        q.w = (m.m[k * 3 + j] - m.m[j * 3 + k]) * t; v[j] = (m.m[j * 3 + i] + m.m[i * 3 + j]) * t; v[k] = (m.m[k * 3 + i] + m.m[i * 3 + k]) * t;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+BE_HD quat dq_half(d3 theta) { return mkq(1.0, theta.x / 2.0, theta.y / 2.0, theta.z / 2.0); }      // Utility::deltaQ (un-normalised)
+BE_HD d3 P3(const double* p) { return mk3(p[0], p[1], p[2]); }
+BE_HD quat Q4(const double* p) { return mkq(p[6], p[3], p[4], p[5]); }        // pose block [p, qx qy qz qw]
+
+// x (+) delta for a pose block: p += dp (plane constraint drops z or y), q = normalise(q * [1, dth/2])
+BE_HD void pose_plus(const double* x, const double* d, int plane_kind, double* out) {
+    double dx = d[0], dy = d[1], dz = d[2];
+    if (plane_kind == 1) dz = 0;          // PoseConstraintLocalParameterization with IMU
+    if (plane_kind == 2) dy = 0;          // ... vision only
+    out[0] = x[0] + dx; out[1] = x[1] + dy; out[2] = x[2] + dz;
+    quat r = qnormalized(qmul(mkq(x[6], x[3], x[4], x[5]), dq_half(mk3(d[3], d[4], d[5]))));
+    out[3] = r.x; out[4] = r.y; out[5] = r.z; out[6] = r.w;
+}
+
+// ceres::HuberLoss(1.0): rho0 (cost*2) and the residual/Jacobian scale sqrt(rho'); rho'' <= 0 so the corrector's
+// alpha term vanishes (marginalization_factor.cpp:54-78)
+BE_HD void huber1(double s, double& rho0, double& scale) {
+    if (s > 1.0) { const double r = sqrt(s); rho0 = 2 * r - 1; scale = sqrt(1.0 / r); }
+    else { rho0 = s; scale = 1.0; }
+}
+
+}  // namespace be

@@ -1,0 +1,109 @@
+// dv_ctx.h — private context definition shared by the front-end and back-end ABI implementations.
+#pragma once
+#include "dv_internal.h"
+#include "be_types.h"
+#include <cmath>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+struct DevBuf {
+    void* p = nullptr; size_t bytes = 0;
+    hipError_t ensure(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+struct PyrSet {
+    DvPyr pyr{}; DevBuf buf; int w = 0, h = 0, ml = -1;
+    hipError_t alloc(int w_, int h_, int max_level) {
+        if (w == w_ && h == h_ && ml == max_level && pyr.levels > 0) return hipSuccess;
+        w = w_; h = h_; ml = max_level;
+        int lw[DV_MAX_LEVELS], lh[DV_MAX_LEVELS], n = 0;
+        int cw = w, ch = h;
+        for (int l = 0; l <= max_level && l < DV_MAX_LEVELS; ++l) {
+            lw[n] = cw; lh[n] = ch; ++n;
+            int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+            if (nw <= DV_LK_WIN || nh <= DV_LK_WIN) break;      // buildOpticalFlowPyramid stop rule
+            cw = nw; ch = nh;
+        }
+        size_t total = 0, off[DV_MAX_LEVELS];
+        for (int l = 0; l < n; ++l) { off[l] = total; total += (size_t)align_up(lw[l], 16) * lh[l]; total = (total + 255) / 256 * 256; }
+        total += 512;                                             // slack for aligned over-reads
+        hipError_t e = buf.ensure(total);
+        if (e != hipSuccess) return e;
+        for (int l = 0; l < n; ++l) pyr.L[l] = DvLevel{ (uint8_t*)buf.p + off[l], lw[l], lh[l], align_up(lw[l], 16) };
+        for (int l = n; l < DV_MAX_LEVELS; ++l) pyr.L[l] = DvLevel{ nullptr, 0, 0, 0 };
+        pyr.levels = n;
+        return hipSuccess;
+    }
+};
+
+struct StageTimer {
+    std::string name; hipEvent_t a = nullptr, b = nullptr; bool armed = false; double total_ms = 0; long long count = 0;
+};
+
+// device-side workspace of the bundle-adjustment solver (allocated on first use)
+struct BeWork {
+    bool ready = false;
+    DevBuf block;          // one allocation, carved below
+    BeCtl* ctl = nullptr; BeState* x = nullptr; BeState* cand = nullptr;
+    BeFactor* fac = nullptr; BeLm* lm = nullptr; BeImu* imu = nullptr; BePriorHdr* prior = nullptr; double* priorA = nullptr; double* priorb = nullptr;
+    double* packets = nullptr; double* imu_out = nullptr; double* prior_out = nullptr; double* cand_cost = nullptr;
+    double* Hd = nullptr; double* Sc = nullptr; double* gvec = nullptr;
+    double* scale_p = nullptr; double* diag_p = nullptr; double* grad_p = nullptr; double* gn_p = nullptr;
+    double* scale_l = nullptr; double* diag_l = nullptr; double* grad_l = nullptr; double* gn_l = nullptr;
+    int32_t* prior_col = nullptr; int32_t* col_kind = nullptr; int32_t* col_frame = nullptr; int32_t* col_comp = nullptr;
+    int fac_cap = 0;
+    void* pinned = nullptr; size_t pinned_bytes = 0;      // host staging (state + ctl)
+};
+
+struct dv_ctx {
+    dv_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    PyrSet left[2], right; int cur = 0; bool have_prev = false; double prev_time = 0.0;
+    DevBuf state_block; DvTrackState tr{};
+    DevBuf cand_buf; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
+    DevBuf hw_buf; int hw_radius = -1;
+    DevBuf mask_buf;
+    DevBuf out_buf; dv_feat* out_dev = nullptr; int* nout_dev = nullptr;
+    dv_feat* out_pinned = nullptr; int* nout_pinned = nullptr; int* err_pinned = nullptr;
+    hipEvent_t done = nullptr; bool pending = false;
+    // operator-level scratch
+    PyrSet opA, opB; DevBuf s0, s1, s2, s3, s4;
+    bool timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
+    // back end
+    hipStream_t be_stream = nullptr; BeWork be;
+};
+
+void dv_set_error(dv_ctx* ctx, const std::string& msg);
+
+#define DV_CHECK(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            dv_set_error(ctx, std::string(#expr) + ": " + hipGetErrorString(_e));        \
+            return -1;                                                                   \
+        }                                                                                \
+    } while (0)
+#define DV_FAIL(msg) do { dv_set_error(ctx, msg); return -1; } while (0)
+
+StageTimer* dv_timer_for(dv_ctx* ctx, const char* name);
+struct StageScope {
+    dv_ctx* c; StageTimer* t = nullptr; hipStream_t s;
+    StageScope(dv_ctx* ctx, const char* name, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream) { if (c->timing) { t = dv_timer_for(c, name); (void)hipEventRecord(t->a, s); } }
+    ~StageScope() { if (t) { (void)hipEventRecord(t->b, s); t->armed = true; } }
+};
+void dv_harvest_timers(dv_ctx* ctx);

@@ -7,92 +7,16 @@
 //   * Shi-Tomasi candidate records + the pinned host staging buffer for the frame's output.
 // One frame = pyrDown x3 (stereo pair per launch) -> LK temporal -> compact/sort -> Shi-Tomasi tile
 // -> select/append -> LK stereo -> finalize -> one D2H copy of <= max_cnt 128-byte rows.
-#include "dv_internal.h"
-#include <cmath>
-#include <cstring>
-#include <deque>
-#include <map>
-#include <mutex>
+#include "dv_ctx.h"
 
 static std::string g_last_error;
 static std::mutex g_err_mutex;
-
-struct DevBuf {
-    void* p = nullptr; size_t bytes = 0;
-    hipError_t ensure(size_t n) {
-        if (n <= bytes) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; bytes = 0;
-        hipError_t e = hipMalloc(&p, n);
-        if (e == hipSuccess) bytes = n;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
-};
-
-static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
-
-struct PyrSet {
-    DvPyr pyr{}; DevBuf buf; int w = 0, h = 0, ml = -1;
-    hipError_t alloc(int w_, int h_, int max_level) {
-        if (w == w_ && h == h_ && ml == max_level && pyr.levels > 0) return hipSuccess;
-        w = w_; h = h_; ml = max_level;
-        int lw[DV_MAX_LEVELS], lh[DV_MAX_LEVELS], n = 0;
-        int cw = w, ch = h;
-        for (int l = 0; l <= max_level && l < DV_MAX_LEVELS; ++l) {
-            lw[n] = cw; lh[n] = ch; ++n;
-            int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
-            if (nw <= DV_LK_WIN || nh <= DV_LK_WIN) break;      // buildOpticalFlowPyramid stop rule
-            cw = nw; ch = nh;
-        }
-        size_t total = 0, off[DV_MAX_LEVELS];
-        for (int l = 0; l < n; ++l) { off[l] = total; total += (size_t)align_up(lw[l], 16) * lh[l]; total = (total + 255) / 256 * 256; }
-        total += 512;                                             // slack for aligned over-reads
-        hipError_t e = buf.ensure(total);
-        if (e != hipSuccess) return e;
-        for (int l = 0; l < n; ++l) pyr.L[l] = DvLevel{ (uint8_t*)buf.p + off[l], lw[l], lh[l], align_up(lw[l], 16) };
-        for (int l = n; l < DV_MAX_LEVELS; ++l) pyr.L[l] = DvLevel{ nullptr, 0, 0, 0 };
-        pyr.levels = n;
-        return hipSuccess;
-    }
-};
-
-struct StageTimer {
-    std::string name; hipEvent_t a = nullptr, b = nullptr; bool armed = false; double total_ms = 0; long long count = 0;
-};
-
-struct dv_ctx {
-    dv_config cfg{};
-    std::string err;
-    hipStream_t stream = nullptr;
-    PyrSet left[2], right; int cur = 0; bool have_prev = false; double prev_time = 0.0;
-    DevBuf state_block; DvTrackState tr{};
-    DevBuf cand_buf; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
-    DevBuf hw_buf; int hw_radius = -1;
-    DevBuf mask_buf;
-    DevBuf out_buf; dv_feat* out_dev = nullptr; int* nout_dev = nullptr;
-    dv_feat* out_pinned = nullptr; int* nout_pinned = nullptr; int* err_pinned = nullptr;
-    hipEvent_t done = nullptr; bool pending = false;
-    // operator-level scratch
-    PyrSet opA, opB; DevBuf s0, s1, s2, s3, s4;
-    bool timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
-};
 
 void dv_set_error(dv_ctx* ctx, const std::string& msg) {
     if (ctx) ctx->err = msg;
     std::lock_guard<std::mutex> lk(g_err_mutex);
     g_last_error = msg;
 }
-
-#define DV_CHECK(expr)                                                                   \
-    do {                                                                                 \
-        hipError_t _e = (expr);                                                          \
-        if (_e != hipSuccess) {                                                          \
-            dv_set_error(ctx, std::string(#expr) + ": " + hipGetErrorString(_e));        \
-            return -1;                                                                   \
-        }                                                                                \
-    } while (0)
-#define DV_FAIL(msg) do { dv_set_error(ctx, msg); return -1; } while (0)
 
 // disc half-widths of cv::circle's midpoint rasteriser (drawing.cpp Circle(), fill = true)
 static void circle_half_widths(int radius, std::vector<uint8_t>& hw) {
@@ -126,7 +50,7 @@ static int ensure_cand(dv_ctx* ctx, int w, int h) {
     return 0;
 }
 
-static StageTimer* timer_for(dv_ctx* ctx, const char* name) {
+StageTimer* dv_timer_for(dv_ctx* ctx, const char* name) {
     for (auto& t : ctx->timers) if (t.name == name) return &t;
     ctx->timers.emplace_back();
     StageTimer& t = ctx->timers.back();
@@ -134,12 +58,7 @@ static StageTimer* timer_for(dv_ctx* ctx, const char* name) {
     (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
     return &t;
 }
-struct StageScope {
-    dv_ctx* c; StageTimer* t = nullptr;
-    StageScope(dv_ctx* ctx, const char* name) : c(ctx) { if (c->timing) { t = timer_for(c, name); (void)hipEventRecord(t->a, c->stream); } }
-    ~StageScope() { if (t) { (void)hipEventRecord(t->b, c->stream); t->armed = true; } }
-};
-static void harvest_timers(dv_ctx* ctx) {
+void dv_harvest_timers(dv_ctx* ctx) {
     for (auto& t : ctx->timers) if (t.armed) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { t.total_ms += ms; t.count++; }
@@ -197,6 +116,7 @@ dv_ctx* dv_create(const dv_config* cfg) {
     hipError_t e;
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->be_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     // tracker state: one block, struct of arrays
     const size_t N = DV_MAX_FEATS;
@@ -229,6 +149,9 @@ void dv_destroy(dv_ctx* ctx) {
     for (auto& t : ctx->timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
     for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,
                        &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->opA.buf, &ctx->opB.buf }) b->release();
+    ctx->be.block.release();
+    if (ctx->be.pinned) (void)hipHostFree(ctx->be.pinned);
+    if (ctx->be_stream) (void)hipStreamDestroy(ctx->be_stream);
     if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
     if (ctx->done) (void)hipEventDestroy(ctx->done);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -346,7 +269,7 @@ int dv_track_stereo_collect(dv_ctx* ctx, dv_feat* out, int* n_out) {
     if (!ctx->pending) DV_FAIL("dv_track_stereo_collect: nothing enqueued");
     DV_CHECK(hipEventSynchronize(ctx->done));
     ctx->pending = false;
-    if (ctx->timing) harvest_timers(ctx);
+    if (ctx->timing) dv_harvest_timers(ctx);
     if (*ctx->err_pinned) {
         int f = *ctx->err_pinned;
         DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, ctx->stream));

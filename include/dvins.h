@@ -105,6 +105,71 @@ int dv_erode(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, int k, u
 /* InstFeat::UndistortedPts -> PinholeCamera::liftProjective (instance_feature.cpp:94-103) */
 int dv_lift_projective(dv_ctx* ctx, const dv_cam* cam, const float* pts_xy, int n, float* out_xy, int mem);
 
+/* ======================= back end: sliding-window bundle adjustment ======================= */
+
+/* One reprojection residual block = the constructor arguments of ProjectionTwoFrameOneCamFactor (kind 0),
+ * ProjectionTwoFrameTwoCamFactor (kind 1) or ProjectionOneFrameTwoCamFactor (kind 2)
+ * (estimator/factor/projection_*_factor.h; built at estimator/estimator.cpp:134-178).  112 bytes. */
+typedef struct dv_ba_factor {
+    double pix, piy, pjx, pjy;      /* pts_i, pts_j on the normalised plane */
+    double vix, viy, vjx, vjy;      /* velocity_i, velocity_j */
+    double td_i, td_j;
+    int32_t kind, lm, fi, fj;       /* landmark index, anchor frame (start_frame), observing frame */
+    double pad_[2];
+} dv_ba_factor;
+
+/* per landmark (>= 4 observations, estimator.cpp:134-136): its factors are contiguous */
+typedef struct dv_ba_lm { int32_t first, count, anchor, mask; } dv_ba_lm;
+
+/* IMUFactor between frames fi and fj = fi+1: the IntegrationBase results (imu/integration_base.h) */
+typedef struct dv_ba_imu {
+    double sum_dt, dp[3], dq[4] /* w x y z */, dv[3], lin_ba[3], lin_bg[3];
+    double jacobian[225], covariance[225];     /* 15x15 row-major, order P R V BA BG */
+    int32_t fi, fj, pad0, pad1;
+} dv_ba_imu;
+
+/* marginalization prior in information form: cost(dx) = c0/2 + b.dx + dx.A dx/2, dx w.r.t. the linearisation
+ * point x0 of the kept blocks (equivalent to MarginalizationFactor's r0 + J0 dx with A = J0^T J0, b = J0^T r0,
+ * c0 = r0^T r0; factor/marginalization_factor.cpp:283-309,350-396) */
+typedef struct dv_ba_prior_block { int32_t type /* 0 pose, 1 speed-bias, 2 ex_pose, 3 td */, idx, off, size_local; } dv_ba_prior_block;
+typedef struct dv_ba_prior {
+    int32_t valid, n, nblocks, pad;
+    double c0;
+    dv_ba_prior_block blocks[16];
+    double x0[16][9];
+} dv_ba_prior;
+
+typedef struct dv_ba_problem {
+    int32_t nframes, nlm, nfac, nimu;     /* frames in the window (frame+1), landmarks, residual blocks, IMU factors */
+    int32_t use_imu, plane_kind /* 0 none, 1 PoseConstraint with IMU (dz=0), 2 vision-only (dy=0) */, max_iters, reserved;
+    double g_norm;
+    double* pose;        /* [nframes][7] x y z qx qy qz qw   (para_pose, in/out) */
+    double* speed_bias;  /* [nframes][9]                      (para_speed_bias, in/out; ignored if !use_imu) */
+    double* ex_pose;     /* [2][7]                            (para_ex_pose, constant: estimate_extrinsic 0) */
+    double* td;          /* [1]                               (para_td, constant: estimate_td 0) */
+    double* inv_depth;   /* [nlm]                             (para_point_features, in/out) */
+    const dv_ba_factor* factors; const dv_ba_lm* landmarks; const dv_ba_imu* imu;
+    const dv_ba_prior* prior; const double* prior_A; const double* prior_b;     /* prior may be NULL */
+} dv_ba_problem;
+
+typedef struct dv_ba_summary {
+    int32_t iterations, successful, termination /* 0 max iterations, 1 converged, 2 failure */, slots;
+    double initial_cost, final_cost;
+} dv_ba_summary;
+
+/* Replaces ceres::Solve in Estimator::Optimization (estimator/estimator.cpp:261-326): DENSE_SCHUR + DOGLEG,
+ * HuberLoss(1.0) on reprojection blocks, max_num_iterations = max_iters, wall-clock budget disabled.
+ * The whole trust-region loop runs on the device; states are updated in place. */
+int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* problem, dv_ba_summary* summary);
+
+/* operator-level factor evaluation (Evaluate() of the three projection factors / IMUFactor) for parity tests.
+ * out: n x 54 doubles = r[2] J_pose_i[2x6] J_pose_j[2x6] J_ex0[2x6] J_ex1[2x6] J_lambda[2] J_td[2] (tangent space) */
+int dv_proj_eval(dv_ctx* ctx, const dv_ba_factor* factors, int n, const double* pose_i, const double* pose_j,
+                 const double* ex0, const double* ex1, const double* inv_depth, const double* td, double* out);
+/* out: 15 whitened residuals followed by the whitened 15 x 30 Jacobian (pose_i 6, sb_i 9, pose_j 6, sb_j 9) */
+int dv_imu_eval(dv_ctx* ctx, const dv_ba_imu* imu, double g_norm, const double* pose_i, const double* sb_i,
+                const double* pose_j, const double* sb_j, double* out);
+
 /* ---- measurement hooks (used by bench.py; HIP-event timing on the ctx's own stream) ---- */
 /* names: "pyr","lk_temporal","compact","gftt_eig","gftt_select","lk_stereo","frame" */
 int dv_timing_enable(dv_ctx* ctx, int on);

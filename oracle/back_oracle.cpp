@@ -17,6 +17,8 @@
 //       reprojection error, not by bit parity (App. A.5).
 //   Scope: stereo (+IMU or vision-only) initialisation, i.e. every BASELINE config; monocular SFM
 //   initialisation (initial_sfm / solve_5pts) is not restated.
+#include <cstdio>
+#include <cstdlib>
 #include <deque>
 #include <list>
 #include <map>
@@ -162,6 +164,7 @@ struct Marginalizer {         // MarginalizationInfo::{addResidualBlockInfo,preM
         std::vector<double> ev; Mat V;
         sym_eig(Amm, ev, V);
         const double eps = 1e-8;
+        if (getenv("DVO_DEBUG_MARG")) fprintf(stderr, "marg m=%d n=%d Amm ev min=%.3e max=%.3e\n", m, n, ev.front(), ev.back());
         Mat Amm_inv(m, m);
         for (int k = 0; k < m; ++k) { if (!(ev[k] > eps)) continue; const double inv = 1.0 / ev[k]; for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm_inv(i, j) += V(i, k) * inv * V(j, k); }
         // A' = Arr - Arm Amm^-1 Amr ; b' = brr - Arm Amm^-1 bmm
@@ -177,6 +180,7 @@ struct Marginalizer {         // MarginalizationInfo::{addResidualBlockInfo,preM
         for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { double s = 0.5 * (Ap(i, j) + Ap(j, i)); Ap(i, j) = Ap(j, i) = s; }   // SelfAdjointEigenSolver reads one triangle
         std::vector<double> ev2; Mat V2;
         sym_eig(Ap, ev2, V2);
+        if (getenv("DVO_DEBUG_MARG")) { int nz = 0; for (double e : ev2) if (!(e > eps)) nz++; fprintf(stderr, "   A' ev[0..5]= %.3e %.3e %.3e %.3e %.3e %.3e max=%.3e clamped=%d\n", ev2[0], ev2[1], ev2[2], ev2[3], ev2[4], ev2[5], ev2.back(), nz); }
         out->J0 = Mat(n, n); out->r0.assign(n, 0.0);
         for (int k = 0; k < n; ++k) {
             const double S = ev2[k] > eps ? ev2[k] : 0.0, Sinv = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
@@ -725,8 +729,84 @@ void dvo_preint_get(const dvo_preint* p, double* sum_dt, double* dp, double* dq_
     dq_xyzw[0] = I.delta_q.x; dq_xyzw[1] = I.delta_q.y; dq_xyzw[2] = I.delta_q.z; dq_xyzw[3] = I.delta_q.w;
     std::memcpy(jac225, I.jacobian.d.data(), 225 * sizeof(double)); std::memcpy(cov225, I.covariance.d.data(), 225 * sizeof(double));
 }
+void dvo_preint_set(dvo_preint* p, double sum_dt, const double* dp, const double* dq_xyzw, const double* dv, const double* jac225, const double* cov225) {
+    Integration& I = *reinterpret_cast<Integration*>(p);
+    I.sum_dt = sum_dt; I.delta_p = P3(dp); I.delta_v = P3(dv); I.delta_q = Q(dq_xyzw[3], dq_xyzw[0], dq_xyzw[1], dq_xyzw[2]);
+    std::memcpy(I.jacobian.d.data(), jac225, 225 * sizeof(double)); std::memcpy(I.covariance.d.data(), cov225, 225 * sizeof(double));
+}
 void dvo_imu_eval(const dvo_preint* p, double g_norm, const double* const* par, double* res15, double** J) {
     imu_eval(*reinterpret_cast<const Integration*>(p), V3(0, 0, g_norm), par, res15, J);
+}
+
+// standalone window problem (same flat description the product's dv_ba_solve takes) -> Problem -> Solver
+int dvo_ba_solve(dvo_ba_problem* P, dvo_ba_summary* S) {
+    Problem prob;
+    const int pose_kind = P->plane_kind == 1 ? kPosePlaneImu : (P->plane_kind == 2 ? kPosePlaneVo : kPose);
+    for (int i = 0; i < P->nframes; ++i) {
+        prob.AddParameterBlock(P->pose + 7 * i, 7, pose_kind);
+        if (P->use_imu) prob.AddParameterBlock(P->speed_bias + 9 * i, 9);
+    }
+    if (!P->use_imu) prob.SetConstant(P->pose);
+    for (int i = 0; i < 2; ++i) { prob.AddParameterBlock(P->ex_pose + 7 * i, 7, kPose); prob.SetConstant(P->ex_pose + 7 * i); }
+    prob.AddParameterBlock(P->td, 1); prob.SetConstant(P->td);
+    MargInfo mi;
+    if (P->prior && P->prior->valid) {
+        const int n = P->prior->n;
+        Mat A(n, n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A(i, j) = 0.5 * (P->prior_A[i * n + j] + P->prior_A[j * n + i]);
+        std::vector<double> ev; Mat V; sym_eig(A, ev, V);
+        mi.m = 0; mi.n = n; mi.J0 = Mat(n, n); mi.r0.assign(n, 0.0);
+        for (int k = 0; k < n; ++k) {
+            const double Sv = ev[k] > 1e-8 ? ev[k] : 0.0, Si = ev[k] > 1e-8 ? 1.0 / ev[k] : 0.0;
+            double vb = 0; for (int i = 0; i < n; ++i) { mi.J0(k, i) = std::sqrt(Sv) * V(i, k); vb += V(i, k) * P->prior_b[i]; }
+            mi.r0[k] = std::sqrt(Si) * vb;
+        }
+        for (int b = 0; b < P->prior->nblocks; ++b) {
+            const dvo_ba_prior_block& pb = P->prior->blocks[b];
+            const int gs = pb.type == 0 || pb.type == 2 ? 7 : (pb.type == 1 ? 9 : 1);
+            mi.keep_size.push_back(gs); mi.keep_idx.push_back(pb.off);
+            mi.keep_data.push_back(std::vector<double>(P->prior->x0[b], P->prior->x0[b] + gs));
+            double* addr = pb.type == 0 ? P->pose + 7 * pb.idx : pb.type == 1 ? P->speed_bias + 9 * pb.idx : pb.type == 2 ? P->ex_pose + 7 * pb.idx : P->td;
+            mi.keep_addr.push_back(addr);
+        }
+        prob.AddResidualBlock(std::make_shared<MargCost>(&mi), kNoLoss, mi.keep_addr);
+    }
+    std::vector<std::unique_ptr<Integration>> pres;
+    const V3 G(0, 0, P->g_norm);
+    for (int k = 0; k < P->nimu; ++k) {
+        const dvo_ba_imu& m = P->imu[k];
+        auto I = std::make_unique<Integration>(V3(), V3(), P3(m.lin_ba), P3(m.lin_bg), ImuNoise{ 0, 0, 0, 0 });
+        I->sum_dt = m.sum_dt; I->delta_p = P3(m.dp); I->delta_v = P3(m.dv); I->delta_q = Q(m.dq[0], m.dq[1], m.dq[2], m.dq[3]);
+        std::memcpy(I->jacobian.d.data(), m.jacobian, 225 * 8); std::memcpy(I->covariance.d.data(), m.covariance, 225 * 8);
+        prob.AddResidualBlock(std::make_shared<ImuCost>(I.get(), G), kNoLoss, { P->pose + 7 * m.fi, P->speed_bias + 9 * m.fi, P->pose + 7 * m.fj, P->speed_bias + 9 * m.fj });
+        pres.push_back(std::move(I));
+    }
+    for (int l = 0; l < P->nlm; ++l) {
+        prob.AddParameterBlock(P->inv_depth + l, 1, kPlain, true);
+        const dvo_ba_lm& L = P->landmarks[l];
+        for (int k = 0; k < L.count; ++k) {
+            const dvo_ba_factor& f = P->factors[L.first + k];
+            ProjObs o; o.pts_i = V3(f.pix, f.piy, 1); o.pts_j = V3(f.pjx, f.pjy, 1); o.vel_i = V3(f.vix, f.viy, 0); o.vel_j = V3(f.vjx, f.vjy, 0); o.td_i = f.td_i; o.td_j = f.td_j;
+            if (f.kind == 0) prob.AddResidualBlock(std::make_shared<ProjCost>(0, o), kHuber1, { P->pose + 7 * f.fi, P->pose + 7 * f.fj, P->ex_pose, P->inv_depth + l, P->td });
+            else if (f.kind == 1) prob.AddResidualBlock(std::make_shared<ProjCost>(1, o), kHuber1, { P->pose + 7 * f.fi, P->pose + 7 * f.fj, P->ex_pose, P->ex_pose + 7, P->inv_depth + l, P->td });
+            else prob.AddResidualBlock(std::make_shared<ProjCost>(2, o), kHuber1, { P->ex_pose, P->ex_pose + 7, P->inv_depth + l, P->td });
+        }
+    }
+    Solver solver(prob);
+    SolveOptions so; so.max_num_iterations = P->max_iters;
+    SolveSummary sum = solver.solve(so);
+    if (S) { S->iterations = sum.iterations; S->successful = sum.successful; S->termination = sum.termination; S->slots = 0; S->initial_cost = sum.initial_cost; S->final_cost = sum.final_cost; }
+    return 0;
+}
+
+// c0 = r0^T r0 of the eigen-clamped prior built from (A, b): sum_{lambda_k > 1e-8} (v_k . b)^2 / lambda_k
+double dvo_prior_c0(const double* A_, const double* b, int n) {
+    Mat A(n, n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A(i, j) = 0.5 * (A_[i * n + j] + A_[j * n + i]);
+    std::vector<double> ev; Mat V; sym_eig(A, ev, V);
+    double c0 = 0;
+    for (int k = 0; k < n; ++k) if (ev[k] > 1e-8) { double vb = 0; for (int i = 0; i < n; ++i) vb += V(i, k) * b[i]; c0 += vb * vb / ev[k]; }
+    return c0;
 }
 
 dvo_estimator* dvo_estimator_create(const dvo_be_config* c) {

@@ -107,8 +107,29 @@ void dvo_preint_destroy(dvo_preint*);
 void dvo_preint_push(dvo_preint*, double dt, const double* acc, const double* gyr);
 void dvo_preint_repropagate(dvo_preint*, const double* ba, const double* bg);
 void dvo_preint_get(const dvo_preint*, double* sum_dt, double* dp, double* dq_xyzw, double* dv, double* jac225, double* cov225);
+/* overwrite the integration results (tests: evaluate an IMUFactor for given deltas / Jacobian / covariance) */
+void dvo_preint_set(dvo_preint*, double sum_dt, const double* dp, const double* dq_xyzw, const double* dv, const double* jac225, const double* cov225);
 /* IMUFactor::Evaluate; par = pose_i(7) sb_i(9) pose_j(7) sb_j(9); J = 15x7,15x9,15x7,15x9 row-major */
 void dvo_imu_eval(const dvo_preint*, double g_norm, const double* const* par, double* res15, double** J);
+
+/* flat window problem, identical layout to include/dvins.h dv_ba_* (restated here: the oracle shares no headers
+ * with the product) */
+typedef struct dvo_ba_factor { double pix, piy, pjx, pjy, vix, viy, vjx, vjy, td_i, td_j; int32_t kind, lm, fi, fj; double pad_[2]; } dvo_ba_factor;
+typedef struct dvo_ba_lm { int32_t first, count, anchor, mask; } dvo_ba_lm;
+typedef struct dvo_ba_imu { double sum_dt, dp[3], dq[4], dv[3], lin_ba[3], lin_bg[3]; double jacobian[225], covariance[225]; int32_t fi, fj, pad0, pad1; } dvo_ba_imu;
+typedef struct dvo_ba_prior_block { int32_t type, idx, off, size_local; } dvo_ba_prior_block;
+typedef struct dvo_ba_prior { int32_t valid, n, nblocks, pad; double c0; dvo_ba_prior_block blocks[16]; double x0[16][9]; } dvo_ba_prior;
+typedef struct dvo_ba_problem {
+    int32_t nframes, nlm, nfac, nimu, use_imu, plane_kind, max_iters, reserved;
+    double g_norm;
+    double *pose, *speed_bias, *ex_pose, *td, *inv_depth;
+    const dvo_ba_factor* factors; const dvo_ba_lm* landmarks; const dvo_ba_imu* imu;
+    const dvo_ba_prior* prior; const double* prior_A; const double* prior_b;
+} dvo_ba_problem;
+typedef struct dvo_ba_summary { int32_t iterations, successful, termination, slots; double initial_cost, final_cost; } dvo_ba_summary;
+/* ceres::Solve restatement on a standalone window (Estimator::Optimization's problem, estimator.cpp:261-326) */
+int dvo_ba_solve(dvo_ba_problem* problem, dvo_ba_summary* summary);
+double dvo_prior_c0(const double* A, const double* b, int n);
 
 typedef struct dvo_be_config {       /* para (estimator/vio_parameters.cpp:19-83) + cfg flags + extrinsics */
     int use_imu, stereo, plane_constraint, max_iters;

@@ -1,0 +1,140 @@
+"""GPU parity tests for the back end: HIP factor evaluation and the on-device trust-region solve (through the
+C ABI) vs the CPU oracle on the same seeded window problems.
+Tolerances (fp64 on both sides, different summation order): factor residual/Jacobian entries 1e-9 relative,
+solved states 1e-6 absolute (m / rad / inverse depth), costs 1e-7 relative; iteration counts must agree."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import ba_gen
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu_ctx_factory):
+    return gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5)
+
+
+def _rand_pose(rng):
+    q = rng.normal(0, 1, 4)
+    q /= np.linalg.norm(q)
+    return np.concatenate([rng.normal(0, 2, 3), q])
+
+
+def test_projection_factors_match_oracle(ctx, oracle):
+    from dynamic_vins_amd.backend import FACTOR_DTYPE, proj_eval
+    rng = np.random.default_rng(0)
+    n = 96
+    fac = np.zeros(n, FACTOR_DTYPE)
+    pose_i = np.array([_rand_pose(rng) for _ in range(n)])
+    pose_j = pose_i.copy()
+    pose_j[:, :3] += rng.normal(0, 0.3, (n, 3))
+    ex0 = np.array([np.concatenate([rng.normal(0, 0.05, 3), [0.5, -0.5, 0.5, -0.5] + rng.normal(0, 0.01, 4)]) for _ in range(n)])
+    ex0[:, 3:] /= np.linalg.norm(ex0[:, 3:], axis=1, keepdims=True)
+    ex1 = ex0.copy()
+    ex1[:, :3] += [0, -0.12, 0]
+    lam = rng.uniform(0.05, 0.8, n)
+    td = rng.normal(0, 0.01, n)
+    for k in range(n):
+        f = fac[k]
+        f["pix"], f["piy"], f["pjx"], f["pjy"] = rng.uniform(-0.5, 0.5, 4)
+        f["vix"], f["viy"], f["vjx"], f["vjy"] = rng.normal(0, 0.2, 4)
+        f["td_i"], f["td_j"] = rng.normal(0, 0.01, 2)
+        f["kind"] = k % 3
+    got = proj_eval(ctx, fac, pose_i, pose_j, ex0, ex1, lam, td)
+    lib = oracle.lib
+    lib.dvo_proj_eval.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    for k in range(n):
+        f = fac[k]
+        kind = int(f["kind"])
+        obs = np.array([f["pix"], f["piy"], 1.0, f["pjx"], f["pjy"], 1.0, f["vix"], f["viy"], f["vjx"], f["vjy"], f["td_i"], f["td_j"]])
+        lk, tk = np.array([lam[k]]), np.array([td[k]])
+        blocks = {0: [pose_i[k], pose_j[k], ex0[k], lk, tk], 1: [pose_i[k], pose_j[k], ex0[k], ex1[k], lk, tk], 2: [ex0[k], ex1[k], lk, tk]}[kind]
+        blocks = [np.ascontiguousarray(b) for b in blocks]
+        J = [np.zeros(2 * len(b)) for b in blocks]
+        par = (C.c_void_p * len(blocks))(*[b.ctypes.data for b in blocks])
+        Jp = (C.c_void_p * len(blocks))(*[j.ctypes.data for j in J])
+        r = np.zeros(2)
+        lib.dvo_proj_eval(kind, obs.ctypes.data, par, r.ctypes.data, Jp)
+        J = [j.reshape(2, -1) for j in J]
+        g = got[k]
+        gr, gJi, gJj, gJe0, gJe1, gJl, gJtd = g[0:2], g[2:14].reshape(2, 6), g[14:26].reshape(2, 6), g[26:38].reshape(2, 6), g[38:50].reshape(2, 6), g[50:52], g[52:54]
+        tol = dict(rtol=1e-9, atol=1e-9)
+        assert np.allclose(gr, r, **tol)
+        if kind == 0:
+            exp = [J[0][:, :6], J[1][:, :6], J[2][:, :6], np.zeros((2, 6)), J[3][:, 0], J[4][:, 0]]
+        elif kind == 1:
+            exp = [J[0][:, :6], J[1][:, :6], J[2][:, :6], J[3][:, :6], J[4][:, 0], J[5][:, 0]]
+        else:
+            exp = [np.zeros((2, 6)), np.zeros((2, 6)), J[0][:, :6], J[1][:, :6], J[2][:, 0], J[3][:, 0]]
+        for a, b in zip([gJi, gJj, gJe0, gJe1, gJl, gJtd], exp):
+            assert np.allclose(a, b, **tol), (kind, a, b)
+
+
+def test_imu_factor_matches_oracle(ctx, oracle):
+    from dynamic_vins_amd.backend import imu_eval
+    prob = ba_gen.make_window(oracle, seed=5, nlm=10)
+    lib = oracle.lib
+    rng = np.random.default_rng(1)
+    for k in (0, 4, 9):
+        rec = prob.imu[k:k + 1].copy()
+        pose_i, pose_j = prob.pose[k].copy(), prob.pose[k + 1].copy()
+        sb_i, sb_j = prob.speed_bias[k].copy(), prob.speed_bias[k + 1].copy()
+        sb_i[3:] += rng.normal(0, 0.01, 6)
+        gr, gJ = imu_eval(ctx, rec, 9.81, pose_i, sb_i, pose_j, sb_j)
+        # oracle: rebuild an Integration through the standalone-solve path is indirect; use dvo_imu_eval on a preint with the same fields
+        lib.dvo_preint_create.restype = C.c_void_p
+        lib.dvo_preint_create.argtypes = [C.c_void_p] * 5
+        z = np.zeros(3)
+        noise = np.zeros(4)
+        h = lib.dvo_preint_create(z.ctypes.data, z.ctypes.data, np.ascontiguousarray(rec["lin_ba"][0]).ctypes.data, np.ascontiguousarray(rec["lin_bg"][0]).ctypes.data, noise.ctypes.data)
+        lib.dvo_preint_set.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        dq = rec["dq"][0]
+        dq_xyzw = np.array([dq[1], dq[2], dq[3], dq[0]])
+        lib.dvo_preint_set(h, float(rec["sum_dt"][0]), np.ascontiguousarray(rec["dp"][0]).ctypes.data, dq_xyzw.ctypes.data, np.ascontiguousarray(rec["dv"][0]).ctypes.data,
+                           np.ascontiguousarray(rec["jacobian"][0]).ctypes.data, np.ascontiguousarray(rec["covariance"][0]).ctypes.data)
+        blocks = [pose_i, sb_i, pose_j, sb_j]
+        J = [np.zeros(15 * len(b)) for b in blocks]
+        par = (C.c_void_p * 4)(*[b.ctypes.data for b in blocks])
+        Jp = (C.c_void_p * 4)(*[j.ctypes.data for j in J])
+        r = np.zeros(15)
+        lib.dvo_imu_eval.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.dvo_imu_eval(h, 9.81, par, r.ctypes.data, Jp)
+        lib.dvo_preint_destroy.argtypes = [C.c_void_p]
+        lib.dvo_preint_destroy(h)
+        oJ = np.hstack([J[0].reshape(15, 7)[:, :6], J[1].reshape(15, 9), J[2].reshape(15, 7)[:, :6], J[3].reshape(15, 9)])
+        scale = max(1.0, np.abs(oJ).max())
+        assert np.allclose(gr, r, rtol=1e-8, atol=1e-8 * max(1.0, np.abs(r).max()))
+        assert np.allclose(gJ, oJ, rtol=1e-8, atol=1e-9 * scale)
+
+
+CASES = [dict(seed=1), dict(seed=2, with_prior=True), dict(seed=3, use_imu=0, nframes=7), dict(seed=4, with_prior=True, outlier_ratio=0.1, max_iters=10),
+         dict(seed=6, nlm=300, max_iters=10, with_prior=True), dict(seed=7, use_imu=0, with_prior=True, plane_kind=2), dict(seed=8, nframes=5, nlm=40),
+         dict(seed=9, nlm=1, max_iters=3)]
+
+
+@pytest.mark.parametrize("kw", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_ba_solve_matches_oracle(ctx, oracle, kw):
+    from dynamic_vins_amd.backend import ba_solve
+    ref = ba_gen.make_window(oracle, **kw)
+    dev = ref.clone()
+    so = ba_gen.oracle_solve(oracle, ref)
+    sd = ba_solve(ctx, dev)
+    assert (sd.iterations, sd.successful, sd.termination) == (so.iterations, so.successful, so.termination)
+    assert np.isclose(sd.initial_cost, so.initial_cost, rtol=1e-9)
+    assert np.isclose(sd.final_cost, so.final_cost, rtol=1e-7)
+    assert so.final_cost < so.initial_cost
+    assert np.allclose(dev.pose, ref.pose, rtol=0, atol=1e-6)
+    assert np.allclose(dev.speed_bias, ref.speed_bias, rtol=0, atol=1e-6)
+    assert np.allclose(dev.inv_depth, ref.inv_depth, rtol=0, atol=1e-6)
+
+
+def test_ba_solve_is_reproducible(ctx, oracle):
+    from dynamic_vins_amd.backend import ba_solve
+    base = ba_gen.make_window(oracle, seed=11, with_prior=True, nlm=200)
+    a, b = base.clone(), base.clone()
+    ba_solve(ctx, a)
+    ba_solve(ctx, b)
+    assert np.array_equal(a.pose, b.pose) and np.array_equal(a.inv_depth, b.inv_depth) and np.array_equal(a.speed_bias, b.speed_bias)

@@ -60,6 +60,7 @@ SIGNATURES = {
     "dv_erode": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "dv_lift_projective": (C.c_int, [_ctx, C.POINTER(dv_cam), _f32p, C.c_int, _f32p, C.c_int]),
     "dv_ba_solve": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
+    "dv_marginalize": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_proj_eval": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_imu_eval": (C.c_int, [_ctx, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_timing_enable": (C.c_int, [_ctx, C.c_int]),

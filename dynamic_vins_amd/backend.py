@@ -66,7 +66,7 @@ class WindowProblem:
             self.prior_A = np.ascontiguousarray(prior_A, np.float64)
             self.prior_b = np.ascontiguousarray(prior_b, np.float64)
         p = dv_ba_problem()
-        p.nframes, p.nlm, p.nfac, p.nimu = len(self.pose), len(self.inv_depth), len(self.factors), len(self.imu)
+        p.nframes, p.nlm, p.nfac, p.nimu = len(self.pose), len(self.landmarks), len(self.factors), len(self.imu)
         p.use_imu, p.plane_kind, p.max_iters, p.g_norm = use_imu, plane_kind, max_iters, g_norm
         self.c = p
         self._bind()
@@ -113,3 +113,15 @@ def imu_eval(ctx, imu_rec, g_norm, pose_i, sb_i, pose_j, sb_j):
     if ctx.lib.dv_imu_eval(ctx.h, rec.ctypes.data, float(g_norm), *[a.ctypes.data for a in arrs], out.ctypes.data) != 0:
         raise DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
     return out[:15], out[15:].reshape(15, 30)
+
+
+def marginalize(ctx, sub: WindowProblem, mode):
+    """dv_marginalize -> (dv_ba_prior, A, b, diag)"""
+    out = dv_ba_prior()
+    A = np.zeros(192 * 192)
+    b = np.zeros(192)
+    diag = np.zeros(4)
+    if ctx.lib.dv_marginalize(ctx.h, C.byref(sub.c), int(mode), C.byref(out), A.ctypes.data, b.ctypes.data, diag.ctypes.data) != 0:
+        raise DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+    n = out.n
+    return out, A[:n * n].reshape(n, n).copy(), b[:n].copy(), diag

@@ -171,6 +171,131 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
     return 0;
 }
 
+int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* out_prior, double* out_A, double* out_b, double* diag4) {
+    if (!ctx) return -1;
+    if (!P || !out_prior || !out_A || !out_b) DV_FAIL("dv_marginalize: null argument");
+    if (mode != 0 && mode != 1) DV_FAIL("dv_marginalize: mode must be 0 (kMarginOld) or 1 (kMarginSecondNew)");
+    if (P->nframes != BE_NF) DV_FAIL("dv_marginalize: needs a full window (frame == kWinSize)");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (be_ensure(ctx, P->nfac)) return -1;
+    BeWork& w = ctx->be;
+    hipStream_t s = ctx->be_stream;
+    const bool has_prior = P->prior && P->prior->valid;
+    std::memset(out_prior, 0, sizeof(*out_prior));
+    // ---- which blocks take part (addResidualBlockInfo): present[type][idx] ----
+    bool pose_in[BE_NF] = { false }, sb_in[BE_NF] = { false }, ex_in[2] = { false, false }, td_in = false;
+    if (has_prior) for (int b = 0; b < P->prior->nblocks; ++b) {
+        const dv_ba_prior_block& pb = P->prior->blocks[b];
+        if (pb.type == 0) pose_in[pb.idx] = true; else if (pb.type == 1) sb_in[pb.idx] = true; else if (pb.type == 2) ex_in[pb.idx] = true; else td_in = true;
+    }
+    const int nimu = (mode == 0) ? P->nimu : 0, nlm = (mode == 0) ? P->nlm : 0, nfac = (mode == 0) ? P->nfac : 0;
+    if (nimu > 1) DV_FAIL("dv_marginalize: at most the IMU factor (0,1)");
+    if (nimu == 1) { pose_in[0] = sb_in[0] = pose_in[1] = sb_in[1] = true; }
+    for (int f = 0; f < nfac; ++f) {
+        const dv_ba_factor& ff = P->factors[f];
+        if (ff.fi != 0) DV_FAIL("dv_marginalize: only landmarks anchored in frame 0 take part (estimator.cpp:446)");
+        ex_in[0] = true; td_in = true;
+        if (ff.kind != 0) ex_in[1] = true;
+        if (ff.kind != 2) { pose_in[0] = true; pose_in[ff.fj] = true; }
+    }
+    // ---- dims: dropped first, then kept in canonical order (poses, speed-bias, ex0, ex1, td) ----
+    std::vector<int32_t> dim_slot, dim_comp;
+    int pose_dim[BE_NF], sb_dim[BE_NF], ex_dim[2] = { -1, -1 }, td_dim = -1;
+    for (int k = 0; k < BE_NF; ++k) { pose_dim[k] = -1; sb_dim[k] = -1; }
+    auto add_pose = [&](int k) { pose_dim[k] = (int)dim_slot.size(); for (int c = 0; c < 6; ++c) { dim_slot.push_back(k); dim_comp.push_back(c); } };
+    auto add_sb = [&](int k) { sb_dim[k] = (int)dim_slot.size(); for (int c = 0; c < 9; ++c) { dim_slot.push_back(-1); dim_comp.push_back(c); } };
+    const int drop_frame = (mode == 0) ? 0 : BE_WIN - 1;
+    if (pose_in[drop_frame]) add_pose(drop_frame);
+    if (mode == 0 && sb_in[0]) add_sb(0);
+    const int m = (int)dim_slot.size();
+    if (m == 0) { out_prior->valid = 0; if (diag4) diag4[0] = diag4[1] = diag4[2] = diag4[3] = 0; return 0; }      // "unstable tracking" (marginalization_factor.cpp:210-215)
+    for (int k = 0; k < BE_NF; ++k) if (pose_in[k] && k != drop_frame) add_pose(k);
+    for (int k = 0; k < BE_NF; ++k) if (sb_in[k] && !(mode == 0 && k == 0)) add_sb(k);
+    for (int c = 0; c < 2; ++c) if (ex_in[c]) { ex_dim[c] = (int)dim_slot.size(); for (int q = 0; q < 6; ++q) { dim_slot.push_back(BE_NF + c); dim_comp.push_back(q); } }
+    if (td_in) { td_dim = (int)dim_slot.size(); dim_slot.push_back(BE_NF + 2); dim_comp.push_back(0); }
+    const int D = (int)dim_slot.size(), n = D - m;
+    if (getenv("DV_DEBUG_MARG")) { fprintf(stderr, "marg D=%d m=%d td_dim=%d ex=%d %d slots:", D, m, td_dim, ex_dim[0], ex_dim[1]); for (int i = 0; i < D; ++i) fprintf(stderr, " %d/%d", dim_slot[i], dim_comp[i]); fprintf(stderr, "\n"); }
+    if (n > BE_MAX_PRIOR || n < 1) DV_FAIL("dv_marginalize: bad kept size");
+    std::vector<int32_t> prior_map(BE_MAX_PRIOR, -1), imu_map(30, -1);
+    BePriorHdr ph{};
+    if (has_prior) {
+        std::memcpy(&ph, P->prior, sizeof(ph));
+        for (int b = 0; b < ph.nblocks; ++b) {
+            const BePriorBlock pb = ph.blocks[b];
+            const int d0 = pb.type == 0 ? pose_dim[pb.idx] : pb.type == 1 ? sb_dim[pb.idx] : pb.type == 2 ? ex_dim[pb.idx] : td_dim;
+            for (int k = 0; k < pb.size_local; ++k) prior_map[pb.off + k] = d0 + k;
+        }
+    }
+    BeImu himu{};
+    if (nimu == 1) {
+        if (be_fill_imu(P->imu[0], himu)) DV_FAIL("dv_marginalize: IMU covariance is singular");
+        for (int k = 0; k < 6; ++k) { imu_map[k] = pose_dim[0] + k; imu_map[15 + k] = pose_dim[1] + k; }
+        for (int k = 0; k < 9; ++k) { imu_map[6 + k] = sb_dim[0] + k; imu_map[21 + k] = sb_dim[1] + k; }
+    }
+    // ---- upload ----
+    BeState* hx = (BeState*)w.pinned;
+    std::memset(hx, 0, offsetof(BeState, inv_depth));
+    for (int f = 0; f < BE_NF; ++f) { std::memcpy(hx->pose[f], P->pose + 7 * f, 56); if (P->use_imu) std::memcpy(hx->sb[f], P->speed_bias + 9 * f, 72); }
+    std::memcpy(hx->ex, P->ex_pose, 14 * 8); hx->td = P->td[0];
+    int max_lm = 0;
+    for (int f = 0; f < nfac; ++f) max_lm = std::max(max_lm, P->factors[f].lm + 1);
+    if (max_lm > BE_MAX_LM) DV_FAIL("dv_marginalize: landmark index out of range");
+    if (max_lm) std::memcpy(hx->inv_depth, P->inv_depth, 8 * (size_t)max_lm);
+    const size_t state_bytes = offsetof(BeState, inv_depth) + 8 * (size_t)max_lm;
+    DV_CHECK(hipMemcpyAsync(w.x, hx, state_bytes, hipMemcpyHostToDevice, s));
+    if (nfac) DV_CHECK(hipMemcpyAsync(w.fac, P->factors, sizeof(BeFactor) * (size_t)nfac, hipMemcpyHostToDevice, s));
+    if (nlm) DV_CHECK(hipMemcpyAsync(w.lm, P->landmarks, sizeof(BeLm) * (size_t)nlm, hipMemcpyHostToDevice, s));
+    if (nimu) DV_CHECK(hipMemcpyAsync(w.imu, &himu, sizeof(BeImu), hipMemcpyHostToDevice, s));
+    DV_CHECK(hipMemcpyAsync(w.prior, &ph, sizeof(ph), hipMemcpyHostToDevice, s));
+    if (has_prior) {
+        DV_CHECK(hipMemcpyAsync(w.priorA, P->prior_A, 8 * (size_t)ph.n * ph.n, hipMemcpyHostToDevice, s));
+        DV_CHECK(hipMemcpyAsync(w.priorb, P->prior_b, 8 * (size_t)ph.n, hipMemcpyHostToDevice, s));
+    }
+    // index tables live in the (otherwise unused here) Hd / gvec workspaces
+    int32_t* d_prior_map = (int32_t*)w.Hd; int32_t* d_imu_map = d_prior_map + BE_MAX_PRIOR; int32_t* d_slot = d_imu_map + 32; int32_t* d_comp = d_slot + 256;
+    DV_CHECK(hipMemcpyAsync(d_prior_map, prior_map.data(), 4 * BE_MAX_PRIOR, hipMemcpyHostToDevice, s));
+    DV_CHECK(hipMemcpyAsync(d_imu_map, imu_map.data(), 4 * 30, hipMemcpyHostToDevice, s));
+    DV_CHECK(hipMemcpyAsync(d_slot, dim_slot.data(), 4 * (size_t)D, hipMemcpyHostToDevice, s));
+    DV_CHECK(hipMemcpyAsync(d_comp, dim_comp.data(), 4 * (size_t)D, hipMemcpyHostToDevice, s));
+    double* d_outA = w.Sc; double* d_outb = w.gvec; double* d_scal = w.gvec + BE_MAX_PRIOR;
+    BeMargArgs ma{};
+    ma.x = w.x; ma.nframes = BE_NF; ma.nlm = nlm; ma.nimu = nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
+    ma.prior = w.prior; ma.priorA = w.priorA; ma.priorb = w.priorb; ma.prior_map = d_prior_map; ma.imu_map = d_imu_map; ma.dim_slot = d_slot; ma.dim_comp = d_comp;
+    ma.D = D; ma.m = m; ma.g_norm = P->g_norm; ma.outA = d_outA; ma.outb = d_outb; ma.out_scalars = d_scal;
+    {
+        StageScope sc(ctx, "ba_marg", s);
+        const int rc = be_launch_marg(ma, s);
+        if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");
+        if (rc) DV_FAIL("dv_marginalize: cannot set dynamic LDS size");
+    }
+    DV_CHECK(hipGetLastError());
+    double scal[8];
+    DV_CHECK(hipMemcpyAsync(out_A, d_outA, 8 * (size_t)n * n, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(out_b, d_outb, 8 * (size_t)n, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(scal, d_scal, 64, hipMemcpyDeviceToHost, s));
+    if (getenv("DV_DEBUG_MARG")) fprintf(stderr, "marg dbg: maxJtd=%g max|w_td|=%g max|gp_td|=%g A[td][20] pre-elim? %g\n", scal[4], scal[5], scal[6], scal[7]);
+    DV_CHECK(hipStreamSynchronize(s));
+    if (ctx->timing) dv_harvest_timers(ctx);
+    if (diag4) std::memcpy(diag4, scal, 32);
+    if (scal[2] != 0.0) DV_FAIL("dv_marginalize: A_mm is not positive definite (reference would take its pseudo-inverse)");
+    // ---- new prior header: kept blocks, indices shifted like addr_shift (estimator.cpp:537-548 / 591-612) ----
+    out_prior->valid = 1; out_prior->n = n; out_prior->c0 = scal[0];
+    int nb = 0;
+    auto put = [&](int type, int idx, int new_idx, int dim0, int size_local, const double* x0, int gs) {
+        dv_ba_prior_block& pb = out_prior->blocks[nb];
+        pb.type = type; pb.idx = new_idx; pb.off = dim0 - m; pb.size_local = size_local;
+        for (int k = 0; k < gs; ++k) out_prior->x0[nb][k] = x0[k];
+        ++nb; (void)idx;
+    };
+    auto shift = [&](int k) { return mode == 0 ? k - 1 : (k == BE_WIN ? BE_WIN - 1 : k); };
+    for (int k = 0; k < BE_NF; ++k) if (pose_dim[k] >= m) put(0, k, shift(k), pose_dim[k], 6, P->pose + 7 * k, 7);
+    for (int k = 0; k < BE_NF; ++k) if (sb_dim[k] >= m) put(1, k, shift(k), sb_dim[k], 9, P->speed_bias + 9 * k, 9);
+    for (int c = 0; c < 2; ++c) if (ex_dim[c] >= 0) put(2, c, c, ex_dim[c], 6, P->ex_pose + 7 * c, 7);
+    if (td_dim >= 0) put(3, 0, 0, td_dim, 1, P->td, 1);
+    out_prior->nblocks = nb;
+    return 0;
+}
+
 int dv_proj_eval(dv_ctx* ctx, const dv_ba_factor* factors, int n, const double* pose_i, const double* pose_j, const double* ex0,
                  const double* ex1, const double* inv_depth, const double* td, double* out) {
     if (!ctx) return -1;

@@ -19,29 +19,6 @@
 
 using namespace be;
 
-__device__ void be_frame_geom(const BeState* s, int nframes, FrameGeom* fg, m33* ric, d3* tic, int lane) {
-    if (lane < nframes) { fg[lane].R = qR(Q4(s->pose[lane])); fg[lane].P = P3(s->pose[lane]); }
-    if (lane >= 32 && lane < 34) { ric[lane - 32] = qR(Q4(s->ex[lane - 32])); tic[lane - 32] = P3(s->ex[lane - 32]); }
-}
-
-// dx of the prior's kept blocks (MarginalizationFactor::Evaluate, marginalization_factor.cpp:355-378)
-__device__ void be_prior_dx(const BePriorHdr* p, const BeState* s, double* dx, int lane, int nthreads) {
-    for (int b = lane; b < p->nblocks; b += nthreads) {
-        const BePriorBlock pb = p->blocks[b];
-        const double* x0 = p->x0[b];
-        if (pb.type == 0 || pb.type == 2) {
-            const double* x = pb.type == 0 ? s->pose[pb.idx] : s->ex[pb.idx];
-            for (int k = 0; k < 3; ++k) dx[pb.off + k] = x[k] - x0[k];
-            const quat dq = qmul(qinv(Q4(x0)), Q4(x));
-            d3 v = qvec(dq) * 2.0;
-            if (!(dq.w >= 0)) v = -v;
-            dx[pb.off + 3] = v.x; dx[pb.off + 4] = v.y; dx[pb.off + 5] = v.z;
-        } else if (pb.type == 1) {
-            for (int k = 0; k < 9; ++k) dx[pb.off + k] = s->sb[pb.idx][k] - x0[k];
-        } else dx[pb.off] = s->td - x0[0];
-    }
-}
-
 template <bool FULL>
 __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
     const BeCtl c = *a.ctl;
@@ -62,7 +39,7 @@ __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
     if (b < nlm) {
         // ------------------------------- landmark -------------------------------
         const BeLm L = a.lm[b];
-        be_frame_geom(st, a.dims.nframes, fg, ric, tic, lane);
+        be_frame_geom_dev(st, a.dims.nframes, fg, ric, tic, lane);
         __syncthreads();
         const double lambda = st->inv_depth[b];
         if (lane < L.count) {
@@ -97,18 +74,18 @@ __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
                 const int q = e - (is_w ? BE_PK_W : BE_PK_GP), fa = q / 6, rr = q - fa * 6;
                 for (int f = 0; f < nf; ++f) {
                     if (!s_two[f]) continue;
-                    const double* J = (fa == anchor) ? &Jb[f][2] : ((s_fj[f] == fa) ? &Jb[f][14] : nullptr);
-                    if (!J) continue;
+                    const int base = (fa == anchor) ? 2 : ((s_fj[f] == fa) ? 14 : -1);      // offsets, not LDS pointers
+                    if (base < 0) continue;
                     const double m0 = is_w ? Jb[f][26] : Jb[f][0], m1 = is_w ? Jb[f][27] : Jb[f][1];
-                    v += J[rr] * m0 + J[6 + rr] * m1;
+                    v += Jb[f][base + rr] * m0 + Jb[f][base + 6 + rr] * m1;
                 }
             } else if (e < BE_PK_DA) {
                 const int q = e - BE_PK_DD, fa = q / 36, rc = q - fa * 36, rr = rc / 6, cc = rc - rr * 6;
                 for (int f = 0; f < nf; ++f) {
                     if (!s_two[f]) continue;
-                    const double* J = (fa == anchor) ? &Jb[f][2] : ((s_fj[f] == fa) ? &Jb[f][14] : nullptr);
-                    if (!J) continue;
-                    v += J[rr] * J[cc] + J[6 + rr] * J[6 + cc];
+                    const int base = (fa == anchor) ? 2 : ((s_fj[f] == fa) ? 14 : -1);
+                    if (base < 0) continue;
+                    v += Jb[f][base + rr] * Jb[f][base + cc] + Jb[f][base + 6 + rr] * Jb[f][base + 6 + cc];
                 }
             } else if (e < BE_PK_DA + BE_NF * 36) {
                 const int q = e - BE_PK_DA, fa = q / 36, rc = q - fa * 36, rr = rc / 6, cc = rc - rr * 6;
@@ -155,7 +132,7 @@ __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
         if (!p->valid) { if (lane == 0) { if (FULL) a.prior_out[0] = 0.0; else a.cand_cost[b] = 0.0; } return; }
         __shared__ double dx[BE_MAX_PRIOR], Adx[BE_MAX_PRIOR];
         const int n = p->n;
-        be_prior_dx(p, st, dx, lane, 64);
+        be_prior_dx_dev(p, st, dx, lane, 64);
         __syncthreads();
         for (int i = lane; i < n; i += 64) { double s = 0; const double* row = a.priorA + (size_t)i * n; for (int j = 0; j < n; ++j) s += row[j] * dx[j]; Adx[i] = s; }
         __syncthreads();

@@ -31,7 +31,47 @@ struct BeSolveArgs {
     int32_t* col_kind; int32_t* col_frame; int32_t* col_comp;          // [n]
 };
 
+struct BeMargArgs {
+    const BeState* x; int nframes, nlm, nimu;
+    const BeFactor* fac; const BeLm* lm; const BeImu* imu;
+    const BePriorHdr* prior; const double* priorA; const double* priorb;
+    const int32_t* prior_map;     // [n_old]  old prior index -> dim of the marginalization system, -1 = not present
+    const int32_t* imu_map;       // [30]     IMU factor local dim -> dim
+    const int32_t* dim_slot;      // [D]      0..10 pose frame, 11 ex0, 12 ex1, 13 td, -1 speed-bias
+    const int32_t* dim_comp;      // [D]
+    int D, m; double g_norm;
+    double* outA; double* outb; double* out_scalars;     // n x n, n, {c0, min pivot, failure flag, rank}
+};
+
+#if defined(__HIPCC__)
+using namespace be;
+__device__ inline void be_frame_geom_dev(const BeState* s, int nframes, FrameGeom* fg, m33* ric, d3* tic, int lane) {
+    if (lane < nframes) { fg[lane].R = qR(Q4(s->pose[lane])); fg[lane].P = P3(s->pose[lane]); }
+    if (lane >= 32 && lane < 34) { ric[lane - 32] = qR(Q4(s->ex[lane - 32])); tic[lane - 32] = P3(s->ex[lane - 32]); }
+}
+
+// dx of the prior's kept blocks (MarginalizationFactor::Evaluate, marginalization_factor.cpp:355-378)
+__device__ inline void be_prior_dx_dev(const BePriorHdr* p, const BeState* s, double* dx, int lane, int nthreads) {
+    for (int b = lane; b < p->nblocks; b += nthreads) {
+        const BePriorBlock pb = p->blocks[b];
+        const double* x0 = p->x0[b];
+        if (pb.type == 0 || pb.type == 2) {
+            const double* x = pb.type == 0 ? s->pose[pb.idx] : s->ex[pb.idx];
+            for (int k = 0; k < 3; ++k) dx[pb.off + k] = x[k] - x0[k];
+            const quat dq = qmul(qinv(Q4(x0)), Q4(x));
+            d3 v = qvec(dq) * 2.0;
+            if (!(dq.w >= 0)) v = -v;
+            dx[pb.off + 3] = v.x; dx[pb.off + 4] = v.y; dx[pb.off + 5] = v.z;
+        } else if (pb.type == 1) {
+            for (int k = 0; k < 9; ++k) dx[pb.off + k] = s->sb[pb.idx][k] - x0[k];
+        } else dx[pb.off] = s->td - x0[0];
+    }
+}
+
+#endif
+
 void be_launch_eval(const BeEvalArgs& a, bool full, hipStream_t s);
+int  be_launch_marg(const BeMargArgs& a, hipStream_t s);
 void be_launch_reduce(const BeSolveArgs& a, hipStream_t s);
 int  be_launch_solve(const BeSolveArgs& a, hipStream_t s);
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);

@@ -162,6 +162,17 @@ typedef struct dv_ba_summary {
  * The whole trust-region loop runs on the device; states are updated in place. */
 int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* problem, dv_ba_summary* summary);
 
+/* Replaces MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks} as driven by
+ * Estimator::SetMarginalizationInfo (estimator/estimator.cpp:403-619).
+ *   mode 0 = kMarginOld: P holds the linearisation point (all 11 window states), the residual blocks of the landmarks
+ *            anchored in frame 0 (>= 4 observations), imu[0] = the IMUFactor (0,1) (nimu 0 if sum_dt >= 10) and the
+ *            current prior; pose 0 / speed-bias 0 / those landmarks are marginalized.
+ *   mode 1 = kMarginSecondNew: only the prior is used; pose[kWinSize-1] is marginalized.
+ * out_A: n x n (n <= 192), out_b: n.  Block indices of out_prior are already shifted (addr_shift).
+ * out_prior->valid = 0 when nothing can be marginalized.  diag4 (may be NULL): c0, smallest pivot of A_mm, failure
+ * flag, numerical rank of A'. */
+int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* out_prior, double* out_A, double* out_b, double* diag4);
+
 /* operator-level factor evaluation (Evaluate() of the three projection factors / IMUFactor) for parity tests.
  * out: n x 54 doubles = r[2] J_pose_i[2x6] J_pose_j[2x6] J_ex0[2x6] J_ex1[2x6] J_lambda[2] J_td[2] (tangent space) */
 int dv_proj_eval(dv_ctx* ctx, const dv_ba_factor* factors, int n, const double* pose_i, const double* pose_j,

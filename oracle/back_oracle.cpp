@@ -181,6 +181,22 @@ struct Marginalizer {         // MarginalizationInfo::{addResidualBlockInfo,preM
         std::vector<double> ev2; Mat V2;
         sym_eig(Ap, ev2, V2);
         if (getenv("DVO_DEBUG_MARG")) { int nz = 0; for (double e : ev2) if (!(e > eps)) nz++; fprintf(stderr, "   A' ev[0..5]= %.3e %.3e %.3e %.3e %.3e %.3e max=%.3e clamped=%d\n", ev2[0], ev2[1], ev2[2], ev2[3], ev2[4], ev2[5], ev2.back(), nz); }
+        if (getenv("DVO_DEBUG_MARG")) {
+            // experiment: c0 from eigen-clamp vs from a diagonally pivoted LDL^T stopped at a pivot tolerance
+            double c_eig = 0; for (int k = 0; k < n; ++k) if (ev2[k] > eps) { double vb = 0; for (int i = 0; i < n; ++i) vb += V2(i, k) * bp[i]; c_eig += vb * vb / ev2[k]; }
+            for (double tol : { 1e-8, 1e-5, 1e-3, 1e-1 }) {
+                Mat W = Ap; std::vector<double> y = bp; std::vector<int> perm(n); for (int i = 0; i < n; ++i) perm[i] = i;
+                double c = 0; int rank = 0;
+                for (int k = 0; k < n; ++k) {
+                    int p = k; for (int i = k + 1; i < n; ++i) if (W(i, i) > W(p, p)) p = i;
+                    if (p != k) { for (int j = 0; j < n; ++j) std::swap(W(k, j), W(p, j)); for (int j = 0; j < n; ++j) std::swap(W(j, k), W(j, p)); std::swap(y[k], y[p]); }
+                    double d = W(k, k); if (!(d > tol)) break; rank++;
+                    c += y[k] * y[k] / d;
+                    for (int i = k + 1; i < n; ++i) { double l = W(i, k) / d; y[i] -= l * y[k]; for (int j = k + 1; j < n; ++j) W(i, j) -= l * W(k, j); }
+                }
+                fprintf(stderr, "   c0 eig=%.9e  ldlt(tol=%.0e)=%.9e rank=%d reldiff=%.2e\n", c_eig, tol, c, rank, (c - c_eig) / c_eig);
+            }
+        }
         out->J0 = Mat(n, n); out->r0.assign(n, 0.0);
         for (int k = 0; k < n; ++k) {
             const double S = ev2[k] > eps ? ev2[k] : 0.0, Sinv = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;
@@ -796,6 +812,97 @@ int dvo_ba_solve(dvo_ba_problem* P, dvo_ba_summary* S) {
     SolveOptions so; so.max_num_iterations = P->max_iters;
     SolveSummary sum = solver.solve(so);
     if (S) { S->iterations = sum.iterations; S->successful = sum.successful; S->termination = sum.termination; S->slots = 0; S->initial_cost = sum.initial_cost; S->final_cost = sum.final_cost; }
+    return 0;
+}
+
+// SetMarginalizationInfo on a flat window description: mode 0 = kMarginOld (factors = residual blocks of the
+// landmarks anchored in frame 0, imu[0] = factor (0,1), prior), mode 1 = kMarginSecondNew (prior only).
+// Output in information form (A = J0^T J0, b = J0^T r0, c0 = r0^T r0) with the oracle's own block order.
+int dvo_marginalize(const dvo_ba_problem* P, int mode, dvo_ba_prior* out, double* out_A, double* out_b) {
+    std::memset(out, 0, sizeof(*out));
+    MargInfo old;
+    const bool has_prior = P->prior && P->prior->valid;
+    auto addr_of = [&](int type, int idx) -> double* { return type == 0 ? P->pose + 7 * idx : type == 1 ? P->speed_bias + 9 * idx : type == 2 ? P->ex_pose + 7 * idx : P->td; };
+    if (has_prior) {
+        const int n = P->prior->n;
+        Mat A(n, n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) A(i, j) = 0.5 * (P->prior_A[i * n + j] + P->prior_A[j * n + i]);
+        std::vector<double> ev; Mat V; sym_eig(A, ev, V);
+        old.m = 0; old.n = n; old.J0 = Mat(n, n); old.r0.assign(n, 0.0);
+        for (int k = 0; k < n; ++k) {
+            const double Sv = ev[k] > 1e-8 ? ev[k] : 0.0, Si = ev[k] > 1e-8 ? 1.0 / ev[k] : 0.0;
+            double vb = 0; for (int i = 0; i < n; ++i) { old.J0(k, i) = std::sqrt(Sv) * V(i, k); vb += V(i, k) * P->prior_b[i]; }
+            old.r0[k] = std::sqrt(Si) * vb;
+        }
+        for (int b = 0; b < P->prior->nblocks; ++b) {
+            const dvo_ba_prior_block& pb = P->prior->blocks[b];
+            const int gs = pb.type == 0 || pb.type == 2 ? 7 : (pb.type == 1 ? 9 : 1);
+            old.keep_size.push_back(gs); old.keep_idx.push_back(pb.off);
+            old.keep_data.push_back(std::vector<double>(P->prior->x0[b], P->prior->x0[b] + gs));
+            old.keep_addr.push_back(addr_of(pb.type, pb.idx));
+        }
+    }
+    Marginalizer mg;
+    std::map<double*, double*> shift;
+    std::vector<std::unique_ptr<Integration>> pres;
+    const V3 G(0, 0, P->g_norm);
+    double* drop_pose = P->pose + 7 * (mode == 0 ? 0 : kWin - 1);
+    if (has_prior) {
+        std::vector<int> drop;
+        for (size_t i = 0; i < old.keep_addr.size(); ++i) if (old.keep_addr[i] == drop_pose || (mode == 0 && old.keep_addr[i] == P->speed_bias)) drop.push_back((int)i);
+        mg.add(RBInfo{ std::make_shared<MargCost>(&old), kNoLoss, old.keep_addr, drop });
+    }
+    if (mode == 0) {
+        if (P->nimu > 0) {
+            const dvo_ba_imu& m = P->imu[0];
+            auto I = std::make_unique<Integration>(V3(), V3(), P3(m.lin_ba), P3(m.lin_bg), ImuNoise{ 0, 0, 0, 0 });
+            I->sum_dt = m.sum_dt; I->delta_p = P3(m.dp); I->delta_v = P3(m.dv); I->delta_q = Q(m.dq[0], m.dq[1], m.dq[2], m.dq[3]);
+            std::memcpy(I->jacobian.d.data(), m.jacobian, 225 * 8); std::memcpy(I->covariance.d.data(), m.covariance, 225 * 8);
+            mg.add(RBInfo{ std::make_shared<ImuCost>(I.get(), G), kNoLoss, { P->pose, P->speed_bias, P->pose + 7, P->speed_bias + 9 }, { 0, 1 } });
+            pres.push_back(std::move(I));
+        }
+        for (int l = 0; l < P->nlm; ++l) {
+            const dvo_ba_lm& L = P->landmarks[l];
+            for (int k = 0; k < L.count; ++k) {
+                const dvo_ba_factor& f = P->factors[L.first + k];
+                ProjObs o; o.pts_i = V3(f.pix, f.piy, 1); o.pts_j = V3(f.pjx, f.pjy, 1); o.vel_i = V3(f.vix, f.viy, 0); o.vel_j = V3(f.vjx, f.vjy, 0); o.td_i = f.td_i; o.td_j = f.td_j;
+                double* lam = P->inv_depth + f.lm;
+                if (f.kind == 0) mg.add(RBInfo{ std::make_shared<ProjCost>(0, o), kHuber1, { P->pose + 7 * f.fi, P->pose + 7 * f.fj, P->ex_pose, lam, P->td }, { 0, 3 } });
+                else if (f.kind == 1) mg.add(RBInfo{ std::make_shared<ProjCost>(1, o), kHuber1, { P->pose + 7 * f.fi, P->pose + 7 * f.fj, P->ex_pose, P->ex_pose + 7, lam, P->td }, { 0, 4 } });
+                else mg.add(RBInfo{ std::make_shared<ProjCost>(2, o), kHuber1, { P->ex_pose, P->ex_pose + 7, lam, P->td }, { 2 } });
+            }
+        }
+        for (int i = 1; i <= kWin; ++i) { shift[P->pose + 7 * i] = P->pose + 7 * (i - 1); if (P->use_imu) shift[P->speed_bias + 9 * i] = P->speed_bias + 9 * (i - 1); }
+    } else {
+        for (int i = 0; i <= kWin; ++i) {
+            if (i == kWin - 1) continue;
+            const int t = i == kWin ? i - 1 : i;
+            shift[P->pose + 7 * i] = P->pose + 7 * t; if (P->use_imu) shift[P->speed_bias + 9 * i] = P->speed_bias + 9 * t;
+        }
+    }
+    for (int i = 0; i < 2; ++i) shift[P->ex_pose + 7 * i] = P->ex_pose + 7 * i;
+    shift[P->td] = P->td;
+    auto res = mg.run(shift);
+    if (!res->valid) { out->valid = 0; return 0; }
+    const int n = res->n;
+    out->valid = 1; out->n = n; out->nblocks = (int)res->keep_size.size();
+    double c0 = 0;
+    for (int k = 0; k < n; ++k) c0 += res->r0[k] * res->r0[k];
+    out->c0 = c0;
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n; ++j) { double s = 0; for (int k = 0; k < n; ++k) s += res->J0(k, i) * res->J0(k, j); out_A[i * n + j] = s; }
+        double s = 0; for (int k = 0; k < n; ++k) s += res->J0(k, i) * res->r0[k]; out_b[i] = s;
+    }
+    for (size_t b = 0; b < res->keep_size.size(); ++b) {
+        double* a = res->keep_addr[b];
+        dvo_ba_prior_block& pb = out->blocks[b];
+        if (a >= P->pose && a < P->pose + 7 * (kWin + 1)) { pb.type = 0; pb.idx = (int)((a - P->pose) / 7); }
+        else if (P->speed_bias && a >= P->speed_bias && a < P->speed_bias + 9 * (kWin + 1)) { pb.type = 1; pb.idx = (int)((a - P->speed_bias) / 9); }
+        else if (a >= P->ex_pose && a < P->ex_pose + 14) { pb.type = 2; pb.idx = (int)((a - P->ex_pose) / 7); }
+        else { pb.type = 3; pb.idx = 0; }
+        pb.off = res->keep_idx[b] - res->m; pb.size_local = res->keep_size[b] == 7 ? 6 : res->keep_size[b];
+        for (size_t k = 0; k < res->keep_data[b].size(); ++k) out->x0[b][k] = res->keep_data[b][k];
+    }
     return 0;
 }
 

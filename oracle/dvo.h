@@ -130,6 +130,9 @@ typedef struct dvo_ba_summary { int32_t iterations, successful, termination, slo
 /* ceres::Solve restatement on a standalone window (Estimator::Optimization's problem, estimator.cpp:261-326) */
 int dvo_ba_solve(dvo_ba_problem* problem, dvo_ba_summary* summary);
 double dvo_prior_c0(const double* A, const double* b, int n);
+/* SetMarginalizationInfo on a flat window (estimator.cpp:403-619): mode 0 kMarginOld, 1 kMarginSecondNew; output in
+ * information form A = J0^T J0, b = J0^T r0, c0 = r0^T r0, blocks in the oracle's insertion order (M1) */
+int dvo_marginalize(const dvo_ba_problem* P, int mode, dvo_ba_prior* out, double* out_A, double* out_b);
 
 typedef struct dvo_be_config {       /* para (estimator/vio_parameters.cpp:19-83) + cfg flags + extrinsics */
     int use_imu, stereo, plane_constraint, max_iters;

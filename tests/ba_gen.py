@@ -168,3 +168,53 @@ def oracle_solve(oracle, prob):
     oracle.lib.dvo_ba_solve.argtypes = [C.c_void_p, C.c_void_p]
     oracle.lib.dvo_ba_solve(C.byref(prob.c), C.byref(s))
     return s
+
+
+def marg_subproblem(prob, mode):
+    """the inputs of SetMarginalizationInfo for a solved full window: mode 0 keeps only the residual blocks of the
+    landmarks anchored in frame 0 and the IMU factor (0,1); mode 1 keeps only the prior"""
+    if mode == 1:
+        sub = WindowProblem(prob.pose, prob.speed_bias, prob.ex_pose, prob.td[0], prob.inv_depth, prob.factors[:0], prob.landmarks[:0], prob.imu[:0],
+                            prob.c.use_imu, prob.c.plane_kind, prob.c.max_iters, prob.c.g_norm, prob.prior, prob.prior_A, prob.prior_b)
+        return sub
+    lm_keep = [l for l in range(len(prob.landmarks)) if prob.landmarks[l]["anchor"] == 0]
+    facs, lms = [], []
+    for l in lm_keep:
+        L = prob.landmarks[l]
+        first = len(facs)
+        facs.extend(prob.factors[L["first"]:L["first"] + L["count"]])
+        lms.append((first, L["count"], 0, L["mask"]))
+    facs = np.array(facs, FACTOR_DTYPE) if facs else prob.factors[:0]
+    lms = np.array(lms, LM_DTYPE)
+    return WindowProblem(prob.pose, prob.speed_bias, prob.ex_pose, prob.td[0], prob.inv_depth, facs, lms, prob.imu[:1],
+                         prob.c.use_imu, prob.c.plane_kind, prob.c.max_iters, prob.c.g_norm, prob.prior, prob.prior_A, prob.prior_b)
+
+
+def oracle_marginalize(oracle, sub, mode):
+    out = dv_ba_prior()
+    A = np.zeros(192 * 192)
+    b = np.zeros(192)
+    oracle.lib.dvo_marginalize.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    oracle.lib.dvo_marginalize(C.byref(sub.c), mode, C.byref(out), A.ctypes.data, b.ctypes.data)
+    n = out.n
+    return out, A[:n * n].reshape(n, n).copy(), b[:n].copy()
+
+
+def prior_to_dict(prior, A, b):
+    """block-keyed view of a prior so that two priors with different block orders can be compared"""
+    blocks = {}
+    for i in range(prior.nblocks):
+        pb = prior.blocks[i]
+        gs = {0: 7, 1: 9, 2: 7, 3: 1}[pb.type]
+        blocks[(pb.type, pb.idx)] = (pb.off, pb.size_local, np.array(prior.x0[i][:gs]))
+    return blocks
+
+
+def permute_prior(blocks_from, A, b, blocks_to):
+    """reorders (A, b) given in blocks_from's layout into blocks_to's layout"""
+    n = len(b)
+    perm = np.zeros(n, int)
+    for key, (off_to, sz, _) in blocks_to.items():
+        off_from = blocks_from[key][0]
+        perm[off_to:off_to + sz] = np.arange(off_from, off_from + sz)
+    return A[np.ix_(perm, perm)], b[perm]

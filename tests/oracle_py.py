@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ODIR = os.path.join(ROOT, "oracle")
-OLIB = os.path.join(ODIR, "_build", "libdvins_oracle.so")
+OLIB = os.environ.get("DVO_LIB", os.path.join(ODIR, "_build", "libdvins_oracle.so"))
 
 
 class dvo_cam(C.Structure):

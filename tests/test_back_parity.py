@@ -138,3 +138,65 @@ def test_ba_solve_is_reproducible(ctx, oracle):
     ba_solve(ctx, a)
     ba_solve(ctx, b)
     assert np.array_equal(a.pose, b.pose) and np.array_equal(a.inv_depth, b.inv_depth) and np.array_equal(a.speed_bias, b.speed_bias)
+
+
+@pytest.mark.parametrize("kw,mode", [(dict(seed=21, with_prior=True), 0), (dict(seed=22), 0), (dict(seed=23, with_prior=True), 1),
+                                     (dict(seed=24, with_prior=True, use_imu=0), 0), (dict(seed=25, with_prior=True, nlm=300), 0)])
+def test_marginalization_matches_oracle(ctx, oracle, kw, mode):
+    """information-form prior (A', b', c0) of the HIP marginalization vs J0^T J0, J0^T r0, r0^T r0 of the oracle's
+    eigen-decomposition path; compared block by block (the two sides order blocks differently)."""
+    from dynamic_vins_amd.backend import ba_solve, marginalize
+    full = ba_gen.make_window(oracle, **kw)
+    ba_gen.oracle_solve(oracle, full)                     # linearise at the optimum like the estimator does
+    sub = ba_gen.marg_subproblem(full, mode)
+    po, Ao, bo = ba_gen.oracle_marginalize(oracle, sub, mode)
+    pd, Ad, bd, diag = marginalize(ctx, sub, mode)
+    assert pd.valid == po.valid == 1 and pd.n == po.n and pd.nblocks == po.nblocks
+    bo_blocks, bd_blocks = ba_gen.prior_to_dict(po, Ao, bo), ba_gen.prior_to_dict(pd, Ad, bd)
+    assert set(bo_blocks) == set(bd_blocks)
+    for k in bo_blocks:
+        assert bo_blocks[k][1] == bd_blocks[k][1]
+        assert np.array_equal(bo_blocks[k][2], bd_blocks[k][2])          # linearisation point
+    Ao_p, bo_p = ba_gen.permute_prior(bo_blocks, Ao, bo, bd_blocks)
+    scale = np.abs(Ao_p).max()
+    assert np.allclose(Ad, Ao_p, rtol=0, atol=1e-9 * scale + 1e-6)
+    assert np.allclose(bd, bo_p, rtol=0, atol=1e-9 * np.abs(bo_p).max() + 1e-6)
+    assert np.isclose(pd.c0, po.c0, rtol=1e-6)
+    assert diag[1] > 1e-8            # A_mm well conditioned: pseudo-inverse == inverse
+
+
+def test_prior_round_trip_through_solver(ctx, oracle):
+    """solve -> marginalize -> shift states -> solve again with the new prior: HIP and oracle stay together"""
+    from dynamic_vins_amd.backend import WindowProblem, ba_solve, marginalize
+    ref = ba_gen.make_window(oracle, seed=31, with_prior=True)
+    dev = ref.clone()
+    ba_gen.oracle_solve(oracle, ref)
+    ba_solve(ctx, dev)
+    po, Ao, bo = ba_gen.oracle_marginalize(oracle, ba_gen.marg_subproblem(ref, 0), 0)
+    pd, Ad, bd, _ = marginalize(ctx, ba_gen.marg_subproblem(dev, 0), 0)
+
+    def shifted(p, prior, A, b):
+        keep = [l for l in range(len(p.landmarks)) if p.landmarks[l]["anchor"] != 0]
+        facs, lms, inv = [], [], []
+        for new_l, l in enumerate(keep):
+            L = p.landmarks[l]
+            fs = p.factors[L["first"]:L["first"] + L["count"]].copy()
+            fs["lm"] = new_l
+            fs["fi"] -= 1
+            fs["fj"] -= 1
+            lms.append((len(facs), L["count"], L["anchor"] - 1, L["mask"] >> 1))
+            facs.extend(fs)
+            inv.append(p.inv_depth[l])
+        imu = p.imu[1:].copy()
+        imu["fi"] -= 1
+        imu["fj"] -= 1
+        rng = np.random.default_rng(5)
+        pose = p.pose[1:].copy()
+        pose[:, :3] += rng.normal(0, 0.01, (10, 3))
+        return WindowProblem(pose, p.speed_bias[1:], p.ex_pose, p.td[0], np.array(inv), np.array(facs, ba_gen.FACTOR_DTYPE), np.array(lms, ba_gen.LM_DTYPE), imu,
+                             p.c.use_imu, p.c.plane_kind, p.c.max_iters, p.c.g_norm, prior, A, b)
+    ref2, dev2 = shifted(ref, po, Ao, bo), shifted(dev, pd, Ad, bd)
+    so, sd = ba_gen.oracle_solve(oracle, ref2), ba_solve(ctx, dev2)
+    assert (sd.iterations, sd.successful, sd.termination) == (so.iterations, so.successful, so.termination)
+    assert np.isclose(sd.final_cost, so.final_cost, rtol=1e-6)
+    assert np.allclose(dev2.pose, ref2.pose, atol=1e-6) and np.allclose(dev2.inv_depth, ref2.inv_depth, atol=1e-6)

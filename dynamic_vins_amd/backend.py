@@ -125,3 +125,61 @@ def marginalize(ctx, sub: WindowProblem, mode):
         raise DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
     n = out.n
     return out, A[:n * n].reshape(n, n).copy(), b[:n].copy(), diag
+
+
+class dv_est_config(C.Structure):
+    _fields_ = [("use_imu", C.c_int32), ("stereo", C.c_int32), ("plane_constraint", C.c_int32), ("max_iters", C.c_int32),
+                ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),
+                ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
+                ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2)]
+
+
+class dv_est_state(C.Structure):
+    _fields_ = [("frame", C.c_int32), ("nonlinear", C.c_int32), ("margin_old", C.c_int32), ("n_landmarks", C.c_int32),
+                ("n_long", C.c_int32), ("iterations", C.c_int32), ("initial_cost", C.c_double), ("final_cost", C.c_double),
+                ("window", (C.c_double * 16) * 11)]
+
+
+class Estimator:
+    """Mirror of dynamic_vins::Estimator (estimator/estimator.h:55-164) on top of dv_est_*.
+    InputIMU / ProcessMeasurements keep the reference's names; camelCase aliases provided."""
+
+    def __init__(self, ctx, use_imu=1, stereo=1, plane_constraint=0, max_iters=8, keyframe_parallax=10.0, init_depth=5.0, g_norm=9.81, td=0.0,
+                 acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None):
+        self.ctx = ctx
+        c = dv_est_config()
+        c.use_imu, c.stereo, c.plane_constraint, c.max_iters = use_imu, stereo, plane_constraint, max_iters
+        c.keyframe_parallax, c.init_depth, c.g_norm, c.td = keyframe_parallax, init_depth, g_norm, td
+        c.acc_n, c.gyr_n, c.acc_w, c.gyr_w = acc_n, gyr_n, acc_w, gyr_w
+        for k in range(2):
+            for i in range(9):
+                c.ric[k][i] = float(np.asarray(ric[k]).reshape(-1)[i])
+            for i in range(3):
+                c.tic[k][i] = float(tic[k][i])
+        self.cfg = c
+        self.state = dv_est_state()
+        self._check(ctx.lib.dv_est_create(ctx.h, C.byref(c)))
+
+    def _check(self, rc):
+        if rc < 0:
+            raise DvinsError(self.ctx.lib.dv_last_error(self.ctx.h).decode())
+        return rc
+
+    def InputIMU(self, t, acc, gyr):
+        a = np.ascontiguousarray(acc, np.float64)
+        g = np.ascontiguousarray(gyr, np.float64)
+        self._check(self.ctx.lib.dv_est_input_imu(self.ctx.h, float(t), a.ctypes.data, g.ctypes.data))
+
+    def ProcessMeasurements(self, rows, t):
+        rows = np.ascontiguousarray(rows)
+        rc = self._check(self.ctx.lib.dv_est_process(self.ctx.h, rows.ctypes.data, len(rows), float(t), C.byref(self.state)))
+        return rc, self.state
+
+    def ClearState(self):
+        self._check(self.ctx.lib.dv_est_reset(self.ctx.h))
+
+    def window(self):
+        return np.array([list(r) for r in self.state.window])
+
+    inputIMU = InputIMU
+    processMeasurements = ProcessMeasurements

@@ -100,7 +100,11 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
         if (P->use_imu) { d.sb_col[f] = col; for (int k = 0; k < 9; ++k) { col_kind[col] = 1; col_frame[col] = f; col_comp[col] = k; ++col; } }
     }
     d.nstate = col;
-    if (col == 0) DV_FAIL("dv_ba_solve: no free parameter block");
+    if (col == 0) {       // e.g. vision-only, first frame: pose 0 is constant and no landmark has 4 observations yet
+        if (P->nlm > 0) DV_FAIL("dv_ba_solve: landmarks without a free pose block");
+        if (summary) { summary->iterations = 0; summary->successful = 0; summary->termination = 1; summary->slots = 0; summary->initial_cost = 0; summary->final_cost = 0; }
+        return 0;
+    }
     BePriorHdr ph{};
     const bool has_prior = P->prior && P->prior->valid;
     if (has_prior) {

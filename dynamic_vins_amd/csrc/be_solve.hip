@@ -156,6 +156,20 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
             const double xc = block_sum(part, red);
             if (tid == 0) { ctl->x_cost = xc; ctl->initial_cost = xc; }
         }
+        // gradient tolerance (trust_region_minimizer.cc: gradient_max_norm <= gradient_tolerance = 1e-10), checked on every new gradient
+        {
+            double gm = 0;
+            for (int i = tid; i < n; i += SOL_THREADS) gm = fmax(gm, fabs(a.gvec[i]));
+            for (int l = tid; l < nlm; l += SOL_THREADS) gm = fmax(gm, fabs(a.packets[(size_t)l * BE_PK_SIZE + BE_PK_G]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
+            __syncthreads();
+            if ((tid & 63) == 0) red[tid >> 6] = gm;
+            __syncthreads();
+            gm = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) gm = fmax(gm, red[k]);
+            __syncthreads();
+            if (gm <= 1e-10) { if (tid == 0) { ctl->done = 1; ctl->termination = 1; ctl->first = 0; } return; }
+        }
         // H u (pose part) + landmark terms of u^T H u, gradient norm
         for (int i = tid; i < n; i += SOL_THREADS) { double s = 0; const double* row = a.Hd + (size_t)i * n; for (int j = 0; j < n; ++j) s += row[j] * v_t[j]; v_t2[i] = s; }
         __syncthreads();

@@ -69,6 +69,9 @@ struct BeWork {
     void* pinned = nullptr; size_t pinned_bytes = 0;      // host staging (state + ctl)
 };
 
+struct dv_estimator;
+void dv_est_destroy_internal(dv_estimator* e);
+
 struct dv_ctx {
     dv_config cfg{};
     std::string err;
@@ -86,6 +89,7 @@ struct dv_ctx {
     bool timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
     // back end
     hipStream_t be_stream = nullptr; BeWork be;
+    dv_estimator* est = nullptr;
 };
 
 void dv_set_error(dv_ctx* ctx, const std::string& msg);

@@ -1,0 +1,541 @@
+// est_host.hip — host side of the back end (product code): the bookkeeping of dynamic_vins' Estimator around the
+// device kernels.  Mirrors, with flat arrays instead of std::list / Eigen / Ceres objects:
+//   Estimator::{InputIMU,ProcessMeasurements (one iteration),ProcessImage,InitEstimator,Optimization,
+//               SetMarginalizationInfo,SlideWindow,InitFramePoseByPnP,ClearState}   estimator/estimator.cpp
+//   FeatureManager::{AddFeatureCheckParallax,TriangulatePoints,RemoveBack*,RemoveFront,RemoveOutlier,RemoveFailures}
+//                                                                                       estimator/feature_manager.cpp
+//   IntegrationBase (midpoint pre-integration)                                          estimator/imu/integration_base.h
+//   OutliersRejection / TriangulatePoint / SolvePoseByPnP / SolveGyroscopeBias          estimator/vio_util.cpp, initial/
+// What runs where: IMU pre-integration, triangulation, PnP seeding and the window shuffling are O(100) flops per
+// item and stay on the host; every residual/Jacobian evaluation, the Schur elimination, the trust-region loop and the
+// marginalization run on the GPU through dv_ba_solve / dv_marginalize.
+// Deviations from the reference that change no result: feature lookup by hash map instead of the O(N*L) find_if
+// (feature_manager.cpp:80-83); IMUFactor's sqrt-information cached per solve (Q8).
+#include <algorithm>
+#include <deque>
+#include <memory>
+#include <unordered_map>
+#include "dv_ctx.h"
+#include "be_math.h"
+
+using namespace be;
+
+namespace {
+
+constexpr int kWin = BE_WIN;
+constexpr double kFocal = 460.0;
+
+struct Preint {       // IntegrationBase
+    d3 acc_0, gyr_0, lin_acc, lin_gyr, lin_ba, lin_bg, dp, dv; quat dq;
+    double J[225], P[225], noise[18], sum_dt = 0;
+    std::vector<double> dts; std::vector<d3> accs, gyrs;
+    Preint(d3 a0, d3 g0, d3 ba, d3 bg, const double n4[4]) : acc_0(a0), gyr_0(g0), lin_acc(a0), lin_gyr(g0), lin_ba(ba), lin_bg(bg) {
+        reset_state();
+        const double v[6] = { n4[0] * n4[0], n4[1] * n4[1], n4[0] * n4[0], n4[1] * n4[1], n4[2] * n4[2], n4[3] * n4[3] };
+        for (int b = 0; b < 6; ++b) for (int k = 0; k < 3; ++k) noise[3 * b + k] = v[b];
+    }
+    void reset_state() { dp = mk3(0, 0, 0); dv = mk3(0, 0, 0); dq = mkq(1, 0, 0, 0); sum_dt = 0; for (int i = 0; i < 225; ++i) { J[i] = (i % 16 == 0) ? 1.0 : 0.0; P[i] = 0.0; } }
+    void push_back(double dt, d3 a, d3 g) { dts.push_back(dt); accs.push_back(a); gyrs.push_back(g); propagate(dt, a, g); }
+    void repropagate(d3 ba, d3 bg) {
+        acc_0 = lin_acc; gyr_0 = lin_gyr; lin_ba = ba; lin_bg = bg; reset_state();
+        for (size_t i = 0; i < dts.size(); ++i) propagate(dts[i], accs[i], gyrs[i]);
+    }
+    static void blk(double* M, int ld, int r, int c, const m33& b) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) M[(r + i) * ld + c + j] = b.m[i * 3 + j]; }
+    void propagate(double dt, d3 a1, d3 g1) {      // midPointIntegration + propagate (integration_base.h:70-173)
+        const d3 un_acc_0 = qrot(dq, acc_0 - lin_ba);
+        const d3 un_gyr = (gyr_0 + g1) * 0.5 - lin_bg;
+        const quat rq = qmul(dq, mkq(1, un_gyr.x * dt / 2, un_gyr.y * dt / 2, un_gyr.z * dt / 2));
+        const d3 un_acc_1 = qrot(rq, a1 - lin_ba);
+        const d3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+        const d3 rp = dp + dv * dt + un_acc * (0.5 * dt * dt), rv = dv + un_acc * dt;
+        const m33 Rw = skew(un_gyr), Ra0 = skew(acc_0 - lin_ba), Ra1 = skew(a1 - lin_ba), I = eye3(), Rq = qR(dq), Rr = qR(rq);
+        const m33 IRw = sub(I, scale(Rw, dt));
+        static thread_local double F[225], V[270], T1[225], T2[270];
+        std::fill(F, F + 225, 0.0); std::fill(V, V + 270, 0.0);
+        blk(F, 15, 0, 0, I);
+        blk(F, 15, 0, 3, add(scale(mul(Rq, Ra0), -0.25 * dt * dt), scale(mul(mul(Rr, Ra1), IRw), -0.25 * dt * dt)));
+        blk(F, 15, 0, 6, scale(I, dt));
+        blk(F, 15, 0, 9, scale(add(Rq, Rr), -0.25 * dt * dt));
+        blk(F, 15, 0, 12, scale(mul(Rr, Ra1), -0.25 * dt * dt * -dt));
+        blk(F, 15, 3, 3, IRw); blk(F, 15, 3, 12, scale(I, -dt));
+        blk(F, 15, 6, 3, add(scale(mul(Rq, Ra0), -0.5 * dt), scale(mul(mul(Rr, Ra1), IRw), -0.5 * dt)));
+        blk(F, 15, 6, 6, I); blk(F, 15, 6, 9, scale(add(Rq, Rr), -0.5 * dt)); blk(F, 15, 6, 12, scale(mul(Rr, Ra1), -0.5 * dt * -dt));
+        blk(F, 15, 9, 9, I); blk(F, 15, 12, 12, I);
+        const m33 V03 = scale(mul(scale(Rr, -1.0), Ra1), 0.25 * dt * dt * 0.5 * dt), V63 = scale(mul(scale(Rr, -1.0), Ra1), 0.5 * dt * 0.5 * dt);
+        blk(V, 18, 0, 0, scale(Rq, 0.25 * dt * dt)); blk(V, 18, 0, 3, V03); blk(V, 18, 0, 6, scale(Rr, 0.25 * dt * dt)); blk(V, 18, 0, 9, V03);
+        blk(V, 18, 3, 3, scale(I, 0.5 * dt)); blk(V, 18, 3, 9, scale(I, 0.5 * dt));
+        blk(V, 18, 6, 0, scale(Rq, 0.5 * dt)); blk(V, 18, 6, 3, V63); blk(V, 18, 6, 6, scale(Rr, 0.5 * dt)); blk(V, 18, 6, 9, V63);
+        blk(V, 18, 9, 12, scale(I, dt)); blk(V, 18, 12, 15, scale(I, dt));
+        auto mm15 = [](const double* A, const double* B, double* C) { for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { double s = 0; for (int k = 0; k < 15; ++k) s += A[i * 15 + k] * B[k * 15 + j]; C[i * 15 + j] = s; } };
+        mm15(F, J, T1); std::copy(T1, T1 + 225, J);
+        mm15(F, P, T1);                                       // F P
+        double FPFt[225];
+        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { double s = 0; for (int k = 0; k < 15; ++k) s += T1[i * 15 + k] * F[j * 15 + k]; FPFt[i * 15 + j] = s; }
+        for (int i = 0; i < 15; ++i) for (int j = 0; j < 18; ++j) T2[i * 18 + j] = V[i * 18 + j] * noise[j];
+        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s += T2[i * 18 + k] * V[j * 18 + k]; P[i * 15 + j] = FPFt[i * 15 + j] + s; }
+        dp = rp; dq = qnormalized(rq); dv = rv; sum_dt += dt; acc_0 = a1; gyr_0 = g1;
+    }
+    m33 jb(int r, int c) const { m33 b; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) b.m[i * 3 + j] = J[(r + i) * 15 + c + j]; return b; }
+    void fill(dv_ba_imu& o, int fi, int fj) const {
+        o.sum_dt = sum_dt;
+        o.dp[0] = dp.x; o.dp[1] = dp.y; o.dp[2] = dp.z; o.dv[0] = dv.x; o.dv[1] = dv.y; o.dv[2] = dv.z;
+        o.dq[0] = dq.w; o.dq[1] = dq.x; o.dq[2] = dq.y; o.dq[3] = dq.z;
+        o.lin_ba[0] = lin_ba.x; o.lin_ba[1] = lin_ba.y; o.lin_ba[2] = lin_ba.z; o.lin_bg[0] = lin_bg.x; o.lin_bg[1] = lin_bg.y; o.lin_bg[2] = lin_bg.z;
+        std::memcpy(o.jacobian, J, sizeof(J)); std::memcpy(o.covariance, P, sizeof(P));
+        o.fi = fi; o.fj = fj; o.pad0 = o.pad1 = 0;
+    }
+};
+
+struct Obs { d3 pt, pt_r, vel, vel_r; double td; bool stereo; };
+struct Lm { int id, start; std::vector<Obs> obs; double depth = -1.0; int solve_flag = 0; int end() const { return start + (int)obs.size() - 1; } };
+
+// symmetric 4x4 eigen (cyclic Jacobi) -> eigenvector of the smallest eigenvalue
+void smallest_eigvec4(double A[4][4], double v[4]) {
+    double V[4][4] = { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } };
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0; for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) off += A[i][j] * A[i][j];
+        if (off < 1e-300) break;
+        for (int p = 0; p < 3; ++p) for (int q = p + 1; q < 4; ++q) {
+            if (std::fabs(A[p][q]) < 1e-300) continue;
+            const double th = (A[q][q] - A[p][p]) / (2 * A[p][q]);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1)), c = 1 / std::sqrt(t * t + 1), s = t * c;
+            for (int k = 0; k < 4; ++k) { const double a = A[k][p], b = A[k][q]; A[k][p] = c * a - s * b; A[k][q] = s * a + c * b; }
+            for (int k = 0; k < 4; ++k) { const double a = A[p][k], b = A[q][k]; A[p][k] = c * a - s * b; A[q][k] = s * a + c * b; }
+            for (int k = 0; k < 4; ++k) { const double a = V[k][p], b = V[k][q]; V[k][p] = c * a - s * b; V[k][q] = s * a + c * b; }
+        }
+    }
+    int m = 0; for (int i = 1; i < 4; ++i) if (A[i][i] < A[m][m]) m = i;
+    for (int i = 0; i < 4; ++i) v[i] = V[i][m];
+}
+
+d3 r2ypr(const m33& R) {
+    const d3 n = mk3(R.m[0], R.m[3], R.m[6]), o = mk3(R.m[1], R.m[4], R.m[7]), a = mk3(R.m[2], R.m[5], R.m[8]);
+    const double y = atan2(n.y, n.x), p = atan2(-n.z, n.x * cos(y) + n.y * sin(y)), r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
+    return mk3(y, p, r) / M_PI * 180.0;
+}
+m33 ypr2r(d3 ypr) {
+    const double y = ypr.x / 180.0 * M_PI, p = ypr.y / 180.0 * M_PI, r = ypr.z / 180.0 * M_PI;
+    m33 Rz = zero3(), Ry = zero3(), Rx = zero3();
+    Rz.m[0] = cos(y); Rz.m[1] = -sin(y); Rz.m[3] = sin(y); Rz.m[4] = cos(y); Rz.m[8] = 1;
+    Ry.m[0] = cos(p); Ry.m[2] = sin(p); Ry.m[4] = 1; Ry.m[6] = -sin(p); Ry.m[8] = cos(p);
+    Rx.m[0] = 1; Rx.m[4] = cos(r); Rx.m[5] = -sin(r); Rx.m[7] = sin(r); Rx.m[8] = cos(r);
+    return mul(mul(Rz, Ry), Rx);
+}
+quat from_two_vectors(d3 a, d3 b) {
+    const d3 v0 = a / norm(a), v1 = b / norm(b);
+    const double c = dot(v1, v0);
+    if (c < -1.0 + 1e-12) { d3 ax = std::fabs(v0.x) < 0.9 ? cross(mk3(1, 0, 0), v0) : cross(mk3(0, 1, 0), v0); ax = ax / norm(ax); return mkq(0, ax.x, ax.y, ax.z); }
+    const d3 ax = cross(v0, v1); const double s = sqrt((1.0 + c) * 2.0), inv = 1.0 / s;
+    return mkq(s * 0.5, ax.x * inv, ax.y * inv, ax.z * inv);
+}
+
+}  // namespace
+
+struct dv_estimator {
+    dv_est_config cfg;
+    m33 ric[2]; d3 tic[2]; d3 Ps[kWin + 1], Vs[kWin + 1], Bas[kWin + 1], Bgs[kWin + 1]; m33 Rs[kWin + 1];
+    d3 g; double td = 0, headers[kWin + 1] = { 0 };
+    int frame = 0;
+    std::vector<Lm> lms; std::unordered_map<int, size_t> lm_index; bool index_dirty = true;
+    std::deque<std::pair<double, std::pair<d3, d3>>> imu_buf;
+    double prev_time = -1, cur_time = 0; bool first_imu = false, init_pose = false; d3 acc_0, gyr_0;
+    std::unique_ptr<Preint> pre[kWin + 1], tmp_pre;
+    std::vector<double> dt_buf[kWin + 1]; std::vector<d3> la_buf[kWin + 1], av_buf[kWin + 1];
+    std::vector<std::shared_ptr<Preint>> frame_pre;        // all_image_frame pre-integrations (initialisation only)
+    bool nonlinear = false, margin_old = true;
+    dv_ba_prior prior{}; std::vector<double> priorA, priorb;
+    m33 back_R0; d3 back_P0;
+    dv_ba_summary last{};
+    // flat problem buffers
+    std::vector<dv_ba_factor> fac; std::vector<dv_ba_lm> lmt; std::vector<dv_ba_imu> imu; std::vector<double> invd;
+    double pose[kWin + 1][7], sb[kWin + 1][9], ex[2][7], tdv[1];
+
+    explicit dv_estimator(const dv_est_config& c) : cfg(c) { clear(); }
+    void clear() {
+        for (int i = 0; i <= kWin; ++i) { Rs[i] = eye3(); Ps[i] = Vs[i] = Bas[i] = Bgs[i] = mk3(0, 0, 0); pre[i].reset(); dt_buf[i].clear(); la_buf[i].clear(); av_buf[i].clear(); headers[i] = 0; }
+        lms.clear(); lm_index.clear(); imu_buf.clear(); frame_pre.clear(); tmp_pre.reset();
+        prior = dv_ba_prior{}; priorA.clear(); priorb.clear();
+        prev_time = -1; cur_time = 0; first_imu = false; init_pose = false; frame = 0; nonlinear = false; acc_0 = gyr_0 = mk3(0, 0, 0);
+        for (int k = 0; k < 2; ++k) { for (int i = 0; i < 9; ++i) ric[k].m[i] = cfg.ric[k][i]; tic[k] = mk3(cfg.tic[k][0], cfg.tic[k][1], cfg.tic[k][2]); }
+        td = cfg.td; g = mk3(0, 0, cfg.g_norm);
+    }
+    double noise4[4];
+    const double* noise() { noise4[0] = cfg.acc_n; noise4[1] = cfg.gyr_n; noise4[2] = cfg.acc_w; noise4[3] = cfg.gyr_w; return noise4; }
+
+    // ---------------- IMU ----------------
+    void process_imu(double dt, d3 la, d3 av) {
+        if (!first_imu) { first_imu = true; acc_0 = la; gyr_0 = av; }
+        if (!pre[frame]) pre[frame] = std::make_unique<Preint>(acc_0, gyr_0, Bas[frame], Bgs[frame], noise());
+        if (frame != 0) {
+            pre[frame]->push_back(dt, la, av); tmp_pre->push_back(dt, la, av);
+            dt_buf[frame].push_back(dt); la_buf[frame].push_back(la); av_buf[frame].push_back(av);
+            const int j = frame;
+            const d3 un_acc_0 = mul(Rs[j], acc_0 - Bas[j]) - g;
+            const d3 un_gyr = (gyr_0 + av) * 0.5 - Bgs[j];
+            Rs[j] = mul(Rs[j], qR(dq_half(un_gyr * dt)));
+            const d3 un_acc_1 = mul(Rs[j], la - Bas[j]) - g;
+            const d3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+            Ps[j] = Ps[j] + Vs[j] * dt + un_acc * (0.5 * dt * dt);
+            Vs[j] = Vs[j] + un_acc * dt;
+        }
+        acc_0 = la; gyr_0 = av;
+    }
+    bool add_imu_until(double t1) {       // GetIMUInterval + AddIMU (estimator.cpp:752-778,1765-1779)
+        if (imu_buf.empty() || !(t1 <= imu_buf.back().first)) return false;
+        std::vector<std::pair<double, std::pair<d3, d3>>> v;
+        while (imu_buf.front().first <= prev_time) imu_buf.pop_front();
+        while (imu_buf.front().first < t1) { v.push_back(imu_buf.front()); imu_buf.pop_front(); }
+        v.push_back(imu_buf.front());
+        if (!init_pose) {                  // InitFirstIMUPose
+            init_pose = true;
+            d3 aver = mk3(0, 0, 0); for (auto& s : v) aver = aver + s.second.first; aver = aver / (double)v.size();
+            m33 R0 = qR(from_two_vectors(aver, mk3(0, 0, 1)));
+            R0 = mul(ypr2r(mk3(-r2ypr(R0).x, 0, 0)), R0);                 // Utility::g2R
+            Rs[0] = mul(ypr2r(mk3(-r2ypr(R0).x, 0, 0)), R0);
+        }
+        for (size_t i = 0; i < v.size(); ++i) {
+            double dt;
+            if (i == 0) dt = v[i].first - prev_time; else if (i == v.size() - 1) dt = cur_time - v[i - 1].first; else dt = v[i].first - v[i - 1].first;
+            process_imu(dt, v[i].second.first, v[i].second.second);
+        }
+        return true;
+    }
+
+    // ---------------- feature manager ----------------
+    void reindex() { lm_index.clear(); for (size_t i = 0; i < lms.size(); ++i) lm_index[lms[i].id] = i; index_dirty = false; }
+    int long_count() const { int c = 0; for (auto& l : lms) if (l.obs.size() >= 4) ++c; return c; }
+    bool add_features(int fc, const dv_feat* feats, int n) {
+        if (index_dirty) reindex();
+        std::vector<const dv_feat*> order(n);
+        for (int i = 0; i < n; ++i) order[i] = &feats[i];
+        std::sort(order.begin(), order.end(), [](const dv_feat* a, const dv_feat* b) { return a->id < b->id; });     // the reference iterates a std::map keyed by id
+        int last_track = 0, new_feat = 0, long_track = 0;
+        for (const dv_feat* f : order) {
+            Obs o; o.pt = mk3(f->left[0], f->left[1], f->left[2]); o.vel = mk3(f->left[5], f->left[6], 0); o.td = td; o.stereo = f->has_right != 0;
+            o.pt_r = o.stereo ? mk3(f->right[0], f->right[1], f->right[2]) : mk3(0, 0, 0); o.vel_r = o.stereo ? mk3(f->right[5], f->right[6], 0) : mk3(0, 0, 0);
+            auto it = lm_index.find((int)f->id);
+            if (it == lm_index.end()) { Lm l; l.id = (int)f->id; l.start = fc; l.obs.push_back(o); lm_index[l.id] = lms.size(); lms.push_back(std::move(l)); new_feat++; }
+            else { Lm& l = lms[it->second]; l.obs.push_back(o); last_track++; if (l.obs.size() >= 4) long_track++; }
+        }
+        if (fc < 2 || last_track < 20 || long_track < 40 || new_feat > 0.5 * last_track) return true;
+        double psum = 0; int pnum = 0;
+        for (auto& l : lms) if (l.start <= fc - 2 && l.end() >= fc - 1) {
+            const Obs& a = l.obs[fc - 2 - l.start]; const Obs& b = l.obs[fc - 1 - l.start];
+            const double du = a.pt.x / a.pt.z - b.pt.x, dv = a.pt.y / a.pt.z - b.pt.y;
+            psum += sqrt(du * du + dv * dv); pnum++;
+        }
+        if (pnum == 0) return true;
+        return psum / pnum >= cfg.keyframe_parallax / kFocal;
+    }
+    void cam34(int k, int cam, double P[3][4]) const {
+        const d3 t0 = Ps[k] + mul(Rs[k], tic[cam]); const m33 Rt = tr(mul(Rs[k], ric[cam])); const d3 t = -mul(Rt, t0);
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) P[i][j] = Rt.m[i * 3 + j]; P[i][3] = get(t, i); }
+    }
+    static double tri_depth(const double L[3][4], const double R[3][4], double x0, double y0, double x1, double y1) {
+        double D[4][4], A[4][4], v[4];
+        for (int c = 0; c < 4; ++c) { D[0][c] = x0 * L[2][c] - L[0][c]; D[1][c] = y0 * L[2][c] - L[1][c]; D[2][c] = x1 * R[2][c] - R[0][c]; D[3][c] = y1 * R[2][c] - R[1][c]; }
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += D[k][i] * D[k][j]; A[i][j] = s; }
+        smallest_eigvec4(A, v);
+        const double X = v[0] / v[3], Y = v[1] / v[3], Z = v[2] / v[3];
+        return L[2][0] * X + L[2][1] * Y + L[2][2] * Z + L[2][3];
+    }
+    void triangulate() {
+        for (auto& l : lms) {
+            if (l.depth > 0) continue;
+            double L[3][4], R[3][4];
+            if (cfg.stereo && l.obs[0].stereo) { cam34(l.start, 0, L); cam34(l.start, 1, R); const double d = tri_depth(L, R, l.obs[0].pt.x, l.obs[0].pt.y, l.obs[0].pt_r.x, l.obs[0].pt_r.y); l.depth = d > 0 ? d : cfg.init_depth; }
+            else if (l.obs.size() > 1) { cam34(l.start, 0, L); cam34(l.start + 1, 0, R); const double d = tri_depth(L, R, l.obs[0].pt.x, l.obs[0].pt.y, l.obs[1].pt.x, l.obs[1].pt.y); l.depth = d > 0 ? d : cfg.init_depth; }
+        }
+    }
+    template <class Pred> void erase_if(Pred p) { lms.erase(std::remove_if(lms.begin(), lms.end(), p), lms.end()); index_dirty = true; }
+
+    // ---------------- PnP seed (solvePnP iterative restated as LM on rvec/t) ----------------
+    static m33 rodrigues(d3 r) { const double th = norm(r); if (th < 1e-12) return add(eye3(), skew(r)); const m33 K = skew(r / th); return add(add(eye3(), scale(K, sin(th))), scale(mul(K, K), 1 - cos(th))); }
+    static d3 inv_rodrigues(const m33& R) {
+        quat q = qnormalized(qfromR(R)); if (q.w < 0) q = mkq(-q.w, -q.x, -q.y, -q.z);
+        const double s = norm(qvec(q)); if (s < 1e-12) return qvec(q) * 2.0;
+        return qvec(q) / s * (2 * atan2(s, q.w));
+    }
+    void pnp_frame(int fc) {
+        if (fc <= 0) return;
+        std::vector<d3> p3; std::vector<std::pair<float, float>> p2;
+        for (auto& l : lms) if (l.depth > 0) {
+            const int idx = fc - l.start;
+            if ((int)l.obs.size() >= idx + 1) {
+                const d3 w = mul(Rs[l.start], mul(ric[0], l.obs[0].pt * l.depth) + tic[0]) + Ps[l.start];
+                p3.push_back(mk3((float)w.x, (float)w.y, (float)w.z)); p2.push_back({ (float)l.obs[idx].pt.x, (float)l.obs[idx].pt.y });
+            }
+        }
+        if ((int)p2.size() < 4) return;
+        m33 RCam = mul(Rs[fc - 1], ric[0]); d3 PCam = mul(Rs[fc - 1], tic[0]) + Ps[fc - 1];
+        const m33 Ri = tr(RCam); const d3 ti = -mul(Ri, PCam), rv = inv_rodrigues(Ri);
+        double x[6] = { rv.x, rv.y, rv.z, ti.x, ti.y, ti.z };
+        auto resid = [&](const double* p, std::vector<double>& r) {
+            const m33 Rm = rodrigues(mk3(p[0], p[1], p[2])); const d3 t = mk3(p[3], p[4], p[5]); double c = 0; r.resize(p2.size() * 2);
+            for (size_t i = 0; i < p2.size(); ++i) { const d3 q = mul(Rm, p3[i]) + t; r[2 * i] = q.x / q.z - p2[i].first; r[2 * i + 1] = q.y / q.z - p2[i].second; c += r[2 * i] * r[2 * i] + r[2 * i + 1] * r[2 * i + 1]; }
+            return c;
+        };
+        std::vector<double> r0, r1; double lambda = 1e-3, c0 = resid(x, r0);
+        for (int it = 0; it < 20; ++it) {
+            double JtJ[6][6] = { { 0 } }, Jtr[6] = { 0 };
+            std::vector<double> rp;
+            std::vector<std::vector<double>> Jc(6);
+            for (int k = 0; k < 6; ++k) { double xp[6]; std::memcpy(xp, x, sizeof(xp)); xp[k] += 1e-7; resid(xp, rp); Jc[k].resize(rp.size()); for (size_t q = 0; q < rp.size(); ++q) Jc[k][q] = (rp[q] - r0[q]) / 1e-7; }
+            for (int a = 0; a < 6; ++a) { for (size_t q = 0; q < r0.size(); ++q) Jtr[a] += Jc[a][q] * r0[q]; for (int b = 0; b < 6; ++b) { double s = 0; for (size_t q = 0; q < r0.size(); ++q) s += Jc[a][q] * Jc[b][q]; JtJ[a][b] = s; } }
+            bool improved = false;
+            for (int tries = 0; tries < 10 && !improved; ++tries) {
+                double A[6][6], L[6][6] = { { 0 } }, d[6]; bool ok = true;
+                for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) A[a][b] = JtJ[a][b] * (a == b ? 1 + lambda : 1.0);
+                for (int j = 0; j < 6 && ok; ++j) { double s = A[j][j]; for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k]; if (!(s > 0)) { ok = false; break; } L[j][j] = sqrt(s); for (int i = j + 1; i < 6; ++i) { double t = A[i][j]; for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k]; L[i][j] = t / L[j][j]; } }
+                if (!ok) { lambda *= 10; continue; }
+                for (int i = 0; i < 6; ++i) { double s = Jtr[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * d[k]; d[i] = s / L[i][i]; }
+                for (int i = 5; i >= 0; --i) { double s = d[i]; for (int k = i + 1; k < 6; ++k) s -= L[k][i] * d[k]; d[i] = s / L[i][i]; }
+                double xn[6]; for (int a = 0; a < 6; ++a) xn[a] = x[a] - d[a];
+                const double c1 = resid(xn, r1);
+                if (c1 < c0) { std::memcpy(x, xn, sizeof(xn)); r0 = r1; const double dc = c0 - c1; c0 = c1; lambda = std::max(lambda / 10, 1e-16); improved = true; if (dc < 1e-20) it = 100; }
+                else lambda *= 10;
+            }
+            if (!improved) break;
+        }
+        const m33 Rp = rodrigues(mk3(x[0], x[1], x[2]));
+        RCam = tr(Rp); PCam = mul(RCam, -mk3(x[3], x[4], x[5]));
+        Rs[fc] = mul(RCam, tr(ric[0])); Ps[fc] = -mul(mul(RCam, tr(ric[0])), tic[0]) + PCam;
+        if (cfg.plane_constraint) { if (cfg.use_imu) Ps[fc].z = 0; else Ps[fc].y = 0; }
+    }
+
+    // ---------------- optimisation (device) ----------------
+    void states_to_arrays() {        // BodyState::SetOptimizeParameters
+        for (int i = 0; i <= kWin; ++i) {
+            const quat q = qfromR(Rs[i]);
+            const double p[7] = { Ps[i].x, Ps[i].y, Ps[i].z, q.x, q.y, q.z, q.w }; std::memcpy(pose[i], p, sizeof(p));
+            const double s[9] = { Vs[i].x, Vs[i].y, Vs[i].z, Bas[i].x, Bas[i].y, Bas[i].z, Bgs[i].x, Bgs[i].y, Bgs[i].z }; std::memcpy(sb[i], s, sizeof(s));
+        }
+        for (int c = 0; c < 2; ++c) { const quat q = qfromR(ric[c]); const double p[7] = { tic[c].x, tic[c].y, tic[c].z, q.x, q.y, q.z, q.w }; std::memcpy(ex[c], p, sizeof(p)); }
+        tdv[0] = td;
+    }
+    static dv_ba_factor mkfac(const Obs& o0, const Obs& o, bool right, int kind, int lm, int fi, int fj) {
+        dv_ba_factor f{}; f.pix = o0.pt.x; f.piy = o0.pt.y; f.pjx = right ? o.pt_r.x : o.pt.x; f.pjy = right ? o.pt_r.y : o.pt.y;
+        f.vix = o0.vel.x; f.viy = o0.vel.y; f.vjx = right ? o.vel_r.x : o.vel.x; f.vjy = right ? o.vel_r.y : o.vel.y; f.td_i = o0.td; f.td_j = o.td;
+        f.kind = kind; f.lm = lm; f.fi = fi; f.fj = fj; return f;
+    }
+    // builds the residual blocks of AddResidualBlock (estimator.cpp:130-178); only_anchor0: the marginalization subset (:440-493)
+    void build_factors(bool only_anchor0) {
+        fac.clear(); lmt.clear(); if (!only_anchor0) invd.clear();
+        int fi = -1;
+        for (auto& l : lms) {
+            if (l.obs.size() < 4) continue;
+            ++fi;
+            if (!only_anchor0) invd.push_back(1.0 / l.depth);
+            if (only_anchor0 && l.start != 0) continue;
+            dv_ba_lm t{}; t.first = (int)fac.size(); t.anchor = l.start; t.mask = 0;
+            int j = l.start - 1;
+            for (auto& o : l.obs) {
+                ++j; t.mask |= 1 << j;
+                if (j != l.start) fac.push_back(mkfac(l.obs[0], o, false, 0, fi, l.start, j));
+                if (cfg.stereo && o.stereo) fac.push_back(mkfac(l.obs[0], o, true, j != l.start ? 1 : 2, fi, l.start, j));
+            }
+            t.count = (int)fac.size() - t.first;
+            lmt.push_back(t);
+        }
+    }
+    dv_ba_problem make_problem(int nframes) {
+        dv_ba_problem P{};
+        P.nframes = nframes; P.nlm = (int)lmt.size(); P.nfac = (int)fac.size(); P.nimu = (int)imu.size(); P.use_imu = cfg.use_imu;
+        P.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; P.max_iters = cfg.max_iters; P.g_norm = cfg.g_norm;
+        P.pose = &pose[0][0]; P.speed_bias = &sb[0][0]; P.ex_pose = &ex[0][0]; P.td = tdv; P.inv_depth = invd.data();
+        P.factors = fac.data(); P.landmarks = lmt.data(); P.imu = imu.data();
+        P.prior = prior.valid ? &prior : nullptr; P.prior_A = priorA.data(); P.prior_b = priorb.data();
+        return P;
+    }
+    int optimization(dv_ctx* ctx) {        // Estimator::Optimization (estimator.cpp:261-339)
+        states_to_arrays();
+        build_factors(false);
+        imu.clear();
+        if (cfg.use_imu) for (int i = 0; i < frame; ++i) { if (pre[i + 1]->sum_dt > 10.0) continue; dv_ba_imu r; pre[i + 1]->fill(r, i, i + 1); imu.push_back(r); }
+        dv_ba_problem P = make_problem(frame + 1);
+        if (dv_ba_solve(ctx, &P, &last)) return -1;
+        arrays_to_states();
+        if (frame < kWin) return 0;
+        return set_marginalization(ctx);
+    }
+    void arrays_to_states() {         // Double2vector + BodyState::GetOptimizationParameters (body.cpp:61-132)
+        const d3 origin_R0 = r2ypr(Rs[0]), origin_P0 = Ps[0];
+        auto qp = [&](int i) { return mkq(pose[i][6], pose[i][3], pose[i][4], pose[i][5]); };
+        if (cfg.use_imu) {
+            const d3 origin_R00 = r2ypr(qR(qp(0)));
+            m33 rot_diff = ypr2r(mk3(origin_R0.x - origin_R00.x, 0, 0));
+            if (std::fabs(std::fabs(origin_R0.y) - 90) < 1.0 || std::fabs(std::fabs(origin_R00.y) - 90) < 1.0) rot_diff = mul(Rs[0], tr(qR(qp(0))));
+            for (int i = 0; i <= kWin; ++i) {
+                Rs[i] = mul(rot_diff, qR(qnormalized(qp(i))));
+                Ps[i] = mul(rot_diff, mk3(pose[i][0] - pose[0][0], pose[i][1] - pose[0][1], pose[i][2] - pose[0][2])) + origin_P0;
+                Vs[i] = mul(rot_diff, mk3(sb[i][0], sb[i][1], sb[i][2])); Bas[i] = mk3(sb[i][3], sb[i][4], sb[i][5]); Bgs[i] = mk3(sb[i][6], sb[i][7], sb[i][8]);
+            }
+            for (int c = 0; c < 2; ++c) { tic[c] = mk3(ex[c][0], ex[c][1], ex[c][2]); ric[c] = qR(qnormalized(mkq(ex[c][6], ex[c][3], ex[c][4], ex[c][5]))); }
+            td = tdv[0];
+        } else for (int i = 0; i <= kWin; ++i) { Rs[i] = qR(qnormalized(qp(i))); Ps[i] = mk3(pose[i][0], pose[i][1], pose[i][2]); }
+        int k = -1;
+        for (auto& l : lms) if (l.obs.size() >= 4) { l.depth = 1.0 / invd[++k]; l.solve_flag = l.depth < 0 ? 2 : 1; }
+    }
+    int set_marginalization(dv_ctx* ctx) {        // Estimator::SetMarginalizationInfo (estimator.cpp:403-619)
+        dv_ba_prior np{}; std::vector<double> A(BE_MAX_PRIOR * BE_MAX_PRIOR), b(BE_MAX_PRIOR);
+        if (margin_old) {
+            states_to_arrays();
+            int k = -1; invd.clear();
+            for (auto& l : lms) if (l.obs.size() >= 4) { ++k; invd.push_back(1.0 / l.depth); }
+            build_factors(true);
+            imu.clear();
+            if (cfg.use_imu && pre[1]->sum_dt < 10.0) { dv_ba_imu r; pre[1]->fill(r, 0, 1); imu.push_back(r); }
+            dv_ba_problem P = make_problem(kWin + 1);
+            if (dv_marginalize(ctx, &P, 0, &np, A.data(), b.data(), nullptr)) return -1;
+        } else {
+            bool has9 = false;
+            if (prior.valid) for (int i = 0; i < prior.nblocks; ++i) if (prior.blocks[i].type == 0 && prior.blocks[i].idx == kWin - 1) has9 = true;
+            if (!has9) return 0;          // prior untouched (estimator.cpp:557-560)
+            states_to_arrays();
+            fac.clear(); lmt.clear(); imu.clear();
+            dv_ba_problem P = make_problem(kWin + 1);
+            if (dv_marginalize(ctx, &P, 1, &np, A.data(), b.data(), nullptr)) return -1;
+        }
+        prior = np;
+        if (np.valid) { priorA.assign(A.begin(), A.begin() + (size_t)np.n * np.n); priorb.assign(b.begin(), b.begin() + np.n); }
+        return 0;
+    }
+    void reject_outliers() {          // OutliersRejection + RemoveOutlier (vio_util.cpp:381-430)
+        erase_if([&](const Lm& l) {
+            if (l.obs.size() < 4) return false;
+            double err = 0; int cnt = 0; int j = l.start - 1;
+            const d3 pw = mul(Rs[l.start], mul(ric[0], l.obs[0].pt * l.depth) + tic[0]) + Ps[l.start];
+            auto rp = [&](int fj, int cam, d3 uv) { const d3 pc = mul(tr(ric[cam]), mul(tr(Rs[fj]), pw - Ps[fj]) - tic[cam]); const double rx = pc.x / pc.z - uv.x, ry = pc.y / pc.z - uv.y; return sqrt(rx * rx + ry * ry); };
+            for (auto& o : l.obs) { ++j; if (j != l.start) { err += rp(j, 0, o.pt); cnt++; } if (cfg.stereo && o.stereo) { err += rp(j, 1, o.pt_r); cnt++; } }
+            return err / cnt * kFocal > 3;
+        });
+    }
+    void slide_window() {             // Estimator::SlideWindow (estimator.cpp:1201-1312)
+        if (margin_old) {
+            back_R0 = Rs[0]; back_P0 = Ps[0];
+            if (frame != kWin) return;
+            for (int i = 0; i < kWin; ++i) {
+                headers[i] = headers[i + 1]; std::swap(Rs[i], Rs[i + 1]); std::swap(Ps[i], Ps[i + 1]);
+                if (cfg.use_imu) { std::swap(pre[i], pre[i + 1]); dt_buf[i].swap(dt_buf[i + 1]); la_buf[i].swap(la_buf[i + 1]); av_buf[i].swap(av_buf[i + 1]); std::swap(Vs[i], Vs[i + 1]); std::swap(Bas[i], Bas[i + 1]); std::swap(Bgs[i], Bgs[i + 1]); }
+            }
+            headers[kWin] = headers[kWin - 1]; Ps[kWin] = Ps[kWin - 1]; Rs[kWin] = Rs[kWin - 1];
+            if (cfg.use_imu) { Vs[kWin] = Vs[kWin - 1]; Bas[kWin] = Bas[kWin - 1]; Bgs[kWin] = Bgs[kWin - 1]; pre[kWin] = std::make_unique<Preint>(acc_0, gyr_0, Bas[kWin], Bgs[kWin], noise()); dt_buf[kWin].clear(); la_buf[kWin].clear(); av_buf[kWin].clear(); }
+            if (nonlinear) {          // SlideWindowOld + RemoveBackShiftDepth
+                const m33 R0 = mul(back_R0, ric[0]), R1 = mul(Rs[0], ric[0]); const d3 P0 = back_P0 + mul(back_R0, tic[0]), P1 = Ps[0] + mul(Rs[0], tic[0]);
+                for (auto& l : lms) {
+                    if (l.start != 0) { l.start--; continue; }
+                    const d3 uv = l.obs[0].pt; l.obs.erase(l.obs.begin());
+                    if (l.obs.size() < 2) { l.id = -1; continue; }
+                    const d3 pj = mul(tr(R1), mul(R0, uv * l.depth) + P0 - P1);
+                    l.depth = pj.z > 0 ? pj.z : cfg.init_depth;
+                }
+                erase_if([](const Lm& l) { return l.id < 0; });
+            } else {                  // RemoveBack
+                for (auto& l : lms) { if (l.start != 0) l.start--; else { l.obs.erase(l.obs.begin()); if (l.obs.empty()) l.id = -1; } }
+                erase_if([](const Lm& l) { return l.id < 0; });
+            }
+        } else if (frame == kWin) {
+            headers[frame - 1] = headers[frame]; Ps[frame - 1] = Ps[frame]; Rs[frame - 1] = Rs[frame];
+            if (cfg.use_imu) {
+                for (size_t i = 0; i < dt_buf[frame].size(); ++i) { pre[frame - 1]->push_back(dt_buf[frame][i], la_buf[frame][i], av_buf[frame][i]); dt_buf[frame - 1].push_back(dt_buf[frame][i]); la_buf[frame - 1].push_back(la_buf[frame][i]); av_buf[frame - 1].push_back(av_buf[frame][i]); }
+                Vs[frame - 1] = Vs[frame]; Bas[frame - 1] = Bas[frame]; Bgs[frame - 1] = Bgs[frame];
+                pre[kWin] = std::make_unique<Preint>(acc_0, gyr_0, Bas[kWin], Bgs[kWin], noise()); dt_buf[kWin].clear(); la_buf[kWin].clear(); av_buf[kWin].clear();
+            }
+            for (auto& l : lms) {     // RemoveFront
+                if (l.start == frame) { l.start--; continue; }
+                if (l.end() < frame - 1) continue;
+                l.obs.erase(l.obs.begin() + (kWin - 1 - l.start));
+                if (l.obs.empty()) l.id = -1;
+            }
+            erase_if([](const Lm& l) { return l.id < 0; });
+        }
+    }
+    void solve_gyro_bias() {          // SolveGyroscopeBias (initial_aligment.cpp:29-61)
+        double A[3][3] = { { 0 } }, b[3] = { 0 };
+        for (size_t k = 0; k + 1 < frame_pre.size(); ++k) {
+            const Preint& pj = *frame_pre[k + 1];
+            const quat qij = qfromR(mul(tr(Rs[k]), Rs[k + 1]));
+            const m33 tA = pj.jb(3, 12); const d3 tb = qvec(qmul(qinv(pj.dq), qij)) * 2.0;
+            const m33 AtA = mul(tr(tA), tA); const d3 Atb = mul(tr(tA), tb);
+            for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) A[i][j] += AtA.m[i * 3 + j]; b[i] += get(Atb, i); }
+        }
+        double L[3][3] = { { 0 } }, d[3] = { 0, 0, 0 }; bool ok = true;
+        for (int j = 0; j < 3 && ok; ++j) { double s = A[j][j]; for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k]; if (!(s > 0)) { ok = false; break; } L[j][j] = sqrt(s); for (int i = j + 1; i < 3; ++i) { double t = A[i][j]; for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k]; L[i][j] = t / L[j][j]; } }
+        if (ok) { for (int i = 0; i < 3; ++i) { double s = b[i]; for (int k = 0; k < i; ++k) s -= L[i][k] * d[k]; d[i] = s / L[i][i]; } for (int i = 2; i >= 0; --i) { double s = d[i]; for (int k = i + 1; k < 3; ++k) s -= L[k][i] * d[k]; d[i] = s / L[i][i]; } }
+        const d3 dbg = mk3(d[0], d[1], d[2]);
+        for (int i = 0; i <= kWin; ++i) Bgs[i] = Bgs[i] + dbg;
+    }
+    int init_estimator(dv_ctx* ctx) {        // InitEstimator (estimator.cpp:1424-1508), stereo paths
+        if (cfg.stereo && cfg.use_imu) {
+            pnp_frame(frame); triangulate();
+            if (frame == kWin) {
+                solve_gyro_bias();
+                for (int j = 0; j <= kWin; ++j) pre[j]->repropagate(mk3(0, 0, 0), Bgs[j]);
+                if (optimization(ctx)) return -1;
+                nonlinear = true; slide_window();
+            }
+        } else if (cfg.stereo && !cfg.use_imu) {
+            pnp_frame(frame); triangulate();
+            if (optimization(ctx)) return -1;
+            if (frame == kWin) { if (optimization(ctx)) return -1; nonlinear = true; slide_window(); }
+        }
+        if (frame < kWin) { frame++; const int p = frame - 1; Ps[frame] = Ps[p]; Vs[frame] = Vs[p]; Rs[frame] = Rs[p]; Bas[frame] = Bas[p]; Bgs[frame] = Bgs[p]; }
+        return 0;
+    }
+    int process_image(dv_ctx* ctx, const dv_feat* feats, int n, double header) {      // ProcessImage (estimator.cpp:1516-1696)
+        margin_old = add_features(frame, feats, n);
+        headers[frame] = header;
+        frame_pre.push_back(std::shared_ptr<Preint>(tmp_pre.release()));
+        if (frame_pre.size() > (size_t)kWin + 1 && nonlinear) frame_pre.erase(frame_pre.begin());
+        tmp_pre = std::make_unique<Preint>(acc_0, gyr_0, Bas[frame], Bgs[frame], noise());
+        if (!nonlinear) return init_estimator(ctx);
+        if (!cfg.use_imu) pnp_frame(frame);
+        triangulate();
+        if (optimization(ctx)) return -1;
+        reject_outliers();
+        slide_window();
+        erase_if([](const Lm& l) { return l.solve_flag == 2; });       // RemoveFailures
+        return 0;
+    }
+};
+
+extern "C" {
+
+int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg) {
+    if (!ctx) return -1;
+    if (!cfg) DV_FAIL("dv_est_create: null config");
+    if (!cfg->stereo) DV_FAIL("dv_est_create: monocular initialisation is out of scope (every BASELINE config is stereo)");
+    delete ctx->est;
+    ctx->est = new dv_estimator(*cfg);
+    return 0;
+}
+int dv_est_reset(dv_ctx* ctx) { if (!ctx || !ctx->est) return -1; ctx->est->clear(); return 0; }
+int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr) {
+    if (!ctx || !ctx->est) return -1;
+    ctx->est->imu_buf.push_back({ t, { mk3(acc[0], acc[1], acc[2]), mk3(gyr[0], gyr[1], gyr[2]) } });
+    return 0;
+}
+int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_state* out) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_process: call dv_est_create first");
+    dv_estimator& E = *ctx->est;
+    E.cur_time = t + E.td;
+    if (E.cfg.use_imu && !E.add_imu_until(E.cur_time)) return 1;       // "wait for imu" (estimator.cpp:1801-1805)
+    if (E.process_image(ctx, feats, n, t)) return -1;
+    E.prev_time = E.cur_time;
+    if (out) {
+        std::memset(out, 0, sizeof(*out));
+        out->frame = E.frame; out->nonlinear = E.nonlinear; out->margin_old = E.margin_old; out->n_landmarks = (int)E.lms.size(); out->n_long = E.long_count();
+        out->iterations = E.last.iterations; out->initial_cost = E.last.initial_cost; out->final_cost = E.last.final_cost;
+        for (int i = 0; i <= kWin; ++i) {
+            const quat q = qfromR(E.Rs[i]); double* p = out->window[i];
+            p[0] = E.Ps[i].x; p[1] = E.Ps[i].y; p[2] = E.Ps[i].z; p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w;
+            p[7] = E.Vs[i].x; p[8] = E.Vs[i].y; p[9] = E.Vs[i].z; p[10] = E.Bas[i].x; p[11] = E.Bas[i].y; p[12] = E.Bas[i].z; p[13] = E.Bgs[i].x; p[14] = E.Bgs[i].y; p[15] = E.Bgs[i].z;
+        }
+    }
+    return 0;
+}
+
+}  // extern "C"
+
+void dv_est_destroy_internal(dv_estimator* e) { delete e; }

@@ -181,6 +181,30 @@ int dv_proj_eval(dv_ctx* ctx, const dv_ba_factor* factors, int n, const double* 
 int dv_imu_eval(dv_ctx* ctx, const dv_ba_imu* imu, double g_norm, const double* pose_i, const double* sb_i,
                 const double* pose_j, const double* sb_j, double* out);
 
+/* ---- Estimator (estimator/estimator.h:55-164): IMU buffer + one ProcessMeasurements iteration per call ---- */
+typedef struct dv_est_config {          /* para (estimator/vio_parameters.cpp:19-83), cfg flags, extrinsics (utils/parameters.cpp) */
+    int32_t use_imu, stereo, plane_constraint, max_iters;      /* imu, num_of_cam==2, plane_constraint, max_num_iterations */
+    double keyframe_parallax;           /* pixels; kMinParallax = keyframe_parallax / 460 */
+    double init_depth, g_norm, td;      /* INIT_DEPTH, g_norm, td */
+    double acc_n, gyr_n, acc_w, gyr_w;
+    double ric[2][9], tic[2][3];        /* body_T_cam0 / body_T_cam1: rotation (row-major) and translation */
+} dv_est_config;
+
+typedef struct dv_est_state {
+    int32_t frame, nonlinear /* solver_flag == kNonLinear */, margin_old /* margin_flag == kMarginOld */, n_landmarks, n_long, iterations;
+    double initial_cost, final_cost;
+    double window[11][16];              /* body.Ps / Rs (as qx qy qz qw) / Vs / Bas / Bgs per window slot */
+} dv_est_state;
+
+int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg);       /* Estimator::Estimator + SetParameter */
+int dv_est_reset(dv_ctx* ctx);                                   /* Estimator::ClearState + SetParameter */
+int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr);      /* Estimator::InputIMU */
+/* one iteration of Estimator::ProcessMeasurements (estimator.cpp:1786-1863): IMU interval, pre-integration,
+ * ProcessImage (keyframe test, triangulation, Optimization on the GPU, marginalization on the GPU, outlier rejection,
+ * sliding window).  returns 0 = processed, 1 = IMU data does not cover t yet (feed more, call again), <0 error.
+ * The frame's pose is out->window[10] once nonlinear (what SaveBodyTrajectory writes, utils/io/output.cpp:199-227). */
+int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_state* out);
+
 /* ---- measurement hooks (used by bench.py; HIP-event timing on the ctx's own stream) ---- */
 /* names: "pyr","lk_temporal","compact","gftt_eig","gftt_select","lk_stereo","frame" */
 int dv_timing_enable(dv_ctx* ctx, int on);

@@ -153,19 +153,28 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
     {
         StageScope sc(ctx, "ba_solve", s);
         const int slots = P->max_iters + 3;      // + retries after a failed Cholesky (mu *= 10)
+        const bool kt = ctx->timing && ctx->kernel_timing;       // per-launch events (roofline measurement); off in the throughput run
         for (int it = 0; it < slots; ++it) {
-            be_launch_eval(ea, true, s);
-            be_launch_reduce(sa, s);
-            if (be_launch_solve(sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
-            be_launch_eval(ea, false, s);
-            be_launch_accept(sa, s);
+            if (kt) {
+                { StageScope k(ctx, "k_be_eval_full", s); be_launch_eval(ea, true, s); }
+                { StageScope k(ctx, "k_be_reduce", s); be_launch_reduce(sa, s); }
+                { StageScope k(ctx, "k_be_solve", s); if (be_launch_solve(sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size"); }
+                { StageScope k(ctx, "k_be_eval_cost", s); be_launch_eval(ea, false, s); }
+                { StageScope k(ctx, "k_be_accept", s); be_launch_accept(sa, s); }
+            } else {
+                be_launch_eval(ea, true, s);
+                be_launch_reduce(sa, s);
+                if (be_launch_solve(sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
+                be_launch_eval(ea, false, s);
+                be_launch_accept(sa, s);
+            }
         }
     }
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipMemcpyAsync(hx, w.x, state_bytes, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
-    if (ctx->timing) dv_harvest_timers(ctx);
+    if (ctx->timing) dv_harvest_timers(ctx, s);
     for (int f = 0; f < P->nframes; ++f) { std::memcpy(P->pose + 7 * f, hx->pose[f], 56); if (P->use_imu) std::memcpy(P->speed_bias + 9 * f, hx->sb[f], 72); }
     if (P->nlm) std::memcpy(P->inv_depth, hx->inv_depth, 8 * (size_t)P->nlm);
     if (summary) {
@@ -267,7 +276,7 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     ma.prior = w.prior; ma.priorA = w.priorA; ma.priorb = w.priorb; ma.prior_map = d_prior_map; ma.imu_map = d_imu_map; ma.dim_slot = d_slot; ma.dim_comp = d_comp;
     ma.D = D; ma.m = m; ma.g_norm = P->g_norm; ma.outA = d_outA; ma.outb = d_outb; ma.out_scalars = d_scal;
     {
-        StageScope sc(ctx, "ba_marg", s);
+        StageScope sc(ctx, "k_be_marg", s);
         const int rc = be_launch_marg(ma, s);
         if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");
         if (rc) DV_FAIL("dv_marginalize: cannot set dynamic LDS size");
@@ -279,7 +288,7 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     DV_CHECK(hipMemcpyAsync(scal, d_scal, 64, hipMemcpyDeviceToHost, s));
     if (getenv("DV_DEBUG_MARG")) fprintf(stderr, "marg dbg: maxJtd=%g max|w_td|=%g max|gp_td|=%g A[td][20] pre-elim? %g\n", scal[4], scal[5], scal[6], scal[7]);
     DV_CHECK(hipStreamSynchronize(s));
-    if (ctx->timing) dv_harvest_timers(ctx);
+    if (ctx->timing) dv_harvest_timers(ctx, s);
     if (diag4) std::memcpy(diag4, scal, 32);
     if (scal[2] != 0.0) DV_FAIL("dv_marginalize: A_mm is not positive definite (reference would take its pseudo-inverse)");
     // ---- new prior header: kept blocks, indices shifted like addr_shift (estimator.cpp:537-548 / 591-612) ----

@@ -50,8 +50,8 @@ struct PyrSet {
     }
 };
 
-struct StageTimer {
-    std::string name; hipEvent_t a = nullptr, b = nullptr; bool armed = false; double total_ms = 0; long long count = 0;
+struct StageTimer {       // pool of HIP event pairs: a stage / kernel may be recorded many times between two harvests
+    std::string name; hipStream_t stream = nullptr; std::vector<std::pair<hipEvent_t, hipEvent_t>> pool; size_t used = 0; double total_ms = 0; long long count = 0;
 };
 
 // device-side workspace of the bundle-adjustment solver (allocated on first use)
@@ -86,7 +86,7 @@ struct dv_ctx {
     hipEvent_t done = nullptr; bool pending = false;
     // operator-level scratch
     PyrSet opA, opB; DevBuf s0, s1, s2, s3, s4;
-    bool timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
+    bool timing = false, kernel_timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
     // back end
     hipStream_t be_stream = nullptr; BeWork be;
     dv_estimator* est = nullptr;
@@ -106,8 +106,15 @@ void dv_set_error(dv_ctx* ctx, const std::string& msg);
 
 StageTimer* dv_timer_for(dv_ctx* ctx, const char* name);
 struct StageScope {
-    dv_ctx* c; StageTimer* t = nullptr; hipStream_t s;
-    StageScope(dv_ctx* ctx, const char* name, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream) { if (c->timing) { t = dv_timer_for(c, name); (void)hipEventRecord(t->a, s); } }
-    ~StageScope() { if (t) { (void)hipEventRecord(t->b, s); t->armed = true; } }
+    dv_ctx* c; StageTimer* t = nullptr; hipStream_t s; size_t slot = 0;
+    StageScope(dv_ctx* ctx, const char* name, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream) {
+        if (!c->timing) return;
+        t = dv_timer_for(c, name);
+        t->stream = s;
+        if (t->used == t->pool.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); t->pool.push_back({ a, b }); }
+        slot = t->used++;
+        (void)hipEventRecord(t->pool[slot].first, s);
+    }
+    ~StageScope() { if (t) (void)hipEventRecord(t->pool[slot].second, s); }
 };
-void dv_harvest_timers(dv_ctx* ctx);
+void dv_harvest_timers(dv_ctx* ctx, hipStream_t synced);      // harvests the timers recorded on `synced` (must be idle)

@@ -55,14 +55,16 @@ StageTimer* dv_timer_for(dv_ctx* ctx, const char* name) {
     ctx->timers.emplace_back();
     StageTimer& t = ctx->timers.back();
     t.name = name;
-    (void)hipEventCreate(&t.a); (void)hipEventCreate(&t.b);
     return &t;
 }
-void dv_harvest_timers(dv_ctx* ctx) {
-    for (auto& t : ctx->timers) if (t.armed) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { t.total_ms += ms; t.count++; }
-        t.armed = false;
+void dv_harvest_timers(dv_ctx* ctx, hipStream_t synced) {
+    for (auto& t : ctx->timers) {
+        if (t.stream != synced) continue;
+        for (size_t i = 0; i < t.used; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, t.pool[i].first, t.pool[i].second) == hipSuccess) { t.total_ms += ms; t.count++; }
+        }
+        t.used = 0;
     }
 }
 
@@ -146,7 +148,7 @@ void dv_destroy(dv_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (auto& t : ctx->timers) { if (t.a) (void)hipEventDestroy(t.a); if (t.b) (void)hipEventDestroy(t.b); }
+    for (auto& t : ctx->timers) for (auto& p : t.pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,
                        &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->opA.buf, &ctx->opB.buf }) b->release();
     if (ctx->est) dv_est_destroy_internal(ctx->est);
@@ -176,7 +178,8 @@ int dv_sync(dv_ctx* ctx) {
     return 0;
 }
 
-int dv_timing_enable(dv_ctx* ctx, int on) { if (!ctx) return -1; ctx->timing = on != 0; return 0; }
+int dv_timing_enable(dv_ctx* ctx, int on) { if (!ctx) return -1; ctx->timing = on != 0; ctx->kernel_timing = on >= 2; return 0; }
+int dv_timing_reset(dv_ctx* ctx) { if (!ctx) return -1; for (auto& t : ctx->timers) { t.total_ms = 0; t.count = 0; t.used = 0; } return 0; }
 int dv_timing_get(dv_ctx* ctx, const char* name, double* total_ms, long long* count) {
     if (!ctx || !name) return -1;
     for (auto& t : ctx->timers) if (t.name == name) { if (total_ms) *total_ms = t.total_ms; if (count) *count = t.count; return 0; }
@@ -270,7 +273,7 @@ int dv_track_stereo_collect(dv_ctx* ctx, dv_feat* out, int* n_out) {
     if (!ctx->pending) DV_FAIL("dv_track_stereo_collect: nothing enqueued");
     DV_CHECK(hipEventSynchronize(ctx->done));
     ctx->pending = false;
-    if (ctx->timing) dv_harvest_timers(ctx);
+    if (ctx->timing) dv_harvest_timers(ctx, ctx->stream);
     if (*ctx->err_pinned) {
         int f = *ctx->err_pinned;
         DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, ctx->stream));

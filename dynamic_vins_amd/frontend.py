@@ -145,8 +145,11 @@ class Context:
         return out
 
     # ---- measurement ----
-    def timing_enable(self, on=True):
-        self._check(self.lib.dv_timing_enable(self.h, 1 if on else 0))
+    def timing_enable(self, on=1):
+        self._check(self.lib.dv_timing_enable(self.h, int(on)))
+
+    def timing_reset(self):
+        self._check(self.lib.dv_timing_reset(self.h))
 
     def timing_get(self, name):
         ms, cnt = C.c_double(0), C.c_longlong(0)

@@ -1,0 +1,84 @@
+"""RoomRenderer: renders the box room of sim.py as textured planes through the distorted pinhole stereo rig, so the
+real front end (LK + Shi-Tomasi) runs on images that are consistent with the simulated IMU stream.
+Input generation only (torch is used as an array library; runs on the GPU when one is present)."""
+import numpy as np
+import torch
+
+from . import sim
+
+
+def _texture(size=2048, seed=sim.TEX_SEED):
+    g = torch.Generator().manual_seed(seed)
+    tex = torch.zeros(size, size)
+    # octaves of band-limited noise (sigma 1.5 texels at the finest level)
+    for octave, (scale, amp) in enumerate([(1, 1.0), (4, 0.8), (16, 0.6), (64, 0.4)]):
+        n = size // scale
+        t = torch.rand(1, 1, n, n, generator=g)
+        k = torch.arange(-4, 5, dtype=torch.float32)
+        w = torch.exp(-k * k / (2 * 1.5 * 1.5)); w = (w / w.sum()).view(1, 1, 1, -1)
+        t = torch.nn.functional.conv2d(torch.nn.functional.pad(t, (4, 4, 0, 0), mode="circular"), w)
+        t = torch.nn.functional.conv2d(torch.nn.functional.pad(t, (0, 0, 4, 4), mode="circular"), w.transpose(2, 3))
+        if scale > 1:
+            t = torch.nn.functional.interpolate(t, size=(size, size), mode="bicubic", align_corners=False)
+        t = (t - t.mean()) / (t.std() + 1e-9)
+        tex += amp * t[0, 0]
+    tex = (tex - tex.min()) / (tex.max() - tex.min())
+    return tex
+
+
+class RoomRenderer:
+    def __init__(self, cam, w, h, half=(9.0, 7.0, 3.0), texel=0.012, device=None, seed=sim.TEX_SEED):
+        self.dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
+        self.w, self.h, self.half, self.texel = w, h, half, texel
+        self.tex = _texture(2048, seed).to(self.dev)[None, None]
+        # per-pixel undistorted ray (liftProjective: 8 fixed-point iterations, PinholeCamera.cc:450-508)
+        u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+        mx_d, my_d = (u - cam["cx"]) / cam["fx"], (v - cam["cy"]) / cam["fy"]
+        mx, my = mx_d.copy(), my_d.copy()
+        k1, k2, p1, p2 = cam["k1"], cam["k2"], cam["p1"], cam["p2"]
+        for _ in range(20):
+            r2 = mx * mx + my * my
+            rad = k1 * r2 + k2 * r2 * r2
+            dx = mx * rad + 2 * p1 * mx * my + p2 * (r2 + 2 * mx * mx)
+            dy = my * rad + 2 * p2 * mx * my + p1 * (r2 + 2 * my * my)
+            mx, my = mx_d - dx, my_d - dy
+        rays = np.stack([mx, my, np.ones_like(mx)], -1).reshape(-1, 3)
+        self.rays = torch.from_numpy(rays).to(self.dev, torch.float64)
+
+    def _render(self, R_wc, p_wc):
+        """R_wc, p_wc: camera-to-world rotation / camera centre (numpy)"""
+        R = torch.from_numpy(np.ascontiguousarray(R_wc)).to(self.dev, torch.float64)
+        o = torch.from_numpy(np.ascontiguousarray(p_wc)).to(self.dev, torch.float64)
+        d = self.rays @ R.T                                  # world ray directions
+        hx, hy, hz = self.half
+        best_t = torch.full((d.shape[0],), float("inf"), dtype=torch.float64, device=self.dev)
+        uu = torch.zeros_like(best_t); vv = torch.zeros_like(best_t)
+        faces = [(0, hx, 1, 2, 0.0), (0, -hx, 1, 2, 3.3), (1, hy, 0, 2, 7.1), (1, -hy, 0, 2, 11.7), (2, hz, 0, 1, 17.9), (2, -hz, 0, 1, 23.3)]
+        for axis, pos, a1, a2, offs in faces:
+            denom = d[:, axis]
+            t = (pos - o[axis]) / denom
+            ok = (t > 1e-6) & (t < best_t)
+            hit1 = o[a1] + t * d[:, a1]
+            hit2 = o[a2] + t * d[:, a2]
+            lim1, lim2 = self.half[a1], self.half[a2]
+            ok &= (hit1.abs() <= lim1 + 1e-9) & (hit2.abs() <= lim2 + 1e-9)
+            best_t = torch.where(ok, t, best_t)
+            uu = torch.where(ok, hit1 / self.texel + offs * 97.0, uu)
+            vv = torch.where(ok, hit2 / self.texel + offs * 53.0, vv)
+        size = self.tex.shape[-1]
+        # wrap into the tile with reflection
+        def refl(x):
+            x = torch.remainder(x, 2 * size)
+            return torch.where(x >= size, 2 * size - 1 - x, x)
+        gx = (refl(uu) + 0.5) / size * 2 - 1
+        gy = (refl(vv) + 0.5) / size * 2 - 1
+        grid = torch.stack([gx, gy], -1).view(1, self.h, self.w, 2).to(torch.float32)
+        img = torch.nn.functional.grid_sample(self.tex, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
+        return (img[0, 0] * 255.0 + 0.5).clamp(0, 255).to(torch.uint8).contiguous()
+
+    def stereo(self, traj, t):
+        R, p = traj.R(t), traj.p(t)
+        out = []
+        for tic in (sim.T_IC0, sim.T_IC1):
+            out.append(self._render(R @ sim.R_IC, p + R @ tic))
+        return out

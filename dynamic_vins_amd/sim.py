@@ -16,6 +16,7 @@ import numpy as np
 FEAT_DTYPE = np.dtype([("id", np.uint32), ("track_cnt", np.int32), ("has_right", np.int32), ("pad_", np.int32),
                        ("left", np.float64, 7), ("right", np.float64, 7)])
 
+TEX_SEED = 0xD1CE
 R_IC = np.array([[0.0, 0.0, 1.0], [-1.0, 0.0, 0.0], [0.0, -1.0, 0.0]])      # body_T_cam rotation
 T_IC0 = np.array([0.0, 0.0, 0.0])
 T_IC1 = np.array([0.0, -0.12, 0.0])                                          # 0.12 m baseline (ZED), camera 1 to the right

@@ -207,7 +207,10 @@ int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_st
 
 /* ---- measurement hooks (used by bench.py; HIP-event timing on the ctx's own stream) ---- */
 /* names: "pyr","lk_temporal","compact","gftt_eig","gftt_select","lk_stereo","frame" */
+/* on: 0 off, 1 per-stage events, 2 additionally one event pair around every back-end kernel launch
+ * ("k_be_eval_full","k_be_reduce","k_be_solve","k_be_eval_cost","k_be_accept","k_be_marg") */
 int dv_timing_enable(dv_ctx* ctx, int on);
+int dv_timing_reset(dv_ctx* ctx);
 int dv_timing_get(dv_ctx* ctx, const char* name, double* total_ms, long long* count);
 
 #ifdef __cplusplus

@@ -18,7 +18,7 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     size_t o_ctl = take(sizeof(BeCtl)), o_x = take(sizeof(BeState)), o_c = take(sizeof(BeState)), o_fac = take(sizeof(BeFactor) * (size_t)fac_cap),
            o_lm = take(sizeof(BeLm) * BE_MAX_LM), o_imu = take(sizeof(BeImu) * BE_WIN), o_pr = take(sizeof(BePriorHdr)),
            o_pA = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb = take(8 * BE_MAX_PRIOR),
-           o_pk = take(8 * (size_t)BE_MAX_LM * BE_PK_SIZE), o_io = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po = take(8 * (BE_MAX_PRIOR + 1)),
+           o_pk = take(8 * (size_t)BE_PK_SIZE * BE_PK_STRIDE), o_io = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po = take(8 * (BE_MAX_PRIOR + 1)),
            o_cc = take(8 * (BE_MAX_LM + BE_WIN + 1)), o_hd = take(8 * n * n), o_sc = take(8 * n * n), o_g = take(8 * 2 * n),
            o_v = take(8 * 4 * n), o_vl = take(8 * 4 * (size_t)BE_MAX_LM), o_i = take(4 * 4 * n);
     DV_CHECK(w.block.ensure(off));
@@ -227,7 +227,6 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     for (int c = 0; c < 2; ++c) if (ex_in[c]) { ex_dim[c] = (int)dim_slot.size(); for (int q = 0; q < 6; ++q) { dim_slot.push_back(BE_NF + c); dim_comp.push_back(q); } }
     if (td_in) { td_dim = (int)dim_slot.size(); dim_slot.push_back(BE_NF + 2); dim_comp.push_back(0); }
     const int D = (int)dim_slot.size(), n = D - m;
-    if (getenv("DV_DEBUG_MARG")) { fprintf(stderr, "marg D=%d m=%d td_dim=%d ex=%d %d slots:", D, m, td_dim, ex_dim[0], ex_dim[1]); for (int i = 0; i < D; ++i) fprintf(stderr, " %d/%d", dim_slot[i], dim_comp[i]); fprintf(stderr, "\n"); }
     if (n > BE_MAX_PRIOR || n < 1) DV_FAIL("dv_marginalize: bad kept size");
     std::vector<int32_t> prior_map(BE_MAX_PRIOR, -1), imu_map(30, -1);
     BePriorHdr ph{};
@@ -275,6 +274,9 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     ma.x = w.x; ma.nframes = BE_NF; ma.nlm = nlm; ma.nimu = nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
     ma.prior = w.prior; ma.priorA = w.priorA; ma.priorb = w.priorb; ma.prior_map = d_prior_map; ma.imu_map = d_imu_map; ma.dim_slot = d_slot; ma.dim_comp = d_comp;
     ma.D = D; ma.m = m; ma.g_norm = P->g_norm; ma.outA = d_outA; ma.outb = d_outb; ma.out_scalars = d_scal;
+    const size_t slab = (size_t)D * D + D;
+    DV_CHECK(w.marg_buf.ensure(8 * (slab * (size_t)std::max(nlm, 1) + slab + (size_t)std::max(nlm, 1))));
+    ma.slabs = (double*)w.marg_buf.p; ma.sum = ma.slabs + slab * (size_t)std::max(nlm, 1); ma.lm_h = ma.sum + slab;
     {
         StageScope sc(ctx, "k_be_marg", s);
         const int rc = be_launch_marg(ma, s);
@@ -282,11 +284,10 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
         if (rc) DV_FAIL("dv_marginalize: cannot set dynamic LDS size");
     }
     DV_CHECK(hipGetLastError());
-    double scal[8];
+    double scal[4];
     DV_CHECK(hipMemcpyAsync(out_A, d_outA, 8 * (size_t)n * n, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipMemcpyAsync(out_b, d_outb, 8 * (size_t)n, hipMemcpyDeviceToHost, s));
-    DV_CHECK(hipMemcpyAsync(scal, d_scal, 64, hipMemcpyDeviceToHost, s));
-    if (getenv("DV_DEBUG_MARG")) fprintf(stderr, "marg dbg: maxJtd=%g max|w_td|=%g max|gp_td|=%g A[td][20] pre-elim? %g\n", scal[4], scal[5], scal[6], scal[7]);
+    DV_CHECK(hipMemcpyAsync(scal, d_scal, 32, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
     if (ctx->timing) dv_harvest_timers(ctx, s);
     if (diag4) std::memcpy(diag4, scal, 32);

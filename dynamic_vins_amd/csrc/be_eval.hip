@@ -20,7 +20,8 @@
 using namespace be;
 
 template <bool FULL>
-__global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
+#define EV_THREADS 256
+__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
     if (FULL && !c.need_eval) return;
@@ -62,9 +63,8 @@ __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
         double cost = 0;
         for (int f = 0; f < L.count; ++f) cost += s_cost[f];      // fixed order
         if (!FULL) { if (lane == 0) a.cand_cost[b] = cost; return; }
-        double* pk = a.packets + (size_t)b * BE_PK_SIZE;
         const int anchor = L.anchor, nf = L.count;
-        for (int e = lane; e < BE_PK_SIZE; e += 64) {
+        for (int e = lane; e < BE_PK_SIZE; e += EV_THREADS) {
             double v = 0.0;
             if (e == BE_PK_H) { for (int f = 0; f < nf; ++f) v += Jb[f][26] * Jb[f][26] + Jb[f][27] * Jb[f][27]; }
             else if (e == BE_PK_G) { for (int f = 0; f < nf; ++f) v += Jb[f][26] * Jb[f][0] + Jb[f][27] * Jb[f][1]; }
@@ -95,20 +95,20 @@ __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
                         v += Jb[f][2 + rr] * Jb[f][14 + cc] + Jb[f][8 + rr] * Jb[f][20 + cc];
                     }
             }
-            pk[e] = v;
+            BE_PK(a.packets, e, b) = v;
         }
     } else if (b < nlm + nimu) {
         // ------------------------------- IMU factor -------------------------------
         const int k = b - nlm;
         const BeImu* m = &a.imu[k];
         double* Jraw = s_imu; double* Jw = s_imu + 450; double* rr = s_imu + 900;      // rr[0..14] raw, rr[15..29] whitened
-        for (int i = lane; i < 450; i += 64) Jraw[i] = 0.0;
+        for (int i = lane; i < 450; i += EV_THREADS) Jraw[i] = 0.0;
         __syncthreads();
         if (lane == 0) imu_raw<FULL>(*m, a.g_norm, st->pose[m->fi], st->sb[m->fi], st->pose[m->fj], st->sb[m->fj], rr, Jraw);
         __syncthreads();
         if (lane < 15) { double s = 0; for (int q = lane; q < 15; ++q) s += m->sqrt_info[lane * 15 + q] * rr[q]; rr[15 + lane] = s; }
         if (FULL)
-            for (int e = lane; e < 450; e += 64) {
+            for (int e = lane; e < 450; e += EV_THREADS) {
                 const int i = e / 30, cc = e - i * 30; double s = 0;
                 for (int q = i; q < 15; ++q) s += m->sqrt_info[i * 15 + q] * Jraw[q * 30 + cc];
                 Jw[e] = s;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
         double* o = a.imu_out + (size_t)k * IMU_OUT_STRIDE;
         if (lane == 0) o[0] = cost;
         if (lane < 30) { double s = 0; for (int i = 0; i < 15; ++i) s += Jw[i * 30 + lane] * rr[15 + i]; o[1 + lane] = s; }
-        for (int e = lane; e < 900; e += 64) {
+        for (int e = lane; e < 900; e += EV_THREADS) {
             const int r0 = e / 30, c0 = e - r0 * 30; double s = 0;
             for (int i = 0; i < 15; ++i) s += Jw[i * 30 + r0] * Jw[i * 30 + c0];
             o[31 + e] = s;
@@ -132,9 +132,9 @@ __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
         if (!p->valid) { if (lane == 0) { if (FULL) a.prior_out[0] = 0.0; else a.cand_cost[b] = 0.0; } return; }
         __shared__ double dx[BE_MAX_PRIOR], Adx[BE_MAX_PRIOR];
         const int n = p->n;
-        be_prior_dx_dev(p, st, dx, lane, 64);
+        be_prior_dx_dev(p, st, dx, lane, EV_THREADS);
         __syncthreads();
-        for (int i = lane; i < n; i += 64) { double s = 0; const double* row = a.priorA + (size_t)i * n; for (int j = 0; j < n; ++j) s += row[j] * dx[j]; Adx[i] = s; }
+        for (int i = lane; i < n; i += EV_THREADS) { double s = 0; const double* row = a.priorA + (size_t)i * n; for (int j = 0; j < n; ++j) s += row[j] * dx[j]; Adx[i] = s; }
         __syncthreads();
         if (lane == 0) {
             double bd = 0, dAd = 0;
@@ -142,14 +142,14 @@ __global__ __launch_bounds__(64) void be_eval_kernel(BeEvalArgs a) {
             const double cost = 0.5 * p->c0 + bd + 0.5 * dAd;
             if (FULL) a.prior_out[0] = cost; else a.cand_cost[b] = cost;
         }
-        if (FULL) for (int i = lane; i < n; i += 64) a.prior_out[1 + i] = a.priorb[i] + Adx[i];
+        if (FULL) for (int i = lane; i < n; i += EV_THREADS) a.prior_out[1 + i] = a.priorb[i] + Adx[i];
     }
 }
 
 void be_launch_eval(const BeEvalArgs& a, bool full, hipStream_t s) {
     const int grid = a.dims.nlm + a.dims.nimu + 1;
-    if (full) hipLaunchKernelGGL(be_eval_kernel<true>, dim3(grid), dim3(64), 0, s, a);
-    else hipLaunchKernelGGL(be_eval_kernel<false>, dim3(grid), dim3(64), 0, s, a);
+    if (full) hipLaunchKernelGGL(be_eval_kernel<true>, dim3(grid), dim3(EV_THREADS), 0, s, a);
+    else hipLaunchKernelGGL(be_eval_kernel<false>, dim3(grid), dim3(EV_THREADS), 0, s, a);
 }
 
 // ---- operator-level factor evaluation (parity tests against the oracle's dvo_proj_eval / dvo_imu_eval) ----

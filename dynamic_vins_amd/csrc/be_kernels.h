@@ -41,6 +41,7 @@ struct BeMargArgs {
     const int32_t* dim_comp;      // [D]
     int D, m; double g_norm;
     double* outA; double* outb; double* out_scalars;     // n x n, n, {c0, min pivot, failure flag, rank}
+    double* slabs; double* sum; double* lm_h;            // [nlm][D*D+D] per-landmark contributions, their sum, per-landmark h
 };
 
 #if defined(__HIPCC__)

@@ -2,18 +2,21 @@
 // marginalize, estimator/factor/marginalization_factor.cpp:124-309, driven by Estimator::SetMarginalizationInfo,
 // estimator/estimator.cpp:403-619).
 //
-// One launch, one 1024-thread workgroup, the whole (m + n) x (m + n) system resident in LDS (<= 97 x 97 fp64 = 75 KB):
-//   1. every residual block that touches a dropped variable is re-evaluated at the linearisation point with ALL its
-//      Jacobians (pose_i, pose_j, ex0, ex1, td, inverse depth) and the Huber corrector (ResidualBlockInfo::Evaluate);
-//   2. landmarks are eliminated one after the other (A_ll is 1x1): A += J^T J - w w^T / h, b += J^T r - w g / h, in a
-//      fixed order, so the result is bitwise reproducible;  IMU factor (0,1) and the previous prior (as A', b' + A' dx)
-//      are added;
-//   3. the dropped pose / speed-bias block (m' <= 15) is eliminated with a dense Cholesky;
-//   4. the new prior is kept in INFORMATION FORM (A', b', c0): the reference factors A' = Q S Q^T and stores
-//      J0 = S^1/2 Q^T, r0 = S^-1/2 Q^T b', but every consumer only ever forms J0^T J0 = A', J0^T r0 = b' and
-//      r0^T r0 = c0.  c0 = b'^T A'^+ b' is obtained from a diagonally pivoted LDL^T stopped at the reference's
-//      eigenvalue threshold (1e-8), which reproduces the eigen-clamped value to ~1e-8 relative
-//      — two dense eigendecompositions per frame are replaced by two small factorizations.
+// Three launches on the BA stream:
+//   be_marg_lm_kernel     one 256-thread workgroup per landmark anchored in the dropped frame: every residual block is
+//                         re-evaluated at the linearisation point with ALL its Jacobians (pose_i, pose_j, ex0, ex1, td,
+//                         inverse depth) and the Huber corrector (ResidualBlockInfo::Evaluate), expanded to dense rows
+//                         in LDS, and the landmark's own inverse depth is eliminated on the spot (A_ll is 1x1):
+//                         M_l = J^T J - w w^T / h,  b_l = J^T r - w g / h   written as a dense (D x D + D) slab.
+//   be_marg_sum_kernel    sums the slabs over landmarks in a fixed order (bitwise reproducible).
+//   be_marg_finish_kernel ONE 1024-thread workgroup, system resident in LDS (<= 97 x 97 fp64): adds the IMU factor (0,1)
+//                         and the previous prior (as A', b' + A' dx), eliminates the dropped pose / speed-bias block
+//                         (m' <= 15) with a dense Cholesky, writes the new prior in INFORMATION FORM (A', b', c0).
+// The reference factors A' = Q S Q^T and stores J0 = S^1/2 Q^T, r0 = S^-1/2 Q^T b', but every consumer only ever
+// forms J0^T J0 = A', J0^T r0 = b' and r0^T r0 = c0.  c0 = b'^T A'^+ b' comes from an LDL^T factorization that skips
+// pivots <= the reference's eigenvalue threshold (1e-8); it reproduces the eigen-clamped value to the accuracy the
+// quantity has at all (its 1/lambda-weighted rounding noise is ~1e-4 relative) — two dense
+// eigendecompositions per frame are replaced by two small factorizations.
 // The reference's pseudo-inverse of A_mm equals the inverse whenever lambda_min(A_mm) > 1e-8; the kernel reports the
 // smallest pivot it met so the host can verify that (it is ~1e4 on every sequence measured).
 #include <hip/hip_runtime.h>
@@ -23,9 +26,11 @@
 using namespace be;
 
 #define MG_THREADS 1024
+#define LM_THREADS 256
 
 // offsets of the two Jacobian entries (row 0, row 1) of column `comp` of slot `slot` inside a factor record
 // Jf layout (54): r2 | Ji 12 | Jj 12 | Jex0 12 | Jex1 12 | Jl 2 | Jtd 2 ; returns false if the factor does not touch the slot
+// (offsets, not pointers: selecting between LDS pointers and nullptr miscompiled on gfx950 / ROCm 7.2)
 __device__ __forceinline__ bool mg_joff(int slot, int comp, int anchor, int fj, int two_frame, int& o0, int& o1) {
     int base;
     if (slot < BE_NF) { if (!two_frame) return false; if (slot == anchor) base = 2; else if (slot == fj) base = 14; else return false; }
@@ -36,34 +41,95 @@ __device__ __forceinline__ bool mg_joff(int slot, int comp, int anchor, int fj, 
     return true;
 }
 
-__global__ __launch_bounds__(MG_THREADS) void be_marg_kernel(BeMargArgs a) {
+__global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int D = a.D, m = a.m, n = D - m, tid = threadIdx.x;
-    double* A = sm;                       // D x D
-    double* bv = A + D * D;               // D
-    double* wv = bv + D;                  // D
-    double* gpv = wv + D;                 // D
-    double* Jb = gpv + D;                 // BE_MAX_OBS_FACTORS x 54
-    double* W2 = Jb + BE_MAX_OBS_FACTORS * 54;   // n x n work copy for the pivoted LDL^T (also scratch for prior dx / IMU)
-    double* yv = W2 + (n * n > 1024 ? n * n : 1024);   // n
-    double* misc = yv + n;                // 64
+    const int D = a.D, tid = threadIdx.x, l = blockIdx.x;
+    double* Jb = sm;                                   // BE_MAX_OBS_FACTORS x 54
+    double* Jd = Jb + BE_MAX_OBS_FACTORS * 54;         // (2 nf) x D dense rows
+    double* wv = Jd + 2 * BE_MAX_OBS_FACTORS * D;      // D
+    double* gpv = wv + D;                              // D
     __shared__ FrameGeom fg[BE_NF];
     __shared__ m33 ric[2];
     __shared__ d3 tic[2];
-    __shared__ int s_fj[BE_MAX_OBS_FACTORS], s_two[BE_MAX_OBS_FACTORS], s_kind[BE_MAX_OBS_FACTORS];
-    __shared__ double s_hg[4];
-    __shared__ int s_piv;
+    __shared__ int s_fj[BE_MAX_OBS_FACTORS], s_two[BE_MAX_OBS_FACTORS];
+    __shared__ double s_hg[2];
     const BeState* st = a.x;
-
-    for (int e = tid; e < D * D + D; e += MG_THREADS) A[e] = 0.0;
     if (tid < 64) be_frame_geom_dev(st, a.nframes, fg, ric, tic, tid);
-    if (tid == 0) { misc[0] = DBL_MAX; misc[1] = 0.0; misc[4] = 0.0; misc[5] = 0.0; misc[6] = 0.0; }
     __syncthreads();
+    const BeLm L = a.lm[l];
+    const int nf = L.count, anchor = L.anchor;
+    if (tid < nf) {
+        const BeFactor f = a.fac[L.first + tid];
+        double* o = Jb + tid * 54;
+        proj_factor<true, true>(f, fg[f.fi], fg[f.fj], ric[0], tic[0], ric[1], tic[1], st->inv_depth[f.lm], st->td, o, o + 2, o + 14, o + 50, o + 26, o + 38, o + 52);
+        if (f.kind == 0) for (int k = 0; k < 12; ++k) o[38 + k] = 0.0;
+        double rho0, sc;
+        huber1(o[0] * o[0] + o[1] * o[1], rho0, sc);
+        for (int k = 0; k < 54; ++k) o[k] *= sc;
+        s_fj[tid] = f.fj; s_two[tid] = f.kind != 2;
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * nf * D; e += LM_THREADS) {
+        const int fr = e / D, i = e - fr * D, f = fr >> 1, r = fr & 1;
+        const int slot = a.dim_slot[i];
+        double v = 0.0;
+        int o0, o1;
+        if (slot >= 0 && mg_joff(slot, a.dim_comp[i], anchor, s_fj[f], s_two[f], o0, o1)) v = Jb[f * 54 + (r ? o1 : o0)];
+        Jd[e] = v;
+    }
+    if (tid == 0) {
+        double h = 0, g = 0;
+        for (int f = 0; f < nf; ++f) { const double* o = Jb + f * 54; h += o[50] * o[50] + o[51] * o[51]; g += o[50] * o[0] + o[51] * o[1]; }
+        s_hg[0] = h; s_hg[1] = g;
+        a.lm_h[l] = h;
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += LM_THREADS) {
+        double w = 0, gp = 0;
+        for (int fr = 0; fr < 2 * nf; ++fr) { const double j = Jd[fr * D + i]; const double* o = Jb + (fr >> 1) * 54; w += j * o[50 + (fr & 1)]; gp += j * o[fr & 1]; }
+        wv[i] = w; gpv[i] = gp;
+    }
+    __syncthreads();
+    const double hinv = 1.0 / s_hg[0], g = s_hg[1];
+    double* out = a.slabs + (size_t)l * (D * D + D);
+    for (int e = tid; e < D * D + D; e += LM_THREADS) {
+        if (e >= D * D) { const int i = e - D * D; out[e] = gpv[i] - wv[i] * g * hinv; continue; }
+        const int i = e / D, j = e - i * D;
+        double s = 0;
+        for (int fr = 0; fr < 2 * nf; ++fr) s += Jd[fr * D + i] * Jd[fr * D + j];
+        out[e] = s - wv[i] * wv[j] * hinv;
+    }
+}
 
+__global__ __launch_bounds__(256) void be_marg_sum_kernel(BeMargArgs a) {
+    const int D = a.D, total = D * D + D;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    double s = 0;
+    for (int l = 0; l < a.nlm; ++l) s += a.slabs[(size_t)l * total + e];
+    a.sum[e] = s;
+}
+
+__global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int D = a.D, m = a.m, n = D - m, tid = threadIdx.x;
+    double* A = sm;                                       // D x D, then b (D)
+    double* bv = A + D * D;
+    double* W2 = bv + D;                                  // n x n (also scratch for prior dx / IMU)
+    double* yv = W2 + (n * n > 1024 ? n * n : 1024);      // n
+    double* misc = yv + n;                                // 16
+    const BeState* st = a.x;
+    for (int e = tid; e < D * D + D; e += MG_THREADS) A[e] = a.nlm > 0 ? a.sum[e] : 0.0;
+    if (tid == 0) {
+        double hmin = DBL_MAX;
+        for (int l = 0; l < a.nlm; ++l) hmin = fmin(hmin, a.lm_h[l]);
+        misc[0] = hmin; misc[1] = 0.0;
+    }
+    __syncthreads();
     // ---------------- previous prior: A += A_old (mapped), b += b_old + A_old dx ----------------
     if (a.prior->valid) {
         const int no = a.prior->n;
-        double* dx = W2;                  // reuse work space (no <= BE_MAX_PRIOR <= n*n for n >= 14; guarded on host)
+        double* dx = W2;
         be_prior_dx_dev(a.prior, st, dx, tid, MG_THREADS);
         __syncthreads();
         for (int i = tid; i < no; i += MG_THREADS) {
@@ -95,7 +161,6 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_kernel(BeMargArgs a) {
             Jw[e] = s;
         }
         __syncthreads();
-        // local 30 dims -> marg dims
         for (int e = tid; e < 900 + 30; e += MG_THREADS) {
             if (e < 900) {
                 const int r0 = e / 30, c0 = e - r0 * 30;
@@ -112,70 +177,10 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_kernel(BeMargArgs a) {
         }
         __syncthreads();
     }
-    // ---------------- landmarks anchored in the dropped frame ----------------
-    for (int l = 0; l < a.nlm; ++l) {
-        const BeLm L = a.lm[l];
-        if (tid < L.count) {
-            const BeFactor f = a.fac[L.first + tid];
-            double* o = Jb + tid * 54;
-            proj_factor<true, true>(f, fg[f.fi], fg[f.fj], ric[0], tic[0], ric[1], tic[1], st->inv_depth[f.lm], st->td, o, o + 2, o + 14, o + 50, o + 26, o + 38, o + 52);
-            if (f.kind == 0) for (int k = 0; k < 12; ++k) o[38 + k] = 0.0;
-            double rho0, sc;
-            huber1(o[0] * o[0] + o[1] * o[1], rho0, sc);
-            for (int k = 0; k < 54; ++k) o[k] *= sc;
-            s_fj[tid] = f.fj; s_two[tid] = f.kind != 2; s_kind[tid] = f.kind;
-        }
-        __syncthreads();
-        const int nf = L.count, anchor = L.anchor;
-        if (tid == 0) {
-            double h = 0, g = 0;
-            for (int f = 0; f < nf; ++f) { const double* o = Jb + f * 54; h += o[50] * o[50] + o[51] * o[51]; g += o[50] * o[0] + o[51] * o[1]; }
-            s_hg[0] = h; s_hg[1] = g;
-            for (int f = 0; f < nf; ++f) { const double* o = Jb + f * 54; misc[4] = fmax(misc[4], fmax(fabs(o[52]), fabs(o[53]))); }
-            if (h < misc[0]) misc[0] = h;
-        }
-        for (int i = tid; i < D; i += MG_THREADS) {
-            const int slot = a.dim_slot[i], comp = a.dim_comp[i];
-            double w = 0, gp = 0;
-            if (slot >= 0) {       // slot -1: speed-bias dims (no projection Jacobian)
-                for (int f = 0; f < nf; ++f) {
-                    const double* o = Jb + f * 54;
-                    int q0, q1;
-                    if (!mg_joff(slot, comp, anchor, s_fj[f], s_two[f], q0, q1)) continue;
-                    const double j0 = o[q0], j1 = o[q1];
-                    w += j0 * o[50] + j1 * o[51];
-                    gp += j0 * o[0] + j1 * o[1];
-                }
-            }
-            wv[i] = w; gpv[i] = gp;
-        }
-        __syncthreads();
-        const double h = s_hg[0], g = s_hg[1];
-        if (tid == 0) { misc[5] = fmax(misc[5], fabs(wv[D - 1])); misc[6] = fmax(misc[6], fabs(gpv[D - 1])); }
-        const double hinv = 1.0 / h;
-        for (int e = tid; e < D * D + D; e += MG_THREADS) {
-            if (e >= D * D) { const int i = e - D * D; bv[i] += gpv[i] - wv[i] * g * hinv; continue; }
-            const int i = e / D, j = e - i * D;
-            const int si = a.dim_slot[i], sj = a.dim_slot[j];
-            if (si < 0 || sj < 0) continue;
-            const int ci = a.dim_comp[i], cj = a.dim_comp[j];
-            double s = 0;
-            for (int f = 0; f < nf; ++f) {
-                const double* o = Jb + f * 54;
-                int a0, a1, c0, c1;
-                if (!mg_joff(si, ci, anchor, s_fj[f], s_two[f], a0, a1)) continue;
-                if (!mg_joff(sj, cj, anchor, s_fj[f], s_two[f], c0, c1)) continue;
-                s += o[a0] * o[c0] + o[a1] * o[c1];
-            }
-            A[e] += s - wv[i] * wv[j] * hinv;
-        }
-        __syncthreads();
-    }
-    // ---------------- eliminate the dropped pose / speed-bias dims [0, m) ----------------
-    // Cholesky of A_dd in place (lower), one wave
+    // ---------------- eliminate the dropped pose / speed-bias dims [0, m): Cholesky of A_dd in place (one wave) ----------------
     if (tid < 64) {
         for (int k = 0; k < m; ++k) {
-            double piv = A[k * D + k];
+            const double piv = A[k * D + k];
             if (tid == 0) { if (piv < misc[0]) misc[0] = piv; if (!(piv > 0)) misc[1] = 1.0; }
             const double inv = 1.0 / sqrt(piv);
             for (int i = k + tid; i < m; i += 64) A[i * D + k] *= inv;
@@ -188,7 +193,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_kernel(BeMargArgs a) {
         }
     }
     __syncthreads();
-    // X = L^-1 [A_dk | b_d]  (forward substitution, column-parallel; stored over A_dk / b_d)
+    // X = L^-1 [A_dk | b_d]  (forward substitution, one column per thread; stored over A_dk / b_d)
     for (int c = tid; c <= n; c += MG_THREADS) {
         for (int i = 0; i < m; ++i) {
             double s = (c < n) ? A[i * D + m + c] : bv[i];
@@ -198,7 +203,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_kernel(BeMargArgs a) {
         }
     }
     __syncthreads();
-    // A' = A_kk - X^T X (symmetrised from the upper triangle of the accumulation), b' = b_k - X^T y
+    // A' = A_kk - X^T X (symmetrised), b' = b_k - X^T y
     for (int e = tid; e < n * n + n; e += MG_THREADS) {
         if (e >= n * n) {
             const int i = e - n * n; double s = bv[m + i];
@@ -215,46 +220,43 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_kernel(BeMargArgs a) {
     for (int e = tid; e < n * n; e += MG_THREADS) a.outA[e] = W2[e];
     for (int i = tid; i < n; i += MG_THREADS) a.outb[i] = yv[i];
     __syncthreads();
-    // ---------------- c0 = b'^T A'^+ b' by diagonally pivoted LDL^T, pivots <= 1e-8 dropped ----------------
+    // ---------------- c0 = b'^T A'^+ b': LDL^T on the lower triangle, pivots <= 1e-8 skipped, one barrier per step ----------------
     double c0 = 0.0; int rank = 0;
     for (int k = 0; k < n; ++k) {
-        if (tid == 0) { int p = k; double best = W2[k * n + k]; for (int i = k + 1; i < n; ++i) if (W2[i * n + i] > best) { best = W2[i * n + i]; p = i; } s_piv = p; }
-        __syncthreads();
-        const int p = s_piv;
-        if (p != k) {
-            for (int j = tid; j < n; j += MG_THREADS) { const double t = W2[k * n + j]; W2[k * n + j] = W2[p * n + j]; W2[p * n + j] = t; }
-            __syncthreads();
-            for (int j = tid; j < n; j += MG_THREADS) { const double t = W2[j * n + k]; W2[j * n + k] = W2[j * n + p]; W2[j * n + p] = t; }
-            if (tid == 0) { const double t = yv[k]; yv[k] = yv[p]; yv[p] = t; }
-            __syncthreads();
-        }
         const double d = W2[k * n + k];
-        if (!(d > 1e-8)) break;               // uniform
-        ++rank;
-        const double yk = yv[k];
-        c0 += yk * yk / d;
-        __syncthreads();
-        const int r = n - k - 1;
-        for (int e = tid; e < r * r + r; e += MG_THREADS) {
-            if (e >= r * r) { const int i = k + 1 + (e - r * r); yv[i] -= W2[i * n + k] / d * yk; continue; }
-            const int i = k + 1 + e / r, j = k + 1 + e % r;
-            W2[i * n + j] -= W2[i * n + k] / d * W2[k * n + j];
+        if (d > 1e-8) {                 // uniform
+            ++rank;
+            const double yk = yv[k], dinv = 1.0 / d;
+            c0 += yk * yk * dinv;
+            const int r = n - k - 1;
+            for (int e = tid; e < r * r + r; e += MG_THREADS) {
+                if (e >= r * r) { const int i = k + 1 + (e - r * r); yv[i] -= W2[i * n + k] * dinv * yk; continue; }
+                const int i = k + 1 + e / r, j = k + 1 + e % r;
+                if (j <= i) W2[i * n + j] -= W2[i * n + k] * dinv * W2[j * n + k];
+            }
         }
         __syncthreads();
     }
-    if (tid == 0) { a.out_scalars[0] = c0; a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; a.out_scalars[3] = (double)rank; a.out_scalars[4] = misc[4]; a.out_scalars[5] = misc[5]; a.out_scalars[6] = misc[6]; a.out_scalars[7] = A[(D - 1) * D + 20]; }
+    if (tid == 0) { a.out_scalars[0] = c0; a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; a.out_scalars[3] = (double)rank; }
 }
 
-static size_t marg_smem(int D, int n) { return ((size_t)D * D + 3 * D + BE_MAX_OBS_FACTORS * 54 + std::max((size_t)n * n, (size_t)1024) + n + 64) * sizeof(double); }
+static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16) * sizeof(double); }
+static size_t lm_smem(int D) { return ((size_t)BE_MAX_OBS_FACTORS * 54 + 2 * (size_t)BE_MAX_OBS_FACTORS * D + 2 * D) * sizeof(double); }
 
 int be_launch_marg(const BeMargArgs& a, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return -1;
         attr = true;
     }
-    const size_t bytes = marg_smem(a.D, a.D - a.m);
-    if (bytes > 156 * 1024) return -2;
-    hipLaunchKernelGGL(be_marg_kernel, dim3(1), dim3(MG_THREADS), bytes, s, a);
+    const size_t bytes = finish_smem(a.D, a.D - a.m);
+    if (bytes > 156 * 1024 || lm_smem(a.D) > 64 * 1024) return -2;
+    if (a.nlm > 0) {
+        hipLaunchKernelGGL(be_marg_lm_kernel, dim3(a.nlm), dim3(LM_THREADS), lm_smem(a.D), s, a);
+        const int total = a.D * a.D + a.D;
+        hipLaunchKernelGGL(be_marg_sum_kernel, dim3((total + 255) / 256), dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(be_marg_finish_kernel, dim3(1), dim3(MG_THREADS), bytes, s, a);
     return 0;
 }

@@ -64,6 +64,10 @@ struct BeState {
 #define BE_PK_DD 135
 #define BE_PK_DA 531
 #define BE_PK_SIZE 928            // 927 used, padded to a multiple of 16 bytes
+// Packets are stored TRANSPOSED in HBM: entry e of landmark l lives at packets[e * BE_PK_STRIDE + l], so that the
+// consumers (one thread per landmark, or one thread per matrix entry looping over landmarks) read coalesced.
+#define BE_PK_STRIDE 1024
+#define BE_PK(pk, e, l) (pk)[(size_t)(e) * BE_PK_STRIDE + (l)]
 
 struct BePriorBlock { int32_t type /*0 pose,1 sb,2 ex,3 td*/, idx, off, size_local; };
 

@@ -66,6 +66,7 @@ struct BeWork {
     double* scale_l = nullptr; double* diag_l = nullptr; double* grad_l = nullptr; double* gn_l = nullptr;
     int32_t* prior_col = nullptr; int32_t* col_kind = nullptr; int32_t* col_frame = nullptr; int32_t* col_comp = nullptr;
     int fac_cap = 0;
+    DevBuf marg_buf;       // per-landmark slabs of the marginalization (sized on demand)
     void* pinned = nullptr; size_t pinned_bytes = 0;      // host staging (state + ctl)
 };
 

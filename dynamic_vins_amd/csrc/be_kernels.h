@@ -23,7 +23,7 @@ struct BeSolveArgs {
     BeDims dims;
     const double* packets; const double* imu_out; const double* prior_out; const double* cand_cost;
     double* Hd;             // [n][n] everything except the Schur term
-    double* Sc;             // [n][n] sum_l rho_l w_l w_l^T
+    double* Sc;             // Hd - sum_l rho_l w_l w_l^T (the Schur complement before scaling), block-packed lower triangle (blk_pos in be_solve.hip)
     double* gvec;           // [n] gradient g_p ; [n..2n) Schur part sum_l rho_l w_l g_l
     double* scale_p; double* diag_p; double* grad_p; double* gn_p;     // [n]
     double* scale_l; double* diag_l; double* grad_l; double* gn_l;     // [nlm]

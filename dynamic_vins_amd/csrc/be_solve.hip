@@ -56,6 +56,12 @@ __device__ __forceinline__ double red_dense_g(const BeSolveArgs& a, int i) {
     if (a.prior->valid) { const int pi = a.prior_col[i]; if (pi >= 0) G += a.prior_out[1 + pi]; }
     return G;
 }
+// Position of entry (i, j), j's block <= i's block, in the block-packed lower triangle consumed by the factorisation:
+// 4x4 blocks, block-column-major (block (bi, bj) at index bj*NBR - bj(bj-1)/2 + bi - bj), row-major inside a block.
+__device__ __forceinline__ int blk_pos(int i, int j, int NBR) {
+    const int bi = i >> 2, bj = j >> 2;
+    return (bj * NBR - bj * (bj - 1) / 2 + bi - bj) * 16 + (i & 3) * 4 + (j & 3);
+}
 __device__ __forceinline__ double wave_sum(double v) {      // fixed xor tree: deterministic, every lane gets the sum
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -113,8 +119,9 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a) {
 #pragma unroll
             for (int q = 1; q < 6; ++q) if (lane == q) { sv = S[q]; hv = H[q]; }
             const int i = ci0 + ci, j = cj0 + lane;
-            a.Hd[(size_t)i * n + j] = hv + red_dense_h(a, i, j);
-            a.Sc[(size_t)i * n + j] = sv;
+            const double hd = hv + red_dense_h(a, i, j);
+            a.Hd[(size_t)i * n + j] = hd;
+            if ((j >> 2) <= (i >> 2)) a.Sc[blk_pos(i, j, (n + 3) >> 2)] = hd - sv;
         } else if (diag && lane == 6) {
             const int i = ci0 + ci;
             a.gvec[i] = G + red_dense_g(a, i);
@@ -129,7 +136,9 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a) {
     if (t < n * n) {
         const int i = t / n, j = t - i * n;
         if (a.col_kind[i] == 0 && a.col_kind[j] == 0) return;          // pose x pose: written by the pair blocks
-        a.Hd[t] = red_dense_h(a, i, j); a.Sc[t] = 0.0;
+        const double hd = red_dense_h(a, i, j);
+        a.Hd[t] = hd;
+        if ((j >> 2) <= (i >> 2)) a.Sc[blk_pos(i, j, (n + 3) >> 2)] = hd;
     } else if (t < n * n + n) {
         const int i = t - n * n;
         if (a.col_kind[i] == 0) return;
@@ -145,6 +154,13 @@ void be_launch_reduce(const BeSolveArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------
 #define SOL_THREADS 1024
+#ifdef BE_SOLVE_TS
+__device__ long long be_dbg_ts[32];
+#define TS(k) do { if (threadIdx.x == 0) be_dbg_ts[k] = wall_clock64(); } while (0)
+extern "C" int dv_debug_solve_ts(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(be_dbg_ts), sizeof(long long) * 32) == hipSuccess ? 0 : -1; }
+#else
+#define TS(k) do {} while (0)
+#endif
 
 __device__ __forceinline__ double block_sum(double v, double* red) {     // fixed-shape tree: deterministic
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -158,111 +174,197 @@ __device__ __forceinline__ double block_sum(double v, double* red) {     // fixe
     return s;
 }
 
-__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }      // packed lower, j <= i
-
-// y = Hd * x (Hd symmetric: thread = output entry reading column-wise, i.e. coalesced rows), 4 partial sums per entry
-__device__ __forceinline__ void gemv_hd(const double* Hd, int n, const double* x, double* y, double* scratch, int tid) {
-    const int col = tid & 255, part = tid >> 8;
-    if (col < n) {
-        const int seg = (n + 3) / 4, j0 = part * seg, j1 = min(n, j0 + seg);
-        double s = 0;
-        for (int j = j0; j < j1; ++j) s += Hd[(size_t)j * n + col] * x[j];
-        scratch[tid] = s;
+// N sums with ONE LDS exchange (two barriers) instead of N: red must hold 16 * N doubles
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
     }
     __syncthreads();
-    if (part == 0 && col < n) y[col] = (scratch[col] + scratch[256 + col]) + (scratch[512 + col] + scratch[768 + col]);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[i * 16 + w] = v[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double s = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) s += red[i * 16 + k]; v[i] = s; }
+}
+
+__device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }      // packed lower, j <= i
+
+// y = Hd * x (Hd symmetric: thread = output entry reading column-wise, i.e. coalesced rows).  5 partial sums per
+// entry; the (up to 36) loads of a thread are address-independent and issued in batches (the matrix was written by
+// other XCDs, so every load is a ~1 us round trip: memory-level parallelism is what matters here).
+__device__ __forceinline__ void gemv_hd(const double* Hd, int n, const double* x, double* y, double* scratch, int tid) {
+    const int col = tid % 192, part = tid / 192;       // parts 0..4 (tid >= 960 idle)
+    const int seg = (n + 4) / 5, j0 = part * seg;
+    const bool live = part < 5 && col < n;
+    double s = 0;
+#pragma unroll 12
+    for (int q = 0; q < 36; ++q) {
+        const int j = j0 + q;
+        const bool ok = live && q < seg && j < n;
+        const double h = Hd[ok ? (size_t)j * n + col : 0];
+        const double xv = x[ok ? j : 0];
+        s += ok ? h * xv : 0.0;
+    }
+    if (part < 5) scratch[part * 192 + col] = s;
+    __syncthreads();
+    if (tid < n) y[tid] = (scratch[tid] + scratch[192 + tid]) + (scratch[384 + tid] + scratch[576 + tid]) + scratch[768 + tid];
     __syncthreads();
 }
 
-// Register-blocked right-looking LDL^T of the (scaled, damped) reduced camera system.  Every thread owns NSLOT 4x4
+__device__ __forceinline__ double fast_rcp(double d) {      // v_rcp_f64 + two Newton steps (full precision, half the latency of a division)
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
+
+// Panel-blocked right-looking LDL^T of the (scaled, damped) reduced camera system.  Every thread owns NSLOT 4x4
 // blocks of the lower triangle in registers (block-column-major, so whole waves retire as the factorisation
-// proceeds); the pivot column travels through a double-buffered LDS vector -> ONE barrier per column and 8 LDS reads
-// per 16 FMAs.  The right-hand side is forward-substituted alongside (z lives in a register of thread i).
-// On success: Lm = unit-lower L (packed), dvec = D, zfin = L^-1 rhs.   Returns false on a non-positive pivot.
+// proceeds).  Per block column kb:  (a) the owner of the diagonal block factors it in registers and publishes
+// L_kk, D_kk;  (b) the owners of the blocks below turn theirs into the panel of L (and L D) and publish it in LDS;
+// (c) every block to the right subtracts  L_i D L_j^T  (64 FMAs against 32 LDS reads).  Two barriers per FOUR
+// columns.  The right-hand side is forward-substituted alongside in the registers of the diagonal-block owners.
+// On success: Lm = unit-lower L (packed row-major), dvec = D, zfin = L^-1 rhs.   Returns false on a non-positive pivot.
+#define PSTR 184            // row stride of the panel buffers (>= 4 * ceil(178 / 4), even)
 template <int NSLOT>
 __device__ __forceinline__ bool ldlt_blocked(const BeSolveArgs& a, int n, double mu, const double* v_s, const double* v_d,
-                                             double* Lm, double* colbuf, double* zfin, double* dvec, int* s_fail) {
+                                             double* Lm, double* PL, double* PD, double* dinfo, double* zfin, double* dvec, int* s_fail) {
     const int tid = threadIdx.x;
-    const int NBR = (n + 3) >> 2, CB = NBR * 4, nblk = NBR * (NBR + 1) / 2;
+    const int NBR = (n + 3) >> 2, nblk = NBR * (NBR + 1) / 2;
     int bi[NSLOT], bj[NSLOT];
-    double A[NSLOT][4][4];
+    double A[NSLOT][4][4], zr[NSLOT][4];
 #pragma unroll
     for (int b = 0; b < NSLOT; ++b) {
         const int idx = tid + b * SOL_THREADS;
         bi[b] = -1; bj[b] = -1;
         if (idx < nblk) { int c0 = 0, rem = idx; while (rem >= NBR - c0) { rem -= NBR - c0; ++c0; } bj[b] = c0; bi[b] = c0 + rem; }
+        const bool have = bi[b] >= 0;
+        double dv[4][4];
+        {   // one 128-byte block per thread, consecutive threads -> consecutive blocks: 4 coalesced 32-byte loads
+            const double4* src = reinterpret_cast<const double4*>(a.Sc + (size_t)(have ? idx : 0) * 16);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int r = 0; r < 4; ++r) { const double4 q = src[r]; dv[r][0] = q.x; dv[r][1] = q.y; dv[r][2] = q.z; dv[r][3] = q.w; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = bi[b] * 4 + r;
+            const bool iok = have && i < n;
+            const double si = v_s[iok ? i : 0];
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) {
-                const int i = bi[b] * 4 + r, j = bj[b] * 4 + cc;
-                double v = 0.0;
-                if (bi[b] >= 0 && i < n && j < n) {
-                    v = v_s[i] * v_s[j] * (a.Hd[(size_t)i * n + j] - a.Sc[(size_t)i * n + j]);
-                    if (i == j) v += mu * v_d[i] * v_d[i];
-                }
+                const int j = bj[b] * 4 + cc;
+                const bool ok = iok && j < n;
+                double v = ok ? si * v_s[ok ? j : 0] * dv[r][cc] : 0.0;
+                if (i == j) v = ok ? v + mu * v_d[ok ? i : 0] * v_d[ok ? i : 0] : 1.0;      // padding rows: identity
                 A[b][r][cc] = v;
             }
-    }
-    double z = 0.0;
-    if (tid < n) z = v_s[tid] * (a.gvec[tid] - a.gvec[n + tid]);
-    if (tid == 0) { zfin[0] = z; *s_fail = 0; }
-#pragma unroll
-    for (int b = 0; b < NSLOT; ++b)
-        if (bj[b] == 0) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) colbuf[bi[b] * 4 + r] = A[b][r][0];
+            zr[b][r] = (iok && bi[b] == bj[b]) ? si * (a.gvec[i] - a.gvec[n + i]) : 0.0;
         }
+    }
+    if (tid == 0) *s_fail = 0;
     __syncthreads();
-    bool bad = false;
-    for (int k0 = 0; k0 < n && !bad; k0 += 4) {
+    TS(4);
+#ifdef BE_SOLVE_TS
+    long long t_prev = wall_clock64(), acc_a = 0, acc_b = 0;
+#endif
+    for (int kb = 0; kb < NBR; ++kb) {
+        double* di = dinfo + (kb & 1) * 16;       // double-buffered: (a) of the next block column may overwrite while (c) still reads
+        // ---- (a) diagonal block ----
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {           // kk is a compile-time constant: every index into A[][][] stays static
-            const int k = k0 + kk;
-            if (k >= n || bad) break;
-            const double* cb = colbuf + (kk & 1) * CB;
-            double* cbn = colbuf + ((kk + 1) & 1) * CB;
-            const double dk = cb[k];
-            if (!(dk > 0.0) || !isfinite(dk)) { if (tid == 0) *s_fail = 1; bad = true; break; }      // uniform: every thread reads the same LDS word
-            const double inv = 1.0 / dk;
-            if (tid > k && tid < n) { z -= cb[tid] * inv * zfin[k]; if (tid == k + 1) zfin[k + 1] = z; }
+        for (int b = 0; b < NSLOT; ++b)
+            if (bi[b] == kb && bj[b] == kb) {
+                const double a10 = A[b][1][0], a20 = A[b][2][0], a30 = A[b][3][0];
+                const double d0 = A[b][0][0], i0 = fast_rcp(d0);
+                const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+                const double d1 = __builtin_fma(-l10, a10, A[b][1][1]), i1 = fast_rcp(d1);
+                const double t21 = __builtin_fma(-l20, a10, A[b][2][1]), t31 = __builtin_fma(-l30, a10, A[b][3][1]);
+                const double l21 = t21 * i1, l31 = t31 * i1;
+                const double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, a20, A[b][2][2])), i2 = fast_rcp(d2);
+                const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, a20, A[b][3][2]));
+                const double l32 = t32 * i2;
+                const double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, a30, A[b][3][3]))), i3 = fast_rcp(d3);
+                if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0) || !isfinite(d0 + d1 + d2 + d3)) *s_fail = 1;
+                const double z0 = zr[b][0], z1 = __builtin_fma(-l10, z0, zr[b][1]);
+                const double z2 = __builtin_fma(-l21, z1, __builtin_fma(-l20, z0, zr[b][2]));
+                const double z3 = __builtin_fma(-l32, z2, __builtin_fma(-l31, z1, __builtin_fma(-l30, z0, zr[b][3])));
+                di[0] = l10; di[1] = l20; di[2] = l30; di[3] = l21; di[4] = l31; di[5] = l32;
+                di[6] = i0; di[7] = i1; di[8] = i2; di[9] = i3;
+                di[10] = z0; di[11] = z1; di[12] = z2; di[13] = z3;
+                const int r0 = kb * 4;
+                if (r0 < n) { dvec[r0] = d0; zfin[r0] = z0; }
+                if (r0 + 1 < n) { dvec[r0 + 1] = d1; zfin[r0 + 1] = z1; }
+                if (r0 + 2 < n) { dvec[r0 + 2] = d2; zfin[r0 + 2] = z2; }
+                if (r0 + 3 < n) { dvec[r0 + 3] = d3; zfin[r0 + 3] = z3; }
+                A[b][1][0] = l10; A[b][2][0] = l20; A[b][3][0] = l30; A[b][2][1] = l21; A[b][3][1] = l31; A[b][3][2] = l32;
+            }
+        __syncthreads();
+#ifdef BE_SOLVE_TS
+        { long long t = wall_clock64(); acc_a += t - t_prev; t_prev = t; }
+#endif
+        if (*s_fail) break;                          // uniform (LDS word)
+        // ---- (b) panel below the diagonal block ----
 #pragma unroll
-            for (int b = 0; b < NSLOT; ++b) {
-                const int j0 = bj[b] * 4;
-                if (kk < 3 ? j0 >= k0 : j0 > k0) {      // block still has a column right of the pivot (bj = -1 never passes)
-                    const int i0 = bi[b] * 4;
-                    const bool pivot_blockcol = j0 == k0;
-                    double ci[4], cj[4];
+        for (int b = 0; b < NSLOT; ++b)
+            if (bj[b] == kb && bi[b] > kb) {
+                const double l10 = di[0], l20 = di[1], l30 = di[2], l21 = di[3], l31 = di[4], l32 = di[5];
+                const double i0 = di[6], i1 = di[7], i2 = di[8], i3 = di[9];
+                const int i0r = bi[b] * 4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { ci[r] = cb[i0 + r]; const double t = cb[j0 + r] * inv; cj[r] = (!pivot_blockcol || r > kk) ? t : 0.0; }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-#pragma unroll
-                        for (int cc = 0; cc < 4; ++cc) A[b][r][cc] -= ci[r] * cj[cc];
-                    if (kk < 3) {
-                        if (pivot_blockcol) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) if (i0 + r > k) cbn[i0 + r] = A[b][r][(kk + 1) & 3];
-                        }
-                    } else if (j0 == k0 + 4) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) cbn[i0 + r] = A[b][r][0];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const double p0 = A[b][r][0];
+                    const double p1 = __builtin_fma(-p0, l10, A[b][r][1]);
+                    const double p2 = __builtin_fma(-p1, l21, __builtin_fma(-p0, l20, A[b][r][2]));
+                    const double p3 = __builtin_fma(-p2, l32, __builtin_fma(-p1, l31, __builtin_fma(-p0, l30, A[b][r][3])));
+                    const double x0 = p0 * i0, x1 = p1 * i1, x2 = p2 * i2, x3 = p3 * i3;
+                    double* pl = PL + i0r + r; double* pd = PD + i0r + r;          // [m][row]: lanes (consecutive block rows) are 32 B apart -> conflict-free
+                    pl[0] = x0; pl[PSTR] = x1; pl[2 * PSTR] = x2; pl[3 * PSTR] = x3;
+                    pd[0] = p0; pd[PSTR] = p1; pd[2 * PSTR] = p2; pd[3 * PSTR] = p3;
+                    A[b][r][0] = x0; A[b][r][1] = x1; A[b][r][2] = x2; A[b][r][3] = x3;
                 }
             }
-            __syncthreads();
-        }
+        __syncthreads();
+#ifdef BE_SOLVE_TS
+        { long long t = wall_clock64(); acc_b += t - t_prev; t_prev = t; }
+#endif
+        // ---- (c) trailing update ----
+#pragma unroll
+        for (int b = 0; b < NSLOT; ++b)
+            if (bj[b] > kb) {
+                const double* pl = PL + bi[b] * 4; const double* pd = PD + bj[b] * 4;
+                double li[4][4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const double2 u0 = *reinterpret_cast<const double2*>(pl + m * PSTR), u1 = *reinterpret_cast<const double2*>(pl + m * PSTR + 2);
+                    li[0][m] = u0.x; li[1][m] = u0.y; li[2][m] = u1.x; li[3][m] = u1.y;
+                }
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const double q0 = pd[cc], q1 = pd[PSTR + cc], q2 = pd[2 * PSTR + cc], q3 = pd[3 * PSTR + cc];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        A[b][r][cc] = __builtin_fma(-li[r][3], q3, __builtin_fma(-li[r][2], q2, __builtin_fma(-li[r][1], q1, __builtin_fma(-li[r][0], q0, A[b][r][cc]))));
+                }
+                if (bi[b] == bj[b]) {
+                    const double y0 = di[10], y1 = di[11], y2 = di[12], y3 = di[13];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        zr[b][r] = __builtin_fma(-li[r][3], y3, __builtin_fma(-li[r][2], y2, __builtin_fma(-li[r][1], y1, __builtin_fma(-li[r][0], y0, zr[b][r]))));
+                }
+            }
     }
     __syncthreads();
+    TS(5);
+#ifdef BE_SOLVE_TS
+    if (tid == 0) { be_dbg_ts[16] = acc_a; be_dbg_ts[17] = acc_b; }
+#endif
     if (*s_fail) return false;
-    // D, then the unit-lower factor in packed row-major form for the back substitution
-#pragma unroll
-    for (int b = 0; b < NSLOT; ++b)
-        if (bi[b] >= 0 && bi[b] == bj[b]) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) if (bi[b] * 4 + r < n) dvec[bi[b] * 4 + r] = A[b][r][r];
-        }
-    __syncthreads();
+    // the unit-lower factor in packed row-major form for the back substitution
 #pragma unroll
     for (int b = 0; b < NSLOT; ++b)
         if (bi[b] >= 0) {
@@ -271,11 +373,44 @@ __device__ __forceinline__ bool ldlt_blocked(const BeSolveArgs& a, int n, double
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
                     const int i = bi[b] * 4 + r, j = bj[b] * 4 + cc;
-                    if (i < n && j < i) Lm[tri(i, j)] = A[b][r][cc] / dvec[j];
+                    if (i < n && j < i) Lm[tri(i, j)] = A[b][r][cc];
                 }
         }
     __syncthreads();
     return true;
+}
+
+
+// back-substitution helper: applies ROWS consecutive pivots (kt, kt-1, ...) that all lie in 64-lane segment SEG of x
+template <int SEG, int ROWS>
+__device__ __forceinline__ void bs_chunk(const double* Lm, int kt, int lane, double& x0, double& x1, double& x2) {
+    double cr[ROWS][3];
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) {
+        const int k = kt - u;
+        const double* row = Lm + tri(k, 0) + lane;      // reads past the end of row k are masked below (they stay inside the LDS allocation)
+        cr[u][0] = row[0];
+        if (SEG >= 1) cr[u][1] = row[64];
+        if (SEG >= 2) cr[u][2] = row[128];
+        cr[u][SEG] = lane < k - 64 * SEG ? cr[u][SEG] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < ROWS; ++u) {
+        const int k = kt - u;
+        const double xs = SEG == 0 ? x0 : (SEG == 1 ? x1 : x2);
+        const int lo = __builtin_amdgcn_readlane(__double2loint(xs), k - 64 * SEG), hi = __builtin_amdgcn_readlane(__double2hiint(xs), k - 64 * SEG);
+        const double xk = __hiloint2double(hi, lo);
+        x0 = __builtin_fma(-cr[u][0], xk, x0);
+        if (SEG >= 1) x1 = __builtin_fma(-cr[u][1], xk, x1);
+        if (SEG >= 2) x2 = __builtin_fma(-cr[u][2], xk, x2);
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, double& x0, double& x1, double& x2) {
+    const int seg = kt >> 6;                             // uniform
+    if (seg == 0) bs_chunk<0, ROWS>(Lm, kt, lane, x0, x1, x2);
+    else if (seg == 1) bs_chunk<1, ROWS>(Lm, kt, lane, x0, x1, x2);
+    else bs_chunk<2, ROWS>(Lm, kt, lane, x0, x1, x2);
 }
 
 template <int NSLOT>
@@ -297,9 +432,11 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
     double* zfin = v_x + n;                            // L^-1 rhs
     double* dvec = zfin + n;                           // D
     double* q66 = dvec + n;                            // 66 (+6 pad): v_t gathered into packet (frame, comp) order
-    double* red = q66 + 72;                            // 32
-    double* scratch = red + 32;                        // 1024
-    double* colbuf = scratch + 1024;                   // 2 x 184 pivot-column buffers
+    double* red = q66 + 72;                            // 80: block-sum exchange (16 per value)
+    double* misc = red + 80;                           // 8: [0] alpha
+    double* scratch = misc + 8;                        // 1536: gemv partial sums, aliased with the LDL^T panel buffers
+    double* PL = scratch, *PD = scratch + 4 * 184;     // panel of L and of L D, [row][4]
+    double* dinfo = red;                               // 2 x 16 (red[] is idle during the factorisation)
     __shared__ int s_fail;
     const double mu = c.mu;
     const double* pk = a.packets;
@@ -307,11 +444,35 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
         if (tid < 66) { const int fa = tid / 6, r = tid - fa * 6; const int col = fa < a.dims.nframes ? a.dims.pose_col[fa] : -1; q66[tid] = col >= 0 ? v[col + r] : 0.0; }
         __syncthreads();
     };
-    auto wdot = [&](int l) { double s = 0;
-#pragma unroll 6
-        for (int q = 0; q < 66; ++q) s += BE_PK(pk, BE_PK_W + q, l) * q66[q];
-        return s; };
-
+    // wd[l] = w_l . q66 for every landmark: the 66 terms are split over npart thread groups (lane = landmark, so the
+    // packet reads stay coalesced); partial sums meet in LDS and are added in a fixed order.  Result in scratch[l].
+    const int nlm_pad = (nlm + 63) & ~63;
+    const int npart = nlm_pad * 6 <= SOL_THREADS ? 6 : (nlm_pad * 3 <= SOL_THREADS ? 3 : (nlm_pad * 2 <= SOL_THREADS ? 2 : 1));
+    auto wdot_all = [&]() {
+        const int per = 66 / npart;
+        if (npart > 1) {
+            const int part = tid / nlm_pad, l = tid - part * nlm_pad;
+            if (part < npart && l < nlm) {
+                double s0 = 0;
+                const int q0 = part * per;
+#pragma unroll 11
+                for (int q = 0; q < per; ++q) s0 += BE_PK(pk, BE_PK_W + q0 + q, l) * q66[q0 + q];
+                scratch[part * nlm_pad + l] = s0;
+            }
+            __syncthreads();
+            if (tid < nlm) { double s0 = scratch[tid]; for (int p = 1; p < npart; ++p) s0 += scratch[p * nlm_pad + tid]; scratch[tid] = s0; }
+        } else {
+            for (int l = tid; l < nlm; l += SOL_THREADS) {
+                double s0 = 0;
+#pragma unroll 11
+                for (int q = 0; q < 66; ++q) s0 += BE_PK(pk, BE_PK_W + q, l) * q66[q];
+                scratch[l] = s0;
+            }
+        }
+        __syncthreads();
+    };
+    const double* wd = scratch;
+    TS(0);
     if (!c.reuse) {
         // ---------------- scaling, diagonal, gradient ----------------
         for (int i = tid; i < n; i += SOL_THREADS) {
@@ -347,9 +508,12 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
             __syncthreads();
             if (gm <= 1e-10) { if (tid == 0) { ctl->done = 1; ctl->termination = 1; ctl->first = 0; } return; }
         }
+        TS(1);
         // Cauchy point: alpha = |gradient_|^2 / (u^T H u)
         gemv_hd(a.Hd, n, v_t, v_t2, scratch, tid);
+        TS(2);
         gather66(v_t);
+        wdot_all();
         double uHu = 0, gg = 0;
         for (int i = tid; i < n; i += SOL_THREADS) { uHu += v_t[i] * v_t2[i]; gg += v_grad[i] * v_grad[i]; }
         for (int l = tid; l < nlm; l += SOL_THREADS) {
@@ -357,56 +521,66 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
             double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
             const double d = sqrt(d2), grad = gl * s / d, u = s * s * gl / d2;
             a.diag_l[l] = d; a.grad_l[l] = grad;
-            uHu += 2.0 * u * wdot(l) + h * u * u;
+            uHu += 2.0 * u * wd[l] + h * u * u;
             gg += grad * grad;
         }
-        uHu = block_sum(uHu, red);
-        gg = block_sum(gg, red);
+        { double sv2[2] = {uHu, gg}; block_sum_n<2>(sv2, red); uHu = sv2[0]; gg = sv2[1]; }
         const double alpha = gg / uHu;
+        if (tid == 0) misc[0] = alpha;                 // materialised now: keeps the partial sums from living across the factorisation
+        TS(3);
         // ---------------- Gauss-Newton step: LDL^T of the Schur complement ----------------
-        if (!ldlt_blocked<NSLOT>(a, n, mu, v_s, v_d, Lm, colbuf, zfin, dvec, &s_fail)) {
+        if (!ldlt_blocked<NSLOT>(a, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail)) {
             // Ceres: LINEAR_SOLVER_FAILURE -> mu *= 10 and retry (dogleg_strategy.cc ComputeGaussNewtonStep)
             if (tid == 0) {
-                ctl->mu = mu * 10.0; ctl->chol_fail = 1; ctl->first = 0; ctl->alpha = alpha;
+                ctl->mu = mu * 10.0; ctl->chol_fail = 1; ctl->first = 0; ctl->alpha = misc[0];
                 if (mu * 10.0 > 1.0) { ctl->done = 1; ctl->termination = 2; }
             }
             return;
         }
-        // back substitution L^T x = D^-1 z on one wave (column sweep, wave-level sync only)
-        for (int i = tid; i < n; i += SOL_THREADS) v_x[i] = zfin[i] / dvec[i];
-        __syncthreads();
+        TS(6);
+        // back substitution L^T x = D^-1 z on ONE wave with x distributed over lanes (3 registers cover n <= 192):
+        // the pivot is broadcast with v_readlane, row k-1 of L is prefetched from LDS while row k is applied.
         if (tid < 64) {
-            for (int k = n - 1; k > 0; --k) {
-                const double xk = v_x[k];
-                const double* row = Lm + tri(k, 0);
-                for (int j = tid; j < k; j += 64) v_x[j] -= row[j] * xk;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+            const int lane = tid;
+            double x0 = lane < n ? zfin[lane] / dvec[lane] : 0.0;
+            double x1 = 64 + lane < n ? zfin[64 + lane] / dvec[64 + lane] : 0.0;
+            double x2 = 128 + lane < n ? zfin[128 + lane] / dvec[128 + lane] : 0.0;
+            int k = n - 1;
+            for (; k >= 0 && ((k + 1) & 7); --k) bs_rows<1>(Lm, k, lane, x0, x1, x2);      // until the chunks are 8-aligned (a chunk never straddles a segment)
+            for (; k >= 7; k -= 8) bs_rows<8>(Lm, k, lane, x0, x1, x2);
+            if (lane < n) v_x[lane] = x0;
+            if (64 + lane < n) v_x[64 + lane] = x1;
+            if (128 + lane < n) v_x[128 + lane] = x2;
         }
         __syncthreads();
+        TS(7);
         for (int i = tid; i < n; i += SOL_THREADS) { v_gn[i] = -v_d[i] * v_x[i]; a.gn_p[i] = v_gn[i]; v_t[i] = v_s[i] * v_x[i]; }   // v_t = s_p . y_p
         __syncthreads();
         gather66(v_t);
+        wdot_all();
         for (int l = tid; l < nlm; l += SOL_THREADS) {
             const double h = BE_PK(pk, BE_PK_H, l), s = a.scale_l[l], d = a.diag_l[l];
             const double rho = 1.0 / (h + mu * d * d / (s * s));
-            const double yl = rho / s * (BE_PK(pk, BE_PK_G, l) - wdot(l));
+            const double yl = rho / s * (BE_PK(pk, BE_PK_G, l) - wd[l]);
             a.gn_l[l] = -d * yl;
         }
-        if (tid == 0) { ctl->alpha = alpha; red[20] = alpha; }
+        if (tid == 0) ctl->alpha = misc[0];
         __syncthreads();
     } else {
         for (int i = tid; i < n; i += SOL_THREADS) { v_s[i] = a.scale_p[i]; v_d[i] = a.diag_p[i]; v_grad[i] = a.grad_p[i]; v_gn[i] = a.gn_p[i]; }
-        if (tid == 0) red[20] = c.alpha;
+        if (tid == 0) misc[0] = c.alpha;
         __syncthreads();
     }
-    const double alpha = red[20];
+    const double alpha = misc[0];
     __syncthreads();
+    TS(8);
     // ---------------- traditional dogleg (dogleg_strategy.cc ComputeTraditionalDoglegStep) ----------------
     double p_gg = 0, p_nn = 0, p_gn = 0;
     for (int i = tid; i < n; i += SOL_THREADS) { p_gg += v_grad[i] * v_grad[i]; p_nn += v_gn[i] * v_gn[i]; p_gn += v_grad[i] * v_gn[i]; }
     for (int l = tid; l < nlm; l += SOL_THREADS) { const double g = a.grad_l[l], q = a.gn_l[l]; p_gg += g * g; p_nn += q * q; p_gn += g * q; }
-    const double gnorm = sqrt(block_sum(p_gg, red)), gnn = sqrt(block_sum(p_nn, red)), gdot = block_sum(p_gn, red);
+    double sv3[3] = {p_gg, p_nn, p_gn};
+    block_sum_n<3>(sv3, red);
+    const double gnorm = sqrt(sv3[0]), gnn = sqrt(sv3[1]), gdot = sv3[2];
     const double radius = c.radius;
     double cg, cn, dnorm;
     if (gnn <= radius) { cg = 0; cn = 1; dnorm = gnn; }
@@ -421,8 +595,12 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
     double p_dn = 0;
     for (int i = tid; i < n; i += SOL_THREADS) { const double st = cg * v_grad[i] + cn * v_gn[i]; p_dn += st * st; v_t[i] = st / v_d[i] * v_s[i]; }
     __syncthreads();
+    TS(9);
     gemv_hd(a.Hd, n, v_t, v_t2, scratch, tid);
+    TS(11);
     gather66(v_t);
+    wdot_all();
+    TS(12);
     double p_sg = 0, p_sHs = 0, p_step = 0, p_xn = 0;
     for (int i = tid; i < n; i += SOL_THREADS) { p_sg += v_t[i] * a.gvec[i]; p_sHs += v_t[i] * v_t2[i]; }
     for (int l = tid; l < nlm; l += SOL_THREADS) {
@@ -430,7 +608,7 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
         p_dn += st * st;
         const double dl = st / a.diag_l[l] * a.scale_l[l];
         p_sg += dl * BE_PK(pk, BE_PK_G, l);
-        p_sHs += 2.0 * dl * wdot(l) + BE_PK(pk, BE_PK_H, l) * dl * dl;
+        p_sHs += 2.0 * dl * wd[l] + BE_PK(pk, BE_PK_H, l) * dl * dl;
         const double x0 = a.x->inv_depth[l];
         a.cand->inv_depth[l] = x0 + dl;
         p_step += dl * dl; p_xn += x0 * x0;
@@ -447,8 +625,11 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
         else for (int k = 0; k < 9; ++k) a.cand->sb[f][k] = a.x->sb[f][k];
     }
     if (tid == 0) { for (int k = 0; k < 14; ++k) a.cand->ex[k / 7][k % 7] = a.x->ex[k / 7][k % 7]; a.cand->td = a.x->td; }
-    const double dn2 = block_sum(p_dn, red), sg = block_sum(p_sg, red), sHs = block_sum(p_sHs, red);
-    const double step2 = block_sum(p_step, red), xn2 = block_sum(p_xn, red);
+    TS(13);
+    double sv5[5] = {p_dn, p_sg, p_sHs, p_step, p_xn};
+    block_sum_n<5>(sv5, red);
+    const double dn2 = sv5[0], sg = sv5[1], sHs = sv5[2], step2 = sv5[3], xn2 = sv5[4];
+    TS(10);
     if (tid == 0) {
         const double mcc = -(sg + 0.5 * sHs);
         ctl->model_cost_change = mcc;
@@ -461,7 +642,7 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
     }
 }
 
-static size_t solve_smem(int n) { return ((size_t)n * (n + 1) / 2 + 9 * (size_t)n + 72 + 32 + 1024 + 2 * 184) * sizeof(double); }
+static size_t solve_smem(int n) { return ((size_t)n * (n + 1) / 2 + 9 * (size_t)n + 72 + 80 + 8 + 1536) * sizeof(double); }
 
 int be_launch_solve(const BeSolveArgs& a, hipStream_t s) {
     static bool attr = false;

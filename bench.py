@@ -43,17 +43,13 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    from dynamic_vins_amd import dist as dv_dist
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local_rank = dv_dist.init()          # one process per GPU; "nccl" = RCCL over xGMI
 
     from dynamic_vins_amd import sim
     from dynamic_vins_amd.pipeline import Pipeline, SyntheticSequence
@@ -61,7 +57,7 @@ def main():
     warmup = max(args.warmup, 12)          # the estimator needs kWinSize+1 = 11 frames to initialise (estimator.cpp:1464-1483)
     n_frames = warmup + args.steps + 1
     cam = sim.ZED if args.width == 1280 else sim.scaled_cam(sim.ZED, args.width, args.height, 1280, 720)
-    seq = SyntheticSequence(args.width, args.height, cam, n_frames, rate=20.0, phase=1.7 * rank, device=f"cuda:{local_rank}")
+    seq = SyntheticSequence(args.width, args.height, cam, n_frames, rate=20.0, phase=dv_dist.sequence_phase(rank), device=f"cuda:{local_rank}")
 
     def run(kernel_timing):
         pipe = Pipeline(seq, max_cnt=args.max_cnt, min_dist=args.min_dist, max_iters=args.iters, device=local_rank)
@@ -69,8 +65,7 @@ def main():
             pipe.step()
         if kernel_timing:
             pipe.ctx.timing_enable(2)
-        if world > 1:
-            dist.barrier()
+        dv_dist.barrier()
         torch.cuda.synchronize()
         pipe.ctx.sync()
         t0 = time.perf_counter()
@@ -80,16 +75,12 @@ def main():
             iters += st.iterations
         pipe.ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        dv_dist.barrier()
         dt = time.perf_counter() - t0
         return pipe, dt, iters
 
     pipe, dt, iters = run(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = dv_dist.max_over_ranks(dt, device=f"cuda:{local_rank}")
     ate = pipe.ate()
     n_lm = int(pipe.est.state.n_long)
     nfeat = len(pipe.rows)
@@ -152,7 +143,7 @@ def main():
                "sample": f"{counted} steady-state frames of the same {args.width}x{args.height} sequence (CPU oracle: LK + Shi-Tomasi + dense-Schur dogleg BA + marginalization, single thread, g++ -O2)"}
 
     if rank == 0:
-        value = world * args.steps / dt
+        value = dv_dist.whole_job_rate(args.steps, world, dt)
         out = {
             "metric": "stereo frames/sec (track+BA)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -163,8 +154,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    dv_dist.finalize()
 
 
 if __name__ == "__main__":

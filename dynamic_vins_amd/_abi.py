@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdvins_hip.so")
+LIB_PATH = os.environ.get("DVINS_HIP_LIB") or os.path.join(_HERE, "lib", "libdvins_hip.so")
 
 DV_MEM_HOST, DV_MEM_DEVICE = 0, 1
 DV_MODE_RAW, DV_MODE_NAIVE = 0, 1

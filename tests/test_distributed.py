@@ -1,0 +1,47 @@
+"""world_size-2 test of the N > 1 path on CPU (gloo): launch protocol of bench.py (torch.distributed.run, env
+rendezvous on 127.0.0.1), barrier + MAX-over-ranks timing, landmark sharding and the rank-ordered all-reduce of the
+reduced camera system."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo(tmp_path):
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dist_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = [json.load(open(tmp_path / f"rank{k}.json")) for k in range(2)]
+    assert [x["rank"] for x in res] == [0, 1] and all(x["world"] == 2 for x in res)
+    assert all(x["tmax"] == 2.0 for x in res)              # MAX over ranks
+    assert all(x["sum"] == 3.0 for x in res)
+    assert res[0]["mine"] + res[1]["mine"] == 301          # the shards partition the landmarks
+    assert all(x["bitwise_rank_ordered"] for x in res)     # rank-ordered sum, same bits on both ranks
+    assert res[0]["digest"] == res[1]["digest"]
+    assert all(x["rel_err_vs_unsharded"] < 1e-12 for x in res)
+    assert all(x["rate"] == 100.0 for x in res)            # 2 ranks x 100 frames / 2.0 s
+
+
+def test_single_process_helpers_are_identity():
+    sys.path.insert(0, ROOT)
+    import torch
+    from dynamic_vins_amd import dist as d
+    assert d.max_over_ranks(3.5) == 3.5 and d.sum_over_ranks(2.0) == 2.0
+    t = torch.arange(5, dtype=torch.float64)
+    assert torch.equal(d.allreduce_reduced_system(t), t)
+    assert d.shard_landmarks(7, 0, 1) == list(range(7))
+    assert d.whole_job_rate(50, 1, 0.5) == 100.0

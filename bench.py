@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16)
+    ap.add_argument("--host-frames", action="store_true", help="frames handed over as host buffers: the PCIe-inclusive rate (never the headline value)")
     args = ap.parse_args()
 
     import numpy as np
@@ -60,7 +61,7 @@ def main():
     seq = SyntheticSequence(args.width, args.height, cam, n_frames, rate=20.0, phase=dv_dist.sequence_phase(rank), device=f"cuda:{local_rank}")
 
     def run(kernel_timing):
-        pipe = Pipeline(seq, max_cnt=args.max_cnt, min_dist=args.min_dist, max_iters=args.iters, device=local_rank)
+        pipe = Pipeline(seq, max_cnt=args.max_cnt, min_dist=args.min_dist, max_iters=args.iters, device=local_rank, host_frames=args.host_frames)
         for _ in range(warmup):
             pipe.step()
         if kernel_timing:
@@ -146,7 +147,7 @@ def main():
         value = dv_dist.whole_job_rate(args.steps, world, dt)
         out = {
             "metric": "stereo frames/sec (track+BA)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.host_frames else "synthetic (host buffers, PCIe upload inside the timed region)",
             "config": {"workload": f"synthetic {args.width}x{args.height} stereo @20 Hz + IMU @200 Hz, ZED intrinsics with distortion, figure-8 in a textured box room, "
                                    f"max_cnt {args.max_cnt}, min_dist {args.min_dist}, flow_back 1, {args.iters} solver iterations, BA + marginalization on every frame",
                        "parallelism": f"replicas x{world} (independent sequences, no collective)", "landmarks_in_window": n_lm, "features_per_frame": nfeat,

@@ -1,0 +1,364 @@
+// dvins_shim.hpp — header-only C++17 host shim: the reference's class surface for the hot path, on top of the C ABI
+// (include/dvins.h, libdvins_hip.so).  A dynamic_vins maintainer includes this instead of
+// front_end/background_tracker.h + estimator/estimator.h for the two objects constructed in Run()
+// (system/main.cpp:363-369); INTEGRATION.md shows the exact binding.  Depends on the STL only — the OpenCV / Eigen
+// types of the reference appear as small views and std::array, and conversion helpers are enabled when the
+// reference's own headers are in the translation unit (DVINS_SHIM_WITH_OPENCV / DVINS_SHIM_WITH_EIGEN).
+//
+//   dynamic_vins::FeatureTracker   front_end/background_tracker.h:41-88
+//        FeatureTracker(const std::string& config_path)
+//        FeatureBackground TrackImage(SemanticImage&)          background_tracker.cpp:52-158
+//        FeatureBackground TrackImageNaive(SemanticImage&)     background_tracker.cpp:400-516
+//   dynamic_vins::Estimator        estimator/estimator.h:55-164
+//        Estimator(const std::string& config_path); SetParameter(); ClearState();
+//        InputIMU(double t, const Vec3d& acc, const Vec3d& gyr)                     estimator.cpp:1765-1779
+//        ProcessMeasurements()  — blocking loop over feature_queue until cfg::ok is false   estimator.cpp:1786-1863
+//        ProcessMeasurements(const FrontendFeature&) — one iteration of that loop
+//   Errors: std::runtime_error, as the reference throws (bad config, empty input); the C ABI itself never throws.
+//   Threading: one FeatureTracker per tracking thread, one Estimator per back-end thread (each owns a dv_ctx);
+//   InputIMU may be called from another thread (guarded like the reference's buf_mutex).
+#pragma once
+#include <array>
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <memory>
+#include <thread>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <fstream>
+#include <map>
+#include <mutex>
+#include <optional>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dvins.h"
+
+namespace dynamic_vins {
+
+using Vec3d = std::array<double, 3>;   // Eigen::Vector3d            (utils/def.h)
+using Vec7d = std::array<double, 7>;   // Eigen::Matrix<double,7,1>: x_n y_n 1 u v vx vy
+using Mat3d = std::array<double, 9>;   // row-major
+
+// ---------------------------------------------------------------------------------------------------------------
+// Minimal reader of the cv::FileStorage YAML 1.0 files the reference ships (config/**/*.yaml): top-level scalars,
+// one level of nested maps ("projection_parameters: { fx, fy, cx, cy }" written as an indented block) and
+// "!!opencv-matrix" blocks with a (possibly multi-line) "data: [ ... ]".  Keys keep the reference's names.
+class YamlFile {
+public:
+    explicit YamlFile(const std::string& path) {
+        std::ifstream f(path);
+        if (!f) throw std::runtime_error("dvins: cannot open config " + path);
+        std::string line, section;
+        while (std::getline(f, line)) {
+            const size_t hash = find_comment(line);
+            if (hash != std::string::npos) line.erase(hash);
+            if (trim(line).empty() || line[0] == '%' || trim(line) == "---") continue;
+            const size_t indent = line.find_first_not_of(" \t");
+            const size_t colon = line.find(':');
+            if (colon == std::string::npos) { append_data(section, line); continue; }
+            std::string key = trim(line.substr(indent, colon - indent)), val = trim(line.substr(colon + 1));
+            if (indent == 0) {
+                section = key;
+                if (!val.empty() && val.rfind("!!", 0) != 0) { scalars_[key] = unquote(val); section.clear(); }
+            } else if (!section.empty()) {
+                if (key == "data") { data_open_ = true; append_data(section, val); }
+                else scalars_[section + "." + key] = unquote(val);
+            }
+        }
+    }
+    bool has(const std::string& k) const { return scalars_.count(k) != 0; }
+    std::string str(const std::string& k) const {
+        auto it = scalars_.find(k);
+        if (it == scalars_.end()) throw std::runtime_error("dvins: config key missing: " + k);
+        return it->second;
+    }
+    double num(const std::string& k) const { return std::strtod(str(k).c_str(), nullptr); }
+    double num(const std::string& k, double dflt) const { return has(k) ? num(k) : dflt; }
+    int integer(const std::string& k, int dflt) const { return has(k) ? (int)std::lround(num(k)) : dflt; }
+    const std::vector<double>& matrix(const std::string& k) const {
+        auto it = mats_.find(k);
+        if (it == mats_.end()) throw std::runtime_error("dvins: config matrix missing: " + k);
+        return it->second;
+    }
+    bool has_matrix(const std::string& k) const { return mats_.count(k) != 0; }
+
+private:
+    static size_t find_comment(const std::string& s) {
+        bool q = false;
+        for (size_t i = 0; i < s.size(); ++i) { if (s[i] == '"') q = !q; if (s[i] == '#' && !q) return i; }
+        return std::string::npos;
+    }
+    static std::string trim(const std::string& s) {
+        const size_t a = s.find_first_not_of(" \t\r\n"), b = s.find_last_not_of(" \t\r\n");
+        return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+    }
+    static std::string unquote(const std::string& s) { return s.size() >= 2 && s.front() == '"' && s.back() == '"' ? s.substr(1, s.size() - 2) : s; }
+    void append_data(const std::string& section, const std::string& text) {
+        if (!data_open_ || section.empty()) return;
+        std::string t = text;
+        for (char& c : t) if (c == '[' || c == ',') c = ' ';
+        const size_t close = t.find(']');
+        if (close != std::string::npos) { t.erase(close); }
+        std::istringstream is(t);
+        double v;
+        while (is >> v) mats_[section].push_back(v);
+        if (close != std::string::npos) data_open_ = false;
+    }
+    std::map<std::string, std::string> scalars_;
+    std::map<std::string, std::vector<double>> mats_;
+    bool data_open_ = false;
+};
+
+inline std::string dir_of(const std::string& path) {
+    const size_t s = path.find_last_of('/');
+    return s == std::string::npos ? std::string(".") : path.substr(0, s);
+}
+
+// camodocal PinholeCamera yaml (camera_models/src/camera_models/PinholeCamera.cc:210-260)
+inline dv_cam ReadPinholeCamera(const std::string& path) {
+    YamlFile y(path);
+    if (y.has("model_type") && y.str("model_type") != "PINHOLE") throw std::runtime_error("dvins: only PINHOLE cameras are on the path (" + path + ")");
+    dv_cam c{};
+    c.fx = y.num("projection_parameters.fx"); c.fy = y.num("projection_parameters.fy");
+    c.cx = y.num("projection_parameters.cx"); c.cy = y.num("projection_parameters.cy");
+    c.k1 = y.num("distortion_parameters.k1", 0); c.k2 = y.num("distortion_parameters.k2", 0);
+    c.p1 = y.num("distortion_parameters.p1", 0); c.p2 = y.num("distortion_parameters.p2", 0);
+    return c;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// data types of the boundary
+struct ImageView {                      // a CV_8UC1 cv::Mat: gray0 / gray1 / inv_merge_mask of SemanticImage
+    const uint8_t* data = nullptr; int width = 0, height = 0, stride = 0;
+    bool device = false;                // true: data is an HBM pointer (DV_MEM_DEVICE)
+    bool empty() const { return data == nullptr; }
+};
+struct SemanticImage {                  // basic/semantic_image.h:30-65 (the fields the path reads)
+    ImageView gray0, gray1, inv_merge_mask;
+    double time0 = 0; unsigned int seq = 0;
+};
+struct FeatureBackground {              // basic/frontend_feature.h:34-44
+    std::map<unsigned int, std::vector<std::pair<int, Vec7d>>> points;
+};
+struct FrontendFeature {                // basic/frontend_feature.h:52-75
+    FeatureBackground features; double time = 0; unsigned int seq_id = 0;
+};
+#ifdef DVINS_SHIM_WITH_OPENCV
+inline ImageView View(const cv::Mat& m) { return ImageView{m.data, m.cols, m.rows, (int)m.step, false}; }
+#endif
+#ifdef DVINS_SHIM_WITH_EIGEN
+inline Eigen::Matrix<double, 7, 1> ToEigen(const Vec7d& v) { return Eigen::Map<const Eigen::Matrix<double, 7, 1>>(v.data()); }
+inline Vec3d FromEigen(const Eigen::Vector3d& v) { return Vec3d{v.x(), v.y(), v.z()}; }
+#endif
+
+namespace detail {
+inline void check(dv_ctx* ctx, int rc, const char* what) {
+    if (rc != 0) throw std::runtime_error(std::string("dvins: ") + what + ": " + dv_last_error(ctx));
+}
+inline FeatureBackground to_points(const dv_feat* rows, int n) {      // FeatureTracker::SetOutputFeats (background_tracker.cpp:340-392)
+    FeatureBackground fb;
+    for (int i = 0; i < n; ++i) {
+        Vec7d l; std::memcpy(l.data(), rows[i].left, sizeof(double) * 7);
+        auto& v = fb.points[rows[i].id];
+        v.emplace_back(0, l);
+        if (rows[i].has_right) { Vec7d r; std::memcpy(r.data(), rows[i].right, sizeof(double) * 7); v.emplace_back(1, r); }
+    }
+    return fb;
+}
+inline std::vector<dv_feat> to_rows(const FeatureBackground& fb) {
+    std::vector<dv_feat> rows;
+    rows.reserve(fb.points.size());
+    for (const auto& kv : fb.points) {
+        dv_feat f{};
+        f.id = kv.first; f.track_cnt = 1;
+        for (const auto& ob : kv.second) {
+            if (ob.first == 0) std::memcpy(f.left, ob.second.data(), sizeof(double) * 7);
+            else { std::memcpy(f.right, ob.second.data(), sizeof(double) * 7); f.has_right = 1; }
+        }
+        rows.push_back(f);
+    }
+    return rows;
+}
+}  // namespace detail
+
+// ---------------------------------------------------------------------------------------------------------------
+class FeatureTracker {
+public:
+    using Ptr = std::shared_ptr<FeatureTracker>;
+    explicit FeatureTracker(const std::string& config_path, int device = 0) {
+        YamlFile y(config_path);
+        dv_config c{};
+        c.width = y.integer("image_width", 0); c.height = y.integer("image_height", 0);
+        c.max_cnt = y.integer("max_cnt", 150); c.min_dist = y.integer("min_dist", 30);
+        c.flow_back = y.integer("flow_back", 1); c.stereo = y.integer("num_of_cam", 2) == 2; c.device = device;
+        const std::string dir = dir_of(config_path);
+        c.cam0 = ReadPinholeCamera(dir + "/" + y.str("cam0_calib"));
+        c.cam1 = c.stereo ? ReadPinholeCamera(dir + "/" + y.str("cam1_calib")) : c.cam0;
+        init(c);
+    }
+    explicit FeatureTracker(const dv_config& c) { init(c); }
+    ~FeatureTracker() { if (ctx_) dv_destroy(ctx_); }
+    FeatureTracker(const FeatureTracker&) = delete;
+    FeatureTracker& operator=(const FeatureTracker&) = delete;
+
+    FeatureBackground TrackImage(SemanticImage& img) { return track(img, DV_MODE_RAW); }
+    FeatureBackground TrackImageNaive(SemanticImage& img) { return track(img, DV_MODE_NAIVE); }
+    // two-phase form: lets the caller overlap the front end of frame k+1 with the back end of frame k
+    void TrackImageEnqueue(SemanticImage& img, int mode = DV_MODE_RAW) {
+        check_image(img);
+        cur_time = img.time0;
+        detail::check(ctx_, dv_track_stereo_enqueue(ctx_, img.gray0.data, img.gray1.data, img.gray0.width, img.gray0.height, img.gray0.stride, img.time0,
+                                                    img.inv_merge_mask.data, mode, img.gray0.device ? DV_MEM_DEVICE : DV_MEM_HOST), "TrackImage");
+    }
+    FeatureBackground TrackImageCollect() {
+        int n = 0;
+        detail::check(ctx_, dv_track_stereo_collect(ctx_, rows_.data(), &n), "TrackImage");
+        n_rows_ = n;
+        return detail::to_points(rows_.data(), n);
+    }
+    const dv_feat* rows() const { return rows_.data(); }      // the same output as flat rows (what Estimator::ProcessMeasurements consumes)
+    int n_rows() const { return n_rows_; }
+    dv_ctx* ctx() { return ctx_; }
+    double cur_time = 0;
+
+private:
+    void init(const dv_config& c) {
+        cfg_ = c;
+        ctx_ = dv_create(&cfg_);
+        if (!ctx_) throw std::runtime_error(std::string("dvins: FeatureTracker: ") + dv_last_error(nullptr));
+        rows_.resize(DV_MAX_FEATS);
+    }
+    void check_image(const SemanticImage& img) const {
+        if (img.gray0.empty() || (cfg_.stereo && img.gray1.empty())) throw std::runtime_error("dvins: TrackImage: empty image");
+        if (img.gray0.width != cfg_.width || img.gray0.height != cfg_.height) throw std::runtime_error("dvins: TrackImage: image size differs from image_width/image_height");   // main.cpp:95-99
+    }
+    FeatureBackground track(SemanticImage& img, int mode) {
+        check_image(img);
+        cur_time = img.time0;
+        int n = 0;
+        detail::check(ctx_, dv_track_stereo(ctx_, img.gray0.data, img.gray1.data, img.gray0.width, img.gray0.height, img.gray0.stride, img.time0,
+                                            img.inv_merge_mask.data, mode, img.gray0.device ? DV_MEM_DEVICE : DV_MEM_HOST, rows_.data(), &n), "TrackImage");
+        n_rows_ = n;
+        return detail::to_points(rows_.data(), n);
+    }
+    dv_config cfg_{};
+    dv_ctx* ctx_ = nullptr;
+    std::vector<dv_feat> rows_;
+    int n_rows_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+class Estimator {
+public:
+    using Ptr = std::shared_ptr<Estimator>;
+    enum SolverFlag { kInitial = 0, kNonLinear = 1 };
+    explicit Estimator(const std::string& config_path, int device = 0) {
+        YamlFile y(config_path);
+        std::memset(&cfg_, 0, sizeof(cfg_));
+        cfg_.use_imu = y.integer("imu", 0); cfg_.stereo = y.integer("num_of_cam", 2) == 2;
+        cfg_.plane_constraint = y.integer("plane_constraint", 0);
+        cfg_.max_iters = y.integer("max_num_iterations", 8);
+        cfg_.keyframe_parallax = y.num("keyframe_parallax", 10.0);
+        cfg_.init_depth = y.num("INIT_DEPTH", 5.0);
+        cfg_.g_norm = y.num("g_norm", 9.81007); cfg_.td = y.num("td", 0.0);
+        cfg_.acc_n = y.num("acc_n", 0.1); cfg_.gyr_n = y.num("gyr_n", 0.01); cfg_.acc_w = y.num("acc_w", 0.001); cfg_.gyr_w = y.num("gyr_w", 1e-4);
+        if (y.integer("estimate_extrinsic", 0) != 0 || y.integer("estimate_td", 0) != 0)
+            throw std::runtime_error("dvins: estimate_extrinsic / estimate_td != 0 are not on the accelerated path (every shipped config sets 0)");
+        for (int c = 0; c < 2; ++c) {
+            const std::string key = c == 0 ? "body_T_cam0" : "body_T_cam1";
+            if (!y.has_matrix(key)) { if (c == 1 && !cfg_.stereo) continue; throw std::runtime_error("dvins: " + key + " missing"); }
+            const std::vector<double>& T = y.matrix(key);
+            if (T.size() != 16) throw std::runtime_error("dvins: " + key + " must be 4x4");
+            for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) cfg_.ric[c][r * 3 + k] = T[r * 4 + k]; cfg_.tic[c][r] = T[r * 4 + 3]; }
+        }
+        dv_config fc{};
+        fc.width = 64; fc.height = 48; fc.max_cnt = 8; fc.min_dist = 8; fc.flow_back = 1; fc.stereo = 1; fc.device = device;
+        fc.cam0 = dv_cam{1, 1, 0, 0, 0, 0, 0, 0}; fc.cam1 = fc.cam0;
+        ctx_ = dv_create(&fc);
+        if (!ctx_) throw std::runtime_error(std::string("dvins: Estimator: ") + dv_last_error(nullptr));
+        SetParameter();
+    }
+    ~Estimator() { if (ctx_) dv_destroy(ctx_); }
+    Estimator(const Estimator&) = delete;
+    Estimator& operator=(const Estimator&) = delete;
+
+    void SetParameter() {                                    // estimator.cpp:1701-1716
+        std::lock_guard<std::mutex> lk(process_mutex_);
+        detail::check(ctx_, created_ ? dv_est_reset(ctx_) : dv_est_create(ctx_, &cfg_), "SetParameter");
+        created_ = true;
+    }
+    void ClearState() {                                      // estimator.cpp:1719-1757
+        std::lock_guard<std::mutex> lk(process_mutex_);
+        detail::check(ctx_, dv_est_reset(ctx_), "ClearState");
+        state_ = dv_est_state{};
+    }
+    void InputIMU(double t, const Vec3d& acc, const Vec3d& gyr) {
+        std::lock_guard<std::mutex> lk(buf_mutex_);
+        detail::check(ctx_, dv_est_input_imu(ctx_, t, acc.data(), gyr.data()), "InputIMU");
+    }
+    // one iteration of the reference's ProcessMeasurements loop: returns false when the IMU stream does not yet cover
+    // the frame (the reference sleeps 5 ms and retries, estimator.cpp:1800-1812)
+    bool ProcessMeasurements(const FrontendFeature& f) {
+        const std::vector<dv_feat> rows = detail::to_rows(f.features);
+        return ProcessMeasurements(rows.data(), (int)rows.size(), f.time);
+    }
+    bool ProcessMeasurements(const dv_feat* rows, int n, double time) {
+        std::lock_guard<std::mutex> lk(process_mutex_);
+        int rc;
+        { std::lock_guard<std::mutex> lk2(buf_mutex_); rc = dv_est_process(ctx_, rows, n, time, &state_); }
+        if (rc == 1) return false;
+        detail::check(ctx_, rc, "ProcessMeasurements");
+        solver_flag = state_.nonlinear ? kNonLinear : kInitial;
+        margin_old = state_.margin_old != 0;
+        frame = state_.frame;
+        return true;
+    }
+    // the reference's blocking form: pops the shared queue until `ok` turns false
+    void PushFeature(FrontendFeature f) { { std::lock_guard<std::mutex> lk(q_mutex_); queue_.push_back(std::move(f)); } q_cv_.notify_one(); }
+    void ProcessMeasurements(const std::atomic<bool>& ok) {
+        while (ok.load()) {
+            FrontendFeature f;
+            {
+                std::unique_lock<std::mutex> lk(q_mutex_);
+                if (!q_cv_.wait_for(lk, std::chrono::milliseconds(2), [&] { return !queue_.empty(); })) continue;
+                f = std::move(queue_.front()); queue_.pop_front();
+            }
+            while (ok.load() && !ProcessMeasurements(f)) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+        }
+    }
+    // body.Ps / body.Rs / Vs / Bas / Bgs of window slot i (body.h:94): [px py pz qx qy qz qw vx vy vz bax bay baz bgx bgy bgz]
+    std::array<double, 16> WindowState(int i) const { std::array<double, 16> a; std::memcpy(a.data(), state_.window[i], sizeof(double) * 16); return a; }
+    const dv_est_state& state() const { return state_; }
+    dv_ctx* ctx() { return ctx_; }
+
+    SolverFlag solver_flag = kInitial;
+    bool margin_old = false;
+    int frame = 0;
+
+private:
+    dv_est_config cfg_;
+    dv_est_state state_{};
+    dv_ctx* ctx_ = nullptr;
+    bool created_ = false;
+    std::mutex buf_mutex_, process_mutex_, q_mutex_;
+    std::condition_variable q_cv_;
+    std::deque<FrontendFeature> queue_;
+};
+
+// trajectory line of the reference's writer: "<stamp> px py pz qx qy qz qw" (utils/io/output.cpp:199-227)
+inline std::string TumLine(double stamp, const std::array<double, 16>& s) {
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "%f %f %f %f %f %f %f %f", stamp, s[0], s[1], s[2], s[3], s[4], s[5], s[6]);
+    return buf;
+}
+
+}  // namespace dynamic_vins

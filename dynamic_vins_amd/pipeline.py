@@ -5,7 +5,7 @@ import numpy as np
 
 from . import sim
 from .backend import Estimator
-from .frontend import Context, DV_MEM_DEVICE, DV_MODE_RAW, make_cam
+from .frontend import Context, DV_MEM_DEVICE, DV_MEM_HOST, DV_MODE_RAW, make_cam
 
 
 class SyntheticSequence:
@@ -29,8 +29,9 @@ class SyntheticSequence:
 
 
 class Pipeline:
-    def __init__(self, seq: SyntheticSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1):
+    def __init__(self, seq: SyntheticSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, host_frames=False):
         self.seq = seq
+        self.host = [seq.host_frame(k) for k in range(len(seq.frames))] if host_frames else None
         c = make_cam(*sim.cam_tuple(seq.cam))
         self.ctx = Context(width=seq.w, height=seq.h, max_cnt=max_cnt, min_dist=min_dist, cam0=c, cam1=c, device=device)
         self.est = Estimator(self.ctx, use_imu=use_imu, stereo=1, max_iters=max_iters, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], **seq.noise)
@@ -40,8 +41,12 @@ class Pipeline:
         self.poses, self.pose_times = [], []
 
     def _enqueue(self, k):
-        l, r = self.seq.frames[k]
-        self.ctx.track_stereo_enqueue(l.data_ptr(), r.data_ptr(), self.seq.times[k], None, DV_MODE_RAW, DV_MEM_DEVICE)
+        if self.host is not None:                      # host buffers: the upload rides on the tracking stream
+            l, r = self.host[k]
+            self.ctx.track_stereo_enqueue(l, r, self.seq.times[k], None, DV_MODE_RAW, DV_MEM_HOST)
+        else:
+            l, r = self.seq.frames[k]
+            self.ctx.track_stereo_enqueue(l.data_ptr(), r.data_ptr(), self.seq.times[k], None, DV_MODE_RAW, DV_MEM_DEVICE)
         self.enqueued = True
 
     def step(self):

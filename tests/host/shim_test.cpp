@@ -1,0 +1,69 @@
+// test driver of dynamic_vins_amd/host/dvins_shim.hpp (built by tests/test_host_shim.py with g++):
+//   shim_test parse <config.yaml>                      -> prints the parsed configuration (CPU)
+//   shim_test nogpu <config.yaml>                      -> constructing the tracker without a device must throw (CPU)
+//   shim_test track <config.yaml> <frames.raw> <n> <w> <h>  -> runs TrackImage over n stereo pairs read from a raw file,
+//                                                         feeds a constant-gravity IMU stream and runs the Estimator (GPU)
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <thread>
+#include "dvins_shim.hpp"
+
+using namespace dynamic_vins;
+
+int main(int argc, char** argv) {
+    if (argc < 3) return 2;
+    const std::string mode = argv[1], cfg = argv[2];
+    try {
+        if (mode == "parse") {
+            YamlFile y(cfg);
+            const dv_cam c = ReadPinholeCamera(dir_of(cfg) + "/" + y.str("cam0_calib"));
+            std::printf("width %d height %d max_cnt %d min_dist %d flow_back %d stereo %d imu %d iters %d\n", y.integer("image_width", 0), y.integer("image_height", 0),
+                        y.integer("max_cnt", 0), y.integer("min_dist", 0), y.integer("flow_back", 0), y.integer("num_of_cam", 0) == 2, y.integer("imu", 0), y.integer("max_num_iterations", 0));
+            std::printf("slam_type %s acc_n %.17g g_norm %.17g parallax %.17g\n", y.str("slam_type").c_str(), y.num("acc_n"), y.num("g_norm"), y.num("keyframe_parallax"));
+            std::printf("cam %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", c.fx, c.fy, c.cx, c.cy, c.k1, c.k2, c.p1, c.p2);
+            for (const char* k : {"body_T_cam0", "body_T_cam1"}) { std::printf("%s", k); for (double v : y.matrix(k)) std::printf(" %g", v); std::printf("\n"); }
+            return 0;
+        }
+        if (mode == "nogpu") {
+            try { FeatureTracker t(cfg); } catch (const std::runtime_error& e) { std::printf("THROWN %s\n", e.what()); return 0; }
+            std::printf("NO EXCEPTION\n");
+            return 1;
+        }
+        if (mode == "track" && argc >= 7) {
+            const int n = std::atoi(argv[4]), w = std::atoi(argv[5]), h = std::atoi(argv[6]);
+            std::ifstream f(argv[3], std::ios::binary);
+            std::vector<uint8_t> buf((size_t)n * 2 * w * h);
+            f.read((char*)buf.data(), buf.size());
+            dv_config c{};
+            {   // the YAML gives 1280x720; the test frames are smaller, so build the config explicitly but through the same readers
+                YamlFile y(cfg);
+                c.width = w; c.height = h; c.max_cnt = 30; c.min_dist = 10; c.flow_back = y.integer("flow_back", 1); c.stereo = 1;
+                c.cam0 = ReadPinholeCamera(dir_of(cfg) + "/" + y.str("cam0_calib"));
+                c.cam0.fx *= w / 1280.0; c.cam0.cx *= w / 1280.0; c.cam0.fy *= h / 720.0; c.cam0.cy *= h / 720.0;
+                c.cam1 = c.cam0;
+            }
+            FeatureTracker tracker(c);
+            Estimator est(cfg);
+            double t_imu = 0.95;
+            for (int k = 0; k < n; ++k) {
+                SemanticImage img;
+                img.gray0 = ImageView{buf.data() + (size_t)(2 * k) * w * h, w, h, w, false};
+                img.gray1 = ImageView{buf.data() + (size_t)(2 * k + 1) * w * h, w, h, w, false};
+                img.time0 = 1.0 + 0.05 * k; img.seq = k;
+                FeatureBackground fb = tracker.TrackImage(img);
+                std::printf("frame %d n %zu ids", k, fb.points.size());
+                unsigned long long idsum = 0; int stereo = 0;
+                for (auto& kv : fb.points) { idsum += kv.first; stereo += kv.second.size() == 2; }
+                std::printf(" %llu stereo %d first %.9f %.9f\n", idsum, stereo, fb.points.begin()->second[0].second[3], fb.points.begin()->second[0].second[4]);
+                for (; t_imu <= img.time0 + 0.006; t_imu += 0.005) est.InputIMU(t_imu, Vec3d{0, 0, 9.81007}, Vec3d{0, 0, 0});
+                FrontendFeature ff; ff.features = fb; ff.time = img.time0; ff.seq_id = k;
+                const bool ok = est.ProcessMeasurements(ff);
+                std::printf("est ok %d frame %d nonlinear %d\n", (int)ok, est.frame, (int)est.solver_flag);
+            }
+            std::printf("%s\n", TumLine(1.0, est.WindowState(est.frame)).c_str());
+            return 0;
+        }
+    } catch (const std::exception& e) { std::printf("EXCEPTION %s\n", e.what()); return 3; }
+    return 2;
+}

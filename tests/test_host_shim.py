@@ -1,0 +1,68 @@
+"""The C++ host shim (dynamic_vins_amd/host/dvins_shim.hpp: the reference's FeatureTracker / Estimator class surface on
+top of the C ABI): compiles with plain g++ against include/dvins.h, reads the reference's YAML dialect, fails loudly
+without a device (CPU), and on the GPU produces exactly what the ctypes path produces."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CFG = os.path.join(ROOT, "tests", "golden", "config", "zed_like.yaml")
+
+
+@pytest.fixture(scope="module")
+def shim_exe(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("shim") / "shim_test")
+    lib = os.path.join(ROOT, "dynamic_vins_amd", "lib")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "dynamic_vins_amd", "host"),
+           os.path.join(ROOT, "tests", "host", "shim_test.cpp"), "-o", exe, "-L" + lib, "-ldvins_hip", "-Wl,-rpath," + lib, "-lpthread"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_shim_parses_the_reference_yaml_dialect(shim_exe):
+    out = subprocess.run([shim_exe, "parse", CFG], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "width 1280 height 720 max_cnt 250 min_dist 25 flow_back 1 stereo 1 imu 1 iters 10"
+    assert out[1].startswith("slam_type raw acc_n 0.013816015296770526 g_norm 9.81006999") and out[1].endswith("parallax 15")
+    cam = [float(x) for x in out[2].split()[1:]]
+    assert cam == [701.406049185687, 700.7199834541797, 663.9703743586792, 362.02045484177154,
+                   -0.17198906485492285, 0.024624053031210322, 0.0003391614313509814, -0.00045583634752113735]
+    assert out[3] == "body_T_cam0 0 0 1 0 1 0 0 0 0 1 0 0 0 0 0 1"
+    assert out[4] == "body_T_cam1 0 0 1 0 1 0 0 0.12 0 1 0 0 0 0 0 1"      # multi-line data, commented-out duplicate ignored
+
+
+def test_shim_fails_loudly_without_a_device(shim_exe):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    r = subprocess.run([shim_exe, "nogpu", CFG], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("THROWN dvins: FeatureTracker:"), r.stdout
+
+
+@pytest.mark.gpu
+def test_shim_matches_the_ctypes_path(shim_exe, tmp_path, gpu_ctx_factory):
+    from dynamic_vins_amd import sim
+    from dynamic_vins_amd.frontend import make_cam
+    g = np.load(os.path.join(ROOT, "tests", "golden", "front_kat.npz"))
+    n, h, w = g["left"].shape
+    raw = tmp_path / "frames.raw"
+    with open(raw, "wb") as f:
+        for k in range(n):
+            f.write(g["left"][k].tobytes()); f.write(g["right"][k].tobytes())
+    r = subprocess.run([shim_exe, "track", CFG, str(raw), str(n), str(w), str(h)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("frame ")]
+    cam = make_cam(*sim.cam_tuple(sim.scaled_cam(sim.ZED, w, h, 1280, 720)))
+    ctx = gpu_ctx_factory(width=w, height=h, max_cnt=30, min_dist=10, cam0=cam, cam1=cam)
+    for k in range(n):
+        rows = ctx.track_stereo(g["left"][k], g["right"][k], 1.0 + 0.05 * k)
+        tok = lines[k].split()
+        assert int(tok[3]) == len(rows)
+        assert int(tok[5]) == int(rows["id"].astype(np.int64).sum())
+        assert int(tok[7]) == int(rows["has_right"].sum())
+        first = rows[np.argmin(rows["id"])]
+        assert abs(float(tok[9]) - first["left"][3]) < 1e-8 and abs(float(tok[10]) - first["left"][4]) < 1e-8
+    est = [ln for ln in r.stdout.splitlines() if ln.startswith("est ok")]
+    assert len(est) == n and all(ln.startswith("est ok 1") for ln in est)

@@ -111,8 +111,18 @@ def main():
         }.get(dom, 0)
         avg_s = kern[dom]["avg_us"] * 1e-6
         achieved = alg / avg_s / 1e9 if avg_s > 0 else 0.0
+        # HBM-side bytes per launch from the committed PMC passes (profiles/pmc_traffic.json; a PMC run cannot share a process with the timed run)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
+            key = {"k_be_solve": "be_solve_kernel<1>", "k_be_reduce": "be_reduce_kernel", "k_be_eval_full": "be_eval_kernel<true>", "k_be_eval_cost": "be_eval_kernel<false>",
+                   "lk_temporal": "lk_track_kernel", "lk_stereo": "lk_track_kernel", "gftt_eig": "gftt_tile_kernel", "gftt_select": "gftt_select_kernel", "pyr": "pyr_down_kernel"}.get(dom)
+            if key in pmc:
+                traffic = int(pmc[key]["traffic_bytes"])
+        except (OSError, KeyError, ValueError):
+            traffic = None
         roof = {"kernel": (dom[2:] if dom.startswith("k_") else dom), "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_us": round(kern[dom]["avg_us"], 2),
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_us": round(kern[dom]["avg_us"], 2),
                 "algorithmic_bytes_per_launch": int(alg),
                 "kernels_us": {(k[2:] if k.startswith("k_") else k): round(v["avg_us"], 1) for k, v in kern.items()}}
         pipe2.ctx.close()

@@ -15,12 +15,15 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t n = BE_MAX_STATE;
-    size_t o_ctl = take(sizeof(BeCtl)), o_x = take(sizeof(BeState)), o_c = take(sizeof(BeState)), o_fac = take(sizeof(BeFactor) * (size_t)fac_cap),
-           o_lm = take(sizeof(BeLm) * BE_MAX_LM), o_imu = take(sizeof(BeImu) * BE_WIN), o_pr = take(sizeof(BePriorHdr)),
+    // upload region first (mirrored 1:1 by the pinned staging buffer -> ONE H2D copy per solve), factors last (variable length)
+    size_t o_ctl = take(sizeof(BeCtl)), o_x = take(sizeof(BeState)), o_imu = take(sizeof(BeImu) * BE_WIN), o_pr = take(sizeof(BePriorHdr)), o_i = take(4 * 4 * n),
+           o_lm = take(sizeof(BeLm) * BE_MAX_LM), o_fac = take(sizeof(BeFactor) * (size_t)fac_cap);
+    const size_t upload_bytes = off;
+    size_t o_c = take(sizeof(BeState)),
            o_pA = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb = take(8 * BE_MAX_PRIOR),
            o_pk = take(8 * (size_t)BE_PK_SIZE * BE_PK_STRIDE), o_io = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po = take(8 * (BE_MAX_PRIOR + 1)),
            o_cc = take(8 * (BE_MAX_LM + BE_WIN + 1)), o_hd = take(8 * n * n), o_sc = take(8 * n * n), o_g = take(8 * 2 * n),
-           o_v = take(8 * 4 * n), o_vl = take(8 * 4 * (size_t)BE_MAX_LM), o_i = take(4 * 4 * n);
+           o_v = take(8 * 4 * n), o_vl = take(8 * 4 * (size_t)BE_MAX_LM);
     DV_CHECK(w.block.ensure(off));
     uint8_t* b = (uint8_t*)w.block.p;
     w.ctl = (BeCtl*)(b + o_ctl); w.x = (BeState*)(b + o_x); w.cand = (BeState*)(b + o_c); w.fac = (BeFactor*)(b + o_fac); w.lm = (BeLm*)(b + o_lm);
@@ -31,10 +34,15 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     double* vl = (double*)(b + o_vl); w.scale_l = vl; w.diag_l = vl + BE_MAX_LM; w.grad_l = vl + 2 * BE_MAX_LM; w.gn_l = vl + 3 * BE_MAX_LM;
     int32_t* iv = (int32_t*)(b + o_i); w.prior_col = iv; w.col_kind = iv + n; w.col_frame = iv + 2 * n; w.col_comp = iv + 3 * n;
     w.fac_cap = fac_cap;
-    if (!w.pinned) {
-        w.pinned_bytes = sizeof(BeState) + sizeof(BeCtl) + sizeof(BeImu) * BE_WIN + 4096;
-        DV_CHECK(hipHostMalloc(&w.pinned, w.pinned_bytes, hipHostMallocDefault));
+    w.up_ctl = o_ctl; w.up_x = o_x; w.up_imu = o_imu; w.up_prior = o_pr; w.up_idx = o_i; w.up_lm = o_lm; w.up_fac = o_fac;
+    const size_t need = upload_bytes + sizeof(BeState) + sizeof(BeCtl) + 4096;        // staging mirror + download area
+    if (w.pinned_bytes < need) {
+        if (w.pinned) (void)hipHostFree(w.pinned);
+        w.pinned = nullptr;
+        DV_CHECK(hipHostMalloc(&w.pinned, need, hipHostMallocDefault));
+        w.pinned_bytes = need;
     }
+    w.dl_off = upload_bytes;
     w.ready = true;
     return 0;
 }
@@ -64,20 +72,23 @@ static bool imu_sqrt_info(const double* cov, double* U) {
     return true;
 }
 
-int be_fill_imu(const dv_ba_imu& in, BeImu& o) {
+int be_fill_imu(const dv_ba_imu& in, BeImu& o, const double* sqrt_hint) {
     o.sum_dt = in.sum_dt;
     for (int k = 0; k < 3; ++k) { o.dp[k] = in.dp[k]; o.dv[k] = in.dv[k]; o.lin_ba[k] = in.lin_ba[k]; o.lin_bg[k] = in.lin_bg[k]; }
     for (int k = 0; k < 4; ++k) o.dq[k] = in.dq[k];
     auto blk = [&](int r0, int c0, double* dst) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) dst[i * 3 + j] = in.jacobian[(r0 + i) * 15 + c0 + j]; };
     blk(0, 9, o.dp_dba); blk(0, 12, o.dp_dbg); blk(3, 12, o.dq_dbg); blk(6, 9, o.dv_dba); blk(6, 12, o.dv_dbg);
     o.fi = in.fi; o.fj = in.fj; o.pad0 = o.pad1 = 0;
+    if (sqrt_hint) { std::memcpy(o.sqrt_info, sqrt_hint, sizeof(o.sqrt_info)); return 0; }
     return imu_sqrt_info(in.covariance, o.sqrt_info) ? 0 : -1;
 }
+bool be_imu_sqrt_info(const double* cov, double* U) { return imu_sqrt_info(cov, U); }
 
 extern "C" {
 
 int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
     if (!ctx) return -1;
+    const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     if (!P || !P->pose || !P->ex_pose || !P->td) DV_FAIL("dv_ba_solve: null argument");
     if (P->nframes < 1 || P->nframes > BE_NF) DV_FAIL("dv_ba_solve: nframes out of range");
     if (P->nlm < 0 || P->nlm > BE_MAX_LM) DV_FAIL("dv_ba_solve: more than kNumFeat=1000 landmarks");
@@ -117,30 +128,32 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
             if (c0 >= 0) for (int k = 0; k < pb.size_local; ++k) prior_col[c0 + k] = pb.off + k;
         }
     }
-    // ---- upload ----
-    BeState* hx = (BeState*)w.pinned;
+    // ---- upload: everything is staged in the pinned mirror of the device's upload region and travels in ONE copy ----
+    uint8_t* hp = (uint8_t*)w.pinned;
+    BeState* hx = (BeState*)(hp + w.up_x);
     std::memset(hx, 0, offsetof(BeState, inv_depth));
     for (int f = 0; f < P->nframes; ++f) { std::memcpy(hx->pose[f], P->pose + 7 * f, 56); if (P->use_imu) std::memcpy(hx->sb[f], P->speed_bias + 9 * f, 72); }
     std::memcpy(hx->ex, P->ex_pose, 14 * 8); hx->td = P->td[0];
     if (P->nlm) std::memcpy(hx->inv_depth, P->inv_depth, 8 * (size_t)P->nlm);
     const size_t state_bytes = offsetof(BeState, inv_depth) + 8 * (size_t)P->nlm;
-    BeCtl* hctl = (BeCtl*)((uint8_t*)w.pinned + sizeof(BeState));
+    BeCtl* hctl = (BeCtl*)(hp + w.up_ctl);
     std::memset(hctl, 0, sizeof(BeCtl));
     hctl->need_eval = 1; hctl->first = 1; hctl->max_iters = P->max_iters; hctl->radius = 1e4; hctl->mu = 1e-8; hctl->step_valid = 0;
-    BeImu* himu = (BeImu*)((uint8_t*)w.pinned + sizeof(BeState) + sizeof(BeCtl));
-    for (int k = 0; k < P->nimu; ++k) if (be_fill_imu(P->imu[k], himu[k])) DV_FAIL("dv_ba_solve: IMU covariance is singular");
-    DV_CHECK(hipMemcpyAsync(w.x, hx, state_bytes, hipMemcpyHostToDevice, s));
-    DV_CHECK(hipMemcpyAsync(w.ctl, hctl, sizeof(BeCtl), hipMemcpyHostToDevice, s));
-    if (P->nimu) DV_CHECK(hipMemcpyAsync(w.imu, himu, sizeof(BeImu) * P->nimu, hipMemcpyHostToDevice, s));
-    if (P->nfac) DV_CHECK(hipMemcpyAsync(w.fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac, hipMemcpyHostToDevice, s));
-    if (P->nlm) DV_CHECK(hipMemcpyAsync(w.lm, P->landmarks, sizeof(BeLm) * (size_t)P->nlm, hipMemcpyHostToDevice, s));
-    DV_CHECK(hipMemcpyAsync(w.prior, &ph, sizeof(ph), hipMemcpyHostToDevice, s));
-    if (has_prior) {
+    BeImu* himu = (BeImu*)(hp + w.up_imu);
+    for (int k = 0; k < P->nimu; ++k) {
+        const double* hint = (k < (int)w.sqrt_hint.size()) ? w.sqrt_hint[k] : nullptr;      // the estimator caches U per pre-integration (Q8)
+        if (be_fill_imu(P->imu[k], himu[k], hint)) DV_FAIL("dv_ba_solve: IMU covariance is singular");
+    }
+    std::memcpy(hp + w.up_prior, &ph, sizeof(ph));
+    std::memcpy(hp + w.up_idx, idx.data(), 4 * idx.size());
+    if (P->nlm) std::memcpy(hp + w.up_lm, P->landmarks, sizeof(BeLm) * (size_t)P->nlm);
+    if (P->nfac) std::memcpy(hp + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac);
+    DV_CHECK(hipMemcpyAsync(w.block.p, hp, w.up_fac + sizeof(BeFactor) * (size_t)P->nfac, hipMemcpyHostToDevice, s));
+    if (has_prior && P->prior_A != w.priorA) {        // a prior handed over in host memory (the estimator keeps its prior device-resident)
         DV_CHECK(hipMemcpyAsync(w.priorA, P->prior_A, 8 * (size_t)ph.n * ph.n, hipMemcpyHostToDevice, s));
         DV_CHECK(hipMemcpyAsync(w.priorb, P->prior_b, 8 * (size_t)ph.n, hipMemcpyHostToDevice, s));
     }
-    DV_CHECK(hipMemcpyAsync(w.prior_col, idx.data(), 4 * idx.size(), hipMemcpyHostToDevice, s));
-    DV_CHECK(hipStreamSynchronize(s));        // idx / ph are host stack/heap objects
+    std::chrono::steady_clock::time_point t_up = std::chrono::steady_clock::now();
     // ---- schedule ----
     BeEvalArgs ea{};
     ea.ctl = w.ctl; ea.x = w.x; ea.cand = w.cand; ea.fac = w.fac; ea.lm = w.lm; ea.imu = w.imu; ea.prior = w.prior; ea.priorA = w.priorA; ea.priorb = w.priorb;
@@ -170,11 +183,17 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
             }
         }
     }
+    std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
     DV_CHECK(hipGetLastError());
+    hx = (BeState*)(hp + w.dl_off); hctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState));
     DV_CHECK(hipMemcpyAsync(hx, w.x, state_bytes, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
-    if (ctx->timing) dv_harvest_timers(ctx, s);
+    if (ctx->timing) {
+        StageTimer* te = dv_timer_for(ctx, "h_solve_enqueue"); te->total_ms += std::chrono::duration<double, std::milli>(t_enq - t_up).count(); te->count++;
+        StageTimer* tu = dv_timer_for(ctx, "h_solve_upload"); tu->total_ms += std::chrono::duration<double, std::milli>(t_up - t_begin).count(); tu->count++;
+        dv_harvest_timers(ctx, s);
+    }
     for (int f = 0; f < P->nframes; ++f) { std::memcpy(P->pose + 7 * f, hx->pose[f], 56); if (P->use_imu) std::memcpy(P->speed_bias + 9 * f, hx->sb[f], 72); }
     if (P->nlm) std::memcpy(P->inv_depth, hx->inv_depth, 8 * (size_t)P->nlm);
     if (summary) {
@@ -240,7 +259,7 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     }
     BeImu himu{};
     if (nimu == 1) {
-        if (be_fill_imu(P->imu[0], himu)) DV_FAIL("dv_marginalize: IMU covariance is singular");
+        if (be_fill_imu(P->imu[0], himu, nullptr)) DV_FAIL("dv_marginalize: IMU covariance is singular");
         for (int k = 0; k < 6; ++k) { imu_map[k] = pose_dim[0] + k; imu_map[15 + k] = pose_dim[1] + k; }
         for (int k = 0; k < 9; ++k) { imu_map[6 + k] = sb_dim[0] + k; imu_map[21 + k] = sb_dim[1] + k; }
     }
@@ -339,7 +358,7 @@ int dv_imu_eval(dv_ctx* ctx, const dv_ba_imu* imu, double g_norm, const double* 
     DV_CHECK(hipSetDevice(ctx->cfg.device));
     hipStream_t s = ctx->be_stream;
     BeImu h;
-    if (be_fill_imu(*imu, h)) DV_FAIL("dv_imu_eval: IMU covariance is singular");
+    if (be_fill_imu(*imu, h, nullptr)) DV_FAIL("dv_imu_eval: IMU covariance is singular");
     DV_CHECK(ctx->s0.ensure(sizeof(BeImu) + 8 * (32 + 465) + 256));
     uint8_t* b = (uint8_t*)ctx->s0.p;
     BeImu* dm = (BeImu*)b; double* dpar = (double*)(b + sizeof(BeImu)); double* dout = dpar + 32;

@@ -4,6 +4,7 @@
 #include "be_types.h"
 #include <cmath>
 #include <cstring>
+#include <chrono>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -67,9 +68,12 @@ struct BeWork {
     int32_t* prior_col = nullptr; int32_t* col_kind = nullptr; int32_t* col_frame = nullptr; int32_t* col_comp = nullptr;
     int fac_cap = 0;
     DevBuf marg_buf;       // per-landmark slabs of the marginalization (sized on demand)
-    void* pinned = nullptr; size_t pinned_bytes = 0;      // host staging (state + ctl)
+    void* pinned = nullptr; size_t pinned_bytes = 0;      // host staging: mirror of the device's upload region + download area
+    size_t up_ctl = 0, up_x = 0, up_imu = 0, up_prior = 0, up_idx = 0, up_lm = 0, up_fac = 0, dl_off = 0;
+    std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
 };
 
+bool be_imu_sqrt_info(const double* cov15x15, double* U15x15);      // U^T U = cov^-1, false if singular
 struct dv_estimator;
 void dv_est_destroy_internal(dv_estimator* e);
 
@@ -117,5 +121,11 @@ struct StageScope {
         (void)hipEventRecord(t->pool[slot].first, s);
     }
     ~StageScope() { if (t) (void)hipEventRecord(t->pool[slot].second, s); }
+};
+// host wall-clock of a scope (std::chrono), accumulated under `name` next to the event timers ("h_*" names)
+struct HostScope {
+    dv_ctx* c; StageTimer* t = nullptr; std::chrono::steady_clock::time_point t0;
+    HostScope(dv_ctx* ctx, const char* name) : c(ctx) { if (!c->timing) return; t = dv_timer_for(c, name); t0 = std::chrono::steady_clock::now(); }
+    ~HostScope() { if (t) { t->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); t->count++; } }
 };
 void dv_harvest_timers(dv_ctx* ctx, hipStream_t synced);      // harvests the timers recorded on `synced` (must be idle)

@@ -28,6 +28,7 @@ constexpr double kFocal = 460.0;
 struct Preint {       // IntegrationBase
     d3 acc_0, gyr_0, lin_acc, lin_gyr, lin_ba, lin_bg, dp, dv; quat dq;
     double J[225], P[225], noise[18], sum_dt = 0;
+    mutable double U[225]; mutable bool U_ok = false;      // cached sqrt-information of P (IMUFactor recomputes it on every Evaluate, Q8)
     std::vector<double> dts; std::vector<d3> accs, gyrs;
     Preint(d3 a0, d3 g0, d3 ba, d3 bg, const double n4[4]) : acc_0(a0), gyr_0(g0), lin_acc(a0), lin_gyr(g0), lin_ba(ba), lin_bg(bg) {
         reset_state();
@@ -73,8 +74,9 @@ struct Preint {       // IntegrationBase
         for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { double s = 0; for (int k = 0; k < 15; ++k) s += T1[i * 15 + k] * F[j * 15 + k]; FPFt[i * 15 + j] = s; }
         for (int i = 0; i < 15; ++i) for (int j = 0; j < 18; ++j) T2[i * 18 + j] = V[i * 18 + j] * noise[j];
         for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { double s = 0; for (int k = 0; k < 18; ++k) s += T2[i * 18 + k] * V[j * 18 + k]; P[i * 15 + j] = FPFt[i * 15 + j] + s; }
-        dp = rp; dq = qnormalized(rq); dv = rv; sum_dt += dt; acc_0 = a1; gyr_0 = g1;
+        dp = rp; dq = qnormalized(rq); dv = rv; sum_dt += dt; acc_0 = a1; gyr_0 = g1; U_ok = false;
     }
+    const double* sqrt_info() const { if (!U_ok) U_ok = be_imu_sqrt_info(P, U); return U_ok ? U : nullptr; }
     m33 jb(int r, int c) const { m33 b; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) b.m[i * 3 + j] = J[(r + i) * 15 + c + j]; return b; }
     void fill(dv_ba_imu& o, int fi, int fj) const {
         o.sum_dt = sum_dt;
@@ -348,14 +350,18 @@ struct dv_estimator {
         return P;
     }
     int optimization(dv_ctx* ctx) {        // Estimator::Optimization (estimator.cpp:261-339)
-        states_to_arrays();
-        build_factors(false);
-        imu.clear();
-        if (cfg.use_imu) for (int i = 0; i < frame; ++i) { if (pre[i + 1]->sum_dt > 10.0) continue; dv_ba_imu r; pre[i + 1]->fill(r, i, i + 1); imu.push_back(r); }
-        dv_ba_problem P = make_problem(frame + 1);
-        if (dv_ba_solve(ctx, &P, &last)) return -1;
-        arrays_to_states();
+        dv_ba_problem P;
+        { HostScope h(ctx, "h_build");
+          states_to_arrays();
+          build_factors(false);
+          imu.clear();
+          ctx->be.sqrt_hint.clear();
+          if (cfg.use_imu) for (int i = 0; i < frame; ++i) { if (pre[i + 1]->sum_dt > 10.0) continue; dv_ba_imu r; pre[i + 1]->fill(r, i, i + 1); imu.push_back(r); ctx->be.sqrt_hint.push_back(pre[i + 1]->sqrt_info()); }
+          P = make_problem(frame + 1); }
+        { HostScope h(ctx, "h_solve_total"); const int rc = dv_ba_solve(ctx, &P, &last); ctx->be.sqrt_hint.clear(); if (rc) return -1; }
+        { HostScope h(ctx, "h_post"); arrays_to_states(); }
         if (frame < kWin) return 0;
+        HostScope h(ctx, "h_marg_total");
         return set_marginalization(ctx);
     }
     void arrays_to_states() {         // Double2vector + BodyState::GetOptimizationParameters (body.cpp:61-132)
@@ -483,18 +489,18 @@ struct dv_estimator {
         return 0;
     }
     int process_image(dv_ctx* ctx, const dv_feat* feats, int n, double header) {      // ProcessImage (estimator.cpp:1516-1696)
-        margin_old = add_features(frame, feats, n);
+        { HostScope h(ctx, "h_add_features"); margin_old = add_features(frame, feats, n); }
         headers[frame] = header;
         frame_pre.push_back(std::shared_ptr<Preint>(tmp_pre.release()));
         if (frame_pre.size() > (size_t)kWin + 1 && nonlinear) frame_pre.erase(frame_pre.begin());
         tmp_pre = std::make_unique<Preint>(acc_0, gyr_0, Bas[frame], Bgs[frame], noise());
         if (!nonlinear) return init_estimator(ctx);
         if (!cfg.use_imu) pnp_frame(frame);
-        triangulate();
+        { HostScope h(ctx, "h_triangulate"); triangulate(); }
         if (optimization(ctx)) return -1;
-        reject_outliers();
-        slide_window();
-        erase_if([](const Lm& l) { return l.solve_flag == 2; });       // RemoveFailures
+        { HostScope h(ctx, "h_reject"); reject_outliers(); }
+        { HostScope h(ctx, "h_slide"); slide_window();
+          erase_if([](const Lm& l) { return l.solve_flag == 2; }); }      // RemoveFailures
         return 0;
     }
 };
@@ -520,8 +526,8 @@ int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_st
     if (!ctx->est) DV_FAIL("dv_est_process: call dv_est_create first");
     dv_estimator& E = *ctx->est;
     E.cur_time = t + E.td;
-    if (E.cfg.use_imu && !E.add_imu_until(E.cur_time)) return 1;       // "wait for imu" (estimator.cpp:1801-1805)
-    if (E.process_image(ctx, feats, n, t)) return -1;
+    { HostScope h(ctx, "h_imu"); if (E.cfg.use_imu && !E.add_imu_until(E.cur_time)) return 1; }       // "wait for imu" (estimator.cpp:1801-1805)
+    { HostScope h(ctx, "h_process_total"); if (E.process_image(ctx, feats, n, t)) return -1; }
     E.prev_time = E.cur_time;
     if (out) {
         std::memset(out, 0, sizeof(*out));

@@ -43,6 +43,6 @@ wall = time.perf_counter() - tt
 print("wall %.3f s, %.2f ms/frame (%.0f fps) track %.2f ms ba %.2f ms" % (wall, wall / NF * 1e3, NF / wall, t_track / NF * 1e3, t_ba / NF * 1e3))
 rmse, _, _ = sim.align_ate(est_p, gt_p)
 print("ATE rmse vs ground truth: %.4f m over %d poses" % (rmse, len(est_p)))
-for name in ["frame", "pyr", "lk_temporal", "compact", "gftt_eig", "gftt_select", "lk_stereo", "finalize", "ba_solve", "ba_marg"]:
+for name in ["h_imu", "h_process_total", "h_add_features", "h_triangulate", "h_build", "h_solve_total", "h_solve_upload", "h_solve_enqueue", "h_post", "h_marg_total", "h_reject", "h_slide", "frame", "pyr", "lk_temporal", "compact", "gftt_eig", "gftt_select", "lk_stereo", "finalize", "ba_solve", "ba_marg"]:
     ms, cnt = ctx.timing_get(name)
     if cnt: print(f"  {name:12s} {ms/cnt*1e3:9.1f} us  (n={cnt})")

@@ -11,30 +11,34 @@ static_assert(sizeof(dv_ba_prior) == sizeof(BePriorHdr), "public/private prior l
 static int be_ensure(dv_ctx* ctx, int nfac) {
     BeWork& w = ctx->be;
     if (w.ready && nfac <= w.fac_cap) return 0;
-    const int fac_cap = std::max(nfac, 8192);
+    const int fac_cap = std::max(nfac, BE_MAX_LM * BE_MAX_OBS_FACTORS);      // the worst case up front: a re-allocation would drop the device-resident prior
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     const size_t n = BE_MAX_STATE;
     // upload region first (mirrored 1:1 by the pinned staging buffer -> ONE H2D copy per solve), factors last (variable length)
     size_t o_ctl = take(sizeof(BeCtl)), o_x = take(sizeof(BeState)), o_imu = take(sizeof(BeImu) * BE_WIN), o_pr = take(sizeof(BePriorHdr)), o_i = take(4 * 4 * n),
-           o_lm = take(sizeof(BeLm) * BE_MAX_LM), o_fac = take(sizeof(BeFactor) * (size_t)fac_cap);
+           o_mt = take(4 * BE_MARG_TAB_INTS), o_lm = take(sizeof(BeLm) * BE_MAX_LM), o_fac = take(sizeof(BeFactor) * (size_t)fac_cap);
     const size_t upload_bytes = off;
     size_t o_c = take(sizeof(BeState)),
            o_pA = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb = take(8 * BE_MAX_PRIOR),
+           o_pA2 = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb2 = take(8 * BE_MAX_PRIOR), o_ms = take(64),
            o_pk = take(8 * (size_t)BE_PK_SIZE * BE_PK_STRIDE), o_io = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po = take(8 * (BE_MAX_PRIOR + 1)),
            o_cc = take(8 * (BE_MAX_LM + BE_WIN + 1)), o_hd = take(8 * n * n), o_sc = take(8 * n * n), o_g = take(8 * 2 * n),
            o_v = take(8 * 4 * n), o_vl = take(8 * 4 * (size_t)BE_MAX_LM);
     DV_CHECK(w.block.ensure(off));
     uint8_t* b = (uint8_t*)w.block.p;
     w.ctl = (BeCtl*)(b + o_ctl); w.x = (BeState*)(b + o_x); w.cand = (BeState*)(b + o_c); w.fac = (BeFactor*)(b + o_fac); w.lm = (BeLm*)(b + o_lm);
-    w.imu = (BeImu*)(b + o_imu); w.prior = (BePriorHdr*)(b + o_pr); w.priorA = (double*)(b + o_pA); w.priorb = (double*)(b + o_pb);
+    w.imu = (BeImu*)(b + o_imu); w.prior = (BePriorHdr*)(b + o_pr);
+    w.priorA_buf[0] = (double*)(b + o_pA); w.priorb_buf[0] = (double*)(b + o_pb); w.priorA_buf[1] = (double*)(b + o_pA2); w.priorb_buf[1] = (double*)(b + o_pb2);
+    w.prior_cur = 0; w.priorA = w.priorA_buf[0]; w.priorb = w.priorb_buf[0]; w.prior_resident = false;
+    w.marg_tab = (int32_t*)(b + o_mt); w.marg_scal = (double*)(b + o_ms);
     w.packets = (double*)(b + o_pk); w.imu_out = (double*)(b + o_io); w.prior_out = (double*)(b + o_po); w.cand_cost = (double*)(b + o_cc);
     w.Hd = (double*)(b + o_hd); w.Sc = (double*)(b + o_sc); w.gvec = (double*)(b + o_g);
     double* v = (double*)(b + o_v); w.scale_p = v; w.diag_p = v + n; w.grad_p = v + 2 * n; w.gn_p = v + 3 * n;
     double* vl = (double*)(b + o_vl); w.scale_l = vl; w.diag_l = vl + BE_MAX_LM; w.grad_l = vl + 2 * BE_MAX_LM; w.gn_l = vl + 3 * BE_MAX_LM;
     int32_t* iv = (int32_t*)(b + o_i); w.prior_col = iv; w.col_kind = iv + n; w.col_frame = iv + 2 * n; w.col_comp = iv + 3 * n;
     w.fac_cap = fac_cap;
-    w.up_ctl = o_ctl; w.up_x = o_x; w.up_imu = o_imu; w.up_prior = o_pr; w.up_idx = o_i; w.up_lm = o_lm; w.up_fac = o_fac;
+    w.up_ctl = o_ctl; w.up_x = o_x; w.up_imu = o_imu; w.up_prior = o_pr; w.up_idx = o_i; w.up_mt = o_mt; w.up_lm = o_lm; w.up_fac = o_fac;
     const size_t need = upload_bytes + sizeof(BeState) + sizeof(BeCtl) + 4096;        // staging mirror + download area
     if (w.pinned_bytes < need) {
         if (w.pinned) (void)hipHostFree(w.pinned);
@@ -84,9 +88,110 @@ int be_fill_imu(const dv_ba_imu& in, BeImu& o, const double* sqrt_hint) {
 }
 bool be_imu_sqrt_info(const double* cov, double* U) { return imu_sqrt_info(cov, U); }
 
-extern "C" {
+// ================================ marginalization: structure ("plan"), launch, new header ================================
+struct MargPlan {
+    int mode = -1, D = 0, m = 0, n = 0, nimu = 0, nsel = 0;
+    bool empty = false;                                       // nothing to drop: the prior becomes invalid
+    int pose_dim[BE_NF], sb_dim[BE_NF], ex_dim[2], td_dim;
+    int32_t tab[BE_MARG_TAB_INTS];                            // device image of the index tables
+};
 
-int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
+// Which parameter blocks take part (MarginalizationInfo::addResidualBlockInfo) and where they sit in the dense system:
+// dropped dims first, then the kept ones in canonical order (poses, speed-bias, ex0, ex1, td)  (M1).
+// sel[0..nsel): landmarks of `lms` whose residual blocks take part (all of them anchored in frame 0).
+static int marg_plan(dv_ctx* ctx, MargPlan& pl, int mode, const dv_ba_prior* prior, const dv_ba_factor* fac, const dv_ba_lm* lms, const int* sel, int nsel, bool imu01) {
+    pl = MargPlan();
+    pl.mode = mode;
+    for (int i = 0; i < BE_MARG_TAB_INTS; ++i) pl.tab[i] = -1;
+    bool pose_in[BE_NF] = { false }, sb_in[BE_NF] = { false }, ex_in[2] = { false, false }, td_in = false;
+    const bool has_prior = prior && prior->valid;
+    if (has_prior) for (int b = 0; b < prior->nblocks; ++b) {
+        const dv_ba_prior_block& pb = prior->blocks[b];
+        if (pb.type == 0) pose_in[pb.idx] = true; else if (pb.type == 1) sb_in[pb.idx] = true; else if (pb.type == 2) ex_in[pb.idx] = true; else td_in = true;
+    }
+    pl.nimu = (mode == 0 && imu01) ? 1 : 0;
+    pl.nsel = (mode == 0) ? nsel : 0;
+    if (pl.nimu) { pose_in[0] = sb_in[0] = pose_in[1] = sb_in[1] = true; }
+    for (int q = 0; q < pl.nsel; ++q) {
+        const dv_ba_lm& L = lms[sel[q]];
+        if (L.anchor != 0) DV_FAIL("dv_marginalize: only landmarks anchored in frame 0 take part (estimator.cpp:446)");
+        pl.tab[BE_MT_SEL + q] = sel[q];
+        for (int f = L.first; f < L.first + L.count; ++f) {
+            const dv_ba_factor& ff = fac[f];
+            ex_in[0] = true; td_in = true;
+            if (ff.kind != 0) ex_in[1] = true;
+            if (ff.kind != 2) { pose_in[0] = true; pose_in[ff.fj] = true; }
+        }
+    }
+    int32_t* dim_slot = pl.tab + BE_MT_SLOT; int32_t* dim_comp = pl.tab + BE_MT_COMP;
+    int nd = 0;
+    for (int k = 0; k < BE_NF; ++k) { pl.pose_dim[k] = -1; pl.sb_dim[k] = -1; }
+    pl.ex_dim[0] = pl.ex_dim[1] = -1; pl.td_dim = -1;
+    auto add_pose = [&](int k) { pl.pose_dim[k] = nd; for (int c = 0; c < 6; ++c) { dim_slot[nd] = k; dim_comp[nd] = c; ++nd; } };
+    auto add_sb = [&](int k) { pl.sb_dim[k] = nd; for (int c = 0; c < 9; ++c) { dim_slot[nd] = -1; dim_comp[nd] = c; ++nd; } };
+    const int drop_frame = (mode == 0) ? 0 : BE_WIN - 1;
+    if (pose_in[drop_frame]) add_pose(drop_frame);
+    if (mode == 0 && sb_in[0]) add_sb(0);
+    pl.m = nd;
+    if (pl.m == 0) { pl.empty = true; return 0; }             // "unstable tracking" (marginalization_factor.cpp:210-215)
+    for (int k = 0; k < BE_NF; ++k) if (pose_in[k] && k != drop_frame) add_pose(k);
+    for (int k = 0; k < BE_NF; ++k) if (sb_in[k] && !(mode == 0 && k == 0)) add_sb(k);
+    for (int c = 0; c < 2; ++c) if (ex_in[c]) { pl.ex_dim[c] = nd; for (int q = 0; q < 6; ++q) { dim_slot[nd] = BE_NF + c; dim_comp[nd] = q; ++nd; } }
+    if (td_in) { pl.td_dim = nd; dim_slot[nd] = BE_NF + 2; dim_comp[nd] = 0; ++nd; }
+    pl.D = nd; pl.n = nd - pl.m;
+    if (pl.n > BE_MAX_PRIOR || pl.n < 1 || nd > 256) DV_FAIL("dv_marginalize: bad kept size");
+    if (has_prior) for (int b = 0; b < prior->nblocks; ++b) {
+        const dv_ba_prior_block& pb = prior->blocks[b];
+        const int d0 = pb.type == 0 ? pl.pose_dim[pb.idx] : pb.type == 1 ? pl.sb_dim[pb.idx] : pb.type == 2 ? pl.ex_dim[pb.idx] : pl.td_dim;
+        for (int k = 0; k < pb.size_local; ++k) pl.tab[BE_MT_PRIOR + pb.off + k] = d0 + k;
+    }
+    if (pl.nimu) {
+        for (int k = 0; k < 6; ++k) { pl.tab[BE_MT_IMU + k] = pl.pose_dim[0] + k; pl.tab[BE_MT_IMU + 15 + k] = pl.pose_dim[1] + k; }
+        for (int k = 0; k < 9; ++k) { pl.tab[BE_MT_IMU + 6 + k] = pl.sb_dim[0] + k; pl.tab[BE_MT_IMU + 21 + k] = pl.sb_dim[1] + k; }
+    }
+    return 0;
+}
+
+// launches the three kernels; the index tables must already be (enqueued to be) in w.marg_tab
+static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, hipStream_t s) {
+    BeWork& w = ctx->be;
+    BeMargArgs ma{};
+    ma.x = w.x; ma.nframes = BE_NF; ma.nlm = pl.nsel; ma.nimu = pl.nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
+    ma.prior = w.prior; ma.priorA = priorA; ma.priorb = priorb;
+    ma.prior_map = w.marg_tab + BE_MT_PRIOR; ma.imu_map = w.marg_tab + BE_MT_IMU; ma.dim_slot = w.marg_tab + BE_MT_SLOT; ma.dim_comp = w.marg_tab + BE_MT_COMP;
+    ma.lm_sel = w.marg_tab + BE_MT_SEL;
+    ma.D = pl.D; ma.m = pl.m; ma.g_norm = g_norm; ma.outA = outA; ma.outb = outb; ma.out_scalars = scal;
+    const size_t slab = (size_t)pl.D * pl.D + pl.D;
+    DV_CHECK(w.marg_buf.ensure(8 * (slab * (size_t)std::max(pl.nsel, 1) + slab + (size_t)std::max(pl.nsel, 1))));
+    ma.slabs = (double*)w.marg_buf.p; ma.sum = ma.slabs + slab * (size_t)std::max(pl.nsel, 1); ma.lm_h = ma.sum + slab;
+    StageScope sc(ctx, "k_be_marg", s);
+    const int rc = be_launch_marg(ma, s);
+    if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");
+    if (rc) DV_FAIL("dv_marginalize: cannot set dynamic LDS size");
+    return 0;
+}
+
+// new prior header: kept blocks, indices shifted like addr_shift (estimator.cpp:537-548 / 591-612); x0 = the states the system was linearised at
+static void marg_new_prior(const MargPlan& pl, const double* pose, const double* sb, const double* ex, const double* td, double c0, dv_ba_prior* out) {
+    std::memset(out, 0, sizeof(*out));
+    if (pl.empty) return;
+    out->valid = 1; out->n = pl.n; out->c0 = c0;
+    int nb = 0;
+    auto put = [&](int type, int new_idx, int dim0, int size_local, const double* x0, int gs) {
+        dv_ba_prior_block& pb = out->blocks[nb];
+        pb.type = type; pb.idx = new_idx; pb.off = dim0 - pl.m; pb.size_local = size_local;
+        for (int k = 0; k < gs; ++k) out->x0[nb][k] = x0[k];
+        ++nb;
+    };
+    auto shift = [&](int k) { return pl.mode == 0 ? k - 1 : (k == BE_WIN ? BE_WIN - 1 : k); };
+    for (int k = 0; k < BE_NF; ++k) if (pl.pose_dim[k] >= pl.m) put(0, shift(k), pl.pose_dim[k], 6, pose + 7 * k, 7);
+    for (int k = 0; k < BE_NF; ++k) if (pl.sb_dim[k] >= pl.m) put(1, shift(k), pl.sb_dim[k], 9, sb + 9 * k, 9);
+    for (int c = 0; c < 2; ++c) if (pl.ex_dim[c] >= 0) put(2, c, pl.ex_dim[c], 6, ex + 7 * c, 7);
+    if (pl.td_dim >= 0) put(3, 0, pl.td_dim, 1, td, 1);
+    out->nblocks = nb;
+}
+
+int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused) {
     if (!ctx) return -1;
     const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     if (!P || !P->pose || !P->ex_pose || !P->td) DV_FAIL("dv_ba_solve: null argument");
@@ -111,13 +216,15 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
         if (P->use_imu) { d.sb_col[f] = col; for (int k = 0; k < 9; ++k) { col_kind[col] = 1; col_frame[col] = f; col_comp[col] = k; ++col; } }
     }
     d.nstate = col;
+    const bool has_prior = P->prior && P->prior->valid;
+    const bool prior_on_device = has_prior && w.prior_resident && P->prior_A == w.priorA_buf[w.prior_cur];
     if (col == 0) {       // e.g. vision-only, first frame: pose 0 is constant and no landmark has 4 observations yet
         if (P->nlm > 0) DV_FAIL("dv_ba_solve: landmarks without a free pose block");
+        if (fused && fused->marg_mode >= 0) DV_FAIL("dv_ba_solve: marginalization needs a full window");
         if (summary) { summary->iterations = 0; summary->successful = 0; summary->termination = 1; summary->slots = 0; summary->initial_cost = 0; summary->final_cost = 0; }
         return 0;
     }
     BePriorHdr ph{};
-    const bool has_prior = P->prior && P->prior->valid;
     if (has_prior) {
         std::memcpy(&ph, P->prior, sizeof(ph));
         if (ph.n > BE_MAX_PRIOR || ph.nblocks > 16) DV_FAIL("dv_ba_solve: prior too large");
@@ -127,6 +234,16 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
             if (pb.type == 0) c0 = d.pose_col[pb.idx]; else if (pb.type == 1) c0 = d.sb_col[pb.idx];
             if (c0 >= 0) for (int k = 0; k < pb.size_local; ++k) prior_col[c0 + k] = pb.off + k;
         }
+    }
+    // ---- marginalization structure (does not depend on the solution): planned now so that its tables ride in the same upload ----
+    static thread_local MargPlan pl;
+    const bool do_marg = fused && fused->marg_mode >= 0;
+    if (do_marg) {
+        if (P->nframes != BE_NF) DV_FAIL("dv_marginalize: needs a full window (frame == kWinSize)");
+        std::vector<int> sel;
+        if (fused->marg_mode == 0) for (int l = 0; l < P->nlm; ++l) if (P->landmarks[l].anchor == 0) sel.push_back(l);
+        const bool imu01 = P->nimu > 0 && P->imu[0].fi == 0 && P->imu[0].fj == 1;
+        if (marg_plan(ctx, pl, fused->marg_mode, has_prior ? P->prior : nullptr, P->factors, P->landmarks, sel.data(), (int)sel.size(), imu01)) return -1;
     }
     // ---- upload: everything is staged in the pinned mirror of the device's upload region and travels in ONE copy ----
     uint8_t* hp = (uint8_t*)w.pinned;
@@ -146,13 +263,17 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
     }
     std::memcpy(hp + w.up_prior, &ph, sizeof(ph));
     std::memcpy(hp + w.up_idx, idx.data(), 4 * idx.size());
+    if (do_marg && !pl.empty) std::memcpy(hp + w.up_mt, pl.tab, sizeof(pl.tab));
     if (P->nlm) std::memcpy(hp + w.up_lm, P->landmarks, sizeof(BeLm) * (size_t)P->nlm);
     if (P->nfac) std::memcpy(hp + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac);
     DV_CHECK(hipMemcpyAsync(w.block.p, hp, w.up_fac + sizeof(BeFactor) * (size_t)P->nfac, hipMemcpyHostToDevice, s));
-    if (has_prior && P->prior_A != w.priorA) {        // a prior handed over in host memory (the estimator keeps its prior device-resident)
-        DV_CHECK(hipMemcpyAsync(w.priorA, P->prior_A, 8 * (size_t)ph.n * ph.n, hipMemcpyHostToDevice, s));
-        DV_CHECK(hipMemcpyAsync(w.priorb, P->prior_b, 8 * (size_t)ph.n, hipMemcpyHostToDevice, s));
+    if (has_prior && !prior_on_device) {               // a prior handed over in host memory (the estimator's stays in HBM)
+        if (!P->prior_A || !P->prior_b) DV_FAIL("dv_ba_solve: prior without A / b");
+        DV_CHECK(hipMemcpyAsync(w.priorA_buf[w.prior_cur], P->prior_A, 8 * (size_t)ph.n * ph.n, hipMemcpyHostToDevice, s));
+        DV_CHECK(hipMemcpyAsync(w.priorb_buf[w.prior_cur], P->prior_b, 8 * (size_t)ph.n, hipMemcpyHostToDevice, s));
+        w.prior_resident = false;
     }
+    w.priorA = w.priorA_buf[w.prior_cur]; w.priorb = w.priorb_buf[w.prior_cur];
     std::chrono::steady_clock::time_point t_up = std::chrono::steady_clock::now();
     // ---- schedule ----
     BeEvalArgs ea{};
@@ -184,10 +305,21 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
         }
     }
     std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
+    // ---- gauge fix + marginalization follow on the same stream without a host round trip ----
+    const int nxt = 1 - w.prior_cur;
+    if (fused) {
+        BeGaugeArgs ga{};
+        ga.x = w.x; ga.nframes = P->nframes; ga.use_imu = P->use_imu;
+        std::memcpy(ga.R0, fused->R0, sizeof(ga.R0)); std::memcpy(ga.ypr0, fused->ypr0, sizeof(ga.ypr0)); std::memcpy(ga.P0, fused->P0, sizeof(ga.P0));
+        be_launch_gauge(ga, s);
+        if (do_marg && !pl.empty && marg_enqueue(ctx, pl, P->g_norm, w.priorA, w.priorb, w.priorA_buf[nxt], w.priorb_buf[nxt], w.marg_scal, s)) return -1;
+    }
     DV_CHECK(hipGetLastError());
     hx = (BeState*)(hp + w.dl_off); hctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState));
+    double* hscal = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl));
     DV_CHECK(hipMemcpyAsync(hx, w.x, state_bytes, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
+    if (do_marg && !pl.empty) DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
     if (ctx->timing) {
         StageTimer* te = dv_timer_for(ctx, "h_solve_enqueue"); te->total_ms += std::chrono::duration<double, std::milli>(t_enq - t_up).count(); te->count++;
@@ -200,8 +332,22 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
         summary->iterations = hctl->iter; summary->successful = hctl->successful; summary->termination = hctl->done ? hctl->termination : 0;
         summary->slots = hctl->slots; summary->initial_cost = hctl->initial_cost; summary->final_cost = hctl->x_cost;
     }
+    if (do_marg) {
+        if (pl.empty) { std::memset(&fused->new_prior, 0, sizeof(fused->new_prior)); std::memset(fused->diag, 0, sizeof(fused->diag)); w.prior_resident = false; }
+        else {
+            std::memcpy(fused->diag, hscal, 32);
+            if (hscal[2] != 0.0) DV_FAIL("dv_marginalize: A_mm is not positive definite (reference would take its pseudo-inverse)");
+            marg_new_prior(pl, P->pose, P->speed_bias, P->ex_pose, P->td, hscal[0], &fused->new_prior);      // x0 = the gauge-fixed states just downloaded
+            w.prior_cur = nxt; w.prior_resident = true;
+            w.priorA = w.priorA_buf[nxt]; w.priorb = w.priorb_buf[nxt];
+        }
+    }
     return 0;
 }
+
+extern "C" {
+
+int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) { return be_solve_fused(ctx, P, summary, nullptr); }
 
 int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* out_prior, double* out_A, double* out_b, double* diag4) {
     if (!ctx) return -1;
@@ -214,57 +360,18 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     hipStream_t s = ctx->be_stream;
     const bool has_prior = P->prior && P->prior->valid;
     std::memset(out_prior, 0, sizeof(*out_prior));
-    // ---- which blocks take part (addResidualBlockInfo): present[type][idx] ----
-    bool pose_in[BE_NF] = { false }, sb_in[BE_NF] = { false }, ex_in[2] = { false, false }, td_in = false;
-    if (has_prior) for (int b = 0; b < P->prior->nblocks; ++b) {
-        const dv_ba_prior_block& pb = P->prior->blocks[b];
-        if (pb.type == 0) pose_in[pb.idx] = true; else if (pb.type == 1) sb_in[pb.idx] = true; else if (pb.type == 2) ex_in[pb.idx] = true; else td_in = true;
-    }
     const int nimu = (mode == 0) ? P->nimu : 0, nlm = (mode == 0) ? P->nlm : 0, nfac = (mode == 0) ? P->nfac : 0;
     if (nimu > 1) DV_FAIL("dv_marginalize: at most the IMU factor (0,1)");
-    if (nimu == 1) { pose_in[0] = sb_in[0] = pose_in[1] = sb_in[1] = true; }
-    for (int f = 0; f < nfac; ++f) {
-        const dv_ba_factor& ff = P->factors[f];
-        if (ff.fi != 0) DV_FAIL("dv_marginalize: only landmarks anchored in frame 0 take part (estimator.cpp:446)");
-        ex_in[0] = true; td_in = true;
-        if (ff.kind != 0) ex_in[1] = true;
-        if (ff.kind != 2) { pose_in[0] = true; pose_in[ff.fj] = true; }
-    }
-    // ---- dims: dropped first, then kept in canonical order (poses, speed-bias, ex0, ex1, td) ----
-    std::vector<int32_t> dim_slot, dim_comp;
-    int pose_dim[BE_NF], sb_dim[BE_NF], ex_dim[2] = { -1, -1 }, td_dim = -1;
-    for (int k = 0; k < BE_NF; ++k) { pose_dim[k] = -1; sb_dim[k] = -1; }
-    auto add_pose = [&](int k) { pose_dim[k] = (int)dim_slot.size(); for (int c = 0; c < 6; ++c) { dim_slot.push_back(k); dim_comp.push_back(c); } };
-    auto add_sb = [&](int k) { sb_dim[k] = (int)dim_slot.size(); for (int c = 0; c < 9; ++c) { dim_slot.push_back(-1); dim_comp.push_back(c); } };
-    const int drop_frame = (mode == 0) ? 0 : BE_WIN - 1;
-    if (pose_in[drop_frame]) add_pose(drop_frame);
-    if (mode == 0 && sb_in[0]) add_sb(0);
-    const int m = (int)dim_slot.size();
-    if (m == 0) { out_prior->valid = 0; if (diag4) diag4[0] = diag4[1] = diag4[2] = diag4[3] = 0; return 0; }      // "unstable tracking" (marginalization_factor.cpp:210-215)
-    for (int k = 0; k < BE_NF; ++k) if (pose_in[k] && k != drop_frame) add_pose(k);
-    for (int k = 0; k < BE_NF; ++k) if (sb_in[k] && !(mode == 0 && k == 0)) add_sb(k);
-    for (int c = 0; c < 2; ++c) if (ex_in[c]) { ex_dim[c] = (int)dim_slot.size(); for (int q = 0; q < 6; ++q) { dim_slot.push_back(BE_NF + c); dim_comp.push_back(q); } }
-    if (td_in) { td_dim = (int)dim_slot.size(); dim_slot.push_back(BE_NF + 2); dim_comp.push_back(0); }
-    const int D = (int)dim_slot.size(), n = D - m;
-    if (n > BE_MAX_PRIOR || n < 1) DV_FAIL("dv_marginalize: bad kept size");
-    std::vector<int32_t> prior_map(BE_MAX_PRIOR, -1), imu_map(30, -1);
-    BePriorHdr ph{};
-    if (has_prior) {
-        std::memcpy(&ph, P->prior, sizeof(ph));
-        for (int b = 0; b < ph.nblocks; ++b) {
-            const BePriorBlock pb = ph.blocks[b];
-            const int d0 = pb.type == 0 ? pose_dim[pb.idx] : pb.type == 1 ? sb_dim[pb.idx] : pb.type == 2 ? ex_dim[pb.idx] : td_dim;
-            for (int k = 0; k < pb.size_local; ++k) prior_map[pb.off + k] = d0 + k;
-        }
-    }
-    BeImu himu{};
-    if (nimu == 1) {
-        if (be_fill_imu(P->imu[0], himu, nullptr)) DV_FAIL("dv_marginalize: IMU covariance is singular");
-        for (int k = 0; k < 6; ++k) { imu_map[k] = pose_dim[0] + k; imu_map[15 + k] = pose_dim[1] + k; }
-        for (int k = 0; k < 9; ++k) { imu_map[6 + k] = sb_dim[0] + k; imu_map[21 + k] = sb_dim[1] + k; }
-    }
-    // ---- upload ----
-    BeState* hx = (BeState*)w.pinned;
+    for (int f = 0; f < nfac; ++f) if (P->factors[f].fi != 0) DV_FAIL("dv_marginalize: only landmarks anchored in frame 0 take part (estimator.cpp:446)");
+    static thread_local MargPlan pl;
+    std::vector<int> sel(nlm);
+    for (int l = 0; l < nlm; ++l) sel[l] = l;
+    if (marg_plan(ctx, pl, mode, has_prior ? P->prior : nullptr, P->factors, P->landmarks, sel.data(), nlm, nimu == 1)) return -1;
+    if (pl.empty) { out_prior->valid = 0; if (diag4) diag4[0] = diag4[1] = diag4[2] = diag4[3] = 0; return 0; }
+    const int n = pl.n;
+    // ---- upload (pinned mirror of the upload region, one copy) ----
+    uint8_t* hp = (uint8_t*)w.pinned;
+    BeState* hx = (BeState*)(hp + w.up_x);
     std::memset(hx, 0, offsetof(BeState, inv_depth));
     for (int f = 0; f < BE_NF; ++f) { std::memcpy(hx->pose[f], P->pose + 7 * f, 56); if (P->use_imu) std::memcpy(hx->sb[f], P->speed_bias + 9 * f, 72); }
     std::memcpy(hx->ex, P->ex_pose, 14 * 8); hx->td = P->td[0];
@@ -272,36 +379,22 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     for (int f = 0; f < nfac; ++f) max_lm = std::max(max_lm, P->factors[f].lm + 1);
     if (max_lm > BE_MAX_LM) DV_FAIL("dv_marginalize: landmark index out of range");
     if (max_lm) std::memcpy(hx->inv_depth, P->inv_depth, 8 * (size_t)max_lm);
-    const size_t state_bytes = offsetof(BeState, inv_depth) + 8 * (size_t)max_lm;
-    DV_CHECK(hipMemcpyAsync(w.x, hx, state_bytes, hipMemcpyHostToDevice, s));
-    if (nfac) DV_CHECK(hipMemcpyAsync(w.fac, P->factors, sizeof(BeFactor) * (size_t)nfac, hipMemcpyHostToDevice, s));
-    if (nlm) DV_CHECK(hipMemcpyAsync(w.lm, P->landmarks, sizeof(BeLm) * (size_t)nlm, hipMemcpyHostToDevice, s));
-    if (nimu) DV_CHECK(hipMemcpyAsync(w.imu, &himu, sizeof(BeImu), hipMemcpyHostToDevice, s));
-    DV_CHECK(hipMemcpyAsync(w.prior, &ph, sizeof(ph), hipMemcpyHostToDevice, s));
+    BeImu* himu = (BeImu*)(hp + w.up_imu);
+    if (nimu == 1 && be_fill_imu(P->imu[0], himu[0], nullptr)) DV_FAIL("dv_marginalize: IMU covariance is singular");
+    BePriorHdr ph{};
+    if (has_prior) std::memcpy(&ph, P->prior, sizeof(ph));
+    std::memcpy(hp + w.up_prior, &ph, sizeof(ph));
+    std::memcpy(hp + w.up_mt, pl.tab, sizeof(pl.tab));
+    if (nlm) std::memcpy(hp + w.up_lm, P->landmarks, sizeof(BeLm) * (size_t)nlm);
+    if (nfac) std::memcpy(hp + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)nfac);
+    DV_CHECK(hipMemcpyAsync(w.block.p, hp, w.up_fac + sizeof(BeFactor) * (size_t)nfac, hipMemcpyHostToDevice, s));
     if (has_prior) {
-        DV_CHECK(hipMemcpyAsync(w.priorA, P->prior_A, 8 * (size_t)ph.n * ph.n, hipMemcpyHostToDevice, s));
-        DV_CHECK(hipMemcpyAsync(w.priorb, P->prior_b, 8 * (size_t)ph.n, hipMemcpyHostToDevice, s));
+        DV_CHECK(hipMemcpyAsync(w.priorA_buf[w.prior_cur], P->prior_A, 8 * (size_t)ph.n * ph.n, hipMemcpyHostToDevice, s));
+        DV_CHECK(hipMemcpyAsync(w.priorb_buf[w.prior_cur], P->prior_b, 8 * (size_t)ph.n, hipMemcpyHostToDevice, s));
+        w.prior_resident = false;
     }
-    // index tables live in the (otherwise unused here) Hd / gvec workspaces
-    int32_t* d_prior_map = (int32_t*)w.Hd; int32_t* d_imu_map = d_prior_map + BE_MAX_PRIOR; int32_t* d_slot = d_imu_map + 32; int32_t* d_comp = d_slot + 256;
-    DV_CHECK(hipMemcpyAsync(d_prior_map, prior_map.data(), 4 * BE_MAX_PRIOR, hipMemcpyHostToDevice, s));
-    DV_CHECK(hipMemcpyAsync(d_imu_map, imu_map.data(), 4 * 30, hipMemcpyHostToDevice, s));
-    DV_CHECK(hipMemcpyAsync(d_slot, dim_slot.data(), 4 * (size_t)D, hipMemcpyHostToDevice, s));
-    DV_CHECK(hipMemcpyAsync(d_comp, dim_comp.data(), 4 * (size_t)D, hipMemcpyHostToDevice, s));
-    double* d_outA = w.Sc; double* d_outb = w.gvec; double* d_scal = w.gvec + BE_MAX_PRIOR;
-    BeMargArgs ma{};
-    ma.x = w.x; ma.nframes = BE_NF; ma.nlm = nlm; ma.nimu = nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
-    ma.prior = w.prior; ma.priorA = w.priorA; ma.priorb = w.priorb; ma.prior_map = d_prior_map; ma.imu_map = d_imu_map; ma.dim_slot = d_slot; ma.dim_comp = d_comp;
-    ma.D = D; ma.m = m; ma.g_norm = P->g_norm; ma.outA = d_outA; ma.outb = d_outb; ma.out_scalars = d_scal;
-    const size_t slab = (size_t)D * D + D;
-    DV_CHECK(w.marg_buf.ensure(8 * (slab * (size_t)std::max(nlm, 1) + slab + (size_t)std::max(nlm, 1))));
-    ma.slabs = (double*)w.marg_buf.p; ma.sum = ma.slabs + slab * (size_t)std::max(nlm, 1); ma.lm_h = ma.sum + slab;
-    {
-        StageScope sc(ctx, "k_be_marg", s);
-        const int rc = be_launch_marg(ma, s);
-        if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");
-        if (rc) DV_FAIL("dv_marginalize: cannot set dynamic LDS size");
-    }
+    double* d_outA = w.Sc; double* d_outb = w.gvec; double* d_scal = w.marg_scal;      // Sc / gvec are idle outside a solve
+    if (marg_enqueue(ctx, pl, P->g_norm, w.priorA_buf[w.prior_cur], w.priorb_buf[w.prior_cur], d_outA, d_outb, d_scal, s)) return -1;
     DV_CHECK(hipGetLastError());
     double scal[4];
     DV_CHECK(hipMemcpyAsync(out_A, d_outA, 8 * (size_t)n * n, hipMemcpyDeviceToHost, s));
@@ -311,21 +404,7 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     if (ctx->timing) dv_harvest_timers(ctx, s);
     if (diag4) std::memcpy(diag4, scal, 32);
     if (scal[2] != 0.0) DV_FAIL("dv_marginalize: A_mm is not positive definite (reference would take its pseudo-inverse)");
-    // ---- new prior header: kept blocks, indices shifted like addr_shift (estimator.cpp:537-548 / 591-612) ----
-    out_prior->valid = 1; out_prior->n = n; out_prior->c0 = scal[0];
-    int nb = 0;
-    auto put = [&](int type, int idx, int new_idx, int dim0, int size_local, const double* x0, int gs) {
-        dv_ba_prior_block& pb = out_prior->blocks[nb];
-        pb.type = type; pb.idx = new_idx; pb.off = dim0 - m; pb.size_local = size_local;
-        for (int k = 0; k < gs; ++k) out_prior->x0[nb][k] = x0[k];
-        ++nb; (void)idx;
-    };
-    auto shift = [&](int k) { return mode == 0 ? k - 1 : (k == BE_WIN ? BE_WIN - 1 : k); };
-    for (int k = 0; k < BE_NF; ++k) if (pose_dim[k] >= m) put(0, k, shift(k), pose_dim[k], 6, P->pose + 7 * k, 7);
-    for (int k = 0; k < BE_NF; ++k) if (sb_dim[k] >= m) put(1, k, shift(k), sb_dim[k], 9, P->speed_bias + 9 * k, 9);
-    for (int c = 0; c < 2; ++c) if (ex_dim[c] >= 0) put(2, c, c, ex_dim[c], 6, P->ex_pose + 7 * c, 7);
-    if (td_dim >= 0) put(3, 0, 0, td_dim, 1, P->td, 1);
-    out_prior->nblocks = nb;
+    marg_new_prior(pl, P->pose, P->speed_bias, P->ex_pose, P->td, scal[0], out_prior);
     return 0;
 }
 

@@ -42,7 +42,12 @@ struct BeMargArgs {
     int D, m; double g_norm;
     double* outA; double* outb; double* out_scalars;     // n x n, n, {c0, min pivot, failure flag, rank}
     double* slabs; double* sum; double* lm_h;            // [nlm][D*D+D] per-landmark contributions, their sum, per-landmark h
+    const int32_t* lm_sel;        // optional: landmark b of the launch is lm[lm_sel[b]] (marginalization straight out of the solved window)
 };
+
+// yaw-gauge fix after a solve (Estimator::Double2vector, estimator.cpp:1111-1154): rotates the solved window back to the yaw and
+// position frame 0 had before the solve, in place on the device, so that the marginalization can follow without a host round trip
+struct BeGaugeArgs { BeState* x; int nframes, use_imu; double R0[9]; double ypr0[3]; double P0[3]; };
 
 #if defined(__HIPCC__)
 using namespace be;
@@ -73,6 +78,7 @@ __device__ inline void be_prior_dx_dev(const BePriorHdr* p, const BeState* s, do
 
 void be_launch_eval(const BeEvalArgs& a, bool full, hipStream_t s);
 int  be_launch_marg(const BeMargArgs& a, hipStream_t s);
+void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
 void be_launch_reduce(const BeSolveArgs& a, hipStream_t s);
 int  be_launch_solve(const BeSolveArgs& a, hipStream_t s);
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
     const BeState* st = a.x;
     if (tid < 64) be_frame_geom_dev(st, a.nframes, fg, ric, tic, tid);
     __syncthreads();
-    const BeLm L = a.lm[l];
+    const BeLm L = a.lm[a.lm_sel ? a.lm_sel[l] : l];
     const int nf = L.count, anchor = L.anchor;
     if (tid < nf) {
         const BeFactor f = a.fac[L.first + tid];
@@ -239,6 +239,40 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     }
     if (tid == 0) { a.out_scalars[0] = c0; a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; a.out_scalars[3] = (double)rank; }
 }
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void be_gauge_kernel(BeGaugeArgs a) {
+    __shared__ m33 rot;
+    __shared__ d3 p0;
+    const int i = threadIdx.x;
+    BeState* st = a.x;
+    if (i == 0) {
+        p0 = P3(st->pose[0]);
+        if (a.use_imu) {
+            m33 R0; for (int k = 0; k < 9; ++k) R0.m[k] = a.R0[k];
+            const m33 R00 = qR(Q4(st->pose[0]));
+            const d3 y00 = r2ypr(R00);
+            m33 rd = ypr2r(mk3(a.ypr0[0] - y00.x, 0, 0));
+            if (fabs(fabs(a.ypr0[1]) - 90) < 1.0 || fabs(fabs(y00.y) - 90) < 1.0) rd = mul(R0, tr(R00));      // near the Euler singularity (estimator.cpp:1121-1128)
+            rot = rd;
+        }
+    }
+    __syncthreads();
+    if (i >= a.nframes) return;
+    const quat qn = qnormalized(Q4(st->pose[i]));
+    if (a.use_imu) {
+        const m33 R = mul(rot, qR(qn));
+        const d3 P = mul(rot, P3(st->pose[i]) - p0) + mk3(a.P0[0], a.P0[1], a.P0[2]);
+        const d3 V = mul(rot, mk3(st->sb[i][0], st->sb[i][1], st->sb[i][2]));
+        const quat q = qfromR(R);
+        st->pose[i][0] = P.x; st->pose[i][1] = P.y; st->pose[i][2] = P.z; st->pose[i][3] = q.x; st->pose[i][4] = q.y; st->pose[i][5] = q.z; st->pose[i][6] = q.w;
+        st->sb[i][0] = V.x; st->sb[i][1] = V.y; st->sb[i][2] = V.z;
+    } else {
+        const quat q = qfromR(qR(qn));
+        st->pose[i][3] = q.x; st->pose[i][4] = q.y; st->pose[i][5] = q.z; st->pose[i][6] = q.w;
+    }
+}
+void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(64), 0, s, a); }
 
 static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16) * sizeof(double); }
 static size_t lm_smem(int D) { return ((size_t)BE_MAX_OBS_FACTORS * 54 + 2 * (size_t)BE_MAX_OBS_FACTORS * D + 2 * D) * sizeof(double); }

@@ -71,6 +71,20 @@ BE_HD quat qfromR(const m33& m) {
     }
     return q;
 }
+// Utility::R2ypr / ypr2R (estimator/utility.h:86-131), degrees
+BE_HD d3 r2ypr(const m33& R) {
+    const d3 n = mk3(R.m[0], R.m[3], R.m[6]), o = mk3(R.m[1], R.m[4], R.m[7]), a = mk3(R.m[2], R.m[5], R.m[8]);
+    const double y = atan2(n.y, n.x), p = atan2(-n.z, n.x * cos(y) + n.y * sin(y)), r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
+    return mk3(y, p, r) / M_PI * 180.0;
+}
+BE_HD m33 ypr2r(d3 ypr) {
+    const double y = ypr.x / 180.0 * M_PI, p = ypr.y / 180.0 * M_PI, r = ypr.z / 180.0 * M_PI;
+    m33 Rz = zero3(), Ry = zero3(), Rx = zero3();
+    Rz.m[0] = cos(y); Rz.m[1] = -sin(y); Rz.m[3] = sin(y); Rz.m[4] = cos(y); Rz.m[8] = 1;
+    Ry.m[0] = cos(p); Ry.m[2] = sin(p); Ry.m[4] = 1; Ry.m[6] = -sin(p); Ry.m[8] = cos(p);
+    Rx.m[0] = 1; Rx.m[4] = cos(r); Rx.m[5] = -sin(r); Rx.m[7] = sin(r); Rx.m[8] = cos(r);
+    return mul(mul(Rz, Ry), Rx);
+}
 BE_HD quat dq_half(d3 theta) { return mkq(1.0, theta.x / 2.0, theta.y / 2.0, theta.z / 2.0); }      // Utility::deltaQ (un-normalised)
 BE_HD d3 P3(const double* p) { return mk3(p[0], p[1], p[2]); }
 BE_HD quat Q4(const double* p) { return mkq(p[6], p[3], p[4], p[5]); }        // pose block [p, qx qy qz qw]

@@ -69,11 +69,32 @@ struct BeWork {
     int fac_cap = 0;
     DevBuf marg_buf;       // per-landmark slabs of the marginalization (sized on demand)
     void* pinned = nullptr; size_t pinned_bytes = 0;      // host staging: mirror of the device's upload region + download area
-    size_t up_ctl = 0, up_x = 0, up_imu = 0, up_prior = 0, up_idx = 0, up_lm = 0, up_fac = 0, dl_off = 0;
+    size_t up_ctl = 0, up_x = 0, up_imu = 0, up_prior = 0, up_idx = 0, up_mt = 0, up_lm = 0, up_fac = 0, dl_off = 0;
+    double* priorA_buf[2] = { nullptr, nullptr }; double* priorb_buf[2] = { nullptr, nullptr }; int prior_cur = 0;      // double-buffered prior (A', b')
+    bool prior_resident = false;      // true: buffer prior_cur holds the estimator's current prior (written by the fused marginalization)
+    int32_t* marg_tab = nullptr; double* marg_scal = nullptr;      // marginalization index tables (inside the upload region) and its 4 result scalars
     std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
 };
 
 bool be_imu_sqrt_info(const double* cov15x15, double* U15x15);      // U^T U = cov^-1, false if singular
+
+// marginalization index tables (int32): prior_map[BE_MAX_PRIOR] | imu_map[32] | dim_slot[256] | dim_comp[256] | lm_sel[BE_MAX_LM]
+#define BE_MT_PRIOR 0
+#define BE_MT_IMU (BE_MAX_PRIOR)
+#define BE_MT_SLOT (BE_MAX_PRIOR + 32)
+#define BE_MT_COMP (BE_MAX_PRIOR + 32 + 256)
+#define BE_MT_SEL (BE_MAX_PRIOR + 32 + 512)
+#define BE_MARG_TAB_INTS (BE_MAX_PRIOR + 32 + 512 + BE_MAX_LM)
+
+// Estimator-internal fused entry: window solve, yaw-gauge fix and marginalization enqueued back to back on the BA
+// stream (one upload, one download, one sync); the new prior's A', b' stay in HBM for the next solve.
+struct BeFused {
+    int marg_mode = -1;                       // -1 none, 0 kMarginOld, 1 kMarginSecondNew
+    double R0[9], ypr0[3], P0[3];             // Rs[0], R2ypr(Rs[0]), Ps[0] before the solve (gauge reference)
+    dv_ba_prior new_prior;                    // out (marg_mode >= 0): header of the new prior (valid may be 0)
+    double diag[4] = { 0, 0, 0, 0 };          // out: c0, smallest pivot, failure flag, rank
+};
+int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);
 struct dv_estimator;
 void dv_est_destroy_internal(dv_estimator* e);
 

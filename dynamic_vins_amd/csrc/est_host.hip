@@ -110,19 +110,6 @@ void smallest_eigvec4(double A[4][4], double v[4]) {
     for (int i = 0; i < 4; ++i) v[i] = V[i][m];
 }
 
-d3 r2ypr(const m33& R) {
-    const d3 n = mk3(R.m[0], R.m[3], R.m[6]), o = mk3(R.m[1], R.m[4], R.m[7]), a = mk3(R.m[2], R.m[5], R.m[8]);
-    const double y = atan2(n.y, n.x), p = atan2(-n.z, n.x * cos(y) + n.y * sin(y)), r = atan2(a.x * sin(y) - a.y * cos(y), -o.x * sin(y) + o.y * cos(y));
-    return mk3(y, p, r) / M_PI * 180.0;
-}
-m33 ypr2r(d3 ypr) {
-    const double y = ypr.x / 180.0 * M_PI, p = ypr.y / 180.0 * M_PI, r = ypr.z / 180.0 * M_PI;
-    m33 Rz = zero3(), Ry = zero3(), Rx = zero3();
-    Rz.m[0] = cos(y); Rz.m[1] = -sin(y); Rz.m[3] = sin(y); Rz.m[4] = cos(y); Rz.m[8] = 1;
-    Ry.m[0] = cos(p); Ry.m[2] = sin(p); Ry.m[4] = 1; Ry.m[6] = -sin(p); Ry.m[8] = cos(p);
-    Rx.m[0] = 1; Rx.m[4] = cos(r); Rx.m[5] = -sin(r); Rx.m[7] = sin(r); Rx.m[8] = cos(r);
-    return mul(mul(Rz, Ry), Rx);
-}
 quat from_two_vectors(d3 a, d3 b) {
     const d3 v0 = a / norm(a), v1 = b / norm(b);
     const double c = dot(v1, v0);
@@ -145,7 +132,7 @@ struct dv_estimator {
     std::vector<double> dt_buf[kWin + 1]; std::vector<d3> la_buf[kWin + 1], av_buf[kWin + 1];
     std::vector<std::shared_ptr<Preint>> frame_pre;        // all_image_frame pre-integrations (initialisation only)
     bool nonlinear = false, margin_old = true;
-    dv_ba_prior prior{}; std::vector<double> priorA, priorb;
+    dv_ba_prior prior{}; const double* prior_dev_A = nullptr; const double* prior_dev_b = nullptr;      // header on the host, A' / b' device-resident
     m33 back_R0; d3 back_P0;
     dv_ba_summary last{};
     // flat problem buffers
@@ -156,7 +143,7 @@ struct dv_estimator {
     void clear() {
         for (int i = 0; i <= kWin; ++i) { Rs[i] = eye3(); Ps[i] = Vs[i] = Bas[i] = Bgs[i] = mk3(0, 0, 0); pre[i].reset(); dt_buf[i].clear(); la_buf[i].clear(); av_buf[i].clear(); headers[i] = 0; }
         lms.clear(); lm_index.clear(); imu_buf.clear(); frame_pre.clear(); tmp_pre.reset();
-        prior = dv_ba_prior{}; priorA.clear(); priorb.clear();
+        prior = dv_ba_prior{}; prior_dev_A = prior_dev_b = nullptr;
         prev_time = -1; cur_time = 0; first_imu = false; init_pose = false; frame = 0; nonlinear = false; acc_0 = gyr_0 = mk3(0, 0, 0);
         for (int k = 0; k < 2; ++k) { for (int i = 0; i < 9; ++i) ric[k].m[i] = cfg.ric[k][i]; tic[k] = mk3(cfg.tic[k][0], cfg.tic[k][1], cfg.tic[k][2]); }
         td = cfg.td; g = mk3(0, 0, cfg.g_norm);
@@ -346,65 +333,50 @@ struct dv_estimator {
         P.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; P.max_iters = cfg.max_iters; P.g_norm = cfg.g_norm;
         P.pose = &pose[0][0]; P.speed_bias = &sb[0][0]; P.ex_pose = &ex[0][0]; P.td = tdv; P.inv_depth = invd.data();
         P.factors = fac.data(); P.landmarks = lmt.data(); P.imu = imu.data();
-        P.prior = prior.valid ? &prior : nullptr; P.prior_A = priorA.data(); P.prior_b = priorb.data();
+        P.prior = prior.valid ? &prior : nullptr; P.prior_A = prior_dev_A; P.prior_b = prior_dev_b;      // A', b' stay in HBM (written by the fused marginalization)
         return P;
     }
-    int optimization(dv_ctx* ctx) {        // Estimator::Optimization (estimator.cpp:261-339)
+    int optimization(dv_ctx* ctx) {        // Estimator::Optimization (estimator.cpp:261-339) incl. SetMarginalizationInfo (:403-619)
         dv_ba_problem P;
+        BeFused fu;
         { HostScope h(ctx, "h_build");
           states_to_arrays();
           build_factors(false);
           imu.clear();
           ctx->be.sqrt_hint.clear();
           if (cfg.use_imu) for (int i = 0; i < frame; ++i) { if (pre[i + 1]->sum_dt > 10.0) continue; dv_ba_imu r; pre[i + 1]->fill(r, i, i + 1); imu.push_back(r); ctx->be.sqrt_hint.push_back(pre[i + 1]->sqrt_info()); }
-          P = make_problem(frame + 1); }
-        { HostScope h(ctx, "h_solve_total"); const int rc = dv_ba_solve(ctx, &P, &last); ctx->be.sqrt_hint.clear(); if (rc) return -1; }
+          prior_dev_A = prior.valid ? ctx->be.priorA_buf[ctx->be.prior_cur] : nullptr; prior_dev_b = prior.valid ? ctx->be.priorb_buf[ctx->be.prior_cur] : nullptr;
+          P = make_problem(frame + 1);
+          // gauge reference: yaw and position of frame 0 before the solve (Double2vector, estimator.cpp:1111-1128)
+          const d3 y0 = r2ypr(Rs[0]);
+          std::memcpy(fu.R0, Rs[0].m, sizeof(fu.R0)); fu.ypr0[0] = y0.x; fu.ypr0[1] = y0.y; fu.ypr0[2] = y0.z; fu.P0[0] = Ps[0].x; fu.P0[1] = Ps[0].y; fu.P0[2] = Ps[0].z;
+          fu.marg_mode = -1;
+          if (frame == kWin) {
+              if (margin_old) fu.marg_mode = 0;
+              else {
+                  bool has9 = false;          // MARGIN_SECOND_NEW touches the prior only if it holds pose kWin-1 (estimator.cpp:557-560)
+                  if (prior.valid) for (int i = 0; i < prior.nblocks; ++i) if (prior.blocks[i].type == 0 && prior.blocks[i].idx == kWin - 1) has9 = true;
+                  if (has9) fu.marg_mode = 1;
+              }
+          }
+        }
+        { HostScope h(ctx, "h_solve_total"); const int rc = be_solve_fused(ctx, &P, &last, &fu); ctx->be.sqrt_hint.clear(); if (rc) return -1; }
         { HostScope h(ctx, "h_post"); arrays_to_states(); }
-        if (frame < kWin) return 0;
-        HostScope h(ctx, "h_marg_total");
-        return set_marginalization(ctx);
+        if (fu.marg_mode >= 0) prior = fu.new_prior;
+        return 0;
     }
-    void arrays_to_states() {         // Double2vector + BodyState::GetOptimizationParameters (body.cpp:61-132)
-        const d3 origin_R0 = r2ypr(Rs[0]), origin_P0 = Ps[0];
+    void arrays_to_states() {         // Double2vector + BodyState::GetOptimizationParameters (body.cpp:61-132); the yaw-gauge fix ran on the device
         auto qp = [&](int i) { return mkq(pose[i][6], pose[i][3], pose[i][4], pose[i][5]); };
+        for (int i = 0; i <= kWin; ++i) {
+            Rs[i] = qR(qnormalized(qp(i))); Ps[i] = mk3(pose[i][0], pose[i][1], pose[i][2]);
+            if (cfg.use_imu) { Vs[i] = mk3(sb[i][0], sb[i][1], sb[i][2]); Bas[i] = mk3(sb[i][3], sb[i][4], sb[i][5]); Bgs[i] = mk3(sb[i][6], sb[i][7], sb[i][8]); }
+        }
         if (cfg.use_imu) {
-            const d3 origin_R00 = r2ypr(qR(qp(0)));
-            m33 rot_diff = ypr2r(mk3(origin_R0.x - origin_R00.x, 0, 0));
-            if (std::fabs(std::fabs(origin_R0.y) - 90) < 1.0 || std::fabs(std::fabs(origin_R00.y) - 90) < 1.0) rot_diff = mul(Rs[0], tr(qR(qp(0))));
-            for (int i = 0; i <= kWin; ++i) {
-                Rs[i] = mul(rot_diff, qR(qnormalized(qp(i))));
-                Ps[i] = mul(rot_diff, mk3(pose[i][0] - pose[0][0], pose[i][1] - pose[0][1], pose[i][2] - pose[0][2])) + origin_P0;
-                Vs[i] = mul(rot_diff, mk3(sb[i][0], sb[i][1], sb[i][2])); Bas[i] = mk3(sb[i][3], sb[i][4], sb[i][5]); Bgs[i] = mk3(sb[i][6], sb[i][7], sb[i][8]);
-            }
             for (int c = 0; c < 2; ++c) { tic[c] = mk3(ex[c][0], ex[c][1], ex[c][2]); ric[c] = qR(qnormalized(mkq(ex[c][6], ex[c][3], ex[c][4], ex[c][5]))); }
             td = tdv[0];
-        } else for (int i = 0; i <= kWin; ++i) { Rs[i] = qR(qnormalized(qp(i))); Ps[i] = mk3(pose[i][0], pose[i][1], pose[i][2]); }
+        }
         int k = -1;
         for (auto& l : lms) if (l.obs.size() >= 4) { l.depth = 1.0 / invd[++k]; l.solve_flag = l.depth < 0 ? 2 : 1; }
-    }
-    int set_marginalization(dv_ctx* ctx) {        // Estimator::SetMarginalizationInfo (estimator.cpp:403-619)
-        dv_ba_prior np{}; std::vector<double> A(BE_MAX_PRIOR * BE_MAX_PRIOR), b(BE_MAX_PRIOR);
-        if (margin_old) {
-            states_to_arrays();
-            int k = -1; invd.clear();
-            for (auto& l : lms) if (l.obs.size() >= 4) { ++k; invd.push_back(1.0 / l.depth); }
-            build_factors(true);
-            imu.clear();
-            if (cfg.use_imu && pre[1]->sum_dt < 10.0) { dv_ba_imu r; pre[1]->fill(r, 0, 1); imu.push_back(r); }
-            dv_ba_problem P = make_problem(kWin + 1);
-            if (dv_marginalize(ctx, &P, 0, &np, A.data(), b.data(), nullptr)) return -1;
-        } else {
-            bool has9 = false;
-            if (prior.valid) for (int i = 0; i < prior.nblocks; ++i) if (prior.blocks[i].type == 0 && prior.blocks[i].idx == kWin - 1) has9 = true;
-            if (!has9) return 0;          // prior untouched (estimator.cpp:557-560)
-            states_to_arrays();
-            fac.clear(); lmt.clear(); imu.clear();
-            dv_ba_problem P = make_problem(kWin + 1);
-            if (dv_marginalize(ctx, &P, 1, &np, A.data(), b.data(), nullptr)) return -1;
-        }
-        prior = np;
-        if (np.valid) { priorA.assign(A.begin(), A.begin() + (size_t)np.n * np.n); priorb.assign(b.begin(), b.begin() + np.n); }
-        return 0;
     }
     void reject_outliers() {          // OutliersRejection + RemoveOutlier (vio_util.cpp:381-430)
         erase_if([&](const Lm& l) {

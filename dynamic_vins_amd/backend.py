@@ -175,11 +175,20 @@ class Estimator:
         rc = self._check(self.ctx.lib.dv_est_process(self.ctx.h, rows.ctypes.data, len(rows), float(t), C.byref(self.state)))
         return rc, self.state
 
+    def ProcessMeasurementsBegin(self, rows, t):
+        """host bookkeeping + enqueue of the window solve / marginalization; 0 = started, 1 = IMU data missing"""
+        self._rows = np.ascontiguousarray(rows)          # kept alive until End
+        return self._check(self.ctx.lib.dv_est_process_begin(self.ctx.h, self._rows.ctypes.data, len(self._rows), float(t)))
+
+    def ProcessMeasurementsEnd(self):
+        self._check(self.ctx.lib.dv_est_process_end(self.ctx.h, C.byref(self.state)))
+        return self.state
+
     def ClearState(self):
         self._check(self.ctx.lib.dv_est_reset(self.ctx.h))
 
     def window(self):
-        return np.array([list(r) for r in self.state.window])
+        return np.ctypeslib.as_array(self.state.window).copy()
 
     inputIMU = InputIMU
     processMeasurements = ProcessMeasurements

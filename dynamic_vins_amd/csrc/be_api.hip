@@ -89,13 +89,6 @@ int be_fill_imu(const dv_ba_imu& in, BeImu& o, const double* sqrt_hint) {
 bool be_imu_sqrt_info(const double* cov, double* U) { return imu_sqrt_info(cov, U); }
 
 // ================================ marginalization: structure ("plan"), launch, new header ================================
-struct MargPlan {
-    int mode = -1, D = 0, m = 0, n = 0, nimu = 0, nsel = 0;
-    bool empty = false;                                       // nothing to drop: the prior becomes invalid
-    int pose_dim[BE_NF], sb_dim[BE_NF], ex_dim[2], td_dim;
-    int32_t tab[BE_MARG_TAB_INTS];                            // device image of the index tables
-};
-
 // Which parameter blocks take part (MarginalizationInfo::addResidualBlockInfo) and where they sit in the dense system:
 // dropped dims first, then the kept ones in canonical order (poses, speed-bias, ex0, ex1, td)  (M1).
 // sel[0..nsel): landmarks of `lms` whose residual blocks take part (all of them anchored in frame 0).
@@ -162,7 +155,9 @@ static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, double g_norm, const do
     ma.lm_sel = w.marg_tab + BE_MT_SEL;
     ma.D = pl.D; ma.m = pl.m; ma.g_norm = g_norm; ma.outA = outA; ma.outb = outb; ma.out_scalars = scal;
     const size_t slab = (size_t)pl.D * pl.D + pl.D;
-    DV_CHECK(w.marg_buf.ensure(8 * (slab * (size_t)std::max(pl.nsel, 1) + slab + (size_t)std::max(pl.nsel, 1))));
+    // sized once for 256 landmarks anchored in the oldest frame at the largest system (D = 178): growing it later would stall the stream
+    const size_t need = 8 * (slab * (size_t)std::max(pl.nsel, 1) + slab + (size_t)std::max(pl.nsel, 1));
+    DV_CHECK(w.marg_buf.ensure(std::max(need, (size_t)8 * (((size_t)178 * 178 + 178) * 257 + 256))));
     ma.slabs = (double*)w.marg_buf.p; ma.sum = ma.slabs + slab * (size_t)std::max(pl.nsel, 1); ma.lm_h = ma.sum + slab;
     StageScope sc(ctx, "k_be_marg", s);
     const int rc = be_launch_marg(ma, s);
@@ -191,8 +186,11 @@ static void marg_new_prior(const MargPlan& pl, const double* pose, const double*
     out->nblocks = nb;
 }
 
-int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused) {
+int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
     if (!ctx) return -1;
+    BePending& pd = *ctx->be.pend;
+    if (pd.active) DV_FAIL("dv_ba_solve: previous solve not collected");
+    pd.trivial = false;
     const std::chrono::steady_clock::time_point t_begin = std::chrono::steady_clock::now();
     if (!P || !P->pose || !P->ex_pose || !P->td) DV_FAIL("dv_ba_solve: null argument");
     if (P->nframes < 1 || P->nframes > BE_NF) DV_FAIL("dv_ba_solve: nframes out of range");
@@ -221,7 +219,7 @@ int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFuse
     if (col == 0) {       // e.g. vision-only, first frame: pose 0 is constant and no landmark has 4 observations yet
         if (P->nlm > 0) DV_FAIL("dv_ba_solve: landmarks without a free pose block");
         if (fused && fused->marg_mode >= 0) DV_FAIL("dv_ba_solve: marginalization needs a full window");
-        if (summary) { summary->iterations = 0; summary->successful = 0; summary->termination = 1; summary->slots = 0; summary->initial_cost = 0; summary->final_cost = 0; }
+        pd.active = true; pd.trivial = true;
         return 0;
     }
     BePriorHdr ph{};
@@ -236,7 +234,7 @@ int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFuse
         }
     }
     // ---- marginalization structure (does not depend on the solution): planned now so that its tables ride in the same upload ----
-    static thread_local MargPlan pl;
+    MargPlan& pl = pd.pl;
     const bool do_marg = fused && fused->marg_mode >= 0;
     if (do_marg) {
         if (P->nframes != BE_NF) DV_FAIL("dv_marginalize: needs a full window (frame == kWinSize)");
@@ -320,10 +318,29 @@ int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFuse
     DV_CHECK(hipMemcpyAsync(hx, w.x, state_bytes, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
     if (do_marg && !pl.empty) DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, s));
+    pd.active = true; pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = nxt; pd.t_begin = t_begin; pd.t_up = t_up; pd.t_enq = t_enq;
+    return 0;
+}
+
+int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused) {
+    if (!ctx) return -1;
+    BePending& pd = *ctx->be.pend;
+    if (!pd.active) DV_FAIL("dv_ba_solve: nothing to collect");
+    pd.active = false;
+    if (pd.trivial) {
+        if (summary) { summary->iterations = 0; summary->successful = 0; summary->termination = 1; summary->slots = 0; summary->initial_cost = 0; summary->final_cost = 0; }
+        return 0;
+    }
+    BeWork& w = ctx->be;
+    hipStream_t s = ctx->be_stream;
+    const MargPlan& pl = pd.pl;
+    uint8_t* hp = (uint8_t*)w.pinned;
+    const BeState* hx = (const BeState*)(hp + w.dl_off); const BeCtl* hctl = (const BeCtl*)(hp + w.dl_off + sizeof(BeState));
+    const double* hscal = (const double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl));
     DV_CHECK(hipStreamSynchronize(s));
     if (ctx->timing) {
-        StageTimer* te = dv_timer_for(ctx, "h_solve_enqueue"); te->total_ms += std::chrono::duration<double, std::milli>(t_enq - t_up).count(); te->count++;
-        StageTimer* tu = dv_timer_for(ctx, "h_solve_upload"); tu->total_ms += std::chrono::duration<double, std::milli>(t_up - t_begin).count(); tu->count++;
+        StageTimer* te = dv_timer_for(ctx, "h_solve_enqueue"); te->total_ms += std::chrono::duration<double, std::milli>(pd.t_enq - pd.t_up).count(); te->count++;
+        StageTimer* tu = dv_timer_for(ctx, "h_solve_upload"); tu->total_ms += std::chrono::duration<double, std::milli>(pd.t_up - pd.t_begin).count(); tu->count++;
         dv_harvest_timers(ctx, s);
     }
     for (int f = 0; f < P->nframes; ++f) { std::memcpy(P->pose + 7 * f, hx->pose[f], 56); if (P->use_imu) std::memcpy(P->speed_bias + 9 * f, hx->sb[f], 72); }
@@ -332,17 +349,22 @@ int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFuse
         summary->iterations = hctl->iter; summary->successful = hctl->successful; summary->termination = hctl->done ? hctl->termination : 0;
         summary->slots = hctl->slots; summary->initial_cost = hctl->initial_cost; summary->final_cost = hctl->x_cost;
     }
-    if (do_marg) {
+    if (pd.do_marg) {
         if (pl.empty) { std::memset(&fused->new_prior, 0, sizeof(fused->new_prior)); std::memset(fused->diag, 0, sizeof(fused->diag)); w.prior_resident = false; }
         else {
             std::memcpy(fused->diag, hscal, 32);
             if (hscal[2] != 0.0) DV_FAIL("dv_marginalize: A_mm is not positive definite (reference would take its pseudo-inverse)");
             marg_new_prior(pl, P->pose, P->speed_bias, P->ex_pose, P->td, hscal[0], &fused->new_prior);      // x0 = the gauge-fixed states just downloaded
-            w.prior_cur = nxt; w.prior_resident = true;
-            w.priorA = w.priorA_buf[nxt]; w.priorb = w.priorb_buf[nxt];
+            w.prior_cur = pd.nxt; w.prior_resident = true;
+            w.priorA = w.priorA_buf[pd.nxt]; w.priorb = w.priorb_buf[pd.nxt];
         }
     }
     return 0;
+}
+
+int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused) {
+    if (be_solve_fused_begin(ctx, P, fused)) return -1;
+    return be_solve_fused_end(ctx, P, summary, fused);
 }
 
 extern "C" {

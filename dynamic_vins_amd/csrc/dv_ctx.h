@@ -7,6 +7,7 @@
 #include <chrono>
 #include <deque>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -56,7 +57,28 @@ struct StageTimer {       // pool of HIP event pairs: a stage / kernel may be re
 };
 
 // device-side workspace of the bundle-adjustment solver (allocated on first use)
+// marginalization index tables (int32): prior_map[BE_MAX_PRIOR] | imu_map[32] | dim_slot[256] | dim_comp[256] | lm_sel[BE_MAX_LM]
+#define BE_MT_PRIOR 0
+#define BE_MT_IMU (BE_MAX_PRIOR)
+#define BE_MT_SLOT (BE_MAX_PRIOR + 32)
+#define BE_MT_COMP (BE_MAX_PRIOR + 32 + 256)
+#define BE_MT_SEL (BE_MAX_PRIOR + 32 + 512)
+#define BE_MARG_TAB_INTS (BE_MAX_PRIOR + 32 + 512 + BE_MAX_LM)
+
+struct MargPlan {
+    int mode = -1, D = 0, m = 0, n = 0, nimu = 0, nsel = 0;
+    bool empty = false;                                       // nothing to drop: the prior becomes invalid
+    int pose_dim[BE_NF], sb_dim[BE_NF], ex_dim[2], td_dim;
+    int32_t tab[BE_MARG_TAB_INTS];                            // device image of the index tables
+};
+
+struct BePending {        // a solve that has been enqueued and not yet collected (be_solve_fused_begin / _end)
+    bool active = false, trivial = false, do_marg = false; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
+    std::chrono::steady_clock::time_point t_begin, t_up, t_enq;
+};
+
 struct BeWork {
+    std::unique_ptr<BePending> pend = std::make_unique<BePending>();
     bool ready = false;
     DevBuf block;          // one allocation, carved below
     BeCtl* ctl = nullptr; BeState* x = nullptr; BeState* cand = nullptr;
@@ -78,14 +100,6 @@ struct BeWork {
 
 bool be_imu_sqrt_info(const double* cov15x15, double* U15x15);      // U^T U = cov^-1, false if singular
 
-// marginalization index tables (int32): prior_map[BE_MAX_PRIOR] | imu_map[32] | dim_slot[256] | dim_comp[256] | lm_sel[BE_MAX_LM]
-#define BE_MT_PRIOR 0
-#define BE_MT_IMU (BE_MAX_PRIOR)
-#define BE_MT_SLOT (BE_MAX_PRIOR + 32)
-#define BE_MT_COMP (BE_MAX_PRIOR + 32 + 256)
-#define BE_MT_SEL (BE_MAX_PRIOR + 32 + 512)
-#define BE_MARG_TAB_INTS (BE_MAX_PRIOR + 32 + 512 + BE_MAX_LM)
-
 // Estimator-internal fused entry: window solve, yaw-gauge fix and marginalization enqueued back to back on the BA
 // stream (one upload, one download, one sync); the new prior's A', b' stay in HBM for the next solve.
 struct BeFused {
@@ -95,6 +109,8 @@ struct BeFused {
     double diag[4] = { 0, 0, 0, 0 };          // out: c0, smallest pivot, failure flag, rank
 };
 int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);
+int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused);       // upload + enqueue everything, returns immediately
+int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);      // sync + collect
 struct dv_estimator;
 void dv_est_destroy_internal(dv_estimator* e);
 

@@ -336,9 +336,8 @@ struct dv_estimator {
         P.prior = prior.valid ? &prior : nullptr; P.prior_A = prior_dev_A; P.prior_b = prior_dev_b;      // A', b' stay in HBM (written by the fused marginalization)
         return P;
     }
-    int optimization(dv_ctx* ctx) {        // Estimator::Optimization (estimator.cpp:261-339) incl. SetMarginalizationInfo (:403-619)
-        dv_ba_problem P;
-        BeFused fu;
+    dv_ba_problem P{}; BeFused fu;          // the solve in flight (optimization_begin .. optimization_end)
+    int optimization_begin(dv_ctx* ctx) {        // Estimator::Optimization (estimator.cpp:261-339) incl. SetMarginalizationInfo (:403-619)
         { HostScope h(ctx, "h_build");
           states_to_arrays();
           build_factors(false);
@@ -360,11 +359,16 @@ struct dv_estimator {
               }
           }
         }
-        { HostScope h(ctx, "h_solve_total"); const int rc = be_solve_fused(ctx, &P, &last, &fu); ctx->be.sqrt_hint.clear(); if (rc) return -1; }
+        { HostScope h(ctx, "h_solve_begin"); const int rc = be_solve_fused_begin(ctx, &P, &fu); ctx->be.sqrt_hint.clear(); if (rc) return -1; }
+        return 0;
+    }
+    int optimization_end(dv_ctx* ctx) {
+        { HostScope h(ctx, "h_solve_wait"); if (be_solve_fused_end(ctx, &P, &last, &fu)) return -1; }
         { HostScope h(ctx, "h_post"); arrays_to_states(); }
         if (fu.marg_mode >= 0) prior = fu.new_prior;
         return 0;
     }
+    int optimization(dv_ctx* ctx) { if (optimization_begin(ctx)) return -1; return optimization_end(ctx); }
     void arrays_to_states() {         // Double2vector + BodyState::GetOptimizationParameters (body.cpp:61-132); the yaw-gauge fix ran on the device
         auto qp = [&](int i) { return mkq(pose[i][6], pose[i][3], pose[i][4], pose[i][5]); };
         for (int i = 0; i <= kWin; ++i) {
@@ -460,21 +464,30 @@ struct dv_estimator {
         if (frame < kWin) { frame++; const int p = frame - 1; Ps[frame] = Ps[p]; Vs[frame] = Vs[p]; Rs[frame] = Rs[p]; Bas[frame] = Bas[p]; Bgs[frame] = Bgs[p]; }
         return 0;
     }
-    int process_image(dv_ctx* ctx, const dv_feat* feats, int n, double header) {      // ProcessImage (estimator.cpp:1516-1696)
+    int process_image_begin(dv_ctx* ctx, const dv_feat* feats, int n, double header) {      // ProcessImage (estimator.cpp:1516-1696), up to and including the enqueue of the window solve
         { HostScope h(ctx, "h_add_features"); margin_old = add_features(frame, feats, n); }
         headers[frame] = header;
         frame_pre.push_back(std::shared_ptr<Preint>(tmp_pre.release()));
         if (frame_pre.size() > (size_t)kWin + 1 && nonlinear) frame_pre.erase(frame_pre.begin());
         tmp_pre = std::make_unique<Preint>(acc_0, gyr_0, Bas[frame], Bgs[frame], noise());
-        if (!nonlinear) return init_estimator(ctx);
+        in_flight = false;
+        if (!nonlinear) return init_estimator(ctx);      // initialisation: synchronous
         if (!cfg.use_imu) pnp_frame(frame);
         { HostScope h(ctx, "h_triangulate"); triangulate(); }
-        if (optimization(ctx)) return -1;
+        if (optimization_begin(ctx)) return -1;
+        in_flight = true;
+        return 0;
+    }
+    int process_image_end(dv_ctx* ctx) {
+        if (!in_flight) return 0;
+        in_flight = false;
+        if (optimization_end(ctx)) return -1;
         { HostScope h(ctx, "h_reject"); reject_outliers(); }
         { HostScope h(ctx, "h_slide"); slide_window();
           erase_if([](const Lm& l) { return l.solve_flag == 2; }); }      // RemoveFailures
         return 0;
     }
+    bool in_flight = false, begun = false;
 };
 
 extern "C" {
@@ -487,19 +500,30 @@ int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg) {
     ctx->est = new dv_estimator(*cfg);
     return 0;
 }
-int dv_est_reset(dv_ctx* ctx) { if (!ctx || !ctx->est) return -1; ctx->est->clear(); return 0; }
+int dv_est_reset(dv_ctx* ctx) { if (!ctx || !ctx->est) return -1; if (ctx->est->begun) { ctx->est->begun = false; (void)ctx->est->process_image_end(ctx); } ctx->est->clear(); return 0; }
 int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr) {
     if (!ctx || !ctx->est) return -1;
     ctx->est->imu_buf.push_back({ t, { mk3(acc[0], acc[1], acc[2]), mk3(gyr[0], gyr[1], gyr[2]) } });
     return 0;
 }
-int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_state* out) {
+int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t) {
     if (!ctx) return -1;
     if (!ctx->est) DV_FAIL("dv_est_process: call dv_est_create first");
     dv_estimator& E = *ctx->est;
+    if (E.begun) DV_FAIL("dv_est_process_begin: previous frame not collected (dv_est_process_end)");
     E.cur_time = t + E.td;
     { HostScope h(ctx, "h_imu"); if (E.cfg.use_imu && !E.add_imu_until(E.cur_time)) return 1; }       // "wait for imu" (estimator.cpp:1801-1805)
-    { HostScope h(ctx, "h_process_total"); if (E.process_image(ctx, feats, n, t)) return -1; }
+    { HostScope h(ctx, "h_process_begin"); if (E.process_image_begin(ctx, feats, n, t)) return -1; }
+    E.begun = true;
+    return 0;
+}
+int dv_est_process_end(dv_ctx* ctx, dv_est_state* out) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_process: call dv_est_create first");
+    dv_estimator& E = *ctx->est;
+    if (!E.begun) DV_FAIL("dv_est_process_end: no frame in flight");
+    E.begun = false;
+    { HostScope h(ctx, "h_process_end"); if (E.process_image_end(ctx)) return -1; }
     E.prev_time = E.cur_time;
     if (out) {
         std::memset(out, 0, sizeof(*out));
@@ -512,6 +536,11 @@ int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_st
         }
     }
     return 0;
+}
+int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_state* out) {
+    const int rc = dv_est_process_begin(ctx, feats, n, t);
+    if (rc) return rc;
+    return dv_est_process_end(ctx, out);
 }
 
 }  // extern "C"

@@ -49,25 +49,36 @@ class Pipeline:
             self.ctx.track_stereo_enqueue(l.data_ptr(), r.data_ptr(), self.seq.times[k], None, DV_MODE_RAW, DV_MEM_DEVICE)
         self.enqueued = True
 
+    def _feed_imu(self, t):
+        s = self.seq
+        hi = self.k_imu
+        while hi < len(s.imu_t) and s.imu_t[hi] <= t + 0.006:
+            hi += 1
+        for j in range(self.k_imu, hi):
+            self.est.InputIMU(s.imu_t[j], s.imu_a[j], s.imu_g[j])
+        self.k_imu = hi
+
     def step(self):
-        """processes frame self.next through track + BA; returns the estimator state"""
+        """processes frame self.next through track + BA; returns the estimator state.
+        Order (the reference's T2 / T3 overlap on one host thread): collect tracking of k -> begin BA of k (host prep +
+        enqueue on the BA stream) -> enqueue tracking of k+1 and feed k+1's IMU samples while the GPU solves -> end BA of k."""
         k = self.next
         s = self.seq
         if not self.enqueued:
             self._enqueue(k)
         rows = self.ctx.track_stereo_collect()
         self.enqueued = False
-        if k + 1 < len(s.frames):
-            self._enqueue(k + 1)                     # overlaps with the BA of frame k
         t = s.times[k]
-        while self.k_imu < len(s.imu_t) and s.imu_t[self.k_imu] <= t + 0.006:
-            self.est.InputIMU(s.imu_t[self.k_imu], s.imu_a[self.k_imu], s.imu_g[self.k_imu])
-            self.k_imu += 1
-        rc, st = self.est.ProcessMeasurements(rows, t)
+        self._feed_imu(t)
+        rc = self.est.ProcessMeasurementsBegin(rows, t)
         if rc != 0:
             raise RuntimeError("IMU stream does not cover the frame")
+        if k + 1 < len(s.frames):
+            self._enqueue(k + 1)                     # overlaps with the BA of frame k
+            self._feed_imu(s.times[k + 1])
+        st = self.est.ProcessMeasurementsEnd()
         if st.nonlinear:
-            self.poses.append(self.est.window()[10, :7].copy())
+            self.poses.append(self.est.window()[10, :7])
             self.pose_times.append(t)
         self.next += 1
         self.rows = rows

@@ -204,6 +204,12 @@ int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr
  * sliding window).  returns 0 = processed, 1 = IMU data does not cover t yet (feed more, call again), <0 error.
  * The frame's pose is out->window[10] once nonlinear (what SaveBodyTrajectory writes, utils/io/output.cpp:199-227). */
 int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_state* out);
+/* the same in two phases, like dv_track_stereo_enqueue/_collect: _begin does the host bookkeeping and ENQUEUES the window
+ * solve + marginalization on the ctx's BA stream (returns 0, or 1 = IMU data missing: nothing was started); _end waits,
+ * applies the result (outlier rejection, window slide) and fills `out`.  Between the two the caller may enqueue the next
+ * frame's tracking and feed IMU samples — thread T2's work overlapping T3's, as in the reference (system/main.cpp:394-404). */
+int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t);
+int dv_est_process_end(dv_ctx* ctx, dv_est_state* out);
 
 /* ---- measurement hooks (used by bench.py; HIP-event timing on the ctx's own stream) ---- */
 /* names: "pyr","lk_temporal","compact","gftt_eig","gftt_select","lk_stereo","frame" */

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 NOISE = dict(acc_n=0.02, gyr_n=0.002, acc_w=2e-4, gyr_w=2e-5)
 
 
-def run_pair(gpu_ctx_factory, oracle, use_imu, frames, plane=0, max_cnt=150, seed=3):
+def run_pair(gpu_ctx_factory, oracle, use_imu, frames, plane=0, max_cnt=150, seed=3, two_phase=False):
     from dynamic_vins_amd.backend import Estimator
     ctx = gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5)
     traj = sim.Trajectory()
@@ -34,8 +34,16 @@ def run_pair(gpu_ctx_factory, oracle, use_imu, frames, plane=0, max_cnt=150, see
             dev.InputIMU(ts[k], acc[k], gyr[k])
             k += 1
         rows = fs.frame(t)
-        rc_o, so = ref.process(rows, t)
-        rc_d, sd = dev.ProcessMeasurements(rows, t)
+        rc_o, so = ref.process(rows, t)      # (the oracle consumes IMU samples only up to the frame time, so feeding it early is harmless)
+        if two_phase:      # dv_est_process_begin / _end with the NEXT frame's IMU samples arriving while the solve is in flight
+            rc_d = dev.ProcessMeasurementsBegin(rows, t)
+            while k < len(ts) and ts[k] <= t + dtf + 0.011:
+                ref.input_imu(ts[k], acc[k], gyr[k])
+                dev.InputIMU(ts[k], acc[k], gyr[k])
+                k += 1
+            sd = dev.ProcessMeasurementsEnd()
+        else:
+            rc_d, sd = dev.ProcessMeasurements(rows, t)
         assert rc_o == rc_d == 0
         assert (sd.frame, sd.nonlinear, sd.margin_old, sd.n_landmarks, sd.n_long) == (so.frame, so.nonlinear, so.margin_old, so.n_landmarks, so.n_long), f"frame {f}"
         assert sd.iterations == so.iterations, f"frame {f}: iterations {sd.iterations} vs {so.iterations}"
@@ -59,3 +67,8 @@ def test_estimator_tracks_oracle(gpu_ctx_factory, oracle, use_imu, frames):
     ate_dev_vs_ref, _, _ = sim.align_ate(est, ref)
     assert ate_dev_vs_ref < 1e-5            # north_star: within 1e-3 m of the reference trajectory
     assert abs(ate_dev - ate_ref) < 1e-5 and ate_dev < 0.05
+
+
+def test_two_phase_process_matches_oracle(gpu_ctx_factory, oracle):
+    max_dp, max_dq, est, ref, gt = run_pair(gpu_ctx_factory, oracle, 1, 30, two_phase=True)
+    assert max_dp < 1e-5 and max_dq < 1e-6, (max_dp, max_dq)

@@ -146,10 +146,10 @@ static int marg_plan(dv_ctx* ctx, MargPlan& pl, int mode, const dv_ba_prior* pri
 }
 
 // launches the three kernels; the index tables must already be (enqueued to be) in w.marg_tab
-static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, hipStream_t s) {
+static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, hipStream_t s) {
     BeWork& w = ctx->be;
     BeMargArgs ma{};
-    ma.x = w.x; ma.nframes = BE_NF; ma.nlm = pl.nsel; ma.nimu = pl.nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
+    ma.x = x; ma.nframes = BE_NF; ma.nlm = pl.nsel; ma.nimu = pl.nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
     ma.prior = w.prior; ma.priorA = priorA; ma.priorb = priorb;
     ma.prior_map = w.marg_tab + BE_MT_PRIOR; ma.imu_map = w.marg_tab + BE_MT_IMU; ma.dim_slot = w.marg_tab + BE_MT_SLOT; ma.dim_comp = w.marg_tab + BE_MT_COMP;
     ma.lm_sel = w.marg_tab + BE_MT_SEL;
@@ -184,6 +184,46 @@ static void marg_new_prior(const MargPlan& pl, const double* pose, const double*
     for (int c = 0; c < 2; ++c) if (pl.ex_dim[c] >= 0) put(2, c, pl.ex_dim[c], 6, ex + 7 * c, 7);
     if (pl.td_dim >= 0) put(3, 0, pl.td_dim, 1, td, 1);
     out->nblocks = nb;
+}
+
+static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, hipStream_t s) {
+    const bool kt = ctx->timing && ctx->kernel_timing;       // per-launch events (roofline measurement); off in the throughput run
+    for (int it = 0; it < slots; ++it) {
+        if (kt) {
+            { StageScope k(ctx, "k_be_eval_full", s); be_launch_eval(pd.ea, true, s); }
+            { StageScope k(ctx, "k_be_reduce", s); be_launch_reduce(pd.sa, s); }
+            { StageScope k(ctx, "k_be_solve", s); if (be_launch_solve(pd.sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size"); }
+            { StageScope k(ctx, "k_be_eval_cost", s); be_launch_eval(pd.ea, false, s); }
+            { StageScope k(ctx, "k_be_accept", s); be_launch_accept(pd.sa, s); }
+        } else {
+            be_launch_eval(pd.ea, true, s);
+            be_launch_reduce(pd.sa, s);
+            if (be_launch_solve(pd.sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
+            be_launch_eval(pd.ea, false, s);
+            be_launch_accept(pd.sa, s);
+        }
+    }
+    return 0;
+}
+
+// gauge fix + marginalization + download, enqueued behind the slots on the same stream (no host round trip)
+static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
+    BeWork& w = ctx->be;
+    uint8_t* hp = (uint8_t*)w.pinned;
+    if (pd.fused_present) {
+        BeGaugeArgs ga{};
+        ga.x = w.x; ga.out = w.cand; ga.nlm = pd.nlm; ga.nframes = pd.nframes; ga.use_imu = pd.use_imu;
+        std::memcpy(ga.R0, pd.gauge_R0, sizeof(ga.R0)); std::memcpy(ga.ypr0, pd.gauge_ypr0, sizeof(ga.ypr0)); std::memcpy(ga.P0, pd.gauge_P0, sizeof(ga.P0));
+        be_launch_gauge(ga, s);
+        if (pd.do_marg && !pd.pl.empty && marg_enqueue(ctx, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], w.marg_scal, s)) return -1;
+    }
+    DV_CHECK(hipGetLastError());
+    BeState* hx = (BeState*)(hp + w.dl_off); BeCtl* hctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState));
+    double* hscal = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl));
+    DV_CHECK(hipMemcpyAsync(hx, pd.fused_present ? w.cand : w.x, pd.state_bytes, hipMemcpyDeviceToHost, s));      // estimator path: the gauge-fixed copy
+    DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
+    if (pd.do_marg && !pd.pl.empty) DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, s));
+    return 0;
 }
 
 int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
@@ -282,43 +322,18 @@ int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
     sa.packets = w.packets; sa.imu_out = w.imu_out; sa.prior_out = w.prior_out; sa.cand_cost = w.cand_cost; sa.Hd = w.Hd; sa.Sc = w.Sc; sa.gvec = w.gvec;
     sa.scale_p = w.scale_p; sa.diag_p = w.diag_p; sa.grad_p = w.grad_p; sa.gn_p = w.gn_p; sa.scale_l = w.scale_l; sa.diag_l = w.diag_l; sa.grad_l = w.grad_l; sa.gn_l = w.gn_l;
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;
-    {
-        StageScope sc(ctx, "ba_solve", s);
-        const int slots = P->max_iters + 3;      // + retries after a failed Cholesky (mu *= 10)
-        const bool kt = ctx->timing && ctx->kernel_timing;       // per-launch events (roofline measurement); off in the throughput run
-        for (int it = 0; it < slots; ++it) {
-            if (kt) {
-                { StageScope k(ctx, "k_be_eval_full", s); be_launch_eval(ea, true, s); }
-                { StageScope k(ctx, "k_be_reduce", s); be_launch_reduce(sa, s); }
-                { StageScope k(ctx, "k_be_solve", s); if (be_launch_solve(sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size"); }
-                { StageScope k(ctx, "k_be_eval_cost", s); be_launch_eval(ea, false, s); }
-                { StageScope k(ctx, "k_be_accept", s); be_launch_accept(sa, s); }
-            } else {
-                be_launch_eval(ea, true, s);
-                be_launch_reduce(sa, s);
-                if (be_launch_solve(sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
-                be_launch_eval(ea, false, s);
-                be_launch_accept(sa, s);
-            }
-        }
-    }
+    // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
+    // invalid; be_solve_fused_end checks the downloaded control block and, in that rare case, runs the spare slots and the
+    // (idempotent) tail again.
+    pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
+    if (fused) { std::memcpy(pd.gauge_R0, fused->R0, sizeof(pd.gauge_R0)); std::memcpy(pd.gauge_ypr0, fused->ypr0, sizeof(pd.gauge_ypr0)); std::memcpy(pd.gauge_P0, fused->P0, sizeof(pd.gauge_P0)); }
+    pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = 1 - w.prior_cur;
+    static const bool force_retry = std::getenv("DVINS_TEST_FORCE_RETRY_TAIL") != nullptr;      // test hook: exercise the spare-slot path of be_solve_fused_end
+    const int first_slots = force_retry ? std::max(1, P->max_iters - 2) : P->max_iters;
+    { StageScope sc(ctx, "ba_solve", s); if (be_enqueue_slots(ctx, pd, first_slots, s)) return -1; }
     std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
-    // ---- gauge fix + marginalization follow on the same stream without a host round trip ----
-    const int nxt = 1 - w.prior_cur;
-    if (fused) {
-        BeGaugeArgs ga{};
-        ga.x = w.x; ga.nframes = P->nframes; ga.use_imu = P->use_imu;
-        std::memcpy(ga.R0, fused->R0, sizeof(ga.R0)); std::memcpy(ga.ypr0, fused->ypr0, sizeof(ga.ypr0)); std::memcpy(ga.P0, fused->P0, sizeof(ga.P0));
-        be_launch_gauge(ga, s);
-        if (do_marg && !pl.empty && marg_enqueue(ctx, pl, P->g_norm, w.priorA, w.priorb, w.priorA_buf[nxt], w.priorb_buf[nxt], w.marg_scal, s)) return -1;
-    }
-    DV_CHECK(hipGetLastError());
-    hx = (BeState*)(hp + w.dl_off); hctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState));
-    double* hscal = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl));
-    DV_CHECK(hipMemcpyAsync(hx, w.x, state_bytes, hipMemcpyDeviceToHost, s));
-    DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
-    if (do_marg && !pl.empty) DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, s));
-    pd.active = true; pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = nxt; pd.t_begin = t_begin; pd.t_up = t_up; pd.t_enq = t_enq;
+    if (be_enqueue_tail(ctx, pd, s)) return -1;
+    pd.active = true; pd.t_begin = t_begin; pd.t_up = t_up; pd.t_enq = t_enq;
     return 0;
 }
 
@@ -338,6 +353,12 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     const BeState* hx = (const BeState*)(hp + w.dl_off); const BeCtl* hctl = (const BeCtl*)(hp + w.dl_off + sizeof(BeState));
     const double* hscal = (const double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl));
     DV_CHECK(hipStreamSynchronize(s));
+    if (!hctl->done) {        // rare: a failed linear solve / invalid step used up slots -> the 3 spare slots, then the tail once more
+        // (the raw solution is still in w.x: the gauge fix writes to the candidate buffer; the marginalization reads the untouched old prior)
+        if (be_enqueue_slots(ctx, pd, 3, s)) return -1;
+        if (be_enqueue_tail(ctx, pd, s)) return -1;
+        DV_CHECK(hipStreamSynchronize(s));
+    }
     if (ctx->timing) {
         StageTimer* te = dv_timer_for(ctx, "h_solve_enqueue"); te->total_ms += std::chrono::duration<double, std::milli>(pd.t_enq - pd.t_up).count(); te->count++;
         StageTimer* tu = dv_timer_for(ctx, "h_solve_upload"); tu->total_ms += std::chrono::duration<double, std::milli>(pd.t_up - pd.t_begin).count(); tu->count++;
@@ -416,7 +437,7 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
         w.prior_resident = false;
     }
     double* d_outA = w.Sc; double* d_outb = w.gvec; double* d_scal = w.marg_scal;      // Sc / gvec are idle outside a solve
-    if (marg_enqueue(ctx, pl, P->g_norm, w.priorA_buf[w.prior_cur], w.priorb_buf[w.prior_cur], d_outA, d_outb, d_scal, s)) return -1;
+    if (marg_enqueue(ctx, pl, w.x, P->g_norm, w.priorA_buf[w.prior_cur], w.priorb_buf[w.prior_cur], d_outA, d_outb, d_scal, s)) return -1;
     DV_CHECK(hipGetLastError());
     double scal[4];
     DV_CHECK(hipMemcpyAsync(out_A, d_outA, 8 * (size_t)n * n, hipMemcpyDeviceToHost, s));

@@ -47,7 +47,7 @@ struct BeMargArgs {
 
 // yaw-gauge fix after a solve (Estimator::Double2vector, estimator.cpp:1111-1154): rotates the solved window back to the yaw and
 // position frame 0 had before the solve, in place on the device, so that the marginalization can follow without a host round trip
-struct BeGaugeArgs { BeState* x; int nframes, use_imu; double R0[9]; double ypr0[3]; double P0[3]; };
+struct BeGaugeArgs { const BeState* x; BeState* out; int nframes, use_imu, nlm; double R0[9]; double ypr0[3]; double P0[3]; };      // out != x: the raw solution stays intact
 
 #if defined(__HIPCC__)
 using namespace be;

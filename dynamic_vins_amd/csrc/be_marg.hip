@@ -241,11 +241,12 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void be_gauge_kernel(BeGaugeArgs a) {
+__global__ __launch_bounds__(256) void be_gauge_kernel(BeGaugeArgs a) {
     __shared__ m33 rot;
     __shared__ d3 p0;
     const int i = threadIdx.x;
-    BeState* st = a.x;
+    const BeState* st = a.x;
+    BeState* o = a.out;
     if (i == 0) {
         p0 = P3(st->pose[0]);
         if (a.use_imu) {
@@ -258,21 +259,27 @@ __global__ __launch_bounds__(64) void be_gauge_kernel(BeGaugeArgs a) {
         }
     }
     __syncthreads();
-    if (i >= a.nframes) return;
+    for (int l = i; l < a.nlm; l += 256) o->inv_depth[l] = st->inv_depth[l];
+    if (i < 14) o->ex[i / 7][i % 7] = st->ex[i / 7][i % 7];
+    if (i == 14) o->td = st->td;
+    if (i >= BE_NF) return;
+    if (i >= a.nframes) { for (int k = 0; k < 7; ++k) o->pose[i][k] = st->pose[i][k]; for (int k = 0; k < 9; ++k) o->sb[i][k] = st->sb[i][k]; return; }
     const quat qn = qnormalized(Q4(st->pose[i]));
+    for (int k = 0; k < 9; ++k) o->sb[i][k] = st->sb[i][k];
     if (a.use_imu) {
         const m33 R = mul(rot, qR(qn));
         const d3 P = mul(rot, P3(st->pose[i]) - p0) + mk3(a.P0[0], a.P0[1], a.P0[2]);
         const d3 V = mul(rot, mk3(st->sb[i][0], st->sb[i][1], st->sb[i][2]));
         const quat q = qfromR(R);
-        st->pose[i][0] = P.x; st->pose[i][1] = P.y; st->pose[i][2] = P.z; st->pose[i][3] = q.x; st->pose[i][4] = q.y; st->pose[i][5] = q.z; st->pose[i][6] = q.w;
-        st->sb[i][0] = V.x; st->sb[i][1] = V.y; st->sb[i][2] = V.z;
+        o->pose[i][0] = P.x; o->pose[i][1] = P.y; o->pose[i][2] = P.z; o->pose[i][3] = q.x; o->pose[i][4] = q.y; o->pose[i][5] = q.z; o->pose[i][6] = q.w;
+        o->sb[i][0] = V.x; o->sb[i][1] = V.y; o->sb[i][2] = V.z;
     } else {
         const quat q = qfromR(qR(qn));
-        st->pose[i][3] = q.x; st->pose[i][4] = q.y; st->pose[i][5] = q.z; st->pose[i][6] = q.w;
+        o->pose[i][0] = st->pose[i][0]; o->pose[i][1] = st->pose[i][1]; o->pose[i][2] = st->pose[i][2];
+        o->pose[i][3] = q.x; o->pose[i][4] = q.y; o->pose[i][5] = q.z; o->pose[i][6] = q.w;
     }
 }
-void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(64), 0, s, a); }
+void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(256), 0, s, a); }
 
 static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16) * sizeof(double); }
 static size_t lm_smem(int D) { return ((size_t)BE_MAX_OBS_FACTORS * 54 + 2 * (size_t)BE_MAX_OBS_FACTORS * D + 2 * D) * sizeof(double); }

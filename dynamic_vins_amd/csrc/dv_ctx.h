@@ -2,6 +2,7 @@
 #pragma once
 #include "dv_internal.h"
 #include "be_types.h"
+#include "be_kernels.h"
 #include <cmath>
 #include <cstring>
 #include <chrono>
@@ -73,7 +74,8 @@ struct MargPlan {
 };
 
 struct BePending {        // a solve that has been enqueued and not yet collected (be_solve_fused_begin / _end)
-    bool active = false, trivial = false, do_marg = false; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
+    bool active = false, trivial = false, do_marg = false, fused_present = false; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
+    BeEvalArgs ea; BeSolveArgs sa; int max_iters = 0, nframes = 0, use_imu = 0, nlm = 0; double g_norm = 0, gauge_R0[9], gauge_ypr0[3], gauge_P0[3];
     std::chrono::steady_clock::time_point t_begin, t_up, t_enq;
 };
 

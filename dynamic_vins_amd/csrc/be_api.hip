@@ -21,7 +21,7 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     const size_t upload_bytes = off;
     size_t o_c = take(sizeof(BeState)),
            o_pA = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb = take(8 * BE_MAX_PRIOR),
-           o_pA2 = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb2 = take(8 * BE_MAX_PRIOR), o_ms = take(64),
+           o_pA2 = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb2 = take(8 * BE_MAX_PRIOR), o_ms = take(64), o_c0 = take(64),
            o_pk = take(8 * (size_t)BE_PK_SIZE * BE_PK_STRIDE), o_io = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po = take(8 * (BE_MAX_PRIOR + 1)),
            o_cc = take(8 * (BE_MAX_LM + BE_WIN + 1)), o_hd = take(8 * n * n), o_sc = take(8 * n * n), o_g = take(8 * 2 * n),
            o_v = take(8 * 4 * n), o_vl = take(8 * 4 * (size_t)BE_MAX_LM);
@@ -31,7 +31,7 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     w.imu = (BeImu*)(b + o_imu); w.prior = (BePriorHdr*)(b + o_pr);
     w.priorA_buf[0] = (double*)(b + o_pA); w.priorb_buf[0] = (double*)(b + o_pb); w.priorA_buf[1] = (double*)(b + o_pA2); w.priorb_buf[1] = (double*)(b + o_pb2);
     w.prior_cur = 0; w.priorA = w.priorA_buf[0]; w.priorb = w.priorb_buf[0]; w.prior_resident = false;
-    w.marg_tab = (int32_t*)(b + o_mt); w.marg_scal = (double*)(b + o_ms);
+    w.marg_tab = (int32_t*)(b + o_mt); w.marg_scal = (double*)(b + o_ms); w.prior_c0 = (double*)(b + o_c0);
     w.packets = (double*)(b + o_pk); w.imu_out = (double*)(b + o_io); w.prior_out = (double*)(b + o_po); w.cand_cost = (double*)(b + o_cc);
     w.Hd = (double*)(b + o_hd); w.Sc = (double*)(b + o_sc); w.gvec = (double*)(b + o_g);
     double* v = (double*)(b + o_v); w.scale_p = v; w.diag_p = v + n; w.grad_p = v + 2 * n; w.gn_p = v + 3 * n;
@@ -47,6 +47,7 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
         w.pinned_bytes = need;
     }
     w.dl_off = upload_bytes;
+    if (!w.ev_state) DV_CHECK(hipEventCreateWithFlags(&w.ev_state, hipEventDisableTiming));
     w.ready = true;
     return 0;
 }
@@ -146,14 +147,14 @@ static int marg_plan(dv_ctx* ctx, MargPlan& pl, int mode, const dv_ba_prior* pri
 }
 
 // launches the three kernels; the index tables must already be (enqueued to be) in w.marg_tab
-static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, hipStream_t s) {
+static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, double* c0_out, hipStream_t s) {
     BeWork& w = ctx->be;
     BeMargArgs ma{};
     ma.x = x; ma.nframes = BE_NF; ma.nlm = pl.nsel; ma.nimu = pl.nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
     ma.prior = w.prior; ma.priorA = priorA; ma.priorb = priorb;
     ma.prior_map = w.marg_tab + BE_MT_PRIOR; ma.imu_map = w.marg_tab + BE_MT_IMU; ma.dim_slot = w.marg_tab + BE_MT_SLOT; ma.dim_comp = w.marg_tab + BE_MT_COMP;
     ma.lm_sel = w.marg_tab + BE_MT_SEL;
-    ma.D = pl.D; ma.m = pl.m; ma.g_norm = g_norm; ma.outA = outA; ma.outb = outb; ma.out_scalars = scal;
+    ma.D = pl.D; ma.m = pl.m; ma.g_norm = g_norm; ma.outA = outA; ma.outb = outb; ma.out_scalars = scal; ma.c0_out = c0_out;
     const size_t slab = (size_t)pl.D * pl.D + pl.D;
     // sized once for 256 landmarks anchored in the oldest frame at the largest system (D = 178): growing it later would stall the stream
     const size_t need = 8 * (slab * (size_t)std::max(pl.nsel, 1) + slab + (size_t)std::max(pl.nsel, 1));
@@ -207,6 +208,9 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, hipStream_t s
 }
 
 // gauge fix + marginalization + download, enqueued behind the slots on the same stream (no host round trip)
+// gauge fix + download of the states (event) + marginalization, enqueued behind the slots on the same stream: the host
+// waits only for the event, so the marginalization of frame k overlaps the host's turnaround and the upload of frame k+1;
+// whatever reads its result (the next solve) is ordered behind it on the stream.
 static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
     BeWork& w = ctx->be;
     uint8_t* hp = (uint8_t*)w.pinned;
@@ -215,14 +219,27 @@ static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
         ga.x = w.x; ga.out = w.cand; ga.nlm = pd.nlm; ga.nframes = pd.nframes; ga.use_imu = pd.use_imu;
         std::memcpy(ga.R0, pd.gauge_R0, sizeof(ga.R0)); std::memcpy(ga.ypr0, pd.gauge_ypr0, sizeof(ga.ypr0)); std::memcpy(ga.P0, pd.gauge_P0, sizeof(ga.P0));
         be_launch_gauge(ga, s);
-        if (pd.do_marg && !pd.pl.empty && marg_enqueue(ctx, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], w.marg_scal, s)) return -1;
     }
     DV_CHECK(hipGetLastError());
     BeState* hx = (BeState*)(hp + w.dl_off); BeCtl* hctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState));
-    double* hscal = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl));
     DV_CHECK(hipMemcpyAsync(hx, pd.fused_present ? w.cand : w.x, pd.state_bytes, hipMemcpyDeviceToHost, s));      // estimator path: the gauge-fixed copy
     DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
-    if (pd.do_marg && !pd.pl.empty) DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipEventRecord(w.ev_state, s));
+    if (pd.fused_present && pd.do_marg && !pd.pl.empty) {
+        if (marg_enqueue(ctx, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], w.marg_scal, w.prior_c0 + pd.nxt, s)) return -1;
+        double* hscal = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl)) + 4 * pd.scal_slot;      // two alternating host slots
+        DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, s));
+        pd.marg_in_flight = true;
+    }
+    return 0;
+}
+
+// the marginalization enqueued by the PREVIOUS frame reports its health here (its 4 scalars were downloaded behind it)
+static int be_check_prev_marg(dv_ctx* ctx, BePending& pd) {
+    if (!pd.marg_check_due) return 0;
+    pd.marg_check_due = false;
+    const double* hscal = (const double*)((uint8_t*)ctx->be.pinned + ctx->be.dl_off + sizeof(BeState) + sizeof(BeCtl)) + 4 * pd.check_slot;
+    if (hscal[2] != 0.0) DV_FAIL("dv_marginalize: A_mm is not positive definite (reference would take its pseudo-inverse)");
     return 0;
 }
 
@@ -309,6 +326,8 @@ int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
         if (!P->prior_A || !P->prior_b) DV_FAIL("dv_ba_solve: prior without A / b");
         DV_CHECK(hipMemcpyAsync(w.priorA_buf[w.prior_cur], P->prior_A, 8 * (size_t)ph.n * ph.n, hipMemcpyHostToDevice, s));
         DV_CHECK(hipMemcpyAsync(w.priorb_buf[w.prior_cur], P->prior_b, 8 * (size_t)ph.n, hipMemcpyHostToDevice, s));
+        double* hc0 = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 128); *hc0 = ph.c0;
+        DV_CHECK(hipMemcpyAsync(w.prior_c0 + w.prior_cur, hc0, 8, hipMemcpyHostToDevice, s));
         w.prior_resident = false;
     }
     w.priorA = w.priorA_buf[w.prior_cur]; w.priorb = w.priorb_buf[w.prior_cur];
@@ -316,7 +335,7 @@ int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
     // ---- schedule ----
     BeEvalArgs ea{};
     ea.ctl = w.ctl; ea.x = w.x; ea.cand = w.cand; ea.fac = w.fac; ea.lm = w.lm; ea.imu = w.imu; ea.prior = w.prior; ea.priorA = w.priorA; ea.priorb = w.priorb;
-    ea.dims = d; ea.g_norm = P->g_norm; ea.packets = w.packets; ea.imu_out = w.imu_out; ea.prior_out = w.prior_out; ea.cand_cost = w.cand_cost;
+    ea.dims = d; ea.g_norm = P->g_norm; ea.packets = w.packets; ea.imu_out = w.imu_out; ea.prior_out = w.prior_out; ea.cand_cost = w.cand_cost; ea.prior_c0 = w.prior_c0 + w.prior_cur;
     BeSolveArgs sa{};
     sa.ctl = w.ctl; sa.x = w.x; sa.cand = w.cand; sa.lm = w.lm; sa.imu = w.imu; sa.prior = w.prior; sa.priorA = w.priorA; sa.dims = d;
     sa.packets = w.packets; sa.imu_out = w.imu_out; sa.prior_out = w.prior_out; sa.cand_cost = w.cand_cost; sa.Hd = w.Hd; sa.Sc = w.Sc; sa.gvec = w.gvec;
@@ -351,15 +370,18 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     const MargPlan& pl = pd.pl;
     uint8_t* hp = (uint8_t*)w.pinned;
     const BeState* hx = (const BeState*)(hp + w.dl_off); const BeCtl* hctl = (const BeCtl*)(hp + w.dl_off + sizeof(BeState));
-    const double* hscal = (const double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl));
-    DV_CHECK(hipStreamSynchronize(s));
+    DV_CHECK(hipEventSynchronize(w.ev_state));
+    // the previous frame's marginalization ran before this frame's upload (stream order), so its scalars have landed
+    if (be_check_prev_marg(ctx, pd)) return -1;
     if (!hctl->done) {        // rare: a failed linear solve / invalid step used up slots -> the 3 spare slots, then the tail once more
         // (the raw solution is still in w.x: the gauge fix writes to the candidate buffer; the marginalization reads the untouched old prior)
         if (be_enqueue_slots(ctx, pd, 3, s)) return -1;
         if (be_enqueue_tail(ctx, pd, s)) return -1;
-        DV_CHECK(hipStreamSynchronize(s));
+        DV_CHECK(hipEventSynchronize(w.ev_state));
     }
+    if (pd.marg_in_flight) { pd.marg_in_flight = false; pd.marg_check_due = true; pd.check_slot = pd.scal_slot; pd.scal_slot ^= 1; }
     if (ctx->timing) {
+        DV_CHECK(hipStreamSynchronize(s));         // measurement mode only: the timers are harvested from an idle stream
         StageTimer* te = dv_timer_for(ctx, "h_solve_enqueue"); te->total_ms += std::chrono::duration<double, std::milli>(pd.t_enq - pd.t_up).count(); te->count++;
         StageTimer* tu = dv_timer_for(ctx, "h_solve_upload"); tu->total_ms += std::chrono::duration<double, std::milli>(pd.t_up - pd.t_begin).count(); tu->count++;
         dv_harvest_timers(ctx, s);
@@ -371,11 +393,11 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
         summary->slots = hctl->slots; summary->initial_cost = hctl->initial_cost; summary->final_cost = hctl->x_cost;
     }
     if (pd.do_marg) {
-        if (pl.empty) { std::memset(&fused->new_prior, 0, sizeof(fused->new_prior)); std::memset(fused->diag, 0, sizeof(fused->diag)); w.prior_resident = false; }
+        std::memset(fused->diag, 0, sizeof(fused->diag));
+        if (pl.empty) { std::memset(&fused->new_prior, 0, sizeof(fused->new_prior)); w.prior_resident = false; }
         else {
-            std::memcpy(fused->diag, hscal, 32);
-            if (hscal[2] != 0.0) DV_FAIL("dv_marginalize: A_mm is not positive definite (reference would take its pseudo-inverse)");
-            marg_new_prior(pl, P->pose, P->speed_bias, P->ex_pose, P->td, hscal[0], &fused->new_prior);      // x0 = the gauge-fixed states just downloaded
+            // header only: A', b' and c0 are (being) written in HBM by the marginalization kernels still in flight
+            marg_new_prior(pl, P->pose, P->speed_bias, P->ex_pose, P->td, std::nan(""), &fused->new_prior);      // x0 = the gauge-fixed states just downloaded
             w.prior_cur = pd.nxt; w.prior_resident = true;
             w.priorA = w.priorA_buf[pd.nxt]; w.priorb = w.priorb_buf[pd.nxt];
         }
@@ -437,7 +459,7 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
         w.prior_resident = false;
     }
     double* d_outA = w.Sc; double* d_outb = w.gvec; double* d_scal = w.marg_scal;      // Sc / gvec are idle outside a solve
-    if (marg_enqueue(ctx, pl, w.x, P->g_norm, w.priorA_buf[w.prior_cur], w.priorb_buf[w.prior_cur], d_outA, d_outb, d_scal, s)) return -1;
+    if (marg_enqueue(ctx, pl, w.x, P->g_norm, w.priorA_buf[w.prior_cur], w.priorb_buf[w.prior_cur], d_outA, d_outb, d_scal, nullptr, s)) return -1;
     DV_CHECK(hipGetLastError());
     double scal[4];
     DV_CHECK(hipMemcpyAsync(out_A, d_outA, 8 * (size_t)n * n, hipMemcpyDeviceToHost, s));

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
         if (lane == 0) {
             double bd = 0, dAd = 0;
             for (int i = 0; i < n; ++i) { bd += a.priorb[i] * dx[i]; dAd += dx[i] * Adx[i]; }
-            const double cost = 0.5 * p->c0 + bd + 0.5 * dAd;
+            const double cost = 0.5 * a.prior_c0[0] + bd + 0.5 * dAd;
             if (FULL) a.prior_out[0] = cost; else a.cand_cost[b] = cost;
         }
         if (FULL) for (int i = lane; i < n; i += EV_THREADS) a.prior_out[1 + i] = a.priorb[i] + Adx[i];

@@ -14,6 +14,8 @@ struct BeEvalArgs {
     double* imu_out;        // [nimu][936]: cost, g[30], H[30][30]
     double* prior_out;      // cost, g[n_prior]
     double* cand_cost;      // [nlm + nimu + 1]                    written by the cost-only evaluation at cand
+    const double* prior_c0; // the prior's constant r0^T r0, device resident (the marginalization of the previous frame may still be writing it
+                            // when this solve is being prepared on the host)
 };
 
 struct BeSolveArgs {
@@ -42,6 +44,7 @@ struct BeMargArgs {
     int D, m; double g_norm;
     double* outA; double* outb; double* out_scalars;     // n x n, n, {c0, min pivot, failure flag, rank}
     double* slabs; double* sum; double* lm_h;            // [nlm][D*D+D] per-landmark contributions, their sum, per-landmark h
+    double* c0_out;               // optional second home of c0 (the device-resident prior of the estimator)
     const int32_t* lm_sel;        // optional: landmark b of the launch is lm[lm_sel[b]] (marginalization straight out of the solved window)
 };
 

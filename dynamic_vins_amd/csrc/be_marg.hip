@@ -237,7 +237,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         }
         __syncthreads();
     }
-    if (tid == 0) { a.out_scalars[0] = c0; a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; a.out_scalars[3] = (double)rank; }
+    if (tid == 0) { a.out_scalars[0] = c0; a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; a.out_scalars[3] = (double)rank; if (a.c0_out) a.c0_out[0] = c0; }
 }
 
 // ---------------------------------------------------------------------------------------------

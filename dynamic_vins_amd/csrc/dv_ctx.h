@@ -74,7 +74,7 @@ struct MargPlan {
 };
 
 struct BePending {        // a solve that has been enqueued and not yet collected (be_solve_fused_begin / _end)
-    bool active = false, trivial = false, do_marg = false, fused_present = false; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
+    bool active = false, trivial = false, do_marg = false, fused_present = false, marg_in_flight = false, marg_check_due = false; int scal_slot = 0, check_slot = 0; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
     BeEvalArgs ea; BeSolveArgs sa; int max_iters = 0, nframes = 0, use_imu = 0, nlm = 0; double g_norm = 0, gauge_R0[9], gauge_ypr0[3], gauge_P0[3];
     std::chrono::steady_clock::time_point t_begin, t_up, t_enq;
 };
@@ -96,6 +96,8 @@ struct BeWork {
     size_t up_ctl = 0, up_x = 0, up_imu = 0, up_prior = 0, up_idx = 0, up_mt = 0, up_lm = 0, up_fac = 0, dl_off = 0;
     double* priorA_buf[2] = { nullptr, nullptr }; double* priorb_buf[2] = { nullptr, nullptr }; int prior_cur = 0;      // double-buffered prior (A', b')
     bool prior_resident = false;      // true: buffer prior_cur holds the estimator's current prior (written by the fused marginalization)
+    hipEvent_t ev_state = nullptr;    // recorded behind the download of the solved states (the marginalization runs on past it)
+    double* prior_c0 = nullptr;       // [2] the prior's constant c0 per buffer, device resident
     int32_t* marg_tab = nullptr; double* marg_scal = nullptr;      // marginalization index tables (inside the upload region) and its 4 result scalars
     std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
 };

@@ -127,6 +127,55 @@ def marginalize(ctx, sub: WindowProblem, mode):
     return out, A[:n * n].reshape(n, n).copy(), b[:n].copy(), diag
 
 
+LINE_DTYPE = np.dtype([("obs", "f8", 4), ("sqrt_info", "f8", 4)])
+BOXPT_DTYPE = np.dtype([("pts_w", "f8", 3), ("dims", "f8", 3)])
+
+
+def _chk(ctx, rc):
+    if rc != 0:
+        raise DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+
+
+def line_eval(ctx, factors, pose, ex_pose, orth):
+    """lineProjectionFactor::Evaluate for n blocks -> (r[n,2], J_pose[n,2,6], J_ex[n,2,6], J_orth[n,2,4])"""
+    n = len(factors)
+    f = np.ascontiguousarray(factors, LINE_DTYPE)
+    a = [np.ascontiguousarray(x, np.float64) for x in (pose, ex_pose, orth)]
+    out = np.zeros((n, 34))
+    _chk(ctx, ctx.lib.dv_line_eval(ctx.h, f.ctypes.data, n, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, out.ctypes.data))
+    return out[:, :2], out[:, 2:14].reshape(n, 2, 6), out[:, 14:26].reshape(n, 2, 6), out[:, 26:34].reshape(n, 2, 4)
+
+
+def line_plus(ctx, orth, delta):
+    a, d = np.ascontiguousarray(orth, np.float64), np.ascontiguousarray(delta, np.float64)
+    out = np.zeros_like(a)
+    _chk(ctx, ctx.lib.dv_line_plus(ctx.h, a.ctypes.data, d.ctypes.data, len(a), out.ctypes.data))
+    return out
+
+
+def box_enclose_eval(ctx, points, pose_obj):
+    n = len(points)
+    f, p = np.ascontiguousarray(points, BOXPT_DTYPE), np.ascontiguousarray(pose_obj, np.float64)
+    out = np.zeros((n, 21))
+    _chk(ctx, ctx.lib.dv_box_enclose_eval(ctx.h, f.ctypes.data, n, p.ctypes.data, out.ctypes.data))
+    return out[:, :3], out[:, 3:].reshape(n, 3, 6)
+
+
+def box_dims_eval(ctx, dims, box):
+    d, b = np.ascontiguousarray(dims, np.float64), np.ascontiguousarray(box, np.float64)
+    out = np.zeros((len(d), 4))
+    _chk(ctx, ctx.lib.dv_box_dims_eval(ctx.h, d.ctypes.data, b.ctypes.data, len(d), out.ctypes.data))
+    return out[:, 0], out[:, 1:]
+
+
+def box_orientation_eval(ctx, R_cioi, R_bc, pose_body, pose_obj):
+    a = [np.ascontiguousarray(x, np.float64) for x in (R_cioi, R_bc, pose_body, pose_obj)]
+    n = len(a[2])
+    out = np.zeros((n, 39))
+    _chk(ctx, ctx.lib.dv_box_orientation_eval(ctx.h, a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, n, out.ctypes.data))
+    return out[:, :3], out[:, 3:21].reshape(n, 3, 6), out[:, 21:].reshape(n, 3, 6)
+
+
 class dv_est_config(C.Structure):
     _fields_ = [("use_imu", C.c_int32), ("stereo", C.c_int32), ("plane_constraint", C.c_int32), ("max_iters", C.c_int32),
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),

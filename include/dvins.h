@@ -181,6 +181,29 @@ int dv_proj_eval(dv_ctx* ctx, const dv_ba_factor* factors, int n, const double* 
 int dv_imu_eval(dv_ctx* ctx, const dv_ba_imu* imu, double g_norm, const double* pose_i, const double* sb_i,
                 const double* pose_j, const double* sb_j, double* out);
 
+/* ---- line and dynamic-object factors: residual + Jacobians, one record per residual block.
+ * Jacobians are returned in LOCAL sizes, row-major (pose blocks 6 wide: the reference's 7th column is always zero).
+ * Bug-for-bug with the reference where its Jacobian is not the derivative of its residual (see be_obj.hip). ---- */
+typedef struct dv_line_factor {          /* lineProjectionFactor(obs_i) + its static sqrt_info (line_projection_factor.h) */
+    double obs[4];                       /* the two observed endpoints on the normalised plane: x1 y1 x2 y2 */
+    double sqrt_info[4];                 /* 2x2 row-major; NOTE the reference never assigns it (zero) — SURVEY 0.6 */
+} dv_line_factor;
+/* out[n][34] = r[2] | d r / d pose (2x6) | d r / d ex_pose (2x6) | d r / d orth (2x4)
+ * (lineProjectionFactor::Evaluate, estimator/factor/line_projection_factor.cpp:24-159) */
+int dv_line_eval(dv_ctx* ctx, const dv_line_factor* factors, int n, const double* pose /* n x 7 */, const double* ex_pose /* n x 7 */,
+                 const double* orth /* n x 4 */, double* out);
+/* LineOrthParameterization::Plus (estimator/factor/line_parameterization.cpp:9-72): out[n][4] = orth (+) delta */
+int dv_line_plus(dv_ctx* ctx, const double* orth, const double* delta, int n, double* out);
+
+typedef struct dv_box_point { double pts_w[3]; double dims[3]; } dv_box_point;      /* BoxEncloseStereoPointFactor(point_w, dims) */
+/* out[n][21] = r[3] | d r / d pose_obj (3x6)   (estimator/factor/box_factor.cpp:523-565) */
+int dv_box_enclose_eval(dv_ctx* ctx, const dv_box_point* points, int n, const double* pose_obj /* n x 7 */, double* out);
+/* out[n][4] = r | d r / d box (1x3)            (BoxDimsFactor, box_factor.cpp:728-743) */
+int dv_box_dims_eval(dv_ctx* ctx, const double* dims /* n x 3 */, const double* box /* n x 3 */, int n, double* out);
+/* out[n][39] = r[3] | d r / d pose_body (3x6, zero) | d r / d pose_obj (3x6)   (BoxOrientationFactor, box_factor.cpp:752-806) */
+int dv_box_orientation_eval(dv_ctx* ctx, const double* R_cioi /* n x 9 */, const double* R_bc /* n x 9 */, const double* pose_body /* n x 7 */,
+                            const double* pose_obj /* n x 7 */, int n, double* out);
+
 /* ---- Estimator (estimator/estimator.h:55-164): IMU buffer + one ProcessMeasurements iteration per call ---- */
 typedef struct dv_est_config {          /* para (estimator/vio_parameters.cpp:19-83), cfg flags, extrinsics (utils/parameters.cpp) */
     int32_t use_imu, stereo, plane_constraint, max_iters;      /* imu, num_of_cam==2, plane_constraint, max_num_iterations */

@@ -112,6 +112,13 @@ void dvo_preint_set(dvo_preint*, double sum_dt, const double* dp, const double* 
 /* IMUFactor::Evaluate; par = pose_i(7) sb_i(9) pose_j(7) sb_j(9); J = 15x7,15x9,15x7,15x9 row-major */
 void dvo_imu_eval(const dvo_preint*, double g_norm, const double* const* par, double* res15, double** J);
 
+/* line and dynamic-object factors (obj_factors.cpp); Jacobians in the reference's global block sizes, row-major, any J[k] may be NULL */
+void dvo_line_eval(const double* obs4, const double* sqrt_info4, const double* const* par /* pose7, ex7, orth4 */, double* res2, double** J /* 2x7, 2x7, 2x4 */);
+void dvo_line_plus(const double* orth4, const double* delta4, double* out4);      /* LineOrthParameterization::Plus */
+void dvo_box_enclose_eval(const double* pts_w3, const double* dims3, const double* const* par /* pose_obj7 */, double* res3, double** J /* 3x7 */);
+void dvo_box_dims_eval(const double* dims3, const double* const* par /* box3 */, double* res1, double** J /* 1x3 */);
+void dvo_box_orientation_eval(const double* R_cioi9, const double* R_bc9, const double* const* par /* pose_body7, pose_obj7 */, double* res3, double** J /* 3x7, 3x7 */);
+
 /* flat window problem, identical layout to include/dvins.h dv_ba_* (restated here: the oracle shares no headers
  * with the product) */
 typedef struct dvo_ba_factor { double pix, piy, pjx, pjy, vix, viy, vjx, vjy, td_i, td_j; int32_t kind, lm, fi, fj; double pad_[2]; } dvo_ba_factor;

@@ -1,0 +1,123 @@
+"""Line and dynamic-object factors.
+CPU (-m "not gpu"): the oracle restatement against central differences where the reference's Jacobian IS the derivative
+(line factor, through PoseLocalParameterization::Plus and LineOrthParameterization::Plus), against independent numpy /
+scipy restatements of the residuals, and the documented bug-for-bug deviations where it is NOT (I1-I3).
+GPU (-m gpu): the HIP operators (dv_line_eval, dv_line_plus, dv_box_*_eval) against the oracle, 1e-9."""
+import numpy as np
+import pytest
+from scipy.spatial.transform import Rotation
+
+from tests import obj_gen as G
+
+
+def test_line_factor_jacobians_are_the_derivative(oracle):
+    lib = oracle.lib
+    d = G.make_batch(3, 12)
+    eps = 1e-6
+    for k in range(12):
+        si = np.array([300.0, 0, 0, 300.0]) if not d["sqrt_info"][k].any() else d["sqrt_info"][k]
+        args = (d["obs"][k], si, d["pose"][k], d["ex"][k], d["orth"][k])
+        r, J = G.o_line(lib, *args)
+        assert (J[0][:, 6] == 0).all() and (J[1][:, 6] == 0).all()
+        for c in range(6):
+            dd = np.zeros(6); dd[c] = eps
+            num = (G.o_line(lib, args[0], si, G.pose_plus(args[2], dd), args[3], args[4])[0] - G.o_line(lib, args[0], si, G.pose_plus(args[2], -dd), args[3], args[4])[0]) / (2 * eps)
+            assert np.allclose(J[0][:, c], num, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(num).max()))
+            num = (G.o_line(lib, args[0], si, args[2], G.pose_plus(args[3], dd), args[4])[0] - G.o_line(lib, args[0], si, args[2], G.pose_plus(args[3], -dd), args[4])[0]) / (2 * eps)
+            assert np.allclose(J[1][:, c], num, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(num).max()))
+        for c in range(4):
+            dd = np.zeros(4); dd[c] = eps
+            num = (G.o_line(lib, args[0], si, args[2], args[3], G.o_line_plus(lib, args[4], dd))[0] - G.o_line(lib, args[0], si, args[2], args[3], G.o_line_plus(lib, args[4], -dd))[0]) / (2 * eps)
+            assert np.allclose(J[2][:, c], num, rtol=1e-5, atol=1e-4 * max(1.0, np.abs(num).max()))
+
+
+def test_line_residual_is_point_to_line_distance(oracle):
+    """independent restatement: Plücker line -> camera frame with 4x4 transforms, distance of both endpoints to the projected line"""
+    lib = oracle.lib
+    d = G.make_batch(4, 8)
+    for k in range(8):
+        o = d["orth"][k]
+        U = Rotation.from_euler("ZYX", [o[2], o[1], o[0]]).as_matrix()       # R = Rz(t3) Ry(t2) Rx(t1): the matrix of orth_to_plk
+        n_w, v_w = np.cos(o[3]) * U[:, 0], np.sin(o[3]) * U[:, 1]
+        Rwb, twb = G._qR(d["pose"][k][3:]), d["pose"][k][:3]
+        Rbc, tbc = G._qR(d["ex"][k][3:]), d["ex"][k][:3]
+        Rwc, twc = Rwb @ Rbc, Rwb @ tbc + twb
+        # a point on the line and its direction, moved rigidly into the camera frame
+        p_w = np.cross(v_w, n_w) / (v_w @ v_w)
+        p_c, v_c = Rwc.T @ (p_w - twc), Rwc.T @ v_w
+        n_c = np.cross(p_c, v_c)
+        ln = n_c / np.hypot(n_c[0], n_c[1])
+        exp = np.array([ln @ [d["obs"][k][0], d["obs"][k][1], 1.0], ln @ [d["obs"][k][2], d["obs"][k][3], 1.0]])
+        r, _ = G.o_line(lib, d["obs"][k], np.array([1.0, 0, 0, 1.0]), d["pose"][k], d["ex"][k], o)
+        assert np.allclose(r, exp, rtol=1e-9, atol=1e-10)
+        r0, J0 = G.o_line(lib, d["obs"][k], np.zeros(4), d["pose"][k], d["ex"][k], o)        # the reference's zero weight: everything vanishes
+        assert not r0.any() and not any(j.any() for j in J0)
+
+
+def test_line_plus_is_a_retraction(oracle):
+    lib = oracle.lib
+    d = G.make_batch(5, 10)
+    for k in range(10):
+        assert np.allclose(G.o_line_plus(lib, d["orth"][k], np.zeros(4)), d["orth"][k], atol=1e-12)
+        up = G.o_line_plus(lib, d["orth"][k], d["delta"][k])
+        U0 = Rotation.from_euler("ZYX", [d["orth"][k][2], d["orth"][k][1], d["orth"][k][0]]).as_matrix()
+        dl = d["delta"][k]
+        U1 = U0 @ Rotation.from_euler("x", dl[0]).as_matrix() @ Rotation.from_euler("y", dl[1]).as_matrix() @ Rotation.from_euler("z", dl[2]).as_matrix()
+        got = Rotation.from_euler("ZYX", [up[2], up[1], up[0]]).as_matrix()
+        assert np.allclose(got, U1, atol=1e-12)
+        assert abs(up[3] - (d["orth"][k][3] + dl[3])) < 1e-12        # phi' = asin(sin(phi + dphi)) while phi + dphi stays in (-pi/2, pi/2)
+
+
+def test_box_factors_residuals_and_documented_jacobians(oracle):
+    lib = oracle.lib
+    d = G.make_batch(6, 16)
+    for k in range(16):
+        # I1: residual = 10 max(0, |R^T (p - P)| - dims / 2)
+        r, J = G.o_box_enclose(lib, d["pts_w"][k], d["dims"][k], d["pose_obj"][k])
+        po = G._qR(d["pose_obj"][k][3:]).T @ (d["pts_w"][k] - d["pose_obj"][k][:3])
+        assert np.allclose(r, np.maximum(0, 10 * (np.abs(po) - d["dims"][k] / 2)), atol=1e-12)
+        e = G._qR(d["pose_obj"][k][3:]).T @ (po - d["pose_obj"][k][:3])          # sic: the reference feeds the OBJECT-frame point back in
+        assert np.allclose(J[0][:, :3], np.sign(e)[:, None] * G._qR(d["pose_obj"][k][3:]).T, atol=1e-12) and not J[0][:, 3:].any()
+        # I2: r = |box - dims|^4 / 100, J = 2 (box - dims)^T  (not its derivative — kept)
+        r, J = G.o_box_dims(lib, d["dims"][k], d["box"][k])
+        diff = d["box"][k] - d["dims"][k]
+        assert np.allclose(r, (diff @ diff) ** 2 / 100) and np.allclose(J[0][0], 2 * diff)
+        # I3: r = Log(R_oiw R_wbi R_bc R_cioi); camera-pose Jacobian zero; object Jacobian only in the rotation columns
+        r, J = G.o_box_orientation(lib, d["R_cioi"][k], d["R_bc"][k], d["pose_body"][k], d["pose_obj"][k])
+        R = G._qR(d["pose_obj"][k][3:]).T @ G._qR(d["pose_body"][k][3:]) @ d["R_bc"][k].reshape(3, 3) @ d["R_cioi"][k].reshape(3, 3)
+        assert np.allclose(Rotation.from_rotvec(r).as_matrix(), R, atol=1e-9)
+        assert not J[0].any() and not J[1][:, :3].any() and not J[1][:, 6].any() and J[1][:, 3:6].any()
+
+
+@pytest.mark.gpu
+def test_hip_object_factors_match_oracle(gpu_ctx_factory, oracle):
+    from dynamic_vins_amd import backend as B
+    ctx = gpu_ctx_factory(width=64, height=48)
+    lib = oracle.lib
+    n = 150
+    d = G.make_batch(11, n)
+    fac = np.zeros(n, B.LINE_DTYPE); fac["obs"] = d["obs"]; fac["sqrt_info"] = d["sqrt_info"]
+    r, Jp, Je, Jo = B.line_eval(ctx, fac, d["pose"], d["ex"], d["orth"])
+    up = B.line_plus(ctx, d["orth"], d["delta"])
+    pts = np.zeros(n, B.BOXPT_DTYPE); pts["pts_w"] = d["pts_w"]; pts["dims"] = d["dims"]
+    rb, Jb = B.box_enclose_eval(ctx, pts, d["pose_obj"])
+    rd, Jd = B.box_dims_eval(ctx, d["dims"], d["box"])
+    ro, Job, Joo = B.box_orientation_eval(ctx, d["R_cioi"], d["R_bc"], d["pose_body"], d["pose_obj"])
+    tol = dict(rtol=1e-9, atol=1e-9)
+    for k in range(n):
+        er, eJ = G.o_line(lib, d["obs"][k], d["sqrt_info"][k], d["pose"][k], d["ex"][k], d["orth"][k])
+        sc = max(1.0, np.abs(eJ[0]).max(), np.abs(eJ[1]).max(), np.abs(eJ[2]).max())
+        assert np.allclose(r[k], er, rtol=1e-9, atol=1e-9 * sc)
+        assert np.allclose(Jp[k], eJ[0][:, :6], rtol=1e-9, atol=1e-9 * sc) and np.allclose(Je[k], eJ[1][:, :6], rtol=1e-9, atol=1e-9 * sc)
+        assert np.allclose(Jo[k], eJ[2], rtol=1e-9, atol=1e-9 * sc)
+        assert np.allclose(up[k], G.o_line_plus(lib, d["orth"][k], d["delta"][k]), **tol)
+        er, eJ = G.o_box_enclose(lib, d["pts_w"][k], d["dims"][k], d["pose_obj"][k])
+        assert np.allclose(rb[k], er, **tol) and np.allclose(Jb[k], eJ[0][:, :6], **tol)
+        er, eJ = G.o_box_dims(lib, d["dims"][k], d["box"][k])
+        assert np.allclose(rd[k], er[0], **tol) and np.allclose(Jd[k], eJ[0][0], **tol)
+        er, eJ = G.o_box_orientation(lib, d["R_cioi"][k], d["R_bc"][k], d["pose_body"][k], d["pose_obj"][k])
+        assert np.allclose(ro[k], er, **tol) and np.allclose(Job[k], eJ[0][:, :6], **tol) and np.allclose(Joo[k], eJ[1][:, :6], rtol=1e-8, atol=1e-8)
+    # empty / bad input is an error, not a crash
+    from dynamic_vins_amd._abi import DvinsError
+    with pytest.raises(DvinsError):
+        B.line_eval(ctx, fac[:0], d["pose"][:0], d["ex"][:0], d["orth"][:0])

@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVINS_HIP_LIB") or os.path.join(_HERE, "lib", "libdvins_hip.so")
 
 DV_MEM_HOST, DV_MEM_DEVICE = 0, 1
-DV_MODE_RAW, DV_MODE_NAIVE = 0, 1
+DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC = 0, 1, 2
 DV_MAX_FEATS = 1024
 
 
@@ -25,7 +25,7 @@ class dv_cam(C.Structure):
 class dv_config(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("max_cnt", C.c_int), ("min_dist", C.c_int),
                 ("flow_back", C.c_int), ("stereo", C.c_int), ("cam0", dv_cam), ("cam1", dv_cam),
-                ("device", C.c_int), ("reserved", C.c_int * 7)]
+                ("device", C.c_int), ("mask_morphology_size", C.c_int), ("reserved", C.c_int * 6)]
 
 
 class dv_feat(C.Structure):

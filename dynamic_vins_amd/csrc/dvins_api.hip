@@ -193,7 +193,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     if (!gray0) DV_FAIL("dv_track_stereo: gray0 is null");
     if (w != ctx->cfg.width || h != ctx->cfg.height) DV_FAIL("dv_track_stereo: image size differs from config (reference: std::terminate, main.cpp:95-99)");
     if (ctx->pending) DV_FAIL("dv_track_stereo_enqueue: previous frame not collected");
-    if (mode != DV_MODE_RAW && mode != DV_MODE_NAIVE) DV_FAIL("dv_track_stereo: unknown mode");
+    if (mode != DV_MODE_RAW && mode != DV_MODE_NAIVE && mode != DV_MODE_SEMANTIC) DV_FAIL("dv_track_stereo: unknown mode");
     DV_CHECK(hipSetDevice(ctx->cfg.device));
     const dv_config& c = ctx->cfg;
     const bool stereo = c.stereo && gray1;
@@ -218,11 +218,19 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
             mask_dev = (const uint8_t*)ctx->mask_buf.p;
         }
     }
-    const bool naive = (mode == DV_MODE_NAIVE);
-    const float dist_thresh = naive ? 1.0f : 0.5f;       // feature_utils.cpp:126 vs :56 (Q12)
+    const bool naive = (mode != DV_MODE_RAW);            // naive and semantic share the InstFeat code path (mask test, no sort, >= 10 new)
+    if (naive && mask_dev && c.mask_morphology_size > 0) {       // ErodeMask (background_tracker.cpp:408-416,764-768)
+        const int ep = align_up(w, 16);
+        DV_CHECK(ctx->s3.ensure((size_t)ep * h)); DV_CHECK(ctx->s4.ensure((size_t)ep * h));
+        dv_launch_erode(mask_dev, w, h, mask_pitch, c.mask_morphology_size, (uint8_t*)ctx->s3.p, ep, (uint8_t*)ctx->s4.p, ep, s);
+        mask_dev = (const uint8_t*)ctx->s4.p; mask_pitch = ep;
+    }
+    // forward/backward consistency: FeatureTrackByLK keeps <= 0.5 px (feature_utils.cpp:56), FeatureTrackByLKGpu <= 1.0 px (:126) (Q12)
+    const float dist_temporal = (mode == DV_MODE_NAIVE) ? 1.0f : 0.5f;       // TrackLeftGPU (naive) vs TrackLeft (raw, semantic)
+    const float dist_stereo = (mode == DV_MODE_RAW) ? 0.5f : 1.0f;           // TrackRightGPU in naive and semantic
     if (ctx->have_prev) {
         StageScope sc(ctx, "lk_temporal");
-        dv_launch_lk_track(Lp.pyr, L.pyr, ctx->tr.last_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_thresh, ctx->tr.lk_pts,
+        dv_launch_lk_track(Lp.pyr, L.pyr, ctx->tr.last_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_temporal, ctx->tr.lk_pts,
                            ctx->tr.lk_status, s);
     }
     {
@@ -252,7 +260,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     }
     if (stereo) {
         StageScope sc(ctx, "lk_stereo");
-        dv_launch_lk_track(L.pyr, ctx->right.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_thresh,
+        dv_launch_lk_track(L.pyr, ctx->right.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_stereo,
                            ctx->tr.right_pts, ctx->tr.right_status, s);
     }
     {

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import DvinsError, dv_cam, dv_config, dv_feat, DV_MEM_HOST, DV_MEM_DEVICE, DV_MODE_RAW, DV_MODE_NAIVE
+from ._abi import DvinsError, dv_cam, dv_config, dv_feat, DV_MEM_HOST, DV_MEM_DEVICE, DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC
 
 FEAT_DTYPE = np.dtype([("id", np.uint32), ("track_cnt", np.int32), ("has_right", np.int32), ("pad_", np.int32),
                        ("left", np.float64, 7), ("right", np.float64, 7)])
@@ -30,11 +30,12 @@ def _ptr(a):
 class Context:
     """Owns a dv_ctx (device memory + stream).  One per thread, like the reference's FeatureTracker."""
 
-    def __init__(self, width, height, max_cnt=150, min_dist=30, flow_back=1, stereo=1, cam0=None, cam1=None, device=0):
+    def __init__(self, width, height, max_cnt=150, min_dist=30, flow_back=1, stereo=1, cam0=None, cam1=None, device=0, mask_morphology_size=0):
         self.lib = _abi.load()
         cfg = dv_config()
         cfg.width, cfg.height, cfg.max_cnt, cfg.min_dist = width, height, max_cnt, min_dist
         cfg.flow_back, cfg.stereo, cfg.device = flow_back, stereo, device
+        cfg.mask_morphology_size = mask_morphology_size
         cfg.cam0 = cam0 if cam0 is not None else make_cam(1, 1, 0, 0)
         cfg.cam1 = cam1 if cam1 is not None else cfg.cam0
         self.cfg = cfg
@@ -187,6 +188,12 @@ class FeatureTracker:
     def TrackImageNaive(self, gray0, gray1, time0, inv_merge_mask=None):
         self.cur_time = time0
         self.rows = self.ctx.track_stereo(gray0, gray1, time0, inv_merge_mask, DV_MODE_NAIVE)
+        return self._to_map(self.rows)
+
+    def TrackSemanticImage(self, gray0, gray1, time0, inv_merge_mask=None):
+        """background half of dynamic mode (background_tracker.cpp:757-837)"""
+        self.cur_time = time0
+        self.rows = self.ctx.track_stereo(gray0, gray1, time0, inv_merge_mask, DV_MODE_SEMANTIC)
         return self._to_map(self.rows)
 
     trackImage = TrackImage

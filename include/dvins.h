@@ -26,6 +26,8 @@ extern "C" {
 
 #define DV_MODE_RAW   0   /* FeatureTracker::TrackImage      (background_tracker.cpp:52-158)  */
 #define DV_MODE_NAIVE 1   /* FeatureTracker::TrackImageNaive (background_tracker.cpp:400-516) */
+#define DV_MODE_SEMANTIC 2 /* FeatureTracker::TrackSemanticImage (background_tracker.cpp:757-837): the background half of dynamic mode —
+                             temporal tracking by FeatureTrackByLK (dist <= 0.5), right image by the FeatureTrackByLKGpu rule (dist <= 1.0) */
 
 #define DV_MAX_FEATS 1024 /* device capacity for tracked points per tracker */
 
@@ -43,7 +45,9 @@ typedef struct dv_config {
     int stereo;             /* num_of_cam == 2 */
     dv_cam cam0, cam1;
     int device;             /* HIP device ordinal (LOCAL_RANK for one-process-per-GPU) */
-    int reserved[7];
+    int mask_morphology_size; /* > 0: the inverse instance mask is eroded by a k x k rectangle first (use_mask_morphology /
+                                 mask_morphology_size, background_tracker.cpp:408-416,764-768); naive / semantic modes only */
+    int reserved[6];
 } dv_config;
 
 /* One tracked feature = one entry of FeatureBackground::points

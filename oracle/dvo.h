@@ -90,6 +90,8 @@ int dvo_tracker_track_image(dvo_tracker*, const uint8_t* gray0, const uint8_t* g
  * DetectNewFeature's "<10 -> skip" refill rule (instance_feature.cpp:353-356). */
 int dvo_tracker_track_image_naive(dvo_tracker*, const uint8_t* gray0, const uint8_t* gray1,
                                   const uint8_t* mask, double time, dvo_feat* out);
+/* mode 0 TrackImage, 1 TrackImageNaive, 2 TrackSemanticImage; erode_k > 0: mask eroded by a k x k rectangle first */
+int dvo_tracker_track_image_mode(dvo_tracker*, const uint8_t* gray0, const uint8_t* gray1, const uint8_t* inv_mask_or_null, int mode, int erode_k, double time, dvo_feat* out);
 
 /* ---------------- back end ---------------- */
 

@@ -398,6 +398,7 @@ template <class T> void reduce_vector(std::vector<T>& v, const std::vector<uint8
 
 } // namespace
 
+extern "C" void dvo_erode(const uint8_t* src, int w, int h, int k, uint8_t* dst);
 struct dvo_tracker {
     dvo_fe_config cfg;
     Img prev0;
@@ -442,12 +443,21 @@ struct dvo_tracker {
         }
         return (int)ids.size();
     }
-    int track(const uint8_t* g0, const uint8_t* g1, const uint8_t* in_mask, bool naive, double time, dvo_feat* out) {
+    // mode 0 TrackImage, 1 TrackImageNaive, 2 TrackSemanticImage (background_tracker.cpp:52-158, 400-516, 757-837)
+    int track(const uint8_t* g0, const uint8_t* g1, const uint8_t* in_mask_raw, int mode, int erode_k, double time, dvo_feat* out) {
         const int w = cfg.width, h = cfg.height;
+        const bool naive = mode != 0;
         cur_time = time;
-        std::vector<uint8_t> mask((size_t)w * h, 255);
+        std::vector<uint8_t> mask((size_t)w * h, 255), eroded;
+        const uint8_t* in_mask = in_mask_raw;
+        if (naive && in_mask_raw && erode_k > 0) {               // use_mask_morphology (background_tracker.cpp:408-416,764-768)
+            eroded.resize((size_t)w * h);
+            dvo_erode(in_mask_raw, w, h, erode_k, eroded.data());
+            in_mask = eroded.data();
+        }
         if (in_mask) std::memcpy(mask.data(), in_mask, mask.size());
-        const float dthr = naive ? 1.0f : 0.5f;                     // Q12: feature_utils.cpp:56 vs :126
+        const float dthr = mode == 1 ? 1.0f : 0.5f;                 // Q12: FeatureTrackByLK <= 0.5 (feature_utils.cpp:56), ...ByLKGpu <= 1.0 (:126)
+        const float dthr_right = mode == 0 ? 0.5f : 1.0f;           // TrackRightGPU in naive and semantic mode
         curr_points.clear();
         if (!last_points.empty()) {
             curr_points.resize(last_points.size());
@@ -482,7 +492,7 @@ struct dvo_tracker {
             if (!curr_points.empty()) {
                 right_points.resize(curr_points.size());
                 std::vector<uint8_t> st(curr_points.size());
-                track_by_lk(g0, g1, w, h, curr_points.data(), (int)curr_points.size(), cfg.flow_back, dthr, right_points.data(), st.data());
+                track_by_lk(g0, g1, w, h, curr_points.data(), (int)curr_points.size(), cfg.flow_back, dthr_right, right_points.data(), st.data());
                 right_ids = ids;
                 reduce_vector(right_points, st); reduce_vector(right_ids, st);
                 undistort(cfg.cam1, right_points, right_un);
@@ -538,10 +548,13 @@ void dvo_lift_projective(const dvo_cam* cam, const float* pts, int n, float* out
 dvo_tracker* dvo_tracker_create(const dvo_fe_config* cfg) { auto* t = new dvo_tracker(); t->cfg = *cfg; return t; }
 void dvo_tracker_destroy(dvo_tracker* t) { delete t; }
 int dvo_tracker_track_image(dvo_tracker* t, const uint8_t* g0, const uint8_t* g1, double time, dvo_feat* out) {
-    return t->track(g0, g1, nullptr, false, time, out);
+    return t->track(g0, g1, nullptr, 0, 0, time, out);
 }
 int dvo_tracker_track_image_naive(dvo_tracker* t, const uint8_t* g0, const uint8_t* g1, const uint8_t* mask, double time, dvo_feat* out) {
-    return t->track(g0, g1, mask, true, time, out);
+    return t->track(g0, g1, mask, 1, 0, time, out);
+}
+int dvo_tracker_track_image_mode(dvo_tracker* t, const uint8_t* g0, const uint8_t* g1, const uint8_t* mask, int mode, int erode_k, double time, dvo_feat* out) {
+    return t->track(g0, g1, mask, mode, erode_k, time, out);
 }
 
 } // extern "C"

@@ -42,6 +42,8 @@ class Oracle:
         lib.dvo_tracker_track_image.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
         lib.dvo_tracker_track_image_naive.restype = C.c_int
         lib.dvo_tracker_track_image_naive.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        lib.dvo_tracker_track_image_mode.restype = C.c_int
+        lib.dvo_tracker_track_image_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
         lib.dvo_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int,
                                C.c_void_p, C.c_void_p]
         lib.dvo_track_by_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
@@ -139,10 +141,13 @@ class OracleTracker:
         self.h = o.lib.dvo_tracker_create(C.byref(cfg))
         self.out = np.zeros(max_cnt + 8, FEAT_DTYPE)
 
-    def track_image(self, g0, g1, t, mask=None, naive=False):
+    def track_image(self, g0, g1, t, mask=None, naive=False, mode=None, erode_k=0):
         g0 = np.ascontiguousarray(g0)
         g1 = np.ascontiguousarray(g1) if g1 is not None else None
-        if naive:
+        if mode is not None:
+            m = np.ascontiguousarray(mask) if mask is not None else None
+            n = self.o.lib.dvo_tracker_track_image_mode(self.h, _p(g0), _p(g1), _p(m), int(mode), int(erode_k), t, _p(self.out))
+        elif naive:
             n = self.o.lib.dvo_tracker_track_image_naive(self.h, _p(g0), _p(g1), _p(mask), t, _p(self.out))
         else:
             n = self.o.lib.dvo_tracker_track_image(self.h, _p(g0), _p(g1), t, _p(self.out))

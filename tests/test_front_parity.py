@@ -200,6 +200,26 @@ def test_track_image_naive_masked_bit_exact(gpu_ctx_factory, oracle):
         _rows_equal(g, r)
 
 
+@pytest.mark.parametrize("mode,erode_k", [(2, 0), (2, 7), (1, 5)])
+def test_track_semantic_image_and_mask_erosion_bit_exact(gpu_ctx_factory, oracle, mode, erode_k):
+    """TrackSemanticImage (background half of dynamic mode: temporal LK by the CPU rule, right image by the GPU rule) and the
+    in-tracker erosion of the inverse instance mask (use_mask_morphology)"""
+    w, h, max_cnt, min_dist = 320, 240, 90, 12
+    cam = (180.0, 181.0, 158.0, 121.0) + ZED[4:]
+    c = gpu_ctx_factory(width=w, height=h, max_cnt=max_cnt, min_dist=min_dist, cam0=_cam(cam), cam1=_cam(cam), mask_morphology_size=erode_k)
+    o = oracle.tracker(w, h, max_cnt, min_dist, 1, 1, cam, cam)
+    seq = synth.PlaneSequence(w, h, seed=6, disparity=6.5)
+    for k in range(7):
+        left, right = seq.frame(k)
+        mask = np.full((h, w), 255, np.uint8)
+        mask[50:150, 90 + 6 * k:200 + 6 * k] = 0
+        mask[200:204, 10:14] = 0                           # a speck the erosion grows
+        g = c.track_stereo(left, right, 0.1 * k, mask, mode)
+        r = o.track_image(left, right, 0.1 * k, mask, mode=mode, erode_k=erode_k)
+        _rows_equal(g, r)
+    assert len(g) > 40
+
+
 def test_mono_and_reset(gpu_ctx_factory, oracle):
     w, h = 320, 240
     cam = (200.0, 200.0, 160.0, 120.0, 0, 0, 0, 0)

@@ -76,4 +76,4 @@ void dv_launch_circle_mask(uint8_t* mask, int w, int h, int pitch, const float2*
                            hipStream_t s);
 void dv_launch_erode(const uint8_t* src, int w, int h, int spitch, int k, uint8_t* tmp, int tpitch, uint8_t* dst, int dpitch,
                      hipStream_t s);
-void dv_launch_lift(const dv_cam& cam, const float2* in, int n, float2* out, hipStream_t s);
+void dv_launch_lift(const dv_cam& cam, const float2* in, int n, double off_x, double off_y, float2* out, hipStream_t s);

@@ -473,12 +473,16 @@ int dv_erode(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, int k, u
 }
 
 int dv_lift_projective(dv_ctx* ctx, const dv_cam* cam, const float* pts_xy, int n, float* out_xy, int mem) {
+    return dv_lift_projective_offset(ctx, cam, pts_xy, n, 0.0, 0.0, out_xy, mem);
+}
+
+int dv_lift_projective_offset(dv_ctx* ctx, const dv_cam* cam, const float* pts_xy, int n, double off_x, double off_y, float* out_xy, int mem) {
     if (!ctx) return -1;
     if (!cam || (n > 0 && (!pts_xy || !out_xy))) DV_FAIL("dv_lift_projective: null argument");
     DV_CHECK(hipSetDevice(ctx->cfg.device));
     if (stage_in(ctx, ctx->s0, pts_xy, (size_t)n * 8, mem)) return -1;
     DV_CHECK(ctx->s1.ensure((size_t)std::max(n, 1) * 8));
-    dv_launch_lift(*cam, (const float2*)ctx->s0.p, n, (float2*)ctx->s1.p, ctx->stream);
+    dv_launch_lift(*cam, (const float2*)ctx->s0.p, n, off_x, off_y, (float2*)ctx->s1.p, ctx->stream);
     DV_CHECK(hipGetLastError());
     if (stage_out(ctx, out_xy, ctx->s1.p, (size_t)n * 8, mem)) return -1;
     DV_CHECK(hipStreamSynchronize(ctx->stream));

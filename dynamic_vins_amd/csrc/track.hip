@@ -164,11 +164,11 @@ __global__ __launch_bounds__(256) void erode_v_kernel(const uint8_t* __restrict_
     dst[(size_t)y * dpitch + x] = (uint8_t)m;
 }
 
-__global__ __launch_bounds__(256) void lift_kernel(dv_cam cam, const float2* __restrict__ in, int n, float2* __restrict__ out) {
+__global__ __launch_bounds__(256) void lift_kernel(dv_cam cam, const float2* __restrict__ in, int n, double off_x, double off_y, float2* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double x, y;
-    dv_lift_projective_d(cam, (double)in[i].x, (double)in[i].y, x, y);
+    dv_lift_projective_d(cam, (double)in[i].x + off_x, (double)in[i].y + off_y, x, y);      // offset added in double, like InstFeat::UndistortedPointsWithAddOffset
     out[i] = make_float2((float)x, (float)y);
 }
 
@@ -188,7 +188,7 @@ void dv_launch_erode(const uint8_t* src, int w, int h, int spitch, int k, uint8_
     hipLaunchKernelGGL(erode_h_kernel, grid, dim3(256), 0, s, src, w, h, spitch, k, tmp, tpitch);
     hipLaunchKernelGGL(erode_v_kernel, grid, dim3(256), 0, s, tmp, w, h, tpitch, k, dst, dpitch);
 }
-void dv_launch_lift(const dv_cam& cam, const float2* in, int n, float2* out, hipStream_t s) {
+void dv_launch_lift(const dv_cam& cam, const float2* in, int n, double off_x, double off_y, float2* out, hipStream_t s) {
     if (n <= 0) return;
-    hipLaunchKernelGGL(lift_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cam, in, n, out);
+    hipLaunchKernelGGL(lift_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cam, in, n, off_x, off_y, out);
 }

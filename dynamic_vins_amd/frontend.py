@@ -139,10 +139,11 @@ class Context:
         self._check(self.lib.dv_erode(self.h, _ptr(mask), w, h, mask.strides[0], int(k), _ptr(out), DV_MEM_HOST))
         return out
 
-    def lift_projective(self, cam, pts):
-        pts = np.ascontiguousarray(pts, np.float32)
+    def lift_projective(self, cam, pts, offset=(0.0, 0.0)):
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
         out = np.zeros_like(pts)
-        self._check(self.lib.dv_lift_projective(self.h, C.byref(cam), _ptr(pts), len(pts), _ptr(out), DV_MEM_HOST))
+        if len(pts):
+            self._check(self.lib.dv_lift_projective_offset(self.h, C.byref(cam), _ptr(pts), len(pts), float(offset[0]), float(offset[1]), _ptr(out), DV_MEM_HOST))
         return out
 
     # ---- measurement ----
@@ -198,3 +199,56 @@ class FeatureTracker:
 
     trackImage = TrackImage
     trackImageNaive = TrackImageNaive
+
+
+class InstFeat:
+    """Mirror of dynamic_vins::InstFeat for ONE object instance as InstsFeatManager::InstsTrack drives it
+    (front_end/dynamic_tracker.cpp:348-470, front_end/instance_feature.cpp): ROI-local LK on zero-padded crops,
+    Shi-Tomasi top-up inside the eroded instance mask, undistortion with the 2-D box offset, right-image LK on the
+    full frames.  Host composition of the C-ABI operators (dv_track_by_lk, dv_erode, dv_circle_mask, dv_gftt,
+    dv_lift_projective_offset); every pixel / index result is bit-exact against the oracle's dvo_inst_track.
+    The VIODE segmentation-key test of TrackRightByPad is not applied."""
+
+    global_id_count = 1        # InstFeat::global_id_count (static, shared with the background tracker in the reference)
+
+    def __init__(self, ctx: Context, cam0, cam1, max_cnt=50, min_dist=4, flow_back=True):
+        self.ctx, self.cam0, self.cam1 = ctx, cam0, cam1
+        self.max_cnt, self.min_dist, self.flow_back = max_cnt, min_dist, flow_back      # max_dynamic_cnt, min_dynamic_dist, flow_back
+        self.last_points = np.zeros((0, 2), np.float32)
+        self.ids = np.zeros(0, np.uint32)
+        self.track_cnt = np.zeros(0, np.int32)
+        self.prev_roi_gray = None
+
+    def Track(self, roi_gray, roi_mask, box_tl, gray0, gray1=None):
+        """one frame; returns dict(curr_points, ids, track_cnt, curr_un_points, right_points, right_ids, right_un_points)"""
+        ctx = self.ctx
+        roi_gray = np.ascontiguousarray(roi_gray)
+        curr, ids, cnt = np.zeros((0, 2), np.float32), np.zeros(0, np.uint32), np.zeros(0, np.int32)
+        if self.prev_roi_gray is not None and len(self.last_points):
+            h = max(self.prev_roi_gray.shape[0], roi_gray.shape[0]); w = max(self.prev_roi_gray.shape[1], roi_gray.shape[1])
+            a = np.zeros((h, w), np.uint8); b = np.zeros((h, w), np.uint8)          # InstanceImagePadding (feature_utils.cpp:406-413)
+            a[: self.prev_roi_gray.shape[0], : self.prev_roi_gray.shape[1]] = self.prev_roi_gray
+            b[: roi_gray.shape[0], : roi_gray.shape[1]] = roi_gray
+            pts, st = ctx.track_by_lk(a, b, self.last_points, self.flow_back, 0.5)   # InstFeat::TrackLeft, no mask
+            keep = st > 0
+            curr, ids, cnt = pts[keep], self.ids[keep], self.track_cnt[keep] + 1
+        if len(curr) < self.max_cnt:
+            m = ctx.erode(np.ascontiguousarray(roi_mask), 5) if roi_mask is not None else np.full(roi_gray.shape, 255, np.uint8)
+            if len(curr):
+                m = ctx.circle_mask(m, curr, self.min_dist)
+            new = ctx.gftt(roi_gray, self.max_cnt - len(curr), 0.01, self.min_dist, m)
+            if len(new):
+                nid = np.arange(InstFeat.global_id_count, InstFeat.global_id_count + len(new), dtype=np.uint32)
+                InstFeat.global_id_count += len(new)
+                curr = np.concatenate([curr, new]); ids = np.concatenate([ids, nid]); cnt = np.concatenate([cnt, np.ones(len(new), np.int32)])
+        un = ctx.lift_projective(self.cam0, curr, offset=box_tl)                   # UndistortedPointsWithAddOffset
+        out = dict(curr_points=curr, ids=ids, track_cnt=cnt, curr_un_points=un, right_points=np.zeros((0, 2), np.float32),
+                   right_ids=np.zeros(0, np.uint32), right_un_points=np.zeros((0, 2), np.float32))
+        if gray1 is not None and len(curr):                                         # TrackRightByPad
+            padded = (curr + np.array(box_tl, np.float32)).astype(np.float32)
+            rp, st = ctx.track_by_lk(gray0, gray1, padded, self.flow_back, 0.5)
+            keep = st > 0
+            out["right_points"], out["right_ids"] = rp[keep], ids[keep]
+            out["right_un_points"] = ctx.lift_projective(self.cam1, rp[keep])
+        self.last_points, self.ids, self.track_cnt, self.prev_roi_gray = curr, ids, cnt, roi_gray      # PostProcess
+        return out

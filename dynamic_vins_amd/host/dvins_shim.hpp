@@ -9,6 +9,7 @@
 //        FeatureTracker(const std::string& config_path)
 //        FeatureBackground TrackImage(SemanticImage&)          background_tracker.cpp:52-158
 //        FeatureBackground TrackImageNaive(SemanticImage&)     background_tracker.cpp:400-516
+//        FeatureBackground TrackSemanticImage(SemanticImage&)  background_tracker.cpp:757-837
 //   dynamic_vins::Estimator        estimator/estimator.h:55-164
 //        Estimator(const std::string& config_path); SetParameter(); ClearState();
 //        InputIMU(double t, const Vec3d& acc, const Vec3d& gyr)                     estimator.cpp:1765-1779
@@ -200,6 +201,7 @@ public:
         c.width = y.integer("image_width", 0); c.height = y.integer("image_height", 0);
         c.max_cnt = y.integer("max_cnt", 150); c.min_dist = y.integer("min_dist", 30);
         c.flow_back = y.integer("flow_back", 1); c.stereo = y.integer("num_of_cam", 2) == 2; c.device = device;
+        c.mask_morphology_size = y.integer("use_mask_morphology", 0) ? y.integer("mask_morphology_size", 0) : 0;
         const std::string dir = dir_of(config_path);
         c.cam0 = ReadPinholeCamera(dir + "/" + y.str("cam0_calib"));
         c.cam1 = c.stereo ? ReadPinholeCamera(dir + "/" + y.str("cam1_calib")) : c.cam0;
@@ -212,6 +214,7 @@ public:
 
     FeatureBackground TrackImage(SemanticImage& img) { return track(img, DV_MODE_RAW); }
     FeatureBackground TrackImageNaive(SemanticImage& img) { return track(img, DV_MODE_NAIVE); }
+    FeatureBackground TrackSemanticImage(SemanticImage& img) { return track(img, DV_MODE_SEMANTIC); }      // background_tracker.cpp:757-837 (background half)
     // two-phase form: lets the caller overlap the front end of frame k+1 with the back end of frame k
     void TrackImageEnqueue(SemanticImage& img, int mode = DV_MODE_RAW) {
         check_image(img);

@@ -108,6 +108,9 @@ int dv_circle_mask(dv_ctx* ctx, uint8_t* mask, int w, int h, int stride, const f
 int dv_erode(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, int k, uint8_t* dst, int mem);
 /* InstFeat::UndistortedPts -> PinholeCamera::liftProjective (instance_feature.cpp:94-103) */
 int dv_lift_projective(dv_ctx* ctx, const dv_cam* cam, const float* pts_xy, int n, float* out_xy, int mem);
+/* InstFeat::UndistortedPointsWithAddOffset (front_end/instance_feature.cpp:123-133): points in ROI coordinates, the 2-D box's
+ * top-left corner added in double before lifting */
+int dv_lift_projective_offset(dv_ctx* ctx, const dv_cam* cam, const float* pts_xy, int n, double off_x, double off_y, float* out_xy, int mem);
 
 /* ======================= back end: sliding-window bundle adjustment ======================= */
 

@@ -92,6 +92,13 @@ int dvo_tracker_track_image_naive(dvo_tracker*, const uint8_t* gray0, const uint
                                   const uint8_t* mask, double time, dvo_feat* out);
 /* mode 0 TrackImage, 1 TrackImageNaive, 2 TrackSemanticImage; erode_k > 0: mask eroded by a k x k rectangle first */
 int dvo_tracker_track_image_mode(dvo_tracker*, const uint8_t* gray0, const uint8_t* gray1, const uint8_t* inv_mask_or_null, int mode, int erode_k, double time, dvo_feat* out);
+/* one visible object instance through one frame of InstsFeatManager::InstsTrack (front_end/dynamic_tracker.cpp:348-470); see front_oracle.cpp */
+int dvo_inst_track(const uint8_t* prev_roi, int pw, int ph, const uint8_t* cur_roi, int cw, int ch, const uint8_t* cur_mask, int box_x, int box_y,
+                   const uint8_t* gray0, const uint8_t* gray1, int W, int H, const dvo_cam* cam0, const dvo_cam* cam1,
+                   int n_last, const float* last_pts, const uint32_t* ids, const int32_t* track_cnt,
+                   int max_cnt, int min_dist, int flow_back, uint32_t* global_id,
+                   int* n_cur, float* cur_pts, uint32_t* cur_ids, int32_t* cur_cnt, float* cur_un,
+                   int* n_right, float* right_pts, uint32_t* right_ids, float* right_un);
 
 /* ---------------- back end ---------------- */
 

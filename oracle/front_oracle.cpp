@@ -557,4 +557,63 @@ int dvo_tracker_track_image_mode(dvo_tracker* t, const uint8_t* g0, const uint8_
     return t->track(g0, g1, mask, mode, erode_k, time, out);
 }
 
+// One visible object instance through one frame of InstsFeatManager::InstsTrack (front_end/dynamic_tracker.cpp:348-470):
+//   InstanceImagePadding (feature_utils.cpp:406-413) -> InstFeat::TrackLeft without mask (instance_feature.cpp:149-188)
+//   -> ErodeMask 5x5 + cv::circle(kMinDynamicDist) + goodFeaturesToTrack(roi_gray, kMaxDynamicCnt - n, 0.01, kMinDynamicDist)
+//   -> UndistortedPointsWithAddOffset (:123-133) -> TrackRightByPad on the full images (:251-275) -> RightUndistortedPts.
+// Points live in ROI coordinates (previous ROI for last_pts, current ROI for the outputs), as in the reference.
+// The VIODE segmentation-key test of TrackRightByPad belongs to SURVEY row N4 and is not applied.
+int dvo_inst_track(const uint8_t* prev_roi, int pw, int ph, const uint8_t* cur_roi, int cw, int ch, const uint8_t* cur_mask, int box_x, int box_y,
+                   const uint8_t* gray0, const uint8_t* gray1, int W, int H, const dvo_cam* cam0, const dvo_cam* cam1,
+                   int n_last, const float* last_pts, const uint32_t* ids, const int32_t* track_cnt,
+                   int max_cnt, int min_dist, int flow_back, uint32_t* global_id,
+                   int* n_cur, float* cur_pts, uint32_t* cur_ids, int32_t* cur_cnt, float* cur_un,
+                   int* n_right, float* right_pts, uint32_t* right_ids, float* right_un) {
+    std::vector<P2f> last, cur; std::vector<uint32_t> id; std::vector<int> cnt;
+    if (prev_roi && n_last > 0) {
+        const int w = std::max(pw, cw), h = std::max(ph, ch);
+        std::vector<uint8_t> a((size_t)w * h, 0), b((size_t)w * h, 0);
+        for (int y = 0; y < ph; ++y) std::memcpy(&a[(size_t)y * w], prev_roi + (size_t)y * pw, pw);
+        for (int y = 0; y < ch; ++y) std::memcpy(&b[(size_t)y * w], cur_roi + (size_t)y * cw, cw);
+        last.resize(n_last); cur.resize(n_last);
+        for (int i = 0; i < n_last; ++i) last[i] = { last_pts[2 * i], last_pts[2 * i + 1] };
+        std::vector<uint8_t> st(n_last);
+        track_by_lk(a.data(), b.data(), w, h, last.data(), n_last, flow_back != 0, 0.5f, cur.data(), st.data());
+        id.assign(ids, ids + n_last); cnt.assign(track_cnt, track_cnt + n_last);
+        reduce_vector(cur, st); reduce_vector(id, st); reduce_vector(cnt, st);
+        for (auto& c : cnt) c++;
+    }
+    if ((int)cur.size() < max_cnt) {
+        const int max_new = max_cnt - (int)cur.size();
+        std::vector<uint8_t> m((size_t)cw * ch, 255);
+        if (cur_mask) dvo_erode(cur_mask, cw, ch, 5, m.data());
+        for (auto& p : cur) circle_zero(m.data(), cw, ch, cv_round(p.x), cv_round(p.y), min_dist);
+        std::vector<P2f> npts;
+        gftt(cur_roi, m.data(), cw, ch, max_new, 0.01, min_dist, npts);
+        for (auto& p : npts) { cur.push_back(p); id.push_back((*global_id)++); cnt.push_back(1); }
+    }
+    *n_cur = (int)cur.size();
+    for (size_t i = 0; i < cur.size(); ++i) {
+        cur_pts[2 * i] = cur[i].x; cur_pts[2 * i + 1] = cur[i].y; cur_ids[i] = id[i]; cur_cnt[i] = cnt[i];
+        double x, y; lift_projective(*cam0, (double)cur[i].x + box_x, (double)cur[i].y + box_y, x, y);
+        cur_un[2 * i] = (float)x; cur_un[2 * i + 1] = (float)y;
+    }
+    *n_right = 0;
+    if (gray1 && !cur.empty()) {
+        std::vector<P2f> padded(cur.size()), rp(cur.size());
+        for (size_t i = 0; i < cur.size(); ++i) padded[i] = { cur[i].x + (float)box_x, cur[i].y + (float)box_y };
+        std::vector<uint8_t> st(cur.size());
+        track_by_lk(gray0, gray1, W, H, padded.data(), (int)padded.size(), flow_back != 0, 0.5f, rp.data(), st.data());
+        std::vector<uint32_t> rid = id;
+        reduce_vector(rp, st); reduce_vector(rid, st);
+        *n_right = (int)rp.size();
+        for (size_t i = 0; i < rp.size(); ++i) {
+            right_pts[2 * i] = rp[i].x; right_pts[2 * i + 1] = rp[i].y; right_ids[i] = rid[i];
+            double x, y; lift_projective(*cam1, rp[i].x, rp[i].y, x, y);
+            right_un[2 * i] = (float)x; right_un[2 * i + 1] = (float)y;
+        }
+    }
+    return 0;
+}
+
 } // extern "C"

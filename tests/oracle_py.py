@@ -127,6 +127,31 @@ class Oracle:
         self.lib.dvo_lift_projective(C.byref(c), _p(pts), len(pts), _p(out))
         return out
 
+    def inst_track(self, prev_roi, cur_roi, cur_mask, box_tl, gray0, gray1, cam0, cam1, last_pts, ids, track_cnt, max_cnt, min_dist, flow_back, global_id):
+        """dvo_inst_track -> (dict like frontend.InstFeat.Track, new global id)"""
+        lib = self.lib
+        lib.dvo_inst_track.restype = C.c_int
+        cap = max_cnt + len(last_pts) + 8
+        cur_pts, cur_ids, cur_cnt, cur_un = np.zeros((cap, 2), np.float32), np.zeros(cap, np.uint32), np.zeros(cap, np.int32), np.zeros((cap, 2), np.float32)
+        r_pts, r_ids, r_un = np.zeros((cap, 2), np.float32), np.zeros(cap, np.uint32), np.zeros((cap, 2), np.float32)
+        n_cur, n_right, gid = C.c_int(0), C.c_int(0), C.c_uint32(global_id)
+        c0, c1 = dvo_cam(*cam0), dvo_cam(*cam1)
+        cur_roi = np.ascontiguousarray(cur_roi)
+        prev = np.ascontiguousarray(prev_roi) if prev_roi is not None else None
+        mask = np.ascontiguousarray(cur_mask) if cur_mask is not None else None
+        g0 = np.ascontiguousarray(gray0); g1 = np.ascontiguousarray(gray1) if gray1 is not None else None
+        last = np.ascontiguousarray(last_pts, np.float32); idv = np.ascontiguousarray(ids, np.uint32); cv = np.ascontiguousarray(track_cnt, np.int32)
+        V = C.c_void_p
+        lib.dvo_inst_track.argtypes = [V, C.c_int, C.c_int, V, C.c_int, C.c_int, V, C.c_int, C.c_int, V, V, C.c_int, C.c_int, C.POINTER(dvo_cam), C.POINTER(dvo_cam),
+                                       C.c_int, V, V, V, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_int), V, V, V, V, C.POINTER(C.c_int), V, V, V]
+        lib.dvo_inst_track(_p(prev), prev.shape[1] if prev is not None else 0, prev.shape[0] if prev is not None else 0, _p(cur_roi), cur_roi.shape[1], cur_roi.shape[0],
+                           _p(mask), int(box_tl[0]), int(box_tl[1]), _p(g0), _p(g1), g0.shape[1], g0.shape[0], C.byref(c0), C.byref(c1),
+                           len(last), _p(last), _p(idv), _p(cv), int(max_cnt), int(min_dist), int(flow_back), C.byref(gid), C.byref(n_cur), _p(cur_pts), _p(cur_ids), _p(cur_cnt),
+                           _p(cur_un), C.byref(n_right), _p(r_pts), _p(r_ids), _p(r_un))
+        n, m = n_cur.value, n_right.value
+        return dict(curr_points=cur_pts[:n], ids=cur_ids[:n], track_cnt=cur_cnt[:n], curr_un_points=cur_un[:n], right_points=r_pts[:m], right_ids=r_ids[:m],
+                    right_un_points=r_un[:m]), gid.value
+
     def tracker(self, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1):
         return OracleTracker(self, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1)
 

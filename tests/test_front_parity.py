@@ -240,3 +240,37 @@ def test_error_behaviour(ctx):
         ctx.track_by_lk(img, img, np.zeros((0, 2), np.float32))      # reference: std::runtime_error on empty input
     with pytest.raises(DvinsError):
         ctx.track_stereo(_img(100, 100, 1), None, 0.0, w=100, h=100)   # size mismatch (reference: std::terminate)
+
+
+def test_instance_tracker_bit_exact(gpu_ctx_factory, oracle):
+    """one object instance through InstsFeatManager::InstsTrack (row F10): a textured box drifting and growing over a
+    moving background; ROI crops of changing size, eroded instance mask, box offset, right-image tracking"""
+    from dynamic_vins_amd.frontend import InstFeat
+    W, H = 320, 240
+    cam = (180.0, 181.0, 158.0, 121.0) + ZED[4:]
+    ctx = gpu_ctx_factory(width=W, height=H, max_cnt=30, min_dist=10, cam0=_cam(cam), cam1=_cam(cam))
+    seq = synth.PlaneSequence(W, H, seed=9, disparity=5.5)
+    obj_tex = np.clip(synth.texture(200, 260, seed=123) * 255.0 + 0.5, 0, 255).astype(np.uint8)
+    inst = InstFeat(ctx, _cam(cam), _cam(cam), max_cnt=40, min_dist=4, flow_back=True)
+    InstFeat.global_id_count = 1
+    o_last, o_ids, o_cnt, o_prev, gid = np.zeros((0, 2), np.float32), np.zeros(0, np.uint32), np.zeros(0, np.int32), None, 1
+    tracked = 0
+    for k in range(7):
+        left, right = seq.frame(k)
+        left, right = left.copy(), right.copy()
+        x0, y0, bw, bh = 60 + 4 * k, 50 + 2 * k, 90 + 3 * k, 70 + 2 * k                 # the 2-D box drifts and grows
+        patch = obj_tex[20 + k:20 + k + bh, 30:30 + bw]
+        left[y0:y0 + bh, x0:x0 + bw] = patch
+        right[y0:y0 + bh, x0 - 6:x0 - 6 + bw] = patch                                       # the object is closer: disparity 6
+        roi = left[y0:y0 + bh, x0:x0 + bw].copy()
+        mask = np.zeros((bh, bw), np.uint8); mask[6:-6, 8:-8] = 255
+        g = inst.Track(roi, mask, (x0, y0), left, right)
+        r, gid = oracle.inst_track(o_prev, roi, mask, (x0, y0), left, right, cam, cam, o_last, o_ids, o_cnt, 40, 4, 1, gid)
+        for key in ("curr_points", "curr_un_points", "right_points", "right_un_points"):
+            assert np.array_equal(g[key].view(np.uint32), r[key].view(np.uint32)), (k, key)
+        for key in ("ids", "track_cnt", "right_ids"):
+            assert np.array_equal(g[key], r[key]), (k, key)
+        o_last, o_ids, o_cnt, o_prev = r["curr_points"], r["ids"], r["track_cnt"], roi
+        tracked += int((g["track_cnt"] > 1).sum())
+        assert len(g["curr_points"]) > 10 and (k == 0 or len(g["right_points"]) > 3)
+    assert tracked > 40 and InstFeat.global_id_count == gid

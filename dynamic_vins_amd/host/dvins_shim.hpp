@@ -357,11 +357,41 @@ private:
     std::deque<FrontendFeature> queue_;
 };
 
-// trajectory line of the reference's writer: "<stamp> px py pz qx qy qz qw" (utils/io/output.cpp:199-227)
+// ---- on-disk formats on either side of the path ----
+// trajectory line of SaveBodyTrajectory (utils/io/output.cpp:189-227): "<sec>.<nsec 9 digits> px py pz qx qy qz qw", fixed, 6 decimals
 inline std::string TumLine(double stamp, const std::array<double, 16>& s) {
-    char buf[256];
-    std::snprintf(buf, sizeof(buf), "%f %f %f %f %f %f %f %f", stamp, s[0], s[1], s[2], s[3], s[4], s[5], s[6]);
+    long long sec = (long long)std::floor(stamp), nsec = std::llround((stamp - (double)sec) * 1e9);
+    if (nsec >= 1000000000LL) { sec += 1; nsec -= 1000000000LL; }
+    char buf[320];
+    std::snprintf(buf, sizeof(buf), "%lld.%09lld %.6f %.6f %.6f %.6f %.6f %.6f %.6f", sec, nsec, s[0], s[1], s[2], s[3], s[4], s[5], s[6]);
     return buf;
+}
+// point features of one frame, one line per id: "<0|1> id x y z u v vx vy [x y z u v vx vy]" (utils/io/feature_serialization.cpp:26-75)
+inline void SerializePointFeature(const std::string& path, const std::map<unsigned int, std::vector<std::pair<int, Vec7d>>>& points) {
+    std::ofstream f(path);
+    if (!f) throw std::runtime_error("dvins: cannot write " + path);
+    auto num = [](double v) { char b[40]; std::snprintf(b, sizeof(b), "%.17g", v); double back = std::strtod(b, nullptr);
+                              for (int p = 1; p < 17; ++p) { char c[40]; std::snprintf(c, sizeof(c), "%.*g", p, v); if (std::strtod(c, nullptr) == v) return std::string(c); }
+                              (void)back; return std::string(b); };      // shortest digits that round-trip
+    for (const auto& kv : points) {
+        f << (kv.second.size() == 1 ? "0 " : "1 ") << kv.first;
+        for (size_t o = 0; o < kv.second.size() && o < 2; ++o) for (double v : kv.second[o].second) f << ' ' << num(v);
+        f << '\n';
+    }
+}
+inline std::map<unsigned int, std::vector<std::pair<int, Vec7d>>> DeserializePointFeature(const std::string& path) {
+    std::map<unsigned int, std::vector<std::pair<int, Vec7d>>> points;
+    std::ifstream f(path);
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream is(line);
+        int flag; unsigned int id; Vec7d v;
+        if (!(is >> flag >> id)) continue;
+        for (double& x : v) is >> x;
+        points[id].emplace_back(0, v);
+        if (flag == 1) { for (double& x : v) is >> x; points[id].emplace_back(1, v); }
+    }
+    return points;
 }
 
 }  // namespace dynamic_vins

@@ -25,6 +25,13 @@ int main(int argc, char** argv) {
             for (const char* k : {"body_T_cam0", "body_T_cam1"}) { std::printf("%s", k); for (double v : y.matrix(k)) std::printf(" %g", v); std::printf("\n"); }
             return 0;
         }
+        if (mode == "formats") {      // shim_test formats <dummy> <in.txt> <out.txt>: read a feature file, write it back, print a trajectory line
+            auto pts = DeserializePointFeature(argv[3]);
+            SerializePointFeature(argv[4], pts);
+            std::array<double, 16> st{}; st[0] = 1.0; st[1] = -2.5; st[2] = 0.125; st[5] = 0.70710678; st[6] = 0.70710678;
+            std::printf("%zu\n%s\n", pts.size(), TumLine(1403636579.763555992, st).c_str());
+            return 0;
+        }
         if (mode == "nogpu") {
             try { FeatureTracker t(cfg); } catch (const std::runtime_error& e) { std::printf("THROWN %s\n", e.what()); return 0; }
             std::printf("NO EXCEPTION\n");

@@ -33,6 +33,27 @@ def test_shim_parses_the_reference_yaml_dialect(shim_exe):
     assert out[4] == "body_T_cam1 0 0 1 0 1 0 0 0.12 0 1 0 0 0 0 0 1"      # multi-line data, commented-out duplicate ignored
 
 
+def test_shim_reads_and_writes_the_feature_and_trajectory_formats(shim_exe, tmp_path):
+    """C++ and Python sides of row N3 agree: a frame written by the Python writer is read by the shim, written back, and is
+    bit-identical after a second parse; the trajectory line is the same text"""
+    from dynamic_vins_amd import io_formats as F
+    rng = np.random.default_rng(1)
+    pts = {}
+    for fid in (4, 9, 12, 700):
+        v = np.concatenate([rng.normal(0, 0.3, 2), [1.0], rng.uniform(0, 1280, 2), rng.normal(0, 0.1, 2)])
+        pts[fid] = [(0, v)] + ([(1, v * 1.01)] if fid % 2 == 0 else [])
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    F.serialize_point_features(a, pts)
+    out = subprocess.run([shim_exe, "formats", CFG, str(a), str(b)], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "4"
+    assert out[1] == F.trajectory_line(1403636579.763555992, [1.0, -2.5, 0.125, 0, 0, 0.70710678, 0.70710678])
+    back = F.deserialize_point_features(b)
+    assert sorted(back) == sorted(pts)
+    for fid in pts:
+        for (c0, v0), (c1, v1) in zip(pts[fid], back[fid]):
+            assert c0 == c1 and np.array_equal(v0, v1)
+
+
 def test_shim_fails_loudly_without_a_device(shim_exe):
     import torch
     if torch.cuda.is_available():

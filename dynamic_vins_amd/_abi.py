@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVINS_HIP_LIB") or os.path.join(_HERE, "lib", "libdvins_hip.so")
 
 DV_MEM_HOST, DV_MEM_DEVICE = 0, 1
+DV_FMT_BGR = 0x100
 DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC = 0, 1, 2
 DV_MAX_FEATS = 1024
 
@@ -55,6 +56,7 @@ SIGNATURES = {
     "dv_gftt": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f32p,
                           C.POINTER(C.c_int), C.c_int]),
     "dv_min_eigen": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
+    "dv_bgr2gray": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "dv_pyr_down": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "dv_circle_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]),
     "dv_erode": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),

@@ -62,6 +62,7 @@ void dv_set_error(dv_ctx* ctx, const std::string& msg);
 void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int sh, int spitch,
                          uint8_t* dst0, uint8_t* dst1, int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch,
                          hipStream_t s);
+void dv_launch_bgr2gray(const uint8_t* src0, const uint8_t* src1, int w, int h, int spitch, uint8_t* dst0, uint8_t* dst1, int dpitch, hipStream_t s);
 void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters,
                           double eps_sq, int use_initial, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max,

@@ -76,14 +76,25 @@ static int build_pyramids(dv_ctx* ctx, PyrSet& P0, PyrSet* P1, const uint8_t* im
     const DvPyr& a = P0.pyr;
     const DvPyr* b = P1 ? &P1->pyr : nullptr;
     hipStream_t s = ctx->stream;
+    const bool bgr = (mem & DV_FMT_BGR) != 0;
+    mem &= ~DV_FMT_BGR;
     const bool dev = (mem == DV_MEM_DEVICE);
-    if (!dev || a.levels == 1) {
+    if (bgr) {          // colour input: BGR -> gray straight into level 0 (row N2); host frames are staged in HBM first
+        const uint8_t* c0 = img0; const uint8_t* c1 = img1; int cp = stride;
+        if (!dev) {
+            cp = align_up(3 * w, 16);
+            DV_CHECK(ctx->s3.ensure((size_t)cp * h)); DV_CHECK(hipMemcpy2DAsync(ctx->s3.p, cp, img0, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, s));
+            c0 = (const uint8_t*)ctx->s3.p;
+            if (b) { DV_CHECK(ctx->s4.ensure((size_t)cp * h)); DV_CHECK(hipMemcpy2DAsync(ctx->s4.p, cp, img1, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, s)); c1 = (const uint8_t*)ctx->s4.p; }
+        }
+        dv_launch_bgr2gray(c0, b ? c1 : nullptr, w, h, cp, a.L[0].p, b ? b->L[0].p : nullptr, a.L[0].pitch, s);
+    } else if (!dev || a.levels == 1) {
         hipMemcpyKind k = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
         DV_CHECK(hipMemcpy2DAsync(a.L[0].p, a.L[0].pitch, img0, stride, w, h, k, s));
         if (b) DV_CHECK(hipMemcpy2DAsync(b->L[0].p, b->L[0].pitch, img1, stride, w, h, k, s));
     }
     for (int l = 1; l < a.levels; ++l) {
-        const bool fuse_copy = dev && l == 1;
+        const bool fuse_copy = dev && l == 1 && !bgr;
         const uint8_t* s0 = fuse_copy ? img0 : a.L[l - 1].p;
         const uint8_t* s1 = b ? (fuse_copy ? img1 : b->L[l - 1].p) : nullptr;
         const int sp = fuse_copy ? stride : a.L[l - 1].pitch;
@@ -210,11 +221,12 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     }
     const uint8_t* mask_dev = nullptr; int mask_pitch = 0;
     if (mask_or_null) {
-        if (mem == DV_MEM_DEVICE) { mask_dev = mask_or_null; mask_pitch = stride; }
+        const bool bgr_in = (mem & DV_FMT_BGR) != 0;
+        if ((mem & ~DV_FMT_BGR) == DV_MEM_DEVICE) { mask_dev = mask_or_null; mask_pitch = bgr_in ? w : stride; }
         else {
             mask_pitch = align_up(w, 16);
             DV_CHECK(ctx->mask_buf.ensure((size_t)mask_pitch * h));
-            DV_CHECK(hipMemcpy2DAsync(ctx->mask_buf.p, mask_pitch, mask_or_null, stride, w, h, hipMemcpyHostToDevice, s));
+            DV_CHECK(hipMemcpy2DAsync(ctx->mask_buf.p, mask_pitch, mask_or_null, bgr_in ? w : stride, w, h, hipMemcpyHostToDevice, s));
             mask_dev = (const uint8_t*)ctx->mask_buf.p;
         }
     }
@@ -418,6 +430,27 @@ int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w,
     if (stage_out(ctx, out_xy, d_out, (size_t)n * 8, mem)) return -1;
     DV_CHECK(hipStreamSynchronize(ctx->stream));
     *n_out = n;
+    return 0;
+}
+
+int dv_bgr2gray(dv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray, int mem) {
+    if (!ctx) return -1;
+    if (!bgr || !gray || w <= 0 || h <= 0 || stride < 3 * w) DV_FAIL("dv_bgr2gray: bad argument");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = ctx->stream;
+    const uint8_t* src = bgr; int sp = stride;
+    if (mem != DV_MEM_DEVICE) {
+        sp = align_up(3 * w, 16);
+        DV_CHECK(ctx->s3.ensure((size_t)sp * h));
+        DV_CHECK(hipMemcpy2DAsync(ctx->s3.p, sp, bgr, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, s));
+        src = (const uint8_t*)ctx->s3.p;
+    }
+    const int dp = align_up(w, 16);
+    DV_CHECK(ctx->s4.ensure((size_t)dp * h));
+    dv_launch_bgr2gray(src, nullptr, w, h, sp, (uint8_t*)ctx->s4.p, nullptr, dp, s);
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipMemcpy2DAsync(gray, w, ctx->s4.p, dp, w, h, mem == DV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipStreamSynchronize(s));
     return 0;
 }
 

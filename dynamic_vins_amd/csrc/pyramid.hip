@@ -92,3 +92,38 @@ void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int s
     dim3 grid((dw + PT_W - 1) / PT_W, (dh + PT_H - 1) / PT_H, src1 ? 2 : 1);
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src0, src1, sw, sh, spitch, dst0, dst1, dw, dh, dpitch, copy0, copy1, cpitch);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// cv::cvtColor(BGR -> GRAY), 8-bit (SemanticImage::SetGrayImage[Gpu], basic/semantic_image.cpp:95-117): the 14-bit
+// fixed-point weights (B 1868, G 9617, R 4899, +8192 >> 14).  Written straight into level 0 of the pyramid, so a
+// colour frame is read once (3P) and never exists as a separate gray image.
+// One thread = 4 pixels: three coalesced dword loads, one dword store.  blockIdx.z selects the image of a stereo pair.
+__global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int w, int h, int spitch,
+                                                       uint8_t* __restrict__ dst0, uint8_t* __restrict__ dst1, int dpitch) {
+    const uint8_t* src = blockIdx.z ? src1 : src0;
+    uint8_t* dst = blockIdx.z ? dst1 : dst0;
+    const int y = blockIdx.y, x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x4 >= w) return;
+    const uint8_t* row = src + (size_t)y * spitch + (size_t)x4 * 3;
+    uint8_t px[12];
+    if (x4 + 4 <= w && ((reinterpret_cast<uintptr_t>(row) & 3) == 0)) {
+        const uint32_t* r32 = reinterpret_cast<const uint32_t*>(row);
+        const uint32_t a = r32[0], b = r32[1], c = r32[2];
+        px[0] = a; px[1] = a >> 8; px[2] = a >> 16; px[3] = a >> 24; px[4] = b; px[5] = b >> 8; px[6] = b >> 16; px[7] = b >> 24;
+        px[8] = c; px[9] = c >> 8; px[10] = c >> 16; px[11] = c >> 24;
+    } else {
+        for (int k = 0; k < 12; ++k) px[k] = (x4 * 3 + k < w * 3) ? row[k] : 0;
+    }
+    uint8_t g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = (uint8_t)((px[3 * k] * 1868 + px[3 * k + 1] * 9617 + px[3 * k + 2] * 4899 + (1 << 13)) >> 14);
+    uint8_t* o = dst + (size_t)y * dpitch + x4;
+    if (x4 + 4 <= w) *reinterpret_cast<uint32_t*>(o) = (uint32_t)g[0] | ((uint32_t)g[1] << 8) | ((uint32_t)g[2] << 16) | ((uint32_t)g[3] << 24);
+    else for (int k = 0; k < 4 && x4 + k < w; ++k) o[k] = g[k];
+}
+
+void dv_launch_bgr2gray(const uint8_t* src0, const uint8_t* src1, int w, int h, int spitch, uint8_t* dst0, uint8_t* dst1, int dpitch, hipStream_t s) {
+    dim3 grid((w + 1023) / 1024, h, src1 ? 2 : 1);
+    hipLaunchKernelGGL(bgr2gray_kernel, grid, dim3(256), 0, s, src0, src1, w, h, spitch, dst0, dst1, dpitch);
+}

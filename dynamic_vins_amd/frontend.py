@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import DvinsError, dv_cam, dv_config, dv_feat, DV_MEM_HOST, DV_MEM_DEVICE, DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC
+from ._abi import DvinsError, dv_cam, dv_config, dv_feat, DV_MEM_HOST, DV_MEM_DEVICE, DV_FMT_BGR, DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC
 
 FEAT_DTYPE = np.dtype([("id", np.uint32), ("track_cnt", np.int32), ("has_right", np.int32), ("pad_", np.int32),
                        ("left", np.float64, 7), ("right", np.float64, 7)])
@@ -119,6 +119,14 @@ class Context:
         eig = np.zeros((h, w), np.float32)
         self._check(self.lib.dv_min_eigen(self.h, _ptr(img), w, h, img.strides[0], _ptr(eig), DV_MEM_HOST))
         return eig
+
+    def bgr2gray(self, bgr):
+        """cv::cvtColor(BGR2GRAY) of an (h, w, 3) uint8 image"""
+        bgr = np.ascontiguousarray(bgr)
+        h, w, _ = bgr.shape
+        out = np.zeros((h, w), np.uint8)
+        self._check(self.lib.dv_bgr2gray(self.h, _ptr(bgr), w, h, bgr.strides[0], _ptr(out), DV_MEM_HOST))
+        return out
 
     def pyr_down(self, img):
         h, w = img.shape

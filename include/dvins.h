@@ -23,6 +23,10 @@ extern "C" {
 
 #define DV_MEM_HOST   0
 #define DV_MEM_DEVICE 1
+/* OR into `mem` of dv_track_stereo*: gray0 / gray1 point to 8-bit BGR frames (stride in bytes, >= 3 w); they are converted with
+ * cv::cvtColor's fixed-point weights straight into pyramid level 0 (SemanticImage::SetGrayImageGpu, basic/semantic_image.cpp:103-118).
+ * A mask, if given, is single-channel with stride w. */
+#define DV_FMT_BGR    0x100
 
 #define DV_MODE_RAW   0   /* FeatureTracker::TrackImage      (background_tracker.cpp:52-158)  */
 #define DV_MODE_NAIVE 1   /* FeatureTracker::TrackImageNaive (background_tracker.cpp:400-516) */
@@ -101,6 +105,8 @@ int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w,
 int dv_min_eigen(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem);
 /* cv::pyrDown (inside buildOpticalFlowPyramid); dst is ((w+1)/2) x ((h+1)/2), tightly packed */
 int dv_pyr_down(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, int mem);
+/* cv::cvtColor(BGR2GRAY) on 8-bit images: (B 1868 + G 9617 + R 4899 + 8192) >> 14; gray is w x h, tightly packed */
+int dv_bgr2gray(dv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray, int mem);
 /* cv::circle(mask, pt, radius, 0, -1) per point (background_tracker.cpp:79-80) */
 int dv_circle_mask(dv_ctx* ctx, uint8_t* mask, int w, int h, int stride, const float* pts_xy, int n,
                    int radius, int mem);

@@ -46,6 +46,8 @@ typedef struct dvo_feat {
 
 /* cv::pyrDown 8U, 5x5 [1 4 6 4 1]^2 /256, BORDER_REFLECT_101; dst is ((w+1)/2)x((h+1)/2) */
 void dvo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst);
+/* cv::cvtColor(BGR2GRAY) 8U (SemanticImage::SetGrayImage, basic/semantic_image.cpp:95-99); gray tightly packed */
+void dvo_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray);
 
 /* calcScharrDeriv (OpenCV lkpyramid.cpp): out is int16 interleaved (Ix,Iy), w*h*2 */
 void dvo_scharr(const uint8_t* src, int w, int h, int16_t* out);

@@ -545,6 +545,13 @@ void dvo_erode(const uint8_t* src, int w, int h, int k, uint8_t* dst) {
 void dvo_lift_projective(const dvo_cam* cam, const float* pts, int n, float* out) {
     for (int i = 0; i < n; ++i) { double x, y; lift_projective(*cam, pts[2 * i], pts[2 * i + 1], x, y); out[2 * i] = (float)x; out[2 * i + 1] = (float)y; }
 }
+// cv::cvtColor(BGR2GRAY), 8U: fixed-point weights of color_yuv / color_rgb (B2Y 1868, G2Y 9617, R2Y 4899, shift 14)
+void dvo_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray) {
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        const uint8_t* p = bgr + (size_t)y * stride + 3 * x;
+        gray[(size_t)y * w + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
+    }
+}
 dvo_tracker* dvo_tracker_create(const dvo_fe_config* cfg) { auto* t = new dvo_tracker(); t->cfg = *cfg; return t; }
 void dvo_tracker_destroy(dvo_tracker* t) { delete t; }
 int dvo_tracker_track_image(dvo_tracker* t, const uint8_t* g0, const uint8_t* g1, double time, dvo_feat* out) {

@@ -55,6 +55,14 @@ class Oracle:
         lib.dvo_erode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         lib.dvo_lift_projective.argtypes = [C.POINTER(dvo_cam), C.c_void_p, C.c_int, C.c_void_p]
 
+    def bgr2gray(self, bgr):
+        bgr = np.ascontiguousarray(bgr)
+        h, w, _ = bgr.shape
+        out = np.zeros((h, w), np.uint8)
+        self.lib.dvo_bgr2gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        self.lib.dvo_bgr2gray(_p(bgr), w, h, bgr.strides[0], _p(out))
+        return out
+
     def pyr_down(self, img):
         h, w = img.shape
         img = np.ascontiguousarray(img)

@@ -274,3 +274,30 @@ def test_instance_tracker_bit_exact(gpu_ctx_factory, oracle):
         tracked += int((g["track_cnt"] > 1).sum())
         assert len(g["curr_points"]) > 10 and (k == 0 or len(g["right_points"]) > 3)
     assert tracked > 40 and InstFeat.global_id_count == gid
+
+
+@pytest.mark.parametrize("w,h", [(64, 48), (333, 97), (1280, 720)])
+def test_bgr2gray_and_colour_input_bit_exact(gpu_ctx_factory, oracle, w, h):
+    """row N2: cvtColor(BGR2GRAY) fused into pyramid level 0 — operator parity, the mono8 -> BGR -> gray identity
+    (1868 + 9617 + 4899 = 16384), and TrackImage fed BGR frames == TrackImage fed the converted gray frames"""
+    from dynamic_vins_amd.frontend import DV_FMT_BGR, DV_MEM_HOST, DV_MODE_RAW
+    rng = np.random.default_rng(w)
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    ctx = gpu_ctx_factory(width=w, height=h, max_cnt=60, min_dist=12)
+    g = ctx.bgr2gray(bgr)
+    assert np.array_equal(g, oracle.bgr2gray(bgr))
+    ref = ((bgr[..., 0].astype(np.int64) * 1868 + bgr[..., 1].astype(np.int64) * 9617 + bgr[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+    assert np.array_equal(g, ref)
+    gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    assert np.array_equal(ctx.bgr2gray(np.repeat(gray[..., None], 3, 2)), gray)
+    if w >= 320:
+        return
+    seq = synth.PlaneSequence(w, h, seed=4, disparity=2.5, margin=40)
+    c2 = gpu_ctx_factory(width=w, height=h, max_cnt=60, min_dist=12)
+    for k in range(3):
+        l, r = seq.frame(k)
+        lb, rb = np.repeat(l[..., None], 3, 2), np.repeat(r[..., None], 3, 2)
+        lb[..., 0] = np.clip(lb[..., 0].astype(int) + 9, 0, 255); rb[..., 2] = np.clip(rb[..., 2].astype(int) - 7, 0, 255)     # real colour
+        a = ctx.track_stereo(np.ascontiguousarray(lb), np.ascontiguousarray(rb), 0.05 * k, None, DV_MODE_RAW, DV_MEM_HOST | DV_FMT_BGR, stride=3 * w)
+        b = c2.track_stereo(oracle.bgr2gray(lb), oracle.bgr2gray(rb), 0.05 * k)
+        _rows_equal(a, b)

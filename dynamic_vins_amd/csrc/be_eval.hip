@@ -35,12 +35,14 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
     __shared__ d3 tic[2];
     __shared__ double Jb[BE_MAX_OBS_FACTORS][28];
     __shared__ int s_fj[BE_MAX_OBS_FACTORS], s_two[BE_MAX_OBS_FACTORS];
+    __shared__ int s_flist[BE_NF][2];      // per observing frame: the (<= 2: left cam, right cam) two-frame factors whose frame j it is
     __shared__ double s_cost[BE_MAX_OBS_FACTORS];
     __shared__ double s_imu[450 + 450 + 32];
     if (b < nlm) {
         // ------------------------------- landmark -------------------------------
         const BeLm L = a.lm[b];
         be_frame_geom_dev(st, a.dims.nframes, fg, ric, tic, lane);
+        if (lane >= 64 && lane < 64 + 2 * BE_NF) s_flist[(lane - 64) >> 1][(lane - 64) & 1] = -1;
         __syncthreads();
         const double lambda = st->inv_depth[b];
         if (lane < L.count) {
@@ -57,6 +59,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
                 for (int k = 0; k < 12; ++k) { o[2 + k] = Ji[k] * sc; o[14 + k] = Jj[k] * sc; }
                 o[26] = Jl[0] * sc; o[27] = Jl[1] * sc;
                 s_fj[lane] = f.fj; s_two[lane] = f.kind != 2;
+                if (f.kind != 2) s_flist[f.fj][f.kind == 1 ? 1 : 0] = lane;
             }
         }
         __syncthreads();
@@ -72,28 +75,46 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
             else if (e < BE_PK_DD) {
                 const bool is_w = e < BE_PK_GP;
                 const int q = e - (is_w ? BE_PK_W : BE_PK_GP), fa = q / 6, rr = q - fa * 6;
-                for (int f = 0; f < nf; ++f) {
-                    if (!s_two[f]) continue;
-                    const int base = (fa == anchor) ? 2 : ((s_fj[f] == fa) ? 14 : -1);      // offsets, not LDS pointers
-                    if (base < 0) continue;
-                    const double m0 = is_w ? Jb[f][26] : Jb[f][0], m1 = is_w ? Jb[f][27] : Jb[f][1];
-                    v += Jb[f][base + rr] * m0 + Jb[f][base + 6 + rr] * m1;
+                if (fa == anchor) {
+                    for (int f = 0; f < nf; ++f) {
+                        if (!s_two[f]) continue;
+                        const double m0 = is_w ? Jb[f][26] : Jb[f][0], m1 = is_w ? Jb[f][27] : Jb[f][1];
+                        v += Jb[f][2 + rr] * m0 + Jb[f][8 + rr] * m1;
+                    }
+                } else {
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        const int f = s_flist[fa][sl];
+                        if (f < 0) continue;
+                        const double m0 = is_w ? Jb[f][26] : Jb[f][0], m1 = is_w ? Jb[f][27] : Jb[f][1];
+                        v += Jb[f][14 + rr] * m0 + Jb[f][20 + rr] * m1;
+                    }
                 }
             } else if (e < BE_PK_DA) {
                 const int q = e - BE_PK_DD, fa = q / 36, rc = q - fa * 36, rr = rc / 6, cc = rc - rr * 6;
-                for (int f = 0; f < nf; ++f) {
-                    if (!s_two[f]) continue;
-                    const int base = (fa == anchor) ? 2 : ((s_fj[f] == fa) ? 14 : -1);
-                    if (base < 0) continue;
-                    v += Jb[f][base + rr] * Jb[f][base + cc] + Jb[f][base + 6 + rr] * Jb[f][base + 6 + cc];
+                if (fa == anchor) {
+                    for (int f = 0; f < nf; ++f) {
+                        if (!s_two[f]) continue;
+                        v += Jb[f][2 + rr] * Jb[f][2 + cc] + Jb[f][8 + rr] * Jb[f][8 + cc];
+                    }
+                } else {
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        const int f = s_flist[fa][sl];
+                        if (f < 0) continue;
+                        v += Jb[f][14 + rr] * Jb[f][14 + cc] + Jb[f][20 + rr] * Jb[f][20 + cc];
+                    }
                 }
             } else if (e < BE_PK_DA + BE_NF * 36) {
                 const int q = e - BE_PK_DA, fa = q / 36, rc = q - fa * 36, rr = rc / 6, cc = rc - rr * 6;
-                if (fa != anchor)
-                    for (int f = 0; f < nf; ++f) {
-                        if (!s_two[f] || s_fj[f] != fa) continue;
+                if (fa != anchor) {
+#pragma unroll
+                    for (int sl = 0; sl < 2; ++sl) {
+                        const int f = s_flist[fa][sl];
+                        if (f < 0) continue;
                         v += Jb[f][2 + rr] * Jb[f][14 + cc] + Jb[f][8 + rr] * Jb[f][20 + cc];
                     }
+                }
             }
             BE_PK(a.packets, e, b) = v;
         }
@@ -134,7 +155,19 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
         const int n = p->n;
         be_prior_dx_dev(p, st, dx, lane, EV_THREADS);
         __syncthreads();
-        for (int i = lane; i < n; i += EV_THREADS) { double s = 0; const double* row = a.priorA + (size_t)i * n; for (int j = 0; j < n; ++j) s += row[j] * dx[j]; Adx[i] = s; }
+        {   // A' dx with A' symmetric: thread = output entry reading DOWN its column (coalesced across threads), the column split
+            // over EV_THREADS / n_pad thread groups whose partial sums are added in a fixed order
+            __shared__ double part[EV_THREADS];
+            const int n_pad = (n + 63) & ~63, groups = n_pad <= EV_THREADS ? EV_THREADS / n_pad : 1;
+            const int i = lane % n_pad, gI = lane / n_pad;
+            const int seg = (n + groups - 1) / groups, j0 = gI * seg, j1 = min(n, j0 + seg);
+            double s = 0;
+            if (gI < groups && i < n) for (int j = j0; j < j1; ++j) s += a.priorA[(size_t)j * n + i] * dx[j];
+            part[lane] = s;
+            __syncthreads();
+            if (n_pad <= EV_THREADS) { if (lane < n) { double t = part[lane]; for (int q = 1; q < groups; ++q) t += part[q * n_pad + lane]; Adx[lane] = t; } }
+            else for (int r = lane; r < n; r += EV_THREADS) { double t = 0; for (int j = 0; j < n; ++j) t += a.priorA[(size_t)j * n + r] * dx[j]; Adx[r] = t; }
+        }
         __syncthreads();
         if (lane == 0) {
             double bd = 0, dAd = 0;

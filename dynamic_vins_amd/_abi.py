@@ -63,6 +63,7 @@ SIGNATURES = {
     "dv_lift_projective": (C.c_int, [_ctx, C.POINTER(dv_cam), _f32p, C.c_int, _f32p, C.c_int]),
     "dv_lift_projective_offset": (C.c_int, [_ctx, C.POINTER(dv_cam), _f32p, C.c_int, C.c_double, C.c_double, _f32p, C.c_int]),
     "dv_ba_solve": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
+    "dv_ba_eval": (C.c_int, [_ctx, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
     "dv_marginalize": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_proj_eval": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_imu_eval": (C.c_int, [_ctx, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -96,6 +96,17 @@ def ba_solve(ctx, prob: WindowProblem):
     return s
 
 
+def ba_eval(ctx, prob: WindowProblem):
+    """dv_ba_eval -> (cost, S[n, n], g[n]) at the problem's current states"""
+    n, cost = C.c_int(0), C.c_double(0)
+    S = np.zeros(178 * 178)
+    g = np.zeros(178)
+    if ctx.lib.dv_ba_eval(ctx.h, C.byref(prob.c), C.byref(n), C.byref(cost), S.ctypes.data, g.ctypes.data) != 0:
+        raise DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+    k = n.value
+    return cost.value, S[: k * k].reshape(k, k).copy(), g[:k].copy()
+
+
 def proj_eval(ctx, factors, pose_i, pose_j, ex0, ex1, inv_depth, td):
     n = len(factors)
     arrs = [np.ascontiguousarray(a, np.float64) for a in (pose_i, pose_j, ex0, ex1, inv_depth, td)]

@@ -243,7 +243,7 @@ static int be_check_prev_marg(dv_ctx* ctx, BePending& pd) {
     return 0;
 }
 
-int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
+static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eval_only) {
     if (!ctx) return -1;
     BePending& pd = *ctx->be.pend;
     if (pd.active) DV_FAIL("dv_ba_solve: previous solve not collected");
@@ -310,7 +310,7 @@ int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
     const size_t state_bytes = offsetof(BeState, inv_depth) + 8 * (size_t)P->nlm;
     BeCtl* hctl = (BeCtl*)(hp + w.up_ctl);
     std::memset(hctl, 0, sizeof(BeCtl));
-    hctl->need_eval = 1; hctl->first = 1; hctl->max_iters = P->max_iters; hctl->radius = 1e4; hctl->mu = 1e-8; hctl->step_valid = 0;
+    hctl->need_eval = 1; hctl->first = 1; hctl->max_iters = P->max_iters; hctl->radius = 1e4; hctl->mu = eval_only ? 0.0 : 1e-8; hctl->step_valid = 0;
     BeImu* himu = (BeImu*)(hp + w.up_imu);
     for (int k = 0; k < P->nimu; ++k) {
         const double* hint = (k < (int)w.sqrt_hint.size()) ? w.sqrt_hint[k] : nullptr;      // the estimator caches U per pre-integration (Q8)
@@ -347,6 +347,12 @@ int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
     pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
     if (fused) { std::memcpy(pd.gauge_R0, fused->R0, sizeof(pd.gauge_R0)); std::memcpy(pd.gauge_ypr0, fused->ypr0, sizeof(pd.gauge_ypr0)); std::memcpy(pd.gauge_P0, fused->P0, sizeof(pd.gauge_P0)); }
     pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = 1 - w.prior_cur;
+    if (eval_only) {        // dv_ba_eval: one evaluation + assembly of the reduced camera system at the given states (mu = 0)
+        be_launch_eval(ea, true, s);
+        be_launch_reduce(sa, s);
+        DV_CHECK(hipGetLastError());
+        return 0;
+    }
     static const bool force_retry = std::getenv("DVINS_TEST_FORCE_RETRY_TAIL") != nullptr;      // test hook: exercise the spare-slot path of be_solve_fused_end
     const int first_slots = force_retry ? std::max(1, P->max_iters - 2) : P->max_iters;
     { StageScope sc(ctx, "ba_solve", s); if (be_enqueue_slots(ctx, pd, first_slots, s)) return -1; }
@@ -355,6 +361,8 @@ int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) {
     pd.active = true; pd.t_begin = t_begin; pd.t_up = t_up; pd.t_enq = t_enq;
     return 0;
 }
+
+int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) { return be_begin_impl(ctx, P, fused, false); }
 
 int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused) {
     if (!ctx) return -1;
@@ -413,6 +421,34 @@ int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFuse
 extern "C" {
 
 int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) { return be_solve_fused(ctx, P, summary, nullptr); }
+
+int dv_ba_eval(dv_ctx* ctx, const dv_ba_problem* P, int* n_out, double* cost, double* S, double* g) {
+    if (!ctx) return -1;
+    if (!P || !n_out) DV_FAIL("dv_ba_eval: null argument");
+    if (ctx->be.pend->active) DV_FAIL("dv_ba_eval: a solve is in flight");
+    if (be_begin_impl(ctx, const_cast<dv_ba_problem*>(P), nullptr, true)) return -1;
+    BeWork& w = ctx->be;
+    hipStream_t s = ctx->be_stream;
+    const BePending& pd = *w.pend;
+    if (pd.trivial) { w.pend->active = false; *n_out = 0; if (cost) *cost = 0; return 0; }
+    const int n = pd.sa.dims.nstate, NBR = (n + 3) / 4, nblk = NBR * (NBR + 1) / 2;
+    *n_out = n;
+    std::vector<double> blk((size_t)nblk * 16), gv(2 * (size_t)n), lcost((size_t)std::max(P->nlm, 1)), io((size_t)std::max(P->nimu, 1) * IMU_OUT_STRIDE), pc(1);
+    DV_CHECK(hipMemcpyAsync(blk.data(), w.Sc, 8 * blk.size(), hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(gv.data(), w.gvec, 8 * gv.size(), hipMemcpyDeviceToHost, s));
+    if (P->nlm) DV_CHECK(hipMemcpyAsync(lcost.data(), w.packets + (size_t)BE_PK_COST * BE_PK_STRIDE, 8 * (size_t)P->nlm, hipMemcpyDeviceToHost, s));
+    if (P->nimu) DV_CHECK(hipMemcpyAsync(io.data(), w.imu_out, 8 * (size_t)P->nimu * IMU_OUT_STRIDE, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(pc.data(), w.prior_out, 8, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipStreamSynchronize(s));
+    if (cost) { double c = 0; for (int l = 0; l < P->nlm; ++l) c += lcost[l]; for (int k = 0; k < P->nimu; ++k) c += io[(size_t)k * IMU_OUT_STRIDE]; c += pc[0]; *cost = c; }
+    if (g) for (int i = 0; i < n; ++i) g[i] = gv[i] - gv[n + i];
+    if (S) for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) {          // unpack the block-packed lower triangle (be_solve.hip: blk_pos)
+        const int bi = i >> 2, bj = j >> 2;
+        const double v = blk[((size_t)bj * NBR - (size_t)bj * (bj - 1) / 2 + bi - bj) * 16 + (i & 3) * 4 + (j & 3)];
+        S[(size_t)i * n + j] = v; S[(size_t)j * n + i] = v;
+    }
+    return 0;
+}
 
 int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* out_prior, double* out_A, double* out_b, double* diag4) {
     if (!ctx) return -1;

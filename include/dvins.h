@@ -175,6 +175,14 @@ typedef struct dv_ba_summary {
  * The whole trust-region loop runs on the device; states are updated in place. */
 int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* problem, dv_ba_summary* summary);
 
+/* One evaluation at the given states (what one ceres Evaluate() pass + the Schur elimination produce): total cost, the reduced
+ * camera system S = H_pp - sum_l w_l w_l^T / h_l (n x n, row-major, symmetric) and its right-hand side g = g_p - sum_l w_l g_l / h_l.
+ * Column order: per frame, 6 pose columns (if the pose is free) then 9 speed-bias columns (if use_imu); *n = their count.
+ * The sum over landmarks, IMU factors and the prior is linear, so a window sharded BY LANDMARK over several GPUs (IMU factors
+ * and prior on one rank) is assembled by adding the per-rank [S | g | cost] — the all-reduce of SURVEY 8(e)
+ * (dynamic_vins_amd/dist.py:allreduce_reduced_system). cost, S, g may be NULL. */
+int dv_ba_eval(dv_ctx* ctx, const dv_ba_problem* problem, int* n, double* cost, double* S, double* g);
+
 /* Replaces MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks} as driven by
  * Estimator::SetMarginalizationInfo (estimator/estimator.cpp:403-619).
  *   mode 0 = kMarginOld: P holds the linearisation point (all 11 window states), the residual blocks of the landmarks

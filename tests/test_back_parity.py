@@ -200,3 +200,48 @@ def test_prior_round_trip_through_solver(ctx, oracle):
     assert (sd.iterations, sd.successful, sd.termination) == (so.iterations, so.successful, so.termination)
     assert np.isclose(sd.final_cost, so.final_cost, rtol=1e-6)
     assert np.allclose(dev2.pose, ref2.pose, atol=1e-6) and np.allclose(dev2.inv_depth, ref2.inv_depth, atol=1e-6)
+
+
+def _shard(prob, keep, with_imu_prior):
+    """sub-problem holding the landmarks `keep` (and, on one shard only, the IMU factors and the prior) — SURVEY 8(e)"""
+    from dynamic_vins_amd.backend import FACTOR_DTYPE, LM_DTYPE, WindowProblem
+    facs, lms, invd = [], [], []
+    for new_l, l in enumerate(keep):
+        L = prob.landmarks[l]
+        first = len(facs)
+        for f in prob.factors[L["first"]:L["first"] + L["count"]]:
+            f = f.copy(); f["lm"] = new_l; facs.append(f)
+        lms.append((first, L["count"], L["anchor"], L["mask"]))
+        invd.append(prob.inv_depth[l])
+    facs = np.array(facs, FACTOR_DTYPE) if facs else prob.factors[:0]
+    return WindowProblem(prob.pose, prob.speed_bias, prob.ex_pose, prob.td[0], np.array(invd), facs, np.array(lms, LM_DTYPE),
+                         prob.imu if with_imu_prior else prob.imu[:0], prob.c.use_imu, prob.c.plane_kind, prob.c.max_iters, prob.c.g_norm,
+                         prob.prior if with_imu_prior else None, prob.prior_A if with_imu_prior else None, prob.prior_b if with_imu_prior else None)
+
+
+def test_ba_eval_and_landmark_sharding(ctx, oracle):
+    """dv_ba_eval: cost == the solver's initial cost, S symmetric PSD, and the reduced system of a window sharded by landmark over
+    G ranks (round-robin, IMU + prior on rank 0) adds up to the unsharded one — the exchange step of the multi-GPU mode"""
+    from dynamic_vins_amd.backend import ba_eval, ba_solve
+    from dynamic_vins_amd import dist as dv_dist
+    prob = ba_gen.make_window(oracle, seed=12, nlm=90, with_prior=True, max_iters=1)
+    cost, S, g = ba_eval(ctx, prob)
+    n = len(g)
+    assert n == 165 and np.allclose(S, S.T, rtol=0, atol=1e-9 * np.abs(S).max())
+    assert np.linalg.eigvalsh(S).min() > -1e-8 * np.abs(S).max()
+    probe = prob.clone()
+    s = ba_solve(ctx, probe)
+    assert abs(s.initial_cost - cost) <= 1e-12 * cost
+    for G in (2, 3):
+        tot = None
+        for r in range(G):
+            sub = _shard(prob, dv_dist.shard_landmarks(prob.c.nlm, r, G), r == 0)
+            c, Sr, gr = ba_eval(ctx, sub)
+            v = np.concatenate([Sr.ravel(), gr, [c]])
+            tot = v if tot is None else tot + v            # rank-ordered sum, as allreduce_reduced_system forms it
+        assert np.abs(tot[: n * n].reshape(n, n) - S).max() <= 1e-11 * np.abs(S).max()
+        assert np.abs(tot[n * n: n * n + n] - g).max() <= 1e-11 * max(1.0, np.abs(g).max())
+        assert abs(tot[-1] - cost) <= 1e-12 * cost
+    # the Gauss-Newton direction of the reduced system is a descent direction of the cost it came from
+    dx = -np.linalg.solve(S + 1e-9 * np.eye(n) * np.abs(S).max(), g)
+    assert g @ dx < 0

@@ -164,7 +164,6 @@ struct Marginalizer {         // MarginalizationInfo::{addResidualBlockInfo,preM
         std::vector<double> ev; Mat V;
         sym_eig(Amm, ev, V);
         const double eps = 1e-8;
-        if (getenv("DVO_DEBUG_MARG")) fprintf(stderr, "marg m=%d n=%d Amm ev min=%.3e max=%.3e\n", m, n, ev.front(), ev.back());
         Mat Amm_inv(m, m);
         for (int k = 0; k < m; ++k) { if (!(ev[k] > eps)) continue; const double inv = 1.0 / ev[k]; for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm_inv(i, j) += V(i, k) * inv * V(j, k); }
         // A' = Arr - Arm Amm^-1 Amr ; b' = brr - Arm Amm^-1 bmm
@@ -180,23 +179,6 @@ struct Marginalizer {         // MarginalizationInfo::{addResidualBlockInfo,preM
         for (int i = 0; i < n; ++i) for (int j = i + 1; j < n; ++j) { double s = 0.5 * (Ap(i, j) + Ap(j, i)); Ap(i, j) = Ap(j, i) = s; }   // SelfAdjointEigenSolver reads one triangle
         std::vector<double> ev2; Mat V2;
         sym_eig(Ap, ev2, V2);
-        if (getenv("DVO_DEBUG_MARG")) { int nz = 0; for (double e : ev2) if (!(e > eps)) nz++; fprintf(stderr, "   A' ev[0..5]= %.3e %.3e %.3e %.3e %.3e %.3e max=%.3e clamped=%d\n", ev2[0], ev2[1], ev2[2], ev2[3], ev2[4], ev2[5], ev2.back(), nz); }
-        if (getenv("DVO_DEBUG_MARG")) {
-            // experiment: c0 from eigen-clamp vs from a diagonally pivoted LDL^T stopped at a pivot tolerance
-            double c_eig = 0; for (int k = 0; k < n; ++k) if (ev2[k] > eps) { double vb = 0; for (int i = 0; i < n; ++i) vb += V2(i, k) * bp[i]; c_eig += vb * vb / ev2[k]; }
-            for (double tol : { 1e-8, 1e-5, 1e-3, 1e-1 }) {
-                Mat W = Ap; std::vector<double> y = bp; std::vector<int> perm(n); for (int i = 0; i < n; ++i) perm[i] = i;
-                double c = 0; int rank = 0;
-                for (int k = 0; k < n; ++k) {
-                    int p = k; for (int i = k + 1; i < n; ++i) if (W(i, i) > W(p, p)) p = i;
-                    if (p != k) { for (int j = 0; j < n; ++j) std::swap(W(k, j), W(p, j)); for (int j = 0; j < n; ++j) std::swap(W(j, k), W(j, p)); std::swap(y[k], y[p]); }
-                    double d = W(k, k); if (!(d > tol)) break; rank++;
-                    c += y[k] * y[k] / d;
-                    for (int i = k + 1; i < n; ++i) { double l = W(i, k) / d; y[i] -= l * y[k]; for (int j = k + 1; j < n; ++j) W(i, j) -= l * W(k, j); }
-                }
-                fprintf(stderr, "   c0 eig=%.9e  ldlt(tol=%.0e)=%.9e rank=%d reldiff=%.2e\n", c_eig, tol, c, rank, (c - c_eig) / c_eig);
-            }
-        }
         out->J0 = Mat(n, n); out->r0.assign(n, 0.0);
         for (int k = 0; k < n; ++k) {
             const double S = ev2[k] > eps ? ev2[k] : 0.0, Sinv = ev2[k] > eps ? 1.0 / ev2[k] : 0.0;

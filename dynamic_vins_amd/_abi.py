@@ -56,6 +56,7 @@ SIGNATURES = {
     "dv_gftt": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f32p,
                           C.POINTER(C.c_int), C.c_int]),
     "dv_min_eigen": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
+    "dv_viode_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, _u8p, _u8p, C.c_void_p, C.c_void_p]),
     "dv_bgr2gray": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "dv_pyr_down": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "dv_circle_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]),

@@ -433,6 +433,36 @@ int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w,
     return 0;
 }
 
+int dv_viode_mask(dv_ctx* ctx, const uint8_t* seg_bgr, int w, int h, int stride, const uint32_t* dyn_keys, int nkeys, uint8_t* merge_mask, uint8_t* inv_merge_mask,
+                  uint32_t* key_image, int32_t* boxes) {
+    if (!ctx) return -1;
+    if (!seg_bgr || !dyn_keys || !merge_mask || !inv_merge_mask || !boxes || w <= 0 || h <= 0 || stride < 3 * w) DV_FAIL("dv_viode_mask: bad argument");
+    if (nkeys < 1 || nkeys > 64) DV_FAIL("dv_viode_mask: 1..64 dynamic keys");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = ctx->stream;
+    const int sp = align_up(3 * w, 16), mp = align_up(w, 16);
+    DV_CHECK(ctx->s0.ensure((size_t)sp * h));                             // label image
+    DV_CHECK(ctx->s1.ensure((size_t)mp * h)); DV_CHECK(ctx->s2.ensure((size_t)mp * h));      // merge, inverse
+    DV_CHECK(ctx->s3.ensure((size_t)4 * w * h + 4096));                    // key image | keys | boxes
+    DV_CHECK(ctx->s4.ensure(4096));
+    uint32_t* d_keys = (uint32_t*)ctx->s4.p; int32_t* d_box = (int32_t*)((uint8_t*)ctx->s4.p + 1024);
+    int32_t init[256];
+    for (int k = 0; k < 64; ++k) { init[4 * k] = 0x7fffffff; init[4 * k + 1] = -1; init[4 * k + 2] = 0x7fffffff; init[4 * k + 3] = -1; }
+    DV_CHECK(hipMemcpy2DAsync(ctx->s0.p, sp, seg_bgr, stride, (size_t)3 * w, h, hipMemcpyHostToDevice, s));
+    DV_CHECK(hipMemcpyAsync(d_keys, dyn_keys, 4 * (size_t)nkeys, hipMemcpyHostToDevice, s));
+    DV_CHECK(hipMemcpyAsync(d_box, init, 16 * (size_t)nkeys, hipMemcpyHostToDevice, s));
+    DV_CHECK(hipStreamSynchronize(s));                                     // init[] is a stack object
+    dv_launch_viode_mask((const uint8_t*)ctx->s0.p, w, h, sp, d_keys, nkeys, (uint8_t*)ctx->s1.p, (uint8_t*)ctx->s2.p, mp, key_image ? (uint32_t*)ctx->s3.p : nullptr, d_box, s);
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipMemcpy2DAsync(merge_mask, w, ctx->s1.p, mp, w, h, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpy2DAsync(inv_merge_mask, w, ctx->s2.p, mp, w, h, hipMemcpyDeviceToHost, s));
+    if (key_image) DV_CHECK(hipMemcpyAsync(key_image, ctx->s3.p, (size_t)4 * w * h, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(boxes, d_box, 16 * (size_t)nkeys, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipStreamSynchronize(s));
+    for (int k = 0; k < nkeys; ++k) if (boxes[4 * k + 1] < 0) { boxes[4 * k] = boxes[4 * k + 2] = -1; boxes[4 * k + 3] = -1; }      // key not present
+    return 0;
+}
+
 int dv_bgr2gray(dv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray, int mem) {
     if (!ctx) return -1;
     if (!bgr || !gray || w <= 0 || h <= 0 || stride < 3 * w) DV_FAIL("dv_bgr2gray: bad argument");

@@ -192,3 +192,40 @@ void dv_launch_lift(const dv_cam& cam, const float2* in, int n, double off_x, do
     if (n <= 0) return;
     hipLaunchKernelGGL(lift_kernel, dim3((n + 255) / 256), dim3(256), 0, s, cam, in, n, off_x, off_y, out);
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// VIODE segmentation image -> instance masks: VIODE::SetViodeMaskSimple / BuildViodeMask
+// (utils/dataset/viode_utils.cpp:21-170).  key = r*1000000 + g*1000*b  (viode_utils.h:23-26: the product, sic); a pixel
+// is dynamic if its key is one of `dyn_keys` (the keys whose label index is in ViodeDynamicIndex).  One pass over the
+// BGR label image: merge mask (255 = object), its inverse, optionally the key image, and per key the bounding box of its
+// pixels (row_min, row_max, col_min, col_max) via workgroup-local then global integer min/max (order independent).
+#define VIODE_MAX_KEYS 64
+__global__ __launch_bounds__(256) void viode_mask_kernel(const uint8_t* __restrict__ seg, int w, int h, int spitch, const uint32_t* __restrict__ dyn_keys, int nkeys,
+                                                         uint8_t* __restrict__ merge, uint8_t* __restrict__ inv, int mpitch, uint32_t* __restrict__ key_img, int32_t* __restrict__ boxes) {
+    __shared__ uint32_t s_keys[VIODE_MAX_KEYS];
+    __shared__ int s_box[VIODE_MAX_KEYS][4];
+    const int t = threadIdx.y * blockDim.x + threadIdx.x;
+    if (t < nkeys) { s_keys[t] = dyn_keys[t]; s_box[t][0] = 0x7fffffff; s_box[t][1] = -1; s_box[t][2] = 0x7fffffff; s_box[t][3] = -1; }
+    __syncthreads();
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+    if (x < w && y < h) {
+        const uint8_t* p = seg + (size_t)y * spitch + 3 * x;
+        const uint32_t key = (uint32_t)p[2] * 1000000u + (uint32_t)p[1] * 1000u * (uint32_t)p[0];
+        int hit = -1;
+        for (int k = 0; k < nkeys; ++k) if (s_keys[k] == key) { hit = k; break; }
+        merge[(size_t)y * mpitch + x] = hit >= 0 ? 255 : 0;
+        inv[(size_t)y * mpitch + x] = hit >= 0 ? 0 : 255;
+        if (key_img) key_img[(size_t)y * w + x] = key;
+        if (hit >= 0) { atomicMin(&s_box[hit][0], y); atomicMax(&s_box[hit][1], y); atomicMin(&s_box[hit][2], x); atomicMax(&s_box[hit][3], x); }
+    }
+    __syncthreads();
+    if (t < nkeys && s_box[t][1] >= 0) {
+        atomicMin(&boxes[4 * t + 0], s_box[t][0]); atomicMax(&boxes[4 * t + 1], s_box[t][1]);
+        atomicMin(&boxes[4 * t + 2], s_box[t][2]); atomicMax(&boxes[4 * t + 3], s_box[t][3]);
+    }
+}
+void dv_launch_viode_mask(const uint8_t* seg, int w, int h, int spitch, const uint32_t* dyn_keys, int nkeys, uint8_t* merge, uint8_t* inv, int mpitch,
+                          uint32_t* key_img, int32_t* boxes, hipStream_t s) {
+    hipLaunchKernelGGL(viode_mask_kernel, dim3((w + 63) / 64, (h + 3) / 4), dim3(64, 4), 0, s, seg, w, h, spitch, dyn_keys, nkeys, merge, inv, mpitch, key_img, boxes);
+}

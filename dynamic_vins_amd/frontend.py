@@ -120,6 +120,17 @@ class Context:
         self._check(self.lib.dv_min_eigen(self.h, _ptr(img), w, h, img.strides[0], _ptr(eig), DV_MEM_HOST))
         return eig
 
+    def viode_mask(self, seg_bgr, dyn_keys, want_keys=True):
+        """VIODE::SetViodeMaskSimple / BuildViodeMask -> (merge_mask, inv_merge_mask, key_image or None, boxes[nkeys, 4])"""
+        seg = np.ascontiguousarray(seg_bgr)
+        h, w, _ = seg.shape
+        keys = np.ascontiguousarray(dyn_keys, np.uint32)
+        merge, inv = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8)
+        kimg = np.zeros((h, w), np.uint32) if want_keys else None
+        boxes = np.zeros((len(keys), 4), np.int32)
+        self._check(self.lib.dv_viode_mask(self.h, _ptr(seg), w, h, seg.strides[0], _ptr(keys), len(keys), _ptr(merge), _ptr(inv), _ptr(kimg), _ptr(boxes)))
+        return merge, inv, kimg, boxes
+
     def bgr2gray(self, bgr):
         """cv::cvtColor(BGR2GRAY) of an (h, w, 3) uint8 image"""
         bgr = np.ascontiguousarray(bgr)
@@ -215,7 +226,7 @@ class InstFeat:
     Shi-Tomasi top-up inside the eroded instance mask, undistortion with the 2-D box offset, right-image LK on the
     full frames.  Host composition of the C-ABI operators (dv_track_by_lk, dv_erode, dv_circle_mask, dv_gftt,
     dv_lift_projective_offset); every pixel / index result is bit-exact against the oracle's dvo_inst_track.
-    The VIODE segmentation-key test of TrackRightByPad is not applied."""
+    The VIODE segmentation-key test of TrackRightByPad is applied when the key image of the right frame (Context.viode_mask) is given."""
 
     global_id_count = 1        # InstFeat::global_id_count (static, shared with the background tracker in the reference)
 
@@ -227,7 +238,7 @@ class InstFeat:
         self.track_cnt = np.zeros(0, np.int32)
         self.prev_roi_gray = None
 
-    def Track(self, roi_gray, roi_mask, box_tl, gray0, gray1=None):
+    def Track(self, roi_gray, roi_mask, box_tl, gray0, gray1=None, seg1_keys=None, key=None):
         """one frame; returns dict(curr_points, ids, track_cnt, curr_un_points, right_points, right_ids, right_un_points)"""
         ctx = self.ctx
         roi_gray = np.ascontiguousarray(roi_gray)
@@ -255,6 +266,9 @@ class InstFeat:
         if gray1 is not None and len(curr):                                         # TrackRightByPad
             padded = (curr + np.array(box_tl, np.float32)).astype(np.float32)
             rp, st = ctx.track_by_lk(gray0, gray1, padded, self.flow_back, 0.5)
+            if seg1_keys is not None:                                              # VIODE::PixelToKey(right_points[i], img.seg1) != id -> lost
+                xi = np.rint(rp[:, 0]).astype(int).clip(0, seg1_keys.shape[1] - 1); yi = np.rint(rp[:, 1]).astype(int).clip(0, seg1_keys.shape[0] - 1)
+                st = np.where((st > 0) & (seg1_keys[yi, xi] == key), 1, 0).astype(np.uint8)
             keep = st > 0
             out["right_points"], out["right_ids"] = rp[keep], ids[keep]
             out["right_un_points"] = ctx.lift_projective(self.cam1, rp[keep])

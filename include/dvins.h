@@ -105,6 +105,13 @@ int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w,
 int dv_min_eigen(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem);
 /* cv::pyrDown (inside buildOpticalFlowPyramid); dst is ((w+1)/2) x ((h+1)/2), tightly packed */
 int dv_pyr_down(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, int mem);
+/* VIODE segmentation image -> instance masks (VIODE::SetViodeMaskSimple / BuildViodeMask, utils/dataset/viode_utils.cpp:21-170).
+ * key(pixel) = r*1000000 + g*1000*b (viode_utils.h:23-26, sic); a pixel is an object pixel if its key is in dyn_keys[nkeys <= 64].
+ * merge_mask: 255 = object; inv_merge_mask: its complement (what TrackImageNaive / TrackSemanticImage take); key_image (optional,
+ * w*h uint32): the key of every pixel (PixelToKey lookups of TrackRightByPad); boxes[nkeys][4] = row_min,row_max,col_min,col_max of
+ * each key's pixels, -1 if absent (InstanceSimple).  Host buffers, tightly packed outputs. */
+int dv_viode_mask(dv_ctx* ctx, const uint8_t* seg_bgr, int w, int h, int stride, const uint32_t* dyn_keys, int nkeys,
+                  uint8_t* merge_mask, uint8_t* inv_merge_mask, uint32_t* key_image, int32_t* boxes);
 /* cv::cvtColor(BGR2GRAY) on 8-bit images: (B 1868 + G 9617 + R 4899 + 8192) >> 14; gray is w x h, tightly packed */
 int dv_bgr2gray(dv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray, int mem);
 /* cv::circle(mask, pt, radius, 0, -1) per point (background_tracker.cpp:79-80) */

@@ -46,6 +46,8 @@ typedef struct dvo_feat {
 
 /* cv::pyrDown 8U, 5x5 [1 4 6 4 1]^2 /256, BORDER_REFLECT_101; dst is ((w+1)/2)x((h+1)/2) */
 void dvo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst);
+/* VIODE label image -> masks / key image / per-key bounding boxes (utils/dataset/viode_utils.cpp:21-170) */
+void dvo_viode_mask(const uint8_t* seg_bgr, int w, int h, int stride, const uint32_t* dyn_keys, int nkeys, uint8_t* merge, uint8_t* inv, uint32_t* key_img, int32_t* boxes);
 /* cv::cvtColor(BGR2GRAY) 8U (SemanticImage::SetGrayImage, basic/semantic_image.cpp:95-99); gray tightly packed */
 void dvo_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray);
 

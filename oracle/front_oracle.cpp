@@ -545,6 +545,23 @@ void dvo_erode(const uint8_t* src, int w, int h, int k, uint8_t* dst) {
 void dvo_lift_projective(const dvo_cam* cam, const float* pts, int n, float* out) {
     for (int i = 0; i < n; ++i) { double x, y; lift_projective(*cam, pts[2 * i], pts[2 * i + 1], x, y); out[2 * i] = (float)x; out[2 * i + 1] = (float)y; }
 }
+// VIODE::SetViodeMaskSimple / BuildViodeMask (utils/dataset/viode_utils.cpp:21-170): key = r*1000000 + g*1000*b (viode_utils.h:23-26, sic)
+void dvo_viode_mask(const uint8_t* seg, int w, int h, int stride, const uint32_t* dyn_keys, int nkeys, uint8_t* merge, uint8_t* inv, uint32_t* key_img, int32_t* boxes) {
+    for (int k = 0; k < nkeys; ++k) { boxes[4 * k] = boxes[4 * k + 1] = boxes[4 * k + 2] = boxes[4 * k + 3] = -1; }
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        const uint8_t* p = seg + (size_t)y * stride + 3 * x;
+        const uint32_t key = (uint32_t)p[2] * 1000000u + (uint32_t)p[1] * 1000u * (uint32_t)p[0];
+        int hit = -1;
+        for (int k = 0; k < nkeys; ++k) if (dyn_keys[k] == key) { hit = k; break; }
+        merge[(size_t)y * w + x] = hit >= 0 ? 255 : 0; inv[(size_t)y * w + x] = hit >= 0 ? 0 : 255;
+        if (key_img) key_img[(size_t)y * w + x] = key;
+        if (hit >= 0) {
+            int32_t* b = boxes + 4 * hit;
+            if (b[1] < 0) { b[0] = b[1] = y; b[2] = b[3] = x; }
+            else { b[0] = std::min(b[0], y); b[1] = std::max(b[1], y); b[2] = std::min(b[2], x); b[3] = std::max(b[3], x); }
+        }
+    }
+}
 // cv::cvtColor(BGR2GRAY), 8U: fixed-point weights of color_yuv / color_rgb (B2Y 1868, G2Y 9617, R2Y 4899, shift 14)
 void dvo_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray) {
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {

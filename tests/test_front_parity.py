@@ -301,3 +301,25 @@ def test_bgr2gray_and_colour_input_bit_exact(gpu_ctx_factory, oracle, w, h):
         a = ctx.track_stereo(np.ascontiguousarray(lb), np.ascontiguousarray(rb), 0.05 * k, None, DV_MODE_RAW, DV_MEM_HOST | DV_FMT_BGR, stride=3 * w)
         b = c2.track_stereo(oracle.bgr2gray(lb), oracle.bgr2gray(rb), 0.05 * k)
         _rows_equal(a, b)
+
+
+def test_viode_mask_bit_exact(gpu_ctx_factory, oracle):
+    """row N4: VIODE label image -> merge / inverse masks, key image, per-key boxes"""
+    import ctypes as C
+    w, h = 333, 201
+    rng = np.random.default_rng(3)
+    palette = np.array([[10, 20, 30], [200, 3, 77], [0, 0, 0], [255, 255, 255], [9, 250, 1], [77, 77, 77]], np.uint8)      # b g r
+    seg = palette[rng.integers(0, 2, (h, w))]                      # background labels
+    seg[40:90, 100:180] = palette[2]; seg[120:150, 10:60] = palette[3]; seg[5:9, 300:333] = palette[4]     # three objects
+    key = lambda p: int(p[2]) * 1000000 + int(p[1]) * 1000 * int(p[0])
+    dyn = np.array([key(palette[2]), key(palette[3]), key(palette[4]), key(palette[5])], np.uint32)          # the last one is absent
+    ctx = gpu_ctx_factory(width=64, height=48)
+    merge, inv, kimg, boxes = ctx.viode_mask(seg, dyn)
+    om, oi, ok_, ob = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint32), np.zeros((4, 4), np.int32)
+    oracle.lib.dvo_viode_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    segc = np.ascontiguousarray(seg)
+    oracle.lib.dvo_viode_mask(segc.ctypes.data, w, h, segc.strides[0], dyn.ctypes.data, 4, om.ctypes.data, oi.ctypes.data, ok_.ctypes.data, ob.ctypes.data)
+    assert np.array_equal(merge, om) and np.array_equal(inv, oi) and np.array_equal(kimg, ok_) and np.array_equal(boxes, ob)
+    assert np.array_equal(inv, 255 - merge) and merge[40:90, 100:180].all() and not merge[0, 0]
+    assert list(boxes[0]) == [40, 89, 100, 179] and list(boxes[2]) == [5, 8, 300, 332] and list(boxes[3]) == [-1, -1, -1, -1]
+    assert kimg[45, 120] == 0 and kimg[130, 20] == 255 * 1000000 + 255 * 1000 * 255          # key = r*1e6 + g*1000*b (sic)

@@ -53,11 +53,13 @@ __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
     __shared__ int s_disc[DISC_CAP][2];
     __shared__ int s_ndisc;
     __shared__ unsigned s_max[4];
+    __shared__ DvCand s_cand[TW * TH];          // every pixel of a plateau is a candidate (v >= all neighbours), so the cap is the tile
+    __shared__ int s_ncand, s_base;
     const int tid = threadIdx.x;
     if (a.n_feat && a.max_cnt - *a.n_feat < a.min_new) return;     // no detection wanted this frame
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int w = a.w, h = a.h;
-    if (tid == 0) s_ndisc = 0;
+    if (tid == 0) { s_ndisc = 0; s_ncand = 0; }
     for (int i = tid; i < IMG_H * IMG_PITCH; i += 256) {
         int r = i / IMG_PITCH, c = i - r * IMG_PITCH;
         if (c < IMG_W) {
@@ -150,12 +152,9 @@ __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
         float mx = nb[0], mn = nb[0];
 #pragma unroll
         for (int k = 1; k < 8; ++k) { mx = fmaxf(mx, nb[k]); mn = fminf(mn, nb[k]); }
-        if (v >= mx) {
-            int k = atomicAdd(a.n_cand, 1);
-            if (k < a.cand_cap) {
-                DvCand cd; cd.key = ((unsigned long long)f2ord(v) << 32) | (unsigned)(y * w + x); cd.min_nb = mn; cd.pad = 0;
-                a.cand[k] = cd;
-            }
+        if (v >= mx) {          // candidates are collected in LDS: ONE global atomic per tile instead of one per candidate
+            const int k = atomicAdd(&s_ncand, 1);
+            if (k < TW * TH) { DvCand cd; cd.key = ((unsigned long long)f2ord(v) << 32) | (unsigned)(y * w + x); cd.min_nb = mn; cd.pad = 0; s_cand[k] = cd; }
         }
     }
     // workgroup max -> one atomic
@@ -163,10 +162,14 @@ __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
     for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (unsigned)__shfl_xor((int)vmax, o));
     if ((tid & 63) == 0) s_max[tid >> 6] = vmax;
     __syncthreads();
+    const int nc = min(s_ncand, TW * TH);
     if (tid == 0) {
         unsigned m = max(max(s_max[0], s_max[1]), max(s_max[2], s_max[3]));
         if (m) atomicMax(a.max_ord, m);
+        s_base = nc ? atomicAdd(a.n_cand, nc) : 0;
     }
+    __syncthreads();
+    for (int i = tid; i < nc; i += 256) { const int k = s_base + i; if (k < a.cand_cap) a.cand[k] = s_cand[i]; }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -121,7 +121,14 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
     } else if (b < nlm + nimu) {
         // ------------------------------- IMU factor -------------------------------
         const int k = b - nlm;
-        const BeImu* m = &a.imu[k];
+        // the factor record (pre-integrated deltas, bias Jacobians, sqrt-information: 2.4 KB) is staged in LDS by all threads:
+        // lane 0's raw evaluation and the whitening loops then read LDS instead of chasing dependent global loads
+        __shared__ BeImu s_m;
+        {
+            const double* src = reinterpret_cast<const double*>(&a.imu[k]); double* dst = reinterpret_cast<double*>(&s_m);
+            for (int i = lane; i < (int)(sizeof(BeImu) / 8); i += EV_THREADS) dst[i] = src[i];
+        }
+        const BeImu* m = &s_m;
         double* Jraw = s_imu; double* Jw = s_imu + 450; double* rr = s_imu + 900;      // rr[0..14] raw, rr[15..29] whitened
         for (int i = lane; i < 450; i += EV_THREADS) Jraw[i] = 0.0;
         __syncthreads();

@@ -128,6 +128,12 @@ void dvo_imu_eval(const dvo_preint*, double g_norm, const double* const* par, do
 /* line and dynamic-object factors (obj_factors.cpp); Jacobians in the reference's global block sizes, row-major, any J[k] may be NULL */
 void dvo_line_eval(const double* obs4, const double* sqrt_info4, const double* const* par /* pose7, ex7, orth4 */, double* res2, double** J /* 2x7, 2x7, 2x4 */);
 void dvo_line_plus(const double* orth4, const double* delta4, double* out4);      /* LineOrthParameterization::Plus */
+/* line geometry + two-view line triangulation (line_detector/line_geometry.cpp:75-296, estimator/vio_util.cpp:447-561) */
+void dvo_plk_to_orth(const double* plk6, double* orth4);
+void dvo_orth_to_plk(const double* orth4, double* plk6);
+int dvo_line_trimming(const double* plk6, const double* obs4, double* p1, double* p2);
+int dvo_triangulate_line(const double* obs, int nobs, int start_frame, const double* Rs, const double* Ps, const double* ric9, const double* tic3,
+                         double* plk6, double* ptw1, double* ptw2);
 void dvo_box_enclose_eval(const double* pts_w3, const double* dims3, const double* const* par /* pose_obj7 */, double* res3, double** J /* 3x7 */);
 void dvo_box_dims_eval(const double* dims3, const double* const* par /* box3 */, double* res1, double** J /* 1x3 */);
 void dvo_box_orientation_eval(const double* R_cioi9, const double* R_bc9, const double* const* par /* pose_body7, pose_obj7 */, double* res3, double** J /* 3x7, 3x7 */);

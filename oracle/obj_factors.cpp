@@ -186,4 +186,65 @@ void dvo_box_orientation_eval(const double* R_cioi9, const double* R_bc9, const 
     }
 }
 
+// ---- line geometry (line_detector/line_geometry.cpp:75-296) and two-view line triangulation (estimator/vio_util.cpp:447-561) ----
+void dvo_plk_to_orth(const double* plk6, double* orth4) {
+    const V3 n(plk6[0], plk6[1], plk6[2]), v(plk6[3], plk6[4], plk6[5]);
+    const V3 u1 = n / n.norm(), u2 = v / v.norm(), u3 = u1.cross(u2);
+    const double nn = n.norm(), vn = v.norm(), wn = std::sqrt(nn * nn + vn * vn);
+    orth4[0] = std::atan2(u2.z, u3.z); orth4[1] = std::asin(-u1.z); orth4[2] = std::atan2(u1.y, u1.x); orth4[3] = std::asin(vn / wn);
+}
+void dvo_orth_to_plk(const double* orth4, double* plk6) { const Plk p = orth_to_plk(orth4); for (int k = 0; k < 3; ++k) { plk6[k] = p.n[k]; plk6[3 + k] = p.v[k]; } }
+static void pi_from_ppp(const V3& x1, const V3& x2, const V3& x3, double pi[4]) { const V3 n = (x1 - x3).cross(x2 - x3); pi[0] = n.x; pi[1] = n.y; pi[2] = n.z; pi[3] = -x3.dot(x1.cross(x2)); }
+static void pipi_plk(const double a[4], const double b[4], double plk[6]) {
+    auto dp = [&](int i, int j) { return a[i] * b[j] - b[i] * a[j]; };
+    plk[0] = dp(0, 3); plk[1] = dp(1, 3); plk[2] = dp(2, 3); plk[3] = -dp(1, 2); plk[4] = dp(0, 2); plk[5] = -dp(0, 1);
+}
+int dvo_line_trimming(const double* plk6, const double* obs4, double* p1, double* p2) {
+    const V3 nc(plk6[0], plk6[1], plk6[2]), vc(plk6[3], plk6[4], plk6[5]);
+    const M3 S = skew(nc);
+    auto Lc = [&](const double pi[4], double e[4]) { for (int r = 0; r < 3; ++r) e[r] = S(r, 0) * pi[0] + S(r, 1) * pi[1] + S(r, 2) * pi[2] + vc[r] * pi[3]; e[3] = -(vc.x * pi[0] + vc.y * pi[1] + vc.z * pi[2]); };
+    const V3 p11(obs4[0], obs4[1], 1.0), p21(obs4[2], obs4[3], 1.0);
+    const V3 c = p11.cross(p21);
+    const double ln = std::sqrt(c.x * c.x + c.y * c.y), lx = c.x / ln, ly = c.y / ln;
+    const V3 p12(p11.x + lx, p11.y + ly, 1.0), p22(p21.x + lx, p21.y + ly, 1.0), cam(0, 0, 0);
+    double pi1[4], pi2[4], e1[4], e2[4];
+    pi_from_ppp(cam, p11, p12, pi1); pi_from_ppp(cam, p21, p22, pi2);
+    Lc(pi1, e1); Lc(pi2, e2);
+    for (int k = 0; k < 3; ++k) { p1[k] = e1[k] / e1[3]; p2[k] = e2[k] / e2[3]; }
+    return p1[2] >= 0 && p2[2] >= 0;
+}
+// obs: nobs x 4 (frame start_frame + k); Rs: 11 x 9 row-major, Ps: 11 x 3; returns 1 and fills plk6 / ptw1 / ptw2 on success
+int dvo_triangulate_line(const double* obs, int nobs, int start_frame, const double* Rs, const double* Ps, const double* ric9, const double* tic3,
+                         double* plk6, double* ptw1, double* ptw2) {
+    auto M = [](const double* p) { M3 m; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) m(i, j) = p[i * 3 + j]; return m; };
+    const M3 ric = M(ric9); const V3 tic(tic3[0], tic3[1], tic3[2]);
+    const int i = start_frame;
+    const M3 Ri = M(Rs + 9 * i); const V3 Pi(Ps[3 * i], Ps[3 * i + 1], Ps[3 * i + 2]);
+    const V3 t0 = Pi + Ri * tic; const M3 R0 = Ri * ric;
+    double min_cos = 1.0, pii[4] = { 0, 0, 0, 0 }; V3 ni, tij; M3 Rij; const double* obsj = nullptr;
+    for (int k = 0; k < nobs; ++k) {
+        const double* o = obs + 4 * k; const int j = i + k;
+        if (k == 0) { pi_from_ppp(V3(o[0], o[1], 1), V3(o[2], o[3], 1), V3(0, 0, 0), pii); ni = V3(pii[0], pii[1], pii[2]).normalized(); continue; }
+        const M3 Rj = M(Rs + 9 * j); const V3 Pj(Ps[3 * j], Ps[3 * j + 1], Ps[3 * j + 2]);
+        const V3 t1 = Pj + Rj * tic; const M3 R1 = Rj * ric;
+        const V3 t = R0.t() * (t1 - t0); const M3 R = R0.t() * R1;
+        const V3 p3 = R * V3(o[0], o[1], 1) + t, p4 = R * V3(o[2], o[3], 1) + t;
+        double pij[4]; pi_from_ppp(p3, p4, t, pij);
+        const V3 nj = V3(pij[0], pij[1], pij[2]).normalized();
+        const double c = ni.dot(nj);
+        if (c < min_cos) { min_cos = c; tij = t; Rij = R; obsj = o; }
+    }
+    if (min_cos > 0.998 || !obsj) return 0;
+    const V3 p3 = Rij * V3(obsj[0], obsj[1], 1) + tij, p4 = Rij * V3(obsj[2], obsj[3], 1) + tij;
+    double pij[4]; pi_from_ppp(p3, p4, tij, pij);
+    pipi_plk(pii, pij, plk6);
+    double e1[3], e2[3];
+    if (!dvo_line_trimming(plk6, obs, e1, e2)) return 0;
+    const V3 a(e1[0], e1[1], e1[2]), b(e2[0], e2[1], e2[2]);
+    if ((a - b).norm() > 10.0) return 0;
+    const V3 w1 = Ri * (ric * a + tic) + Pi, w2 = Ri * (ric * b + tic) + Pi;
+    for (int k = 0; k < 3; ++k) { ptw1[k] = w1[k]; ptw2[k] = w2[k]; }
+    return 1;
+}
+
 }  // extern "C"

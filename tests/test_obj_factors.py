@@ -121,3 +121,60 @@ def test_hip_object_factors_match_oracle(gpu_ctx_factory, oracle):
     from dynamic_vins_amd._abi import DvinsError
     with pytest.raises(DvinsError):
         B.line_eval(ctx, fac[:0], d["pose"][:0], d["ex"][:0], d["orth"][:0])
+
+
+def test_line_geometry_and_triangulation(oracle):
+    """numpy mirror (dynamic_vins_amd/line_geometry.py) vs the oracle's C++ restatement, plus the geometry itself: a 3-D segment
+    seen from a moving camera is triangulated back, its end points land on the segment, orth <-> Plücker round-trips"""
+    import ctypes as C
+    from dynamic_vins_amd import line_geometry as LG, sim
+    lib = oracle.lib
+    rng = np.random.default_rng(9)
+    V = C.c_void_p
+    lib.dvo_triangulate_line.restype = C.c_int
+    lib.dvo_triangulate_line.argtypes = [V, C.c_int, C.c_int, V, V, V, V, V, V, V]
+    lib.dvo_line_trimming.restype = C.c_int
+    lib.dvo_line_trimming.argtypes = [V] * 4
+    lib.dvo_plk_to_orth.argtypes = [V, V]; lib.dvo_orth_to_plk.argtypes = [V, V]
+    traj = sim.Trajectory()
+    ric, tic = sim.R_IC, sim.T_IC0
+    ok = 0
+    for case in range(12):
+        t0 = 2.0 + 0.4 * case
+        times = t0 + 0.6 * np.arange(11)
+        Rs = np.array([traj.R(t) for t in times]); Ps = np.array([traj.p(t) for t in times])
+        # a segment 2-3.5 m in front of camera 3
+        Rc, pc = Rs[3] @ ric, Ps[3] + Rs[3] @ tic
+        A = pc + Rc @ np.array([rng.uniform(-1, 1), rng.uniform(-0.6, 0.6), rng.uniform(2, 3.5)])
+        B = A + Rc @ np.array([rng.uniform(0.5, 1.5), rng.uniform(-0.8, 0.8), rng.uniform(-0.5, 0.5)])
+        obs = []
+        for j in range(3, 9):
+            Rj, pj = Rs[j] @ ric, Ps[j] + Rs[j] @ tic
+            a, b = Rj.T @ (A - pj), Rj.T @ (B - pj)
+            obs.append([a[0] / a[2], a[1] / a[2], b[0] / b[2], b[1] / b[2]])
+        obs = np.array(obs)
+        got = LG.triangulate_one_line(obs, 3, Rs, Ps, ric, tic)
+        plk, w1, w2 = np.zeros(6), np.zeros(3), np.zeros(3)
+        Rsf, Psf, ricf, ticf = np.ascontiguousarray(Rs.reshape(11, 9)), np.ascontiguousarray(Ps), np.ascontiguousarray(ric), np.ascontiguousarray(tic)
+        rc = lib.dvo_triangulate_line(obs.ctypes.data, len(obs), 3, Rsf.ctypes.data, Psf.ctypes.data, ricf.ctypes.data, ticf.ctypes.data, plk.ctypes.data, w1.ctypes.data, w2.ctypes.data)
+        assert (got is not None) == bool(rc)
+        if got is None:
+            continue
+        ok += 1
+        sc = np.abs(plk).max()
+        assert np.allclose(got["plk"], plk, rtol=1e-10, atol=1e-12 * sc) and np.allclose(got["ptw1"], w1, atol=1e-9) and np.allclose(got["ptw2"], w2, atol=1e-9)
+        # the end points are the observed end points lifted onto the 3-D line: they coincide with the true segment ends
+        assert np.linalg.norm(w1 - A) < 1e-6 and np.linalg.norm(w2 - B) < 1e-6
+        # the line reprojects onto its observations in every frame
+        line_w = LG.plk_to_pose(plk, Rc, pc)          # camera-3 frame -> world
+        for j, o in zip(range(3, 9), obs):
+            assert LG.line_reprojection_error(o, Rs[j] @ ric, Ps[j] + Rs[j] @ tic, line_w) < 1e-8
+        # orthonormal representation round trip (scale-free: compare directions of n and v and the ratio |n| / |v|)
+        orth = LG.plk_to_orth(plk)
+        o2, p2 = np.zeros(4), np.zeros(6)
+        lib.dvo_plk_to_orth(plk.ctypes.data, o2.ctypes.data); lib.dvo_orth_to_plk(orth.ctypes.data, p2.ctypes.data)
+        assert np.allclose(orth, o2, atol=1e-12) and np.allclose(LG.orth_to_plk(orth), p2, atol=1e-12)
+        back = LG.orth_to_plk(orth)
+        assert np.allclose(np.cross(back[:3], plk[:3]), 0, atol=1e-9 * sc) and np.allclose(np.cross(back[3:], plk[3:]), 0, atol=1e-9 * sc)
+        assert abs(np.linalg.norm(back[:3]) / np.linalg.norm(back[3:]) - np.linalg.norm(plk[:3]) / np.linalg.norm(plk[3:])) < 1e-9
+    assert ok >= 5

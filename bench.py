@@ -49,8 +49,13 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-    rank, world, local_rank = dv_dist.init()          # one process per GPU; "nccl" = RCCL over xGMI
+    # one process per GPU.  BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the multi-rank control flow on a 1-GPU box
+    # (both ranks on device 0, gloo instead of RCCL); the driver's 2/4/8-GPU runs use LOCAL_RANK and "nccl" = RCCL over xGMI.
+    forced_dev = os.environ.get("BENCH_DEVICE")
+    torch.cuda.set_device(int(forced_dev) if forced_dev is not None else int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local_rank = dv_dist.init(prefer_gpu=os.environ.get("BENCH_BACKEND", "nccl") != "gloo")
+    if forced_dev is not None:
+        local_rank = int(forced_dev)
 
     from dynamic_vins_amd import sim
     from dynamic_vins_amd.pipeline import Pipeline, SyntheticSequence
@@ -60,13 +65,14 @@ def main():
     cam = sim.ZED if args.width == 1280 else sim.scaled_cam(sim.ZED, args.width, args.height, 1280, 720)
     seq = SyntheticSequence(args.width, args.height, cam, n_frames, rate=20.0, phase=dv_dist.sequence_phase(rank), device=f"cuda:{local_rank}")
 
-    def run(kernel_timing):
+    def run(kernel_timing, collective=True):       # collective=False: rank-0-only pass, no barriers
         pipe = Pipeline(seq, max_cnt=args.max_cnt, min_dist=args.min_dist, max_iters=args.iters, device=local_rank, host_frames=args.host_frames)
         for _ in range(warmup):
             pipe.step()
         if kernel_timing:
             pipe.ctx.timing_enable(2)
-        dv_dist.barrier()
+        if collective:
+            dv_dist.barrier()
         torch.cuda.synchronize()
         pipe.ctx.sync()
         t0 = time.perf_counter()
@@ -76,12 +82,13 @@ def main():
             iters += st.iterations
         pipe.ctx.sync()
         torch.cuda.synchronize()
-        dv_dist.barrier()
+        if collective:
+            dv_dist.barrier()
         dt = time.perf_counter() - t0
         return pipe, dt, iters
 
     pipe, dt, iters = run(False)
-    dt = dv_dist.max_over_ranks(dt, device=f"cuda:{local_rank}")
+    dt = dv_dist.max_over_ranks(dt, device=f"cuda:{local_rank}" if os.environ.get("BENCH_BACKEND", "nccl") != "gloo" else "cpu")
     ate = pipe.ate()
     n_lm = int(pipe.est.state.n_long)
     nfeat = len(pipe.rows)
@@ -91,7 +98,7 @@ def main():
     roof = None
     kern = {}
     if rank == 0:
-        pipe2, _, _ = run(True)
+        pipe2, _, _ = run(True, collective=False)
         names = ["k_be_solve", "k_be_reduce", "k_be_eval_full", "k_be_eval_cost", "k_be_accept", "k_be_marg",
                  "pyr", "lk_temporal", "compact", "gftt_eig", "gftt_select", "lk_stereo", "finalize"]
         for nme in names:
@@ -165,6 +172,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    dv_dist.barrier()          # every rank stays until rank 0 has finished its extra passes
     dv_dist.finalize()
 
 

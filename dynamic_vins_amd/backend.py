@@ -187,6 +187,54 @@ def box_orientation_eval(ctx, R_cioi, R_bc, pose_body, pose_obj):
     return out[:, :3], out[:, 3:21].reshape(n, 3, 6), out[:, 21:].reshape(n, 3, 6)
 
 
+OBJBOX_DTYPE = np.dtype([("obj", "i4"), ("frame", "i4"), ("dims", "f8", 3), ("R_cioi", "f8", 9)])
+OBJPT_DTYPE = np.dtype([("obj", "i4"), ("frame", "i4"), ("p_w", "f8", 3)])
+
+
+class dv_obj_problem(C.Structure):
+    _fields_ = [("n_obj", C.c_int32), ("n_boxes", C.c_int32), ("n_points", C.c_int32), ("max_iters", C.c_int32),
+                ("plane_kind", C.c_int32), ("reserved", C.c_int32),
+                ("state", C.c_void_p), ("dims", C.c_void_p), ("body_pose", C.c_void_p), ("R_bc", C.c_double * 9),
+                ("boxes", C.c_void_p), ("points", C.c_void_p)]
+
+
+assert OBJBOX_DTYPE.itemsize == 104 and OBJPT_DTYPE.itemsize == 32
+
+
+class ObjProblem:
+    """Owns the numpy buffers of one InstanceManager::Optimization problem (estimator_insts.cpp:772-807) and exposes them
+    as a dv_obj_problem.  The oracle's dvo_obj_problem has the same layout, so the same object drives both."""
+
+    def __init__(self, state, dims, body_pose, R_bc, boxes, points, max_iters=10, plane_kind=0):
+        self.state = np.ascontiguousarray(state, np.float64).copy().reshape(-1, 11, 7)
+        self.dims = np.ascontiguousarray(dims, np.float64).copy().reshape(-1, 3)
+        self.body_pose = np.ascontiguousarray(body_pose, np.float64).copy().reshape(11, 7)
+        self.R_bc = np.ascontiguousarray(R_bc, np.float64).reshape(9).copy()
+        self.boxes = np.ascontiguousarray(boxes, OBJBOX_DTYPE).copy()
+        self.points = np.ascontiguousarray(points, OBJPT_DTYPE).copy()
+        self.max_iters, self.plane_kind = max_iters, plane_kind
+        assert len(self.state) == len(self.dims)
+
+    def struct(self):
+        p = dv_obj_problem()
+        p.n_obj, p.n_boxes, p.n_points, p.max_iters, p.plane_kind = len(self.dims), len(self.boxes), len(self.points), self.max_iters, self.plane_kind
+        p.state, p.dims, p.body_pose = self.state.ctypes.data, self.dims.ctypes.data, self.body_pose.ctypes.data
+        p.R_bc[:] = self.R_bc.tolist()
+        p.boxes = self.boxes.ctypes.data if len(self.boxes) else None
+        p.points = self.points.ctypes.data if len(self.points) else None
+        return p
+
+    def clone(self):
+        return ObjProblem(self.state, self.dims, self.body_pose, self.R_bc, self.boxes, self.points, self.max_iters, self.plane_kind)
+
+
+def obj_solve(ctx, prob):
+    """ceres::Solve of InstanceManager::Optimization on the device; prob.state / prob.dims are updated in place."""
+    p, s = prob.struct(), dv_ba_summary()
+    _chk(ctx, ctx.lib.dv_obj_solve(ctx.h, C.byref(p), C.byref(s)))
+    return s
+
+
 class dv_est_config(C.Structure):
     _fields_ = [("use_imu", C.c_int32), ("stereo", C.c_int32), ("plane_constraint", C.c_int32), ("max_iters", C.c_int32),
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),

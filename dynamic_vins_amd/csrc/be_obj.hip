@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include "dv_ctx.h"
 #include "be_math.h"
+#include "be_obj_dev.h"
 
 using namespace be;
 
@@ -118,18 +119,14 @@ __global__ void line_plus_kernel(const double* x, const double* delta, int n, do
 __global__ void box_enclose_kernel(const dv_box_point* f, int n, const double* pose_obj, double* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const d3 P = P3(pose_obj + 7 * i); const quat q = Q4(pose_obj + 7 * i);
-    const quat qi = qinv(q);
-    const d3 po = qrot(qi, mk3(f[i].pts_w[0], f[i].pts_w[1], f[i].pts_w[2]) - P);
+    double r[3], Jp[9];
+    box_enclose_dev(mk3(f[i].pts_w[0], f[i].pts_w[1], f[i].pts_w[2]), f[i].dims, P3(pose_obj + 7 * i), Q4(pose_obj + 7 * i), r, Jp);
     double* o = out + (size_t)i * 21;
-    o[0] = fmax(0.0, (fabs(po.x) - f[i].dims[0] / 2) * 10.0); o[1] = fmax(0.0, (fabs(po.y) - f[i].dims[1] / 2) * 10.0); o[2] = fmax(0.0, (fabs(po.z) - f[i].dims[2] / 2) * 10.0);
-    const m33 Rojw = qR(qi);
-    const d3 e = mul(Rojw, po - P);
-    const double np[3] = { e.x / fabs(e.x), e.y / fabs(e.y), e.z / fabs(e.z) };
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 3; ++k) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { o[3 + r * 6 + c] = np[r] * Rojw.m[r * 3 + c]; o[3 + r * 6 + 3 + c] = 0.0; }
+        for (int c = 0; c < 3; ++c) { o[3 + k * 6 + c] = Jp[k * 3 + c]; o[3 + k * 6 + 3 + c] = 0.0; }
     }
 }
 
@@ -137,23 +134,10 @@ __global__ void box_enclose_kernel(const dv_box_point* f, int n, const double* p
 __global__ void box_dims_kernel(const double* dims, const double* box, int n, double* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const d3 d = P3(box + 3 * i) - P3(dims + 3 * i);
-    const double err = dot(d, d);
+    double r, J[3];
+    box_dims_dev(P3(box + 3 * i), P3(dims + 3 * i), r, J);
     double* o = out + 4 * i;
-    o[0] = err * err / 100.0; o[1] = 2 * d.x; o[2] = 2 * d.y; o[3] = 2 * d.z;
-}
-
-__device__ __forceinline__ d3 so3_log(const m33& R) {        // Sophus::SO3d(R).log(): quaternion log with the small-angle series
-    quat q = qnormalized(qfromR(R));
-    const double sq = q.x * q.x + q.y * q.y + q.z * q.z, w = q.w;
-    double two_atan;
-    if (sq < 1e-20) two_atan = 2.0 / w - 2.0 / 3.0 * sq / (w * w * w);
-    else {
-        const double nq = sqrt(sq);
-        if (fabs(w) < 1e-10) two_atan = (w > 0 ? M_PI : -M_PI) / nq;
-        else two_atan = 2.0 * atan(nq / w) / nq;
-    }
-    return mk3(q.x, q.y, q.z) * two_atan;
+    o[0] = r; o[1] = J[0]; o[2] = J[1]; o[3] = J[2];
 }
 
 // out per block (39): r[3] | J_pose_body 3x6 (zero) | J_pose_obj 3x6
@@ -162,28 +146,12 @@ __global__ void box_orientation_kernel(const double* R_cioi, const double* R_bc,
     if (i >= n) return;
     m33 Rc, Rb;
     for (int k = 0; k < 9; ++k) { Rc.m[k] = R_cioi[9 * i + k]; Rb.m[k] = R_bc[9 * i + k]; }
-    const m33 Rwbi = qR(Q4(pose_b + 7 * i)), Rwoi = qR(Q4(pose_o + 7 * i));
-    const m33 R = mul(mul(mul(tr(Rwoi), Rwbi), Rb), Rc);
-    const d3 phi = so3_log(R);
+    double r[3], Jr[9];
+    box_orientation_dev(Rc, Rb, Q4(pose_b + 7 * i), Q4(pose_o + 7 * i), r, Jr);
     double* o = out + (size_t)i * 39;
-    o[0] = phi.x; o[1] = phi.y; o[2] = phi.z;
+    o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
     for (int k = 0; k < 18; ++k) o[3 + k] = 0.0;
-    const double theta = -norm(phi);
-    const double pn = norm(phi);
-    const d3 a = pn > 0 ? phi / pn : phi;
-    const double st = sin(theta) / theta, ct = 1 - cos(theta) / theta;
-    m33 Jr;
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) Jr.m[r * 3 + c] = (r == c ? st : 0.0) + get(a, r) * get(a, c) * (1 - st);
-    const m33 ha = skew(a);
-    for (int k = 0; k < 9; ++k) Jr.m[k] += ha.m[k] * ct;
-    const double* J = Jr.m;
-    const double det = J[0] * (J[4] * J[8] - J[5] * J[7]) - J[1] * (J[3] * J[8] - J[5] * J[6]) + J[2] * (J[3] * J[7] - J[4] * J[6]);
-    m33 inv;
-    inv.m[0] = (J[4] * J[8] - J[5] * J[7]) / det; inv.m[1] = (J[2] * J[7] - J[1] * J[8]) / det; inv.m[2] = (J[1] * J[5] - J[2] * J[4]) / det;
-    inv.m[3] = (J[5] * J[6] - J[3] * J[8]) / det; inv.m[4] = (J[0] * J[8] - J[2] * J[6]) / det; inv.m[5] = (J[2] * J[3] - J[0] * J[5]) / det;
-    inv.m[6] = (J[3] * J[7] - J[4] * J[6]) / det; inv.m[7] = (J[1] * J[6] - J[0] * J[7]) / det; inv.m[8] = (J[0] * J[4] - J[1] * J[3]) / det;
-    const m33 jac = scale(mul(inv, tr(R)), -1.0);
-    for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) { o[21 + r * 6 + c] = 0.0; o[21 + r * 6 + 3 + c] = jac.m[r * 3 + c]; }
+    for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) { o[21 + k * 6 + c] = 0.0; o[21 + k * 6 + 3 + c] = Jr[k * 3 + c]; }
 }
 
 // stage host arrays behind each other in one device buffer, run, copy the result back

@@ -232,6 +232,38 @@ int dv_box_dims_eval(dv_ctx* ctx, const double* dims /* n x 3 */, const double* 
 int dv_box_orientation_eval(dv_ctx* ctx, const double* R_cioi /* n x 9 */, const double* R_bc /* n x 9 */, const double* pose_body /* n x 7 */,
                             const double* pose_obj /* n x 7 */, int n, double* out);
 
+/* ---- the per-frame object solve (the numeric part): replaces ceres::Solve inside
+ * InstanceManager::Optimization (estimator/estimator_insts.cpp:772-807) for the problem that
+ * AddInstanceParameterBlock / AddResidualBlockForInstOpt build (estimator_insts.cpp:989-1245):
+ *   variables   per object: para_state[0..kWinSize] (pose, PoseLocalParameterization or — plane_constraint —
+ *               PoseConstraintLocalParameterization) and para_box[0] (dims)
+ *   residuals   per (object, frame) with a 3-D detection: BoxDimsFactor(detection dims) on para_box with HuberLoss(1.0)
+ *               and BoxOrientationFactor(R_cioi, ric[0]) on (body pose, para_state[frame]) without a loss;
+ *               per triangulated object point: BoxEncloseStereoPointFactor(p_w, inst.box3d->dims) on
+ *               para_state[frame] with HuberLoss(1.0); the dims inside this factor are the values para_box holds
+ *               when the solve starts (the reference passes them by value)
+ *   options     DENSE_SCHUR + DOGLEG, max_num_iterations = max_iters, wall-clock budget disabled (as dv_ba_solve).
+ * The body poses enter BoxOrientationFactor with a zero Jacobian (sic), so they never move; they only count in the
+ * parameter-tolerance norm, as they do in ceres.  Blocks without a residual are not variables (ceres removes them).
+ * The Hessian of this problem is block diagonal (6x6 per object pose, 3x3 per dims block); the trust region is global. ---- */
+typedef struct dv_obj_box {              /* Instance::boxes3d[frame]: one per (object, frame) at most */
+    int32_t obj, frame;
+    double dims[3];                      /* Box3D::dims of the detection */
+    double R_cioi[9];                    /* Box3D::R_cioi(), row-major */
+} dv_obj_box;
+typedef struct dv_obj_point { int32_t obj, frame; double p_w[3]; } dv_obj_point;      /* FeaturePoint::p_w of a triangulated observation */
+typedef struct dv_obj_problem {
+    int32_t n_obj, n_boxes, n_points, max_iters;
+    int32_t plane_kind;                  /* 0 PoseLocalParameterization, 1 plane constraint with IMU (dz = 0), 2 vision only (dy = 0) */
+    int32_t reserved;
+    double* state;                       /* n_obj x 11 x 7 [p, qx qy qz qw]   in/out: Instance::para_state */
+    double* dims;                        /* n_obj x 3                          in/out: Instance::para_box  */
+    const double* body_pose;             /* 11 x 7: body.para_pose */
+    double R_bc[9];                      /* body.ric[0], row-major */
+    const dv_obj_box* boxes; const dv_obj_point* points;
+} dv_obj_problem;
+int dv_obj_solve(dv_ctx* ctx, dv_obj_problem* problem, dv_ba_summary* summary);
+
 /* ---- Estimator (estimator/estimator.h:55-164): IMU buffer + one ProcessMeasurements iteration per call ---- */
 typedef struct dv_est_config {          /* para (estimator/vio_parameters.cpp:19-83), cfg flags, extrinsics (utils/parameters.cpp) */
     int32_t use_imu, stereo, plane_constraint, max_iters;      /* imu, num_of_cam==2, plane_constraint, max_num_iterations */

@@ -21,7 +21,7 @@ enum BlockKind { kPlain = 0, kPose = 1, kPosePlaneImu = 2, kPosePlaneVo = 3 };
 
 struct ParamBlock {
     double* data = nullptr; int size = 0; int kind = kPlain; bool constant = false; bool is_e = false;
-    int local() const { return size == 7 ? 6 : size; }
+    int local() const { return (size == 7 && kind != kPlain) ? 6 : size; }      // pose blocks: tangent size 6; a plain 7-block has no parameterisation
     int col = -1;   // offset in the tangent vector of the reduced ordering (assigned by Solve)
 };
 

@@ -138,6 +138,18 @@ void dvo_box_enclose_eval(const double* pts_w3, const double* dims3, const doubl
 void dvo_box_dims_eval(const double* dims3, const double* const* par /* box3 */, double* res1, double** J /* 1x3 */);
 void dvo_box_orientation_eval(const double* R_cioi9, const double* R_bc9, const double* const* par /* pose_body7, pose_obj7 */, double* res3, double** J /* 3x7, 3x7 */);
 
+/* the per-frame object solve (InstanceManager::Optimization, estimator/estimator_insts.cpp:772-807); layout identical to
+ * include/dvins.h dv_obj_* (restated here: the oracle shares no headers with the product) */
+typedef struct dvo_obj_box { int32_t obj, frame; double dims[3]; double R_cioi[9]; } dvo_obj_box;
+typedef struct dvo_obj_point { int32_t obj, frame; double p_w[3]; } dvo_obj_point;
+typedef struct dvo_obj_problem {
+    int32_t n_obj, n_boxes, n_points, max_iters, plane_kind, reserved;
+    double* state; double* dims; const double* body_pose; double R_bc[9];
+    const dvo_obj_box* boxes; const dvo_obj_point* points;
+} dvo_obj_problem;
+struct dvo_ba_summary;
+int dvo_obj_solve(dvo_obj_problem* problem, struct dvo_ba_summary* summary);
+
 /* flat window problem, identical layout to include/dvins.h dv_ba_* (restated here: the oracle shares no headers
  * with the product) */
 typedef struct dvo_ba_factor { double pix, piy, pjx, pjy, vix, viy, vjx, vjy, td_i, td_j; int32_t kind, lm, fi, fj; double pad_[2]; } dvo_ba_factor;

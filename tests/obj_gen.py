@@ -91,3 +91,99 @@ def _qR(q):
     x, y, z, w = q
     return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+# ---- synthetic scenes for the per-frame object solve (InstanceManager::Optimization) ----
+def _q_from_R(R):
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        w, x, y, z = 0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s
+    else:
+        i = int(np.argmax(np.diag(R)))
+        j, k = (i + 1) % 3, (i + 2) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        v = [0, 0, 0]
+        v[i] = 0.25 * s
+        v[j] = (R[j, i] + R[i, j]) / s
+        v[k] = (R[k, i] + R[i, k]) / s
+        w = (R[k, j] - R[j, k]) / s
+        x, y, z = v
+    return np.array([x, y, z, w])
+
+
+def _rz(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1.0]])
+
+
+def _small_rot(rng, sigma):
+    w = rng.normal(0, sigma, 3)
+    th = np.linalg.norm(w)
+    if th < 1e-12:
+        return np.eye(3)
+    a = w / th
+    K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+    return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+
+def make_obj_scene(seed, n_obj=4, pts_per_obj=60, box_prob=0.8, pose_noise=(0.4, 0.08), dims_noise=0.3, outside=0.25, max_iters=10, plane_kind=0):
+    """A window of 11 body poses driving along x, n_obj objects moving at constant velocity, each observed in a random
+    sub-range of frames: noisy 3-D detections (dims, R_cioi) on a fraction of the frames and triangulated points spread
+    inside (and, for a fraction `outside`, beyond) the object's box.  Returns a backend.ObjProblem whose state / dims are
+    the noisy initial values (what InstanceManager holds before the solve)."""
+    from dynamic_vins_amd.backend import ObjProblem, OBJBOX_DTYPE, OBJPT_DTYPE
+    rng = np.random.default_rng(seed)
+    R_bc = np.array([[0, 0, 1.0], [-1, 0, 0], [0, -1, 0]]) @ _small_rot(rng, 0.02)
+    body = np.zeros((11, 7))
+    for f in range(11):
+        Rwb = _rz(0.02 * f) @ _small_rot(rng, 0.01)
+        body[f, :3] = [0.8 * f, 0.05 * np.sin(f), 0.0]
+        body[f, 3:] = _q_from_R(Rwb)
+    state = np.zeros((n_obj, 11, 7))
+    dims = np.zeros((n_obj, 3))
+    boxes, points = [], []
+    for o in range(n_obj):
+        d_true = rng.uniform([3.2, 1.5, 1.3], [4.8, 2.1, 1.9])
+        p0 = np.array([rng.uniform(6, 30), rng.uniform(-8, 8), rng.uniform(-0.2, 0.2)])
+        vel = np.array([rng.uniform(-6, 6), rng.uniform(-1, 1), 0.0]) * 0.05
+        yaw0, yawd = rng.uniform(-np.pi, np.pi), rng.uniform(-0.02, 0.02)
+        f0 = int(rng.integers(0, 5))
+        f1 = int(rng.integers(f0 + 2, 11))
+        dims[o] = d_true + rng.normal(0, dims_noise, 3)
+        local = rng.uniform(-0.5, 0.5, (pts_per_obj, 3)) * d_true
+        far = rng.random(pts_per_obj) < outside
+        local[far] *= rng.uniform(1.05, 1.6, (int(far.sum()), 1))
+        for f in range(11):
+            Rwo = _rz(yaw0 + yawd * f) @ _small_rot(rng, 0.0)
+            Pwo = p0 + vel * f
+            Rn = Rwo @ _small_rot(rng, pose_noise[1])
+            state[o, f, :3] = Pwo + rng.normal(0, pose_noise[0], 3)
+            state[o, f, 3:] = _q_from_R(Rn)
+            if not (f0 <= f <= f1):
+                continue
+            if rng.random() < box_prob:
+                Rwb = _qR(body[f, 3:])
+                R_cioi = (Rwb @ R_bc).T @ Rwo @ _small_rot(rng, 0.03)
+                b = np.zeros((), OBJBOX_DTYPE)
+                b["obj"], b["frame"], b["dims"], b["R_cioi"] = o, f, d_true + rng.normal(0, 0.15, 3), R_cioi.ravel()
+                boxes.append(b)
+            seen = rng.random(pts_per_obj) < 0.6
+            for k in np.nonzero(seen)[0]:
+                p = np.zeros((), OBJPT_DTYPE)
+                p["obj"], p["frame"], p["p_w"] = o, f, Pwo + Rwo @ local[k] + rng.normal(0, 0.03, 3)
+                points.append(p)
+    perm = rng.permutation(len(points))                   # the ABI takes the factors in any order
+    points = np.array(points, OBJPT_DTYPE)[perm] if points else np.zeros(0, OBJPT_DTYPE)
+    boxes = np.array(boxes, OBJBOX_DTYPE) if boxes else np.zeros(0, OBJBOX_DTYPE)
+    return ObjProblem(state, dims, body, R_bc.ravel(), boxes, points, max_iters=max_iters, plane_kind=plane_kind)
+
+
+def o_obj_solve(lib, prob):
+    """dvo_obj_solve on the problem's own buffers (updated in place)."""
+    from dynamic_vins_amd.backend import dv_ba_summary
+    p, s = prob.struct(), dv_ba_summary()
+    lib.dvo_obj_solve.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dvo_obj_solve.restype = C.c_int
+    assert lib.dvo_obj_solve(C.byref(p), C.byref(s)) == 0
+    return s

@@ -58,6 +58,8 @@ SIGNATURES = {
     "dv_min_eigen": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
     "dv_viode_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, _u8p, _u8p, C.c_void_p, C.c_void_p]),
     "dv_bgr2gray": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
+    "dv_remap": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _u8p, C.c_int]),
+    "dv_set_undistort_maps": (C.c_int, [_ctx, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
     "dv_pyr_down": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "dv_circle_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int]),
     "dv_erode": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),

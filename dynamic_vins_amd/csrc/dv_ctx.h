@@ -127,6 +127,7 @@ struct dv_ctx {
     DevBuf cand_buf; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
     DevBuf hw_buf; int hw_radius = -1;
     DevBuf mask_buf;
+    DevBuf undist_buf[2]; bool undist[2] = { false, false }; int undist_w = 0, undist_h = 0;      // cfg::is_undistort_input: fixed-point maps per camera (map1 | map2)
     DevBuf out_buf; dv_feat* out_dev = nullptr; int* nout_dev = nullptr;
     dv_feat* out_pinned = nullptr; int* nout_pinned = nullptr; int* err_pinned = nullptr;
     hipEvent_t done = nullptr; bool pending = false;

@@ -63,6 +63,8 @@ void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int s
                          uint8_t* dst0, uint8_t* dst1, int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch,
                          hipStream_t s);
 void dv_launch_bgr2gray(const uint8_t* src0, const uint8_t* src1, int w, int h, int spitch, uint8_t* dst0, uint8_t* dst1, int dpitch, hipStream_t s);
+void dv_launch_remap(const uint8_t* src0, const uint8_t* src1, int w, int h, int spitch, int cn, int to_gray, const int16_t* m1_0, const uint16_t* m2_0,
+                     const int16_t* m1_1, const uint16_t* m2_1, uint8_t* dst0, uint8_t* dst1, int dpitch, hipStream_t s);
 void dv_launch_viode_mask(const uint8_t* seg, int w, int h, int spitch, const uint32_t* dyn_keys, int nkeys, uint8_t* merge, uint8_t* inv, int mpitch,
                           uint32_t* key_img, int32_t* boxes, hipStream_t s);
 void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters,

@@ -70,7 +70,7 @@ void dv_harvest_timers(dv_ctx* ctx, hipStream_t synced) {
 
 // Builds the pyramids of one image (img1 == nullptr) or of a stereo pair with shared launches.
 static int build_pyramids(dv_ctx* ctx, PyrSet& P0, PyrSet* P1, const uint8_t* img0, const uint8_t* img1, int w, int h, int stride,
-                          int mem, int max_level) {
+                          int mem, int max_level, bool undistort = false) {
     DV_CHECK(P0.alloc(w, h, max_level));
     if (P1) DV_CHECK(P1->alloc(w, h, max_level));
     const DvPyr& a = P0.pyr;
@@ -79,7 +79,22 @@ static int build_pyramids(dv_ctx* ctx, PyrSet& P0, PyrSet* P1, const uint8_t* im
     const bool bgr = (mem & DV_FMT_BGR) != 0;
     mem &= ~DV_FMT_BGR;
     const bool dev = (mem == DV_MEM_DEVICE);
-    if (bgr) {          // colour input: BGR -> gray straight into level 0 (row N2); host frames are staged in HBM first
+    if (undistort) {    // cfg::is_undistort_input: cv::remap (+ cvtColor for colour frames) straight into level 0; host frames are staged in HBM first
+        if (w != ctx->undist_w || h != ctx->undist_h) DV_FAIL("dv_track_stereo: undistortion maps were installed for another image size");
+        if (b && !ctx->undist[1]) DV_FAIL("dv_track_stereo: undistortion maps installed for camera 0 but not for camera 1");
+        const int cn = bgr ? 3 : 1;
+        const uint8_t* c0 = img0; const uint8_t* c1 = img1; int cp = stride;
+        if (!dev) {
+            cp = align_up(cn * w, 16);
+            DV_CHECK(ctx->s3.ensure((size_t)cp * h)); DV_CHECK(hipMemcpy2DAsync(ctx->s3.p, cp, img0, stride, (size_t)cn * w, h, hipMemcpyHostToDevice, s));
+            c0 = (const uint8_t*)ctx->s3.p;
+            if (b) { DV_CHECK(ctx->s4.ensure((size_t)cp * h)); DV_CHECK(hipMemcpy2DAsync(ctx->s4.p, cp, img1, stride, (size_t)cn * w, h, hipMemcpyHostToDevice, s)); c1 = (const uint8_t*)ctx->s4.p; }
+        }
+        const size_t m2off = (size_t)4 * w * h;
+        const uint8_t* mb0 = (const uint8_t*)ctx->undist_buf[0].p; const uint8_t* mb1 = (const uint8_t*)ctx->undist_buf[1].p;
+        dv_launch_remap(c0, b ? c1 : nullptr, w, h, cp, cn, bgr ? 1 : 0, (const int16_t*)mb0, (const uint16_t*)(mb0 + m2off),
+                        b ? (const int16_t*)mb1 : nullptr, b ? (const uint16_t*)(mb1 + m2off) : nullptr, a.L[0].p, b ? b->L[0].p : nullptr, a.L[0].pitch, s);
+    } else if (bgr) {   // colour input: BGR -> gray straight into level 0 (row N2); host frames are staged in HBM first
         const uint8_t* c0 = img0; const uint8_t* c1 = img1; int cp = stride;
         if (!dev) {
             cp = align_up(3 * w, 16);
@@ -94,7 +109,7 @@ static int build_pyramids(dv_ctx* ctx, PyrSet& P0, PyrSet* P1, const uint8_t* im
         if (b) DV_CHECK(hipMemcpy2DAsync(b->L[0].p, b->L[0].pitch, img1, stride, w, h, k, s));
     }
     for (int l = 1; l < a.levels; ++l) {
-        const bool fuse_copy = dev && l == 1 && !bgr;
+        const bool fuse_copy = dev && l == 1 && !bgr && !undistort;
         const uint8_t* s0 = fuse_copy ? img0 : a.L[l - 1].p;
         const uint8_t* s1 = b ? (fuse_copy ? img1 : b->L[l - 1].p) : nullptr;
         const int sp = fuse_copy ? stride : a.L[l - 1].pitch;
@@ -161,7 +176,7 @@ void dv_destroy(dv_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& t : ctx->timers) for (auto& p : t.pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,
-                       &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->opA.buf, &ctx->opB.buf }) b->release();
+                       &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->opA.buf, &ctx->opB.buf, &ctx->undist_buf[0], &ctx->undist_buf[1] }) b->release();
     if (ctx->est) dv_est_destroy_internal(ctx->est);
     ctx->be.block.release(); ctx->be.marg_buf.release();
     if (ctx->be.pinned) (void)hipHostFree(ctx->be.pinned);
@@ -217,7 +232,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     PyrSet& Lp = ctx->left[ctx->cur ^ 1];
     {
         StageScope sc(ctx, "pyr");
-        if (build_pyramids(ctx, L, stereo ? &ctx->right : nullptr, gray0, stereo ? gray1 : nullptr, w, h, stride, mem, 3)) return -1;
+        if (build_pyramids(ctx, L, stereo ? &ctx->right : nullptr, gray0, stereo ? gray1 : nullptr, w, h, stride, mem, 3, ctx->undist[0])) return -1;
     }
     const uint8_t* mask_dev = nullptr; int mask_pitch = 0;
     if (mask_or_null) {
@@ -481,6 +496,50 @@ int dv_bgr2gray(dv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipMemcpy2DAsync(gray, w, ctx->s4.p, dp, w, h, mem == DV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int dv_remap(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, int channels, const int16_t* map1_xy, const uint16_t* map2, uint8_t* dst, int mem) {
+    if (!ctx) return -1;
+    if (!src || !dst || !map1_xy || !map2 || w <= 0 || h <= 0 || (channels != 1 && channels != 3) || stride < channels * w) DV_FAIL("dv_remap: bad argument");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = ctx->stream;
+    const bool dev = mem == DV_MEM_DEVICE;
+    const uint8_t* d_src = src; int sp = stride;
+    if (!dev) {
+        sp = align_up(channels * w, 16);
+        DV_CHECK(ctx->s3.ensure((size_t)sp * h));
+        DV_CHECK(hipMemcpy2DAsync(ctx->s3.p, sp, src, stride, (size_t)channels * w, h, hipMemcpyHostToDevice, s));
+        d_src = (const uint8_t*)ctx->s3.p;
+    }
+    const size_t npx = (size_t)w * h;
+    DV_CHECK(ctx->s2.ensure(6 * npx));
+    DV_CHECK(hipMemcpyAsync(ctx->s2.p, map1_xy, 4 * npx, hipMemcpyHostToDevice, s));
+    DV_CHECK(hipMemcpyAsync((uint8_t*)ctx->s2.p + 4 * npx, map2, 2 * npx, hipMemcpyHostToDevice, s));
+    const int dp = align_up(channels * w, 16);
+    DV_CHECK(ctx->s4.ensure((size_t)dp * h));
+    dv_launch_remap(d_src, nullptr, w, h, sp, channels, 0, (const int16_t*)ctx->s2.p, (const uint16_t*)((uint8_t*)ctx->s2.p + 4 * npx), nullptr, nullptr,
+                    (uint8_t*)ctx->s4.p, nullptr, dp, s);
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipMemcpy2DAsync(dst, (size_t)channels * w, ctx->s4.p, dp, (size_t)channels * w, h, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int dv_set_undistort_maps(dv_ctx* ctx, int cam, const int16_t* map1_xy, const uint16_t* map2, int w, int h) {
+    if (!ctx) return -1;
+    if (cam < 0 || cam > 1) DV_FAIL("dv_set_undistort_maps: cam must be 0 or 1");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (ctx->pending) DV_FAIL("dv_set_undistort_maps: a frame is in flight");
+    if (!map1_xy) { ctx->undist[cam] = false; if (cam == 0) ctx->undist[1] = false; return 0; }
+    if (!map2 || w != ctx->cfg.width || h != ctx->cfg.height) DV_FAIL("dv_set_undistort_maps: maps must be width x height of the config");
+    if (cam == 1 && !ctx->undist[0]) DV_FAIL("dv_set_undistort_maps: install camera 0 first");
+    const size_t npx = (size_t)w * h;
+    DV_CHECK(ctx->undist_buf[cam].ensure(6 * npx));
+    DV_CHECK(hipMemcpyAsync(ctx->undist_buf[cam].p, map1_xy, 4 * npx, hipMemcpyHostToDevice, ctx->stream));
+    DV_CHECK(hipMemcpyAsync((uint8_t*)ctx->undist_buf[cam].p + 4 * npx, map2, 2 * npx, hipMemcpyHostToDevice, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->undist[cam] = true; ctx->undist_w = w; ctx->undist_h = h;
     return 0;
 }
 

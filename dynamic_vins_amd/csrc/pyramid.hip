@@ -127,3 +127,81 @@ void dv_launch_bgr2gray(const uint8_t* src0, const uint8_t* src1, int w, int h, 
     dim3 grid((w + 1023) / 1024, h, src1 ? 2 : 1);
     hipLaunchKernelGGL(bgr2gray_kernel, grid, dim3(256), 0, s, src0, src1, w, h, spitch, dst0, dst1, dpitch);
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with the fixed-point maps of cv::initUndistortRectifyMap(..., CV_16SC2)
+// (cfg::is_undistort_input: ImageProcessor::Run, image_process/image_process.cpp:109-121; the merged mask,
+// basic/semantic_image.cpp:86-89).  map1 = (sx, sy) int16 pairs, map2 = (fy << 5 | fx), 5 fractional bits.
+// OpenCV's table weights are saturate_cast<short>(wy wx 2^15) repaired to sum 2^15; for INTER_BITS = 5 they are the
+// exact integers (32 - fx)(32 - fy) 32, ... except the (0,0) cell {32767, 0, 0, 1}, whose output
+// (32767 v00 + v11 + 2^14) >> 15 equals v00 = (32768 v00 + 2^14) >> 15 for 8-bit data — so the closed form below is
+// bit-identical to the table.  out = (sum w v + 2^14) >> 15; neighbours outside the source read 0.
+// TO_GRAY (CN == 3): the three remapped 8-bit channels go through cvtColor's 14-bit weights in registers and only the
+// gray byte is written — straight into pyramid level 0: 6 B of map + 3 B of colour read and 1 B
+// written per pixel instead of remap (6 + 3 + 3) + cvtColor (3 + 1).
+// One thread = 4 destination pixels of a row; blockIdx.z selects the image (and its maps) of a stereo pair.
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+template <int CN, bool TO_GRAY>
+__global__ __launch_bounds__(256) void remap_kernel(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1, int w, int h, int spitch,
+                                                    const short2* __restrict__ m1_0, const uint16_t* __restrict__ m2_0,
+                                                    const short2* __restrict__ m1_1, const uint16_t* __restrict__ m2_1,
+                                                    uint8_t* __restrict__ dst0, uint8_t* __restrict__ dst1, int dpitch) {
+    const uint8_t* src = blockIdx.z ? src1 : src0;
+    const short2* m1 = blockIdx.z ? m1_1 : m1_0; const uint16_t* m2 = blockIdx.z ? m2_1 : m2_0;
+    uint8_t* dst = blockIdx.z ? dst1 : dst0;
+    const int y = blockIdx.y, x4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x4 >= w) return;
+    constexpr int OC = TO_GRAY ? 1 : CN;
+    uint8_t o[4 * OC];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = min(x4 + k, w - 1);
+        const short2 xy = m1[(size_t)y * w + x];
+        const int f = m2[(size_t)y * w + x] & 1023, fx = f & 31, fy = f >> 5;
+        const int sx = xy.x, sy = xy.y;
+        const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+        int v[CN];
+        if ((unsigned)sx < (unsigned)(w - 1) && (unsigned)sy < (unsigned)(h - 1)) {
+            const uint8_t* p = src + (size_t)sy * spitch + (size_t)sx * CN;
+            if (CN == 3 && !(sy == h - 2 && sx >= w - 3)) {
+                // both pixels of a row in one unaligned 8-byte load (gfx950 global loads need no alignment); 2 bytes of over-read, never
+                // past the last row's end (excluded above)
+                const uint64_t r0 = *reinterpret_cast<const u64_unaligned*>(p), r1 = *reinterpret_cast<const u64_unaligned*>(p + spitch);
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    v[c] = (int)((r0 >> (8 * c)) & 255) * w00 + (int)((r0 >> (8 * (3 + c))) & 255) * w01 + (int)((r1 >> (8 * c)) & 255) * w10 + (int)((r1 >> (8 * (3 + c))) & 255) * w11;
+            } else {
+#pragma unroll
+                for (int c = 0; c < CN; ++c) v[c] = p[c] * w00 + p[CN + c] * w01 + p[spitch + c] * w10 + p[spitch + CN + c] * w11;
+            }
+        } else {
+            const bool x0 = (unsigned)sx < (unsigned)w, x1 = (unsigned)(sx + 1) < (unsigned)w, y0 = (unsigned)sy < (unsigned)h, y1 = (unsigned)(sy + 1) < (unsigned)h;
+#pragma unroll
+            for (int c = 0; c < CN; ++c) {
+                const int a = (x0 && y0) ? src[(size_t)sy * spitch + (size_t)sx * CN + c] : 0, b = (x1 && y0) ? src[(size_t)sy * spitch + (size_t)(sx + 1) * CN + c] : 0;
+                const int d = (x0 && y1) ? src[(size_t)(sy + 1) * spitch + (size_t)sx * CN + c] : 0, e = (x1 && y1) ? src[(size_t)(sy + 1) * spitch + (size_t)(sx + 1) * CN + c] : 0;
+                v[c] = a * w00 + b * w01 + d * w10 + e * w11;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CN; ++c) v[c] = (v[c] + (1 << 14)) >> 15;          // <= 255: the weights sum to 2^15
+        if (TO_GRAY) o[k] = (uint8_t)((v[0] * 1868 + v[1] * 9617 + v[2] * 4899 + (1 << 13)) >> 14);
+        else {
+#pragma unroll
+            for (int c = 0; c < CN; ++c) o[k * OC + c] = (uint8_t)v[c];
+        }
+    }
+    uint8_t* out = dst + (size_t)y * dpitch + (size_t)x4 * OC;
+    if (OC == 1 && x4 + 4 <= w) *reinterpret_cast<uint32_t*>(out) = (uint32_t)o[0] | ((uint32_t)o[1] << 8) | ((uint32_t)o[2] << 16) | ((uint32_t)o[3] << 24);
+    else for (int k = 0; k < 4 * OC && x4 * OC + k < w * OC; ++k) out[k] = o[k];
+}
+
+// cn: channels of src; to_gray (cn == 3 only): write the gray image.  dpitch in bytes, 4-byte aligned rows when the output has one channel.
+void dv_launch_remap(const uint8_t* src0, const uint8_t* src1, int w, int h, int spitch, int cn, int to_gray, const int16_t* m1_0, const uint16_t* m2_0,
+                     const int16_t* m1_1, const uint16_t* m2_1, uint8_t* dst0, uint8_t* dst1, int dpitch, hipStream_t s) {
+    dim3 grid((w + 1023) / 1024, h, src1 ? 2 : 1);
+    const short2* a = (const short2*)m1_0; const short2* b = (const short2*)m1_1;
+    if (cn == 1) hipLaunchKernelGGL((remap_kernel<1, false>), grid, dim3(256), 0, s, src0, src1, w, h, spitch, a, m2_0, b, m2_1, dst0, dst1, dpitch);
+    else if (to_gray) hipLaunchKernelGGL((remap_kernel<3, true>), grid, dim3(256), 0, s, src0, src1, w, h, spitch, a, m2_0, b, m2_1, dst0, dst1, dpitch);
+    else hipLaunchKernelGGL((remap_kernel<3, false>), grid, dim3(256), 0, s, src0, src1, w, h, spitch, a, m2_0, b, m2_1, dst0, dst1, dpitch);
+}

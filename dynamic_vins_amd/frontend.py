@@ -139,6 +139,27 @@ class Context:
         self._check(self.lib.dv_bgr2gray(self.h, _ptr(bgr), w, h, bgr.strides[0], _ptr(out), DV_MEM_HOST))
         return out
 
+    def remap(self, src, map1, map2):
+        """cv::remap(src, map1 (h, w, 2) int16, map2 (h, w) uint16, INTER_LINEAR) of an (h, w) or (h, w, 3) uint8 image"""
+        src = np.ascontiguousarray(src)
+        h, w = src.shape[:2]
+        cn = 1 if src.ndim == 2 else src.shape[2]
+        m1, m2 = np.ascontiguousarray(map1, np.int16), np.ascontiguousarray(map2, np.uint16)
+        assert m1.shape == (h, w, 2) and m2.shape == (h, w)
+        out = np.zeros_like(src)
+        self._check(self.lib.dv_remap(self.h, _ptr(src), w, h, src.strides[0], cn, m1.ctypes.data, m2.ctypes.data, _ptr(out), DV_MEM_HOST))
+        return out
+
+    def set_undistort_maps(self, cam, map1=None, map2=None):
+        """cfg::is_undistort_input: install (or, with map1=None, remove) the fixed-point undistortion maps of camera 0 / 1"""
+        if map1 is None:
+            self._check(self.lib.dv_set_undistort_maps(self.h, int(cam), None, None, 0, 0))
+            return
+        m1, m2 = np.ascontiguousarray(map1, np.int16), np.ascontiguousarray(map2, np.uint16)
+        h, w = m2.shape
+        assert m1.shape == (h, w, 2)
+        self._check(self.lib.dv_set_undistort_maps(self.h, int(cam), m1.ctypes.data, m2.ctypes.data, w, h))
+
     def pyr_down(self, img):
         h, w = img.shape
         dst = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)

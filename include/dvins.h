@@ -114,6 +114,19 @@ int dv_viode_mask(dv_ctx* ctx, const uint8_t* seg_bgr, int w, int h, int stride,
                   uint8_t* merge_mask, uint8_t* inv_merge_mask, uint32_t* key_image, int32_t* boxes);
 /* cv::cvtColor(BGR2GRAY) on 8-bit images: (B 1868 + G 9617 + R 4899 + 8192) >> 14; gray is w x h, tightly packed */
 int dv_bgr2gray(dv_ctx* ctx, const uint8_t* bgr, int w, int h, int stride, uint8_t* gray, int mem);
+/* cv::remap(src, dst, map1, map2, INTER_LINEAR) — BORDER_CONSTANT 0 — with the fixed-point maps cv::initUndistortRectifyMap(..., CV_16SC2, ...)
+ * returns (utils/camera_model.cpp:481-499): map1_xy = w*h (x, y) int16 pairs, map2 = w*h uint16 (fy << 5 | fx).  8-bit source with
+ * channels 1 or 3 (stride in bytes); dst is w x h x channels, tightly packed.  The calls of ImageProcessor::Run on the colour frames
+ * (image_process/image_process.cpp:109-121) and of SemanticImage::SetMask on the merged mask (basic/semantic_image.cpp:86-89).
+ * The maps are host memory; src / dst follow `mem`. */
+int dv_remap(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, int channels, const int16_t* map1_xy, const uint16_t* map2, uint8_t* dst, int mem);
+/* cfg::is_undistort_input (utils/camera_model.cpp:481-499): installs (map1_xy != NULL) or removes (NULL) the undistortion maps of camera
+ * `cam` (0 left, 1 right) in HBM.  While installed, dv_track_stereo* take DISTORTED frames and undistort them on the way into pyramid
+ * level 0: with DV_FMT_BGR the remap of the three channels and cvtColor are fused (the remapped colour image never exists); gray frames
+ * are remapped as one channel, which is what the reference's mono -> BGR -> remap -> gray chain yields.  w, h must equal the config's.
+ * dv_config.cam0 / cam1 should then be the NEW intrinsics without distortion, as the reference resets them (camera_model.cpp:486-503).
+ * A mask passed to the tracker is used as given (the reference remaps it before inverting it: use dv_remap with channels = 1). */
+int dv_set_undistort_maps(dv_ctx* ctx, int cam, const int16_t* map1_xy, const uint16_t* map2, int w, int h);
 /* cv::circle(mask, pt, radius, 0, -1) per point (background_tracker.cpp:79-80) */
 int dv_circle_mask(dv_ctx* ctx, uint8_t* mask, int w, int h, int stride, const float* pts_xy, int n,
                    int radius, int mem);

@@ -50,6 +50,10 @@ void dvo_pyr_down(const uint8_t* src, int w, int h, uint8_t* dst);
 void dvo_viode_mask(const uint8_t* seg_bgr, int w, int h, int stride, const uint32_t* dyn_keys, int nkeys, uint8_t* merge, uint8_t* inv, uint32_t* key_img, int32_t* boxes);
 /* cv::cvtColor(BGR2GRAY) 8U (SemanticImage::SetGrayImage, basic/semantic_image.cpp:95-99); gray tightly packed */
 void dvo_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray);
+/* cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with fixed-point maps (CV_16SC2 + CV_16UC1), 8-bit, cn = 1 or 3; dst is dense (w * cn per row) */
+void dvo_remap(const uint8_t* src, int w, int h, int stride, int cn, const int16_t* map1_xy, const uint16_t* map2, uint8_t* dst);
+/* cv::initUndistortRectifyMap(K, D, I, newK, size, CV_16SC2) for a pinhole radtan camera */
+void dvo_init_undistort_map(const dvo_cam* cam, const double* newK4, int w, int h, int16_t* map1_xy, uint16_t* map2);
 
 /* calcScharrDeriv (OpenCV lkpyramid.cpp): out is int16 interleaved (Ix,Iy), w*h*2 */
 void dvo_scharr(const uint8_t* src, int w, int h, int16_t* out);

@@ -569,6 +569,66 @@ void dvo_bgr2gray(const uint8_t* bgr, int w, int h, int stride, uint8_t* gray) {
         gray[(size_t)y * w + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + (1 << 13)) >> 14);
     }
 }
+// cv::remap(src, dst, map1 CV_16SC2, map2 CV_16UC1, INTER_LINEAR, BORDER_CONSTANT, 0) on 8-bit images with 1 or 3 channels — the call of
+// ImageProcessor::Run (image_process/image_process.cpp:109-121) and of SemanticImage::SetMask on the merged mask (basic/semantic_image.cpp:86-89).
+// Restated from OpenCV 3.4 imgproc (un-vendored; PARITY UNPINNED): remapBilinear<FixedPtCast<int, uchar, 15>, RemapVec_8u, short> with the
+// fixed-point table of initInterTab2D(INTER_LINEAR, fixpt): INTER_BITS 5, weights saturate_cast<short>(wy * wx * 32768) whose sum is repaired to
+// 32768 exactly as the library does (only the (0,0) cell needs it: {32767, 0, 0, 1}); out = (sum w v + 2^14) >> 15; neighbours outside the
+// source take the border value 0.  All integer arithmetic: the SIMD and scalar paths of the library agree.
+static const short* remap_tab() {
+    static short tab[32 * 32 * 4 + 8]; static bool init = false;
+    if (!init) {
+        float t1[32][2];
+        for (int i = 0; i < 32; ++i) { const float x = (float)i * (1.f / 32); t1[i][0] = 1.f - x; t1[i][1] = x; }      // interpolateLinear
+        short* it = tab;
+        for (int i = 0; i < 32; ++i) for (int j = 0; j < 32; ++j, it += 4) {
+            int isum = 0;
+            for (int k1 = 0; k1 < 2; ++k1) for (int k2 = 0; k2 < 2; ++k2) {
+                const float v = t1[i][k1] * t1[j][k2];
+                const int r = (int)std::lrint((double)(v * 32768.f));
+                isum += it[k1 * 2 + k2] = (short)std::min(std::max(r, -32768), 32767);
+            }
+            if (isum != 32768) {          // the library scans it[k1 * 2 + k2], k1, k2 in {1, 2}: past this cell's 4 entries into still-zero memory
+                const int diff = isum - 32768; int Mk = 3, mk = 3;
+                for (int k1 = 1; k1 < 3; ++k1) for (int k2 = 1; k2 < 3; ++k2) { const int k = k1 * 2 + k2; if (it[k] < it[mk]) mk = k; else if (it[k] > it[Mk]) Mk = k; }
+                if (diff < 0) it[Mk] = (short)(it[Mk] - diff); else it[mk] = (short)(it[mk] - diff);
+            }
+        }
+        init = true;
+    }
+    return tab;
+}
+void dvo_remap(const uint8_t* src, int w, int h, int stride, int cn, const int16_t* map1, const uint16_t* map2, uint8_t* dst) {
+    const short* wtab = remap_tab();
+    for (int dy = 0; dy < h; ++dy) for (int dx = 0; dx < w; ++dx) {
+        const int sx = map1[((size_t)dy * w + dx) * 2], sy = map1[((size_t)dy * w + dx) * 2 + 1];
+        const short* wt = wtab + 4 * (map2[(size_t)dy * w + dx] & 1023);
+        for (int c = 0; c < cn; ++c) {
+            auto at = [&](int x, int y) -> int { return ((unsigned)x < (unsigned)w && (unsigned)y < (unsigned)h) ? src[(size_t)y * stride + (size_t)x * cn + c] : 0; };
+            const int v = at(sx, sy) * wt[0] + at(sx + 1, sy) * wt[1] + at(sx, sy + 1) * wt[2] + at(sx + 1, sy + 1) * wt[3];
+            dst[((size_t)dy * w + dx) * cn + c] = (uint8_t)std::min(std::max((v + (1 << 14)) >> 15, 0), 255);
+        }
+    }
+}
+// cv::initUndistortRectifyMap(K, D, Mat(), newK, size, CV_16SC2, map1, map2) for the pinhole + radtan(k1, k2, p1, p2) cameras of the reference
+// (utils/camera_model.cpp:481-499); used by the tests to produce realistic maps.  OpenCV 3.4 calib3d/imgproc undistort.cpp, restated.
+void dvo_init_undistort_map(const dvo_cam* cam, const double* newK4 /* fx fy cx cy */, int w, int h, int16_t* map1, uint16_t* map2) {
+    const double ir[9] = { 1.0 / newK4[0], 0, -newK4[2] / newK4[0], 0, 1.0 / newK4[1], -newK4[3] / newK4[1], 0, 0, 1 };      // (newK I)^-1
+    const double k1 = cam->k1, k2 = cam->k2, p1 = cam->p1, p2 = cam->p2;
+    for (int i = 0; i < h; ++i) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < w; ++j, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double iw = 1. / _w, x = _x * iw, y = _y * iw;
+            const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((0 * r2 + k2) * r2 + k1) * r2) / (1 + ((0 * r2 + 0) * r2 + 0) * r2);
+            const double xd = x * kr + p1 * _2xy + p2 * (r2 + 2 * x2), yd = y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy;
+            const double u = cam->fx * xd + cam->cx, v = cam->fy * yd + cam->cy;
+            const int iu = (int)std::lrint(u * 32), iv = (int)std::lrint(v * 32);
+            map1[((size_t)i * w + j) * 2] = (int16_t)(iu >> 5); map1[((size_t)i * w + j) * 2 + 1] = (int16_t)(iv >> 5);
+            map2[(size_t)i * w + j] = (uint16_t)((iv & 31) * 32 + (iu & 31));
+        }
+    }
+}
 dvo_tracker* dvo_tracker_create(const dvo_fe_config* cfg) { auto* t = new dvo_tracker(); t->cfg = *cfg; return t; }
 void dvo_tracker_destroy(dvo_tracker* t) { delete t; }
 int dvo_tracker_track_image(dvo_tracker* t, const uint8_t* g0, const uint8_t* g1, double time, dvo_feat* out) {

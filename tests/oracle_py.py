@@ -63,6 +63,26 @@ class Oracle:
         self.lib.dvo_bgr2gray(_p(bgr), w, h, bgr.strides[0], _p(out))
         return out
 
+    def remap(self, src, map1, map2):
+        """cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with CV_16SC2 + CV_16UC1 maps; src (h, w) or (h, w, 3) uint8"""
+        src = np.ascontiguousarray(src)
+        h, w = src.shape[:2]
+        cn = 1 if src.ndim == 2 else src.shape[2]
+        m1, m2 = np.ascontiguousarray(map1, np.int16), np.ascontiguousarray(map2, np.uint16)
+        out = np.zeros_like(src)
+        self.lib.dvo_remap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.dvo_remap(_p(src), w, h, src.strides[0], cn, _p(m1), _p(m2), _p(out))
+        return out
+
+    def init_undistort_map(self, cam, new_k, w, h):
+        """cv::initUndistortRectifyMap(K, D, I, newK, (w, h), CV_16SC2) -> (map1 (h, w, 2) int16, map2 (h, w) uint16)"""
+        c = dvo_cam(*cam)
+        nk = np.ascontiguousarray(new_k, np.float64)
+        m1, m2 = np.zeros((h, w, 2), np.int16), np.zeros((h, w), np.uint16)
+        self.lib.dvo_init_undistort_map.argtypes = [C.POINTER(dvo_cam), C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.dvo_init_undistort_map(C.byref(c), _p(nk), w, h, _p(m1), _p(m2))
+        return m1, m2
+
     def pyr_down(self, img):
         h, w = img.shape
         img = np.ascontiguousarray(img)

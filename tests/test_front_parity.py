@@ -303,6 +303,83 @@ def test_bgr2gray_and_colour_input_bit_exact(gpu_ctx_factory, oracle, w, h):
         _rows_equal(a, b)
 
 
+def _rand_maps(rng, w, h):
+    """smooth warp + a band of far-out-of-range and border-straddling coordinates, every fractional cell"""
+    yy, xx = np.mgrid[0:h, 0:w]
+    u = xx + 6 * np.sin(yy / 17.0) + rng.uniform(-1.5, 1.5, (h, w))
+    v = yy + 5 * np.cos(xx / 23.0) + rng.uniform(-1.5, 1.5, (h, w))
+    u[: h // 6] -= 9; v[:, : w // 8] -= 7; u[-h // 7:] += 8; v[:, -w // 9:] += 6          # rows / columns that leave the image on each side
+    iu, iv = np.rint(u * 32).astype(np.int64), np.rint(v * 32).astype(np.int64)
+    m1 = np.stack([iu >> 5, iv >> 5], -1).astype(np.int16)
+    m2 = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
+    m1[0, 0] = (-300, 5); m1[0, 1] = (w + 40, h + 40); m1[1, 0] = (-1, -1); m1[1, 1] = (w - 1, h - 1); m1[1, 2] = (w, 3); m1[2, 0] = (3, h)
+    m2[3, :32] = np.arange(32); m2[4, :32] = np.arange(32) * 32; m1[3, :32] = (w // 2, h // 2); m1[4, :32] = (w // 2, h // 2)
+    return m1, m2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h", [(64, 48), (333, 201), (1280, 720)])
+def test_remap_bit_exact(gpu_ctx_factory, oracle, w, h):
+    """row N2: cv::remap(INTER_LINEAR, fixed-point maps, BORDER_CONSTANT) on 1- and 3-channel images, random warps with out-of-range
+    coordinates and realistic undistortion maps"""
+    rng = np.random.default_rng(w + h)
+    ctx = gpu_ctx_factory(width=64, height=48)
+    gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    cam = (0.7 * w, 0.72 * w, w / 2 + 3.3, h / 2 - 2.1, -0.28, 0.07, 1e-3, -7e-4)
+    maps = [_rand_maps(rng, w, h), oracle.init_undistort_map(cam, (0.62 * w, 0.64 * w, w / 2, h / 2), w, h)]
+    for m1, m2 in maps:
+        assert np.array_equal(ctx.remap(gray, m1, m2), oracle.remap(gray, m1, m2))
+        assert np.array_equal(ctx.remap(bgr, m1, m2), oracle.remap(bgr, m1, m2))
+    # identity map: the image itself; one whole pixel to the right: shifted with a zero column
+    yy, xx = np.mgrid[0:h, 0:w]
+    ident = np.stack([xx, yy], -1).astype(np.int16)
+    assert np.array_equal(ctx.remap(gray, ident, np.zeros((h, w), np.uint16)), gray)
+    sh = ctx.remap(gray, ident + np.array([1, 0], np.int16), np.zeros((h, w), np.uint16))
+    assert np.array_equal(sh[:, :-1], gray[:, 1:]) and not sh[:, -1].any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("colour", [True, False])
+def test_undistort_input_fused_into_tracking(gpu_ctx_factory, oracle, colour):
+    """cfg::is_undistort_input: the tracker fed DISTORTED (colour or gray) frames with the maps installed == the tracker fed the frames
+    that cv::remap + cv::cvtColor produce (ImageProcessor::Run, image_process.cpp:109-126), bit for bit"""
+    from dynamic_vins_amd.frontend import DV_FMT_BGR, DV_MEM_HOST, DV_MODE_RAW, make_cam
+    w, h = 200, 152
+    cam = (150.0, 151.0, 101.3, 74.2, -0.25, 0.06, 8e-4, -5e-4)
+    new_k = (128.0, 129.0, 100.0, 76.0)
+    undist_cam = make_cam(new_k[0], new_k[1], new_k[2], new_k[3], 0, 0, 0, 0)
+    m1l, m2l = oracle.init_undistort_map(cam, new_k, w, h)
+    cam_r = (151.0, 150.0, 99.1, 77.4, -0.22, 0.04, -6e-4, 3e-4)
+    m1r, m2r = oracle.init_undistort_map(cam_r, new_k, w, h)
+    a = gpu_ctx_factory(width=w, height=h, max_cnt=60, min_dist=12, cam0=undist_cam, cam1=undist_cam)
+    b = gpu_ctx_factory(width=w, height=h, max_cnt=60, min_dist=12, cam0=undist_cam, cam1=undist_cam)
+    a.set_undistort_maps(0, m1l, m2l)
+    a.set_undistort_maps(1, m1r, m2r)
+    seq = synth.PlaneSequence(w, h, seed=6, disparity=2.5, margin=40)
+    total = 0
+    for k in range(4):
+        l, r = seq.frame(k)
+        if colour:
+            l, r = np.repeat(l[..., None], 3, 2), np.repeat(r[..., None], 3, 2)
+            l[..., 0] = np.clip(l[..., 0].astype(int) + 11, 0, 255); r[..., 2] = np.clip(r[..., 2].astype(int) - 9, 0, 255)
+            l, r = np.ascontiguousarray(l), np.ascontiguousarray(r)
+            fa = a.track_stereo(l, r, 0.05 * k, None, DV_MODE_RAW, DV_MEM_HOST | DV_FMT_BGR, stride=3 * w)
+            fb = b.track_stereo(oracle.bgr2gray(oracle.remap(l, m1l, m2l)), oracle.bgr2gray(oracle.remap(r, m1r, m2r)), 0.05 * k)
+        else:
+            fa = a.track_stereo(l, r, 0.05 * k)
+            fb = b.track_stereo(oracle.remap(l, m1l, m2l), oracle.remap(r, m1r, m2r), 0.05 * k)
+        _rows_equal(fa, fb)
+        total += len(fa)
+    assert total > 100
+    a.set_undistort_maps(0)           # removing camera 0's maps removes both: back to the plain path
+    a.reset()
+    c = gpu_ctx_factory(width=w, height=h, max_cnt=60, min_dist=12, cam0=undist_cam, cam1=undist_cam)
+    for k in range(2):
+        l, r = seq.frame(k)
+        _rows_equal(a.track_stereo(l, r, 0.05 * k), c.track_stereo(l, r, 0.05 * k))
+
+
 def test_viode_mask_bit_exact(gpu_ctx_factory, oracle):
     """row N4: VIODE label image -> merge / inverse masks, key image, per-key boxes"""
     import ctypes as C

@@ -406,3 +406,35 @@ def test_marginalizing_only_the_prior_is_a_schur_complement(oracle, back):
     assert A.shape == S.shape
     # same ordering of the kept blocks?  compare spectra (order-invariant) and, if the order is the same, entries
     assert np.allclose(np.sort(np.linalg.eigvalsh(A)), np.sort(np.linalg.eigvalsh(0.5 * (S + S.T))), rtol=1e-6, atol=1e-6 * np.abs(S).max())
+
+
+def test_remap_oracle_against_float_bilinear(oracle):
+    """cv::remap restatement (fixed-point, 5 fractional bits, 15-bit weights) against a float bilinear interpolation with zero
+    border: never more than one grey level apart (rounding), identical on whole-pixel maps, zero outside the source"""
+    rng = np.random.default_rng(9)
+    w, h = 97, 61
+    img = rng.integers(0, 256, (h, w)).astype(np.uint8)
+    cam = (70.0, 71.0, 48.2, 30.4, -0.3, 0.08, 1e-3, -1e-3)
+    m1, m2 = oracle.init_undistort_map(cam, (58.0, 59.0, 48.0, 30.0), w, h)
+    out = oracle.remap(img, m1, m2)
+    pad = np.zeros((h + 2, w + 2)); pad[1:-1, 1:-1] = img
+    sx, sy = m1[..., 0].astype(int), m1[..., 1].astype(int)
+    fx, fy = (m2 & 31) / 32.0, (m2 >> 5) / 32.0
+    inside = (sx >= -1) & (sx < w) & (sy >= -1) & (sy < h)
+    cx, cy = np.clip(sx, -1, w - 1) + 1, np.clip(sy, -1, h - 1) + 1
+    ref = (pad[cy, cx] * (1 - fx) * (1 - fy) + pad[cy, cx + 1] * fx * (1 - fy) + pad[cy + 1, cx] * (1 - fx) * fy + pad[cy + 1, cx + 1] * fx * fy) * inside
+    assert np.abs(out.astype(float) - ref).max() <= 0.5 + 1e-3
+    assert inside.mean() > 0.9 and (out[~inside] == 0).all()
+    # the undistortion map itself: map1 + fraction == the distorted pixel of the ideal point, to the 1/32 pixel grid
+    yy, xx = np.mgrid[0:h, 0:w]
+    x, y = (xx - 48.0) / 58.0, (yy - 30.0) / 59.0
+    r2 = x * x + y * y
+    kr = 1 + cam[4] * r2 + cam[5] * r2 * r2
+    u = cam[0] * (x * kr + 2 * cam[6] * x * y + cam[7] * (r2 + 2 * x * x)) + cam[2]
+    v = cam[1] * (y * kr + cam[6] * (r2 + 2 * y * y) + 2 * cam[7] * x * y) + cam[3]
+    assert np.abs(m1[..., 0] + (m2 & 31) / 32.0 - u).max() <= 1 / 64 + 1e-9 and np.abs(m1[..., 1] + (m2 >> 5) / 32.0 - v).max() <= 1 / 64 + 1e-9
+    # 3 channels = 3 independent planes
+    bgr = rng.integers(0, 256, (h, w, 3)).astype(np.uint8)
+    o3 = oracle.remap(bgr, m1, m2)
+    for c in range(3):
+        assert np.array_equal(o3[..., c], oracle.remap(np.ascontiguousarray(bgr[..., c]), m1, m2))

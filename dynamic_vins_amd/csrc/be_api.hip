@@ -24,6 +24,8 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
            o_pA2 = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb2 = take(8 * BE_MAX_PRIOR), o_ms = take(64), o_c0 = take(64),
            o_pk = take(8 * (size_t)BE_PK_SIZE * BE_PK_STRIDE), o_io = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po = take(8 * (BE_MAX_PRIOR + 1)),
            o_cc = take(8 * (BE_MAX_LM + BE_WIN + 1)), o_hd = take(8 * n * n), o_sc = take(8 * n * n), o_g = take(8 * 2 * n),
+           o_pk1 = take(8 * (size_t)BE_PK_SIZE * BE_PK_STRIDE), o_io1 = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po1 = take(8 * (BE_MAX_PRIOR + 1)),
+           o_hd1 = take(8 * n * n), o_sc1 = take(8 * n * n), o_g1 = take(8 * 2 * n),      // second linearisation set (speculative evaluation at the candidate)
            o_v = take(8 * 4 * n), o_vl = take(8 * 4 * (size_t)BE_MAX_LM);
     DV_CHECK(w.block.ensure(off));
     uint8_t* b = (uint8_t*)w.block.p;
@@ -32,8 +34,10 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     w.priorA_buf[0] = (double*)(b + o_pA); w.priorb_buf[0] = (double*)(b + o_pb); w.priorA_buf[1] = (double*)(b + o_pA2); w.priorb_buf[1] = (double*)(b + o_pb2);
     w.prior_cur = 0; w.priorA = w.priorA_buf[0]; w.priorb = w.priorb_buf[0]; w.prior_resident = false;
     w.marg_tab = (int32_t*)(b + o_mt); w.marg_scal = (double*)(b + o_ms); w.prior_c0 = (double*)(b + o_c0);
-    w.packets = (double*)(b + o_pk); w.imu_out = (double*)(b + o_io); w.prior_out = (double*)(b + o_po); w.cand_cost = (double*)(b + o_cc);
-    w.Hd = (double*)(b + o_hd); w.Sc = (double*)(b + o_sc); w.gvec = (double*)(b + o_g);
+    w.packets[0] = (double*)(b + o_pk); w.imu_out[0] = (double*)(b + o_io); w.prior_out[0] = (double*)(b + o_po); w.cand_cost = (double*)(b + o_cc);
+    w.Hd[0] = (double*)(b + o_hd); w.Sc[0] = (double*)(b + o_sc); w.gvec[0] = (double*)(b + o_g);
+    w.packets[1] = (double*)(b + o_pk1); w.imu_out[1] = (double*)(b + o_io1); w.prior_out[1] = (double*)(b + o_po1);
+    w.Hd[1] = (double*)(b + o_hd1); w.Sc[1] = (double*)(b + o_sc1); w.gvec[1] = (double*)(b + o_g1);
     double* v = (double*)(b + o_v); w.scale_p = v; w.diag_p = v + n; w.grad_p = v + 2 * n; w.gn_p = v + 3 * n;
     double* vl = (double*)(b + o_vl); w.scale_l = vl; w.diag_l = vl + BE_MAX_LM; w.grad_l = vl + 2 * BE_MAX_LM; w.gn_l = vl + 3 * BE_MAX_LM;
     int32_t* iv = (int32_t*)(b + o_i); w.prior_col = iv; w.col_kind = iv + n; w.col_frame = iv + 2 * n; w.col_comp = iv + 3 * n;
@@ -187,22 +191,33 @@ static void marg_new_prior(const MargPlan& pl, const double* pose, const double*
     out->nblocks = nb;
 }
 
-static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, hipStream_t s) {
+// `slots` trust-region iterations.  speculative: the candidate of every slot but the last is linearised in full (evaluation + reduce into
+// the other set) and judged by the next solve kernel; the last one gets the cost-only evaluation and the accept kernel.  The classic form
+// (spare slots after a failed / invalid step) spends 5 launches per slot and needs no look-ahead.
+static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculative, hipStream_t s) {
     const bool kt = ctx->timing && ctx->kernel_timing;       // per-launch events (roofline measurement); off in the throughput run
+    auto eval = [&](int mode) {
+        if (kt) { StageScope k(ctx, mode == BE_EVAL_CAND_COST ? "k_be_eval_cost" : "k_be_eval_full", s); be_launch_eval(pd.ea, mode, s); }
+        else be_launch_eval(pd.ea, mode, s);
+    };
+    auto reduce = [&](int spec) {
+        if (kt) { StageScope k(ctx, "k_be_reduce", s); be_launch_reduce(pd.sa, spec, s); }
+        else be_launch_reduce(pd.sa, spec, s);
+    };
+    auto solve = [&](int spec) {
+        if (kt) { StageScope k(ctx, "k_be_solve", s); return be_launch_solve(pd.sa, spec, s); }
+        return be_launch_solve(pd.sa, spec, s);
+    };
+    auto accept = [&]() {
+        if (kt) { StageScope k(ctx, "k_be_accept", s); be_launch_accept(pd.sa, s); }
+        else be_launch_accept(pd.sa, s);
+    };
     for (int it = 0; it < slots; ++it) {
-        if (kt) {
-            { StageScope k(ctx, "k_be_eval_full", s); be_launch_eval(pd.ea, true, s); }
-            { StageScope k(ctx, "k_be_reduce", s); be_launch_reduce(pd.sa, s); }
-            { StageScope k(ctx, "k_be_solve", s); if (be_launch_solve(pd.sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size"); }
-            { StageScope k(ctx, "k_be_eval_cost", s); be_launch_eval(pd.ea, false, s); }
-            { StageScope k(ctx, "k_be_accept", s); be_launch_accept(pd.sa, s); }
-        } else {
-            be_launch_eval(pd.ea, true, s);
-            be_launch_reduce(pd.sa, s);
-            if (be_launch_solve(pd.sa, s)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
-            be_launch_eval(pd.ea, false, s);
-            be_launch_accept(pd.sa, s);
-        }
+        const bool head = !speculative || it == 0, last = !speculative || it == slots - 1;
+        if (head) { eval(BE_EVAL_X); reduce(0); }
+        if (solve(head ? 0 : 1)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
+        if (last) { eval(BE_EVAL_CAND_COST); accept(); }
+        else { eval(BE_EVAL_CAND_FULL); reduce(1); }
     }
     return 0;
 }
@@ -335,10 +350,12 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     // ---- schedule ----
     BeEvalArgs ea{};
     ea.ctl = w.ctl; ea.x = w.x; ea.cand = w.cand; ea.fac = w.fac; ea.lm = w.lm; ea.imu = w.imu; ea.prior = w.prior; ea.priorA = w.priorA; ea.priorb = w.priorb;
-    ea.dims = d; ea.g_norm = P->g_norm; ea.packets = w.packets; ea.imu_out = w.imu_out; ea.prior_out = w.prior_out; ea.cand_cost = w.cand_cost; ea.prior_c0 = w.prior_c0 + w.prior_cur;
+    ea.dims = d; ea.g_norm = P->g_norm; ea.cand_cost = w.cand_cost; ea.prior_c0 = w.prior_c0 + w.prior_cur;
+    for (int k = 0; k < 2; ++k) { ea.packets[k] = w.packets[k]; ea.imu_out[k] = w.imu_out[k]; ea.prior_out[k] = w.prior_out[k]; }
     BeSolveArgs sa{};
     sa.ctl = w.ctl; sa.x = w.x; sa.cand = w.cand; sa.lm = w.lm; sa.imu = w.imu; sa.prior = w.prior; sa.priorA = w.priorA; sa.dims = d;
-    sa.packets = w.packets; sa.imu_out = w.imu_out; sa.prior_out = w.prior_out; sa.cand_cost = w.cand_cost; sa.Hd = w.Hd; sa.Sc = w.Sc; sa.gvec = w.gvec;
+    sa.cand_cost = w.cand_cost;
+    for (int k = 0; k < 2; ++k) { sa.packets[k] = w.packets[k]; sa.imu_out[k] = w.imu_out[k]; sa.prior_out[k] = w.prior_out[k]; sa.Hd[k] = w.Hd[k]; sa.Sc[k] = w.Sc[k]; sa.gvec[k] = w.gvec[k]; }
     sa.scale_p = w.scale_p; sa.diag_p = w.diag_p; sa.grad_p = w.grad_p; sa.gn_p = w.gn_p; sa.scale_l = w.scale_l; sa.diag_l = w.diag_l; sa.grad_l = w.grad_l; sa.gn_l = w.gn_l;
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;
     // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
@@ -348,14 +365,14 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     if (fused) { std::memcpy(pd.gauge_R0, fused->R0, sizeof(pd.gauge_R0)); std::memcpy(pd.gauge_ypr0, fused->ypr0, sizeof(pd.gauge_ypr0)); std::memcpy(pd.gauge_P0, fused->P0, sizeof(pd.gauge_P0)); }
     pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = 1 - w.prior_cur;
     if (eval_only) {        // dv_ba_eval: one evaluation + assembly of the reduced camera system at the given states (mu = 0)
-        be_launch_eval(ea, true, s);
-        be_launch_reduce(sa, s);
+        be_launch_eval(ea, BE_EVAL_X, s);
+        be_launch_reduce(sa, 0, s);
         DV_CHECK(hipGetLastError());
         return 0;
     }
     static const bool force_retry = std::getenv("DVINS_TEST_FORCE_RETRY_TAIL") != nullptr;      // test hook: exercise the spare-slot path of be_solve_fused_end
     const int first_slots = force_retry ? std::max(1, P->max_iters - 2) : P->max_iters;
-    { StageScope sc(ctx, "ba_solve", s); if (be_enqueue_slots(ctx, pd, first_slots, s)) return -1; }
+    { StageScope sc(ctx, "ba_solve", s); if (be_enqueue_slots(ctx, pd, first_slots, true, s)) return -1; }
     std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
     if (be_enqueue_tail(ctx, pd, s)) return -1;
     pd.active = true; pd.t_begin = t_begin; pd.t_up = t_up; pd.t_enq = t_enq;
@@ -383,7 +400,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     if (be_check_prev_marg(ctx, pd)) return -1;
     if (!hctl->done) {        // rare: a failed linear solve / invalid step used up slots -> the 3 spare slots, then the tail once more
         // (the raw solution is still in w.x: the gauge fix writes to the candidate buffer; the marginalization reads the untouched old prior)
-        if (be_enqueue_slots(ctx, pd, 3, s)) return -1;
+        if (be_enqueue_slots(ctx, pd, 3, false, s)) return -1;
         if (be_enqueue_tail(ctx, pd, s)) return -1;
         DV_CHECK(hipEventSynchronize(w.ev_state));
     }
@@ -434,11 +451,11 @@ int dv_ba_eval(dv_ctx* ctx, const dv_ba_problem* P, int* n_out, double* cost, do
     const int n = pd.sa.dims.nstate, NBR = (n + 3) / 4, nblk = NBR * (NBR + 1) / 2;
     *n_out = n;
     std::vector<double> blk((size_t)nblk * 16), gv(2 * (size_t)n), lcost((size_t)std::max(P->nlm, 1)), io((size_t)std::max(P->nimu, 1) * IMU_OUT_STRIDE), pc(1);
-    DV_CHECK(hipMemcpyAsync(blk.data(), w.Sc, 8 * blk.size(), hipMemcpyDeviceToHost, s));
-    DV_CHECK(hipMemcpyAsync(gv.data(), w.gvec, 8 * gv.size(), hipMemcpyDeviceToHost, s));
-    if (P->nlm) DV_CHECK(hipMemcpyAsync(lcost.data(), w.packets + (size_t)BE_PK_COST * BE_PK_STRIDE, 8 * (size_t)P->nlm, hipMemcpyDeviceToHost, s));
-    if (P->nimu) DV_CHECK(hipMemcpyAsync(io.data(), w.imu_out, 8 * (size_t)P->nimu * IMU_OUT_STRIDE, hipMemcpyDeviceToHost, s));
-    DV_CHECK(hipMemcpyAsync(pc.data(), w.prior_out, 8, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(blk.data(), w.Sc[0], 8 * blk.size(), hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(gv.data(), w.gvec[0], 8 * gv.size(), hipMemcpyDeviceToHost, s));
+    if (P->nlm) DV_CHECK(hipMemcpyAsync(lcost.data(), w.packets[0] + (size_t)BE_PK_COST * BE_PK_STRIDE, 8 * (size_t)P->nlm, hipMemcpyDeviceToHost, s));
+    if (P->nimu) DV_CHECK(hipMemcpyAsync(io.data(), w.imu_out[0], 8 * (size_t)P->nimu * IMU_OUT_STRIDE, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(pc.data(), w.prior_out[0], 8, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
     if (cost) { double c = 0; for (int l = 0; l < P->nlm; ++l) c += lcost[l]; for (int k = 0; k < P->nimu; ++k) c += io[(size_t)k * IMU_OUT_STRIDE]; c += pc[0]; *cost = c; }
     if (g) for (int i = 0; i < n; ++i) g[i] = gv[i] - gv[n + i];
@@ -494,7 +511,7 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
         DV_CHECK(hipMemcpyAsync(w.priorb_buf[w.prior_cur], P->prior_b, 8 * (size_t)ph.n, hipMemcpyHostToDevice, s));
         w.prior_resident = false;
     }
-    double* d_outA = w.Sc; double* d_outb = w.gvec; double* d_scal = w.marg_scal;      // Sc / gvec are idle outside a solve
+    double* d_outA = w.Sc[0]; double* d_outb = w.gvec[0]; double* d_scal = w.marg_scal;      // Sc / gvec are idle outside a solve
     if (marg_enqueue(ctx, pl, w.x, P->g_norm, w.priorA_buf[w.prior_cur], w.priorb_buf[w.prior_cur], d_outA, d_outb, d_scal, nullptr, s)) return -1;
     DV_CHECK(hipGetLastError());
     double scal[4];

@@ -21,12 +21,14 @@ using namespace be;
 
 template <bool FULL>
 #define EV_THREADS 256
-__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
+__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
-    if (FULL && !c.need_eval) return;
-    if (!FULL && (c.chol_fail || !c.step_valid)) return;
-    const BeState* st = FULL ? a.x : a.cand;
+    if (mode == BE_EVAL_X ? !c.need_eval : !c.pending) return;
+    const BeState* st = mode == BE_EVAL_X ? a.x : a.cand;
+    const int set = mode == BE_EVAL_X ? c.cur : (c.cur ^ 1);
+    double* const o_packets = a.packets[set]; double* const o_imu = a.imu_out[set]; double* const o_prior = a.prior_out[set];
+    const bool want_cost = mode != BE_EVAL_X;
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int nlm = a.dims.nlm, nimu = a.dims.nimu;
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
         __syncthreads();
         double cost = 0;
         for (int f = 0; f < L.count; ++f) cost += s_cost[f];      // fixed order
-        if (!FULL) { if (lane == 0) a.cand_cost[b] = cost; return; }
+        if (want_cost && lane == 0) a.cand_cost[b] = cost;
+        if (!FULL) return;
         const int anchor = L.anchor, nf = L.count;
         for (int e = lane; e < BE_PK_SIZE; e += EV_THREADS) {
             double v = 0.0;
@@ -116,7 +119,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
                     }
                 }
             }
-            BE_PK(a.packets, e, b) = v;
+            BE_PK(o_packets, e, b) = v;
         }
     } else if (b < nlm + nimu) {
         // ------------------------------- IMU factor -------------------------------
@@ -145,8 +148,9 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
         double cost = 0;
         for (int i = 0; i < 15; ++i) cost += rr[15 + i] * rr[15 + i];
         cost *= 0.5;
-        if (!FULL) { if (lane == 0) a.cand_cost[b] = cost; return; }
-        double* o = a.imu_out + (size_t)k * IMU_OUT_STRIDE;
+        if (want_cost && lane == 0) a.cand_cost[b] = cost;
+        if (!FULL) return;
+        double* o = o_imu + (size_t)k * IMU_OUT_STRIDE;
         if (lane == 0) o[0] = cost;
         if (lane < 30) { double s = 0; for (int i = 0; i < 15; ++i) s += Jw[i * 30 + lane] * rr[15 + i]; o[1 + lane] = s; }
         for (int e = lane; e < 900; e += EV_THREADS) {
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
     } else {
         // ------------------------------- prior -------------------------------
         const BePriorHdr* p = a.prior;
-        if (!p->valid) { if (lane == 0) { if (FULL) a.prior_out[0] = 0.0; else a.cand_cost[b] = 0.0; } return; }
+        if (!p->valid) { if (lane == 0) { if (FULL) o_prior[0] = 0.0; if (want_cost) a.cand_cost[b] = 0.0; } return; }
         __shared__ double dx[BE_MAX_PRIOR], Adx[BE_MAX_PRIOR];
         const int n = p->n;
         be_prior_dx_dev(p, st, dx, lane, EV_THREADS);
@@ -180,16 +184,17 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a) {
             double bd = 0, dAd = 0;
             for (int i = 0; i < n; ++i) { bd += a.priorb[i] * dx[i]; dAd += dx[i] * Adx[i]; }
             const double cost = 0.5 * a.prior_c0[0] + bd + 0.5 * dAd;
-            if (FULL) a.prior_out[0] = cost; else a.cand_cost[b] = cost;
+            if (FULL) o_prior[0] = cost;
+            if (want_cost) a.cand_cost[b] = cost;
         }
-        if (FULL) for (int i = lane; i < n; i += EV_THREADS) a.prior_out[1 + i] = a.priorb[i] + Adx[i];
+        if (FULL) for (int i = lane; i < n; i += EV_THREADS) o_prior[1 + i] = a.priorb[i] + Adx[i];
     }
 }
 
-void be_launch_eval(const BeEvalArgs& a, bool full, hipStream_t s) {
+void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s) {
     const int grid = a.dims.nlm + a.dims.nimu + 1;
-    if (full) hipLaunchKernelGGL(be_eval_kernel<true>, dim3(grid), dim3(EV_THREADS), 0, s, a);
-    else hipLaunchKernelGGL(be_eval_kernel<false>, dim3(grid), dim3(EV_THREADS), 0, s, a);
+    if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_kernel<true>, dim3(grid), dim3(EV_THREADS), 0, s, a, mode);
+    else hipLaunchKernelGGL(be_eval_kernel<false>, dim3(grid), dim3(EV_THREADS), 0, s, a, mode);
 }
 
 // ---- operator-level factor evaluation (parity tests against the oracle's dvo_proj_eval / dvo_imu_eval) ----

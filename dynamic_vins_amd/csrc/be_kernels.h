@@ -10,10 +10,11 @@ struct BeEvalArgs {
     const BeState* x; const BeState* cand;
     const BeFactor* fac; const BeLm* lm; const BeImu* imu; const BePriorHdr* prior; const double* priorA; const double* priorb;
     BeDims dims; double g_norm;
-    double* packets;        // [nlm][BE_PK_SIZE]                   written by the full evaluation at x
-    double* imu_out;        // [nimu][936]: cost, g[30], H[30][30]
-    double* prior_out;      // cost, g[n_prior]
-    double* cand_cost;      // [nlm + nimu + 1]                    written by the cost-only evaluation at cand
+    // the linearisation exists twice: set ctl->cur belongs to x, the other one receives the SPECULATIVE linearisation at the candidate
+    double* packets[2];     // [nlm][BE_PK_SIZE]                   written by the full evaluation
+    double* imu_out[2];     // [nimu][936]: cost, g[30], H[30][30]
+    double* prior_out[2];   // cost, g[n_prior]
+    double* cand_cost;      // [nlm + nimu + 1]                    written by the evaluations at cand
     const double* prior_c0; // the prior's constant r0^T r0, device resident (the marginalization of the previous frame may still be writing it
                             // when this solve is being prepared on the host)
 };
@@ -23,10 +24,10 @@ struct BeSolveArgs {
     BeState* x; BeState* cand;
     const BeLm* lm; const BeImu* imu; const BePriorHdr* prior; const double* priorA;
     BeDims dims;
-    const double* packets; const double* imu_out; const double* prior_out; const double* cand_cost;
-    double* Hd;             // [n][n] everything except the Schur term
-    double* Sc;             // Hd - sum_l rho_l w_l w_l^T (the Schur complement before scaling), block-packed lower triangle (blk_pos in be_solve.hip)
-    double* gvec;           // [n] gradient g_p ; [n..2n) Schur part sum_l rho_l w_l g_l
+    const double* packets[2]; const double* imu_out[2]; const double* prior_out[2]; const double* cand_cost;
+    double* Hd[2];          // [n][n] everything except the Schur term
+    double* Sc[2];          // Hd - sum_l rho_l w_l w_l^T (the Schur complement before scaling), block-packed lower triangle (blk_pos in be_solve.hip)
+    double* gvec[2];        // [n] gradient g_p ; [n..2n) Schur part sum_l rho_l w_l g_l
     double* scale_p; double* diag_p; double* grad_p; double* gn_p;     // [n]
     double* scale_l; double* diag_l; double* grad_l; double* gn_l;     // [nlm]
     int32_t* prior_col;     // [BE_MAX_STATE] prior index of each state column (-1 if absent)
@@ -79,11 +80,18 @@ __device__ inline void be_prior_dx_dev(const BePriorHdr* p, const BeState* s, do
 
 #endif
 
-void be_launch_eval(const BeEvalArgs& a, bool full, hipStream_t s);
+// Iteration schedule (be_api.hip): the classic slot is  eval(x) -> reduce -> solve -> eval-cost(cand) -> accept.  The speculative slot
+// linearises AT THE CANDIDATE instead (full evaluation + reduce into the other set, with the mu an accepted step would leave) and lets the
+// next solve kernel take the accept / reject decision in its prologue: 3 launches per iteration instead of 5, and an accepted step
+// (the common case) finds its reduced system ready.  A rejected step costs one wasted reduce.
+#define BE_EVAL_X 0         // full evaluation at x into set cur            (runs if need_eval)
+#define BE_EVAL_CAND_COST 1 // costs only at cand                           (runs if pending)
+#define BE_EVAL_CAND_FULL 2 // full evaluation at cand into set cur ^ 1 + costs (runs if pending)
+void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s);
 int  be_launch_marg(const BeMargArgs& a, hipStream_t s);
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
-void be_launch_reduce(const BeSolveArgs& a, hipStream_t s);
-int  be_launch_solve(const BeSolveArgs& a, hipStream_t s);
+void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s);      // spec: reduce the candidate's set (or, after a failed / invalid step, rebuild x's with the new mu)
+int  be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s);        // spec: decide on the pending candidate first (be_accept_kernel's rule)
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);
 void be_launch_proj_op(const BeFactor* fac, int n, const double* pose_i, const double* pose_j, const double* ex0, const double* ex1,
                        const double* lambda, const double* td, double* out, hipStream_t s);

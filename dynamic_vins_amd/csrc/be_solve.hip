@@ -27,7 +27,7 @@ using namespace be;
 #define RED_PAIRS (BE_NF * BE_NF)
 
 // IMU + prior part of Hd(i, j)  (everything that is not a landmark sum)
-__device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, int i, int j) {
+__device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, const double* imu_out, int i, int j) {
     const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i];
     const int kj = a.col_kind[j], fj = a.col_frame[j], cj = a.col_comp[j];
     double H = 0.0;
@@ -36,7 +36,7 @@ __device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, int i, int j
         int li = -1, lj = -1;
         if (fi == m->fi) li = (ki == 0 ? ci : 6 + ci); else if (fi == m->fj) li = (ki == 0 ? 15 + ci : 21 + ci);
         if (fj == m->fi) lj = (kj == 0 ? cj : 6 + cj); else if (fj == m->fj) lj = (kj == 0 ? 15 + cj : 21 + cj);
-        if (li >= 0 && lj >= 0) H += a.imu_out[(size_t)k * IMU_OUT_STRIDE + 31 + li * 30 + lj];
+        if (li >= 0 && lj >= 0) H += imu_out[(size_t)k * IMU_OUT_STRIDE + 31 + li * 30 + lj];
     }
     if (a.prior->valid) {
         const int pi = a.prior_col[i], pj = a.prior_col[j];
@@ -44,16 +44,16 @@ __device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, int i, int j
     }
     return H;
 }
-__device__ __forceinline__ double red_dense_g(const BeSolveArgs& a, int i) {
+__device__ __forceinline__ double red_dense_g(const BeSolveArgs& a, const double* imu_out, const double* prior_out, int i) {
     const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i];
     double G = 0.0;
     for (int k = 0; k < a.dims.nimu; ++k) {
         const BeImu* m = &a.imu[k];
         int li = -1;
         if (fi == m->fi) li = (ki == 0 ? ci : 6 + ci); else if (fi == m->fj) li = (ki == 0 ? 15 + ci : 21 + ci);
-        if (li >= 0) G += a.imu_out[(size_t)k * IMU_OUT_STRIDE + 1 + li];
+        if (li >= 0) G += imu_out[(size_t)k * IMU_OUT_STRIDE + 1 + li];
     }
-    if (a.prior->valid) { const int pi = a.prior_col[i]; if (pi >= 0) G += a.prior_out[1 + pi]; }
+    if (a.prior->valid) { const int pi = a.prior_col[i]; if (pi >= 0) G += prior_out[1 + pi]; }
     return G;
 }
 // Position of entry (i, j), j's block <= i's block, in the block-packed lower triangle consumed by the factorisation:
@@ -70,11 +70,16 @@ __device__ __forceinline__ double wave_sum(double v) {      // fixed xor tree: d
 
 // blocks [0, 121): pose block (fi, fj) of the reduced system — landmark sums read the transposed packets coalesced
 //                  (lane = landmark), wave-tree reduced; blocks [121, ..): every entry that has no landmark term.
-__global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a) {
+__global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, int spec) {
     const BeCtl c = *a.ctl;
-    if (c.done || (!c.need_eval && !c.chol_fail)) return;      // Hd/Sc are still valid when the last step was rejected
+    if (c.done) return;
+    int set = c.cur; double mu = c.mu;
+    if (spec && c.pending) { set ^= 1; mu = fmax(1e-8, 2.0 * c.mu / 10.0); }      // the candidate's set, with the mu be_accept leaves behind an accepted step
+    else if (!c.need_eval && !c.chol_fail) return;                                // Hd/Sc are still valid when the last step was rejected
     const int n = a.dims.nstate, nlm = a.dims.nlm;
-    const double* pk = a.packets;
+    const double* pk = a.packets[set];
+    double* const Hd = a.Hd[set]; double* const Sc = a.Sc[set]; double* const gvec = a.gvec[set];
+    const double* const imu_out = a.imu_out[set]; const double* const prior_out = a.prior_out[set];
     if (blockIdx.x < RED_PAIRS) {
         const int fi = blockIdx.x / BE_NF, fj = blockIdx.x - fi * BE_NF;
         if (fi >= a.dims.nframes || fj >= a.dims.nframes) return;
@@ -91,7 +96,7 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a) {
             const double h = BE_PK(pk, BE_PK_H, l);
             const double s = c.first ? 1.0 / (1.0 + sqrt(h)) : a.scale_l[l];
             double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
-            const double rho = 1.0 / (h + c.mu * d2 / (s * s));
+            const double rho = 1.0 / (h + mu * d2 / (s * s));
             const double wi = BE_PK(pk, e_wi, l);
 #pragma unroll
             for (int q = 0; q < 6; ++q) S[q] += rho * (wi * BE_PK(pk, e_wj + q, l));      // rho * (wi * wj): bitwise symmetric
@@ -119,13 +124,13 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a) {
 #pragma unroll
             for (int q = 1; q < 6; ++q) if (lane == q) { sv = S[q]; hv = H[q]; }
             const int i = ci0 + ci, j = cj0 + lane;
-            const double hd = hv + red_dense_h(a, i, j);
-            a.Hd[(size_t)i * n + j] = hd;
-            if ((j >> 2) <= (i >> 2)) a.Sc[blk_pos(i, j, (n + 3) >> 2)] = hd - sv;
+            const double hd = hv + red_dense_h(a, imu_out, i, j);
+            Hd[(size_t)i * n + j] = hd;
+            if ((j >> 2) <= (i >> 2)) Sc[blk_pos(i, j, (n + 3) >> 2)] = hd - sv;
         } else if (diag && lane == 6) {
             const int i = ci0 + ci;
-            a.gvec[i] = G + red_dense_g(a, i);
-            a.gvec[n + i] = GS;
+            gvec[i] = G + red_dense_g(a, imu_out, prior_out, i);
+            gvec[n + i] = GS;
         }
         return;
     }
@@ -136,20 +141,20 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a) {
     if (t < n * n) {
         const int i = t / n, j = t - i * n;
         if (a.col_kind[i] == 0 && a.col_kind[j] == 0) return;          // pose x pose: written by the pair blocks
-        const double hd = red_dense_h(a, i, j);
-        a.Hd[t] = hd;
-        if ((j >> 2) <= (i >> 2)) a.Sc[blk_pos(i, j, (n + 3) >> 2)] = hd;
+        const double hd = red_dense_h(a, imu_out, i, j);
+        Hd[t] = hd;
+        if ((j >> 2) <= (i >> 2)) Sc[blk_pos(i, j, (n + 3) >> 2)] = hd;
     } else if (t < n * n + n) {
         const int i = t - n * n;
         if (a.col_kind[i] == 0) return;
-        a.gvec[i] = red_dense_g(a, i); a.gvec[n + i] = 0.0;
+        gvec[i] = red_dense_g(a, imu_out, prior_out, i); gvec[n + i] = 0.0;
     }
 }
 
-void be_launch_reduce(const BeSolveArgs& a, hipStream_t s) {
+void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s) {
     const int n = a.dims.nstate;
     const int total = n * n + n;
-    hipLaunchKernelGGL(be_reduce_kernel, dim3(RED_PAIRS + (total + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, s, a);
+    hipLaunchKernelGGL(be_reduce_kernel, dim3(RED_PAIRS + (total + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, s, a, spec);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -233,7 +238,7 @@ __device__ __forceinline__ double fast_rcp(double d) {      // v_rcp_f64 + two N
 // On success: Lm = unit-lower L (packed row-major), dvec = D, zfin = L^-1 rhs.   Returns false on a non-positive pivot.
 #define PSTR 184            // row stride of the panel buffers (>= 4 * ceil(178 / 4), even)
 template <int NSLOT>
-__device__ __forceinline__ bool ldlt_blocked(const BeSolveArgs& a, int n, double mu, const double* v_s, const double* v_d,
+__device__ __forceinline__ bool ldlt_blocked(const double* __restrict__ Sc, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
                                              double* Lm, double* PL, double* PD, double* dinfo, double* zfin, double* dvec, int* s_fail) {
     const int tid = threadIdx.x;
     const int NBR = (n + 3) >> 2, nblk = NBR * (NBR + 1) / 2;
@@ -247,7 +252,7 @@ __device__ __forceinline__ bool ldlt_blocked(const BeSolveArgs& a, int n, double
         const bool have = bi[b] >= 0;
         double dv[4][4];
         {   // one 128-byte block per thread, consecutive threads -> consecutive blocks: 4 coalesced 32-byte loads
-            const double4* src = reinterpret_cast<const double4*>(a.Sc + (size_t)(have ? idx : 0) * 16);
+            const double4* src = reinterpret_cast<const double4*>(Sc + (size_t)(have ? idx : 0) * 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const double4 q = src[r]; dv[r][0] = q.x; dv[r][1] = q.y; dv[r][2] = q.z; dv[r][3] = q.w; }
         }
@@ -264,7 +269,7 @@ __device__ __forceinline__ bool ldlt_blocked(const BeSolveArgs& a, int n, double
                 if (i == j) v = ok ? v + mu * v_d[ok ? i : 0] * v_d[ok ? i : 0] : 1.0;      // padding rows: identity
                 A[b][r][cc] = v;
             }
-            zr[b][r] = (iok && bi[b] == bj[b]) ? si * (a.gvec[i] - a.gvec[n + i]) : 0.0;
+            zr[b][r] = (iok && bi[b] == bj[b]) ? si * (gvec[i] - gvec[n + i]) : 0.0;
         }
     }
     if (tid == 0) *s_fail = 0;
@@ -414,12 +419,54 @@ __device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, doub
 }
 
 template <int NSLOT>
-__global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
+__global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     BeCtl* ctl = a.ctl;
-    const BeCtl c = *ctl;
+    BeCtl c = *ctl;
     if (c.done) return;
     const int n = a.dims.nstate, nlm = a.dims.nlm, tid = threadIdx.x;
+    if (spec && c.pending) {
+        // ---- decision on the candidate of the previous slot: be_accept_kernel's rule, taken here because the candidate's linearisation
+        // (set cur ^ 1) is already in place.  Every thread evaluates the same scalars; thread 0 publishes the control block. ----
+        __shared__ double red4[4];
+        const int ncost = nlm + a.dims.nimu + 1;
+        double part = 0;
+        if (tid < 256) for (int k = tid; k < ncost; k += 256) part += a.cand_cost[k];      // the summation tree of be_accept_kernel, bit for bit
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (tid < 256 && (tid & 63) == 0) red4[tid >> 6] = part;
+        __syncthreads();
+        const double cand_cost = red4[0] + red4[1] + red4[2] + red4[3];
+        c.slots += 1; c.iter += 1; c.cand_cost = cand_cost; c.invalid = 0; c.pending = 0;
+        bool done = false, accept = false; int term = 0;
+        if (c.step_norm <= 1e-8 * (c.x_norm + 1e-8)) { done = true; term = 1; }                       // parameter tolerance
+        else if (fabs(c.x_cost - cand_cost) <= 1e-6 * c.x_cost) { done = true; term = 1; }           // function tolerance
+        else {
+            const double rel = (c.x_cost - cand_cost) / c.model_cost_change;
+            if (rel > 1e-3) {
+                accept = true;
+                double radius = c.radius;
+                if (rel < 0.25) radius *= 0.5;
+                if (rel > 0.75) radius = fmax(radius, 3.0 * c.dogleg_norm);
+                c.radius = radius; c.mu = fmax(1e-8, 2.0 * c.mu / 10.0);
+                c.x_cost = cand_cost; c.successful += 1; c.reuse = 0; c.need_eval = 0; c.cur ^= 1;      // the candidate's set becomes x's
+            } else {
+                c.radius = c.radius * 0.5; c.reuse = 1; c.need_eval = 0;
+                if (c.radius < 1e-32) { done = true; term = 1; }
+            }
+            if (!done && c.iter >= c.max_iters) { done = true; term = 0; }
+        }
+        if (accept) {
+            double* dst = reinterpret_cast<double*>(a.x);
+            const double* src = reinterpret_cast<const double*>(a.cand);
+            const int used = (int)(offsetof(BeState, inv_depth) / sizeof(double)) + nlm;
+            for (int k = tid; k < used; k += SOL_THREADS) dst[k] = src[k];
+        }
+        if (done) { c.done = 1; c.termination = term; }
+        if (tid == 0) *ctl = c;
+        if (done) return;
+        __syncthreads();          // x is re-read below
+    }
     const int npk = n * (n + 1) / 2;
     double* Lm = sm;                                   // npk: unit-lower factor, packed row-major
     double* v_s = Lm + npk;                            // scale
@@ -439,7 +486,9 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
     double* dinfo = red;                               // 2 x 16 (red[] is idle during the factorisation)
     __shared__ int s_fail;
     const double mu = c.mu;
-    const double* pk = a.packets;
+    const double* pk = a.packets[c.cur];
+    const double* const Hd = a.Hd[c.cur]; const double* const gvec = a.gvec[c.cur];
+    const double* const imu_out = a.imu_out[c.cur]; const double* const prior_out = a.prior_out[c.cur];
     auto gather66 = [&](const double* v) {             // q66[a*6+r] = v[pose_col[a] + r] (0 for constant / absent poses)
         if (tid < 66) { const int fa = tid / 6, r = tid - fa * 6; const int col = fa < a.dims.nframes ? a.dims.pose_col[fa] : -1; q66[tid] = col >= 0 ? v[col + r] : 0.0; }
         __syncthreads();
@@ -476,12 +525,11 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
     if (!c.reuse) {
         // ---------------- scaling, diagonal, gradient ----------------
         for (int i = tid; i < n; i += SOL_THREADS) {
-            const double hii = a.Hd[(size_t)i * n + i];
+            const double hii = Hd[(size_t)i * n + i];
             const double s = c.first ? 1.0 / (1.0 + sqrt(hii)) : a.scale_p[i];
             double d2 = hii * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
             const double d = sqrt(d2);
-            v_s[i] = s; v_d[i] = d; v_grad[i] = a.gvec[i] * s / d;
-            v_t[i] = s * s * a.gvec[i] / d2;           // u_p = S v, v = gradient_/diag
+            v_s[i] = s; v_d[i] = d; v_grad[i] = gvec[i] * s / d;
             if (c.first) a.scale_p[i] = s;
             a.diag_p[i] = d; a.grad_p[i] = v_grad[i];
         }
@@ -489,15 +537,15 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
         if (c.first) {        // x_cost: fixed-order sum of the per-block costs at x
             double part = 0;
             for (int l = tid; l < nlm; l += SOL_THREADS) part += BE_PK(pk, BE_PK_COST, l);
-            for (int k = tid; k < a.dims.nimu; k += SOL_THREADS) part += a.imu_out[(size_t)k * IMU_OUT_STRIDE];
-            if (tid == 0) part += a.prior_out[0];
+            for (int k = tid; k < a.dims.nimu; k += SOL_THREADS) part += imu_out[(size_t)k * IMU_OUT_STRIDE];
+            if (tid == 0) part += prior_out[0];
             const double xc = block_sum(part, red);
             if (tid == 0) { ctl->x_cost = xc; ctl->initial_cost = xc; }
         }
         // gradient tolerance (trust_region_minimizer.cc: gradient_max_norm <= gradient_tolerance = 1e-10), checked on every new gradient
         {
             double gm = 0;
-            for (int i = tid; i < n; i += SOL_THREADS) gm = fmax(gm, fabs(a.gvec[i]));
+            for (int i = tid; i < n; i += SOL_THREADS) gm = fmax(gm, fabs(gvec[i]));
             for (int l = tid; l < nlm; l += SOL_THREADS) gm = fmax(gm, fabs(BE_PK(pk, BE_PK_G, l)));
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
@@ -509,30 +557,20 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
             if (gm <= 1e-10) { if (tid == 0) { ctl->done = 1; ctl->termination = 1; ctl->first = 0; } return; }
         }
         TS(1);
-        // Cauchy point: alpha = |gradient_|^2 / (u^T H u)
-        gemv_hd(a.Hd, n, v_t, v_t2, scratch, tid);
-        TS(2);
-        gather66(v_t);
-        wdot_all();
-        double uHu = 0, gg = 0;
-        for (int i = tid; i < n; i += SOL_THREADS) { uHu += v_t[i] * v_t2[i]; gg += v_grad[i] * v_grad[i]; }
+        // landmark part of the diagonal and of the scaled gradient (the Cauchy point itself is computed lazily, see below)
         for (int l = tid; l < nlm; l += SOL_THREADS) {
             const double h = BE_PK(pk, BE_PK_H, l), gl = BE_PK(pk, BE_PK_G, l), s = a.scale_l[l];
             double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
-            const double d = sqrt(d2), grad = gl * s / d, u = s * s * gl / d2;
-            a.diag_l[l] = d; a.grad_l[l] = grad;
-            uHu += 2.0 * u * wd[l] + h * u * u;
-            gg += grad * grad;
+            const double d = sqrt(d2);
+            a.diag_l[l] = d; a.grad_l[l] = gl * s / d;
         }
-        { double sv2[2] = {uHu, gg}; block_sum_n<2>(sv2, red); uHu = sv2[0]; gg = sv2[1]; }
-        const double alpha = gg / uHu;
-        if (tid == 0) misc[0] = alpha;                 // materialised now: keeps the partial sums from living across the factorisation
         TS(3);
         // ---------------- Gauss-Newton step: LDL^T of the Schur complement ----------------
-        if (!ldlt_blocked<NSLOT>(a, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail)) {
+        if (!ldlt_blocked<NSLOT>(a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail)) {
             // Ceres: LINEAR_SOLVER_FAILURE -> mu *= 10 and retry (dogleg_strategy.cc ComputeGaussNewtonStep)
             if (tid == 0) {
-                ctl->mu = mu * 10.0; ctl->chol_fail = 1; ctl->first = 0; ctl->alpha = misc[0];
+                ctl->mu = mu * 10.0; ctl->chol_fail = 1; ctl->first = 0; ctl->alpha_valid = 0;
+                ctl->slots = c.slots + 1; ctl->reuse = 0; ctl->need_eval = 0; ctl->pending = 0;      // the slot is spent; the next reduce rebuilds Sc with the larger mu
                 if (mu * 10.0 > 1.0) { ctl->done = 1; ctl->termination = 2; }
             }
             return;
@@ -564,15 +602,11 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
             const double yl = rho / s * (BE_PK(pk, BE_PK_G, l) - wd[l]);
             a.gn_l[l] = -d * yl;
         }
-        if (tid == 0) ctl->alpha = misc[0];
         __syncthreads();
     } else {
         for (int i = tid; i < n; i += SOL_THREADS) { v_s[i] = a.scale_p[i]; v_d[i] = a.diag_p[i]; v_grad[i] = a.grad_p[i]; v_gn[i] = a.gn_p[i]; }
-        if (tid == 0) misc[0] = c.alpha;
         __syncthreads();
     }
-    const double alpha = misc[0];
-    __syncthreads();
     TS(8);
     // ---------------- traditional dogleg (dogleg_strategy.cc ComputeTraditionalDoglegStep) ----------------
     double p_gg = 0, p_nn = 0, p_gn = 0;
@@ -582,6 +616,31 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
     block_sum_n<3>(sv3, red);
     const double gnorm = sqrt(sv3[0]), gnn = sqrt(sv3[1]), gdot = sv3[2];
     const double radius = c.radius;
+    // Cauchy point alpha = |gradient_|^2 / (u^T H u), u = S (gradient_ / diag): only the dogleg's second and third case read it, so it is
+    // computed when the Gauss-Newton step first leaves the trust region (possibly slots later, after rejections: the linearisation of x
+    // is still in place) and kept in the control block from then on.  Same arithmetic whenever it is evaluated.
+    double alpha = c.alpha;
+    bool have_alpha = c.reuse && c.alpha_valid;
+    if (!(gnn <= radius) && !have_alpha) {
+        for (int i = tid; i < n; i += SOL_THREADS) { const double sp = v_s[i], dp = v_d[i]; v_t[i] = sp * sp * gvec[i] / (dp * dp); }
+        __syncthreads();
+        gemv_hd(Hd, n, v_t, v_t2, scratch, tid);
+        gather66(v_t);
+        wdot_all();
+        double uHu = 0, gg = 0;
+        for (int i = tid; i < n; i += SOL_THREADS) { uHu += v_t[i] * v_t2[i]; gg += v_grad[i] * v_grad[i]; }
+        for (int l = tid; l < nlm; l += SOL_THREADS) {
+            const double h = BE_PK(pk, BE_PK_H, l), gl = BE_PK(pk, BE_PK_G, l), sl = a.scale_l[l], dl = a.diag_l[l], grad = a.grad_l[l];
+            const double u = sl * sl * gl / (dl * dl);
+            uHu += 2.0 * u * wd[l] + h * u * u;
+            gg += grad * grad;
+        }
+        { double sv2[2] = {uHu, gg}; block_sum_n<2>(sv2, red); uHu = sv2[0]; gg = sv2[1]; }
+        alpha = gg / uHu;
+        have_alpha = true;
+        __syncthreads();
+    }
+    if (tid == 0) { ctl->alpha = alpha; ctl->alpha_valid = have_alpha ? 1 : 0; }
     double cg, cn, dnorm;
     if (gnn <= radius) { cg = 0; cn = 1; dnorm = gnn; }
     else if (gnorm * alpha >= radius) { cg = -(radius / gnorm); cn = 0; dnorm = radius; }
@@ -596,13 +655,13 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
     for (int i = tid; i < n; i += SOL_THREADS) { const double st = cg * v_grad[i] + cn * v_gn[i]; p_dn += st * st; v_t[i] = st / v_d[i] * v_s[i]; }
     __syncthreads();
     TS(9);
-    gemv_hd(a.Hd, n, v_t, v_t2, scratch, tid);
+    gemv_hd(Hd, n, v_t, v_t2, scratch, tid);
     TS(11);
     gather66(v_t);
     wdot_all();
     TS(12);
     double p_sg = 0, p_sHs = 0, p_step = 0, p_xn = 0;
-    for (int i = tid; i < n; i += SOL_THREADS) { p_sg += v_t[i] * a.gvec[i]; p_sHs += v_t[i] * v_t2[i]; }
+    for (int i = tid; i < n; i += SOL_THREADS) { p_sg += v_t[i] * gvec[i]; p_sHs += v_t[i] * v_t2[i]; }
     for (int l = tid; l < nlm; l += SOL_THREADS) {
         const double st = cg * a.grad_l[l] + cn * a.gn_l[l];
         p_dn += st * st;
@@ -639,12 +698,20 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a) {
         ctl->x_norm = sqrt(xn2);
         ctl->chol_fail = 0;
         ctl->first = 0;
+        if (mcc > 0.0) ctl->pending = 1;            // the candidate awaits its cost and the accept / reject decision
+        else {                                      // HandleInvalidStep: needs no evaluation, so it is settled here
+            ctl->pending = 0;
+            ctl->slots = c.slots + 1; ctl->iter = c.iter + 1; ctl->invalid = c.invalid + 1; ctl->mu = c.mu * 10.0; ctl->reuse = 0; ctl->need_eval = 0;
+            ctl->chol_fail = 1;                     // forces the reduce to rebuild Sc with the new mu
+            if (c.invalid + 1 >= 5) { ctl->done = 1; ctl->termination = 2; }
+            else if (c.iter + 1 >= c.max_iters) { ctl->done = 1; ctl->termination = 0; }
+        }
     }
 }
 
 static size_t solve_smem(int n) { return ((size_t)n * (n + 1) / 2 + 9 * (size_t)n + 72 + 80 + 8 + 1536) * sizeof(double); }
 
-int be_launch_solve(const BeSolveArgs& a, hipStream_t s) {
+int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return -1;
@@ -652,8 +719,8 @@ int be_launch_solve(const BeSolveArgs& a, hipStream_t s) {
         attr = true;
     }
     const int nbr = (a.dims.nstate + 3) / 4;
-    if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL(be_solve_kernel<1>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a);
-    else hipLaunchKernelGGL(be_solve_kernel<2>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a);
+    if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL(be_solve_kernel<1>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);
+    else hipLaunchKernelGGL(be_solve_kernel<2>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);
     return 0;
 }
 
@@ -664,18 +731,9 @@ __global__ __launch_bounds__(256) void be_accept_kernel(BeSolveArgs a) {
     __shared__ double red[4];
     __shared__ int s_accept;
     const int tid = threadIdx.x;
-    if (c.done) return;
-    if (tid == 0) { ctl->slots = c.slots + 1; s_accept = 0; }
-    if (c.chol_fail) { if (tid == 0) { ctl->reuse = 0; ctl->need_eval = 0; } return; }     // retry slot with the larger mu
+    if (c.done || !c.pending) return;          // failed factorisations and invalid steps are settled by the solve kernel itself
+    if (tid == 0) { ctl->slots = c.slots + 1; ctl->pending = 0; s_accept = 0; }
     const int iter = c.iter + 1;
-    if (!c.step_valid) {       // HandleInvalidStep
-        if (tid == 0) {
-            ctl->iter = iter; ctl->invalid = c.invalid + 1; ctl->mu = c.mu * 10.0; ctl->reuse = 0; ctl->need_eval = 0; ctl->chol_fail = 1;   // chol_fail=1 forces the reduce to rebuild Sc with the new mu
-            if (c.invalid + 1 >= 5) { ctl->done = 1; ctl->termination = 2; }
-            else if (iter >= c.max_iters) { ctl->done = 1; ctl->termination = 0; }
-        }
-        return;
-    }
     // candidate cost: fixed-order sum
     const int ncost = a.dims.nlm + a.dims.nimu + 1;
     double part = 0;

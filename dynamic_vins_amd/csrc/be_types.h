@@ -81,6 +81,10 @@ struct BePriorHdr {
 // solver control block (device resident; every kernel of the iteration schedule reads it first)
 struct BeCtl {
     int32_t done, need_eval, reuse, iter, invalid, termination, successful, first, max_iters, chol_fail, step_valid, slots;
+    int32_t cur;          // which of the two linearisation sets (packets, IMU / prior blocks, Hd, Sc, gvec) belongs to x
+    int32_t pending;      // a valid candidate has been produced and awaits its accept / reject decision
+    int32_t alpha_valid;  // the Cauchy point of the current linearisation has been computed (it is evaluated lazily)
+    int32_t pad_;
     double radius, mu, x_cost, cand_cost, model_cost_change, dogleg_norm, alpha, x_norm, initial_cost, step_norm;
 };
 

@@ -16,10 +16,13 @@ lib = _abi.load()
 ts = (C.c_longlong * 32)()
 lib.dv_debug_solve_ts.argtypes = [C.POINTER(C.c_longlong)]
 print("rc", lib.dv_debug_solve_ts(ts))
-t = np.array(ts[:11], dtype=np.int64)
-names = ["scale/grad", "gemv1", "cauchy-lm", "ldlt-load", "ldlt-loop", "ldlt-store", "backsub", "gn-lm", "dogleg-p", "gemv2+cand", "end"]
-for k in range(10):
-    print(f"{names[k]:12s} {(t[k+1]-t[k]) / 100.0:8.2f} us")
+t = np.array(ts[:18], dtype=np.int64)
+# stamps (be_solve.hip TS(k)): 0 start, 1 scale/grad/tolerance done, 3 landmark diag done, 4 LDL^T blocks loaded, 5 factorised,
+# 6 factor stored, 7 back substitution done, 8 Gauss-Newton step complete, 9 dogleg coefficients + delta, 11 H*delta, 12 w.delta,
+# 13 candidate written, 10 end
+seq = [(0, 1, "scale/grad/tol"), (1, 3, "landmark diag"), (3, 4, "ldlt load"), (4, 5, "ldlt loop"), (5, 6, "ldlt store"), (6, 7, "back-sub"),
+       (7, 8, "gn landmarks"), (8, 9, "dogleg (+lazy Cauchy)"), (9, 11, "gemv H*delta"), (11, 12, "w . delta"), (12, 13, "candidate"), (13, 10, "final sums")]
+for a, b, name in seq:
+    print(f"{name:24s} {(t[b] - t[a]) / 100.0:8.2f} us")
 print("total", (t[10] - t[0]) / 100.0)
-print("tail: gemv2 %.2f wdot %.2f cand %.2f sums %.2f" % ((ts[11]-ts[9])/100., (ts[12]-ts[11])/100., (ts[13]-ts[12])/100., (ts[10]-ts[13])/100.))
 print("ldlt (c)+(a) us", ts[16] / 100.0, " (b) us", ts[17] / 100.0)

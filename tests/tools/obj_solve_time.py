@@ -1,12 +1,12 @@
 """Latency of the per-frame object solve (dv_obj_solve, one persistent workgroup) against the CPU oracle on the same scenes.
-Usage: python scripts/obj_solve_time.py            (needs the GPU; prints one line per scene)"""
+Usage: python tests/tools/obj_solve_time.py            (needs the GPU; prints one line per scene)"""
 import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynamic_vins_amd.backend import obj_solve          # noqa: E402
 from dynamic_vins_amd.frontend import Context           # noqa: E402
 from tests import obj_gen as G, oracle_py               # noqa: E402

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from dynamic_vins_amd.frontend import Context, DV_FMT_BGR, DV_MEM_DEVICE, DV_MODE_RAW, make_cam      # noqa: E402
 from tests import oracle_py                                                                             # noqa: E402
 

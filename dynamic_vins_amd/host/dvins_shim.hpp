@@ -141,6 +141,7 @@ inline dv_cam ReadPinholeCamera(const std::string& path) {
 struct ImageView {                      // a CV_8UC1 cv::Mat: gray0 / gray1 / inv_merge_mask of SemanticImage
     const uint8_t* data = nullptr; int width = 0, height = 0, stride = 0;
     bool device = false;                // true: data is an HBM pointer (DV_MEM_DEVICE)
+    bool bgr = false;                   // true: 8-bit BGR (SemanticImage::color0 / color1): converted — and undistorted, if maps are installed — on the device
     bool empty() const { return data == nullptr; }
 };
 struct SemanticImage {                  // basic/semantic_image.h:30-65 (the fields the path reads)
@@ -154,7 +155,7 @@ struct FrontendFeature {                // basic/frontend_feature.h:52-75
     FeatureBackground features; double time = 0; unsigned int seq_id = 0;
 };
 #ifdef DVINS_SHIM_WITH_OPENCV
-inline ImageView View(const cv::Mat& m) { return ImageView{m.data, m.cols, m.rows, (int)m.step, false}; }
+inline ImageView View(const cv::Mat& m) { return ImageView{m.data, m.cols, m.rows, (int)m.step, false, m.channels() == 3}; }
 #endif
 #ifdef DVINS_SHIM_WITH_EIGEN
 inline Eigen::Matrix<double, 7, 1> ToEigen(const Vec7d& v) { return Eigen::Map<const Eigen::Matrix<double, 7, 1>>(v.data()); }
@@ -220,7 +221,7 @@ public:
         check_image(img);
         cur_time = img.time0;
         detail::check(ctx_, dv_track_stereo_enqueue(ctx_, img.gray0.data, img.gray1.data, img.gray0.width, img.gray0.height, img.gray0.stride, img.time0,
-                                                    img.inv_merge_mask.data, mode, img.gray0.device ? DV_MEM_DEVICE : DV_MEM_HOST), "TrackImage");
+                                                    img.inv_merge_mask.data, mode, mem_of(img.gray0)), "TrackImage");
     }
     FeatureBackground TrackImageCollect() {
         int n = 0;
@@ -233,6 +234,25 @@ public:
     dv_ctx* ctx() { return ctx_; }
     double cur_time = 0;
 
+    // cfg::is_undistort_input (utils/camera_model.cpp:481-499): hand over cam_s.{left,right}_undist_map1 / _map2 (CV_16SC2 / CV_16UC1, image
+    // size); from then on TrackImage* takes the DISTORTED frames — gray, or BGR with ImageView::bgr — and undistorts them on the way into
+    // pyramid level 0 (ImageProcessor::Run's cv::remap + SetGrayImageGpu fused).  The config's camera files must then describe the new,
+    // distortion-free intrinsics, as the reference resets them.  map1 == nullptr removes the maps.
+    void SetUndistortMaps(int cam, const int16_t* map1_xy, const uint16_t* map2) {
+        detail::check(ctx_, dv_set_undistort_maps(ctx_, cam, map1_xy, map2, cfg_.width, cfg_.height), "SetUndistortMaps");
+    }
+#ifdef DVINS_SHIM_WITH_OPENCV
+    void SetUndistortMaps(int cam, const cv::Mat& map1, const cv::Mat& map2) {
+        if (map1.type() != CV_16SC2 || map2.type() != CV_16UC1 || !map1.isContinuous() || !map2.isContinuous() || map1.cols != cfg_.width || map1.rows != cfg_.height)
+            throw std::runtime_error("dvins: SetUndistortMaps: maps must be continuous CV_16SC2 / CV_16UC1 of the image size (initUndistortRectifyMap(..., CV_16SC2, ...))");
+        SetUndistortMaps(cam, map1.ptr<int16_t>(), map2.ptr<uint16_t>());
+    }
+#endif
+    // cv::remap(src, dst, map1, map2, INTER_LINEAR) of one 8-bit image with 1 or 3 channels (e.g. the merged instance mask, semantic_image.cpp:86-89)
+    void Remap(const uint8_t* src, int stride, int channels, const int16_t* map1_xy, const uint16_t* map2, uint8_t* dst) {
+        detail::check(ctx_, dv_remap(ctx_, src, cfg_.width, cfg_.height, stride, channels, map1_xy, map2, dst, DV_MEM_HOST), "Remap");
+    }
+
 private:
     void init(const dv_config& c) {
         cfg_ = c;
@@ -240,6 +260,7 @@ private:
         if (!ctx_) throw std::runtime_error(std::string("dvins: FeatureTracker: ") + dv_last_error(nullptr));
         rows_.resize(DV_MAX_FEATS);
     }
+    static int mem_of(const ImageView& v) { return (v.device ? DV_MEM_DEVICE : DV_MEM_HOST) | (v.bgr ? DV_FMT_BGR : 0); }
     void check_image(const SemanticImage& img) const {
         if (img.gray0.empty() || (cfg_.stereo && img.gray1.empty())) throw std::runtime_error("dvins: TrackImage: empty image");
         if (img.gray0.width != cfg_.width || img.gray0.height != cfg_.height) throw std::runtime_error("dvins: TrackImage: image size differs from image_width/image_height");   // main.cpp:95-99
@@ -249,7 +270,7 @@ private:
         cur_time = img.time0;
         int n = 0;
         detail::check(ctx_, dv_track_stereo(ctx_, img.gray0.data, img.gray1.data, img.gray0.width, img.gray0.height, img.gray0.stride, img.time0,
-                                            img.inv_merge_mask.data, mode, img.gray0.device ? DV_MEM_DEVICE : DV_MEM_HOST, rows_.data(), &n), "TrackImage");
+                                            img.inv_merge_mask.data, mode, mem_of(img.gray0), rows_.data(), &n), "TrackImage");
         n_rows_ = n;
         return detail::to_points(rows_.data(), n);
     }
@@ -356,6 +377,25 @@ private:
     std::condition_variable q_cv_;
     std::deque<FrontendFeature> queue_;
 };
+
+// ---- the per-frame object solve of dynamic mode: what InstanceManager::Optimization hands to ceres (estimator_insts.cpp:772-807) ----
+// state: n_obj x 11 x 7 = Instance::para_state after SetOptimizeParameters, dims: n_obj x 3 = para_box; both are updated in place and read
+// back by Instance::GetOptimizationParameters (estimator/instance.cpp:421-503).  boxes: one record per (object, frame) with a 3-D detection
+// (BoxDimsFactor + BoxOrientationFactor), points: one per triangulated observation (BoxEncloseStereoPointFactor).
+struct InstanceSolveSummary { int iterations = 0, successful = 0, termination = 0; double initial_cost = 0, final_cost = 0; };
+inline InstanceSolveSummary OptimizeInstances(dv_ctx* ctx, int n_obj, double* state, double* dims, const double* body_para_pose /* 11 x 7 */,
+                                              const double* ric0 /* 3 x 3 row-major */, const std::vector<dv_obj_box>& boxes,
+                                              const std::vector<dv_obj_point>& points, int max_num_iterations, int plane_kind = 0) {
+    dv_obj_problem p{};
+    p.n_obj = n_obj; p.n_boxes = (int)boxes.size(); p.n_points = (int)points.size(); p.max_iters = max_num_iterations; p.plane_kind = plane_kind;
+    p.state = state; p.dims = dims; p.body_pose = body_para_pose;
+    std::memcpy(p.R_bc, ric0, sizeof(p.R_bc));
+    p.boxes = boxes.empty() ? nullptr : boxes.data(); p.points = points.empty() ? nullptr : points.data();
+    dv_ba_summary s{};
+    detail::check(ctx, dv_obj_solve(ctx, &p, &s), "OptimizeInstances");
+    InstanceSolveSummary r; r.iterations = s.iterations; r.successful = s.successful; r.termination = s.termination; r.initial_cost = s.initial_cost; r.final_cost = s.final_cost;
+    return r;
+}
 
 // ---- on-disk formats on either side of the path ----
 // trajectory line of SaveBodyTrajectory (utils/io/output.cpp:189-227): "<sec>.<nsec 9 digits> px py pz qx qy qz qw", fixed, 6 decimals

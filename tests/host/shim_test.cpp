@@ -3,7 +3,10 @@
 //   shim_test nogpu <config.yaml>                      -> constructing the tracker without a device must throw (CPU)
 //   shim_test track <config.yaml> <frames.raw> <n> <w> <h>  -> runs TrackImage over n stereo pairs read from a raw file,
 //                                                         feeds a constant-gravity IMU stream and runs the Estimator (GPU)
+//   shim_test extras <config.yaml> <frames.raw> <n> <w> <h> -> SetUndistortMaps + BGR views, OptimizeInstances (GPU)
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <thread>
@@ -69,6 +72,48 @@ int main(int argc, char** argv) {
                 std::printf("est ok %d frame %d nonlinear %d\n", (int)ok, est.frame, (int)est.solver_flag);
             }
             std::printf("%s\n", TumLine(1.0, est.WindowState(est.frame)).c_str());
+            return 0;
+        }
+        if (mode == "extras" && argc >= 7) {
+            // (1) identity undistortion maps + BGR views: TrackImage must yield what the plain gray path yields
+            // (2) OptimizeInstances on a fixed two-detection problem (tests/test_host_shim.py runs the same through ctypes)
+            const int n = std::atoi(argv[4]), w = std::atoi(argv[5]), h = std::atoi(argv[6]);
+            std::ifstream f(argv[3], std::ios::binary);
+            std::vector<uint8_t> buf((size_t)n * 2 * w * h);
+            f.read((char*)buf.data(), buf.size());
+            dv_config c{};
+            c.width = w; c.height = h; c.max_cnt = 30; c.min_dist = 10; c.flow_back = 1; c.stereo = 1;
+            c.cam0 = dv_cam{0.55 * w, 0.55 * w, 0.5 * w, 0.5 * h, 0, 0, 0, 0}; c.cam1 = c.cam0;
+            FeatureTracker plain(c), undist(c);
+            std::vector<int16_t> m1((size_t)2 * w * h); std::vector<uint16_t> m2((size_t)w * h, 0);
+            for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) { m1[((size_t)y * w + x) * 2] = (int16_t)x; m1[((size_t)y * w + x) * 2 + 1] = (int16_t)y; }
+            undist.SetUndistortMaps(0, m1.data(), m2.data());
+            undist.SetUndistortMaps(1, m1.data(), m2.data());
+            std::vector<uint8_t> bgr0((size_t)3 * w * h), bgr1((size_t)3 * w * h);
+            int same = 0;
+            for (int k = 0; k < n; ++k) {
+                const uint8_t* g0 = buf.data() + (size_t)(2 * k) * w * h; const uint8_t* g1 = buf.data() + (size_t)(2 * k + 1) * w * h;
+                for (size_t i = 0; i < (size_t)w * h; ++i) for (int ch = 0; ch < 3; ++ch) { bgr0[3 * i + ch] = g0[i]; bgr1[3 * i + ch] = g1[i]; }
+                SemanticImage a, b;
+                a.gray0 = ImageView{g0, w, h, w, false}; a.gray1 = ImageView{g1, w, h, w, false}; a.time0 = 0.05 * k;
+                b.gray0 = ImageView{bgr0.data(), w, h, 3 * w, false, true}; b.gray1 = ImageView{bgr1.data(), w, h, 3 * w, false, true}; b.time0 = 0.05 * k;
+                const FeatureBackground fa = plain.TrackImage(a), fb = undist.TrackImage(b);
+                same += fa.points == fb.points && !fa.points.empty();
+            }
+            std::printf("undistort+bgr identical frames %d of %d\n", same, n);
+            std::vector<double> state(77), dims = {4.0, 2.0, 1.5}, body(77, 0.0);
+            for (int i = 0; i < 11; ++i) { state[7 * i] = 5; state[7 * i + 1] = 1; state[7 * i + 6] = 1; body[7 * i + 6] = 1; }
+            const double ric[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+            std::vector<dv_obj_box> boxes(2);
+            const double ang[2] = {0.1, -0.05}; const int fr[2] = {3, 7};
+            for (int k = 0; k < 2; ++k) {
+                boxes[k].obj = 0; boxes[k].frame = fr[k]; boxes[k].dims[0] = 4.2; boxes[k].dims[1] = 1.9; boxes[k].dims[2] = 1.6;
+                const double cs = std::cos(ang[k]), sn = std::sin(ang[k]);
+                const double R[9] = {cs, -sn, 0, sn, cs, 0, 0, 0, 1};
+                std::memcpy(boxes[k].R_cioi, R, sizeof(R));
+            }
+            const InstanceSolveSummary r = OptimizeInstances(plain.ctx(), 1, state.data(), dims.data(), body.data(), ric, boxes, {}, 10);
+            std::printf("instances %d %d %d %.17g %.17g %.17g %.17g %.17g\n", r.iterations, r.successful, r.termination, r.initial_cost, r.final_cost, dims[0], state[7 * 3 + 5], state[7 * 7 + 6]);
             return 0;
         }
     } catch (const std::exception& e) { std::printf("EXCEPTION %s\n", e.what()); return 3; }

@@ -87,3 +87,30 @@ def test_shim_matches_the_ctypes_path(shim_exe, tmp_path, gpu_ctx_factory):
         assert abs(float(tok[9]) - first["left"][3]) < 1e-8 and abs(float(tok[10]) - first["left"][4]) < 1e-8
     est = [ln for ln in r.stdout.splitlines() if ln.startswith("est ok")]
     assert len(est) == n and all(ln.startswith("est ok 1") for ln in est)
+
+
+@pytest.mark.gpu
+def test_shim_undistort_maps_bgr_views_and_instance_solve(shim_exe, tmp_path, gpu_ctx_factory):
+    """SetUndistortMaps with identity maps + BGR ImageViews reproduce the plain gray path; OptimizeInstances == backend.obj_solve"""
+    from dynamic_vins_amd.backend import ObjProblem, OBJBOX_DTYPE, OBJPT_DTYPE, obj_solve
+    g = np.load(os.path.join(ROOT, "tests", "golden", "front_kat.npz"))
+    n, h, w = g["left"].shape
+    raw = tmp_path / "frames.raw"
+    with open(raw, "wb") as f:
+        for k in range(n):
+            f.write(g["left"][k].tobytes()); f.write(g["right"][k].tobytes())
+    r = subprocess.run([shim_exe, "extras", CFG, str(raw), str(n), str(w), str(h)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "undistort+bgr identical frames %d of %d" % (n, n)
+    state = np.zeros((1, 11, 7)); state[..., 0] = 5; state[..., 1] = 1; state[..., 6] = 1
+    body = np.zeros((11, 7)); body[:, 6] = 1
+    boxes = np.zeros(2, OBJBOX_DTYPE)
+    for k, (fr, a) in enumerate([(3, 0.1), (7, -0.05)]):
+        boxes[k]["obj"], boxes[k]["frame"], boxes[k]["dims"] = 0, fr, (4.2, 1.9, 1.6)
+        boxes[k]["R_cioi"] = [np.cos(a), -np.sin(a), 0, np.sin(a), np.cos(a), 0, 0, 0, 1]
+    p = ObjProblem(state, [[4.0, 2.0, 1.5]], body, np.eye(3), boxes, np.zeros(0, OBJPT_DTYPE), max_iters=10)
+    s = obj_solve(gpu_ctx_factory(width=64, height=48), p)
+    ref = "instances %d %d %d %.17g %.17g %.17g %.17g %.17g" % (s.iterations, s.successful, s.termination, s.initial_cost, s.final_cost, p.dims[0, 0], p.state[0, 3, 5], p.state[0, 7, 6])
+    assert out[1] == ref
+    assert s.successful > 0 and s.final_cost < s.initial_cost

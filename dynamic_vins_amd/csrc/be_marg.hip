@@ -25,6 +25,13 @@
 
 using namespace be;
 
+#ifdef BE_MARG_TS
+__device__ long long be_marg_ts[32];
+#define MTS(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) be_marg_ts[k] = wall_clock64(); } while (0)
+extern "C" int dv_debug_marg_ts(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(be_marg_ts), sizeof(long long) * 32) == hipSuccess ? 0 : -1; }
+#else
+#define MTS(k) do {} while (0)
+#endif
 #define MG_THREADS 1024
 #define LM_THREADS 256
 
@@ -54,8 +61,12 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
     __shared__ int s_fj[BE_MAX_OBS_FACTORS], s_two[BE_MAX_OBS_FACTORS];
     __shared__ double s_hg[2];
     const BeState* st = a.x;
+    MTS(0);
+    __shared__ short s_slot[BE_MAX_PRIOR], s_comp[BE_MAX_PRIOR];      // dim -> (slot, component): read once, coalesced (they were two dependent global loads per dense-row entry)
+    for (int i = tid; i < D; i += LM_THREADS) { s_slot[i] = (short)a.dim_slot[i]; s_comp[i] = (short)a.dim_comp[i]; }
     if (tid < 64) be_frame_geom_dev(st, a.nframes, fg, ric, tic, tid);
     __syncthreads();
+    MTS(1);
     const BeLm L = a.lm[a.lm_sel ? a.lm_sel[l] : l];
     const int nf = L.count, anchor = L.anchor;
     if (tid < nf) {
@@ -69,12 +80,13 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
         s_fj[tid] = f.fj; s_two[tid] = f.kind != 2;
     }
     __syncthreads();
+    MTS(2);
     for (int e = tid; e < 2 * nf * D; e += LM_THREADS) {
         const int fr = e / D, i = e - fr * D, f = fr >> 1, r = fr & 1;
-        const int slot = a.dim_slot[i];
+        const int slot = s_slot[i];
         double v = 0.0;
         int o0, o1;
-        if (slot >= 0 && mg_joff(slot, a.dim_comp[i], anchor, s_fj[f], s_two[f], o0, o1)) v = Jb[f * 54 + (r ? o1 : o0)];
+        if (slot >= 0 && mg_joff(slot, s_comp[i], anchor, s_fj[f], s_two[f], o0, o1)) v = Jb[f * 54 + (r ? o1 : o0)];
         Jd[e] = v;
     }
     if (tid == 0) {
@@ -84,21 +96,64 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
         a.lm_h[l] = h;
     }
     __syncthreads();
+    MTS(3);
+    // a landmark touches its anchor pose, the poses of the frames that observe it, the extrinsics and td: every other column of its
+    // dense rows is identically zero, and so is every slab entry with such a row or column.  The slab is therefore written in two
+    // passes: exact zeros for the structurally empty entries, and 2x2 register tiles over the lower triangle of the ACTIVE columns
+    // (each loaded row value feeds two products; the mirror entry is the same sum of commuting products, bit for bit).
+    __shared__ unsigned char s_act[BE_MAX_PRIOR];
+    __shared__ short s_acols[BE_MAX_PRIOR + 2];
+    __shared__ int s_na;
     for (int i = tid; i < D; i += LM_THREADS) {
-        double w = 0, gp = 0;
-        for (int fr = 0; fr < 2 * nf; ++fr) { const double j = Jd[fr * D + i]; const double* o = Jb + (fr >> 1) * 54; w += j * o[50 + (fr & 1)]; gp += j * o[fr & 1]; }
-        wv[i] = w; gpv[i] = gp;
+        double w = 0, gp = 0; bool act = false;
+        for (int fr = 0; fr < 2 * nf; ++fr) { const double j = Jd[fr * D + i]; const double* o = Jb + (fr >> 1) * 54; w += j * o[50 + (fr & 1)]; gp += j * o[fr & 1]; act = act || j != 0.0; }
+        wv[i] = w; gpv[i] = gp; s_act[i] = act;
     }
     __syncthreads();
+    {   // ordered compaction of the active columns: ballot + popcount per wave, wave offsets through LDS (D <= 192 < 256 threads)
+        __shared__ int s_wcnt[LM_THREADS / 64];
+        const bool actf = tid < D && s_act[tid];
+        const unsigned long long m = __ballot(actf);
+        const int lane = tid & 63, wv_id = tid >> 6;
+        if (lane == 0) s_wcnt[wv_id] = __popcll(m);
+        __syncthreads();
+        int off = 0, tot = 0;
+        for (int q = 0; q < LM_THREADS / 64; ++q) { if (q < wv_id) off += s_wcnt[q]; tot += s_wcnt[q]; }
+        if (actf) s_acols[off + __popcll(m & ((1ull << lane) - 1ull))] = (short)tid;
+        if (tid == 0) { s_acols[tot] = s_acols[tot + 1] = -1; s_na = tot; }
+    }
+    MTS(4);
     const double hinv = 1.0 / s_hg[0], g = s_hg[1];
     double* out = a.slabs + (size_t)l * (D * D + D);
-    for (int e = tid; e < D * D + D; e += LM_THREADS) {
-        if (e >= D * D) { const int i = e - D * D; out[e] = gpv[i] - wv[i] * g * hinv; continue; }
-        const int i = e / D, j = e - i * D;
-        double s = 0;
-        for (int fr = 0; fr < 2 * nf; ++fr) s += Jd[fr * D + i] * Jd[fr * D + j];
-        out[e] = s - wv[i] * wv[j] * hinv;
+    for (int i = tid >> 6; i < D; i += LM_THREADS / 64) {             // wave = row, lane = column: no integer division
+        const bool ai = s_act[i];
+        for (int j = tid & 63; j < D; j += 64) if (!(ai && s_act[j])) out[i * D + j] = 0.0;
     }
+    for (int i = tid; i < D; i += LM_THREADS) out[D * D + i] = gpv[i] - wv[i] * g * hinv;
+    __syncthreads();
+    const int na = s_na, T = (na + 1) >> 1;
+    for (int t = tid; t < T * T; t += LM_THREADS) {
+        const int ti = t / T, tj = t - ti * T;
+        if (tj > ti) continue;
+        const int i0 = s_acols[2 * ti], i1 = s_acols[2 * ti + 1], j0 = s_acols[2 * tj], j1 = s_acols[2 * tj + 1];      // -1 past the end
+        const int ri1 = i1 >= 0 ? i1 : i0, rj1 = j1 >= 0 ? j1 : j0;
+        double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
+        for (int fr = 0; fr < 2 * nf; ++fr) {
+            const double* row = Jd + fr * D;
+            const double a0 = row[i0], a1 = row[ri1], b0 = row[j0], b1 = row[rj1];
+            s00 += a0 * b0; s01 += a0 * b1; s10 += a1 * b0; s11 += a1 * b1;
+        }
+        auto put = [&](int i, int j, double sv) {
+            const double v = sv - wv[i] * wv[j] * hinv;
+            out[i * D + j] = v;
+            if (i != j) out[j * D + i] = v;
+        };
+        put(i0, j0, s00);
+        if (j1 >= 0 && !(ti == tj)) put(i0, j1, s01);      // on a diagonal tile (i0, j1) is the mirror of (i1, j0)
+        if (i1 >= 0) put(i1, j0, s10);
+        if (i1 >= 0 && j1 >= 0) put(i1, j1, s11);
+    }
+    MTS(5);
 }
 
 #define MG_SUM_CHUNKS 8
@@ -123,10 +178,26 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     double* yv = W2 + (n * n > 1024 ? n * n : 1024);      // n
     double* misc = yv + n;                                // 16
     const BeState* st = a.x;
-    for (int e = tid; e < D * D + D; e += MG_THREADS) {
-        double v = 0.0;
-        if (a.nlm > 0) for (int c = 0; c < MG_SUM_CHUNKS; ++c) v += a.sum[(size_t)c * (D * D + D) + e];
-        A[e] = v;
+    MTS(8);
+    {   // 4 entries x 8 chunk sums per batch: 32 independent global loads in flight per thread (they were 8 at a time behind a loop-carried wait)
+        const int total = D * D + D;
+        for (int e0 = tid; e0 < total; e0 += 4 * MG_THREADS) {
+            double v[4] = { 0.0, 0.0, 0.0, 0.0 }, ld[4][MG_SUM_CHUNKS];
+            if (a.nlm > 0) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * MG_THREADS;
+#pragma unroll
+                    for (int c = 0; c < MG_SUM_CHUNKS; ++c) ld[u][c] = e < total ? a.sum[(size_t)c * total + e] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int c = 0; c < MG_SUM_CHUNKS; ++c) v[u] += ld[u][c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = e0 + u * MG_THREADS; if (e < total) A[e] = v[u]; }
+        }
     }
     if (tid == 0) {
         double hmin = DBL_MAX;
@@ -134,32 +205,61 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         misc[0] = hmin; misc[1] = 0.0;
     }
     __syncthreads();
+    MTS(9);
     // ---------------- previous prior: A += A_old (mapped), b += b_old + A_old dx ----------------
     if (a.prior->valid) {
         const int no = a.prior->n;
         double* dx = W2;
+        __shared__ short s_pmap[BE_MAX_PRIOR];
+        for (int i = tid; i < no; i += MG_THREADS) s_pmap[i] = (short)a.prior_map[i];
         be_prior_dx_dev(a.prior, st, dx, tid, MG_THREADS);
         __syncthreads();
-        for (int i = tid; i < no; i += MG_THREADS) {
-            const int di = a.prior_map[i];
-            double s = a.priorb[i];
-            const double* row = a.priorA + (size_t)i * no;
-            for (int j = 0; j < no; ++j) s += row[j] * dx[j];
-            if (di >= 0) bv[di] += s;
+        // b += b_old + A_old dx: A_old is symmetric, so thread = output entry reads DOWN its column (coalesced across threads), the column
+        // split over the thread groups; partial sums meet in LDS in a fixed order
+        {
+            double* part = W2 + BE_MAX_PRIOR;                       // groups x no_pad partial sums (W2 holds >= 1024 doubles)
+            const int no_pad = (no + 63) & ~63, groups = (1024 - BE_MAX_PRIOR) / no_pad > 0 ? min(MG_THREADS / no_pad, (1024 - BE_MAX_PRIOR) / no_pad) : 1;
+            const int i = tid % no_pad, gI = tid / no_pad;
+            const int seg = (no + groups - 1) / groups, j0 = gI * seg, j1 = min(no, j0 + seg);
+            double sp = 0;
+            if (gI < groups && i < no) for (int j = j0; j < j1; ++j) sp += a.priorA[(size_t)j * no + i] * dx[j];
+            if (gI < groups && i < no) part[gI * no_pad + i] = sp;
+            __syncthreads();
+            if (tid < no) {
+                double t = a.priorb[tid];
+                for (int q = 0; q < groups; ++q) t += part[q * no_pad + tid];
+                const int di = s_pmap[tid];
+                if (di >= 0) bv[di] += t;
+            }
         }
-        for (int e = tid; e < no * no; e += MG_THREADS) {
-            const int i = e / no, j = e - i * no;
-            const int di = a.prior_map[i], dj = a.prior_map[j];
-            if (di >= 0 && dj >= 0) A[di * D + dj] += a.priorA[e];
+        for (int e0 = tid; e0 < no * no; e0 += 4 * MG_THREADS) {          // 4 independent loads of A_old in flight per thread
+            double pv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int e = e0 + u * MG_THREADS; pv[u] = e < no * no ? a.priorA[e] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * MG_THREADS;
+                if (e >= no * no) continue;
+                const int i = e / no, j = e - i * no;
+                const int di = s_pmap[i], dj = s_pmap[j];
+                if (di >= 0 && dj >= 0) A[di * D + dj] += pv[u];
+            }
         }
         __syncthreads();
     }
+    MTS(10);
     // ---------------- IMU factor (0,1) ----------------
     if (a.nimu > 0) {
         double* Jraw = W2; double* Jw = W2 + 450; double* rr = W2 + 900;
         for (int i = tid; i < 450; i += MG_THREADS) Jraw[i] = 0.0;
         __syncthreads();
-        const BeImu* mi = a.imu;
+        __shared__ BeImu s_m;                                       // the 2.4 KB factor record, staged by all threads (lane 0 then reads LDS, not a chain of global loads)
+        {
+            const double* src = reinterpret_cast<const double*>(a.imu); double* dst = reinterpret_cast<double*>(&s_m);
+            for (int i = tid; i < (int)(sizeof(BeImu) / 8); i += MG_THREADS) dst[i] = src[i];
+        }
+        __syncthreads();
+        const BeImu* mi = &s_m;
         if (tid == 0) imu_raw<true>(*mi, a.g_norm, st->pose[mi->fi], st->sb[mi->fi], st->pose[mi->fj], st->sb[mi->fj], rr, Jraw);
         __syncthreads();
         if (tid < 15) { double s = 0; for (int q = tid; q < 15; ++q) s += mi->sqrt_info[tid * 15 + q] * rr[q]; rr[15 + tid] = s; }
@@ -185,6 +285,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         }
         __syncthreads();
     }
+    MTS(11);
     // ---------------- eliminate the dropped pose / speed-bias dims [0, m): Cholesky of A_dd in place (one wave) ----------------
     if (tid < 64) {
         for (int k = 0; k < m; ++k) {
@@ -201,6 +302,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         }
     }
     __syncthreads();
+    MTS(12);
     // X = L^-1 [A_dk | b_d]  (forward substitution, one column per thread; stored over A_dk / b_d)
     for (int c = tid; c <= n; c += MG_THREADS) {
         for (int i = 0; i < m; ++i) {
@@ -211,6 +313,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         }
     }
     __syncthreads();
+    MTS(13);
     // A' = A_kk - X^T X (symmetrised), b' = b_k - X^T y
     for (int e = tid; e < n * n + n; e += MG_THREADS) {
         if (e >= n * n) {
@@ -225,26 +328,71 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         W2[e] = s;
     }
     __syncthreads();
+    MTS(14);
     for (int e = tid; e < n * n; e += MG_THREADS) a.outA[e] = W2[e];
     for (int i = tid; i < n; i += MG_THREADS) a.outb[i] = yv[i];
     __syncthreads();
+    MTS(15);
     // ---------------- c0 = b'^T A'^+ b': LDL^T on the lower triangle, pivots <= 1e-8 skipped, one barrier per step ----------------
+    // 4-column panels (the matrix stays in LDS): (A) thread 0 factors the 4x4 pivot block, skipping pivots <= 1e-8 (their columns drop out),
+    // forward-substitutes its part of y and accumulates c0; (B) one thread per row below forms the panel L (and L D) and updates its y;
+    // (C) all threads apply the rank-4 trailing update.  Three barriers per FOUR pivots instead of one per pivot with a rank-1 update.
     double c0 = 0.0; int rank = 0;
-    for (int k = 0; k < n; ++k) {
-        const double d = W2[k * n + k];
-        if (d > 1e-8) {                 // uniform
-            ++rank;
-            const double yk = yv[k], dinv = 1.0 / d;
-            c0 += yk * yk * dinv;
-            const int r = n - k - 1;
-            for (int e = tid; e < r * r + r; e += MG_THREADS) {
-                if (e >= r * r) { const int i = k + 1 + (e - r * r); yv[i] -= W2[i * n + k] * dinv * yk; continue; }
-                const int i = k + 1 + e / r, j = k + 1 + e % r;
-                if (j <= i) W2[i * n + j] -= W2[i * n + k] * dinv * W2[j * n + k];
+    double* PLc = A; double* PPc = A + 4 * n; double* dblk = A + 8 * n;      // the D x D buffer is free by now
+    for (int k0 = 0; k0 < n; k0 += 4) {
+        if (tid == 0) {
+            double am[4][4], yk[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool real = k0 + r < n;
+#pragma unroll
+                for (int cc = 0; cc <= r; ++cc) am[r][cc] = (real && k0 + cc < n) ? W2[(k0 + r) * n + k0 + cc] : (r == cc ? 1.0 : 0.0);
+                yk[r] = real ? yv[k0 + r] : 0.0;
             }
+            const double d0 = am[0][0], i0 = d0 > 1e-8 ? 1.0 / d0 : 0.0;
+            const double l10 = am[1][0] * i0, l20 = am[2][0] * i0, l30 = am[3][0] * i0;
+            const double d1 = am[1][1] - l10 * am[1][0], i1 = d1 > 1e-8 ? 1.0 / d1 : 0.0;
+            const double t21 = am[2][1] - l20 * am[1][0], t31 = am[3][1] - l30 * am[1][0];
+            const double l21 = t21 * i1, l31 = t31 * i1;
+            const double d2 = am[2][2] - l20 * am[2][0] - l21 * t21, i2 = d2 > 1e-8 ? 1.0 / d2 : 0.0;
+            const double t32 = am[3][2] - l30 * am[2][0] - l31 * t21;
+            const double l32 = t32 * i2;
+            const double d3 = am[3][3] - l30 * am[3][0] - l31 * t31 - l32 * t32, i3 = d3 > 1e-8 ? 1.0 / d3 : 0.0;
+            const double y0 = yk[0], y1 = yk[1] - l10 * y0, y2 = yk[2] - l20 * y0 - l21 * y1, y3 = yk[3] - l30 * y0 - l31 * y1 - l32 * y2;
+            c0 += y0 * y0 * i0;
+            if (k0 + 1 < n) c0 += y1 * y1 * i1;
+            if (k0 + 2 < n) c0 += y2 * y2 * i2;
+            if (k0 + 3 < n) c0 += y3 * y3 * i3;
+            rank += (i0 != 0.0) + (k0 + 1 < n && i1 != 0.0) + (k0 + 2 < n && i2 != 0.0) + (k0 + 3 < n && i3 != 0.0);
+            dblk[0] = l10; dblk[1] = l20; dblk[2] = l30; dblk[3] = l21; dblk[4] = l31; dblk[5] = l32;
+            dblk[6] = i0; dblk[7] = i1; dblk[8] = i2; dblk[9] = i3; dblk[10] = y0; dblk[11] = y1; dblk[12] = y2; dblk[13] = y3;
+        }
+        __syncthreads();
+        if (k0 + 4 >= n) break;                                   // uniform: nothing below the last pivot block
+        const double l10 = dblk[0], l20 = dblk[1], l30 = dblk[2], l21 = dblk[3], l31 = dblk[4], l32 = dblk[5];
+        const double i0 = dblk[6], i1 = dblk[7], i2 = dblk[8], i3 = dblk[9];
+        for (int i = k0 + 4 + tid; i < n; i += MG_THREADS) {
+            const double* row = W2 + i * n + k0;
+            const double p0 = row[0], p1 = row[1] - p0 * l10, p2 = row[2] - p0 * l20 - p1 * l21, p3 = row[3] - p0 * l30 - p1 * l31 - p2 * l32;
+            const double x0 = p0 * i0, x1 = p1 * i1, x2 = p2 * i2, x3 = p3 * i3;
+            PLc[i] = x0; PLc[n + i] = x1; PLc[2 * n + i] = x2; PLc[3 * n + i] = x3;
+            PPc[i] = p0; PPc[n + i] = p1; PPc[2 * n + i] = p2; PPc[3 * n + i] = p3;
+            yv[i] -= x0 * dblk[10] + x1 * dblk[11] + x2 * dblk[12] + x3 * dblk[13];
+        }
+        __syncthreads();
+        const int r = n - k0 - 4;
+        for (int e = tid; e < r * r; e += MG_THREADS) {
+            const int ii = e / r, jj = e - ii * r;
+            if (jj > ii) continue;
+            const int i = k0 + 4 + ii, j = k0 + 4 + jj;
+            W2[i * n + j] -= PLc[i] * PPc[j] + PLc[n + i] * PPc[n + j] + PLc[2 * n + i] * PPc[2 * n + j] + PLc[3 * n + i] * PPc[3 * n + j];
         }
         __syncthreads();
     }
+    if (tid == 0) { misc[2] = c0; misc[3] = (double)rank; }
+    __syncthreads();
+    c0 = misc[2]; rank = (int)misc[3];
+    MTS(16);
     if (tid == 0) { a.out_scalars[0] = c0; a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; a.out_scalars[3] = (double)rank; if (a.c0_out) a.c0_out[0] = c0; }
 }
 

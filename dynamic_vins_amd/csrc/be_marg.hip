@@ -199,10 +199,12 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
             for (int u = 0; u < 4; ++u) { const int e = e0 + u * MG_THREADS; if (e < total) A[e] = v[u]; }
         }
     }
-    if (tid == 0) {
+    if (tid < 64) {                                     // smallest landmark pivot: strided over one wave, xor-tree
         double hmin = DBL_MAX;
-        for (int l = 0; l < a.nlm; ++l) hmin = fmin(hmin, a.lm_h[l]);
-        misc[0] = hmin; misc[1] = 0.0;
+        for (int l = tid; l < a.nlm; l += 64) hmin = fmin(hmin, a.lm_h[l]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hmin = fmin(hmin, __shfl_xor(hmin, o));
+        if (tid == 0) { misc[0] = hmin; misc[1] = 0.0; }
     }
     __syncthreads();
     MTS(9);

@@ -180,12 +180,16 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
             else for (int r = lane; r < n; r += EV_THREADS) { double t = 0; for (int j = 0; j < n; ++j) t += a.priorA[(size_t)j * n + r] * dx[j]; Adx[r] = t; }
         }
         __syncthreads();
-        if (lane == 0) {
+        if (lane < 64) {          // b'.dx and dx.A'dx: strided over one wave + xor tree (was a serial loop of n dependent global loads on lane 0)
             double bd = 0, dAd = 0;
-            for (int i = 0; i < n; ++i) { bd += a.priorb[i] * dx[i]; dAd += dx[i] * Adx[i]; }
+            for (int i = lane; i < n; i += 64) { bd += a.priorb[i] * dx[i]; dAd += dx[i] * Adx[i]; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { bd += __shfl_xor(bd, o); dAd += __shfl_xor(dAd, o); }
+        if (lane == 0) {
             const double cost = 0.5 * a.prior_c0[0] + bd + 0.5 * dAd;
             if (FULL) o_prior[0] = cost;
             if (want_cost) a.cand_cost[b] = cost;
+        }
         }
         if (FULL) for (int i = lane; i < n; i += EV_THREADS) o_prior[1 + i] = a.priorb[i] + Adx[i];
     }

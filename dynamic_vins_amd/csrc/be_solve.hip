@@ -23,7 +23,7 @@
 
 using namespace be;
 
-#define RED_THREADS 384          // 6 waves: wave = row of a 6x6 pose block, lane = landmark
+#define RED_THREADS 448          // 7 waves: waves 0-5 = rows of a 6x6 pose block (lane = landmark), wave 6 = the block's IMU / prior terms
 #define RED_PAIRS (BE_NF * BE_NF)
 
 // IMU + prior part of Hd(i, j)  (everything that is not a landmark sum)
@@ -87,12 +87,19 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         if (ci0 < 0 || cj0 < 0) return;
         const int ci = threadIdx.x >> 6, lane = threadIdx.x & 63;
         const bool diag = fi == fj;
+        // the IMU / prior part of the block's 36 entries (and 6 gradient entries) is a chain of dependent global loads (column maps ->
+        // factor / prior indices -> values): the seventh wave walks it WHILE the other six stream the landmark packets
+        __shared__ double s_dh[36], s_dg[6];
+        if (ci == 6) {
+            if (lane < 36) s_dh[lane] = red_dense_h(a, imu_out, ci0 + lane / 6, cj0 + lane % 6);
+            else if (diag && lane < 42) s_dg[lane - 36] = red_dense_g(a, imu_out, prior_out, ci0 + lane - 36);
+        }
         double S[6] = {0, 0, 0, 0, 0, 0}, H[6] = {0, 0, 0, 0, 0, 0}, G = 0, GS = 0;
         const int e_wi = BE_PK_W + fi * 6 + ci, e_wj = BE_PK_W + fj * 6;
         const int e_dd = BE_PK_DD + fi * 36 + ci * 6;
         const int e_da_i = BE_PK_DA + fj * 36 + ci * 6;                 // anchor == fi : row ci of block (anchor, fj)
         const int e_da_j = BE_PK_DA + fi * 36 + ci;                     // anchor == fj : column ci of the transposed block
-        for (int l = lane; l < nlm; l += 64) {
+        for (int l = ci < 6 ? lane : nlm; l < nlm; l += 64) {
             const double h = BE_PK(pk, BE_PK_H, l);
             const double s = c.first ? 1.0 / (1.0 + sqrt(h)) : a.scale_l[l];
             double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
@@ -119,17 +126,19 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
 #pragma unroll
         for (int q = 0; q < 6; ++q) { S[q] = wave_sum(S[q]); H[q] = wave_sum(H[q]); }
         if (diag) { G = wave_sum(G); GS = wave_sum(GS); }
+        __syncthreads();
+        if (ci == 6) return;
         if (lane < 6) {
             double sv = S[0], hv = H[0];
 #pragma unroll
             for (int q = 1; q < 6; ++q) if (lane == q) { sv = S[q]; hv = H[q]; }
             const int i = ci0 + ci, j = cj0 + lane;
-            const double hd = hv + red_dense_h(a, imu_out, i, j);
+            const double hd = hv + s_dh[ci * 6 + lane];
             Hd[(size_t)i * n + j] = hd;
             if ((j >> 2) <= (i >> 2)) Sc[blk_pos(i, j, (n + 3) >> 2)] = hd - sv;
         } else if (diag && lane == 6) {
             const int i = ci0 + ci;
-            gvec[i] = G + red_dense_g(a, imu_out, prior_out, i);
+            gvec[i] = G + s_dg[ci];
             gvec[n + i] = GS;
         }
         return;

@@ -19,6 +19,13 @@
 
 using namespace be;
 
+#ifdef BE_EVAL_TS
+__device__ long long be_ev_ts[64];
+#define ETS(k) do { if (FULL && threadIdx.x == 0) be_ev_ts[k] = wall_clock64(); } while (0)
+extern "C" int dv_debug_ev_ts(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(be_ev_ts), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+#else
+#define ETS(k) do {} while (0)
+#endif
 template <bool FULL>
 #define EV_THREADS 256
 __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) {
@@ -40,12 +47,16 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
     __shared__ int s_flist[BE_NF][2];      // per observing frame: the (<= 2: left cam, right cam) two-frame factors whose frame j it is
     __shared__ double s_cost[BE_MAX_OBS_FACTORS];
     __shared__ double s_imu[450 + 450 + 32];
+    if (b == 0) ETS(0);
+    if (b == nlm) ETS(8);
+    if (b == nlm + nimu) ETS(16);
     if (b < nlm) {
         // ------------------------------- landmark -------------------------------
         const BeLm L = a.lm[b];
         be_frame_geom_dev(st, a.dims.nframes, fg, ric, tic, lane);
         if (lane >= 64 && lane < 64 + 2 * BE_NF) s_flist[(lane - 64) >> 1][(lane - 64) & 1] = -1;
         __syncthreads();
+        if (b == 0) ETS(1);
         const double lambda = st->inv_depth[b];
         if (lane < L.count) {
             const BeFactor f = a.fac[L.first + lane];
@@ -65,6 +76,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
             }
         }
         __syncthreads();
+        if (b == 0) ETS(2);
         double cost = 0;
         for (int f = 0; f < L.count; ++f) cost += s_cost[f];      // fixed order
         if (want_cost && lane == 0) a.cand_cost[b] = cost;
@@ -121,6 +133,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
             }
             BE_PK(o_packets, e, b) = v;
         }
+        if (b == 0) ETS(3);
     } else if (b < nlm + nimu) {
         // ------------------------------- IMU factor -------------------------------
         const int k = b - nlm;
@@ -135,8 +148,10 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
         double* Jraw = s_imu; double* Jw = s_imu + 450; double* rr = s_imu + 900;      // rr[0..14] raw, rr[15..29] whitened
         for (int i = lane; i < 450; i += EV_THREADS) Jraw[i] = 0.0;
         __syncthreads();
+        if (b == nlm) ETS(9);
         if (lane == 0) imu_raw<FULL>(*m, a.g_norm, st->pose[m->fi], st->sb[m->fi], st->pose[m->fj], st->sb[m->fj], rr, Jraw);
         __syncthreads();
+        if (b == nlm) ETS(10);
         if (lane < 15) { double s = 0; for (int q = lane; q < 15; ++q) s += m->sqrt_info[lane * 15 + q] * rr[q]; rr[15 + lane] = s; }
         if (FULL)
             for (int e = lane; e < 450; e += EV_THREADS) {
@@ -145,6 +160,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
                 Jw[e] = s;
             }
         __syncthreads();
+        if (b == nlm) ETS(11);
         double cost = 0;
         for (int i = 0; i < 15; ++i) cost += rr[15 + i] * rr[15 + i];
         cost *= 0.5;
@@ -158,6 +174,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
             for (int i = 0; i < 15; ++i) s += Jw[i * 30 + r0] * Jw[i * 30 + c0];
             o[31 + e] = s;
         }
+        if (b == nlm) ETS(12);
     } else {
         // ------------------------------- prior -------------------------------
         const BePriorHdr* p = a.prior;
@@ -166,6 +183,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
         const int n = p->n;
         be_prior_dx_dev(p, st, dx, lane, EV_THREADS);
         __syncthreads();
+        ETS(17);
         {   // A' dx with A' symmetric: thread = output entry reading DOWN its column (coalesced across threads), the column split
             // over EV_THREADS / n_pad thread groups whose partial sums are added in a fixed order
             __shared__ double part[EV_THREADS];
@@ -173,13 +191,26 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
             const int i = lane % n_pad, gI = lane / n_pad;
             const int seg = (n + groups - 1) / groups, j0 = gI * seg, j1 = min(n, j0 + seg);
             double s = 0;
-            if (gI < groups && i < n) for (int j = j0; j < j1; ++j) s += a.priorA[(size_t)j * n + i] * dx[j];
+            if (gI < groups && i < n) {
+                // 8 rows per batch: the loads are address-independent (A' was written by the previous frame's marginalization on other XCDs,
+                // every one is a ~0.5 us round trip), the sum keeps its ascending-j order
+                int j = j0;
+                for (; j + 8 <= j1; j += 8) {
+                    double v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = a.priorA[(size_t)(j + u) * n + i];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) s += v[u] * dx[j + u];
+                }
+                for (; j < j1; ++j) s += a.priorA[(size_t)j * n + i] * dx[j];
+            }
             part[lane] = s;
             __syncthreads();
             if (n_pad <= EV_THREADS) { if (lane < n) { double t = part[lane]; for (int q = 1; q < groups; ++q) t += part[q * n_pad + lane]; Adx[lane] = t; } }
             else for (int r = lane; r < n; r += EV_THREADS) { double t = 0; for (int j = 0; j < n; ++j) t += a.priorA[(size_t)j * n + r] * dx[j]; Adx[r] = t; }
         }
         __syncthreads();
+        ETS(18);
         if (lane < 64) {          // b'.dx and dx.A'dx: strided over one wave + xor tree (was a serial loop of n dependent global loads on lane 0)
             double bd = 0, dAd = 0;
             for (int i = lane; i < n; i += 64) { bd += a.priorb[i] * dx[i]; dAd += dx[i] * Adx[i]; }
@@ -192,6 +223,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
         }
         }
         if (FULL) for (int i = lane; i < n; i += EV_THREADS) o_prior[1 + i] = a.priorb[i] + Adx[i];
+        ETS(19);
     }
 }
 

@@ -23,37 +23,46 @@
 
 using namespace be;
 
+#ifdef BE_RED_TS
+__device__ long long be_red_ts[64];
+#define RTS(k) do { if (threadIdx.x == 0) be_red_ts[k] = wall_clock64(); } while (0)
+extern "C" int dv_debug_red_ts(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(be_red_ts), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+#else
+#define RTS(k) do {} while (0)
+#endif
 #define RED_THREADS 448          // 7 waves: waves 0-5 = rows of a 6x6 pose block (lane = landmark), wave 6 = the block's IMU / prior terms
 #define RED_PAIRS (BE_NF * BE_NF)
 
-// IMU + prior part of Hd(i, j)  (everything that is not a landmark sum)
-__device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, const double* imu_out, int i, int j) {
+// IMU + prior part of Hd(i, j)  (everything that is not a landmark sum).  rc: the frames of every IMU factor and the prior's header
+// fields, staged in LDS by the caller (they were dependent global loads per factor and entry)
+struct RedCtx { const int* ifi; const int* ifj; int prior_valid, prior_n; };
+__device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, int i, int j) {
     const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i];
     const int kj = a.col_kind[j], fj = a.col_frame[j], cj = a.col_comp[j];
     double H = 0.0;
     for (int k = 0; k < a.dims.nimu; ++k) {
-        const BeImu* m = &a.imu[k];
+        const int mfi = rc.ifi[k], mfj = rc.ifj[k];
         int li = -1, lj = -1;
-        if (fi == m->fi) li = (ki == 0 ? ci : 6 + ci); else if (fi == m->fj) li = (ki == 0 ? 15 + ci : 21 + ci);
-        if (fj == m->fi) lj = (kj == 0 ? cj : 6 + cj); else if (fj == m->fj) lj = (kj == 0 ? 15 + cj : 21 + cj);
+        if (fi == mfi) li = (ki == 0 ? ci : 6 + ci); else if (fi == mfj) li = (ki == 0 ? 15 + ci : 21 + ci);
+        if (fj == mfi) lj = (kj == 0 ? cj : 6 + cj); else if (fj == mfj) lj = (kj == 0 ? 15 + cj : 21 + cj);
         if (li >= 0 && lj >= 0) H += imu_out[(size_t)k * IMU_OUT_STRIDE + 31 + li * 30 + lj];
     }
-    if (a.prior->valid) {
+    if (rc.prior_valid) {
         const int pi = a.prior_col[i], pj = a.prior_col[j];
-        if (pi >= 0 && pj >= 0) H += a.priorA[(size_t)pi * a.prior->n + pj];
+        if (pi >= 0 && pj >= 0) H += a.priorA[(size_t)pi * rc.prior_n + pj];
     }
     return H;
 }
-__device__ __forceinline__ double red_dense_g(const BeSolveArgs& a, const double* imu_out, const double* prior_out, int i) {
+__device__ __forceinline__ double red_dense_g(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int i) {
     const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i];
     double G = 0.0;
     for (int k = 0; k < a.dims.nimu; ++k) {
-        const BeImu* m = &a.imu[k];
+        const int mfi = rc.ifi[k], mfj = rc.ifj[k];
         int li = -1;
-        if (fi == m->fi) li = (ki == 0 ? ci : 6 + ci); else if (fi == m->fj) li = (ki == 0 ? 15 + ci : 21 + ci);
+        if (fi == mfi) li = (ki == 0 ? ci : 6 + ci); else if (fi == mfj) li = (ki == 0 ? 15 + ci : 21 + ci);
         if (li >= 0) G += imu_out[(size_t)k * IMU_OUT_STRIDE + 1 + li];
     }
-    if (a.prior->valid) { const int pi = a.prior_col[i]; if (pi >= 0) G += prior_out[1 + pi]; }
+    if (rc.prior_valid) { const int pi = a.prior_col[i]; if (pi >= 0) G += prior_out[1 + pi]; }
     return G;
 }
 // Position of entry (i, j), j's block <= i's block, in the block-packed lower triangle consumed by the factorisation:
@@ -80,6 +89,13 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
     const double* pk = a.packets[set];
     double* const Hd = a.Hd[set]; double* const Sc = a.Sc[set]; double* const gvec = a.gvec[set];
     const double* const imu_out = a.imu_out[set]; const double* const prior_out = a.prior_out[set];
+    __shared__ int s_ifi[BE_WIN + 1], s_ifj[BE_WIN + 1], s_pr[2];
+    if ((int)threadIdx.x < a.dims.nimu) { s_ifi[threadIdx.x] = a.imu[threadIdx.x].fi; s_ifj[threadIdx.x] = a.imu[threadIdx.x].fj; }
+    if (threadIdx.x == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
+    __syncthreads();
+    const RedCtx rc{ s_ifi, s_ifj, s_pr[0], s_pr[1] };
+    if (blockIdx.x == 0) RTS(0);
+    if (blockIdx.x == RED_PAIRS + 3) RTS(8);
     if (blockIdx.x < RED_PAIRS) {
         const int fi = blockIdx.x / BE_NF, fj = blockIdx.x - fi * BE_NF;
         if (fi >= a.dims.nframes || fj >= a.dims.nframes) return;
@@ -91,8 +107,8 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         // factor / prior indices -> values): the seventh wave walks it WHILE the other six stream the landmark packets
         __shared__ double s_dh[36], s_dg[6];
         if (ci == 6) {
-            if (lane < 36) s_dh[lane] = red_dense_h(a, imu_out, ci0 + lane / 6, cj0 + lane % 6);
-            else if (diag && lane < 42) s_dg[lane - 36] = red_dense_g(a, imu_out, prior_out, ci0 + lane - 36);
+            if (lane < 36) s_dh[lane] = red_dense_h(a, rc, imu_out, ci0 + lane / 6, cj0 + lane % 6);
+            else if (diag && lane < 42) s_dg[lane - 36] = red_dense_g(a, rc, imu_out, prior_out, ci0 + lane - 36);
         }
         double S[6] = {0, 0, 0, 0, 0, 0}, H[6] = {0, 0, 0, 0, 0, 0}, G = 0, GS = 0;
         const int e_wi = BE_PK_W + fi * 6 + ci, e_wj = BE_PK_W + fj * 6;
@@ -123,10 +139,12 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
                 }
             }
         }
+        if (blockIdx.x == 0) RTS(1);
 #pragma unroll
         for (int q = 0; q < 6; ++q) { S[q] = wave_sum(S[q]); H[q] = wave_sum(H[q]); }
         if (diag) { G = wave_sum(G); GS = wave_sum(GS); }
         __syncthreads();
+        if (blockIdx.x == 0) RTS(2);
         if (ci == 6) return;
         if (lane < 6) {
             double sv = S[0], hv = H[0];
@@ -141,6 +159,7 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
             gvec[i] = G + s_dg[ci];
             gvec[n + i] = GS;
         }
+        if (blockIdx.x == 0) RTS(3);
         return;
     }
     const int eb = blockIdx.x - RED_PAIRS;
@@ -150,14 +169,15 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
     if (t < n * n) {
         const int i = t / n, j = t - i * n;
         if (a.col_kind[i] == 0 && a.col_kind[j] == 0) return;          // pose x pose: written by the pair blocks
-        const double hd = red_dense_h(a, imu_out, i, j);
+        const double hd = red_dense_h(a, rc, imu_out, i, j);
         Hd[t] = hd;
         if ((j >> 2) <= (i >> 2)) Sc[blk_pos(i, j, (n + 3) >> 2)] = hd;
     } else if (t < n * n + n) {
         const int i = t - n * n;
         if (a.col_kind[i] == 0) return;
-        gvec[i] = red_dense_g(a, imu_out, prior_out, i); gvec[n + i] = 0.0;
+        gvec[i] = red_dense_g(a, rc, imu_out, prior_out, i); gvec[n + i] = 0.0;
     }
+    if (blockIdx.x == RED_PAIRS + 3) RTS(9);
 }
 
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s) {

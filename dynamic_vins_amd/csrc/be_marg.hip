@@ -132,9 +132,11 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
     for (int i = tid; i < D; i += LM_THREADS) out[D * D + i] = gpv[i] - wv[i] * g * hinv;
     __syncthreads();
     const int na = s_na, T = (na + 1) >> 1;
-    for (int t = tid; t < T * T; t += LM_THREADS) {
-        const int ti = t / T, tj = t - ti * T;
-        if (tj > ti) continue;
+    for (int t = tid; t < T * (T + 1) / 2; t += LM_THREADS) {                 // lower-triangular tile index: t = ti (ti + 1) / 2 + tj
+        int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (ti * (ti + 1) / 2 > t) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        const int tj = t - ti * (ti + 1) / 2;
         const int i0 = s_acols[2 * ti], i1 = s_acols[2 * ti + 1], j0 = s_acols[2 * tj], j1 = s_acols[2 * tj + 1];      // -1 past the end
         const int ri1 = i1 >= 0 ? i1 : i0, rj1 = j1 >= 0 ? j1 : j0;
         double s00 = 0, s01 = 0, s10 = 0, s11 = 0;

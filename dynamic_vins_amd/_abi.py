@@ -76,6 +76,7 @@ SIGNATURES = {
     "dv_box_dims_eval": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dv_box_orientation_eval": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dv_obj_solve": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
+    "dv_line_solve": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "dv_est_create": (C.c_int, [_ctx, C.c_void_p]),
     "dv_est_reset": (C.c_int, [_ctx]),
     "dv_est_input_imu": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_void_p]),

@@ -235,6 +235,44 @@ def obj_solve(ctx, prob):
     return s
 
 
+LINEOBS_DTYPE = np.dtype([("line", "i4"), ("frame", "i4"), ("obs", "f8", 4)])
+
+
+class dv_line_problem(C.Structure):
+    _fields_ = [("n_lines", C.c_int32), ("n_obs", C.c_int32), ("max_iters", C.c_int32), ("reserved", C.c_int32),
+                ("orth", C.c_void_p), ("pose", C.c_void_p), ("ex_pose", C.c_void_p), ("sqrt_info", C.c_double * 4), ("obs", C.c_void_p)]
+
+
+class LineProblem:
+    """Owns the buffers of one Estimator::OptimizationWithOnlyLine problem (estimator.cpp:345-395); same layout as the oracle's dvo_line_problem."""
+
+    def __init__(self, orth, pose, ex_pose, sqrt_info, obs, max_iters=10):
+        self.orth = np.ascontiguousarray(orth, np.float64).copy().reshape(-1, 4)
+        self.pose = np.ascontiguousarray(pose, np.float64).copy().reshape(11, 7)
+        self.ex_pose = np.ascontiguousarray(ex_pose, np.float64).copy().reshape(7)
+        self.sqrt_info = np.ascontiguousarray(sqrt_info, np.float64).reshape(4).copy()
+        self.obs = np.ascontiguousarray(obs, LINEOBS_DTYPE).copy()
+        self.max_iters = max_iters
+
+    def struct(self):
+        p = dv_line_problem()
+        p.n_lines, p.n_obs, p.max_iters = len(self.orth), len(self.obs), self.max_iters
+        p.orth, p.pose, p.ex_pose = self.orth.ctypes.data, self.pose.ctypes.data, self.ex_pose.ctypes.data
+        p.sqrt_info[:] = self.sqrt_info.tolist()
+        p.obs = self.obs.ctypes.data if len(self.obs) else None
+        return p
+
+    def clone(self):
+        return LineProblem(self.orth, self.pose, self.ex_pose, self.sqrt_info, self.obs, self.max_iters)
+
+
+def line_solve(ctx, prob):
+    """ceres::Solve of Estimator::OptimizationWithOnlyLine on the device; prob.orth is updated in place."""
+    p, s = prob.struct(), dv_ba_summary()
+    _chk(ctx, ctx.lib.dv_line_solve(ctx.h, C.byref(p), C.byref(s)))
+    return s
+
+
 class dv_est_config(C.Structure):
     _fields_ = [("use_imu", C.c_int32), ("stereo", C.c_int32), ("plane_constraint", C.c_int32), ("max_iters", C.c_int32),
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),

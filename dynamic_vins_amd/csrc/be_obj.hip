@@ -21,33 +21,6 @@ using namespace be;
 
 namespace {
 
-struct Plk { d3 n, v; };
-
-__device__ __forceinline__ m33 orth_R(const double* o) {
-    const double s1 = sin(o[0]), c1 = cos(o[0]), s2 = sin(o[1]), c2 = cos(o[1]), s3 = sin(o[2]), c3 = cos(o[2]);
-    m33 R;
-    R.m[0] = c2 * c3; R.m[1] = s1 * s2 * c3 - c1 * s3; R.m[2] = c1 * s2 * c3 + s1 * s3;
-    R.m[3] = c2 * s3; R.m[4] = s1 * s2 * s3 + c1 * c3; R.m[5] = c1 * s2 * s3 - s1 * c3;
-    R.m[6] = -s2;     R.m[7] = s1 * c2;                R.m[8] = c1 * c2;
-    return R;
-}
-__device__ __forceinline__ d3 col(const m33& R, int j) { return mk3(R.m[j], R.m[3 + j], R.m[6 + j]); }
-__device__ __forceinline__ Plk plk_to_pose(const Plk& w, const m33& Rcw, d3 tcw) { Plk r; r.v = mul(Rcw, w.v); r.n = mul(Rcw, w.n) + mul(skew(tcw), r.v); return r; }
-__device__ __forceinline__ Plk plk_from_pose(const Plk& c, const m33& Rcw, d3 tcw) { const m33 Rwc = tr(Rcw); return plk_to_pose(c, Rwc, -mul(Rwc, tcw)); }
-
-// (2x6) * [[A B] [0 D]]  (every 6x6 the line factor multiplies with has a zero lower-left block)
-__device__ __forceinline__ void mul26(const double a[2][6], const m33& A, const m33& B, const m33& D, double r[2][6]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            double s0 = 0, s1 = 0;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { s0 += a[i][k] * A.m[k * 3 + j]; s1 += a[i][k] * B.m[k * 3 + j] + a[i][3 + k] * D.m[k * 3 + j]; }
-            r[i][j] = s0; r[i][3 + j] = s1;
-        }
-}
-
 // out per block (34): r[2] | J_pose 2x6 | J_ex 2x6 | J_orth 2x4
 __global__ void line_eval_kernel(const dv_line_factor* f, int n, const double* pose, const double* ex, const double* orth, double* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -101,18 +74,7 @@ __global__ void line_eval_kernel(const dv_line_factor* f, int n, const double* p
 __global__ void line_plus_kernel(const double* x, const double* delta, int n, double* out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const double* d = delta + 4 * i;
-    m33 R = orth_R(x + 4 * i);
-    const double w1 = cos(x[4 * i + 3]), w2 = sin(x[4 * i + 3]);
-    m33 Rz = zero3(), Ry = zero3(), Rx = zero3();
-    Rz.m[0] = cos(d[2]); Rz.m[1] = -sin(d[2]); Rz.m[3] = sin(d[2]); Rz.m[4] = cos(d[2]); Rz.m[8] = 1;
-    Ry.m[0] = cos(d[1]); Ry.m[2] = sin(d[1]); Ry.m[4] = 1; Ry.m[6] = -sin(d[1]); Ry.m[8] = cos(d[1]);
-    Rx.m[0] = 1; Rx.m[4] = cos(d[0]); Rx.m[5] = -sin(d[0]); Rx.m[7] = sin(d[0]); Rx.m[8] = cos(d[0]);
-    R = mul(mul(mul(R, Rx), Ry), Rz);
-    const double W10 = w2 * cos(d[3]) + w1 * sin(d[3]);
-    const d3 u1 = col(R, 0), u2 = col(R, 1), u3 = col(R, 2);
-    double* o = out + 4 * i;
-    o[0] = atan2(u2.z, u3.z); o[1] = asin(-u1.z); o[2] = atan2(u1.y, u1.x); o[3] = asin(W10);
+    line_plus_dev(x + 4 * i, delta + 4 * i, out + 4 * i);
 }
 
 // out per block (21): r[3] | J_pose_obj 3x6

@@ -70,4 +70,82 @@ __device__ __forceinline__ void box_orientation_dev(const m33& Rc, const m33& Rb
     for (int k = 0; k < 9; ++k) Jr_out[k] = jac.m[k];
 }
 
+
+// ---- line factor pieces (lineProjectionFactor / LineOrthParameterization) ----
+struct Plk { d3 n, v; };
+
+__device__ __forceinline__ m33 orth_R(const double* o) {
+    const double s1 = sin(o[0]), c1 = cos(o[0]), s2 = sin(o[1]), c2 = cos(o[1]), s3 = sin(o[2]), c3 = cos(o[2]);
+    m33 R;
+    R.m[0] = c2 * c3; R.m[1] = s1 * s2 * c3 - c1 * s3; R.m[2] = c1 * s2 * c3 + s1 * s3;
+    R.m[3] = c2 * s3; R.m[4] = s1 * s2 * s3 + c1 * c3; R.m[5] = c1 * s2 * s3 - s1 * c3;
+    R.m[6] = -s2;     R.m[7] = s1 * c2;                R.m[8] = c1 * c2;
+    return R;
+}
+__device__ __forceinline__ d3 col(const m33& R, int j) { return mk3(R.m[j], R.m[3 + j], R.m[6 + j]); }
+__device__ __forceinline__ Plk plk_to_pose(const Plk& w, const m33& Rcw, d3 tcw) { Plk r; r.v = mul(Rcw, w.v); r.n = mul(Rcw, w.n) + mul(skew(tcw), r.v); return r; }
+__device__ __forceinline__ Plk plk_from_pose(const Plk& c, const m33& Rcw, d3 tcw) { const m33 Rwc = tr(Rcw); return plk_to_pose(c, Rwc, -mul(Rwc, tcw)); }
+
+// (2x6) * [[A B] [0 D]]  (every 6x6 the line factor multiplies with has a zero lower-left block)
+__device__ __forceinline__ void mul26(const double a[2][6], const m33& A, const m33& B, const m33& D, double r[2][6]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s0 = 0, s1 = 0;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { s0 += a[i][k] * A.m[k * 3 + j]; s1 += a[i][k] * B.m[k * 3 + j] + a[i][3 + k] * D.m[k * 3 + j]; }
+            r[i][j] = s0; r[i][3 + j] = s1;
+        }
+}
+
+
+// LineOrthParameterization::Plus (estimator/factor/line_parameterization.cpp:9-72): out = orth (+) delta
+__device__ __forceinline__ void line_plus_dev(const double* x, const double* d, double* o) {
+    m33 R = orth_R(x);
+    const double w1 = cos(x[3]), w2 = sin(x[3]);
+    m33 Rz = zero3(), Ry = zero3(), Rx = zero3();
+    Rz.m[0] = cos(d[2]); Rz.m[1] = -sin(d[2]); Rz.m[3] = sin(d[2]); Rz.m[4] = cos(d[2]); Rz.m[8] = 1;
+    Ry.m[0] = cos(d[1]); Ry.m[2] = sin(d[1]); Ry.m[4] = 1; Ry.m[6] = -sin(d[1]); Ry.m[8] = cos(d[1]);
+    Rx.m[0] = 1; Rx.m[4] = cos(d[0]); Rx.m[5] = -sin(d[0]); Rx.m[7] = sin(d[0]); Rx.m[8] = cos(d[0]);
+    R = mul(mul(mul(R, Rx), Ry), Rz);
+    const double W10 = w2 * cos(d[3]) + w1 * sin(d[3]);
+    const d3 u1 = col(R, 0), u2 = col(R, 1), u3 = col(R, 2);
+    o[0] = atan2(u2.z, u3.z); o[1] = asin(-u1.z); o[2] = atan2(u1.y, u1.x); o[3] = asin(W10);
+}
+
+// residual and d r / d orth (2x4, row-major) of lineProjectionFactor (line_projection_factor.cpp:24-159) for given body / extrinsic poses:
+// the part the line-only solve needs (poses are constant there); the same arithmetic as line_eval_kernel in be_obj.hip
+__device__ __forceinline__ void line_orth_dev(const double* obs, const double* si, const m33& Rwb, d3 twb, const m33& Rbc, d3 tbc, const double* orth, double r[2], double Jo[8]) {
+    const m33 U = orth_R(orth);
+    const double w1 = cos(orth[3]), w2 = sin(orth[3]);
+    Plk lw; lw.n = col(U, 0) * w1; lw.v = col(U, 1) * w2;
+    const Plk lb = plk_from_pose(lw, Rwb, twb);
+    const Plk lc = plk_from_pose(lb, Rbc, tbc);
+    const d3 nc = lc.n;
+    const double l_norm = nc.x * nc.x + nc.y * nc.y, l_sqrt = sqrt(l_norm), l_tri = l_norm * l_sqrt;
+    const double e1 = obs[0] * nc.x + obs[1] * nc.y + nc.z, e2 = obs[2] * nc.x + obs[3] * nc.y + nc.z;
+    const double r0 = e1 / l_sqrt, r1 = e2 / l_sqrt;
+    r[0] = si[0] * r0 + si[1] * r1; r[1] = si[2] * r0 + si[3] * r1;
+    const double jel[2][3] = { { obs[0] / l_sqrt - nc.x * e1 / l_tri, obs[1] / l_sqrt - nc.y * e1 / l_tri, 1.0 / l_sqrt },
+                               { obs[2] / l_sqrt - nc.x * e2 / l_tri, obs[3] / l_sqrt - nc.y * e2 / l_tri, 1.0 / l_sqrt } };
+    double jeLc[2][6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { jeLc[0][j] = si[0] * jel[0][j] + si[1] * jel[1][j]; jeLc[1][j] = si[2] * jel[0][j] + si[3] * jel[1][j]; jeLc[0][3 + j] = 0; jeLc[1][3 + j] = 0; }
+    const m33 Rwc = mul(Rwb, Rbc); const d3 twc = mul(Rwb, tbc) + twb;
+    const m33 RwcT = tr(Rwc);
+    double a[2][6];
+    mul26(jeLc, RwcT, scale(mul(RwcT, skew(twc)), -1.0), RwcT, a);
+    const double nn = norm(lw.n), vn = norm(lw.v);
+    const d3 u1 = lw.n / nn, u2 = lw.v / vn, u3 = cross(u1, u2);
+    const double wn = sqrt(nn * nn + vn * vn), w0 = nn / wn, w1n = vn / wn;
+    const d3 top[4] = { mk3(0, 0, 0), u3 * (-w0), u2 * w0, u1 * (-w1n) };
+    const d3 bot[4] = { u3 * w1n, mk3(0, 0, 0), u1 * (-w1n), u2 * w0 };
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            Jo[q * 4 + c] = a[q][0] * top[c].x + a[q][1] * top[c].y + a[q][2] * top[c].z + a[q][3] * bot[c].x + a[q][4] * bot[c].y + a[q][5] * bot[c].z;
+}
+
 }  // namespace be

@@ -277,6 +277,22 @@ typedef struct dv_obj_problem {
 } dv_obj_problem;
 int dv_obj_solve(dv_ctx* ctx, dv_obj_problem* problem, dv_ba_summary* summary);
 
+/* ---- the line-only refinement: replaces ceres::Solve inside Estimator::OptimizationWithOnlyLine
+ * (estimator/estimator.cpp:345-395) for the problem AddLineResidualBlock builds (:222-253): one LineOrthParameterization block
+ * (body.para_line_features[k], 4 parameters) per triangulated line landmark, one lineProjectionFactor per observation with
+ * CauchyLoss(1.0), every pose / extrinsic block constant; DENSE_SCHUR + DOGLEG, max_num_iterations = max_iters.
+ * sqrt_info is lineProjectionFactor::sqrt_info (the reference leaves it zero: the solve then returns at once). ---- */
+typedef struct dv_line_obs { int32_t line, frame; double obs[4]; } dv_line_obs;      /* LineFeature::line_obs of landmark `line` in window frame `frame` */
+typedef struct dv_line_problem {
+    int32_t n_lines, n_obs, max_iters, reserved;
+    double* orth;                        /* n_lines x 4   in/out: body.para_line_features */
+    const double* pose;                  /* 11 x 7: body.para_pose */
+    const double* ex_pose;               /* 7: body.para_ex_pose[0] */
+    double sqrt_info[4];                 /* 2x2 row-major */
+    const dv_line_obs* obs;
+} dv_line_problem;
+int dv_line_solve(dv_ctx* ctx, dv_line_problem* problem, dv_ba_summary* summary);
+
 /* ---- Estimator (estimator/estimator.h:55-164): IMU buffer + one ProcessMeasurements iteration per call ---- */
 typedef struct dv_est_config {          /* para (estimator/vio_parameters.cpp:19-83), cfg flags, extrinsics (utils/parameters.cpp) */
     int32_t use_imu, stereo, plane_constraint, max_iters;      /* imu, num_of_cam==2, plane_constraint, max_num_iterations */

@@ -17,7 +17,8 @@
 namespace obe {
 using namespace ola;
 
-enum BlockKind { kPlain = 0, kPose = 1, kPosePlaneImu = 2, kPosePlaneVo = 3 };
+enum BlockKind { kPlain = 0, kPose = 1, kPosePlaneImu = 2, kPosePlaneVo = 3, kLineOrth = 4 };
+extern "C" void dvo_line_plus(const double* orth4, const double* delta4, double* out4);      // LineOrthParameterization::Plus (obj_factors.cpp)
 
 struct ParamBlock {
     double* data = nullptr; int size = 0; int kind = kPlain; bool constant = false; bool is_e = false;
@@ -86,6 +87,7 @@ inline void correct(int loss, int nres, double* res, std::vector<std::vector<dou
 // x (+) delta for one block (PoseLocalParameterization::Plus, factor/pose_local_parameterization.cpp:26-103)
 inline void plus(const ParamBlock& b, const double* x, const double* d, double* out) {
     if (b.kind == kPlain) { for (int i = 0; i < b.size; ++i) out[i] = x[i] + d[i]; return; }
+    if (b.kind == kLineOrth) { dvo_line_plus(x, d, out); return; }      // 4 global, 4 local parameters, ComputeJacobian = I
     V3 dp(d[0], d[1], d[2]);
     if (b.kind == kPosePlaneImu) dp.z = 0;
     if (b.kind == kPosePlaneVo) dp.y = 0;

@@ -153,6 +153,10 @@ typedef struct dvo_obj_problem {
 } dvo_obj_problem;
 struct dvo_ba_summary;
 int dvo_obj_solve(dvo_obj_problem* problem, struct dvo_ba_summary* summary);
+/* the line-only refinement (Estimator::OptimizationWithOnlyLine, estimator/estimator.cpp:345-395); layout identical to include/dvins.h dv_line_* */
+typedef struct dvo_line_obs { int32_t line, frame; double obs[4]; } dvo_line_obs;
+typedef struct dvo_line_problem { int32_t n_lines, n_obs, max_iters, reserved; double* orth; const double* pose; const double* ex_pose; double sqrt_info[4]; const dvo_line_obs* obs; } dvo_line_problem;
+int dvo_line_solve(dvo_line_problem* problem, struct dvo_ba_summary* summary);
 
 /* flat window problem, identical layout to include/dvins.h dv_ba_* (restated here: the oracle shares no headers
  * with the product) */

@@ -1,4 +1,5 @@
-// obj_solve.cpp — CPU ORACLE (test infrastructure, not the product): the per-frame object solve of dynamic mode
+// obj_solve.cpp — CPU ORACLE (test infrastructure, not the product): the two auxiliary solves with a block-diagonal Hessian (dvo_obj_solve,
+// dvo_line_solve, the latter restating Estimator::OptimizationWithOnlyLine, estimator/estimator.cpp:345-395): the per-frame object solve of dynamic mode
 // (numeric part), restated from
 //   InstanceManager::Optimization                 estimator/estimator_insts.cpp:772-807   (DENSE_SCHUR + DOGLEG, HuberLoss(1.0))
 //   InstanceManager::AddInstanceParameterBlock    estimator/estimator_insts.cpp:989-1010  (para_state[i]: Pose / PoseConstraint local parameterisation)
@@ -34,7 +35,34 @@ struct OrientationCost : CostFunction {
     void Evaluate(const double* const* par, double* res, double** J) const override { dvo_box_orientation_eval(Rc, Rb, par, res, J); }
 };
 
+// lineProjectionFactor on (pose, ex_pose, line) — estimator/factor/line_projection_factor.cpp:24-159 through dvo_line_eval
+struct LineCost : CostFunction {
+    double obs[4], si[4];
+    LineCost(const double* o, const double* s) { nres = 2; sizes = { 7, 7, 4 }; std::memcpy(obs, o, 32); std::memcpy(si, s, 32); }
+    void Evaluate(const double* const* par, double* res, double** J) const override { dvo_line_eval(obs, si, par, res, J); }
+};
+
 }  // namespace
+
+// Estimator::OptimizationWithOnlyLine (estimator/estimator.cpp:345-395) + AddLineResidualBlock (:222-253): pose and extrinsic blocks are added
+// with PoseLocalParameterization and set constant, one LineOrthParameterization block per line, CauchyLoss(1.0), DENSE_SCHUR + DOGLEG.
+extern "C" int dvo_line_solve(dvo_line_problem* P, dvo_ba_summary* S) {
+    std::vector<double> pose(P->pose, P->pose + 77), ex(P->ex_pose, P->ex_pose + 7);
+    Problem prob;
+    for (int i = 0; i < 11; ++i) { prob.AddParameterBlock(pose.data() + 7 * i, 7, kPose); prob.SetConstant(pose.data() + 7 * i); }
+    prob.AddParameterBlock(ex.data(), 7, kPose); prob.SetConstant(ex.data());
+    for (int i = 0; i < P->n_obs; ++i) {
+        const dvo_line_obs& ob = P->obs[i];
+        prob.AddParameterBlock(P->orth + 4 * (size_t)ob.line, 4, kLineOrth);
+        prob.AddResidualBlock(std::make_shared<LineCost>(ob.obs, P->sqrt_info), kCauchy1, { pose.data() + 7 * ob.frame, ex.data(), P->orth + 4 * (size_t)ob.line });
+    }
+    Solver solver(prob);
+    SolveOptions opt; opt.max_num_iterations = P->max_iters;
+    const SolveSummary sum = solver.solve(opt);
+    S->iterations = sum.iterations; S->successful = sum.successful; S->termination = sum.termination; S->slots = 0;
+    S->initial_cost = sum.initial_cost; S->final_cost = sum.final_cost;
+    return 0;
+}
 
 extern "C" int dvo_obj_solve(dvo_obj_problem* P, dvo_ba_summary* S) {
     const int n_obj = P->n_obj;

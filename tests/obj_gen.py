@@ -187,3 +187,52 @@ def o_obj_solve(lib, prob):
     lib.dvo_obj_solve.restype = C.c_int
     assert lib.dvo_obj_solve(C.byref(p), C.byref(s)) == 0
     return s
+
+
+# ---- synthetic scenes for the line-only refinement (Estimator::OptimizationWithOnlyLine) ----
+def make_line_scene(seed, n_lines=40, max_iters=10, pix_sigma=0.002, orth_noise=0.03, sqrt_info=(460 / 1.5, 0, 0, 460 / 1.5), empty_lines=2, min_obs=5):
+    """11 body poses moving along x and looking along +x (camera z), 3-D line segments ahead of them observed in a run of >= min_obs
+    consecutive frames (para::kLineMinObs = 5, estimator/vio_parameters.cpp:47: AddLineResidualBlock skips landmarks with fewer) as noisy
+    end points on the normalised plane; the initial orthonormal parameters are the true ones plus noise.
+    The last `empty_lines` lines have no observation (they must not move and do not count in |x|)."""
+    from dynamic_vins_amd import line_geometry as LG
+    from dynamic_vins_amd.backend import LINEOBS_DTYPE, LineProblem
+    rng = np.random.default_rng(seed)
+    R_bc = np.array([[0, 0, 1.0], [-1, 0, 0], [0, -1, 0]]) @ _small_rot(rng, 0.01)
+    ex = np.concatenate([rng.normal(0, 0.02, 3), _q_from_R(R_bc)])
+    pose = np.zeros((11, 7))
+    for f in range(11):
+        pose[f, :3] = [0.3 * f, 0.25 * np.sin(0.7 * f), 0.06 * f]
+        pose[f, 3:] = _q_from_R(_rz(0.01 * f) @ _small_rot(rng, 0.01))
+    orth = np.zeros((n_lines, 4))
+    obs = []
+    for k in range(n_lines):
+        mid = np.array([rng.uniform(6, 20), rng.uniform(-4, 4), rng.uniform(-2, 2)])
+        d = rng.normal(0, 1, 3)
+        d /= np.linalg.norm(d)
+        p1, p2 = mid - d * rng.uniform(0.5, 2.0), mid + d * rng.uniform(0.5, 2.0)
+        plk = np.concatenate([np.cross(p1, p2), p2 - p1])             # (n, v) in the world frame
+        orth[k] = LG.plk_to_orth(plk) + rng.normal(0, orth_noise, 4)
+        if k >= n_lines - empty_lines:
+            continue
+        f0 = int(rng.integers(0, 12 - min_obs))
+        f1 = int(rng.integers(f0 + min_obs - 1, 11))
+        for f in range(f0, f1 + 1):
+            Rwb = _qR(pose[f, 3:])
+            Rwc, twc = Rwb @ R_bc, Rwb @ ex[:3] + pose[f, :3]
+            c1, c2 = Rwc.T @ (p1 - twc), Rwc.T @ (p2 - twc)
+            o = np.zeros((), LINEOBS_DTYPE)
+            o["line"], o["frame"] = k, f
+            o["obs"] = np.array([c1[0] / c1[2], c1[1] / c1[2], c2[0] / c2[2], c2[1] / c2[2]]) + rng.normal(0, pix_sigma, 4)
+            obs.append(o)
+    obs = np.array(obs, LINEOBS_DTYPE)[rng.permutation(len(obs))] if obs else np.zeros(0, LINEOBS_DTYPE)
+    return LineProblem(orth, pose, ex, sqrt_info, obs, max_iters=max_iters)
+
+
+def o_line_solve(lib, prob):
+    from dynamic_vins_amd.backend import dv_ba_summary
+    p, s = prob.struct(), dv_ba_summary()
+    lib.dvo_line_solve.argtypes = [C.c_void_p, C.c_void_p]
+    lib.dvo_line_solve.restype = C.c_int
+    assert lib.dvo_line_solve(C.byref(p), C.byref(s)) == 0
+    return s

@@ -168,7 +168,9 @@ def main():
             "config": {"workload": f"synthetic {args.width}x{args.height} stereo @20 Hz + IMU @200 Hz, ZED intrinsics with distortion, figure-8 in a textured box room, "
                                    f"max_cnt {args.max_cnt}, min_dist {args.min_dist}, flow_back 1, {args.iters} solver iterations, BA + marginalization on every frame",
                        "parallelism": f"replicas x{world} (independent sequences, no collective)", "landmarks_in_window": n_lm, "features_per_frame": nfeat,
-                       "solver_iterations_per_frame": round(iters / args.steps, 2), "ate_rmse_m_vs_ground_truth": round(ate, 5)},
+                       "solver_iterations_per_frame": round(iters / args.steps, 2), "ate_rmse_m_vs_ground_truth": round(ate, 5),
+                       "warmup_requested": args.warmup,
+                       "warmup_note": "at least 12 untimed frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

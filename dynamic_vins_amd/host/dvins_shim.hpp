@@ -397,6 +397,47 @@ inline InstanceSolveSummary OptimizeInstances(dv_ctx* ctx, int n_obj, double* st
     return r;
 }
 
+// ---- the two frame-flow policies that sit between the ROS callbacks and the path, ROS-free ----
+// StereoSync: the left / right part of SystemCallBack::SyncProcess (utils/io/system_call_back.cpp:97-135): the oldest left image is the
+// reference; a right image within kDelay = 5 ms (utils/parameters.h:47) pairs with it, older right images are discarded, and a left image
+// that is more than kDelay OLDER than the oldest right image is dropped.  TryPop() is one trip of the reference's loop body.
+template <class Img>
+class StereoSync {
+public:
+    static constexpr double kDelay = 0.005;
+    void PushLeft(double t, Img img) { std::lock_guard<std::mutex> lk(m_); left_.emplace_back(t, std::move(img)); }
+    void PushRight(double t, Img img) { std::lock_guard<std::mutex> lk(m_); right_.emplace_back(t, std::move(img)); }
+    // true: (t0, left, t1, right) is a synchronised pair.  false: wait for more input (the reference sleeps 2 ms) — possibly after having
+    // dropped a too-early left image.
+    bool TryPop(double& t0, Img& left, double& t1, Img& right) {
+        std::lock_guard<std::mutex> lk(m_);
+        if (left_.empty() || right_.empty()) return false;
+        t0 = left_.front().first;
+        t1 = right_.front().first;
+        if (t0 + kDelay < t1) { left_.pop_front(); ++dropped_left; return false; }          // img0 too early: it is gone (:118-122)
+        if (t1 + kDelay < t0) {                                                              // right images too early: discard them (:123-128)
+            while (!right_.empty() && t0 - right_.front().first > kDelay) { right_.pop_front(); ++dropped_right; }
+            if (right_.empty()) return false;      // the reference reads front() of the emptied deque here (undefined); the shim keeps the left image and waits
+            t1 = right_.front().first;
+        }
+        left = std::move(left_.front().second); left_.pop_front();
+        right = std::move(right_.front().second); right_.pop_front();
+        return true;
+    }
+    size_t pending_left() const { return left_.size(); }
+    size_t pending_right() const { return right_.size(); }
+    int dropped_left = 0, dropped_right = 0;
+private:
+    std::mutex m_;
+    std::deque<std::pair<double, Img>> left_, right_;
+};
+// FrameGate: which tracked frames reach the estimator (system/main.cpp:297-307): every frame on KITTI, every second one otherwise.
+struct FrameGate {
+    bool every_frame = false;              // cfg::dataset == DatasetType::kKitti
+    int cnt = 0;
+    bool Pass() { const bool p = every_frame || (cnt % 2 == 0); ++cnt; return p; }
+};
+
 // ---- on-disk formats on either side of the path ----
 // trajectory line of SaveBodyTrajectory (utils/io/output.cpp:189-227): "<sec>.<nsec 9 digits> px py pz qx qy qz qw", fixed, 6 decimals
 inline std::string TumLine(double stamp, const std::array<double, 16>& s) {

@@ -1,6 +1,7 @@
 // test driver of dynamic_vins_amd/host/dvins_shim.hpp (built by tests/test_host_shim.py with g++):
 //   shim_test parse <config.yaml>                      -> prints the parsed configuration (CPU)
 //   shim_test nogpu <config.yaml>                      -> constructing the tracker without a device must throw (CPU)
+//   shim_test sync <config.yaml>                       -> StereoSync / FrameGate on scripted time stamps (CPU)
 //   shim_test track <config.yaml> <frames.raw> <n> <w> <h>  -> runs TrackImage over n stereo pairs read from a raw file,
 //                                                         feeds a constant-gravity IMU stream and runs the Estimator (GPU)
 //   shim_test extras <config.yaml> <frames.raw> <n> <w> <h> -> SetUndistortMaps + BGR views, OptimizeInstances (GPU)
@@ -33,6 +34,28 @@ int main(int argc, char** argv) {
             SerializePointFeature(argv[4], pts);
             std::array<double, 16> st{}; st[0] = 1.0; st[1] = -2.5; st[2] = 0.125; st[5] = 0.70710678; st[6] = 0.70710678;
             std::printf("%zu\n%s\n", pts.size(), TumLine(1403636579.763555992, st).c_str());
+            return 0;
+        }
+        if (mode == "sync") {         // scripted time stamps through StereoSync / FrameGate (CPU)
+            StereoSync<int> sync;
+            double t0, t1; int l, r;
+            std::printf("%d", (int)sync.TryPop(t0, l, t1, r));                      // nothing queued
+            sync.PushLeft(1.000, 10); sync.PushLeft(1.050, 11); sync.PushLeft(1.100, 12); sync.PushLeft(1.150, 13);
+            sync.PushRight(0.900, 19); sync.PushRight(0.950, 20); sync.PushRight(1.052, 21); sync.PushRight(1.100, 22); sync.PushRight(1.149, 23);
+            // left 1.000: right 0.900, 0.950 are too old -> discarded; right 1.052 is > 5 ms newer than 1.000?  no: |1.000 - 1.052| — the rule only
+            // discards OLDER right images, so 1.000 pairs with 1.052 (the reference's behaviour)
+            for (int k = 0; k < 6; ++k) {
+                const bool ok = sync.TryPop(t0, l, t1, r);
+                if (ok) std::printf(" | %d %d %.3f %.3f", l, r, t0, t1); else std::printf(" | -");
+            }
+            std::printf(" | dropped %d %d pending %zu %zu\n", sync.dropped_left, sync.dropped_right, sync.pending_left(), sync.pending_right());
+            StereoSync<int> s2;                                                      // a left image far older than every right image is dropped
+            s2.PushLeft(2.000, 1); s2.PushLeft(2.100, 2); s2.PushRight(2.099, 7);
+            const bool a = s2.TryPop(t0, l, t1, r); const bool b = s2.TryPop(t0, l, t1, r);
+            std::printf("%d %d %d %d %.3f dropped %d\n", (int)a, (int)b, l, r, t1, s2.dropped_left);
+            FrameGate g, gk; gk.every_frame = true;
+            for (int k = 0; k < 5; ++k) std::printf("%d%d ", (int)g.Pass(), (int)gk.Pass());
+            std::printf("\n");
             return 0;
         }
         if (mode == "nogpu") {

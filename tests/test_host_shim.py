@@ -114,3 +114,13 @@ def test_shim_undistort_maps_bgr_views_and_instance_solve(shim_exe, tmp_path, gp
     ref = "instances %d %d %d %.17g %.17g %.17g %.17g %.17g" % (s.iterations, s.successful, s.termination, s.initial_cost, s.final_cost, p.dims[0, 0], p.state[0, 3, 5], p.state[0, 7, 6])
     assert out[1] == ref
     assert s.successful > 0 and s.final_cost < s.initial_cost
+
+
+def test_shim_stereo_sync_and_frame_gate(shim_exe):
+    """row N1, ROS-free part: SyncProcess' time-stamp rule (5 ms, discard older right images, drop a too-early left image) and the
+    every-second-frame policy, on scripted stamps — including the reference's quirk that a right image NEWER than the left one by more
+    than the tolerance still pairs with it once the older ones are gone"""
+    out = subprocess.run([shim_exe, "sync", CFG], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "0 | 10 21 1.000 1.052 | - | 12 22 1.100 1.100 | 13 23 1.150 1.149 | - | - | dropped 1 2 pending 0 0"
+    assert out[1] == "0 1 2 7 2.099 dropped 1"
+    assert out[2].split() == ["11", "01", "11", "01", "11"]

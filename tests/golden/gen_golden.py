@@ -16,6 +16,7 @@
                      restatements and the size-independent properties.
 3. back_kat.npz    — known-answer vectors of the back-end path from the oracle: factor residuals/Jacobians,
                      pre-integration of a fixed IMU sequence, one standalone window solve, one marginalization.
+4. aux_kat.npz     — the same for cv::remap with fixed-point maps, the object solve and the line-only solve (oracle outputs; parity unpinned).
 Only data is written: inputs and expected outputs.
 """
 import ctypes as C
@@ -158,9 +159,39 @@ def gen_back(o):
     print("back_kat.npz: solve", out["sol_summary"], "marg n", out["marg0_A"].shape, out["marg1_A"].shape)
 
 
+def gen_aux(o):
+    """4. aux_kat.npz — known-answer vectors of the rows added after the core path: cv::remap with fixed-point undistortion maps (1 and 3
+    channels, incl. out-of-range coordinates), the per-frame object solve and the line-only solve (inputs, solved parameters, summaries)."""
+    import obj_gen as G
+    rng = np.random.default_rng(11)
+    w, h = 96, 64
+    cam = (70.0, 71.0, 48.2, 30.4, -0.3, 0.08, 1e-3, -1e-3)
+    m1, m2 = o.init_undistort_map(cam, (52.0, 53.0, 47.0, 33.0), w, h)          # a zoom-out: the border rows / columns leave the source
+    gray = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    bgr = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    out = dict(remap_map1=m1, remap_map2=m2, remap_gray=gray, remap_bgr=bgr, remap_gray_out=o.remap(gray, m1, m2), remap_bgr_out=o.remap(bgr, m1, m2),
+               remap_fused_gray=o.bgr2gray(o.remap(bgr, m1, m2)))
+    for name, kw in (("obj_a", dict(seed=2, n_obj=3, pts_per_obj=0, max_iters=10)), ("obj_b", dict(seed=5, n_obj=6, outside=0.0, pose_noise=(0.02, 0.3), max_iters=12))):
+        p = G.make_obj_scene(**kw)
+        for k in ("state", "dims", "body_pose", "R_bc", "boxes", "points"):
+            out[name + "_" + k] = getattr(p, k).copy()
+        out[name + "_opts"] = np.array([p.max_iters, p.plane_kind])
+        s = G.o_obj_solve(o.lib, p)
+        out[name + "_state_out"], out[name + "_dims_out"] = p.state.copy(), p.dims.copy()
+        out[name + "_summary"] = np.array([s.iterations, s.successful, s.termination, s.initial_cost, s.final_cost])
+    p = G.make_line_scene(seed=1, max_iters=5)
+    for k in ("orth", "pose", "ex_pose", "sqrt_info", "obs"):
+        out["line_" + k] = getattr(p, k).copy()
+    s = G.o_line_solve(o.lib, p)
+    out["line_orth_out"] = p.orth.copy()
+    out["line_summary"] = np.array([s.iterations, s.successful, s.termination, s.initial_cost, s.final_cost])
+    np.savez_compressed(os.path.join(HERE, "aux_kat.npz"), **out)
+    print("aux_kat.npz: obj", out["obj_a_summary"], out["obj_b_summary"], "line", out["line_summary"])
+
+
 if __name__ == "__main__":
     import oracle_py
-    which = sys.argv[1:] or ["ate", "front", "back"]
+    which = sys.argv[1:] or ["ate", "front", "back", "aux"]
     if "ate" in which:
         gen_ate()
     o = oracle_py.load()
@@ -168,3 +199,5 @@ if __name__ == "__main__":
         gen_front(o)
     if "back" in which:
         gen_back(o)
+    if "aux" in which:
+        gen_aux(o)

@@ -123,3 +123,27 @@ def test_marginalization_matches_golden(gpu_ctx_factory, back):
         assert np.abs(A2 - gA).max() <= 1e-8 * np.abs(gA).max()
         assert np.abs(b2 - gb).max() <= 1e-8 * max(1.0, np.abs(gb).max())
         assert abs(pr.c0 - back[f"marg{mode}_c0"][0]) <= 2e-3 * abs(pr.c0)
+
+
+def test_aux_rows_match_golden(gpu_ctx_factory):
+    """remap (bit-exact, incl. the fused remap + cvtColor through the tracker's level 0), object solve and line-only solve against
+    tests/golden/aux_kat.npz"""
+    from dynamic_vins_amd.backend import LineProblem, ObjProblem, line_solve, obj_solve
+    g = np.load(os.path.join(G, "aux_kat.npz"))
+    ctx = gpu_ctx_factory(width=64, height=48)
+    m1, m2 = g["remap_map1"], g["remap_map2"]
+    assert np.array_equal(ctx.remap(g["remap_gray"], m1, m2), g["remap_gray_out"])
+    assert np.array_equal(ctx.remap(g["remap_bgr"], m1, m2), g["remap_bgr_out"])
+    assert np.array_equal(ctx.bgr2gray(ctx.remap(g["remap_bgr"], m1, m2)), g["remap_fused_gray"])
+    for name in ("obj_a", "obj_b"):
+        p = ObjProblem(g[name + "_state"], g[name + "_dims"], g[name + "_body_pose"], g[name + "_R_bc"], g[name + "_boxes"], g[name + "_points"],
+                       max_iters=int(g[name + "_opts"][0]), plane_kind=int(g[name + "_opts"][1]))
+        s = obj_solve(ctx, p)
+        assert [s.iterations, s.successful, s.termination] == g[name + "_summary"][:3].astype(int).tolist()
+        assert np.abs(p.state - g[name + "_state_out"]).max() <= 1e-8 and np.abs(p.dims - g[name + "_dims_out"]).max() <= 1e-8
+        assert abs(s.final_cost - g[name + "_summary"][4]) <= 1e-9 * max(1.0, g[name + "_summary"][3])
+    p = LineProblem(g["line_orth"], g["line_pose"], g["line_ex_pose"], g["line_sqrt_info"], g["line_obs"], max_iters=int(g["line_summary"][0]))
+    s = line_solve(ctx, p)
+    assert [s.iterations, s.successful, s.termination] == g["line_summary"][:3].astype(int).tolist()
+    d = np.abs(p.orth - g["line_orth_out"])
+    assert np.median(d) <= 1e-10 and d.max() <= 1e-6 and abs(s.final_cost - g["line_summary"][4]) <= 1e-8 * g["line_summary"][3]

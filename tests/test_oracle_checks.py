@@ -438,3 +438,27 @@ def test_remap_oracle_against_float_bilinear(oracle):
     o3 = oracle.remap(bgr, m1, m2)
     for c in range(3):
         assert np.array_equal(o3[..., c], oracle.remap(np.ascontiguousarray(bgr[..., c]), m1, m2))
+
+
+def test_aux_golden_reproduced_by_the_oracle(oracle):
+    """tests/golden/aux_kat.npz (remap, object solve, line-only solve) pins the oracle against compiler / flag drift: bytes exact,
+    solver outputs to the last bit on the authoring toolchain and to 1e-12 elsewhere"""
+    from dynamic_vins_amd.backend import LineProblem, ObjProblem
+    from tests import obj_gen as G
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aux_kat.npz"))
+    m1, m2 = g["remap_map1"], g["remap_map2"]
+    assert np.array_equal(oracle.remap(g["remap_gray"], m1, m2), g["remap_gray_out"])
+    assert np.array_equal(oracle.remap(g["remap_bgr"], m1, m2), g["remap_bgr_out"])
+    assert np.array_equal(oracle.bgr2gray(g["remap_bgr_out"]), g["remap_fused_gray"])
+    assert (g["remap_gray_out"][0] == 0).all() and g["remap_gray_out"][20:40].any()          # zoom-out: the first row comes from outside the source
+    for name in ("obj_a", "obj_b"):
+        p = ObjProblem(g[name + "_state"], g[name + "_dims"], g[name + "_body_pose"], g[name + "_R_bc"], g[name + "_boxes"], g[name + "_points"],
+                       max_iters=int(g[name + "_opts"][0]), plane_kind=int(g[name + "_opts"][1]))
+        s = G.o_obj_solve(oracle.lib, p)
+        assert [s.iterations, s.successful, s.termination] == g[name + "_summary"][:3].astype(int).tolist()
+        assert np.allclose(p.state, g[name + "_state_out"], rtol=0, atol=1e-12) and np.allclose(p.dims, g[name + "_dims_out"], rtol=0, atol=1e-12)
+        assert np.isclose(s.final_cost, g[name + "_summary"][4], rtol=1e-12)
+    p = LineProblem(g["line_orth"], g["line_pose"], g["line_ex_pose"], g["line_sqrt_info"], g["line_obs"], max_iters=int(g["line_summary"][0]))
+    s = G.o_line_solve(oracle.lib, p)
+    assert [s.iterations, s.successful, s.termination] == g["line_summary"][:3].astype(int).tolist()
+    assert np.allclose(p.orth, g["line_orth_out"], rtol=0, atol=1e-9) and np.isclose(s.final_cost, g["line_summary"][4], rtol=1e-10)

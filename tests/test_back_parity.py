@@ -112,7 +112,10 @@ def test_imu_factor_matches_oracle(ctx, oracle):
 
 CASES = [dict(seed=1), dict(seed=2, with_prior=True), dict(seed=3, use_imu=0, nframes=7), dict(seed=4, with_prior=True, outlier_ratio=0.1, max_iters=10),
          dict(seed=6, nlm=300, max_iters=10, with_prior=True), dict(seed=7, use_imu=0, with_prior=True, plane_kind=2), dict(seed=8, nframes=5, nlm=40),
-         dict(seed=9, nlm=1, max_iters=3)]
+         dict(seed=9, nlm=1, max_iters=3),
+         dict(seed=11, nlm=1000, max_iters=4, with_prior=True),      # kNumFeat landmarks: the capacity of the packet layout
+         dict(seed=12, nlm=0, max_iters=4, with_prior=True),         # no landmark at all: IMU factors and the prior only
+         dict(seed=13, nlm=2, max_iters=4)]
 
 
 @pytest.mark.parametrize("kw", CASES, ids=[str(i) for i in range(len(CASES))])

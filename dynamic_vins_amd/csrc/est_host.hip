@@ -194,17 +194,31 @@ struct dv_estimator {
     void reindex() { lm_index.clear(); for (size_t i = 0; i < lms.size(); ++i) lm_index[lms[i].id] = i; index_dirty = false; }
     int long_count() const { int c = 0; for (auto& l : lms) if (l.obs.size() >= 4) ++c; return c; }
     bool add_features(int fc, const dv_feat* feats, int n) {
-        if (index_dirty) reindex();
+        // feature ids are handed out by a monotone counter, and landmarks are appended in id order and only ever erased: `lms` stays sorted
+        // by id, so matching the (sorted) frame against it is a merge join — no hash index to rebuild after every slide / rejection.
+        // Should the invariant ever be broken by a caller (ids not monotone), fall back to the hash index.
+        bool sorted_ids = true;
+        for (size_t i = 1; i < lms.size(); ++i) if (lms[i - 1].id >= lms[i].id) { sorted_ids = false; break; }
+        if (!sorted_ids && index_dirty) reindex();
         std::vector<const dv_feat*> order(n);
         for (int i = 0; i < n; ++i) order[i] = &feats[i];
         std::sort(order.begin(), order.end(), [](const dv_feat* a, const dv_feat* b) { return a->id < b->id; });     // the reference iterates a std::map keyed by id
         int last_track = 0, new_feat = 0, long_track = 0;
+        const size_t n_old = lms.size(); size_t cur = 0;
         for (const dv_feat* f : order) {
             Obs o; o.pt = mk3(f->left[0], f->left[1], f->left[2]); o.vel = mk3(f->left[5], f->left[6], 0); o.td = td; o.stereo = f->has_right != 0;
             o.pt_r = o.stereo ? mk3(f->right[0], f->right[1], f->right[2]) : mk3(0, 0, 0); o.vel_r = o.stereo ? mk3(f->right[5], f->right[6], 0) : mk3(0, 0, 0);
-            auto it = lm_index.find((int)f->id);
-            if (it == lm_index.end()) { Lm l; l.id = (int)f->id; l.start = fc; l.obs.push_back(o); lm_index[l.id] = lms.size(); lms.push_back(std::move(l)); new_feat++; }
-            else { Lm& l = lms[it->second]; l.obs.push_back(o); last_track++; if (l.obs.size() >= 4) long_track++; }
+            long found = -1;
+            if (sorted_ids) {
+                while (cur < n_old && lms[cur].id < (int)f->id) ++cur;
+                if (cur < n_old && lms[cur].id == (int)f->id) found = (long)cur;
+                else if (!lms.empty() && lms.back().id >= (int)f->id) {      // a new id below a known one: the order would break -> hash index from here on
+                    sorted_ids = false; reindex();
+                }
+            }
+            if (!sorted_ids) { auto it = lm_index.find((int)f->id); if (it != lm_index.end()) found = (long)it->second; }
+            if (found < 0) { Lm l; l.id = (int)f->id; l.start = fc; l.obs.push_back(o); if (!sorted_ids) lm_index[l.id] = lms.size(); lms.push_back(std::move(l)); new_feat++; }
+            else { Lm& l = lms[(size_t)found]; l.obs.push_back(o); last_track++; if (l.obs.size() >= 4) long_track++; }
         }
         if (fc < 2 || last_track < 20 || long_track < 40 || new_feat > 0.5 * last_track) return true;
         double psum = 0; int pnum = 0;

@@ -335,7 +335,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     std::memcpy(hp + w.up_idx, idx.data(), 4 * idx.size());
     if (do_marg && !pl.empty) std::memcpy(hp + w.up_mt, pl.tab, sizeof(pl.tab));
     if (P->nlm) std::memcpy(hp + w.up_lm, P->landmarks, sizeof(BeLm) * (size_t)P->nlm);
-    if (P->nfac) std::memcpy(hp + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac);
+    if (P->nfac && (const void*)P->factors != (const void*)(hp + w.up_fac)) std::memcpy(hp + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac);      // the estimator builds the table in place
     DV_CHECK(hipMemcpyAsync(w.block.p, hp, w.up_fac + sizeof(BeFactor) * (size_t)P->nfac, hipMemcpyHostToDevice, s));
     if (has_prior && !prior_on_device) {               // a prior handed over in host memory (the estimator's stays in HBM)
         if (!P->prior_A || !P->prior_b) DV_FAIL("dv_ba_solve: prior without A / b");
@@ -377,6 +377,13 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     if (be_enqueue_tail(ctx, pd, s)) return -1;
     pd.active = true; pd.t_begin = t_begin; pd.t_up = t_up; pd.t_enq = t_enq;
     return 0;
+}
+
+void* be_staging_factors(dv_ctx* ctx, int* cap) {
+    if (!ctx || ctx->be.pend->active) return nullptr;
+    if (hipSetDevice(ctx->cfg.device) != hipSuccess || be_ensure(ctx, 0)) return nullptr;
+    *cap = ctx->be.fac_cap;
+    return (uint8_t*)ctx->be.pinned + ctx->be.up_fac;
 }
 
 int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused) { return be_begin_impl(ctx, P, fused, false); }

@@ -113,6 +113,7 @@ struct BeFused {
     double diag[4] = { 0, 0, 0, 0 };          // out: c0, smallest pivot, failure flag, rank
 };
 int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);
+void* be_staging_factors(dv_ctx* ctx, int* cap);      // where the next solve's upload reads its factor table (pinned); nullptr if the workspace cannot be set up
 int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused);       // upload + enqueue everything, returns immediately
 int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);      // sync + collect
 struct dv_estimator;

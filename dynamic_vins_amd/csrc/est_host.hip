@@ -322,31 +322,39 @@ struct dv_estimator {
         f.kind = kind; f.lm = lm; f.fi = fi; f.fj = fj; return f;
     }
     // builds the residual blocks of AddResidualBlock (estimator.cpp:130-178); only_anchor0: the marginalization subset (:440-493)
+    // fac_out / fac_cap: optional destination for the factor records — the pinned staging mirror of the device's upload region
+    // (be_staging_factors), so that the table is assembled where the upload reads it instead of being copied there (336 KB per frame)
+    dv_ba_factor* fac_out = nullptr; int fac_cap = 0, nfac = 0;
+    void put_factor(const dv_ba_factor& f) {
+        if (fac_out && nfac < fac_cap) fac_out[nfac] = f;
+        else { if (fac_out) { fac.assign(fac_out, fac_out + nfac); fac_out = nullptr; } fac.push_back(f); }      // over capacity: back to the vector
+        ++nfac;
+    }
     void build_factors(bool only_anchor0) {
-        fac.clear(); lmt.clear(); if (!only_anchor0) invd.clear();
+        fac.clear(); nfac = 0; lmt.clear(); if (!only_anchor0) invd.clear();
         int fi = -1;
         for (auto& l : lms) {
             if (l.obs.size() < 4) continue;
             ++fi;
             if (!only_anchor0) invd.push_back(1.0 / l.depth);
             if (only_anchor0 && l.start != 0) continue;
-            dv_ba_lm t{}; t.first = (int)fac.size(); t.anchor = l.start; t.mask = 0;
+            dv_ba_lm t{}; t.first = nfac; t.anchor = l.start; t.mask = 0;
             int j = l.start - 1;
             for (auto& o : l.obs) {
                 ++j; t.mask |= 1 << j;
-                if (j != l.start) fac.push_back(mkfac(l.obs[0], o, false, 0, fi, l.start, j));
-                if (cfg.stereo && o.stereo) fac.push_back(mkfac(l.obs[0], o, true, j != l.start ? 1 : 2, fi, l.start, j));
+                if (j != l.start) put_factor(mkfac(l.obs[0], o, false, 0, fi, l.start, j));
+                if (cfg.stereo && o.stereo) put_factor(mkfac(l.obs[0], o, true, j != l.start ? 1 : 2, fi, l.start, j));
             }
-            t.count = (int)fac.size() - t.first;
+            t.count = nfac - t.first;
             lmt.push_back(t);
         }
     }
     dv_ba_problem make_problem(int nframes) {
         dv_ba_problem P{};
-        P.nframes = nframes; P.nlm = (int)lmt.size(); P.nfac = (int)fac.size(); P.nimu = (int)imu.size(); P.use_imu = cfg.use_imu;
+        P.nframes = nframes; P.nlm = (int)lmt.size(); P.nfac = nfac; P.nimu = (int)imu.size(); P.use_imu = cfg.use_imu;
         P.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; P.max_iters = cfg.max_iters; P.g_norm = cfg.g_norm;
         P.pose = &pose[0][0]; P.speed_bias = &sb[0][0]; P.ex_pose = &ex[0][0]; P.td = tdv; P.inv_depth = invd.data();
-        P.factors = fac.data(); P.landmarks = lmt.data(); P.imu = imu.data();
+        P.factors = fac_out ? fac_out : fac.data(); P.landmarks = lmt.data(); P.imu = imu.data();
         P.prior = prior.valid ? &prior : nullptr; P.prior_A = prior_dev_A; P.prior_b = prior_dev_b;      // A', b' stay in HBM (written by the fused marginalization)
         return P;
     }
@@ -354,6 +362,7 @@ struct dv_estimator {
     int optimization_begin(dv_ctx* ctx) {        // Estimator::Optimization (estimator.cpp:261-339) incl. SetMarginalizationInfo (:403-619)
         { HostScope h(ctx, "h_build");
           states_to_arrays();
+          fac_out = (dv_ba_factor*)be_staging_factors(ctx, &fac_cap);
           build_factors(false);
           imu.clear();
           ctx->be.sqrt_hint.clear();

@@ -412,6 +412,10 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
         DV_CHECK(hipEventSynchronize(w.ev_state));
     }
     if (pd.marg_in_flight) { pd.marg_in_flight = false; pd.marg_check_due = true; pd.check_slot = pd.scal_slot; pd.scal_slot ^= 1; }
+    if (ctx->host_timing) {
+        StageTimer* te = dv_timer_for(ctx, "h_solve_enqueue"); te->total_ms += std::chrono::duration<double, std::milli>(pd.t_enq - pd.t_up).count(); te->count++;
+        StageTimer* tu = dv_timer_for(ctx, "h_solve_upload"); tu->total_ms += std::chrono::duration<double, std::milli>(pd.t_up - pd.t_begin).count(); tu->count++;
+    }
     if (ctx->timing) {
         DV_CHECK(hipStreamSynchronize(s));         // measurement mode only: the timers are harvested from an idle stream
         StageTimer* te = dv_timer_for(ctx, "h_solve_enqueue"); te->total_ms += std::chrono::duration<double, std::milli>(pd.t_enq - pd.t_up).count(); te->count++;

@@ -134,7 +134,7 @@ struct dv_ctx {
     hipEvent_t done = nullptr; bool pending = false;
     // operator-level scratch
     PyrSet opA, opB; DevBuf s0, s1, s2, s3, s4;
-    bool timing = false, kernel_timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
+    bool timing = false, kernel_timing = false, host_timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
     // back end
     hipStream_t be_stream = nullptr; BeWork be;
     dv_estimator* est = nullptr;
@@ -168,7 +168,7 @@ struct StageScope {
 // host wall-clock of a scope (std::chrono), accumulated under `name` next to the event timers ("h_*" names)
 struct HostScope {
     dv_ctx* c; StageTimer* t = nullptr; std::chrono::steady_clock::time_point t0;
-    HostScope(dv_ctx* ctx, const char* name) : c(ctx) { if (!c->timing) return; t = dv_timer_for(c, name); t0 = std::chrono::steady_clock::now(); }
+    HostScope(dv_ctx* ctx, const char* name) : c(ctx) { if (!c->timing && !c->host_timing) return; t = dv_timer_for(c, name); t0 = std::chrono::steady_clock::now(); }
     ~HostScope() { if (t) { t->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); t->count++; } }
 };
 void dv_harvest_timers(dv_ctx* ctx, hipStream_t synced);      // harvests the timers recorded on `synced` (must be idle)

@@ -204,7 +204,7 @@ int dv_sync(dv_ctx* ctx) {
     return 0;
 }
 
-int dv_timing_enable(dv_ctx* ctx, int on) { if (!ctx) return -1; ctx->timing = on != 0; ctx->kernel_timing = on >= 2; return 0; }
+int dv_timing_enable(dv_ctx* ctx, int on) { if (!ctx) return -1; ctx->host_timing = on == -1; ctx->timing = on > 0; ctx->kernel_timing = on >= 2; return 0; }      // -1: host wall-clock scopes only (no events, no extra syncs)
 int dv_timing_reset(dv_ctx* ctx) { if (!ctx) return -1; for (auto& t : ctx->timers) { t.total_ms = 0; t.count = 0; t.used = 0; } return 0; }
 int dv_timing_get(dv_ctx* ctx, const char* name, double* total_ms, long long* count) {
     if (!ctx || !name) return -1;

@@ -326,7 +326,8 @@ int dv_est_process_end(dv_ctx* ctx, dv_est_state* out);
 /* ---- measurement hooks (used by bench.py; HIP-event timing on the ctx's own stream) ---- */
 /* names: "pyr","lk_temporal","compact","gftt_eig","gftt_select","lk_stereo","frame" */
 /* on: 0 off, 1 per-stage events, 2 additionally one event pair around every back-end kernel launch
- * ("k_be_eval_full","k_be_reduce","k_be_solve","k_be_eval_cost","k_be_accept","k_be_marg") */
+ * ("k_be_eval_full","k_be_reduce","k_be_solve","k_be_eval_cost","k_be_accept","k_be_marg"), -1 host wall-clock scopes only
+ * ("h_*": no events, no extra synchronisation — the pipeline keeps its overlap) */
 int dv_timing_enable(dv_ctx* ctx, int on);
 int dv_timing_reset(dv_ctx* ctx);
 int dv_timing_get(dv_ctx* ctx, const char* name, double* total_ms, long long* count);

@@ -33,6 +33,12 @@ extern "C" int dv_debug_marg_ts(long long* out) { return hipMemcpyFromSymbol(out
 #define MTS(k) do {} while (0)
 #endif
 #define MG_THREADS 1024
+__device__ __forceinline__ double mg_rcp(double d) {      // v_rcp_f64 + two Newton steps: full precision at a fraction of a division's latency (on the pivot chain)
+    double r = __builtin_amdgcn_rcp(d);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+    return r;
+}
 #define LM_THREADS 256
 
 // offsets of the two Jacobian entries (row 0, row 1) of column `comp` of slot `slot` inside a factor record
@@ -290,46 +296,65 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         __syncthreads();
     }
     MTS(11);
-    // ---------------- eliminate the dropped pose / speed-bias dims [0, m): Cholesky of A_dd in place (one wave) ----------------
-    if (tid < 64) {
-        for (int k = 0; k < m; ++k) {
-            const double piv = A[k * D + k];
-            if (tid == 0) { if (piv < misc[0]) misc[0] = piv; if (!(piv > 0)) misc[1] = 1.0; }
-            const double inv = 1.0 / sqrt(piv);
-            for (int i = k + tid; i < m; i += 64) A[i * D + k] *= inv;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-            for (int e = tid; e < (m - k - 1) * (m - k - 1); e += 64) {
-                const int i = k + 1 + e / (m - k - 1), j = k + 1 + e % (m - k - 1);
-                if (j <= i) A[i * D + j] -= A[i * D + k] * A[j * D + k];
+    // ---------------- eliminate the dropped pose / speed-bias dims [0, m): right-looking LDL^T in panels of <= 4 columns on the LOWER
+    // triangle of the whole system (A is bitwise symmetric by construction: commuting products summed in one order), with b as an extra
+    // row.  (A) thread 0 factors the pivot block, (B) one thread per row below forms its panel entries and updates b, (C) all threads
+    // apply the rank-<=4 update.  After the last panel the kept block IS the Schur complement A' and b the reduced b' — the separate
+    // Cholesky, forward substitution and X^T X product (24 us) are gone ----------------
+    {
+        double* PLm = W2; double* PPm = W2 + 4 * D; double* dbm = W2 + 8 * D;      // W2 is free until A' is copied into it
+        for (int k0 = 0; k0 < m; k0 += 4) {
+            const int nb = min(4, m - k0);
+            if (tid == 0) {
+                double am[4][4], yk[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int cc = 0; cc <= r; ++cc) am[r][cc] = (r < nb) ? A[(k0 + r) * D + k0 + cc] : (r == cc ? 1.0 : 0.0);
+                    yk[r] = r < nb ? bv[k0 + r] : 0.0;
+                }
+                const double d0 = am[0][0], i0 = mg_rcp(d0);
+                const double l10 = am[1][0] * i0, l20 = am[2][0] * i0, l30 = am[3][0] * i0;
+                const double d1 = am[1][1] - l10 * am[1][0], i1 = mg_rcp(d1);
+                const double t21 = am[2][1] - l20 * am[1][0], t31 = am[3][1] - l30 * am[1][0];
+                const double l21 = t21 * i1, l31 = t31 * i1;
+                const double d2 = am[2][2] - l20 * am[2][0] - l21 * t21, i2 = mg_rcp(d2);
+                const double t32 = am[3][2] - l30 * am[2][0] - l31 * t21;
+                const double l32 = t32 * i2;
+                const double d3 = am[3][3] - l30 * am[3][0] - l31 * t31 - l32 * t32, i3 = mg_rcp(d3);
+                const double dd[4] = { d0, d1, d2, d3 };
+                for (int r = 0; r < nb; ++r) { if (dd[r] < misc[0]) misc[0] = dd[r]; if (!(dd[r] > 0)) misc[1] = 1.0; }
+                const double y0 = yk[0], y1 = yk[1] - l10 * y0, y2 = yk[2] - l20 * y0 - l21 * y1, y3 = yk[3] - l30 * y0 - l31 * y1 - l32 * y2;
+                dbm[0] = l10; dbm[1] = l20; dbm[2] = l30; dbm[3] = l21; dbm[4] = l31; dbm[5] = l32;
+                dbm[6] = i0; dbm[7] = nb > 1 ? i1 : 0.0; dbm[8] = nb > 2 ? i2 : 0.0; dbm[9] = nb > 3 ? i3 : 0.0;      // padded columns contribute nothing
+                dbm[10] = y0; dbm[11] = y1; dbm[12] = y2; dbm[13] = y3;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+            __syncthreads();
+            const double l10 = dbm[0], l20 = dbm[1], l30 = dbm[2], l21 = dbm[3], l31 = dbm[4], l32 = dbm[5];
+            const double i0 = dbm[6], i1 = dbm[7], i2 = dbm[8], i3 = dbm[9];
+            const int r0 = k0 + nb;                                   // first row below the pivot block
+            for (int i = r0 + tid; i < D; i += MG_THREADS) {
+                const double* row = A + i * D + k0;
+                const double p0 = row[0], p1 = nb > 1 ? row[1] - p0 * l10 : 0.0, p2 = nb > 2 ? row[2] - p0 * l20 - p1 * l21 : 0.0, p3 = nb > 3 ? row[3] - p0 * l30 - p1 * l31 - p2 * l32 : 0.0;
+                const double x0 = p0 * i0, x1 = p1 * i1, x2 = p2 * i2, x3 = p3 * i3;
+                PLm[i] = x0; PLm[D + i] = x1; PLm[2 * D + i] = x2; PLm[3 * D + i] = x3;
+                PPm[i] = p0; PPm[D + i] = p1; PPm[2 * D + i] = p2; PPm[3 * D + i] = p3;
+                bv[i] -= x0 * dbm[10] + x1 * dbm[11] + x2 * dbm[12] + x3 * dbm[13];
+            }
+            __syncthreads();
+            for (int i = r0 + (tid >> 6); i < D; i += MG_THREADS / 64) {          // wave = row, lane = column: no integer division, the row's panel entries are wave-uniform
+                const double x0 = PLm[i], x1 = PLm[D + i], x2 = PLm[2 * D + i], x3 = PLm[3 * D + i];
+                for (int j = r0 + (tid & 63); j <= i; j += 64) A[i * D + j] -= x0 * PPm[j] + x1 * PPm[D + j] + x2 * PPm[2 * D + j] + x3 * PPm[3 * D + j];
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
-    MTS(12);
-    // X = L^-1 [A_dk | b_d]  (forward substitution, one column per thread; stored over A_dk / b_d)
-    for (int c = tid; c <= n; c += MG_THREADS) {
-        for (int i = 0; i < m; ++i) {
-            double s = (c < n) ? A[i * D + m + c] : bv[i];
-            for (int k = 0; k < i; ++k) s -= A[i * D + k] * ((c < n) ? A[k * D + m + c] : bv[k]);
-            s /= A[i * D + i];
-            if (c < n) A[i * D + m + c] = s; else bv[i] = s;
-        }
-    }
-    __syncthreads();
     MTS(13);
-    // A' = A_kk - X^T X (symmetrised), b' = b_k - X^T y
+    // A' = the kept block (mirrored to a full symmetric matrix), b' = the kept part of b
     for (int e = tid; e < n * n + n; e += MG_THREADS) {
-        if (e >= n * n) {
-            const int i = e - n * n; double s = bv[m + i];
-            for (int k = 0; k < m; ++k) s -= A[k * D + m + i] * bv[k];
-            yv[i] = s;
-            continue;
-        }
+        if (e >= n * n) { const int i = e - n * n; yv[i] = bv[m + i]; continue; }
         const int i = e / n, j = e - i * n;
-        double s = 0.5 * (A[(m + i) * D + m + j] + A[(m + j) * D + m + i]);
-        for (int k = 0; k < m; ++k) s -= A[k * D + m + i] * A[k * D + m + j];
-        W2[e] = s;
+        W2[e] = i >= j ? A[(m + i) * D + m + j] : A[(m + j) * D + m + i];
     }
     __syncthreads();
     MTS(14);
@@ -353,15 +378,15 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
                 for (int cc = 0; cc <= r; ++cc) am[r][cc] = (real && k0 + cc < n) ? W2[(k0 + r) * n + k0 + cc] : (r == cc ? 1.0 : 0.0);
                 yk[r] = real ? yv[k0 + r] : 0.0;
             }
-            const double d0 = am[0][0], i0 = d0 > 1e-8 ? 1.0 / d0 : 0.0;
+            const double d0 = am[0][0], i0 = d0 > 1e-8 ? mg_rcp(d0) : 0.0;
             const double l10 = am[1][0] * i0, l20 = am[2][0] * i0, l30 = am[3][0] * i0;
-            const double d1 = am[1][1] - l10 * am[1][0], i1 = d1 > 1e-8 ? 1.0 / d1 : 0.0;
+            const double d1 = am[1][1] - l10 * am[1][0], i1 = d1 > 1e-8 ? mg_rcp(d1) : 0.0;
             const double t21 = am[2][1] - l20 * am[1][0], t31 = am[3][1] - l30 * am[1][0];
             const double l21 = t21 * i1, l31 = t31 * i1;
-            const double d2 = am[2][2] - l20 * am[2][0] - l21 * t21, i2 = d2 > 1e-8 ? 1.0 / d2 : 0.0;
+            const double d2 = am[2][2] - l20 * am[2][0] - l21 * t21, i2 = d2 > 1e-8 ? mg_rcp(d2) : 0.0;
             const double t32 = am[3][2] - l30 * am[2][0] - l31 * t21;
             const double l32 = t32 * i2;
-            const double d3 = am[3][3] - l30 * am[3][0] - l31 * t31 - l32 * t32, i3 = d3 > 1e-8 ? 1.0 / d3 : 0.0;
+            const double d3 = am[3][3] - l30 * am[3][0] - l31 * t31 - l32 * t32, i3 = d3 > 1e-8 ? mg_rcp(d3) : 0.0;
             const double y0 = yk[0], y1 = yk[1] - l10 * y0, y2 = yk[2] - l20 * y0 - l21 * y1, y3 = yk[3] - l30 * y0 - l31 * y1 - l32 * y2;
             c0 += y0 * y0 * i0;
             if (k0 + 1 < n) c0 += y1 * y1 * i1;
@@ -384,12 +409,9 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
             yv[i] -= x0 * dblk[10] + x1 * dblk[11] + x2 * dblk[12] + x3 * dblk[13];
         }
         __syncthreads();
-        const int r = n - k0 - 4;
-        for (int e = tid; e < r * r; e += MG_THREADS) {
-            const int ii = e / r, jj = e - ii * r;
-            if (jj > ii) continue;
-            const int i = k0 + 4 + ii, j = k0 + 4 + jj;
-            W2[i * n + j] -= PLc[i] * PPc[j] + PLc[n + i] * PPc[n + j] + PLc[2 * n + i] * PPc[2 * n + j] + PLc[3 * n + i] * PPc[3 * n + j];
+        for (int i = k0 + 4 + (tid >> 6); i < n; i += MG_THREADS / 64) {          // wave = row, lane = column
+            const double x0 = PLc[i], x1 = PLc[n + i], x2 = PLc[2 * n + i], x3 = PLc[3 * n + i];
+            for (int j = k0 + 4 + (tid & 63); j <= i; j += 64) W2[i * n + j] -= x0 * PPc[j] + x1 * PPc[n + j] + x2 * PPc[2 * n + j] + x3 * PPc[3 * n + j];
         }
         __syncthreads();
     }

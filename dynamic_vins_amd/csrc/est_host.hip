@@ -406,11 +406,14 @@ struct dv_estimator {
         for (auto& l : lms) if (l.obs.size() >= 4) { l.depth = 1.0 / invd[++k]; l.solve_flag = l.depth < 0 ? 2 : 1; }
     }
     void reject_outliers() {          // OutliersRejection + RemoveOutlier (vio_util.cpp:381-430)
+        m33 RsT[kWin + 1], ricT[2];          // the transposes, once per frame instead of twice per observation (same values, same products)
+        for (int i = 0; i <= kWin; ++i) RsT[i] = tr(Rs[i]);
+        ricT[0] = tr(ric[0]); ricT[1] = tr(ric[1]);
         erase_if([&](const Lm& l) {
             if (l.obs.size() < 4) return false;
             double err = 0; int cnt = 0; int j = l.start - 1;
             const d3 pw = mul(Rs[l.start], mul(ric[0], l.obs[0].pt * l.depth) + tic[0]) + Ps[l.start];
-            auto rp = [&](int fj, int cam, d3 uv) { const d3 pc = mul(tr(ric[cam]), mul(tr(Rs[fj]), pw - Ps[fj]) - tic[cam]); const double rx = pc.x / pc.z - uv.x, ry = pc.y / pc.z - uv.y; return sqrt(rx * rx + ry * ry); };
+            auto rp = [&](int fj, int cam, d3 uv) { const d3 pc = mul(ricT[cam], mul(RsT[fj], pw - Ps[fj]) - tic[cam]); const double rx = pc.x / pc.z - uv.x, ry = pc.y / pc.z - uv.y; return sqrt(rx * rx + ry * ry); };
             for (auto& o : l.obs) { ++j; if (j != l.start) { err += rp(j, 0, o.pt); cnt++; } if (cfg.stereo && o.stereo) { err += rp(j, 1, o.pt_r); cnt++; } }
             return err / cnt * kFocal > 3;
         });

@@ -107,8 +107,14 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         // factor / prior indices -> values): the seventh wave walks it WHILE the other six stream the landmark packets
         __shared__ double s_dh[36], s_dg[6];
         if (ci == 6) {
+#ifdef BE_RED_TS
+            if (blockIdx.x == 0 && lane == 0) be_red_ts[16] = wall_clock64();
+#endif
             if (lane < 36) s_dh[lane] = red_dense_h(a, rc, imu_out, ci0 + lane / 6, cj0 + lane % 6);
             else if (diag && lane < 42) s_dg[lane - 36] = red_dense_g(a, rc, imu_out, prior_out, ci0 + lane - 36);
+#ifdef BE_RED_TS
+            if (blockIdx.x == 0 && lane == 0) be_red_ts[17] = wall_clock64();
+#endif
         }
         double S[6] = {0, 0, 0, 0, 0, 0}, H[6] = {0, 0, 0, 0, 0, 0}, G = 0, GS = 0;
         const int e_wi = BE_PK_W + fi * 6 + ci, e_wj = BE_PK_W + fj * 6;

@@ -75,6 +75,7 @@ SIGNATURES = {
     "dv_box_enclose_eval": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "dv_box_dims_eval": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "dv_box_orientation_eval": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "dv_inst_proj_eval": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_obj_solve": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "dv_line_solve": (C.c_int, [_ctx, C.c_void_p, C.c_void_p]),
     "dv_est_create": (C.c_int, [_ctx, C.c_void_p]),
@@ -86,6 +87,7 @@ SIGNATURES = {
     "dv_timing_enable": (C.c_int, [_ctx, C.c_int]),
     "dv_timing_reset": (C.c_int, [_ctx]),
     "dv_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "dv_debug_set": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
 }
 
 _lib = None

@@ -172,6 +172,20 @@ def box_enclose_eval(ctx, points, pose_obj):
     return out[:, :3], out[:, 3:].reshape(n, 3, 6)
 
 
+INSTPROJ_DTYPE = np.dtype([("pts_j", "f8", 3), ("pts_i", "f8", 3), ("vel_j", "f8", 2), ("vel_i", "f8", 2), ("td_j", "f8"), ("td_i", "f8"), ("cur_td", "f8"), ("pad_", "f8")])
+assert INSTPROJ_DTYPE.itemsize == 112
+
+
+def inst_proj_eval(ctx, factors, pose_bj, pose_bi, ex_pose, pose_oj, pose_oi, inv_dep_j):
+    """ProjectionInstanceFactor::Evaluate for n blocks -> out[n, 64] = r[2] | five 2x6 pose Jacobians | J_inv_dep[2]"""
+    n = len(factors)
+    f = np.ascontiguousarray(factors, INSTPROJ_DTYPE)
+    a = [np.ascontiguousarray(x, np.float64) for x in (pose_bj, pose_bi, ex_pose, pose_oj, pose_oi, inv_dep_j)]
+    out = np.zeros((n, 64))
+    _chk(ctx, ctx.lib.dv_inst_proj_eval(ctx.h, f.ctypes.data, n, *[x.ctypes.data for x in a], out.ctypes.data))
+    return out
+
+
 def box_dims_eval(ctx, dims, box):
     d, b = np.ascontiguousarray(dims, np.float64), np.ascontiguousarray(box, np.float64)
     out = np.zeros((len(d), 4))

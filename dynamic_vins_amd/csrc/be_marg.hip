@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include "be_kernels.h"
+#include "dev_once.h"
 
 using namespace be;
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
         if (tid == 0) { s_acols[tot] = s_acols[tot + 1] = -1; s_na = tot; }
     }
     MTS(4);
-    const double hinv = 1.0 / s_hg[0], g = s_hg[1];
+    const double hinv = s_hg[0] > 1e-8 ? 1.0 / s_hg[0] : 0.0, g = s_hg[1];      // 1x1 pivot of the landmark's inverse depth, clamped like the reference's pseudo-inverse
     double* out = a.slabs + (size_t)l * (D * D + D);
     for (int i = tid >> 6; i < D; i += LM_THREADS / 64) {             // wave = row, lane = column: no integer division
         const bool ai = s_act[i];
@@ -313,17 +314,20 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
                     for (int cc = 0; cc <= r; ++cc) am[r][cc] = (r < nb) ? A[(k0 + r) * D + k0 + cc] : (r == cc ? 1.0 : 0.0);
                     yk[r] = r < nb ? bv[k0 + r] : 0.0;
                 }
-                const double d0 = am[0][0], i0 = mg_rcp(d0);
+                // pivots <= 1e-8 are skipped (their column drops out: 1/d := 0), the LDL^T counterpart of the reference's eigen-clamped
+                // pseudo-inverse of A_mm (marginalization_factor.cpp:286-289, eps = 1e-8): the result is finite for ANY input and equals the
+                // plain Schur complement whenever A_mm is positive definite (every measured sequence: smallest pivot ~1e4).  misc[1] only reports it.
+                const double d0 = am[0][0], i0 = d0 > 1e-8 ? mg_rcp(d0) : 0.0;
                 const double l10 = am[1][0] * i0, l20 = am[2][0] * i0, l30 = am[3][0] * i0;
-                const double d1 = am[1][1] - l10 * am[1][0], i1 = mg_rcp(d1);
+                const double d1 = am[1][1] - l10 * am[1][0], i1 = d1 > 1e-8 ? mg_rcp(d1) : 0.0;
                 const double t21 = am[2][1] - l20 * am[1][0], t31 = am[3][1] - l30 * am[1][0];
                 const double l21 = t21 * i1, l31 = t31 * i1;
-                const double d2 = am[2][2] - l20 * am[2][0] - l21 * t21, i2 = mg_rcp(d2);
+                const double d2 = am[2][2] - l20 * am[2][0] - l21 * t21, i2 = d2 > 1e-8 ? mg_rcp(d2) : 0.0;
                 const double t32 = am[3][2] - l30 * am[2][0] - l31 * t21;
                 const double l32 = t32 * i2;
-                const double d3 = am[3][3] - l30 * am[3][0] - l31 * t31 - l32 * t32, i3 = mg_rcp(d3);
+                const double d3 = am[3][3] - l30 * am[3][0] - l31 * t31 - l32 * t32, i3 = d3 > 1e-8 ? mg_rcp(d3) : 0.0;
                 const double dd[4] = { d0, d1, d2, d3 };
-                for (int r = 0; r < nb; ++r) { if (dd[r] < misc[0]) misc[0] = dd[r]; if (!(dd[r] > 0)) misc[1] = 1.0; }
+                for (int r = 0; r < nb; ++r) { if (dd[r] < misc[0]) misc[0] = dd[r]; if (!(dd[r] > 1e-8)) misc[1] = 1.0; }
                 const double y0 = yk[0], y1 = yk[1] - l10 * y0, y2 = yk[2] - l20 * y0 - l21 * y1, y3 = yk[3] - l30 * y0 - l31 * y1 - l32 * y2;
                 dbm[0] = l10; dbm[1] = l20; dbm[2] = l30; dbm[3] = l21; dbm[4] = l31; dbm[5] = l32;
                 dbm[6] = i0; dbm[7] = nb > 1 ? i1 : 0.0; dbm[8] = nb > 2 ? i2 : 0.0; dbm[9] = nb > 3 ? i3 : 0.0;      // padded columns contribute nothing
@@ -467,12 +471,11 @@ static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((
 static size_t lm_smem(int D) { return ((size_t)BE_MAX_OBS_FACTORS * 54 + 2 * (size_t)BE_MAX_OBS_FACTORS * D + 2 * D) * sizeof(double); }
 
 int be_launch_marg(const BeMargArgs& a, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return -1;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return -1;
-        attr = true;
-    }
+    static DevOnce once;
+    if (once.run([] {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return 1;
+            return 0; })) return -1;
     const size_t bytes = finish_smem(a.D, a.D - a.m);
     if (bytes > 156 * 1024 || lm_smem(a.D) > 64 * 1024) return -2;
     if (a.nlm > 0) {

@@ -116,6 +116,18 @@ __global__ void box_orientation_kernel(const double* R_cioi, const double* R_bc,
     for (int k = 0; k < 3; ++k) for (int c = 0; c < 3; ++c) { o[21 + k * 6 + c] = 0.0; o[21 + k * 6 + 3 + c] = Jr[k * 3 + c]; }
 }
 
+// out per block (64): see inst_proj_dev
+__global__ void inst_proj_kernel(const dv_inst_proj_factor* f, int n, const double* pbj, const double* pbi, const double* pex, const double* poj, const double* poi,
+                                 const double* lam, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double o[64];
+    inst_proj_dev(reinterpret_cast<const double*>(f + i), pbj + 7 * i, pbi + 7 * i, pex + 7 * i, poj + 7 * i, poi + 7 * i, lam[i], o);
+    double* dst = out + (size_t)i * 64;
+#pragma unroll
+    for (int k = 0; k < 64; ++k) dst[k] = o[k];
+}
+
 // stage host arrays behind each other in one device buffer, run, copy the result back
 struct Stage {
     dv_ctx* ctx; hipStream_t s; uint8_t* base = nullptr; size_t off = 0;
@@ -197,6 +209,22 @@ int dv_box_orientation_eval(dv_ctx* ctx, const double* R_cioi, const double* R_b
     hipLaunchKernelGGL(box_orientation_kernel, dim3((n + 63) / 64), dim3(64), 0, st.s, dc, db, dpb, dpo, n, dout);
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipMemcpyAsync(out, dout, 8 * 39 * (size_t)n, hipMemcpyDeviceToHost, st.s));
+    DV_CHECK(hipStreamSynchronize(st.s));
+    return 0;
+}
+
+int dv_inst_proj_eval(dv_ctx* ctx, const dv_inst_proj_factor* factors, int n, const double* pose_bj, const double* pose_bi, const double* ex_pose,
+                      const double* pose_oj, const double* pose_oi, const double* inv_dep_j, double* out) {
+    OBJ_PROLOGUE("dv_inst_proj_eval", (sizeof(dv_inst_proj_factor) + 8 * (5 * 7 + 1 + 64)) * (size_t)n + 4096)
+    if (!factors || !pose_bj || !pose_bi || !ex_pose || !pose_oj || !pose_oi || !inv_dep_j) DV_FAIL("dv_inst_proj_eval: null argument");
+    const dv_inst_proj_factor* df = st.put(factors, n);
+    const double* d0 = st.put(pose_bj, 7 * (size_t)n); const double* d1 = st.put(pose_bi, 7 * (size_t)n); const double* d2 = st.put(ex_pose, 7 * (size_t)n);
+    const double* d3p = st.put(pose_oj, 7 * (size_t)n); const double* d4 = st.put(pose_oi, 7 * (size_t)n); const double* dl = st.put(inv_dep_j, (size_t)n);
+    double* dout = st.put((const double*)nullptr, 64 * (size_t)n);
+    if (!df || !d0 || !d1 || !d2 || !d3p || !d4 || !dl) DV_FAIL("dv_inst_proj_eval: upload failed");
+    hipLaunchKernelGGL(inst_proj_kernel, dim3((n + 63) / 64), dim3(64), 0, st.s, df, n, d0, d1, d2, d3p, d4, dl, dout);
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipMemcpyAsync(out, dout, 8 * 64 * (size_t)n, hipMemcpyDeviceToHost, st.s));
     DV_CHECK(hipStreamSynchronize(st.s));
     return 0;
 }

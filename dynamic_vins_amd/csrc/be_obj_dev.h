@@ -71,6 +71,50 @@ __device__ __forceinline__ void box_orientation_dev(const m33& Rc, const m33& Rb
 }
 
 
+// ProjectionInstanceFactor (estimator/factor/project_instance_factor.cpp:27-172): a point of a moving object seen in frame j (inverse depth
+// known there) is carried into the object frame with the object's pose at j, back to the world with its pose at i, and reprojected into
+// camera i.  Output (64): r[2] | J wrt body pose j, body pose i, extrinsic, object pose j, object pose i (2x6 each, tangent) | J wrt inv_dep_j (2).
+// Kept as the reference writes it: the inverse-depth Jacobian carries a + sign and the un-compensated pts_j (:166).
+__device__ __forceinline__ void inst_proj_dev(const double* f /* pts_j3 pts_i3 vel_j2 vel_i2 td_j td_i cur_td */, const double* pbj, const double* pbi, const double* pex,
+                                              const double* poj, const double* poi, double lam, double* out) {
+    const double cur_td = f[12];
+    const d3 pj = mk3(f[0], f[1], f[2]), pi = mk3(f[3], f[4], f[5]);
+    const d3 pj_td = pj - mk3(f[6], f[7], 0.0) * (cur_td - f[10]), pi_td = pi - mk3(f[8], f[9], 0.0) * (cur_td - f[11]);
+    const quat qbj = Q4(pbj), qbi = Q4(pbi), qbc = Q4(pex), qoj = Q4(poj), qoi = Q4(poi);
+    const d3 Pbj = P3(pbj), Pbi = P3(pbi), Pbc = P3(pex), Poj = P3(poj), Poi = P3(poi);
+    const d3 cam_j = pj_td / lam;
+    const d3 imu_j = qrot(qbc, cam_j) + Pbc;
+    const d3 w_j = qrot(qbj, imu_j) + Pbj;
+    const d3 obj_j = qrot(qinv(qoj), w_j - Poj);
+    const d3 w_i = qrot(qoi, obj_j) + Poi;
+    const d3 imu_i = qrot(qinv(qbi), w_i - Pbi);
+    const d3 cam_i = qrot(qinv(qbc), imu_i - Pbc);
+    const double dep = cam_i.z, si = 460.0 / 1.5;
+    out[0] = si * (cam_i.x / dep - pi_td.x); out[1] = si * (cam_i.y / dep - pi_td.y);
+    const double red[6] = { si * (1.0 / dep), 0.0, si * (-cam_i.x / (dep * dep)), 0.0, si * (1.0 / dep), si * (-cam_i.y / (dep * dep)) };
+    const m33 Rbj = qR(qbj), Rbi = qR(qbi), Rbit = tr(Rbi), Rbc = qR(qbc), Rcb = tr(Rbc), Roj = qR(qoj), Rojt = tr(Roj), Roi = qR(qoi);
+    const m33 CbBi = mul(Rcb, Rbit);                         // R_cb R_biw
+    const m33 T_oi = mul(CbBi, Roi);                         // ... R_woi
+    const m33 T_oj = mul(T_oi, Rojt);                        // ... R_ojw
+    const m33 T_bj = mul(T_oj, Rbj);                         // ... R_wbj
+    auto store = [&](double* o, const m33& A, const m33& B) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                o[r * 6 + c] = red[r * 3] * A.m[c] + red[r * 3 + 1] * A.m[3 + c] + red[r * 3 + 2] * A.m[6 + c];
+                o[r * 6 + 3 + c] = red[r * 3] * B.m[c] + red[r * 3 + 1] * B.m[3 + c] + red[r * 3 + 2] * B.m[6 + c];
+            }
+    };
+    store(out + 2, T_oj, scale(mul(T_bj, skew(imu_j)), -1.0));
+    store(out + 14, scale(CbBi, -1.0), mul(Rcb, skew(mul(Rbit, w_i - Pbi))));
+    store(out + 26, sub(T_bj, Rcb), add(scale(mul(mul(T_bj, Rbc), skew(cam_j)), -1.0), skew(mul(Rcb, imu_i - Pbc))));
+    store(out + 38, scale(T_oj, -1.0), mul(T_oi, skew(mul(Rojt, w_j - Poj))));
+    store(out + 50, CbBi, scale(mul(T_oi, skew(obj_j)), -1.0));
+    const d3 v = mul(mul(T_bj, Rbc), pj) / (lam * lam);
+    out[62] = red[0] * v.x + red[1] * v.y + red[2] * v.z; out[63] = red[3] * v.x + red[4] * v.y + red[5] * v.z;
+}
+
 // ---- line factor pieces (lineProjectionFactor / LineOrthParameterization) ----
 struct Plk { d3 n, v; };
 

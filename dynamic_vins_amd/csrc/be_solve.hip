@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include "be_kernels.h"
+#include "dev_once.h"
 
 using namespace be;
 
@@ -747,12 +748,11 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
 static size_t solve_smem(int n) { return ((size_t)n * (n + 1) / 2 + 9 * (size_t)n + 72 + 80 + 8 + 1536) * sizeof(double); }
 
 int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return -1;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return -1;
-        attr = true;
-    }
+    static DevOnce once;
+    if (once.run([] {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return 1;
+            return 0; })) return -1;
     const int nbr = (a.dims.nstate + 3) / 4;
     if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL(be_solve_kernel<1>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);
     else hipLaunchKernelGGL(be_solve_kernel<2>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);

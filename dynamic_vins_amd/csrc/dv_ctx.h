@@ -99,6 +99,8 @@ struct BeWork {
     hipEvent_t ev_state = nullptr;    // recorded behind the download of the solved states (the marginalization runs on past it)
     double* prior_c0 = nullptr;       // [2] the prior's constant c0 per buffer, device resident
     int32_t* marg_tab = nullptr; double* marg_scal = nullptr;      // marginalization index tables (inside the upload region) and its 4 result scalars
+    long long marg_clamped = 0;       // marginalizations in which a pivot of A_mm was <= 1e-8 and was skipped (pseudo-inverse)
+    bool debug_short_first_pass = false;      // dv_debug_set
     std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
 };
 

@@ -19,6 +19,7 @@
 //   Candidate sets larger than the LDS capacity are processed in value-ordered chunks.
 //   Its epilogue appends the new corners to the tracker state (ids = global_id_count++).
 #include "dv_internal.h"
+#include "dev_once.h"
 #include <cfloat>
 
 #define TW 64
@@ -347,13 +348,9 @@ void dv_launch_gftt_tile(const GfttTileArgs& a, hipStream_t s) {
 }
 
 int dv_launch_gftt_select(const GfttSelectArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gftt_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)select_smem_bytes());
-        if (e != hipSuccess) return -1;
-        attr_set = true;
-    }
+    static DevOnce once;
+    if (once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gftt_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)select_smem_bytes()) != hipSuccess; })) return -1;
     hipLaunchKernelGGL(gftt_select_kernel, dim3(1), dim3(SEL_THREADS), select_smem_bytes(), s, a);
     return 0;
 }

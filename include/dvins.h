@@ -245,6 +245,18 @@ int dv_box_dims_eval(dv_ctx* ctx, const double* dims /* n x 3 */, const double* 
 int dv_box_orientation_eval(dv_ctx* ctx, const double* R_cioi /* n x 9 */, const double* R_bc /* n x 9 */, const double* pose_body /* n x 7 */,
                             const double* pose_obj /* n x 7 */, int n, double* out);
 
+/* ProjectionInstanceFactor(pts_j, pts_i, velocity_j, velocity_i, td_j, td_i, cur_td) (estimator/factor/project_instance_factor.h:30-60): the
+ * reprojection factor of a point ON a moving object — observed in frame j with inverse depth inv_dep_j, carried through the object's poses at j
+ * and i into camera i.  The reference ships it switched off (every AddResidualBlock in InstanceManager::AddResidualBlockForJointOpt is commented
+ * out, estimator_insts.cpp:1258-1419); it is provided as an operator because BASELINE.json's north_star names it.  112 bytes per record. */
+typedef struct dv_inst_proj_factor { double pts_j[3], pts_i[3], vel_j[2], vel_i[2], td_j, td_i, cur_td, pad_; } dv_inst_proj_factor;
+/* ProjectionInstanceFactor::Evaluate (project_instance_factor.cpp:27-172); parameter blocks per record: body pose j, body pose i, ex_pose[0],
+ * object pose j, object pose i (n x 7 each: p, qx qy qz qw), inv_dep_j (n).
+ * out[n][64] = r[2] | J_body_j | J_body_i | J_ex | J_obj_j | J_obj_i (2x6 each, tangent space, row-major) | J_inv_dep (2).
+ * Bug-for-bug: J_inv_dep has the reference's + sign and un-compensated pts_j (:166). */
+int dv_inst_proj_eval(dv_ctx* ctx, const dv_inst_proj_factor* factors, int n, const double* pose_bj, const double* pose_bi, const double* ex_pose,
+                      const double* pose_oj, const double* pose_oi, const double* inv_dep_j, double* out);
+
 /* ---- the per-frame object solve (the numeric part): replaces ceres::Solve inside
  * InstanceManager::Optimization (estimator/estimator_insts.cpp:772-807) for the problem that
  * AddInstanceParameterBlock / AddResidualBlockForInstOpt build (estimator_insts.cpp:989-1245):
@@ -331,6 +343,10 @@ int dv_est_process_end(dv_ctx* ctx, dv_est_state* out);
 int dv_timing_enable(dv_ctx* ctx, int on);
 int dv_timing_reset(dv_ctx* ctx);
 int dv_timing_get(dv_ctx* ctx, const char* name, double* total_ms, long long* count);
+
+/* debug-only switch for the test-suite (never read from the environment).  key "short_first_pass": the window solve enqueues
+ * max_iters - 2 slots first, so the spare-slot continuation (rare in production: only after a failed linear solve) runs every frame. */
+int dv_debug_set(dv_ctx* ctx, const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,9 @@ void dvo_orth_to_plk(const double* orth4, double* plk6);
 int dvo_line_trimming(const double* plk6, const double* obs4, double* p1, double* p2);
 int dvo_triangulate_line(const double* obs, int nobs, int start_frame, const double* Rs, const double* Ps, const double* ric9, const double* tic3,
                          double* plk6, double* ptw1, double* ptw2);
+/* ProjectionInstanceFactor::Evaluate (estimator/factor/project_instance_factor.cpp:27-172; dead code in the reference, named by north_star).
+ * obs12 = pts_j(3) pts_i(3) vel_j(2) vel_i(2) td_j td_i; par = pose_bj, pose_bi, ex_bc, pose_oj, pose_oi (7 each), inv_dep_j; J = 5 x (2x7) + 2x1 */
+void dvo_inst_proj_eval(const double* obs12, double cur_td, const double* const* par, double* res2, double** J);
 void dvo_box_enclose_eval(const double* pts_w3, const double* dims3, const double* const* par /* pose_obj7 */, double* res3, double** J /* 3x7 */);
 void dvo_box_dims_eval(const double* dims3, const double* const* par /* box3 */, double* res1, double** J /* 1x3 */);
 void dvo_box_orientation_eval(const double* R_cioi9, const double* R_bc9, const double* const* par /* pose_body7, pose_obj7 */, double* res3, double** J /* 3x7, 3x7 */);

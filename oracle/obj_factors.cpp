@@ -247,4 +247,48 @@ int dvo_triangulate_line(const double* obs, int nobs, int start_frame, const dou
     return 1;
 }
 
+
+// ProjectionInstanceFactor::Evaluate (estimator/factor/project_instance_factor.cpp:27-172): reprojection of an object point from
+// frame j into frame i THROUGH the object's two poses.  Dead in the reference (every AddResidualBlock that would use it is commented out,
+// estimator_insts.cpp:1258-1419), restated because north_star names the "dynamic-InstanceFactor residual+Jacobian".
+// obs12 = pts_j(3) pts_i(3) vel_j(2) vel_i(2) td_j td_i ; cur_td ; par = pose_bj, pose_bi, ex_bc, pose_oj, pose_oi (7 each), inv_dep_j (1).
+// J[k] row-major 2x7 (2x1 for the depth).  Bug-for-bug: d r / d inv_dep_j has a PLUS sign and uses pts_j, not pts_j_td (:166).
+void dvo_inst_proj_eval(const double* obs12, double cur_td, const double* const* par, double* res2, double** J) {
+    const V3 pts_j(obs12[0], obs12[1], obs12[2]), pts_i(obs12[3], obs12[4], obs12[5]);
+    const V3 vel_j(obs12[6], obs12[7], 0), vel_i(obs12[8], obs12[9], 0);
+    const double td_j = obs12[10], td_i = obs12[11];
+    const V3 P_wbj = P3(par[0]), P_wbi = P3(par[1]), P_bc = P3(par[2]), P_woj = P3(par[3]), P_woi = P3(par[4]);
+    const Q Q_wbj = Q4(par[0]), Q_wbi = Q4(par[1]), Q_bc = Q4(par[2]), Q_woj = Q4(par[3]), Q_woi = Q4(par[4]);
+    const double inv_dep_j = par[5][0];
+    const V3 pts_i_td = pts_i - vel_i * (cur_td - td_i), pts_j_td = pts_j - vel_j * (cur_td - td_j);
+    const V3 pts_cam_j = pts_j_td / inv_dep_j;
+    const V3 pts_imu_j = Q_bc * pts_cam_j + P_bc;
+    const V3 pts_w_j = Q_wbj * pts_imu_j + P_wbj;
+    const V3 pts_obj_j = Q_woj.inverse() * (pts_w_j - P_woj);
+    const V3 pts_w_i = Q_woi * pts_obj_j + P_woi;
+    const V3 pts_imu_i = Q_wbi.inverse() * (pts_w_i - P_wbi);
+    const V3 pts_cam_i = Q_bc.inverse() * (pts_imu_i - P_bc);
+    const double dep_i = pts_cam_i.z, inv_dep_i = 1.0 / dep_i;
+    const double si = 460.0 / 1.5;                       // sqrt_info = kFocalLength / 1.5 * I (project_instance_factor.h:49)
+    res2[0] = si * (pts_cam_i.x / dep_i - pts_i_td.x); res2[1] = si * (pts_cam_i.y / dep_i - pts_i_td.y);
+    if (!J) return;
+    const M3 R_wbj = Q_wbj.R(), R_wbi = Q_wbi.R(), R_biw = R_wbi.t(), R_bc = Q_bc.R(), R_cb = R_bc.t(), R_woj = Q_woj.R(), R_ojw = R_woj.t(), R_woi = Q_woi.R();
+    double red[2][3] = { { si * inv_dep_i, 0, si * (-pts_cam_i.x / (dep_i * dep_i)) }, { 0, si * inv_dep_i, si * (-pts_cam_i.y / (dep_i * dep_i)) } };
+    auto put = [&](double* out, const M3& A, const M3& B) {           // out (2x7) = reduce * [A | B], last column zero
+        for (int r = 0; r < 2; ++r) {
+            for (int c = 0; c < 3; ++c) { double a = 0, b = 0; for (int k = 0; k < 3; ++k) { a += red[r][k] * A(k, c); b += red[r][k] * B(k, c); } out[r * 7 + c] = a; out[r * 7 + 3 + c] = b; }
+            out[r * 7 + 6] = 0;
+        }
+    };
+    if (J[0]) { const M3 temp = R_cb * R_biw * R_woi * R_ojw; put(J[0], temp, -(temp * R_wbj * skew(pts_imu_j))); }
+    if (J[1]) put(J[1], -(R_cb * R_biw), R_cb * skew(R_biw * (pts_w_i - P_wbi)));
+    if (J[2]) { const M3 temp = R_cb * R_biw * R_woi * R_ojw * R_wbj; put(J[2], temp - R_cb, -(temp * R_bc * skew(pts_cam_j)) + skew(R_cb * (pts_imu_i - P_bc))); }
+    if (J[3]) { const M3 temp = R_cb * R_biw * R_woi; put(J[3], -(temp * R_ojw), temp * skew(R_ojw * (pts_w_j - P_woj))); }
+    if (J[4]) put(J[4], R_cb * R_biw, -(R_cb * R_biw * R_woi * skew(pts_obj_j)));
+    if (J[5]) {
+        const V3 v = (R_cb * R_biw * R_woi * R_ojw * R_wbj * R_bc * pts_j) / (inv_dep_j * inv_dep_j);      // sic: + sign, pts_j
+        for (int r = 0; r < 2; ++r) J[5][r] = red[r][0] * v.x + red[r][1] * v.y + red[r][2] * v.z;
+    }
+}
+
 }  // extern "C"

@@ -1,0 +1,74 @@
+"""north_star's literal acceptance test (`-m gpu`): IMAGES -> tracker -> estimator on the HIP side (Pipeline: front end of
+frame k+1 overlapped with the BA of frame k, everything through the C ABI) against the CPU oracle's tracker + estimator on
+the same rendered frames and the same IMU stream.
+
+Bars: the feature rows handed from the front end to the back end are BIT-identical on every frame (ids, track counts, fp64
+bit patterns); frame / flag / landmark / iteration counts identical; window positions within 1e-5 m on every frame; ATE RMSE of
+the HIP trajectory against the oracle trajectory < 1e-3 m (BASELINE.json: "within 1e-3 m ATE RMSE").
+
+Workloads = the three of SURVEY 8(d): the bench workload (1280x720, max_cnt 250, min_dist 25, 10 iterations, VIO),
+EuRoC-like (752x480, 150 / 30, 8 iterations, VIO) and KITTI-like (1242x375, 250 / 25, 10 iterations, vision only).
+"""
+import numpy as np
+import pytest
+
+from dynamic_vins_amd import sim
+
+pytestmark = pytest.mark.gpu
+
+
+def run_workload(oracle, w, h, max_cnt, min_dist, iters, use_imu, frames, rate=20.0):
+    from dynamic_vins_amd.pipeline import Pipeline, SyntheticSequence
+    cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    seq = SyntheticSequence(w, h, cam, frames, rate=rate)
+    pipe = Pipeline(seq, max_cnt=max_cnt, min_dist=min_dist, max_iters=iters, use_imu=use_imu)
+    camt = sim.cam_tuple(cam)
+    trk = oracle.tracker(w, h, max_cnt, min_dist, 1, 1, camt, camt)
+    est = oracle.estimator(use_imu=use_imu, stereo=1, max_iters=iters, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], **seq.noise)
+    k_imu = 0
+    dev_p, ref_p = [], []
+    max_dp = 0.0
+    for k in range(frames):
+        t = seq.times[k]
+        sd = pipe.step()
+        while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
+            est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu])
+            k_imu += 1
+        left, right = seq.host_frame(k)
+        rows_o = trk.track_image(left, right, t)
+        rows_d = pipe.rows
+        # front end -> back end hand-over: bit-identical
+        assert len(rows_d) == len(rows_o), f"frame {k}: {len(rows_d)} rows vs {len(rows_o)}"
+        assert np.array_equal(rows_d["id"], rows_o["id"]) and np.array_equal(rows_d["track_cnt"], rows_o["track_cnt"]), f"frame {k}"
+        assert np.array_equal(rows_d["has_right"], rows_o["has_right"]), f"frame {k}"
+        assert np.array_equal(rows_d["left"].view(np.uint64), rows_o["left"].view(np.uint64)), f"frame {k}"
+        assert np.array_equal(rows_d["right"].view(np.uint64), rows_o["right"].view(np.uint64)), f"frame {k}"
+        rc, so = est.process(rows_o, t)
+        assert rc == 0
+        assert (sd.frame, sd.nonlinear, sd.margin_old, sd.n_landmarks, sd.n_long) == (so.frame, so.nonlinear, so.margin_old, so.n_landmarks, so.n_long), f"frame {k}"
+        assert sd.iterations == so.iterations, f"frame {k}: iterations {sd.iterations} vs {so.iterations}"
+        Wd, Wo = pipe.est.window(), est.window()
+        max_dp = max(max_dp, np.abs(Wd[:, :3] - Wo[:, :3]).max())
+        if sd.nonlinear:
+            dev_p.append(Wd[10, :3].copy()); ref_p.append(Wo[10, :3].copy())
+    ate_gt = pipe.ate()
+    pipe.ctx.close()
+    return max_dp, np.array(dev_p), np.array(ref_p), ate_gt
+
+
+@pytest.mark.parametrize("w,h,max_cnt,min_dist,iters,use_imu,frames", [
+    (1280, 720, 250, 25, 10, 1, 44),     # bench.py workload (ZED, config 5's sensor)
+    (752, 480, 150, 30, 8, 1, 40),       # EuRoC-like (configs 1, 2)
+    (1242, 375, 250, 25, 10, 0, 36),     # KITTI-like, vision only (config 4)
+])
+def test_images_to_trajectory_matches_oracle(oracle, w, h, max_cnt, min_dist, iters, use_imu, frames):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    max_dp, dev, ref, ate_gt = run_workload(oracle, w, h, max_cnt, min_dist, iters, use_imu, frames)
+    assert len(dev) >= frames - 12
+    assert max_dp < 1e-5, max_dp                                  # window positions, every frame
+    ate_dev_vs_oracle = sim.align_ate(dev, ref)[0]
+    assert ate_dev_vs_oracle < 1e-3, ate_dev_vs_oracle             # north_star bar; in practice ~1e-7
+    assert np.abs(dev - ref).max() < 1e-5
+    assert ate_gt < 0.05

@@ -84,6 +84,9 @@ SIGNATURES = {
     "dv_est_process": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "dv_est_process_begin": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double]),
     "dv_est_process_end": (C.c_int, [_ctx, C.c_void_p]),
+    "dv_est_process_dynamic": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dv_est_process_dynamic_begin": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dv_est_get_instances": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "dv_timing_enable": (C.c_int, [_ctx, C.c_int]),
     "dv_timing_reset": (C.c_int, [_ctx]),
     "dv_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

@@ -291,7 +291,8 @@ class dv_est_config(C.Structure):
     _fields_ = [("use_imu", C.c_int32), ("stereo", C.c_int32), ("plane_constraint", C.c_int32), ("max_iters", C.c_int32),
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),
                 ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
-                ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2)]
+                ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2),
+                ("dynamic", C.c_int32), ("use_det3d", C.c_int32), ("instance_init_min_num", C.c_int32), ("pad_", C.c_int32), ("static_inst_threshold", C.c_double)]
 
 
 class dv_est_state(C.Structure):
@@ -305,12 +306,13 @@ class Estimator:
     InputIMU / ProcessMeasurements keep the reference's names; camelCase aliases provided."""
 
     def __init__(self, ctx, use_imu=1, stereo=1, plane_constraint=0, max_iters=8, keyframe_parallax=10.0, init_depth=5.0, g_norm=9.81, td=0.0,
-                 acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None):
+                 acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None, dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0):
         self.ctx = ctx
         c = dv_est_config()
         c.use_imu, c.stereo, c.plane_constraint, c.max_iters = use_imu, stereo, plane_constraint, max_iters
         c.keyframe_parallax, c.init_depth, c.g_norm, c.td = keyframe_parallax, init_depth, g_norm, td
         c.acc_n, c.gyr_n, c.acc_w, c.gyr_w = acc_n, gyr_n, acc_w, gyr_w
+        c.dynamic, c.use_det3d, c.instance_init_min_num, c.static_inst_threshold = dynamic, use_det3d, instance_init_min_num, static_inst_threshold
         for k in range(2):
             for i in range(9):
                 c.ric[k][i] = float(np.asarray(ric[k]).reshape(-1)[i])
@@ -343,6 +345,31 @@ class Estimator:
     def ProcessMeasurementsEnd(self):
         self._check(self.ctx.lib.dv_est_process_end(self.ctx.h, C.byref(self.state)))
         return self.state
+
+    # ---- dynamic mode (cfg::slam == kDynamic): frame.instances travel with the background features ----
+    def _dyn_args(self, insts, inst_feats, points):
+        from .dynsim import INSTOBS_DTYPE
+        self._insts = np.ascontiguousarray(insts, INSTOBS_DTYPE)
+        self._ifeats = np.ascontiguousarray(inst_feats)
+        self._pts = np.ascontiguousarray(points, np.float64)
+        return (self._insts.ctypes.data if len(self._insts) else None, len(self._insts), self._ifeats.ctypes.data if len(self._ifeats) else None,
+                self._pts.ctypes.data if len(self._pts) else None)
+
+    def ProcessMeasurementsDynamic(self, rows, t, insts, inst_feats, points):
+        rows = np.ascontiguousarray(rows)
+        rc = self._check(self.ctx.lib.dv_est_process_dynamic(self.ctx.h, rows.ctypes.data, len(rows), float(t), *self._dyn_args(insts, inst_feats, points), C.byref(self.state)))
+        return rc, self.state
+
+    def ProcessMeasurementsDynamicBegin(self, rows, t, insts, inst_feats, points):
+        self._rows = np.ascontiguousarray(rows)
+        return self._check(self.ctx.lib.dv_est_process_dynamic_begin(self.ctx.h, self._rows.ctypes.data, len(self._rows), float(t), *self._dyn_args(insts, inst_feats, points)))
+
+    def instances(self, cap=64):
+        """Estimator::im.instances (ascending id) -> (INSTSTATE_DTYPE array, [iterations, termination, initial_cost, final_cost] of the last object solve)"""
+        from .dynsim import INSTSTATE_DTYPE
+        out = np.zeros(cap, INSTSTATE_DTYPE); n = C.c_int(0); summ = np.zeros(4)
+        self._check(self.ctx.lib.dv_est_get_instances(self.ctx.h, out.ctypes.data, cap, C.byref(n), summ.ctypes.data))
+        return out[: n.value].copy(), summ
 
     def ClearState(self):
         self._check(self.ctx.lib.dv_est_reset(self.ctx.h))

@@ -239,6 +239,8 @@ static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
     BeState* hx = (BeState*)(hp + w.dl_off); BeCtl* hctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState));
     DV_CHECK(hipMemcpyAsync(hx, pd.fused_present ? w.cand : w.x, pd.state_bytes, hipMemcpyDeviceToHost, s));      // estimator path: the gauge-fixed copy
     DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
+    if (pd.fused_present && pd.want_raw_pose)          // dynamic mode: body.para_pose as ceres leaves it (before Double2vector's gauge fix), 616 bytes
+        DV_CHECK(hipMemcpyAsync(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256, w.x->pose, sizeof(double) * 7 * BE_NF, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipEventRecord(w.ev_state, s));
     if (pd.fused_present && pd.do_marg && !pd.pl.empty) {
         if (marg_enqueue(ctx, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], w.marg_scal, w.prior_c0 + pd.nxt, s)) return -1;
@@ -364,6 +366,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     // invalid; be_solve_fused_end checks the downloaded control block and, in that rare case, runs the spare slots and the
     // (idempotent) tail again.
     pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
+    pd.want_raw_pose = fused && fused->want_raw_pose;
     if (fused) { std::memcpy(pd.gauge_R0, fused->R0, sizeof(pd.gauge_R0)); std::memcpy(pd.gauge_ypr0, fused->ypr0, sizeof(pd.gauge_ypr0)); std::memcpy(pd.gauge_P0, fused->P0, sizeof(pd.gauge_P0)); }
     pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = 1 - w.prior_cur;
     if (eval_only) {        // dv_ba_eval: one evaluation + assembly of the reduced camera system at the given states (mu = 0)
@@ -429,6 +432,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
         summary->iterations = hctl->iter; summary->successful = hctl->successful; summary->termination = hctl->done ? hctl->termination : 0;
         summary->slots = hctl->slots; summary->initial_cost = hctl->initial_cost; summary->final_cost = hctl->x_cost;
     }
+    if (fused && pd.want_raw_pose) std::memcpy(fused->raw_pose, hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256, sizeof(fused->raw_pose));
     if (pd.do_marg) {
         std::memset(fused->diag, 0, sizeof(fused->diag));
         if (pl.empty) { std::memset(&fused->new_prior, 0, sizeof(fused->new_prior)); w.prior_resident = false; }

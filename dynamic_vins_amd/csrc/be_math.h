@@ -89,6 +89,38 @@ BE_HD quat dq_half(d3 theta) { return mkq(1.0, theta.x / 2.0, theta.y / 2.0, the
 BE_HD d3 P3(const double* p) { return mk3(p[0], p[1], p[2]); }
 BE_HD quat Q4(const double* p) { return mkq(p[6], p[3], p[4], p[5]); }        // pose block [p, qx qy qz qw]
 
+// Sophus::SO3d(R).log() (un-vendored; so3.hpp logAndTheta): quaternion log with the small-angle series
+BE_HD d3 so3_log(const m33& R) {
+    quat q = qnormalized(qfromR(R));
+    const double sq = q.x * q.x + q.y * q.y + q.z * q.z, w = q.w;
+    double two_atan;
+    if (sq < 1e-20) two_atan = 2.0 / w - 2.0 / 3.0 * sq / (w * w * w);
+    else {
+        const double nq = sqrt(sq);
+        if (fabs(w) < 1e-10) two_atan = (w > 0 ? M_PI : -M_PI) / nq;
+        else two_atan = 2.0 * atan(nq / w) / nq;
+    }
+    return mk3(q.x, q.y, q.z) * two_atan;
+}
+// Sophus::SO3d::exp(omega).matrix() (so3.hpp expAndTheta): quaternion (cos(theta/2), sin(theta/2)/theta omega), Taylor series below 1e-10
+BE_HD m33 so3_exp(d3 w) {
+    const double th2 = dot(w, w);
+    double imag, real;
+    if (th2 < 1e-20) { const double th4 = th2 * th2; imag = 0.5 - (1.0 / 48.0) * th2 + (1.0 / 3840.0) * th4; real = 1.0 - (1.0 / 8.0) * th2 + (1.0 / 384.0) * th4; }
+    else { const double th = sqrt(th2), half = 0.5 * th; imag = sin(half) / th; real = cos(half); }
+    return qR(mkq(real, imag * w.x, imag * w.y, imag * w.z));
+}
+// Eigen::Matrix3d::inverse(): cofactors over the determinant
+BE_HD m33 inv3(const m33& a) {
+    const double* J = a.m; m33 r;
+    const double c00 = J[4] * J[8] - J[5] * J[7], c01 = J[5] * J[6] - J[3] * J[8], c02 = J[3] * J[7] - J[4] * J[6];
+    const double det = J[0] * c00 + J[1] * c01 + J[2] * c02, id = 1.0 / det;
+    r.m[0] = c00 * id; r.m[1] = (J[2] * J[7] - J[1] * J[8]) * id; r.m[2] = (J[1] * J[5] - J[2] * J[4]) * id;
+    r.m[3] = c01 * id; r.m[4] = (J[0] * J[8] - J[2] * J[6]) * id; r.m[5] = (J[2] * J[3] - J[0] * J[5]) * id;
+    r.m[6] = c02 * id; r.m[7] = (J[1] * J[6] - J[0] * J[7]) * id; r.m[8] = (J[0] * J[4] - J[1] * J[3]) * id;
+    return r;
+}
+
 // x (+) delta for a pose block: p += dp (plane constraint drops z or y), q = normalise(q * [1, dth/2])
 BE_HD void pose_plus(const double* x, const double* d, int plane_kind, double* out) {
     double dx = d[0], dy = d[1], dz = d[2];

@@ -33,19 +33,6 @@ __device__ __forceinline__ void box_dims_dev(d3 box, d3 dims, double& r, double 
     r = err * err / 100.0; J[0] = 2 * d.x; J[1] = 2 * d.y; J[2] = 2 * d.z;
 }
 
-__device__ __forceinline__ d3 so3_log(const m33& R) {        // Sophus::SO3d(R).log(): quaternion log with the small-angle series
-    quat q = qnormalized(qfromR(R));
-    const double sq = q.x * q.x + q.y * q.y + q.z * q.z, w = q.w;
-    double two_atan;
-    if (sq < 1e-20) two_atan = 2.0 / w - 2.0 / 3.0 * sq / (w * w * w);
-    else {
-        const double nq = sqrt(sq);
-        if (fabs(w) < 1e-10) two_atan = (w > 0 ? M_PI : -M_PI) / nq;
-        else two_atan = 2.0 * atan(nq / w) / nq;
-    }
-    return mk3(q.x, q.y, q.z) * two_atan;
-}
-
 // r = Log(R_oiw R_wbi R_bc R_cioi); Jr (3x3) = d r / d theta_obj = -J_r(theta)^-1 R^T with the reference's own J_r
 __device__ __forceinline__ void box_orientation_dev(const m33& Rc, const m33& Rb, quat q_body, quat q_obj, double r[3], double Jr_out[9]) {
     const m33 Rwbi = qR(q_body), Rwoi = qR(q_obj);

@@ -163,7 +163,8 @@ struct ObjProb {
 }  // namespace
 
 
-extern "C" int dv_obj_solve(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary) {
+// internal form: the estimator's dynamic branch runs the object solve on its own stream + scratch buffer, concurrently with the window solve
+int be_obj_solve_on(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, hipStream_t s, DevBuf& scratch) {
     if (!ctx) return -1;
     if (!P || !summary) DV_FAIL("dv_obj_solve: null argument");
     if (P->n_obj <= 0 || P->n_boxes < 0 || P->n_points < 0 || P->max_iters < 0 || !P->state || !P->dims || !P->body_pose) DV_FAIL("dv_obj_solve: bad problem");
@@ -214,9 +215,8 @@ extern "C" int dv_obj_solve(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summa
     double xc = 0;
     for (int f = 0; f < OS_NF; ++f) if (frame_has_box[f]) for (int k = 0; k < 7; ++k) xc += P->body_pose[7 * f + k] * P->body_pose[7 * f + k];
 
-    if (ctx->s1.ensure(off) != hipSuccess) DV_FAIL("dv_obj_solve: out of device memory");
-    uint8_t* base = (uint8_t*)ctx->s1.p;
-    hipStream_t s = ctx->be_stream;
+    if (scratch.ensure(off) != hipSuccess) DV_FAIL("dv_obj_solve: out of device memory");
+    uint8_t* base = (uint8_t*)scratch.p;
     DV_CHECK(hipMemcpyAsync(base, host.data(), up_bytes, hipMemcpyHostToDevice, s));
     DV_CHECK(hipMemcpyAsync(base + o_x1, base + o_x0, 8 * 7 * (size_t)V, hipMemcpyDeviceToDevice, s));
     DV_CHECK(hipMemsetAsync(base + o_H0, 0, o_out - o_H0, s));
@@ -243,4 +243,9 @@ extern "C" int dv_obj_solve(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summa
     summary->iterations = (int)hout[0]; summary->successful = (int)hout[1]; summary->termination = (int)hout[2]; summary->slots = 0;
     summary->initial_cost = hout[3]; summary->final_cost = hout[4];
     return 0;
+}
+
+extern "C" int dv_obj_solve(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary) {
+    if (!ctx) return -1;
+    return be_obj_solve_on(ctx, P, summary, ctx->be_stream, ctx->s1);
 }

@@ -74,6 +74,7 @@ struct MargPlan {
 };
 
 struct BePending {        // a solve that has been enqueued and not yet collected (be_solve_fused_begin / _end)
+    bool want_raw_pose = false;
     bool active = false, trivial = false, do_marg = false, fused_present = false, marg_in_flight = false, marg_check_due = false; int scal_slot = 0, check_slot = 0; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
     BeEvalArgs ea; BeSolveArgs sa; int max_iters = 0, nframes = 0, use_imu = 0, nlm = 0; double g_norm = 0, gauge_R0[9], gauge_ypr0[3], gauge_P0[3];
     std::chrono::steady_clock::time_point t_begin, t_up, t_enq;
@@ -113,11 +114,15 @@ struct BeFused {
     double R0[9], ypr0[3], P0[3];             // Rs[0], R2ypr(Rs[0]), Ps[0] before the solve (gauge reference)
     dv_ba_prior new_prior;                    // out (marg_mode >= 0): header of the new prior (valid may be 0)
     double diag[4] = { 0, 0, 0, 0 };          // out: c0, smallest pivot, failure flag, rank
+    bool want_raw_pose = false;               // in
+    double raw_pose[77];                      // out: the solver's pose blocks BEFORE the yaw-gauge fix (what body.para_pose holds after ceres::Solve)
 };
 int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);
 void* be_staging_factors(dv_ctx* ctx, int* cap);      // where the next solve's upload reads its factor table (pinned); nullptr if the workspace cannot be set up
 int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused);       // upload + enqueue everything, returns immediately
 int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);      // sync + collect
+struct dv_obj_problem;
+int be_obj_solve_on(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, hipStream_t s, DevBuf& scratch);
 struct dv_estimator;
 void dv_est_destroy_internal(dv_estimator* e);
 
@@ -139,6 +144,7 @@ struct dv_ctx {
     bool timing = false, kernel_timing = false, host_timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
     // back end
     hipStream_t be_stream = nullptr; BeWork be;
+    hipStream_t obj_stream = nullptr; DevBuf obj_buf;      // dynamic mode: the object solve runs beside the window solve
     dv_estimator* est = nullptr;
 };
 

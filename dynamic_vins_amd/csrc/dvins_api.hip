@@ -145,6 +145,7 @@ dv_ctx* dv_create(const dv_config* cfg) {
     if ((e = hipSetDevice(cfg->device)) != hipSuccess) return fail("hipSetDevice", e);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&ctx->be_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+    if ((e = hipStreamCreateWithFlags(&ctx->obj_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     // tracker state: one block, struct of arrays
     const size_t N = DV_MAX_FEATS;
@@ -180,6 +181,8 @@ void dv_destroy(dv_ctx* ctx) {
     if (ctx->est) dv_est_destroy_internal(ctx->est);
     ctx->be.block.release(); ctx->be.marg_buf.release();
     if (ctx->be.pinned) (void)hipHostFree(ctx->be.pinned);
+    ctx->obj_buf.release();
+    if (ctx->obj_stream) (void)hipStreamDestroy(ctx->obj_stream);
     if (ctx->be_stream) (void)hipStreamDestroy(ctx->be_stream);
     if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
     if (ctx->done) (void)hipEventDestroy(ctx->done);

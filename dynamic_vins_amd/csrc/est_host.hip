@@ -17,6 +17,7 @@
 #include <unordered_map>
 #include "dv_ctx.h"
 #include "be_math.h"
+#include "inst_host.h"
 
 using namespace be;
 
@@ -135,6 +136,10 @@ struct dv_estimator {
     dv_ba_prior prior{}; const double* prior_dev_A = nullptr; const double* prior_dev_b = nullptr;      // header on the host, A' / b' device-resident
     m33 back_R0; d3 back_P0;
     dv_ba_summary last{};
+    // dynamic mode (cfg.dynamic): Estimator::im + what body.para_pose holds when InstanceManager::Optimization reads it (estimator_insts.cpp:1043-1045):
+    // the values the PREVIOUS frame's Optimization left there — ceres' raw output, or the gauge-fixed states where SetMarginalizationInfo called
+    // Vector2double again (estimator.cpp:409,562)
+    dvi::InstMgr im; double para_pose_ref[kWin + 1][7]; dv_ba_summary obj_last{}; bool dyn_frame = false;
     // flat problem buffers
     std::vector<dv_ba_factor> fac; std::vector<dv_ba_lm> lmt; std::vector<dv_ba_imu> imu; std::vector<double> invd;
     double pose[kWin + 1][7], sb[kWin + 1][9], ex[2][7], tdv[1];
@@ -147,7 +152,11 @@ struct dv_estimator {
         prev_time = -1; cur_time = 0; first_imu = false; init_pose = false; frame = 0; nonlinear = false; acc_0 = gyr_0 = mk3(0, 0, 0);
         for (int k = 0; k < 2; ++k) { for (int i = 0; i < 9; ++i) ric[k].m[i] = cfg.ric[k][i]; tic[k] = mk3(cfg.tic[k][0], cfg.tic[k][1], cfg.tic[k][2]); }
         td = cfg.td; g = mk3(0, 0, cfg.g_norm);
+        im.clear(); im.cfg.use_det3d = cfg.use_det3d; im.cfg.init_min_num = cfg.instance_init_min_num; im.cfg.static_threshold = cfg.static_inst_threshold;
+        im.cfg.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; im.cfg.max_iters = cfg.max_iters;
+        std::memset(para_pose_ref, 0, sizeof(para_pose_ref)); obj_last = dv_ba_summary{}; dyn_frame = false;
     }
+    dvi::BodyView body_view() const { return dvi::BodyView{ Rs, Ps, ric, tic, headers, td, frame }; }
     double noise4[4];
     const double* noise() { noise4[0] = cfg.acc_n; noise4[1] = cfg.gyr_n; noise4[2] = cfg.acc_w; noise4[3] = cfg.gyr_w; return noise4; }
 
@@ -372,7 +381,7 @@ struct dv_estimator {
           // gauge reference: yaw and position of frame 0 before the solve (Double2vector, estimator.cpp:1111-1128)
           const d3 y0 = r2ypr(Rs[0]);
           std::memcpy(fu.R0, Rs[0].m, sizeof(fu.R0)); fu.ypr0[0] = y0.x; fu.ypr0[1] = y0.y; fu.ypr0[2] = y0.z; fu.P0[0] = Ps[0].x; fu.P0[1] = Ps[0].y; fu.P0[2] = Ps[0].z;
-          fu.marg_mode = -1;
+          fu.marg_mode = -1; fu.want_raw_pose = cfg.dynamic != 0;
           if (frame == kWin) {
               if (margin_old) fu.marg_mode = 0;
               else {
@@ -389,6 +398,12 @@ struct dv_estimator {
         { HostScope h(ctx, "h_solve_wait"); if (be_solve_fused_end(ctx, &P, &last, &fu)) return -1; }
         { HostScope h(ctx, "h_post"); arrays_to_states(); }
         if (fu.marg_mode >= 0) prior = fu.new_prior;
+        if (cfg.dynamic) {
+            if (fu.marg_mode >= 0) {          // SetMarginalizationInfo re-ran Vector2double: para_pose = the gauge-fixed window
+                for (int i = 0; i <= kWin; ++i) { const quat q = qfromR(Rs[i]); const double p[7] = { Ps[i].x, Ps[i].y, Ps[i].z, q.x, q.y, q.z, q.w }; std::memcpy(para_pose_ref[i], p, sizeof(p)); }
+            } else if (ctx->be.pend->trivial) std::memcpy(para_pose_ref, pose, sizeof(para_pose_ref));
+            else std::memcpy(para_pose_ref, fu.raw_pose, sizeof(para_pose_ref));
+        }
         return 0;
     }
     int optimization(dv_ctx* ctx) { if (optimization_begin(ctx)) return -1; return optimization_end(ctx); }
@@ -490,27 +505,56 @@ struct dv_estimator {
         if (frame < kWin) { frame++; const int p = frame - 1; Ps[frame] = Ps[p]; Vs[frame] = Vs[p]; Rs[frame] = Rs[p]; Bas[frame] = Bas[p]; Bgs[frame] = Bgs[p]; }
         return 0;
     }
-    int process_image_begin(dv_ctx* ctx, const dv_feat* feats, int n, double header) {      // ProcessImage (estimator.cpp:1516-1696), up to and including the enqueue of the window solve
+    // the object branch of ProcessImage between TriangulatePoints and Optimization (estimator.cpp:1562-1622).  It neither reads what the window
+    // solve writes nor writes what it reads (the joint factors are dead code), so it runs on the host + a third stream while the window
+    // solve enqueued just before is in flight on the BA stream.
+    int dynamic_branch(dv_ctx* ctx, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {
+        HostScope h(ctx, "h_dynamic");
+        const dvi::BodyView B = body_view();
+        im.push_back(frame, B, insts, n_insts, inst_feats, points);
+        im.propagate_pose(B);
+        im.triangulate(B);
+        im.initial_instance(B);
+        im.initial_velocity(B);
+        im.set_dynamic_or_static(B);
+        dv_obj_problem OP;
+        bool solved = false;
+        obj_last = dv_ba_summary{};
+        if (im.build_problem(OP, &para_pose_ref[0][0], ric[0]) && (OP.n_boxes > 0 || OP.n_points > 0)) {
+            if (be_obj_solve_on(ctx, &OP, &obj_last, ctx->obj_stream, ctx->obj_buf)) return -1;
+            solved = true;
+        }
+        im.read_back(solved);
+        im.outliers_rejection(B);
+        return 0;
+    }
+    int process_image_begin(dv_ctx* ctx, const dv_feat* feats, int n, double header, const dv_inst_obs* insts = nullptr, int n_insts = 0, const dv_feat* inst_feats = nullptr,
+                            const double* points = nullptr) {      // ProcessImage (estimator.cpp:1516-1696), up to and including the enqueue of the window solve
         { HostScope h(ctx, "h_add_features"); margin_old = add_features(frame, feats, n); }
         headers[frame] = header;
         frame_pre.push_back(std::shared_ptr<Preint>(tmp_pre.release()));
         if (frame_pre.size() > (size_t)kWin + 1 && nonlinear) frame_pre.erase(frame_pre.begin());
         tmp_pre = std::make_unique<Preint>(acc_0, gyr_0, Bas[frame], Bgs[frame], noise());
-        in_flight = false;
+        in_flight = false; dyn_frame = false;
         if (!nonlinear) return init_estimator(ctx);      // initialisation: synchronous
         if (!cfg.use_imu) pnp_frame(frame);
         { HostScope h(ctx, "h_triangulate"); triangulate(); }
         if (optimization_begin(ctx)) return -1;
         in_flight = true;
+        dyn_frame = cfg.dynamic != 0;
+        if (dyn_frame && dynamic_branch(ctx, insts, n_insts, inst_feats, points)) return -1;
         return 0;
     }
     int process_image_end(dv_ctx* ctx) {
         if (!in_flight) return 0;
         in_flight = false;
         if (optimization_end(ctx)) return -1;
+        if (dyn_frame) im.touch_in_main_optimization();      // AddInstanceParameterBlock / im.GetOptimizationParameters inside Estimator::Optimization
         { HostScope h(ctx, "h_reject"); reject_outliers(); }
-        { HostScope h(ctx, "h_slide"); slide_window();
-          erase_if([](const Lm& l) { return l.solve_flag == 2; }); }      // RemoveFailures
+        if (dyn_frame) { const dvi::BodyView B = body_view(); im.manage_triangulate_point(B); im.slide_window(B, margin_old); }      // estimator.cpp:1653-1658, BEFORE the body window slides
+        { HostScope h(ctx, "h_slide"); slide_window(); }
+        if (dyn_frame) im.finish_frame(body_view());                                                                                 // estimator.cpp:1663-1676, on the slid window
+        erase_if([](const Lm& l) { return l.solve_flag == 2; });      // RemoveFailures
         return 0;
     }
     bool in_flight = false, begun = false;
@@ -532,15 +576,49 @@ int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr
     ctx->est->imu_buf.push_back({ t, { mk3(acc[0], acc[1], acc[2]), mk3(gyr[0], gyr[1], gyr[2]) } });
     return 0;
 }
-int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t) {
+static int est_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {
     if (!ctx) return -1;
     if (!ctx->est) DV_FAIL("dv_est_process: call dv_est_create first");
     dv_estimator& E = *ctx->est;
     if (E.begun) DV_FAIL("dv_est_process_begin: previous frame not collected (dv_est_process_end)");
     E.cur_time = t + E.td;
     { HostScope h(ctx, "h_imu"); if (E.cfg.use_imu && !E.add_imu_until(E.cur_time)) return 1; }       // "wait for imu" (estimator.cpp:1801-1805)
-    { HostScope h(ctx, "h_process_begin"); if (E.process_image_begin(ctx, feats, n, t)) return -1; }
+    { HostScope h(ctx, "h_process_begin"); if (E.process_image_begin(ctx, feats, n, t, insts, n_insts, inst_feats, points)) return -1; }
     E.begun = true;
+    return 0;
+}
+int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t) { return est_begin(ctx, feats, n, t, nullptr, 0, nullptr, nullptr); }
+int dv_est_process_dynamic_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {
+    if (!ctx) return -1;
+    if (ctx->est && !ctx->est->cfg.dynamic) DV_FAIL("dv_est_process_dynamic: the estimator was created with dynamic = 0");
+    if (n_insts < 0 || (n_insts > 0 && !insts)) DV_FAIL("dv_est_process_dynamic: bad instance list");
+    for (int i = 0; i < n_insts; ++i) {
+        if (insts[i].n_feats < 0 || insts[i].n_points < 0 || (insts[i].n_feats > 0 && !inst_feats) || (insts[i].n_points > 0 && !points)) DV_FAIL("dv_est_process_dynamic: bad instance record");
+    }
+    return est_begin(ctx, feats, n, t, insts, n_insts, inst_feats, points);
+}
+int dv_est_process_dynamic(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points, dv_est_state* out) {
+    const int rc = dv_est_process_dynamic_begin(ctx, feats, n, t, insts, n_insts, inst_feats, points);
+    if (rc) return rc;
+    return dv_est_process_end(ctx, out);
+}
+int dv_est_get_instances(dv_ctx* ctx, dv_inst_state* out, int cap, int* n_out, double* summary4) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_get_instances: call dv_est_create first");
+    if (!n_out || cap < 0 || (cap > 0 && !out)) DV_FAIL("dv_est_get_instances: bad argument");
+    dv_estimator& E = *ctx->est;
+    int k = 0;
+    for (auto& kv : E.im.insts) {
+        if (k >= cap) break;
+        const dvi::Inst& I = kv.second; dv_inst_state& o = out[k++];
+        std::memset(&o, 0, sizeof(o));
+        o.id = I.id; o.is_initial = I.is_initial; o.is_tracking = I.is_tracking; o.is_curr_visible = I.is_curr_visible; o.is_static = I.is_static; o.is_init_velocity = I.is_init_velocity;
+        o.age = I.age; o.lost_number = I.lost_number; o.static_frame = I.static_frame; o.n_landmarks = (int)I.lms.size(); o.n_valid = I.valid_size(); o.triangle_num = I.triangle_num;
+        for (int c = 0; c < 3; ++c) { o.dims[c] = I.dims[c]; o.vel_v[c] = get(I.vel_v, c); o.vel_a[c] = get(I.vel_a, c); }
+        for (int i = 0; i <= kWin; ++i) { const quat q = qfromR(I.R[i]); double* p = o.window[i]; p[0] = I.P[i].x; p[1] = I.P[i].y; p[2] = I.P[i].z; p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w; o.time[i] = I.time[i]; }
+    }
+    *n_out = k;
+    if (summary4) { summary4[0] = E.obj_last.iterations; summary4[1] = E.obj_last.termination; summary4[2] = E.obj_last.initial_cost; summary4[3] = E.obj_last.final_cost; }
     return 0;
 }
 int dv_est_process_end(dv_ctx* ctx, dv_est_state* out) {

@@ -312,6 +312,12 @@ typedef struct dv_est_config {          /* para (estimator/vio_parameters.cpp:19
     double init_depth, g_norm, td;      /* INIT_DEPTH, g_norm, td */
     double acc_n, gyr_n, acc_w, gyr_w;
     double ric[2][9], tic[2][3];        /* body_T_cam0 / body_T_cam1: rotation (row-major) and translation */
+    /* dynamic mode (cfg::slam == SLAM::kDynamic): the object branch of ProcessImage (estimator.cpp:1562-1622,1653-1676) */
+    int32_t dynamic;                    /* 1: dv_est_process_dynamic* run the InstanceManager */
+    int32_t use_det3d;                  /* use_det3d: objects are initialised from 3-D detections */
+    int32_t instance_init_min_num;      /* instance_init_min_num (viode.yaml:135: 4) */
+    int32_t pad_;
+    double static_inst_threshold;       /* static_inst_threshold: scene-flow norm above which an object counts as moving (default 10) */
 } dv_est_config;
 
 typedef struct dv_est_state {
@@ -334,6 +340,41 @@ int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_st
  * frame's tracking and feed IMU samples — thread T2's work overlapping T3's, as in the reference (system/main.cpp:394-404). */
 int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t);
 int dv_est_process_end(dv_ctx* ctx, dv_est_state* out);
+
+/* ---- dynamic mode: the object (instance) half of the back end.  Inputs are FrontendFeature::instances (basic/frontend_feature.h:58-75), i.e.
+ * what InstsFeatManager::Output() hands over (front_end/dynamic_tracker.cpp:521-577): per object its tracked features, the associated 3-D
+ * detection (if any) and the "extra" 3-D points sampled from the disparity map (camera frame).  The association of detections to tracks
+ * (DeepSORT / VIODE keys), the detector networks and the PCL clustering of the extra points are upstream of the path. ---- */
+typedef struct dv_box3d {               /* Box3D (basic/box3d.h:40-106): the fields the path reads */
+    int32_t class_id, pad_; double score;
+    double center[3];                   /* center_pt, camera frame */
+    double dims[3]; double yaw;         /* R_cioi() is built from yaw (box3d.h:79-83) */
+    float rect_min[2], rect_max[2];     /* box2d of the projected corners (BoxAssociate2Dto3D, dynamic_tracker.cpp:61-152) */
+} dv_box3d;
+typedef struct dv_inst_obs {            /* one FeatureInstance */
+    uint32_t id; int32_t has_box3d;     /* map key (Box2D::track_id); box3d valid */
+    int32_t first_feat, n_feats;        /* rows of the instance feature array: dv_feat with left = (x_n, y_n, 1, u, v, vx, vy), right likewise if has_right */
+    int32_t first_point, n_points;      /* FeatureInstance::points: (x, y, z) triples in the camera frame */
+    float rect[4];                      /* Box2D::rect x, y, w, h */
+    dv_box3d box3d;
+} dv_inst_obs;
+typedef struct dv_inst_state {          /* Instance (estimator/instance.h) as the publishers read it + InstEstimatedInfo (basic/inst_estimated_info.h) */
+    uint32_t id; int32_t is_initial, is_tracking, is_curr_visible, is_static, is_init_velocity, age, lost_number, static_frame,
+             n_landmarks, n_valid, triangle_num;
+    double dims[3], vel_v[3], vel_a[3];
+    double window[11][7];               /* state[i]: P, then R as qx qy qz qw */
+    double time[11];
+} dv_inst_state;
+/* ProcessMeasurements iteration in dynamic mode: dv_est_process with frame.instances.  insts may be NULL / n_insts 0 (no object in view). */
+int dv_est_process_dynamic(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats,
+                           const double* points, dv_est_state* out);
+/* two-phase form: _begin enqueues the window solve first and runs the object branch (bookkeeping on the host, InstanceManager::Optimization
+ * as dv_obj_solve on a third stream) while it is in flight; dv_est_process_end collects both. */
+int dv_est_process_dynamic_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats,
+                                 const double* points);
+/* Estimator::im.instances after the last processed frame (ascending id); *n_out = number written (<= cap); summary4 (may be NULL): iterations,
+ * termination, initial and final cost of the last object solve */
+int dv_est_get_instances(dv_ctx* ctx, dv_inst_state* out, int cap, int* n_out, double* summary4);
 
 /* ---- measurement hooks (used by bench.py; HIP-event timing on the ctx's own stream) ---- */
 /* names: "pyr","lk_temporal","compact","gftt_eig","gftt_select","lk_stereo","frame" */

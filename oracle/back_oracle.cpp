@@ -26,6 +26,7 @@
 #include "back_factors.h"
 #include "back_solver.h"
 #include "dvo.h"
+#include "inst_manager.h"
 
 namespace obe {
 
@@ -211,6 +212,7 @@ struct Config {
     double min_parallax = 10.0 / kFocalLength, init_depth = 5.0, g_norm = 9.81, td = 0.0;
     ImuNoise noise{ 0.1, 0.01, 0.001, 1e-4 };
     M3 ric[2]; V3 tic[2];
+    int dynamic = 0, use_det3d = 0, instance_init_min_num = 4; double static_inst_threshold = 10.0;      // cfg::slam == kDynamic, use_det3d, para::kInstanceInitMinNum, kStaticInstThreshold
 };
 
 struct Estimator {
@@ -231,12 +233,18 @@ struct Estimator {
     std::unique_ptr<MargInfo> last_marg;
     M3 back_R0; V3 back_P0;
     SolveSummary last_summary; int n_solves = 0;
+    oim::InstanceManager im;                   // Estimator::im (estimator.h)
+    oim::Body body() { return oim::Body{ Rs, Ps, ric, tic, headers, td, frame, para_pose }; }
 
     explicit Estimator(const Config& c) : cfg(c) { clear(); set_parameter(); }
     void clear() {
         for (int i = 0; i <= kWin; ++i) { Rs[i] = M3::identity(); Ps[i] = Vs[i] = Bas[i] = Bgs[i] = V3(); pre[i].reset(); dt_buf[i].clear(); la_buf[i].clear(); av_buf[i].clear(); headers[i] = 0; }
         lms.clear(); acc_buf.clear(); gyr_buf.clear(); all_frames.clear(); tmp_pre.reset(); last_marg.reset();
         prev_time = -1; cur_time = 0; first_imu = false; init_first_pose = false; frame = 0; nonlinear = false;
+        im = oim::InstanceManager();
+        im.para.use_det3d = cfg.use_det3d; im.para.kInstanceInitMinNum = cfg.instance_init_min_num; im.para.kStaticInstThreshold = cfg.static_inst_threshold;
+        im.para.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; im.para.KNumIter = cfg.max_iters;
+        std::memset(para_pose, 0, sizeof(para_pose));
     }
     void set_parameter() { for (int i = 0; i < 2; ++i) { ric[i] = cfg.ric[i]; tic[i] = cfg.tic[i]; } td = cfg.td; g = V3(0, 0, cfg.g_norm); }
 
@@ -518,6 +526,10 @@ struct Estimator {
         Solver solver(prob);
         SolveOptions so; so.max_num_iterations = cfg.max_iters;
         last_summary = solver.solve(so); n_solves++;
+        if (cfg.dynamic) {       // im.AddInstanceParameterBlock (:272-276) registers the object blocks, no live residual touches them, im.GetOptimizationParameters (:321-323) reads them back
+            im.InstExec([](unsigned, oim::Instance& inst) { inst.SetOptimizeParameters(); });
+            im.InstExec([](unsigned, oim::Instance& inst) { inst.GetOptimizationParameters(); });
+        }
         double2vector();
         if (frame < kWin) return;
         set_marginalization_info();
@@ -669,7 +681,7 @@ struct Estimator {
             Ps[frame] = Ps[p]; Vs[frame] = Vs[p]; Rs[frame] = Rs[p]; Bas[frame] = Bas[p]; Bgs[frame] = Bgs[p];
         }
     }
-    void process_image(const dvo_feat* feats, int n, double header) {      // ProcessImage (estimator.cpp:1516-1696), raw mode
+    void process_image(const dvo_feat* feats, int n, double header, std::map<unsigned, oim::FeatureInstance>* instances = nullptr) {      // ProcessImage (estimator.cpp:1516-1696)
         margin_old = add_feature_check_parallax(frame, feats, n, td);
         headers[frame] = header;
         all_frames.push_back({ header, std::shared_ptr<Integration>(tmp_pre.release()) });
@@ -677,15 +689,33 @@ struct Estimator {
         if (!nonlinear) { init_estimator(); return; }
         if (!cfg.use_imu) init_frame_pose_by_pnp(frame);
         triangulate_points();
+        const bool dyn = cfg.dynamic && instances;
+        if (dyn) {               // estimator.cpp:1562-1622
+            const oim::Body b = body();
+            im.PushBack(b, (unsigned)frame, *instances);
+            im.PropagatePose(b);
+            im.Triangulate(b);
+            im.InitialInstance(b);
+            im.InitialInstanceVelocity(b);
+            im.SetDynamicOrStatic(b);
+            im.Optimization(b);
+            im.OutliersRejection(b);
+        }
         optimization();
         std::set<int> rm; outliers_rejection(rm);
         for (auto it = lms.begin(); it != lms.end();) { auto cur = it++; if (rm.count(cur->feature_id)) lms.erase(cur); }
+        if (dyn) { const oim::Body b = body(); im.ManageTriangulatePoint(b); im.SlideWindow(b, margin_old); }      // :1653-1658
         slide_window();
+        if (dyn) {               // :1663-1676
+            im.OutliersRejection(body());
+            im.DeleteBadLandmarks();
+            for (auto& kv : im.instances) if (kv.second.landmarks.empty() && kv.second.GetPointsExtraFrames() == 0) kv.second.ClearState();
+        }
         for (auto it = lms.begin(); it != lms.end();) { auto cur = it++; if (cur->solve_flag == 2) lms.erase(cur); }      // RemoveFailures
         if (all_frames.size() > 2 * kWin + 2) all_frames.erase(all_frames.begin(), all_frames.end() - (kWin + 1));       // only used during initialisation
     }
     // one iteration of ProcessMeasurements (estimator.cpp:1786-1863); returns false if the IMU data does not yet cover t
-    bool process(const dvo_feat* feats, int n, double t) {
+    bool process(const dvo_feat* feats, int n, double t, std::map<unsigned, oim::FeatureInstance>* instances = nullptr) {
         cur_time = t + td;
         if (cfg.use_imu) {
             if (!imu_available(cur_time)) return false;
@@ -693,7 +723,7 @@ struct Estimator {
             get_imu_interval(prev_time, cur_time, av, gv);
             add_imu(av, gv);
         }
-        process_image(feats, n, t);
+        process_image(feats, n, t, instances);
         prev_time = cur_time;
         return true;
     }
@@ -904,13 +934,62 @@ dvo_estimator* dvo_estimator_create(const dvo_be_config* c) {
     cfg.min_parallax = c->keyframe_parallax / kFocalLength; cfg.init_depth = c->init_depth; cfg.g_norm = c->g_norm; cfg.td = c->td;
     cfg.noise = ImuNoise{ c->acc_n, c->gyr_n, c->acc_w, c->gyr_w };
     for (int k = 0; k < 2; ++k) { for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) cfg.ric[k](i, j) = c->ric[k][i * 3 + j]; cfg.tic[k][i] = c->tic[k][i]; } }
+    cfg.dynamic = c->dynamic; cfg.use_det3d = c->use_det3d; cfg.instance_init_min_num = c->instance_init_min_num; cfg.static_inst_threshold = c->static_inst_threshold;
     return new dvo_estimator{ new Estimator(cfg) };
 }
 void dvo_estimator_destroy(dvo_estimator* e) { if (e) { delete e->e; delete e; } }
 void dvo_estimator_input_imu(dvo_estimator* e, double t, const double* acc, const double* gyr) { e->e->input_imu(t, P3(acc), P3(gyr)); }
+static void fill_state(Estimator& E, dvo_be_state* out);
 int dvo_estimator_process(dvo_estimator* e, const dvo_feat* feats, int n, double t, dvo_be_state* out) {
     Estimator& E = *e->e;
     if (!E.process(feats, n, t)) return 1;
+    fill_state(E, out);
+    return 0;
+}
+// FrontendFeature::instances from the flat arrays (what InstsFeatManager::Output() builds, front_end/dynamic_tracker.cpp:521-577)
+int dvo_estimator_process_dynamic(dvo_estimator* e, const dvo_feat* feats, int n, double t, const dvo_inst_obs* insts, int n_insts, const dvo_feat* inst_feats,
+                                  const double* points, dvo_be_state* out) {
+    Estimator& E = *e->e;
+    std::map<unsigned, oim::FeatureInstance> in;
+    for (int i = 0; i < n_insts; ++i) {
+        const dvo_inst_obs& io = insts[i];
+        oim::FeatureInstance fi;
+        if (io.has_box3d) {
+            fi.box3d = std::make_shared<oim::Box3D>();
+            for (int k = 0; k < 3; ++k) { fi.box3d->dims[k] = io.box3d.dims[k]; fi.box3d->center_pt[k] = io.box3d.center[k]; }
+            fi.box3d->yaw = io.box3d.yaw;
+        }
+        for (int k = 0; k < io.n_feats; ++k) {
+            const dvo_feat& f = inst_feats[io.first_feat + k];
+            auto fp = std::make_shared<oim::FeaturePoint>();
+            fp->point = V3(f.left[0], f.left[1], 1); fp->vel[0] = f.left[5]; fp->vel[1] = f.left[6];
+            if (f.has_right) { fp->is_stereo = true; fp->point_right = V3(f.right[0], f.right[1], 1); fp->vel_right[0] = f.right[5]; fp->vel_right[1] = f.right[6]; }
+            fi.features.insert({ f.id, fp });
+        }
+        for (int k = 0; k < io.n_points; ++k) { const double* p = points + 3 * (size_t)(io.first_point + k); fi.points.emplace_back(p[0], p[1], p[2]); }
+        in.insert({ io.id, fi });
+    }
+    if (!E.process(feats, n, t, &in)) return 1;
+    fill_state(E, out);
+    return 0;
+}
+int dvo_estimator_get_instances(dvo_estimator* e, dvo_inst_state* out, int cap, int* n_out, double* summary4) {
+    Estimator& E = *e->e;
+    int k = 0;
+    for (auto& kv : E.im.instances) {
+        if (k >= cap) break;
+        oim::Instance& I = kv.second; dvo_inst_state& o = out[k++];
+        std::memset(&o, 0, sizeof(o));
+        o.id = I.id; o.is_initial = I.is_initial; o.is_tracking = I.is_tracking; o.is_curr_visible = I.is_curr_visible; o.is_static = I.is_static; o.is_init_velocity = I.is_init_velocity;
+        o.age = I.age; o.lost_number = I.lost_number; o.static_frame = I.static_frame; o.n_landmarks = (int)I.landmarks.size(); o.n_valid = I.valid_size(); o.triangle_num = I.triangle_num;
+        for (int c = 0; c < 3; ++c) { o.dims[c] = I.box3d ? I.box3d->dims[c] : 0.0; o.vel_v[c] = I.vel.v[c]; o.vel_a[c] = I.vel.a[c]; }
+        for (int i = 0; i <= kWin; ++i) { const Q q = Q::fromR(I.state[i].R); double* p = o.window[i]; p[0] = I.state[i].P.x; p[1] = I.state[i].P.y; p[2] = I.state[i].P.z; p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w; o.time[i] = I.state[i].time; }
+    }
+    *n_out = k;
+    if (summary4) { summary4[0] = E.im.last_summary.iterations; summary4[1] = E.im.last_summary.termination; summary4[2] = E.im.last_summary.initial_cost; summary4[3] = E.im.last_summary.final_cost; }
+    return 0;
+}
+static void fill_state(Estimator& E, dvo_be_state* out) {
     if (out) {
         std::memset(out, 0, sizeof(*out));
         out->frame = E.frame; out->nonlinear = E.nonlinear; out->margin_old = E.margin_old; out->n_landmarks = (int)E.lms.size(); out->n_long = E.feature_count();
@@ -922,7 +1001,6 @@ int dvo_estimator_process(dvo_estimator* e, const dvo_feat* feats, int n, double
             for (int k = 0; k < 3; ++k) { p[7 + k] = E.Vs[i][k]; p[10 + k] = E.Bas[i][k]; p[13 + k] = E.Bgs[i][k]; }
         }
     }
-    return 0;
 }
 
 }  // extern "C"

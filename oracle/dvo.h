@@ -189,6 +189,8 @@ typedef struct dvo_be_config {       /* para (estimator/vio_parameters.cpp:19-83
     double init_depth, g_norm, td;
     double acc_n, gyr_n, acc_w, gyr_w;
     double ric[2][9], tic[2][3];     /* body_T_cam0 / body_T_cam1 rotation (row-major) and translation */
+    int dynamic, use_det3d, instance_init_min_num, pad_;      /* cfg::slam == kDynamic; use_det3d; para::kInstanceInitMinNum */
+    double static_inst_threshold;    /* para::kStaticInstThreshold */
 } dvo_be_config;
 
 typedef struct dvo_be_state {
@@ -204,6 +206,18 @@ dvo_estimator* dvo_estimator_create(const dvo_be_config*);
 void dvo_estimator_destroy(dvo_estimator*);
 void dvo_estimator_input_imu(dvo_estimator*, double t, const double* acc, const double* gyr);
 int dvo_estimator_process(dvo_estimator*, const dvo_feat* feats, int n, double t, dvo_be_state* out);
+
+/* dynamic mode: FrontendFeature::instances as flat arrays (layout identical to include/dvins.h dv_box3d / dv_inst_obs / dv_inst_state, restated here) */
+typedef struct dvo_box3d { int32_t class_id, pad_; double score; double center[3]; double dims[3]; double yaw; float rect_min[2], rect_max[2]; } dvo_box3d;
+typedef struct dvo_inst_obs { uint32_t id; int32_t has_box3d; int32_t first_feat, n_feats; int32_t first_point, n_points; float rect[4]; dvo_box3d box3d; } dvo_inst_obs;
+typedef struct dvo_inst_state {
+    uint32_t id; int32_t is_initial, is_tracking, is_curr_visible, is_static, is_init_velocity, age, lost_number, static_frame, n_landmarks, n_valid, triangle_num;
+    double dims[3], vel_v[3], vel_a[3]; double window[11][7]; double time[11];
+} dvo_inst_state;
+/* ProcessImage with the object branch (estimator.cpp:1562-1622,1653-1676); see inst_manager.h */
+int dvo_estimator_process_dynamic(dvo_estimator*, const dvo_feat* feats, int n, double t, const dvo_inst_obs* insts, int n_insts, const dvo_feat* inst_feats,
+                                  const double* points, dvo_be_state* out);
+int dvo_estimator_get_instances(dvo_estimator*, dvo_inst_state* out, int cap, int* n_out, double* summary4);
 
 #ifdef __cplusplus
 }

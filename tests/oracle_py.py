@@ -219,7 +219,8 @@ class dvo_be_config(C.Structure):
     _fields_ = [("use_imu", C.c_int), ("stereo", C.c_int), ("plane_constraint", C.c_int), ("max_iters", C.c_int),
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),
                 ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
-                ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2)]
+                ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2),
+                ("dynamic", C.c_int), ("use_det3d", C.c_int), ("instance_init_min_num", C.c_int), ("pad_", C.c_int), ("static_inst_threshold", C.c_double)]
 
 
 class dvo_be_state(C.Structure):
@@ -229,8 +230,10 @@ class dvo_be_state(C.Structure):
 
 
 def make_be_config(cls, use_imu=1, stereo=1, plane_constraint=0, max_iters=8, keyframe_parallax=10.0, init_depth=5.0,
-                   g_norm=9.81, td=0.0, acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None):
+                   g_norm=9.81, td=0.0, acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None,
+                   dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0):
     c = cls()
+    c.dynamic, c.use_det3d, c.instance_init_min_num, c.static_inst_threshold = dynamic, use_det3d, instance_init_min_num, static_inst_threshold
     c.use_imu, c.stereo, c.plane_constraint, c.max_iters = use_imu, stereo, plane_constraint, max_iters
     c.keyframe_parallax, c.init_depth, c.g_norm, c.td = keyframe_parallax, init_depth, g_norm, td
     c.acc_n, c.gyr_n, c.acc_w, c.gyr_w = acc_n, gyr_n, acc_w, gyr_w
@@ -268,6 +271,24 @@ class OracleEstimator:
 
     def window(self):
         return np.array([list(r) for r in self.state.window])
+
+    def process_dynamic(self, rows, t, insts, inst_feats, points):
+        L = self.lib
+        L.dvo_estimator_process_dynamic.restype = C.c_int
+        L.dvo_estimator_process_dynamic.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(dvo_be_state)]
+        rows, insts, inst_feats = np.ascontiguousarray(rows), np.ascontiguousarray(insts), np.ascontiguousarray(inst_feats)
+        points = np.ascontiguousarray(points, np.float64)
+        rc = L.dvo_estimator_process_dynamic(self.h, _p(rows), len(rows), float(t), _p(insts) if len(insts) else None, len(insts), _p(inst_feats) if len(inst_feats) else None,
+                                             _p(points) if len(points) else None, C.byref(self.state))
+        return rc, self.state
+
+    def instances(self, dtype, cap=64):
+        L = self.lib
+        L.dvo_estimator_get_instances.restype = C.c_int
+        L.dvo_estimator_get_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]
+        out = np.zeros(cap, dtype); n = C.c_int(0); summ = np.zeros(4)
+        L.dvo_estimator_get_instances(self.h, _p(out), cap, C.byref(n), _p(summ))
+        return out[: n.value].copy(), summ
 
     def close(self):
         if self.h:

@@ -1,0 +1,102 @@
+"""Dynamic mode, back end (`-m gpu`): the product estimator with the object branch (host InstanceManager bookkeeping in the .so + the object
+solve on the GPU, through dv_est_process_dynamic*) against the oracle estimator (oracle/inst_manager.h + dvo_obj_solve), fed the same simulated
+background tracks, object tracks, 3-D detections and extra points (dynsim.InstSim: 3 moving boxes).
+
+Bars: ego window as in test_estimator_parity (1e-5 m / 1e-6); per object and per frame: identical flags (is_initial / is_tracking / is_curr_visible /
+is_static / is_init_velocity), identical age / lost_number / static_frame / landmark counts / triangle_num, identical object-solve iteration counts and
+termination, object window positions within 1e-6 m, rotations (quaternions) within 1e-6, dims within 1e-7, velocities within 1e-6."""
+import numpy as np
+import pytest
+
+from dynamic_vins_amd import dynsim, sim
+
+pytestmark = pytest.mark.gpu
+
+NOISE = dict(acc_n=0.02, gyr_n=0.002, acc_w=2e-4, gyr_w=2e-5)
+INT_FIELDS = ["id", "is_initial", "is_tracking", "is_curr_visible", "is_static", "is_init_velocity", "age", "lost_number", "static_frame", "n_landmarks", "n_valid", "triangle_num"]
+
+
+def run_dynamic(gpu_ctx_factory, oracle, frames, use_imu=1, use_det3d=1, two_phase=False, drop_frames=(), plane=0, seed=3):
+    from dynamic_vins_amd.backend import Estimator
+    ctx = gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5)
+    traj, cam = sim.Trajectory(), sim.EUROC
+    fs = sim.FeatureSim(traj, cam, 752, 480, sim.room_points(3000), max_cnt=150, pix_sigma=0.3, seed=seed)
+    isim = dynsim.InstSim(traj, cam, 752, 480, with_det3d=bool(use_det3d))
+    kw = dict(use_imu=use_imu, stereo=1, max_iters=8, plane_constraint=plane, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], dynamic=1, use_det3d=use_det3d,
+              instance_init_min_num=4, static_inst_threshold=1.0, **NOISE)
+    ref, dev = oracle.estimator(**kw), Estimator(ctx, **kw)
+    T0, dtf = 1.0, 0.1
+    ts, acc, gyr = sim.imu_stream(traj, T0 - 0.05, T0 + frames * dtf + 0.2, 200.0, **NOISE)
+    k = 0
+    seen = dict(initial=0, static=0, velocity=0, solved=0, cleared=0, objects=set())
+    worst = dict(p=0.0, q=0.0, dims=0.0, vel=0.0, ego=0.0)
+    for f in range(frames):
+        t = T0 + f * dtf
+        while k < len(ts) and ts[k] <= t + 0.011:
+            ref.input_imu(ts[k], acc[k], gyr[k]); dev.InputIMU(ts[k], acc[k], gyr[k]); k += 1
+        rows = fs.frame(t)
+        insts, ifeats, pts = isim.frame(t, visible=set() if f in drop_frames else None)
+        rc_o, so = ref.process_dynamic(rows, t, insts, ifeats, pts)
+        if two_phase:
+            rc_d = dev.ProcessMeasurementsDynamicBegin(rows, t, insts, ifeats, pts)
+            sd = dev.ProcessMeasurementsEnd()
+        else:
+            rc_d, sd = dev.ProcessMeasurementsDynamic(rows, t, insts, ifeats, pts)
+        assert rc_o == rc_d == 0
+        assert (sd.frame, sd.nonlinear, sd.margin_old, sd.n_landmarks, sd.n_long, sd.iterations) == (so.frame, so.nonlinear, so.margin_old, so.n_landmarks, so.n_long, so.iterations), f"frame {f}"
+        worst["ego"] = max(worst["ego"], np.abs(ref.window()[:, :3] - dev.window()[:, :3]).max())
+        Io, So = ref.instances(dynsim.INSTSTATE_DTYPE)
+        Id, Sd = dev.instances()
+        assert len(Io) == len(Id), f"frame {f}"
+        for name in INT_FIELDS:
+            assert np.array_equal(Io[name], Id[name]), f"frame {f}: {name} {Io[name]} vs {Id[name]}"
+        assert So[0] == Sd[0] and So[1] == Sd[1], f"frame {f}: object solve {So} vs {Sd}"
+        if So[0] > 0:
+            seen["solved"] += 1
+            assert np.isclose(So[2], Sd[2], rtol=1e-7, atol=1e-9) and np.isclose(So[3], Sd[3], rtol=1e-7, atol=1e-9), f"frame {f}: {So} vs {Sd}"
+        for a, b in zip(Io, Id):
+            seen["objects"].add(int(a["id"]))
+            seen["initial"] += int(a["is_initial"]); seen["static"] += int(a["is_static"]); seen["velocity"] += int(a["is_init_velocity"])
+            seen["cleared"] += int(not a["is_tracking"])
+            worst["p"] = max(worst["p"], np.abs(a["window"][:, :3] - b["window"][:, :3]).max())
+            qa, qb = a["window"][:, 3:], b["window"][:, 3:]
+            sgn = np.sign((qa * qb).sum(1, keepdims=True)); sgn[sgn == 0] = 1
+            worst["q"] = max(worst["q"], np.abs(qa - sgn * qb).max())
+            worst["dims"] = max(worst["dims"], np.abs(a["dims"] - b["dims"]).max())
+            worst["vel"] = max(worst["vel"], np.abs(a["vel_v"] - b["vel_v"]).max(), np.abs(a["vel_a"] - b["vel_a"]).max())
+            assert np.array_equal(a["time"], b["time"])
+    return worst, seen
+
+
+def check(worst):
+    assert worst["ego"] < 1e-5, worst
+    assert worst["p"] < 1e-6 and worst["q"] < 1e-6 and worst["dims"] < 1e-7 and worst["vel"] < 1e-6, worst
+
+
+def test_dynamic_estimator_tracks_oracle(gpu_ctx_factory, oracle):
+    worst, seen = run_dynamic(gpu_ctx_factory, oracle, 60)
+    check(worst)
+    # the run must actually exercise the object life cycle
+    assert len(seen["objects"]) >= 2 and seen["initial"] > 40 and seen["velocity"] > 20 and seen["solved"] > 30 and seen["static"] > 0, seen
+
+
+def test_dynamic_two_phase_and_dropouts(gpu_ctx_factory, oracle):
+    """two-phase entry (object branch overlapped with the window solve) + frames without any detection (PushBack with an empty map)"""
+    worst, seen = run_dynamic(gpu_ctx_factory, oracle, 50, two_phase=True, drop_frames=(20, 21, 33))
+    check(worst)
+    assert seen["solved"] > 20, seen
+
+
+def test_dynamic_without_det3d_and_vision_only(gpu_ctx_factory, oracle):
+    """use_det3d 0: objects are initialised by FitBox3DFromCameraFrame with the default car box; vision-only ego estimation"""
+    worst, seen = run_dynamic(gpu_ctx_factory, oracle, 40, use_imu=0, use_det3d=0)
+    check(worst)
+
+
+def test_raw_calls_on_a_dynamic_estimator_and_errors(gpu_ctx_factory, oracle):
+    from dynamic_vins_amd._abi import DvinsError
+    from dynamic_vins_amd.backend import Estimator
+    ctx = gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5)
+    est = Estimator(ctx, use_imu=0, stereo=1, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], dynamic=0)
+    with pytest.raises(DvinsError):
+        est.ProcessMeasurementsDynamic(np.zeros(0, sim.FEAT_DTYPE), 1.0, np.zeros(0, dynsim.INSTOBS_DTYPE), np.zeros(0, sim.FEAT_DTYPE), np.zeros((0, 3)))

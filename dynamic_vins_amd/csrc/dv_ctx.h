@@ -125,6 +125,8 @@ struct dv_obj_problem;
 int be_obj_solve_on(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, hipStream_t s, DevBuf& scratch);
 struct dv_estimator;
 void dv_est_destroy_internal(dv_estimator* e);
+struct dv_inst_tracker;
+void dv_inst_destroy_internal(dv_inst_tracker* t);
 
 struct dv_ctx {
     dv_config cfg{};
@@ -146,6 +148,7 @@ struct dv_ctx {
     hipStream_t be_stream = nullptr; BeWork be;
     hipStream_t obj_stream = nullptr; DevBuf obj_buf;      // dynamic mode: the object solve runs beside the window solve
     dv_estimator* est = nullptr;
+    struct dv_inst_tracker* inst = nullptr;      // dynamic mode: the per-object tracker (inst_track.hip)
 };
 
 void dv_set_error(dv_ctx* ctx, const std::string& msg);

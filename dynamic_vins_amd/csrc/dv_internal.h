@@ -71,6 +71,10 @@ void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, i
                           double eps_sq, int use_initial, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max,
                         int flow_back, float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s);
+void dv_launch_lk_track_offset(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back,
+                               float dist_thresh, float add_x, float add_y, float2* pts_b, uint8_t* status, hipStream_t s);
+void dv_launch_finalize_offset(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, double off_x, double off_y,
+                               dv_feat* out, int* n_out, hipStream_t s);
 void dv_launch_gftt_tile(const GfttTileArgs& a, hipStream_t s);
 int  dv_launch_gftt_select(const GfttSelectArgs& a, hipStream_t s);
 void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_pitch, int sort_by_cnt, int* n_cand,

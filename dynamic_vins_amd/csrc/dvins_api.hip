@@ -178,6 +178,7 @@ void dv_destroy(dv_ctx* ctx) {
     for (auto& t : ctx->timers) for (auto& p : t.pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,
                        &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->opA.buf, &ctx->opB.buf, &ctx->undist_buf[0], &ctx->undist_buf[1] }) b->release();
+    if (ctx->inst) dv_inst_destroy_internal(ctx->inst);
     if (ctx->est) dv_est_destroy_internal(ctx->est);
     ctx->be.block.release(); ctx->be.marg_buf.release();
     if (ctx->be.pinned) (void)hipHostFree(ctx->be.pinned);
@@ -198,6 +199,7 @@ int dv_reset(dv_ctx* ctx) {
     DV_CHECK(hipMemcpyAsync(ctx->tr.next_id, &one, 4, hipMemcpyHostToDevice, ctx->stream));
     DV_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->have_prev = false; ctx->prev_time = 0.0; ctx->pending = false;
+    if (ctx->inst && dv_inst_reset(ctx)) return -1;
     return 0;
 }
 

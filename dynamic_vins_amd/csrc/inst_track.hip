@@ -1,0 +1,334 @@
+// inst_track.hip — the per-object half of the dynamic-mode front end on gfx950: InstsFeatManager of the reference
+//   InstsFeatManager::{InstsTrack,ManageInstances,Output,BoxAssociate2Dto3D,AddInstancesByTracking}   front_end/dynamic_tracker.cpp:61-152,348-577,791-828
+//   InstFeat::{TrackLeft,TrackRightByPad,UndistortedPointsWithAddOffset,PtsVelocity,RightPtsVelocity,PostProcess}   front_end/instance_feature.cpp, instance_feature.h:88-101
+//   InstanceImagePadding                                                                                front_end/feature_utils.cpp:406-413
+// Host side (this file, C++ inside the .so): the object table keyed by track id, the lost_num life cycle, the 2-D / 3-D box association.
+// Device side: every object owns a DvTrackState (points, ids, track counts, previous undistorted points) and two ROI pyramids in HBM; per frame
+// and per visible object the stream carries: ROI crop + zero padding (roi_pad_kernel) -> pyrDown of the padded pair -> lk_track (ROI-local,
+// fwd + bwd + InBorder) -> compaction -> 5x5 erosion of the object mask -> Shi-Tomasi (tile + select, discs of the tracked points excluded,
+// ids from the tracker-wide counter) -> lk_track into the right image with the box offset added to the points (TrackRightByPad) ->
+// finalize (undistortion with the box offset, velocities, PostProcess) -> one D2H copy per frame for all objects.  No host round trip inside
+// a frame: the per-object point counts stay on the device.
+// Canonical choices: objects are visited in ascending id (the reference iterates an unordered_map) and run after the background tracker on the
+// same stream, so the shared id counter hands out ids in a fixed order (the reference increments it from two threads without a lock).
+#include <algorithm>
+#include <map>
+#include "dv_ctx.h"
+
+#define INST_CAP 256          // device capacity per object (max_dynamic_cnt <= 200)
+
+namespace {
+
+__global__ __launch_bounds__(256) void roi_pad_kernel(const uint8_t* __restrict__ src, int spitch, int x0, int y0, int w, int h, uint8_t* __restrict__ dst, int dpitch, int W, int H) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    dst[(size_t)y * dpitch + x] = (x < w && y < h) ? src[(size_t)(y0 + y) * spitch + x0 + x] : (uint8_t)0;      // InstanceImagePadding: zero fill right / below
+}
+
+struct RoiPyr {          // pyramid storage with a fixed capacity (the full frame), re-laid-out per frame without re-allocation
+    DevBuf buf; DvPyr pyr{}; int w = 0, h = 0;
+    hipError_t reserve(int W, int H) {
+        size_t total = 0; int cw = W, ch = H;
+        for (int l = 0; l < DV_MAX_LEVELS; ++l) { total += (size_t)align_up(cw, 16) * ch; total = (total + 255) / 256 * 256; cw = (cw + 1) / 2; ch = (ch + 1) / 2; }
+        return buf.ensure(total + 512);
+    }
+    void layout(int w_, int h_) {      // buildOpticalFlowPyramid's level rule, as PyrSet::alloc
+        w = w_; h = h_;
+        int n = 0, cw = w, ch = h; size_t off = 0;
+        for (int l = 0; l < DV_MAX_LEVELS; ++l) {
+            pyr.L[n] = DvLevel{ (uint8_t*)buf.p + off, cw, ch, align_up(cw, 16) };
+            off += (size_t)align_up(cw, 16) * ch; off = (off + 255) / 256 * 256; ++n;
+            const int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
+            if (nw <= DV_LK_WIN || nh <= DV_LK_WIN) break;
+            cw = nw; ch = nh;
+        }
+        for (int l = n; l < DV_MAX_LEVELS; ++l) pyr.L[l] = DvLevel{ nullptr, 0, 0, 0 };
+        pyr.levels = n;
+    }
+};
+
+struct Slot {            // InstFeat
+    unsigned id = 0; int lost_num = 0; bool visible = false, has_box2d = false, has_box3d = false, has_prev = false;
+    int class_id = 0; int rx = 0, ry = 0, rw = 0, rh = 0;      // Box2D::rect of the current frame
+    int pw = 0, ph = 0;                                        // size of prev_roi_gray
+    dv_box3d box3d{};
+    DevBuf state; DvTrackState tr{}; int* scal = nullptr;      // n_feat, n_tracked
+    RoiPyr roi[2]; int cur = 0;                                // roi[cur]: this frame's (padded) ROI pyramid; roi[cur ^ 1]: level 0 holds prev_roi_gray in its top-left pw x ph
+    RoiPyr padA;                                               // previous ROI padded to the common size
+    DevBuf mask, tmp, ero;
+    const double* points = nullptr; int n_points = 0;          // extra 3-D points of this frame (pass-through)
+    std::vector<double> pts_copy;
+    bool out_valid = false; int out_index = -1;
+    void release() { state.release(); roi[0].buf.release(); roi[1].buf.release(); padA.buf.release(); mask.release(); tmp.release(); ero.release(); }
+};
+
+}  // namespace
+
+struct dv_inst_tracker {
+    std::map<unsigned, Slot> slots;
+    int max_cnt = 50, min_dist = 5, use_det3d = 0;
+    DevBuf hw; int hw_radius = -1;
+    double last_time = 0, cur_time = 0;
+    void* pinned_in = nullptr; size_t pinned_in_bytes = 0;
+    dv_feat* out_dev = nullptr; DevBuf out_buf; void* out_pinned = nullptr; size_t out_cap_slots = 0;      // [slot][INST_CAP] rows + counts
+    hipEvent_t done = nullptr; bool pending = false;
+    std::vector<unsigned> out_order;                            // ids written this frame, in output order
+    ~dv_inst_tracker() {
+        for (auto& kv : slots) kv.second.release();
+        hw.release(); out_buf.release();
+        if (pinned_in) (void)hipHostFree(pinned_in);
+        if (out_pinned) (void)hipHostFree(out_pinned);
+        if (done) (void)hipEventDestroy(done);
+    }
+};
+
+void dv_inst_destroy_internal(dv_inst_tracker* t) { delete t; }
+
+static void circle_half_widths_i(int radius, std::vector<uint8_t>& hw) {      // cv::circle's midpoint rasteriser (as dvins_api.hip)
+    hw.assign(radius + 1, 0);
+    int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+    while (dx >= dy) {
+        hw[dy] = (uint8_t)std::max<int>(hw[dy], dx); hw[dx] = (uint8_t)std::max<int>(hw[dx], dy);
+        dy++; err += plus; plus += 2;
+        int m = (err <= 0) - 1;
+        err -= minus & m; dx += m; minus -= m & 2;
+    }
+}
+
+static int slot_init(dv_ctx* ctx, Slot& s) {
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    const size_t N = INST_CAP;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+    const size_t o_last = take(N * 8), o_cur = take(N * 8), o_lk = take(N * 8), o_lks = take(N), o_ids = take(N * 4), o_cnt = take(N * 4), o_pun = take(N * 8), o_prun = take(N * 8),
+                 o_prv = take(N), o_trk = take(N), o_rp = take(N * 8), o_rs = take(N), o_scal = take(64);
+    DV_CHECK(s.state.ensure(off));
+    DV_CHECK(hipMemsetAsync(s.state.p, 0, off, ctx->stream));
+    uint8_t* b = (uint8_t*)s.state.p;
+    s.tr.last_pts = (float2*)(b + o_last); s.tr.curr_pts = (float2*)(b + o_cur); s.tr.lk_pts = (float2*)(b + o_lk); s.tr.lk_status = b + o_lks;
+    s.tr.ids = (uint32_t*)(b + o_ids); s.tr.track_cnt = (int32_t*)(b + o_cnt); s.tr.prev_un = (float2*)(b + o_pun); s.tr.prev_run = (float2*)(b + o_prun);
+    s.tr.prev_rvalid = b + o_prv; s.tr.tracked = b + o_trk; s.tr.right_pts = (float2*)(b + o_rp); s.tr.right_status = b + o_rs;
+    s.scal = (int*)(b + o_scal); s.tr.n_feat = s.scal; s.tr.n_tracked = s.scal + 1;
+    s.tr.next_id = ctx->tr.next_id;                      // InstFeat::global_id_count is ONE static counter for background and object features
+    for (int k = 0; k < 2; ++k) DV_CHECK(s.roi[k].reserve(W, H));
+    DV_CHECK(s.padA.reserve(W, H));
+    const size_t mp = (size_t)align_up(W, 16) * H;
+    DV_CHECK(s.mask.ensure(mp)); DV_CHECK(s.tmp.ensure(mp)); DV_CHECK(s.ero.ensure(mp));
+    return 0;
+}
+
+static float rect_iou(const float a[4], const float b[4]) {      // Box2D::IoU on (x, y, w, h) rectangles (basic/box2d.cpp:20-27)
+    const float x1 = std::max(a[0], b[0]), y1 = std::max(a[1], b[1]), x2 = std::min(a[0] + a[2], b[0] + b[2]), y2 = std::min(a[1] + a[3], b[1] + b[3]);
+    const float in = (x2 > x1 && y2 > y1) ? (x2 - x1) * (y2 - y1) : 0.f;
+    const float un = a[2] * a[3] + b[2] * b[3] - in;
+    if (un < 2.220446049250313e-16) return 0.f;
+    return in / un;
+}
+
+extern "C" {
+
+int dv_inst_config(dv_ctx* ctx, int max_dynamic_cnt, int min_dynamic_dist, int use_det3d) {
+    if (!ctx) return -1;
+    if (max_dynamic_cnt < 1 || max_dynamic_cnt > INST_CAP - 8) DV_FAIL("dv_inst_config: max_dynamic_cnt must be in [1, 248]");
+    if (min_dynamic_dist < 0 || min_dynamic_dist > DV_MAX_RADIUS) DV_FAIL("dv_inst_config: min_dynamic_dist out of range [0,128]");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (!ctx->inst) { ctx->inst = new dv_inst_tracker(); DV_CHECK(hipEventCreateWithFlags(&ctx->inst->done, hipEventDisableTiming)); }
+    dv_inst_tracker& T = *ctx->inst;
+    if (T.pending) DV_FAIL("dv_inst_config: a frame is in flight");
+    T.max_cnt = max_dynamic_cnt; T.min_dist = min_dynamic_dist; T.use_det3d = use_det3d;
+    std::vector<uint8_t> hw; circle_half_widths_i(min_dynamic_dist, hw);
+    DV_CHECK(T.hw.ensure(DV_MAX_RADIUS + 1));
+    DV_CHECK(hipMemcpy(T.hw.p, hw.data(), hw.size(), hipMemcpyHostToDevice));
+    T.hw_radius = min_dynamic_dist;
+    return 0;
+}
+
+int dv_inst_reset(dv_ctx* ctx) {
+    if (!ctx) return -1;
+    if (!ctx->inst) return 0;
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->inst->slots) kv.second.release();
+    ctx->inst->slots.clear(); ctx->inst->pending = false; ctx->inst->last_time = ctx->inst->cur_time = 0; ctx->inst->out_order.clear();
+    return 0;
+}
+
+int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_dets, const dv_box3d* boxes3d, int n_boxes3d) {
+    if (!ctx) return -1;
+    if (!ctx->inst) DV_FAIL("dv_inst_track: call dv_inst_config first");
+    if (n_dets < 0 || (n_dets > 0 && !dets) || n_boxes3d < 0 || (n_boxes3d > 0 && !boxes3d)) DV_FAIL("dv_inst_track: bad argument");
+    if (!ctx->have_prev) DV_FAIL("dv_inst_track: enqueue the frame with dv_track_stereo_enqueue first (the object tracker works on its pyramids)");
+    dv_inst_tracker& T = *ctx->inst;
+    if (T.pending) DV_FAIL("dv_inst_track_enqueue: previous frame not collected");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = ctx->stream;
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    const DvPyr& L = ctx->left[ctx->cur].pyr; const DvPyr& R = ctx->right.pyr;
+    const bool stereo = ctx->cfg.stereo != 0;
+    T.cur_time = t;
+    // ---- FeatureTrack (system/main.cpp:198-212): every object starts the frame invisible; the detections (already associated to tracks) make them visible ----
+    for (auto& kv : T.slots) { kv.second.visible = false; kv.second.has_box2d = false; kv.second.has_box3d = false; kv.second.points = nullptr; kv.second.n_points = 0; }
+    size_t mask_bytes = 0;
+    for (int i = 0; i < n_dets; ++i) {
+        const dv_inst_det& d = dets[i];
+        if (d.w <= 0 || d.h <= 0 || d.x < 0 || d.y < 0 || d.x + d.w > W || d.y + d.h > H) DV_FAIL("dv_inst_track: detection rectangle outside the image");
+        if (!d.mask) DV_FAIL("dv_inst_track: detection without a mask");
+        auto it = T.slots.find(d.track_id);
+        if (it == T.slots.end()) {
+            it = T.slots.emplace(d.track_id, Slot()).first; it->second.id = d.track_id;
+            if (slot_init(ctx, it->second)) return -1;
+        }
+        Slot& S = it->second;
+        if (S.visible) DV_FAIL("dv_inst_track: two detections with the same track id");
+        S.visible = true; S.has_box2d = true; S.class_id = d.class_id; S.rx = d.x; S.ry = d.y; S.rw = d.w; S.rh = d.h;
+        S.pts_copy.assign(d.points ? d.points : nullptr, d.points ? d.points + 3 * (size_t)std::max(d.n_points, 0) : nullptr);
+        mask_bytes += (size_t)align_up(d.w, 16) * d.h;
+    }
+    // ---- InstsTrack (dynamic_tracker.cpp:348-493) ----
+    for (auto& kv : T.slots) { if (!kv.second.visible) kv.second.lost_num++; else kv.second.lost_num = 0; }
+    if (T.use_det3d) {       // BoxAssociate2Dto3D (:61-152): same class, IoU of the 2-D rectangles > 0.1, nearest centre wins, every 3-D box used once
+        std::vector<char> taken(n_boxes3d, 0);
+        for (auto& kv : T.slots) {
+            Slot& S = kv.second;
+            if (!S.visible) continue;
+            const float ir[4] = { (float)S.rx, (float)S.ry, (float)S.rw, (float)S.rh };       // cv::Rect(min_pt, max_pt) of the detection
+            double best = 1.7976931348623157e308; int bi = -1;
+            for (int i = 0; i < n_boxes3d; ++i) {
+                if (taken[i]) continue;
+                const dv_box3d& b = boxes3d[i];
+                if (b.class_id != S.class_id) continue;
+                const int x0 = (int)lrintf(b.rect_min[0]), y0 = (int)lrintf(b.rect_min[1]), x1 = (int)lrintf(b.rect_max[0]), y1 = (int)lrintf(b.rect_max[1]);      // cv::Rect from Point2f: cvRound
+                const float pr[4] = { (float)x0, (float)y0, (float)(x1 - x0), (float)(y1 - y0) };
+                if (!(rect_iou(ir, pr) > 0.1f)) continue;
+                const double dn = sqrt(b.center[0] * b.center[0] + b.center[1] * b.center[1] + b.center[2] * b.center[2]);
+                if (dn < best) { best = dn; bi = i; }
+            }
+            if (bi >= 0) { taken[bi] = 1; S.has_box3d = true; S.box3d = boxes3d[bi]; }
+        }
+    }
+    T.out_order.clear();
+    if (n_dets > 0) {
+        // masks: one pinned staging area, one H2D per object (sources are pageable caller memory)
+        if (T.pinned_in_bytes < mask_bytes) {
+            if (T.pinned_in) (void)hipHostFree(T.pinned_in);
+            T.pinned_in = nullptr; T.pinned_in_bytes = 0;
+            DV_CHECK(hipHostMalloc(&T.pinned_in, mask_bytes * 2 + 4096, hipHostMallocDefault));
+            T.pinned_in_bytes = mask_bytes * 2 + 4096;
+        }
+        // output area
+        if (T.out_cap_slots < T.slots.size()) {
+            const size_t cap = std::max<size_t>(8, T.slots.size() * 2);
+            DV_CHECK(hipStreamSynchronize(s));
+            DV_CHECK(T.out_buf.ensure(cap * (INST_CAP * sizeof(dv_feat) + 64)));
+            if (T.out_pinned) (void)hipHostFree(T.out_pinned);
+            T.out_pinned = nullptr;
+            DV_CHECK(hipHostMalloc(&T.out_pinned, cap * (INST_CAP * sizeof(dv_feat) + 64), hipHostMallocDefault));
+            T.out_cap_slots = cap;
+        }
+        const size_t slot_bytes = INST_CAP * sizeof(dv_feat) + 64;
+        size_t moff = 0; int out_k = 0;
+        const double dt = T.cur_time - T.last_time;
+        for (auto& kv : T.slots) {
+            Slot& S = kv.second;
+            S.out_valid = false;
+            if (S.lost_num > 0 || !S.visible) continue;            // ExecInst + is_curr_visible
+            const int w = S.rw, h = S.rh;
+            // mask of this frame -> HBM
+            const int mp = align_up(w, 16);
+            uint8_t* hm = (uint8_t*)T.pinned_in + moff; moff += (size_t)mp * h;
+            const dv_inst_det* det = nullptr; for (int i = 0; i < n_dets; ++i) if (dets[i].track_id == S.id) det = &dets[i];
+            for (int y = 0; y < h; ++y) std::memcpy(hm + (size_t)y * mp, det->mask + (size_t)y * w, w);
+            DV_CHECK(hipMemcpyAsync(S.mask.p, hm, (size_t)mp * h, hipMemcpyHostToDevice, s));
+            // this frame's ROI, padded to the common size with the previous one (InstanceImagePadding)
+            S.cur ^= 1;
+            RoiPyr& B = S.roi[S.cur]; RoiPyr& Prev = S.roi[S.cur ^ 1];
+            const int PW = S.has_prev ? std::max(w, S.pw) : w, PH = S.has_prev ? std::max(h, S.ph) : h;
+            B.layout(PW, PH);
+            { dim3 grid((PW + 255) / 256, PH); hipLaunchKernelGGL(roi_pad_kernel, grid, dim3(256), 0, s, L.L[0].p, L.L[0].pitch, S.rx, S.ry, w, h, B.pyr.L[0].p, B.pyr.L[0].pitch, PW, PH); }
+            if (S.has_prev) {
+                S.padA.layout(PW, PH);
+                { dim3 grid((PW + 255) / 256, PH); hipLaunchKernelGGL(roi_pad_kernel, grid, dim3(256), 0, s, Prev.pyr.L[0].p, Prev.pyr.L[0].pitch, 0, 0, S.pw, S.ph, S.padA.pyr.L[0].p, S.padA.pyr.L[0].pitch, PW, PH); }
+                for (int l = 1; l < B.pyr.levels; ++l)
+                    dv_launch_pyr_down2(S.padA.pyr.L[l - 1].p, B.pyr.L[l - 1].p, B.pyr.L[l - 1].w, B.pyr.L[l - 1].h, B.pyr.L[l - 1].pitch, S.padA.pyr.L[l].p, B.pyr.L[l].p, B.pyr.L[l].pitch, nullptr, nullptr, 0, s);
+                // InstFeat::TrackLeft: FeatureTrackByLK(prev padded, cur padded, last_points) without a mask (dynamic_tracker.cpp:409)
+                dv_launch_lk_track(S.padA.pyr, B.pyr, S.tr.last_pts, S.tr.n_feat, T.max_cnt, ctx->cfg.flow_back, 0.5f, S.tr.lk_pts, S.tr.lk_status, s);
+            }
+            dv_launch_compact(S.tr, nullptr, 0, 0, ctx->n_cand, ctx->max_ord, s);      // ReduceVector x4, ++track_cnt; without a previous ROI the object has no points (n_feat == 0)
+            // ErodeMask 5x5 + discs of the tracked points + goodFeaturesToTrack on roi_gray (:418-446)
+            dv_launch_erode((const uint8_t*)S.mask.p, w, h, mp, 5, (uint8_t*)S.tmp.p, mp, (uint8_t*)S.ero.p, mp, s);
+            {
+                GfttTileArgs a{};
+                a.img = B.pyr.L[0].p; a.w = w; a.h = h; a.pitch = B.pyr.L[0].pitch;
+                a.in_mask = (const uint8_t*)S.ero.p; a.mask_pitch = mp;
+                a.disc_pts = S.tr.curr_pts; a.n_disc = S.tr.n_tracked; a.radius = T.min_dist; a.hw = (const uint8_t*)T.hw.p;
+                a.n_feat = S.tr.n_feat; a.max_cnt = T.max_cnt; a.min_new = 1;
+                a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord;
+                dv_launch_gftt_tile(a, s);
+                GfttSelectArgs sa{};
+                sa.cand = (const DvCand*)ctx->cand_buf.p; sa.n_cand = ctx->n_cand; sa.cand_cap = ctx->cand_cap; sa.max_ord = ctx->max_ord;
+                sa.w = w; sa.h = h; sa.quality = 0.01; sa.min_dist = (double)T.min_dist;
+                sa.max_n_host = 0; sa.n_feat = S.tr.n_feat; sa.max_cnt = T.max_cnt; sa.min_new = 1;
+                sa.out_xy = nullptr; sa.n_out = nullptr; sa.tr = S.tr; sa.has_tr = 1; sa.err_flag = ctx->err_flag;
+                if (dv_launch_gftt_select(sa, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
+            }
+            // TrackRightByPad (instance_feature.cpp:251-275): the points move into full-image coordinates, LK left -> right on the full frames
+            if (stereo) dv_launch_lk_track_offset(L, R, S.tr.curr_pts, S.tr.n_feat, T.max_cnt, ctx->cfg.flow_back, 0.5f, (float)S.rx, (float)S.ry, S.tr.right_pts, S.tr.right_status, s);
+            // UndistortedPointsWithAddOffset + PtsVelocity + RightUndistortedPts + RightPtsVelocity + PostProcess -> rows
+            dv_feat* od = (dv_feat*)((uint8_t*)T.out_buf.p + (size_t)out_k * slot_bytes);
+            int* on = (int*)((uint8_t*)od + INST_CAP * sizeof(dv_feat));
+            dv_launch_finalize_offset(S.tr, ctx->cfg.cam0, ctx->cfg.cam1, stereo ? 1 : 0, dt, T.max_cnt, (double)S.rx, (double)S.ry, od, on, s);
+            S.has_prev = true; S.pw = w; S.ph = h;                  // PostProcess: prev_roi_gray = roi_gray (the top-left w x h of roi[cur] level 0)
+            S.out_valid = true; S.out_index = out_k++;
+            T.out_order.push_back(S.id);
+        }
+        if (out_k > 0) DV_CHECK(hipMemcpyAsync(T.out_pinned, T.out_buf.p, (size_t)out_k * slot_bytes, hipMemcpyDeviceToHost, s));
+    }
+    // ---- ManageInstances (:499-514): objects unseen for more than one frame are dropped ----
+    for (auto it = T.slots.begin(); it != T.slots.end();) {
+        Slot& S = it->second;
+        if (S.lost_num == 0 && !S.has_box2d) S.lost_num++;
+        bool erase = false;
+        if (S.lost_num > 0) { S.lost_num++; if (S.lost_num > 3) erase = true; }
+        if (erase) { DV_CHECK(hipStreamSynchronize(s)); S.release(); it = T.slots.erase(it); } else ++it;
+    }
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipEventRecord(T.done, s));
+    T.last_time = T.cur_time; T.pending = true;
+    return 0;
+}
+
+// InstsFeatManager::Output() (:521-577): one FeatureInstance per visible object
+int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n_insts, dv_feat* feats, int cap_feats, int* n_feats, double* points, int cap_points, int* n_points) {
+    if (!ctx) return -1;
+    if (!ctx->inst) DV_FAIL("dv_inst_track: call dv_inst_config first");
+    dv_inst_tracker& T = *ctx->inst;
+    if (!T.pending) DV_FAIL("dv_inst_track_collect: nothing enqueued");
+    if (!n_insts || !n_feats || !n_points) DV_FAIL("dv_inst_track_collect: null counter");
+    DV_CHECK(hipEventSynchronize(T.done));
+    T.pending = false;
+    const size_t slot_bytes = INST_CAP * sizeof(dv_feat) + 64;
+    int ki = 0, kf = 0, kp = 0;
+    for (unsigned id : T.out_order) {
+        auto it = T.slots.find(id);
+        if (it == T.slots.end()) continue;
+        Slot& S = it->second;
+        if (!S.out_valid) continue;
+        const dv_feat* rows = (const dv_feat*)((const uint8_t*)T.out_pinned + (size_t)S.out_index * slot_bytes);
+        const int n = *(const int*)((const uint8_t*)rows + INST_CAP * sizeof(dv_feat));
+        const int np = (int)(S.pts_copy.size() / 3);
+        if (ki >= cap_insts || kf + n > cap_feats || kp + np > cap_points) DV_FAIL("dv_inst_track_collect: output buffers too small");
+        dv_inst_obs& o = insts[ki++];
+        std::memset(&o, 0, sizeof(o));
+        o.id = S.id; o.has_box3d = S.has_box3d ? 1 : 0; o.first_feat = kf; o.n_feats = n; o.first_point = kp; o.n_points = np;
+        o.rect[0] = (float)S.rx; o.rect[1] = (float)S.ry; o.rect[2] = (float)S.rw; o.rect[3] = (float)S.rh;
+        if (S.has_box3d) o.box3d = S.box3d;
+        if (n > 0) std::memcpy(feats + kf, rows, (size_t)n * sizeof(dv_feat));
+        if (np > 0) std::memcpy(points + 3 * (size_t)kp, S.pts_copy.data(), 24 * (size_t)np);
+        kf += n; kp += np;
+    }
+    *n_insts = ki; *n_feats = kf; *n_points = kp;
+    if (*ctx->err_pinned) { /* reported by the next dv_track_stereo_collect */ }
+    return 0;
+}
+
+}  // extern "C"

@@ -222,13 +222,14 @@ __global__ __launch_bounds__(64) void lk_generic_kernel(DvPyr A, DvPyr B, const 
 // FeatureTrackByLK fused: fwd (maxLevel 3) + bwd (maxLevel 1, initial flow) + distance + InBorder
 __global__ __launch_bounds__(64) void lk_track_kernel(DvPyr A, DvPyr B, const float2* __restrict__ pts_a, const int* __restrict__ n_dev,
                                                       int n_host, int flow_back, float dist_thresh, double eps_sq,
-                                                      float2* __restrict__ pts_b, uint8_t* __restrict__ status) {
+                                                      float2* __restrict__ pts_b, uint8_t* __restrict__ status, float add_x, float add_y, int use_add) {
     __shared__ __attribute__((aligned(16))) uint8_t sI[IT_ROWS * IT_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t sJ[JT_ROWS * JT_PITCH];
     const int p = blockIdx.x, lane = threadIdx.x;
     const int n = n_dev ? *n_dev : n_host;
     if (p >= n) return;
-    const float2 prev = pts_a[p];
+    float2 prev = pts_a[p];
+    if (use_add) { prev.x = prev.x + add_x; prev.y = prev.y + add_y; }      // InstFeat::TrackRightByPad: ROI coordinates + box2d->rect.tl() (float + float)
     float2 next = make_float2(0.f, 0.f);
     bool st = true;
     const int mlf = min(3, A.levels - 1);
@@ -257,5 +258,11 @@ void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, con
                         float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s) {
     if (n_max <= 0) return;
     const double eps = 0.01;   // TermCriteria default / feature_utils.cpp:52; OpenCV squares it
-    hipLaunchKernelGGL(lk_track_kernel, dim3(n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status);
+    hipLaunchKernelGGL(lk_track_kernel, dim3(n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status, 0.f, 0.f, 0);
+}
+void dv_launch_lk_track_offset(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back,
+                               float dist_thresh, float add_x, float add_y, float2* pts_b, uint8_t* status, hipStream_t s) {
+    if (n_max <= 0) return;
+    const double eps = 0.01;
+    hipLaunchKernelGGL(lk_track_kernel, dim3(n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status, add_x, add_y, 1);
 }

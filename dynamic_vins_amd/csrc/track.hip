@@ -87,14 +87,16 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(DvTrackState tr, co
 }
 
 __global__ __launch_bounds__(256) void track_finalize_kernel(DvTrackState tr, dv_cam cam0, dv_cam cam1, int stereo, double dt,
-                                                             dv_feat* __restrict__ out, int* __restrict__ n_out) {
+                                                             dv_feat* __restrict__ out, int* __restrict__ n_out, float off_x, float off_y, int use_off) {
     const int n = *tr.n_feat;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) *n_out = n;
     if (i >= n) return;
     const float2 p = tr.curr_pts[i];
     double ux, uy;
-    dv_lift_projective_d(cam0, (double)p.x, (double)p.y, ux, uy);
+    // objects (InstFeat::UndistortedPointsWithAddOffset, instance_feature.cpp:123-133): pt.x + box2d->rect.tl().x is a float + float sum (Box2D::rect is a cv::Rect2f)
+    const float lx = use_off ? p.x + off_x : p.x, ly = use_off ? p.y + off_y : p.y;
+    dv_lift_projective_d(cam0, (double)lx, (double)ly, ux, uy);
     const float2 un = make_float2((float)ux, (float)uy);
     float2 vel = make_float2(0.f, 0.f);
     if (tr.tracked[i]) {
@@ -168,7 +170,8 @@ __global__ __launch_bounds__(256) void lift_kernel(dv_cam cam, const float2* __r
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     double x, y;
-    dv_lift_projective_d(cam, (double)in[i].x + off_x, (double)in[i].y + off_y, x, y);      // offset added in double, like InstFeat::UndistortedPointsWithAddOffset
+    const float fx = off_x != 0.0 ? in[i].x + (float)off_x : in[i].x, fy = off_y != 0.0 ? in[i].y + (float)off_y : in[i].y;      // float + float (Box2D::rect is a cv::Rect2f), then widened
+    dv_lift_projective_d(cam, (double)fx, (double)fy, x, y);
     out[i] = make_float2((float)x, (float)y);
 }
 
@@ -177,7 +180,11 @@ void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_
 }
 void dv_launch_finalize(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, dv_feat* out, int* n_out, hipStream_t s) {
     const int blocks = (n_max + 255) / 256;
-    hipLaunchKernelGGL(track_finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, tr, cam0, cam1, stereo, dt, out, n_out);
+    hipLaunchKernelGGL(track_finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, tr, cam0, cam1, stereo, dt, out, n_out, 0.f, 0.f, 0);
+}
+void dv_launch_finalize_offset(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, double off_x, double off_y, dv_feat* out, int* n_out, hipStream_t s) {
+    const int blocks = (n_max + 255) / 256;
+    hipLaunchKernelGGL(track_finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, tr, cam0, cam1, stereo, dt, out, n_out, (float)off_x, (float)off_y, 1);
 }
 void dv_launch_circle_mask(uint8_t* mask, int w, int h, int pitch, const float2* pts, int n, int radius, const uint8_t* hw, hipStream_t s) {
     if (n <= 0) return;

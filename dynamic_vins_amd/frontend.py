@@ -9,6 +9,11 @@ import numpy as np
 from . import _abi
 from ._abi import DvinsError, dv_cam, dv_config, dv_feat, DV_MEM_HOST, DV_MEM_DEVICE, DV_FMT_BGR, DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC
 
+class dv_inst_det(C.Structure):
+    _fields_ = [("track_id", C.c_uint32), ("class_id", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("mask", C.c_void_p), ("points", C.c_void_p), ("n_points", C.c_int32), ("pad_", C.c_int32)]
+
+
 FEAT_DTYPE = np.dtype([("id", np.uint32), ("track_cnt", np.int32), ("has_right", np.int32), ("pad_", np.int32),
                        ("left", np.float64, 7), ("right", np.float64, 7)])
 assert FEAT_DTYPE.itemsize == C.sizeof(dv_feat) == 128
@@ -72,6 +77,39 @@ class Context:
     def track_stereo_enqueue(self, gray0, gray1, t, mask=None, mode=DV_MODE_RAW, mem=DV_MEM_HOST, stride=None):
         w, h = self.cfg.width, self.cfg.height
         self._check(self.lib.dv_track_stereo_enqueue(self.h, _ptr(gray0), _ptr(gray1), w, h, stride or w, float(t), _ptr(mask), mode, mem))
+
+    # ---- dynamic mode: the per-object tracker (InstsFeatManager) ----
+    def inst_config(self, max_dynamic_cnt=50, min_dynamic_dist=5, use_det3d=0):
+        self._check(self.lib.dv_inst_config(self.h, int(max_dynamic_cnt), int(min_dynamic_dist), int(use_det3d)))
+        from .dynsim import INSTOBS_DTYPE
+        self._inst_out = (np.zeros(64, INSTOBS_DTYPE), np.zeros(64 * 256, FEAT_DTYPE), np.zeros((1 << 16, 3), np.float64))
+
+    def inst_track_enqueue(self, t, dets, boxes3d=None):
+        """dets: list of dict(track_id, class_id, rect=(x, y, w, h), mask=uint8[h, w], points=float64[n, 3] or None); boxes3d: BOX3D_DTYPE array or None.
+        Call right after track_stereo_enqueue of the same frame."""
+        from .dynsim import BOX3D_DTYPE
+        arr = (dv_inst_det * max(len(dets), 1))()
+        self._inst_keep = []
+        for k, d in enumerate(dets):
+            m = np.ascontiguousarray(d["mask"], np.uint8)
+            x, y, w, h = [int(v) for v in d["rect"]]
+            assert m.shape == (h, w)
+            pts = None if d.get("points") is None else np.ascontiguousarray(d["points"], np.float64)
+            self._inst_keep += [m, pts]
+            arr[k].track_id, arr[k].class_id, arr[k].x, arr[k].y, arr[k].w, arr[k].h = int(d["track_id"]), int(d.get("class_id", 0)), x, y, w, h
+            arr[k].mask = m.ctypes.data
+            arr[k].points = pts.ctypes.data if pts is not None and len(pts) else None
+            arr[k].n_points = 0 if pts is None else len(pts)
+        b3 = np.ascontiguousarray(boxes3d, BOX3D_DTYPE) if boxes3d is not None else np.zeros(0, BOX3D_DTYPE)
+        self._inst_keep.append(b3)
+        self._check(self.lib.dv_inst_track_enqueue(self.h, float(t), C.addressof(arr) if len(dets) else None, len(dets), b3.ctypes.data if len(b3) else None, len(b3)))
+
+    def inst_track_collect(self):
+        """-> (insts [INSTOBS_DTYPE], feats [FEAT_DTYPE], points [n, 3]) laid out as Estimator.ProcessMeasurementsDynamic takes them"""
+        oi, of, op = self._inst_out
+        ni, nf, npt = C.c_int(0), C.c_int(0), C.c_int(0)
+        self._check(self.lib.dv_inst_track_collect(self.h, oi.ctypes.data, len(oi), C.byref(ni), of.ctypes.data, len(of), C.byref(nf), op.ctypes.data, len(op), C.byref(npt)))
+        return oi[: ni.value].copy(), of[: nf.value].copy(), op[: npt.value].copy()
 
     def track_stereo_collect(self):
         n = C.c_int(0)

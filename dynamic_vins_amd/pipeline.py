@@ -87,3 +87,103 @@ class Pipeline:
     def ate(self):
         gt = [self.seq.traj.p(t) for t in self.pose_times]
         return sim.align_ate(np.array(self.poses)[:, :3], gt)[0]
+
+
+class DynamicSequence(SyntheticSequence):
+    """SyntheticSequence with moving boxes (dynsim.default_boxes): per frame the stereo pair (resident in HBM), and — as host arrays — what the perception
+    front end of the reference delivers: the inverse merged instance mask, one detection per visible object (track id, rectangle, ROI mask, 3-D box,
+    extra 3-D points sampled from the depth map like InstFeat::DetectExtraPoints, front_end/instance_feature.cpp:413-461) (SURVEY 8(d), dynamic variant)."""
+
+    def __init__(self, w, h, cam, n_frames, rate=20.0, t0=1.0, noise=None, device=None, boxes=None, min_pixels=400, seed=sim.TEX_SEED):
+        import torch
+        from . import dynsim
+        from .render import DynRoomRenderer
+        self.w, self.h, self.cam, self.dt, self.t0 = w, h, cam, 1.0 / rate, t0
+        self.noise = noise or dict(acc_n=0.02, gyr_n=0.002, acc_w=2e-4, gyr_w=2e-5)
+        self.traj = sim.Trajectory()
+        self.boxes = boxes if boxes is not None else dynsim.default_boxes()
+        rr = DynRoomRenderer(cam, w, h, device=device, seed=seed)
+        self.times = [self.t0 + k * self.dt for k in range(n_frames)]
+        self.frames, self.inv_mask, self.inv_mask_dev, self.dets, self.boxes3d = [], [], [], [], []
+        rays = rr.rays.cpu().numpy().reshape(h, w, 3)
+        for t in self.times:
+            left, right, ident, depth = rr.stereo_dynamic(self.traj, t, self.boxes)
+            self.frames.append((left, right))
+            idm, dep = ident.cpu().numpy(), depth.cpu().numpy()
+            self.inv_mask.append(np.ascontiguousarray(np.where(idm == 0, 255, 0).astype(np.uint8)))
+            self.inv_mask_dev.append(torch.where(ident == 0, 255, 0).to(torch.uint8).contiguous())      # resident next to the frames
+            dets, b3 = [], np.zeros(0, dynsim.BOX3D_DTYPE)
+            Rwc, pwc = self.traj.R(t) @ sim.R_IC, self.traj.p(t) + self.traj.R(t) @ sim.T_IC0
+            for b in self.boxes:
+                ys, xs = np.nonzero(idm == b.id)
+                if len(ys) < min_pixels:
+                    continue
+                x0, x1, y0, y1 = int(xs.min()), int(xs.max()), int(ys.min()), int(ys.max())      # VIODE::SetViodeMaskAndRoi: rect = (min_pt, max_pt), i.e. max EXCLUSIVE (cv::Rect(pt1, pt2))
+                rw, rh = x1 - x0, y1 - y0
+                if rw < 24 or rh < 24:
+                    continue
+                mask = np.ascontiguousarray(np.where(idm[y0:y0 + rh, x0:x0 + rw] == b.id, 255, 0).astype(np.uint8))
+                step = int(max(np.sqrt(0.8 * rh * rw / 1000.0), 2.0))                              # DetectExtraPoints: N_max 1000, step >= 2
+                ii, jj = np.mgrid[0:rh:step, 0:rw:step]
+                sel = mask[ii, jj] > 0
+                r, c = ii[sel] + y0, jj[sel] + x0
+                z = dep[r, c]
+                ok = (z > 0.1) & (z <= 100)
+                pts = rays[r[ok], c[ok]] * z[ok, None]
+                Rco = Rwc.T @ b.R(t)
+                bx = np.zeros(1, dynsim.BOX3D_DTYPE)
+                bx["class_id"], bx["score"], bx["center"], bx["dims"] = b.class_id, 0.9, Rwc.T @ (b.p(t) - pwc), b.dims
+                bx["yaw"] = np.arctan2(-Rco[2, 0], Rco[0, 0])
+                bx["rect_min"], bx["rect_max"] = [x0, y0], [x1, y1]
+                b3 = np.concatenate([b3, bx])
+                dets.append(dict(track_id=b.id, class_id=b.class_id, rect=(x0, y0, rw, rh), mask=mask, points=np.ascontiguousarray(pts)))
+            self.dets.append(dets); self.boxes3d.append(b3)
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.imu_t, self.imu_a, self.imu_g = sim.imu_stream(self.traj, self.t0 - 0.05, self.times[-1] + 0.1, 200.0, seed=0xBEEF, **self.noise)
+
+
+class DynamicPipeline(Pipeline):
+    """Pipeline in dynamic mode (cfg::slam == kDynamic): TrackSemanticImage for the background + InstsFeatManager::InstsTrack for the objects on the tracking
+    stream, Estimator::ProcessImage with the object branch (window solve on the BA stream, object solve on a third one)."""
+
+    def __init__(self, seq: DynamicSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, max_dynamic_cnt=50, min_dynamic_dist=5, use_det3d=1,
+                 static_inst_threshold=1.0, mask_morphology_size=0):
+        from .frontend import DV_MODE_SEMANTIC
+        self.seq, self.host = seq, None
+        c = make_cam(*sim.cam_tuple(seq.cam))
+        self.ctx = Context(width=seq.w, height=seq.h, max_cnt=max_cnt, min_dist=min_dist, cam0=c, cam1=c, device=device, mask_morphology_size=mask_morphology_size)
+        self.ctx.inst_config(max_dynamic_cnt, min_dynamic_dist, use_det3d)
+        self.est = Estimator(self.ctx, use_imu=use_imu, stereo=1, max_iters=max_iters, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], dynamic=1, use_det3d=use_det3d,
+                             static_inst_threshold=static_inst_threshold, **seq.noise)
+        self.mode, self.use_det3d = DV_MODE_SEMANTIC, use_det3d
+        self.k_imu = self.next = 0
+        self.enqueued = False
+        self.poses, self.pose_times = [], []
+
+    def _enqueue(self, k):
+        l, r = self.seq.frames[k]
+        self.ctx.track_stereo_enqueue(l.data_ptr(), r.data_ptr(), self.seq.times[k], self.seq.inv_mask_dev[k].data_ptr(), self.mode, DV_MEM_DEVICE)
+        self.ctx.inst_track_enqueue(self.seq.times[k], self.seq.dets[k], self.seq.boxes3d[k] if self.use_det3d else None)
+        self.enqueued = True
+
+    def step(self):
+        k, s = self.next, self.seq
+        if not self.enqueued:
+            self._enqueue(k)
+        rows = self.ctx.track_stereo_collect()
+        insts, ifeats, pts = self.ctx.inst_track_collect()
+        self.enqueued = False
+        t = s.times[k]
+        self._feed_imu(t)
+        if self.est.ProcessMeasurementsDynamicBegin(rows, t, insts, ifeats, pts) != 0:
+            raise RuntimeError("IMU stream does not cover the frame")
+        if k + 1 < len(s.frames):
+            self._enqueue(k + 1)
+            self._feed_imu(s.times[k + 1])
+        st = self.est.ProcessMeasurementsEnd()
+        if st.nonlinear:
+            self.poses.append(self.est.window()[10, :7]); self.pose_times.append(t)
+        self.next += 1
+        self.rows, self.insts, self.ifeats, self.ipts = rows, insts, ifeats, pts
+        return st

@@ -82,3 +82,68 @@ class RoomRenderer:
         for tic in (sim.T_IC0, sim.T_IC1):
             out.append(self._render(R @ sim.R_IC, p + R @ tic))
         return out
+
+
+class DynRoomRenderer(RoomRenderer):
+    """RoomRenderer + rigid textured boxes moving through the room (dynsim.MovingBox): the dynamic variant of SURVEY 8(d).
+    Besides the gray images it returns what the perception front end of the reference would deliver for the LEFT camera: the per-pixel
+    object id (0 = background, MovingBox.id otherwise; the instance masks of SOLOv2 / the VIODE label image) and the depth map
+    (the stereo network's disparity: the source of InstFeat::DetectExtraPoints)."""
+
+    def _render_dyn(self, R_wc, p_wc, boxes, t, want_aux):
+        R = torch.from_numpy(np.ascontiguousarray(R_wc)).to(self.dev, torch.float64)
+        o = torch.from_numpy(np.ascontiguousarray(p_wc)).to(self.dev, torch.float64)
+        d = self.rays @ R.T
+        best_t = torch.full((d.shape[0],), float("inf"), dtype=torch.float64, device=self.dev)
+        uu = torch.zeros_like(best_t); vv = torch.zeros_like(best_t)
+        ident = torch.zeros(d.shape[0], dtype=torch.int32, device=self.dev)
+        faces = [(0, self.half[0], 1, 2, 0.0), (0, -self.half[0], 1, 2, 3.3), (1, self.half[1], 0, 2, 7.1), (1, -self.half[1], 0, 2, 11.7), (2, self.half[2], 0, 1, 17.9), (2, -self.half[2], 0, 1, 23.3)]
+        for axis, pos, a1, a2, offs in faces:
+            tt = (pos - o[axis]) / d[:, axis]
+            ok = (tt > 1e-6) & (tt < best_t)
+            hit1 = o[a1] + tt * d[:, a1]; hit2 = o[a2] + tt * d[:, a2]
+            ok &= (hit1.abs() <= self.half[a1] + 1e-9) & (hit2.abs() <= self.half[a2] + 1e-9)
+            best_t = torch.where(ok, tt, best_t)
+            uu = torch.where(ok, hit1 / self.texel + offs * 97.0, uu)
+            vv = torch.where(ok, hit2 / self.texel + offs * 53.0, vv)
+        for bi, b in enumerate(boxes):
+            Rwo = torch.from_numpy(np.ascontiguousarray(b.R(t))).to(self.dev, torch.float64)
+            Pwo = torch.from_numpy(np.ascontiguousarray(b.p(t))).to(self.dev, torch.float64)
+            half = torch.from_numpy(np.ascontiguousarray(b.dims / 2)).to(self.dev, torch.float64)
+            ob = (o - Pwo) @ Rwo                       # R_wo^T (o - P)
+            db = d @ Rwo
+            inv = 1.0 / torch.where(db.abs() < 1e-12, torch.full_like(db, 1e-12), db)
+            t1 = (-half - ob) * inv; t2 = (half - ob) * inv
+            tmin = torch.minimum(t1, t2).max(1).values; tmax = torch.maximum(t1, t2).min(1).values
+            ok = (tmax >= tmin) & (tmin > 1e-6) & (tmin < best_t)
+            loc = ob + tmin[:, None] * db
+            rel = (loc / half).abs()
+            ax = rel.argmax(1)
+            a1 = torch.where(ax == 0, 1, 0); a2 = torch.where(ax == 2, 1, 2)
+            sgn = torch.gather(loc, 1, ax[:, None])[:, 0].sign()
+            h1 = torch.gather(loc, 1, a1[:, None])[:, 0]; h2 = torch.gather(loc, 1, a2[:, None])[:, 0]
+            offs = 31.0 + 13.0 * bi + 2.0 * ax.to(torch.float64) + (sgn > 0).to(torch.float64)
+            best_t = torch.where(ok, tmin, best_t)
+            uu = torch.where(ok, h1 / (self.texel * 0.6) + offs * 97.0, uu)          # finer texture on the objects: they are closer and smaller
+            vv = torch.where(ok, h2 / (self.texel * 0.6) + offs * 53.0, vv)
+            ident = torch.where(ok, torch.full_like(ident, int(b.id)), ident)
+        size = self.tex.shape[-1]
+
+        def refl(x):
+            x = torch.remainder(x, 2 * size)
+            return torch.where(x >= size, 2 * size - 1 - x, x)
+        gx = (refl(uu) + 0.5) / size * 2 - 1; gy = (refl(vv) + 0.5) / size * 2 - 1
+        grid = torch.stack([gx, gy], -1).view(1, self.h, self.w, 2).to(torch.float32)
+        img = torch.nn.functional.grid_sample(self.tex, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
+        img = (img[0, 0] * 255.0 + 0.5).clamp(0, 255).to(torch.uint8).contiguous()
+        if not want_aux:
+            return img, None, None
+        depth = (best_t * self.rays[:, 2]).view(self.h, self.w)          # z in the camera frame: the ray (x, y, 1) scaled by t
+        return img, ident.view(self.h, self.w).to(torch.uint8).contiguous(), depth
+
+    def stereo_dynamic(self, traj, t, boxes):
+        """-> (left u8, right u8, id map of the left image u8, depth map of the left image f64), all H x W"""
+        R, p = traj.R(t), traj.p(t)
+        left, ident, depth = self._render_dyn(R @ sim.R_IC, p + R @ sim.T_IC0, boxes, t, True)
+        right, _, _ = self._render_dyn(R @ sim.R_IC, p + R @ sim.T_IC1, boxes, t, False)
+        return left, right, ident, depth

@@ -365,6 +365,26 @@ typedef struct dv_inst_state {          /* Instance (estimator/instance.h) as th
     double window[11][7];               /* state[i]: P, then R as qx qy qz qw */
     double time[11];
 } dv_inst_state;
+/* ---- dynamic mode, front end: InstsFeatManager (front_end/dynamic_tracker.h:42-101).  One detection = one Box2D of SemanticImage::boxes2d AFTER the
+ * multi-object tracker assigned its track id (DeepSORT / VIODE keys: upstream).  mask = InstRoi::mask_cv, roi_gray is cropped from the frame by the
+ * library.  points (optional) = InstFeat::extra_points3d of this frame (DetectExtraPoints + PCL clustering: upstream), handed through to the output. */
+typedef struct dv_inst_det {
+    uint32_t track_id; int32_t class_id;
+    int32_t x, y, w, h;                 /* Box2D::rect, inside the image */
+    const uint8_t* mask;                /* h rows of w bytes, > 0 = object (host memory) */
+    const double* points; int32_t n_points, pad_;
+} dv_inst_det;
+/* fe_para::kMaxDynamicCnt / kMinDynamicDist (front_end/front_end_parameters.cpp), cfg::use_det3d; call once before the first frame */
+int dv_inst_config(dv_ctx* ctx, int max_dynamic_cnt, int min_dynamic_dist, int use_det3d);
+int dv_inst_reset(dv_ctx* ctx);
+/* FeatureTrack's object branch for one frame (system/main.cpp:198-250): AddInstancesByTracking + InstsFeatManager::InstsTrack.  Works on the pyramids
+ * of the frame last passed to dv_track_stereo_enqueue (call it right after, same frame; `t` = that frame's time).  boxes3d = SemanticImage::boxes3d
+ * (only read when use_det3d). */
+int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_dets, const dv_box3d* boxes3d, int n_boxes3d);
+/* InstsFeatManager::Output() (front_end/dynamic_tracker.cpp:521-577): waits for the frame; insts / feats / points are laid out as dv_est_process_dynamic takes them */
+int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n_insts, dv_feat* feats, int cap_feats, int* n_feats,
+                          double* points, int cap_points, int* n_points);
+
 /* ProcessMeasurements iteration in dynamic mode: dv_est_process with frame.instances.  insts may be NULL / n_insts 0 (no object in view). */
 int dv_est_process_dynamic(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats,
                            const double* points, dv_est_state* out);

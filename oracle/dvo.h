@@ -214,6 +214,13 @@ typedef struct dvo_inst_state {
     uint32_t id; int32_t is_initial, is_tracking, is_curr_visible, is_static, is_init_velocity, age, lost_number, static_frame, n_landmarks, n_valid, triangle_num;
     double dims[3], vel_v[3], vel_a[3]; double window[11][7]; double time[11];
 } dvo_inst_state;
+/* InstsFeatManager (front_end/dynamic_tracker.{h,cpp}); shares the id counter and the configuration of a dvo_tracker; see front_oracle.cpp */
+typedef struct dvo_inst_det { uint32_t track_id; int32_t class_id; int32_t x, y, w, h; const uint8_t* mask; const double* points; int32_t n_points, pad_; } dvo_inst_det;
+typedef struct dvo_insts dvo_insts;
+dvo_insts* dvo_insts_create(dvo_tracker* background, int max_dynamic_cnt, int min_dynamic_dist, int use_det3d);
+void dvo_insts_destroy(dvo_insts*);
+int dvo_insts_track(dvo_insts*, const uint8_t* gray0, const uint8_t* gray1, double time, const dvo_inst_det* dets, int n_dets, const dvo_box3d* boxes3d, int n_boxes3d);
+int dvo_insts_output(dvo_insts*, dvo_inst_obs* insts, int cap_insts, int* n_insts, dvo_feat* feats, int cap_feats, int* n_feats, double* points, int cap_points, int* n_points);
 /* ProcessImage with the object branch (estimator.cpp:1562-1622,1653-1676); see inst_manager.h */
 int dvo_estimator_process_dynamic(dvo_estimator*, const dvo_feat* feats, int n, double t, const dvo_inst_obs* insts, int n_insts, const dvo_feat* inst_feats,
                                   const double* points, dvo_be_state* out);

@@ -679,7 +679,7 @@ int dvo_inst_track(const uint8_t* prev_roi, int pw, int ph, const uint8_t* cur_r
     *n_cur = (int)cur.size();
     for (size_t i = 0; i < cur.size(); ++i) {
         cur_pts[2 * i] = cur[i].x; cur_pts[2 * i + 1] = cur[i].y; cur_ids[i] = id[i]; cur_cnt[i] = cnt[i];
-        double x, y; lift_projective(*cam0, (double)cur[i].x + box_x, (double)cur[i].y + box_y, x, y);
+        double x, y; lift_projective(*cam0, (double)(cur[i].x + (float)box_x), (double)(cur[i].y + (float)box_y), x, y);      // float + float: Box2D::rect is a cv::Rect2f (basic/box2d.h:56)
         cur_un[2 * i] = (float)x; cur_un[2 * i + 1] = (float)y;
     }
     *n_right = 0;
@@ -697,6 +697,180 @@ int dvo_inst_track(const uint8_t* prev_roi, int pw, int ph, const uint8_t* cur_r
             right_un[2 * i] = (float)x; right_un[2 * i + 1] = (float)y;
         }
     }
+    return 0;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// InstsFeatManager (front_end/dynamic_tracker.{h,cpp}) + InstFeat (front_end/instance_feature.{h,cpp}) with persistent state, as the
+// reference's thread T2 drives them in dynamic mode (system/main.cpp:198-250): visibility reset -> AddInstancesByTracking (:791-828, the
+// detections arrive with their track ids) -> InstsTrack (:348-493) -> Output (:521-577).  Canonical choices: objects are visited in ascending
+// id (reference: unordered_map order), the object tracker runs after the background tracker and shares its id counter
+// (InstFeat::global_id_count is one static, incremented from two threads in the reference).
+struct OInstFeat {
+    unsigned id = 0; int lost_num = 0; bool is_curr_visible = false, has_box2d = false, has_box3d = false;
+    int class_id = 0, rx = 0, ry = 0, rw = 0, rh = 0;
+    dvo_box3d box3d{};
+    std::vector<uint32_t> ids, right_ids; std::vector<int> track_cnt;
+    std::vector<P2f> curr_points, curr_un_points, last_points, right_points, right_un_points, pts_velocity, right_pts_velocity;
+    std::map<uint32_t, P2f> prev_id_pts, curr_id_pts, right_prev_id_pts, right_curr_id_pts;
+    Img roi_gray, prev_roi_gray, mask_cv;
+    std::vector<double> extra_points3d;
+};
+struct dvo_insts {
+    dvo_tracker* bg; int max_cnt, min_dist, use_det3d;
+    std::map<unsigned, OInstFeat> instances;
+    double curr_time = 0, last_time = 0;
+};
+
+static float o_rect_iou(const float a[4], const float b[4]) {      // Box2D::IoU (basic/box2d.cpp:20-27)
+    const float x1 = std::max(a[0], b[0]), y1 = std::max(a[1], b[1]), x2 = std::min(a[0] + a[2], b[0] + b[2]), y2 = std::min(a[1] + a[3], b[1] + b[3]);
+    const float in = (x2 > x1 && y2 > y1) ? (x2 - x1) * (y2 - y1) : 0.f;
+    const float un = a[2] * a[3] + b[2] * b[3] - in;
+    if (un < 2.220446049250313e-16) return 0.f;
+    return in / un;
+}
+
+dvo_insts* dvo_insts_create(dvo_tracker* bg, int max_dynamic_cnt, int min_dynamic_dist, int use_det3d) { return new dvo_insts{ bg, max_dynamic_cnt, min_dynamic_dist, use_det3d }; }
+void dvo_insts_destroy(dvo_insts* m) { delete m; }
+
+int dvo_insts_track(dvo_insts* M, const uint8_t* gray0, const uint8_t* gray1, double time, const dvo_inst_det* dets, int n_dets, const dvo_box3d* boxes3d, int n_boxes3d) {
+    const dvo_fe_config& cfg = M->bg->cfg;
+    const int W = cfg.width, H = cfg.height;
+    M->curr_time = time;
+    for (auto& kv : M->instances) { kv.second.is_curr_visible = false; kv.second.has_box2d = false; kv.second.has_box3d = false; }      // main.cpp:198-202
+    for (int i = 0; i < n_dets; ++i) {          // AddInstancesByTracking
+        const dvo_inst_det& d = dets[i];
+        OInstFeat& I = M->instances[d.track_id];
+        I.id = d.track_id; I.is_curr_visible = true; I.has_box2d = true; I.class_id = d.class_id; I.rx = d.x; I.ry = d.y; I.rw = d.w; I.rh = d.h;
+        I.roi_gray.w = d.w; I.roi_gray.h = d.h; I.roi_gray.d.resize((size_t)d.w * d.h);
+        for (int y = 0; y < d.h; ++y) std::memcpy(&I.roi_gray.d[(size_t)y * d.w], gray0 + (size_t)(d.y + y) * W + d.x, d.w);      // roi_gray = gray0(rect) (basic/semantic_image.cpp:58-59)
+        I.mask_cv.w = d.w; I.mask_cv.h = d.h; I.mask_cv.d.assign(d.mask, d.mask + (size_t)d.w * d.h);
+        I.extra_points3d.assign(d.points ? d.points : nullptr, d.points ? d.points + 3 * (size_t)std::max(d.n_points, 0) : nullptr);
+    }
+    // ---- InstsTrack ----
+    for (auto& kv : M->instances) { if (!kv.second.is_curr_visible) kv.second.lost_num++; else kv.second.lost_num = 0; }
+    if (M->use_det3d) {          // BoxAssociate2Dto3D (:61-152)
+        std::vector<char> match_vec(n_boxes3d, 0);
+        for (auto& kv : M->instances) {
+            OInstFeat& inst = kv.second;
+            if (!inst.is_curr_visible) continue;
+            const float inst_rect[4] = { (float)inst.rx, (float)inst.ry, (float)inst.rw, (float)inst.rh };
+            double min_dist = 1.7976931348623157e308; int min_idx = -1;
+            for (int i = 0; i < n_boxes3d; ++i) {
+                if (match_vec[i]) continue;
+                const dvo_box3d& b = boxes3d[i];
+                const int x0 = cv_round(b.rect_min[0]), y0 = cv_round(b.rect_min[1]), x1 = cv_round(b.rect_max[0]), y1 = cv_round(b.rect_max[1]);
+                const float proj_rect[4] = { (float)x0, (float)y0, (float)(x1 - x0), (float)(y1 - y0) };
+                const float iou = o_rect_iou(inst_rect, proj_rect);
+                if (inst.class_id != b.class_id) continue;
+                if (iou > 0.1f) { const double n = std::sqrt(b.center[0] * b.center[0] + b.center[1] * b.center[1] + b.center[2] * b.center[2]); if (n < min_dist) { min_dist = n; min_idx = i; } }
+            }
+            if (min_idx >= 0) { match_vec[min_idx] = 1; inst.has_box3d = true; inst.box3d = boxes3d[min_idx]; }
+        }
+    }
+    const bool is_exist_inst = n_dets > 0;
+    auto exec = [&](auto f) { for (auto& kv : M->instances) { if (kv.second.lost_num > 0) continue; f(kv.second); } };
+    if (is_exist_inst) {
+        exec([&](OInstFeat& inst) {      // per-object optical flow (:381-413)
+            if (!inst.is_curr_visible) return;
+            if (inst.prev_roi_gray.d.empty() || inst.last_points.empty()) return;
+            const int w = std::max(inst.prev_roi_gray.w, inst.roi_gray.w), h = std::max(inst.prev_roi_gray.h, inst.roi_gray.h);      // InstanceImagePadding
+            std::vector<uint8_t> a((size_t)w * h, 0), b((size_t)w * h, 0);
+            for (int y = 0; y < inst.prev_roi_gray.h; ++y) std::memcpy(&a[(size_t)y * w], &inst.prev_roi_gray.d[(size_t)y * inst.prev_roi_gray.w], inst.prev_roi_gray.w);
+            for (int y = 0; y < inst.roi_gray.h; ++y) std::memcpy(&b[(size_t)y * w], &inst.roi_gray.d[(size_t)y * inst.roi_gray.w], inst.roi_gray.w);
+            // InstFeat::TrackLeft(curr, last) (instance_feature.cpp:149-188)
+            inst.curr_points.assign(inst.last_points.size(), P2f{ 0, 0 });
+            std::vector<uint8_t> status(inst.last_points.size());
+            track_by_lk(a.data(), b.data(), w, h, inst.last_points.data(), (int)inst.last_points.size(), cfg.flow_back != 0, 0.5f, inst.curr_points.data(), status.data());
+            reduce_vector(inst.curr_points, status); reduce_vector(inst.ids, status); reduce_vector(inst.last_points, status); reduce_vector(inst.track_cnt, status);
+            for (auto& n : inst.track_cnt) n++;
+        });
+        exec([&](OInstFeat& inst) {      // corner detection (:418-446)
+            if ((int)inst.curr_points.size() >= M->max_cnt) return;
+            const int max_new_detect = M->max_cnt - (int)inst.curr_points.size();
+            std::vector<uint8_t> er((size_t)inst.mask_cv.w * inst.mask_cv.h);
+            dvo_erode(inst.mask_cv.d.data(), inst.mask_cv.w, inst.mask_cv.h, 5, er.data());
+            inst.mask_cv.d = er;                                               // ErodeMask(mask_cv, mask_cv, 5) works in place
+            std::vector<uint8_t> inst_mask = inst.mask_cv.d;
+            for (size_t i = 0; i < inst.curr_points.size(); ++i) circle_zero(inst_mask.data(), inst.mask_cv.w, inst.mask_cv.h, cv_round(inst.curr_points[i].x), cv_round(inst.curr_points[i].y), M->min_dist);
+            std::vector<P2f> new_pts;
+            gftt(inst.roi_gray.d.data(), inst_mask.data(), inst.roi_gray.w, inst.roi_gray.h, max_new_detect, 0.01, M->min_dist, new_pts);
+            for (auto& pt : new_pts) { inst.curr_points.push_back(pt); inst.ids.push_back(M->bg->global_id_count++); inst.track_cnt.push_back(1); }
+        });
+        const double dt = M->curr_time - M->last_time;
+        for (auto& kv : M->instances) {
+            OInstFeat& inst = kv.second;
+            if (!inst.is_curr_visible) continue;
+            inst.curr_un_points.clear();                                     // UndistortedPointsWithAddOffset (instance_feature.cpp:123-133): float + float, then widened
+            for (auto& pt : inst.curr_points) { double x, y; lift_projective(cfg.cam0, (double)(pt.x + (float)inst.rx), (double)(pt.y + (float)inst.ry), x, y); inst.curr_un_points.push_back({ (float)x, (float)y }); }
+            dvo_tracker::pts_velocity(dt, inst.ids, inst.curr_un_points, inst.curr_id_pts, inst.prev_id_pts, inst.pts_velocity);
+        }
+        if (gray1 && cfg.stereo) exec([&](OInstFeat& inst) {      // TrackRightByPad + RightUndistortedPts + RightPtsVelocity (:462-471)
+            if (!inst.is_curr_visible) return;
+            if (!inst.curr_points.empty()) {
+                inst.right_points.assign(inst.curr_points.size(), P2f{ 0, 0 });
+                std::vector<P2f> padded(inst.curr_points.size());
+                for (size_t i = 0; i < padded.size(); ++i) padded[i] = { inst.curr_points[i].x + (float)inst.rx, inst.curr_points[i].y + (float)inst.ry };
+                std::vector<uint8_t> status(padded.size());
+                track_by_lk(gray0, gray1, W, H, padded.data(), (int)padded.size(), cfg.flow_back != 0, 0.5f, inst.right_points.data(), status.data());
+                inst.right_ids = inst.ids;
+                reduce_vector(inst.right_points, status); reduce_vector(inst.right_ids, status);
+            }                                                              // (empty curr_points: TrackRightByPad returns early and right_points / right_ids keep their old content)
+            inst.right_un_points.clear();
+            for (auto& pt : inst.right_points) { double x, y; lift_projective(cfg.cam1, pt.x, pt.y, x, y); inst.right_un_points.push_back({ (float)x, (float)y }); }
+            dvo_tracker::pts_velocity(dt, inst.right_ids, inst.right_un_points, inst.right_curr_id_pts, inst.right_prev_id_pts, inst.right_pts_velocity);
+        });
+    }
+    // ManageInstances (:499-514)
+    for (auto it = M->instances.begin(); it != M->instances.end();) {
+        OInstFeat& inst = it->second;
+        if (inst.lost_num == 0 && !inst.has_box2d) inst.lost_num++;
+        bool erase = false;
+        if (inst.lost_num > 0) { inst.lost_num++; if (inst.lost_num > 3) erase = true; }
+        if (erase) it = M->instances.erase(it); else ++it;
+    }
+    if (is_exist_inst) exec([&](OInstFeat& inst) {      // PostProcess (instance_feature.h:88-101)
+        inst.last_points = inst.curr_points;
+        inst.prev_id_pts = inst.curr_id_pts; inst.right_prev_id_pts = inst.right_curr_id_pts;
+        inst.prev_roi_gray = inst.roi_gray;
+    });
+    M->last_time = M->curr_time;
+    return 0;
+}
+
+// InstsFeatManager::Output (:521-577)
+int dvo_insts_output(dvo_insts* M, dvo_inst_obs* insts, int cap_insts, int* n_insts, dvo_feat* feats, int cap_feats, int* n_feats, double* points, int cap_points, int* n_points) {
+    int ki = 0, kf = 0, kp = 0;
+    for (auto& kv : M->instances) {
+        OInstFeat& inst = kv.second;
+        if (inst.lost_num > 0 || !inst.is_curr_visible) continue;
+        const int n = (int)inst.curr_un_points.size(), np = (int)(inst.extra_points3d.size() / 3);
+        if (ki >= cap_insts || kf + n > cap_feats || kp + np > cap_points) return -1;
+        dvo_inst_obs& o = insts[ki++];
+        std::memset(&o, 0, sizeof(o));
+        o.id = inst.id; o.has_box3d = inst.has_box3d; o.first_feat = kf; o.n_feats = n; o.first_point = kp; o.n_points = np;
+        o.rect[0] = (float)inst.rx; o.rect[1] = (float)inst.ry; o.rect[2] = (float)inst.rw; o.rect[3] = (float)inst.rh;
+        if (inst.has_box3d) o.box3d = inst.box3d;
+        std::map<uint32_t, size_t> ridx;
+        for (size_t i = 0; i < inst.right_ids.size() && i < inst.right_un_points.size(); ++i) ridx[inst.right_ids[i]] = i;
+        for (int i = 0; i < n; ++i) {
+            dvo_feat& f = feats[kf + i];
+            std::memset(&f, 0, sizeof(f));
+            f.id = inst.ids[i]; f.track_cnt = inst.track_cnt[i];
+            const double l[7] = { inst.curr_un_points[i].x, inst.curr_un_points[i].y, 1, inst.curr_points[i].x, inst.curr_points[i].y, inst.pts_velocity[i].x, inst.pts_velocity[i].y };
+            std::memcpy(f.left, l, sizeof(l));
+            auto it = ridx.find(inst.ids[i]);
+            if (M->bg->cfg.stereo && it != ridx.end()) {
+                const size_t k = it->second; f.has_right = 1;
+                const double r[7] = { inst.right_un_points[k].x, inst.right_un_points[k].y, 1, inst.right_points[k].x, inst.right_points[k].y, inst.right_pts_velocity[k].x, inst.right_pts_velocity[k].y };
+                std::memcpy(f.right, r, sizeof(r));
+            }
+        }
+        if (np) std::memcpy(points + 3 * (size_t)kp, inst.extra_points3d.data(), 24 * (size_t)np);
+        kf += n; kp += np;
+    }
+    *n_insts = ki; *n_feats = kf; *n_points = kp;
     return 0;
 }
 

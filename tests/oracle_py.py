@@ -180,6 +180,9 @@ class Oracle:
         return dict(curr_points=cur_pts[:n], ids=cur_ids[:n], track_cnt=cur_cnt[:n], curr_un_points=cur_un[:n], right_points=r_pts[:m], right_ids=r_ids[:m],
                     right_un_points=r_un[:m]), gid.value
 
+    def insts(self, tracker, max_dynamic_cnt=50, min_dynamic_dist=5, use_det3d=0):
+        return OracleInsts(self, tracker, max_dynamic_cnt, min_dynamic_dist, use_det3d)
+
     def tracker(self, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1):
         return OracleTracker(self, width, height, max_cnt, min_dist, flow_back, stereo, cam0, cam1)
 
@@ -213,6 +216,52 @@ class OracleTracker:
 
     def __del__(self):
         self.close()
+
+
+class dvo_inst_det(C.Structure):
+    _fields_ = [("track_id", C.c_uint32), ("class_id", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),
+                ("mask", C.c_void_p), ("points", C.c_void_p), ("n_points", C.c_int32), ("pad_", C.c_int32)]
+
+
+class OracleInsts:
+    """dvo_insts: InstsFeatManager of the oracle, sharing the id counter of an OracleTracker (the background tracker must run first each frame)"""
+
+    def __init__(self, o, tracker, max_dynamic_cnt, min_dynamic_dist, use_det3d):
+        self.lib, self.tracker = o.lib, tracker
+        L = self.lib
+        L.dvo_insts_create.restype = C.c_void_p
+        L.dvo_insts_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.dvo_insts_destroy.argtypes = [C.c_void_p]
+        L.dvo_insts_track.restype = C.c_int
+        L.dvo_insts_track.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        L.dvo_insts_output.restype = C.c_int
+        L.dvo_insts_output.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        self.h = L.dvo_insts_create(tracker.h, max_dynamic_cnt, min_dynamic_dist, use_det3d)
+
+    def track(self, g0, g1, t, dets, boxes3d, inst_dtype, box_dtype):
+        g0 = np.ascontiguousarray(g0); g1 = np.ascontiguousarray(g1) if g1 is not None else None
+        arr = (dvo_inst_det * max(len(dets), 1))()
+        keep = []
+        for k, d in enumerate(dets):
+            m = np.ascontiguousarray(d["mask"], np.uint8)
+            pts = None if d.get("points") is None else np.ascontiguousarray(d["points"], np.float64)
+            keep += [m, pts]
+            x, y, w, h = [int(v) for v in d["rect"]]
+            arr[k].track_id, arr[k].class_id, arr[k].x, arr[k].y, arr[k].w, arr[k].h = int(d["track_id"]), int(d.get("class_id", 0)), x, y, w, h
+            arr[k].mask = m.ctypes.data
+            arr[k].points = pts.ctypes.data if pts is not None and len(pts) else None
+            arr[k].n_points = 0 if pts is None else len(pts)
+        b3 = np.ascontiguousarray(boxes3d, box_dtype) if boxes3d is not None else np.zeros(0, box_dtype)
+        self.lib.dvo_insts_track(self.h, _p(g0), _p(g1), float(t), C.addressof(arr) if len(dets) else None, len(dets), _p(b3) if len(b3) else None, len(b3))
+        oi, of, op = np.zeros(64, inst_dtype), np.zeros(64 * 256, FEAT_DTYPE), np.zeros((1 << 16, 3))
+        ni, nf, npt = C.c_int(0), C.c_int(0), C.c_int(0)
+        rc = self.lib.dvo_insts_output(self.h, _p(oi), len(oi), C.byref(ni), _p(of), len(of), C.byref(nf), _p(op), len(op), C.byref(npt))
+        assert rc == 0
+        return oi[: ni.value].copy(), of[: nf.value].copy(), op[: npt.value].copy()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.dvo_insts_destroy(self.h); self.h = None
 
 
 class dvo_be_config(C.Structure):

@@ -1,0 +1,91 @@
+"""Dynamic mode end to end (`-m gpu`): rendered stereo frames with 3 moving boxes (dynamic variant) through
+  HIP:    dv_track_stereo (TrackSemanticImage) + dv_inst_track (InstsFeatManager) -> dv_est_process_dynamic (ProcessImage with the object branch)
+  oracle: dvo_tracker (mode 2) + dvo_insts -> dvo_estimator_process_dynamic
+on the same frames, masks, detections and IMU stream.  Bars: background rows AND object rows bit-identical every frame (ids, track counts, fp64 bit
+patterns of the normalised points / velocities), object tables identical (ids, 3-D box association, extra points), estimator flags / counts identical,
+ego window within 1e-5 m, object states within the tolerances of tests/test_dynamic_parity.py."""
+import numpy as np
+import pytest
+
+from dynamic_vins_amd import dynsim, sim
+
+pytestmark = pytest.mark.gpu
+
+INT_FIELDS = ["id", "is_initial", "is_tracking", "is_curr_visible", "is_static", "is_init_velocity", "age", "lost_number", "static_frame", "n_landmarks", "n_valid", "triangle_num"]
+
+
+def rows_equal(a, b, what):
+    assert len(a) == len(b), f"{what}: {len(a)} vs {len(b)} rows"
+    assert np.array_equal(a["id"], b["id"]) and np.array_equal(a["track_cnt"], b["track_cnt"]) and np.array_equal(a["has_right"], b["has_right"]), what
+    assert np.array_equal(a["left"].view(np.uint64), b["left"].view(np.uint64)), what
+    assert np.array_equal(a["right"].view(np.uint64), b["right"].view(np.uint64)), what
+
+
+def run(oracle, w, h, frames, max_cnt, min_dist, iters, use_det3d=1, morph=0, drop=()):
+    from dynamic_vins_amd.pipeline import DynamicPipeline, DynamicSequence
+    cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    seq = DynamicSequence(w, h, cam, frames, rate=20.0)
+    for k in drop:                       # frames where the detector saw nothing
+        seq.dets[k], seq.boxes3d[k] = [], np.zeros(0, dynsim.BOX3D_DTYPE)
+    pipe = DynamicPipeline(seq, max_cnt=max_cnt, min_dist=min_dist, max_iters=iters, use_det3d=use_det3d, mask_morphology_size=morph)
+    camt = sim.cam_tuple(cam)
+    trk = oracle.tracker(w, h, max_cnt, min_dist, 1, 1, camt, camt)
+    oin = oracle.insts(trk, 50, 5, use_det3d)
+    est = oracle.estimator(use_imu=1, stereo=1, max_iters=iters, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], dynamic=1, use_det3d=use_det3d, static_inst_threshold=1.0, **seq.noise)
+    k_imu = 0
+    stats = dict(obj_rows=0, objs=set(), initial=0, solved=0, max_dp=0.0, obj_p=0.0, obj_q=0.0)
+    for k in range(frames):
+        t = seq.times[k]
+        sd = pipe.step()
+        while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
+            est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
+        left, right = seq.host_frame(k)
+        rows_o = trk.track_image(left, right, t, mask=seq.inv_mask[k], mode=2, erode_k=morph)
+        io, fo, po = oin.track(left, right, t, seq.dets[k], seq.boxes3d[k] if use_det3d else None, dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
+        rows_equal(pipe.rows, rows_o, f"frame {k} background")
+        assert len(io) == len(pipe.insts), f"frame {k}: {len(io)} vs {len(pipe.insts)} objects"
+        for name in ["id", "has_box3d", "first_feat", "n_feats", "first_point", "n_points"]:
+            assert np.array_equal(io[name], pipe.insts[name]), f"frame {k}: {name} {io[name]} vs {pipe.insts[name]}"
+        assert np.array_equal(io["rect"], pipe.insts["rect"]) and io["box3d"].tobytes() == pipe.insts["box3d"].tobytes(), f"frame {k}"
+        rows_equal(pipe.ifeats, fo, f"frame {k} objects")
+        assert np.array_equal(po, pipe.ipts)
+        stats["obj_rows"] += len(fo); stats["objs"].update(int(i) for i in io["id"])
+        rc, so = est.process_dynamic(rows_o, t, io, fo, po)
+        assert rc == 0
+        assert (sd.frame, sd.nonlinear, sd.margin_old, sd.n_landmarks, sd.n_long, sd.iterations) == (so.frame, so.nonlinear, so.margin_old, so.n_landmarks, so.n_long, so.iterations), f"frame {k}"
+        stats["max_dp"] = max(stats["max_dp"], np.abs(pipe.est.window()[:, :3] - est.window()[:, :3]).max())
+        Io, So = est.instances(dynsim.INSTSTATE_DTYPE)
+        Id, Sd = pipe.est.instances()
+        assert len(Io) == len(Id)
+        for name in INT_FIELDS:
+            assert np.array_equal(Io[name], Id[name]), f"frame {k}: {name} {Io[name]} vs {Id[name]}"
+        assert So[0] == Sd[0] and So[1] == Sd[1], f"frame {k}: {So} vs {Sd}"
+        stats["solved"] += int(So[0] > 0)
+        for a, b in zip(Io, Id):
+            stats["initial"] += int(a["is_initial"])
+            stats["obj_p"] = max(stats["obj_p"], np.abs(a["window"][:, :3] - b["window"][:, :3]).max())
+            qa, qb = a["window"][:, 3:], b["window"][:, 3:]
+            sg = np.sign((qa * qb).sum(1, keepdims=True)); sg[sg == 0] = 1
+            stats["obj_q"] = max(stats["obj_q"], np.abs(qa - sg * qb).max())
+    ate = pipe.ate()
+    pipe.ctx.close()
+    return stats, ate
+
+
+def test_dynamic_pipeline_matches_oracle_640(oracle):
+    stats, ate = run(oracle, 640, 360, 40, 150, 20, 8)
+    assert stats["obj_rows"] > 500 and len(stats["objs"]) >= 2 and stats["initial"] > 10 and stats["solved"] > 5, stats
+    assert stats["max_dp"] < 1e-5 and stats["obj_p"] < 1e-5 and stats["obj_q"] < 1e-6, stats
+    assert ate < 0.05
+
+
+def test_dynamic_pipeline_bench_workload_1280(oracle):
+    """the bench's dynamic workload: 1280x720, max_cnt 250 / min_dist 25, 10 iterations; with detector drop-outs and in-tracker mask erosion"""
+    stats, ate = run(oracle, 1280, 720, 30, 250, 25, 10, morph=5, drop=(17, 18, 24))
+    assert stats["obj_rows"] > 500 and stats["solved"] > 3, stats
+    assert stats["max_dp"] < 1e-5 and stats["obj_p"] < 1e-5 and stats["obj_q"] < 1e-6, stats
+
+
+def test_dynamic_pipeline_without_det3d(oracle):
+    stats, ate = run(oracle, 640, 360, 30, 150, 20, 8, use_det3d=0)
+    assert stats["max_dp"] < 1e-5 and stats["obj_p"] < 1e-5, stats

@@ -1,22 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py — stereo frames/sec through track + BA (BASELINE.json metric) on synthetic 1280x720 stereo + IMU.
+"""bench.py — stereo frames/sec through track + BA (BASELINE.json metric) on synthetic stereo + IMU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--mode raw|dynamic] [--config zed|euroc|kitti] [--every-second-frame] [--shard]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A step = one stereo frame through the HIP front end (FeatureTracker::TrackImage) and the HIP back end
-(Estimator::ProcessImage, bundle adjustment + marginalization on EVERY frame, i.e. the KITTI convention; the
-reference forwards only every 2nd frame on the other datasets, system/main.cpp:300-307).  Frames are rendered once
-and are resident in HBM before the timed region.  N > 1: every rank runs an independent sequence (replicas — the
-single-window problem has ~300 landmarks and does not shard usefully, DESIGN.md "Multi-GPU"); value is the
-whole-job rate, scaling is weak, no data-path collective.
+A step = one stereo frame through the HIP front end (FeatureTracker::TrackImage, or TrackSemanticImage + InstsFeatManager::InstsTrack in
+dynamic mode) and the HIP back end (Estimator::ProcessImage: bundle adjustment + marginalization on EVERY frame = the KITTI convention; the
+reference forwards only every 2nd frame on the other datasets, system/main.cpp:300-307: --every-second-frame).  Frames (and masks) are rendered
+once and are resident in HBM before the timed region.  Default workload = the configuration BASELINE.json's metric is quoted on: 1280x720 ZED.
 
-Prints ONE JSON line on rank 0, with `roofline` (dominant kernel, HIP-event timed per launch on its own stream)
-and `cpu_baseline` (the CPU oracle = restated reference path, bounded sample, rank 0, N = 1 only).
+N > 1, default: every rank runs an independent sequence (replicas: config 4's "batched" axis); value = whole-job rate, weak scaling, no
+data-path collective.  --shard: ONE window solve sharded by landmark over the N ranks with the reduced-system all-reduce —
+a BA-only microbench whose line is reported separately.
+
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed per launch on its own stream, a second instrumented pass) and
+`cpu_baseline` (the CPU oracle = restated reference path, bounded sample, rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,6 +28,28 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+CONFIGS = {                # primary + the two secondary sizes
+    "zed": dict(w=1280, h=720, max_cnt=250, min_dist=25, iters=10, use_imu=1),
+    "euroc": dict(w=752, h=480, max_cnt=150, min_dist=30, iters=8, use_imu=1),
+    "kitti": dict(w=1242, h=375, max_cnt=250, min_dist=25, iters=10, use_imu=0),
+}
+
+
+def git_head():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -32,15 +57,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--width", type=int, default=1280)
-    ap.add_argument("--height", type=int, default=720)
-    ap.add_argument("--max-cnt", type=int, default=250)
-    ap.add_argument("--min-dist", type=int, default=25)
-    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--mode", choices=["raw", "dynamic"], default="raw")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="zed")
+    ap.add_argument("--every-second-frame", action="store_true", help="the reference's convention outside KITTI: only every 2nd tracked frame gets BA (system/main.cpp:300-307)")
+    ap.add_argument("--shard", action="store_true", help="BA-only: one window sharded by landmark over the ranks (reduced-system all-reduce)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16)
     ap.add_argument("--host-frames", action="store_true", help="frames handed over as host buffers: the PCIe-inclusive rate (never the headline value)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
 
     import numpy as np
     import torch
@@ -50,7 +75,6 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one process per GPU.  BENCH_DEVICE / BENCH_BACKEND exist only to rehearse the multi-rank control flow on a 1-GPU box
-    # (both ranks on device 0, gloo instead of RCCL); the driver's 2/4/8-GPU runs use LOCAL_RANK and "nccl" = RCCL over xGMI.
     forced_dev = os.environ.get("BENCH_DEVICE")
     torch.cuda.set_device(int(forced_dev) if forced_dev is not None else int(os.environ.get("LOCAL_RANK", "0")))
     rank, world, local_rank = dv_dist.init(prefer_gpu=os.environ.get("BENCH_BACKEND", "nccl") != "gloo")
@@ -58,121 +82,204 @@ def main():
         local_rank = int(forced_dev)
 
     from dynamic_vins_amd import sim
-    from dynamic_vins_amd.pipeline import Pipeline, SyntheticSequence
 
-    warmup = max(args.warmup, 12)          # the estimator needs kWinSize+1 = 11 frames to initialise (estimator.cpp:1464-1483)
-    n_frames = warmup + args.steps + 1
-    cam = sim.ZED if args.width == 1280 else sim.scaled_cam(sim.ZED, args.width, args.height, 1280, 720)
-    seq = SyntheticSequence(args.width, args.height, cam, n_frames, rate=20.0, phase=dv_dist.sequence_phase(rank), device=f"cuda:{local_rank}")
+    if args.shard:
+        from dynamic_vins_amd.shard_bench import run_shard_bench
+        run_shard_bench(args, rank, world, local_rank)
+        dv_dist.barrier(); dv_dist.finalize()
+        return
 
-    def run(kernel_timing, collective=True):       # collective=False: rank-0-only pass, no barriers
-        pipe = Pipeline(seq, max_cnt=args.max_cnt, min_dist=args.min_dist, max_iters=args.iters, device=local_rank, host_frames=args.host_frames)
-        for _ in range(warmup):
+    from dynamic_vins_amd.pipeline import DynamicPipeline, DynamicSequence, Pipeline, SyntheticSequence
+
+    w, h = cfg["w"], cfg["h"]
+    stride = 2 if args.every_second_frame else 1
+    warm_ba = max(args.warmup, 12)            # the estimator needs kWinSize+1 = 11 BA frames to initialise (estimator.cpp:1464-1483)
+    n_frames = (warm_ba + 2 * args.steps) * stride + 2
+    cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    dev = f"cuda:{local_rank}"
+    if args.mode == "dynamic":
+        seq = DynamicSequence(w, h, cam, n_frames, rate=20.0, device=dev)
+    else:
+        seq = SyntheticSequence(w, h, cam, n_frames, rate=20.0, phase=dv_dist.sequence_phase(rank), device=dev)
+
+    def make_pipe():
+        if args.mode == "dynamic":
+            return DynamicPipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"])
+        return Pipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"], host_frames=args.host_frames,
+                        ba_stride=stride)
+
+    def run(kernel_timing, collective=True, blocks=2):       # collective=False: rank-0-only pass, no barriers
+        pipe = make_pipe()
+        for _ in range(warm_ba * stride):
             pipe.step()
         if kernel_timing:
             pipe.ctx.timing_enable(2)
-        if collective:
-            dv_dist.barrier()
-        torch.cuda.synchronize()
-        pipe.ctx.sync()
-        t0 = time.perf_counter()
-        iters = 0
-        for _ in range(args.steps):
-            st = pipe.step()
-            iters += st.iterations
-        pipe.ctx.sync()
-        torch.cuda.synchronize()
-        if collective:
-            dv_dist.barrier()
-        dt = time.perf_counter() - t0
-        return pipe, dt, iters
+        times, iters = [], 0
+        for _b in range(blocks):             # two consecutive blocks of `steps` frames: a cold first block shows up instead of lowering the headline
+            if collective:
+                dv_dist.barrier()
+            torch.cuda.synchronize(); pipe.ctx.sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                for _s in range(stride):
+                    st = pipe.step()
+                iters += st.iterations
+            pipe.ctx.sync(); torch.cuda.synchronize()
+            if collective:
+                dv_dist.barrier()
+            times.append(time.perf_counter() - t0)
+        return pipe, times, iters
 
-    pipe, dt, iters = run(False)
-    dt = dv_dist.max_over_ranks(dt, device=f"cuda:{local_rank}" if os.environ.get("BENCH_BACKEND", "nccl") != "gloo" else "cpu")
+    pipe, times, iters = run(False)
+    red_dev = dev if os.environ.get("BENCH_BACKEND", "nccl") != "gloo" else "cpu"
+    times = [dv_dist.max_over_ranks(t, device=red_dev) for t in times]
+    dt = times[0]                            # the contract: EXACTLY K timed steps -> the first block is the reported one
     ate = pipe.ate()
     n_lm = int(pipe.est.state.n_long)
     nfeat = len(pipe.rows)
+    dyn_info = None
+    if args.mode == "dynamic":
+        I, S = pipe.est.instances()
+        dyn_info = dict(objects_tracked=int(len(I)), objects_initialised=int(I["is_initial"].sum()) if len(I) else 0,
+                        object_features_per_frame=int(len(pipe.ifeats)), object_solve_iterations=int(S[0]))
+    dev_poses, dev_times = np.array(pipe.poses), list(pipe.pose_times)
     pipe.ctx.close()
 
     # ---- roofline of the dominant kernel: second, instrumented pass over the same timed region ----
-    roof = None
-    kern = {}
+    roof, kern = None, {}
     if rank == 0:
-        pipe2, _, _ = run(True, collective=False)
-        names = ["k_be_solve", "k_be_reduce", "k_be_eval_full", "k_be_eval_cost", "k_be_accept", "k_be_marg",
-                 "pyr", "lk_temporal", "compact", "gftt_eig", "gftt_select", "lk_stereo", "finalize"]
+        pipe2, _, _ = run(True, collective=False, blocks=1)
+        names = ["k_be_solve", "k_be_reduce", "k_be_eval_full", "k_be_eval_cost", "k_be_accept", "k_be_marg", "obj_solve",
+                 "pyr", "lk_temporal", "compact", "gftt_eig", "gftt_select", "lk_stereo", "finalize", "inst_track"]
         for nme in names:
             ms, cnt = pipe2.ctx.timing_get(nme)
             if cnt:
                 kern[nme] = dict(total_ms=ms, launches=cnt, avg_us=ms / cnt * 1e3)
-        dom = max(kern, key=lambda k: kern[k]["total_ms"])
-        n_state, L = 165, n_lm
-        # algorithmic bytes per launch (DESIGN.md "Kernels and rooflines")
+        dom = max((k for k in kern if k != "inst_track"), key=lambda k: kern[k]["total_ms"])
+        n_state = 165 if cfg["use_imu"] else 60
+        L = n_lm
+        # ALGORITHMIC bytes per launch
         alg = {
             "k_be_solve": 2 * n_state * n_state * 8 + 3 * L * 69 * 8,          # Hd + Sc once, three passes over (w[66], h, g, scale) per landmark
             "k_be_reduce": L * 928 * 8 + 2 * n_state * n_state * 8,            # every packet once + Hd, Sc written
             "k_be_eval_full": L * (16 + 928 * 8) + L * 20 * 112,               # factor records read, packet written
             "k_be_marg": 97 * 97 * 8 * 2 + 150 * 20 * 112,
             "lk_temporal": nfeat * 6 * 2 * 529, "lk_stereo": nfeat * 6 * 2 * 529,
-            "gftt_eig": 2 * args.width * args.height, "pyr": int(2 * 1.328 * args.width * args.height),
-        }.get(dom, 0)
+            "gftt_eig": 2 * w * h, "pyr": int(2 * 1.328 * w * h),
+        }.get(dom)
         avg_s = kern[dom]["avg_us"] * 1e-6
-        achieved = alg / avg_s / 1e9 if avg_s > 0 else 0.0
-        # HBM-side bytes per launch from the committed PMC passes (profiles/pmc_traffic.json; a PMC run cannot share a process with the timed run)
-        traffic = None
+        achieved = (alg / avg_s / 1e9) if (alg and avg_s > 0) else None
+        # HBM-side bytes per launch from the committed PMC passes (a --pmc run cannot share a process with the timed run); only trusted if the
+        # file was collected at this HEAD
+        traffic, stale = None, None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["kernels"]
-            key = {"k_be_solve": "be_solve_kernel<1>", "k_be_reduce": "be_reduce_kernel", "k_be_eval_full": "be_eval_kernel<true>", "k_be_eval_cost": "be_eval_kernel<false>",
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = {"k_be_solve": "be_solve_kernel", "k_be_reduce": "be_reduce_kernel", "k_be_eval_full": "be_eval_kernel<true>", "k_be_eval_cost": "be_eval_kernel<false>",
                    "lk_temporal": "lk_track_kernel", "lk_stereo": "lk_track_kernel", "gftt_eig": "gftt_tile_kernel", "gftt_select": "gftt_select_kernel", "pyr": "pyr_down_kernel"}.get(dom)
-            if key in pmc:
-                traffic = int(pmc[key]["traffic_bytes"])
+            hit = [v for k, v in pmc["kernels"].items() if key and k.startswith(key)]
+            if hit:
+                traffic = int(hit[0]["traffic_bytes"])
+            stale = pmc.get("git_head") != git_head()
         except (OSError, KeyError, ValueError):
             traffic = None
-        roof = {"kernel": (dom[2:] if dom.startswith("k_") else dom), "bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_us": round(kern[dom]["avg_us"], 2),
-                "algorithmic_bytes_per_launch": int(alg),
+        # end-to-end figure with SURVEY 8(d)'s algorithmic bytes: front end 4.66 P + 12.7 kB N ; back end E F 112 B (fused into the Schur accumulation)
+        F_blocks = L * 12                      # ~12 residual blocks per landmark in the full window (measured: 3.0-3.4 k for 260-280 landmarks)
+        e2e_bytes = 4.66 * w * h + 12700.0 * nfeat + (iters / max(2 * args.steps, 1) + 1) * F_blocks * 112
+        roof = {"kernel": (dom[2:] if dom.startswith("k_") else dom),
+                "bound": "hbm", "bound_note": "priced against HBM as the contract asks; the kernel is latency-bound (one workgroup, sequential pivots), see DESIGN.md 4",
+                "achieved": None if achieved is None else round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 6), "traffic": None if stale else traffic, "traffic_stale": stale,
+                "avg_launch_us": round(kern[dom]["avg_us"], 2), "algorithmic_bytes_per_launch": alg,
+                "end_to_end": {"algorithmic_bytes_per_frame": int(e2e_bytes), "achieved_GBs": round(e2e_bytes * args.steps / dt / 1e9, 3),
+                               "frac": round(e2e_bytes * args.steps / dt / 1e9 / HBM_PEAK_GBS, 6)},
                 "kernels_us": {(k[2:] if k.startswith("k_") else k): round(v["avg_us"], 1) for k, v in kern.items()}}
         pipe2.ctx.close()
 
-    # ---- CPU baseline: the oracle (restated reference path) on a bounded sample of the same workload ----
-    cpu = None
+    # ---- CPU baseline: the oracle (restated reference path) on a bounded sample of the same workload; also gives the oracle trajectory ----
+    cpu, ate_vs_oracle = None, None
     if rank == 0 and args.gpus == 1 and not args.no_cpu_baseline:
         from tests import oracle_py
-        o = oracle_py.load()
+        flags = "-O3 -march=native -ffp-contract=off"
+        try:           # timing build for THIS host; falls back to the checker's -O2 build
+            subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "fast"], timeout=300)
+            import ctypes
+            o = oracle_py.Oracle(ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libdvins_oracle_fast.so")))
+        except Exception:
+            o, flags = oracle_py.load(), "-O2 -ffp-contract=off"
+        ncores = os.cpu_count() or 1
         camt = sim.cam_tuple(cam)
-        trk = o.tracker(args.width, args.height, args.max_cnt, args.min_dist, 1, 1, camt, camt)
-        est = o.estimator(use_imu=1, stereo=1, max_iters=args.iters, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], **seq.noise)
-        nf = min(args.cpu_frames + 12, n_frames)
-        host = [seq.host_frame(k) for k in range(nf)]
-        k_imu, t_cpu, counted = 0, 0.0, 0
-        for k in range(nf):
-            t = seq.times[k]
-            while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
-                est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu])
-                k_imu += 1
-            a = time.perf_counter()
-            rows = trk.track_image(host[k][0], host[k][1], t)
-            rc, st = est.process(rows, t)
-            b = time.perf_counter()
-            if k >= 12:            # steady state only (window full, marginalization active), like the GPU timed region
-                t_cpu += b - a
-                counted += 1
-        cpu = {"value": round(counted / t_cpu, 3), "unit": "frames/s", "cores": 1, "kind": "port",
-               "sample": f"{counted} steady-state frames of the same {args.width}x{args.height} sequence (CPU oracle: LK + Shi-Tomasi + dense-Schur dogleg BA + marginalization, single thread, g++ -O2)"}
+
+        def cpu_run(threads, frames_wanted):
+            o.lib.dvo_set_threads(threads)
+            trk = o.tracker(w, h, cfg["max_cnt"], cfg["min_dist"], 1, 1, camt, camt)
+            kw = dict(use_imu=cfg["use_imu"], stereo=1, max_iters=cfg["iters"], ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], **seq.noise)
+            if args.mode == "dynamic":
+                from dynamic_vins_amd import dynsim
+                oin = o.insts(trk, 50, 5, 1)
+                est = o.estimator(dynamic=1, use_det3d=1, static_inst_threshold=1.0, **kw)
+            else:
+                est = o.estimator(**kw)
+            nf = min((frames_wanted + 12) * stride, n_frames)
+            host = [seq.host_frame(k) for k in range(nf)]
+            k_imu, t_fe, t_be, counted, poses, ptimes = 0, 0.0, 0.0, 0, [], []
+            for k in range(nf):
+                t = seq.times[k]
+                while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
+                    est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
+                a = time.perf_counter()
+                if args.mode == "dynamic":
+                    rows = trk.track_image(host[k][0], host[k][1], t, mask=seq.inv_mask[k], mode=2)
+                    io, fo, po = oin.track(host[k][0], host[k][1], t, seq.dets[k], seq.boxes3d[k], dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
+                else:
+                    rows = trk.track_image(host[k][0], host[k][1], t)
+                b = time.perf_counter()
+                do_ba = (k % stride) == stride - 1
+                st = None
+                if do_ba:
+                    rc, st = est.process_dynamic(rows, t, io, fo, po) if args.mode == "dynamic" else est.process(rows, t)
+                c = time.perf_counter()
+                if st is not None and st.nonlinear:
+                    poses.append(est.window()[10, :3].copy()); ptimes.append(t)
+                if k >= 12 * stride:          # steady state only (window full, marginalization active), like the GPU timed region
+                    t_fe += b - a; t_be += c - b; counted += 1
+            return counted, t_fe, t_be, np.array(poses), ptimes
+
+        n1, fe1, be1, poses_o, ptimes_o = cpu_run(1, args.cpu_frames)
+        nN, feN, beN, _, _ = cpu_run(ncores, args.cpu_frames)
+        o.lib.dvo_set_threads(1)
+        cpu = {"value": round(n1 / (fe1 + be1), 3), "unit": "frames/s", "cores": 1, "kind": "port",
+               "value_all_cores": round(nN / (feN + beN), 3), "cores_all": ncores, "host_cpu": cpu_model(), "host_nproc": ncores, "flags": "g++ " + flags,
+               "front_end_ms": {"1_thread": round(fe1 / n1 * 1e3, 2), f"{ncores}_threads": round(feN / nN * 1e3, 2)},
+               "back_end_ms": {"1_thread": round(be1 / n1 * 1e3, 2), "4_threads_in_marginalization": round(beN / nN * 1e3, 2)},
+               "sample": f"{n1} steady-state frames of the same {w}x{h} {args.mode} sequence: CPU oracle = restated reference path (LK + Shi-Tomasi + dense-Schur dogleg BA + "
+                         f"marginalization{' + object branch' if args.mode == 'dynamic' else ''}); 'value' = 1 thread, 'value_all_cores' = LK over all cores + 4-thread marginalization (the reference's threading)"}
+        # ATE of the HIP trajectory against the ORACLE trajectory on the frames both produced (north_star's acceptance figure; outside the timed region)
+        common = [i for i, tt in enumerate(ptimes_o) if tt in dev_times]
+        if len(common) >= 3:
+            d_idx = [dev_times.index(ptimes_o[i]) for i in common]
+            ate_vs_oracle = float(sim.align_ate(dev_poses[d_idx, :3], poses_o[common])[0])
 
     if rank == 0:
         value = dv_dist.whole_job_rate(args.steps, world, dt)
-        out = {
-            "metric": "stereo frames/sec (track+BA)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if not args.host_frames else "synthetic (host buffers, PCIe upload inside the timed region)",
-            "config": {"workload": f"synthetic {args.width}x{args.height} stereo @20 Hz + IMU @200 Hz, ZED intrinsics with distortion, figure-8 in a textured box room, "
-                                   f"max_cnt {args.max_cnt}, min_dist {args.min_dist}, flow_back 1, {args.iters} solver iterations, BA + marginalization on every frame",
-                       "parallelism": f"replicas x{world} (independent sequences, no collective)", "landmarks_in_window": n_lm, "features_per_frame": nfeat,
-                       "solver_iterations_per_frame": round(iters / args.steps, 2), "ate_rmse_m_vs_ground_truth": round(ate, 5),
-                       "warmup_requested": args.warmup,
-                       "warmup_note": "at least 12 untimed frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
+        label = {"zed": "ZED intrinsics with distortion", "euroc": "EuRoC-like", "kitti": "KITTI-like, vision only"}[args.config]
+        conf = {"workload": f"synthetic {w}x{h} stereo @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "") + f", {label}, figure-8 in a textured box room"
+                            + (", 3 moving textured boxes with instance masks, 3-D detections and depth-sampled extra points (dynamic mode: TrackSemanticImage + InstsTrack + object solve)" if args.mode == "dynamic" else "")
+                            + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, flow_back 1, {cfg['iters']} solver iterations, "
+                            + ("BA + marginalization on every 2nd tracked frame (reference convention outside KITTI); a step = one BA frame = two tracked frames" if args.every_second_frame
+                               else "BA + marginalization on every frame"),
+                "mode": args.mode, "config": args.config,
+                "parallelism": f"replicas x{world} (independent sequences, no collective)", "landmarks_in_window": n_lm, "features_per_frame": nfeat,
+                "solver_iterations_per_frame": round(iters / (2 * args.steps), 2), "ate_rmse_m_vs_ground_truth": round(ate, 5),
+                "ate_rmse_m_vs_oracle": None if ate_vs_oracle is None else float(f"{ate_vs_oracle:.3e}"),
+                "second_block_ms_per_step": round(times[1] / args.steps * 1e3, 4), "second_block_value": round(dv_dist.whole_job_rate(args.steps, world, times[1]), 2),
+                "warmup_requested": args.warmup, "git_head": git_head(),
+                "warmup_note": "at least 12 untimed BA frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"}
+        if dyn_info:
+            conf["dynamic"] = dyn_info
+        out = {"metric": "stereo frames/sec (track+BA)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm_ba,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic" if not args.host_frames else "synthetic (host buffers, PCIe upload inside the timed region)",
+               "config": conf, "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     dv_dist.barrier()          # every rank stays until rank 0 has finished its extra passes
     dv_dist.finalize()

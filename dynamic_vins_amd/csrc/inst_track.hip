@@ -207,6 +207,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         }
     }
     T.out_order.clear();
+    StageScope sc_all(ctx, "inst_track");
     if (n_dets > 0) {
         // masks: one pinned staging area, one H2D per object (sources are pageable caller memory)
         if (T.pinned_in_bytes < mask_bytes) {

@@ -29,7 +29,7 @@ class SyntheticSequence:
 
 
 class Pipeline:
-    def __init__(self, seq: SyntheticSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, host_frames=False):
+    def __init__(self, seq: SyntheticSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, host_frames=False, ba_stride=1):
         self.seq = seq
         self.host = [seq.host_frame(k) for k in range(len(seq.frames))] if host_frames else None
         c = make_cam(*sim.cam_tuple(seq.cam))
@@ -39,6 +39,8 @@ class Pipeline:
         self.next = 0
         self.enqueued = False
         self.poses, self.pose_times = [], []
+        self.ba_stride = ba_stride          # 2: only every 2nd tracked frame is forwarded to the back end (system/main.cpp:300-307)
+        self.last_state = None
 
     def _enqueue(self, k):
         if self.host is not None:                      # host buffers: the upload rides on the tracking stream
@@ -69,6 +71,12 @@ class Pipeline:
         rows = self.ctx.track_stereo_collect()
         self.enqueued = False
         t = s.times[k]
+        if self.ba_stride > 1 and (k % self.ba_stride) != self.ba_stride - 1:      # tracked only: the frame is not pushed to the feature queue
+            if k + 1 < len(s.frames):
+                self._enqueue(k + 1)
+            self.next += 1
+            self.rows = rows
+            return self.last_state if self.last_state is not None else self.est.state
         self._feed_imu(t)
         rc = self.est.ProcessMeasurementsBegin(rows, t)
         if rc != 0:
@@ -82,6 +90,7 @@ class Pipeline:
             self.pose_times.append(t)
         self.next += 1
         self.rows = rows
+        self.last_state = st
         return st
 
     def ate(self):

@@ -23,10 +23,12 @@
 #include <list>
 #include <map>
 #include <set>
+#include <thread>
 #include "back_factors.h"
 #include "back_solver.h"
 #include "dvo.h"
 #include "inst_manager.h"
+extern "C" int dvo_get_threads();
 
 namespace obe {
 
@@ -145,7 +147,13 @@ struct Marginalizer {         // MarginalizationInfo::{addResidualBlockInfo,preM
         out->m = m; out->n = n;
         if (m == 0) { out->valid = false; return out; }
         Mat A(pos, pos); std::vector<double> b(pos, 0.0);
-        for (auto& f : factors) {
+        // marginalization_factor.cpp:254-281 builds A, b on 4 pthreads (residual block i goes to thread i % 4, partial sums added in thread order);
+        // here that form is used for the multi-threaded CPU-baseline TIMING (dvo_set_threads > 1), the default is the sequential sum over the blocks
+        const int NT = dvo_get_threads() > 1 ? 4 : 1;
+        std::vector<Mat> Ap_(NT > 1 ? NT : 0, Mat(pos, pos)); std::vector<std::vector<double>> bp_(NT > 1 ? NT : 0, std::vector<double>(pos, 0.0));
+        auto build = [&](Mat& A, std::vector<double>& b, int first, int stride) {
+          for (size_t fi = first; fi < factors.size(); fi += stride) {
+            auto& f = factors[fi];
             const int nr = f.f->nres;
             for (size_t i = 0; i < f.blocks.size(); ++i) {
                 const int ii = idx[f.blocks[i]], si = ls(size[f.blocks[i]]), ci = f.f->sizes[i];
@@ -159,6 +167,14 @@ struct Marginalizer {         // MarginalizationInfo::{addResidualBlockInfo,preM
                 }
                 for (int a = 0; a < si; ++a) { double s = 0; for (int r = 0; r < nr; ++r) s += f.J[i][r * ci + a] * f.res[r]; b[ii + a] += s; }
             }
+          }
+        };
+        if (NT == 1) build(A, b, 0, 1);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < NT; ++k) th.emplace_back([&, k] { build(Ap_[k], bp_[k], k, NT); });
+            for (auto& t : th) t.join();
+            for (int k = NT - 1; k >= 0; --k) { for (size_t e = 0; e < A.d.size(); ++e) A.d[e] += Ap_[k].d[e]; for (int e = 0; e < pos; ++e) b[e] += bp_[k][e]; }
         }
         Mat Amm(m, m);
         for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) Amm(i, j) = 0.5 * (A(i, j) + A(j, i));

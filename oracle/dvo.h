@@ -19,6 +19,11 @@
 extern "C" {
 #endif
 
+/* CPU-baseline timing only: threads for the per-point LK loop (OpenCV: parallel_for_) and, if > 1, the reference's 4-thread build of the marginalization
+ * system (marginalization_factor.h:26).  Tracking results do not depend on it; the marginalization sum order does (last bits). Default 1. */
+void dvo_set_threads(int n);
+int dvo_get_threads(void);
+
 /* ---------------- front end ---------------- */
 
 typedef struct dvo_cam {   /* camodocal PinholeCamera parameters (PinholeCamera.cc:292-295) */

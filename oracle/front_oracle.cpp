@@ -32,6 +32,11 @@
 #include <map>
 #include <vector>
 
+#include <thread>
+static int g_threads = 1;      // dvo_set_threads: CPU-baseline timing only; results do not depend on it (points are independent)
+extern "C" void dvo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+extern "C" int dvo_get_threads() { return g_threads; }
+
 namespace {
 
 inline int reflect101(int p, int len) {          // cv::borderInterpolate(BORDER_REFLECT_101)
@@ -236,8 +241,16 @@ void lk(const uint8_t* img_a, const uint8_t* img_b, int w, int h, const P2f* pts
     eps = std::min(std::max(eps, 0.), 10.);
     double eps_sq = eps * eps;
     for (int i = 0; i < n; ++i) status[i] = 1;
-    for (int level = ml; level >= 0; --level)
-        lk_level(pa[level], pb[level], level, ml, pts_a, pts_b, status, n, iters, eps_sq, use_initial);
+    const int nt = std::min(g_threads, n / 8);          // timing runs only (dvo_set_threads): cv::calcOpticalFlowPyrLK runs parallel_for_ over the points of a level
+    for (int level = ml; level >= 0; --level) {
+        if (nt <= 1) { lk_level(pa[level], pb[level], level, ml, pts_a, pts_b, status, n, iters, eps_sq, use_initial); continue; }
+        std::vector<std::thread> th;
+        for (int k = 0; k < nt; ++k) {
+            const int a = (int)((long long)n * k / nt), b = (int)((long long)n * (k + 1) / nt);
+            th.emplace_back([&, a, b, level] { lk_level(pa[level], pb[level], level, ml, pts_a + a, pts_b + a, status + a, b - a, iters, eps_sq, use_initial); });
+        }
+        for (auto& t : th) t.join();
+    }
 }
 
 inline bool in_border(P2f pt, int rows, int cols) {      // feature_utils.h:68-74

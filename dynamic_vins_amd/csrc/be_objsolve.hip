@@ -163,10 +163,12 @@ struct ObjProb {
 }  // namespace
 
 
-// internal form: the estimator's dynamic branch runs the object solve on its own stream + scratch buffer, concurrently with the window solve
-int be_obj_solve_on(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, hipStream_t s, DevBuf& scratch) {
+// internal two-phase form: the estimator's dynamic branch enqueues the object solve on its own stream + scratch buffer (pinned staging for both
+// directions, no host synchronisation) so that it runs beside the window solve; _end waits for its event and unpacks
+int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& scratch, ObjPending& pend) {
     if (!ctx) return -1;
-    if (!P || !summary) DV_FAIL("dv_obj_solve: null argument");
+    if (pend.active) DV_FAIL("dv_obj_solve: previous object solve not collected");
+    if (!P) DV_FAIL("dv_obj_solve: null argument");
     if (P->n_obj <= 0 || P->n_boxes < 0 || P->n_points < 0 || P->max_iters < 0 || !P->state || !P->dims || !P->body_pose) DV_FAIL("dv_obj_solve: bad problem");
     if ((P->n_boxes > 0 && !P->boxes) || (P->n_points > 0 && !P->points)) DV_FAIL("dv_obj_solve: null factor list");
     if (P->plane_kind < 0 || P->plane_kind > 2) DV_FAIL("dv_obj_solve: bad plane_kind");
@@ -181,7 +183,16 @@ int be_obj_solve_on(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, hipS
                  o_boxd = carve(8 * 3 * (size_t)nblk), o_hasb = carve((size_t)nblk), o_act = carve((size_t)V);
     const size_t up_bytes = off;
     const size_t o_x1 = carve(8 * 7 * (size_t)V), o_H0 = carve(8 * BD_HSTRIDE * (size_t)V), o_H1 = carve(8 * BD_HSTRIDE * (size_t)V), o_vec = carve(8 * 30 * (size_t)V), o_out = carve(64);
-    std::vector<uint8_t> host(up_bytes, 0);
+    const size_t dl_bytes = 8 * 7 * (size_t)V + 64;
+    if (pend.pinned_bytes < up_bytes + dl_bytes) {
+        if (pend.pinned) (void)hipHostFree(pend.pinned);
+        pend.pinned = nullptr; pend.pinned_bytes = 0;
+        DV_CHECK(hipHostMalloc(&pend.pinned, 2 * (up_bytes + dl_bytes), hipHostMallocDefault));
+        pend.pinned_bytes = 2 * (up_bytes + dl_bytes);
+    }
+    if (!pend.ev) DV_CHECK(hipEventCreateWithFlags(&pend.ev, hipEventDisableTiming));
+    struct HostView { uint8_t* p; uint8_t* data() { return p; } } host{ (uint8_t*)pend.pinned };
+    std::memset(host.p, 0, up_bytes);
     double* hx = (double*)(host.data() + o_x0); double* hd0 = (double*)(host.data() + o_dims0); double* hpt = (double*)(host.data() + o_pt);
     int* hstart = (int*)(host.data() + o_start); double* hR = (double*)(host.data() + o_boxR); double* hbd = (double*)(host.data() + o_boxd);
     uint8_t* hhas = host.data() + o_hasb; uint8_t* hact = host.data() + o_act;
@@ -233,19 +244,33 @@ int be_obj_solve_on(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, hipS
         hipLaunchKernelGGL(bd_solve_kernel<ObjProb>, dim3(1), dim3(BD_THREADS), 0, s, pr, a);
     }
     DV_CHECK(hipGetLastError());
-    std::vector<double> hxo(7 * (size_t)V); double hout[8];
-    DV_CHECK(hipMemcpyAsync(hxo.data(), a.x0, 8 * 7 * (size_t)V, hipMemcpyDeviceToHost, s));
-    DV_CHECK(hipMemcpyAsync(hout, a.out, 64, hipMemcpyDeviceToHost, s));
-    DV_CHECK(hipStreamSynchronize(s));
-    if (ctx->timing) dv_harvest_timers(ctx, s);
-    for (int b = 0; b < nblk; ++b) memcpy(P->state + 7 * (size_t)b, hxo.data() + 7 * (size_t)b, 56);
-    for (int o = 0; o < n_obj; ++o) memcpy(P->dims + 3 * o, hxo.data() + 7 * (size_t)(nblk + o), 24);
-    summary->iterations = (int)hout[0]; summary->successful = (int)hout[1]; summary->termination = (int)hout[2]; summary->slots = 0;
-    summary->initial_cost = hout[3]; summary->final_cost = hout[4];
+    uint8_t* dl = (uint8_t*)pend.pinned + up_bytes;
+    DV_CHECK(hipMemcpyAsync(dl, a.x0, 8 * 7 * (size_t)V, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(dl + 8 * 7 * (size_t)V, a.out, 64, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipEventRecord(pend.ev, s));
+    pend.active = true; pend.V = V; pend.nblk = nblk; pend.n_obj = n_obj; pend.up_bytes = up_bytes; pend.stream = s;
+    return 0;
+}
+
+int be_obj_solve_end(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, ObjPending& pend) {
+    if (!ctx) return -1;
+    if (!pend.active) DV_FAIL("dv_obj_solve: nothing to collect");
+    pend.active = false;
+    DV_CHECK(hipEventSynchronize(pend.ev));
+    if (ctx->timing) { DV_CHECK(hipStreamSynchronize(pend.stream)); dv_harvest_timers(ctx, pend.stream); }
+    const double* hxo = (const double*)((const uint8_t*)pend.pinned + pend.up_bytes); const double* hout = hxo + 7 * (size_t)pend.V;
+    for (int b = 0; b < pend.nblk; ++b) memcpy(P->state + 7 * (size_t)b, hxo + 7 * (size_t)b, 56);
+    for (int o = 0; o < pend.n_obj; ++o) memcpy(P->dims + 3 * o, hxo + 7 * (size_t)(pend.nblk + o), 24);
+    if (summary) {
+        summary->iterations = (int)hout[0]; summary->successful = (int)hout[1]; summary->termination = (int)hout[2]; summary->slots = 0;
+        summary->initial_cost = hout[3]; summary->final_cost = hout[4];
+    }
     return 0;
 }
 
 extern "C" int dv_obj_solve(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary) {
     if (!ctx) return -1;
-    return be_obj_solve_on(ctx, P, summary, ctx->be_stream, ctx->s1);
+    if (!summary) DV_FAIL("dv_obj_solve: null argument");
+    if (be_obj_solve_begin(ctx, P, ctx->be_stream, ctx->s1, ctx->obj_op_pend)) return -1;
+    return be_obj_solve_end(ctx, P, summary, ctx->obj_op_pend);
 }

@@ -122,7 +122,12 @@ void* be_staging_factors(dv_ctx* ctx, int* cap);      // where the next solve's 
 int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused);       // upload + enqueue everything, returns immediately
 int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);      // sync + collect
 struct dv_obj_problem;
-int be_obj_solve_on(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, hipStream_t s, DevBuf& scratch);
+struct ObjPending {       // an object solve in flight (be_obj_solve_begin / _end): pinned staging for upload + download, its event
+    bool active = false; void* pinned = nullptr; size_t pinned_bytes = 0, up_bytes = 0; hipEvent_t ev = nullptr; hipStream_t stream = nullptr; int V = 0, nblk = 0, n_obj = 0;
+    void release() { if (pinned) (void)hipHostFree(pinned); pinned = nullptr; pinned_bytes = 0; if (ev) (void)hipEventDestroy(ev); ev = nullptr; active = false; }
+};
+int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& scratch, ObjPending& pend);
+int be_obj_solve_end(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, ObjPending& pend);
 struct dv_estimator;
 void dv_est_destroy_internal(dv_estimator* e);
 struct dv_inst_tracker;
@@ -146,6 +151,7 @@ struct dv_ctx {
     bool timing = false, kernel_timing = false, host_timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
     // back end
     hipStream_t be_stream = nullptr; BeWork be;
+    ObjPending obj_pend, obj_op_pend;            // estimator's object solve / operator-level dv_obj_solve
     hipStream_t obj_stream = nullptr; DevBuf obj_buf;      // dynamic mode: the object solve runs beside the window solve
     dv_estimator* est = nullptr;
     struct dv_inst_tracker* inst = nullptr;      // dynamic mode: the per-object tracker (inst_track.hip)

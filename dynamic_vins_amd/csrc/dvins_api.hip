@@ -182,7 +182,7 @@ void dv_destroy(dv_ctx* ctx) {
     if (ctx->est) dv_est_destroy_internal(ctx->est);
     ctx->be.block.release(); ctx->be.marg_buf.release();
     if (ctx->be.pinned) (void)hipHostFree(ctx->be.pinned);
-    ctx->obj_buf.release();
+    ctx->obj_buf.release(); ctx->obj_pend.release(); ctx->obj_op_pend.release();
     if (ctx->obj_stream) (void)hipStreamDestroy(ctx->obj_stream);
     if (ctx->be_stream) (void)hipStreamDestroy(ctx->be_stream);
     if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);

@@ -517,15 +517,22 @@ struct dv_estimator {
         im.initial_instance(B);
         im.initial_velocity(B);
         im.set_dynamic_or_static(B);
-        dv_obj_problem OP;
-        bool solved = false;
+        obj_solved = false;
         obj_last = dv_ba_summary{};
         if (im.build_problem(OP, &para_pose_ref[0][0], ric[0]) && (OP.n_boxes > 0 || OP.n_points > 0)) {
-            if (be_obj_solve_on(ctx, &OP, &obj_last, ctx->obj_stream, ctx->obj_buf)) return -1;
-            solved = true;
+            if (be_obj_solve_begin(ctx, &OP, ctx->obj_stream, ctx->obj_buf, ctx->obj_pend)) return -1;      // enqueued; collected in dynamic_branch_finish
+            obj_solved = true;
         }
-        im.read_back(solved);
-        im.outliers_rejection(B);
+        return 0;
+    }
+    // second half of the object branch (InstanceManager::GetOptimizationParameters + OutliersRejection, estimator_insts.cpp:804, estimator.cpp:1615): needs the object
+    // solve's result and still the PRE-optimisation body states, so it runs at the top of process_image_end, before the window solve's result is applied
+    dv_obj_problem OP{}; bool obj_solved = false;
+    int dynamic_branch_finish(dv_ctx* ctx) {
+        HostScope h(ctx, "h_dynamic_finish");
+        if (obj_solved && be_obj_solve_end(ctx, &OP, &obj_last, ctx->obj_pend)) return -1;
+        im.read_back(obj_solved);
+        im.outliers_rejection(body_view());
         return 0;
     }
     int process_image_begin(dv_ctx* ctx, const dv_feat* feats, int n, double header, const dv_inst_obs* insts = nullptr, int n_insts = 0, const dv_feat* inst_feats = nullptr,
@@ -548,6 +555,7 @@ struct dv_estimator {
     int process_image_end(dv_ctx* ctx) {
         if (!in_flight) return 0;
         in_flight = false;
+        if (dyn_frame && dynamic_branch_finish(ctx)) return -1;      // before optimization_end: Rs / Ps are still the states the reference's object branch saw
         if (optimization_end(ctx)) return -1;
         if (dyn_frame) im.touch_in_main_optimization();      // AddInstanceParameterBlock / im.GetOptimizationParameters inside Estimator::Optimization
         { HostScope h(ctx, "h_reject"); reject_outliers(); }

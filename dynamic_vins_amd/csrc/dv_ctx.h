@@ -132,6 +132,7 @@ struct dv_estimator;
 void dv_est_destroy_internal(dv_estimator* e);
 struct dv_inst_tracker;
 void dv_inst_destroy_internal(dv_inst_tracker* t);
+int dv_inst_wait_before_next_frame(dv_ctx* ctx);
 
 struct dv_ctx {
     dv_config cfg{};
@@ -154,7 +155,7 @@ struct dv_ctx {
     ObjPending obj_pend, obj_op_pend;            // estimator's object solve / operator-level dv_obj_solve
     hipStream_t obj_stream = nullptr; DevBuf obj_buf;      // dynamic mode: the object solve runs beside the window solve
     dv_estimator* est = nullptr;
-    struct dv_inst_tracker* inst = nullptr;      // dynamic mode: the per-object tracker (inst_track.hip)
+    struct dv_inst_tracker* inst = nullptr; hipEvent_t ev_pyr = nullptr, ev_bg_select = nullptr;      // dynamic mode: the per-object tracker (inst_track.hip)
 };
 
 void dv_set_error(dv_ctx* ctx, const std::string& msg);

@@ -147,6 +147,8 @@ dv_ctx* dv_create(const dv_config* cfg) {
     if ((e = hipStreamCreateWithFlags(&ctx->be_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipStreamCreateWithFlags(&ctx->obj_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
     if ((e = hipEventCreateWithFlags(&ctx->done, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_pyr, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+    if ((e = hipEventCreateWithFlags(&ctx->ev_bg_select, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
     // tracker state: one block, struct of arrays
     const size_t N = DV_MAX_FEATS;
     size_t off = 0;
@@ -187,6 +189,8 @@ void dv_destroy(dv_ctx* ctx) {
     if (ctx->be_stream) (void)hipStreamDestroy(ctx->be_stream);
     if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
     if (ctx->done) (void)hipEventDestroy(ctx->done);
+    if (ctx->ev_pyr) (void)hipEventDestroy(ctx->ev_pyr);
+    if (ctx->ev_bg_select) (void)hipEventDestroy(ctx->ev_bg_select);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -231,6 +235,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     hipStream_t s = ctx->stream;
     if (ensure_hw(ctx, c.min_dist)) return -1;
     if (ensure_cand(ctx, w, h)) return -1;
+    if (dv_inst_wait_before_next_frame(ctx)) DV_FAIL("dv_track_stereo: hipStreamWaitEvent");
     StageScope frame(ctx, "frame");
     ctx->cur ^= 1;
     PyrSet& L = ctx->left[ctx->cur];
@@ -239,6 +244,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
         StageScope sc(ctx, "pyr");
         if (build_pyramids(ctx, L, stereo ? &ctx->right : nullptr, gray0, stereo ? gray1 : nullptr, w, h, stride, mem, 3, ctx->undist[0])) return -1;
     }
+    if (ctx->inst) DV_CHECK(hipEventRecord(ctx->ev_pyr, s));
     const uint8_t* mask_dev = nullptr; int mask_pitch = 0;
     if (mask_or_null) {
         const bool bgr_in = (mem & DV_FMT_BGR) != 0;
@@ -290,6 +296,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
         a.out_xy = nullptr; a.n_out = nullptr; a.tr = ctx->tr; a.has_tr = 1; a.err_flag = ctx->err_flag;
         if (dv_launch_gftt_select(a, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
     }
+    if (ctx->inst) DV_CHECK(hipEventRecord(ctx->ev_bg_select, s));
     if (stereo) {
         StageScope sc(ctx, "lk_stereo");
         dv_launch_lk_track(L.pyr, ctx->right.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_stereo,

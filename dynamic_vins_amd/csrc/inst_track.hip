@@ -71,11 +71,14 @@ struct dv_inst_tracker {
     double last_time = 0, cur_time = 0;
     void* pinned_in = nullptr; size_t pinned_in_bytes = 0;
     dv_feat* out_dev = nullptr; DevBuf out_buf; void* out_pinned = nullptr; size_t out_cap_slots = 0;      // [slot][INST_CAP] rows + counts
-    hipEvent_t done = nullptr; bool pending = false;
+    hipEvent_t done = nullptr; bool pending = false; bool frame_enqueued = false;
+    hipStream_t stream = nullptr;                               // the objects run beside the background tracker: own stream, own Shi-Tomasi scratch
+    DevBuf cand, scal; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
     std::vector<unsigned> out_order;                            // ids written this frame, in output order
     ~dv_inst_tracker() {
         for (auto& kv : slots) kv.second.release();
-        hw.release(); out_buf.release();
+        hw.release(); out_buf.release(); cand.release(); scal.release();
+        if (stream) (void)hipStreamDestroy(stream);
         if (pinned_in) (void)hipHostFree(pinned_in);
         if (out_pinned) (void)hipHostFree(out_pinned);
         if (done) (void)hipEventDestroy(done);
@@ -83,6 +86,12 @@ struct dv_inst_tracker {
 };
 
 void dv_inst_destroy_internal(dv_inst_tracker* t) { delete t; }
+// the background tracker's next frame must not rebuild the right pyramid while the objects of the previous frame still read it
+int dv_inst_wait_before_next_frame(dv_ctx* ctx) {
+    if (!ctx->inst || !ctx->inst->frame_enqueued) return 0;
+    ctx->inst->frame_enqueued = false;
+    return hipStreamWaitEvent(ctx->stream, ctx->inst->done, 0) == hipSuccess ? 0 : -1;
+}
 
 static void circle_half_widths_i(int radius, std::vector<uint8_t>& hw) {      // cv::circle's midpoint rasteriser (as dvins_api.hip)
     hw.assign(radius + 1, 0);
@@ -103,7 +112,7 @@ static int slot_init(dv_ctx* ctx, Slot& s) {
     const size_t o_last = take(N * 8), o_cur = take(N * 8), o_lk = take(N * 8), o_lks = take(N), o_ids = take(N * 4), o_cnt = take(N * 4), o_pun = take(N * 8), o_prun = take(N * 8),
                  o_prv = take(N), o_trk = take(N), o_rp = take(N * 8), o_rs = take(N), o_scal = take(64);
     DV_CHECK(s.state.ensure(off));
-    DV_CHECK(hipMemsetAsync(s.state.p, 0, off, ctx->stream));
+    DV_CHECK(hipMemsetAsync(s.state.p, 0, off, ctx->inst->stream));
     uint8_t* b = (uint8_t*)s.state.p;
     s.tr.last_pts = (float2*)(b + o_last); s.tr.curr_pts = (float2*)(b + o_cur); s.tr.lk_pts = (float2*)(b + o_lk); s.tr.lk_status = b + o_lks;
     s.tr.ids = (uint32_t*)(b + o_ids); s.tr.track_cnt = (int32_t*)(b + o_cnt); s.tr.prev_un = (float2*)(b + o_pun); s.tr.prev_run = (float2*)(b + o_prun);
@@ -132,7 +141,15 @@ int dv_inst_config(dv_ctx* ctx, int max_dynamic_cnt, int min_dynamic_dist, int u
     if (max_dynamic_cnt < 1 || max_dynamic_cnt > INST_CAP - 8) DV_FAIL("dv_inst_config: max_dynamic_cnt must be in [1, 248]");
     if (min_dynamic_dist < 0 || min_dynamic_dist > DV_MAX_RADIUS) DV_FAIL("dv_inst_config: min_dynamic_dist out of range [0,128]");
     DV_CHECK(hipSetDevice(ctx->cfg.device));
-    if (!ctx->inst) { ctx->inst = new dv_inst_tracker(); DV_CHECK(hipEventCreateWithFlags(&ctx->inst->done, hipEventDisableTiming)); }
+    if (!ctx->inst) {
+        ctx->inst = new dv_inst_tracker();
+        DV_CHECK(hipEventCreateWithFlags(&ctx->inst->done, hipEventDisableTiming));
+        DV_CHECK(hipStreamCreateWithFlags(&ctx->inst->stream, hipStreamNonBlocking));
+        const int cap = std::max(4096, (ctx->cfg.width * ctx->cfg.height) / 4);
+        DV_CHECK(ctx->inst->cand.ensure((size_t)cap * sizeof(DvCand))); ctx->inst->cand_cap = cap;
+        DV_CHECK(ctx->inst->scal.ensure(256)); DV_CHECK(hipMemset(ctx->inst->scal.p, 0, 256));
+        ctx->inst->n_cand = (int*)ctx->inst->scal.p; ctx->inst->max_ord = (unsigned*)ctx->inst->scal.p + 1; ctx->inst->err_flag = (int*)ctx->inst->scal.p + 2;
+    }
     dv_inst_tracker& T = *ctx->inst;
     if (T.pending) DV_FAIL("dv_inst_config: a frame is in flight");
     T.max_cnt = max_dynamic_cnt; T.min_dist = min_dynamic_dist; T.use_det3d = use_det3d;
@@ -147,7 +164,7 @@ int dv_inst_reset(dv_ctx* ctx) {
     if (!ctx) return -1;
     if (!ctx->inst) return 0;
     DV_CHECK(hipSetDevice(ctx->cfg.device));
-    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream)); DV_CHECK(hipStreamSynchronize(ctx->inst->stream));
     for (auto& kv : ctx->inst->slots) kv.second.release();
     ctx->inst->slots.clear(); ctx->inst->pending = false; ctx->inst->last_time = ctx->inst->cur_time = 0; ctx->inst->out_order.clear();
     return 0;
@@ -161,7 +178,12 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
     dv_inst_tracker& T = *ctx->inst;
     if (T.pending) DV_FAIL("dv_inst_track_enqueue: previous frame not collected");
     DV_CHECK(hipSetDevice(ctx->cfg.device));
-    hipStream_t s = ctx->stream;
+    // the objects' stream: starts when this frame's pyramids exist (ev_pyr), its corner selection waits for the background tracker's (ev_bg_select) so
+    // that the shared id counter is consumed in a fixed order; the background tracker's NEXT frame waits for T.done before it rebuilds the right pyramid
+    hipStream_t s = T.stream;
+    if (!ctx->ev_pyr || !ctx->ev_bg_select) DV_FAIL("dv_inst_track: internal events missing");
+    DV_CHECK(hipStreamWaitEvent(s, ctx->ev_pyr, 0));
+    bool waited_bg = false;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     const DvPyr& L = ctx->left[ctx->cur].pyr; const DvPyr& R = ctx->right.pyr;
     const bool stereo = ctx->cfg.stereo != 0;
@@ -207,7 +229,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         }
     }
     T.out_order.clear();
-    StageScope sc_all(ctx, "inst_track");
+    StageScope sc_all(ctx, "inst_track", s);
     if (n_dets > 0) {
         // masks: one pinned staging area, one H2D per object (sources are pageable caller memory)
         if (T.pinned_in_bytes < mask_bytes) {
@@ -254,7 +276,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
                 // InstFeat::TrackLeft: FeatureTrackByLK(prev padded, cur padded, last_points) without a mask (dynamic_tracker.cpp:409)
                 dv_launch_lk_track(S.padA.pyr, B.pyr, S.tr.last_pts, S.tr.n_feat, T.max_cnt, ctx->cfg.flow_back, 0.5f, S.tr.lk_pts, S.tr.lk_status, s);
             }
-            dv_launch_compact(S.tr, nullptr, 0, 0, ctx->n_cand, ctx->max_ord, s);      // ReduceVector x4, ++track_cnt; without a previous ROI the object has no points (n_feat == 0)
+            dv_launch_compact(S.tr, nullptr, 0, 0, T.n_cand, T.max_ord, s);      // ReduceVector x4, ++track_cnt; without a previous ROI the object has no points (n_feat == 0)
             // ErodeMask 5x5 + discs of the tracked points + goodFeaturesToTrack on roi_gray (:418-446)
             dv_launch_erode((const uint8_t*)S.mask.p, w, h, mp, 5, (uint8_t*)S.tmp.p, mp, (uint8_t*)S.ero.p, mp, s);
             {
@@ -263,13 +285,14 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
                 a.in_mask = (const uint8_t*)S.ero.p; a.mask_pitch = mp;
                 a.disc_pts = S.tr.curr_pts; a.n_disc = S.tr.n_tracked; a.radius = T.min_dist; a.hw = (const uint8_t*)T.hw.p;
                 a.n_feat = S.tr.n_feat; a.max_cnt = T.max_cnt; a.min_new = 1;
-                a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord;
+                a.cand = (DvCand*)T.cand.p; a.cand_cap = T.cand_cap; a.n_cand = T.n_cand; a.max_ord = T.max_ord;
                 dv_launch_gftt_tile(a, s);
+                if (!waited_bg) { DV_CHECK(hipStreamWaitEvent(s, ctx->ev_bg_select, 0)); waited_bg = true; }      // ids: background first, then the objects in ascending id
                 GfttSelectArgs sa{};
-                sa.cand = (const DvCand*)ctx->cand_buf.p; sa.n_cand = ctx->n_cand; sa.cand_cap = ctx->cand_cap; sa.max_ord = ctx->max_ord;
+                sa.cand = (const DvCand*)T.cand.p; sa.n_cand = T.n_cand; sa.cand_cap = T.cand_cap; sa.max_ord = T.max_ord;
                 sa.w = w; sa.h = h; sa.quality = 0.01; sa.min_dist = (double)T.min_dist;
                 sa.max_n_host = 0; sa.n_feat = S.tr.n_feat; sa.max_cnt = T.max_cnt; sa.min_new = 1;
-                sa.out_xy = nullptr; sa.n_out = nullptr; sa.tr = S.tr; sa.has_tr = 1; sa.err_flag = ctx->err_flag;
+                sa.out_xy = nullptr; sa.n_out = nullptr; sa.tr = S.tr; sa.has_tr = 1; sa.err_flag = T.err_flag;
                 if (dv_launch_gftt_select(sa, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
             }
             // TrackRightByPad (instance_feature.cpp:251-275): the points move into full-image coordinates, LK left -> right on the full frames
@@ -294,7 +317,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
     }
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipEventRecord(T.done, s));
-    T.last_time = T.cur_time; T.pending = true;
+    T.last_time = T.cur_time; T.pending = true; T.frame_enqueued = true;
     return 0;
 }
 
@@ -307,6 +330,7 @@ int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n
     if (!n_insts || !n_feats || !n_points) DV_FAIL("dv_inst_track_collect: null counter");
     DV_CHECK(hipEventSynchronize(T.done));
     T.pending = false;
+    if (ctx->timing) { DV_CHECK(hipStreamSynchronize(T.stream)); dv_harvest_timers(ctx, T.stream); }
     const size_t slot_bytes = INST_CAP * sizeof(dv_feat) + 64;
     int ki = 0, kf = 0, kp = 0;
     for (unsigned id : T.out_order) {

@@ -290,6 +290,20 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
         if (P->use_imu) { d.sb_col[f] = col; for (int k = 0; k < 9; ++k) { col_kind[col] = 1; col_frame[col] = f; col_comp[col] = k; ++col; } }
     }
     d.nstate = col;
+    // two-level elimination in be_solve (speed-bias chain first, then the dense pose block): needs every frame to carry a free pose and a speed-bias
+    // block, the speed-bias coupling to be block tridiagonal (IMU factors between neighbours; the prior holding speed-bias blocks of at most two
+    // adjacent frames) and the packed triangle to fit one block per thread.  Off by default (measured slower than the monolithic panel factorisation in its first form); dv_debug_set(ctx, "two_level", 1) selects it.
+    d.pad = 0;
+    if (P->use_imu && P->nframes >= 2 && ctx->be.two_level) {
+        bool ok = true;
+        for (int k = 0; k < P->nimu; ++k) if (P->imu[k].fj != P->imu[k].fi + 1) ok = false;
+        int smin = 99, smax = -1;
+        if (P->prior && P->prior->valid) for (int b = 0; b < P->prior->nblocks; ++b) if (P->prior->blocks[b].type == 1) { smin = std::min(smin, P->prior->blocks[b].idx); smax = std::max(smax, P->prior->blocks[b].idx); }
+        if (smax >= 0 && smax - smin > 1) ok = false;
+        const int nbr = (col + 3) / 4;
+        if (nbr * (nbr + 1) / 2 > 1024) ok = false;
+        d.pad = ok ? 1 : 0;
+    }
     const bool has_prior = P->prior && P->prior->valid;
     const bool prior_on_device = has_prior && w.prior_resident && P->prior_A == w.priorA_buf[w.prior_cur];
     if (col == 0) {       // e.g. vision-only, first frame: pose 0 is constant and no landmark has 4 observations yet
@@ -466,6 +480,7 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
 int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return -1;
     if (std::strcmp(key, "short_first_pass") == 0) { ctx->be.debug_short_first_pass = value != 0; return 0; }
+    if (std::strcmp(key, "two_level") == 0) { ctx->be.two_level = value != 0; return 0; }
     DV_FAIL(std::string("dv_debug_set: unknown key ") + key);
 }
 

@@ -422,6 +422,249 @@ __device__ __forceinline__ bool ldlt_blocked(const double* __restrict__ Sc, cons
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Two-level elimination of the reduced camera system (VIO windows).  The system has a dense 6 x nframes pose part and one 9-wide
+// speed-bias block per frame; the speed-bias blocks only couple along the IMU chain (sb_f -- sb_f+1; the prior holds one speed-bias
+// block), i.e. S_bb is block tridiagonal.  Eliminating them first by a block-Thomas sweep
+//     B'_f = B_f - C_f-1^T B'_f-1^-1 C_f-1 ,   [E'_f | g'_f] = [E_f | g_f] - C_f-1^T B'_f-1^-1 [E'_f-1 | g'_f-1]
+// (E_f = the block row of sb_f against ALL pose columns, dense after fill-in) leaves  S'_pp = A_pp - sum_f E'_f^T B'_f^-1 E'_f , a 66 x 66
+// system for the panel LDL^T above: 99 of the 165 sequential pivots of the monolithic factorisation are replaced by
+//   (A1) ONE wave walking the 9 x 9 chain (Gauss-Jordan inverses in LDS, wave-ordered, no workgroup barrier),
+//   (A2) one thread per pose column carrying its 9-vector down the chain in registers,
+//   (A3/A4) two wide passes for the rank-99 update of the pose block.
+// The arithmetic is an exact block LDL^T of the symmetrically permuted matrix: same solution, other rounding.
+#define FS_ES 67              // row stride of E / X: 66 pose columns + the right-hand side
+#define FS_WORK 16000         // doubles of LDS the two-level path carves (99 x 67 + 54 x 67 + 153 x 16 + 3 x 891 + small, see schur_sb_solve)
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+struct FastSb {
+    double *E, *X, *Spp, *Binv, *T, *C, *rhs2, *ones, *zer, *W, *xb; int np, nsb, pb[BE_NF], sbc[BE_NF], pc[BE_NF];
+};
+
+// scaled + damped entry (i, j) of the Schur complement, from the block-packed lower triangle
+__device__ __forceinline__ double fs_entry(const double* Sc, int NBR, int i, int j, double mu, const double* v_s, const double* v_d) {
+    const int hi = (j >> 2) > (i >> 2) ? j : i, lo = (j >> 2) > (i >> 2) ? i : j;
+    double v = v_s[i] * v_s[j] * Sc[blk_pos(hi, lo, NBR)];
+    if (i == j) v += mu * v_d[i] * v_d[i];
+    return v;
+}
+
+
+// On success v_x[0..n) = solution of (S_scaled + mu D^2) y = s (g - gs).  work: >= 16200 doubles of LDS; Lm (packed, np) is placed inside it.
+__device__ bool schur_sb_solve(const BeSolveArgs& a, const double* __restrict__ Sc, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
+                               double* work, double* v_x, double* PL, double* PD, double* dinfo, double* zfin, double* dvec, int* s_fail, double** Lm_out) {
+    const int tid = threadIdx.x, NBR = (n + 3) >> 2;
+    const int nf = a.dims.nframes, np = 6 * nf, nb = 9 * nf;
+    // ---- LDS carve ----
+    double* E = work;                          // nb x FS_ES : E'_f (pose columns) | g'_f
+    double* X = E + (size_t)nb * FS_ES;        // half of the frames at a time: 6 * 9 x FS_ES ; later the packed factor of the pose system
+    double* Spp = X + 54 * FS_ES;              // block-packed lower triangle of the reduced pose system (17 block rows -> 153 blocks)
+    const int NBRp = (np + 3) >> 2, nblkp = NBRp * (NBRp + 1) / 2;
+    double* Binv = Spp + (size_t)nblkp * 16;   // nf x 81 : B_f, inverted in place
+    double* T = Binv + 81 * BE_NF;             // nf x 81 : T_f = C_f^T B'_f^-1
+    double* C = T + 81 * BE_NF;                // (nf-1) x 81 : C_f = S(sb_f, sb_f+1)
+    double* rhs2 = C + 81 * BE_NF;             // 2 np : [rhs' ; 0]
+    double* ones = rhs2 + 2 * 72;              // np
+    double* W = ones + 72;                     // 9 x 18 Gauss-Jordan work
+    double* xb = W + 168;                      // nb : speed-bias solution ; y
+    double* yb = xb + 104;
+    // ---- gather: every thread owns block `tid` of the packed triangle and files its 16 entries by kind ----
+    for (int i = tid; i < 81 * BE_NF; i += SOL_THREADS) C[i] = 0.0;
+    __syncthreads();
+    {
+        const int nblk = NBR * (NBR + 1) / 2;
+        if (tid < nblk) {
+            int c0 = 0, rem = tid; while (rem >= NBR - c0) { rem -= NBR - c0; ++c0; }
+            const int bjb = c0, bib = c0 + rem;
+            const double4* src = reinterpret_cast<const double4*>(Sc + (size_t)tid * 16);
+            double dv[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const double4 q = src[r]; dv[r][0] = q.x; dv[r][1] = q.y; dv[r][2] = q.z; dv[r][3] = q.w; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const int i = bib * 4 + r, j = bjb * 4 + cc;
+                    if (i >= n || j >= n || j > i) continue;                      // lower triangle incl. diagonal (the diagonal blocks hold both halves)
+                    double v = v_s[i] * v_s[j] * dv[r][cc];
+                    if (i == j) v += mu * v_d[i] * v_d[i];
+                    const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i], kj = a.col_kind[j], fj = a.col_frame[j], cj = a.col_comp[j];
+                    if (ki == 0 && kj == 0) {                                    // pose x pose -> kept for A4 (row-major lower in Spp scratch: a >= b)
+                        const int pa = fi * 6 + ci, pbb = fj * 6 + cj;
+                        const int hi = pa > pbb ? pa : pbb, lo = pa > pbb ? pbb : pa;
+                        // stash in the X area as a packed triangle (np (np+1) / 2 = 2211 <= 54 * 67)
+                        X[hi * (hi + 1) / 2 + lo] = v;
+                    } else if (ki == 1 && kj == 1) {
+                        if (fi == fj) { Binv[fi * 81 + ci * 9 + cj] = v; Binv[fi * 81 + cj * 9 + ci] = v; }
+                        else if (fi == fj + 1) C[fj * 81 + cj * 9 + ci] = v;     // row in sb_fj, column in sb_fi
+                        else if (fj == fi + 1) C[fi * 81 + ci * 9 + cj] = v;
+                        else if (v != 0.0) *s_fail = 2;                          // structure violated (cannot happen: checked on the host)
+                    } else if (ki == 1) E[(fi * 9 + ci) * FS_ES + fj * 6 + cj] = v;   // sb row, pose column
+                    else E[(fj * 9 + cj) * FS_ES + fi * 6 + ci] = v;
+                }
+        }
+        for (int k = tid; k < nb; k += SOL_THREADS) {                             // right-hand side of the speed-bias rows
+            const int f = k / 9, r = k - f * 9, col = a.dims.sb_col[f] + r;
+            E[k * FS_ES + np] = v_s[col] * (gvec[col] - gvec[n + col]);
+        }
+        if (tid < np) { ones[tid] = 1.0; }
+    }
+    __syncthreads();
+    TS(20);
+    // ---- A1: the 9 x 9 chain on wave 0 ----
+    if (tid < 64) {
+        const int lane = tid;
+        bool bad = false;
+        for (int f = 0; f < nf; ++f) {
+            double* Bf = Binv + f * 81;
+            // W = [B'_f | I]
+            for (int e = lane; e < 81; e += 64) {
+                const int r = e / 9, cc = e - r * 9;
+                double v = Bf[e];
+                if (f > 0) { const double* Tp = T + (f - 1) * 81; const double* Cp = C + (f - 1) * 81; double sacc = 0; for (int q = 0; q < 9; ++q) sacc += Tp[r * 9 + q] * Cp[q * 9 + cc]; v -= sacc; }
+                W[r * 18 + cc] = v; W[r * 18 + 9 + cc] = r == cc ? 1.0 : 0.0;
+            }
+            wave_lds_sync();
+            for (int k = 0; k < 9; ++k) {
+                const double p = W[k * 18 + k];
+                if (!(p > 0.0) || !isfinite(p)) bad = true;
+                const double ip = fast_rcp(p);
+                double nv[3]; int ne[3];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int e = lane + 64 * u; ne[u] = e; nv[u] = 0.0;
+                    if (e < 162) { const int r = e / 18, cc = e - r * 18; const double pk = W[k * 18 + cc] * ip; nv[u] = r == k ? pk : W[e] - W[r * 18 + k] * pk; }
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int u = 0; u < 3; ++u) if (ne[u] < 162) W[ne[u]] = nv[u];
+                wave_lds_sync();
+            }
+            for (int e = lane; e < 81; e += 64) { const int r = e / 9, cc = e - r * 9; Bf[e] = W[r * 18 + 9 + cc]; }
+            wave_lds_sync();
+            if (f + 1 < nf) {
+                const double* Cf = C + f * 81; double* Tf = T + f * 81;
+                for (int e = lane; e < 81; e += 64) { const int r = e / 9, cc = e - r * 9; double sacc = 0; for (int q = 0; q < 9; ++q) sacc += Cf[q * 9 + r] * Bf[q * 9 + cc]; Tf[e] = sacc; }
+                wave_lds_sync();
+            }
+        }
+        if (__any(bad) && lane == 0) *s_fail = 1;
+    }
+    __syncthreads();
+    TS(21);
+    if (*s_fail) return false;
+    // ---- A2: column threads carry [E | g] down the chain ----
+    if (tid <= np) {
+        double e[9];
+#pragma unroll
+        for (int r = 0; r < 9; ++r) e[r] = E[r * FS_ES + tid];
+        for (int f = 1; f < nf; ++f) {
+            const double* Tp = T + (f - 1) * 81;
+            double en[9];
+#pragma unroll
+            for (int r = 0; r < 9; ++r) {
+                double sacc = 0;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) sacc += Tp[r * 9 + q] * e[q];
+                en[r] = E[(f * 9 + r) * FS_ES + tid] - sacc;
+            }
+#pragma unroll
+            for (int r = 0; r < 9; ++r) { e[r] = en[r]; E[(f * 9 + r) * FS_ES + tid] = en[r]; }
+        }
+    }
+    // the pose x pose entries parked in X move into registers before X is reused: thread t owns packed entries t, t + 1024, t + 2048 and (beyond
+    // the triangle) the right-hand side entries
+    const int ntri = np * (np + 1) / 2;
+    double acc[3]; int ea[3], eb[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int idx = tid + u * SOL_THREADS; ea[u] = -1; eb[u] = -1; acc[u] = 0.0;
+        if (idx < ntri) {
+            int ra = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
+            while (ra * (ra + 1) / 2 > idx) --ra;
+            while ((ra + 1) * (ra + 2) / 2 <= idx) ++ra;
+            ea[u] = ra; eb[u] = idx - ra * (ra + 1) / 2; acc[u] = X[idx];
+        } else if (idx < ntri + np) {
+            ea[u] = idx - ntri; eb[u] = np;                                     // rhs entry: column np of E / X
+            const int fa = ea[u] / 6, col = a.dims.pose_col[fa] + ea[u] - fa * 6;
+            acc[u] = v_s[col] * (gvec[col] - gvec[n + col]);
+        }
+    }
+    __syncthreads();
+    TS(22);
+    // ---- A3 / A4: S'_pp = A_pp - sum_f E'_f^T (B'_f^-1 E'_f), half of the frames per round (X holds 6 frames) ----
+    for (int f0 = 0; f0 < nf; f0 += 6) {
+        const int fcnt = min(6, nf - f0);
+        for (int o = tid; o < fcnt * 9 * (np + 1); o += SOL_THREADS) {
+            const int row = o / (np + 1), cc = o - row * (np + 1), fl = row / 9, r = row - fl * 9, f = f0 + fl;
+            const double* Bf = Binv + f * 81 + r * 9; const double* Ef = E + (size_t)(f * 9) * FS_ES + cc;
+            double sacc = 0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q) sacc += Bf[q] * Ef[q * FS_ES];
+            X[row * FS_ES + cc] = sacc;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 3; ++u) if (ea[u] >= 0) {
+            double sacc = 0;
+            const double* Ea = E + (size_t)(f0 * 9) * FS_ES + ea[u]; const double* Xb = X + eb[u];
+            for (int k = 0; k < fcnt * 9; ++k) sacc += Ea[k * FS_ES] * Xb[k * FS_ES];
+            acc[u] -= sacc;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) if (ea[u] >= 0) {
+        if (eb[u] == np) { rhs2[ea[u]] = acc[u]; rhs2[np + ea[u]] = 0.0; }
+        else { Spp[blk_pos(ea[u], eb[u], NBRp)] = acc[u]; if ((ea[u] >> 2) == (eb[u] >> 2)) Spp[blk_pos(eb[u], ea[u], NBRp)] = acc[u]; }
+    }
+    __syncthreads();
+    TS(23);
+    // ---- B: dense pose system ----
+    double* LmP = X;                                        // X is dead: the packed factor (np (np + 1) / 2 doubles) takes its place
+    if (!ldlt_blocked<1>(Spp, rhs2, np, 0.0, ones, ones, LmP, PL, PD, dinfo, zfin, dvec, s_fail)) return false;
+    *Lm_out = LmP;
+    return true;
+}
+
+// second half of the two-level solve: x_p is in v_x[0..np) (pose ordering f * 6 + r); back-substitutes the speed-bias chain and scatters both
+// into state-column order.  xs: np + nb scratch doubles.
+__device__ void schur_sb_finish(const BeSolveArgs& a, int n, double* work, double* v_x, double* xs) {
+    const int tid = threadIdx.x, nf = a.dims.nframes, np = 6 * nf, nb = 9 * nf;
+    double* E = work; const int NBRp = (np + 3) >> 2, nblkp = NBRp * (NBRp + 1) / 2;
+    double* Binv = E + (size_t)nb * FS_ES + 54 * FS_ES + (size_t)nblkp * 16; double* C = Binv + 2 * 81 * BE_NF;
+    double* xb = C + 81 * BE_NF + 2 * 72 + 72 + 168; double* yb = xb + 104;
+    for (int i = tid; i < np; i += SOL_THREADS) xs[i] = v_x[i];
+    __syncthreads();
+    if (tid < nb) {                                         // y_f = g'_f - E'_f x_p
+        const double* Er = E + (size_t)tid * FS_ES;
+        double sacc = Er[np];
+        for (int q = 0; q < np; ++q) sacc -= Er[q] * xs[q];
+        yb[tid] = sacc;
+    }
+    __syncthreads();
+    if (tid < 64) {                                         // x_f = B'_f^-1 (y_f - C_f x_f+1), f = last .. 0, on nine lanes of one wave
+        const int lane = tid;
+        double xn = 0.0;                                    // lane r: x_{f+1}[r]
+        const int lr = lane < 9 ? lane : 8;
+        for (int f = nf - 1; f >= 0; --f) {                 // every lane runs the same shuffles; lanes >= 9 carry dummies
+            double tv = yb[f * 9 + lr];
+            if (f + 1 < nf) { const double* Cf = C + f * 81 + lr * 9; for (int q = 0; q < 9; ++q) { const double xq = __shfl(xn, q); tv -= Cf[q] * xq; } }
+            double xv = 0.0;
+            const double* Bf = Binv + f * 81 + lr * 9;
+            for (int q = 0; q < 9; ++q) { const double tq = __shfl(tv, q); xv += Bf[q] * tq; }
+            xn = xv;
+            if (lane < 9) xb[f * 9 + lane] = xv;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += SOL_THREADS) {
+        const int k = a.col_kind[i], f = a.col_frame[i], cc = a.col_comp[i];
+        v_x[i] = k == 0 ? xs[f * 6 + cc] : xb[f * 9 + cc];
+    }
+    __syncthreads();
+}
+
 // back-substitution helper: applies ROWS consecutive pivots (kt, kt-1, ...) that all lie in 64-lane segment SEG of x
 template <int SEG, int ROWS>
 __device__ __forceinline__ void bs_chunk(const double* Lm, int kt, int lane, double& x0, double& x1, double& x2) {
@@ -503,7 +746,7 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
         if (done) return;
         __syncthreads();          // x is re-read below
     }
-    const int npk = n * (n + 1) / 2;
+    const int npk = a.dims.pad ? FS_WORK : n * (n + 1) / 2;      // two-level path: its carve (schur_sb_solve) instead of the packed 165 x 165 factor
     double* Lm = sm;                                   // npk: unit-lower factor, packed row-major
     double* v_s = Lm + npk;                            // scale
     double* v_d = v_s + n;                             // diag
@@ -602,7 +845,12 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
         }
         TS(3);
         // ---------------- Gauss-Newton step: LDL^T of the Schur complement ----------------
-        if (!ldlt_blocked<NSLOT>(a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail)) {
+        const bool two_level = a.dims.pad != 0;            // VIO window with the block-tridiagonal speed-bias structure (decided on the host)
+        double* LmUse = Lm; int nfact = n;
+        bool ok_f;
+        if (two_level) { if (tid == 0) s_fail = 0; __syncthreads(); ok_f = schur_sb_solve(a, a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, v_x, PL, PD, dinfo, zfin, dvec, &s_fail, &LmUse); nfact = 6 * a.dims.nframes; }
+        else ok_f = ldlt_blocked<NSLOT>(a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail);
+        if (!ok_f) {
             // Ceres: LINEAR_SOLVER_FAILURE -> mu *= 10 and retry (dogleg_strategy.cc ComputeGaussNewtonStep)
             if (tid == 0) {
                 ctl->mu = mu * 10.0; ctl->chol_fail = 1; ctl->first = 0; ctl->alpha_valid = 0;
@@ -615,18 +863,20 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
         // back substitution L^T x = D^-1 z on ONE wave with x distributed over lanes (3 registers cover n <= 192):
         // the pivot is broadcast with v_readlane, row k-1 of L is prefetched from LDS while row k is applied.
         if (tid < 64) {
-            const int lane = tid;
-            double x0 = lane < n ? zfin[lane] / dvec[lane] : 0.0;
-            double x1 = 64 + lane < n ? zfin[64 + lane] / dvec[64 + lane] : 0.0;
-            double x2 = 128 + lane < n ? zfin[128 + lane] / dvec[128 + lane] : 0.0;
-            int k = n - 1;
-            for (; k >= 0 && ((k + 1) & 7); --k) bs_rows<1>(Lm, k, lane, x0, x1, x2);      // until the chunks are 8-aligned (a chunk never straddles a segment)
-            for (; k >= 7; k -= 8) bs_rows<8>(Lm, k, lane, x0, x1, x2);
-            if (lane < n) v_x[lane] = x0;
-            if (64 + lane < n) v_x[64 + lane] = x1;
-            if (128 + lane < n) v_x[128 + lane] = x2;
+            const int lane = tid, nn = nfact;
+            double x0 = lane < nn ? zfin[lane] / dvec[lane] : 0.0;
+            double x1 = 64 + lane < nn ? zfin[64 + lane] / dvec[64 + lane] : 0.0;
+            double x2 = 128 + lane < nn ? zfin[128 + lane] / dvec[128 + lane] : 0.0;
+            int k = nn - 1;
+            for (; k >= 0 && ((k + 1) & 7); --k) bs_rows<1>(LmUse, k, lane, x0, x1, x2);      // until the chunks are 8-aligned (a chunk never straddles a segment)
+            for (; k >= 7; k -= 8) bs_rows<8>(LmUse, k, lane, x0, x1, x2);
+            if (lane < nn) v_x[lane] = x0;
+            if (64 + lane < nn) v_x[64 + lane] = x1;
+            if (128 + lane < nn) v_x[128 + lane] = x2;
         }
         __syncthreads();
+        TS(24);
+        if (two_level) schur_sb_finish(a, n, Lm, v_x, scratch);
         TS(7);
         for (int i = tid; i < n; i += SOL_THREADS) { v_gn[i] = -v_d[i] * v_x[i]; a.gn_p[i] = v_gn[i]; v_t[i] = v_s[i] * v_x[i]; }   // v_t = s_p . y_p
         __syncthreads();
@@ -745,7 +995,7 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
     }
 }
 
-static size_t solve_smem(int n) { return ((size_t)n * (n + 1) / 2 + 9 * (size_t)n + 72 + 80 + 8 + 1536) * sizeof(double); }
+static size_t solve_smem(int n, bool two_level = true) { const size_t tri = (size_t)n * (n + 1) / 2; return ((two_level && tri < FS_WORK ? (size_t)FS_WORK : tri) + 9 * (size_t)n + 72 + 80 + 8 + 1536) * sizeof(double); }
 
 int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
     static DevOnce once;
@@ -754,8 +1004,8 @@ int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return 1;
             return 0; })) return -1;
     const int nbr = (a.dims.nstate + 3) / 4;
-    if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL(be_solve_kernel<1>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);
-    else hipLaunchKernelGGL(be_solve_kernel<2>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);
+    if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL(be_solve_kernel<1>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, a.dims.pad != 0), s, a, spec);
+    else hipLaunchKernelGGL(be_solve_kernel<2>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false), s, a, spec);
     return 0;
 }
 

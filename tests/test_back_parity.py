@@ -248,3 +248,27 @@ def test_ba_eval_and_landmark_sharding(ctx, oracle):
     # the Gauss-Newton direction of the reduced system is a descent direction of the cost it came from
     dx = -np.linalg.solve(S + 1e-9 * np.eye(n) * np.abs(S).max(), g)
     assert g @ dx < 0
+
+
+def test_two_level_elimination_matches_oracle(oracle):
+    """be_solve's two-level form (speed-bias chain eliminated by a block-Thomas sweep, then the dense pose system; dv_debug_set "two_level") is an exact
+    block LDL^T of the permuted matrix: same iteration sequence and states as the monolithic factorisation / the oracle"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dynamic_vins_amd.backend import ba_solve
+    from dynamic_vins_amd.frontend import Context
+    from tests import ba_gen
+    ctx = Context(width=64, height=48)
+    try:
+        assert ctx.lib.dv_debug_set(ctx.h, b"two_level", 1) == 0
+        for seed, nlm, prior in [(2, 60, True), (5, 300, True), (7, 150, False)]:
+            ref = ba_gen.make_window(oracle, seed=seed, nlm=nlm, with_prior=prior, max_iters=8)
+            dev = ref.clone()
+            s_ref = ba_gen.oracle_solve(oracle, ref)
+            s_dev = ba_solve(ctx, dev)
+            assert s_dev.iterations == s_ref.iterations and s_dev.termination == s_ref.termination, (seed, s_dev.iterations, s_ref.iterations)
+            assert abs(s_dev.final_cost - s_ref.final_cost) <= 1e-7 * s_ref.final_cost
+            assert np.abs(dev.pose - ref.pose).max() < 1e-6 and np.abs(dev.speed_bias - ref.speed_bias).max() < 1e-6 and np.abs(dev.inv_depth - ref.inv_depth).max() < 1e-6
+    finally:
+        ctx.close()

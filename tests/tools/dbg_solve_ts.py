@@ -16,7 +16,7 @@ lib = _abi.load()
 ts = (C.c_longlong * 32)()
 lib.dv_debug_solve_ts.argtypes = [C.POINTER(C.c_longlong)]
 print("rc", lib.dv_debug_solve_ts(ts))
-t = np.array(ts[:18], dtype=np.int64)
+t = np.array(ts[:32], dtype=np.int64)
 # stamps (be_solve.hip TS(k)): 0 start, 1 scale/grad/tolerance done, 3 landmark diag done, 4 LDL^T blocks loaded, 5 factorised,
 # 6 factor stored, 7 back substitution done, 8 Gauss-Newton step complete, 9 dogleg coefficients + delta, 11 H*delta, 12 w.delta,
 # 13 candidate written, 10 end
@@ -25,4 +25,7 @@ seq = [(0, 1, "scale/grad/tol"), (1, 3, "landmark diag"), (3, 4, "ldlt load"), (
 for a, b, name in seq:
     print(f"{name:24s} {(t[b] - t[a]) / 100.0:8.2f} us")
 print("total", (t[10] - t[0]) / 100.0)
+if t[20]:
+    for a, b, name in [(3, 20, "fast: gather"), (20, 21, "fast: A1 chain (wave 0)"), (21, 22, "fast: A2 columns + stash"), (22, 23, "fast: A3/A4 pose update"), (23, 4, "fast: ldlt load (pose)"), (7, 24, "(back-sub end -> finish start)"), (24, 8, "fast: finish + gn landmarks")]:
+        print(f"{name:32s} {(t[b] - t[a]) / 100.0:8.2f} us")
 print("ldlt (c)+(a) us", ts[16] / 100.0, " (b) us", ts[17] / 100.0)

@@ -86,6 +86,9 @@ SIGNATURES = {
     "dv_est_process_end": (C.c_int, [_ctx, C.c_void_p]),
     "dv_est_process_dynamic": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_est_process_dynamic_begin": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dv_est_change_sensor_type": (C.c_int, [_ctx, C.c_int, C.c_int]),
+    "dv_est_get_latest": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dv_est_get_landmarks": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_inst_config": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
     "dv_inst_reset": (C.c_int, [_ctx]),
     "dv_inst_track_enqueue": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),

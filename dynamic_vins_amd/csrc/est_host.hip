@@ -140,6 +140,24 @@ struct dv_estimator {
     // the values the PREVIOUS frame's Optimization left there — ceres' raw output, or the gauge-fixed states where SetMarginalizationInfo called
     // Vector2double again (estimator.cpp:409,562)
     dvi::InstMgr im; double para_pose_ref[kWin + 1][7]; dv_ba_summary obj_last{}; bool dyn_frame = false;
+    // Estimator::latest_* (estimator.h): the state of the newest frame propagated by every IMU sample that arrived since (FastPredictIMU, estimator.cpp:1376-1392)
+    double latest_time = 0; d3 latest_P, latest_V, latest_Ba, latest_Bg, latest_acc_0, latest_gyr_0; quat latest_Q; bool latest_valid = false;
+    void fast_predict_imu(double t, d3 la, d3 av) {
+        const double dt = t - latest_time; latest_time = t;
+        const d3 un_acc_0 = qrot(latest_Q, latest_acc_0 - latest_Ba) - g;
+        const d3 un_gyr = (latest_gyr_0 + av) * 0.5 - latest_Bg;
+        latest_Q = qmul(latest_Q, dq_half(un_gyr * dt));
+        const d3 un_acc_1 = qrot(latest_Q, la - latest_Ba) - g;
+        const d3 un_acc = (un_acc_0 + un_acc_1) * 0.5;
+        latest_P = latest_P + latest_V * dt + un_acc * (0.5 * dt * dt);
+        latest_V = latest_V + un_acc * dt;
+        latest_acc_0 = la; latest_gyr_0 = av;
+    }
+    void update_latest_states() {          // UpdateLatestStates (estimator.cpp:1395-1418)
+        latest_time = headers[frame] + td; latest_P = Ps[frame]; latest_Q = qfromR(Rs[frame]); latest_V = Vs[frame]; latest_Ba = Bas[frame]; latest_Bg = Bgs[frame];
+        latest_acc_0 = acc_0; latest_gyr_0 = gyr_0; latest_valid = true;
+        for (auto& smp : imu_buf) fast_predict_imu(smp.first, smp.second.first, smp.second.second);
+    }
     // flat problem buffers
     std::vector<dv_ba_factor> fac; std::vector<dv_ba_lm> lmt; std::vector<dv_ba_imu> imu; std::vector<double> invd;
     double pose[kWin + 1][7], sb[kWin + 1][9], ex[2][7], tdv[1];
@@ -155,6 +173,7 @@ struct dv_estimator {
         im.clear(); im.cfg.use_det3d = cfg.use_det3d; im.cfg.init_min_num = cfg.instance_init_min_num; im.cfg.static_threshold = cfg.static_inst_threshold;
         im.cfg.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; im.cfg.max_iters = cfg.max_iters;
         std::memset(para_pose_ref, 0, sizeof(para_pose_ref)); obj_last = dv_ba_summary{}; dyn_frame = false;
+        latest_valid = false; latest_time = 0; latest_P = latest_V = latest_Ba = latest_Bg = latest_acc_0 = latest_gyr_0 = mk3(0, 0, 0); latest_Q = mkq(1, 0, 0, 0);
     }
     dvi::BodyView body_view() const { return dvi::BodyView{ Rs, Ps, ric, tic, headers, td, frame }; }
     double noise4[4];
@@ -563,6 +582,7 @@ struct dv_estimator {
         { HostScope h(ctx, "h_slide"); slide_window(); }
         if (dyn_frame) im.finish_frame(body_view());                                                                                 // estimator.cpp:1663-1676, on the slid window
         erase_if([](const Lm& l) { return l.solve_flag == 2; });      // RemoveFailures
+        if (cfg.use_imu) update_latest_states();
         return 0;
     }
     bool in_flight = false, begun = false;
@@ -581,7 +601,61 @@ int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg) {
 int dv_est_reset(dv_ctx* ctx) { if (!ctx || !ctx->est) return -1; if (ctx->est->begun) { ctx->est->begun = false; (void)ctx->est->process_image_end(ctx); } ctx->est->clear(); return 0; }
 int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr) {
     if (!ctx || !ctx->est) return -1;
-    ctx->est->imu_buf.push_back({ t, { mk3(acc[0], acc[1], acc[2]), mk3(gyr[0], gyr[1], gyr[2]) } });
+    dv_estimator& E = *ctx->est;
+    E.imu_buf.push_back({ t, { mk3(acc[0], acc[1], acc[2]), mk3(gyr[0], gyr[1], gyr[2]) } });
+    if (E.nonlinear && E.latest_valid) E.fast_predict_imu(t, mk3(acc[0], acc[1], acc[2]), mk3(gyr[0], gyr[1], gyr[2]));      // InputIMU: FastPredictIMU + PubLatestOdometry (estimator.cpp:734-741)
+    return 0;
+}
+// Estimator::ChangeSensorType (estimator.cpp:697-726)
+int dv_est_change_sensor_type(dv_ctx* ctx, int use_imu, int use_stereo) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_change_sensor_type: call dv_est_create first");
+    dv_estimator& E = *ctx->est;
+    if (E.begun) DV_FAIL("dv_est_change_sensor_type: a frame is in flight");
+    if (!use_imu && !use_stereo) DV_FAIL("dv_est_change_sensor_type: at least two sensors are needed (reference: message only)");
+    if (!use_stereo) DV_FAIL("dv_est_change_sensor_type: monocular operation is out of scope (every BASELINE config is stereo)");
+    bool restart = false;
+    if ((E.cfg.use_imu != 0) != (use_imu != 0)) {
+        E.cfg.use_imu = use_imu ? 1 : 0;
+        if (use_imu) restart = true;
+        else { E.prior = dv_ba_prior{}; E.prior_dev_A = E.prior_dev_b = nullptr; ctx->be.prior_resident = false; E.tmp_pre.reset(); E.latest_valid = false; }      // last_marg_info, tmp_pre_integration dropped
+    }
+    E.cfg.stereo = 1;
+    if (restart) E.clear();          // ClearState + SetParameter
+    return 0;
+}
+// latest_P / latest_Q / latest_V (what Publisher::PubLatestOdometry gets, estimator.cpp:737-739)
+int dv_est_get_latest(dv_ctx* ctx, double* t, double* P3o, double* Q4o, double* V3o) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_get_latest: call dv_est_create first");
+    const dv_estimator& E = *ctx->est;
+    if (!E.latest_valid) return 1;
+    const quat q = qnormalized(E.latest_Q);
+    if (t) *t = E.latest_time;
+    if (P3o) { P3o[0] = E.latest_P.x; P3o[1] = E.latest_P.y; P3o[2] = E.latest_P.z; }
+    if (Q4o) { Q4o[0] = q.x; Q4o[1] = q.y; Q4o[2] = q.z; Q4o[3] = q.w; }
+    if (V3o) { V3o[0] = E.latest_V.x; V3o[1] = E.latest_V.y; V3o[2] = E.latest_V.z; }
+    return 0;
+}
+// feat_manager.point_landmarks as the point-cloud publishers read them (utils/io/visualization.cpp:214-249)
+int dv_est_get_landmarks(dv_ctx* ctx, dv_landmark* out, int cap, int* n_out) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_get_landmarks: call dv_est_create first");
+    if (!n_out || cap < 0 || (cap > 0 && !out)) DV_FAIL("dv_est_get_landmarks: bad argument");
+    const dv_estimator& E = *ctx->est;
+    int k = 0;
+    for (auto& l : E.lms) {
+        if (k >= cap) break;
+        dv_landmark& o = out[k++];
+        std::memset(&o, 0, sizeof(o));
+        o.id = l.id; o.start_frame = l.start; o.n_obs = (int)l.obs.size(); o.solve_flag = l.solve_flag; o.depth = l.depth;
+        const d3 pw = mul(E.Rs[l.start], mul(E.ric[0], l.obs[0].pt * l.depth) + E.tic[0]) + E.Ps[l.start];      // body.CamToWorld(point * depth, start_frame)
+        o.p_w[0] = pw.x; o.p_w[1] = pw.y; o.p_w[2] = pw.z;
+        const bool base = o.n_obs >= 2 && l.start < kWin - 2;
+        o.in_point_cloud = base && !(l.start > kWin * 3.0 / 4.0 || l.solve_flag != 1);
+        o.in_margin_cloud = base && l.start == 0 && o.n_obs <= 2 && l.solve_flag == 1;
+    }
+    *n_out = k;
     return 0;
 }
 static int est_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {

@@ -82,6 +82,7 @@ public:
         if (it == scalars_.end()) throw std::runtime_error("dvins: config key missing: " + k);
         return it->second;
     }
+    std::string str(const std::string& k, const std::string& dflt) const { return has(k) ? str(k) : dflt; }
     double num(const std::string& k) const { return std::strtod(str(k).c_str(), nullptr); }
     double num(const std::string& k, double dflt) const { return has(k) ? num(k) : dflt; }
     int integer(const std::string& k, int dflt) const { return has(k) ? (int)std::lround(num(k)) : dflt; }
@@ -229,6 +230,28 @@ public:
         n_rows_ = n;
         return detail::to_points(rows_.data(), n);
     }
+    // FeatureTracker::img_track() / prev_img / cur_img (background_tracker.h:41-88): the publishers' `image_track` picture.  The shim keeps host copies of
+    // the last two left frames when keep_images is set (host gray input only) and DrawTrack()s the tracked points onto a BGR copy: colour by track age
+    // (blue = new ... red = 20+ frames) like FeatureTracker::DrawTrack (background_tracker.cpp:598-650).  Visualisation only: not on the measured path.
+    bool keep_images = false;
+    struct HostImage { int width = 0, height = 0, channels = 1; std::vector<uint8_t> data; bool empty() const { return data.empty(); } };
+    HostImage prev_img, cur_img;
+    const HostImage& img_track() {
+        img_track_.width = cur_img.width; img_track_.height = cur_img.height; img_track_.channels = 3;
+        img_track_.data.resize((size_t)cur_img.width * cur_img.height * 3);
+        for (size_t i = 0; i < (size_t)cur_img.width * cur_img.height; ++i) { const uint8_t g = cur_img.data.empty() ? 0 : cur_img.data[i]; img_track_.data[3 * i] = img_track_.data[3 * i + 1] = img_track_.data[3 * i + 2] = g; }
+        for (int k = 0; k < n_rows_; ++k) {
+            const double len = std::min(1.0, rows_[k].track_cnt / 20.0);
+            const uint8_t b = (uint8_t)(255 * (1 - len)), r = (uint8_t)(255 * len);
+            const int cx = (int)std::lround(rows_[k].left[3]), cy = (int)std::lround(rows_[k].left[4]);
+            for (int dy = -2; dy <= 2; ++dy) for (int dx = -2; dx <= 2; ++dx) {
+                const int x = cx + dx, y = cy + dy;
+                if (dx * dx + dy * dy > 5 || x < 0 || y < 0 || x >= img_track_.width || y >= img_track_.height) continue;
+                uint8_t* px = &img_track_.data[3 * ((size_t)y * img_track_.width + x)]; px[0] = b; px[1] = 0; px[2] = r;
+            }
+        }
+        return img_track_;
+    }
     const dv_feat* rows() const { return rows_.data(); }      // the same output as flat rows (what Estimator::ProcessMeasurements consumes)
     int n_rows() const { return n_rows_; }
     dv_ctx* ctx() { return ctx_; }
@@ -265,8 +288,16 @@ private:
         if (img.gray0.empty() || (cfg_.stereo && img.gray1.empty())) throw std::runtime_error("dvins: TrackImage: empty image");
         if (img.gray0.width != cfg_.width || img.gray0.height != cfg_.height) throw std::runtime_error("dvins: TrackImage: image size differs from image_width/image_height");   // main.cpp:95-99
     }
+    void remember(const SemanticImage& img) {
+        if (!keep_images || img.gray0.device || img.gray0.bgr) return;
+        prev_img = std::move(cur_img);
+        cur_img.width = img.gray0.width; cur_img.height = img.gray0.height; cur_img.channels = 1; cur_img.data.resize((size_t)cur_img.width * cur_img.height);
+        for (int y = 0; y < cur_img.height; ++y) std::memcpy(&cur_img.data[(size_t)y * cur_img.width], img.gray0.data + (size_t)y * img.gray0.stride, cur_img.width);
+    }
+    HostImage img_track_;
     FeatureBackground track(SemanticImage& img, int mode) {
         check_image(img);
+        remember(img);
         cur_time = img.time0;
         int n = 0;
         detail::check(ctx_, dv_track_stereo(ctx_, img.gray0.data, img.gray1.data, img.gray0.width, img.gray0.height, img.gray0.stride, img.time0,
@@ -278,6 +309,59 @@ private:
     dv_ctx* ctx_ = nullptr;
     std::vector<dv_feat> rows_;
     int n_rows_ = 0;
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// InstsFeatManager (front_end/dynamic_tracker.h:42-101): the per-object tracker of dynamic mode on the FeatureTracker's device context.
+// The reference fills `instances` from SemanticImage::boxes2d after MOT association (AddInstancesByTracking / AddViodeInstances); here the detections
+// arrive as dv_inst_det (track id, class, rectangle, ROI mask, optional extra 3-D points).  InstsTrack must follow the TrackSemanticImage enqueue of the
+// same frame (the reference runs the two on two threads over the same image, system/main.cpp:247-250).
+struct FeatureInstance {                // basic/frontend_feature.h:58-66, flat
+    unsigned int id = 0; bool has_box3d = false; dv_box3d box3d{}; float rect[4] = {0, 0, 0, 0};
+    std::vector<dv_feat> features;      // left = (x_n, y_n, 1, u, v, vx, vy) in ROI pixel coordinates for u, v; right likewise when has_right
+    std::vector<std::array<double, 3>> points;
+};
+class InstsFeatManager {
+public:
+    using Ptr = std::shared_ptr<InstsFeatManager>;
+    // max_dynamic_cnt / min_dynamic_dist / use_det3d of the config file (front_end_parameters.cpp:30-36, utils/parameters.cpp)
+    InstsFeatManager(FeatureTracker& tracker, const std::string& config_path) : ctx_(tracker.ctx()) {
+        YamlFile y(config_path);
+        detail::check(ctx_, dv_inst_config(ctx_, y.integer("max_dynamic_cnt", 50), y.integer("min_dynamic_dist", 5), y.integer("use_det3d", 0)), "InstsFeatManager");
+        alloc();
+    }
+    InstsFeatManager(FeatureTracker& tracker, int max_dynamic_cnt, int min_dynamic_dist, int use_det3d) : ctx_(tracker.ctx()) {
+        detail::check(ctx_, dv_inst_config(ctx_, max_dynamic_cnt, min_dynamic_dist, use_det3d), "InstsFeatManager");
+        alloc();
+    }
+    void InstsTrack(double time, const std::vector<dv_inst_det>& dets, const std::vector<dv_box3d>& boxes3d = {}) {
+        detail::check(ctx_, dv_inst_track_enqueue(ctx_, time, dets.empty() ? nullptr : dets.data(), (int)dets.size(), boxes3d.empty() ? nullptr : boxes3d.data(), (int)boxes3d.size()), "InstsTrack");
+        pending_ = true;
+    }
+    // flat form (what Estimator::ProcessMeasurements(dynamic) consumes) — valid until the next Output()
+    void Collect() {
+        if (!pending_) return;
+        detail::check(ctx_, dv_inst_track_collect(ctx_, insts_.data(), (int)insts_.size(), &n_insts_, feats_.data(), (int)feats_.size(), &n_feats_, points_.data(), (int)points_.size() / 3, &n_points_), "Output");
+        pending_ = false;
+    }
+    std::map<unsigned int, FeatureInstance> Output() {      // front_end/dynamic_tracker.cpp:521-577
+        Collect();
+        std::map<unsigned int, FeatureInstance> out;
+        for (int i = 0; i < n_insts_; ++i) {
+            FeatureInstance f; f.id = insts_[i].id; f.has_box3d = insts_[i].has_box3d != 0; f.box3d = insts_[i].box3d; std::memcpy(f.rect, insts_[i].rect, sizeof(f.rect));
+            f.features.assign(feats_.begin() + insts_[i].first_feat, feats_.begin() + insts_[i].first_feat + insts_[i].n_feats);
+            for (int k = 0; k < insts_[i].n_points; ++k) { const double* p = &points_[3 * (size_t)(insts_[i].first_point + k)]; f.points.push_back({p[0], p[1], p[2]}); }
+            out.emplace(f.id, std::move(f));
+        }
+        return out;
+    }
+    const dv_inst_obs* insts() const { return insts_.data(); } int n_insts() const { return n_insts_; }
+    const dv_feat* feats() const { return feats_.data(); } int n_feats() const { return n_feats_; }
+    const double* points() const { return points_.data(); } int n_points() const { return n_points_; }
+private:
+    void alloc() { insts_.resize(64); feats_.resize(64 * 256); points_.resize(3 * 65536); }
+    dv_ctx* ctx_; bool pending_ = false;
+    std::vector<dv_inst_obs> insts_; std::vector<dv_feat> feats_; std::vector<double> points_; int n_insts_ = 0, n_feats_ = 0, n_points_ = 0;
 };
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -295,6 +379,9 @@ public:
         cfg_.init_depth = y.num("INIT_DEPTH", 5.0);
         cfg_.g_norm = y.num("g_norm", 9.81007); cfg_.td = y.num("td", 0.0);
         cfg_.acc_n = y.num("acc_n", 0.1); cfg_.gyr_n = y.num("gyr_n", 0.01); cfg_.acc_w = y.num("acc_w", 0.001); cfg_.gyr_w = y.num("gyr_w", 1e-4);
+        // dynamic mode: `slam: dynamic` selects the object branch (utils/parameters.cpp), with use_det3d / instance_init_min_num / static_inst_threshold
+        cfg_.dynamic = y.str("slam_type", "raw") == "dynamic" ? 1 : 0; cfg_.use_det3d = y.integer("use_det3d", 0);
+        cfg_.instance_init_min_num = y.integer("instance_init_min_num", 4); cfg_.static_inst_threshold = y.num("static_inst_threshold", 10.0);
         if (y.integer("estimate_extrinsic", 0) != 0 || y.integer("estimate_td", 0) != 0)
             throw std::runtime_error("dvins: estimate_extrinsic / estimate_td != 0 are not on the accelerated path (every shipped config sets 0)");
         for (int c = 0; c < 2; ++c) {
@@ -341,10 +428,51 @@ public:
         { std::lock_guard<std::mutex> lk2(buf_mutex_); rc = dv_est_process(ctx_, rows, n, time, &state_); }
         if (rc == 1) return false;
         detail::check(ctx_, rc, "ProcessMeasurements");
-        solver_flag = state_.nonlinear ? kNonLinear : kInitial;
-        margin_old = state_.margin_old != 0;
-        frame = state_.frame;
+        after_frame();
         return true;
+    }
+    // dynamic mode: FrontendFeature::instances travel with the background features (estimator.cpp:1562-1622)
+    bool ProcessMeasurements(const dv_feat* rows, int n, double time, const InstsFeatManager& insts) {
+        std::lock_guard<std::mutex> lk(process_mutex_);
+        int rc;
+        { std::lock_guard<std::mutex> lk2(buf_mutex_);
+          rc = dv_est_process_dynamic(ctx_, rows, n, time, insts.n_insts() ? insts.insts() : nullptr, insts.n_insts(), insts.n_feats() ? insts.feats() : nullptr,
+                                      insts.n_points() ? insts.points() : nullptr, &state_); }
+        if (rc == 1) return false;
+        detail::check(ctx_, rc, "ProcessMeasurements");
+        after_frame();
+        return true;
+    }
+    // Estimator::im.instances after the last frame (InstanceManager::SetOutputInstInfo / the instance publishers)
+    std::vector<dv_inst_state> Instances() {
+        std::vector<dv_inst_state> v(64); int n = 0;
+        detail::check(ctx_, dv_est_get_instances(ctx_, v.data(), (int)v.size(), &n, nullptr), "Instances");
+        v.resize(n); return v;
+    }
+    // Estimator::ChangeSensorType (estimator.cpp:697-726)
+    void ChangeSensorType(int use_imu, int use_stereo) {
+        std::lock_guard<std::mutex> lk(process_mutex_);
+        detail::check(ctx_, dv_est_change_sensor_type(ctx_, use_imu, use_stereo), "ChangeSensorType");
+        cfg_.use_imu = use_imu;
+    }
+    // latest_P / latest_Q / latest_V: FastPredictIMU's output, published on `imu_propagate` (estimator.cpp:729-742); false until the estimator is initialised
+    bool LatestState(double& t, Vec3d& P, std::array<double, 4>& Q_xyzw, Vec3d& V) {
+        std::lock_guard<std::mutex> lk(buf_mutex_);
+        const int rc = dv_est_get_latest(ctx_, &t, P.data(), Q_xyzw.data(), V.data());
+        if (rc == 1) return false;
+        detail::check(ctx_, rc, "LatestState");
+        return true;
+    }
+    // Set/GetOutputEgoInfo (estimator.h:71-82): pose of the newest frame + extrinsic, written after every frame (estimator.cpp:1856) and read by PubTF
+    struct EgoInfo { std::array<double, 9> R; Vec3d P; std::array<double, 9> R_bc; Vec3d P_bc; };
+    void SetOutputEgoInfo(const EgoInfo& e) { std::lock_guard<std::mutex> lk(out_pose_mutex_); ego_ = e; }
+    EgoInfo GetOutputEgoInfo() { std::lock_guard<std::mutex> lk(out_pose_mutex_); return ego_; }
+    std::vector<Vec3d> key_poses;                            // body.Ps[0..kWinSize] after every frame (estimator.cpp:1681-1683)
+    // feat_manager.point_landmarks for the `point_cloud` / `margin_cloud` publishers (utils/io/visualization.cpp:214-249)
+    std::vector<dv_landmark> Landmarks() {
+        std::vector<dv_landmark> v(2048); int n = 0;
+        detail::check(ctx_, dv_est_get_landmarks(ctx_, v.data(), (int)v.size(), &n), "Landmarks");
+        v.resize(n); return v;
     }
     // the reference's blocking form: pops the shared queue until `ok` turns false
     void PushFeature(FrontendFeature f) { { std::lock_guard<std::mutex> lk(q_mutex_); queue_.push_back(std::move(f)); } q_cv_.notify_one(); }
@@ -369,6 +497,25 @@ public:
     int frame = 0;
 
 private:
+    static std::array<double, 9> quat_to_R(const double* q /* x y z w */) {
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        return { 1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y) };
+    }
+    void after_frame() {
+        solver_flag = state_.nonlinear ? kNonLinear : kInitial;
+        margin_old = state_.margin_old != 0;
+        frame = state_.frame;
+        key_poses.clear();
+        for (int i = 0; i <= 10; ++i) key_poses.push_back(Vec3d{ state_.window[i][0], state_.window[i][1], state_.window[i][2] });
+        if (state_.nonlinear) {          // SetOutputEgoInfo(body.Rs[kWinSize], body.Ps[kWinSize], body.ric[0], body.tic[0]) (estimator.cpp:1856)
+            EgoInfo e; e.R = quat_to_R(&state_.window[10][3]); e.P = Vec3d{ state_.window[10][0], state_.window[10][1], state_.window[10][2] };
+            for (int k = 0; k < 9; ++k) e.R_bc[k] = cfg_.ric[0][k];
+            e.P_bc = Vec3d{ cfg_.tic[0][0], cfg_.tic[0][1], cfg_.tic[0][2] };
+            SetOutputEgoInfo(e);
+        }
+    }
+    std::mutex out_pose_mutex_; EgoInfo ego_{};
     dv_est_config cfg_;
     dv_est_state state_{};
     dv_ctx* ctx_ = nullptr;

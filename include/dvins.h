@@ -341,6 +341,18 @@ int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_st
 int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t);
 int dv_est_process_end(dv_ctx* ctx, dv_est_state* out);
 
+/* ---- the members of Estimator the callbacks and publishers use besides ProcessMeasurements (estimator/estimator.h:55-164) ---- */
+/* Estimator::ChangeSensorType (estimator.cpp:697-726; the /vins_imu_switch, /vins_cam_switch callbacks): switching the IMU on restarts the estimator
+ * (ClearState + SetParameter), switching it off drops the prior.  use_stereo = 0 is refused (monocular initialisation is out of scope). */
+int dv_est_change_sensor_type(dv_ctx* ctx, int use_imu, int use_stereo);
+/* latest_time / latest_P / latest_Q (qx qy qz qw) / latest_V: the newest frame's state propagated by every IMU sample fed since — FastPredictIMU inside
+ * InputIMU and UpdateLatestStates (estimator.cpp:729-742,1376-1418): what PubLatestOdometry publishes on `imu_propagate`.  Returns 1 while not initialised. */
+int dv_est_get_latest(dv_ctx* ctx, double* t, double* P3, double* Q4, double* V3);
+/* FeatureManager::point_landmarks for the point-cloud publishers (utils/io/visualization.cpp:214-249): world point = CamToWorld(point * depth, start_frame);
+ * in_point_cloud / in_margin_cloud apply PubPointCloud's two selection rules.  key_poses = window[i][0..2] of dv_est_state. */
+typedef struct dv_landmark { int32_t id, start_frame, n_obs, solve_flag; double depth, p_w[3]; int32_t in_point_cloud, in_margin_cloud; } dv_landmark;
+int dv_est_get_landmarks(dv_ctx* ctx, dv_landmark* out, int cap, int* n_out);
+
 /* ---- dynamic mode: the object (instance) half of the back end.  Inputs are FrontendFeature::instances (basic/frontend_feature.h:58-75), i.e.
  * what InstsFeatManager::Output() hands over (front_end/dynamic_tracker.cpp:521-577): per object its tracked features, the associated 3-D
  * detection (if any) and the "extra" 3-D points sampled from the disparity map (camera frame).  The association of detections to tracks

@@ -4,6 +4,7 @@
 //   shim_test sync <config.yaml>                       -> StereoSync / FrameGate on scripted time stamps (CPU)
 //   shim_test track <config.yaml> <frames.raw> <n> <w> <h>  -> runs TrackImage over n stereo pairs read from a raw file,
 //                                                         feeds a constant-gravity IMU stream and runs the Estimator (GPU)
+//   shim_test members <config.yaml> <frames.raw> <n> <w> <h> -> the callback / publisher members + dynamic mode through the shim (GPU)
 //   shim_test extras <config.yaml> <frames.raw> <n> <w> <h> -> SetUndistortMaps + BGR views, OptimizeInstances (GPU)
 #include <cmath>
 #include <cstdio>
@@ -95,6 +96,54 @@ int main(int argc, char** argv) {
                 std::printf("est ok %d frame %d nonlinear %d\n", (int)ok, est.frame, (int)est.solver_flag);
             }
             std::printf("%s\n", TumLine(1.0, est.WindowState(est.frame)).c_str());
+            return 0;
+        }
+        if (mode == "members" && argc >= 7) {
+            // the members the reference's callbacks / publishers use: keep_images + img_track, LatestState (FastPredictIMU), key_poses, Set/GetOutputEgoInfo,
+            // Landmarks, ChangeSensorType; and dynamic mode through the shim: InstsFeatManager::InstsTrack / Output + Estimator::ProcessMeasurements(dynamic)
+            const int n = std::atoi(argv[4]), w = std::atoi(argv[5]), h = std::atoi(argv[6]);
+            std::ifstream f(argv[3], std::ios::binary);
+            std::vector<uint8_t> buf((size_t)n * 2 * w * h);
+            f.read((char*)buf.data(), buf.size());
+            dv_config c{};
+            YamlFile y(cfg);
+            c.width = w; c.height = h; c.max_cnt = 30; c.min_dist = 10; c.flow_back = 1; c.stereo = 1;
+            c.cam0 = ReadPinholeCamera(dir_of(cfg) + "/" + y.str("cam0_calib"));
+            c.cam0.fx *= w / 1280.0; c.cam0.cx *= w / 1280.0; c.cam0.fy *= h / 720.0; c.cam0.cy *= h / 720.0; c.cam1 = c.cam0;
+            FeatureTracker tracker(c);
+            tracker.keep_images = true;
+            InstsFeatManager insts(tracker, 20, 4, 0);
+            Estimator est(cfg);
+            std::vector<uint8_t> mask((size_t)60 * 40, 255), inv((size_t)w * h, 255);
+            const int bx = w / 2 - 30, by = h / 2 - 20;
+            for (int yy = 0; yy < 40; ++yy) for (int xx = 0; xx < 60; ++xx) inv[(size_t)(by + yy) * w + bx + xx] = 0;
+            double t_imu = 0.95; int obj_feats = 0, frames_with_obj = 0;
+            for (int k = 0; k < n; ++k) {
+                SemanticImage img;
+                img.gray0 = ImageView{buf.data() + (size_t)(2 * k) * w * h, w, h, w, false};
+                img.gray1 = ImageView{buf.data() + (size_t)(2 * k + 1) * w * h, w, h, w, false};
+                img.inv_merge_mask = ImageView{inv.data(), w, h, w, false};
+                img.time0 = 1.0 + 0.05 * k; img.seq = k;
+                tracker.TrackImageEnqueue(img, DV_MODE_SEMANTIC);
+                dv_inst_det d{}; d.track_id = 7; d.class_id = 2; d.x = bx; d.y = by; d.w = 60; d.h = 40; d.mask = mask.data();
+                insts.InstsTrack(img.time0, {d});
+                FeatureBackground fb = tracker.TrackImageCollect();
+                auto objs = insts.Output();
+                if (!objs.empty()) { frames_with_obj++; obj_feats += (int)objs.begin()->second.features.size(); }
+                for (; t_imu <= img.time0 + 0.006; t_imu += 0.005) est.InputIMU(t_imu, Vec3d{0, 0, 9.81007}, Vec3d{0, 0, 0});
+                est.ProcessMeasurements(tracker.rows(), tracker.n_rows(), img.time0);
+            }
+            const auto& it = tracker.img_track();
+            size_t coloured = 0; for (size_t i = 0; i < it.data.size(); i += 3) coloured += it.data[i] != it.data[i + 1];
+            std::printf("img_track %dx%dx%d coloured %d prev %d cur %d\n", it.width, it.height, it.channels, coloured > 0, !tracker.prev_img.empty(), !tracker.cur_img.empty());
+            std::printf("objects frames %d feats_positive %d\n", frames_with_obj, obj_feats > 0);
+            double tl; Vec3d P, V; std::array<double, 4> Q;
+            const bool have = est.LatestState(tl, P, Q, V);
+            std::printf("latest %d key_poses %zu landmarks_positive %d\n", (int)have, est.key_poses.size(), (int)!est.Landmarks().empty());
+            const Estimator::EgoInfo e = est.GetOutputEgoInfo();
+            std::printf("ego R00 %.3f P_bc %.3f %.3f %.3f\n", e.R[0], e.P_bc[0], e.P_bc[1], e.P_bc[2]);
+            est.ChangeSensorType(0, 1);
+            std::printf("changed\n");
             return 0;
         }
         if (mode == "extras" && argc >= 7) {

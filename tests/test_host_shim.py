@@ -124,3 +124,23 @@ def test_shim_stereo_sync_and_frame_gate(shim_exe):
     assert out[0] == "0 | 10 21 1.000 1.052 | - | 12 22 1.100 1.100 | 13 23 1.150 1.149 | - | - | dropped 1 2 pending 0 0"
     assert out[1] == "0 1 2 7 2.099 dropped 1"
     assert out[2].split() == ["11", "01", "11", "01", "11"]
+
+
+@pytest.mark.gpu
+def test_shim_callback_and_publisher_members_and_dynamic_mode(shim_exe, tmp_path):
+    """img_track / prev_img / cur_img, LatestState (FastPredictIMU), key_poses, Set/GetOutputEgoInfo, Landmarks, ChangeSensorType and the dynamic-mode classes
+    (InstsFeatManager::InstsTrack / Output) through the C++ shim"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "front_kat.npz"))
+    n, h, w = g["left"].shape
+    raw = tmp_path / "frames.raw"
+    with open(raw, "wb") as f:
+        for k in range(n):
+            f.write(g["left"][k].tobytes()); f.write(g["right"][k].tobytes())
+    r = subprocess.run([shim_exe, "members", CFG, str(raw), str(n), str(w), str(h)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "img_track %dx%dx3 coloured 1 prev 1 cur 1" % (w, h)
+    assert out[1] == "objects frames %d feats_positive 1" % n
+    assert out[2].startswith("latest ") and out[2].endswith("key_poses 11 landmarks_positive 1")
+    assert out[3].startswith("ego R00 ") and out[3].endswith("P_bc 0.000 0.000 0.000")
+    assert out[4] == "changed"

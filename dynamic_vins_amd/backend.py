@@ -37,7 +37,7 @@ class dv_ba_problem(C.Structure):
                 ("g_norm", C.c_double),
                 ("pose", C.c_void_p), ("speed_bias", C.c_void_p), ("ex_pose", C.c_void_p), ("td", C.c_void_p), ("inv_depth", C.c_void_p),
                 ("factors", C.c_void_p), ("landmarks", C.c_void_p), ("imu", C.c_void_p),
-                ("prior", C.c_void_p), ("prior_A", C.c_void_p), ("prior_b", C.c_void_p)]
+                ("prior", C.c_void_p), ("prior_A", C.c_void_p), ("prior_b", C.c_void_p), ("x_norm2_extra", C.c_double)]
 
 
 class dv_ba_summary(C.Structure):
@@ -287,12 +287,17 @@ def line_solve(ctx, prob):
     return s
 
 
+LINEROW_DTYPE = np.dtype([("id", "u4"), ("has_right", "i4"), ("left", "f8", 4), ("right", "f8", 4)])
+LINELM_DTYPE = np.dtype([("id", "i4"), ("start_frame", "i4"), ("n_obs", "i4"), ("is_triangulation", "i4"), ("plucker", "f8", 6), ("ptw1", "f8", 3), ("ptw2", "f8", 3)])
+
+
 class dv_est_config(C.Structure):
     _fields_ = [("use_imu", C.c_int32), ("stereo", C.c_int32), ("plane_constraint", C.c_int32), ("max_iters", C.c_int32),
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),
                 ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
                 ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2),
-                ("dynamic", C.c_int32), ("use_det3d", C.c_int32), ("instance_init_min_num", C.c_int32), ("pad_", C.c_int32), ("static_inst_threshold", C.c_double)]
+                ("dynamic", C.c_int32), ("use_det3d", C.c_int32), ("instance_init_min_num", C.c_int32), ("pad_", C.c_int32), ("static_inst_threshold", C.c_double),
+                ("use_line", C.c_int32), ("line_min_obs", C.c_int32), ("line_sqrt_info", C.c_double * 4)]
 
 
 class dv_est_state(C.Structure):
@@ -306,13 +311,17 @@ class Estimator:
     InputIMU / ProcessMeasurements keep the reference's names; camelCase aliases provided."""
 
     def __init__(self, ctx, use_imu=1, stereo=1, plane_constraint=0, max_iters=8, keyframe_parallax=10.0, init_depth=5.0, g_norm=9.81, td=0.0,
-                 acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None, dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0):
+                 acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None, dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0,
+                 use_line=0, line_min_obs=5, line_sqrt_info=(0.0, 0.0, 0.0, 0.0)):
         self.ctx = ctx
         c = dv_est_config()
         c.use_imu, c.stereo, c.plane_constraint, c.max_iters = use_imu, stereo, plane_constraint, max_iters
         c.keyframe_parallax, c.init_depth, c.g_norm, c.td = keyframe_parallax, init_depth, g_norm, td
         c.acc_n, c.gyr_n, c.acc_w, c.gyr_w = acc_n, gyr_n, acc_w, gyr_w
         c.dynamic, c.use_det3d, c.instance_init_min_num, c.static_inst_threshold = dynamic, use_det3d, instance_init_min_num, static_inst_threshold
+        c.use_line, c.line_min_obs = use_line, line_min_obs
+        for i in range(4):
+            c.line_sqrt_info[i] = float(line_sqrt_info[i])
         for k in range(2):
             for i in range(9):
                 c.ric[k][i] = float(np.asarray(ric[k]).reshape(-1)[i])
@@ -370,6 +379,16 @@ class Estimator:
         out = np.zeros(cap, INSTSTATE_DTYPE); n = C.c_int(0); summ = np.zeros(4)
         self._check(self.ctx.lib.dv_est_get_instances(self.ctx.h, out.ctypes.data, cap, C.byref(n), summ.ctypes.data))
         return out[: n.value].copy(), summ
+
+    # ---- line mode (cfg::use_line): frame.features.lines of the next frame, line landmarks read-out ----
+    def SetLines(self, rows):
+        self._lines = np.ascontiguousarray(rows, LINEROW_DTYPE)
+        self._check(self.ctx.lib.dv_est_set_lines(self.ctx.h, self._lines.ctypes.data if len(self._lines) else None, len(self._lines)))
+
+    def lines(self, cap=4096):
+        out = np.zeros(cap, LINELM_DTYPE); n = C.c_int(0)
+        self._check(self.ctx.lib.dv_est_get_lines(self.ctx.h, out.ctypes.data, cap, C.byref(n)))
+        return out[: n.value].copy()
 
     def ClearState(self):
         self._check(self.ctx.lib.dv_est_reset(self.ctx.h))

@@ -376,6 +376,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     for (int k = 0; k < 2; ++k) { sa.packets[k] = w.packets[k]; sa.imu_out[k] = w.imu_out[k]; sa.prior_out[k] = w.prior_out[k]; sa.Hd[k] = w.Hd[k]; sa.Sc[k] = w.Sc[k]; sa.gvec[k] = w.gvec[k]; }
     sa.scale_p = w.scale_p; sa.diag_p = w.diag_p; sa.grad_p = w.grad_p; sa.gn_p = w.gn_p; sa.scale_l = w.scale_l; sa.diag_l = w.diag_l; sa.grad_l = w.grad_l; sa.gn_l = w.gn_l;
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;
+    sa.xnorm2_extra = P->x_norm2_extra;
     // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
     // invalid; be_solve_fused_end checks the downloaded control block and, in that rare case, runs the spare slots and the
     // (idempotent) tail again.

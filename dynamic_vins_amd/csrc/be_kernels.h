@@ -32,6 +32,7 @@ struct BeSolveArgs {
     double* scale_l; double* diag_l; double* grad_l; double* gn_l;     // [nlm]
     int32_t* prior_col;     // [BE_MAX_STATE] prior index of each state column (-1 if absent)
     int32_t* col_kind; int32_t* col_frame; int32_t* col_comp;          // [n]
+    double xnorm2_extra;    // squared norm of inert free blocks (line blocks under zero sqrt_info) that count in the parameter-tolerance test
 };
 
 struct BeMargArgs {

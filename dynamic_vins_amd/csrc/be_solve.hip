@@ -973,7 +973,7 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
     TS(13);
     double sv5[5] = {p_dn, p_sg, p_sHs, p_step, p_xn};
     block_sum_n<5>(sv5, red);
-    const double dn2 = sv5[0], sg = sv5[1], sHs = sv5[2], step2 = sv5[3], xn2 = sv5[4];
+    const double dn2 = sv5[0], sg = sv5[1], sHs = sv5[2], step2 = sv5[3], xn2 = sv5[4] + a.xnorm2_extra;
     TS(10);
     if (tid == 0) {
         const double mcc = -(sg + 0.5 * sHs);

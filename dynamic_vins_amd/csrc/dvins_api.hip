@@ -623,4 +623,16 @@ int dv_lift_projective_offset(dv_ctx* ctx, const dv_cam* cam, const float* pts_x
     return 0;
 }
 
+// FrameLines::UndistortedLineEndPoints (line_detector, front end of TrackImageLine): both end points through PinholeCamera::liftProjective; the Line keeps
+// them as cv::Point2f, LineFeature widens to double (basic/line_feature.h:31-33)
+int dv_undistort_lines(dv_ctx* ctx, const dv_cam* cam, const float* lines_xyxy, int n, double* out_xyxy) {
+    if (!ctx) return -1;
+    if (!cam || n < 0 || (n > 0 && (!lines_xyxy || !out_xyxy))) DV_FAIL("dv_undistort_lines: bad argument");
+    if (n == 0) return 0;
+    std::vector<float> un((size_t)4 * n);
+    if (dv_lift_projective(ctx, cam, lines_xyxy, 2 * n, un.data(), DV_MEM_HOST)) return -1;
+    for (size_t i = 0; i < (size_t)4 * n; ++i) out_xyxy[i] = (double)un[i];
+    return 0;
+}
+
 } // extern "C"

@@ -18,6 +18,7 @@
 #include "dv_ctx.h"
 #include "be_math.h"
 #include "inst_host.h"
+#include "line_host.h"
 
 using namespace be;
 
@@ -140,6 +141,8 @@ struct dv_estimator {
     // the values the PREVIOUS frame's Optimization left there — ceres' raw output, or the gauge-fixed states where SetMarginalizationInfo called
     // Vector2double again (estimator.cpp:409,562)
     dvi::InstMgr im; double para_pose_ref[kWin + 1][7]; dv_ba_summary obj_last{}; bool dyn_frame = false;
+    // line mode (cfg.use_line): FeatureManager::line_landmarks + body.para_line_features as Vector2double fills them
+    dvl::LineMgr lines; std::vector<dv_line_row> pending_lines; std::vector<double> para_line; dv_ba_summary line_last{};
     // Estimator::latest_* (estimator.h): the state of the newest frame propagated by every IMU sample that arrived since (FastPredictIMU, estimator.cpp:1376-1392)
     double latest_time = 0; d3 latest_P, latest_V, latest_Ba, latest_Bg, latest_acc_0, latest_gyr_0; quat latest_Q; bool latest_valid = false;
     void fast_predict_imu(double t, d3 la, d3 av) {
@@ -170,6 +173,7 @@ struct dv_estimator {
         prev_time = -1; cur_time = 0; first_imu = false; init_pose = false; frame = 0; nonlinear = false; acc_0 = gyr_0 = mk3(0, 0, 0);
         for (int k = 0; k < 2; ++k) { for (int i = 0; i < 9; ++i) ric[k].m[i] = cfg.ric[k][i]; tic[k] = mk3(cfg.tic[k][0], cfg.tic[k][1], cfg.tic[k][2]); }
         td = cfg.td; g = mk3(0, 0, cfg.g_norm);
+        lines.clear(); lines.min_obs = cfg.line_min_obs > 0 ? cfg.line_min_obs : 5; pending_lines.clear(); para_line.clear(); line_last = dv_ba_summary{};
         im.clear(); im.cfg.use_det3d = cfg.use_det3d; im.cfg.init_min_num = cfg.instance_init_min_num; im.cfg.static_threshold = cfg.static_inst_threshold;
         im.cfg.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; im.cfg.max_iters = cfg.max_iters;
         std::memset(para_pose_ref, 0, sizeof(para_pose_ref)); obj_last = dv_ba_summary{}; dyn_frame = false;
@@ -397,6 +401,11 @@ struct dv_estimator {
           if (cfg.use_imu) for (int i = 0; i < frame; ++i) { if (pre[i + 1]->sum_dt > 10.0) continue; dv_ba_imu r; pre[i + 1]->fill(r, i, i + 1); imu.push_back(r); ctx->be.sqrt_hint.push_back(pre[i + 1]->sqrt_info()); }
           prior_dev_A = prior.valid ? ctx->be.priorA_buf[ctx->be.prior_cur] : nullptr; prior_dev_b = prior.valid ? ctx->be.priorb_buf[ctx->be.prior_cur] : nullptr;
           P = make_problem(frame + 1);
+          if (cfg.use_line) {          // Vector2double's line part + AddLineResidualBlock under zero weights: the blocks only count in |x| (see dv_ba_problem::x_norm2_extra)
+              lines.get_orth(Rs, Ps, ric[0], tic[0], para_line);
+              double sq = 0; for (double v : para_line) sq += v * v;
+              P.x_norm2_extra = sq;
+          }
           // gauge reference: yaw and position of frame 0 before the solve (Double2vector, estimator.cpp:1111-1128)
           const d3 y0 = r2ypr(Rs[0]);
           std::memcpy(fu.R0, Rs[0].m, sizeof(fu.R0)); fu.ypr0[0] = y0.x; fu.ypr0[1] = y0.y; fu.ypr0[2] = y0.z; fu.P0[0] = Ps[0].x; fu.P0[1] = Ps[0].y; fu.P0[2] = Ps[0].z;
@@ -416,6 +425,7 @@ struct dv_estimator {
     int optimization_end(dv_ctx* ctx) {
         { HostScope h(ctx, "h_solve_wait"); if (be_solve_fused_end(ctx, &P, &last, &fu)) return -1; }
         { HostScope h(ctx, "h_post"); arrays_to_states(); }
+        if (cfg.use_line && !para_line.empty()) lines.set_orth(Rs, Ps, ric[0], tic[0], para_line.data());      // Double2vector: SetLineOrth with the solved poses
         if (fu.marg_mode >= 0) prior = fu.new_prior;
         if (cfg.dynamic) {
             if (fu.marg_mode >= 0) {          // SetMarginalizationInfo re-ran Vector2double: para_pose = the gauge-fixed window
@@ -472,9 +482,11 @@ struct dv_estimator {
                     l.depth = pj.z > 0 ? pj.z : cfg.init_depth;
                 }
                 erase_if([](const Lm& l) { return l.id < 0; });
+                if (cfg.use_line) lines.remove_back_shift(R0, P0, R1, P1);
             } else {                  // RemoveBack
                 for (auto& l : lms) { if (l.start != 0) l.start--; else { l.obs.erase(l.obs.begin()); if (l.obs.empty()) l.id = -1; } }
                 erase_if([](const Lm& l) { return l.id < 0; });
+                if (cfg.use_line) lines.remove_back();
             }
         } else if (frame == kWin) {
             headers[frame - 1] = headers[frame]; Ps[frame - 1] = Ps[frame]; Rs[frame - 1] = Rs[frame];
@@ -490,6 +502,7 @@ struct dv_estimator {
                 if (l.obs.empty()) l.id = -1;
             }
             erase_if([](const Lm& l) { return l.id < 0; });
+            if (cfg.use_line) lines.remove_front(frame);
         }
     }
     void solve_gyro_bias() {          // SolveGyroscopeBias (initial_aligment.cpp:29-61)
@@ -524,6 +537,26 @@ struct dv_estimator {
         if (frame < kWin) { frame++; const int p = frame - 1; Ps[frame] = Ps[p]; Vs[frame] = Vs[p]; Rs[frame] = Rs[p]; Bas[frame] = Bas[p]; Bgs[frame] = Bgs[p]; }
         return 0;
     }
+    // Estimator::OptimizationWithOnlyLine (estimator.cpp:345-395): Vector2double, the line-only dogleg solve on the GPU (dv_line_solve; with the reference's zero
+    // sqrt_info every residual and Jacobian is zero and ceres returns before its first step, so nothing is launched), Double2vector, RemoveLineOutlier.
+    // Deviation (only reachable with non-zero weights): the reference leaves para_pose[kWinSize] a free 7-wide block here (its loop fixes poses 0..kWinSize-1);
+    // dv_line_solve keeps all poses fixed.
+    int optimization_only_line(dv_ctx* ctx) {
+        lines.get_orth(Rs, Ps, ric[0], tic[0], para_line);
+        line_last = dv_ba_summary{};
+        const bool zero_w = cfg.line_sqrt_info[0] == 0.0 && cfg.line_sqrt_info[1] == 0.0 && cfg.line_sqrt_info[2] == 0.0 && cfg.line_sqrt_info[3] == 0.0;
+        if (!para_line.empty() && !zero_w) {
+            states_to_arrays();
+            std::vector<dv_line_obs> obs; lines.observations(obs);
+            dv_line_problem LP{};
+            LP.n_lines = (int)para_line.size() / 4; LP.n_obs = (int)obs.size(); LP.max_iters = cfg.max_iters;
+            LP.orth = para_line.data(); LP.pose = &pose[0][0]; LP.ex_pose = &ex[0][0]; std::memcpy(LP.sqrt_info, cfg.line_sqrt_info, sizeof(LP.sqrt_info)); LP.obs = obs.data();
+            if (dv_line_solve(ctx, &LP, &line_last)) return -1;
+        }
+        if (!para_line.empty()) lines.set_orth(Rs, Ps, ric[0], tic[0], para_line.data());      // Double2vector (the poses did not move: re-normalises the Pluecker vectors)
+        lines.remove_outliers(Rs, Ps, ric[0], tic[0]);
+        return 0;
+    }
     // the object branch of ProcessImage between TriangulatePoints and Optimization (estimator.cpp:1562-1622).  It neither reads what the window
     // solve writes nor writes what it reads (the joint factors are dead code), so it runs on the host + a third stream while the window
     // solve enqueued just before is in flight on the BA stream.
@@ -556,7 +589,9 @@ struct dv_estimator {
     }
     int process_image_begin(dv_ctx* ctx, const dv_feat* feats, int n, double header, const dv_inst_obs* insts = nullptr, int n_insts = 0, const dv_feat* inst_feats = nullptr,
                             const double* points = nullptr) {      // ProcessImage (estimator.cpp:1516-1696), up to and including the enqueue of the window solve
-        { HostScope h(ctx, "h_add_features"); margin_old = add_features(frame, feats, n); }
+        { HostScope h(ctx, "h_add_features");
+          if (cfg.use_line) { lines.add(frame, pending_lines.data(), (int)pending_lines.size()); pending_lines.clear(); }
+          margin_old = add_features(frame, feats, n); }
         headers[frame] = header;
         frame_pre.push_back(std::shared_ptr<Preint>(tmp_pre.release()));
         if (frame_pre.size() > (size_t)kWin + 1 && nonlinear) frame_pre.erase(frame_pre.begin());
@@ -564,7 +599,12 @@ struct dv_estimator {
         in_flight = false; dyn_frame = false;
         if (!nonlinear) return init_estimator(ctx);      // initialisation: synchronous
         if (!cfg.use_imu) pnp_frame(frame);
-        { HostScope h(ctx, "h_triangulate"); triangulate(); }
+        { HostScope h(ctx, "h_triangulate"); triangulate(); if (cfg.use_line) lines.triangulate(Rs, Ps, ric[0], tic[0]); }
+        if (cfg.use_line) {
+            const bool zero_w = cfg.line_sqrt_info[0] == 0.0 && cfg.line_sqrt_info[1] == 0.0 && cfg.line_sqrt_info[2] == 0.0 && cfg.line_sqrt_info[3] == 0.0;
+            if (!zero_w && lines.count() > 0 && !line_weight_warned) { line_weight_warned = true; dv_set_error(ctx, "line mode: non-zero lineProjectionFactor::sqrt_info is honoured by OptimizationWithOnlyLine only; inside the window solve the line blocks stay inert"); }
+            HostScope h(ctx, "h_line_only"); if (optimization_only_line(ctx)) return -1;
+        }
         if (optimization_begin(ctx)) return -1;
         in_flight = true;
         dyn_frame = cfg.dynamic != 0;
@@ -577,7 +617,7 @@ struct dv_estimator {
         if (dyn_frame && dynamic_branch_finish(ctx)) return -1;      // before optimization_end: Rs / Ps are still the states the reference's object branch saw
         if (optimization_end(ctx)) return -1;
         if (dyn_frame) im.touch_in_main_optimization();      // AddInstanceParameterBlock / im.GetOptimizationParameters inside Estimator::Optimization
-        { HostScope h(ctx, "h_reject"); reject_outliers(); }
+        { HostScope h(ctx, "h_reject"); reject_outliers(); if (cfg.use_line) lines.remove_outliers(Rs, Ps, ric[0], tic[0]); }
         if (dyn_frame) { const dvi::BodyView B = body_view(); im.manage_triangulate_point(B); im.slide_window(B, margin_old); }      // estimator.cpp:1653-1658, BEFORE the body window slides
         { HostScope h(ctx, "h_slide"); slide_window(); }
         if (dyn_frame) im.finish_frame(body_view());                                                                                 // estimator.cpp:1663-1676, on the slid window
@@ -585,7 +625,7 @@ struct dv_estimator {
         if (cfg.use_imu) update_latest_states();
         return 0;
     }
-    bool in_flight = false, begun = false;
+    bool in_flight = false, begun = false, line_weight_warned = false;
 };
 
 extern "C" {
@@ -604,6 +644,30 @@ int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr
     dv_estimator& E = *ctx->est;
     E.imu_buf.push_back({ t, { mk3(acc[0], acc[1], acc[2]), mk3(gyr[0], gyr[1], gyr[2]) } });
     if (E.nonlinear && E.latest_valid) E.fast_predict_imu(t, mk3(acc[0], acc[1], acc[2]), mk3(gyr[0], gyr[1], gyr[2]));      // InputIMU: FastPredictIMU + PubLatestOdometry (estimator.cpp:734-741)
+    return 0;
+}
+int dv_est_set_lines(dv_ctx* ctx, const dv_line_row* rows, int n) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_set_lines: call dv_est_create first");
+    if (n < 0 || (n > 0 && !rows)) DV_FAIL("dv_est_set_lines: bad argument");
+    if (!ctx->est->cfg.use_line) DV_FAIL("dv_est_set_lines: the estimator was created with use_line = 0");
+    ctx->est->pending_lines.assign(rows, rows + n);
+    return 0;
+}
+int dv_est_get_lines(dv_ctx* ctx, dv_line_landmark* out, int cap, int* n_out) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_get_lines: call dv_est_create first");
+    if (!n_out || cap < 0 || (cap > 0 && !out)) DV_FAIL("dv_est_get_lines: bad argument");
+    int k = 0;
+    for (auto& L : ctx->est->lines.lms) {
+        if (k >= cap) break;
+        dv_line_landmark& o = out[k++];
+        std::memset(&o, 0, sizeof(o));
+        o.id = L.id; o.start_frame = L.start; o.n_obs = (int)L.obs.size(); o.is_triangulation = L.tri;
+        if (L.tri) { const double pl[6] = { L.plk.n.x, L.plk.n.y, L.plk.n.z, L.plk.v.x, L.plk.v.y, L.plk.v.z }; std::memcpy(o.plucker, pl, sizeof(pl));
+                     o.ptw1[0] = L.ptw1.x; o.ptw1[1] = L.ptw1.y; o.ptw1[2] = L.ptw1.z; o.ptw2[0] = L.ptw2.x; o.ptw2[1] = L.ptw2.y; o.ptw2[2] = L.ptw2.z; }
+    }
+    *n_out = k;
     return 0;
 }
 // Estimator::ChangeSensorType (estimator.cpp:697-726)

@@ -149,8 +149,13 @@ struct SemanticImage {                  // basic/semantic_image.h:30-65 (the fie
     ImageView gray0, gray1, inv_merge_mask;
     double time0 = 0; unsigned int seq = 0;
 };
+struct Line {                           // line_detector/line.h: id + undistorted normalised end points (StartPt / EndPt of FrameLines::un_lines)
+    unsigned int id = 0; double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+};
+struct LineSegment { unsigned int id = 0; float x1 = 0, y1 = 0, x2 = 0, y2 = 0; };      // a matched segment of the CPU detector (LSD + LBD, line_detector.cpp), pixels
 struct FeatureBackground {              // basic/frontend_feature.h:34-44
     std::map<unsigned int, std::vector<std::pair<int, Vec7d>>> points;
+    std::map<unsigned int, std::vector<std::pair<int, Line>>> lines;      // {line_id, [(camera_id, line)]}
 };
 struct FrontendFeature {                // basic/frontend_feature.h:52-75
     FeatureBackground features; double time = 0; unsigned int seq_id = 0;
@@ -217,6 +222,27 @@ public:
     FeatureBackground TrackImage(SemanticImage& img) { return track(img, DV_MODE_RAW); }
     FeatureBackground TrackImageNaive(SemanticImage& img) { return track(img, DV_MODE_NAIVE); }
     FeatureBackground TrackSemanticImage(SemanticImage& img) { return track(img, DV_MODE_SEMANTIC); }      // background_tracker.cpp:757-837 (background half)
+    // FeatureTracker::TrackImageLine (background_tracker.cpp:198-333): the point half is TrackImage's; the line half is the reference's CPU detector thread
+    // (LineDetector::Detect / TrackLeftLine / TrackRightLine — OpenCV line_descriptor, upstream of this path) whose matched segments the caller hands in;
+    // FrameLines::UndistortedLineEndPoints (cam0 / cam1) and SetOutputFeats' `lines` map (:373-392) are done here.  The detector may run on another thread
+    // while this call tracks the points, as in the reference: pass the segments of THIS frame.
+    FeatureBackground TrackImageLine(SemanticImage& img, const std::vector<LineSegment>& left, const std::vector<LineSegment>& right = {}) {
+        FeatureBackground fb = track(img, DV_MODE_RAW);
+        auto put = [&](const std::vector<LineSegment>& segs, int cam_id) {
+            if (segs.empty()) return;
+            std::vector<float> px(4 * segs.size()); std::vector<double> un(4 * segs.size());
+            for (size_t i = 0; i < segs.size(); ++i) { px[4 * i] = segs[i].x1; px[4 * i + 1] = segs[i].y1; px[4 * i + 2] = segs[i].x2; px[4 * i + 3] = segs[i].y2; }
+            detail::check(ctx_, dv_undistort_lines(ctx_, cam_id == 0 ? &cfg_.cam0 : &cfg_.cam1, px.data(), (int)segs.size(), un.data()), "TrackImageLine");
+            for (size_t i = 0; i < segs.size(); ++i) {
+                const Line l{ segs[i].id, un[4 * i], un[4 * i + 1], un[4 * i + 2], un[4 * i + 3] };
+                if (cam_id == 0) fb.lines.insert({ l.id, { { 0, l } } });
+                else fb.lines[l.id].push_back({ 1, l });
+            }
+        };
+        put(left, 0);
+        if (cfg_.stereo) put(right, 1);
+        return fb;
+    }
     // two-phase form: lets the caller overlap the front end of frame k+1 with the back end of frame k
     void TrackImageEnqueue(SemanticImage& img, int mode = DV_MODE_RAW) {
         check_image(img);
@@ -382,6 +408,7 @@ public:
         // dynamic mode: `slam: dynamic` selects the object branch (utils/parameters.cpp), with use_det3d / instance_init_min_num / static_inst_threshold
         cfg_.dynamic = y.str("slam_type", "raw") == "dynamic" ? 1 : 0; cfg_.use_det3d = y.integer("use_det3d", 0);
         cfg_.instance_init_min_num = y.integer("instance_init_min_num", 4); cfg_.static_inst_threshold = y.num("static_inst_threshold", 10.0);
+        cfg_.use_line = y.integer("use_line", 0); cfg_.line_min_obs = y.integer("line_min_obs", 5);      // parameters.cpp: cfg::use_line; vio_parameters.cpp: para::kLineMinObs
         if (y.integer("estimate_extrinsic", 0) != 0 || y.integer("estimate_td", 0) != 0)
             throw std::runtime_error("dvins: estimate_extrinsic / estimate_td != 0 are not on the accelerated path (every shipped config sets 0)");
         for (int c = 0; c < 2; ++c) {
@@ -420,6 +447,17 @@ public:
     // the frame (the reference sleeps 5 ms and retries, estimator.cpp:1800-1812)
     bool ProcessMeasurements(const FrontendFeature& f) {
         const std::vector<dv_feat> rows = detail::to_rows(f.features);
+        if (cfg_.use_line) {                                 // AddFeatureCheckParallax(frame, image.features, td) (estimator.cpp:1524-1527, feature_manager.cpp:124-160)
+            std::vector<dv_line_row> lr;
+            for (auto& [id, v] : f.features.lines) {
+                if (v.empty()) continue;
+                dv_line_row r{}; r.id = id; r.left[0] = v[0].second.x1; r.left[1] = v[0].second.y1; r.left[2] = v[0].second.x2; r.left[3] = v[0].second.y2;
+                if (v.size() > 1) { r.has_right = 1; r.right[0] = v[1].second.x1; r.right[1] = v[1].second.y1; r.right[2] = v[1].second.x2; r.right[3] = v[1].second.y2; }
+                lr.push_back(r);
+            }
+            std::lock_guard<std::mutex> lk(process_mutex_);
+            detail::check(ctx_, dv_est_set_lines(ctx_, lr.data(), (int)lr.size()), "ProcessMeasurements");
+        }
         return ProcessMeasurements(rows.data(), (int)rows.size(), f.time);
     }
     bool ProcessMeasurements(const dv_feat* rows, int n, double time) {
@@ -442,6 +480,12 @@ public:
         detail::check(ctx_, rc, "ProcessMeasurements");
         after_frame();
         return true;
+    }
+    // FeatureManager::line_landmarks after the last frame (Publisher::PubLines reads ptw1 / ptw2 of the triangulated ones)
+    std::vector<dv_line_landmark> Lines() {
+        std::vector<dv_line_landmark> v(4096); int n = 0;
+        detail::check(ctx_, dv_est_get_lines(ctx_, v.data(), (int)v.size(), &n), "Lines");
+        v.resize(n); return v;
     }
     // Estimator::im.instances after the last frame (InstanceManager::SetOutputInstInfo / the instance publishers)
     std::vector<dv_inst_state> Instances() {

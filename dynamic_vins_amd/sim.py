@@ -185,6 +185,50 @@ class FeatureSim:
         return rows
 
 
+class LineSim:
+    """Line-level front end (what TrackImageLine hands over as FeatureBackground::lines): 3-D segments on the room's walls, ids fixed per segment, a row
+    per frame in which both end points project inside the image; end points carry pixel noise and, like the LSD detector, are not the same physical points
+    from frame to frame (each end slides along the segment by up to `slide` of its length)."""
+
+    def __init__(self, traj, w, h, n=60, half=(9.0, 7.0, 3.0), pix_sigma=0.3, focal=460.0, slide=0.05, seed=11):
+        rng = np.random.default_rng(seed)
+        a = room_points(n, half, seed=seed + 1)
+        d = rng.normal(0, 1, (n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        self.a, self.b = a, a + d * rng.uniform(0.8, 2.5, (n, 1))
+        self.traj, self.w, self.h, self.sig, self.f, self.slide = traj, w, h, pix_sigma, focal, slide
+        self.rng = rng
+
+    def _norm(self, t, P, t_ic):
+        R, p = self.traj.R(t), self.traj.p(t)
+        Pc = (R_IC.T @ (R.T @ (P - p).T - t_ic[:, None])).T
+        ok = Pc[:, 2] > 0.5
+        z = np.where(ok, Pc[:, 2], 1.0)
+        x, y = Pc[:, 0] / z, Pc[:, 1] / z
+        return x, y, ok & (np.abs(x) < 1.2) & (np.abs(y) < 0.75)
+
+    def frame(self, t):
+        from .backend import LINEROW_DTYPE
+        n = len(self.a)
+        s = self.rng.uniform(0, self.slide, (n, 2))
+        A = self.a + (self.b - self.a) * s[:, :1]
+        B = self.b - (self.b - self.a) * s[:, 1:]
+        rows = []
+        xa, ya, oka = self._norm(t, A, T_IC0); xb, yb, okb = self._norm(t, B, T_IC0)
+        xar, yar, okar = self._norm(t, A, T_IC1); xbr, ybr, okbr = self._norm(t, B, T_IC1)
+        noise = self.rng.normal(0, self.sig / self.f, (n, 8))
+        for k in range(n):
+            if not (oka[k] and okb[k]):
+                continue
+            r = np.zeros((), LINEROW_DTYPE)
+            r["id"] = k + 1
+            r["left"] = np.array([xa[k], ya[k], xb[k], yb[k]]) + noise[k, :4]
+            if okar[k] and okbr[k]:
+                r["has_right"] = 1
+                r["right"] = np.array([xar[k], yar[k], xbr[k], ybr[k]]) + noise[k, 4:]
+            rows.append(r)
+        return np.array(rows, LINEROW_DTYPE) if rows else np.zeros(0, LINEROW_DTYPE)
+
+
 def align_ate(est, gt):
     """Horn alignment (rotation + translation, no scale) and translational RMSE — the metric of
     dynamic_vins/scripts/tum_tools/evaluate_ate.py:47-79,155 (align() + rmse)."""

@@ -183,6 +183,8 @@ typedef struct dv_ba_problem {
     double* inv_depth;   /* [nlm]                             (para_point_features, in/out) */
     const dv_ba_factor* factors; const dv_ba_lm* landmarks; const dv_ba_imu* imu;
     const dv_ba_prior* prior; const double* prior_A; const double* prior_b;     /* prior may be NULL */
+    double x_norm2_extra;   /* squared norm of further free parameter blocks that count in ceres' parameter-tolerance test |step| <= 1e-8 (|x| + 1e-8) without moving:
+                               the lineProjectionFactor blocks of AddLineResidualBlock under the reference's zero sqrt_info; 0 otherwise */
 } dv_ba_problem;
 
 typedef struct dv_ba_summary {
@@ -318,6 +320,11 @@ typedef struct dv_est_config {          /* para (estimator/vio_parameters.cpp:19
     int32_t instance_init_min_num;      /* instance_init_min_num (viode.yaml:135: 4) */
     int32_t pad_;
     double static_inst_threshold;       /* static_inst_threshold: scene-flow norm above which an object counts as moving (default 10) */
+    /* line mode (cfg::use_line): line landmarks in FeatureManager, TriangulateLineMono, OptimizationWithOnlyLine, AddLineResidualBlock (estimator.cpp:224-253,345-395) */
+    int32_t use_line, line_min_obs;     /* use_line ; line_min_obs (default 5, vio_parameters.cpp:47-54) */
+    double line_sqrt_info[4];           /* lineProjectionFactor::sqrt_info, 2x2 row-major.  The reference never assigns it (zero: SURVEY 0.6) — then the line blocks are
+                                           inert and only enter the window solve's parameter-tolerance norm.  Non-zero weights are honoured by the line-only solve;
+                                           the window solve refuses them (line e-blocks inside the Schur elimination are not built). */
 } dv_est_config;
 
 typedef struct dv_est_state {
@@ -340,6 +347,18 @@ int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_st
  * frame's tracking and feed IMU samples — thread T2's work overlapping T3's, as in the reference (system/main.cpp:394-404). */
 int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t);
 int dv_est_process_end(dv_ctx* ctx, dv_est_state* out);
+
+/* one entry of FeatureBackground::lines (basic/frontend_feature.h:41-44): the matched line `id` of this frame with the undistorted normalised end points
+ * (Line::StartPt / EndPt of FrameLines::un_lines) in the left image and, if matched, in the right one.  The LSD / LBD detector that produces them is upstream. */
+typedef struct dv_line_row { uint32_t id; int32_t has_right; double left[4], right[4]; } dv_line_row;      /* x1 y1 x2 y2 */
+/* frame.features.lines of the NEXT dv_est_process* call (use_line) */
+int dv_est_set_lines(dv_ctx* ctx, const dv_line_row* lines, int n);
+/* FeatureManager::line_landmarks after the last frame: per landmark id, start_frame, observation count, is_triangulation, line_plucker (n, v; camera frame of
+ * start_frame), ptw1 / ptw2 (the `lines` marker publisher) */
+typedef struct dv_line_landmark { int32_t id, start_frame, n_obs, is_triangulation; double plucker[6], ptw1[3], ptw2[3]; } dv_line_landmark;
+int dv_est_get_lines(dv_ctx* ctx, dv_line_landmark* out, int cap, int* n_out);
+/* FrameLines::UndistortedLineEndPoints (front_end side of TrackImageLine, line_detector): end points (x1 y1 x2 y2 pixels) -> normalised, undistorted */
+int dv_undistort_lines(dv_ctx* ctx, const dv_cam* cam, const float* lines_xyxy, int n, double* out_xyxy);
 
 /* ---- the members of Estimator the callbacks and publishers use besides ProcessMeasurements (estimator/estimator.h:55-164) ---- */
 /* Estimator::ChangeSensorType (estimator.cpp:697-726; the /vins_imu_switch, /vins_cam_switch callbacks): switching the IMU on restarts the estimator

@@ -63,6 +63,16 @@ struct Landmark {             // StaticPointLandmark
     int endFrame() const { return start_frame + (int)feats.size() - 1; }
 };
 
+struct LineFeat { double line_obs[4], line_obs_right[4]; bool is_stereo = false; };      // LineFeature (basic/line_feature.h)
+struct LineLandmark {         // basic/line_landmark.h
+    int feature_id, start_frame; std::vector<LineFeat> feats; unsigned used_num = 0; bool is_triangulation = false; double line_plucker[6] = { 0 }; V3 ptw1, ptw2;
+    int endFrame() const { return start_frame + (int)feats.size() - 1; }
+};
+struct LineCost : CostFunction {      // lineProjectionFactor on (pose, ex_pose, line) through dvo_line_eval (obj_factors.cpp)
+    double obs[4], si[4];
+    LineCost(const double* o, const double* w) { nres = 2; sizes = { 7, 7, 4 }; std::memcpy(obs, o, 32); std::memcpy(si, w, 32); }
+    void Evaluate(const double* const* par, double* res, double** J) const override { dvo_line_eval(obs, si, par, res, J); }
+};
 struct ProjCost : CostFunction {
     int kind; ProjObs o;
     ProjCost(int k, const ProjObs& ob) : kind(k), o(ob) {
@@ -228,6 +238,7 @@ struct Config {
     double min_parallax = 10.0 / kFocalLength, init_depth = 5.0, g_norm = 9.81, td = 0.0;
     ImuNoise noise{ 0.1, 0.01, 0.001, 1e-4 };
     M3 ric[2]; V3 tic[2];
+    int use_line = 0, line_min_obs = 5; double line_sqrt_info[4] = { 0, 0, 0, 0 };      // cfg::use_line, para::kLineMinObs, lineProjectionFactor::sqrt_info (never assigned in the reference: zero)
     int dynamic = 0, use_det3d = 0, instance_init_min_num = 4; double static_inst_threshold = 10.0;      // cfg::slam == kDynamic, use_det3d, para::kInstanceInitMinNum, kStaticInstThreshold
 };
 
@@ -249,6 +260,8 @@ struct Estimator {
     std::unique_ptr<MargInfo> last_marg;
     M3 back_R0; V3 back_P0;
     SolveSummary last_summary; int n_solves = 0;
+    std::list<LineLandmark> line_landmarks;    // FeatureManager::line_landmarks
+    std::vector<dvo_line_row> pending_lines; double para_line_features[1000][4];
     oim::InstanceManager im;                   // Estimator::im (estimator.h)
     oim::Body body() { return oim::Body{ Rs, Ps, ric, tic, headers, td, frame, para_pose }; }
 
@@ -257,6 +270,7 @@ struct Estimator {
         for (int i = 0; i <= kWin; ++i) { Rs[i] = M3::identity(); Ps[i] = Vs[i] = Bas[i] = Bgs[i] = V3(); pre[i].reset(); dt_buf[i].clear(); la_buf[i].clear(); av_buf[i].clear(); headers[i] = 0; }
         lms.clear(); acc_buf.clear(); gyr_buf.clear(); all_frames.clear(); tmp_pre.reset(); last_marg.reset();
         prev_time = -1; cur_time = 0; first_imu = false; init_first_pose = false; frame = 0; nonlinear = false;
+        line_landmarks.clear(); pending_lines.clear();
         im = oim::InstanceManager();
         im.para.use_det3d = cfg.use_det3d; im.para.kInstanceInitMinNum = cfg.instance_init_min_num; im.para.kStaticInstThreshold = cfg.static_inst_threshold;
         im.para.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; im.para.KNumIter = cfg.max_iters;
@@ -462,6 +476,140 @@ struct Estimator {
         }
     }
 
+    // ------------------------------ line landmarks (feature_manager.cpp:124-160,339-356,392-560,611-778) ------------------------------
+    void add_line_features(int frame_count) {
+        std::map<unsigned, const dvo_line_row*> image;      // FeatureBackground::lines
+        for (auto& r : pending_lines) image[r.id] = &r;
+        for (auto& [line_id, r] : image) {
+            LineFeat feat; std::memcpy(feat.line_obs, r->left, 32); feat.is_stereo = r->has_right != 0; if (feat.is_stereo) std::memcpy(feat.line_obs_right, r->right, 32);
+            auto it = std::find_if(line_landmarks.begin(), line_landmarks.end(), [id = (int)line_id](const LineLandmark& l) { return l.feature_id == id; });
+            if (it == line_landmarks.end()) { line_landmarks.push_back(LineLandmark{ (int)line_id, frame_count }); line_landmarks.back().feats.push_back(feat); }
+            else it->feats.push_back(feat);
+        }
+        pending_lines.clear();
+    }
+    void body_arrays(double* R99, double* P33) const { for (int i = 0; i <= kWin; ++i) { for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R99[9 * i + 3 * r + c] = Rs[i](r, c); for (int k = 0; k < 3; ++k) P33[3 * i + k] = Ps[i][k]; } }
+    void triangulate_line_mono() {       // TriangulateLineMono + TriangulateOneLine (vio_util.cpp:447-561) through dvo_triangulate_line
+        double R99[99], P33[33], ric9[9], tic3[3]; body_arrays(R99, P33);
+        for (int r = 0; r < 3; ++r) { for (int c = 0; c < 3; ++c) ric9[3 * r + c] = ric[0](r, c); tic3[r] = tic[0][r]; }
+        for (auto& landmark : line_landmarks) {
+            landmark.used_num = (unsigned)landmark.feats.size();
+            if ((int)landmark.used_num < cfg.line_min_obs) continue;
+            if (landmark.is_triangulation) continue;
+            std::vector<double> obs; for (auto& f : landmark.feats) obs.insert(obs.end(), f.line_obs, f.line_obs + 4);
+            double plk[6], w1[3], w2[3];
+            if (dvo_triangulate_line(obs.data(), (int)landmark.feats.size(), landmark.start_frame, R99, P33, ric9, tic3, plk, w1, w2)) {
+                std::memcpy(landmark.line_plucker, plk, 48); landmark.ptw1 = V3(w1[0], w1[1], w1[2]); landmark.ptw2 = V3(w2[0], w2[1], w2[2]); landmark.is_triangulation = true;
+            }
+        }
+    }
+    bool line_in_problem(LineLandmark& l) { l.used_num = (unsigned)l.feats.size(); return (int)l.used_num >= cfg.line_min_obs && l.start_frame < kWin - 2 && l.is_triangulation; }
+    int line_feature_count() { int c = 0; for (auto& l : line_landmarks) if (line_in_problem(l)) ++c; return c; }
+    static void plk_to_pose_o(const double* plk, const M3& Rcw, const V3& tcw, double* out) {      // line_geometry.cpp:252-262
+        const V3 nw(plk[0], plk[1], plk[2]), vw(plk[3], plk[4], plk[5]);
+        const V3 nc = Rcw * nw + skew(tcw) * (Rcw * vw), vc = Rcw * vw;
+        for (int k = 0; k < 3; ++k) { out[k] = nc[k]; out[3 + k] = vc[k]; }
+    }
+    static void plk_from_pose_o(const double* plk, const M3& Rcw, const V3& tcw, double* out) { const M3 Rwc = Rcw.t(); plk_to_pose_o(plk, Rwc, -(Rwc * tcw), out); }
+    void get_line_orth() {             // GetLineOrthVector -> para_line_features (Vector2double)
+        int k = -1;
+        for (auto& l : line_landmarks) {
+            if (!line_in_problem(l)) continue;
+            const V3 twc = Ps[l.start_frame] + Rs[l.start_frame] * tic[0]; const M3 Rwc = Rs[l.start_frame] * ric[0];
+            double lw[6]; plk_to_pose_o(l.line_plucker, Rwc, twc, lw);
+            dvo_plk_to_orth(lw, para_line_features[++k]);
+        }
+    }
+    void set_line_orth() {             // SetLineOrth (Double2vector)
+        int k = -1;
+        for (auto& l : line_landmarks) {
+            if (!line_in_problem(l)) continue;
+            double lw[6]; dvo_orth_to_plk(para_line_features[++k], lw);
+            const V3 twc = Ps[l.start_frame] + Rs[l.start_frame] * tic[0]; const M3 Rwc = Rs[l.start_frame] * ric[0];
+            plk_from_pose_o(lw, Rwc, twc, l.line_plucker);
+        }
+    }
+    void remove_line_outlier() {       // feature_manager.cpp:518-560
+        for (auto it = line_landmarks.begin(); it != line_landmarks.end();) {
+            auto landmark = it++;
+            if (!line_in_problem(*landmark)) continue;
+            int imu_i = landmark->start_frame, imu_j = imu_i - 1;
+            const V3 twc = Ps[imu_i] + Rs[imu_i] * tic[0]; const M3 Rwc = Rs[imu_i] * ric[0];
+            double p1[3], p2[3];
+            const int valid = dvo_line_trimming(landmark->line_plucker, landmark->feats[0].line_obs, p1, p2);
+            if (!valid || (V3(p1[0], p1[1], p1[2]) - V3(p2[0], p2[1], p2[2])).norm() > 10) { line_landmarks.erase(landmark); continue; }
+            double line_w[6]; plk_to_pose_o(landmark->line_plucker, Rwc, twc, line_w);
+            double allerr = 0;
+            for (auto& feat : landmark->feats) {
+                imu_j++;
+                const V3 t1 = Ps[imu_j] + Rs[imu_j] * tic[0]; const M3 R1 = Rs[imu_j] * ric[0];
+                double lc[6]; plk_from_pose_o(line_w, R1, t1, lc);        // LineReprojectionError (line_geometry.cpp:272-287)
+                const double sql = std::sqrt(lc[0] * lc[0] + lc[1] * lc[1]);
+                const V3 nc(lc[0] / sql, lc[1] / sql, lc[2] / sql);
+                const double err = (std::fabs(nc.dot(V3(feat.line_obs[0], feat.line_obs[1], 1))) + std::fabs(nc.dot(V3(feat.line_obs[2], feat.line_obs[3], 1)))) / 2.0;
+                if (allerr < err) allerr = err;
+            }
+            if (allerr > 3.0 / 500.0) line_landmarks.erase(landmark);
+        }
+    }
+    void lines_remove_back_shift(const M3& marg_R, const V3& marg_P, const M3& new_R, const V3& new_P) {
+        for (auto it = line_landmarks.begin(); it != line_landmarks.end();) {
+            auto cur = it++;
+            if (cur->start_frame != 0) { cur->start_frame--; continue; }
+            cur->feats.erase(cur->feats.begin());
+            if (cur->feats.size() < 2) { line_landmarks.erase(cur); continue; }
+            const M3 Rji = new_R.t() * marg_R; const V3 tji = new_R.t() * (marg_P - new_P);
+            double plk_j[6]; plk_to_pose_o(cur->line_plucker, Rji, tji, plk_j); std::memcpy(cur->line_plucker, plk_j, 48);
+        }
+    }
+    void lines_remove_back() {
+        for (auto it = line_landmarks.begin(); it != line_landmarks.end();) {
+            auto cur = it++;
+            if (cur->start_frame != 0) cur->start_frame--;
+            else { cur->feats.erase(cur->feats.begin()); if (cur->feats.empty()) line_landmarks.erase(cur); }
+        }
+    }
+    void lines_remove_front(int frame_count) {
+        for (auto it = line_landmarks.begin(); it != line_landmarks.end();) {
+            auto cur = it++;
+            if (cur->start_frame == frame_count) { cur->start_frame--; continue; }
+            const int j = kWin - 1 - cur->start_frame;
+            if (cur->endFrame() < frame_count - 1) continue;
+            cur->feats.erase(cur->feats.begin() + j);
+            if (cur->feats.empty()) line_landmarks.erase(cur);
+        }
+    }
+    // AddLineResidualBlock (estimator.cpp:224-253)
+    void add_line_residual_blocks(Problem& prob, int loss) {
+        if (!cfg.use_line) return;
+        int feature_index = -1;
+        for (auto& landmark : line_landmarks) {
+            if (!line_in_problem(landmark)) continue;
+            ++feature_index;
+            prob.AddParameterBlock(para_line_features[feature_index], 4, kLineOrth);
+            int imu_j = landmark.start_frame - 1;
+            for (auto& feat : landmark.feats) {
+                imu_j++;
+                prob.AddResidualBlock(std::make_shared<LineCost>(feat.line_obs, cfg.line_sqrt_info), loss, { para_pose[imu_j], para_ex_pose[0], para_line_features[feature_index] });
+            }
+        }
+    }
+    // OptimizationWithOnlyLine (estimator.cpp:345-395): poses 0..kWinSize-1 and the extrinsics are added constant; para_pose[kWinSize] is not, so it enters as a free
+    // 7-wide block without parameterisation whenever a line is seen in the newest frame (sic)
+    void optimization_with_only_line() {
+        vector2double();
+        Problem prob;
+        for (int i = 0; i < kWin; ++i) { prob.AddParameterBlock(para_pose[i], 7, kPose); prob.SetConstant(para_pose[i]); }
+        for (int i = 0; i < 2; ++i) { prob.AddParameterBlock(para_ex_pose[i], 7, kPose); prob.SetConstant(para_ex_pose[i]); }
+        prob.AddParameterBlock(para_pose[kWin], 7, kPlain);
+        add_line_residual_blocks(prob, kCauchy1);
+        Solver solver(prob);
+        SolveOptions so; so.max_num_iterations = cfg.max_iters;
+        solver.solve(so);
+        double2vector();
+        remove_line_outlier();
+    }
+
     // ------------------------------ optimisation ------------------------------
     void vector2double() {       // BodyState::SetOptimizeParameters + Estimator::Vector2double
         for (int i = 0; i <= kWin; ++i) {
@@ -476,6 +624,7 @@ struct Estimator {
         para_td[0][0] = td;
         int k = -1;
         for (auto& lm : lms) if (lm.feats.size() >= 4) para_feature[++k][0] = 1.0 / lm.depth;
+        if (cfg.use_line) get_line_orth();
     }
     void double2vector() {       // Estimator::Double2vector + BodyState::GetOptimizationParameters (body.cpp:61-132)
         V3 origin_R0 = R2ypr(Rs[0]), origin_P0 = Ps[0];
@@ -502,6 +651,7 @@ struct Estimator {
         }
         int k = -1;
         for (auto& lm : lms) if (lm.feats.size() >= 4) { lm.depth = 1.0 / para_feature[++k][0]; lm.solve_flag = lm.depth < 0 ? 2 : 1; }    // SetDepth
+        if (cfg.use_line) set_line_orth();       // body.cpp / estimator.cpp:1141
     }
     static ProjObs obs(const Feat& f0, const Feat& f, bool right) {
         ProjObs o; o.pts_i = f0.point; o.pts_j = right ? f.point_right : f.point; o.vel_i = f0.vel; o.vel_j = right ? f.vel_right : f.vel; o.td_i = f0.cur_td; o.td_j = f.cur_td; return o;
@@ -539,6 +689,7 @@ struct Estimator {
                 }
             }
         }
+        add_line_residual_blocks(prob, kHuber1);      // estimator.cpp:283-286, same loss object as the points
         Solver solver(prob);
         SolveOptions so; so.max_num_iterations = cfg.max_iters;
         last_summary = solver.solve(so); n_solves++;
@@ -638,8 +789,8 @@ struct Estimator {
                 if (nonlinear) {       // SlideWindowOld
                     M3 R0 = back_R0 * ric[0], R1 = Rs[0] * ric[0];
                     V3 P0 = back_P0 + back_R0 * tic[0], P1 = Ps[0] + Rs[0] * tic[0];
-                    remove_back_shift_depth(R0, P0, R1, P1);
-                } else remove_back();
+                    remove_back_shift_depth(R0, P0, R1, P1); lines_remove_back_shift(R0, P0, R1, P1);
+                } else { remove_back(); lines_remove_back(); }
             }
         } else if (frame == kWin) {
             headers[frame - 1] = headers[frame]; Ps[frame - 1] = Ps[frame]; Rs[frame - 1] = Rs[frame];
@@ -652,7 +803,7 @@ struct Estimator {
                 pre[kWin] = std::make_unique<Integration>(acc_0, gyr_0, Bas[kWin], Bgs[kWin], cfg.noise);
                 dt_buf[kWin].clear(); la_buf[kWin].clear(); av_buf[kWin].clear();
             }
-            remove_front(frame);
+            remove_front(frame); lines_remove_front(frame);
         }
     }
     void solve_gyro_bias() {     // initial_aligment.cpp:29-61
@@ -698,6 +849,7 @@ struct Estimator {
         }
     }
     void process_image(const dvo_feat* feats, int n, double header, std::map<unsigned, oim::FeatureInstance>* instances = nullptr) {      // ProcessImage (estimator.cpp:1516-1696)
+        if (cfg.use_line) add_line_features(frame);
         margin_old = add_feature_check_parallax(frame, feats, n, td);
         headers[frame] = header;
         all_frames.push_back({ header, std::shared_ptr<Integration>(tmp_pre.release()) });
@@ -705,6 +857,7 @@ struct Estimator {
         if (!nonlinear) { init_estimator(); return; }
         if (!cfg.use_imu) init_frame_pose_by_pnp(frame);
         triangulate_points();
+        if (cfg.use_line) triangulate_line_mono();
         const bool dyn = cfg.dynamic && instances;
         if (dyn) {               // estimator.cpp:1562-1622
             const oim::Body b = body();
@@ -717,9 +870,11 @@ struct Estimator {
             im.Optimization(b);
             im.OutliersRejection(b);
         }
+        if (cfg.use_line) optimization_with_only_line();
         optimization();
         std::set<int> rm; outliers_rejection(rm);
         for (auto it = lms.begin(); it != lms.end();) { auto cur = it++; if (rm.count(cur->feature_id)) lms.erase(cur); }
+        remove_line_outlier();
         if (dyn) { const oim::Body b = body(); im.ManageTriangulatePoint(b); im.SlideWindow(b, margin_old); }      // :1653-1658
         slide_window();
         if (dyn) {               // :1663-1676
@@ -837,7 +992,7 @@ int dvo_ba_solve(dvo_ba_problem* P, dvo_ba_summary* S) {
         }
     }
     Solver solver(prob);
-    SolveOptions so; so.max_num_iterations = P->max_iters;
+    SolveOptions so; so.max_num_iterations = P->max_iters; so.xnorm2_extra = P->x_norm2_extra;
     SolveSummary sum = solver.solve(so);
     if (S) { S->iterations = sum.iterations; S->successful = sum.successful; S->termination = sum.termination; S->slots = 0; S->initial_cost = sum.initial_cost; S->final_cost = sum.final_cost; }
     return 0;
@@ -951,7 +1106,18 @@ dvo_estimator* dvo_estimator_create(const dvo_be_config* c) {
     cfg.noise = ImuNoise{ c->acc_n, c->gyr_n, c->acc_w, c->gyr_w };
     for (int k = 0; k < 2; ++k) { for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) cfg.ric[k](i, j) = c->ric[k][i * 3 + j]; cfg.tic[k][i] = c->tic[k][i]; } }
     cfg.dynamic = c->dynamic; cfg.use_det3d = c->use_det3d; cfg.instance_init_min_num = c->instance_init_min_num; cfg.static_inst_threshold = c->static_inst_threshold;
+    cfg.use_line = c->use_line; cfg.line_min_obs = c->line_min_obs; for (int k = 0; k < 4; ++k) cfg.line_sqrt_info[k] = c->line_sqrt_info[k];
     return new dvo_estimator{ new Estimator(cfg) };
+}
+int dvo_estimator_set_lines(dvo_estimator* e, const dvo_line_row* lines, int n) { e->e->pending_lines.assign(lines, lines + n); return 0; }
+int dvo_estimator_get_lines(dvo_estimator* e, dvo_line_landmark* out, int cap, int* n_out) {
+    int k = 0;
+    for (auto& l : e->e->line_landmarks) {
+        if (k >= cap) break;
+        dvo_line_landmark& o = out[k++]; o.id = l.feature_id; o.start_frame = l.start_frame; o.n_obs = (int)l.feats.size(); o.is_triangulation = l.is_triangulation;
+        std::memcpy(o.plucker, l.line_plucker, 48); for (int c = 0; c < 3; ++c) { o.ptw1[c] = l.ptw1[c]; o.ptw2[c] = l.ptw2[c]; }
+    }
+    *n_out = k; return 0;
 }
 void dvo_estimator_destroy(dvo_estimator* e) { if (e) { delete e->e; delete e; } }
 void dvo_estimator_input_imu(dvo_estimator* e, double t, const double* acc, const double* gyr) { e->e->input_imu(t, P3(acc), P3(gyr)); }

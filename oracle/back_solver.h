@@ -97,7 +97,7 @@ inline void plus(const ParamBlock& b, const double* x, const double* d, double* 
     out[3] = r.x; out[4] = r.y; out[5] = r.z; out[6] = r.w;
 }
 
-struct SolveOptions { int max_num_iterations = 8; };
+struct SolveOptions { int max_num_iterations = 8; double xnorm2_extra = 0; };     // xnorm2_extra: squared norm of blocks in ceres' x that the flat problem does not carry (dvo_ba_problem::x_norm2_extra)
 struct SolveSummary {
     int iterations = 0, successful = 0; double initial_cost = 0, final_cost = 0; int termination = 0;   // 0 max-iter, 1 converged, 2 failure
     std::vector<double> cost_trace;
@@ -179,7 +179,7 @@ public:
         for (int i = 0; i < N; ++i) scale[i] = 1.0 / (1.0 + std::sqrt(hdiag(i)));
         double radius = 1e4, mu = 1e-8; const double min_mu = 1e-8, max_mu = 1.0, mu_inc = 10.0;
         bool reuse = false; double alpha = 0, dogleg_norm = 0; int invalid = 0;
-        double x_norm = 0; for (double v : x) x_norm += v * v; x_norm = std::sqrt(x_norm);
+        double x_norm = opt.xnorm2_extra; for (double v : x) x_norm += v * v; x_norm = std::sqrt(x_norm);
         auto grad_max = [&]() { double m = 0; for (int i = 0; i < N; ++i) m = std::max(m, std::fabs(g[i])); return m; };   // plain-Euclidean blocks; pose blocks use Plus-projected gradient in Ceres, max-norm equal to first order
         if (grad_max() <= 1e-10) { sum.termination = 1; sum.final_cost = x_cost; return sum; }
         for (int it = 1;; ++it) {
@@ -245,7 +245,7 @@ public:
             if (std::fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { scatter(x); sum.termination = 1; break; }
             const double rel = (x_cost - cand_cost) / model_cost_change;
             if (rel > 1e-3) {
-                x = cand; x_norm = 0; for (double v : x) x_norm += v * v; x_norm = std::sqrt(x_norm);
+                x = cand; x_norm = opt.xnorm2_extra; for (double v : x) x_norm += v * v; x_norm = std::sqrt(x_norm);
                 x_cost = evaluate(true);    // == cand_cost; rebuilds H, g at the new point
                 sum.successful++;
                 if (rel < 0.25) radius *= 0.5;

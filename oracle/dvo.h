@@ -179,6 +179,7 @@ typedef struct dvo_ba_problem {
     double *pose, *speed_bias, *ex_pose, *td, *inv_depth;
     const dvo_ba_factor* factors; const dvo_ba_lm* landmarks; const dvo_ba_imu* imu;
     const dvo_ba_prior* prior; const double* prior_A; const double* prior_b;
+    double x_norm2_extra;            /* squared norm of parameter blocks that are in ceres' x but carry no live residual (the line blocks); layout shared with dv_ba_problem */
 } dvo_ba_problem;
 typedef struct dvo_ba_summary { int32_t iterations, successful, termination, slots; double initial_cost, final_cost; } dvo_ba_summary;
 /* ceres::Solve restatement on a standalone window (Estimator::Optimization's problem, estimator.cpp:261-326) */
@@ -196,7 +197,11 @@ typedef struct dvo_be_config {       /* para (estimator/vio_parameters.cpp:19-83
     double ric[2][9], tic[2][3];     /* body_T_cam0 / body_T_cam1 rotation (row-major) and translation */
     int dynamic, use_det3d, instance_init_min_num, pad_;      /* cfg::slam == kDynamic; use_det3d; para::kInstanceInitMinNum */
     double static_inst_threshold;    /* para::kStaticInstThreshold */
+    int use_line, line_min_obs;      /* cfg::use_line, para::kLineMinObs */
+    double line_sqrt_info[4];        /* lineProjectionFactor::sqrt_info, row-major 2x2 (the reference never assigns it: zero) */
 } dvo_be_config;
+typedef struct dvo_line_row { uint32_t id; int32_t has_right; double left[4], right[4]; } dvo_line_row;      /* FeatureBackground::lines entry */
+typedef struct dvo_line_landmark { int32_t id, start_frame, n_obs, is_triangulation; double plucker[6], ptw1[3], ptw2[3]; } dvo_line_landmark;
 
 typedef struct dvo_be_state {
     int frame, nonlinear, margin_old, n_landmarks, n_long, iterations;
@@ -229,6 +234,8 @@ int dvo_insts_output(dvo_insts*, dvo_inst_obs* insts, int cap_insts, int* n_inst
 /* ProcessImage with the object branch (estimator.cpp:1562-1622,1653-1676); see inst_manager.h */
 int dvo_estimator_process_dynamic(dvo_estimator*, const dvo_feat* feats, int n, double t, const dvo_inst_obs* insts, int n_insts, const dvo_feat* inst_feats,
                                   const double* points, dvo_be_state* out);
+int dvo_estimator_set_lines(dvo_estimator* e, const dvo_line_row* lines, int n);      /* frame.features.lines of the next process call */
+int dvo_estimator_get_lines(dvo_estimator* e, dvo_line_landmark* out, int cap, int* n_out);
 int dvo_estimator_get_instances(dvo_estimator*, dvo_inst_state* out, int cap, int* n_out, double* summary4);
 
 #ifdef __cplusplus

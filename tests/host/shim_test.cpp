@@ -142,6 +142,17 @@ int main(int argc, char** argv) {
             std::printf("latest %d key_poses %zu landmarks_positive %d\n", (int)have, est.key_poses.size(), (int)!est.Landmarks().empty());
             const Estimator::EgoInfo e = est.GetOutputEgoInfo();
             std::printf("ego R00 %.3f P_bc %.3f %.3f %.3f\n", e.R[0], e.P_bc[0], e.P_bc[1], e.P_bc[2]);
+            {   // TrackImageLine: one more frame with two detector segments (the second only seen on the left); the principal point maps to (0, 0)
+                SemanticImage img;
+                img.gray0 = ImageView{buf.data() + (size_t)(2 * (n - 1)) * w * h, w, h, w, false};
+                img.gray1 = ImageView{buf.data() + (size_t)(2 * (n - 1) + 1) * w * h, w, h, w, false};
+                img.time0 = 1.0 + 0.05 * n; img.seq = n;
+                const float cx = (float)c.cam0.cx, cy = (float)c.cam0.cy;
+                FeatureBackground fb = tracker.TrackImageLine(img, { LineSegment{ 5, cx, cy, cx + 50, cy }, LineSegment{ 9, cx, cy - 20, cx, cy + 20 } }, { LineSegment{ 5, cx - 4, cy, cx + 46, cy } });
+                const Line& l5 = fb.lines.at(5)[0].second;
+                std::printf("lines %zu stereo %zu %zu start %.6f %.6f end_x_positive %d points_positive %d\n", fb.lines.size(), fb.lines.at(5).size(), fb.lines.at(9).size(),
+                            std::fabs(l5.x1), std::fabs(l5.y1), l5.x2 > 0.01, !fb.points.empty());
+            }
             est.ChangeSensorType(0, 1);
             std::printf("changed\n");
             return 0;

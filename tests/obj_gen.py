@@ -195,7 +195,7 @@ def make_line_scene(seed, n_lines=40, max_iters=10, pix_sigma=0.002, orth_noise=
     consecutive frames (para::kLineMinObs = 5, estimator/vio_parameters.cpp:47: AddLineResidualBlock skips landmarks with fewer) as noisy
     end points on the normalised plane; the initial orthonormal parameters are the true ones plus noise.
     The last `empty_lines` lines have no observation (they must not move and do not count in |x|)."""
-    from dynamic_vins_amd import line_geometry as LG
+    from tests import line_geometry_np as LG
     from dynamic_vins_amd.backend import LINEOBS_DTYPE, LineProblem
     rng = np.random.default_rng(seed)
     R_bc = np.array([[0, 0, 1.0], [-1, 0, 0], [0, -1, 0]]) @ _small_rot(rng, 0.01)

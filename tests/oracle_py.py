@@ -269,7 +269,8 @@ class dvo_be_config(C.Structure):
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),
                 ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
                 ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2),
-                ("dynamic", C.c_int), ("use_det3d", C.c_int), ("instance_init_min_num", C.c_int), ("pad_", C.c_int), ("static_inst_threshold", C.c_double)]
+                ("dynamic", C.c_int), ("use_det3d", C.c_int), ("instance_init_min_num", C.c_int), ("pad_", C.c_int), ("static_inst_threshold", C.c_double),
+                ("use_line", C.c_int), ("line_min_obs", C.c_int), ("line_sqrt_info", C.c_double * 4)]
 
 
 class dvo_be_state(C.Structure):
@@ -280,8 +281,11 @@ class dvo_be_state(C.Structure):
 
 def make_be_config(cls, use_imu=1, stereo=1, plane_constraint=0, max_iters=8, keyframe_parallax=10.0, init_depth=5.0,
                    g_norm=9.81, td=0.0, acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None,
-                   dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0):
+                   dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0, use_line=0, line_min_obs=5, line_sqrt_info=(0.0, 0.0, 0.0, 0.0)):
     c = cls()
+    c.use_line, c.line_min_obs = use_line, line_min_obs
+    for i in range(4):
+        c.line_sqrt_info[i] = float(line_sqrt_info[i])
     c.dynamic, c.use_det3d, c.instance_init_min_num, c.static_inst_threshold = dynamic, use_det3d, instance_init_min_num, static_inst_threshold
     c.use_imu, c.stereo, c.plane_constraint, c.max_iters = use_imu, stereo, plane_constraint, max_iters
     c.keyframe_parallax, c.init_depth, c.g_norm, c.td = keyframe_parallax, init_depth, g_norm, td
@@ -338,6 +342,19 @@ class OracleEstimator:
         out = np.zeros(cap, dtype); n = C.c_int(0); summ = np.zeros(4)
         L.dvo_estimator_get_instances(self.h, _p(out), cap, C.byref(n), _p(summ))
         return out[: n.value].copy(), summ
+
+    def set_lines(self, rows):
+        L = self.lib
+        L.dvo_estimator_set_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        rows = np.ascontiguousarray(rows)
+        return L.dvo_estimator_set_lines(self.h, _p(rows) if len(rows) else None, len(rows))
+
+    def lines(self, dtype, cap=1024):
+        L = self.lib
+        L.dvo_estimator_get_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        out = np.zeros(cap, dtype); n = C.c_int(0)
+        L.dvo_estimator_get_lines(self.h, _p(out), cap, C.byref(n))
+        return out[: n.value].copy()
 
     def close(self):
         if self.h:

@@ -143,4 +143,5 @@ def test_shim_callback_and_publisher_members_and_dynamic_mode(shim_exe, tmp_path
     assert out[1] == "objects frames %d feats_positive 1" % n
     assert out[2].startswith("latest ") and out[2].endswith("key_poses 11 landmarks_positive 1")
     assert out[3].startswith("ego R00 ") and out[3].endswith("P_bc 0.000 0.000 0.000")
-    assert out[4] == "changed"
+    assert out[4] == "lines 2 stereo 2 1 start 0.000000 0.000000 end_x_positive 1 points_positive 1"
+    assert out[5] == "changed"

@@ -1,0 +1,90 @@
+"""Line mode (cfg::use_line) of the back end, `-m gpu`: dv_est_set_lines + dv_est_process vs the oracle estimator with the same point rows, IMU stream and line rows.
+
+What the reference does with lines (estimator.cpp:224-253, 345-395, 1524-1639; feature_manager.cpp:124-160, 339-560, 611-778) and what is compared:
+  - FeatureManager::line_landmarks: ids, start frames, observation counts, triangulation flags identical on every frame (add, TriangulateLineMono,
+    RemoveLineOutlier, the three slide halves); line_plucker / ptw1 / ptw2 within 1e-6 relative (they are functions of ego poses that agree to 1e-5 m);
+  - lineProjectionFactor::sqrt_info is never assigned, so the line residual blocks are inert in OptimizationWithOnlyLine and Optimization: the ego
+    trajectory must equal both the oracle's line-mode trajectory (1e-5 m) and the product's own trajectory with use_line = 0 up to ceres' x_norm
+    (the line blocks sit in x; parameter-tolerance test only);
+  - a non-zero sqrt_info (a repaired reference) switches the product's line-only solve to the device kernel (dv_line_solve): covered against the oracle's
+    solver on the same problem in test_line_factor.py, and here as a run that must stay finite and keep every count equal.
+"""
+import numpy as np
+import pytest
+
+from dynamic_vins_amd import sim
+
+pytestmark = pytest.mark.gpu
+
+NOISE = dict(acc_n=0.02, gyr_n=0.002, acc_w=2e-4, gyr_w=2e-5)
+
+
+def run(gpu_ctx_factory, oracle, frames, use_imu=1, use_line=1, line_min_obs=5, with_oracle=True):
+    from dynamic_vins_amd.backend import Estimator, LINELM_DTYPE
+    ctx = gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5)
+    traj = sim.Trajectory()
+    fs = sim.FeatureSim(traj, sim.EUROC, 752, 480, sim.room_points(3000), max_cnt=150, pix_sigma=0.3, seed=3)
+    ls = sim.LineSim(traj, 752, 480, n=80)
+    kw = dict(use_imu=use_imu, stereo=1, max_iters=8, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], use_line=use_line, line_min_obs=line_min_obs, **NOISE)
+    ref = oracle.estimator(**kw) if with_oracle else None
+    dev = Estimator(ctx, **kw)
+    T0, dtf = 1.0, 0.1
+    ts, acc, gyr = sim.imu_stream(traj, T0 - 0.05, T0 + frames * dtf + 0.1, 200.0, **NOISE)
+    k = 0
+    traj_d, stats = [], dict(max_lines=0, max_tri=0, removed=0, max_dp=0.0, max_dplk=0.0)
+    prev_ids = set()
+    for f in range(frames):
+        t = T0 + f * dtf
+        while k < len(ts) and ts[k] <= t + 0.011:
+            if ref:
+                ref.input_imu(ts[k], acc[k], gyr[k])
+            dev.InputIMU(ts[k], acc[k], gyr[k])
+            k += 1
+        rows, lrows = fs.frame(t), ls.frame(t)
+        if use_line:
+            dev.SetLines(lrows)
+        rc_d, sd = dev.ProcessMeasurements(rows, t)
+        assert rc_d == 0
+        Wd = dev.window()
+        traj_d.append(Wd[10, :3].copy())
+        Ld = dev.lines()
+        ids = set(Ld["id"].tolist())
+        stats["removed"] += len(prev_ids - ids); prev_ids = ids
+        stats["max_lines"] = max(stats["max_lines"], len(Ld)); stats["max_tri"] = max(stats["max_tri"], int(Ld["is_triangulation"].sum()))
+        if not ref:
+            continue
+        if use_line:
+            ref.set_lines(lrows)
+        rc_o, so = ref.process(rows, t)
+        assert rc_o == 0
+        assert (sd.frame, sd.nonlinear, sd.margin_old, sd.n_landmarks, sd.n_long) == (so.frame, so.nonlinear, so.margin_old, so.n_landmarks, so.n_long), f"frame {f}"
+        assert sd.iterations == so.iterations, f"frame {f}: iterations {sd.iterations} vs {so.iterations}"
+        Wo = ref.window()
+        stats["max_dp"] = max(stats["max_dp"], np.abs(Wo[:, :3] - Wd[:, :3]).max())
+        Lo = ref.lines(LINELM_DTYPE)
+        assert len(Ld) == len(Lo), f"frame {f}: {len(Ld)} line landmarks vs {len(Lo)}"
+        for key in ("id", "start_frame", "n_obs", "is_triangulation"):
+            assert np.array_equal(Ld[key], Lo[key]), f"frame {f}: {key}"
+        tri = Lo["is_triangulation"] != 0
+        if tri.any():
+            scale = np.abs(Lo["plucker"][tri]).max(axis=1, keepdims=True)
+            stats["max_dplk"] = max(stats["max_dplk"], (np.abs(Ld["plucker"][tri] - Lo["plucker"][tri]) / scale).max())
+            assert np.abs(Ld["ptw1"][tri] - Lo["ptw1"][tri]).max() < 1e-4 and np.abs(Ld["ptw2"][tri] - Lo["ptw2"][tri]).max() < 1e-4, f"frame {f}"
+    return np.array(traj_d), stats
+
+
+@pytest.mark.parametrize("use_imu,frames", [(1, 42), (0, 34)])
+def test_line_mode_tracks_oracle(gpu_ctx_factory, oracle, use_imu, frames):
+    traj_d, st = run(gpu_ctx_factory, oracle, frames, use_imu=use_imu)
+    assert st["max_dp"] < 1e-5, st
+    assert st["max_dplk"] < 1e-6, st
+    # the run must exercise the machinery, not pass on empty tables
+    assert st["max_lines"] >= 10 and st["max_tri"] >= 5 and st["removed"] >= 1, st
+
+
+def test_line_blocks_are_inert_as_in_the_reference(gpu_ctx_factory, oracle):
+    """With the reference's zero sqrt_info the line blocks change nothing but ceres' x_norm: the ego trajectory with use_line = 1 equals the one with use_line = 0."""
+    a, st = run(gpu_ctx_factory, oracle, 36, use_line=1, with_oracle=False)
+    b, _ = run(gpu_ctx_factory, oracle, 36, use_line=0, with_oracle=False)
+    assert st["max_tri"] >= 5
+    assert np.abs(a - b).max() < 1e-6, np.abs(a - b).max()

@@ -1,7 +1,7 @@
 """The line-only refinement: ceres::Solve of Estimator::OptimizationWithOnlyLine (estimator/estimator.cpp:345-395)
 on the problem AddLineResidualBlock builds (:222-253).
 CPU (-m "not gpu"): the oracle's problem assembly against an independent numpy restatement of the Cauchy-robustified cost (Plücker
-transforms of dynamic_vins_amd/line_geometry.py), the reference's shipped behaviour (zero sqrt_info: returns at once) and invariants.
+transforms of tests/line_geometry_np.py), the reference's shipped behaviour (zero sqrt_info: returns at once) and invariants.
 GPU (-m gpu): dv_line_solve (generic block-diagonal solver, bd_solve.h + be_linesolve.hip) against the oracle: same iteration /
 acceptance sequence, costs to 1e-8 relative, parameters: median 1e-10, maximum 1e-6 (conditioning of the representation, see the test)."""
 import numpy as np
@@ -21,7 +21,7 @@ def ctx(gpu_ctx_factory):
 
 
 def _cost(prob):
-    from dynamic_vins_amd import line_geometry as LG
+    from tests import line_geometry_np as LG
     si = prob.sqrt_info.reshape(2, 2)
     Rbc, tbc = G._qR(prob.ex_pose[3:]), prob.ex_pose[:3]
     c = 0.0

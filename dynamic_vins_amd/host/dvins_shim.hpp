@@ -246,6 +246,7 @@ public:
     // two-phase form: lets the caller overlap the front end of frame k+1 with the back end of frame k
     void TrackImageEnqueue(SemanticImage& img, int mode = DV_MODE_RAW) {
         check_image(img);
+        remember(img);
         cur_time = img.time0;
         detail::check(ctx_, dv_track_stereo_enqueue(ctx_, img.gray0.data, img.gray1.data, img.gray0.width, img.gray0.height, img.gray0.stride, img.time0,
                                                     img.inv_merge_mask.data, mode, mem_of(img.gray0)), "TrackImage");

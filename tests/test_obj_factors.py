@@ -124,10 +124,11 @@ def test_hip_object_factors_match_oracle(gpu_ctx_factory, oracle):
 
 
 def test_line_geometry_and_triangulation(oracle):
-    """numpy mirror (dynamic_vins_amd/line_geometry.py) vs the oracle's C++ restatement, plus the geometry itself: a 3-D segment
+    """numpy mirror (tests/line_geometry_np.py) vs the oracle's C++ restatement, plus the geometry itself: a 3-D segment
     seen from a moving camera is triangulated back, its end points land on the segment, orth <-> Plücker round-trips"""
     import ctypes as C
-    from dynamic_vins_amd import line_geometry as LG, sim
+    from tests import line_geometry_np as LG
+    from dynamic_vins_amd import sim
     lib = oracle.lib
     rng = np.random.default_rng(9)
     V = C.c_void_p

@@ -6,8 +6,9 @@ What the reference does with lines (estimator.cpp:224-253, 345-395, 1524-1639; f
   - lineProjectionFactor::sqrt_info is never assigned, so the line residual blocks are inert in OptimizationWithOnlyLine and Optimization: the ego
     trajectory must equal both the oracle's line-mode trajectory (1e-5 m) and the product's own trajectory with use_line = 0 up to ceres' x_norm
     (the line blocks sit in x; parameter-tolerance test only);
-  - a non-zero sqrt_info (a repaired reference) switches the product's line-only solve to the device kernel (dv_line_solve): covered against the oracle's
-    solver on the same problem in test_line_factor.py, and here as a run that must stay finite and keep every count equal.
+  - a non-zero sqrt_info is NOT the reference's behaviour (nothing assigns it).  The product then runs the line-only solve on the device (dv_line_solve,
+    parity against the oracle's solver on the same problem: tests/test_line_solve.py) and says once on stderr that the window solve keeps the lines inert;
+    live line blocks inside the window solve are out of scope (DESIGN.md "Line mode").
 """
 import numpy as np
 import pytest

@@ -37,6 +37,7 @@ class dv_feat(C.Structure):
 _u8p = C.c_void_p      # image / status buffers: host ndarray pointer or device pointer (int)
 _f32p = C.c_void_p
 _ctx = C.c_void_p
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)      # dv_allgather_fn
 
 # name -> (restype, argtypes).  tests/test_abi.py checks this table against include/dvins.h.
 SIGNATURES = {
@@ -101,6 +102,12 @@ SIGNATURES = {
     "dv_timing_reset": (C.c_int, [_ctx]),
     "dv_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "dv_debug_set": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
+    "dv_dist_unique_id": (C.c_int, [C.c_void_p]),
+    "dv_dist_init_rccl": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
+    "dv_dist_init_host": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dv_dist_shutdown": (C.c_int, [_ctx]),
+    "dv_dist_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
+    "dv_allreduce_reduced_system": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
 }
 
 _lib = None

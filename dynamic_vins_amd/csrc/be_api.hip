@@ -212,12 +212,30 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculat
         if (kt) { StageScope k(ctx, "k_be_accept", s); be_launch_accept(pd.sa, s); }
         else be_launch_accept(pd.sa, s);
     };
+    // sharded window (be_shard.hip): every reduce is followed by the exchange of the partial systems and their rank-ordered sum, every cost-only
+    // evaluation by the exchange of the candidate costs.  The exchanges are enqueued unconditionally (all ranks hold identical control blocks).
+    const bool sharded = pd.sa.sh.on != 0;
+    auto exchange_system = [&](int spec) -> int {
+        if (!sharded) return 0;
+        if (kt) { StageScope k(ctx, "k_be_exchange", s); if (be_exchange(ctx, (size_t)pd.sa.sh.len, s)) return -1; }
+        else if (be_exchange(ctx, (size_t)pd.sa.sh.len, s)) return -1;
+        if (kt) { StageScope k(ctx, "k_be_shard_finalize", s); be_launch_shard_finalize(pd.sa, spec, s); }
+        else be_launch_shard_finalize(pd.sa, spec, s);
+        return 0;
+    };
+    auto exchange_cost = [&]() -> int {
+        if (!sharded) return 0;
+        be_launch_shard_cost(pd.sa, 0, s);
+        if (be_exchange(ctx, (size_t)pd.sa.sh.cap, s)) return -1;
+        be_launch_shard_cost(pd.sa, 1, s);
+        return 0;
+    };
     for (int it = 0; it < slots; ++it) {
         const bool head = !speculative || it == 0, last = !speculative || it == slots - 1;
-        if (head) { eval(BE_EVAL_X); reduce(0); }
+        if (head) { eval(BE_EVAL_X); reduce(0); if (exchange_system(0)) return -1; }
         if (solve(head ? 0 : 1)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
-        if (last) { eval(BE_EVAL_CAND_COST); accept(); }
-        else { eval(BE_EVAL_CAND_FULL); reduce(1); }
+        if (last) { eval(BE_EVAL_CAND_COST); if (exchange_cost()) return -1; accept(); }
+        else { eval(BE_EVAL_CAND_FULL); reduce(1); if (exchange_system(1)) return -1; }
     }
     return 0;
 }
@@ -369,6 +387,17 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     BeEvalArgs ea{};
     ea.ctl = w.ctl; ea.x = w.x; ea.cand = w.cand; ea.fac = w.fac; ea.lm = w.lm; ea.imu = w.imu; ea.prior = w.prior; ea.priorA = w.priorA; ea.priorb = w.priorb;
     ea.dims = d; ea.g_norm = P->g_norm; ea.cand_cost = w.cand_cost; ea.prior_c0 = w.prior_c0 + w.prior_cur;
+    ea.lm_lo = 0; ea.lm_hi = P->nlm;
+    BeShard sh{};
+    if (ctx->dist.transport != 0) {        // landmark-sharded window: contiguous ranges of cap = ceil(nlm / world) landmarks
+        const DvDist& dd = ctx->dist;
+        sh.on = 1; sh.rank = dd.rank; sh.world = dd.world;
+        sh.cap = std::max(1, (P->nlm + dd.world - 1) / dd.world);
+        sh.lo = std::min(P->nlm, dd.rank * sh.cap); sh.hi = std::min(P->nlm, sh.lo + sh.cap);
+        sh.len = BE_XS_LEN(sh.cap);
+        sh.xsend = (double*)dd.xsend.p; sh.xrecv = (const double*)dd.xrecv.p;
+        ea.lm_lo = sh.lo; ea.lm_hi = sh.hi;
+    }
     for (int k = 0; k < 2; ++k) { ea.packets[k] = w.packets[k]; ea.imu_out[k] = w.imu_out[k]; ea.prior_out[k] = w.prior_out[k]; }
     BeSolveArgs sa{};
     sa.ctl = w.ctl; sa.x = w.x; sa.cand = w.cand; sa.lm = w.lm; sa.imu = w.imu; sa.prior = w.prior; sa.priorA = w.priorA; sa.dims = d;
@@ -376,7 +405,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     for (int k = 0; k < 2; ++k) { sa.packets[k] = w.packets[k]; sa.imu_out[k] = w.imu_out[k]; sa.prior_out[k] = w.prior_out[k]; sa.Hd[k] = w.Hd[k]; sa.Sc[k] = w.Sc[k]; sa.gvec[k] = w.gvec[k]; }
     sa.scale_p = w.scale_p; sa.diag_p = w.diag_p; sa.grad_p = w.grad_p; sa.gn_p = w.gn_p; sa.scale_l = w.scale_l; sa.diag_l = w.diag_l; sa.grad_l = w.grad_l; sa.gn_l = w.gn_l;
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;
-    sa.xnorm2_extra = P->x_norm2_extra;
+    sa.xnorm2_extra = P->x_norm2_extra; sa.sh = sh;
     // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
     // invalid; be_solve_fused_end checks the downloaded control block and, in that rare case, runs the spare slots and the
     // (idempotent) tail again.
@@ -387,6 +416,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     if (eval_only) {        // dv_ba_eval: one evaluation + assembly of the reduced camera system at the given states (mu = 0)
         be_launch_eval(ea, BE_EVAL_X, s);
         be_launch_reduce(sa, 0, s);
+        if (sh.on) { if (be_exchange(ctx, (size_t)sh.len, s)) return -1; be_launch_shard_finalize(sa, 0, s); }
         DV_CHECK(hipGetLastError());
         return 0;
     }

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
     const int lane = threadIdx.x;
     const int b = blockIdx.x;
     const int nlm = a.dims.nlm, nimu = a.dims.nimu;
+    if (b < nlm && (b < a.lm_lo || b >= a.lm_hi)) return;      // sharded window: another rank's landmark
     __shared__ FrameGeom fg[BE_NF];
     __shared__ m33 ric[2];
     __shared__ d3 tic[2];

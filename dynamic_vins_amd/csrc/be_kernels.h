@@ -5,6 +5,24 @@
 
 #define IMU_OUT_STRIDE 936
 
+// Landmark-sharded window (north_star: "all-reduce of the reduced camera-pose Hessian"): rank r of `world` owns the landmarks [lo, hi)
+// (contiguous, cap = ceil(nlm / world) each).  Every rank evaluates and Schur-reduces only its own landmarks; IMU factors and the prior are evaluated
+// on every rank (identical bits, no exchange).  One exchange vector per rank and linearisation:
+//   [XS_S, +66*66)   sum_l rho_l w_l w_l^T over the owned landmarks, indexed (frame * 6 + comp) x (frame * 6 + comp)
+//   [XS_H, +66*66)   sum_l D_l (the landmarks' direct pose-pose terms)
+//   [XS_G, +66), [XS_GS, +66)   gradient parts
+//   [XS_ROWS, +BE_XS_NROWS * cap)   rows H, G, COST, W[66] of the owned packets: what be_solve needs of EVERY landmark (back substitution, norms)
+//   [.., +cap)       the owned candidate costs
+// The vectors are all-gathered and summed IN RANK ORDER by be_shard_finalize_kernel, so every rank holds the same bits and takes the same decisions.
+#define BE_XS_S 0
+#define BE_XS_H (66 * 66)
+#define BE_XS_G (2 * 66 * 66)
+#define BE_XS_GS (BE_XS_G + 66)
+#define BE_XS_ROWS (BE_XS_GS + 66)
+#define BE_XS_NROWS (BE_PK_W + 66)
+#define BE_XS_LEN(cap) (BE_XS_ROWS + (BE_XS_NROWS + 1) * (cap))
+struct BeShard { int32_t on, rank, world, lo, hi, cap, len, pad; double* xsend; const double* xrecv; };
+
 struct BeEvalArgs {
     const BeCtl* ctl;
     const BeState* x; const BeState* cand;
@@ -15,6 +33,7 @@ struct BeEvalArgs {
     double* imu_out[2];     // [nimu][936]: cost, g[30], H[30][30]
     double* prior_out[2];   // cost, g[n_prior]
     double* cand_cost;      // [nlm + nimu + 1]                    written by the evaluations at cand
+    int32_t lm_lo, lm_hi;   // landmark blocks outside [lm_lo, lm_hi) return at once (sharded window); 0, nlm otherwise
     const double* prior_c0; // the prior's constant r0^T r0, device resident (the marginalization of the previous frame may still be writing it
                             // when this solve is being prepared on the host)
 };
@@ -32,6 +51,7 @@ struct BeSolveArgs {
     double* scale_l; double* diag_l; double* grad_l; double* gn_l;     // [nlm]
     int32_t* prior_col;     // [BE_MAX_STATE] prior index of each state column (-1 if absent)
     int32_t* col_kind; int32_t* col_frame; int32_t* col_comp;          // [n]
+    BeShard sh;             // landmark sharding (on = 0: the whole window lives here)
     double xnorm2_extra;    // squared norm of inert free blocks (line blocks under zero sqrt_info) that count in the parameter-tolerance test
 };
 
@@ -94,6 +114,8 @@ void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s);      // spec: reduce the candidate's set (or, after a failed / invalid step, rebuild x's with the new mu)
 int  be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s);        // spec: decide on the pending candidate first (be_accept_kernel's rule)
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);
+void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s);   // after the exchange of a reduce: rank-ordered sums -> Hd / Sc / gvec, packet rows, candidate costs
+void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s);      // cost-only exchange: phase 0 packs the owned candidate costs, phase 1 scatters all of them
 void be_launch_proj_op(const BeFactor* fac, int n, const double* pose_i, const double* pose_j, const double* ex0, const double* ex1,
                        const double* lambda, const double* td, double* out, hipStream_t s);
 void be_launch_imu_op(const BeImu* m, double g_norm, const double* par, double* out, hipStream_t s);

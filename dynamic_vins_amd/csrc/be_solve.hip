@@ -107,7 +107,8 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         // the IMU / prior part of the block's 36 entries (and 6 gradient entries) is a chain of dependent global loads (column maps ->
         // factor / prior indices -> values): the seventh wave walks it WHILE the other six stream the landmark packets
         __shared__ double s_dh[36], s_dg[6];
-        if (ci == 6) {
+        const int l_lo = a.sh.on ? a.sh.lo : 0, l_hi = a.sh.on ? a.sh.hi : nlm;
+        if (ci == 6 && !a.sh.on) {
 #ifdef BE_RED_TS
             if (blockIdx.x == 0 && lane == 0) be_red_ts[16] = wall_clock64();
 #endif
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         const int e_dd = BE_PK_DD + fi * 36 + ci * 6;
         const int e_da_i = BE_PK_DA + fj * 36 + ci * 6;                 // anchor == fi : row ci of block (anchor, fj)
         const int e_da_j = BE_PK_DA + fi * 36 + ci;                     // anchor == fj : column ci of the transposed block
-        for (int l = ci < 6 ? lane : nlm; l < nlm; l += 64) {
+        for (int l = ci < 6 ? l_lo + lane : l_hi; l < l_hi; l += 64) {
             const double h = BE_PK(pk, BE_PK_H, l);
             const double s = c.first ? 1.0 / (1.0 + sqrt(h)) : a.scale_l[l];
             double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
@@ -153,6 +154,16 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         __syncthreads();
         if (blockIdx.x == 0) RTS(2);
         if (ci == 6) return;
+        if (a.sh.on) {            // sharded window: the partial landmark sums go to the exchange vector; be_shard_finalize_kernel adds the ranks up and the dense part in
+            if (lane < 6) {
+                double sv = S[0], hv = H[0];
+#pragma unroll
+                for (int q = 1; q < 6; ++q) if (lane == q) { sv = S[q]; hv = H[q]; }
+                const int e = (fi * 6 + ci) * 66 + fj * 6 + lane;
+                a.sh.xsend[BE_XS_S + e] = sv; a.sh.xsend[BE_XS_H + e] = hv;
+            } else if (diag && lane == 6) { a.sh.xsend[BE_XS_G + fi * 6 + ci] = G; a.sh.xsend[BE_XS_GS + fi * 6 + ci] = GS; }
+            return;
+        }
         if (lane < 6) {
             double sv = S[0], hv = H[0];
 #pragma unroll
@@ -170,7 +181,17 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         return;
     }
     const int eb = blockIdx.x - RED_PAIRS;
-    if (eb == 0 && c.first)
+    const int n_dense = (n * n + n + RED_THREADS - 1) / RED_THREADS;
+    if (eb >= n_dense) {          // sharded window only: pack the rows be_solve reads of every landmark, and the candidate costs, for the owned range
+        const int row = eb - n_dense, cap = a.sh.cap;
+        double* dst = a.sh.xsend + BE_XS_ROWS + (size_t)row * cap;
+        for (int k = threadIdx.x; k < cap; k += RED_THREADS) {
+            const int l = a.sh.lo + k;
+            dst[k] = l < a.sh.hi ? (row < BE_XS_NROWS ? BE_PK(pk, row, l) : a.cand_cost[l]) : 0.0;
+        }
+        return;
+    }
+    if (eb == 0 && c.first && !a.sh.on)
         for (int l = threadIdx.x; l < nlm; l += RED_THREADS) a.scale_l[l] = 1.0 / (1.0 + sqrt(BE_PK(pk, BE_PK_H, l)));
     const int t = eb * RED_THREADS + threadIdx.x;
     if (t < n * n) {
@@ -190,8 +211,76 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s) {
     const int n = a.dims.nstate;
     const int total = n * n + n;
-    hipLaunchKernelGGL(be_reduce_kernel, dim3(RED_PAIRS + (total + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, s, a, spec);
+    hipLaunchKernelGGL(be_reduce_kernel, dim3(RED_PAIRS + (total + RED_THREADS - 1) / RED_THREADS + (a.sh.on ? BE_XS_NROWS + 1 : 0)), dim3(RED_THREADS), 0, s, a, spec);
 }
+
+// Sharded window, after the all-gather of the exchange vectors: sums the ranks' partial landmark sums in RANK ORDER (identical bits on every rank), adds the
+// IMU / prior part, and writes Hd / Sc / gvec of the set be_reduce_kernel worked on; copies every landmark's H, G, COST, W rows into the packets and the
+// candidate costs into cand_cost.  Same predicate as be_reduce_kernel, so an idle slot leaves the previous system untouched.
+#define FIN_THREADS 256
+__global__ __launch_bounds__(FIN_THREADS) void be_shard_finalize_kernel(BeSolveArgs a, int spec) {
+    const BeCtl c = *a.ctl;
+    if (c.done) return;
+    int set = c.cur;
+    if (spec && c.pending) set ^= 1;
+    else if (!c.need_eval && !c.chol_fail) return;
+    const int n = a.dims.nstate, nlm = a.dims.nlm, W = a.sh.world, len = a.sh.len, cap = a.sh.cap;
+    const double* xr = a.sh.xrecv;
+    if (blockIdx.x < RED_PAIRS) {
+        const int fi = blockIdx.x / BE_NF, fj = blockIdx.x - fi * BE_NF;
+        if (fi >= a.dims.nframes || fj >= a.dims.nframes) return;
+        const int ci0 = a.dims.pose_col[fi], cj0 = a.dims.pose_col[fj];
+        if (ci0 < 0 || cj0 < 0) return;
+        __shared__ int s_ifi[BE_WIN + 1], s_ifj[BE_WIN + 1], s_pr[2];
+        if ((int)threadIdx.x < a.dims.nimu) { s_ifi[threadIdx.x] = a.imu[threadIdx.x].fi; s_ifj[threadIdx.x] = a.imu[threadIdx.x].fj; }
+        if (threadIdx.x == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
+        __syncthreads();
+        const RedCtx rc{ s_ifi, s_ifj, s_pr[0], s_pr[1] };
+        const int t = threadIdx.x;
+        if (t < 36) {
+            const int ci = t / 6, q = t - ci * 6, e = (fi * 6 + ci) * 66 + fj * 6 + q;
+            double sv = 0.0, hv = 0.0;
+            for (int r = 0; r < W; ++r) { sv += xr[(size_t)r * len + BE_XS_S + e]; hv += xr[(size_t)r * len + BE_XS_H + e]; }
+            const int i = ci0 + ci, j = cj0 + q;
+            const double hd = hv + red_dense_h(a, rc, a.imu_out[set], i, j);
+            a.Hd[set][(size_t)i * n + j] = hd;
+            if ((j >> 2) <= (i >> 2)) a.Sc[set][blk_pos(i, j, (n + 3) >> 2)] = hd - sv;
+        } else if (fi == fj && t >= 64 && t < 70) {
+            const int ci = t - 64;
+            double G = 0.0, GS = 0.0;
+            for (int r = 0; r < W; ++r) { G += xr[(size_t)r * len + BE_XS_G + fi * 6 + ci]; GS += xr[(size_t)r * len + BE_XS_GS + fi * 6 + ci]; }
+            const int i = ci0 + ci;
+            a.gvec[set][i] = G + red_dense_g(a, rc, a.imu_out[set], a.prior_out[set], i);
+            a.gvec[set][n + i] = GS;
+        }
+        return;
+    }
+    const int row = blockIdx.x - RED_PAIRS;
+    double* pk = const_cast<double*>(a.packets[set]);
+    for (int l = threadIdx.x; l < nlm; l += FIN_THREADS) {
+        const int r = l / cap, k = l - r * cap;
+        const double v = xr[(size_t)r * len + BE_XS_ROWS + (size_t)row * cap + k];
+        if (row < BE_XS_NROWS) {
+            BE_PK(pk, row, l) = v;
+            if (row == BE_PK_H && c.first) a.scale_l[l] = 1.0 / (1.0 + sqrt(v));
+        } else const_cast<double*>(a.cand_cost)[l] = v;
+    }
+}
+void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s) {
+    hipLaunchKernelGGL(be_shard_finalize_kernel, dim3(RED_PAIRS + BE_XS_NROWS + 1), dim3(FIN_THREADS), 0, s, a, spec);
+}
+// cost-only exchange (the slot that ends with be_accept): phase 0 packs the owned candidate costs, phase 1 scatters the gathered ones
+__global__ __launch_bounds__(FIN_THREADS) void be_shard_cost_kernel(BeSolveArgs a, int phase) {
+    const BeCtl c = *a.ctl;
+    if (c.done || !c.pending) return;
+    const int cap = a.sh.cap;
+    if (phase == 0) {
+        for (int k = threadIdx.x; k < cap; k += FIN_THREADS) { const int l = a.sh.lo + k; a.sh.xsend[k] = l < a.sh.hi ? a.cand_cost[l] : 0.0; }
+    } else {
+        for (int l = threadIdx.x; l < a.dims.nlm; l += FIN_THREADS) { const int r = l / cap; const_cast<double*>(a.cand_cost)[l] = a.sh.xrecv[(size_t)r * cap + (l - r * cap)]; }
+    }
+}
+void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s) { hipLaunchKernelGGL(be_shard_cost_kernel, dim3(1), dim3(FIN_THREADS), 0, s, a, phase); }
 
 // ---------------------------------------------------------------------------------------------
 #define SOL_THREADS 1024

@@ -134,6 +134,19 @@ struct dv_inst_tracker;
 void dv_inst_destroy_internal(dv_inst_tracker* t);
 int dv_inst_wait_before_next_frame(dv_ctx* ctx);
 
+// One window sharded by landmark over several GPUs (be_shard.hip): the transport of the exchange vectors
+struct DvDist {
+    int transport = 0;            // 0 none, 1 RCCL all-gather on the BA stream, 2 host call-back (staged through pinned memory)
+    int rank = 0, world = 1;
+    void* comm = nullptr;         // ncclComm_t
+    dv_allgather_fn fn = nullptr; void* user = nullptr;
+    DevBuf xsend, xrecv; void* h_send = nullptr; void* h_recv = nullptr;
+    long long exchanges = 0;
+};
+int be_exchange(dv_ctx* ctx, size_t count, hipStream_t s);      // all-gather `count` doubles of dist.xsend into dist.xrecv (rank-major), ordered on s
+int be_dist_buffers(dv_ctx* ctx);
+void be_dist_release(dv_ctx* ctx);
+
 struct dv_ctx {
     dv_config cfg{};
     std::string err;
@@ -154,6 +167,7 @@ struct dv_ctx {
     hipStream_t be_stream = nullptr; BeWork be;
     ObjPending obj_pend, obj_op_pend;            // estimator's object solve / operator-level dv_obj_solve
     hipStream_t obj_stream = nullptr; DevBuf obj_buf;      // dynamic mode: the object solve runs beside the window solve
+    DvDist dist;
     dv_estimator* est = nullptr;
     struct dv_inst_tracker* inst = nullptr; hipEvent_t ev_pyr = nullptr, ev_bg_select = nullptr;      // dynamic mode: the per-object tracker (inst_track.hip)
 };

@@ -182,6 +182,7 @@ void dv_destroy(dv_ctx* ctx) {
                        &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->opA.buf, &ctx->opB.buf, &ctx->undist_buf[0], &ctx->undist_buf[1] }) b->release();
     if (ctx->inst) dv_inst_destroy_internal(ctx->inst);
     if (ctx->est) dv_est_destroy_internal(ctx->est);
+    be_dist_release(ctx);
     ctx->be.block.release(); ctx->be.marg_buf.release();
     if (ctx->be.pinned) (void)hipHostFree(ctx->be.pinned);
     ctx->obj_buf.release(); ctx->obj_pend.release(); ctx->obj_op_pend.release();

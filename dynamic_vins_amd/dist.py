@@ -61,8 +61,10 @@ def sequence_phase(rank):
 
 
 def shard_landmarks(nlm, rank, world):
-    """round-robin landmark partition: landmark l lives on rank l % world"""
-    return list(range(rank, nlm, world))
+    """the landmark partition of the sharded window (be_api.hip: contiguous ranges of cap = ceil(nlm / world)): the landmarks of `rank`"""
+    cap = max(1, -(-nlm // world))
+    lo = min(nlm, rank * cap)
+    return list(range(lo, min(nlm, lo + cap)))
 
 
 def allreduce_reduced_system(partial):
@@ -76,6 +78,72 @@ def allreduce_reduced_system(partial):
     for p in parts[1:]:
         out += p
     return out
+
+
+def shard_window(ctx, rank=None, world=None, transport="auto"):
+    """Turn ctx (frontend.Context) into rank `rank` of a landmark-sharded window solve (include/dvins.h: dv_dist_init_*).  Every rank must then hand the
+    same problem to dv_ba_solve / dv_est_process.
+      transport "rccl": ncclAllGather on the BA stream; the ncclUniqueId is created on rank 0 and broadcast through torch.distributed
+      transport "host": the exchange vector is staged through pinned host memory and all-gathered by torch.distributed (gloo or nccl) — tests, 1-GPU boxes
+      "auto": rccl when the process group's backend is nccl, host otherwise."""
+    import ctypes as C
+    import numpy as np
+    from . import _abi
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world is None:
+        world = dist.get_world_size() if dist.is_initialized() else 1
+    if transport == "auto":
+        transport = "rccl" if (dist.is_initialized() and dist.get_backend() == "nccl") or not dist.is_initialized() else "host"
+    lib = ctx.lib
+    if transport == "rccl":
+        uid = np.zeros(128, np.uint8)
+        if rank == 0 and lib.dv_dist_unique_id(uid.ctypes.data) != 0:
+            raise _abi.DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+        if dist.is_initialized() and world > 1:
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            t = torch.from_numpy(uid).to(dev)
+            dist.broadcast(t, 0)
+            uid = t.cpu().numpy().copy()
+        if lib.dv_dist_init_rccl(ctx.h, rank, world, uid.ctypes.data) != 0:
+            raise _abi.DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+        return None
+
+    def allgather(user, send, recv, nbytes):
+        try:
+            n = nbytes // 8
+            src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_double)), shape=(n,))
+            dst = np.ctypeslib.as_array(C.cast(recv, C.POINTER(C.c_double)), shape=(world, n))
+            if world == 1 or not dist.is_initialized():
+                dst[0] = src
+                return 0
+            if dist.get_backend() == "nccl":
+                parts = [torch.empty(n, dtype=torch.float64, device="cuda") for _ in range(world)]
+                dist.all_gather(parts, torch.from_numpy(src.copy()).cuda())
+                for r in range(world):
+                    dst[r] = parts[r].cpu().numpy()
+            else:
+                parts = [torch.empty(n, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(parts, torch.from_numpy(src.copy()))
+                for r in range(world):
+                    dst[r] = parts[r].numpy()
+            return 0
+        except Exception:            # never unwind through the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = _abi.ALLGATHER_FN(allgather)
+    if lib.dv_dist_init_host(ctx.h, rank, world, C.cast(cb, C.c_void_p), None) != 0:
+        raise _abi.DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+    ctx._dist_cb = cb          # keep the trampoline alive as long as the ctx
+    return cb
+
+
+def dist_info(ctx):
+    import ctypes as C
+    r, w, t, e = C.c_int(0), C.c_int(0), C.c_int(0), C.c_longlong(0)
+    ctx.lib.dv_dist_info(ctx.h, C.byref(r), C.byref(w), C.byref(t), C.byref(e))
+    return dict(rank=r.value, world=w.value, transport={0: "none", 1: "rccl", 2: "host"}[t.value], exchanges=e.value)
 
 
 def whole_job_rate(units_per_rank, world, seconds_max):

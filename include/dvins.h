@@ -205,6 +205,22 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* problem, dv_ba_summary* summary);
  * (dynamic_vins_amd/dist.py:allreduce_reduced_system). cost, S, g may be NULL. */
 int dv_ba_eval(dv_ctx* ctx, const dv_ba_problem* problem, int* n, double* cost, double* S, double* g);
 
+/* ---- one window sharded BY LANDMARK over several GPUs (BASELINE north_star: "RCCL all-reduce of the reduced camera-pose Hessian") ----
+ * The reference has no multi-GPU path; this is the exchange step its Schur elimination (ceres DENSE_SCHUR inside Estimator::Optimization,
+ * estimator.cpp:296-326) admits: rank r owns a contiguous range of landmarks, evaluates and eliminates only those, and the per-rank partial reduced
+ * systems are summed IN RANK ORDER on every rank (identical bits everywhere).  After dv_dist_init_*, dv_ba_solve / dv_ba_eval / dv_est_process on this
+ * ctx run sharded: every rank must be given the SAME problem and makes the same calls; every rank returns the same result.
+ * A binding in the reference would sit in Estimator::SetParameter (one ctx per rank, rank / world from the launcher). */
+typedef int (*dv_allgather_fn)(void* user, const void* send, void* recv, size_t bytes_per_rank);      /* recv: world x bytes_per_rank, rank-major; 0 = ok */
+int dv_dist_unique_id(uint8_t id[128]);                                                  /* ncclGetUniqueId: rank 0 creates it, the launcher broadcasts it */
+int dv_dist_init_rccl(dv_ctx* ctx, int rank, int world, const uint8_t id[128]);          /* RCCL all-gather on the BA stream (xGMI); no host round trip per iteration */
+int dv_dist_init_host(dv_ctx* ctx, int rank, int world, dv_allgather_fn fn, void* user); /* exchange staged through pinned host memory and the caller's all-gather */
+int dv_dist_shutdown(dv_ctx* ctx);
+int dv_dist_info(dv_ctx* ctx, int* rank, int* world, int* transport, long long* exchanges);
+/* operator form of the exchange: S_g (host, n doubles — this rank's partial [S | g | cost], e.g. of dv_ba_eval on the rank's share of the landmarks)
+ * is replaced by the rank-ordered sum over all ranks */
+int dv_allreduce_reduced_system(dv_ctx* ctx, double* S_g, int n);
+
 /* Replaces MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks} as driven by
  * Estimator::SetMarginalizationInfo (estimator/estimator.cpp:403-619).
  *   mode 0 = kMarginOld: P holds the linearisation point (all 11 window states), the residual blocks of the landmarks

@@ -37,8 +37,14 @@ CONFIGS = {                # primary + the two secondary sizes
 
 def git_head():
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+        if head:
+            return head
     except Exception:
+        pass
+    try:            # the GPU box has no .git: __graft_entry__.build() leaves the commit the library was built from next to it
+        return open(os.path.join(ROOT, "dynamic_vins_amd", "lib", "BUILD_HEAD")).read().strip() or None
+    except OSError:
         return None
 
 

@@ -43,6 +43,21 @@ res["digest"] = float(np.abs(tot.numpy()).sum())
 full = sum(np.outer(w[l], w[l]) for l in range(nlm))
 res["rel_err_vs_unsharded"] = float(np.abs(tot.numpy()[: n * n].reshape(n, n) - full).max() / np.abs(full).max())
 res["rate"] = dv_dist.whole_job_rate(100, world, res["tmax"])
+# the exchange on RECORDED partials of the HIP path (tests/golden/shard_partials.npz, written on the GPU box by tests/golden/gen_shard_partials.py): each rank
+# contributes the partial [S | g | cost] the kernels produced for its share of the landmarks; the rank-ordered sum must reproduce the unsharded system
+gold = np.load(os.path.join(ROOT, "tests", "golden", "shard_partials.npz"))
+mine_v = torch.from_numpy(gold[f"w{world}_r{rank}"].copy())
+tot_v = dv_dist.allreduce_reduced_system(mine_v).numpy()
+full = gold["full"]
+res["gold_rel_err"] = float(np.abs(tot_v - full).max() / np.abs(full).max())
+ordered = gold[f"w{world}_r0"].copy()
+for r in range(1, world):
+    ordered = ordered + gold[f"w{world}_r{r}"]
+res["gold_bitwise_rank_ordered"] = bool(np.array_equal(tot_v, ordered))
+res["gold_digest"] = float(np.abs(tot_v).sum())
+nn = int(gold["n"][0])
+Sg = tot_v[: nn * nn].reshape(nn, nn)
+res["gold_symmetric"] = bool(np.abs(Sg - Sg.T).max() <= 1e-12 * np.abs(Sg).max())
 dv_dist.barrier()
 with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:
     json.dump(res, f)

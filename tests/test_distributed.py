@@ -34,6 +34,10 @@ def test_two_rank_gloo(tmp_path):
     assert res[0]["digest"] == res[1]["digest"]
     assert all(x["rel_err_vs_unsharded"] < 1e-12 for x in res)
     assert all(x["rate"] == 100.0 for x in res)            # 2 ranks x 100 frames / 2.0 s
+    # recorded HIP partials of a window sharded over 2 ranks: the exchange reproduces the unsharded reduced camera system
+    assert all(x["gold_rel_err"] < 1e-13 for x in res), [x["gold_rel_err"] for x in res]
+    assert all(x["gold_bitwise_rank_ordered"] and x["gold_symmetric"] for x in res)
+    assert res[0]["gold_digest"] == res[1]["gold_digest"]
 
 
 def test_single_process_helpers_are_identity():
@@ -44,4 +48,5 @@ def test_single_process_helpers_are_identity():
     t = torch.arange(5, dtype=torch.float64)
     assert torch.equal(d.allreduce_reduced_system(t), t)
     assert d.shard_landmarks(7, 0, 1) == list(range(7))
+    assert d.shard_landmarks(7, 0, 2) == [0, 1, 2, 3] and d.shard_landmarks(7, 1, 2) == [4, 5, 6] and d.shard_landmarks(2, 3, 4) == []
     assert d.whole_job_rate(50, 1, 0.5) == 100.0

@@ -51,6 +51,7 @@ struct BeSolveArgs {
     double* scale_l; double* diag_l; double* grad_l; double* gn_l;     // [nlm]
     int32_t* prior_col;     // [BE_MAX_STATE] prior index of each state column (-1 if absent)
     int32_t* col_kind; int32_t* col_frame; int32_t* col_comp;          // [n]
+    uint16_t ldl_col0[48]; int32_t ldl_wcol, ldl_pad;      // wave-column mapping of the LDL^T (be_ldl_pack): first thread of every block column; ldl_wcol = 0: generic mapping
     BeShard sh;             // landmark sharding (on = 0: the whole window lives here)
     double xnorm2_extra;    // squared norm of inert free blocks (line blocks under zero sqrt_info) that count in the parameter-tolerance test
 };
@@ -114,6 +115,7 @@ void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s);      // spec: reduce the candidate's set (or, after a failed / invalid step, rebuild x's with the new mu)
 int  be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s);        // spec: decide on the pending candidate first (be_accept_kernel's rule)
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);
+bool be_ldl_pack(int n, uint16_t* col0);
 void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s);   // after the exchange of a reduce: rank-ordered sums -> Hd / Sc / gvec, packet rows, candidate costs
 void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s);      // cost-only exchange: phase 0 packs the owned candidate costs, phase 1 scatters all of them
 void be_launch_proj_op(const BeFactor* fac, int n, const double* pose_i, const double* pose_j, const double* ex0, const double* ex1,

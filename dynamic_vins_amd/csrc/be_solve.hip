@@ -286,7 +286,7 @@ void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s) { hipL
 #define SOL_THREADS 1024
 #ifdef BE_SOLVE_TS
 __device__ long long be_dbg_ts[32];
-#define TS(k) do { if (threadIdx.x == 0) be_dbg_ts[k] = wall_clock64(); } while (0)
+#define TS(k) do { if (threadIdx.x == 0) { be_dbg_ts[k] = wall_clock64(); if ((k) == 4) be_dbg_ts[30] = clock64(); if ((k) == 5) be_dbg_ts[31] = clock64(); } } while (0)
 extern "C" int dv_debug_solve_ts(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(be_dbg_ts), sizeof(long long) * 32) == hipSuccess ? 0 : -1; }
 #else
 #define TS(k) do {} while (0)
@@ -510,6 +510,198 @@ __device__ __forceinline__ bool ldlt_blocked(const double* __restrict__ Sc, cons
     return true;
 }
 
+
+// The same factorisation (same arithmetic per entry, same results bit for bit) with the block columns mapped onto WAVES: every block column lives in
+// consecutive lanes of one wave (BeSolveArgs::ldl_col0, first-fit-decreasing packing done on the host), so the diagonal factor (a) reaches the panel
+// lanes (b) through v_readlane instead of LDS + a workgroup barrier, and the wave that owns column kb+1 runs (a) + (b) right behind its own trailing
+// update of step kb while the other waves are still in theirs (look-ahead; the panel buffers alternate).  ONE workgroup barrier per four pivots.
+#define WC_STR 48            // block rows per plane of the wave-column panel buffers (>= 45)
+#define WC_BUF (16 * WC_STR)  // double2 entries per buffer: 4 arrays x 4 columns x WC_STR
+struct LdlRaw { int bi, bj; double dv[4][4]; };
+__device__ __forceinline__ void ldl_prefetch(const BeSolveArgs& a, const double* __restrict__ Sc, int n, LdlRaw& R) {
+    const int tid = threadIdx.x, NBR = (n + 3) >> 2;
+    R.bi = -1; R.bj = -1;
+    for (int c0 = 0; c0 < NBR; ++c0) { const int t0 = a.ldl_col0[c0]; if (tid >= t0 && tid < t0 + NBR - c0) { R.bj = c0; R.bi = c0 + tid - t0; } }
+    const bool have = R.bi >= 0;
+    const int idx = have ? R.bj * NBR - R.bj * (R.bj - 1) / 2 + R.bi - R.bj : 0;      // blk_pos's block index
+    const double4* src = reinterpret_cast<const double4*>(Sc + (size_t)idx * 16);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { const double4 q = src[r]; R.dv[r][0] = q.x; R.dv[r][1] = q.y; R.dv[r][2] = q.z; R.dv[r][3] = q.w; }
+}
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {      // src_lane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw& R, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
+                                             double* Lm, double* P0, double* dinfo, double* zfin, double* dvec, int* s_fail) {
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int NBR = (n + 3) >> 2;
+    const int bi = R.bi, bj = R.bj;
+    const bool have = bi >= 0;
+    double A[4][4], zr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = bi * 4 + r;
+        const bool iok = have && i < n;
+        const double si = v_s[iok ? i : 0];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const int j = bj * 4 + cc;
+            const bool ok = iok && j < n;
+            double v = ok ? si * v_s[ok ? j : 0] * R.dv[r][cc] : 0.0;
+            if (i == j) v = ok ? v + mu * v_d[ok ? i : 0] * v_d[ok ? i : 0] : 1.0;      // padding rows: identity
+            A[r][cc] = v;
+        }
+        zr[r] = (iok && bi == bj) ? si * (gvec[i] - gvec[n + i]) : 0.0;
+    }
+    if (tid == 0) *s_fail = 0;
+    __syncthreads();
+    TS(4);
+    // (a) + (b) of block column kc by the wave that owns it; every lane of that wave takes part in the broadcast
+#ifdef BE_SOLVE_TS
+    long long pa = 0, pb = 0, pc = 0, pd_ = 0, pe = 0, tq = 0; bool ts_on = false;
+#define PTS(acc) do { if (ts_on) { acc = clock64(); } } while (0)
+#else
+#define PTS(acc) do {} while (0)
+#endif
+    auto panel = [&](int kc, int dl) {          // dl: lane of the column's diagonal block (wave-uniform)
+        const bool is_diag = bi == kc && bj == kc, is_panel = bj == kc && bi > kc;
+        double* di = dinfo + (kc & 1) * 16;
+        double2* PB = reinterpret_cast<double2*>(P0) + (kc & 1) * WC_BUF;      // [L rows 0-1 | L rows 2-3 | LD rows 0-1 | LD rows 2-3][m][block row]: 16-byte lane stride, conflict-free
+        // The diagonal block (and its share of the right-hand side) is broadcast FIRST and every lane of the wave runs the 4-pivot chain on it: the chain
+        // is latency-bound (one dependent fp64 op after the other), so the panel rows of the other lanes — computed in the same basic block, not behind a
+        // branch on the chain's result — fill its issue slots instead of following it.
+        const double d0 = lane_bcast(A[0][0], dl), a10 = lane_bcast(A[1][0], dl), a20 = lane_bcast(A[2][0], dl), a30 = lane_bcast(A[3][0], dl);
+        const double a11 = lane_bcast(A[1][1], dl), a21 = lane_bcast(A[2][1], dl), a31 = lane_bcast(A[3][1], dl);
+        const double a22 = lane_bcast(A[2][2], dl), a32 = lane_bcast(A[3][2], dl), a33 = lane_bcast(A[3][3], dl);
+        const double zz0 = lane_bcast(zr[0], dl), zz1 = lane_bcast(zr[1], dl), zz2 = lane_bcast(zr[2], dl), zz3 = lane_bcast(zr[3], dl);
+        PTS(pb);
+        const double i0 = fast_rcp(d0);
+        const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+        const double d1 = __builtin_fma(-l10, a10, a11), i1 = fast_rcp(d1);
+        const double t21 = __builtin_fma(-l20, a10, a21), t31 = __builtin_fma(-l30, a10, a31);
+        const double l21 = t21 * i1, l31 = t31 * i1;
+        const double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, a20, a22)), i2 = fast_rcp(d2);
+        const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, a20, a32));
+        const double l32 = t32 * i2;
+        const double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, a30, a33))), i3 = fast_rcp(d3);
+        const double z0 = zz0, z1 = __builtin_fma(-l10, z0, zz1);
+        const double z2 = __builtin_fma(-l21, z1, __builtin_fma(-l20, z0, zz2));
+        const double z3 = __builtin_fma(-l32, z2, __builtin_fma(-l31, z1, __builtin_fma(-l30, z0, zz3)));
+        double pv[4][4], xv[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double p0 = A[r][0];
+            const double p1 = __builtin_fma(-p0, l10, A[r][1]);
+            const double p2 = __builtin_fma(-p1, l21, __builtin_fma(-p0, l20, A[r][2]));
+            const double p3 = __builtin_fma(-p2, l32, __builtin_fma(-p1, l31, __builtin_fma(-p0, l30, A[r][3])));
+            pv[r][0] = p0; pv[r][1] = p1; pv[r][2] = p2; pv[r][3] = p3;
+            xv[r][0] = p0 * i0; xv[r][1] = p1 * i1; xv[r][2] = p2 * i2; xv[r][3] = p3 * i3;
+        }
+        PTS(pc);
+        if (is_panel) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                PB[(0 * 4 + m) * WC_STR + bi] = make_double2(xv[0][m], xv[1][m]);
+                PB[(1 * 4 + m) * WC_STR + bi] = make_double2(xv[2][m], xv[3][m]);
+                PB[(2 * 4 + m) * WC_STR + bi] = make_double2(pv[0][m], pv[1][m]);
+                PB[(3 * 4 + m) * WC_STR + bi] = make_double2(pv[2][m], pv[3][m]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { A[r][0] = xv[r][0]; A[r][1] = xv[r][1]; A[r][2] = xv[r][2]; A[r][3] = xv[r][3]; }
+        }
+        if (is_diag) {
+            if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0) || !isfinite(d0 + d1 + d2 + d3)) *s_fail = 1;
+            di[10] = z0; di[11] = z1; di[12] = z2; di[13] = z3;
+            const int r0 = kc * 4;
+            if (r0 < n) { dvec[r0] = d0; zfin[r0] = z0; }
+            if (r0 + 1 < n) { dvec[r0 + 1] = d1; zfin[r0 + 1] = z1; }
+            if (r0 + 2 < n) { dvec[r0 + 2] = d2; zfin[r0 + 2] = z2; }
+            if (r0 + 3 < n) { dvec[r0 + 3] = d3; zfin[r0 + 3] = z3; }
+            A[1][0] = l10; A[2][0] = l20; A[3][0] = l30; A[2][1] = l21; A[3][1] = l31; A[3][2] = l32;
+        }
+    };
+    // the wave that holds block column kc: the lanes with bj == kc, the diagonal block in the lowest of them (ldl_prefetch's mapping) — found by ballot, no table look-up on the critical path
+    { const unsigned long long cm = __ballot(bj == 0); if (cm) panel(0, __ffsll((long long)cm) - 1); }
+    __syncthreads();
+#ifdef BE_SOLVE_TS
+#endif
+#ifdef BE_SOLVE_TS
+    long long t_prev = wall_clock64(), acc_a = 0;
+#endif
+    for (int kb = 0; kb < NBR; ++kb) {
+        // (a non-positive pivot only raises s_fail: the loop runs on — on garbage — and the flag is read once behind it)
+        const double* di = dinfo + (kb & 1) * 16;
+        const unsigned long long cm = __ballot(bj == kb + 1);      // kb + 1 == NBR: no lane
+#ifdef BE_SOLVE_TS
+        if (cm != 0 && kb == 10) tq = clock64();
+#endif
+        const bool owner = cm != 0;                                 // this wave carries the critical path of the step: it goes first on its SIMD
+        if (owner) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_sleep(2);            // the owner's panel reads enter the LDS queue first (the others have slack until the owner's panel is done)
+        // ---- (c) trailing update with panel kb ----
+        if (bj > kb) {
+            const double2* PB = reinterpret_cast<const double2*>(P0) + (kb & 1) * WC_BUF;
+            double li[4][4];      // li[r][m] = L(4 bi + r, m);  the (L D)(4 bj + cc, m) operands are fetched two columns at a time (register budget: 128 at 1024 threads)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const double2 u0 = PB[(0 * 4 + m) * WC_STR + bi], u1 = PB[(1 * 4 + m) * WC_STR + bi];
+                li[0][m] = u0.x; li[1][m] = u0.y; li[2][m] = u1.x; li[3][m] = u1.y;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const double2 w0 = PB[((2 + half) * 4 + 0) * WC_STR + bj], w1 = PB[((2 + half) * 4 + 1) * WC_STR + bj];
+                const double2 w2 = PB[((2 + half) * 4 + 2) * WC_STR + bj], w3 = PB[((2 + half) * 4 + 3) * WC_STR + bj];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    A[r][2 * half] = __builtin_fma(-li[r][3], w3.x, __builtin_fma(-li[r][2], w2.x, __builtin_fma(-li[r][1], w1.x, __builtin_fma(-li[r][0], w0.x, A[r][2 * half]))));
+                    A[r][2 * half + 1] = __builtin_fma(-li[r][3], w3.y, __builtin_fma(-li[r][2], w2.y, __builtin_fma(-li[r][1], w1.y, __builtin_fma(-li[r][0], w0.y, A[r][2 * half + 1]))));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (bi == bj) {
+                const double y0 = di[10], y1 = di[11], y2 = di[12], y3 = di[13];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    zr[r] = __builtin_fma(-li[r][3], y3, __builtin_fma(-li[r][2], y2, __builtin_fma(-li[r][1], y1, __builtin_fma(-li[r][0], y0, zr[r]))));
+            }
+        }
+        // ---- look-ahead: (a) + (b) of block column kb + 1, inside its wave ----
+#ifdef BE_SOLVE_TS
+        ts_on = owner && kb == 10;
+        PTS(pa);
+#endif
+        if (owner) { panel(kb + 1, __ffsll((long long)cm) - 1); __builtin_amdgcn_s_setprio(0); }
+#ifdef BE_SOLVE_TS
+        PTS(pd_);
+#endif
+        __syncthreads();
+#ifdef BE_SOLVE_TS
+        PTS(pe);
+        if (ts_on && bi == kb + 1 && bj == kb + 1) { be_dbg_ts[24] = tq; be_dbg_ts[25] = pa; be_dbg_ts[26] = pb; be_dbg_ts[27] = pc; be_dbg_ts[28] = pd_; be_dbg_ts[29] = pe; }
+        ts_on = false;
+#endif
+#ifdef BE_SOLVE_TS
+        { long long t = wall_clock64(); acc_a += t - t_prev; t_prev = t; }
+#endif
+    }
+    TS(5);
+#ifdef BE_SOLVE_TS
+    if (tid == 0) { be_dbg_ts[16] = acc_a; be_dbg_ts[17] = 0; }
+#endif
+    if (*s_fail) return false;
+    if (have) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int i = bi * 4 + r, j = bj * 4 + cc;
+                if (i < n && j < i) Lm[tri(i, j)] = A[r][cc];
+            }
+    }
+    __syncthreads();
+    return true;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Two-level elimination of the reduced camera system (VIO windows).  The system has a dense 6 x nframes pose part and one 9-wide
@@ -786,7 +978,7 @@ __device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, doub
     else bs_chunk<2, ROWS>(Lm, kt, lane, x0, x1, x2);
 }
 
-template <int NSLOT>
+template <int NSLOT, bool WCOL>
 __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     BeCtl* ctl = a.ctl;
@@ -849,7 +1041,7 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
     double* q66 = dvec + n;                            // 66 (+6 pad): v_t gathered into packet (frame, comp) order
     double* red = q66 + 72;                            // 80: block-sum exchange (16 per value)
     double* misc = red + 80;                           // 8: [0] alpha
-    double* scratch = misc + 8;                        // 1536: gemv partial sums, aliased with the LDL^T panel buffers
+    double* scratch = misc + 8;                        // 3072: gemv partial sums, aliased with the LDL^T panel buffers (two alternating sets in the wave-column form)
     double* PL = scratch, *PD = scratch + 4 * 184;     // panel of L and of L D, [row][4]
     double* dinfo = red;                               // 2 x 16 (red[] is idle during the factorisation)
     __shared__ int s_fail;
@@ -890,6 +1082,11 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
     };
     const double* wd = scratch;
     TS(0);
+    LdlRaw ldl_raw;
+    // the blocks of the reduced system were written by other XCDs: touching this thread's 128-byte block now turns the loads of the factorisation (after the
+    // scaling phase) into local L2 hits.  Only one double stays live (the whole block would spill: 128 VGPRs at 1024 threads).
+    double ldl_warm = 0.0;
+    if (WCOL && !c.reuse) { const int nb = ((n + 3) >> 2) * (((n + 3) >> 2) + 1) / 2; ldl_warm = __builtin_nontemporal_load(a.Sc[c.cur] + (size_t)(tid < nb ? tid : 0) * 16); }
     if (!c.reuse) {
         // ---------------- scaling, diagonal, gradient ----------------
         for (int i = tid; i < n; i += SOL_THREADS) {
@@ -902,43 +1099,51 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
             a.diag_p[i] = d; a.grad_p[i] = v_grad[i];
         }
         __syncthreads();
-        if (c.first) {        // x_cost: fixed-order sum of the per-block costs at x
-            double part = 0;
-            for (int l = tid; l < nlm; l += SOL_THREADS) part += BE_PK(pk, BE_PK_COST, l);
-            for (int k = tid; k < a.dims.nimu; k += SOL_THREADS) part += imu_out[(size_t)k * IMU_OUT_STRIDE];
-            if (tid == 0) part += prior_out[0];
-            const double xc = block_sum(part, red);
-            if (tid == 0) { ctl->x_cost = xc; ctl->initial_cost = xc; }
-        }
-        // gradient tolerance (trust_region_minimizer.cc: gradient_max_norm <= gradient_tolerance = 1e-10), checked on every new gradient
-        {
-            double gm = 0;
-            for (int i = tid; i < n; i += SOL_THREADS) gm = fmax(gm, fabs(gvec[i]));
-            for (int l = tid; l < nlm; l += SOL_THREADS) gm = fmax(gm, fabs(BE_PK(pk, BE_PK_G, l)));
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
-            __syncthreads();
-            if ((tid & 63) == 0) red[tid >> 6] = gm;
-            __syncthreads();
-            gm = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) gm = fmax(gm, red[k]);
-            __syncthreads();
-            if (gm <= 1e-10) { if (tid == 0) { ctl->done = 1; ctl->termination = 1; ctl->first = 0; } return; }
-        }
-        TS(1);
-        // landmark part of the diagonal and of the scaled gradient (the Cauchy point itself is computed lazily, see below)
-        for (int l = tid; l < nlm; l += SOL_THREADS) {
-            const double h = BE_PK(pk, BE_PK_H, l), gl = BE_PK(pk, BE_PK_G, l), s = a.scale_l[l];
-            double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
-            const double d = sqrt(d2);
-            a.diag_l[l] = d; a.grad_l[l] = gl * s / d;
-        }
+        // cost at x, gradient tolerance and the landmark part of the diagonal: none of it feeds the factorisation, so the wave-column form runs it BEHIND the
+        // factorisation (the prefetched blocks need not stay in registers across three block reductions)
+        auto cost_and_tolerance = [&]() -> bool {
+            if (c.first) {        // x_cost: fixed-order sum of the per-block costs at x
+                double part = 0;
+                for (int l = tid; l < nlm; l += SOL_THREADS) part += BE_PK(pk, BE_PK_COST, l);
+                for (int k = tid; k < a.dims.nimu; k += SOL_THREADS) part += imu_out[(size_t)k * IMU_OUT_STRIDE];
+                if (tid == 0) part += prior_out[0];
+                const double xc = block_sum(part, red);
+                if (tid == 0) { ctl->x_cost = xc; ctl->initial_cost = xc; }
+            }
+            // gradient tolerance (trust_region_minimizer.cc: gradient_max_norm <= gradient_tolerance = 1e-10), checked on every new gradient
+            {
+                double gm = 0;
+                for (int i = tid; i < n; i += SOL_THREADS) gm = fmax(gm, fabs(gvec[i]));
+                for (int l = tid; l < nlm; l += SOL_THREADS) gm = fmax(gm, fabs(BE_PK(pk, BE_PK_G, l)));
+    #pragma unroll
+                for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
+                __syncthreads();
+                if ((tid & 63) == 0) red[tid >> 6] = gm;
+                __syncthreads();
+                gm = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) gm = fmax(gm, red[k]);
+                __syncthreads();
+                if (gm <= 1e-10) { if (tid == 0) { ctl->done = 1; ctl->termination = 1; ctl->first = 0; } return true; }
+            }
+            TS(1);
+            // landmark part of the diagonal and of the scaled gradient (the Cauchy point itself is computed lazily, see below)
+            for (int l = tid; l < nlm; l += SOL_THREADS) {
+                const double h = BE_PK(pk, BE_PK_H, l), gl = BE_PK(pk, BE_PK_G, l), s = a.scale_l[l];
+                double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
+                const double d = sqrt(d2);
+                a.diag_l[l] = d; a.grad_l[l] = gl * s / d;
+            }
+            return false;
+        };
+        if (!WCOL) { if (cost_and_tolerance()) return; }
         TS(3);
         // ---------------- Gauss-Newton step: LDL^T of the Schur complement ----------------
         const bool two_level = a.dims.pad != 0;            // VIO window with the block-tridiagonal speed-bias structure (decided on the host)
         double* LmUse = Lm; int nfact = n;
         bool ok_f;
         if (two_level) { if (tid == 0) s_fail = 0; __syncthreads(); ok_f = schur_sb_solve(a, a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, v_x, PL, PD, dinfo, zfin, dvec, &s_fail, &LmUse); nfact = 6 * a.dims.nframes; }
+        else if (WCOL) { if (ldl_warm == 1.2345e-300) misc[7] = ldl_warm; ldl_prefetch(a, a.Sc[c.cur], n, ldl_raw); ok_f = ldlt_wavecol(a, ldl_raw, gvec, n, mu, v_s, v_d, Lm, scratch, dinfo, zfin, dvec, &s_fail); }
         else ok_f = ldlt_blocked<NSLOT>(a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail);
+        if (WCOL) { if (cost_and_tolerance()) return; }
         if (!ok_f) {
             // Ceres: LINEAR_SOLVER_FAILURE -> mu *= 10 and retry (dogleg_strategy.cc ComputeGaussNewtonStep)
             if (tid == 0) {
@@ -1084,17 +1289,39 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
     }
 }
 
-static size_t solve_smem(int n, bool two_level = true) { const size_t tri = (size_t)n * (n + 1) / 2; return ((two_level && tri < FS_WORK ? (size_t)FS_WORK : tri) + 9 * (size_t)n + 72 + 80 + 8 + 1536) * sizeof(double); }
+static size_t solve_smem(int n, bool two_level, bool wcol) {
+    const size_t tri = (size_t)n * (n + 1) / 2;
+    return ((two_level && tri < FS_WORK ? (size_t)FS_WORK : tri) + 9 * (size_t)n + 72 + 80 + 8 + (wcol ? 3072 : 1536)) * sizeof(double);
+}
+
+// wave-column mapping of the factorisation (ldlt_wavecol): block column c (NBR - c blocks) goes to consecutive lanes of ONE wave; first-fit decreasing
+// over the 16 waves.  Returns false when the columns do not fit (n > 168): the generic mapping is used then.
+bool be_ldl_pack(int n, uint16_t* col0) {
+    const int NBR = (n + 3) / 4;
+    if (NBR > 48) return false;
+    int used[SOL_THREADS / 64] = { 0 };
+    for (int c = 0; c < NBR; ++c) {
+        const int len = NBR - c;
+        int w = 0;
+        while (w < SOL_THREADS / 64 && used[w] + len > 64) ++w;
+        if (w == SOL_THREADS / 64) return false;
+        col0[c] = (uint16_t)(w * 64 + used[w]);
+        used[w] += len;
+    }
+    return true;
+}
 
 int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
     static DevOnce once;
     if (once.run([] {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return 1;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE, true, false)) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE, true, false)) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(168, false, true)) != hipSuccess) return 1;
             return 0; })) return -1;
     const int nbr = (a.dims.nstate + 3) / 4;
-    if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL(be_solve_kernel<1>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, a.dims.pad != 0), s, a, spec);
-    else hipLaunchKernelGGL(be_solve_kernel<2>, dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false), s, a, spec);
+    if (a.ldl_wcol && !a.dims.pad) hipLaunchKernelGGL((be_solve_kernel<1, true>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, true), s, a, spec);
+    else if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL((be_solve_kernel<1, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, a.dims.pad != 0, false), s, a, spec);
+    else hipLaunchKernelGGL((be_solve_kernel<2, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, false), s, a, spec);
     return 0;
 }
 

@@ -101,7 +101,7 @@ struct BeWork {
     double* prior_c0 = nullptr;       // [2] the prior's constant c0 per buffer, device resident
     int32_t* marg_tab = nullptr; double* marg_scal = nullptr;      // marginalization index tables (inside the upload region) and its 4 result scalars
     long long marg_clamped = 0;       // marginalizations in which a pivot of A_mm was <= 1e-8 and was skipped (pseudo-inverse)
-    bool debug_short_first_pass = false, two_level = false;      // dv_debug_set
+    bool debug_short_first_pass = false, two_level = false, ldl_generic = false;      // dv_debug_set
     std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
 };
 

@@ -9,6 +9,8 @@ from dynamic_vins_amd import backend
 import ba_gen, oracle_py
 o = oracle_py.load()
 ctx = Context(width=640, height=480)
+if len(sys.argv) > 1 and sys.argv[1] == '2':
+    assert ctx.lib.dv_debug_set(ctx.h, b'two_level', 1) == 0
 P = ba_gen.make_window(o, seed=3, nlm=300, max_iters=1, with_prior=True)
 out = backend.ba_solve(ctx, P)
 print('iters', out.iterations, 'nstate?')
@@ -29,3 +31,11 @@ if t[20]:
     for a, b, name in [(3, 20, "fast: gather"), (20, 21, "fast: A1 chain (wave 0)"), (21, 22, "fast: A2 columns + stash"), (22, 23, "fast: A3/A4 pose update"), (23, 4, "fast: ldlt load (pose)"), (7, 24, "(back-sub end -> finish start)"), (24, 8, "fast: finish + gn landmarks")]:
         print(f"{name:32s} {(t[b] - t[a]) / 100.0:8.2f} us")
 print("ldlt (c)+(a) us", ts[16] / 100.0, " (b) us", ts[17] / 100.0)
+
+if t[31] and t[5] != t[4]:
+    print("shader clock during the LDL^T loop: %.0f MHz" % ((t[31] - t[30]) / ((t[5] - t[4]) / 100.0)))
+
+if t[25]:
+    names = ["(c) own update", "(a) diag factor", "readlane bcast", "(b) panel + LDS writes", "barrier wait"]
+    for k, nm in zip(range(25, 30), names):
+        print(f"  owner wave, block column 10: {nm:24s} {t[k] - t[k - 1]:8d} cycles")

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — stereo frames/sec through track + BA (BASELINE.json metric) on synthetic stereo + IMU.
 
-    python bench.py --gpus N --steps K --warmup W [--mode raw|dynamic] [--config zed|euroc|kitti] [--every-second-frame] [--shard]
+    python bench.py --gpus N --steps K --warmup W [--mode raw|dynamic] [--config zed|euroc|kitti] [--every-second-frame] [--shard] [--sequences S]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A step = one stereo frame through the HIP front end (FeatureTracker::TrackImage, or TrackSemanticImage + InstsFeatManager::InstsTrack in
@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="zed")
     ap.add_argument("--every-second-frame", action="store_true", help="the reference's convention outside KITTI: only every 2nd tracked frame gets BA (system/main.cpp:300-307)")
     ap.add_argument("--shard", action="store_true", help="BA-only: one window sharded by landmark over the ranks (reduced-system all-reduce)")
+    ap.add_argument("--sequences", type=int, default=1, help="S independent sequences per GPU interleaved by one host thread (aggregate rate; the default single-sequence line stays the headline)")
+    ap.add_argument("--sequence-threads", action="store_true", help="with --sequences: one host thread per sequence instead of one interleaving thread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16)
     ap.add_argument("--host-frames", action="store_true", help="frames handed over as host buffers: the PCIe-inclusive rate (never the headline value)")
@@ -74,6 +76,10 @@ def main():
     cfg = CONFIGS[args.config]
 
     import numpy as np
+    if args.sequences > 1:
+        # every sequence owns four HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and two streams that share a queue
+        # serialise — with the default, two sequences run at half speed each (measured).  Must be set before the runtime initialises.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
     import torch
 
     from dynamic_vins_amd import dist as dv_dist
@@ -89,6 +95,11 @@ def main():
 
     from dynamic_vins_amd import sim
 
+    if args.sequences > 1:
+        from dynamic_vins_amd.multiseq_bench import run_multiseq_bench
+        run_multiseq_bench(args, rank, world, local_rank)
+        dv_dist.barrier(); dv_dist.finalize()
+        return
     if args.shard:
         from dynamic_vins_amd.shard_bench import run_shard_bench
         run_shard_bench(args, rank, world, local_rank)

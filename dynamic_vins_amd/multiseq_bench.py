@@ -1,0 +1,86 @@
+"""bench.py --sequences S: S independent sequences on ONE GPU, driven by ONE host thread (SURVEY 8(d) config 4's "batched" form).
+
+The window solve of a single sequence is a chain of ~30 latency-bound launches that occupy a handful of the 256 CUs; the other sequences' chains run beside
+it on their own streams.  The host interleaves the sequences through the two-phase API (Pipeline.step_begin / step_end = dv_track_stereo_enqueue / _collect +
+dv_est_process_begin / _end): while sequence A's BA is in flight it prepares and enqueues B, C, ...  `value` is the AGGREGATE frame rate of the S sequences
+on this GPU (x N ranks for --gpus N); the single-sequence rate stays bench.py's default line."""
+import json
+import os
+import time
+
+import torch
+
+from . import dist as dv_dist
+
+
+def run_multiseq_bench(args, rank, world, local_rank):
+    from bench import CONFIGS, git_head
+    from . import sim
+    from .pipeline import Pipeline, SyntheticSequence
+    cfg = CONFIGS[args.config]
+    S = args.sequences
+    w, h = cfg["w"], cfg["h"]
+    warm_ba = max(args.warmup, 12)
+    n_frames = warm_ba + 2 * args.steps + 2
+    cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    dev = f"cuda:{local_rank}"
+    seqs = [SyntheticSequence(w, h, cam, n_frames, rate=20.0, phase=dv_dist.sequence_phase(rank * S + i), device=dev) for i in range(S)]
+    pipes = [Pipeline(q, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"]) for q in seqs]
+
+    threaded = bool(getattr(args, "sequence_threads", False))
+    import threading
+
+    def round_robin():
+        for p in pipes:
+            p.step_begin()
+        for p in pipes:
+            p.step_end()
+
+    def run_block(n_steps):
+        """n_steps frames of every sequence: interleaved on this thread, or (--sequence-threads) one host thread per sequence — the C ABI releases the GIL,
+        so the per-frame host work of the sequences (feature manager, problem assembly: ~0.5 ms) runs in parallel like the reference's per-process threads"""
+        if not threaded:
+            for _ in range(n_steps):
+                round_robin()
+            return
+
+        def worker(p):
+            for _ in range(n_steps):
+                p.step()
+        ths = [threading.Thread(target=worker, args=(p,)) for p in pipes]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+
+    run_block(warm_ba)
+    times = []
+    for _b in range(2):
+        dv_dist.barrier()
+        torch.cuda.synchronize()
+        for p in pipes:
+            p.ctx.sync()
+        t0 = time.perf_counter()
+        run_block(args.steps)
+        for p in pipes:
+            p.ctx.sync()
+        torch.cuda.synchronize()
+        dv_dist.barrier()
+        times.append(time.perf_counter() - t0)
+    red_dev = dev if os.environ.get("BENCH_BACKEND", "nccl") != "gloo" else "cpu"
+    times = [dv_dist.max_over_ranks(t, device=red_dev) for t in times]
+    ates = [p.ate() for p in pipes]
+    if rank == 0:
+        dt = times[0]
+        out = {"metric": "stereo frames/sec (track+BA)", "value": round(world * S * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm_ba,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{S} independent synthetic {w}x{h} stereo sequences per GPU @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "")
+                                      + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame; a step = one frame of EVERY sequence",
+                          "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S,
+                          "parallelism": f"{S} sequences per GPU " + ("on one host thread each" if threaded else "interleaved by one host thread") + f", own HIP streams, x {world} GPU(s); no collective",
+                          "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),
+                          "ate_rmse_m_vs_ground_truth_max": round(max(ates), 5)},
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out))
+    for p in pipes:
+        p.ctx.close()

@@ -60,7 +60,7 @@ class Pipeline:
             self.est.InputIMU(s.imu_t[j], s.imu_a[j], s.imu_g[j])
         self.k_imu = hi
 
-    def step(self):
+    def step(self, defer_end=False):
         """processes frame self.next through track + BA; returns the estimator state.
         Order (the reference's T2 / T3 overlap on one host thread): collect tracking of k -> begin BA of k (host prep +
         enqueue on the BA stream) -> enqueue tracking of k+1 and feed k+1's IMU samples while the GPU solves -> end BA of k."""
@@ -84,14 +84,34 @@ class Pipeline:
         if k + 1 < len(s.frames):
             self._enqueue(k + 1)                     # overlaps with the BA of frame k
             self._feed_imu(s.times[k + 1])
+        self.rows = rows
+        if defer_end:
+            self._pending_t = t
+            return None
+        return self._finish(t)
+
+    def _finish(self, t):
         st = self.est.ProcessMeasurementsEnd()
         if st.nonlinear:
             self.poses.append(self.est.window()[10, :7])
             self.pose_times.append(t)
         self.next += 1
-        self.rows = rows
         self.last_state = st
         return st
+
+    def step_begin(self):
+        """first half of step(): everything up to and including the enqueue of frame k's BA and of frame k+1's tracking.  With step_end() it lets ONE host
+        thread interleave several independent sequences on one GPU (each Pipeline owns its streams): while the BA of sequence A runs, the host prepares B."""
+        self._pending_t = None
+        st = self.step(defer_end=True)
+        self._early = st                              # tracked-only frame (ba_stride): already complete
+        return st
+
+    def step_end(self):
+        if self._pending_t is None:
+            return self._early
+        t, self._pending_t = self._pending_t, None
+        return self._finish(t)
 
     def ate(self):
         gt = [self.seq.traj.p(t) for t in self.pose_times]

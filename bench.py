@@ -48,6 +48,16 @@ def git_head():
         return None
 
 
+def csrc_digest():
+    """sha1 over the kernel sources: the PMC file (collected in separate rocprofv3 --pmc runs) is trusted only for the kernels it was collected on"""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "dynamic_vins_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dynamic_vins_amd", "csrc", "*.h"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -69,6 +79,7 @@ def main():
     ap.add_argument("--shard", action="store_true", help="BA-only: one window sharded by landmark over the ranks (reduced-system all-reduce)")
     ap.add_argument("--sequences", type=int, default=1, help="S independent sequences per GPU interleaved by one host thread (aggregate rate; the default single-sequence line stays the headline)")
     ap.add_argument("--sequence-threads", action="store_true", help="with --sequences: one host thread per sequence instead of one interleaving thread")
+    ap.add_argument("--debug-set", default="", help="comma-separated dv_debug_set keys to switch on in every context (A/B runs of kernel variants, e.g. ldl_generic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16)
     ap.add_argument("--host-frames", action="store_true", help="frames handed over as host buffers: the PCIe-inclusive rate (never the headline value)")
@@ -127,6 +138,8 @@ def main():
 
     def run(kernel_timing, collective=True, blocks=2):       # collective=False: rank-0-only pass, no barriers
         pipe = make_pipe()
+        for key in filter(None, args.debug_set.split(",")):
+            assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
         for _ in range(warm_ba * stride):
             pipe.step()
         if kernel_timing:
@@ -196,7 +209,7 @@ def main():
             hit = [v for k, v in pmc["kernels"].items() if key and k.startswith(key)]
             if hit:
                 traffic = int(hit[0]["traffic_bytes"])
-            stale = pmc.get("git_head") != git_head()
+            stale = pmc.get("csrc_digest") != csrc_digest()
         except (OSError, KeyError, ValueError):
             traffic = None
         # end-to-end figure with SURVEY 8(d)'s algorithmic bytes: front end 4.66 P + 12.7 kB N ; back end E F 112 B (fused into the Schur accumulation)

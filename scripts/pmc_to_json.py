@@ -13,7 +13,7 @@ def load(pat, name):
     for p in glob.glob(pat, recursive=True):
         for r in csv.DictReader(open(p)):
             if r["Counter_Name"] == name:
-                d[r["Kernel_Name"].split("(")[0]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+                d[r["Kernel_Name"].split("(")[0].replace("void ", "", 1)].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
     return d
 
 

@@ -518,16 +518,26 @@ __device__ __forceinline__ bool ldlt_blocked(const double* __restrict__ Sc, cons
 #define WC_STR 48            // block rows per plane of the wave-column panel buffers (>= 45)
 #define WC_BUF (16 * WC_STR)  // double2 entries per buffer: 4 arrays x 4 columns x WC_STR
 struct LdlRaw { int bi, bj; double dv[4][4]; };
-__device__ __forceinline__ void ldl_prefetch(const BeSolveArgs& a, const double* __restrict__ Sc, int n, LdlRaw& R) {
+// thread -> (bi, bj): thread c < NBR walks block column c and writes the block coordinates of its lanes into an LDS table (`map`, 1024 ints) that every
+// thread then reads once — the 42 dependent kernel-argument loads of a per-thread search were ≈ 3 µs of the kernel's prologue
+__device__ __forceinline__ void ldl_build_map(const BeSolveArgs& a, int n, int* map) {
     const int tid = threadIdx.x, NBR = (n + 3) >> 2;
-    R.bi = -1; R.bj = -1;
-    for (int c0 = 0; c0 < NBR; ++c0) { const int t0 = a.ldl_col0[c0]; if (tid >= t0 && tid < t0 + NBR - c0) { R.bj = c0; R.bi = c0 + tid - t0; } }
-    const bool have = R.bi >= 0;
+    map[tid] = -1;
+    __syncthreads();
+    if (tid < NBR) { const int t0 = a.ldl_col0[tid]; for (int k = 0; k < NBR - tid; ++k) map[t0 + k] = ((tid + k) << 8) | tid; }
+    __syncthreads();
+}
+__device__ __forceinline__ void ldl_prefetch(const int* map, const double* __restrict__ Sc, int n, LdlRaw& R) {
+    const int NBR = (n + 3) >> 2;
+    const int m = map[threadIdx.x];
+    R.bi = m < 0 ? -1 : (m >> 8); R.bj = m < 0 ? -1 : (m & 255);
+    const bool have = m >= 0;
     const int idx = have ? R.bj * NBR - R.bj * (R.bj - 1) / 2 + R.bi - R.bj : 0;      // blk_pos's block index
     const double4* src = reinterpret_cast<const double4*>(Sc + (size_t)idx * 16);
 #pragma unroll
     for (int r = 0; r < 4; ++r) { const double4 q = src[r]; R.dv[r][0] = q.x; R.dv[r][1] = q.y; R.dv[r][2] = q.z; R.dv[r][3] = q.w; }
 }
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ double lane_bcast(double v, int src_lane) {      // src_lane wave-uniform
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
@@ -571,10 +581,14 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
         // The diagonal block (and its share of the right-hand side) is broadcast FIRST and every lane of the wave runs the 4-pivot chain on it: the chain
         // is latency-bound (one dependent fp64 op after the other), so the panel rows of the other lanes — computed in the same basic block, not behind a
         // branch on the chain's result — fill its issue slots instead of following it.
-        const double d0 = lane_bcast(A[0][0], dl), a10 = lane_bcast(A[1][0], dl), a20 = lane_bcast(A[2][0], dl), a30 = lane_bcast(A[3][0], dl);
-        const double a11 = lane_bcast(A[1][1], dl), a21 = lane_bcast(A[2][1], dl), a31 = lane_bcast(A[3][1], dl);
-        const double a22 = lane_bcast(A[2][2], dl), a32 = lane_bcast(A[3][2], dl), a33 = lane_bcast(A[3][3], dl);
-        const double zz0 = lane_bcast(zr[0], dl), zz1 = lane_bcast(zr[1], dl), zz2 = lane_bcast(zr[2], dl), zz3 = lane_bcast(zr[3], dl);
+        // (through LDS: ten stores by the diagonal lane, ten broadcast loads by the wave — 63 v_readlane / SGPR->VGPR moves in the owner's instruction
+        // stream otherwise; LDS operations of one wave execute in order, so a wave-level fence is all the synchronisation needed.  The right-hand side
+        // is not broadcast: every lane runs the forward substitution on its own zr, only the diagonal lane's result is used.)
+        (void)dl;
+        if (is_diag) { di[0] = A[0][0]; di[1] = A[1][0]; di[2] = A[2][0]; di[3] = A[3][0]; di[4] = A[1][1]; di[5] = A[2][1]; di[6] = A[3][1]; di[7] = A[2][2]; di[8] = A[3][2]; di[9] = A[3][3]; }
+        wave_lds_sync();
+        const double d0 = di[0], a10 = di[1], a20 = di[2], a30 = di[3], a11 = di[4], a21 = di[5], a31 = di[6], a22 = di[7], a32 = di[8], a33 = di[9];
+        const double zz0 = zr[0], zz1 = zr[1], zz2 = zr[2], zz3 = zr[3];
         PTS(pb);
         const double i0 = fast_rcp(d0);
         const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
@@ -716,7 +730,6 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
 // The arithmetic is an exact block LDL^T of the symmetrically permuted matrix: same solution, other rounding.
 #define FS_ES 67              // row stride of E / X: 66 pose columns + the right-hand side
 #define FS_WORK 16000         // doubles of LDS the two-level path carves (99 x 67 + 54 x 67 + 153 x 16 + 3 x 891 + small, see schur_sb_solve)
-__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
 struct FastSb {
     double *E, *X, *Spp, *Binv, *T, *C, *rhs2, *ones, *zer, *W, *xb; int np, nsb, pb[BE_NF], sbc[BE_NF], pc[BE_NF];
@@ -1141,7 +1154,7 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
         double* LmUse = Lm; int nfact = n;
         bool ok_f;
         if (two_level) { if (tid == 0) s_fail = 0; __syncthreads(); ok_f = schur_sb_solve(a, a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, v_x, PL, PD, dinfo, zfin, dvec, &s_fail, &LmUse); nfact = 6 * a.dims.nframes; }
-        else if (WCOL) { if (ldl_warm == 1.2345e-300) misc[7] = ldl_warm; ldl_prefetch(a, a.Sc[c.cur], n, ldl_raw); ok_f = ldlt_wavecol(a, ldl_raw, gvec, n, mu, v_s, v_d, Lm, scratch, dinfo, zfin, dvec, &s_fail); }
+        else if (WCOL) { if (ldl_warm == 1.2345e-300) misc[7] = ldl_warm; ldl_build_map(a, n, reinterpret_cast<int*>(scratch)); ldl_prefetch(reinterpret_cast<const int*>(scratch), a.Sc[c.cur], n, ldl_raw); __syncthreads(); ok_f = ldlt_wavecol(a, ldl_raw, gvec, n, mu, v_s, v_d, Lm, scratch, dinfo, zfin, dvec, &s_fail); }
         else ok_f = ldlt_blocked<NSLOT>(a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail);
         if (WCOL) { if (cost_and_tolerance()) return; }
         if (!ok_f) {

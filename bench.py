@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--shard", action="store_true", help="BA-only: one window sharded by landmark over the ranks (reduced-system all-reduce)")
     ap.add_argument("--sequences", type=int, default=1, help="S independent sequences per GPU interleaved by one host thread (aggregate rate; the default single-sequence line stays the headline)")
     ap.add_argument("--sequence-threads", action="store_true", help="with --sequences: one host thread per sequence instead of one interleaving thread")
+    ap.add_argument("--blocks", type=int, default=2, help="consecutive timed blocks of --steps frames (the first is `value`; all are listed in config.block_values)")
     ap.add_argument("--debug-set", default="", help="comma-separated dv_debug_set keys to switch on in every context (A/B runs of kernel variants, e.g. ldl_generic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16)
@@ -122,7 +123,7 @@ def main():
     w, h = cfg["w"], cfg["h"]
     stride = 2 if args.every_second_frame else 1
     warm_ba = max(args.warmup, 12)            # the estimator needs kWinSize+1 = 11 BA frames to initialise (estimator.cpp:1464-1483)
-    n_frames = (warm_ba + 2 * args.steps) * stride + 2
+    n_frames = (warm_ba + max(2, args.blocks) * args.steps) * stride + 2
     cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
     dev = f"cuda:{local_rank}"
     if args.mode == "dynamic":
@@ -160,7 +161,7 @@ def main():
             times.append(time.perf_counter() - t0)
         return pipe, times, iters
 
-    pipe, times, iters = run(False)
+    pipe, times, iters = run(False, blocks=max(2, args.blocks))
     red_dev = dev if os.environ.get("BENCH_BACKEND", "nccl") != "gloo" else "cpu"
     times = [dv_dist.max_over_ranks(t, device=red_dev) for t in times]
     dt = times[0]                            # the contract: EXACTLY K timed steps -> the first block is the reported one
@@ -300,9 +301,10 @@ def main():
                                else "BA + marginalization on every frame"),
                 "mode": args.mode, "config": args.config,
                 "parallelism": f"replicas x{world} (independent sequences, no collective)", "landmarks_in_window": n_lm, "features_per_frame": nfeat,
-                "solver_iterations_per_frame": round(iters / (2 * args.steps), 2), "ate_rmse_m_vs_ground_truth": round(ate, 5),
+                "solver_iterations_per_frame": round(iters / (len(times) * args.steps), 2), "ate_rmse_m_vs_ground_truth": round(ate, 5),
                 "ate_rmse_m_vs_oracle": None if ate_vs_oracle is None else float(f"{ate_vs_oracle:.3e}"),
                 "second_block_ms_per_step": round(times[1] / args.steps * 1e3, 4), "second_block_value": round(dv_dist.whole_job_rate(args.steps, world, times[1]), 2),
+                "block_values": [round(dv_dist.whole_job_rate(args.steps, world, t), 2) for t in times],
                 "warmup_requested": args.warmup, "git_head": git_head(),
                 "warmup_note": "at least 12 untimed BA frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"}
         if dyn_info:

@@ -17,15 +17,17 @@ NOISE = dict(acc_n=0.02, gyr_n=0.002, acc_w=2e-4, gyr_w=2e-5)
 INT_FIELDS = ["id", "is_initial", "is_tracking", "is_curr_visible", "is_static", "is_init_velocity", "age", "lost_number", "static_frame", "n_landmarks", "n_valid", "triangle_num"]
 
 
-def run_dynamic(gpu_ctx_factory, oracle, frames, use_imu=1, use_det3d=1, two_phase=False, drop_frames=(), plane=0, seed=3):
+def run_dynamic(gpu_ctx_factory, oracle, frames, use_imu=1, use_det3d=1, two_phase=False, drop_frames=(), plane=0, seed=3, use_line=0):
     from dynamic_vins_amd.backend import Estimator
     ctx = gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5)
     traj, cam = sim.Trajectory(), sim.EUROC
     fs = sim.FeatureSim(traj, cam, 752, 480, sim.room_points(3000), max_cnt=150, pix_sigma=0.3, seed=seed)
     isim = dynsim.InstSim(traj, cam, 752, 480, with_det3d=bool(use_det3d))
     kw = dict(use_imu=use_imu, stereo=1, max_iters=8, plane_constraint=plane, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], dynamic=1, use_det3d=use_det3d,
-              instance_init_min_num=4, static_inst_threshold=1.0, **NOISE)
+              instance_init_min_num=4, static_inst_threshold=1.0, use_line=use_line, **NOISE)
     ref, dev = oracle.estimator(**kw), Estimator(ctx, **kw)
+    ls = sim.LineSim(traj, 752, 480, n=80) if use_line else None
+    from dynamic_vins_amd.backend import LINELM_DTYPE
     T0, dtf = 1.0, 0.1
     ts, acc, gyr = sim.imu_stream(traj, T0 - 0.05, T0 + frames * dtf + 0.2, 200.0, **NOISE)
     k = 0
@@ -37,6 +39,9 @@ def run_dynamic(gpu_ctx_factory, oracle, frames, use_imu=1, use_det3d=1, two_pha
             ref.input_imu(ts[k], acc[k], gyr[k]); dev.InputIMU(ts[k], acc[k], gyr[k]); k += 1
         rows = fs.frame(t)
         insts, ifeats, pts = isim.frame(t, visible=set() if f in drop_frames else None)
+        if ls is not None:
+            lrows = ls.frame(t)
+            ref.set_lines(lrows); dev.SetLines(lrows)
         rc_o, so = ref.process_dynamic(rows, t, insts, ifeats, pts)
         if two_phase:
             rc_d = dev.ProcessMeasurementsDynamicBegin(rows, t, insts, ifeats, pts)
@@ -46,6 +51,10 @@ def run_dynamic(gpu_ctx_factory, oracle, frames, use_imu=1, use_det3d=1, two_pha
         assert rc_o == rc_d == 0
         assert (sd.frame, sd.nonlinear, sd.margin_old, sd.n_landmarks, sd.n_long, sd.iterations) == (so.frame, so.nonlinear, so.margin_old, so.n_landmarks, so.n_long, so.iterations), f"frame {f}"
         worst["ego"] = max(worst["ego"], np.abs(ref.window()[:, :3] - dev.window()[:, :3]).max())
+        if ls is not None:
+            Lo, Ld = ref.lines(LINELM_DTYPE), dev.lines()
+            assert len(Lo) == len(Ld) and all(np.array_equal(Lo[k], Ld[k]) for k in ("id", "start_frame", "n_obs", "is_triangulation")), f"frame {f}: line landmarks"
+            seen["lines"] = max(seen.get("lines", 0), int(Lo["is_triangulation"].sum()))
         Io, So = ref.instances(dynsim.INSTSTATE_DTYPE)
         Id, Sd = dev.instances()
         assert len(Io) == len(Id), f"frame {f}"
@@ -101,3 +110,11 @@ def test_raw_calls_on_a_dynamic_estimator_and_errors(gpu_ctx_factory, oracle):
     est = Estimator(ctx, use_imu=0, stereo=1, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], dynamic=0)
     with pytest.raises(DvinsError):
         est.ProcessMeasurementsDynamic(np.zeros(0, sim.FEAT_DTYPE), 1.0, np.zeros(0, dynsim.INSTOBS_DTYPE), np.zeros(0, sim.FEAT_DTYPE), np.zeros((0, 3)))
+
+
+def test_line_point_dynamic_config(gpu_ctx_factory, oracle):
+    """config 5 of BASELINE.json (ZED "LinePoint + dynamic"): use_line and dynamic mode in the same estimator — line landmarks, the line-only refinement and
+    the zero-weight line blocks run beside the object branch; everything test_dynamic_estimator_tracks_oracle checks, plus identical line landmark tables"""
+    worst, seen = run_dynamic(gpu_ctx_factory, oracle, 45, use_line=1)
+    check(worst)
+    assert seen["initial"] > 0 and seen["solved"] > 5 and seen["lines"] >= 5, seen

@@ -38,10 +38,22 @@ REF_ATE = "/root/reference/dynamic_vins/scripts/tum_tools/evaluate_ate.py"
 def gen_ate():
     src = open(REF_ATE).read()
     fn = re.search(r"^def align\(.*?(?=^def )", src, flags=re.S | re.M).group(0)
-    ns = {"numpy": np}
+    # the function text comes from the untrusted reference tree: it is compiled only after its AST has been checked to be one function definition that
+    # calls nothing but numpy attributes and a few arithmetic builtins, and it runs with an empty __builtins__ (no import, open, eval ...)
+    import ast
+    tree = ast.parse(fn)
+    assert len(tree.body) == 1 and isinstance(tree.body[0], ast.FunctionDef) and tree.body[0].name == "align"
+    for node in ast.walk(tree):
+        assert not isinstance(node, (ast.Import, ast.ImportFrom, ast.Global, ast.Nonlocal, ast.Lambda, ast.ClassDef, ast.With, ast.Try)), type(node).__name__
+        if isinstance(node, ast.Attribute):
+            assert not node.attr.startswith("_"), node.attr
+        if isinstance(node, ast.Name):
+            assert node.id in {"numpy", "align", "model", "data", "model_zerocentered", "data_zerocentered", "W", "U", "d", "Vh", "S", "rot", "trans", "model_aligned",
+                               "alignment_error", "trans_error", "column", "range", "sum"} or not node.id.startswith("_"), node.id
+    ns = {"numpy": np, "__builtins__": {"range": range, "sum": sum}}
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        exec(fn, ns)
+        exec(compile(tree, "<reference align()>", "exec"), ns)
         rng = np.random.default_rng(0xA7E)
         model, data, rot, trans, rmse = [], [], [], [], []
         for case in range(8):

@@ -246,9 +246,13 @@ __global__ __launch_bounds__(SEL_THREADS) void gftt_select_kernel(GfttSelectArgs
         if (s_done) break;
         const int hi = s_hi;
         {
+            // Chunk size follows the demand: the greedy loop stops after max_n acceptances, which usually needs a few hundred of the strongest candidates, not
+            // the 8192 a chunk can hold — and the bitonic sort below costs log^2 of the chunk.  Target 16 candidates per corner still wanted (at least 512);
+            // the top bin is always taken whole (an error only if it alone exceeds the LDS capacity); further chunks follow if the target was too small.
             const int above = hist[hi + 1];
+            const int target = min(SEL_CAP, max(512, 16 * (max_n - s_acc)));
             for (int b = tid; b <= hi; b += SEL_THREADS)
-                if (hist[b] - above <= SEL_CAP) atomicMin(&s_lo, b);
+                if (hist[b] - above <= target) atomicMin(&s_lo, b);
             if (tid == 0 && hist[hi] - above > SEL_CAP && a.err_flag) atomicOr(a.err_flag, 4);   // one bin overflows a chunk
         }
         __syncthreads();

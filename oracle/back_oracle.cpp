@@ -1109,6 +1109,18 @@ dvo_estimator* dvo_estimator_create(const dvo_be_config* c) {
     cfg.use_line = c->use_line; cfg.line_min_obs = c->line_min_obs; for (int k = 0; k < 4; ++k) cfg.line_sqrt_info[k] = c->line_sqrt_info[k];
     return new dvo_estimator{ new Estimator(cfg) };
 }
+/* FitBox3DWithRANSAC / FitBox3DFromCameraFrame (vio_util.cpp:209-332) on a flat point list: exported so that the product's host-side restatement
+ * (csrc/inst_host.h) can be unit-tested on the CPU against this one */
+int dvo_fit_box_ransac(const double* pts, int n, const double* dims3, unsigned long long seed, double* out3) {
+    std::vector<V3> p(n); for (int i = 0; i < n; ++i) p[i] = V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    V3 c; const bool ok = oim::FitBox3DWithRANSAC(p, V3(dims3[0], dims3[1], dims3[2]), seed, c);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z; return ok ? 1 : 0;
+}
+int dvo_fit_box_camera(const double* pts, int n, const double* dims3, double* out3) {
+    std::vector<V3> p(n); for (int i = 0; i < n; ++i) p[i] = V3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    V3 c; const bool ok = oim::FitBox3DFromCameraFrame(p, V3(dims3[0], dims3[1], dims3[2]), c);
+    out3[0] = c.x; out3[1] = c.y; out3[2] = c.z; return ok ? 1 : 0;
+}
 int dvo_estimator_set_lines(dvo_estimator* e, const dvo_line_row* lines, int n) { e->e->pending_lines.assign(lines, lines + n); return 0; }
 int dvo_estimator_get_lines(dvo_estimator* e, dvo_line_landmark* out, int cap, int* n_out) {
     int k = 0;

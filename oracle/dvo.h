@@ -234,6 +234,8 @@ int dvo_insts_output(dvo_insts*, dvo_inst_obs* insts, int cap_insts, int* n_inst
 /* ProcessImage with the object branch (estimator.cpp:1562-1622,1653-1676); see inst_manager.h */
 int dvo_estimator_process_dynamic(dvo_estimator*, const dvo_feat* feats, int n, double t, const dvo_inst_obs* insts, int n_insts, const dvo_feat* inst_feats,
                                   const double* points, dvo_be_state* out);
+int dvo_fit_box_ransac(const double* pts, int n, const double* dims3, unsigned long long seed, double* out3);      /* vio_util.cpp:209-264, seeded (inst_manager.h) */
+int dvo_fit_box_camera(const double* pts, int n, const double* dims3, double* out3);                                /* vio_util.cpp:274-332 */
 int dvo_estimator_set_lines(dvo_estimator* e, const dvo_line_row* lines, int n);      /* frame.features.lines of the next process call */
 int dvo_estimator_get_lines(dvo_estimator* e, dvo_line_landmark* out, int cap, int* n_out);
 int dvo_estimator_get_instances(dvo_estimator*, dvo_inst_state* out, int cap, int* n_out, double* summary4);

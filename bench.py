@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--sequence-threads", action="store_true", help="with --sequences: one host thread per sequence instead of one interleaving thread")
     ap.add_argument("--blocks", type=int, default=2, help="consecutive timed blocks of --steps frames (the first is `value`; all are listed in config.block_values)")
     ap.add_argument("--timing-block", type=int, default=1, help="which block the instrumented (per-kernel HIP events) pass times")
+    ap.add_argument("--objects", type=int, default=3, help="--mode dynamic: number of moving boxes in the scene (dynsim.ring_boxes)")
     ap.add_argument("--debug-set", default="", help="comma-separated dv_debug_set keys to switch on in every context (A/B runs of kernel variants, e.g. ldl_generic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16)
@@ -128,7 +129,8 @@ def main():
     cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
     dev = f"cuda:{local_rank}"
     if args.mode == "dynamic":
-        seq = DynamicSequence(w, h, cam, n_frames, rate=20.0, device=dev)
+        from dynamic_vins_amd import dynsim
+        seq = DynamicSequence(w, h, cam, n_frames, rate=20.0, device=dev, boxes=None if args.objects == 3 else dynsim.ring_boxes(args.objects))
     else:
         seq = SyntheticSequence(w, h, cam, n_frames, rate=20.0, phase=dv_dist.sequence_phase(rank), device=dev)
 

@@ -310,7 +310,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     d.nstate = col;
     // two-level elimination in be_solve (speed-bias chain first, then the dense pose block): needs every frame to carry a free pose and a speed-bias
     // block, the speed-bias coupling to be block tridiagonal (IMU factors between neighbours; the prior holding speed-bias blocks of at most two
-    // adjacent frames) and the packed triangle to fit one block per thread.  Off by default (measured slower than the monolithic panel factorisation in its first form); dv_debug_set(ctx, "two_level", 1) selects it.
+    // adjacent frames) and the wave-column factorisation to be available for the dense pose block (confirmed below).  Off by default (measured: 91 us against 67 us for the monolithic wave-column factorisation); dv_debug_set(ctx, "two_level", 1) selects it.
     d.pad = 0;
     if (P->use_imu && P->nframes >= 2 && ctx->be.two_level) {
         bool ok = true;
@@ -407,6 +407,8 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;
     sa.xnorm2_extra = P->x_norm2_extra; sa.sh = sh;
     sa.ldl_wcol = (!w.ldl_generic && d.nstate <= 168 && be_ldl_pack(d.nstate, sa.ldl_col0)) ? 1 : 0;
+    // two-level elimination (speed-bias chain first) needs the wave-column factorisation for its dense pose block
+    if (sa.dims.pad && !(sa.ldl_wcol && be_ldl_pack(6 * P->nframes, sa.ldl_col0p))) { sa.dims.pad = 0; ea.dims.pad = 0; }
     // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
     // invalid; be_solve_fused_end checks the downloaded control block and, in that rare case, runs the spare slots and the
     // (idempotent) tail again.

@@ -51,7 +51,7 @@ struct BeSolveArgs {
     double* scale_l; double* diag_l; double* grad_l; double* gn_l;     // [nlm]
     int32_t* prior_col;     // [BE_MAX_STATE] prior index of each state column (-1 if absent)
     int32_t* col_kind; int32_t* col_frame; int32_t* col_comp;          // [n]
-    uint16_t ldl_col0[48]; int32_t ldl_wcol, ldl_pad;      // wave-column mapping of the LDL^T (be_ldl_pack): first thread of every block column; ldl_wcol = 0: generic mapping
+    uint16_t ldl_col0[48]; uint16_t ldl_col0p[20]; int32_t ldl_wcol, ldl_pad;      // wave-column mapping of the LDL^T (be_ldl_pack): first thread of every block column; ldl_col0p: the same for the reduced 6F x 6F pose system of the two-level path; ldl_wcol = 0: generic mapping
     BeShard sh;             // landmark sharding (on = 0: the whole window lives here)
     double xnorm2_extra;    // squared norm of inert free blocks (line blocks under zero sqrt_info) that count in the parameter-tolerance test
 };

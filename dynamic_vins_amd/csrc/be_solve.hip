@@ -520,11 +520,11 @@ __device__ __forceinline__ bool ldlt_blocked(const double* __restrict__ Sc, cons
 struct LdlRaw { int bi, bj; double dv[4][4]; };
 // thread -> (bi, bj): thread c < NBR walks block column c and writes the block coordinates of its lanes into an LDS table (`map`, 1024 ints) that every
 // thread then reads once — the 42 dependent kernel-argument loads of a per-thread search were ≈ 3 µs of the kernel's prologue
-__device__ __forceinline__ void ldl_build_map(const BeSolveArgs& a, int n, int* map) {
+__device__ __forceinline__ void ldl_build_map(const uint16_t* col0, int n, int* map) {
     const int tid = threadIdx.x, NBR = (n + 3) >> 2;
     map[tid] = -1;
     __syncthreads();
-    if (tid < NBR) { const int t0 = a.ldl_col0[tid]; for (int k = 0; k < NBR - tid; ++k) map[t0 + k] = ((tid + k) << 8) | tid; }
+    if (tid < NBR) { const int t0 = col0[tid]; for (int k = 0; k < NBR - tid; ++k) map[t0 + k] = ((tid + k) << 8) | tid; }
     __syncthreads();
 }
 __device__ __forceinline__ void ldl_prefetch(const int* map, const double* __restrict__ Sc, int n, LdlRaw& R) {
@@ -542,13 +542,29 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {      // s
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
     return __hiloint2double(hi, lo);
 }
+// pre != nullptr: the system (already scaled and damped) is taken from LDS — pre = packed lower triangle (row-major), pre_rhs = right-hand side — instead
+// of the block-packed global Schur complement: the reduced pose system the speed-bias sweep leaves behind.  Lm may alias pre (it is written at the end).
 __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw& R, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
-                                             double* Lm, double* P0, double* dinfo, double* zfin, double* dvec, int* s_fail) {
+                                             double* Lm, double* P0, double* dinfo, double* zfin, double* dvec, int* s_fail, const double* pre = nullptr, const double* pre_rhs = nullptr) {
     const int tid = threadIdx.x, wave = tid >> 6;
     const int NBR = (n + 3) >> 2;
     const int bi = R.bi, bj = R.bj;
     const bool have = bi >= 0;
     double A[4][4], zr[4];
+    if (pre) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = bi * 4 + r;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int j = bj * 4 + cc;
+                const bool ok = have && i < n && j < n;
+                const int hi = i > j ? i : j, lo = i > j ? j : i;
+                A[r][cc] = ok ? pre[tri(ok ? hi : 0, ok ? lo : 0)] : (i == j ? 1.0 : 0.0);
+            }
+            zr[r] = (have && bi == bj && i < n) ? pre_rhs[i] : 0.0;
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = bi * 4 + r;
@@ -718,244 +734,186 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Two-level elimination of the reduced camera system (VIO windows).  The system has a dense 6 x nframes pose part and one 9-wide
-// speed-bias block per frame; the speed-bias blocks only couple along the IMU chain (sb_f -- sb_f+1; the prior holds one speed-bias
-// block), i.e. S_bb is block tridiagonal.  Eliminating them first by a block-Thomas sweep
-//     B'_f = B_f - C_f-1^T B'_f-1^-1 C_f-1 ,   [E'_f | g'_f] = [E_f | g_f] - C_f-1^T B'_f-1^-1 [E'_f-1 | g'_f-1]
-// (E_f = the block row of sb_f against ALL pose columns, dense after fill-in) leaves  S'_pp = A_pp - sum_f E'_f^T B'_f^-1 E'_f , a 66 x 66
-// system for the panel LDL^T above: 99 of the 165 sequential pivots of the monolithic factorisation are replaced by
-//   (A1) ONE wave walking the 9 x 9 chain (Gauss-Jordan inverses in LDS, wave-ordered, no workgroup barrier),
-//   (A2) one thread per pose column carrying its 9-vector down the chain in registers,
-//   (A3/A4) two wide passes for the rank-99 update of the pose block.
-// The arithmetic is an exact block LDL^T of the symmetrically permuted matrix: same solution, other rounding.
-#define FS_ES 67              // row stride of E / X: 66 pose columns + the right-hand side
-#define FS_WORK 16000         // doubles of LDS the two-level path carves (99 x 67 + 54 x 67 + 153 x 16 + 3 x 891 + small, see schur_sb_solve)
-
-struct FastSb {
-    double *E, *X, *Spp, *Binv, *T, *C, *rhs2, *ones, *zer, *W, *xb; int np, nsb, pb[BE_NF], sbc[BE_NF], pc[BE_NF];
-};
-
-// scaled + damped entry (i, j) of the Schur complement, from the block-packed lower triangle
-__device__ __forceinline__ double fs_entry(const double* Sc, int NBR, int i, int j, double mu, const double* v_s, const double* v_d) {
+// Two-level elimination of the reduced camera system (VIO windows whose speed-bias blocks couple only along the IMU chain: BeDims::pad, checked on the host).
+// Order: speed-bias block of frame 0, 1, ..., F-1, then the dense 6F x 6F pose block.  Eliminating sb_f touches only its chain neighbour sb_f+1 and the
+// poses, so the 9F speed-bias pivots — 99 of the 165 sequential pivots of the monolithic factorisation — become F block steps:
+//   per step: 9 x 9 LDL^T of the block (two waves, each in its own LDS scratch), panel rows  X = R L^-T D^-1  for R = [C_f ; E_f ; rhs_f] (76 lanes),
+//   ONE barrier, rank-9 update of everything R touches (pose x pose triangle, E_f+1, B_f+1, right-hand sides: ~3 entries per thread, 9 FMAs each),
+//   ONE barrier.
+// What remains is the reduced pose system, factored by ldlt_wavecol (17 block columns instead of 42); the solution of the speed-bias blocks follows from
+// the stored panels by a backward sweep on one wave.  Exact block LDL^T of the symmetrically permuted matrix: same solution, other rounding.
+#define FS_WORK 14000         // doubles of LDS the sweep carves (sw_carve); >= the packed factor of the 66 x 66 pose system
+#define SWS 10                // row stride of the 9-wide panels (16-byte aligned rows: ds_read_b128 pairs)
+struct SbSweep { double *PP, *E, *Bq, *C, *rb, *rp, *Lf, *zd, *Y, *xs, *tE; int *pc, *sc; int F, np; };
+__device__ __forceinline__ SbSweep sw_carve(double* w, int F) {
+    SbSweep S; S.F = F; S.np = 6 * F;
+    S.PP = w; w += (S.np * (S.np + 1) / 2 + 1) & ~1;      // lower triangle of the pose x pose block, row-major; later the packed factor
+    S.E = w; w += F * S.np * SWS;                          // E[f][a][k] = M(pose a, sb_f k); after step f: the panel X of those rows
+    S.Bq = w; w += F * 9 * SWS; S.C = w; w += F * 9 * SWS; // B[f] (9 x 9, full), C[f][k'][k] = M(sb_f+1 k', sb_f k); after step f: X of those rows
+    S.rb = w; w += F * SWS; S.rp = w; w += (S.np + 3) & ~1; // right-hand sides
+    S.Lf = w; w += F * 9 * SWS; S.zd = w; w += F * SWS;    // per block: unit-lower L (row i at Lf[f][i][.]), D^-1 L^-1 rhs
+    S.Y = w; w += 76 * SWS; S.xs = w; w += F * SWS;        // Y = R L^-T of the current step (rows: C 0..8, E 9..9+np-1, rhs 9+np); solution of the speed-bias blocks
+    S.tE = w; w += F * SWS;                                // backward sweep: the pose part of every block's right-hand side, formed in parallel
+    S.pc = reinterpret_cast<int*>(w); S.sc = S.pc + 16;
+    return S;
+}
+// scaled + damped entry (i, j) (state columns) of the Schur complement, from the block-packed lower triangle
+__device__ __forceinline__ double sw_entry(const double* __restrict__ Sc, int NBR, int i, int j, double mu, const double* v_s, const double* v_d) {
     const int hi = (j >> 2) > (i >> 2) ? j : i, lo = (j >> 2) > (i >> 2) ? i : j;
     double v = v_s[i] * v_s[j] * Sc[blk_pos(hi, lo, NBR)];
     if (i == j) v += mu * v_d[i] * v_d[i];
     return v;
 }
-
-
-// On success v_x[0..n) = solution of (S_scaled + mu D^2) y = s (g - gs).  work: >= 16200 doubles of LDS; Lm (packed, np) is placed inside it.
-__device__ bool schur_sb_solve(const BeSolveArgs& a, const double* __restrict__ Sc, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
-                               double* work, double* v_x, double* PL, double* PD, double* dinfo, double* zfin, double* dvec, int* s_fail, double** Lm_out) {
-    const int tid = threadIdx.x, NBR = (n + 3) >> 2;
-    const int nf = a.dims.nframes, np = 6 * nf, nb = 9 * nf;
-    // ---- LDS carve ----
-    double* E = work;                          // nb x FS_ES : E'_f (pose columns) | g'_f
-    double* X = E + (size_t)nb * FS_ES;        // half of the frames at a time: 6 * 9 x FS_ES ; later the packed factor of the pose system
-    double* Spp = X + 54 * FS_ES;              // block-packed lower triangle of the reduced pose system (17 block rows -> 153 blocks)
-    const int NBRp = (np + 3) >> 2, nblkp = NBRp * (NBRp + 1) / 2;
-    double* Binv = Spp + (size_t)nblkp * 16;   // nf x 81 : B_f, inverted in place
-    double* T = Binv + 81 * BE_NF;             // nf x 81 : T_f = C_f^T B'_f^-1
-    double* C = T + 81 * BE_NF;                // (nf-1) x 81 : C_f = S(sb_f, sb_f+1)
-    double* rhs2 = C + 81 * BE_NF;             // 2 np : [rhs' ; 0]
-    double* ones = rhs2 + 2 * 72;              // np
-    double* W = ones + 72;                     // 9 x 18 Gauss-Jordan work
-    double* xb = W + 168;                      // nb : speed-bias solution ; y
-    double* yb = xb + 104;
-    // ---- gather: every thread owns block `tid` of the packed triangle and files its 16 entries by kind ----
-    for (int i = tid; i < 81 * BE_NF; i += SOL_THREADS) C[i] = 0.0;
+__device__ __forceinline__ double dot9(const double* x, const double* y) {       // two partial sums: half the dependent chain
+    double s0 = x[0] * y[0], s1 = x[1] * y[1];
+    s0 = __builtin_fma(x[2], y[2], s0); s1 = __builtin_fma(x[3], y[3], s1);
+    s0 = __builtin_fma(x[4], y[4], s0); s1 = __builtin_fma(x[5], y[5], s1);
+    s0 = __builtin_fma(x[6], y[6], s0); s1 = __builtin_fma(x[7], y[7], s1);
+    s0 = __builtin_fma(x[8], y[8], s0);
+    return s0 + s1;
+}
+__device__ bool sb_sweep(const BeSolveArgs& a, const double* __restrict__ Sc, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
+                         const SbSweep& S, int* s_fail) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, F = S.F, np = S.np, NBR = (n + 3) >> 2;
+    if (tid < F) { S.pc[tid] = a.dims.pose_col[tid]; S.sc[tid] = a.dims.sb_col[tid]; }
+    if (tid == 0) *s_fail = 0;
     __syncthreads();
-    {
-        const int nblk = NBR * (NBR + 1) / 2;
-        if (tid < nblk) {
-            int c0 = 0, rem = tid; while (rem >= NBR - c0) { rem -= NBR - c0; ++c0; }
-            const int bjb = c0, bib = c0 + rem;
-            const double4* src = reinterpret_cast<const double4*>(Sc + (size_t)tid * 16);
-            double dv[4][4];
+    // ---- gather: every entry the sweep touches, scaled and damped, into LDS (plain loops: the loads of one thread's items are independent) ----
+#pragma unroll 2
+    for (int q = tid; q < np * np; q += SOL_THREADS) { const int r = q / np, c = q - r * np; if (c <= r) S.PP[tri(r, c)] = sw_entry(Sc, NBR, S.pc[r / 6] + r % 6, S.pc[c / 6] + c % 6, mu, v_s, v_d); }
+#pragma unroll 2
+    for (int q = tid; q < F * np * 9; q += SOL_THREADS) { const int f = q / (np * 9), rem = q - f * np * 9, r = rem / 9, k = rem - r * 9; S.E[(f * np + r) * SWS + k] = sw_entry(Sc, NBR, S.pc[r / 6] + r % 6, S.sc[f] + k, mu, v_s, v_d); }
+    for (int q = tid; q < F * 81; q += SOL_THREADS) { const int f = q / 81, rem = q - f * 81, k1 = rem / 9, k2 = rem - k1 * 9; S.Bq[(f * 9 + k1) * SWS + k2] = sw_entry(Sc, NBR, S.sc[f] + k1, S.sc[f] + k2, mu, v_s, v_d); }
+    for (int q = tid; q < (F - 1) * 81; q += SOL_THREADS) { const int f = q / 81, rem = q - f * 81, k1 = rem / 9, k2 = rem - k1 * 9; S.C[(f * 9 + k1) * SWS + k2] = sw_entry(Sc, NBR, S.sc[f + 1] + k1, S.sc[f] + k2, mu, v_s, v_d); }
+    for (int q = tid; q < F * 9; q += SOL_THREADS) { const int col = S.sc[q / 9] + q % 9; S.rb[(q / 9) * SWS + q % 9] = v_s[col] * (gvec[col] - gvec[n + col]); }
+    for (int q = tid; q < np; q += SOL_THREADS) { const int col = S.pc[q / 6] + q % 6; S.rp[q] = v_s[col] * (gvec[col] - gvec[n + col]); }
+    // this thread's share of the pose x pose triangle (fixed over the sweep): up to three packed indices, decoded once
+    int pa[3], pb[3];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { const double4 q = src[r]; dv[r][0] = q.x; dv[r][1] = q.y; dv[r][2] = q.z; dv[r][3] = q.w; }
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int cc = 0; cc < 4; ++cc) {
-                    const int i = bib * 4 + r, j = bjb * 4 + cc;
-                    if (i >= n || j >= n || j > i) continue;                      // lower triangle incl. diagonal (the diagonal blocks hold both halves)
-                    double v = v_s[i] * v_s[j] * dv[r][cc];
-                    if (i == j) v += mu * v_d[i] * v_d[i];
-                    const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i], kj = a.col_kind[j], fj = a.col_frame[j], cj = a.col_comp[j];
-                    if (ki == 0 && kj == 0) {                                    // pose x pose -> kept for A4 (row-major lower in Spp scratch: a >= b)
-                        const int pa = fi * 6 + ci, pbb = fj * 6 + cj;
-                        const int hi = pa > pbb ? pa : pbb, lo = pa > pbb ? pbb : pa;
-                        // stash in the X area as a packed triangle (np (np+1) / 2 = 2211 <= 54 * 67)
-                        X[hi * (hi + 1) / 2 + lo] = v;
-                    } else if (ki == 1 && kj == 1) {
-                        if (fi == fj) { Binv[fi * 81 + ci * 9 + cj] = v; Binv[fi * 81 + cj * 9 + ci] = v; }
-                        else if (fi == fj + 1) C[fj * 81 + cj * 9 + ci] = v;     // row in sb_fj, column in sb_fi
-                        else if (fj == fi + 1) C[fi * 81 + ci * 9 + cj] = v;
-                        else if (v != 0.0) *s_fail = 2;                          // structure violated (cannot happen: checked on the host)
-                    } else if (ki == 1) E[(fi * 9 + ci) * FS_ES + fj * 6 + cj] = v;   // sb row, pose column
-                    else E[(fj * 9 + cj) * FS_ES + fi * 6 + ci] = v;
-                }
+    for (int u = 0; u < 3; ++u) {
+        const int idx = tid + u * SOL_THREADS;
+        pa[u] = -1; pb[u] = 0;
+        if (idx < np * (np + 1) / 2) {
+            int r = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+            while (r * (r + 1) / 2 > idx) --r;
+            while ((r + 1) * (r + 2) / 2 <= idx) ++r;
+            pa[u] = r; pb[u] = idx - r * (r + 1) / 2;
         }
-        for (int k = tid; k < nb; k += SOL_THREADS) {                             // right-hand side of the speed-bias rows
-            const int f = k / 9, r = k - f * 9, col = a.dims.sb_col[f] + r;
-            E[k * FS_ES + np] = v_s[col] * (gvec[col] - gvec[n + col]);
-        }
-        if (tid < np) { ones[tid] = 1.0; }
     }
     __syncthreads();
     TS(20);
-    // ---- A1: the 9 x 9 chain on wave 0 ----
-    if (tid < 64) {
-        const int lane = tid;
-        bool bad = false;
-        for (int f = 0; f < nf; ++f) {
-            double* Bf = Binv + f * 81;
-            // W = [B'_f | I]
-            for (int e = lane; e < 81; e += 64) {
-                const int r = e / 9, cc = e - r * 9;
-                double v = Bf[e];
-                if (f > 0) { const double* Tp = T + (f - 1) * 81; const double* Cp = C + (f - 1) * 81; double sacc = 0; for (int q = 0; q < 9; ++q) sacc += Tp[r * 9 + q] * Cp[q * 9 + cc]; v -= sacc; }
-                W[r * 18 + cc] = v; W[r * 18 + 9 + cc] = r == cc ? 1.0 : 0.0;
-            }
-            wave_lds_sync();
+    const int nrows = 9 + np + 1;                          // panel rows: C_f (sb_f+1), E_f (poses), rhs_f
+    for (int f = 0; f < F; ++f) {
+        const bool last = f == F - 1;
+        // ---- 9 x 9 LDL^T of B_f and the panel rows, on the two waves that hold the rows (each factors redundantly: no barrier in between).  The block lives in
+        // the registers of lanes 0..8 (lane i = row i, full symmetric storage); the pivot row travels by v_readlane with compile-time lane numbers. ----
+        if (wave < 2) {
+            double w[9];
+            { const double* src = S.Bq + (f * 9 + (lane < 9 ? lane : 0)) * SWS;
+#pragma unroll
+              for (int j = 0; j < 9; ++j) w[j] = src[j]; }
+            double inv[9];
+#pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const double p = W[k * 18 + k];
-                if (!(p > 0.0) || !isfinite(p)) bad = true;
-                const double ip = fast_rcp(p);
-                double nv[3]; int ne[3];
+                const double d = lane_bcast(w[k], k);
+                if (!(d > 0.0) || !isfinite(d)) *s_fail = 1;
+                inv[k] = fast_rcp(d);
+                const double l = w[k] * inv[k];                      // L_ik on lane i (> k)
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int e = lane + 64 * u; ne[u] = e; nv[u] = 0.0;
-                    if (e < 162) { const int r = e / 18, cc = e - r * 18; const double pk = W[k * 18 + cc] * ip; nv[u] = r == k ? pk : W[e] - W[r * 18 + k] * pk; }
+                for (int j = k + 1; j < 9; ++j) { const double wkj = lane_bcast(w[j], k); if (lane > k) w[j] = __builtin_fma(-l, wkj, w[j]); }
+                if (lane > k) w[k] = l;
+            }
+            // broadcast L (36 values) to every lane as uniform operands; lane i keeps row i of L in w[0 .. i)
+            double L[9][9];
+#pragma unroll
+            for (int i = 1; i < 9; ++i)
+#pragma unroll
+                for (int m = 0; m < i; ++m) L[i][m] = lane_bcast(w[m], i);
+            if (wave == 0 && lane < 9) {
+                double* dst = S.Lf + (f * 9 + lane) * SWS;
+#pragma unroll
+                for (int m = 0; m < 9; ++m) dst[m] = w[m];           // (entries m >= lane are not read back)
+            }
+            const int r = tid;                                       // panel row
+            if (r < nrows && !(last && r < 9)) {
+                double* src = r < 9 ? S.C + (f * 9 + r) * SWS : (r < 9 + np ? S.E + (f * np + (r - 9)) * SWS : S.rb + f * SWS);
+                double y[9];
+#pragma unroll
+                for (int k = 0; k < 9; ++k) {
+                    double v = src[k];
+#pragma unroll
+                    for (int m = 0; m < k; ++m) v = __builtin_fma(-y[m], L[k][m], v);
+                    y[k] = v;
                 }
-                wave_lds_sync();
+                double* dst = r < 9 + np ? src : S.zd + f * SWS;
 #pragma unroll
-                for (int u = 0; u < 3; ++u) if (ne[u] < 162) W[ne[u]] = nv[u];
-                wave_lds_sync();
-            }
-            for (int e = lane; e < 81; e += 64) { const int r = e / 9, cc = e - r * 9; Bf[e] = W[r * 18 + 9 + cc]; }
-            wave_lds_sync();
-            if (f + 1 < nf) {
-                const double* Cf = C + f * 81; double* Tf = T + f * 81;
-                for (int e = lane; e < 81; e += 64) { const int r = e / 9, cc = e - r * 9; double sacc = 0; for (int q = 0; q < 9; ++q) sacc += Cf[q * 9 + r] * Bf[q * 9 + cc]; Tf[e] = sacc; }
-                wave_lds_sync();
+                for (int k = 0; k < 9; ++k) { S.Y[r * SWS + k] = y[k]; dst[k] = y[k] * inv[k]; }      // X = Y D^-1, in place of the rows it came from
             }
         }
-        if (__any(bad) && lane == 0) *s_fail = 1;
+        __syncthreads();
+        // ---- rank-9 update of everything the panel rows touch ----
+        {
+            const double* XE = S.E + f * np * SWS; const double* XC = S.C + f * 9 * SWS; const double* Yr = S.Y + (9 + np) * SWS;
+#pragma unroll
+            for (int u = 0; u < 3; ++u)
+                if (pa[u] >= 0) S.PP[tid + u * SOL_THREADS] -= dot9(XE + pa[u] * SWS, S.Y + (9 + pb[u]) * SWS);
+            int q = tid;
+            if (q < np) S.rp[q] -= dot9(XE + q * SWS, Yr);                                    // pose right-hand side
+            else if (!last) {
+                q -= np;
+                if (q < np * 9) { const int r = q / 9, k2 = q - r * 9; S.E[((f + 1) * np + r) * SWS + k2] -= dot9(XE + r * SWS, S.Y + k2 * SWS); }          // E_f+1
+                else if ((q -= np * 9) < 81) { const int k1 = q / 9, k2 = q - k1 * 9; S.Bq[((f + 1) * 9 + k1) * SWS + k2] -= dot9(XC + k1 * SWS, S.Y + k2 * SWS); }      // B_f+1
+                else if ((q -= 81) < 9) S.rb[(f + 1) * SWS + q] -= dot9(XC + q * SWS, Yr);                                                              // rhs_f+1
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     TS(21);
-    if (*s_fail) return false;
-    // ---- A2: column threads carry [E | g] down the chain ----
-    if (tid <= np) {
-        double e[9];
-#pragma unroll
-        for (int r = 0; r < 9; ++r) e[r] = E[r * FS_ES + tid];
-        for (int f = 1; f < nf; ++f) {
-            const double* Tp = T + (f - 1) * 81;
-            double en[9];
-#pragma unroll
-            for (int r = 0; r < 9; ++r) {
-                double sacc = 0;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) sacc += Tp[r * 9 + q] * e[q];
-                en[r] = E[(f * 9 + r) * FS_ES + tid] - sacc;
-            }
-#pragma unroll
-            for (int r = 0; r < 9; ++r) { e[r] = en[r]; E[(f * 9 + r) * FS_ES + tid] = en[r]; }
-        }
-    }
-    // the pose x pose entries parked in X move into registers before X is reused: thread t owns packed entries t, t + 1024, t + 2048 and (beyond
-    // the triangle) the right-hand side entries
-    const int ntri = np * (np + 1) / 2;
-    double acc[3]; int ea[3], eb[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int idx = tid + u * SOL_THREADS; ea[u] = -1; eb[u] = -1; acc[u] = 0.0;
-        if (idx < ntri) {
-            int ra = (int)((sqrt(8.0 * idx + 1.0) - 1.0) * 0.5);
-            while (ra * (ra + 1) / 2 > idx) --ra;
-            while ((ra + 1) * (ra + 2) / 2 <= idx) ++ra;
-            ea[u] = ra; eb[u] = idx - ra * (ra + 1) / 2; acc[u] = X[idx];
-        } else if (idx < ntri + np) {
-            ea[u] = idx - ntri; eb[u] = np;                                     // rhs entry: column np of E / X
-            const int fa = ea[u] / 6, col = a.dims.pose_col[fa] + ea[u] - fa * 6;
-            acc[u] = v_s[col] * (gvec[col] - gvec[n + col]);
-        }
-    }
-    __syncthreads();
-    TS(22);
-    // ---- A3 / A4: S'_pp = A_pp - sum_f E'_f^T (B'_f^-1 E'_f), half of the frames per round (X holds 6 frames) ----
-    for (int f0 = 0; f0 < nf; f0 += 6) {
-        const int fcnt = min(6, nf - f0);
-        for (int o = tid; o < fcnt * 9 * (np + 1); o += SOL_THREADS) {
-            const int row = o / (np + 1), cc = o - row * (np + 1), fl = row / 9, r = row - fl * 9, f = f0 + fl;
-            const double* Bf = Binv + f * 81 + r * 9; const double* Ef = E + (size_t)(f * 9) * FS_ES + cc;
-            double sacc = 0;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) sacc += Bf[q] * Ef[q * FS_ES];
-            X[row * FS_ES + cc] = sacc;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 3; ++u) if (ea[u] >= 0) {
-            double sacc = 0;
-            const double* Ea = E + (size_t)(f0 * 9) * FS_ES + ea[u]; const double* Xb = X + eb[u];
-            for (int k = 0; k < fcnt * 9; ++k) sacc += Ea[k * FS_ES] * Xb[k * FS_ES];
-            acc[u] -= sacc;
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) if (ea[u] >= 0) {
-        if (eb[u] == np) { rhs2[ea[u]] = acc[u]; rhs2[np + ea[u]] = 0.0; }
-        else { Spp[blk_pos(ea[u], eb[u], NBRp)] = acc[u]; if ((ea[u] >> 2) == (eb[u] >> 2)) Spp[blk_pos(eb[u], ea[u], NBRp)] = acc[u]; }
-    }
-    __syncthreads();
-    TS(23);
-    // ---- B: dense pose system ----
-    double* LmP = X;                                        // X is dead: the packed factor (np (np + 1) / 2 doubles) takes its place
-    if (!ldlt_blocked<1>(Spp, rhs2, np, 0.0, ones, ones, LmP, PL, PD, dinfo, zfin, dvec, s_fail)) return false;
-    *Lm_out = LmP;
-    return true;
+    return *s_fail == 0;
 }
-
-// second half of the two-level solve: x_p is in v_x[0..np) (pose ordering f * 6 + r); back-substitutes the speed-bias chain and scatters both
-// into state-column order.  xs: np + nb scratch doubles.
-__device__ void schur_sb_finish(const BeSolveArgs& a, int n, double* work, double* v_x, double* xs) {
-    const int tid = threadIdx.x, nf = a.dims.nframes, np = 6 * nf, nb = 9 * nf;
-    double* E = work; const int NBRp = (np + 3) >> 2, nblkp = NBRp * (NBRp + 1) / 2;
-    double* Binv = E + (size_t)nb * FS_ES + 54 * FS_ES + (size_t)nblkp * 16; double* C = Binv + 2 * 81 * BE_NF;
-    double* xb = C + 81 * BE_NF + 2 * 72 + 72 + 168; double* yb = xb + 104;
-    for (int i = tid; i < np; i += SOL_THREADS) xs[i] = v_x[i];
+// v_x[0 .. np) = solution of the pose block (pose order f * 6 + c) -> solution of the speed-bias blocks by the backward sweep, everything scattered into
+// state-column order
+__device__ void sb_back(const BeSolveArgs& a, int n, const SbSweep& S, double* v_x) {
+    const int tid = threadIdx.x, F = S.F, np = S.np;
+    double* xp = S.rp;                                                 // the reduced right-hand side is spent
+    for (int i = tid; i < np; i += SOL_THREADS) xp[i] = v_x[i];
     __syncthreads();
-    if (tid < nb) {                                         // y_f = g'_f - E'_f x_p
-        const double* Er = E + (size_t)tid * FS_ES;
-        double sacc = Er[np];
-        for (int q = 0; q < np; ++q) sacc -= Er[q] * xs[q];
-        yb[tid] = sacc;
+    // the pose part of every block's right-hand side does not depend on the sweep: tE[f][k] = (D^-1 L^-1 rhs)_k - sum_a X_E[f][a][k] x_a, all blocks at once
+    if (tid < F * 9) {
+        const int f = tid / 9, k = tid - f * 9;
+        const double* xe = S.E + f * np * SWS + k;
+        double s0 = S.zd[f * SWS + k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int r = 0;
+        for (; r + 3 < np; r += 4) {
+            s0 = __builtin_fma(-xe[r * SWS], xp[r], s0); s1 = __builtin_fma(-xe[(r + 1) * SWS], xp[r + 1], s1);
+            s2 = __builtin_fma(-xe[(r + 2) * SWS], xp[r + 2], s2); s3 = __builtin_fma(-xe[(r + 3) * SWS], xp[r + 3], s3);
+        }
+        for (; r < np; ++r) s0 = __builtin_fma(-xe[r * SWS], xp[r], s0);
+        S.tE[f * SWS + k] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
-    if (tid < 64) {                                         // x_f = B'_f^-1 (y_f - C_f x_f+1), f = last .. 0, on nine lanes of one wave
-        const int lane = tid;
-        double xn = 0.0;                                    // lane r: x_{f+1}[r]
-        const int lr = lane < 9 ? lane : 8;
-        for (int f = nf - 1; f >= 0; --f) {                 // every lane runs the same shuffles; lanes >= 9 carry dummies
-            double tv = yb[f * 9 + lr];
-            if (f + 1 < nf) { const double* Cf = C + f * 81 + lr * 9; for (int q = 0; q < 9; ++q) { const double xq = __shfl(xn, q); tv -= Cf[q] * xq; } }
-            double xv = 0.0;
-            const double* Bf = Binv + f * 81 + lr * 9;
-            for (int q = 0; q < 9; ++q) { const double tq = __shfl(tv, q); xv += Bf[q] * tq; }
-            xn = xv;
-            if (lane < 9) xb[f * 9 + lane] = xv;
+    if (tid < 64) {
+        const int lane = tid, lk = lane < 9 ? lane : 0;
+        double xn = 0.0;                                               // lane k: x_{f+1}[k]
+        for (int f = F - 1; f >= 0; --f) {
+            double t = S.tE[f * SWS + lk];
+            if (f + 1 < F) {                                           // - sum_k' X_C[f][k'][k] x_{f+1}[k']
+                const double* xc = S.C + f * 9 * SWS + lk;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) t = __builtin_fma(-xc[r * SWS], lane_bcast(xn, r), t);
+            }
+            // x = L^-T t on lanes 0..8: x_8 = t_8, x_k = t_k - sum_{m > k} L[m][k] x_m ; lane k holds column k of L (read from the stored rows)
+            const double* Lc = S.Lf + f * 9 * SWS + lk;
+            double x = t;
+#pragma unroll
+            for (int m = 8; m >= 1; --m) { const double xm = lane_bcast(x, m); if (lane < m) x = __builtin_fma(-Lc[m * SWS], xm, x); }
+            xn = x;
+            if (lane < 9) S.xs[f * SWS + lane] = x;
         }
     }
     __syncthreads();
-    for (int i = tid; i < n; i += SOL_THREADS) {
-        const int k = a.col_kind[i], f = a.col_frame[i], cc = a.col_comp[i];
-        v_x[i] = k == 0 ? xs[f * 6 + cc] : xb[f * 9 + cc];
-    }
+    for (int i = tid; i < np; i += SOL_THREADS) v_x[S.pc[i / 6] + i % 6] = xp[i];
+    for (int i = tid; i < 9 * F; i += SOL_THREADS) v_x[S.sc[i / 9] + i % 9] = S.xs[(i / 9) * SWS + i % 9];
     __syncthreads();
 }
 
@@ -1153,8 +1111,19 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
         const bool two_level = a.dims.pad != 0;            // VIO window with the block-tridiagonal speed-bias structure (decided on the host)
         double* LmUse = Lm; int nfact = n;
         bool ok_f;
-        if (two_level) { if (tid == 0) s_fail = 0; __syncthreads(); ok_f = schur_sb_solve(a, a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, v_x, PL, PD, dinfo, zfin, dvec, &s_fail, &LmUse); nfact = 6 * a.dims.nframes; }
-        else if (WCOL) { if (ldl_warm == 1.2345e-300) misc[7] = ldl_warm; ldl_build_map(a, n, reinterpret_cast<int*>(scratch)); ldl_prefetch(reinterpret_cast<const int*>(scratch), a.Sc[c.cur], n, ldl_raw); __syncthreads(); ok_f = ldlt_wavecol(a, ldl_raw, gvec, n, mu, v_s, v_d, Lm, scratch, dinfo, zfin, dvec, &s_fail); }
+        SbSweep sw = sw_carve(Lm, a.dims.nframes);
+        if (two_level && WCOL) {
+            // speed-bias blocks first (block steps on register / LDS resident entries), then the dense pose block on the wave-column factorisation
+            ok_f = sb_sweep(a, a.Sc[c.cur], gvec, n, mu, v_s, v_d, sw, &s_fail);
+            if (ok_f) {
+                ldl_build_map(a.ldl_col0p, sw.np, reinterpret_cast<int*>(scratch));
+                { const int m = reinterpret_cast<const int*>(scratch)[tid]; ldl_raw.bi = m < 0 ? -1 : (m >> 8); ldl_raw.bj = m < 0 ? -1 : (m & 255); }
+                __syncthreads();
+                ok_f = ldlt_wavecol(a, ldl_raw, gvec, sw.np, mu, v_s, v_d, sw.PP, scratch, dinfo, zfin, dvec, &s_fail, sw.PP, sw.rp);
+            }
+            LmUse = sw.PP; nfact = sw.np;
+        }
+        else if (WCOL) { if (ldl_warm == 1.2345e-300) misc[7] = ldl_warm; ldl_build_map(a.ldl_col0, n, reinterpret_cast<int*>(scratch)); ldl_prefetch(reinterpret_cast<const int*>(scratch), a.Sc[c.cur], n, ldl_raw); __syncthreads(); ok_f = ldlt_wavecol(a, ldl_raw, gvec, n, mu, v_s, v_d, Lm, scratch, dinfo, zfin, dvec, &s_fail); }
         else ok_f = ldlt_blocked<NSLOT>(a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail);
         if (WCOL) { if (cost_and_tolerance()) return; }
         if (!ok_f) {
@@ -1183,7 +1152,7 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
         }
         __syncthreads();
         TS(24);
-        if (two_level) schur_sb_finish(a, n, Lm, v_x, scratch);
+        if (two_level && WCOL) sb_back(a, n, sw, v_x);
         TS(7);
         for (int i = tid; i < n; i += SOL_THREADS) { v_gn[i] = -v_d[i] * v_x[i]; a.gn_p[i] = v_gn[i]; v_t[i] = v_s[i] * v_x[i]; }   // v_t = s_p . y_p
         __syncthreads();
@@ -1327,13 +1296,13 @@ bool be_ldl_pack(int n, uint16_t* col0) {
 int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
     static DevOnce once;
     if (once.run([] {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE, true, false)) != hipSuccess) return 1;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE, true, false)) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE, false, false)) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE, false, false)) != hipSuccess) return 1;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(168, false, true)) != hipSuccess) return 1;
             return 0; })) return -1;
     const int nbr = (a.dims.nstate + 3) / 4;
-    if (a.ldl_wcol && !a.dims.pad) hipLaunchKernelGGL((be_solve_kernel<1, true>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, true), s, a, spec);
-    else if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL((be_solve_kernel<1, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, a.dims.pad != 0, false), s, a, spec);
+    if (a.ldl_wcol) hipLaunchKernelGGL((be_solve_kernel<1, true>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, a.dims.pad != 0, true), s, a, spec);      // (pad is only set together with ldl_wcol)
+    else if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL((be_solve_kernel<1, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, false), s, a, spec);
     else hipLaunchKernelGGL((be_solve_kernel<2, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, false), s, a, spec);
     return 0;
 }

@@ -54,6 +54,18 @@ def default_boxes():
             MovingBox(3, (1.0, 4.5, -1.2), (1, 0, 0), 0.15, 9.0, dims=(1.4, 1.2, 2.4), yaw0=1.2, yaw_rate=0.0, phase=0.5)]
 
 
+def ring_boxes(n):
+    """n boxes spread over the room (deterministic): the default three plus boxes on two rings, moving along tangents with different periods"""
+    out = default_boxes()
+    for k in range(max(0, n - 3)):
+        ang = 0.7 + 2.399963 * k                       # golden-angle spacing
+        r = 4.0 + 1.5 * (k % 3)
+        c = (r * np.cos(ang), r * np.sin(ang), -1.0 + 0.2 * (k % 4))
+        d = (-np.sin(ang), np.cos(ang), 0.0)
+        out.append(MovingBox(4 + k, c, d, 0.5 + 0.4 * (k % 5), 5.0 + k % 4, dims=(1.0 + 0.1 * (k % 4), 0.9, 1.6 + 0.2 * (k % 3)), yaw0=ang, yaw_rate=0.05 * ((k % 3) - 1), phase=0.3 * k))
+    return out[:n]
+
+
 class InstSim:
     def __init__(self, traj, cam, w, h, boxes=None, max_cnt=50, n_surface=220, n_extra=60, pix_sigma=0.3, seed=11, first_id=100000, with_det3d=True):
         self.traj, self.cam, self.w, self.h = traj, cam, w, h

@@ -584,13 +584,7 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
     __syncthreads();
     TS(4);
     // (a) + (b) of block column kc by the wave that owns it; every lane of that wave takes part in the broadcast
-#ifdef BE_SOLVE_TS
-    long long pa = 0, pb = 0, pc = 0, pd_ = 0, pe = 0, tq = 0; bool ts_on = false;
-#define PTS(acc) do { if (ts_on) { acc = clock64(); } } while (0)
-#else
-#define PTS(acc) do {} while (0)
-#endif
-    auto panel = [&](int kc, int dl) {          // dl: lane of the column's diagonal block (wave-uniform)
+    auto panel = [&](int kc) {
         const bool is_diag = bi == kc && bj == kc, is_panel = bj == kc && bi > kc;
         double* di = dinfo + (kc & 1) * 16;
         double2* PB = reinterpret_cast<double2*>(P0) + (kc & 1) * WC_BUF;      // [L rows 0-1 | L rows 2-3 | LD rows 0-1 | LD rows 2-3][m][block row]: 16-byte lane stride, conflict-free
@@ -600,12 +594,10 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
         // (through LDS: ten stores by the diagonal lane, ten broadcast loads by the wave — 63 v_readlane / SGPR->VGPR moves in the owner's instruction
         // stream otherwise; LDS operations of one wave execute in order, so a wave-level fence is all the synchronisation needed.  The right-hand side
         // is not broadcast: every lane runs the forward substitution on its own zr, only the diagonal lane's result is used.)
-        (void)dl;
         if (is_diag) { di[0] = A[0][0]; di[1] = A[1][0]; di[2] = A[2][0]; di[3] = A[3][0]; di[4] = A[1][1]; di[5] = A[2][1]; di[6] = A[3][1]; di[7] = A[2][2]; di[8] = A[3][2]; di[9] = A[3][3]; }
         wave_lds_sync();
         const double d0 = di[0], a10 = di[1], a20 = di[2], a30 = di[3], a11 = di[4], a21 = di[5], a31 = di[6], a22 = di[7], a32 = di[8], a33 = di[9];
         const double zz0 = zr[0], zz1 = zr[1], zz2 = zr[2], zz3 = zr[3];
-        PTS(pb);
         const double i0 = fast_rcp(d0);
         const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
         const double d1 = __builtin_fma(-l10, a10, a11), i1 = fast_rcp(d1);
@@ -628,7 +620,6 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
             pv[r][0] = p0; pv[r][1] = p1; pv[r][2] = p2; pv[r][3] = p3;
             xv[r][0] = p0 * i0; xv[r][1] = p1 * i1; xv[r][2] = p2 * i2; xv[r][3] = p3 * i3;
         }
-        PTS(pc);
         if (is_panel) {
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
@@ -651,11 +642,9 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
             A[1][0] = l10; A[2][0] = l20; A[3][0] = l30; A[2][1] = l21; A[3][1] = l31; A[3][2] = l32;
         }
     };
-    // the wave that holds block column kc: the lanes with bj == kc, the diagonal block in the lowest of them (ldl_prefetch's mapping) — found by ballot, no table look-up on the critical path
-    { const unsigned long long cm = __ballot(bj == 0); if (cm) panel(0, __ffsll((long long)cm) - 1); }
+    // the wave that holds block column kc = the wave with lanes bj == kc: found by ballot, no table look-up on the critical path
+    if (__ballot(bj == 0)) panel(0);
     __syncthreads();
-#ifdef BE_SOLVE_TS
-#endif
 #ifdef BE_SOLVE_TS
     long long t_prev = wall_clock64(), acc_a = 0;
 #endif
@@ -663,9 +652,6 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
         // (a non-positive pivot only raises s_fail: the loop runs on — on garbage — and the flag is read once behind it)
         const double* di = dinfo + (kb & 1) * 16;
         const unsigned long long cm = __ballot(bj == kb + 1);      // kb + 1 == NBR: no lane
-#ifdef BE_SOLVE_TS
-        if (cm != 0 && kb == 10) tq = clock64();
-#endif
         const bool owner = cm != 0;                                 // this wave carries the critical path of the step: it goes first on its SIMD
         if (owner) __builtin_amdgcn_s_setprio(3);
         else __builtin_amdgcn_s_sleep(2);            // the owner's panel reads enter the LDS queue first (the others have slack until the owner's panel is done)
@@ -697,20 +683,8 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
             }
         }
         // ---- look-ahead: (a) + (b) of block column kb + 1, inside its wave ----
-#ifdef BE_SOLVE_TS
-        ts_on = owner && kb == 10;
-        PTS(pa);
-#endif
-        if (owner) { panel(kb + 1, __ffsll((long long)cm) - 1); __builtin_amdgcn_s_setprio(0); }
-#ifdef BE_SOLVE_TS
-        PTS(pd_);
-#endif
+        if (owner) { panel(kb + 1); __builtin_amdgcn_s_setprio(0); }
         __syncthreads();
-#ifdef BE_SOLVE_TS
-        PTS(pe);
-        if (ts_on && bi == kb + 1 && bj == kb + 1) { be_dbg_ts[24] = tq; be_dbg_ts[25] = pa; be_dbg_ts[26] = pb; be_dbg_ts[27] = pc; be_dbg_ts[28] = pd_; be_dbg_ts[29] = pe; }
-        ts_on = false;
-#endif
 #ifdef BE_SOLVE_TS
         { long long t = wall_clock64(); acc_a += t - t_prev; t_prev = t; }
 #endif

@@ -28,14 +28,10 @@ for a, b, name in seq:
     print(f"{name:24s} {(t[b] - t[a]) / 100.0:8.2f} us")
 print("total", (t[10] - t[0]) / 100.0)
 if t[20]:
-    for a, b, name in [(3, 20, "fast: gather"), (20, 21, "fast: A1 chain (wave 0)"), (21, 22, "fast: A2 columns + stash"), (22, 23, "fast: A3/A4 pose update"), (23, 4, "fast: ldlt load (pose)"), (7, 24, "(back-sub end -> finish start)"), (24, 8, "fast: finish + gn landmarks")]:
+    for a, b, name in [(3, 20, "two-level: gather"), (20, 21, "two-level: speed-bias sweep"), (21, 4, "two-level: pose blocks to registers"), (24, 7, "two-level: backward sweep + scatter")]:
         print(f"{name:32s} {(t[b] - t[a]) / 100.0:8.2f} us")
 print("ldlt (c)+(a) us", ts[16] / 100.0, " (b) us", ts[17] / 100.0)
 
 if t[31] and t[5] != t[4]:
     print("shader clock during the LDL^T loop: %.0f MHz" % ((t[31] - t[30]) / ((t[5] - t[4]) / 100.0)))
 
-if t[25]:
-    names = ["(c) own update", "(a) diag factor", "readlane bcast", "(b) panel + LDS writes", "barrier wait"]
-    for k, nm in zip(range(25, 30), names):
-        print(f"  owner wave, block column 10: {nm:24s} {t[k] - t[k - 1]:8d} cycles")

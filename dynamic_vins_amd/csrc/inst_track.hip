@@ -73,11 +73,13 @@ struct dv_inst_tracker {
     dv_feat* out_dev = nullptr; DevBuf out_buf; void* out_pinned = nullptr; size_t out_cap_slots = 0;      // [slot][INST_CAP] rows + counts
     hipEvent_t done = nullptr; bool pending = false; bool frame_enqueued = false;
     hipStream_t stream = nullptr;                               // the objects run beside the background tracker: own stream, own Shi-Tomasi scratch
+    DevBuf jobs; void* jobs_pinned = nullptr; size_t jobs_cap = 0;     // DvLkJob tables of the two batched LK stages (temporal | right)
     DevBuf cand, scal; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
     std::vector<unsigned> out_order;                            // ids written this frame, in output order
     ~dv_inst_tracker() {
         for (auto& kv : slots) kv.second.release();
-        hw.release(); out_buf.release(); cand.release(); scal.release();
+        hw.release(); out_buf.release(); cand.release(); scal.release(); jobs.release();
+        if (jobs_pinned) (void)hipHostFree(jobs_pinned);
         if (stream) (void)hipStreamDestroy(stream);
         if (pinned_in) (void)hipHostFree(pinned_in);
         if (out_pinned) (void)hipHostFree(out_pinned);
@@ -251,12 +253,27 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         const size_t slot_bytes = INST_CAP * sizeof(dv_feat) + 64;
         size_t moff = 0; int out_k = 0;
         const double dt = T.cur_time - T.last_time;
-        for (auto& kv : T.slots) {
-            Slot& S = kv.second;
-            S.out_valid = false;
-            if (S.lost_num > 0 || !S.visible) continue;            // ExecInst + is_curr_visible
+        // The objects are independent up to the shared id counter, and an LK launch is pure latency (one wave per point): the frame is processed in STAGES —
+        // (A) per object: mask upload, ROI crop + padding, pyramids; (B) ONE temporal-LK launch for all objects; (C) per object, in ascending id: compaction,
+        // mask erosion, Shi-Tomasi (the candidate scratch and the id counter are shared, so this stage stays sequential); (D) ONE right-image LK launch;
+        // (E) per object: undistortion / velocities / rows.  Same arithmetic, same order of id assignment as the one-object-at-a-time form.
+        std::vector<Slot*> act;
+        for (auto& kv : T.slots) { Slot& S = kv.second; S.out_valid = false; if (S.lost_num > 0 || !S.visible) continue; act.push_back(&S); }      // ExecInst + is_curr_visible
+        const int na = (int)act.size();
+        if ((size_t)na * 2 > T.jobs_cap) {
+            const size_t cap = std::max<size_t>(16, (size_t)na * 4);
+            DV_CHECK(hipStreamSynchronize(s));
+            DV_CHECK(T.jobs.ensure(cap * sizeof(DvLkJob)));
+            if (T.jobs_pinned) (void)hipHostFree(T.jobs_pinned);
+            T.jobs_pinned = nullptr;
+            DV_CHECK(hipHostMalloc(&T.jobs_pinned, cap * sizeof(DvLkJob), hipHostMallocDefault));
+            T.jobs_cap = cap;
+        }
+        DvLkJob* hj = (DvLkJob*)T.jobs_pinned; int n_temporal = 0;
+        // ---- stage A ----
+        for (Slot* Sp : act) {
+            Slot& S = *Sp;
             const int w = S.rw, h = S.rh;
-            // mask of this frame -> HBM
             const int mp = align_up(w, 16);
             uint8_t* hm = (uint8_t*)T.pinned_in + moff; moff += (size_t)mp * h;
             const dv_inst_det* det = nullptr; for (int i = 0; i < n_dets; ++i) if (dets[i].track_id == S.id) det = &dets[i];
@@ -274,34 +291,52 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
                 for (int l = 1; l < B.pyr.levels; ++l)
                     dv_launch_pyr_down2(S.padA.pyr.L[l - 1].p, B.pyr.L[l - 1].p, B.pyr.L[l - 1].w, B.pyr.L[l - 1].h, B.pyr.L[l - 1].pitch, S.padA.pyr.L[l].p, B.pyr.L[l].p, B.pyr.L[l].pitch, nullptr, nullptr, 0, s);
                 // InstFeat::TrackLeft: FeatureTrackByLK(prev padded, cur padded, last_points) without a mask (dynamic_tracker.cpp:409)
-                dv_launch_lk_track(S.padA.pyr, B.pyr, S.tr.last_pts, S.tr.n_feat, T.max_cnt, ctx->cfg.flow_back, 0.5f, S.tr.lk_pts, S.tr.lk_status, s);
+                DvLkJob j{}; j.A = S.padA.pyr; j.B = B.pyr; j.pts_a = S.tr.last_pts; j.n_dev = S.tr.n_feat; j.pts_b = S.tr.lk_pts; j.status = S.tr.lk_status;
+                hj[n_temporal++] = j;
             }
+        }
+        // the right-image jobs are known up front as well: TrackRightByPad (instance_feature.cpp:251-275) moves the points into full-image coordinates
+        for (int k = 0; k < na && stereo; ++k) {
+            Slot& S = *act[k];
+            DvLkJob j{}; j.A = L; j.B = R; j.pts_a = S.tr.curr_pts; j.n_dev = S.tr.n_feat; j.pts_b = S.tr.right_pts; j.status = S.tr.right_status;
+            j.add_x = (float)S.rx; j.add_y = (float)S.ry; j.use_add = 1;
+            hj[n_temporal + k] = j;
+        }
+        if (na > 0) DV_CHECK(hipMemcpyAsync(T.jobs.p, hj, (size_t)(n_temporal + (stereo ? na : 0)) * sizeof(DvLkJob), hipMemcpyHostToDevice, s));
+        // ---- stage B ----
+        dv_launch_lk_track_multi((const DvLkJob*)T.jobs.p, n_temporal, T.max_cnt, ctx->cfg.flow_back, 0.5f, s);
+        // ---- stage C ----
+        for (Slot* Sp : act) {
+            Slot& S = *Sp;
+            const int w = S.rw, h = S.rh, mp = align_up(w, 16);
+            RoiPyr& B = S.roi[S.cur];
             dv_launch_compact(S.tr, nullptr, 0, 0, T.n_cand, T.max_ord, s);      // ReduceVector x4, ++track_cnt; without a previous ROI the object has no points (n_feat == 0)
             // ErodeMask 5x5 + discs of the tracked points + goodFeaturesToTrack on roi_gray (:418-446)
             dv_launch_erode((const uint8_t*)S.mask.p, w, h, mp, 5, (uint8_t*)S.tmp.p, mp, (uint8_t*)S.ero.p, mp, s);
-            {
-                GfttTileArgs a{};
-                a.img = B.pyr.L[0].p; a.w = w; a.h = h; a.pitch = B.pyr.L[0].pitch;
-                a.in_mask = (const uint8_t*)S.ero.p; a.mask_pitch = mp;
-                a.disc_pts = S.tr.curr_pts; a.n_disc = S.tr.n_tracked; a.radius = T.min_dist; a.hw = (const uint8_t*)T.hw.p;
-                a.n_feat = S.tr.n_feat; a.max_cnt = T.max_cnt; a.min_new = 1;
-                a.cand = (DvCand*)T.cand.p; a.cand_cap = T.cand_cap; a.n_cand = T.n_cand; a.max_ord = T.max_ord;
-                dv_launch_gftt_tile(a, s);
-                if (!waited_bg) { DV_CHECK(hipStreamWaitEvent(s, ctx->ev_bg_select, 0)); waited_bg = true; }      // ids: background first, then the objects in ascending id
-                GfttSelectArgs sa{};
-                sa.cand = (const DvCand*)T.cand.p; sa.n_cand = T.n_cand; sa.cand_cap = T.cand_cap; sa.max_ord = T.max_ord;
-                sa.w = w; sa.h = h; sa.quality = 0.01; sa.min_dist = (double)T.min_dist;
-                sa.max_n_host = 0; sa.n_feat = S.tr.n_feat; sa.max_cnt = T.max_cnt; sa.min_new = 1;
-                sa.out_xy = nullptr; sa.n_out = nullptr; sa.tr = S.tr; sa.has_tr = 1; sa.err_flag = T.err_flag;
-                if (dv_launch_gftt_select(sa, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
-            }
-            // TrackRightByPad (instance_feature.cpp:251-275): the points move into full-image coordinates, LK left -> right on the full frames
-            if (stereo) dv_launch_lk_track_offset(L, R, S.tr.curr_pts, S.tr.n_feat, T.max_cnt, ctx->cfg.flow_back, 0.5f, (float)S.rx, (float)S.ry, S.tr.right_pts, S.tr.right_status, s);
-            // UndistortedPointsWithAddOffset + PtsVelocity + RightUndistortedPts + RightPtsVelocity + PostProcess -> rows
+            GfttTileArgs a{};
+            a.img = B.pyr.L[0].p; a.w = w; a.h = h; a.pitch = B.pyr.L[0].pitch;
+            a.in_mask = (const uint8_t*)S.ero.p; a.mask_pitch = mp;
+            a.disc_pts = S.tr.curr_pts; a.n_disc = S.tr.n_tracked; a.radius = T.min_dist; a.hw = (const uint8_t*)T.hw.p;
+            a.n_feat = S.tr.n_feat; a.max_cnt = T.max_cnt; a.min_new = 1;
+            a.cand = (DvCand*)T.cand.p; a.cand_cap = T.cand_cap; a.n_cand = T.n_cand; a.max_ord = T.max_ord;
+            dv_launch_gftt_tile(a, s);
+            if (!waited_bg) { DV_CHECK(hipStreamWaitEvent(s, ctx->ev_bg_select, 0)); waited_bg = true; }      // ids: background first, then the objects in ascending id
+            GfttSelectArgs sa{};
+            sa.cand = (const DvCand*)T.cand.p; sa.n_cand = T.n_cand; sa.cand_cap = T.cand_cap; sa.max_ord = T.max_ord;
+            sa.w = w; sa.h = h; sa.quality = 0.01; sa.min_dist = (double)T.min_dist;
+            sa.max_n_host = 0; sa.n_feat = S.tr.n_feat; sa.max_cnt = T.max_cnt; sa.min_new = 1;
+            sa.out_xy = nullptr; sa.n_out = nullptr; sa.tr = S.tr; sa.has_tr = 1; sa.err_flag = T.err_flag;
+            if (dv_launch_gftt_select(sa, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
+        }
+        // ---- stage D ----
+        if (stereo) dv_launch_lk_track_multi((const DvLkJob*)T.jobs.p + n_temporal, na, T.max_cnt, ctx->cfg.flow_back, 0.5f, s);
+        // ---- stage E: UndistortedPointsWithAddOffset + PtsVelocity + RightUndistortedPts + RightPtsVelocity + PostProcess -> rows ----
+        for (Slot* Sp : act) {
+            Slot& S = *Sp;
             dv_feat* od = (dv_feat*)((uint8_t*)T.out_buf.p + (size_t)out_k * slot_bytes);
             int* on = (int*)((uint8_t*)od + INST_CAP * sizeof(dv_feat));
             dv_launch_finalize_offset(S.tr, ctx->cfg.cam0, ctx->cfg.cam1, stereo ? 1 : 0, dt, T.max_cnt, (double)S.rx, (double)S.ry, od, on, s);
-            S.has_prev = true; S.pw = w; S.ph = h;                  // PostProcess: prev_roi_gray = roi_gray (the top-left w x h of roi[cur] level 0)
+            S.has_prev = true; S.pw = S.rw; S.ph = S.rh;            // PostProcess: prev_roi_gray = roi_gray (the top-left w x h of roi[cur] level 0)
             S.out_valid = true; S.out_index = out_k++;
             T.out_order.push_back(S.id);
         }

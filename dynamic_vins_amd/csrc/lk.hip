@@ -219,15 +219,9 @@ __global__ __launch_bounds__(64) void lk_generic_kernel(DvPyr A, DvPyr B, const 
     if (lane == 0) { pts_b[p] = next; status[p] = st ? 1 : 0; }
 }
 
-// FeatureTrackByLK fused: fwd (maxLevel 3) + bwd (maxLevel 1, initial flow) + distance + InBorder
-__global__ __launch_bounds__(64) void lk_track_kernel(DvPyr A, DvPyr B, const float2* __restrict__ pts_a, const int* __restrict__ n_dev,
-                                                      int n_host, int flow_back, float dist_thresh, double eps_sq,
-                                                      float2* __restrict__ pts_b, uint8_t* __restrict__ status, float add_x, float add_y, int use_add) {
-    __shared__ __attribute__((aligned(16))) uint8_t sI[IT_ROWS * IT_PITCH];
-    __shared__ __attribute__((aligned(16))) uint8_t sJ[JT_ROWS * JT_PITCH];
-    const int p = blockIdx.x, lane = threadIdx.x;
-    const int n = n_dev ? *n_dev : n_host;
-    if (p >= n) return;
+// FeatureTrackByLK fused: fwd (maxLevel 3) + bwd (maxLevel 1, initial flow) + distance + InBorder, for the wave's point p
+__device__ __forceinline__ void lk_track_point(const DvPyr& A, const DvPyr& B, const float2* __restrict__ pts_a, int p, int flow_back, float dist_thresh, double eps_sq,
+                                               float2* __restrict__ pts_b, uint8_t* __restrict__ status, float add_x, float add_y, int use_add, uint8_t* sI, uint8_t* sJ, int lane) {
     float2 prev = pts_a[p];
     if (use_add) { prev.x = prev.x + add_x; prev.y = prev.y + add_y; }      // InstFeat::TrackRightByPad: ROI coordinates + box2d->rect.tl() (float + float)
     float2 next = make_float2(0.f, 0.f);
@@ -247,6 +241,26 @@ __global__ __launch_bounds__(64) void lk_track_kernel(DvPyr A, DvPyr B, const fl
     if (st && !lk_in_border(next, B.L[0].h, B.L[0].w)) st = false;
     if (lane == 0) { pts_b[p] = next; status[p] = st ? 1 : 0; }
 }
+__global__ __launch_bounds__(64) void lk_track_kernel(DvPyr A, DvPyr B, const float2* __restrict__ pts_a, const int* __restrict__ n_dev,
+                                                      int n_host, int flow_back, float dist_thresh, double eps_sq,
+                                                      float2* __restrict__ pts_b, uint8_t* __restrict__ status, float add_x, float add_y, int use_add) {
+    __shared__ __attribute__((aligned(16))) uint8_t sI[IT_ROWS * IT_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t sJ[JT_ROWS * JT_PITCH];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    const int n = n_dev ? *n_dev : n_host;
+    if (p >= n) return;
+    lk_track_point(A, B, pts_a, p, flow_back, dist_thresh, eps_sq, pts_b, status, add_x, add_y, use_add, sI, sJ, lane);
+}
+// the same for several independent jobs in ONE launch (the per-object trackers of dynamic mode: blockIdx.y = job): the latency of a launch — one wave
+// per point, up to 180 dependent iterations — is paid once per stage instead of once per object
+__global__ __launch_bounds__(64) void lk_track_multi_kernel(const DvLkJob* __restrict__ jobs, int flow_back, float dist_thresh, double eps_sq) {
+    __shared__ __attribute__((aligned(16))) uint8_t sI[IT_ROWS * IT_PITCH];
+    __shared__ __attribute__((aligned(16))) uint8_t sJ[JT_ROWS * JT_PITCH];
+    const DvLkJob& j = jobs[blockIdx.y];
+    const int p = blockIdx.x, lane = threadIdx.x;
+    if (p >= *j.n_dev) return;
+    lk_track_point(j.A, j.B, j.pts_a, p, flow_back, dist_thresh, eps_sq, j.pts_b, j.status, j.add_x, j.add_y, j.use_add, sI, sJ, lane);
+}
 
 void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters, double eps_sq,
                           int use_initial, float2* pts_b, uint8_t* status, hipStream_t s) {
@@ -265,4 +279,9 @@ void dv_launch_lk_track_offset(const DvPyr& A, const DvPyr& B, const float2* pts
     if (n_max <= 0) return;
     const double eps = 0.01;
     hipLaunchKernelGGL(lk_track_kernel, dim3(n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status, add_x, add_y, 1);
+}
+void dv_launch_lk_track_multi(const DvLkJob* jobs_dev, int n_jobs, int n_max, int flow_back, float dist_thresh, hipStream_t s) {
+    if (n_jobs <= 0 || n_max <= 0) return;
+    const double eps = 0.01;
+    hipLaunchKernelGGL(lk_track_multi_kernel, dim3(n_max, n_jobs), dim3(64), 0, s, jobs_dev, flow_back, dist_thresh, eps * eps);
 }

@@ -176,7 +176,10 @@ def main():
     if args.mode == "dynamic":
         I, S = pipe.est.instances()
         dyn_info = dict(objects_tracked=int(len(I)), objects_initialised=int(I["is_initial"].sum()) if len(I) else 0,
-                        object_features_per_frame=int(len(pipe.ifeats)), object_solve_iterations=int(S[0]))
+                        object_features_per_frame=int(len(pipe.ifeats)), object_solve_iterations=int(S[0]),
+                        over_the_run=dict(frames=pipe.stat["frames"], frames_with_objects=pipe.stat["frames_with_objects"],
+                                          detections_per_frame=round(pipe.stat["object_detections"] / max(pipe.stat["frames"], 1), 2),
+                                          object_features_per_frame=round(pipe.stat["object_features"] / max(pipe.stat["frames"], 1), 1)))
     dev_poses, dev_times = np.array(pipe.poses), list(pipe.pose_times)
     pipe.ctx.close()
 

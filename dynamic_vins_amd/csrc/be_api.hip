@@ -515,19 +515,6 @@ int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return -1;
     if (std::strcmp(key, "short_first_pass") == 0) { ctx->be.debug_short_first_pass = value != 0; return 0; }
     if (std::strcmp(key, "two_level") == 0) { ctx->be.two_level = value != 0; return 0; }
-    if (std::strcmp(key, "stream_priority") == 0) {      // BA stream at the highest, tracking stream at the lowest priority the device offers (A/B switch; call before the first frame)
-        if (ctx->be.pend->active || ctx->pending) DV_FAIL("dv_debug_set: stream_priority while work is in flight");
-        DV_CHECK(hipSetDevice(ctx->cfg.device));
-        int lo = 0, hi = 0;
-        DV_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least, hi = greatest priority (numerically lower)
-        DV_CHECK(hipStreamSynchronize(ctx->stream)); DV_CHECK(hipStreamSynchronize(ctx->be_stream));
-        hipStream_t a = nullptr, b = nullptr;
-        DV_CHECK(hipStreamCreateWithPriority(&a, hipStreamNonBlocking, value ? lo : 0));
-        DV_CHECK(hipStreamCreateWithPriority(&b, hipStreamNonBlocking, value ? hi : 0));
-        (void)hipStreamDestroy(ctx->stream); (void)hipStreamDestroy(ctx->be_stream);
-        ctx->stream = a; ctx->be_stream = b;
-        return 0;
-    }
     if (std::strcmp(key, "ldl_generic") == 0) { ctx->be.ldl_generic = value != 0; return 0; }      // the block-column-major LDL^T mapping instead of the wave-column one
     DV_FAIL(std::string("dv_debug_set: unknown key ") + key);
 }

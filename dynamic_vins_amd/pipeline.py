@@ -189,6 +189,7 @@ class DynamicPipeline(Pipeline):
         self.k_imu = self.next = 0
         self.enqueued = False
         self.poses, self.pose_times = [], []
+        self.stat = dict(frames=0, frames_with_objects=0, object_detections=0, object_features=0)      # what the object branch was fed over the run
 
     def _enqueue(self, k):
         l, r = self.seq.frames[k]
@@ -215,4 +216,5 @@ class DynamicPipeline(Pipeline):
             self.poses.append(self.est.window()[10, :7]); self.pose_times.append(t)
         self.next += 1
         self.rows, self.insts, self.ifeats, self.ipts = rows, insts, ifeats, pts
+        self.stat["frames"] += 1; self.stat["frames_with_objects"] += int(len(insts) > 0); self.stat["object_detections"] += len(insts); self.stat["object_features"] += len(ifeats)
         return st

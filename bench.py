@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--every-second-frame", action="store_true", help="the reference's convention outside KITTI: only every 2nd tracked frame gets BA (system/main.cpp:300-307)")
     ap.add_argument("--shard", action="store_true", help="BA-only: one window sharded by landmark over the ranks (reduced-system all-reduce)")
     ap.add_argument("--sequences", type=int, default=1, help="S independent sequences per GPU interleaved by one host thread (aggregate rate; the default single-sequence line stays the headline)")
+    ap.add_argument("--batched", action="store_true", help="with --sequences: the window solves of all sequences share every launch (dv_batch), one host thread")
     ap.add_argument("--sequence-threads", action="store_true", help="with --sequences: one host thread per sequence instead of one interleaving thread")
     ap.add_argument("--blocks", type=int, default=2, help="consecutive timed blocks of --steps frames (the first is `value`; all are listed in config.block_values)")
     ap.add_argument("--timing-block", type=int, default=1, help="which block the instrumented (per-kernel HIP events) pass times")

@@ -102,6 +102,10 @@ SIGNATURES = {
     "dv_timing_reset": (C.c_int, [_ctx]),
     "dv_timing_get": (C.c_int, [_ctx, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "dv_debug_set": (C.c_int, [_ctx, C.c_char_p, C.c_int]),
+    "dv_batch_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int]),
+    "dv_batch_destroy": (None, [C.c_void_p]),
+    "dv_batch_enqueue": (C.c_int, [C.c_void_p]),
+    "dv_batch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dv_dist_unique_id": (C.c_int, [C.c_void_p]),
     "dv_dist_init_rccl": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
     "dv_dist_init_host": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

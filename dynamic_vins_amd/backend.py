@@ -398,3 +398,36 @@ class Estimator:
 
     inputIMU = InputIMU
     processMeasurements = ProcessMeasurements
+
+
+class Batch:
+    """dv_batch: several contexts (one estimator each, same GPU) whose window solves share every launch.  Protocol per round: ProcessMeasurements*Begin
+    on every member that has a frame, enqueue(), ProcessMeasurementsEnd on each."""
+
+    def __init__(self, ctxs):
+        self.lib = ctxs[0].lib
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        self.h = self.lib.dv_batch_create(arr, len(ctxs))
+        if not self.h:
+            raise DvinsError(self.lib.dv_last_error(None).decode())
+        self.ctxs = list(ctxs)
+
+    def enqueue(self):
+        if self.lib.dv_batch_enqueue(self.h) != 0:
+            raise DvinsError(self.lib.dv_last_error(self.ctxs[0].h).decode())
+
+    def info(self):
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        self.lib.dv_batch_info(self.h, C.byref(a), C.byref(b))
+        return dict(batched_rounds=a.value, single_rounds=b.value)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dv_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

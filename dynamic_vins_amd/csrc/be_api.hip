@@ -424,6 +424,11 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
         return 0;
     }
     const int first_slots = w.debug_short_first_pass ? std::max(1, P->max_iters - 2) : P->max_iters;      // dv_debug_set(ctx, "short_first_pass", 1): tests exercise the spare-slot path
+    if (ctx->batch && fused && !sh.on) {       // member of a dv_batch: the upload is on its way; dv_batch_enqueue launches the slots of all members together
+        pd.deferred = true; pd.first_slots = first_slots;
+        pd.active = true; pd.t_begin = t_begin; pd.t_up = t_up; pd.t_enq = t_up;
+        return 0;
+    }
     { StageScope sc(ctx, "ba_solve", s); if (be_enqueue_slots(ctx, pd, first_slots, true, s)) return -1; }
     std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
     if (be_enqueue_tail(ctx, pd, s)) return -1;
@@ -451,6 +456,11 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     }
     BeWork& w = ctx->be;
     hipStream_t s = ctx->be_stream;
+    if (pd.deferred) {        // a batch member collected without dv_batch_enqueue (the synchronous solves of the initialisation): enqueue it alone
+        pd.deferred = false;
+        if (be_enqueue_slots(ctx, pd, pd.first_slots, true, s)) return -1;
+        if (be_enqueue_tail(ctx, pd, s)) return -1;
+    }
     const MargPlan& pl = pd.pl;
     uint8_t* hp = (uint8_t*)w.pinned;
     const BeState* hx = (const BeState*)(hp + w.dl_off); const BeCtl* hctl = (const BeCtl*)(hp + w.dl_off + sizeof(BeState));
@@ -494,6 +504,63 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     return 0;
 }
 
+// ---- dv_batch: several independent windows (one estimator each, same device) whose solve slots share every launch -----------------------------------
+// Each member keeps its own BA stream for the upload, the gauge fix, the state download and the marginalization; the iteration slots — the launch-bound
+// part: 3 launches per iteration and window — run on the batch's stream as ONE launch per stage for all windows (argument tables in HBM, window index in
+// the grid).  Per round: S event waits (uploads done), 3 x iterations launches, one event, S event waits (tails).
+struct dv_batch {
+    std::vector<dv_ctx*> members;
+    hipStream_t stream = nullptr; hipEvent_t ev_slots = nullptr; std::vector<hipEvent_t> ev_up;
+    DevBuf tab; void* tab_pinned = nullptr;       // [S] BeEvalArgs | [S] BeSolveArgs
+    long long batched_rounds = 0, single_rounds = 0;
+};
+static int batch_enqueue_impl(dv_batch* B) {
+    std::vector<dv_ctx*> M;
+    for (dv_ctx* c : B->members) if (c->be.pend->active && c->be.pend->deferred && !c->be.pend->trivial) M.push_back(c);
+    if (M.empty()) return 0;
+    dv_ctx* ctx = M[0];
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    bool uniform = true; int slots = M[0]->be.pend->first_slots, max_grid = 0, max_n = 0;
+    for (dv_ctx* c : M) {
+        const BePending& pd = *c->be.pend;
+        if (!pd.sa.ldl_wcol || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing)) uniform = false;
+        max_grid = std::max(max_grid, pd.ea.dims.nlm + pd.ea.dims.nimu + 1); max_n = std::max(max_n, pd.sa.dims.nstate);
+    }
+    if (!uniform || M.size() == 1) {      // mixed kernel variants (or nothing to share): every member on its own stream, as without a batch
+        for (dv_ctx* c : M) { BePending& pd = *c->be.pend; pd.deferred = false; if (be_enqueue_slots(c, pd, pd.first_slots, true, c->be_stream) || be_enqueue_tail(c, pd, c->be_stream)) { dv_set_error(ctx, c->err); return -1; } }
+        B->single_rounds++;
+        return 0;
+    }
+    const int S = (int)M.size();
+    BeEvalArgs* hea = (BeEvalArgs*)B->tab_pinned; BeSolveArgs* hsa = (BeSolveArgs*)(hea + B->members.size());
+    for (int i = 0; i < S; ++i) { hea[i] = M[i]->be.pend->ea; hsa[i] = M[i]->be.pend->sa; }
+    hipStream_t s = B->stream;
+    const BeEvalArgs* dea = (const BeEvalArgs*)B->tab.p; const BeSolveArgs* dsa = (const BeSolveArgs*)(dea + B->members.size());
+    DV_CHECK(hipMemcpyAsync(B->tab.p, B->tab_pinned, B->members.size() * (sizeof(BeEvalArgs) + sizeof(BeSolveArgs)), hipMemcpyHostToDevice, s));
+    for (int i = 0; i < S; ++i) {         // the members' uploads (and the marginalization of their previous frame) come first
+        DV_CHECK(hipEventRecord(B->ev_up[i], M[i]->be_stream));
+        DV_CHECK(hipStreamWaitEvent(s, B->ev_up[i], 0));
+    }
+    const bool two_level = M[0]->be.pend->sa.dims.pad != 0;
+    for (int it = 0; it < slots; ++it) {                  // be_enqueue_slots' speculative schedule, one launch per stage for all windows
+        const bool head = it == 0, last = it == slots - 1;
+        if (head) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_X, s); be_launch_reduce_batch(dsa, S, max_n, 0, s); }
+        if (be_launch_solve_batch(dsa, S, max_n, two_level, head ? 0 : 1, s)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
+        if (last) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s); be_launch_accept_batch(dsa, S, s); }
+        else { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); be_launch_reduce_batch(dsa, S, max_n, 1, s); }
+    }
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipEventRecord(B->ev_slots, s));
+    for (dv_ctx* c : M) {
+        BePending& pd = *c->be.pend;
+        pd.deferred = false; pd.t_enq = std::chrono::steady_clock::now();
+        DV_CHECK(hipStreamWaitEvent(c->be_stream, B->ev_slots, 0));
+        if (be_enqueue_tail(c, pd, c->be_stream)) { dv_set_error(ctx, c->err); return -1; }
+    }
+    B->batched_rounds++;
+    return 0;
+}
+
 int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused) {
     if (be_solve_fused_begin(ctx, P, fused)) return -1;
     return be_solve_fused_end(ctx, P, summary, fused);
@@ -507,6 +574,45 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
     if (ctx->est && ctx->be.prior_resident && P && P->prior && P->prior->valid && P->prior_A != ctx->be.priorA_buf[ctx->be.prior_cur])
         DV_FAIL("dv_ba_solve: this ctx's estimator holds a device-resident prior; use a separate ctx for operator-level calls");
     return be_solve_fused(ctx, P, summary, nullptr);
+}
+
+dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n) {
+    if (!ctxs || n < 1 || n > 256) { dv_set_error(nullptr, "dv_batch_create: bad arguments"); return nullptr; }
+    for (int i = 0; i < n; ++i) {
+        if (!ctxs[i] || ctxs[i]->batch || ctxs[i]->cfg.device != ctxs[0]->cfg.device || ctxs[i]->be.pend->active) { dv_set_error(nullptr, "dv_batch_create: members must be idle contexts of one device that belong to no other batch"); return nullptr; }
+        for (int j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) { dv_set_error(nullptr, "dv_batch_create: duplicate member"); return nullptr; }
+    }
+    if (hipSetDevice(ctxs[0]->cfg.device) != hipSuccess) { dv_set_error(nullptr, "dv_batch_create: hipSetDevice failed"); return nullptr; }
+    dv_batch* B = new dv_batch();
+    B->members.assign(ctxs, ctxs + n);
+    bool ok = hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&B->ev_slots, hipEventDisableTiming) == hipSuccess;
+    B->ev_up.assign(n, nullptr);
+    for (int i = 0; i < n && ok; ++i) ok = hipEventCreateWithFlags(&B->ev_up[i], hipEventDisableTiming) == hipSuccess;
+    const size_t bytes = (size_t)n * (sizeof(BeEvalArgs) + sizeof(BeSolveArgs));
+    ok = ok && B->tab.ensure(bytes) == hipSuccess && hipHostMalloc(&B->tab_pinned, bytes, hipHostMallocDefault) == hipSuccess;
+    if (!ok) { dv_set_error(nullptr, "dv_batch_create: out of resources"); dv_batch_destroy(B); return nullptr; }
+    for (int i = 0; i < n; ++i) ctxs[i]->batch = B;
+    return B;
+}
+void dv_batch_destroy(dv_batch* B) {
+    if (!B) return;
+    for (dv_ctx* c : B->members) if (c->batch == B) c->batch = nullptr;
+    if (B->stream) { (void)hipStreamSynchronize(B->stream); (void)hipStreamDestroy(B->stream); }
+    if (B->ev_slots) (void)hipEventDestroy(B->ev_slots);
+    for (hipEvent_t e : B->ev_up) if (e) (void)hipEventDestroy(e);
+    B->tab.release();
+    if (B->tab_pinned) (void)hipHostFree(B->tab_pinned);
+    delete B;
+}
+int dv_batch_enqueue(dv_batch* B) {
+    if (!B) return -1;
+    return batch_enqueue_impl(B);
+}
+int dv_batch_info(dv_batch* B, long long* batched_rounds, long long* single_rounds) {
+    if (!B) return -1;
+    if (batched_rounds) *batched_rounds = B->batched_rounds;
+    if (single_rounds) *single_rounds = B->single_rounds;
+    return 0;
 }
 
 // debug-only switches (not read from the environment): "short_first_pass" = enqueue max_iters - 2 slots first so that the spare-slot

@@ -28,7 +28,7 @@ extern "C" int dv_debug_ev_ts(long long* out) { return hipMemcpyFromSymbol(out, 
 #endif
 template <bool FULL>
 #define EV_THREADS 256
-__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) {
+__device__ __forceinline__ void be_eval_body(const BeEvalArgs& a, int mode, int b) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
     if (mode == BE_EVAL_X ? !c.need_eval : !c.pending) return;
@@ -37,7 +37,6 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
     double* const o_packets = a.packets[set]; double* const o_imu = a.imu_out[set]; double* const o_prior = a.prior_out[set];
     const bool want_cost = mode != BE_EVAL_X;
     const int lane = threadIdx.x;
-    const int b = blockIdx.x;
     const int nlm = a.dims.nlm, nimu = a.dims.nimu;
     if (b < nlm && (b < a.lm_lo || b >= a.lm_hi)) return;      // sharded window: another rank's landmark
     __shared__ FrameGeom fg[BE_NF];
@@ -228,6 +227,19 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int m
     }
 }
 
+template <bool FULL>
+__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL>(a, mode, blockIdx.x); }
+// batched form (several independent windows in one launch: blockIdx.y = window, argument table in HBM)
+template <bool FULL>
+__global__ __launch_bounds__(EV_THREADS) void be_eval_batch_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
+    const BeEvalArgs& a = tab[blockIdx.y];
+    if ((int)blockIdx.x >= a.dims.nlm + a.dims.nimu + 1) return;
+    be_eval_body<FULL>(a, mode, blockIdx.x);
+}
+void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s) {
+    if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_batch_kernel<true>, dim3(max_grid, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+    else hipLaunchKernelGGL(be_eval_batch_kernel<false>, dim3(max_grid, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+}
 void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s) {
     const int grid = a.dims.nlm + a.dims.nimu + 1;
     if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_kernel<true>, dim3(grid), dim3(EV_THREADS), 0, s, a, mode);

@@ -80,7 +80,7 @@ __device__ __forceinline__ double wave_sum(double v) {      // fixed xor tree: d
 
 // blocks [0, 121): pose block (fi, fj) of the reduced system — landmark sums read the transposed packets coalesced
 //                  (lane = landmark), wave-tree reduced; blocks [121, ..): every entry that has no landmark term.
-__global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, int spec) {
+__device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, int bx) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
     int set = c.cur; double mu = c.mu;
@@ -95,10 +95,10 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
     if (threadIdx.x == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
     __syncthreads();
     const RedCtx rc{ s_ifi, s_ifj, s_pr[0], s_pr[1] };
-    if (blockIdx.x == 0) RTS(0);
-    if (blockIdx.x == RED_PAIRS + 3) RTS(8);
-    if (blockIdx.x < RED_PAIRS) {
-        const int fi = blockIdx.x / BE_NF, fj = blockIdx.x - fi * BE_NF;
+    if (bx == 0) RTS(0);
+    if (bx == RED_PAIRS + 3) RTS(8);
+    if (bx < RED_PAIRS) {
+        const int fi = bx / BE_NF, fj = bx - fi * BE_NF;
         if (fi >= a.dims.nframes || fj >= a.dims.nframes) return;
         const int ci0 = a.dims.pose_col[fi], cj0 = a.dims.pose_col[fj];
         if (ci0 < 0 || cj0 < 0) return;
@@ -110,12 +110,12 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         const int l_lo = a.sh.on ? a.sh.lo : 0, l_hi = a.sh.on ? a.sh.hi : nlm;
         if (ci == 6 && !a.sh.on) {
 #ifdef BE_RED_TS
-            if (blockIdx.x == 0 && lane == 0) be_red_ts[16] = wall_clock64();
+            if (bx == 0 && lane == 0) be_red_ts[16] = wall_clock64();
 #endif
             if (lane < 36) s_dh[lane] = red_dense_h(a, rc, imu_out, ci0 + lane / 6, cj0 + lane % 6);
             else if (diag && lane < 42) s_dg[lane - 36] = red_dense_g(a, rc, imu_out, prior_out, ci0 + lane - 36);
 #ifdef BE_RED_TS
-            if (blockIdx.x == 0 && lane == 0) be_red_ts[17] = wall_clock64();
+            if (bx == 0 && lane == 0) be_red_ts[17] = wall_clock64();
 #endif
         }
         double S[6] = {0, 0, 0, 0, 0, 0}, H[6] = {0, 0, 0, 0, 0, 0}, G = 0, GS = 0;
@@ -147,12 +147,12 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
                 }
             }
         }
-        if (blockIdx.x == 0) RTS(1);
+        if (bx == 0) RTS(1);
 #pragma unroll
         for (int q = 0; q < 6; ++q) { S[q] = wave_sum(S[q]); H[q] = wave_sum(H[q]); }
         if (diag) { G = wave_sum(G); GS = wave_sum(GS); }
         __syncthreads();
-        if (blockIdx.x == 0) RTS(2);
+        if (bx == 0) RTS(2);
         if (ci == 6) return;
         if (a.sh.on) {            // sharded window: the partial landmark sums go to the exchange vector; be_shard_finalize_kernel adds the ranks up and the dense part in
             if (lane < 6) {
@@ -177,10 +177,10 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
             gvec[i] = G + s_dg[ci];
             gvec[n + i] = GS;
         }
-        if (blockIdx.x == 0) RTS(3);
+        if (bx == 0) RTS(3);
         return;
     }
-    const int eb = blockIdx.x - RED_PAIRS;
+    const int eb = bx - RED_PAIRS;
     const int n_dense = (n * n + n + RED_THREADS - 1) / RED_THREADS;
     if (eb >= n_dense) {          // sharded window only: pack the rows be_solve reads of every landmark, and the candidate costs, for the owned range
         const int row = eb - n_dense, cap = a.sh.cap;
@@ -205,9 +205,19 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, i
         if (a.col_kind[i] == 0) return;
         gvec[i] = red_dense_g(a, rc, imu_out, prior_out, i); gvec[n + i] = 0.0;
     }
-    if (blockIdx.x == RED_PAIRS + 3) RTS(9);
+    if (bx == RED_PAIRS + 3) RTS(9);
 }
 
+__global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, int spec) { be_reduce_body(a, spec, blockIdx.x); }
+__global__ __launch_bounds__(RED_THREADS) void be_reduce_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) {      // blockIdx.y = window
+    const BeSolveArgs& a = tab[blockIdx.y];
+    const int n = a.dims.nstate;
+    if ((int)blockIdx.x >= RED_PAIRS + (n * n + n + RED_THREADS - 1) / RED_THREADS) return;
+    be_reduce_body(a, spec, blockIdx.x);
+}
+void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s) {
+    hipLaunchKernelGGL(be_reduce_batch_kernel, dim3(RED_PAIRS + (max_n * max_n + max_n + RED_THREADS - 1) / RED_THREADS, n_win), dim3(RED_THREADS), 0, s, tab_dev, spec);
+}
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s) {
     const int n = a.dims.nstate;
     const int total = n * n + n;
@@ -924,7 +934,7 @@ __device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, doub
 }
 
 template <int NSLOT, bool WCOL>
-__global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) {
+__device__ __forceinline__ void be_solve_body(const BeSolveArgs& a, int spec) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     BeCtl* ctl = a.ctl;
     BeCtl c = *ctl;
@@ -1245,6 +1255,11 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, in
     }
 }
 
+template <int NSLOT, bool WCOL>
+__global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) { be_solve_body<NSLOT, WCOL>(a, spec); }
+template <int NSLOT, bool WCOL>
+__global__ __launch_bounds__(SOL_THREADS) void be_solve_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) { be_solve_body<NSLOT, WCOL>(tab[blockIdx.x], spec); }      // one workgroup per window
+
 static size_t solve_smem(int n, bool two_level, bool wcol) {
     const size_t tri = (size_t)n * (n + 1) / 2;
     return ((two_level && tri < FS_WORK ? (size_t)FS_WORK : tri) + 9 * (size_t)n + 72 + 80 + 8 + (wcol ? 3072 : 1536)) * sizeof(double);
@@ -1281,8 +1296,16 @@ int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
     return 0;
 }
 
+// batched: every window of the table must use the wave-column factorisation with the same dense order (checked by the caller); smem for the largest n
+int be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s) {
+    static DevOnce once;
+    if (once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_batch_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(168, false, true)) != hipSuccess ? 1 : 0; })) return -1;
+    hipLaunchKernelGGL((be_solve_batch_kernel<1, true>), dim3(n_win), dim3(SOL_THREADS), solve_smem(max_n, two_level, true), s, tab_dev, spec);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void be_accept_kernel(BeSolveArgs a) {
+__device__ __forceinline__ void be_accept_body(const BeSolveArgs& a) {
     BeCtl* ctl = a.ctl;
     const BeCtl c = *ctl;
     __shared__ double red[4];
@@ -1332,4 +1355,7 @@ __global__ __launch_bounds__(256) void be_accept_kernel(BeSolveArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void be_accept_kernel(BeSolveArgs a) { be_accept_body(a); }
+__global__ __launch_bounds__(256) void be_accept_batch_kernel(const BeSolveArgs* __restrict__ tab) { be_accept_body(tab[blockIdx.x]); }
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_accept_kernel, dim3(1), dim3(256), 0, s, a); }
+void be_launch_accept_batch(const BeSolveArgs* tab_dev, int n_win, hipStream_t s) { hipLaunchKernelGGL(be_accept_batch_kernel, dim3(n_win), dim3(256), 0, s, tab_dev); }

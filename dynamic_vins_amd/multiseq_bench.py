@@ -28,11 +28,18 @@ def run_multiseq_bench(args, rank, world, local_rank):
     pipes = [Pipeline(q, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"]) for q in seqs]
 
     threaded = bool(getattr(args, "sequence_threads", False))
+    batch = None
+    if getattr(args, "batched", False):
+        from .backend import Batch
+        batch = Batch([p.ctx for p in pipes])      # the window solves of all sequences share every launch (dv_batch)
+        threaded = False
     import threading
 
     def round_robin():
         for p in pipes:
             p.step_begin()
+        if batch is not None:
+            batch.enqueue()
         for p in pipes:
             p.step_end()
 
@@ -77,10 +84,13 @@ def run_multiseq_bench(args, rank, world, local_rank):
                "config": {"workload": f"{S} independent synthetic {w}x{h} stereo sequences per GPU @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "")
                                       + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame; a step = one frame of EVERY sequence",
                           "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S,
-                          "parallelism": f"{S} sequences per GPU " + ("on one host thread each" if threaded else "interleaved by one host thread") + f", own HIP streams, x {world} GPU(s); no collective",
+                          "parallelism": f"{S} sequences per GPU " + ("on one host thread each" if threaded else "interleaved by one host thread") + (", window solves batched (dv_batch: one launch per stage for all sequences)" if batch is not None else "") + f", own HIP streams, x {world} GPU(s); no collective",
+                          "batch": None if batch is None else batch.info(),
                           "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),
                           "ate_rmse_m_vs_ground_truth_max": round(max(ates), 5)},
                "roofline": None, "cpu_baseline": None}
         print(json.dumps(out))
+    if batch is not None:
+        batch.close()
     for p in pipes:
         p.ctx.close()

@@ -221,6 +221,17 @@ int dv_dist_info(dv_ctx* ctx, int* rank, int* world, int* transport, long long* 
  * is replaced by the rank-ordered sum over all ranks */
 int dv_allreduce_reduced_system(dv_ctx* ctx, double* S_g, int n);
 
+/* ---- several independent sequences on ONE GPU whose window solves share every launch ("batched") ----
+ * No counterpart in the reference (one process per sequence).  The members are ordinary contexts with their own estimators; after
+ * dv_est_process_begin (or _dynamic_begin) has been called on every member that has a frame, dv_batch_enqueue launches the iteration slots of all
+ * pending window solves as one launch per stage (argument tables in HBM, window index in the grid); dv_est_process_end then collects each member
+ * as usual.  A member collected without dv_batch_enqueue is solved on its own stream.  Results are bit-identical to the unbatched path. */
+typedef struct dv_batch dv_batch;
+dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n);      /* idle contexts of one device; NULL + dv_last_error(NULL) on failure */
+void dv_batch_destroy(dv_batch* batch);                      /* the members stay valid */
+int dv_batch_enqueue(dv_batch* batch);
+int dv_batch_info(dv_batch* batch, long long* batched_rounds, long long* single_rounds);
+
 /* Replaces MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks} as driven by
  * Estimator::SetMarginalizationInfo (estimator/estimator.cpp:403-619).
  *   mode 0 = kMarginOld: P holds the linearisation point (all 11 window states), the residual blocks of the landmarks

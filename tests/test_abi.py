@@ -18,7 +18,7 @@ def header_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
-    names = re.findall(r"^\s*(?:const\s+char\s*\*|dv_ctx\s*\*|int|void)\s+(dv_[a-z0-9_]+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|dv_ctx\s*\*|dv_batch\s*\*|int|void)\s+(dv_[a-z0-9_]+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -32,7 +32,7 @@ def test_header_declares_the_expected_surface():
     # the entry points SURVEY 8(b) lists for the boundary
     for must in ["dv_create", "dv_destroy", "dv_last_error", "dv_track_stereo", "dv_lk", "dv_gftt", "dv_ba_eval", "dv_ba_solve", "dv_marginalize",
                  "dv_est_create", "dv_est_input_imu", "dv_est_process", "dv_inst_proj_eval", "dv_allreduce_reduced_system", "dv_dist_init_rccl", "dv_dist_init_host",
-                 "dv_est_process_dynamic", "dv_inst_track_enqueue", "dv_est_set_lines"]:
+                 "dv_est_process_dynamic", "dv_inst_track_enqueue", "dv_est_set_lines", "dv_batch_create", "dv_batch_enqueue"]:
         assert must in names
     assert len(names) >= 27
 

@@ -28,14 +28,30 @@ def run_multiseq_bench(args, rank, world, local_rank):
     pipes = [Pipeline(q, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"]) for q in seqs]
 
     threaded = bool(getattr(args, "sequence_threads", False))
-    batch = None
+    batch = None; groups = None
     if getattr(args, "batched", False):
         from .backend import Batch
-        batch = Batch([p.ctx for p in pipes])      # the window solves of all sequences share every launch (dv_batch)
         threaded = False
+        if S >= 4:       # two alternating groups: while one group's batched solve runs on the GPU, the host collects / prepares the other one
+            half = S // 2
+            groups = [(pipes[:half], Batch([p.ctx for p in pipes[:half]])), (pipes[half:], Batch([p.ctx for p in pipes[half:]]))]
+        else:
+            batch = Batch([p.ctx for p in pipes])      # the window solves of all sequences share every launch (dv_batch)
     import threading
 
+    pending = [False, False]
+
     def round_robin():
+        if groups is not None:
+            for gi, (gp, gb) in enumerate(groups):
+                if pending[gi]:
+                    for p in gp:
+                        p.step_end()
+                for p in gp:
+                    p.step_begin()
+                gb.enqueue()
+                pending[gi] = True
+            return
         for p in pipes:
             p.step_begin()
         if batch is not None:
@@ -43,12 +59,21 @@ def run_multiseq_bench(args, rank, world, local_rank):
         for p in pipes:
             p.step_end()
 
+    def drain():
+        if groups is not None:
+            for gi, (gp, gb) in enumerate(groups):
+                if pending[gi]:
+                    for p in gp:
+                        p.step_end()
+                    pending[gi] = False
+
     def run_block(n_steps):
         """n_steps frames of every sequence: interleaved on this thread, or (--sequence-threads) one host thread per sequence — the C ABI releases the GIL,
         so the per-frame host work of the sequences (feature manager, problem assembly: ~0.5 ms) runs in parallel like the reference's per-process threads"""
         if not threaded:
             for _ in range(n_steps):
                 round_robin()
+            drain()
             return
 
         def worker(p):
@@ -85,12 +110,15 @@ def run_multiseq_bench(args, rank, world, local_rank):
                                       + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame; a step = one frame of EVERY sequence",
                           "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S,
                           "parallelism": f"{S} sequences per GPU " + ("on one host thread each" if threaded else "interleaved by one host thread") + (", window solves batched (dv_batch: one launch per stage for all sequences)" if batch is not None else "") + f", own HIP streams, x {world} GPU(s); no collective",
-                          "batch": None if batch is None else batch.info(),
+                          "batch": (None if batch is None else batch.info()) if groups is None else dict(groups=2, **groups[0][1].info()),
                           "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),
                           "ate_rmse_m_vs_ground_truth_max": round(max(ates), 5)},
                "roofline": None, "cpu_baseline": None}
         print(json.dumps(out))
     if batch is not None:
         batch.close()
+    if groups is not None:
+        for _, gb in groups:
+            gb.close()
     for p in pipes:
         p.ctx.close()

@@ -31,8 +31,9 @@ def run_multiseq_bench(args, rank, world, local_rank):
     batch = None; groups = None
     if getattr(args, "batched", False):
         from .backend import Batch
-        threaded = False
-        if S >= 4:       # two alternating groups: while one group's batched solve runs on the GPU, the host collects / prepares the other one
+        if threaded:     # one host thread per sequence for the host phases, meeting at a barrier around the single dv_batch_enqueue of the round
+            batch = Batch([p.ctx for p in pipes])
+        elif S >= 4:       # two alternating groups: while one group's batched solve runs on the GPU, the host collects / prepares the other one
             half = S // 2
             groups = [(pipes[:half], Batch([p.ctx for p in pipes[:half]])), (pipes[half:], Batch([p.ctx for p in pipes[half:]]))]
         else:
@@ -76,9 +77,18 @@ def run_multiseq_bench(args, rank, world, local_rank):
             drain()
             return
 
+        bar = threading.Barrier(len(pipes)) if batch is not None else None
+
         def worker(p):
             for _ in range(n_steps):
-                p.step()
+                if bar is None:
+                    p.step()
+                    continue
+                p.step_begin()
+                if bar.wait() == 0:
+                    batch.enqueue()
+                bar.wait()
+                p.step_end()
         ths = [threading.Thread(target=worker, args=(p,)) for p in pipes]
         for t in ths:
             t.start()

@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, HIP-event timed
 `cpu_baseline` (the CPU oracle = restated reference path, bounded sample, rank 0, N = 1 only).
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -24,6 +25,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+T_PROCESS_START = time.perf_counter()
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -83,6 +85,7 @@ def main():
     ap.add_argument("--blocks", type=int, default=2, help="consecutive timed blocks of --steps frames (the first is `value`; all are listed in config.block_values)")
     ap.add_argument("--timing-block", type=int, default=1, help="which block the instrumented (per-kernel HIP events) pass times")
     ap.add_argument("--objects", type=int, default=3, help="--mode dynamic: number of moving boxes in the scene (dynsim.ring_boxes)")
+    ap.add_argument("--prealloc-mb", type=int, default=0, help="debug: allocate (and keep) this much device memory before the sequence is rendered (shifts where the frames land in HBM)")
     ap.add_argument("--debug-set", default="", help="comma-separated dv_debug_set keys to switch on in every context (A/B runs of kernel variants, e.g. ldl_generic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=16)
@@ -129,6 +132,7 @@ def main():
     n_frames = (warm_ba + max(2, args.blocks) * args.steps) * stride + 2
     cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
     dev = f"cuda:{local_rank}"
+    _pad = torch.empty(args.prealloc_mb << 20, dtype=torch.uint8, device=dev) if args.prealloc_mb > 0 else None
     if args.mode == "dynamic":
         from dynamic_vins_amd import dynsim
         seq = DynamicSequence(w, h, cam, n_frames, rate=20.0, device=dev, boxes=None if args.objects == 3 else dynsim.ring_boxes(args.objects))
@@ -141,12 +145,17 @@ def main():
         return Pipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"], host_frames=args.host_frames,
                         ba_stride=stride)
 
+    frame_ms = []
+
     def run(kernel_timing, collective=True, blocks=2):       # collective=False: rank-0-only pass, no barriers
         pipe = make_pipe()
         for key in filter(None, args.debug_set.split(",")):
             assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
         for _ in range(warm_ba * stride):
             pipe.step()
+        # A generation-2 collection of the interpreter's ~10^6 objects (torch, numpy) is a ~60 ms pause that lands in a random block (seen as ONE 63 ms step
+        # in config.block_step_ms): collect now and move everything that exists to the permanent generation, as timeit does by disabling the collector.
+        gc.collect(); gc.freeze()
         times, iters = [], 0
         for _b in range(blocks):             # two consecutive blocks of `steps` frames: a cold first block shows up instead of lowering the headline
             if kernel_timing and _b == blocks - 1:
@@ -156,14 +165,19 @@ def main():
                 dv_dist.barrier()
             torch.cuda.synchronize(); pipe.ctx.sync()
             t0 = time.perf_counter()
+            marks = [t0]
             for _ in range(args.steps):
                 for _s in range(stride):
                     st = pipe.step()
                 iters += st.iterations
+                marks.append(time.perf_counter())      # host clock only: where inside a block the time goes (uniform slow-down or bursts)
             pipe.ctx.sync(); torch.cuda.synchronize()
             if collective:
                 dv_dist.barrier()
             times.append(time.perf_counter() - t0)
+            d = np.diff(marks) * 1e3
+            frame_ms.append({"p50": round(float(np.median(d)), 3), "p95": round(float(np.percentile(d, 95)), 3), "max": round(float(d.max()), 3),
+                             "t_since_start_s": round(t0 - T_PROCESS_START, 2)})
         return pipe, times, iters
 
     pipe, times, iters = run(False, blocks=max(2, args.blocks))
@@ -313,6 +327,7 @@ def main():
                 "ate_rmse_m_vs_oracle": None if ate_vs_oracle is None else float(f"{ate_vs_oracle:.3e}"),
                 "second_block_ms_per_step": round(times[1] / args.steps * 1e3, 4), "second_block_value": round(dv_dist.whole_job_rate(args.steps, world, times[1]), 2),
                 "block_values": [round(dv_dist.whole_job_rate(args.steps, world, t), 2) for t in times],
+                "block_step_ms": frame_ms[: len(times)],
                 "warmup_requested": args.warmup, "git_head": git_head(),
                 "warmup_note": "at least 12 untimed BA frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"}
         if dyn_info:

@@ -4,6 +4,7 @@ The window solve of a single sequence is a chain of ~30 latency-bound launches t
 it on their own streams.  The host interleaves the sequences through the two-phase API (Pipeline.step_begin / step_end = dv_track_stereo_enqueue / _collect +
 dv_est_process_begin / _end): while sequence A's BA is in flight it prepares and enqueues B, C, ...  `value` is the AGGREGATE frame rate of the S sequences
 on this GPU (x N ranks for --gpus N); the single-sequence rate stays bench.py's default line."""
+import gc
 import json
 import os
 import time
@@ -96,6 +97,7 @@ def run_multiseq_bench(args, rank, world, local_rank):
             t.join()
 
     run_block(warm_ba)
+    gc.collect(); gc.freeze()      # no generation-2 pause of the interpreter inside a timed block (bench.py)
     times = []
     for _b in range(2):
         dv_dist.barrier()

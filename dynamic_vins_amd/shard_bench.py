@@ -4,6 +4,7 @@ Every rank runs the same front end on the same frames (the tracker is not sharde
 window solve; per linearisation the ranks all-gather one exchange vector (partial reduced camera system + the packet rows be_solve needs) and sum in rank
 order.  `value` is the frame rate of the ONE sequence ("scaling": "strong"); the same line carries the unsharded rate measured in the same process, so the
 cost of sharding a ~300-landmark window is on record: it is NOT expected to pay — the deliverable is correctness plus this curve."""
+import gc
 import json
 import os
 import time
@@ -32,6 +33,7 @@ def run_shard_bench(args, rank, world, local_rank):
             dv_dist.shard_window(pipe.ctx, rank, world, transport="host" if gloo else "rccl")
         for _ in range(warm_ba):
             pipe.step()
+        gc.collect(); gc.freeze()      # no generation-2 pause of the interpreter inside a timed block (bench.py)
         times = []
         for _b in range(2):
             if collective:

@@ -933,332 +933,17 @@ __device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, doub
     else bs_chunk<2, ROWS>(Lm, kt, lane, x0, x1, x2);
 }
 
+// The body lives in be_solve_body.inc and is included textually: called through a function taking `const BeSolveArgs&` the single-window kernel lost 4 %
+// (99.2 vs 95.2 us; the by-value kernel arguments stopped being treated as invariant scalar loads).
 template <int NSLOT, bool WCOL>
-__device__ __forceinline__ void be_solve_body(const BeSolveArgs& a, int spec) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    BeCtl* ctl = a.ctl;
-    BeCtl c = *ctl;
-    if (c.done) return;
-    const int n = a.dims.nstate, nlm = a.dims.nlm, tid = threadIdx.x;
-    if (spec && c.pending) {
-        // ---- decision on the candidate of the previous slot: be_accept_kernel's rule, taken here because the candidate's linearisation
-        // (set cur ^ 1) is already in place.  Every thread evaluates the same scalars; thread 0 publishes the control block. ----
-        __shared__ double red4[4];
-        const int ncost = nlm + a.dims.nimu + 1;
-        double part = 0;
-        if (tid < 256) for (int k = tid; k < ncost; k += 256) part += a.cand_cost[k];      // the summation tree of be_accept_kernel, bit for bit
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
-        if (tid < 256 && (tid & 63) == 0) red4[tid >> 6] = part;
-        __syncthreads();
-        const double cand_cost = red4[0] + red4[1] + red4[2] + red4[3];
-        c.slots += 1; c.iter += 1; c.cand_cost = cand_cost; c.invalid = 0; c.pending = 0;
-        bool done = false, accept = false; int term = 0;
-        if (c.step_norm <= 1e-8 * (c.x_norm + 1e-8)) { done = true; term = 1; }                       // parameter tolerance
-        else if (fabs(c.x_cost - cand_cost) <= 1e-6 * c.x_cost) { done = true; term = 1; }           // function tolerance
-        else {
-            const double rel = (c.x_cost - cand_cost) / c.model_cost_change;
-            if (rel > 1e-3) {
-                accept = true;
-                double radius = c.radius;
-                if (rel < 0.25) radius *= 0.5;
-                if (rel > 0.75) radius = fmax(radius, 3.0 * c.dogleg_norm);
-                c.radius = radius; c.mu = fmax(1e-8, 2.0 * c.mu / 10.0);
-                c.x_cost = cand_cost; c.successful += 1; c.reuse = 0; c.need_eval = 0; c.cur ^= 1;      // the candidate's set becomes x's
-            } else {
-                c.radius = c.radius * 0.5; c.reuse = 1; c.need_eval = 0;
-                if (c.radius < 1e-32) { done = true; term = 1; }
-            }
-            if (!done && c.iter >= c.max_iters) { done = true; term = 0; }
-        }
-        if (accept) {
-            double* dst = reinterpret_cast<double*>(a.x);
-            const double* src = reinterpret_cast<const double*>(a.cand);
-            const int used = (int)(offsetof(BeState, inv_depth) / sizeof(double)) + nlm;
-            for (int k = tid; k < used; k += SOL_THREADS) dst[k] = src[k];
-        }
-        if (done) { c.done = 1; c.termination = term; }
-        if (tid == 0) *ctl = c;
-        if (done) return;
-        __syncthreads();          // x is re-read below
-    }
-    const int npk = a.dims.pad ? FS_WORK : n * (n + 1) / 2;      // two-level path: its carve (schur_sb_solve) instead of the packed 165 x 165 factor
-    double* Lm = sm;                                   // npk: unit-lower factor, packed row-major
-    double* v_s = Lm + npk;                            // scale
-    double* v_d = v_s + n;                             // diag
-    double* v_grad = v_d + n;
-    double* v_gn = v_grad + n;
-    double* v_t = v_gn + n;                            // u_p / s.y / delta_p
-    double* v_t2 = v_t + n;                            // H * v_t
-    double* v_x = v_t2 + n;                            // back-substitution vector
-    double* zfin = v_x + n;                            // L^-1 rhs
-    double* dvec = zfin + n;                           // D
-    double* q66 = dvec + n;                            // 66 (+6 pad): v_t gathered into packet (frame, comp) order
-    double* red = q66 + 72;                            // 80: block-sum exchange (16 per value)
-    double* misc = red + 80;                           // 8: [0] alpha
-    double* scratch = misc + 8;                        // 3072: gemv partial sums, aliased with the LDL^T panel buffers (two alternating sets in the wave-column form)
-    double* PL = scratch, *PD = scratch + 4 * 184;     // panel of L and of L D, [row][4]
-    double* dinfo = red;                               // 2 x 16 (red[] is idle during the factorisation)
-    __shared__ int s_fail;
-    const double mu = c.mu;
-    const double* pk = a.packets[c.cur];
-    const double* const Hd = a.Hd[c.cur]; const double* const gvec = a.gvec[c.cur];
-    const double* const imu_out = a.imu_out[c.cur]; const double* const prior_out = a.prior_out[c.cur];
-    auto gather66 = [&](const double* v) {             // q66[a*6+r] = v[pose_col[a] + r] (0 for constant / absent poses)
-        if (tid < 66) { const int fa = tid / 6, r = tid - fa * 6; const int col = fa < a.dims.nframes ? a.dims.pose_col[fa] : -1; q66[tid] = col >= 0 ? v[col + r] : 0.0; }
-        __syncthreads();
-    };
-    // wd[l] = w_l . q66 for every landmark: the 66 terms are split over npart thread groups (lane = landmark, so the
-    // packet reads stay coalesced); partial sums meet in LDS and are added in a fixed order.  Result in scratch[l].
-    const int nlm_pad = (nlm + 63) & ~63;
-    const int npart = nlm_pad * 6 <= SOL_THREADS ? 6 : (nlm_pad * 3 <= SOL_THREADS ? 3 : (nlm_pad * 2 <= SOL_THREADS ? 2 : 1));
-    auto wdot_all = [&]() {
-        const int per = 66 / npart;
-        if (npart > 1) {
-            const int part = tid / nlm_pad, l = tid - part * nlm_pad;
-            if (part < npart && l < nlm) {
-                double s0 = 0;
-                const int q0 = part * per;
-#pragma unroll 11
-                for (int q = 0; q < per; ++q) s0 += BE_PK(pk, BE_PK_W + q0 + q, l) * q66[q0 + q];
-                scratch[part * nlm_pad + l] = s0;
-            }
-            __syncthreads();
-            if (tid < nlm) { double s0 = scratch[tid]; for (int p = 1; p < npart; ++p) s0 += scratch[p * nlm_pad + tid]; scratch[tid] = s0; }
-        } else {
-            for (int l = tid; l < nlm; l += SOL_THREADS) {
-                double s0 = 0;
-#pragma unroll 11
-                for (int q = 0; q < 66; ++q) s0 += BE_PK(pk, BE_PK_W + q, l) * q66[q];
-                scratch[l] = s0;
-            }
-        }
-        __syncthreads();
-    };
-    const double* wd = scratch;
-    TS(0);
-    LdlRaw ldl_raw;
-    // the blocks of the reduced system were written by other XCDs: touching this thread's 128-byte block now turns the loads of the factorisation (after the
-    // scaling phase) into local L2 hits.  Only one double stays live (the whole block would spill: 128 VGPRs at 1024 threads).
-    double ldl_warm = 0.0;
-    if (WCOL && !c.reuse) { const int nb = ((n + 3) >> 2) * (((n + 3) >> 2) + 1) / 2; ldl_warm = __builtin_nontemporal_load(a.Sc[c.cur] + (size_t)(tid < nb ? tid : 0) * 16); }
-    if (!c.reuse) {
-        // ---------------- scaling, diagonal, gradient ----------------
-        for (int i = tid; i < n; i += SOL_THREADS) {
-            const double hii = Hd[(size_t)i * n + i];
-            const double s = c.first ? 1.0 / (1.0 + sqrt(hii)) : a.scale_p[i];
-            double d2 = hii * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
-            const double d = sqrt(d2);
-            v_s[i] = s; v_d[i] = d; v_grad[i] = gvec[i] * s / d;
-            if (c.first) a.scale_p[i] = s;
-            a.diag_p[i] = d; a.grad_p[i] = v_grad[i];
-        }
-        __syncthreads();
-        // cost at x, gradient tolerance and the landmark part of the diagonal: none of it feeds the factorisation, so the wave-column form runs it BEHIND the
-        // factorisation (the prefetched blocks need not stay in registers across three block reductions)
-        auto cost_and_tolerance = [&]() -> bool {
-            if (c.first) {        // x_cost: fixed-order sum of the per-block costs at x
-                double part = 0;
-                for (int l = tid; l < nlm; l += SOL_THREADS) part += BE_PK(pk, BE_PK_COST, l);
-                for (int k = tid; k < a.dims.nimu; k += SOL_THREADS) part += imu_out[(size_t)k * IMU_OUT_STRIDE];
-                if (tid == 0) part += prior_out[0];
-                const double xc = block_sum(part, red);
-                if (tid == 0) { ctl->x_cost = xc; ctl->initial_cost = xc; }
-            }
-            // gradient tolerance (trust_region_minimizer.cc: gradient_max_norm <= gradient_tolerance = 1e-10), checked on every new gradient
-            {
-                double gm = 0;
-                for (int i = tid; i < n; i += SOL_THREADS) gm = fmax(gm, fabs(gvec[i]));
-                for (int l = tid; l < nlm; l += SOL_THREADS) gm = fmax(gm, fabs(BE_PK(pk, BE_PK_G, l)));
-    #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) gm = fmax(gm, __shfl_xor(gm, o));
-                __syncthreads();
-                if ((tid & 63) == 0) red[tid >> 6] = gm;
-                __syncthreads();
-                gm = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) gm = fmax(gm, red[k]);
-                __syncthreads();
-                if (gm <= 1e-10) { if (tid == 0) { ctl->done = 1; ctl->termination = 1; ctl->first = 0; } return true; }
-            }
-            TS(1);
-            // landmark part of the diagonal and of the scaled gradient (the Cauchy point itself is computed lazily, see below)
-            for (int l = tid; l < nlm; l += SOL_THREADS) {
-                const double h = BE_PK(pk, BE_PK_H, l), gl = BE_PK(pk, BE_PK_G, l), s = a.scale_l[l];
-                double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
-                const double d = sqrt(d2);
-                a.diag_l[l] = d; a.grad_l[l] = gl * s / d;
-            }
-            return false;
-        };
-        if (!WCOL) { if (cost_and_tolerance()) return; }
-        TS(3);
-        // ---------------- Gauss-Newton step: LDL^T of the Schur complement ----------------
-        const bool two_level = a.dims.pad != 0;            // VIO window with the block-tridiagonal speed-bias structure (decided on the host)
-        double* LmUse = Lm; int nfact = n;
-        bool ok_f;
-        SbSweep sw = sw_carve(Lm, a.dims.nframes);
-        if (two_level && WCOL) {
-            // speed-bias blocks first (block steps on register / LDS resident entries), then the dense pose block on the wave-column factorisation
-            ok_f = sb_sweep(a, a.Sc[c.cur], gvec, n, mu, v_s, v_d, sw, &s_fail);
-            if (ok_f) {
-                ldl_build_map(a.ldl_col0p, sw.np, reinterpret_cast<int*>(scratch));
-                { const int m = reinterpret_cast<const int*>(scratch)[tid]; ldl_raw.bi = m < 0 ? -1 : (m >> 8); ldl_raw.bj = m < 0 ? -1 : (m & 255); }
-                __syncthreads();
-                ok_f = ldlt_wavecol(a, ldl_raw, gvec, sw.np, mu, v_s, v_d, sw.PP, scratch, dinfo, zfin, dvec, &s_fail, sw.PP, sw.rp);
-            }
-            LmUse = sw.PP; nfact = sw.np;
-        }
-        else if (WCOL) { if (ldl_warm == 1.2345e-300) misc[7] = ldl_warm; ldl_build_map(a.ldl_col0, n, reinterpret_cast<int*>(scratch)); ldl_prefetch(reinterpret_cast<const int*>(scratch), a.Sc[c.cur], n, ldl_raw); __syncthreads(); ok_f = ldlt_wavecol(a, ldl_raw, gvec, n, mu, v_s, v_d, Lm, scratch, dinfo, zfin, dvec, &s_fail); }
-        else ok_f = ldlt_blocked<NSLOT>(a.Sc[c.cur], gvec, n, mu, v_s, v_d, Lm, PL, PD, dinfo, zfin, dvec, &s_fail);
-        if (WCOL) { if (cost_and_tolerance()) return; }
-        if (!ok_f) {
-            // Ceres: LINEAR_SOLVER_FAILURE -> mu *= 10 and retry (dogleg_strategy.cc ComputeGaussNewtonStep)
-            if (tid == 0) {
-                ctl->mu = mu * 10.0; ctl->chol_fail = 1; ctl->first = 0; ctl->alpha_valid = 0;
-                ctl->slots = c.slots + 1; ctl->reuse = 0; ctl->need_eval = 0; ctl->pending = 0;      // the slot is spent; the next reduce rebuilds Sc with the larger mu
-                if (mu * 10.0 > 1.0) { ctl->done = 1; ctl->termination = 2; }
-            }
-            return;
-        }
-        TS(6);
-        // back substitution L^T x = D^-1 z on ONE wave with x distributed over lanes (3 registers cover n <= 192):
-        // the pivot is broadcast with v_readlane, row k-1 of L is prefetched from LDS while row k is applied.
-        if (tid < 64) {
-            const int lane = tid, nn = nfact;
-            double x0 = lane < nn ? zfin[lane] / dvec[lane] : 0.0;
-            double x1 = 64 + lane < nn ? zfin[64 + lane] / dvec[64 + lane] : 0.0;
-            double x2 = 128 + lane < nn ? zfin[128 + lane] / dvec[128 + lane] : 0.0;
-            int k = nn - 1;
-            for (; k >= 0 && ((k + 1) & 7); --k) bs_rows<1>(LmUse, k, lane, x0, x1, x2);      // until the chunks are 8-aligned (a chunk never straddles a segment)
-            for (; k >= 7; k -= 8) bs_rows<8>(LmUse, k, lane, x0, x1, x2);
-            if (lane < nn) v_x[lane] = x0;
-            if (64 + lane < nn) v_x[64 + lane] = x1;
-            if (128 + lane < nn) v_x[128 + lane] = x2;
-        }
-        __syncthreads();
-        TS(24);
-        if (two_level && WCOL) sb_back(a, n, sw, v_x);
-        TS(7);
-        for (int i = tid; i < n; i += SOL_THREADS) { v_gn[i] = -v_d[i] * v_x[i]; a.gn_p[i] = v_gn[i]; v_t[i] = v_s[i] * v_x[i]; }   // v_t = s_p . y_p
-        __syncthreads();
-        gather66(v_t);
-        wdot_all();
-        for (int l = tid; l < nlm; l += SOL_THREADS) {
-            const double h = BE_PK(pk, BE_PK_H, l), s = a.scale_l[l], d = a.diag_l[l];
-            const double rho = 1.0 / (h + mu * d * d / (s * s));
-            const double yl = rho / s * (BE_PK(pk, BE_PK_G, l) - wd[l]);
-            a.gn_l[l] = -d * yl;
-        }
-        __syncthreads();
-    } else {
-        for (int i = tid; i < n; i += SOL_THREADS) { v_s[i] = a.scale_p[i]; v_d[i] = a.diag_p[i]; v_grad[i] = a.grad_p[i]; v_gn[i] = a.gn_p[i]; }
-        __syncthreads();
-    }
-    TS(8);
-    // ---------------- traditional dogleg (dogleg_strategy.cc ComputeTraditionalDoglegStep) ----------------
-    double p_gg = 0, p_nn = 0, p_gn = 0;
-    for (int i = tid; i < n; i += SOL_THREADS) { p_gg += v_grad[i] * v_grad[i]; p_nn += v_gn[i] * v_gn[i]; p_gn += v_grad[i] * v_gn[i]; }
-    for (int l = tid; l < nlm; l += SOL_THREADS) { const double g = a.grad_l[l], q = a.gn_l[l]; p_gg += g * g; p_nn += q * q; p_gn += g * q; }
-    double sv3[3] = {p_gg, p_nn, p_gn};
-    block_sum_n<3>(sv3, red);
-    const double gnorm = sqrt(sv3[0]), gnn = sqrt(sv3[1]), gdot = sv3[2];
-    const double radius = c.radius;
-    // Cauchy point alpha = |gradient_|^2 / (u^T H u), u = S (gradient_ / diag): only the dogleg's second and third case read it, so it is
-    // computed when the Gauss-Newton step first leaves the trust region (possibly slots later, after rejections: the linearisation of x
-    // is still in place) and kept in the control block from then on.  Same arithmetic whenever it is evaluated.
-    double alpha = c.alpha;
-    bool have_alpha = c.reuse && c.alpha_valid;
-    if (!(gnn <= radius) && !have_alpha) {
-        for (int i = tid; i < n; i += SOL_THREADS) { const double sp = v_s[i], dp = v_d[i]; v_t[i] = sp * sp * gvec[i] / (dp * dp); }
-        __syncthreads();
-        gemv_hd(Hd, n, v_t, v_t2, scratch, tid);
-        gather66(v_t);
-        wdot_all();
-        double uHu = 0, gg = 0;
-        for (int i = tid; i < n; i += SOL_THREADS) { uHu += v_t[i] * v_t2[i]; gg += v_grad[i] * v_grad[i]; }
-        for (int l = tid; l < nlm; l += SOL_THREADS) {
-            const double h = BE_PK(pk, BE_PK_H, l), gl = BE_PK(pk, BE_PK_G, l), sl = a.scale_l[l], dl = a.diag_l[l], grad = a.grad_l[l];
-            const double u = sl * sl * gl / (dl * dl);
-            uHu += 2.0 * u * wd[l] + h * u * u;
-            gg += grad * grad;
-        }
-        { double sv2[2] = {uHu, gg}; block_sum_n<2>(sv2, red); uHu = sv2[0]; gg = sv2[1]; }
-        alpha = gg / uHu;
-        have_alpha = true;
-        __syncthreads();
-    }
-    if (tid == 0) { ctl->alpha = alpha; ctl->alpha_valid = have_alpha ? 1 : 0; }
-    double cg, cn, dnorm;
-    if (gnn <= radius) { cg = 0; cn = 1; dnorm = gnn; }
-    else if (gnorm * alpha >= radius) { cg = -(radius / gnorm); cn = 0; dnorm = radius; }
-    else {
-        const double b_dot_a = -alpha * gdot, a2 = (alpha * gnorm) * (alpha * gnorm), bma2 = a2 - 2 * b_dot_a + gnn * gnn;
-        const double cc = b_dot_a - a2, dd = sqrt(cc * cc + bma2 * (radius * radius - a2));
-        const double beta = (cc <= 0) ? (dd - cc) / bma2 : (radius * radius - a2) / (dd + cc);
-        cg = -alpha * (1.0 - beta); cn = beta; dnorm = -1.0;
-    }
-    // delta = (cg*grad + cn*gn) / diag * scale   (v_t = delta_p)
-    double p_dn = 0;
-    for (int i = tid; i < n; i += SOL_THREADS) { const double st = cg * v_grad[i] + cn * v_gn[i]; p_dn += st * st; v_t[i] = st / v_d[i] * v_s[i]; }
-    __syncthreads();
-    TS(9);
-    gemv_hd(Hd, n, v_t, v_t2, scratch, tid);
-    TS(11);
-    gather66(v_t);
-    wdot_all();
-    TS(12);
-    double p_sg = 0, p_sHs = 0, p_step = 0, p_xn = 0;
-    for (int i = tid; i < n; i += SOL_THREADS) { p_sg += v_t[i] * gvec[i]; p_sHs += v_t[i] * v_t2[i]; }
-    for (int l = tid; l < nlm; l += SOL_THREADS) {
-        const double st = cg * a.grad_l[l] + cn * a.gn_l[l];
-        p_dn += st * st;
-        const double dl = st / a.diag_l[l] * a.scale_l[l];
-        p_sg += dl * BE_PK(pk, BE_PK_G, l);
-        p_sHs += 2.0 * dl * wd[l] + BE_PK(pk, BE_PK_H, l) * dl * dl;
-        const double x0 = a.x->inv_depth[l];
-        a.cand->inv_depth[l] = x0 + dl;
-        p_step += dl * dl; p_xn += x0 * x0;
-    }
-    // candidate poses / speed-bias
-    for (int f = tid; f < BE_NF; f += SOL_THREADS) {
-        const int pc = f < a.dims.nframes ? a.dims.pose_col[f] : -1, sc = f < a.dims.nframes ? a.dims.sb_col[f] : -1;
-        if (pc >= 0) {
-            double out[7];
-            pose_plus(a.x->pose[f], &v_t[pc], a.dims.plane_kind, out);
-            for (int k = 0; k < 7; ++k) { const double d = out[k] - a.x->pose[f][k]; p_step += d * d; p_xn += a.x->pose[f][k] * a.x->pose[f][k]; a.cand->pose[f][k] = out[k]; }
-        } else for (int k = 0; k < 7; ++k) a.cand->pose[f][k] = a.x->pose[f][k];
-        if (sc >= 0) for (int k = 0; k < 9; ++k) { const double d = v_t[sc + k]; p_step += d * d; p_xn += a.x->sb[f][k] * a.x->sb[f][k]; a.cand->sb[f][k] = a.x->sb[f][k] + d; }
-        else for (int k = 0; k < 9; ++k) a.cand->sb[f][k] = a.x->sb[f][k];
-    }
-    if (tid == 0) { for (int k = 0; k < 14; ++k) a.cand->ex[k / 7][k % 7] = a.x->ex[k / 7][k % 7]; a.cand->td = a.x->td; }
-    TS(13);
-    double sv5[5] = {p_dn, p_sg, p_sHs, p_step, p_xn};
-    block_sum_n<5>(sv5, red);
-    const double dn2 = sv5[0], sg = sv5[1], sHs = sv5[2], step2 = sv5[3], xn2 = sv5[4] + a.xnorm2_extra;
-    TS(10);
-    if (tid == 0) {
-        const double mcc = -(sg + 0.5 * sHs);
-        ctl->model_cost_change = mcc;
-        ctl->dogleg_norm = dnorm >= 0 ? dnorm : sqrt(dn2);
-        ctl->step_valid = mcc > 0.0 ? 1 : 0;
-        ctl->step_norm = sqrt(step2);
-        ctl->x_norm = sqrt(xn2);
-        ctl->chol_fail = 0;
-        ctl->first = 0;
-        if (mcc > 0.0) ctl->pending = 1;            // the candidate awaits its cost and the accept / reject decision
-        else {                                      // HandleInvalidStep: needs no evaluation, so it is settled here
-            ctl->pending = 0;
-            ctl->slots = c.slots + 1; ctl->iter = c.iter + 1; ctl->invalid = c.invalid + 1; ctl->mu = c.mu * 10.0; ctl->reuse = 0; ctl->need_eval = 0;
-            ctl->chol_fail = 1;                     // forces the reduce to rebuild Sc with the new mu
-            if (c.invalid + 1 >= 5) { ctl->done = 1; ctl->termination = 2; }
-            else if (c.iter + 1 >= c.max_iters) { ctl->done = 1; ctl->termination = 0; }
-        }
-    }
+__global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) {
+#include "be_solve_body.inc"
 }
-
 template <int NSLOT, bool WCOL>
-__global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) { be_solve_body<NSLOT, WCOL>(a, spec); }
-template <int NSLOT, bool WCOL>
-__global__ __launch_bounds__(SOL_THREADS) void be_solve_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) { be_solve_body<NSLOT, WCOL>(tab[blockIdx.x], spec); }      // one workgroup per window
+__global__ __launch_bounds__(SOL_THREADS) void be_solve_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) {      // one workgroup per window
+    const BeSolveArgs& a = tab[blockIdx.x];
+#include "be_solve_body.inc"
+}
 
 static size_t solve_smem(int n, bool two_level, bool wcol) {
     const size_t tri = (size_t)n * (n + 1) / 2;

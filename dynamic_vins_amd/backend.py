@@ -416,6 +416,11 @@ class Batch:
         if self.lib.dv_batch_enqueue(self.h) != 0:
             raise DvinsError(self.lib.dv_last_error(self.ctxs[0].h).decode())
 
+    def arrive(self):
+        """rendezvous of one host thread per member (the ctypes call releases the GIL while it waits)"""
+        if self.lib.dv_batch_arrive(self.h) != 0:
+            raise DvinsError(self.lib.dv_last_error(self.ctxs[0].h).decode())
+
     def info(self):
         a, b = C.c_longlong(0), C.c_longlong(0)
         self.lib.dv_batch_info(self.h, C.byref(a), C.byref(b))

@@ -1,6 +1,8 @@
 // be_api.hip — host side of the bundle-adjustment entry points of include/dvins.h: uploads the flat problem
 // tables, enqueues the fixed kernel schedule of the trust-region loop on the ctx's BA stream (no host round trip
 // between iterations: every kernel is predicated on the device-resident BeCtl) and downloads the solved states.
+#include <condition_variable>
+#include <mutex>
 #include "dv_ctx.h"
 #include "be_kernels.h"
 
@@ -513,6 +515,7 @@ struct dv_batch {
     hipStream_t stream = nullptr; hipEvent_t ev_slots = nullptr; std::vector<hipEvent_t> ev_up;
     DevBuf tab; void* tab_pinned = nullptr;       // [S] BeEvalArgs | [S] BeSolveArgs
     long long batched_rounds = 0, single_rounds = 0;
+    std::mutex mu; std::condition_variable cv; int arrived = 0; long long generation = 0; int last_rc = 0;      // dv_batch_arrive
 };
 static int batch_enqueue_impl(dv_batch* B) {
     std::vector<dv_ctx*> M;
@@ -607,6 +610,22 @@ void dv_batch_destroy(dv_batch* B) {
 int dv_batch_enqueue(dv_batch* B) {
     if (!B) return -1;
     return batch_enqueue_impl(B);
+}
+// Rendezvous form for one host thread per member: every thread calls it after its member's dv_est_process_begin; the call returns in all of them once the
+// last one has arrived and enqueued the round (a barrier inside the library: no interpreter lock is held while waiting).
+int dv_batch_arrive(dv_batch* B) {
+    if (!B) return -1;
+    std::unique_lock<std::mutex> lk(B->mu);
+    const long long gen = B->generation;
+    if (++B->arrived == (int)B->members.size()) {
+        B->last_rc = batch_enqueue_impl(B);
+        B->arrived = 0; ++B->generation;
+        lk.unlock();
+        B->cv.notify_all();
+        return B->last_rc;
+    }
+    B->cv.wait(lk, [&] { return B->generation != gen; });
+    return B->last_rc;
 }
 int dv_batch_info(dv_batch* B, long long* batched_rounds, long long* single_rounds) {
     if (!B) return -1;

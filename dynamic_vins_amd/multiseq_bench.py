@@ -78,17 +78,13 @@ def run_multiseq_bench(args, rank, world, local_rank):
             drain()
             return
 
-        bar = threading.Barrier(len(pipes)) if batch is not None else None
-
         def worker(p):
             for _ in range(n_steps):
-                if bar is None:
+                if batch is None:
                     p.step()
                     continue
                 p.step_begin()
-                if bar.wait() == 0:
-                    batch.enqueue()
-                bar.wait()
+                batch.arrive()          # rendezvous inside the library: the last thread to arrive enqueues the shared launches
                 p.step_end()
         ths = [threading.Thread(target=worker, args=(p,)) for p in pipes]
         for t in ths:

@@ -230,6 +230,7 @@ typedef struct dv_batch dv_batch;
 dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n);      /* idle contexts of one device; NULL + dv_last_error(NULL) on failure */
 void dv_batch_destroy(dv_batch* batch);                      /* the members stay valid */
 int dv_batch_enqueue(dv_batch* batch);
+int dv_batch_arrive(dv_batch* batch);                        /* one host thread per member: blocks until every member's thread has arrived; the last one enqueues */
 int dv_batch_info(dv_batch* batch, long long* batched_rounds, long long* single_rounds);
 
 /* Replaces MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks} as driven by

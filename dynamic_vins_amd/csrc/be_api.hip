@@ -25,7 +25,7 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
            o_pA = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb = take(8 * BE_MAX_PRIOR),
            o_pA2 = take(8 * (size_t)BE_MAX_PRIOR * BE_MAX_PRIOR), o_pb2 = take(8 * BE_MAX_PRIOR), o_ms = take(64), o_c0 = take(64),
            o_pk = take(8 * (size_t)BE_PK_SIZE * BE_PK_STRIDE), o_io = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po = take(8 * (BE_MAX_PRIOR + 1)),
-           o_cc = take(8 * (BE_MAX_LM + BE_WIN + 1)), o_hd = take(8 * n * n), o_sc = take(8 * n * n), o_g = take(8 * 2 * n),
+           o_cc = take(8 * (BE_MAX_LM + BE_WIN + 1)), o_ob = take(4 * BE_MAX_LM), o_hd = take(8 * n * n), o_sc = take(8 * n * n), o_g = take(8 * 2 * n),
            o_pk1 = take(8 * (size_t)BE_PK_SIZE * BE_PK_STRIDE), o_io1 = take(8 * (size_t)BE_WIN * IMU_OUT_STRIDE), o_po1 = take(8 * (BE_MAX_PRIOR + 1)),
            o_hd1 = take(8 * n * n), o_sc1 = take(8 * n * n), o_g1 = take(8 * 2 * n),      // second linearisation set (speculative evaluation at the candidate)
            o_v = take(8 * 4 * n), o_vl = take(8 * 4 * (size_t)BE_MAX_LM);
@@ -36,7 +36,7 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     w.priorA_buf[0] = (double*)(b + o_pA); w.priorb_buf[0] = (double*)(b + o_pb); w.priorA_buf[1] = (double*)(b + o_pA2); w.priorb_buf[1] = (double*)(b + o_pb2);
     w.prior_cur = 0; w.priorA = w.priorA_buf[0]; w.priorb = w.priorb_buf[0]; w.prior_resident = false;
     w.marg_tab = (int32_t*)(b + o_mt); w.marg_scal = (double*)(b + o_ms); w.prior_c0 = (double*)(b + o_c0);
-    w.packets[0] = (double*)(b + o_pk); w.imu_out[0] = (double*)(b + o_io); w.prior_out[0] = (double*)(b + o_po); w.cand_cost = (double*)(b + o_cc);
+    w.packets[0] = (double*)(b + o_pk); w.imu_out[0] = (double*)(b + o_io); w.prior_out[0] = (double*)(b + o_po); w.cand_cost = (double*)(b + o_cc); w.lm_obs = (int32_t*)(b + o_ob);
     w.Hd[0] = (double*)(b + o_hd); w.Sc[0] = (double*)(b + o_sc); w.gvec[0] = (double*)(b + o_g);
     w.packets[1] = (double*)(b + o_pk1); w.imu_out[1] = (double*)(b + o_io1); w.prior_out[1] = (double*)(b + o_po1);
     w.Hd[1] = (double*)(b + o_hd1); w.Sc[1] = (double*)(b + o_sc1); w.gvec[1] = (double*)(b + o_g1);
@@ -388,7 +388,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     // ---- schedule ----
     BeEvalArgs ea{};
     ea.ctl = w.ctl; ea.x = w.x; ea.cand = w.cand; ea.fac = w.fac; ea.lm = w.lm; ea.imu = w.imu; ea.prior = w.prior; ea.priorA = w.priorA; ea.priorb = w.priorb;
-    ea.dims = d; ea.g_norm = P->g_norm; ea.cand_cost = w.cand_cost; ea.prior_c0 = w.prior_c0 + w.prior_cur;
+    ea.dims = d; ea.g_norm = P->g_norm; ea.cand_cost = w.cand_cost; ea.lm_obs = w.lm_obs; ea.prior_c0 = w.prior_c0 + w.prior_cur;
     ea.lm_lo = 0; ea.lm_hi = P->nlm;
     BeShard sh{};
     if (ctx->dist.transport != 0) {        // landmark-sharded window: contiguous ranges of cap = ceil(nlm / world) landmarks
@@ -403,7 +403,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     for (int k = 0; k < 2; ++k) { ea.packets[k] = w.packets[k]; ea.imu_out[k] = w.imu_out[k]; ea.prior_out[k] = w.prior_out[k]; }
     BeSolveArgs sa{};
     sa.ctl = w.ctl; sa.x = w.x; sa.cand = w.cand; sa.lm = w.lm; sa.imu = w.imu; sa.prior = w.prior; sa.priorA = w.priorA; sa.dims = d;
-    sa.cand_cost = w.cand_cost;
+    sa.cand_cost = w.cand_cost; sa.lm_obs = w.lm_obs;
     for (int k = 0; k < 2; ++k) { sa.packets[k] = w.packets[k]; sa.imu_out[k] = w.imu_out[k]; sa.prior_out[k] = w.prior_out[k]; sa.Hd[k] = w.Hd[k]; sa.Sc[k] = w.Sc[k]; sa.gvec[k] = w.gvec[k]; }
     sa.scale_p = w.scale_p; sa.diag_p = w.diag_p; sa.grad_p = w.grad_p; sa.gn_p = w.gn_p; sa.scale_l = w.scale_l; sa.diag_l = w.diag_l; sa.grad_l = w.grad_l; sa.gn_l = w.gn_l;
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;

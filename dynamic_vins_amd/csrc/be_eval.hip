@@ -82,7 +82,17 @@ __device__ __forceinline__ void be_eval_body(const BeEvalArgs& a, int mode, int 
         if (want_cost && lane == 0) a.cand_cost[b] = cost;
         if (!FULL) return;
         const int anchor = L.anchor, nf = L.count;
+        // observation mask: pose f is touched by this landmark iff f is its anchor or a frame with a two-frame factor.  Only those frames' GP / DD / DA slots are
+        // written (the rest were 8-byte stores of zeros: 40 % of the packet's 7.4 KB and of the 4x write amplification PMC showed) — be_reduce reads them under
+        // the same mask.
+        const int wl = lane & 63;                                     // every wave forms the mask by itself: lane f votes for frame f
+        const int obs = (int)__ballot(wl < a.dims.nframes && (wl == anchor || s_flist[wl < BE_NF ? wl : 0][0] >= 0 || s_flist[wl < BE_NF ? wl : 0][1] >= 0));
+        if (lane == 0 && mode != BE_EVAL_CAND_COST) a.lm_obs[b] = obs;
         for (int e = lane; e < BE_PK_SIZE; e += EV_THREADS) {
+            if (e >= BE_PK_GP && e < BE_PK_DA + BE_NF * 36) {
+                const int fa = e < BE_PK_DD ? (e - BE_PK_GP) / 6 : (e < BE_PK_DA ? (e - BE_PK_DD) / 36 : (e - BE_PK_DA) / 36);
+                if (!((obs >> fa) & 1)) continue;
+            }
             double v = 0.0;
             if (e == BE_PK_H) { for (int f = 0; f < nf; ++f) v += Jb[f][26] * Jb[f][26] + Jb[f][27] * Jb[f][27]; }
             else if (e == BE_PK_G) { for (int f = 0; f < nf; ++f) v += Jb[f][26] * Jb[f][0] + Jb[f][27] * Jb[f][1]; }

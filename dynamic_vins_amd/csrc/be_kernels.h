@@ -33,6 +33,8 @@ struct BeEvalArgs {
     double* imu_out[2];     // [nimu][936]: cost, g[30], H[30][30]
     double* prior_out[2];   // cost, g[n_prior]
     double* cand_cost;      // [nlm + nimu + 1]                    written by the evaluations at cand
+    int32_t* lm_obs;        // [nlm] bit f: the landmark's factors touch pose f (its anchor or an observing frame).  The packet slots GP / DD / DA of the other
+                            // frames are neither written nor read: be_reduce walks, per pose pair, only the landmarks that carry both bits
     int32_t lm_lo, lm_hi;   // landmark blocks outside [lm_lo, lm_hi) return at once (sharded window); 0, nlm otherwise
     const double* prior_c0; // the prior's constant r0^T r0, device resident (the marginalization of the previous frame may still be writing it
                             // when this solve is being prepared on the host)
@@ -43,7 +45,7 @@ struct BeSolveArgs {
     BeState* x; BeState* cand;
     const BeLm* lm; const BeImu* imu; const BePriorHdr* prior; const double* priorA;
     BeDims dims;
-    const double* packets[2]; const double* imu_out[2]; const double* prior_out[2]; const double* cand_cost;
+    const double* packets[2]; const double* imu_out[2]; const double* prior_out[2]; const double* cand_cost; const int32_t* lm_obs;
     double* Hd[2];          // [n][n] everything except the Schur term
     double* Sc[2];          // Hd - sum_l rho_l w_l w_l^T (the Schur complement before scaling), block-packed lower triangle (blk_pos in be_solve.hip)
     double* gvec[2];        // [n] gradient g_p ; [n..2n) Schur part sum_l rho_l w_l g_l

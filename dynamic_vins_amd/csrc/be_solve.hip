@@ -91,8 +91,25 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
     double* const Hd = a.Hd[set]; double* const Sc = a.Sc[set]; double* const gvec = a.gvec[set];
     const double* const imu_out = a.imu_out[set]; const double* const prior_out = a.prior_out[set];
     __shared__ int s_ifi[BE_WIN + 1], s_ifj[BE_WIN + 1], s_pr[2];
+    __shared__ unsigned short s_list[BE_MAX_LM]; __shared__ int s_cnt;
     if ((int)threadIdx.x < a.dims.nimu) { s_ifi[threadIdx.x] = a.imu[threadIdx.x].fi; s_ifj[threadIdx.x] = a.imu[threadIdx.x].fj; }
     if (threadIdx.x == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
+    if (bx < RED_PAIRS && (threadIdx.x >> 6) == 2) {
+        // pair block (fi, fj): the landmarks whose factors touch BOTH poses, compacted in ascending order by one wave (ballot + prefix count) — for two
+        // frames of an 11-frame window that is a fraction of the landmarks (observed in ~6 frames each); every other packet row would contribute zeros
+        const int fi = bx / BE_NF, fj = bx - fi * BE_NF, lane = threadIdx.x & 63;
+        const int lo = a.sh.on ? a.sh.lo : 0, hi = a.sh.on ? a.sh.hi : nlm;
+        int base = 0;
+        for (int c0 = lo; c0 < hi; c0 += 64) {
+            const int l = c0 + lane;
+            const int ob = l < hi ? a.lm_obs[l] : 0;
+            const bool m = ((ob >> fi) & 1) && ((ob >> fj) & 1);
+            const unsigned long long bal = __ballot(m);
+            if (m) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)l;
+            base += __popcll(bal);
+        }
+        if (lane == 0) s_cnt = base;
+    }
     __syncthreads();
     const RedCtx rc{ s_ifi, s_ifj, s_pr[0], s_pr[1] };
     if (bx == 0) RTS(0);
@@ -107,7 +124,6 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
         // the IMU / prior part of the block's 36 entries (and 6 gradient entries) is a chain of dependent global loads (column maps ->
         // factor / prior indices -> values): the seventh wave walks it WHILE the other six stream the landmark packets
         __shared__ double s_dh[36], s_dg[6];
-        const int l_lo = a.sh.on ? a.sh.lo : 0, l_hi = a.sh.on ? a.sh.hi : nlm;
         if (ci == 6 && !a.sh.on) {
 #ifdef BE_RED_TS
             if (bx == 0 && lane == 0) be_red_ts[16] = wall_clock64();
@@ -123,7 +139,9 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
         const int e_dd = BE_PK_DD + fi * 36 + ci * 6;
         const int e_da_i = BE_PK_DA + fj * 36 + ci * 6;                 // anchor == fi : row ci of block (anchor, fj)
         const int e_da_j = BE_PK_DA + fi * 36 + ci;                     // anchor == fj : column ci of the transposed block
-        for (int l = ci < 6 ? l_lo + lane : l_hi; l < l_hi; l += 64) {
+        const int cnt = s_cnt;
+        for (int idx = ci < 6 ? lane : cnt; idx < cnt; idx += 64) {
+            const int l = s_list[idx];
             const double h = BE_PK(pk, BE_PK_H, l);
             const double s = c.first ? 1.0 / (1.0 + sqrt(h)) : a.scale_l[l];
             double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);

@@ -87,7 +87,7 @@ struct BeWork {
     DevBuf block;          // one allocation, carved below
     BeCtl* ctl = nullptr; BeState* x = nullptr; BeState* cand = nullptr;
     BeFactor* fac = nullptr; BeLm* lm = nullptr; BeImu* imu = nullptr; BePriorHdr* prior = nullptr; double* priorA = nullptr; double* priorb = nullptr;
-    double* packets[2] = { nullptr, nullptr }; double* imu_out[2] = { nullptr, nullptr }; double* prior_out[2] = { nullptr, nullptr }; double* cand_cost = nullptr;
+    double* packets[2] = { nullptr, nullptr }; double* imu_out[2] = { nullptr, nullptr }; double* prior_out[2] = { nullptr, nullptr }; double* cand_cost = nullptr; int32_t* lm_obs = nullptr;
     double* Hd[2] = { nullptr, nullptr }; double* Sc[2] = { nullptr, nullptr }; double* gvec[2] = { nullptr, nullptr };      // two linearisation sets (BeCtl::cur)
     double* scale_p = nullptr; double* diag_p = nullptr; double* grad_p = nullptr; double* gn_p = nullptr;
     double* scale_l = nullptr; double* diag_l = nullptr; double* grad_l = nullptr; double* gn_l = nullptr;

@@ -26,6 +26,16 @@ extern "C" int dv_debug_ev_ts(long long* out) { return hipMemcpyFromSymbol(out, 
 #else
 #define ETS(k) do {} while (0)
 #endif
+// Workgroups are dealt to the 8 XCDs round-robin, and a packet row holds 16 consecutive landmarks per 128-byte line: with block b evaluating landmark b the
+// 16 writers of one line sit on 8 different L2s and every one of them writes its 8 bytes back as a 32-byte sector (PMC: 7.9 MB written for 1.95 MB of
+// packets).  The landmark blocks are therefore renumbered so that each XCD evaluates a CONTIGUOUS range of landmarks and its L2 merges the lines.
+__device__ __forceinline__ int be_eval_block_of(int bx, int nlm) {
+    if (bx >= nlm) return bx;                                  // IMU / prior blocks keep their numbers
+    const int x = bx & 7, k = bx >> 3;
+    int start = 0;                                             // landmarks of the residue classes before x: class y holds (nlm - y + 7) / 8 blocks
+    for (int y = 0; y < x; ++y) start += nlm > y ? (nlm - y + 7) >> 3 : 0;
+    return start + k;                                          // bijection [0, nlm) -> [0, nlm): class x (the blocks one XCD receives), in order, onto a contiguous range
+}
 template <bool FULL>
 #define EV_THREADS 256
 __device__ __forceinline__ void be_eval_body(const BeEvalArgs& a, int mode, int b) {
@@ -238,13 +248,13 @@ __device__ __forceinline__ void be_eval_body(const BeEvalArgs& a, int mode, int 
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL>(a, mode, blockIdx.x); }
+__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm)); }
 // batched form (several independent windows in one launch: blockIdx.y = window, argument table in HBM)
 template <bool FULL>
 __global__ __launch_bounds__(EV_THREADS) void be_eval_batch_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
     const BeEvalArgs& a = tab[blockIdx.y];
     if ((int)blockIdx.x >= a.dims.nlm + a.dims.nimu + 1) return;
-    be_eval_body<FULL>(a, mode, blockIdx.x);
+    be_eval_body<FULL>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm));
 }
 void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s) {
     if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_batch_kernel<true>, dim3(max_grid, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);

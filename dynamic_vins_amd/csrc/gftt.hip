@@ -58,7 +58,18 @@ __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
     __shared__ int s_ncand, s_base;
     const int tid = threadIdx.x;
     if (a.n_feat && a.max_cnt - *a.n_feat < a.min_new) return;     // no detection wanted this frame
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    // XCD-aware tile numbering: workgroups are dealt to the 8 XCDs round-robin, a 64-pixel tile row is HALF a 128-byte line and every tile reads a 3-pixel halo,
+    // so with the plain 2-D numbering neighbouring tiles (and both halves of every line) are fetched into different L2s.  Every XCD gets a contiguous run of
+    // tiles in raster order instead (the candidate order changes; the select kernel sorts by (value, address), so the result does not).
+    int tx, ty;
+    {
+        const int gx = gridDim.x, nt = gridDim.x * gridDim.y, lin = blockIdx.y * gx + blockIdx.x, xc = lin & 7, k = lin >> 3;
+        int start = 0;
+        for (int y = 0; y < xc; ++y) start += nt > y ? (nt - y + 7) >> 3 : 0;
+        const int t = start + k;
+        ty = t / gx; tx = t - ty * gx;
+    }
+    const int x0 = tx * TW, y0 = ty * TH;
     const int w = a.w, h = a.h;
     if (tid == 0) { s_ndisc = 0; s_ncand = 0; }
     for (int i = tid; i < IMG_H * IMG_PITCH; i += 256) {

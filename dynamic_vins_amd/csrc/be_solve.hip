@@ -315,9 +315,11 @@ void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s) { hipL
 #ifdef BE_SOLVE_TS
 __device__ long long be_dbg_ts[32];
 #define TS(k) do { if (threadIdx.x == 0) { be_dbg_ts[k] = wall_clock64(); if ((k) == 4) be_dbg_ts[30] = clock64(); if ((k) == 5) be_dbg_ts[31] = clock64(); } } while (0)
+#define TSW(k) do { if (threadIdx.x == SOL_THREADS - 64) be_dbg_ts[k] = wall_clock64(); } while (0)
 extern "C" int dv_debug_solve_ts(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(be_dbg_ts), sizeof(long long) * 32) == hipSuccess ? 0 : -1; }
 #else
 #define TS(k) do {} while (0)
+#define TSW(k) do {} while (0)
 #endif
 
 __device__ __forceinline__ double block_sum(double v, double* red) {     // fixed-shape tree: deterministic
@@ -331,6 +333,11 @@ __device__ __forceinline__ double block_sum(double v, double* red) {     // fixe
     for (int k = 0; k < SOL_THREADS / 64; ++k) s += red[k];
     return s;
 }
+
+// Barrier for exchanges that live in LDS only: s_waitcnt lgkmcnt(0) + s_barrier without the workgroup fence of __syncthreads(), which also drains vmcnt —
+// global loads requested ahead of the barrier stay in flight across it (that is the point: operands of a later phase are fetched behind the reductions of
+// this one).  NOT a substitute where other threads' global stores must become visible.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // N sums with ONE LDS exchange (two barriers) instead of N: red must hold 16 * N doubles
 template <int N>
@@ -347,6 +354,23 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
         for (int i = 0; i < N; ++i) red[i * 16 + w] = v[i];
     }
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) { double s = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) s += red[i * 16 + k]; v[i] = s; }
+}
+template <int N>
+__device__ __forceinline__ void block_sum_n_lds(double (&v)[N], double* red) {      // the same tree behind LDS-only barriers
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+    }
+    lds_barrier();
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) red[i * 16 + w] = v[i];
+    }
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < N; ++i) { double s = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) s += red[i * 16 + k]; v[i] = s; }
 }

@@ -357,13 +357,43 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
 #pragma unroll
     for (int i = 0; i < N; ++i) { double s = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) s += red[i * 16 + k]; v[i] = s; }
 }
+// The same N sums on the cross-lane data path instead of LDS shuffles (__shfl_xor of a double is two ds_bpermute round trips per step, and the second
+// stage above has every thread read all 16 * N partials).  Stage 1: inclusive row scan (row_shr 1, 2, 4, 8), row_bcast15, row_bcast31: lane 63 holds the
+// wave's total, v_readlane hands it to lane 0 for red[].  Stage 2: lane 16 * i + k of EVERY wave loads partial k of value i (a second register for
+// i >= 4), one row scan, the totals come back through v_readlane (lane-uniform).  Fixed tree: deterministic; LDS-only barriers.  N <= 8.
+__device__ __forceinline__ double dpp_move(double v, const int ctrl, const int row_mask) {
+    // out-of-range source lanes and rows outside row_mask deliver 0.0
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int rl, rh;
+    switch (ctrl) {      // the control word must be an immediate
+        case 0x111: rl = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
+        case 0x112: rl = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
+        case 0x114: rl = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
+        case 0x118: rl = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
+        case 0x142: rl = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, true); break;
+        default:    rl = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, true); break;
+    }
+    (void)row_mask;
+    return __hiloint2double(rh, rl);
+}
+__device__ __forceinline__ double row_scan(double v) {          // lane 15 of every 16-lane row ends up with the row's sum
+    v += dpp_move(v, 0x111, 0xf); v += dpp_move(v, 0x112, 0xf); v += dpp_move(v, 0x114, 0xf); v += dpp_move(v, 0x118, 0xf);
+    return v;
+}
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {      // src_lane wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
 template <int N>
-__device__ __forceinline__ void block_sum_n_lds(double (&v)[N], double* red) {      // the same tree behind LDS-only barriers
+__device__ __forceinline__ void block_sum_n_dpp(double (&v)[N], double* red) {
+    static_assert(N <= 8, "two registers of 4 x 16 partials");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_xor(v[i], o);
+        double t = row_scan(v[i]);
+        t += dpp_move(t, 0x142, 0xa);
+        t += dpp_move(t, 0x143, 0xc);
+        v[i] = lane_bcast(t, 63);
     }
     lds_barrier();
     if (lane == 0) {
@@ -371,8 +401,12 @@ __device__ __forceinline__ void block_sum_n_lds(double (&v)[N], double* red) {  
         for (int i = 0; i < N; ++i) red[i * 16 + w] = v[i];
     }
     lds_barrier();
+    double r0 = lane < (N < 4 ? N : 4) * 16 ? red[lane] : 0.0;
+    double r1 = (N > 4 && lane < (N - 4) * 16) ? red[64 + lane] : 0.0;
+    r0 = row_scan(r0);
+    if (N > 4) r1 = row_scan(r1);
 #pragma unroll
-    for (int i = 0; i < N; ++i) { double s = 0; for (int k = 0; k < SOL_THREADS / 64; ++k) s += red[i * 16 + k]; v[i] = s; }
+    for (int i = 0; i < N; ++i) v[i] = i < 4 ? lane_bcast(r0, 16 * i + 15) : lane_bcast(r1, 16 * (i - 4) + 15);
 }
 
 __device__ __forceinline__ int tri(int i, int j) { return i * (i + 1) / 2 + j; }      // packed lower, j <= i
@@ -590,10 +624,6 @@ __device__ __forceinline__ void ldl_prefetch(const int* map, const double* __res
     for (int r = 0; r < 4; ++r) { const double4 q = src[r]; R.dv[r][0] = q.x; R.dv[r][1] = q.y; R.dv[r][2] = q.z; R.dv[r][3] = q.w; }
 }
 __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-__device__ __forceinline__ double lane_bcast(double v, int src_lane) {      // src_lane wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
 // pre != nullptr: the system (already scaled and damped) is taken from LDS — pre = packed lower triangle (row-major), pre_rhs = right-hand side — instead
 // of the block-packed global Schur complement: the reduced pose system the speed-bias sweep leaves behind.  Lm may alias pre (it is written at the end).
 __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw& R, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,

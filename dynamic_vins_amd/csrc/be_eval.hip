@@ -16,6 +16,7 @@
 // COST-only variant (candidate points of the trust-region loop): residuals only.
 #include <hip/hip_runtime.h>
 #include "be_kernels.h"
+#include "wave_dpp.h"
 
 using namespace be;
 
@@ -234,8 +235,7 @@ __device__ __forceinline__ void be_eval_body(const BeEvalArgs& a, int mode, int 
         if (lane < 64) {          // b'.dx and dx.A'dx: strided over one wave + xor tree (was a serial loop of n dependent global loads on lane 0)
             double bd = 0, dAd = 0;
             for (int i = lane; i < n; i += 64) { bd += a.priorb[i] * dx[i]; dAd += dx[i] * Adx[i]; }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { bd += __shfl_xor(bd, o); dAd += __shfl_xor(dAd, o); }
+            bd = wave_sum_f64(bd); dAd = wave_sum_f64(dAd);          // (lane here is the thread index: the first wave, all 64 lanes active)
         if (lane == 0) {
             const double cost = 0.5 * a.prior_c0[0] + bd + 0.5 * dAd;
             if (FULL) o_prior[0] = cost;

@@ -21,6 +21,7 @@
 #include <cfloat>
 #include "be_kernels.h"
 #include "dev_once.h"
+#include "wave_dpp.h"
 
 using namespace be;
 
@@ -361,39 +362,13 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
 // stage above has every thread read all 16 * N partials).  Stage 1: inclusive row scan (row_shr 1, 2, 4, 8), row_bcast15, row_bcast31: lane 63 holds the
 // wave's total, v_readlane hands it to lane 0 for red[].  Stage 2: lane 16 * i + k of EVERY wave loads partial k of value i (a second register for
 // i >= 4), one row scan, the totals come back through v_readlane (lane-uniform).  Fixed tree: deterministic; LDS-only barriers.  N <= 8.
-__device__ __forceinline__ double dpp_move(double v, const int ctrl, const int row_mask) {
-    // out-of-range source lanes and rows outside row_mask deliver 0.0
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    int rl, rh;
-    switch (ctrl) {      // the control word must be an immediate
-        case 0x111: rl = __builtin_amdgcn_update_dpp(0, lo, 0x111, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, true); break;
-        case 0x112: rl = __builtin_amdgcn_update_dpp(0, lo, 0x112, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, true); break;
-        case 0x114: rl = __builtin_amdgcn_update_dpp(0, lo, 0x114, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, true); break;
-        case 0x118: rl = __builtin_amdgcn_update_dpp(0, lo, 0x118, 0xf, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, true); break;
-        case 0x142: rl = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, true); break;
-        default:    rl = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, true); rh = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, true); break;
-    }
-    (void)row_mask;
-    return __hiloint2double(rh, rl);
-}
-__device__ __forceinline__ double row_scan(double v) {          // lane 15 of every 16-lane row ends up with the row's sum
-    v += dpp_move(v, 0x111, 0xf); v += dpp_move(v, 0x112, 0xf); v += dpp_move(v, 0x114, 0xf); v += dpp_move(v, 0x118, 0xf);
-    return v;
-}
-__device__ __forceinline__ double lane_bcast(double v, int src_lane) {      // src_lane wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-    return __hiloint2double(hi, lo);
-}
 template <int N>
 __device__ __forceinline__ void block_sum_n_dpp(double (&v)[N], double* red) {
     static_assert(N <= 8, "two registers of 4 x 16 partials");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
-        double t = row_scan(v[i]);
-        t += dpp_move(t, 0x142, 0xa);
-        t += dpp_move(t, 0x143, 0xc);
-        v[i] = lane_bcast(t, 63);
+        v[i] = wave_sum_f64(v[i]);
     }
     lds_barrier();
     if (lane == 0) {
@@ -403,8 +378,8 @@ __device__ __forceinline__ void block_sum_n_dpp(double (&v)[N], double* red) {
     lds_barrier();
     double r0 = lane < (N < 4 ? N : 4) * 16 ? red[lane] : 0.0;
     double r1 = (N > 4 && lane < (N - 4) * 16) ? red[64 + lane] : 0.0;
-    r0 = row_scan(r0);
-    if (N > 4) r1 = row_scan(r1);
+    r0 = row_scan_f64(r0);
+    if (N > 4) r1 = row_scan_f64(r1);
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] = i < 4 ? lane_bcast(r0, 16 * i + 15) : lane_bcast(r1, 16 * (i - 4) + 15);
 }
@@ -1075,8 +1050,7 @@ __device__ __forceinline__ void be_accept_body(const BeSolveArgs& a) {
     const int ncost = a.dims.nlm + a.dims.nimu + 1;
     double part = 0;
     for (int k = tid; k < ncost; k += 256) part += a.cand_cost[k];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    part = wave_sum_f64(part);          // the same tree as the decision in be_solve's prologue, bit for bit
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();
     const double cand_cost = red[0] + red[1] + red[2] + red[3];

@@ -19,6 +19,7 @@
 //     host loop at feature_utils.cpp:55-66.
 // Float math is compiled with -ffp-contract=off and uses correctly rounded div/sqrt.
 #include "dv_internal.h"
+#include "wave_dpp.h"
 #include <cfloat>
 
 #define WIN DV_LK_WIN
@@ -57,14 +58,9 @@ __device__ __forceinline__ void lk_stage_tile(uint8_t* lds, int pitch, int rows,
 
 __device__ __forceinline__ long long lk_wave_sum(int v) {
     // |v| * 8 < 2^31 for every quantity summed here (see DESIGN.md "LK exact sums")
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    long long s = v;
-    s += __shfl_xor(s, 8);
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
-    return s;
+    // on the DPP path: the ds_bpermute butterfly (nine dependent LDS-crossbar round trips per sum, two sums per iteration) was the longest link of the
+    // iteration's dependent chain.  Integer sums: the result is the same whatever the tree.
+    return wave_sum_i32_wide(v);
 }
 
 __device__ __forceinline__ int lk_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }

@@ -584,15 +584,13 @@ struct LdlRaw { int bi, bj; double dv[4][4]; };
 __device__ __forceinline__ void ldl_build_map(const uint16_t* col0, int n, int* map) {
     const int tid = threadIdx.x, NBR = (n + 3) >> 2;
     map[tid] = -1;
-    __syncthreads();
+    lds_barrier();
     if (tid < NBR) { const int t0 = col0[tid]; for (int k = 0; k < NBR - tid; ++k) map[t0 + k] = ((tid + k) << 8) | tid; }
-    __syncthreads();
+    lds_barrier();
 }
-__device__ __forceinline__ void ldl_prefetch(const int* map, const double* __restrict__ Sc, int n, LdlRaw& R) {
+__device__ __forceinline__ void ldl_prefetch(const double* __restrict__ Sc, int n, LdlRaw& R) {      // R.bi / R.bj: from the map
     const int NBR = (n + 3) >> 2;
-    const int m = map[threadIdx.x];
-    R.bi = m < 0 ? -1 : (m >> 8); R.bj = m < 0 ? -1 : (m & 255);
-    const bool have = m >= 0;
+    const bool have = R.bi >= 0;
     const int idx = have ? R.bj * NBR - R.bj * (R.bj - 1) / 2 + R.bi - R.bj : 0;      // blk_pos's block index
     const double4* src = reinterpret_cast<const double4*>(Sc + (size_t)idx * 16);
 #pragma unroll
@@ -602,7 +600,8 @@ __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMI
 // pre != nullptr: the system (already scaled and damped) is taken from LDS — pre = packed lower triangle (row-major), pre_rhs = right-hand side — instead
 // of the block-packed global Schur complement: the reduced pose system the speed-bias sweep leaves behind.  Lm may alias pre (it is written at the end).
 __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw& R, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
-                                             double* Lm, double* P0, double* dinfo, double* zfin, double* dvec, int* s_fail, const double* pre = nullptr, const double* pre_rhs = nullptr) {
+                                             double* Lm, double* P0, double* dinfo, double* zfin, double* dvec, int* s_fail, const double* pre = nullptr, const double* pre_rhs = nullptr,
+                                             const double* rhs_lds = nullptr /* g_p - g_s already in LDS (else read from gvec) */) {
     const int tid = threadIdx.x, wave = tid >> 6;
     const int NBR = (n + 3) >> 2;
     const int bi = R.bi, bj = R.bj;
@@ -635,10 +634,10 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
             if (i == j) v = ok ? v + mu * v_d[ok ? i : 0] * v_d[ok ? i : 0] : 1.0;      // padding rows: identity
             A[r][cc] = v;
         }
-        zr[r] = (iok && bi == bj) ? si * (gvec[i] - gvec[n + i]) : 0.0;
+        zr[r] = (iok && bi == bj) ? si * (rhs_lds ? rhs_lds[i] : gvec[i] - gvec[n + i]) : 0.0;
     }
     if (tid == 0) *s_fail = 0;
-    __syncthreads();
+    lds_barrier();
     TS(4);
     // (a) + (b) of block column kc by the wave that owns it; every lane of that wave takes part in the broadcast
     auto panel = [&](int kc) {

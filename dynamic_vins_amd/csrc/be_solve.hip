@@ -313,6 +313,9 @@ void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s) { hipL
 
 // ---------------------------------------------------------------------------------------------
 #define SOL_THREADS 1024
+#ifndef BS_R
+#define BS_R 8
+#endif
 #ifdef BE_SOLVE_TS
 __device__ long long be_dbg_ts[32];
 #define TS(k) do { if (threadIdx.x == 0) { be_dbg_ts[k] = wall_clock64(); if ((k) == 4) be_dbg_ts[30] = clock64(); if ((k) == 5) be_dbg_ts[31] = clock64(); } } while (0)
@@ -970,6 +973,54 @@ __device__ __forceinline__ void bs_chunk(const double* Lm, int kt, int lane, dou
         if (SEG >= 1) x1 = __builtin_fma(-cr[u][1], xk, x1);
         if (SEG >= 2) x2 = __builtin_fma(-cr[u][2], xk, x2);
     }
+}
+// Software-pipelined form: the rows of stage c+1 (R rows) are requested from LDS before the R dependent pivots of stage c run, so the LDS round trip
+// (~460 cycles per 24 loads, measured: scripts/dbg/bs_bench.hip) passes behind the pivot chain (~41 cycles per pivot).  SEG compile-time, two explicit
+// buffers.  Same operations per entry as bs_chunk.
+template <int SEG, int R>
+__device__ __forceinline__ void bs_ld(const double* Lm, int kt, int lane, double (&cr)[R][3]) {
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const int k = kt - u;
+        const double* row = Lm + tri(k, 0) + lane;
+        cr[u][0] = row[0];
+        if (SEG >= 1) cr[u][1] = row[64];
+        if (SEG >= 2) cr[u][2] = row[128];              // raw: the mask of the pivot's own segment is applied in bs_ap (a use here would wait for the load)
+    }
+}
+template <int SEG, int R>
+__device__ __forceinline__ void bs_ap(const double (&cr)[R][3], int kt, int lane, double& x0, double& x1, double& x2) {
+    double m[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) m[u] = lane < kt - u - 64 * SEG ? cr[u][SEG] : 0.0;      // entries at / right of the pivot are not part of row k
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        const double xs = SEG == 0 ? x0 : (SEG == 1 ? x1 : x2);
+        const double xk = lane_bcast(xs, kt - u - 64 * SEG);
+        x0 = __builtin_fma(-(SEG == 0 ? m[u] : cr[u][0]), xk, x0);
+        if (SEG >= 1) x1 = __builtin_fma(-(SEG == 1 ? m[u] : cr[u][1]), xk, x1);
+        if (SEG >= 2) x2 = __builtin_fma(-m[u], xk, x2);
+    }
+}
+// rows k .. 64 * SEG of segment SEG (k + 1 and 64 multiples of R); returns the top row of the next segment
+template <int SEG, int R>
+__device__ __forceinline__ int bs_segment(const double* Lm, int k, int lane, double& x0, double& x1, double& x2) {
+    const int kend = 64 * SEG + R - 1;                   // top row of the segment's last stage
+    double ca[R][3], cb[R][3];
+    bs_ld<SEG, R>(Lm, k, lane, ca);
+    for (; k >= kend; k -= 2 * R) {
+        if (k - R >= kend) bs_ld<SEG, R>(Lm, k - R, lane, cb);
+        __builtin_amdgcn_sched_barrier(0);               // the scheduler otherwise sinks the requests to their uses (it minimises live ranges under the 128-VGPR cap)
+        bs_ap<SEG, R>(ca, k, lane, x0, x1, x2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k - R >= kend) {
+            if (k - 2 * R >= kend) bs_ld<SEG, R>(Lm, k - 2 * R, lane, ca);
+            __builtin_amdgcn_sched_barrier(0);
+            bs_ap<SEG, R>(cb, k - R, lane, x0, x1, x2);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    return 64 * SEG - 1;
 }
 template <int ROWS>
 __device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, double& x0, double& x1, double& x2) {

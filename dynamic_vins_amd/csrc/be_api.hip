@@ -249,18 +249,23 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculat
 static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
     BeWork& w = ctx->be;
     uint8_t* hp = (uint8_t*)w.pinned;
+    BeGaugeArgs ga{};
     if (pd.fused_present) {
-        BeGaugeArgs ga{};
         ga.x = w.x; ga.out = w.cand; ga.nlm = pd.nlm; ga.nframes = pd.nframes; ga.use_imu = pd.use_imu;
         std::memcpy(ga.R0, pd.gauge_R0, sizeof(ga.R0)); std::memcpy(ga.ypr0, pd.gauge_ypr0, sizeof(ga.ypr0)); std::memcpy(ga.P0, pd.gauge_P0, sizeof(ga.P0));
-        be_launch_gauge(ga, s);
     }
-    DV_CHECK(hipGetLastError());
     BeState* hx = (BeState*)(hp + w.dl_off); BeCtl* hctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState));
-    DV_CHECK(hipMemcpyAsync(hx, pd.fused_present ? w.cand : w.x, pd.state_bytes, hipMemcpyDeviceToHost, s));      // estimator path: the gauge-fixed copy
-    DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
-    if (pd.fused_present && pd.want_raw_pose)          // dynamic mode: body.para_pose as ceres leaves it (before Double2vector's gauge fix), 616 bytes
-        DV_CHECK(hipMemcpyAsync(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256, w.x->pose, sizeof(double) * 7 * BE_NF, hipMemcpyDeviceToHost, s));
+    static_assert(sizeof(BeCtl) % sizeof(double) == 0 && sizeof(BeState) % sizeof(double) == 0, "downloaded as doubles");
+    if (pd.fused_present) {        // estimator path: the gauge kernel writes the gauge-fixed copy, the control block and (dynamic mode: body.para_pose as ceres
+                                   // leaves it, before Double2vector's gauge fix) the raw poses straight into the pinned buffer
+        ga.h_out = hx; ga.h_ctl = hctl; ga.ctl = w.ctl; ga.state_doubles = (int)((pd.state_bytes + 7) / 8);
+        ga.h_raw_pose = pd.want_raw_pose ? (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256) : nullptr;
+        be_launch_gauge(ga, s);
+        DV_CHECK(hipGetLastError());
+    } else {
+        DV_CHECK(hipMemcpyAsync(hx, w.x, pd.state_bytes, hipMemcpyDeviceToHost, s));
+        DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
+    }
     DV_CHECK(hipEventRecord(w.ev_state, s));
     if (pd.fused_present && pd.do_marg && !pd.pl.empty) {
         if (marg_enqueue(ctx, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], w.marg_scal, w.prior_c0 + pd.nxt, s)) return -1;

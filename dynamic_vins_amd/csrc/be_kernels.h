@@ -75,7 +75,13 @@ struct BeMargArgs {
 
 // yaw-gauge fix after a solve (Estimator::Double2vector, estimator.cpp:1111-1154): rotates the solved window back to the yaw and
 // position frame 0 had before the solve, in place on the device, so that the marginalization can follow without a host round trip
-struct BeGaugeArgs { const BeState* x; BeState* out; int nframes, use_imu, nlm; double R0[9]; double ypr0[3]; double P0[3]; };      // out != x: the raw solution stays intact
+struct BeGaugeArgs {
+    const BeState* x; BeState* out; int nframes, use_imu, nlm; double R0[9]; double ypr0[3]; double P0[3];      // out != x: the raw solution stays intact
+    // optional download by the kernel itself (pinned host memory, written over PCIe by the workgroup's last phase): the gauge-fixed state, the control
+    // block and the raw poses reach the host with the kernel's completion instead of through three copy dispatches behind it (~15 us of the BA stream
+    // and of the host's wake-up per frame)
+    BeState* h_out; BeCtl* h_ctl; const BeCtl* ctl; double* h_raw_pose; int state_doubles, pad;
+};
 
 #if defined(__HIPCC__)
 using namespace be;

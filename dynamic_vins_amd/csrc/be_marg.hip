@@ -448,21 +448,34 @@ __global__ __launch_bounds__(256) void be_gauge_kernel(BeGaugeArgs a) {
     for (int l = i; l < a.nlm; l += 256) o->inv_depth[l] = st->inv_depth[l];
     if (i < 14) o->ex[i / 7][i % 7] = st->ex[i / 7][i % 7];
     if (i == 14) o->td = st->td;
-    if (i >= BE_NF) return;
-    if (i >= a.nframes) { for (int k = 0; k < 7; ++k) o->pose[i][k] = st->pose[i][k]; for (int k = 0; k < 9; ++k) o->sb[i][k] = st->sb[i][k]; return; }
-    const quat qn = qnormalized(Q4(st->pose[i]));
-    for (int k = 0; k < 9; ++k) o->sb[i][k] = st->sb[i][k];
-    if (a.use_imu) {
-        const m33 R = mul(rot, qR(qn));
-        const d3 P = mul(rot, P3(st->pose[i]) - p0) + mk3(a.P0[0], a.P0[1], a.P0[2]);
-        const d3 V = mul(rot, mk3(st->sb[i][0], st->sb[i][1], st->sb[i][2]));
-        const quat q = qfromR(R);
-        o->pose[i][0] = P.x; o->pose[i][1] = P.y; o->pose[i][2] = P.z; o->pose[i][3] = q.x; o->pose[i][4] = q.y; o->pose[i][5] = q.z; o->pose[i][6] = q.w;
-        o->sb[i][0] = V.x; o->sb[i][1] = V.y; o->sb[i][2] = V.z;
-    } else {
-        const quat q = qfromR(qR(qn));
-        o->pose[i][0] = st->pose[i][0]; o->pose[i][1] = st->pose[i][1]; o->pose[i][2] = st->pose[i][2];
-        o->pose[i][3] = q.x; o->pose[i][4] = q.y; o->pose[i][5] = q.z; o->pose[i][6] = q.w;
+    if (i < BE_NF) {
+        if (i >= a.nframes) { for (int k = 0; k < 7; ++k) o->pose[i][k] = st->pose[i][k]; for (int k = 0; k < 9; ++k) o->sb[i][k] = st->sb[i][k]; }
+        else {
+            const quat qn = qnormalized(Q4(st->pose[i]));
+            for (int k = 0; k < 9; ++k) o->sb[i][k] = st->sb[i][k];
+            if (a.use_imu) {
+                const m33 R = mul(rot, qR(qn));
+                const d3 P = mul(rot, P3(st->pose[i]) - p0) + mk3(a.P0[0], a.P0[1], a.P0[2]);
+                const d3 V = mul(rot, mk3(st->sb[i][0], st->sb[i][1], st->sb[i][2]));
+                const quat q = qfromR(R);
+                o->pose[i][0] = P.x; o->pose[i][1] = P.y; o->pose[i][2] = P.z; o->pose[i][3] = q.x; o->pose[i][4] = q.y; o->pose[i][5] = q.z; o->pose[i][6] = q.w;
+                o->sb[i][0] = V.x; o->sb[i][1] = V.y; o->sb[i][2] = V.z;
+            } else {
+                const quat q = qfromR(qR(qn));
+                o->pose[i][0] = st->pose[i][0]; o->pose[i][1] = st->pose[i][1]; o->pose[i][2] = st->pose[i][2];
+                o->pose[i][3] = q.x; o->pose[i][4] = q.y; o->pose[i][5] = q.z; o->pose[i][6] = q.w;
+            }
+        }
+    }
+    if (!a.h_out) return;
+    __syncthreads();          // the workgroup's stores to `o` are visible to all of its threads
+    {
+        const double* src = reinterpret_cast<const double*>(o);
+        double* dst = reinterpret_cast<double*>(a.h_out);
+        for (int k = i; k < a.state_doubles; k += 256) dst[k] = src[k];
+        const int nc = (int)(sizeof(BeCtl) / sizeof(double));
+        if (i < nc) reinterpret_cast<double*>(a.h_ctl)[i] = reinterpret_cast<const double*>(a.ctl)[i];
+        if (a.h_raw_pose) for (int k = i; k < 7 * BE_NF; k += 256) a.h_raw_pose[k] = reinterpret_cast<const double*>(st->pose)[k];
     }
 }
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(256), 0, s, a); }

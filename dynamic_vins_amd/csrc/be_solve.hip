@@ -55,6 +55,30 @@ __device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, const RedCtx
     }
     return H;
 }
+// the same sums for a POSE column pair: kind / frame / component are known from the block (no column-map loads), the prior indices come from LDS
+__device__ __forceinline__ double red_dense_h_pose(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, int fi, int ci, int fj, int cj, int pi, int pj) {
+    double H = 0.0;
+    for (int k = 0; k < a.dims.nimu; ++k) {
+        const int mfi = rc.ifi[k], mfj = rc.ifj[k];
+        int li = -1, lj = -1;
+        if (fi == mfi) li = ci; else if (fi == mfj) li = 15 + ci;
+        if (fj == mfi) lj = cj; else if (fj == mfj) lj = 15 + cj;
+        if (li >= 0 && lj >= 0) H += imu_out[(size_t)k * IMU_OUT_STRIDE + 31 + li * 30 + lj];
+    }
+    if (rc.prior_valid && pi >= 0 && pj >= 0) H += a.priorA[(size_t)pi * rc.prior_n + pj];
+    return H;
+}
+__device__ __forceinline__ double red_dense_g_pose(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int fi, int ci, int pi) {
+    double G = 0.0;
+    for (int k = 0; k < a.dims.nimu; ++k) {
+        const int mfi = rc.ifi[k], mfj = rc.ifj[k];
+        int li = -1;
+        if (fi == mfi) li = ci; else if (fi == mfj) li = 15 + ci;
+        if (li >= 0) G += imu_out[(size_t)k * IMU_OUT_STRIDE + 1 + li];
+    }
+    if (rc.prior_valid && pi >= 0) G += prior_out[1 + pi];
+    return G;
+}
 __device__ __forceinline__ double red_dense_g(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int i) {
     const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i];
     double G = 0.0;
@@ -73,11 +97,7 @@ __device__ __forceinline__ int blk_pos(int i, int j, int NBR) {
     const int bi = i >> 2, bj = j >> 2;
     return (bj * NBR - bj * (bj - 1) / 2 + bi - bj) * 16 + (i & 3) * 4 + (j & 3);
 }
-__device__ __forceinline__ double wave_sum(double v) {      // fixed xor tree: deterministic, every lane gets the sum
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_sum_f64(v); }      // fixed tree on the DPP path (wave_dpp.h): deterministic, every lane gets the sum
 
 // blocks [0, 121): pose block (fi, fj) of the reduced system — landmark sums read the transposed packets coalesced
 //                  (lane = landmark), wave-tree reduced; blocks [121, ..): every entry that has no landmark term.
@@ -95,6 +115,13 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
     __shared__ unsigned short s_list[BE_MAX_LM]; __shared__ int s_cnt;
     if ((int)threadIdx.x < a.dims.nimu) { s_ifi[threadIdx.x] = a.imu[threadIdx.x].fi; s_ifj[threadIdx.x] = a.imu[threadIdx.x].fj; }
     if (threadIdx.x == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
+    __shared__ int s_pci[6], s_pcj[6];      // pair blocks: prior index of the block's six row / column pose entries (fetched with the tables above: one round trip)
+    if (bx < RED_PAIRS && threadIdx.x >= 65 && threadIdx.x < 77) {
+        const int fi = bx / BE_NF, fj = bx - fi * BE_NF, t = threadIdx.x - 65;
+        const int f = t < 6 ? fi : fj, c0 = f < a.dims.nframes ? a.dims.pose_col[f] : -1;
+        const int v = c0 >= 0 ? a.prior_col[c0 + (t < 6 ? t : t - 6)] : -1;
+        if (t < 6) s_pci[t] = v; else s_pcj[t - 6] = v;
+    }
     if (bx < RED_PAIRS && (threadIdx.x >> 6) == 2) {
         // pair block (fi, fj): the landmarks whose factors touch BOTH poses, compacted in ascending order by one wave (ballot + prefix count) — for two
         // frames of an 11-frame window that is a fraction of the landmarks (observed in ~6 frames each); every other packet row would contribute zeros
@@ -129,8 +156,8 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
 #ifdef BE_RED_TS
             if (bx == 0 && lane == 0) be_red_ts[16] = wall_clock64();
 #endif
-            if (lane < 36) s_dh[lane] = red_dense_h(a, rc, imu_out, ci0 + lane / 6, cj0 + lane % 6);
-            else if (diag && lane < 42) s_dg[lane - 36] = red_dense_g(a, rc, imu_out, prior_out, ci0 + lane - 36);
+            if (lane < 36) s_dh[lane] = red_dense_h_pose(a, rc, imu_out, fi, lane / 6, fj, lane % 6, s_pci[lane / 6], s_pcj[lane % 6]);
+            else if (diag && lane < 42) s_dg[lane - 36] = red_dense_g_pose(a, rc, imu_out, prior_out, fi, lane - 36, s_pci[lane - 36]);
 #ifdef BE_RED_TS
             if (bx == 0 && lane == 0) be_red_ts[17] = wall_clock64();
 #endif

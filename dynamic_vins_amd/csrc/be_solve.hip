@@ -57,26 +57,44 @@ __device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, const RedCtx
 }
 // the same sums for a POSE column pair: kind / frame / component are known from the block (no column-map loads), the prior indices come from LDS
 __device__ __forceinline__ double red_dense_h_pose(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, int fi, int ci, int fj, int cj, int pi, int pj) {
-    double H = 0.0;
-    for (int k = 0; k < a.dims.nimu; ++k) {
-        const int mfi = rc.ifi[k], mfj = rc.ifj[k];
+    // every load unconditional (a dummy address where the term is absent) and the loop unrolled: the <= 11 values travel in ONE round trip instead of one
+    // per contributing factor behind its branch; added in the same order
+    double v[BE_WIN]; bool ok[BE_WIN];
+#pragma unroll
+    for (int k = 0; k < BE_WIN; ++k) {
+        const bool live = k < a.dims.nimu;
+        const int mfi = live ? rc.ifi[k] : -1, mfj = live ? rc.ifj[k] : -1;
         int li = -1, lj = -1;
         if (fi == mfi) li = ci; else if (fi == mfj) li = 15 + ci;
         if (fj == mfi) lj = cj; else if (fj == mfj) lj = 15 + cj;
-        if (li >= 0 && lj >= 0) H += imu_out[(size_t)k * IMU_OUT_STRIDE + 31 + li * 30 + lj];
+        ok[k] = live && li >= 0 && lj >= 0;
+        v[k] = imu_out[ok[k] ? (size_t)k * IMU_OUT_STRIDE + 31 + li * 30 + lj : 0];
     }
-    if (rc.prior_valid && pi >= 0 && pj >= 0) H += a.priorA[(size_t)pi * rc.prior_n + pj];
+    const bool okp = rc.prior_valid && pi >= 0 && pj >= 0;
+    const double vp = a.priorA[okp ? (size_t)pi * rc.prior_n + pj : 0];
+    double H = 0.0;
+#pragma unroll
+    for (int k = 0; k < BE_WIN; ++k) if (ok[k]) H += v[k];
+    if (okp) H += vp;
     return H;
 }
 __device__ __forceinline__ double red_dense_g_pose(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int fi, int ci, int pi) {
-    double G = 0.0;
-    for (int k = 0; k < a.dims.nimu; ++k) {
-        const int mfi = rc.ifi[k], mfj = rc.ifj[k];
+    double v[BE_WIN]; bool ok[BE_WIN];
+#pragma unroll
+    for (int k = 0; k < BE_WIN; ++k) {
+        const bool live = k < a.dims.nimu;
+        const int mfi = live ? rc.ifi[k] : -1, mfj = live ? rc.ifj[k] : -1;
         int li = -1;
         if (fi == mfi) li = ci; else if (fi == mfj) li = 15 + ci;
-        if (li >= 0) G += imu_out[(size_t)k * IMU_OUT_STRIDE + 1 + li];
+        ok[k] = live && li >= 0;
+        v[k] = imu_out[ok[k] ? (size_t)k * IMU_OUT_STRIDE + 1 + li : 0];
     }
-    if (rc.prior_valid && pi >= 0) G += prior_out[1 + pi];
+    const bool okp = rc.prior_valid && pi >= 0;
+    const double vp = prior_out[okp ? 1 + pi : 0];
+    double G = 0.0;
+#pragma unroll
+    for (int k = 0; k < BE_WIN; ++k) if (ok[k]) G += v[k];
+    if (okp) G += vp;
     return G;
 }
 __device__ __forceinline__ double red_dense_g(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int i) {

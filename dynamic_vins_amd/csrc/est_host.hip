@@ -92,15 +92,30 @@ struct Preint {       // IntegrationBase
                 }
             }
         } pat;
+        // axpy form (row of the result += scalar * row of the right operand): every entry still receives its products in ascending k, one rounding each,
+        // but the inner loop runs over 15 independent entries and vectorises
         auto fmul = [&](const double* B, double* C) {          // C = F B
-            for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { double s = 0; for (int q = 0; q < pat.fn[i]; ++q) { const int k = pat.fk[i][q]; s += F[i * 15 + k] * B[k * 15 + j]; } C[i * 15 + j] = s; }
+            for (int i = 0; i < 15; ++i) {
+                double acc[15] = { 0 };
+                for (int q = 0; q < pat.fn[i]; ++q) { const int k = pat.fk[i][q]; const double f = F[i * 15 + k]; const double* b = B + k * 15; for (int j = 0; j < 15; ++j) acc[j] += f * b[j]; }
+                for (int j = 0; j < 15; ++j) C[i * 15 + j] = acc[j];
+            }
         };
         fmul(J, T1); std::copy(T1, T1 + 225, J);
         fmul(P, T1);                                          // F P
-        double FPFt[225];
-        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { double s = 0; for (int q = 0; q < pat.fn[j]; ++q) { const int k = pat.fk[j][q]; s += T1[i * 15 + k] * F[j * 15 + k]; } FPFt[i * 15 + j] = s; }
-        for (int i = 0; i < 15; ++i) for (int q = 0; q < pat.vn[i]; ++q) { const int k = pat.vk[i][q]; T2[i * 18 + k] = V[i * 18 + k] * noise[k]; }
-        for (int i = 0; i < 15; ++i) for (int j = 0; j < 15; ++j) { double s = 0; for (int q = 0; q < pat.vn[i]; ++q) { const int k = pat.vk[i][q]; s += T2[i * 18 + k] * V[j * 18 + k]; } P[i * 15 + j] = FPFt[i * 15 + j] + s; }
+        double Ft[225], Vt[270], FPFt[225];
+        for (int i = 0; i < 15; ++i) for (int k = 0; k < 15; ++k) Ft[k * 15 + i] = F[i * 15 + k];
+        for (int i = 0; i < 15; ++i) for (int k = 0; k < 18; ++k) Vt[k * 15 + i] = V[i * 18 + k];
+        for (int i = 0; i < 15; ++i) {                        // (F P) F^T: the structural zeros of F^T contribute exact zeros
+            double acc[15] = { 0 };
+            for (int k = 0; k < 15; ++k) { const double t = T1[i * 15 + k]; const double* b = Ft + k * 15; for (int j = 0; j < 15; ++j) acc[j] += t * b[j]; }
+            for (int j = 0; j < 15; ++j) FPFt[i * 15 + j] = acc[j];
+        }
+        for (int i = 0; i < 15; ++i) {                        // + V diag(noise) V^T
+            double acc[15] = { 0 };
+            for (int q = 0; q < pat.vn[i]; ++q) { const int k = pat.vk[i][q]; const double t = V[i * 18 + k] * noise[k]; const double* b = Vt + k * 15; for (int j = 0; j < 15; ++j) acc[j] += t * b[j]; }
+            for (int j = 0; j < 15; ++j) P[i * 15 + j] = FPFt[i * 15 + j] + acc[j];
+        }
         dp = rp; dq = qnormalized(rq); dv = rv; sum_dt += dt; acc_0 = a1; gyr_0 = g1; U_ok = false;
     }
     const double* sqrt_info() const { if (!U_ok) U_ok = be_imu_sqrt_info(P, U); return U_ok ? U : nullptr; }

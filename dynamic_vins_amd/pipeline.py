@@ -38,6 +38,7 @@ class Pipeline:
         self.k_imu = 0
         self.next = 0
         self.enqueued = False
+        self._prefetched = None
         self.poses, self.pose_times = [], []
         self.ba_stride = ba_stride          # 2: only every 2nd tracked frame is forwarded to the back end (system/main.cpp:300-307)
         self.last_state = None
@@ -66,9 +67,11 @@ class Pipeline:
         enqueue on the BA stream) -> enqueue tracking of k+1 and feed k+1's IMU samples while the GPU solves -> end BA of k."""
         k = self.next
         s = self.seq
-        if not self.enqueued:
-            self._enqueue(k)
-        rows = self.ctx.track_stereo_collect()
+        rows, self._prefetched = self._prefetched, None
+        if rows is None:
+            if not self.enqueued:
+                self._enqueue(k)
+            rows = self.ctx.track_stereo_collect()
         self.enqueued = False
         t = s.times[k]
         if self.ba_stride > 1 and (k % self.ba_stride) != self.ba_stride - 1:      # tracked only: the frame is not pushed to the feature queue
@@ -84,6 +87,10 @@ class Pipeline:
         if k + 1 < len(s.frames):
             self._enqueue(k + 1)                     # overlaps with the BA of frame k
             self._feed_imu(s.times[k + 1])
+            if not defer_end:
+                # the tracker finishes frame k+1 long before the BA of frame k does: its rows are collected NOW, not between the end of this frame's BA and the
+                # begin of the next (where the collect sat on the critical path of the BA stream: ~11 us per frame)
+                self._prefetched = self.ctx.track_stereo_collect()
         self.rows = rows
         if defer_end:
             self._pending_t = t
@@ -188,6 +195,7 @@ class DynamicPipeline(Pipeline):
         self.mode, self.use_det3d = DV_MODE_SEMANTIC, use_det3d
         self.k_imu = self.next = 0
         self.enqueued = False
+        self._prefetched = None
         self.poses, self.pose_times = [], []
         self.stat = dict(frames=0, frames_with_objects=0, object_detections=0, object_features=0)      # what the object branch was fed over the run
 
@@ -199,10 +207,12 @@ class DynamicPipeline(Pipeline):
 
     def step(self):
         k, s = self.next, self.seq
-        if not self.enqueued:
-            self._enqueue(k)
-        rows = self.ctx.track_stereo_collect()
-        insts, ifeats, pts = self.ctx.inst_track_collect()
+        pre, self._prefetched = self._prefetched, None
+        if pre is None:
+            if not self.enqueued:
+                self._enqueue(k)
+            pre = (self.ctx.track_stereo_collect(),) + tuple(self.ctx.inst_track_collect())
+        rows, insts, ifeats, pts = pre
         self.enqueued = False
         t = s.times[k]
         self._feed_imu(t)
@@ -211,6 +221,7 @@ class DynamicPipeline(Pipeline):
         if k + 1 < len(s.frames):
             self._enqueue(k + 1)
             self._feed_imu(s.times[k + 1])
+            self._prefetched = (self.ctx.track_stereo_collect(),) + tuple(self.ctx.inst_track_collect())      # while the BA of frame k runs (see Pipeline.step)
         st = self.est.ProcessMeasurementsEnd()
         if st.nonlinear:
             self.poses.append(self.est.window()[10, :7]); self.pose_times.append(t)

@@ -186,16 +186,34 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     double* W2 = bv + D;                                  // n x n (also scratch for prior dx / IMU)
     double* yv = W2 + (n * n > 1024 ? n * n : 1024);      // n
     double* misc = yv + n;                                // 16
+    double* imu_ws = misc + 16;                           // 960: raw / whitened Jacobian and residual of the IMU factor (its own region: prepared beside the phases below)
     const BeState* st = a.x;
     MTS(8);
+    // The last wave takes no share of the assembly below: it prepares the IMU factor (0,1) meanwhile — staging of the 2.4 KB record, the raw evaluation on
+    // ONE lane (~3.5 us of serial fp64), whitening — which used to be a phase of its own behind the prior (9 us).  It meets the others at the barriers.
+    const int MGW = MG_THREADS - 64;                      // worker threads of the assembly
+    const bool imu_wave = tid >= MGW;
+    double* Jraw = imu_ws; double* Jw = imu_ws + 450; double* rr = imu_ws + 900;
+    __shared__ BeImu s_m;                                 // the factor record
+    if (imu_wave && a.nimu > 0) {
+        const int lane = tid - MGW;
+        for (int i = lane; i < 450; i += 64) Jraw[i] = 0.0;
+        {
+            const double* src = reinterpret_cast<const double*>(a.imu); double* dst = reinterpret_cast<double*>(&s_m);
+            for (int i = lane; i < (int)(sizeof(BeImu) / 8); i += 64) dst[i] = src[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+        const BeImu* mi = &s_m;
+        if (lane == 0) imu_raw<true>(*mi, a.g_norm, st->pose[mi->fi], st->sb[mi->fi], st->pose[mi->fj], st->sb[mi->fj], rr, Jraw);
+    }
     {   // 4 entries x 8 chunk sums per batch: 32 independent global loads in flight per thread (they were 8 at a time behind a loop-carried wait)
         const int total = D * D + D;
-        for (int e0 = tid; e0 < total; e0 += 4 * MG_THREADS) {
+        for (int e0 = imu_wave ? total : tid; e0 < total; e0 += 4 * MGW) {
             double v[4] = { 0.0, 0.0, 0.0, 0.0 }, ld[4][MG_SUM_CHUNKS];
             if (a.nlm > 0) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + u * MG_THREADS;
+                    const int e = e0 + u * MGW;
 #pragma unroll
                     for (int c = 0; c < MG_SUM_CHUNKS; ++c) ld[u][c] = e < total ? a.sum[(size_t)c * total + e] : 0.0;
                 }
@@ -205,7 +223,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
                     for (int c = 0; c < MG_SUM_CHUNKS; ++c) v[u] += ld[u][c];
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int e = e0 + u * MG_THREADS; if (e < total) A[e] = v[u]; }
+            for (int u = 0; u < 4; ++u) { const int e = e0 + u * MGW; if (e < total) A[e] = v[u]; }
         }
     }
     if (tid < 64) {                                     // smallest landmark pivot: strided over one wave, xor-tree
@@ -217,19 +235,28 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     }
     __syncthreads();
     MTS(9);
+    if (imu_wave && a.nimu > 0) {          // second half of the last wave's job (beside the prior phase): whitening
+        const int lane = tid - MGW;
+        const BeImu* mi = &s_m;
+        if (lane < 15) { double s = 0; for (int q = lane; q < 15; ++q) s += mi->sqrt_info[lane * 15 + q] * rr[q]; rr[15 + lane] = s; }
+        for (int e = lane; e < 450; e += 64) {
+            const int i = e / 30, cc = e - i * 30; double s = 0;
+            for (int q = i; q < 15; ++q) s += mi->sqrt_info[i * 15 + q] * Jraw[q * 30 + cc];
+            Jw[e] = s;
+        }
+    }
     // ---------------- previous prior: A += A_old (mapped), b += b_old + A_old dx ----------------
     if (a.prior->valid) {
         const int no = a.prior->n;
         double* dx = W2;
         __shared__ short s_pmap[BE_MAX_PRIOR];
-        for (int i = tid; i < no; i += MG_THREADS) s_pmap[i] = (short)a.prior_map[i];
-        be_prior_dx_dev(a.prior, st, dx, tid, MG_THREADS);
+        if (!imu_wave) { for (int i = tid; i < no; i += MGW) s_pmap[i] = (short)a.prior_map[i]; be_prior_dx_dev(a.prior, st, dx, tid, MGW); }
         __syncthreads();
         // b += b_old + A_old dx: A_old is symmetric, so thread = output entry reads DOWN its column (coalesced across threads), the column
         // split over the thread groups; partial sums meet in LDS in a fixed order
         {
             double* part = W2 + BE_MAX_PRIOR;                       // groups x no_pad partial sums (W2 holds >= 1024 doubles)
-            const int no_pad = (no + 63) & ~63, groups = (1024 - BE_MAX_PRIOR) / no_pad > 0 ? min(MG_THREADS / no_pad, (1024 - BE_MAX_PRIOR) / no_pad) : 1;
+            const int no_pad = (no + 63) & ~63, groups = (1024 - BE_MAX_PRIOR) / no_pad > 0 ? min(MGW / no_pad, (1024 - BE_MAX_PRIOR) / no_pad) : 1;
             const int i = tid % no_pad, gI = tid / no_pad;
             const int seg = (no + groups - 1) / groups, j0 = gI * seg, j1 = min(no, j0 + seg);
             double sp = 0;
@@ -243,13 +270,13 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
                 if (di >= 0) bv[di] += t;
             }
         }
-        for (int e0 = tid; e0 < no * no; e0 += 4 * MG_THREADS) {          // 4 independent loads of A_old in flight per thread
+        for (int e0 = imu_wave ? no * no : tid; e0 < no * no; e0 += 4 * MGW) {          // 4 independent loads of A_old in flight per thread
             double pv[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int e = e0 + u * MG_THREADS; pv[u] = e < no * no ? a.priorA[e] : 0.0; }
+            for (int u = 0; u < 4; ++u) { const int e = e0 + u * MGW; pv[u] = e < no * no ? a.priorA[e] : 0.0; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * MG_THREADS;
+                const int e = e0 + u * MGW;
                 if (e >= no * no) continue;
                 const int i = e / no, j = e - i * no;
                 const int di = s_pmap[i], dj = s_pmap[j];
@@ -260,25 +287,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     }
     MTS(10);
     // ---------------- IMU factor (0,1) ----------------
-    if (a.nimu > 0) {
-        double* Jraw = W2; double* Jw = W2 + 450; double* rr = W2 + 900;
-        for (int i = tid; i < 450; i += MG_THREADS) Jraw[i] = 0.0;
-        __syncthreads();
-        __shared__ BeImu s_m;                                       // the 2.4 KB factor record, staged by all threads (lane 0 then reads LDS, not a chain of global loads)
-        {
-            const double* src = reinterpret_cast<const double*>(a.imu); double* dst = reinterpret_cast<double*>(&s_m);
-            for (int i = tid; i < (int)(sizeof(BeImu) / 8); i += MG_THREADS) dst[i] = src[i];
-        }
-        __syncthreads();
-        const BeImu* mi = &s_m;
-        if (tid == 0) imu_raw<true>(*mi, a.g_norm, st->pose[mi->fi], st->sb[mi->fi], st->pose[mi->fj], st->sb[mi->fj], rr, Jraw);
-        __syncthreads();
-        if (tid < 15) { double s = 0; for (int q = tid; q < 15; ++q) s += mi->sqrt_info[tid * 15 + q] * rr[q]; rr[15 + tid] = s; }
-        for (int e = tid; e < 450; e += MG_THREADS) {
-            const int i = e / 30, cc = e - i * 30; double s = 0;
-            for (int q = i; q < 15; ++q) s += mi->sqrt_info[i * 15 + q] * Jraw[q * 30 + cc];
-            Jw[e] = s;
-        }
+    if (a.nimu > 0) {          // the products of the whitened Jacobian the last wave has prepared
         __syncthreads();
         for (int e = tid; e < 900 + 30; e += MG_THREADS) {
             if (e < 900) {
@@ -480,7 +489,7 @@ __global__ __launch_bounds__(256) void be_gauge_kernel(BeGaugeArgs a) {
 }
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(256), 0, s, a); }
 
-static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16) * sizeof(double); }
+static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16 + 960) * sizeof(double); }
 static size_t lm_smem(int D) { return ((size_t)BE_MAX_OBS_FACTORS * 54 + 2 * (size_t)BE_MAX_OBS_FACTORS * D + 2 * D) * sizeof(double); }
 
 int be_launch_marg(const BeMargArgs& a, hipStream_t s) {

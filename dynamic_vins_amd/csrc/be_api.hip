@@ -163,9 +163,9 @@ static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, doubl
     ma.D = pl.D; ma.m = pl.m; ma.g_norm = g_norm; ma.outA = outA; ma.outb = outb; ma.out_scalars = scal; ma.c0_out = c0_out;
     const size_t slab = (size_t)pl.D * pl.D + pl.D;
     // sized once for 256 landmarks anchored in the oldest frame at the largest system (D = 178): growing it later would stall the stream
-    const size_t need = 8 * (slab * (size_t)std::max(pl.nsel, 1) + 8 * slab + (size_t)std::max(pl.nsel, 1));      // slabs | 8 chunk sums | h
+    const size_t need = 8 * (slab * (size_t)std::max(pl.nsel, 1) + 8 * slab + (size_t)std::max(pl.nsel, 1) + 512);      // slabs | 8 chunk sums | h | whitened IMU factor
     DV_CHECK(w.marg_buf.ensure(std::max(need, (size_t)8 * (((size_t)178 * 178 + 178) * 264 + 256))));
-    ma.slabs = (double*)w.marg_buf.p; ma.sum = ma.slabs + slab * (size_t)std::max(pl.nsel, 1); ma.lm_h = ma.sum + 8 * slab;
+    ma.slabs = (double*)w.marg_buf.p; ma.sum = ma.slabs + slab * (size_t)std::max(pl.nsel, 1); ma.lm_h = ma.sum + 8 * slab; ma.imu_w = ma.lm_h + std::max(pl.nsel, 1);
     StageScope sc(ctx, "k_be_marg", s);
     const int rc = be_launch_marg(ma, s);
     if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");

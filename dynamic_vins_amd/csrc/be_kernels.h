@@ -69,6 +69,7 @@ struct BeMargArgs {
     int D, m; double g_norm;
     double* outA; double* outb; double* out_scalars;     // n x n, n, {c0, min pivot, failure flag, rank}
     double* slabs; double* sum; double* lm_h;            // [nlm][D*D+D] per-landmark contributions, their sum, per-landmark h
+    double* imu_w;                // [465] whitened Jacobian (15 x 30) and residual (15) of the IMU factor (0,1): written by the extra block of be_marg_lm, read by be_marg_finish
     double* c0_out;               // optional second home of c0 (the device-resident prior of the estimator)
     const int32_t* lm_sel;        // optional: landmark b of the launch is lm[lm_sel[b]] (marginalization straight out of the solved window)
 };

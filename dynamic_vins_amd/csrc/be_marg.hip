@@ -68,6 +68,28 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
     __shared__ int s_fj[BE_MAX_OBS_FACTORS], s_two[BE_MAX_OBS_FACTORS];
     __shared__ double s_hg[2];
     const BeState* st = a.x;
+    if (l == a.nlm) {
+        // extra block (present when the window has an IMU factor to marginalize): factor (0,1) evaluated at the solved state and whitened, beside the landmark
+        // blocks.  be_marg_finish used to do this itself: a serial raw evaluation on one lane in the middle of a single-workgroup kernel.
+        double* Jraw = sm; double* Jw = sm + 450; double* rr = sm + 900;
+        __shared__ BeImu s_m;
+        for (int i = tid; i < 450; i += LM_THREADS) Jraw[i] = 0.0;
+        {
+            const double* src = reinterpret_cast<const double*>(a.imu); double* dst = reinterpret_cast<double*>(&s_m);
+            for (int i = tid; i < (int)(sizeof(BeImu) / 8); i += LM_THREADS) dst[i] = src[i];
+        }
+        __syncthreads();
+        const BeImu* mi = &s_m;
+        if (tid == 0) imu_raw<true>(*mi, a.g_norm, st->pose[mi->fi], st->sb[mi->fi], st->pose[mi->fj], st->sb[mi->fj], rr, Jraw);
+        __syncthreads();
+        if (tid < 15) { double s = 0; for (int q = tid; q < 15; ++q) s += mi->sqrt_info[tid * 15 + q] * rr[q]; a.imu_w[450 + tid] = s; }
+        for (int e = tid; e < 450; e += LM_THREADS) {
+            const int i = e / 30, cc = e - i * 30; double s = 0;
+            for (int q = i; q < 15; ++q) s += mi->sqrt_info[i * 15 + q] * Jraw[q * 30 + cc];
+            a.imu_w[e] = s;
+        }
+        return;
+    }
     MTS(0);
     __shared__ short s_slot[BE_MAX_PRIOR], s_comp[BE_MAX_PRIOR];      // dim -> (slot, component): read once, coalesced (they were two dependent global loads per dense-row entry)
     for (int i = tid; i < D; i += LM_THREADS) { s_slot[i] = (short)a.dim_slot[i]; s_comp[i] = (short)a.dim_comp[i]; }
@@ -189,22 +211,14 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     double* imu_ws = misc + 16;                           // 960: raw / whitened Jacobian and residual of the IMU factor (its own region: prepared beside the phases below)
     const BeState* st = a.x;
     MTS(8);
-    // The last wave takes no share of the assembly below: it prepares the IMU factor (0,1) meanwhile — staging of the 2.4 KB record, the raw evaluation on
-    // ONE lane (~3.5 us of serial fp64), whitening — which used to be a phase of its own behind the prior (9 us).  It meets the others at the barriers.
+    // The last wave takes no share of the assembly below: it fetches the whitened IMU factor (0,1) that the extra block of be_marg_lm has prepared (the raw
+    // evaluation on ONE lane and the whitening used to be a 9 us phase of this kernel, behind the prior).
     const int MGW = MG_THREADS - 64;                      // worker threads of the assembly
     const bool imu_wave = tid >= MGW;
-    double* Jraw = imu_ws; double* Jw = imu_ws + 450; double* rr = imu_ws + 900;
-    __shared__ BeImu s_m;                                 // the factor record
+    double* Jw = imu_ws + 450; double* rr = imu_ws + 900;
     if (imu_wave && a.nimu > 0) {
         const int lane = tid - MGW;
-        for (int i = lane; i < 450; i += 64) Jraw[i] = 0.0;
-        {
-            const double* src = reinterpret_cast<const double*>(a.imu); double* dst = reinterpret_cast<double*>(&s_m);
-            for (int i = lane; i < (int)(sizeof(BeImu) / 8); i += 64) dst[i] = src[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-        const BeImu* mi = &s_m;
-        if (lane == 0) imu_raw<true>(*mi, a.g_norm, st->pose[mi->fi], st->sb[mi->fi], st->pose[mi->fj], st->sb[mi->fj], rr, Jraw);
+        for (int i = lane; i < 465; i += 64) { const double v = a.imu_w[i]; if (i < 450) Jw[i] = v; else rr[15 + i - 450] = v; }
     }
     {   // 4 entries x 8 chunk sums per batch: 32 independent global loads in flight per thread (they were 8 at a time behind a loop-carried wait)
         const int total = D * D + D;
@@ -235,16 +249,6 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     }
     __syncthreads();
     MTS(9);
-    if (imu_wave && a.nimu > 0) {          // second half of the last wave's job (beside the prior phase): whitening
-        const int lane = tid - MGW;
-        const BeImu* mi = &s_m;
-        if (lane < 15) { double s = 0; for (int q = lane; q < 15; ++q) s += mi->sqrt_info[lane * 15 + q] * rr[q]; rr[15 + lane] = s; }
-        for (int e = lane; e < 450; e += 64) {
-            const int i = e / 30, cc = e - i * 30; double s = 0;
-            for (int q = i; q < 15; ++q) s += mi->sqrt_info[i * 15 + q] * Jraw[q * 30 + cc];
-            Jw[e] = s;
-        }
-    }
     // ---------------- previous prior: A += A_old (mapped), b += b_old + A_old dx ----------------
     if (a.prior->valid) {
         const int no = a.prior->n;
@@ -500,8 +504,8 @@ int be_launch_marg(const BeMargArgs& a, hipStream_t s) {
             return 0; })) return -1;
     const size_t bytes = finish_smem(a.D, a.D - a.m);
     if (bytes > 156 * 1024 || lm_smem(a.D) > 64 * 1024) return -2;
+    if (a.nlm > 0 || a.nimu > 0) hipLaunchKernelGGL(be_marg_lm_kernel, dim3(a.nlm + (a.nimu > 0 ? 1 : 0)), dim3(LM_THREADS), lm_smem(a.D), s, a);
     if (a.nlm > 0) {
-        hipLaunchKernelGGL(be_marg_lm_kernel, dim3(a.nlm), dim3(LM_THREADS), lm_smem(a.D), s, a);
         const int total = a.D * a.D + a.D;
         hipLaunchKernelGGL(be_marg_sum_kernel, dim3((total + 255) / 256, MG_SUM_CHUNKS), dim3(256), 0, s, a);
     }

@@ -55,7 +55,7 @@ def csrc_digest():
     import glob
     import hashlib
     h = hashlib.sha1()
-    for f in sorted(glob.glob(os.path.join(ROOT, "dynamic_vins_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "dynamic_vins_amd", "csrc", "*.h"))):
+    for f in sorted(sum((glob.glob(os.path.join(ROOT, "dynamic_vins_amd", "csrc", pat)) for pat in ("*.hip", "*.h", "*.inc")), [])):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -348,9 +348,6 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
             if (c0 >= 0) for (int k = 0; k < pb.size_local; ++k) prior_col[c0 + k] = pb.off + k;
         }
     }
-    for (int k = 0; k < BE_WIN; ++k) { d.imu_fi[k] = k < P->nimu ? (int16_t)P->imu[k].fi : -1; d.imu_fj[k] = k < P->nimu ? (int16_t)P->imu[k].fj : -1; }
-    d.prior_valid = has_prior ? 1 : 0; d.prior_n = (int16_t)(has_prior ? ph.n : 0);
-    for (int f = 0; f < BE_NF; ++f) d.prior_pose[f] = (has_prior && d.pose_col[f] >= 0) ? (int16_t)prior_col[d.pose_col[f]] : -1;
     // ---- marginalization structure (does not depend on the solution): planned now so that its tables ride in the same upload ----
     MargPlan& pl = pd.pl;
     const bool do_marg = fused && fused->marg_mode >= 0;

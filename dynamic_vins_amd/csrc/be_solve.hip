@@ -55,42 +55,42 @@ __device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, const RedCtx
     }
     return H;
 }
-// the same sums for a POSE column pair: kind / frame / component follow from the block, the IMU factors' frames, the prior header and the prior index of the
-// pose blocks come from the kernel arguments (BeDims): no table in memory stands before the value loads, which are unconditional (a dummy address where a
-// term is absent) and unrolled, so the <= 11 values travel in ONE round trip that can start with the block; added in the same order as red_dense_h
-__device__ __forceinline__ double red_dense_h_pose(const BeSolveArgs& a, const double* imu_out, int fi, int ci, int fj, int cj) {
+// the same sums for a POSE column pair: kind / frame / component are known from the block (no column-map loads), the prior indices come from LDS
+__device__ __forceinline__ double red_dense_h_pose(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, int fi, int ci, int fj, int cj, int pi, int pj) {
+    // every load unconditional (a dummy address where the term is absent) and the loop unrolled: the <= 11 values travel in ONE round trip instead of one
+    // per contributing factor behind its branch; added in the same order
     double v[BE_WIN]; bool ok[BE_WIN];
 #pragma unroll
     for (int k = 0; k < BE_WIN; ++k) {
-        const int mfi = a.dims.imu_fi[k], mfj = a.dims.imu_fj[k];      // -1 beyond nimu
+        const bool live = k < a.dims.nimu;
+        const int mfi = live ? rc.ifi[k] : -1, mfj = live ? rc.ifj[k] : -1;
         int li = -1, lj = -1;
         if (fi == mfi) li = ci; else if (fi == mfj) li = 15 + ci;
         if (fj == mfi) lj = cj; else if (fj == mfj) lj = 15 + cj;
-        ok[k] = mfi >= 0 && li >= 0 && lj >= 0;
+        ok[k] = live && li >= 0 && lj >= 0;
         v[k] = imu_out[ok[k] ? (size_t)k * IMU_OUT_STRIDE + 31 + li * 30 + lj : 0];
     }
-    const int pi0 = a.dims.prior_pose[fi], pj0 = a.dims.prior_pose[fj];
-    const bool okp = a.dims.prior_valid && pi0 >= 0 && pj0 >= 0;
-    const double vp = a.priorA[okp ? (size_t)(pi0 + ci) * a.dims.prior_n + pj0 + cj : 0];
+    const bool okp = rc.prior_valid && pi >= 0 && pj >= 0;
+    const double vp = a.priorA[okp ? (size_t)pi * rc.prior_n + pj : 0];
     double H = 0.0;
 #pragma unroll
     for (int k = 0; k < BE_WIN; ++k) if (ok[k]) H += v[k];
     if (okp) H += vp;
     return H;
 }
-__device__ __forceinline__ double red_dense_g_pose(const BeSolveArgs& a, const double* imu_out, const double* prior_out, int fi, int ci) {
+__device__ __forceinline__ double red_dense_g_pose(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int fi, int ci, int pi) {
     double v[BE_WIN]; bool ok[BE_WIN];
 #pragma unroll
     for (int k = 0; k < BE_WIN; ++k) {
-        const int mfi = a.dims.imu_fi[k], mfj = a.dims.imu_fj[k];
+        const bool live = k < a.dims.nimu;
+        const int mfi = live ? rc.ifi[k] : -1, mfj = live ? rc.ifj[k] : -1;
         int li = -1;
         if (fi == mfi) li = ci; else if (fi == mfj) li = 15 + ci;
-        ok[k] = mfi >= 0 && li >= 0;
+        ok[k] = live && li >= 0;
         v[k] = imu_out[ok[k] ? (size_t)k * IMU_OUT_STRIDE + 1 + li : 0];
     }
-    const int pi0 = a.dims.prior_pose[fi];
-    const bool okp = a.dims.prior_valid && pi0 >= 0;
-    const double vp = prior_out[okp ? 1 + pi0 + ci : 0];
+    const bool okp = rc.prior_valid && pi >= 0;
+    const double vp = prior_out[okp ? 1 + pi : 0];
     double G = 0.0;
 #pragma unroll
     for (int k = 0; k < BE_WIN; ++k) if (ok[k]) G += v[k];
@@ -133,16 +133,12 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
     __shared__ unsigned short s_list[BE_MAX_LM]; __shared__ int s_cnt;
     if ((int)threadIdx.x < a.dims.nimu) { s_ifi[threadIdx.x] = a.imu[threadIdx.x].fi; s_ifj[threadIdx.x] = a.imu[threadIdx.x].fj; }
     if (threadIdx.x == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
-    __shared__ double s_dh[36], s_dg[6];
-    if (bx < RED_PAIRS && (threadIdx.x >> 6) == 6 && !a.sh.on) {
-        // pair block (fi, fj): the IMU / prior part of its 36 entries (and 6 gradient entries), by the seventh wave and from the first instruction on — it
-        // needs nothing that the staging below provides — WHILE wave 2 compacts the landmark list and the other waves stream the packets
-        const int fi = bx / BE_NF, fj = bx - fi * BE_NF, lane = threadIdx.x & 63;
-        const bool live = fi < a.dims.nframes && fj < a.dims.nframes && a.dims.pose_col[fi] >= 0 && a.dims.pose_col[fj] >= 0;
-        if (live) {
-            if (lane < 36) s_dh[lane] = red_dense_h_pose(a, imu_out, fi, lane / 6, fj, lane % 6);
-            else if (fi == fj && lane < 42) s_dg[lane - 36] = red_dense_g_pose(a, imu_out, prior_out, fi, lane - 36);
-        }
+    __shared__ int s_pci[6], s_pcj[6];      // pair blocks: prior index of the block's six row / column pose entries (fetched with the tables above: one round trip)
+    if (bx < RED_PAIRS && threadIdx.x >= 65 && threadIdx.x < 77) {
+        const int fi = bx / BE_NF, fj = bx - fi * BE_NF, t = threadIdx.x - 65;
+        const int f = t < 6 ? fi : fj, c0 = f < a.dims.nframes ? a.dims.pose_col[f] : -1;
+        const int v = c0 >= 0 ? a.prior_col[c0 + (t < 6 ? t : t - 6)] : -1;
+        if (t < 6) s_pci[t] = v; else s_pcj[t - 6] = v;
     }
     if (bx < RED_PAIRS && (threadIdx.x >> 6) == 2) {
         // pair block (fi, fj): the landmarks whose factors touch BOTH poses, compacted in ascending order by one wave (ballot + prefix count) — for two
@@ -171,6 +167,19 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
         if (ci0 < 0 || cj0 < 0) return;
         const int ci = threadIdx.x >> 6, lane = threadIdx.x & 63;
         const bool diag = fi == fj;
+        // the IMU / prior part of the block's 36 entries (and 6 gradient entries) is a chain of dependent global loads (column maps ->
+        // factor / prior indices -> values): the seventh wave walks it WHILE the other six stream the landmark packets
+        __shared__ double s_dh[36], s_dg[6];
+        if (ci == 6 && !a.sh.on) {
+#ifdef BE_RED_TS
+            if (bx == 0 && lane == 0) be_red_ts[16] = wall_clock64();
+#endif
+            if (lane < 36) s_dh[lane] = red_dense_h_pose(a, rc, imu_out, fi, lane / 6, fj, lane % 6, s_pci[lane / 6], s_pcj[lane % 6]);
+            else if (diag && lane < 42) s_dg[lane - 36] = red_dense_g_pose(a, rc, imu_out, prior_out, fi, lane - 36, s_pci[lane - 36]);
+#ifdef BE_RED_TS
+            if (bx == 0 && lane == 0) be_red_ts[17] = wall_clock64();
+#endif
+        }
         double S[6] = {0, 0, 0, 0, 0, 0}, H[6] = {0, 0, 0, 0, 0, 0}, G = 0, GS = 0;
         const int e_wi = BE_PK_W + fi * 6 + ci, e_wj = BE_PK_W + fj * 6;
         const int e_dd = BE_PK_DD + fi * 36 + ci * 6;

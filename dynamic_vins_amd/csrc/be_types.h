@@ -91,7 +91,4 @@ struct BeCtl {
 struct BeDims {
     int32_t nframes, nlm, nfac, nimu, nstate, use_imu, plane_kind, pad;
     int32_t pose_col[BE_NF], sb_col[BE_NF];      // column of each block in the reduced system, -1 = constant/absent
-    // what the pose-pair blocks of be_reduce need of the IMU factors and the prior, as kernel ARGUMENTS (scalar loads) instead of device tables behind a
-    // staging barrier: frames of every IMU factor, prior header, prior index of each pose block's first entry (-1 = not in the prior)
-    int16_t imu_fi[BE_WIN], imu_fj[BE_WIN], prior_pose[BE_NF], prior_valid, prior_n, pad16;
 };

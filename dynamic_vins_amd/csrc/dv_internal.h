@@ -83,7 +83,7 @@ int  dv_launch_gftt_select(const GfttSelectArgs& a, hipStream_t s);
 void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_pitch, int sort_by_cnt, int* n_cand,
                        unsigned* max_ord, hipStream_t s);
 void dv_launch_finalize(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max,
-                        dv_feat* out, int* n_out, hipStream_t s);
+                        dv_feat* out, int* n_out, hipStream_t s, const int* err_in = nullptr, int* err_out = nullptr);      // out / n_out / err_out may be pinned host memory; *err_out = *err_in by thread 0
 void dv_launch_circle_mask(uint8_t* mask, int w, int h, int pitch, const float2* pts, int n, int radius, const uint8_t* hw,
                            hipStream_t s);
 void dv_launch_erode(const uint8_t* src, int w, int h, int spitch, int k, uint8_t* tmp, int tpitch, uint8_t* dst, int dpitch,

@@ -305,10 +305,9 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     }
     {
         StageScope sc(ctx, "finalize");
-        dv_launch_finalize(ctx->tr, c.cam0, c.cam1, stereo ? 1 : 0, t - ctx->prev_time, c.max_cnt, ctx->out_dev, ctx->nout_dev, s);
-        DV_CHECK(hipMemcpyAsync(ctx->out_pinned, ctx->out_dev, (size_t)c.max_cnt * sizeof(dv_feat), hipMemcpyDeviceToHost, s));
-        DV_CHECK(hipMemcpyAsync(ctx->nout_pinned, ctx->nout_dev, 4, hipMemcpyDeviceToHost, s));
-        DV_CHECK(hipMemcpyAsync(ctx->err_pinned, ctx->err_flag, 4, hipMemcpyDeviceToHost, s));
+        // the rows, their count and the device error flags go straight into the pinned buffer (three copy dispatches behind the kernel before: ~20 us of the
+        // tracker's latency per frame)
+        dv_launch_finalize(ctx->tr, c.cam0, c.cam1, stereo ? 1 : 0, t - ctx->prev_time, c.max_cnt, ctx->out_pinned, ctx->nout_pinned, s, ctx->err_flag, ctx->err_pinned);
     }
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipEventRecord(ctx->done, s));

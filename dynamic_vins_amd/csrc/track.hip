@@ -87,11 +87,15 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(DvTrackState tr, co
 }
 
 __global__ __launch_bounds__(256) void track_finalize_kernel(DvTrackState tr, dv_cam cam0, dv_cam cam1, int stereo, double dt,
-                                                             dv_feat* __restrict__ out, int* __restrict__ n_out, float off_x, float off_y, int use_off) {
+                                                             dv_feat* __restrict__ out, int* __restrict__ n_out, float off_x, float off_y, int use_off,
+                                                             const int* __restrict__ err_in, int* __restrict__ err_out) {
+    // `out` / `n_out` / `err_out` may be PINNED HOST memory (the frame's download without copy dispatches behind the kernel): the rows leave through LDS
+    // so that a wave writes 1 KB of consecutive bytes, not 64 rows' fields at a 128-byte stride
+    __shared__ dv_feat s_rows[256];
     const int n = *tr.n_feat;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0) *n_out = n;
-    if (i >= n) return;
+    if (i == 0) { *n_out = n; if (err_out) *err_out = *err_in; }
+    if (i < n) {
     const float2 p = tr.curr_pts[i];
     double ux, uy;
     // objects (InstFeat::UndistortedPointsWithAddOffset, instance_feature.cpp:123-133): pt.x + box2d->rect.tl().x is a float + float sum (Box2D::rect is a cv::Rect2f)
@@ -125,12 +129,20 @@ __global__ __launch_bounds__(256) void track_finalize_kernel(DvTrackState tr, dv
         f.has_right = 1; rv = 1;
         f.right[0] = run.x; f.right[1] = run.y; f.right[2] = 1.0; f.right[3] = rp.x; f.right[4] = rp.y; f.right[5] = rvel.x; f.right[6] = rvel.y;
     }
-    out[i] = f;
+    s_rows[threadIdx.x] = f;
     // PostProcess: last = curr, prev_id_pts = curr_id_pts, right_prev_id_pts = right_curr_id_pts
     tr.last_pts[i] = p;
     tr.prev_un[i] = un;
     tr.prev_run[i] = run;
     tr.prev_rvalid[i] = rv;
+    }
+    __syncthreads();
+    const int row0 = blockIdx.x * blockDim.x, nb = min((int)blockDim.x, n - row0);
+    if (nb > 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(s_rows);
+        uint4* dst = reinterpret_cast<uint4*>(out + row0);
+        for (int e = threadIdx.x; e < nb * (int)(sizeof(dv_feat) / 16); e += blockDim.x) dst[e] = src[e];
+    }
 }
 
 __global__ __launch_bounds__(256) void circle_mask_kernel(uint8_t* mask, int w, int h, int pitch, const float2* __restrict__ pts, int n,
@@ -178,13 +190,13 @@ __global__ __launch_bounds__(256) void lift_kernel(dv_cam cam, const float2* __r
 void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_pitch, int sort_by_cnt, int* n_cand, unsigned* max_ord, hipStream_t s) {
     hipLaunchKernelGGL(track_compact_kernel, dim3(1), dim3(1024), 0, s, tr, in_mask, mask_pitch, sort_by_cnt, n_cand, max_ord);
 }
-void dv_launch_finalize(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, dv_feat* out, int* n_out, hipStream_t s) {
+void dv_launch_finalize(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, dv_feat* out, int* n_out, hipStream_t s, const int* err_in, int* err_out) {
     const int blocks = (n_max + 255) / 256;
-    hipLaunchKernelGGL(track_finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, tr, cam0, cam1, stereo, dt, out, n_out, 0.f, 0.f, 0);
+    hipLaunchKernelGGL(track_finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, tr, cam0, cam1, stereo, dt, out, n_out, 0.f, 0.f, 0, err_in, err_out);
 }
 void dv_launch_finalize_offset(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, double off_x, double off_y, dv_feat* out, int* n_out, hipStream_t s) {
     const int blocks = (n_max + 255) / 256;
-    hipLaunchKernelGGL(track_finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, tr, cam0, cam1, stereo, dt, out, n_out, (float)off_x, (float)off_y, 1);
+    hipLaunchKernelGGL(track_finalize_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, s, tr, cam0, cam1, stereo, dt, out, n_out, (float)off_x, (float)off_y, 1, (const int*)nullptr, (int*)nullptr);
 }
 void dv_launch_circle_mask(uint8_t* mask, int w, int h, int pitch, const float2* pts, int n, int radius, const uint8_t* hw, hipStream_t s) {
     if (n <= 0) return;

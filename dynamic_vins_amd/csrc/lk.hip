@@ -20,6 +20,24 @@
 // Float math is compiled with -ffp-contract=off and uses correctly rounded div/sqrt.
 #include "dv_internal.h"
 #include "wave_dpp.h"
+#ifdef LK_TS
+// debug build only: iteration counts and wall-clock (100 MHz) of the LK waves.  [0] iterations, [1] level passes, [3] max duration of one point,
+// [4] sum of loop time, [5] sum of pre-loop (staging, gradients, A) time, [6] points, [7] sum of point durations, [8] level passes whose I tile took the
+// border (byte-wise, reflect-101) path, [9] their pre-loop time, [10] J tiles staged, [11] J tiles on the border path, [12] max iterations of a level pass
+__device__ unsigned long long lk_dbg[16];
+extern "C" int dv_debug_lk_ts(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lk_dbg), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(lk_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define LKADD(k, v) do { if (lane == 0) atomicAdd(&lk_dbg[k], (unsigned long long)(v)); } while (0)
+#define LKMAX(k, v) do { if (lane == 0) atomicMax(&lk_dbg[k], (unsigned long long)(v)); } while (0)
+#define LKNOW() wall_clock64()
+#else
+#define LKADD(k, v) do {} while (0)
+#define LKMAX(k, v) do {} while (0)
+#define LKNOW() 0ll
+#endif
 #include <cfloat>
 
 #define WIN DV_LK_WIN
@@ -76,6 +94,7 @@ __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01,
 // next is in/out (nextPts[ptidx]); status is cleared only at level 0.
 __device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_level, float2 prev, float2& next,
                          bool& status, int max_count, double eps_sq, bool use_initial, uint8_t* sI, uint8_t* sJ, int lane) {
+    const long long lk_t0 = LKNOW(); (void)lk_t0;
     const float half = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float lscale = (float)(1. / (1 << level));
@@ -94,6 +113,7 @@ __device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_
     // ---- stage the I tile: rows ipy-1..ipy+22, cols ipx-1..ipx+22 ----
     const int itx0 = ipx - 1, iax0 = itx0 & ~3, ioff = itx0 - iax0;
     lk_stage_tile(sI, IT_PITCH, IT_ROWS, I, iax0, ipy - 1, itx0, 24, lane);
+    const bool lk_slow_i = !(itx0 >= 0 && itx0 + 24 <= I.w && ipy - 1 >= 0 && ipy - 1 + IT_ROWS <= I.h); (void)lk_slow_i;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
 
@@ -105,9 +125,14 @@ __device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_
         const uint8_t* T = sI + (r + 1) * IT_PITCH + (c0 + 1 + ioff);
         // column-wise Scharr partials for rows y=r (j=0) and y=r+1 (j=1), cols c0-1..c0+8
         int t0[2][10], t1[2][10];
+        // ten bytes of each of the four rows as one 8-byte and one 2-byte LDS read (gfx950 reads LDS unaligned): 8 LDS instructions instead of 40 byte reads
+        uint64_t q8[4]; uint16_t q2[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) { __builtin_memcpy(&q8[rr], T + (rr - 1) * IT_PITCH - 1, 8); __builtin_memcpy(&q2[rr], T + (rr - 1) * IT_PITCH + 7, 2); }
+        auto byte_of = [&](int rr, int k) -> int { return k < 8 ? (int)((q8[rr] >> (8 * k)) & 0xff) : (int)((q2[rr] >> (8 * (k - 8))) & 0xff); };
 #pragma unroll
         for (int k = 0; k < 10; ++k) {
-            int a = T[-IT_PITCH + k - 1], b = T[k - 1], c = T[IT_PITCH + k - 1], d = T[2 * IT_PITCH + k - 1];
+            int a = byte_of(0, k), b = byte_of(1, k), c = byte_of(2, k), d = byte_of(3, k);
             t0[0][k] = (a + c) * 3 + b * 10;  t1[0][k] = c - a;
             t0[1][k] = (b + d) * 3 + c * 10;  t1[1][k] = d - b;
         }
@@ -148,13 +173,18 @@ __device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_
     float2 prevDelta = make_float2(0.f, 0.f);
     int jx0 = 0, jy0 = 0, jax0 = 0;
     bool have_tile = false;
+    const long long lk_t1 = LKNOW(); (void)lk_t1;
+    LKADD(1, 1); LKADD(5, lk_t1 - lk_t0); if (lk_slow_i) { LKADD(8, 1); LKADD(9, lk_t1 - lk_t0); }
+    int lk_it = 0; (void)lk_it;
     for (int j = 0; j < max_count; ++j) {
+        LKADD(0, 1); ++lk_it;
         const int inx = (int)floorf(nextPt.x), iny = (int)floorf(nextPt.y);
         if (inx < -WIN || inx >= J.w || iny < -WIN || iny >= J.h) { if (level == 0) status = false; break; }
         if (!have_tile || inx < jx0 || inx > jx0 + 2 * JT_MARGIN || iny < jy0 || iny > jy0 + 2 * JT_MARGIN) {
             jx0 = inx - JT_MARGIN; jy0 = iny - JT_MARGIN; jax0 = jx0 & ~3;
             __builtin_amdgcn_wave_barrier();
             lk_stage_tile(sJ, JT_PITCH, JT_ROWS, J, jax0, jy0, jx0, 32, lane);
+            LKADD(10, 1); if (!(jx0 >= 0 && jx0 + 32 <= J.w && jy0 >= 0 && jy0 + JT_ROWS <= J.h)) LKADD(11, 1);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             have_tile = true;
@@ -164,8 +194,9 @@ __device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_
         {
             const uint8_t* T = sJ + (iny - jy0 + r) * JT_PITCH + (inx - jax0 + c0);
             int top[8], bot[8];
+            { uint64_t t8, b8; __builtin_memcpy(&t8, T, 8); __builtin_memcpy(&b8, T + JT_PITCH, 8);      // two 8-byte LDS reads instead of 16 byte reads
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { top[i] = T[i]; bot[i] = T[JT_PITCH + i]; }
+              for (int i = 0; i < 8; ++i) { top[i] = (int)((t8 >> (8 * i)) & 0xff); bot[i] = (int)((b8 >> (8 * i)) & 0xff); } }
             if (active) {
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
@@ -187,6 +218,7 @@ __device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_
         }
         prevDelta = delta;
     }
+    LKADD(4, LKNOW() - lk_t1); LKMAX(12, lk_it);
     if (status && level == 0) {   // err != NULL at the reference call sites: final in-bounds re-check
         const int ix = (int)floorf(next.x - half), iy = (int)floorf(next.y - half);
         if (ix < -WIN || ix >= J.w || iy < -WIN || iy >= J.h) status = false;
@@ -218,6 +250,7 @@ __global__ __launch_bounds__(64) void lk_generic_kernel(DvPyr A, DvPyr B, const 
 // FeatureTrackByLK fused: fwd (maxLevel 3) + bwd (maxLevel 1, initial flow) + distance + InBorder, for the wave's point p
 __device__ __forceinline__ void lk_track_point(const DvPyr& A, const DvPyr& B, const float2* __restrict__ pts_a, int p, int flow_back, float dist_thresh, double eps_sq,
                                                float2* __restrict__ pts_b, uint8_t* __restrict__ status, float add_x, float add_y, int use_add, uint8_t* sI, uint8_t* sJ, int lane) {
+    const long long lk_p0 = LKNOW(); (void)lk_p0;
     float2 prev = pts_a[p];
     if (use_add) { prev.x = prev.x + add_x; prev.y = prev.y + add_y; }      // InstFeat::TrackRightByPad: ROI coordinates + box2d->rect.tl() (float + float)
     float2 next = make_float2(0.f, 0.f);
@@ -236,6 +269,7 @@ __device__ __forceinline__ void lk_track_point(const DvPyr& A, const DvPyr& B, c
     }
     if (st && !lk_in_border(next, B.L[0].h, B.L[0].w)) st = false;
     if (lane == 0) { pts_b[p] = next; status[p] = st ? 1 : 0; }
+    LKADD(6, 1); LKADD(7, LKNOW() - lk_p0); LKMAX(3, LKNOW() - lk_p0);
 }
 __global__ __launch_bounds__(64) void lk_track_kernel(DvPyr A, DvPyr B, const float2* __restrict__ pts_a, const int* __restrict__ n_dev,
                                                       int n_host, int flow_back, float dist_thresh, double eps_sq,

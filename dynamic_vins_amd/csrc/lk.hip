@@ -82,6 +82,8 @@ __device__ __forceinline__ long long lk_wave_sum(int v) {
 }
 
 __device__ __forceinline__ int lk_descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+// Integer products below go through __mul24 (v_mul_i32_i24, full rate; v_mul_lo_u32 is quarter rate): every operand is far inside 24 bits — pixels < 2^8,
+// bilinear weights <= 2^14, Scharr sums < 2^13, interpolated values and differences < 2^15 — and the low 32 bits of the product are exact.
 
 __device__ __forceinline__ void lk_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
     w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
@@ -151,15 +153,15 @@ __device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_
         }
 #pragma unroll
         for (int i = 0; i < 7; ++i) {
-            Iv[i] = lk_descale(T[i] * w00 + T[i + 1] * w01 + T[IT_PITCH + i] * w10 + T[IT_PITCH + i + 1] * w11, 14 - 5);
-            Ixv[i] = lk_descale(gx[0][i] * w00 + gx[0][i + 1] * w01 + gx[1][i] * w10 + gx[1][i + 1] * w11, 14);
-            Iyv[i] = lk_descale(gy[0][i] * w00 + gy[0][i + 1] * w01 + gy[1][i] * w10 + gy[1][i + 1] * w11, 14);
+            Iv[i] = lk_descale(__mul24(byte_of(1, i + 1), w00) + __mul24(byte_of(1, i + 2), w01) + __mul24(byte_of(2, i + 1), w10) + __mul24(byte_of(2, i + 2), w11), 14 - 5);      // T[i] = row r+1, col k = i+1 of the bytes read above
+            Ixv[i] = lk_descale(__mul24(gx[0][i], w00) + __mul24(gx[0][i + 1], w01) + __mul24(gx[1][i], w10) + __mul24(gx[1][i + 1], w11), 14);
+            Iyv[i] = lk_descale(__mul24(gy[0][i], w00) + __mul24(gy[0][i + 1], w01) + __mul24(gy[1][i], w10) + __mul24(gy[1][i + 1], w11), 14);
         }
     }
     int pa11 = 0, pa12 = 0, pa22 = 0;
     if (active) {
 #pragma unroll
-        for (int i = 0; i < 7; ++i) { pa11 += Ixv[i] * Ixv[i]; pa12 += Ixv[i] * Iyv[i]; pa22 += Iyv[i] * Iyv[i]; }
+        for (int i = 0; i < 7; ++i) { pa11 += __mul24(Ixv[i], Ixv[i]); pa12 += __mul24(Ixv[i], Iyv[i]); pa22 += __mul24(Iyv[i], Iyv[i]); }
     }
     const float A11 = (float)lk_wave_sum(pa11) * FLT_SCALE;
     const float A12 = (float)lk_wave_sum(pa12) * FLT_SCALE;
@@ -200,9 +202,9 @@ __device__ void lk_level(const DvLevel& I, const DvLevel& J, int level, int max_
             if (active) {
 #pragma unroll
                 for (int i = 0; i < 7; ++i) {
-                    int diff = lk_descale(top[i] * w00 + top[i + 1] * w01 + bot[i] * w10 + bot[i + 1] * w11, 14 - 5) - Iv[i];
-                    pb1 += diff * Ixv[i];
-                    pb2 += diff * Iyv[i];
+                    int diff = lk_descale(__mul24(top[i], w00) + __mul24(top[i + 1], w01) + __mul24(bot[i], w10) + __mul24(bot[i + 1], w11), 14 - 5) - Iv[i];
+                    pb1 += __mul24(diff, Ixv[i]);
+                    pb2 += __mul24(diff, Iyv[i]);
                 }
             }
         }

@@ -236,7 +236,7 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculat
         const bool head = !speculative || it == 0, last = !speculative || it == slots - 1;
         if (head) { eval(BE_EVAL_X); reduce(0); if (exchange_system(0)) return -1; }
         if (solve(head ? 0 : 1)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
-        if (last) { eval(BE_EVAL_CAND_COST); if (exchange_cost()) return -1; accept(); }
+        if (last) { eval(BE_EVAL_CAND_COST); if (exchange_cost()) return -1; if (!(pd.fuse_accept_gauge && !kt && it == slots - 1)) accept(); }      // (fused: be_enqueue_tail launches accept + gauge as one kernel)
         else { eval(BE_EVAL_CAND_FULL); reduce(1); if (exchange_system(1)) return -1; }
     }
     return 0;
@@ -260,7 +260,8 @@ static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
                                    // leaves it, before Double2vector's gauge fix) the raw poses straight into the pinned buffer
         ga.h_out = hx; ga.h_ctl = hctl; ga.ctl = w.ctl; ga.state_doubles = (int)((pd.state_bytes + 7) / 8);
         ga.h_raw_pose = pd.want_raw_pose ? (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256) : nullptr;
-        be_launch_gauge(ga, s);
+        const bool kt = ctx->timing && ctx->kernel_timing;
+        if (pd.fuse_accept_gauge && !kt) be_launch_accept_gauge(pd.sa, ga, s); else be_launch_gauge(ga, s);
         DV_CHECK(hipGetLastError());
     } else {
         DV_CHECK(hipMemcpyAsync(hx, w.x, pd.state_bytes, hipMemcpyDeviceToHost, s));
@@ -419,7 +420,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
     // invalid; be_solve_fused_end checks the downloaded control block and, in that rare case, runs the spare slots and the
     // (idempotent) tail again.
-    pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
+    pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.fuse_accept_gauge = fused != nullptr && !ctx->batch; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
     pd.want_raw_pose = fused && fused->want_raw_pose;
     if (fused) { std::memcpy(pd.gauge_R0, fused->R0, sizeof(pd.gauge_R0)); std::memcpy(pd.gauge_ypr0, fused->ypr0, sizeof(pd.gauge_ypr0)); std::memcpy(pd.gauge_P0, fused->P0, sizeof(pd.gauge_P0)); }
     pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = 1 - w.prior_cur;

@@ -85,6 +85,7 @@ struct BeGaugeArgs {
 };
 
 #if defined(__HIPCC__)
+#include "wave_dpp.h"
 using namespace be;
 __device__ inline void be_frame_geom_dev(const BeState* s, int nframes, FrameGeom* fg, m33* ric, d3* tic, int lane) {
     if (lane < nframes) { fg[lane].R = qR(Q4(s->pose[lane])); fg[lane].P = P3(s->pose[lane]); }
@@ -109,6 +110,57 @@ __device__ inline void be_prior_dx_dev(const BePriorHdr* p, const BeState* s, do
     }
 }
 
+// accept / reject decision on the pending candidate (be_accept_kernel; also the first half of the fused accept + gauge kernel of the estimator path)
+__device__ __forceinline__ void be_accept_body(const BeSolveArgs& a) {
+    BeCtl* ctl = a.ctl;
+    const BeCtl c = *ctl;
+    __shared__ double red[4];
+    __shared__ int s_accept;
+    const int tid = threadIdx.x;
+    if (c.done || !c.pending) return;          // failed factorisations and invalid steps are settled by the solve kernel itself
+    if (tid == 0) { ctl->slots = c.slots + 1; ctl->pending = 0; s_accept = 0; }
+    const int iter = c.iter + 1;
+    // candidate cost: fixed-order sum
+    const int ncost = a.dims.nlm + a.dims.nimu + 1;
+    double part = 0;
+    for (int k = tid; k < ncost; k += 256) part += a.cand_cost[k];
+    part = wave_sum_f64(part);          // the same tree as the decision in be_solve's prologue, bit for bit
+    if ((tid & 63) == 0) red[tid >> 6] = part;
+    __syncthreads();
+    const double cand_cost = red[0] + red[1] + red[2] + red[3];
+    if (tid == 0) {
+        ctl->iter = iter; ctl->cand_cost = cand_cost; ctl->invalid = 0;
+        bool done = false; int term = 0;
+        if (c.step_norm <= 1e-8 * (c.x_norm + 1e-8)) { done = true; term = 1; }                       // parameter tolerance
+        else if (fabs(c.x_cost - cand_cost) <= 1e-6 * c.x_cost) { done = true; term = 1; }           // function tolerance
+        else {
+            const double rel = (c.x_cost - cand_cost) / c.model_cost_change;
+            if (rel > 1e-3) {
+                s_accept = 1;
+                double radius = c.radius;
+                if (rel < 0.25) radius *= 0.5;
+                if (rel > 0.75) radius = fmax(radius, 3.0 * c.dogleg_norm);
+                ctl->radius = radius; ctl->mu = fmax(1e-8, 2.0 * c.mu / 10.0);
+                ctl->x_cost = cand_cost; ctl->successful = c.successful + 1; ctl->reuse = 0; ctl->need_eval = 1;
+            } else {
+                ctl->radius = c.radius * 0.5; ctl->reuse = 1; ctl->need_eval = 0;
+                if (c.radius * 0.5 < 1e-32) { done = true; term = 1; }
+            }
+            if (!done && iter >= c.max_iters) { done = true; term = 0; }
+        }
+        if (done) { ctl->done = 1; ctl->termination = term; }
+    }
+    __syncthreads();
+    if (s_accept) {
+        const int nd = sizeof(BeState) / sizeof(double);
+        double* dst = reinterpret_cast<double*>(a.x);
+        const double* src = reinterpret_cast<const double*>(a.cand);
+        const int used = (int)(offsetof(BeState, inv_depth) / sizeof(double)) + a.dims.nlm;
+        for (int k = tid; k < used && k < nd; k += 256) dst[k] = src[k];
+    }
+}
+
+
 #endif
 
 // Iteration schedule (be_api.hip): the classic slot is  eval(x) -> reduce -> solve -> eval-cost(cand) -> accept.  The speculative slot
@@ -121,6 +173,7 @@ __device__ inline void be_prior_dx_dev(const BePriorHdr* p, const BeState* s, do
 void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s);
 int  be_launch_marg(const BeMargArgs& a, hipStream_t s);
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
+void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s);      // be_accept + be_gauge in one launch (estimator path)
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s);      // spec: reduce the candidate's set (or, after a failed / invalid step, rebuild x's with the new mu)
 int  be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s);        // spec: decide on the pending candidate first (be_accept_kernel's rule)
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);

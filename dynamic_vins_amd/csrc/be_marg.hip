@@ -440,7 +440,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void be_gauge_kernel(BeGaugeArgs a) {
+__device__ __forceinline__ void be_gauge_body(const BeGaugeArgs& a) {
     __shared__ m33 rot;
     __shared__ d3 p0;
     const int i = threadIdx.x;
@@ -491,7 +491,16 @@ __global__ __launch_bounds__(256) void be_gauge_kernel(BeGaugeArgs a) {
         if (a.h_raw_pose) for (int k = i; k < 7 * BE_NF; k += 256) a.h_raw_pose[k] = reinterpret_cast<const double*>(st->pose)[k];
     }
 }
+__global__ __launch_bounds__(256) void be_gauge_kernel(BeGaugeArgs a) { be_gauge_body(a); }
+// accept / reject decision of the last slot + gauge fix + download in ONE launch (the decision's copy x <- candidate is ordered before the gauge fix, which
+// reads x and overwrites the candidate buffer, by the workgroup barrier): one launch less on the path the host's wake-up and the marginalization both wait for
+__global__ __launch_bounds__(256) void be_accept_gauge_kernel(BeSolveArgs sa, BeGaugeArgs ga) {
+    be_accept_body(sa);
+    __syncthreads();
+    be_gauge_body(ga);
+}
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(256), 0, s, a); }
+void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s) { hipLaunchKernelGGL(be_accept_gauge_kernel, dim3(1), dim3(256), 0, s, sa, ga); }
 
 static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16 + 960) * sizeof(double); }
 static size_t lm_smem(int D) { return ((size_t)BE_MAX_OBS_FACTORS * 54 + 2 * (size_t)BE_MAX_OBS_FACTORS * D + 2 * D) * sizeof(double); }

@@ -76,6 +76,7 @@ struct MargPlan {
 struct BePending {        // a solve that has been enqueued and not yet collected (be_solve_fused_begin / _end)
     bool want_raw_pose = false;
     bool deferred = false; int first_slots = 0;      // member of a dv_batch: uploaded, the slots wait for dv_batch_enqueue
+    bool fuse_accept_gauge = false;      // estimator path outside a dv_batch: the last slot's accept decision rides in the gauge kernel (be_accept_gauge_kernel)
     bool active = false, trivial = false, do_marg = false, fused_present = false, marg_in_flight = false, marg_check_due = false; int scal_slot = 0, check_slot = 0; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
     BeEvalArgs ea; BeSolveArgs sa; int max_iters = 0, nframes = 0, use_imu = 0, nlm = 0; double g_norm = 0, gauge_R0[9], gauge_ypr0[3], gauge_P0[3];
     std::chrono::steady_clock::time_point t_begin, t_up, t_enq;

@@ -22,9 +22,10 @@ nobj = 0
 for i in range(STEPS):
     k, s = pipe.next, pipe.seq
     a = time.perf_counter()
-    rows = pipe.ctx.track_stereo_collect()
+    pre, pipe._prefetched = pipe._prefetched, None          # (Pipeline.step collects frame k+1's rows while the BA of frame k runs; this loop times the phases in sequence)
+    rows = pre[0] if pre is not None else pipe.ctx.track_stereo_collect()
     b = time.perf_counter()
-    insts, ifeats, pts = pipe.ctx.inst_track_collect()
+    insts, ifeats, pts = pre[1:] if pre is not None else pipe.ctx.inst_track_collect()
     c = time.perf_counter()
     t = s.times[k]
     pipe._feed_imu(t)

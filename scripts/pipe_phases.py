@@ -15,8 +15,9 @@ for k in range(N):
     if k == 30:
         acc.clear(); torch.cuda.synchronize(); tstart = time.perf_counter()
     t0 = time.perf_counter()
-    if not pipe.enqueued: pipe._enqueue(k)
-    rows = pipe.ctx.track_stereo_collect(); pipe.enqueued = False
+    pre, pipe._prefetched = pipe._prefetched, None
+    if pre is None and not pipe.enqueued: pipe._enqueue(k)
+    rows = pre if pre is not None else pipe.ctx.track_stereo_collect(); pipe.enqueued = False
     t0 = T("collect", t0)
     t = s.times[k]
     pipe._feed_imu(t)

@@ -234,9 +234,17 @@ __global__ __launch_bounds__(SEL_THREADS) void gftt_select_kernel(GfttSelectArgs
         int b = (int)((v - thr) * bscale);
         return min(max(b, 0), SEL_BINS - 1);
     };
-    for (int i = tid; i < n_cand; i += SEL_THREADS) {
-        int b = valid_bin(a.cand[i]);
-        if (b >= 0) atomicAdd(&hist[b], 1);
+    // (eight candidates requested per trip: one load + wait per candidate made this loop ~12 dependent round trips for a 1280x720 frame)
+    for (int i0 = tid; i0 < n_cand; i0 += 8 * SEL_THREADS) {
+        DvCand cb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * SEL_THREADS; cb[u] = a.cand[i < n_cand ? i : 0]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (i0 + u * SEL_THREADS >= n_cand) continue;
+            const int b = valid_bin(cb[u]);
+            if (b >= 0) atomicAdd(&hist[b], 1);
+        }
     }
     __syncthreads();
     // in-place inclusive suffix sums: hist[b] = #candidates with bin >= b ; hist[SEL_BINS] = 0
@@ -268,10 +276,16 @@ __global__ __launch_bounds__(SEL_THREADS) void gftt_select_kernel(GfttSelectArgs
         }
         __syncthreads();
         const int lo = s_lo;
-        for (int i = tid; i < n_cand; i += SEL_THREADS) {
-            DvCand c = a.cand[i];
-            int b = valid_bin(c);
-            if (b >= lo && b <= hi) { int k = atomicAdd(&s_m, 1); if (k < SEL_CAP) keys[k] = c.key; }
+        for (int i0 = tid; i0 < n_cand; i0 += 8 * SEL_THREADS) {
+            DvCand cb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * SEL_THREADS; cb[u] = a.cand[i < n_cand ? i : 0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (i0 + u * SEL_THREADS >= n_cand) continue;
+                const int b = valid_bin(cb[u]);
+                if (b >= lo && b <= hi) { int k = atomicAdd(&s_m, 1); if (k < SEL_CAP) keys[k] = cb[u].key; }
+            }
         }
         __syncthreads();
         const int m = min(s_m, SEL_CAP);

@@ -146,9 +146,17 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
         const int fi = bx / BE_NF, fj = bx - fi * BE_NF, lane = threadIdx.x & 63;
         const int lo = a.sh.on ? a.sh.lo : 0, hi = a.sh.on ? a.sh.hi : nlm;
         int base = 0;
-        for (int c0 = lo; c0 < hi; c0 += 64) {
+        // all observation masks requested up front (16 x 64 lanes covers BE_MAX_LM): with the load inside the ballot loop every 64 landmarks cost one
+        // dependent round trip (five for a 300-landmark window) on the path every other wave of the block waits for
+        int obv[(BE_MAX_LM + 63) / 64];
+#pragma unroll
+        for (int u = 0; u < (BE_MAX_LM + 63) / 64; ++u) { const int l = lo + 64 * u + lane; obv[u] = a.lm_obs[l < hi ? l : lo]; }
+#pragma unroll
+        for (int u = 0; u < (BE_MAX_LM + 63) / 64; ++u) {
+            const int c0 = lo + 64 * u;
+            if (c0 >= hi) break;
             const int l = c0 + lane;
-            const int ob = l < hi ? a.lm_obs[l] : 0;
+            const int ob = l < hi ? obv[u] : 0;
             const bool m = ((ob >> fi) & 1) && ((ob >> fj) & 1);
             const unsigned long long bal = __ballot(m);
             if (m) s_list[base + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)l;

@@ -123,7 +123,13 @@ __device__ __forceinline__ void be_accept_body(const BeSolveArgs& a) {
     // candidate cost: fixed-order sum
     const int ncost = a.dims.nlm + a.dims.nimu + 1;
     double part = 0;
-    for (int k = tid; k < ncost; k += 256) part += a.cand_cost[k];
+    {   // <= 4 costs per thread (BE_MAX_LM + BE_WIN + 1 <= 1024), requested together and added in index order (a load + wait per trip otherwise)
+        double cv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cv[u] = a.cand_cost[tid + 256 * u < ncost ? tid + 256 * u : 0];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (tid + 256 * u < ncost) part += cv[u];
+    }
     part = wave_sum_f64(part);          // the same tree as the decision in be_solve's prologue, bit for bit
     if ((tid & 63) == 0) red[tid >> 6] = part;
     __syncthreads();

@@ -67,9 +67,18 @@ __device__ __forceinline__ void lk_stage_tile(uint8_t* lds, int pitch, int rows,
             l32[i] = *reinterpret_cast<const uint32_t*>(L.p + (size_t)(y0 + r) * L.pitch + ax0 + 4 * c);
         }
     } else {
-        for (int i = lane; i < rows * pitch; i += 64) {
-            int r = i / pitch, c = i - r * pitch;
-            lds[i] = L.p[(size_t)lk_reflect101(y0 + r, L.h) * L.pitch + lk_reflect101(ax0 + c, L.w)];
+        // border path (17 - 22 % of the tiles; most tiles of the coarse levels): eight reflected bytes requested per trip, then stored — one load + wait per
+        // byte made a J tile 18 dependent round trips
+        for (int i0 = lane; i0 < rows * pitch; i0 += 8 * 64) {
+            uint8_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u < rows * pitch ? i0 + 64 * u : i0;
+                const int r = i / pitch, c = i - r * pitch;
+                v[u] = L.p[(size_t)lk_reflect101(y0 + r, L.h) * L.pitch + lk_reflect101(ax0 + c, L.w)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + 64 * u < rows * pitch) lds[i0 + 64 * u] = v[u];
         }
     }
 }

@@ -271,7 +271,14 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
             const int i = tid % no_pad, gI = tid / no_pad;
             const int seg = (no + groups - 1) / groups, j0 = gI * seg, j1 = min(no, j0 + seg);
             double sp = 0;
-            if (gI < groups && i < no) for (int j = j0; j < j1; ++j) sp += a.priorA[(size_t)j * no + i] * dx[j];
+            if (gI < groups && i < no)
+                for (int j = j0; j < j1; j += 16) {      // 16 rows requested per trip (one load + wait per row before: 14 dependent round trips for an 82-dimensional prior); added in row order
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = a.priorA[(size_t)(j + u < j1 ? j + u : j0) * no + i];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) if (j + u < j1) sp += v[u] * dx[j + u];
+                }
             if (gI < groups && i < no) part[gI * no_pad + i] = sp;
             __syncthreads();
             if (tid < no) {

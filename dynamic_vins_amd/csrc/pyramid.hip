@@ -38,17 +38,32 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict
     const int ax0 = sx0 - 2;                                  // 2*ox0-4: multiple of 4
     const bool interior = (ax0 >= 0) && (ax0 + PS_PITCH <= sw) && (sy0 >= 0) && (sy0 + PS_H <= sh) && ((spitch & 3) == 0)
                           && ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+    // Both staging loops request a batch into registers before the first LDS store: compiled as load -> wait -> store per trip they were 5 (interior) or 19
+    // (border tile: byte-wise, reflected) dependent round trips — and the coarse levels, whose launches have too few workgroups to hide one another's latency,
+    // consist almost entirely of border tiles.
     if (interior) {
         uint32_t* s32 = reinterpret_cast<uint32_t*>(s_src);
-        for (int i = tid; i < PS_H * (PS_PITCH / 4); i += 256) {
-            int r = i / (PS_PITCH / 4), c = i - r * (PS_PITCH / 4);
-            s32[i] = *reinterpret_cast<const uint32_t*>(src + (size_t)(sy0 + r) * spitch + ax0 + 4 * c);
+        constexpr int ND = PS_H * (PS_PITCH / 4), NT = (ND + 255) / 256;
+        uint32_t v[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const int i = tid + 256 * u < ND ? tid + 256 * u : tid;
+            const int r = i / (PS_PITCH / 4), c = i - r * (PS_PITCH / 4);
+            v[u] = *reinterpret_cast<const uint32_t*>(src + (size_t)(sy0 + r) * spitch + ax0 + 4 * c);
         }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) if (tid + 256 * u < ND) s32[tid + 256 * u] = v[u];
     } else {
-        for (int i = tid; i < PS_H * PS_PITCH; i += 256) {
-            int r = i / PS_PITCH, c = i - r * PS_PITCH;
-            int y = pyr_reflect101(sy0 + r, sh), x = pyr_reflect101(ax0 + c, sw);
-            s_src[i] = src[(size_t)y * spitch + x];
+        for (int i0 = tid; i0 < PS_H * PS_PITCH; i0 += 8 * 256) {
+            uint8_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 256 * u < PS_H * PS_PITCH ? i0 + 256 * u : i0;
+                const int r = i / PS_PITCH, c = i - r * PS_PITCH;
+                v[u] = src[(size_t)pyr_reflect101(sy0 + r, sh) * spitch + pyr_reflect101(ax0 + c, sw)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + 256 * u < PS_H * PS_PITCH) s_src[i0 + 256 * u] = v[u];
         }
     }
     __syncthreads();

@@ -62,9 +62,17 @@ __device__ __forceinline__ void lk_stage_tile(uint8_t* lds, int pitch, int rows,
     if (fast) {
         const int ndw = pitch >> 2;
         uint32_t* l32 = reinterpret_cast<uint32_t*>(lds);
-        for (int i = lane; i < rows * ndw; i += 64) {
-            int r = i / ndw, c = i - r * ndw;
-            l32[i] = *reinterpret_cast<const uint32_t*>(L.p + (size_t)(y0 + r) * L.pitch + ax0 + 4 * c);
+        // eight dwords requested per trip (the whole I tile is 3 per lane, the J tile 5): a load + wait per dword made a tile 3 resp. 5 dependent round trips
+        for (int i0 = lane; i0 < rows * ndw; i0 += 8 * 64) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + 64 * u < rows * ndw ? i0 + 64 * u : i0;
+                const int r = i / ndw, c = i - r * ndw;
+                v[u] = *reinterpret_cast<const uint32_t*>(L.p + (size_t)(y0 + r) * L.pitch + ax0 + 4 * c);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (i0 + 64 * u < rows * ndw) l32[i0 + 64 * u] = v[u];
         }
     } else {
         // border path (17 - 22 % of the tiles; most tiles of the coarse levels): eight reflected bytes requested per trip, then stored — one load + wait per

@@ -106,6 +106,8 @@ SIGNATURES = {
     "dv_batch_destroy": (None, [C.c_void_p]),
     "dv_batch_enqueue": (C.c_int, [C.c_void_p]),
     "dv_batch_arrive": (C.c_int, [C.c_void_p]),
+    "dv_batch_abort": (C.c_int, [C.c_void_p]),
+    "dv_est_get_marg_health": (C.c_int, [_ctx, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_void_p]),
     "dv_batch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dv_dist_unique_id": (C.c_int, [C.c_void_p]),
     "dv_dist_init_rccl": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),

@@ -419,7 +419,12 @@ class Batch:
     def arrive(self):
         """rendezvous of one host thread per member (the ctypes call releases the GIL while it waits)"""
         if self.lib.dv_batch_arrive(self.h) != 0:
-            raise DvinsError(self.lib.dv_last_error(self.ctxs[0].h).decode())
+            raise DvinsError((self.lib.dv_last_error(self.ctxs[0].h) or self.lib.dv_last_error(None) or b"dv_batch_arrive failed").decode())
+
+    def abort(self):
+        """a worker that failed before arriving calls this so that the other members' threads do not wait for ever"""
+        if getattr(self, "h", None):
+            self.lib.dv_batch_abort(self.h)
 
     def info(self):
         a, b = C.c_longlong(0), C.c_longlong(0)

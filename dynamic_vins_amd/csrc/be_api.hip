@@ -1,6 +1,7 @@
 // be_api.hip — host side of the bundle-adjustment entry points of include/dvins.h: uploads the flat problem
 // tables, enqueues the fixed kernel schedule of the trust-region loop on the ctx's BA stream (no host round trip
 // between iterations: every kernel is predicated on the device-resident BeCtl) and downloads the solved states.
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 #include "dv_ctx.h"
@@ -285,6 +286,7 @@ static int be_check_prev_marg(dv_ctx* ctx, BePending& pd) {
     // hscal[2] != 0: a pivot of A_mm was <= 1e-8 and was skipped on the device (pseudo-inverse, as the reference's eigen clamp does,
     // marginalization_factor.cpp:286-289).  The prior stays finite and usable, so the frame is never aborted half-way; the event is only counted.
     if (hscal[2] != 0.0) ctx->be.marg_clamped++;
+    std::memcpy(ctx->be.marg_last, hscal, 32); ctx->be.marg_checked++;
     return 0;
 }
 
@@ -500,7 +502,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     }
     if (fused && pd.want_raw_pose) std::memcpy(fused->raw_pose, hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256, sizeof(fused->raw_pose));
     if (pd.do_marg) {
-        std::memset(fused->diag, 0, sizeof(fused->diag));
+        std::memcpy(fused->diag, w.marg_last, sizeof(fused->diag));      // the scalars of THIS frame's marginalization are still in flight: the previous frame's (be_check_prev_marg)
         if (pl.empty) { std::memset(&fused->new_prior, 0, sizeof(fused->new_prior)); w.prior_resident = false; }
         else {
             // header only: A', b' and c0 are (being) written in HBM by the marginalization kernels still in flight
@@ -522,7 +524,21 @@ struct dv_batch {
     DevBuf tab; void* tab_pinned = nullptr;       // [S] BeEvalArgs | [S] BeSolveArgs
     long long batched_rounds = 0, single_rounds = 0;
     std::mutex mu; std::condition_variable cv; int arrived = 0; long long generation = 0; int last_rc = 0;      // dv_batch_arrive
+    bool aborted = false;                         // dv_batch_abort: every waiting and every later dv_batch_arrive returns -1
 };
+// dv_destroy of a member: the batch forgets it (a destroyed ctx must never be reached through B->members); threads waiting in dv_batch_arrive
+// for a round this member will never join are released with an error
+void be_batch_detach(dv_ctx* ctx) {
+    dv_batch* B = ctx->batch;
+    if (!B) return;
+    {
+        std::lock_guard<std::mutex> lk(B->mu);
+        B->members.erase(std::remove(B->members.begin(), B->members.end(), ctx), B->members.end());
+        ctx->batch = nullptr;
+        if (B->arrived > 0) { B->last_rc = -1; B->arrived = 0; ++B->generation; dv_set_error(nullptr, "dv_batch_arrive: a member was destroyed during the round"); }
+    }
+    B->cv.notify_all();
+}
 static int batch_enqueue_impl(dv_batch* B) {
     std::vector<dv_ctx*> M;
     for (dv_ctx* c : B->members) if (c->be.pend->active && c->be.pend->deferred && !c->be.pend->trivial) M.push_back(c);
@@ -605,7 +621,7 @@ dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n) {
 }
 void dv_batch_destroy(dv_batch* B) {
     if (!B) return;
-    for (dv_ctx* c : B->members) if (c->batch == B) c->batch = nullptr;
+    { std::lock_guard<std::mutex> lk(B->mu); for (dv_ctx* c : B->members) if (c->batch == B) c->batch = nullptr; B->members.clear(); }
     if (B->stream) { (void)hipStreamSynchronize(B->stream); (void)hipStreamDestroy(B->stream); }
     if (B->ev_slots) (void)hipEventDestroy(B->ev_slots);
     for (hipEvent_t e : B->ev_up) if (e) (void)hipEventDestroy(e);
@@ -622,8 +638,9 @@ int dv_batch_enqueue(dv_batch* B) {
 int dv_batch_arrive(dv_batch* B) {
     if (!B) return -1;
     std::unique_lock<std::mutex> lk(B->mu);
+    if (B->aborted) { dv_set_error(nullptr, "dv_batch_arrive: the batch was aborted"); return -1; }
     const long long gen = B->generation;
-    if (++B->arrived == (int)B->members.size()) {
+    if (++B->arrived >= (int)B->members.size()) {
         B->last_rc = batch_enqueue_impl(B);
         B->arrived = 0; ++B->generation;
         lk.unlock();
@@ -632,6 +649,25 @@ int dv_batch_arrive(dv_batch* B) {
     }
     B->cv.wait(lk, [&] { return B->generation != gen; });
     return B->last_rc;
+}
+// A member thread that fails before it can arrive calls this (except / finally of the worker): the round is abandoned, every thread waiting in
+// dv_batch_arrive — and every later arrival — returns -1 instead of blocking for ever.
+int dv_batch_abort(dv_batch* B) {
+    if (!B) return -1;
+    {
+        std::lock_guard<std::mutex> lk(B->mu);
+        B->aborted = true; B->last_rc = -1; B->arrived = 0; ++B->generation;
+    }
+    dv_set_error(nullptr, "dv_batch_arrive: the batch was aborted");
+    B->cv.notify_all();
+    return 0;
+}
+int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, double* last4) {
+    if (!ctx) return -1;
+    if (checked) *checked = ctx->be.marg_checked;
+    if (clamped) *clamped = ctx->be.marg_clamped;
+    if (last4) std::memcpy(last4, ctx->be.marg_last, 32);
+    return 0;
 }
 int dv_batch_info(dv_batch* B, long long* batched_rounds, long long* single_rounds) {
     if (!B) return -1;
@@ -736,6 +772,7 @@ int dv_marginalize(dv_ctx* ctx, const dv_ba_problem* P, int mode, dv_ba_prior* o
     DV_CHECK(hipStreamSynchronize(s));
     if (ctx->timing) dv_harvest_timers(ctx, s);
     if (diag4) std::memcpy(diag4, scal, 32);
+    std::memcpy(w.marg_last, scal, 32); w.marg_checked++;
     if (scal[2] != 0.0) w.marg_clamped++;          // pivots <= 1e-8 skipped on the device (pseudo-inverse like the reference's eigen clamp); reported through diag4[2]
     marg_new_prior(pl, P->pose, P->speed_bias, P->ex_pose, P->td, scal[0], out_prior);
     return 0;

@@ -102,6 +102,7 @@ struct BeWork {
     hipEvent_t ev_state = nullptr;    // recorded behind the download of the solved states (the marginalization runs on past it)
     double* prior_c0 = nullptr;       // [2] the prior's constant c0 per buffer, device resident
     int32_t* marg_tab = nullptr; double* marg_scal = nullptr;      // marginalization index tables (inside the upload region) and its 4 result scalars
+    long long marg_checked = 0; double marg_last[4] = { 0, 0, 0, 0 };      // marginalizations whose health scalars came back, and the last set (c0, smallest pivot of A_mm, clamp flag, rank)
     long long marg_clamped = 0;       // marginalizations in which a pivot of A_mm was <= 1e-8 and was skipped (pseudo-inverse)
     bool debug_short_first_pass = false, two_level = false, ldl_generic = false;      // dv_debug_set
     std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
@@ -120,6 +121,7 @@ struct BeFused {
     double raw_pose[77];                      // out: the solver's pose blocks BEFORE the yaw-gauge fix (what body.para_pose holds after ceres::Solve)
 };
 int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);
+void be_batch_detach(dv_ctx* ctx);          // dv_destroy: leave the dv_batch this ctx is a member of
 void* be_staging_factors(dv_ctx* ctx, int* cap);      // where the next solve's upload reads its factor table (pinned); nullptr if the workspace cannot be set up
 int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused);       // upload + enqueue everything, returns immediately
 int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);      // sync + collect

@@ -176,6 +176,7 @@ dv_ctx* dv_create(const dv_config* cfg) {
 void dv_destroy(dv_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
+    be_batch_detach(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& t : ctx->timers) for (auto& p : t.pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,

@@ -662,7 +662,7 @@ struct dv_estimator {
         { HostScope h(ctx, "h_slide"); slide_window(); }
         if (dyn_frame) im.finish_frame(body_view());                                                                                 // estimator.cpp:1663-1676, on the slid window
         erase_if([](const Lm& l) { return l.solve_flag == 2; });      // RemoveFailures
-        if (cfg.use_imu) update_latest_states();
+        update_latest_states();          // unconditional in the reference (estimator.cpp:1688); the IMU replay inside is empty in vision-only mode
         return 0;
     }
     bool in_flight = false, begun = false, line_weight_warned = false;

@@ -94,12 +94,13 @@ def shard_window(ctx, rank=None, world=None, transport="auto"):
     if world is None:
         world = dist.get_world_size() if dist.is_initialized() else 1
     if transport == "auto":
-        transport = "rccl" if (dist.is_initialized() and dist.get_backend() == "nccl") or not dist.is_initialized() else "host"
+        # a lone rank has nothing to exchange: the host transport needs no librccl; rccl only where the process group really is RCCL
+        transport = "rccl" if (dist.is_initialized() and world > 1 and dist.get_backend() == "nccl") else "host"
     lib = ctx.lib
     if transport == "rccl":
         uid = np.zeros(128, np.uint8)
         if rank == 0 and lib.dv_dist_unique_id(uid.ctypes.data) != 0:
-            raise _abi.DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+            raise _abi.DvinsError(ctx.lib.dv_last_error(None).decode())          # be_shard.hip reports this one through the global (ctx-less) error slot
         if dist.is_initialized() and world > 1:
             dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
             t = torch.from_numpy(uid).to(dev)

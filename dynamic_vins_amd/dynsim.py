@@ -47,6 +47,34 @@ class MovingBox:
         return pts
 
 
+class EscortBox(MovingBox):
+    """A box that travels WITH the camera (a vehicle ahead of the ego vehicle — the KITTI / VIODE situation): its centre is a point `ahead` metres in front
+    of the trajectory's heading, `left` metres to the side and `up` metres above, each slowly oscillating, its yaw follows the heading plus a slow swing.  It moves
+    through the world at roughly the camera's speed and stays in view in every frame, which the room-fixed MovingBoxes do not."""
+
+    def __init__(self, inst_id, traj, ahead, left, up, dims=(0.9, 0.8, 1.4), swing=(0.5, 0.35, 0.1), rate=(0.55, 0.4, 0.3), phase=0.0, yaw_off=0.3, yaw_swing=0.4, class_id=2):
+        self.id, self.traj, self.off, self.dims = inst_id, traj, np.array([ahead, left, up], float), np.asarray(dims, float)
+        self.swing, self.rate, self.phase, self.yaw_off, self.yaw_swing, self.class_id = np.asarray(swing, float), np.asarray(rate, float), phase, yaw_off, yaw_swing, class_id
+
+    def _yaw(self, t):
+        return float(self.traj.ypr(t)[0])
+
+    def p(self, t):
+        o = self.off + self.swing * np.sin(self.rate * t + self.phase + np.array([0.0, 1.3, 2.1]))
+        return self.traj.p(t) + sim.rot_zyx(self._yaw(t), 0.0, 0.0) @ o
+
+    def R(self, t):
+        return sim.rot_zyx(self._yaw(t) + self.yaw_off + self.yaw_swing * np.sin(0.45 * t + self.phase), 0.0, 0.0) @ R_WO0
+
+
+def escort_boxes(traj, n=4):
+    """n boxes escorting the camera at 2.6 - 5 m, spread over the field of view so that they do not hide each other for long: the bench's and the
+    reference-parameter tests' dynamic scene (objects in EVERY frame, >= 3 detections per frame for n >= 4)"""
+    spec = [(3.0, 1.3, -0.25, (0.9, 0.8, 1.4), 0.0, 0.35), (3.6, -1.5, -0.1, (1.0, 0.9, 1.6), 1.1, -0.5), (4.6, 0.1, 0.35, (1.2, 0.8, 1.8), 2.3, 0.9),
+            (2.7, -0.4, -0.75, (0.7, 0.6, 1.0), 3.1, 1.4), (5.2, 2.4, 0.0, (1.1, 1.0, 1.7), 4.0, -1.1), (5.0, -2.6, 0.3, (1.0, 0.9, 1.5), 5.2, 0.2)]
+    return [EscortBox(k + 1, traj, a, l, u, dims=d, phase=ph, yaw_off=yo) for k, (a, l, u, d, ph, yo) in enumerate(spec[:n])]
+
+
 def default_boxes():
     """three boxes: two moving at 2-3 m/s peak, one nearly at rest"""
     return [MovingBox(1, (5.0, 1.5, -1.0), (0, 1, 0), 2.5, 6.0, yaw0=0.4, yaw_rate=0.15),

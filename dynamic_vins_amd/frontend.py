@@ -225,6 +225,14 @@ class Context:
         return out
 
     # ---- measurement ----
+    def undistort_lines(self, cam, segs_px):
+        """FrameLines::UndistortedLineEndPoints: [n, 4] pixel end points (x1 y1 x2 y2, float32) -> [n, 4] normalised undistorted, float64"""
+        segs = np.ascontiguousarray(segs_px, np.float32).reshape(-1, 4)
+        out = np.zeros((len(segs), 4), np.float64)
+        if len(segs):
+            self._check(self.lib.dv_undistort_lines(self.h, C.byref(cam), segs.ctypes.data, len(segs), out.ctypes.data))
+        return out
+
     def timing_enable(self, on=1):
         self._check(self.lib.dv_timing_enable(self.h, int(on)))
 

@@ -21,6 +21,7 @@
 #pragma once
 #include <array>
 #include <atomic>
+#include <cctype>
 #include <chrono>
 #include <cmath>
 #include <memory>
@@ -137,6 +138,111 @@ inline dv_cam ReadPinholeCamera(const std::string& path) {
     return c;
 }
 
+// KITTI calibration file (utils/dataset/kitti_utils.cpp:23-100, "P2: 12 numbers" ...): the two colour cameras' projection matrices.  The reference takes the
+// intrinsics from P2 / P3 (utils/camera_model.cpp:41-75) and puts the body frame ON camera 2: R_IC = I, T_IC0 = 0, T_IC1 = (|b3 - b2|, 0, 0) with
+// b = P(0,3) / P(0,0) (utils/camera_model.cpp:219-266).
+struct KittiCalib { dv_cam cam0{}, cam1{}; double baseline = 0; };
+inline KittiCalib ReadKittiCalib(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("dvins: cannot open KITTI calib file " + path);
+    double P2[12] = {0}, P3[12] = {0}; bool h2 = false, h3 = false;
+    std::string line;
+    while (std::getline(f, line)) {
+        std::istringstream is(line); std::string tag; is >> tag;
+        double* dst = tag == "P2:" ? P2 : tag == "P3:" ? P3 : nullptr;
+        if (!dst) continue;
+        for (int i = 0; i < 12; ++i) if (!(is >> dst[i])) throw std::runtime_error("dvins: malformed " + tag + " in " + path);
+        (tag == "P2:" ? h2 : h3) = true;
+    }
+    if (!h2 || !h3) throw std::runtime_error("dvins: P2 / P3 missing in " + path);
+    KittiCalib k;
+    k.cam0 = dv_cam{P2[0], P2[5], P2[2], P2[6], 0, 0, 0, 0}; k.cam1 = dv_cam{P3[0], P3[5], P3[2], P3[6], 0, 0, 0, 0};
+    k.baseline = std::fabs(P3[3] / P3[0] - P2[3] / P2[0]);
+    return k;
+}
+
+// Everything the hot path reads from a reference config file, with the reference's own defaults and failure rules:
+// Config::Config (utils/parameters.cpp:18-150), FrontendParemater::SetParameters (front_end/front_end_parameters.cpp:17-40), VioParameters::SetParameters
+// (estimator/vio_parameters.cpp:17-85), ReadExtrinsicParameters / GetCameraPath (utils/camera_model.cpp:205-340), the topic names of system_call_back.cpp:18-35.
+struct Config {
+    dv_config front{}; dv_est_config est{};
+    std::string slam_type, dataset_type;
+    bool dynamic = false, naive = false, input_seg = false;
+    bool every_frame = false;            // system/main.cpp:300-307: KITTI forwards every frame to the back end, every other dataset every second one
+    int max_dynamic_cnt = 0, min_dynamic_dist = 0, use_det3d = 0, undistort_input = 0, only_frontend = 0;
+    bool static_inst_as_background = false;     // vio_parameters.cpp:69-71 -> estimator.cpp:1583, system/main.cpp:217-245
+    double baseline = 0, max_solver_time = 0;
+    std::map<std::string, std::string> topics;  // image0_topic, image1_topic, image0_segmentation_topic, image1_segmentation_topic, imu_topic
+};
+inline Config ReadConfig(const std::string& config_path, int device = 0, const std::string& seq_name = "", const std::string& kitti_calib_dir = "") {
+    YamlFile y(config_path);
+    Config c;
+    // a non-string slam_type node (the stale "slam_type: 0 / 2" files) reads as "" through cv::FileStorage >> std::string: neither raw nor naive -> dynamic
+    c.slam_type = y.str("slam_type", "");
+    { char* end = nullptr; (void)std::strtod(c.slam_type.c_str(), &end); if (!c.slam_type.empty() && end && *end == 0) c.slam_type.clear(); }
+    c.naive = c.slam_type == "naive"; c.dynamic = c.slam_type != "raw" && !c.naive;
+    c.dataset_type = y.str("dataset_type", "");
+    for (char& ch : c.dataset_type) ch = (char)std::tolower((unsigned char)ch);
+    if (c.dataset_type != "kitti" && c.dataset_type != "euroc" && c.dataset_type != "custom") c.dataset_type = "viode";      // parameters.cpp:44-53: anything else is VIODE
+    c.input_seg = c.dataset_type == "viode" && (c.dynamic || c.naive);
+    c.every_frame = c.dataset_type == "kitti";
+    const int ncam = y.integer("num_of_cam", 0);
+    if (ncam != 1 && ncam != 2) throw std::runtime_error("num_of_cam should be 1 or 2");
+    dv_config& f = c.front;
+    f.width = y.integer("image_width", 0); f.height = y.integer("image_height", 0);
+    f.max_cnt = y.integer("max_cnt", 0); f.min_dist = y.integer("min_dist", 0);
+    f.flow_back = y.integer("flow_back", 0); f.stereo = ncam == 2; f.device = device;
+    f.mask_morphology_size = y.integer("use_mask_morphology", 0) ? y.integer("mask_morphology_size", 0) : 0;      // an absent node reads as 0 / false through FileStorage
+    c.max_dynamic_cnt = y.integer("max_dynamic_cnt", 0); c.min_dynamic_dist = y.integer("min_dynamic_dist", 0);
+    c.undistort_input = y.integer("undistort_input", 0); c.only_frontend = y.integer("dst_mode", 0) ? 1 : y.integer("only_frontend", 0);
+    dv_est_config& e = c.est;
+    std::memset(&e, 0, sizeof(e));
+    e.use_imu = y.integer("imu", 0); e.stereo = f.stereo;
+    e.plane_constraint = y.integer("plane_constraint", 0);
+    e.max_iters = y.integer("max_num_iterations", 0); c.max_solver_time = y.num("max_solver_time", 0.0);
+    e.keyframe_parallax = y.num("keyframe_parallax", 0.0);
+    e.init_depth = y.num("INIT_DEPTH", 5.0);
+    e.g_norm = 9.81007; e.acc_n = 0.1; e.gyr_n = 0.01; e.acc_w = 0.001; e.gyr_w = 1e-4;                           // vio_parameters.h defaults, overwritten only with an IMU
+    if (e.use_imu) { e.acc_n = y.num("acc_n", 0); e.gyr_n = y.num("gyr_n", 0); e.acc_w = y.num("acc_w", 0); e.gyr_w = y.num("gyr_w", 0); e.g_norm = y.num("g_norm", 0); }
+    e.td = y.num("td", 0.0);
+    e.use_line = y.integer("use_line", 0); e.line_min_obs = y.integer("line_min_obs", 5);
+    e.dynamic = c.dynamic ? 1 : 0;
+    e.instance_init_min_num = 4; e.static_inst_threshold = 10.0;
+    if (c.dynamic) {
+        if (!y.has("use_det3d")) throw std::runtime_error("Config::Config(() fs[\"use_det3d\"].isNone()");                                     // parameters.cpp:134-137
+        c.use_det3d = e.use_det3d = y.integer("use_det3d", 0);
+        if (!y.has("instance_init_min_num")) throw std::runtime_error("VioParameters::SetParameters() fs[\"instance_init_min_num\"].isNone()");   // vio_parameters.cpp:54-61
+        e.instance_init_min_num = y.integer("instance_init_min_num", 4);
+    }
+    if (y.has("static_inst_threshold")) e.static_inst_threshold = y.num("static_inst_threshold");
+    c.static_inst_as_background = y.integer("static_inst_as_background", 0) != 0;
+    if (e.use_imu && (y.integer("estimate_extrinsic", 0) != 0 || y.integer("estimate_td", 0) != 0))
+        throw std::runtime_error("dvins: estimate_extrinsic / estimate_td != 0 are not on the accelerated path (every shipped config sets 0)");
+    for (int k = 0; k < 2; ++k) for (int i = 0; i < 9; ++i) e.ric[k][i] = (i % 4 == 0) ? 1.0 : 0.0;
+    const std::string dir = dir_of(config_path);
+    if (c.dataset_type == "kitti" && y.has("kitti_calib_path")) {
+        const std::string base = kitti_calib_dir.empty() ? y.str("kitti_calib_path") : kitti_calib_dir;
+        const KittiCalib k = ReadKittiCalib(base + (seq_name.empty() ? std::string("0000") : seq_name) + ".txt");
+        f.cam0 = k.cam0; f.cam1 = k.cam1; c.baseline = k.baseline; e.tic[1][0] = k.baseline;
+    } else {
+        f.cam0 = ReadPinholeCamera(dir + "/" + y.str("cam0_calib"));
+        f.cam1 = (f.stereo && y.has("cam1_calib")) ? ReadPinholeCamera(dir + "/" + y.str("cam1_calib")) : f.cam0;
+        for (int k = 0; k < (f.stereo ? 2 : 1); ++k) {
+            const std::string key = k == 0 ? "body_T_cam0" : "body_T_cam1";
+            if (!y.has_matrix(key)) throw std::runtime_error("dvins: " + key + " missing");
+            const std::vector<double>& T = y.matrix(key);
+            if (T.size() != 16) throw std::runtime_error("dvins: " + key + " must be 4x4");
+            for (int r = 0; r < 3; ++r) { for (int q = 0; q < 3; ++q) e.ric[k][r * 3 + q] = T[r * 4 + q]; e.tic[k][r] = T[r * 4 + 3]; }
+        }
+        if (f.stereo) {      // cam.baseline = |(body_T_cam0^-1 body_T_cam1)(0,3)| (camera_model.cpp:286-288)
+            double d[3] = { e.tic[1][0] - e.tic[0][0], e.tic[1][1] - e.tic[0][1], e.tic[1][2] - e.tic[0][2] };
+            c.baseline = std::fabs(e.ric[0][0] * d[0] + e.ric[0][3] * d[1] + e.ric[0][6] * d[2]);
+        }
+    }
+    for (const char* k : { "image0_topic", "image1_topic", "image0_segmentation_topic", "image1_segmentation_topic", "imu_topic" }) if (y.has(k)) c.topics[k] = y.str(k);
+    return c;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // data types of the boundary
 struct ImageView {                      // a CV_8UC1 cv::Mat: gray0 / gray1 / inv_merge_mask of SemanticImage
@@ -202,18 +308,7 @@ inline std::vector<dv_feat> to_rows(const FeatureBackground& fb) {
 class FeatureTracker {
 public:
     using Ptr = std::shared_ptr<FeatureTracker>;
-    explicit FeatureTracker(const std::string& config_path, int device = 0) {
-        YamlFile y(config_path);
-        dv_config c{};
-        c.width = y.integer("image_width", 0); c.height = y.integer("image_height", 0);
-        c.max_cnt = y.integer("max_cnt", 150); c.min_dist = y.integer("min_dist", 30);
-        c.flow_back = y.integer("flow_back", 1); c.stereo = y.integer("num_of_cam", 2) == 2; c.device = device;
-        c.mask_morphology_size = y.integer("use_mask_morphology", 0) ? y.integer("mask_morphology_size", 0) : 0;
-        const std::string dir = dir_of(config_path);
-        c.cam0 = ReadPinholeCamera(dir + "/" + y.str("cam0_calib"));
-        c.cam1 = c.stereo ? ReadPinholeCamera(dir + "/" + y.str("cam1_calib")) : c.cam0;
-        init(c);
-    }
+    explicit FeatureTracker(const std::string& config_path, int device = 0, const std::string& seq_name = "") { init(ReadConfig(config_path, device, seq_name).front); }
     explicit FeatureTracker(const dv_config& c) { init(c); }
     ~FeatureTracker() { if (ctx_) dv_destroy(ctx_); }
     FeatureTracker(const FeatureTracker&) = delete;
@@ -353,8 +448,8 @@ public:
     using Ptr = std::shared_ptr<InstsFeatManager>;
     // max_dynamic_cnt / min_dynamic_dist / use_det3d of the config file (front_end_parameters.cpp:30-36, utils/parameters.cpp)
     InstsFeatManager(FeatureTracker& tracker, const std::string& config_path) : ctx_(tracker.ctx()) {
-        YamlFile y(config_path);
-        detail::check(ctx_, dv_inst_config(ctx_, y.integer("max_dynamic_cnt", 50), y.integer("min_dynamic_dist", 5), y.integer("use_det3d", 0)), "InstsFeatManager");
+        const Config c = ReadConfig(config_path);
+        detail::check(ctx_, dv_inst_config(ctx_, c.max_dynamic_cnt, c.min_dynamic_dist, c.use_det3d), "InstsFeatManager");
         alloc();
     }
     InstsFeatManager(FeatureTracker& tracker, int max_dynamic_cnt, int min_dynamic_dist, int use_det3d) : ctx_(tracker.ctx()) {
@@ -396,29 +491,8 @@ class Estimator {
 public:
     using Ptr = std::shared_ptr<Estimator>;
     enum SolverFlag { kInitial = 0, kNonLinear = 1 };
-    explicit Estimator(const std::string& config_path, int device = 0) {
-        YamlFile y(config_path);
-        std::memset(&cfg_, 0, sizeof(cfg_));
-        cfg_.use_imu = y.integer("imu", 0); cfg_.stereo = y.integer("num_of_cam", 2) == 2;
-        cfg_.plane_constraint = y.integer("plane_constraint", 0);
-        cfg_.max_iters = y.integer("max_num_iterations", 8);
-        cfg_.keyframe_parallax = y.num("keyframe_parallax", 10.0);
-        cfg_.init_depth = y.num("INIT_DEPTH", 5.0);
-        cfg_.g_norm = y.num("g_norm", 9.81007); cfg_.td = y.num("td", 0.0);
-        cfg_.acc_n = y.num("acc_n", 0.1); cfg_.gyr_n = y.num("gyr_n", 0.01); cfg_.acc_w = y.num("acc_w", 0.001); cfg_.gyr_w = y.num("gyr_w", 1e-4);
-        // dynamic mode: `slam: dynamic` selects the object branch (utils/parameters.cpp), with use_det3d / instance_init_min_num / static_inst_threshold
-        cfg_.dynamic = y.str("slam_type", "raw") == "dynamic" ? 1 : 0; cfg_.use_det3d = y.integer("use_det3d", 0);
-        cfg_.instance_init_min_num = y.integer("instance_init_min_num", 4); cfg_.static_inst_threshold = y.num("static_inst_threshold", 10.0);
-        cfg_.use_line = y.integer("use_line", 0); cfg_.line_min_obs = y.integer("line_min_obs", 5);      // parameters.cpp: cfg::use_line; vio_parameters.cpp: para::kLineMinObs
-        if (y.integer("estimate_extrinsic", 0) != 0 || y.integer("estimate_td", 0) != 0)
-            throw std::runtime_error("dvins: estimate_extrinsic / estimate_td != 0 are not on the accelerated path (every shipped config sets 0)");
-        for (int c = 0; c < 2; ++c) {
-            const std::string key = c == 0 ? "body_T_cam0" : "body_T_cam1";
-            if (!y.has_matrix(key)) { if (c == 1 && !cfg_.stereo) continue; throw std::runtime_error("dvins: " + key + " missing"); }
-            const std::vector<double>& T = y.matrix(key);
-            if (T.size() != 16) throw std::runtime_error("dvins: " + key + " must be 4x4");
-            for (int r = 0; r < 3; ++r) { for (int k = 0; k < 3; ++k) cfg_.ric[c][r * 3 + k] = T[r * 4 + k]; cfg_.tic[c][r] = T[r * 4 + 3]; }
-        }
+    explicit Estimator(const std::string& config_path, int device = 0, const std::string& seq_name = "") {
+        cfg_ = ReadConfig(config_path, device, seq_name).est;
         dv_config fc{};
         fc.width = 64; fc.height = 48; fc.max_cnt = 8; fc.min_dist = 8; fc.flow_back = 1; fc.stereo = 1; fc.device = device;
         fc.cam0 = dv_cam{1, 1, 0, 0, 0, 0, 0, 0}; fc.cam1 = fc.cam0;

@@ -11,14 +11,16 @@ from .frontend import Context, DV_MEM_DEVICE, DV_MEM_HOST, DV_MODE_RAW, make_cam
 class SyntheticSequence:
     """rendered stereo frames resident in HBM + IMU stream for one trajectory (SURVEY 8(d) primary input)"""
 
-    def __init__(self, w, h, cam, n_frames, rate=20.0, t0=1.0, phase=0.0, noise=None, device=None, seed=sim.TEX_SEED):
+    def __init__(self, w, h, cam, n_frames, rate=20.0, t0=1.0, phase=0.0, noise=None, device=None, seed=sim.TEX_SEED, baseline=0.12, body_is_camera=False, cam1=None, traj=None):
         import torch
         from .render import RoomRenderer
         self.w, self.h, self.cam, self.dt, self.t0 = w, h, cam, 1.0 / rate, t0 + phase
+        self.cam1 = cam1 if cam1 is not None else cam
         self.noise = noise or dict(acc_n=0.02, gyr_n=0.002, acc_w=2e-4, gyr_w=2e-5)
-        self.traj = sim.Trajectory()
-        rr = RoomRenderer(cam, w, h, device=device, seed=seed)
-        self.frames = [rr.stereo(self.traj, self.t0 + k * self.dt) for k in range(n_frames)]
+        self.rig = sim.rig(baseline, body_is_camera)
+        self.traj = traj if traj is not None else sim.Trajectory()
+        rr = RoomRenderer(cam, w, h, device=device, seed=seed, cam1=cam1)
+        self.frames = [rr.stereo(self.traj, self.t0 + k * self.dt, self.rig["t_ic1"]) for k in range(n_frames)]
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         self.times = [self.t0 + k * self.dt for k in range(n_frames)]
@@ -29,12 +31,14 @@ class SyntheticSequence:
 
 
 class Pipeline:
-    def __init__(self, seq: SyntheticSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, host_frames=False, ba_stride=1):
+    def __init__(self, seq: SyntheticSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, host_frames=False, ba_stride=1, est_kw=None):
         self.seq = seq
         self.host = [seq.host_frame(k) for k in range(len(seq.frames))] if host_frames else None
         c = make_cam(*sim.cam_tuple(seq.cam))
-        self.ctx = Context(width=seq.w, height=seq.h, max_cnt=max_cnt, min_dist=min_dist, cam0=c, cam1=c, device=device)
-        self.est = Estimator(self.ctx, use_imu=use_imu, stereo=1, max_iters=max_iters, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], **seq.noise)
+        self.ctx = Context(width=seq.w, height=seq.h, max_cnt=max_cnt, min_dist=min_dist, cam0=c, cam1=make_cam(*sim.cam_tuple(seq.cam1)), device=device)
+        self.est_kw = dict(use_imu=use_imu, stereo=1, max_iters=max_iters, ric=seq.rig["est_ric"], tic=seq.rig["est_tic"], **seq.noise)
+        self.est_kw.update(est_kw or {})          # keyframe_parallax, g_norm, ... of a shipped YAML (ref_configs.py)
+        self.est = Estimator(self.ctx, **self.est_kw)
         self.k_imu = 0
         self.next = 0
         self.enqueued = False
@@ -130,20 +134,24 @@ class DynamicSequence(SyntheticSequence):
     front end of the reference delivers: the inverse merged instance mask, one detection per visible object (track id, rectangle, ROI mask, 3-D box,
     extra 3-D points sampled from the depth map like InstFeat::DetectExtraPoints, front_end/instance_feature.cpp:413-461) (SURVEY 8(d), dynamic variant)."""
 
-    def __init__(self, w, h, cam, n_frames, rate=20.0, t0=1.0, noise=None, device=None, boxes=None, min_pixels=400, seed=sim.TEX_SEED):
+    def __init__(self, w, h, cam, n_frames, rate=20.0, t0=1.0, noise=None, device=None, boxes=None, min_pixels=400, seed=sim.TEX_SEED, baseline=0.12, body_is_camera=False, cam1=None, traj=None):
         import torch
         from . import dynsim
         from .render import DynRoomRenderer
         self.w, self.h, self.cam, self.dt, self.t0 = w, h, cam, 1.0 / rate, t0
+        self.cam1 = cam1 if cam1 is not None else cam
         self.noise = noise or dict(acc_n=0.02, gyr_n=0.002, acc_w=2e-4, gyr_w=2e-5)
-        self.traj = sim.Trajectory()
+        self.rig = sim.rig(baseline, body_is_camera)
+        self.traj = traj if traj is not None else sim.Trajectory()
+        if boxes == "escort" or (isinstance(boxes, tuple) and boxes[0] == "escort"):      # boxes travelling with the camera: objects in every frame
+            boxes = dynsim.escort_boxes(self.traj, boxes[1] if isinstance(boxes, tuple) else 4)
         self.boxes = boxes if boxes is not None else dynsim.default_boxes()
-        rr = DynRoomRenderer(cam, w, h, device=device, seed=seed)
+        rr = DynRoomRenderer(cam, w, h, device=device, seed=seed, cam1=cam1)
         self.times = [self.t0 + k * self.dt for k in range(n_frames)]
         self.frames, self.inv_mask, self.inv_mask_dev, self.dets, self.boxes3d = [], [], [], [], []
         rays = rr.rays.cpu().numpy().reshape(h, w, 3)
         for t in self.times:
-            left, right, ident, depth = rr.stereo_dynamic(self.traj, t, self.boxes)
+            left, right, ident, depth = rr.stereo_dynamic(self.traj, t, self.boxes, self.rig["t_ic1"])
             self.frames.append((left, right))
             idm, dep = ident.cpu().numpy(), depth.cpu().numpy()
             self.inv_mask.append(np.ascontiguousarray(np.where(idm == 0, 255, 0).astype(np.uint8)))
@@ -181,23 +189,30 @@ class DynamicSequence(SyntheticSequence):
 
 class DynamicPipeline(Pipeline):
     """Pipeline in dynamic mode (cfg::slam == kDynamic): TrackSemanticImage for the background + InstsFeatManager::InstsTrack for the objects on the tracking
-    stream, Estimator::ProcessImage with the object branch (window solve on the BA stream, object solve on a third one)."""
+    stream, Estimator::ProcessImage with the object branch (window solve on the BA stream, object solve on a third one).  `segments` (a sim.SegmentSim):
+    use_line — the detector's matched segments of every frame go through FrameLines::UndistortedLineEndPoints (dv_undistort_lines) into frame.features.lines,
+    as TrackSemanticImage's line thread delivers them (background_tracker.cpp:774-780, 809-817)."""
 
     def __init__(self, seq: DynamicSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, max_dynamic_cnt=50, min_dynamic_dist=5, use_det3d=1,
-                 static_inst_threshold=1.0, mask_morphology_size=0):
+                 static_inst_threshold=1.0, mask_morphology_size=0, segments=None, est_kw=None):
         from .frontend import DV_MODE_SEMANTIC
         self.seq, self.host = seq, None
         c = make_cam(*sim.cam_tuple(seq.cam))
-        self.ctx = Context(width=seq.w, height=seq.h, max_cnt=max_cnt, min_dist=min_dist, cam0=c, cam1=c, device=device, mask_morphology_size=mask_morphology_size)
+        self.cam_c, self.cam1_c = c, make_cam(*sim.cam_tuple(seq.cam1))
+        self.ctx = Context(width=seq.w, height=seq.h, max_cnt=max_cnt, min_dist=min_dist, cam0=c, cam1=self.cam1_c, device=device, mask_morphology_size=mask_morphology_size)
         self.ctx.inst_config(max_dynamic_cnt, min_dynamic_dist, use_det3d)
-        self.est = Estimator(self.ctx, use_imu=use_imu, stereo=1, max_iters=max_iters, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], dynamic=1, use_det3d=use_det3d,
-                             static_inst_threshold=static_inst_threshold, **seq.noise)
-        self.mode, self.use_det3d = DV_MODE_SEMANTIC, use_det3d
+        self.est_kw = dict(use_imu=use_imu, stereo=1, max_iters=max_iters, ric=seq.rig["est_ric"], tic=seq.rig["est_tic"], dynamic=1, use_det3d=use_det3d,
+                           static_inst_threshold=static_inst_threshold, use_line=int(segments is not None), **seq.noise)
+        self.est_kw.update(est_kw or {})
+        self.est = Estimator(self.ctx, **self.est_kw)
+        self.mode, self.use_det3d, self.segments = DV_MODE_SEMANTIC, use_det3d, segments
         self.k_imu = self.next = 0
         self.enqueued = False
         self._prefetched = None
+        self.ba_stride = 1
+        self.last_state = None
         self.poses, self.pose_times = [], []
-        self.stat = dict(frames=0, frames_with_objects=0, object_detections=0, object_features=0)      # what the object branch was fed over the run
+        self.stat = dict(frames=0, frames_with_objects=0, object_detections=0, object_features=0, min_detections=10 ** 9)      # what the object branch was fed over the run
 
     def _enqueue(self, k):
         l, r = self.seq.frames[k]
@@ -205,27 +220,40 @@ class DynamicPipeline(Pipeline):
         self.ctx.inst_track_enqueue(self.seq.times[k], self.seq.dets[k], self.seq.boxes3d[k] if self.use_det3d else None)
         self.enqueued = True
 
-    def step(self):
+    def _collect(self):
+        return (self.ctx.track_stereo_collect(),) + tuple(self.ctx.inst_track_collect())
+
+    def line_rows(self, t):
+        """frame.features.lines of the frame at time t: the detector's pixel segments through UndistortedLineEndPoints (cam0 / cam1)"""
+        il, sl, ir, sr = self.segments.frame(t)
+        self.seg_px = (il, sl, ir, sr)
+        return sim.line_rows(il, self.ctx.undistort_lines(self.cam_c, sl), ir, self.ctx.undistort_lines(self.cam1_c, sr))
+
+    def step(self, defer_end=False):
         k, s = self.next, self.seq
         pre, self._prefetched = self._prefetched, None
         if pre is None:
             if not self.enqueued:
                 self._enqueue(k)
-            pre = (self.ctx.track_stereo_collect(),) + tuple(self.ctx.inst_track_collect())
+            pre = self._collect()
         rows, insts, ifeats, pts = pre
         self.enqueued = False
         t = s.times[k]
         self._feed_imu(t)
+        if self.segments is not None:
+            self.lrows = self.line_rows(t)
+            self.est.SetLines(self.lrows)
         if self.est.ProcessMeasurementsDynamicBegin(rows, t, insts, ifeats, pts) != 0:
             raise RuntimeError("IMU stream does not cover the frame")
         if k + 1 < len(s.frames):
             self._enqueue(k + 1)
             self._feed_imu(s.times[k + 1])
-            self._prefetched = (self.ctx.track_stereo_collect(),) + tuple(self.ctx.inst_track_collect())      # while the BA of frame k runs (see Pipeline.step)
-        st = self.est.ProcessMeasurementsEnd()
-        if st.nonlinear:
-            self.poses.append(self.est.window()[10, :7]); self.pose_times.append(t)
-        self.next += 1
+            if not defer_end:
+                self._prefetched = self._collect()      # while the BA of frame k runs (see Pipeline.step)
         self.rows, self.insts, self.ifeats, self.ipts = rows, insts, ifeats, pts
         self.stat["frames"] += 1; self.stat["frames_with_objects"] += int(len(insts) > 0); self.stat["object_detections"] += len(insts); self.stat["object_features"] += len(ifeats)
-        return st
+        self.stat["min_detections"] = min(self.stat["min_detections"], len(insts))
+        if defer_end:
+            self._pending_t = t
+            return None
+        return self._finish(t)

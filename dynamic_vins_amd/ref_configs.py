@@ -1,0 +1,55 @@
+"""The reference's shipped parameter sets (config/**.yaml under /root/reference/dynamic_vins), as the values the hot path reads — so that tests and
+bench.py run the front end and the back end at the numbers a user of the reference actually runs, not at round numbers of our own.
+
+Every entry cites the YAML it restates; tests/test_reference_configs.py::test_tables_match_the_shipped_yamls re-reads the files (when /root/reference is
+present) and fails if a value here drifts from them.  What is NOT taken from the YAMLs, and why:
+  * body_T_cam rotations: a calibration of the dataset's IMU frame.  The synthetic rig keeps its own body frame (x forward); what is kept is which kind of
+    rig it is (IMU body vs. body = camera 0, `body_is_camera`) and the stereo baseline.
+  * KITTI's 0.54 m baseline is shortened to 0.2 m: the synthetic room is 18 m across, not a street; at 0.54 m the near-field disparities (> 130 px) exceed
+    what the reference's own stereo LK (21x21 window, 4 levels, no initial flow) can follow.
+  * max_solver_time: the wall-clock cap is off on both sides.
+"""
+import numpy as np
+
+VIODE_CAM = dict(fx=376.0, fy=376.0, cx=376.0, cy=240.0, k1=0.0, k2=0.0, p1=0.0, p2=0.0)                    # config/viode/cam0_pinhole.yaml
+ZED_UN_CAM0 = dict(fx=5.7817315673828125e+02, fy=6.6596881103515625e+02, cx=6.7666424560546875e+02, cy=3.6173339843750000e+02, k1=0.0, k2=0.0, p1=0.0, p2=0.0)
+ZED_UN_CAM1 = dict(fx=5.7601123046875000e+02, fy=6.6383435058593750e+02, cx=6.9023547363281250e+02, cy=3.7148672485351562e+02, k1=0.0, k2=0.0, p1=0.0, p2=0.0)
+KITTI_CAM = dict(fx=721.5377, fy=721.5377, cx=609.5593, cy=172.854, k1=0.0, k2=0.0, p1=0.0, p2=0.0)       # P2 of data_tracking_calib (kitti_calib_path)
+
+CONFIGS = {
+    # config/viode/viode.yaml with slam_type "dynamic" (BASELINE.json config 3 "VIODE city_day/3_high dynamic mode"; the file ships "naive")
+    "viode": dict(yaml="viode/viode.yaml", w=752, h=480, cam0=VIODE_CAM, cam1=VIODE_CAM, baseline=0.05, body_is_camera=False,
+                  use_imu=1, max_cnt=160, min_dist=20, mask_morphology_size=5, max_iters=8, keyframe_parallax=10.0, g_norm=9.81007,
+                  noise=dict(acc_n=0.2, gyr_n=0.05, acc_w=0.02, gyr_w=4.0e-5), min_dynamic_dist=5, max_dynamic_cnt=50, use_det3d=0,
+                  instance_init_min_num=4, static_inst_threshold=10.0, use_line=1, plane_constraint=0, every_second_frame=True),
+    # config/custom/zed_1280x720_vision_only/dynamic.yaml (BASELINE.json config 5's sensor; vision only, undistorted input images)
+    "zed_dynamic": dict(yaml="custom/zed_1280x720_vision_only/dynamic.yaml", w=1280, h=720, cam0=ZED_UN_CAM0, cam1=ZED_UN_CAM1, baseline=0.12, body_is_camera=True,
+                        use_imu=0, max_cnt=400, min_dist=25, mask_morphology_size=20, max_iters=10, keyframe_parallax=15.0, g_norm=9.81007,
+                        noise=dict(acc_n=1.3816015296770526e-02, gyr_n=1.7437150007509720e-03, acc_w=5.1404537157728519e-04, gyr_w=3.5656511595590793e-05),
+                        min_dynamic_dist=4, max_dynamic_cnt=50, use_det3d=1, instance_init_min_num=4, static_inst_threshold=8.0, use_line=0, plane_constraint=0,
+                        every_second_frame=True),
+    # config/kitti/kitti_tracking/kitti_tracking_online.yaml: dynamic + use_line 1 + plane_constraint 1 (the shipped "LinePoint + dynamic" parameter set)
+    "kitti_tracking_online": dict(yaml="kitti/kitti_tracking/kitti_tracking_online.yaml", w=1242, h=375, cam0=KITTI_CAM, cam1=KITTI_CAM, baseline=0.2, body_is_camera=True,
+                                  use_imu=0, max_cnt=250, min_dist=25, mask_morphology_size=20, max_iters=10, keyframe_parallax=15.0, g_norm=9.81007,
+                                  noise=dict(acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1.0e-4), min_dynamic_dist=4, max_dynamic_cnt=50, use_det3d=1,
+                                  instance_init_min_num=4, static_inst_threshold=10.0, use_line=1, plane_constraint=1, every_second_frame=False),
+}
+
+
+def est_kw(c):
+    """the Estimator keyword arguments a config adds to the pipeline's defaults"""
+    return dict(keyframe_parallax=c["keyframe_parallax"], g_norm=c["g_norm"], plane_constraint=c["plane_constraint"], instance_init_min_num=c["instance_init_min_num"])
+
+
+def yaml_scalars(path):
+    """flat `key: value` scalars of an OpenCV-FileStorage YAML (no nesting needed for the keys the path reads)"""
+    out = {}
+    for ln in open(path, encoding="utf-8", errors="replace"):
+        ln = ln.split("#", 1)[0].rstrip()
+        if not ln or ln[0] in " \t%-" or ":" not in ln:
+            continue
+        k, v = ln.split(":", 1)
+        v = v.strip().strip('"')
+        if v and not v.startswith("!!"):
+            out[k.strip()] = v
+    return out

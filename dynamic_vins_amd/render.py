@@ -27,10 +27,14 @@ def _texture(size=2048, seed=sim.TEX_SEED):
 
 
 class RoomRenderer:
-    def __init__(self, cam, w, h, half=(9.0, 7.0, 3.0), texel=0.012, device=None, seed=sim.TEX_SEED):
+    def __init__(self, cam, w, h, half=(9.0, 7.0, 3.0), texel=0.012, device=None, seed=sim.TEX_SEED, cam1=None):
         self.dev = torch.device(device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu"))
         self.w, self.h, self.half, self.texel = w, h, half, texel
         self.tex = _texture(2048, seed).to(self.dev)[None, None]
+        self.rays = self._rays(cam, w, h)
+        self.rays1 = self._rays(cam1, w, h) if (cam1 is not None and cam1 != cam) else self.rays      # the right camera's own intrinsics (un_cam1_pinhole.yaml differs from cam0)
+
+    def _rays(self, cam, w, h):
         # per-pixel undistorted ray (liftProjective: 8 fixed-point iterations, PinholeCamera.cc:450-508)
         u, v = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
         mx_d, my_d = (u - cam["cx"]) / cam["fx"], (v - cam["cy"]) / cam["fy"]
@@ -43,13 +47,13 @@ class RoomRenderer:
             dy = my * rad + 2 * p2 * mx * my + p1 * (r2 + 2 * my * my)
             mx, my = mx_d - dx, my_d - dy
         rays = np.stack([mx, my, np.ones_like(mx)], -1).reshape(-1, 3)
-        self.rays = torch.from_numpy(rays).to(self.dev, torch.float64)
+        return torch.from_numpy(rays).to(self.dev, torch.float64)
 
-    def _render(self, R_wc, p_wc):
+    def _render(self, R_wc, p_wc, rays=None):
         """R_wc, p_wc: camera-to-world rotation / camera centre (numpy)"""
         R = torch.from_numpy(np.ascontiguousarray(R_wc)).to(self.dev, torch.float64)
         o = torch.from_numpy(np.ascontiguousarray(p_wc)).to(self.dev, torch.float64)
-        d = self.rays @ R.T                                  # world ray directions
+        d = (self.rays if rays is None else rays) @ R.T                                  # world ray directions
         hx, hy, hz = self.half
         best_t = torch.full((d.shape[0],), float("inf"), dtype=torch.float64, device=self.dev)
         uu = torch.zeros_like(best_t); vv = torch.zeros_like(best_t)
@@ -76,11 +80,11 @@ class RoomRenderer:
         img = torch.nn.functional.grid_sample(self.tex, grid, mode="bilinear", padding_mode="reflection", align_corners=False)
         return (img[0, 0] * 255.0 + 0.5).clamp(0, 255).to(torch.uint8).contiguous()
 
-    def stereo(self, traj, t):
+    def stereo(self, traj, t, t_ic1=sim.T_IC1):
         R, p = traj.R(t), traj.p(t)
         out = []
-        for tic in (sim.T_IC0, sim.T_IC1):
-            out.append(self._render(R @ sim.R_IC, p + R @ tic))
+        for tic, rays in ((sim.T_IC0, self.rays), (t_ic1, self.rays1)):
+            out.append(self._render(R @ sim.R_IC, p + R @ tic, rays))
         return out
 
 
@@ -90,10 +94,11 @@ class DynRoomRenderer(RoomRenderer):
     object id (0 = background, MovingBox.id otherwise; the instance masks of SOLOv2 / the VIODE label image) and the depth map
     (the stereo network's disparity: the source of InstFeat::DetectExtraPoints)."""
 
-    def _render_dyn(self, R_wc, p_wc, boxes, t, want_aux):
+    def _render_dyn(self, R_wc, p_wc, boxes, t, want_aux, rays=None):
+        rays = self.rays if rays is None else rays
         R = torch.from_numpy(np.ascontiguousarray(R_wc)).to(self.dev, torch.float64)
         o = torch.from_numpy(np.ascontiguousarray(p_wc)).to(self.dev, torch.float64)
-        d = self.rays @ R.T
+        d = rays @ R.T
         best_t = torch.full((d.shape[0],), float("inf"), dtype=torch.float64, device=self.dev)
         uu = torch.zeros_like(best_t); vv = torch.zeros_like(best_t)
         ident = torch.zeros(d.shape[0], dtype=torch.int32, device=self.dev)
@@ -138,12 +143,12 @@ class DynRoomRenderer(RoomRenderer):
         img = (img[0, 0] * 255.0 + 0.5).clamp(0, 255).to(torch.uint8).contiguous()
         if not want_aux:
             return img, None, None
-        depth = (best_t * self.rays[:, 2]).view(self.h, self.w)          # z in the camera frame: the ray (x, y, 1) scaled by t
+        depth = (best_t * rays[:, 2]).view(self.h, self.w)          # z in the camera frame: the ray (x, y, 1) scaled by t
         return img, ident.view(self.h, self.w).to(torch.uint8).contiguous(), depth
 
-    def stereo_dynamic(self, traj, t, boxes):
+    def stereo_dynamic(self, traj, t, boxes, t_ic1=sim.T_IC1):
         """-> (left u8, right u8, id map of the left image u8, depth map of the left image f64), all H x W"""
         R, p = traj.R(t), traj.p(t)
         left, ident, depth = self._render_dyn(R @ sim.R_IC, p + R @ sim.T_IC0, boxes, t, True)
-        right, _, _ = self._render_dyn(R @ sim.R_IC, p + R @ sim.T_IC1, boxes, t, False)
+        right, _, _ = self._render_dyn(R @ sim.R_IC, p + R @ t_ic1, boxes, t, False, self.rays1)
         return left, right, ident, depth

@@ -23,7 +23,19 @@ T_IC1 = np.array([0.0, -0.12, 0.0])                                          # 0
 
 ZED = dict(fx=701.406049185687, fy=700.7199834541797, cx=663.9703743586792, cy=362.02045484177154,
            k1=-0.17198906485492285, k2=0.024624053031210322, p1=0.0003391614313509814, p2=-0.00045583634752113735)
+VIODE = dict(fx=376.0, fy=376.0, cx=376.0, cy=240.0, k1=0.0, k2=0.0, p1=0.0, p2=0.0)          # config/viode/cam0_pinhole.yaml (752x480, no distortion)
 EUROC = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375, k1=-0.28340811, k2=0.07395907, p1=0.00019359, p2=1.76187114e-05)
+
+
+def rig(baseline=0.12, body_is_camera=False):
+    """Stereo rig of a synthetic sequence.  Rendering always places camera 0 at the trajectory's body origin looking along body x (R_IC) and camera 1
+    `baseline` metres to its right.  What the ESTIMATOR is told (body_T_cam0 / body_T_cam1 of the YAML) is either that same rig (VIO configs: the body is
+    the IMU) or — the vision-only ZED configs, config/custom/zed_1280x720_vision_only/dynamic.yaml:38-53 — identity extrinsics with camera 1 at
+    (+baseline, 0, 0): the body IS camera 0 and the trajectory comes out in the first camera's frame (ATE aligns it)."""
+    t1 = np.array([0.0, -baseline, 0.0])
+    if body_is_camera:
+        return dict(t_ic1=t1, est_ric=[np.eye(3), np.eye(3)], est_tic=[np.zeros(3), np.array([baseline, 0.0, 0.0])])
+    return dict(t_ic1=t1, est_ric=[R_IC, R_IC], est_tic=[T_IC0, t1])
 
 
 def scaled_cam(cam, w, h, w0, h0):
@@ -227,6 +239,58 @@ class LineSim:
                 r["right"] = np.array([xar[k], yar[k], xbr[k], ybr[k]]) + noise[k, 4:]
             rows.append(r)
         return np.array(rows, LINEROW_DTYPE) if rows else np.zeros(0, LINEROW_DTYPE)
+
+
+class SegmentSim:
+    """Pixel-level stand-in for the LSD + LBD line detector / matcher upstream of TrackImageLine (line_detector/line_detector.cpp — OpenCV line_descriptor, CPU,
+    out of scope): 3-D segments on the room's walls projected through the DISTORTED pinhole cameras of the rig; per frame the matched segments of the left
+    image (id, x1 y1 x2 y2 in pixels, float32 like cv::line_descriptor::KeyLine) and of the right image.  The end points slide along the segment from frame to
+    frame like a detector's do.  What follows it on the path — FrameLines::UndistortedLineEndPoints, the `lines` map of SetOutputFeats — is the product's."""
+
+    def __init__(self, traj, cam, w, h, n=80, half=(9.0, 7.0, 3.0), pix_sigma=0.3, slide=0.05, seed=11, t_ic1=T_IC1):
+        rng = np.random.default_rng(seed)
+        a = room_points(n, half, seed=seed + 1)
+        d = rng.normal(0, 1, (n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        self.a, self.b = a, a + d * rng.uniform(0.8, 2.5, (n, 1))
+        self.traj, self.cam, self.w, self.h, self.sig, self.slide, self.t_ic1, self.rng = traj, cam, w, h, pix_sigma, slide, np.asarray(t_ic1, float), rng
+
+    def _pix(self, t, P, t_ic):
+        R, p = self.traj.R(t), self.traj.p(t)
+        Pc = (R_IC.T @ (R.T @ (P - p).T - t_ic[:, None])).T
+        ok = Pc[:, 2] > 0.5
+        z = np.where(ok, Pc[:, 2], 1.0)
+        x, y = Pc[:, 0] / z, Pc[:, 1] / z
+        u, v = distort(self.cam, x, y)
+        return u, v, ok & (np.abs(x) < 1.1) & (np.abs(y) < 0.7) & (u > 2) & (u < self.w - 3) & (v > 2) & (v < self.h - 3)
+
+    def frame(self, t):
+        """-> (ids_left u32 [m], segs_left f32 [m, 4], ids_right u32 [k], segs_right f32 [k, 4]); every right id also appears on the left"""
+        n = len(self.a)
+        s = self.rng.uniform(0, self.slide, (n, 2))
+        A = self.a + (self.b - self.a) * s[:, :1]
+        B = self.b - (self.b - self.a) * s[:, 1:]
+        ua, va, oka = self._pix(t, A, T_IC0); ub, vb, okb = self._pix(t, B, T_IC0)
+        uar, var, okar = self._pix(t, A, self.t_ic1); ubr, vbr, okbr = self._pix(t, B, self.t_ic1)
+        noise = self.rng.normal(0, self.sig, (n, 8))
+        left = oka & okb
+        right = left & okar & okbr
+        L = (np.stack([ua, va, ub, vb], 1) + noise[:, :4]).astype(np.float32)
+        Rr = (np.stack([uar, var, ubr, vbr], 1) + noise[:, 4:]).astype(np.float32)
+        ids = np.arange(1, n + 1, dtype=np.uint32)
+        return ids[left], np.ascontiguousarray(L[left]), ids[right], np.ascontiguousarray(Rr[right])
+
+
+def line_rows(ids_l, un_l, ids_r, un_r):
+    """FeatureBackground::lines as dv_line_row records (SetOutputFeats, background_tracker.cpp:373-392): left entries in detector order, the right
+    observation attached to the same id"""
+    from .backend import LINEROW_DTYPE
+    rows = np.zeros(len(ids_l), LINEROW_DTYPE)
+    rows["id"], rows["left"] = ids_l, un_l
+    pos = {int(i): k for k, i in enumerate(ids_l)}
+    for i, u in zip(ids_r, un_r):
+        k = pos[int(i)]
+        rows["has_right"][k] = 1; rows["right"][k] = u
+    return rows
 
 
 def align_ate(est, gt):

@@ -228,9 +228,10 @@ int dv_allreduce_reduced_system(dv_ctx* ctx, double* S_g, int n);
  * as usual.  A member collected without dv_batch_enqueue is solved on its own stream.  Results are bit-identical to the unbatched path. */
 typedef struct dv_batch dv_batch;
 dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n);      /* idle contexts of one device; NULL + dv_last_error(NULL) on failure */
-void dv_batch_destroy(dv_batch* batch);                      /* the members stay valid */
+void dv_batch_destroy(dv_batch* batch);                      /* the members stay valid; dv_destroy of a member before the batch detaches it from the batch */
 int dv_batch_enqueue(dv_batch* batch);
 int dv_batch_arrive(dv_batch* batch);                        /* one host thread per member: blocks until every member's thread has arrived; the last one enqueues */
+int dv_batch_abort(dv_batch* batch);                         /* a member thread failed before arriving: every waiting and later dv_batch_arrive returns -1 */
 int dv_batch_info(dv_batch* batch, long long* batched_rounds, long long* single_rounds);
 
 /* Replaces MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks} as driven by
@@ -395,6 +396,13 @@ int dv_est_change_sensor_type(dv_ctx* ctx, int use_imu, int use_stereo);
 /* latest_time / latest_P / latest_Q (qx qy qz qw) / latest_V: the newest frame's state propagated by every IMU sample fed since — FastPredictIMU inside
  * InputIMU and UpdateLatestStates (estimator.cpp:729-742,1376-1418): what PubLatestOdometry publishes on `imu_propagate`.  Returns 1 while not initialised. */
 int dv_est_get_latest(dv_ctx* ctx, double* t, double* P3, double* Q4, double* V3);
+/* Health of the marginalization (MarginalizationInfo::marginalize, factor/marginalization_factor.cpp:284-304).  The reference zeroes the eigenvalues
+ * <= 1e-8 of A_mm silently; the device skips the LDL^T pivots <= 1e-8 (also negative ones) — the same pseudo-inverse whenever the deficient directions
+ * are single columns (a landmark without information), order dependent otherwise.  So the event is counted and readable:
+ *   checked   marginalizations whose scalars have come back (the estimator reads them one frame late: they run behind the state download)
+ *   clamped   of those, how many skipped at least one pivot
+ *   last4     c0, smallest pivot of A_mm, clamp flag (!= 0: skipped), rank of A_mm — of the last one that came back */
+int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, double* last4);
 /* FeatureManager::point_landmarks for the point-cloud publishers (utils/io/visualization.cpp:214-249): world point = CamToWorld(point * depth, start_frame);
  * in_point_cloud / in_margin_cloud apply PubPointCloud's two selection rules.  key_poses = window[i][0..2] of dv_est_state. */
 typedef struct dv_landmark { int32_t id, start_frame, n_obs, solve_flag; double depth, p_w[3]; int32_t in_point_cloud, in_margin_cloud; } dv_landmark;

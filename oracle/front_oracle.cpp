@@ -544,14 +544,18 @@ void dvo_circle_mask(uint8_t* mask, int w, int h, const float* pts, int n, int r
     for (int i = 0; i < n; ++i) circle_zero(mask, w, h, cv_round(pts[2 * i]), cv_round(pts[2 * i + 1]), radius);
 }
 void dvo_erode(const uint8_t* src, int w, int h, int k, uint8_t* dst) {
-    const int a = k / 2;                                            // anchor (-1,-1) -> centre = k/2
+    // min over the k x k rectangle, anchor (-1,-1) -> centre = k/2, border = +inf for erode.  The minimum over a rectangle is the minimum over its rows of the
+    // row minima: two 1-D passes give exactly the 2-D result (k = 20 on 1280x720 would be 3.7e8 comparisons per frame in the direct form).
+    const int a = k / 2;
+    std::vector<uint8_t> tmp((size_t)w * h);
     for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
         int m = 255;
-        for (int dy = -a; dy < k - a; ++dy) for (int dx = -a; dx < k - a; ++dx) {
-            int yy = y + dy, xx = x + dx;
-            if (yy < 0 || yy >= h || xx < 0 || xx >= w) continue;  // border = +inf for erode
-            m = std::min(m, (int)src[(size_t)yy * w + xx]);
-        }
+        for (int dx = -a; dx < k - a; ++dx) { const int xx = x + dx; if (xx >= 0 && xx < w) m = std::min(m, (int)src[(size_t)y * w + xx]); }
+        tmp[(size_t)y * w + x] = (uint8_t)m;
+    }
+    for (int y = 0; y < h; ++y) for (int x = 0; x < w; ++x) {
+        int m = 255;
+        for (int dy = -a; dy < k - a; ++dy) { const int yy = y + dy; if (yy >= 0 && yy < h) m = std::min(m, (int)tmp[(size_t)yy * w + x]); }
         dst[(size_t)y * w + x] = (uint8_t)m;
     }
 }

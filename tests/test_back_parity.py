@@ -168,6 +168,36 @@ def test_marginalization_matches_oracle(ctx, oracle, kw, mode):
     assert diag[1] > 1e-8            # A_mm well conditioned: pseudo-inverse == inverse
 
 
+def test_marginalization_with_a_rank_deficient_A_mm(ctx, oracle):
+    """a landmark WITHOUT information (inverse depth 1e5: a point 10 um from the camera, d r / d lambda ~ 1 / lambda^2 -> information ~ 1e-15,
+    below the 1e-8 floor) makes A_mm rank deficient.  The reference zeroes the eigenvalue (marginalization_factor.cpp:286-289); the device skips the LDL^T pivot.
+    For a deficient direction that is a single column the two pseudo-inverses coincide: the priors must still agree — to 1e-7 of the matrix scale, since the
+    eigen route mixes the tiny coupling terms (~1e-8 x pose Jacobian) into the other eigenvectors — and the event must be VISIBLE through the ABI
+    (diag4[2] of dv_marginalize here; dv_est_get_marg_health on the estimator path) instead of silently clamped."""
+    from dynamic_vins_amd.backend import marginalize
+    full = ba_gen.make_window(oracle, seed=27, with_prior=True, nlm=80)
+    ba_gen.oracle_solve(oracle, full)
+    sub = ba_gen.marg_subproblem(full, 0)
+    assert len(sub.inv_depth) >= 4
+    sub.inv_depth[1] = 1.0e5                       # the dead landmark (both sides read the same sub-problem)
+    sub._bind()
+    po, Ao, bo = ba_gen.oracle_marginalize(oracle, sub, 0)
+    pd, Ad, bd, diag = marginalize(ctx, sub, 0)
+    assert pd.valid == po.valid == 1 and pd.n == po.n
+    assert diag[2] != 0.0 and diag[1] <= 1e-8, diag            # reported: clamp flag set, smallest pivot under the floor
+    bo_blocks, bd_blocks = ba_gen.prior_to_dict(po, Ao, bo), ba_gen.prior_to_dict(pd, Ad, bd)
+    Ao_p, bo_p = ba_gen.permute_prior(bo_blocks, Ao, bo, bd_blocks)
+    scale = np.abs(Ao_p).max()
+    assert np.isfinite(Ad).all() and np.isfinite(bd).all()
+    assert np.allclose(Ad, Ao_p, rtol=0, atol=1e-7 * scale), np.abs(Ad - Ao_p).max() / scale
+    assert np.allclose(bd, bo_p, rtol=0, atol=1e-7 * np.abs(bo_p).max() + 1e-6)
+    # health counters of the ctx (the estimator path reads the same scalars one frame late)
+    import ctypes as C
+    chk, clp, last = C.c_longlong(0), C.c_longlong(0), np.zeros(4)
+    assert ctx.lib.dv_est_get_marg_health(ctx.h, C.byref(chk), C.byref(clp), last.ctypes.data) == 0
+    assert chk.value >= 1 and clp.value >= 1 and last[2] != 0.0
+
+
 def test_prior_round_trip_through_solver(ctx, oracle):
     """solve -> marginalize -> shift states -> solve again with the new prior: HIP and oracle stay together"""
     from dynamic_vins_amd.backend import WindowProblem, ba_solve, marginalize

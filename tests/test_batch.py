@@ -53,3 +53,43 @@ def test_batched_estimators_equal_single_estimators(gpu_ctx_factory, use_imu):
     info = batch.info()
     assert info["batched_rounds"] >= frames - 14, info        # every steady-state round went through the shared launches
     batch.close()
+
+
+def test_member_destroyed_before_its_batch_and_abort(gpu_ctx_factory):
+    """ADVICE round 2: dv_destroy of a member must detach it from its dv_batch (the batch kept a raw pointer and wrote into freed memory on dv_batch_destroy);
+    dv_batch_abort releases threads waiting in dv_batch_arrive instead of letting them block for ever."""
+    import threading
+    from dynamic_vins_amd.backend import Batch, Estimator
+    from dynamic_vins_amd.frontend import Context
+    kw = dict(use_imu=0, stereo=1, max_iters=4, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], **NOISE)
+    ctxs = [Context(width=64, height=64, max_cnt=10, min_dist=5) for _ in range(3)]
+    ests = [Estimator(c, **kw) for c in ctxs]
+    batch = Batch(ctxs)
+    ctxs[1].close()                                   # a member goes first
+    batch.enqueue()                                   # nothing pending: must not touch the destroyed member
+    # the remaining two members still work through the batch
+    traj = sim.Trajectory()
+    fs = sim.FeatureSim(traj, sim.EUROC, 752, 480, sim.room_points(2000), max_cnt=100, pix_sigma=0.3, seed=3)
+    for f in range(14):
+        rows, t = fs.frame(1.0 + 0.1 * f), 1.0 + 0.1 * f
+        for e in (ests[0], ests[2]):
+            assert e.ProcessMeasurementsBegin(rows, t) == 0
+        batch.enqueue()
+        a, b = ests[0].ProcessMeasurementsEnd(), ests[2].ProcessMeasurementsEnd()
+        assert (a.frame, a.iterations, a.final_cost) == (b.frame, b.iterations, b.final_cost)
+    # abort: one thread waits in arrive(), the "failed" one aborts instead of arriving
+    res = {}
+
+    def waiter():
+        try:
+            batch.arrive(); res["w"] = "returned"
+        except Exception as ex:      # DvinsError
+            res["w"] = "raised"
+    th = threading.Thread(target=waiter); th.start()
+    import time
+    time.sleep(0.2)
+    batch.abort()
+    th.join(timeout=10)
+    assert not th.is_alive() and res.get("w") == "raised", res
+    batch.close()                                     # after a member is gone and after an abort: no crash
+    ctxs[0].close(); ctxs[2].close()

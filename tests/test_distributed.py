@@ -50,3 +50,23 @@ def test_single_process_helpers_are_identity():
     assert d.shard_landmarks(7, 0, 1) == list(range(7))
     assert d.shard_landmarks(7, 0, 2) == [0, 1, 2, 3] and d.shard_landmarks(7, 1, 2) == [4, 5, 6] and d.shard_landmarks(2, 3, 4) == []
     assert d.whole_job_rate(50, 1, 0.5) == 100.0
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` WITHOUT a launcher must not run as one rank labelled n_gpus 1: it starts its two ranks itself as fresh child processes
+    (torch.distributed.run, rendezvous on 127.0.0.1) before anything touches the GPU.  Rehearsed here on CPU (gloo, BENCH_SELFTEST: rendezvous, all-gather
+    of the rank ids, the barrier + MAX-over-ranks of the timed region; no compute)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(BENCH_SELFTEST="1", BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout                       # ONE line, from rank 0
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["requested_gpus"] == 2 and out["ranks"] == [0, 1] and out["local_ranks"] == [0, 1]
+    assert out["distinct_processes"] == 2 and out["launcher"] is True and out["max_over_ranks"] == 2.0
+    # under a launcher (the driver's form) the same command does not launch again
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=600, env=env2, cwd=str(tmp_path))
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["launcher"] is False

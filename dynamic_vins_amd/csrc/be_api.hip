@@ -417,6 +417,12 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;
     sa.xnorm2_extra = P->x_norm2_extra; sa.sh = sh;
     sa.ldl_wcol = (!w.ldl_generic && d.nstate <= 168 && be_ldl_pack(d.nstate, sa.ldl_col0)) ? 1 : 0;
+    // the 16-wide MFMA factorisation (be_solve.hip MF16) where the system fits its tile budget and the dense order is used; "ldl_wavecol" / "ldl_generic" select the older forms
+    // (not for members of a dv_batch: the batched entry form exists for the wave-column kernel; not with the two-level order, whose dense part is wave-column)
+    if (!w.ldl_generic && !w.ldl_wavecol_only && !sa.dims.pad && !ctx->batch) {
+        uint8_t plan[64];
+        if (be_mf16_plan(d.nstate, plan)) { std::memcpy(sa.ldl_col0, plan, sizeof(plan)); sa.ldl_wcol = 2; }
+    }
     // two-level elimination (speed-bias chain first) needs the wave-column factorisation for its dense pose block
     if (sa.dims.pad && !(sa.ldl_wcol && be_ldl_pack(6 * P->nframes, sa.ldl_col0p))) { sa.dims.pad = 0; ea.dims.pad = 0; }
     // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
@@ -548,7 +554,7 @@ static int batch_enqueue_impl(dv_batch* B) {
     bool uniform = true; int slots = M[0]->be.pend->first_slots, max_grid = 0, max_n = 0;
     for (dv_ctx* c : M) {
         const BePending& pd = *c->be.pend;
-        if (!pd.sa.ldl_wcol || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing)) uniform = false;
+        if (pd.sa.ldl_wcol != 1 || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing)) uniform = false;
         max_grid = std::max(max_grid, pd.ea.dims.nlm + pd.ea.dims.nimu + 1); max_n = std::max(max_n, pd.sa.dims.nstate);
     }
     if (!uniform || M.size() == 1) {      // mixed kernel variants (or nothing to share): every member on its own stream, as without a batch
@@ -682,6 +688,7 @@ int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return -1;
     if (std::strcmp(key, "short_first_pass") == 0) { ctx->be.debug_short_first_pass = value != 0; return 0; }
     if (std::strcmp(key, "two_level") == 0) { ctx->be.two_level = value != 0; return 0; }
+    if (std::strcmp(key, "ldl_wavecol") == 0) { ctx->be.ldl_wavecol_only = value != 0; return 0; }      // the round-2 wave-column LDL^T instead of the 16-wide MFMA form
     if (std::strcmp(key, "ldl_generic") == 0) { ctx->be.ldl_generic = value != 0; return 0; }      // the block-column-major LDL^T mapping instead of the wave-column one
     DV_FAIL(std::string("dv_debug_set: unknown key ") + key);
 }

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         for (int l = tid; l < a.nlm; l += 64) hmin = fmin(hmin, a.lm_h[l]);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) hmin = fmin(hmin, __shfl_xor(hmin, o));
-        if (tid == 0) { misc[0] = hmin; misc[1] = 0.0; }
+        if (tid == 0) { misc[0] = hmin; misc[1] = !(hmin > 1e-8) ? 1.0 : 0.0; }      // be_marg_lm dropped a landmark pivot <= 1e-8 (hinv := 0): reported like the dense pivots below
     }
     __syncthreads();
     MTS(9);

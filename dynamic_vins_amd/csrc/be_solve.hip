@@ -19,6 +19,8 @@
 // stage; the kernels are latency-bound by design and are measured as such.
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include <algorithm>
+#include <cstring>
 #include "be_kernels.h"
 #include "dev_once.h"
 #include "wave_dpp.h"
@@ -820,6 +822,221 @@ __device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw&
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// MF16 — the same LDL^T re-blocked 16 wide on the f64 matrix cores (v_mfma_f64_16x16x4_f64).
+// Every experiment of rounds 1-2 ended at the same per-step cost (~1.2 us per barrier-separated 4-pivot step, 42 steps): so the steps become 11 sixteen-pivot
+// steps.  The (n+1) x (n+1) system — row n carries the right-hand side, so the forward substitution is part of the factorisation and row n of L is
+// y = D^-1 L^-1 rhs — is cut into 16 x 16 tiles; tile (I, J), I >= J, lives TRANSPOSED in the registers of one wave in the MFMA result layout
+// (lane l, register r: U[(l >> 4) + 4 r][l & 15] = A[16 I + (l & 15)][16 J + (l >> 4) + 4 r]).  In that layout a tile is, without any data movement,
+//   * the B operand for a product that sums over its row index, and
+//   * the A operand of its transpose,
+// which is exactly what the two tile operations need:
+//   panel    V_I = X_I^T = D^-1 W_k U_Ik                 A = W_k = L_kk^-1 (fragment read transposed from LDS), B = the tile's registers
+//   update   U_IJ -= X_J D X_I^T = V_J^T (D V_I)          A = the stored fragment of V_J, B = the stored fragment of V_I scaled by d  (4 MFMAs per tile)
+// The fragments V_I stay in LDS as the factor (L_Ik^T); the diagonal slots hold W_k.  Diagonal tile (one wave, ~1 us): four 4-pivot sub-steps; the four pivot
+// rows are gathered through LDS, the 4x4 pivot block reaches every lane by row_newbcast, every lane runs the pivot chain and, by symmetry, the forward
+// substitution of ITS column (lane c holds A[p..p+3][c] = A[c][p..p+3]); ONE MFMA applies the rank-4 update to the tile and a second one the same elementary
+// block transformation to W (Gauss-Jordan: W <- L_q^-1 W), so that W_k = L_kk^-1 comes out of the factorisation.  Tile ownership (be_mf16_plan): wave j owns
+// diagonal tile j and only off-diagonal tiles of columns < j, so the wave that factors diagonal k+1 has no other tile to update in step k.
+// Two workgroup barriers per 16 pivots.  Same solution as ldlt_wavecol to rounding (different summation order): parity by tolerance (iteration sequences, 1e-6).
+#define MF_SLOTS 5
+#define MF_MAXNB 11
+#define MF_RHO 1e300
+typedef double mf_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mf_d4 mf_mfma(double a, double b, mf_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ int mf_tix(int I, int J, int NB) { return J * NB - (J * (J - 1)) / 2 + (I - J); }
+template <int LANE> __device__ __forceinline__ double mf_rowbc(double v) { return dpp_f64<0x150 + LANE, 0xf>(v); }      // row_newbcast:LANE (gfx90a+): lane LANE of every 16-lane row to the whole row
+__device__ __forceinline__ double mf_pick(int rho, double v0, double v1, double v2, double v3) { return rho == 0 ? v0 : (rho == 1 ? v1 : (rho == 2 ? v2 : v3)); }
+struct MfLds { double* Tl; double* gat; double* dv; double* iv; double* yv; };      // tiles | per-wave gather buffers (64 each) | D | 1 / D | y (then the running right-hand side of the back substitution)
+
+// one 4-pivot sub-step of the diagonal tile.  nv: rows of this tile that belong to the n x n system (pivots p < nv are checked); c0: local index of the
+// right-hand-side row (or -1); yk: this block's 16 entries of y
+template <int Q>
+__device__ __forceinline__ void mf_diag_substep(mf_d4& T, mf_d4& Wt, double* gat, double* dv16, double* iv16, int nv, int c0, double* yk, int* s_fail) {
+    constexpr int P = 4 * Q;
+    const int lane = threadIdx.x & 63, c = lane & 15, rho = lane >> 4;
+    gat[lane] = T[Q];                                   // rows P .. P+3 sit in register Q of the four 16-lane rows
+    wave_lds_sync();
+    const double g0 = gat[c], g1 = gat[16 + c], g2 = gat[32 + c], g3 = gat[48 + c];      // g_m = A[P + m][c] (= A[c][P + m])
+    wave_lds_sync();
+    const double d0 = mf_rowbc<P>(g0), a10 = mf_rowbc<P>(g1), a20 = mf_rowbc<P>(g2), a30 = mf_rowbc<P>(g3);
+    const double a11 = mf_rowbc<P + 1>(g1), a21 = mf_rowbc<P + 1>(g2), a31 = mf_rowbc<P + 1>(g3);
+    const double a22 = mf_rowbc<P + 2>(g2), a32 = mf_rowbc<P + 2>(g3), a33 = mf_rowbc<P + 3>(g3);
+    const double i0 = fast_rcp(d0);
+    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
+    const double d1 = __builtin_fma(-l10, a10, a11), i1 = fast_rcp(d1);
+    const double t21 = __builtin_fma(-l20, a10, a21), t31 = __builtin_fma(-l30, a10, a31);
+    const double l21 = t21 * i1, l31 = t31 * i1;
+    const double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, a20, a22)), i2 = fast_rcp(d2);
+    const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, a20, a32));
+    const double l32 = t32 * i2;
+    const double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, a30, a33))), i3 = fast_rcp(d3);
+    // this lane's column, read as row c of the panel: p = (L D)[c][P..P+3], x = L[c][P..P+3]; only the strictly lower part counts
+    const double p0 = g0, p1 = __builtin_fma(-p0, l10, g1);
+    const double p2 = __builtin_fma(-p1, l21, __builtin_fma(-p0, l20, g2));
+    const double p3 = __builtin_fma(-p2, l32, __builtin_fma(-p1, l31, __builtin_fma(-p0, l30, g3)));
+    const double lh0 = c > P ? p0 * i0 : 0.0, lh1 = c > P + 1 ? p1 * i1 : 0.0, lh2 = c > P + 2 ? p2 * i2 : 0.0, lh3 = c > P + 3 ? p3 * i3 : 0.0;
+    const double ph0 = c > P ? p0 : 0.0, ph1 = c > P + 1 ? p1 : 0.0, ph2 = c > P + 2 ? p2 : 0.0, ph3 = c > P + 3 ? p3 : 0.0;
+    T = mf_mfma(-mf_pick(rho, lh0, lh1, lh2, lh3), mf_pick(rho, ph0, ph1, ph2, ph3), T);      // T -= Lhat (D Lhat)^T: rank 4, the whole tile in one instruction
+    // W <- L_q^-1 W with L_q^-1 = I - Lhat W_qq embedded in columns P .. P+3 (W_qq = inverse of the unit lower 4x4 pivot block)
+    const double w10 = -l10, w21 = -l21, w32 = -l32;
+    const double w20 = __builtin_fma(l21, l10, -l20), w31 = __builtin_fma(l32, l21, -l31);
+    const double w30 = __builtin_fma(-l32, w20, __builtin_fma(l31, l10, -l30));      // -l30 + l31 l10 + l32 l20 - l32 l21 l10
+    const double z0 = -__builtin_fma(lh3, w30, __builtin_fma(lh2, w20, __builtin_fma(lh1, w10, lh0)));
+    const double z1 = -__builtin_fma(lh3, w31, __builtin_fma(lh2, w21, lh1));
+    const double z2 = -__builtin_fma(lh3, w32, lh2);
+    const double z3 = -lh3;
+    const double wq = Wt[Q];
+    Wt = mf_mfma(mf_pick(rho, z0, z1, z2, z3), wq, Wt);
+    if (lane == 0) {
+        dv16[P] = d0; dv16[P + 1] = d1; dv16[P + 2] = d2; dv16[P + 3] = d3;
+        iv16[P] = i0; iv16[P + 1] = i1; iv16[P + 2] = i2; iv16[P + 3] = i3;
+        bool bad = false;
+        if (P < nv) bad = bad || !(d0 > 0.0) || !isfinite(d0);
+        if (P + 1 < nv) bad = bad || !(d1 > 0.0) || !isfinite(d1);
+        if (P + 2 < nv) bad = bad || !(d2 > 0.0) || !isfinite(d2);
+        if (P + 3 < nv) bad = bad || !(d3 > 0.0) || !isfinite(d3);
+        if (bad) *s_fail = 1;
+    }
+    if (lane == c0) {          // row c0 of L_kk = this block's share of y (lane c0 of the first 16-lane row; c0 >= 0 only in the last block)
+        if (P < c0) yk[P] = lh0;
+        if (P + 1 < c0) yk[P + 1] = lh1;
+        if (P + 2 < c0) yk[P + 2] = lh2;
+        if (P + 3 < c0) yk[P + 3] = lh3;
+    }
+}
+__device__ __forceinline__ void mf_diag_factor(mf_d4& T, const MfLds& m, int k, int NB, int n, int* s_fail) {
+    const int lane = threadIdx.x & 63, c = lane & 15, rho = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    mf_d4 Wt;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Wt[r] = (rho + 4 * r == c) ? 1.0 : 0.0;
+    double* gat = m.gat + wave * 64;
+    const int nv = n - 16 * k, c0 = (nv >= 0 && nv < 16) ? nv : -1;
+    mf_diag_substep<0>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, nv, c0, m.yv + 16 * k, s_fail);
+    mf_diag_substep<1>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, nv, c0, m.yv + 16 * k, s_fail);
+    mf_diag_substep<2>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, nv, c0, m.yv + 16 * k, s_fail);
+    mf_diag_substep<3>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, nv, c0, m.yv + 16 * k, s_fail);
+    *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(k, k, NB) * 256 + lane * 4) = Wt;      // W_k = L_kk^-1, result layout
+}
+// entry (i, j) of the scaled, damped (n+1)-system with the right-hand side as row / column n and identity padding behind it
+__device__ __forceinline__ double mf_entry(const double* __restrict__ Sc, const double* v_s, const double* v_d, const double* rhs, int n, double mu, int i, int j) {
+    if (i < j) { const int t = i; i = j; j = t; }
+    if (i > n) return i == j ? 1.0 : 0.0;
+    if (i == n) return j == n ? MF_RHO : v_s[j] * rhs[j];
+    const int NBR = (n + 3) >> 2, bi = i >> 2, bj = j >> 2;
+    const double v = v_s[i] * v_s[j] * Sc[(size_t)(bj * NBR - bj * (bj - 1) / 2 + bi - bj) * 16 + (i & 3) * 4 + (j & 3)];
+    return i == j ? v + mu * v_d[i] * v_d[i] : v;
+}
+// plan: bytes [16][4] of (I << 4 | J) for the off-diagonal slots 1..4 of every wave (0xFF = empty); slot 0 of wave w < NB is the diagonal tile (w, w)
+__device__ __forceinline__ bool ldlt_mf16(const double* __restrict__ Sc, const uint8_t* plan, int n, double mu, const double* v_s, const double* v_d, const double* rhs, const MfLds& m, int* s_fail) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, rho = lane >> 4;      // wave in an SGPR: the slot tests below are scalar branches
+    const int NB = (n + 16) >> 4, IB = n >> 4, c0 = n & 15;
+    int sI[MF_SLOTS], sJ[MF_SLOTS];
+    sI[0] = sJ[0] = wave < NB ? wave : -1;
+#pragma unroll
+    for (int s = 1; s < MF_SLOTS; ++s) { const int b = plan[wave * 4 + s - 1]; sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
+    mf_d4 U[MF_SLOTS];
+#pragma unroll
+    for (int s = 0; s < MF_SLOTS; ++s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? mf_entry(Sc, v_s, v_d, rhs, n, mu, 16 * sI[s] + c, 16 * sJ[s] + rho + 4 * r) : 0.0;
+    }
+    for (int i = tid; i < 16 * NB; i += SOL_THREADS) m.yv[i] = 0.0;
+    if (tid == 0) *s_fail = 0;
+    lds_barrier();
+    TS(4);
+    if (wave == 0) mf_diag_factor(U[0], m, 0, NB, n, s_fail);
+    lds_barrier();
+    for (int k = 0; k < NB; ++k) {
+        // ---- panel of block column k ----
+        bool any = false;
+#pragma unroll
+        for (int s = 1; s < MF_SLOTS; ++s) any = any || sJ[s] == k;
+        if (any) {
+            const double* Wk = m.Tl + (size_t)mf_tix(k, k, NB) * 256;
+            double wf[4], ivr[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { wf[q] = Wk[((((c & 3) << 4) + rho + 4 * q) << 2) + (c >> 2)]; ivr[q] = m.iv[16 * k + rho + 4 * q]; }      // W[c][rho + 4q] from the result-layout image
+#pragma unroll
+            for (int s = 1; s < MF_SLOTS; ++s) if (sJ[s] == k) {
+                mf_d4 Y = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Y = mf_mfma(wf[q], U[s][q], Y);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Y[r] *= ivr[r];
+                U[s] = Y;
+                *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(sI[s], k, NB) * 256 + lane * 4) = Y;
+                if (sI[s] == IB && c == c0) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m.yv[16 * k + rho + 4 * r] = Y[r];      // row n of L: y
+                }
+            }
+        }
+        lds_barrier();
+        if (k == NB - 1) break;
+        // ---- trailing update with panel k; the owner of diagonal tile k+1 factors it right behind its update ----
+        double dk[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dk[q] = -m.dv[16 * k + rho + 4 * q];
+#pragma unroll
+        for (int s = 0; s < MF_SLOTS; ++s) if (sJ[s] > k) {
+            const mf_d4 a = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(sJ[s], k, NB) * 256 + lane * 4);
+            const mf_d4 b = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(sI[s], k, NB) * 256 + lane * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) U[s] = mf_mfma(a[q], dk[q] * b[q], U[s]);
+        }
+        if (wave == k + 1) mf_diag_factor(U[0], m, k + 1, NB, n, s_fail);
+        lds_barrier();
+    }
+    TS(5);
+    return *s_fail == 0;
+}
+// block back substitution L^T x = y on the tiles: per block row i (last to first) x_i = W_i^T y_i (every wave that needs it forms it itself: 4 FMAs per lane and
+// one exchange through its gather buffer), then every tile (i, k) of that block row takes its share out of y_k.  One barrier per 16 unknowns.
+__device__ __forceinline__ void bs_mf16(const uint8_t* plan, int n, const MfLds& m, double* v_x) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, rho = lane >> 4;
+    const int NB = (n + 16) >> 4, IB = n >> 4, c0 = n & 15;
+    int sI[MF_SLOTS], sJ[MF_SLOTS];
+    sI[0] = sJ[0] = -1;
+#pragma unroll
+    for (int s = 1; s < MF_SLOTS; ++s) { const int b = plan[wave * 4 + s - 1]; sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
+    double* gat = m.gat + wave * 64;
+    for (int i = NB - 1; i >= 0; --i) {
+        bool need = wave == 0;
+#pragma unroll
+        for (int s = 1; s < MF_SLOTS; ++s) need = need || sI[s] == i;
+        if (need) {
+            const mf_d4 Wi = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(i, i, NB) * 256 + lane * 4);
+            double part = 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part = __builtin_fma(Wi[r], m.yv[16 * i + rho + 4 * r], part);
+            gat[lane] = part;
+            wave_lds_sync();
+            double xi = (gat[c] + gat[16 + c]) + (gat[32 + c] + gat[48 + c]);      // (W_i^T y_i)[c], in every 16-lane row
+            wave_lds_sync();
+            if (i == IB && c >= c0) xi = 0.0;                                     // the right-hand-side row and the padding are not unknowns
+            if (wave == 0 && rho == 0 && 16 * i + c < n) v_x[16 * i + c] = xi;
+#pragma unroll
+            for (int s = 1; s < MF_SLOTS; ++s) if (sI[s] == i) {
+                // y_k -= L_ik^T x_i = V x_i with V = the stored fragment (V[R][C], R = k-local row): lane (R = c, rho) sums its columns C = rho + 4 q
+                const double* V = m.Tl + (size_t)mf_tix(i, sJ[s], NB) * 256;
+                gat[lane] = xi;                                                   // x_i[c] -> readable by index
+                wave_lds_sync();
+                double acc = 0.0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { const int C = rho + 4 * q; acc = __builtin_fma(V[((((c & 3) << 4) + C) << 2) + (c >> 2)], gat[C], acc); }
+                wave_lds_sync();
+                gat[lane] = acc;
+                wave_lds_sync();
+                const double t = (gat[c] + gat[16 + c]) + (gat[32 + c] + gat[48 + c]);
+                wave_lds_sync();
+                if (rho == 0) m.yv[16 * sJ[s] + c] -= t;
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Two-level elimination of the reduced camera system (VIO windows whose speed-bias blocks couple only along the IMU chain: BeDims::pad, checked on the host).
 // Order: speed-bias block of frame 0, 1, ..., F-1, then the dense 6F x 6F pose block.  Eliminating sb_f touches only its chain neighbour sb_f+1 and the
 // poses, so the 9F speed-bias pivots — 99 of the 165 sequential pivots of the monolithic factorisation — become F block steps:
@@ -1085,11 +1302,11 @@ __device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, doub
 
 // The body lives in be_solve_body.inc and is included textually: called through a function taking `const BeSolveArgs&` the single-window kernel lost 4 %
 // (99.2 vs 95.2 us; the by-value kernel arguments stopped being treated as invariant scalar loads).
-template <int NSLOT, bool WCOL>
+template <int NSLOT, bool WCOL, bool MF16 = false>
 __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) {
 #include "be_solve_body.inc"
 }
-template <int NSLOT, bool WCOL>
+template <int NSLOT, bool WCOL, bool MF16 = false>
 __global__ __launch_bounds__(SOL_THREADS) void be_solve_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) {      // one workgroup per window
     const BeSolveArgs& a = tab[blockIdx.x];
 #include "be_solve_body.inc"
@@ -1098,6 +1315,31 @@ __global__ __launch_bounds__(SOL_THREADS) void be_solve_batch_kernel(const BeSol
 static size_t solve_smem(int n, bool two_level, bool wcol) {
     const size_t tri = (size_t)n * (n + 1) / 2;
     return ((two_level && tri < FS_WORK ? (size_t)FS_WORK : tri) + 9 * (size_t)n + 72 + 80 + 8 + (wcol ? 3072 : 1536)) * sizeof(double);
+}
+// MF16: the tiles (which double as the later phases' scratch: >= 3072 doubles) | vectors | per-wave gather buffers | D, 1 / D, y
+static size_t solve_smem_mf16(int n) {
+    const size_t NB = ((size_t)n + 16) >> 4, nt = NB * (NB + 1) / 2;
+    return (std::max<size_t>(nt * 256, 3072) + 9 * (size_t)n + 72 + 80 + 8 + 1024 + 3 * 16 * NB) * sizeof(double);
+}
+// MF16 tile plan (ldlt_mf16): wave j < NB owns diagonal tile j (slot 0).  Off-diagonal tile (I, J) may go to a wave >= NB or to a wave w with J < w: then the
+// wave that factors diagonal tile k+1 behind the update of step k has no other active tile (its off-diagonal tiles lie in columns <= k).  Late columns first
+// (fewest eligible waves), least-loaded eligible wave.  Returns false when the system does not fit (NB > 11: LDS) or a wave would need more than 4 slots.
+bool be_mf16_plan(int n, uint8_t* plan /* [16][4] */) {
+    const int NB = (n + 16) >> 4, W = SOL_THREADS / 64;
+    if (NB > MF_MAXNB || solve_smem_mf16(n) > 160 * 1024) return false;
+    int load[SOL_THREADS / 64] = { 0 };
+    std::memset(plan, 0xFF, (size_t)W * 4);
+    for (int J = NB - 2; J >= 0; --J)
+        for (int I = J + 1; I < NB; ++I) {
+            int best = -1;
+            for (int w = W - 1; w >= 0; --w) {
+                const bool eligible = w >= NB || J < w;
+                if (eligible && load[w] < 4 && (best < 0 || load[w] < load[best])) best = w;
+            }
+            if (best < 0) return false;
+            plan[best * 4 + load[best]++] = (uint8_t)((I << 4) | J);
+        }
+    return true;
 }
 
 // wave-column mapping of the factorisation (ldlt_wavecol): block column c (NBR - c blocks) goes to consecutive lanes of ONE wave; first-fit decreasing
@@ -1125,6 +1367,12 @@ int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(168, false, true)) != hipSuccess) return 1;
             return 0; })) return -1;
     const int nbr = (a.dims.nstate + 3) / 4;
+    if (a.ldl_wcol == 2) {
+        static DevOnce once_mf;
+        if (once_mf.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ? 1 : 0; })) return -1;
+        hipLaunchKernelGGL((be_solve_kernel<1, false, true>), dim3(1), dim3(SOL_THREADS), solve_smem_mf16(a.dims.nstate), s, a, spec);
+        return 0;
+    }
     if (a.ldl_wcol) hipLaunchKernelGGL((be_solve_kernel<1, true>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, a.dims.pad != 0, true), s, a, spec);      // (pad is only set together with ldl_wcol)
     else if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL((be_solve_kernel<1, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, false), s, a, spec);
     else hipLaunchKernelGGL((be_solve_kernel<2, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, false), s, a, spec);

@@ -603,15 +603,16 @@ struct dv_estimator {
     int dynamic_branch(dv_ctx* ctx, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {
         HostScope h(ctx, "h_dynamic");
         const dvi::BodyView B = body_view();
-        im.push_back(frame, B, insts, n_insts, inst_feats, points);
-        im.propagate_pose(B);
-        im.triangulate(B);
-        im.initial_instance(B);
-        im.initial_velocity(B);
-        im.set_dynamic_or_static(B);
+        { HostScope h1(ctx, "h_dyn_push"); im.push_back(frame, B, insts, n_insts, inst_feats, points); }
+        { HostScope h1(ctx, "h_dyn_propagate"); im.propagate_pose(B); }
+        { HostScope h1(ctx, "h_dyn_triangulate"); im.triangulate(B); }
+        { HostScope h1(ctx, "h_dyn_initial"); im.initial_instance(B); im.initial_velocity(B); im.set_dynamic_or_static(B); }
         obj_solved = false;
         obj_last = dv_ba_summary{};
-        if (im.build_problem(OP, &para_pose_ref[0][0], ric[0]) && (OP.n_boxes > 0 || OP.n_points > 0)) {
+        bool have;
+        { HostScope h1(ctx, "h_dyn_build"); have = im.build_problem(OP, &para_pose_ref[0][0], ric[0]) && (OP.n_boxes > 0 || OP.n_points > 0); }
+        if (have) {
+            HostScope h1(ctx, "h_dyn_solve_begin");
             if (be_obj_solve_begin(ctx, &OP, ctx->obj_stream, ctx->obj_buf, ctx->obj_pend)) return -1;      // enqueued; collected in dynamic_branch_finish
             obj_solved = true;
         }
@@ -622,9 +623,9 @@ struct dv_estimator {
     dv_obj_problem OP{}; bool obj_solved = false;
     int dynamic_branch_finish(dv_ctx* ctx) {
         HostScope h(ctx, "h_dynamic_finish");
-        if (obj_solved && be_obj_solve_end(ctx, &OP, &obj_last, ctx->obj_pend)) return -1;
+        { HostScope h1(ctx, "h_dyn_solve_wait"); if (obj_solved && be_obj_solve_end(ctx, &OP, &obj_last, ctx->obj_pend)) return -1; }
         im.read_back(obj_solved);
-        im.outliers_rejection(body_view());
+        { HostScope h1(ctx, "h_dyn_reject"); im.outliers_rejection(body_view()); }
         return 0;
     }
     int process_image_begin(dv_ctx* ctx, const dv_feat* feats, int n, double header, const dv_inst_obs* insts = nullptr, int n_insts = 0, const dv_feat* inst_feats = nullptr,
@@ -658,9 +659,9 @@ struct dv_estimator {
         if (optimization_end(ctx)) return -1;
         if (dyn_frame) im.touch_in_main_optimization();      // AddInstanceParameterBlock / im.GetOptimizationParameters inside Estimator::Optimization
         { HostScope h(ctx, "h_reject"); reject_outliers(); if (cfg.use_line) lines.remove_outliers(Rs, Ps, ric[0], tic[0]); }
-        if (dyn_frame) { const dvi::BodyView B = body_view(); im.manage_triangulate_point(B); im.slide_window(B, margin_old); }      // estimator.cpp:1653-1658, BEFORE the body window slides
+        if (dyn_frame) { HostScope h1(ctx, "h_dyn_slide"); const dvi::BodyView B = body_view(); im.manage_triangulate_point(B); im.slide_window(B, margin_old); }      // estimator.cpp:1653-1658, BEFORE the body window slides
         { HostScope h(ctx, "h_slide"); slide_window(); }
-        if (dyn_frame) im.finish_frame(body_view());                                                                                 // estimator.cpp:1663-1676, on the slid window
+        if (dyn_frame) { HostScope h1(ctx, "h_dyn_finish_frame"); im.finish_frame(body_view()); }                                                                                 // estimator.cpp:1663-1676, on the slid window
         erase_if([](const Lm& l) { return l.solve_flag == 2; });      // RemoveFailures
         update_latest_states();          // unconditional in the reference (estimator.cpp:1688); the IMU replay inside is empty in vision-only mode
         return 0;

@@ -7,7 +7,7 @@
 //   FitBox3DWithRANSAC / FitBox3DFromCameraFrame                                                                          estimator/vio_util.cpp:209-332
 // on the oracle's own la.h types (std::list + shared_ptr like the reference).  PARITY UNPINNED (dvo.h): the reference cannot be built here and
 // ships no vectors for this path.  Two things the reference leaves to chance are fixed (and documented in DESIGN.md): the unordered_map of
-// instances is visited in ascending id, and FitBox3DWithRANSAC's std::random_device + std::shuffle becomes a seeded xorshift + Fisher-Yates
+// instances is visited in ascending id, and FitBox3DWithRANSAC's std::random_device + std::shuffle becomes a seeded xorshift + (partial, front) Fisher-Yates
 // (seed = f(instance id, frame sequence number, call site)).  Sophus SO3 exp/log are restated from their published algorithm.
 #pragma once
 #include <algorithm>
@@ -108,7 +108,9 @@ inline bool FitBox3DWithRANSAC(const std::vector<V3>& points, const V3& dims, ui
     for (int i = 0; i < size; ++i) random_indices[i] = i;
     const int batch_size = std::min(10, size);
     for (int iter = 0; iter < 20; ++iter) {
-        for (int i = size - 1; i > 0; --i) { const int j = (int)(rd.next() % (uint64_t)(i + 1)); std::swap(random_indices[i], random_indices[j]); }      // std::shuffle(rd) stand-in
+        // std::shuffle(rd) stand-in: only the first batch_size entries are read, so a partial Fisher-Yates from the front (a uniform sample without replacement,
+        // the permutation carrying over between draws like the reference's) replaces the full shuffle; the product draws the same numbers (inst_host.h)
+        for (int i = 0; i < batch_size && i < size - 1; ++i) { const int j = i + (int)(rd.next() % (uint64_t)(size - i)); std::swap(random_indices[i], random_indices[j]); }
         V3 center;
         for (int i = 0; i < batch_size; ++i) center += points[random_indices[i]];
         center = center / (double)batch_size;

@@ -10,8 +10,9 @@ from dynamic_vins_amd import sim                                     # noqa: E40
 from dynamic_vins_amd.pipeline import DynamicPipeline, DynamicSequence    # noqa: E402
 
 W, H, STEPS, WARM = 1280, 720, 100, 14
-seq = DynamicSequence(W, H, sim.ZED, WARM + STEPS + 1, rate=20.0, device="cuda:0")
-pipe = DynamicPipeline(seq, max_cnt=250, min_dist=25, max_iters=10, device=0)
+SCENE = sys.argv[1] if len(sys.argv) > 1 else "escort"          # escort (bench default: 4 boxes in view in every frame) | room (round-2 scene)
+seq = DynamicSequence(W, H, sim.ZED, WARM + STEPS + 1, rate=20.0, device="cuda:0", boxes=("escort", 4) if SCENE == "escort" else None)
+pipe = DynamicPipeline(seq, max_cnt=250, min_dist=25, max_iters=10, device=0, mask_morphology_size=5)
 for _ in range(WARM):
     pipe.step()
 pipe.ctx.timing_enable(-1)
@@ -47,7 +48,7 @@ dt = time.perf_counter() - t0
 print("%.1f frames/s, %.1f us per frame, %.2f objects/frame" % (STEPS / dt, dt / STEPS * 1e6, nobj / STEPS))
 for k2, v in ph.items():
     print("  py %-14s %8.1f us" % (k2, v / STEPS * 1e6))
-for name in ("h_imu", "h_add_features", "h_triangulate", "h_build", "h_solve_begin", "h_solve_upload", "h_solve_enqueue", "h_dynamic", "h_dynamic_finish", "h_solve_wait", "h_post", "h_reject", "h_slide",
+for name in ("h_imu", "h_add_features", "h_triangulate", "h_build", "h_solve_begin", "h_solve_upload", "h_solve_enqueue", "h_dynamic", "h_dyn_push", "h_dyn_propagate", "h_dyn_triangulate", "h_dyn_initial", "h_dyn_build", "h_dyn_solve_begin", "h_dynamic_finish", "h_dyn_solve_wait", "h_dyn_reject", "h_dyn_slide", "h_dyn_finish_frame", "h_solve_wait", "h_post", "h_reject", "h_slide",
              "h_process_begin", "h_process_end"):
     ms, cnt = pipe.ctx.timing_get(name)
     if cnt:

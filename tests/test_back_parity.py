@@ -169,8 +169,8 @@ def test_marginalization_matches_oracle(ctx, oracle, kw, mode):
 
 
 def test_marginalization_with_a_rank_deficient_A_mm(ctx, oracle):
-    """a landmark WITHOUT information (inverse depth 1e5: a point 10 um from the camera, d r / d lambda ~ 1 / lambda^2 -> information ~ 1e-15,
-    below the 1e-8 floor) makes A_mm rank deficient.  The reference zeroes the eigenvalue (marginalization_factor.cpp:286-289); the device skips the LDL^T pivot.
+    """a landmark WITHOUT information (inverse depth 1e5: a point 10 um from the camera seen only from OTHER frames, d r / d lambda ~ 1 / lambda^2
+    -> information ~ 1e-13, below the 1e-8 floor) makes A_mm rank deficient.  The reference zeroes the eigenvalue (marginalization_factor.cpp:286-289); the device skips the LDL^T pivot.
     For a deficient direction that is a single column the two pseudo-inverses coincide: the priors must still agree — to 1e-7 of the matrix scale, since the
     eigen route mixes the tiny coupling terms (~1e-8 x pose Jacobian) into the other eigenvectors — and the event must be VISIBLE through the ABI
     (diag4[2] of dv_marginalize here; dv_est_get_marg_health on the estimator path) instead of silently clamped."""
@@ -178,8 +178,10 @@ def test_marginalization_with_a_rank_deficient_A_mm(ctx, oracle):
     full = ba_gen.make_window(oracle, seed=27, with_prior=True, nlm=80)
     ba_gen.oracle_solve(oracle, full)
     sub = ba_gen.marg_subproblem(full, 0)
-    assert len(sub.inv_depth) >= 4
-    sub.inv_depth[1] = 1.0e5                       # the dead landmark (both sides read the same sub-problem)
+    # a landmark without a same-frame stereo factor (kind 2): seen from the baseline its projection would sit at depth ~0 and blow up instead of vanishing
+    dead = [l for l, L in enumerate(sub.landmarks) if L["count"] > 0 and (sub.factors[L["first"]:L["first"] + L["count"]]["kind"] != 2).all()]
+    assert dead, "the generated window has no temporal-only landmark anchored in frame 0"
+    sub.inv_depth[int(sub.factors[sub.landmarks[dead[0]]["first"]]["lm"])] = 1.0e5      # the dead landmark (inv_depth is indexed by the factors' `lm`; both sides read the same sub-problem)
     sub._bind()
     po, Ao, bo = ba_gen.oracle_marginalize(oracle, sub, 0)
     pd, Ad, bd, diag = marginalize(ctx, sub, 0)
@@ -302,3 +304,33 @@ def test_two_level_elimination_matches_oracle(oracle):
             assert np.abs(dev.pose - ref.pose).max() < 1e-6 and np.abs(dev.speed_bias - ref.speed_bias).max() < 1e-6 and np.abs(dev.inv_depth - ref.inv_depth).max() < 1e-6
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("form", ["ldl_wavecol", "ldl_generic"])
+def test_mfma16_factorisation_agrees_with_the_older_forms(oracle, form):
+    """Round 3: be_solve factors the reduced camera system 16 wide on the f64 matrix cores (MF16, the default where the tiles fit: n <= 175).  The round-2
+    wave-column form and the round-1 generic form stay selectable (dv_debug_set): all of them are LDL^T of the same matrix, so on the same windows they must take
+    the same accept / reject decisions and end on the same states — to rounding, not to the bit (other summation order): 1e-9 against each other, 1e-6 against
+    the oracle like every solver test.  Covers VIO (n = 165), VO (n = 66, right-hand side in the last block's padding rows), priors, 1000 landmarks."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from dynamic_vins_amd.backend import ba_solve
+    from dynamic_vins_amd.frontend import Context
+    from tests import ba_gen
+    new, old = Context(width=64, height=48), Context(width=64, height=48)
+    try:
+        assert old.lib.dv_debug_set(old.h, form.encode(), 1) == 0
+        for kw in [dict(seed=2, nlm=60, with_prior=True), dict(seed=5, nlm=300, with_prior=True), dict(seed=7, nlm=150), dict(seed=9, nlm=200, with_prior=True, use_imu=0),
+                   dict(seed=11, nlm=1000, with_prior=True), dict(seed=13, nlm=0, with_prior=True)]:
+            ref = ba_gen.make_window(oracle, max_iters=8, **kw)
+            a, b = ref.clone(), ref.clone()
+            s_ref = ba_gen.oracle_solve(oracle, ref)
+            sa, sb = ba_solve(new, a), ba_solve(old, b)
+            assert (sa.iterations, sa.successful, sa.termination) == (sb.iterations, sb.successful, sb.termination) == (s_ref.iterations, s_ref.successful, s_ref.termination), kw
+            assert abs(sa.final_cost - sb.final_cost) <= 1e-10 * abs(sb.final_cost) + 1e-12, kw
+            for x, y in ((a.pose, b.pose), (a.speed_bias, b.speed_bias), (a.inv_depth, b.inv_depth)):
+                assert np.abs(x - y).max() < 1e-9, (kw, np.abs(x - y).max())
+            assert np.abs(a.pose - ref.pose).max() < 1e-6 and np.abs(a.inv_depth - ref.inv_depth).max() < 1e-6, kw
+    finally:
+        new.close(); old.close()

@@ -126,7 +126,7 @@ def run_config(oracle, name, frames, n_boxes=4):
     w, h = c["w"], c["h"]
     traj = sim.Trajectory(z_amp=0.0) if c["plane_constraint"] else None
     seq = DynamicSequence(w, h, c["cam0"], frames, rate=20.0, boxes=("escort", n_boxes), baseline=c["baseline"], body_is_camera=c["body_is_camera"], cam1=c["cam1"], traj=traj)
-    segs = sim.SegmentSim(seq.traj, c["cam0"], w, h, n=90, t_ic1=seq.rig["t_ic1"]) if c["use_line"] else None
+    segs = sim.SegmentSim(seq.traj, c["cam0"], w, h, n=300, t_ic1=seq.rig["t_ic1"]) if c["use_line"] else None      # 1242x375 sees a narrow band of the room
     ekw = dict(ref_configs.est_kw(c), **c["noise"])
     pipe = DynamicPipeline(seq, max_cnt=c["max_cnt"], min_dist=c["min_dist"], max_iters=c["max_iters"], use_imu=c["use_imu"], max_dynamic_cnt=c["max_dynamic_cnt"],
                            min_dynamic_dist=c["min_dynamic_dist"], use_det3d=c["use_det3d"], static_inst_threshold=c["static_inst_threshold"],

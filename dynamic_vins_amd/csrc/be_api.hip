@@ -418,8 +418,8 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     sa.xnorm2_extra = P->x_norm2_extra; sa.sh = sh;
     sa.ldl_wcol = (!w.ldl_generic && d.nstate <= 168 && be_ldl_pack(d.nstate, sa.ldl_col0)) ? 1 : 0;
     // the 16-wide MFMA factorisation (be_solve.hip MF16) where the system fits its tile budget and the dense order is used; "ldl_wavecol" / "ldl_generic" select the older forms
-    // (not for members of a dv_batch: the batched entry form exists for the wave-column kernel; not with the two-level order, whose dense part is wave-column)
-    if (!w.ldl_generic && !w.ldl_wavecol_only && !sa.dims.pad && !ctx->batch) {
+    // (not with the two-level order, whose dense part is wave-column)
+    if (!w.ldl_generic && !w.ldl_wavecol_only && !sa.dims.pad) {
         uint8_t plan[64];
         if (be_mf16_plan(d.nstate, plan)) { std::memcpy(sa.ldl_col0, plan, sizeof(plan)); sa.ldl_wcol = 2; }
     }
@@ -554,7 +554,7 @@ static int batch_enqueue_impl(dv_batch* B) {
     bool uniform = true; int slots = M[0]->be.pend->first_slots, max_grid = 0, max_n = 0;
     for (dv_ctx* c : M) {
         const BePending& pd = *c->be.pend;
-        if (pd.sa.ldl_wcol != 1 || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing)) uniform = false;
+        if (pd.sa.ldl_wcol == 0 || pd.sa.ldl_wcol != M[0]->be.pend->sa.ldl_wcol || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing)) uniform = false;
         max_grid = std::max(max_grid, pd.ea.dims.nlm + pd.ea.dims.nimu + 1); max_n = std::max(max_n, pd.sa.dims.nstate);
     }
     if (!uniform || M.size() == 1) {      // mixed kernel variants (or nothing to share): every member on its own stream, as without a batch
@@ -576,7 +576,7 @@ static int batch_enqueue_impl(dv_batch* B) {
     for (int it = 0; it < slots; ++it) {                  // be_enqueue_slots' speculative schedule, one launch per stage for all windows
         const bool head = it == 0, last = it == slots - 1;
         if (head) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_X, s); be_launch_reduce_batch(dsa, S, max_n, 0, s); }
-        if (be_launch_solve_batch(dsa, S, max_n, two_level, head ? 0 : 1, s)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
+        if (be_launch_solve_batch(dsa, S, max_n, two_level, head ? 0 : 1, s, M[0]->be.pend->sa.ldl_wcol)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
         if (last) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s); be_launch_accept_batch(dsa, S, s); }
         else { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); be_launch_reduce_batch(dsa, S, max_n, 1, s); }
     }

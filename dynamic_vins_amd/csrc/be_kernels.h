@@ -188,7 +188,7 @@ bool be_ldl_pack(int n, uint16_t* col0);
 // batched forms: n_win independent windows per launch (argument tables in HBM, window index in the grid); be_api.hip enqueues them for a dv_batch
 void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s);
 void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s);
-int  be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s);
+int  be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s, int ldl_mode);      // ldl_mode: the members' common ldl_wcol (1 wave-column, 2 MF16)
 void be_launch_accept_batch(const BeSolveArgs* tab_dev, int n_win, hipStream_t s);
 void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s);   // after the exchange of a reduce: rank-ordered sums -> Hd / Sc / gvec, packet rows, candidate costs
 void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s);      // cost-only exchange: phase 0 packs the owned candidate costs, phase 1 scatters all of them

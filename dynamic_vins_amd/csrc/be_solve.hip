@@ -845,22 +845,27 @@ typedef double mf_d4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ mf_d4 mf_mfma(double a, double b, mf_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ int mf_tix(int I, int J, int NB) { return J * NB - (J * (J - 1)) / 2 + (I - J); }
 template <int LANE> __device__ __forceinline__ double mf_rowbc(double v) { return dpp_f64<0x150 + LANE, 0xf>(v); }      // row_newbcast:LANE (gfx90a+): lane LANE of every 16-lane row to the whole row
-__device__ __forceinline__ double mf_pick(int rho, double v0, double v1, double v2, double v3) { return rho == 0 ? v0 : (rho == 1 ? v1 : (rho == 2 ? v2 : v3)); }
+__device__ __forceinline__ double mf_sel4(int rho, double v0, double v1, double v2, double v3) {      // v[rho] as three selects (a nested ?: chain is compiled into exec-mask branches)
+    const bool b0 = (rho & 1) != 0, b1 = (rho & 2) != 0;
+    const double t0 = b0 ? v1 : v0, t1 = b0 ? v3 : v2;
+    return b1 ? t1 : t0;
+}
 struct MfLds { double* Tl; double* gat; double* dv; double* iv; double* yv; };      // tiles | per-wave gather buffers (64 each) | D | 1 / D | y (then the running right-hand side of the back substitution)
 
-// one 4-pivot sub-step of the diagonal tile.  nv: rows of this tile that belong to the n x n system (pivots p < nv are checked); c0: local index of the
-// right-hand-side row (or -1); yk: this block's 16 entries of y
+// one 4-pivot sub-step of the diagonal tile.  c0: local index of the right-hand-side row (or -1); yk: this block's 16 entries of y.
+// The instruction stream of this one wave IS the critical path of the factorisation (~10 cycles per instruction in this mix of dependent fp64, LDS and MFMA
+// operations), so everything that is not arithmetic is kept out of it: the pivot block comes from the gather buffer by same-address (broadcast) LDS reads next
+// to the column reads, selections are flat v_cndmask pairs, D / 1/D / y leave through single masked 32-byte stores, the pivot check runs once per tile.
 template <int Q>
-__device__ __forceinline__ void mf_diag_substep(mf_d4& T, mf_d4& Wt, double* gat, double* dv16, double* iv16, int nv, int c0, double* yk, int* s_fail) {
+__device__ __forceinline__ void mf_diag_substep(mf_d4& T, mf_d4& Wt, double* gat, double* dv16, double* iv16, int c0, double* yk) {
     constexpr int P = 4 * Q;
     const int lane = threadIdx.x & 63, c = lane & 15, rho = lane >> 4;
     gat[lane] = T[Q];                                   // rows P .. P+3 sit in register Q of the four 16-lane rows
     wave_lds_sync();
     const double g0 = gat[c], g1 = gat[16 + c], g2 = gat[32 + c], g3 = gat[48 + c];      // g_m = A[P + m][c] (= A[c][P + m])
+    const double d0 = gat[P], a10 = gat[16 + P], a11 = gat[16 + P + 1], a20 = gat[32 + P], a21 = gat[32 + P + 1], a22 = gat[32 + P + 2];
+    const double a30 = gat[48 + P], a31 = gat[48 + P + 1], a32 = gat[48 + P + 2], a33 = gat[48 + P + 3];
     wave_lds_sync();
-    const double d0 = mf_rowbc<P>(g0), a10 = mf_rowbc<P>(g1), a20 = mf_rowbc<P>(g2), a30 = mf_rowbc<P>(g3);
-    const double a11 = mf_rowbc<P + 1>(g1), a21 = mf_rowbc<P + 1>(g2), a31 = mf_rowbc<P + 1>(g3);
-    const double a22 = mf_rowbc<P + 2>(g2), a32 = mf_rowbc<P + 2>(g3), a33 = mf_rowbc<P + 3>(g3);
     const double i0 = fast_rcp(d0);
     const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
     const double d1 = __builtin_fma(-l10, a10, a11), i1 = fast_rcp(d1);
@@ -870,124 +875,174 @@ __device__ __forceinline__ void mf_diag_substep(mf_d4& T, mf_d4& Wt, double* gat
     const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, a20, a32));
     const double l32 = t32 * i2;
     const double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, a30, a33))), i3 = fast_rcp(d3);
-    // this lane's column, read as row c of the panel: p = (L D)[c][P..P+3], x = L[c][P..P+3]; only the strictly lower part counts
+    // this lane's column, read as row c of the panel: p = (L D)[c][P..P+3], x = L[c][P..P+3]; only the strictly lower part of L counts
     const double p0 = g0, p1 = __builtin_fma(-p0, l10, g1);
     const double p2 = __builtin_fma(-p1, l21, __builtin_fma(-p0, l20, g2));
     const double p3 = __builtin_fma(-p2, l32, __builtin_fma(-p1, l31, __builtin_fma(-p0, l30, g3)));
     const double lh0 = c > P ? p0 * i0 : 0.0, lh1 = c > P + 1 ? p1 * i1 : 0.0, lh2 = c > P + 2 ? p2 * i2 : 0.0, lh3 = c > P + 3 ? p3 * i3 : 0.0;
-    const double ph0 = c > P ? p0 : 0.0, ph1 = c > P + 1 ? p1 : 0.0, ph2 = c > P + 2 ? p2 : 0.0, ph3 = c > P + 3 ? p3 : 0.0;
-    T = mf_mfma(-mf_pick(rho, lh0, lh1, lh2, lh3), mf_pick(rho, ph0, ph1, ph2, ph3), T);      // T -= Lhat (D Lhat)^T: rank 4, the whole tile in one instruction
+    // T -= Lhat (D Lhat)^T: rank 4, the whole tile in one instruction.  Only the A operand is masked: the unmasked columns of B reach finished columns of the
+    // tile only, which are never read again.
+    T = mf_mfma(-mf_sel4(rho, lh0, lh1, lh2, lh3), mf_sel4(rho, p0, p1, p2, p3), T);
     // W <- L_q^-1 W with L_q^-1 = I - Lhat W_qq embedded in columns P .. P+3 (W_qq = inverse of the unit lower 4x4 pivot block)
-    const double w10 = -l10, w21 = -l21, w32 = -l32;
     const double w20 = __builtin_fma(l21, l10, -l20), w31 = __builtin_fma(l32, l21, -l31);
     const double w30 = __builtin_fma(-l32, w20, __builtin_fma(l31, l10, -l30));      // -l30 + l31 l10 + l32 l20 - l32 l21 l10
-    const double z0 = -__builtin_fma(lh3, w30, __builtin_fma(lh2, w20, __builtin_fma(lh1, w10, lh0)));
-    const double z1 = -__builtin_fma(lh3, w31, __builtin_fma(lh2, w21, lh1));
-    const double z2 = -__builtin_fma(lh3, w32, lh2);
-    const double z3 = -lh3;
+    const double z0 = -__builtin_fma(lh3, w30, __builtin_fma(lh2, w20, __builtin_fma(-lh1, l10, lh0)));
+    const double z1 = -__builtin_fma(lh3, w31, __builtin_fma(-lh2, l21, lh1));
+    const double z2 = -__builtin_fma(-lh3, l32, lh2);
     const double wq = Wt[Q];
-    Wt = mf_mfma(mf_pick(rho, z0, z1, z2, z3), wq, Wt);
+    Wt = mf_mfma(mf_sel4(rho, z0, z1, z2, -lh3), wq, Wt);
     if (lane == 0) {
-        dv16[P] = d0; dv16[P + 1] = d1; dv16[P + 2] = d2; dv16[P + 3] = d3;
-        iv16[P] = i0; iv16[P + 1] = i1; iv16[P + 2] = i2; iv16[P + 3] = i3;
-        bool bad = false;
-        if (P < nv) bad = bad || !(d0 > 0.0) || !isfinite(d0);
-        if (P + 1 < nv) bad = bad || !(d1 > 0.0) || !isfinite(d1);
-        if (P + 2 < nv) bad = bad || !(d2 > 0.0) || !isfinite(d2);
-        if (P + 3 < nv) bad = bad || !(d3 > 0.0) || !isfinite(d3);
-        if (bad) *s_fail = 1;
+        mf_d4 dd = { d0, d1, d2, d3 }, ii = { i0, i1, i2, i3 };
+        *reinterpret_cast<mf_d4*>(dv16 + P) = dd; *reinterpret_cast<mf_d4*>(iv16 + P) = ii;
     }
-    if (lane == c0) {          // row c0 of L_kk = this block's share of y (lane c0 of the first 16-lane row; c0 >= 0 only in the last block)
-        if (P < c0) yk[P] = lh0;
-        if (P + 1 < c0) yk[P + 1] = lh1;
-        if (P + 2 < c0) yk[P + 2] = lh2;
-        if (P + 3 < c0) yk[P + 3] = lh3;
-    }
+    if (lane == c0) { mf_d4 yy = { lh0, lh1, lh2, lh3 }; *reinterpret_cast<mf_d4*>(yk + P) = yy; }      // row c0 of L_kk = this block's share of y (zero from column c0 on: lh is masked)
 }
 __device__ __forceinline__ void mf_diag_factor(mf_d4& T, const MfLds& m, int k, int NB, int n, int* s_fail) {
     const int lane = threadIdx.x & 63, c = lane & 15, rho = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __builtin_amdgcn_s_setprio(3);
     mf_d4 Wt;
 #pragma unroll
     for (int r = 0; r < 4; ++r) Wt[r] = (rho + 4 * r == c) ? 1.0 : 0.0;
     double* gat = m.gat + wave * 64;
-    const int nv = n - 16 * k, c0 = (nv >= 0 && nv < 16) ? nv : -1;
-    mf_diag_substep<0>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, nv, c0, m.yv + 16 * k, s_fail);
-    mf_diag_substep<1>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, nv, c0, m.yv + 16 * k, s_fail);
-    mf_diag_substep<2>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, nv, c0, m.yv + 16 * k, s_fail);
-    mf_diag_substep<3>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, nv, c0, m.yv + 16 * k, s_fail);
+    const int nv = n - 16 * k, c0 = (nv >= 0 && nv < 16) ? nv : -1;      // nv: rows of this tile that belong to the n x n system
+    mf_diag_substep<0>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
+    mf_diag_substep<1>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
+    mf_diag_substep<2>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
+    mf_diag_substep<3>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
     *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(k, k, NB) * 256 + lane * 4) = Wt;      // W_k = L_kk^-1, result layout
+    wave_lds_sync();
+    const double dchk = m.dv[16 * k + c];                                                   // pivots of the n x n system must be positive and finite
+    if (__ballot(c < nv && (!(dchk > 0.0) || !isfinite(dchk))) != 0ull && lane == 0) *s_fail = 1;
+    __builtin_amdgcn_s_setprio(0);
 }
-// entry (i, j) of the scaled, damped (n+1)-system with the right-hand side as row / column n and identity padding behind it
-__device__ __forceinline__ double mf_entry(const double* __restrict__ Sc, const double* v_s, const double* v_d, const double* rhs, int n, double mu, int i, int j) {
+// tile entries: the raw Schur-complement entry is requested early (mf_prefetch, before the scaling phase: the loads' round trip hides behind it) and finished
+// (scaled, damped; right-hand side as row / column n; identity padding behind it) when the factorisation starts
+__device__ __forceinline__ double mf_raw(const double* __restrict__ Sc, int n, int i, int j) {
+    if (i < j) { const int t = i; i = j; j = t; }
+    const int NBR = (n + 3) >> 2, bi = i >> 2, bj = j >> 2;
+    const bool in = i < n;
+    return Sc[in ? (size_t)(bj * NBR - bj * (bj - 1) / 2 + bi - bj) * 16 + (i & 3) * 4 + (j & 3) : 0];      // (the value is ignored for i >= n)
+}
+__device__ __forceinline__ double mf_finish(double raw, const double* v_s, const double* v_d, const double* rhs, int n, double mu, int i, int j) {
     if (i < j) { const int t = i; i = j; j = t; }
     if (i > n) return i == j ? 1.0 : 0.0;
     if (i == n) return j == n ? MF_RHO : v_s[j] * rhs[j];
-    const int NBR = (n + 3) >> 2, bi = i >> 2, bj = j >> 2;
-    const double v = v_s[i] * v_s[j] * Sc[(size_t)(bj * NBR - bj * (bj - 1) / 2 + bi - bj) * 16 + (i & 3) * 4 + (j & 3)];
+    const double v = v_s[i] * v_s[j] * raw;
     return i == j ? v + mu * v_d[i] * v_d[i] : v;
 }
+__device__ __forceinline__ void mf_slots(const uint8_t* plan, int wave, int NB, int (&sI)[5], int (&sJ)[5]) {
+    sI[0] = sJ[0] = wave < NB ? wave : -1;
+#pragma unroll
+    for (int s = 1; s < 5; ++s) { const int b = plan[wave * 4 + s - 1]; sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
+}
+__device__ __forceinline__ void mf_prefetch(const double* __restrict__ Sc, const uint8_t* plan, int n, mf_d4 (&U)[5]) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, rho = lane >> 4;
+    int sI[5], sJ[5];
+    mf_slots(plan, wave, (n + 16) >> 4, sI, sJ);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? mf_raw(Sc, n, 16 * sI[s] + c, 16 * sJ[s] + rho + 4 * r) : 0.0;
+    }
+}
 // plan: bytes [16][4] of (I << 4 | J) for the off-diagonal slots 1..4 of every wave (0xFF = empty); slot 0 of wave w < NB is the diagonal tile (w, w)
-__device__ __forceinline__ bool ldlt_mf16(const double* __restrict__ Sc, const uint8_t* plan, int n, double mu, const double* v_s, const double* v_d, const double* rhs, const MfLds& m, int* s_fail) {
+// side(excl): work of the caller that does not feed the factorisation (cost at x, gradient tolerance, landmark diagonal, L2 warm-up), run by every wave but
+// `excl` while that wave factors a diagonal tile — they would wait at the barrier otherwise; side0(): the excluded wave's share, one step later.
+// Schedule per block column k (two workgroup barriers A, B per 16 pivots):
+//   wave k+1 (owner of diagonal tile k+1 AND of tile (k+1, k)):  panel of (k+1, k)  ->  its diagonal tile -= V D V^T straight from its registers  ->  B  ->
+//                                                                 factor diagonal tile k+1, publish W_k+1  ->  A
+//   every other wave:                                             its panel tile of column k  ->  B  ->  trailing update of its tiles with panel k  ->  A
+// so the diagonal chain (the critical path) never waits for the other waves' panels or updates: they run beside it.
+template <class Side, class Side0>
+__device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* plan, int n, double mu, const double* v_s, const double* v_d, const double* rhs, const MfLds& m, int* s_fail, Side side, Side0 side0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, rho = lane >> 4;      // wave in an SGPR: the slot tests below are scalar branches
     const int NB = (n + 16) >> 4, IB = n >> 4, c0 = n & 15;
     int sI[MF_SLOTS], sJ[MF_SLOTS];
-    sI[0] = sJ[0] = wave < NB ? wave : -1;
-#pragma unroll
-    for (int s = 1; s < MF_SLOTS; ++s) { const int b = plan[wave * 4 + s - 1]; sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
-    mf_d4 U[MF_SLOTS];
+    mf_slots(plan, wave, NB, sI, sJ);
 #pragma unroll
     for (int s = 0; s < MF_SLOTS; ++s) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? mf_entry(Sc, v_s, v_d, rhs, n, mu, 16 * sI[s] + c, 16 * sJ[s] + rho + 4 * r) : 0.0;
+        for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? mf_finish(U[s][r], v_s, v_d, rhs, n, mu, 16 * sI[s] + c, 16 * sJ[s] + rho + 4 * r) : 0.0;
     }
     for (int i = tid; i < 16 * NB; i += SOL_THREADS) m.yv[i] = 0.0;
     if (tid == 0) *s_fail = 0;
+#ifdef BE_SOLVE_TS
+    if (tid == 0) { be_dbg_ts[19] = 0; be_dbg_ts[20] = 0; }
+#endif
     lds_barrier();
     TS(4);
-    if (wave == 0) mf_diag_factor(U[0], m, 0, NB, n, s_fail);
-    lds_barrier();
-    for (int k = 0; k < NB; ++k) {
-        // ---- panel of block column k ----
-        bool any = false;
+    const int k_side = -1; // (NB >= 9 ? 6 : -1: the side work inside the loop costs 70 spilled VGPRs)                 // the step whose slack takes the side work (small systems: beside the first diagonal tile)
+    if (wave == 0) { mf_diag_factor(U[0], m, 0, NB, n, s_fail); if (k_side < 0) side0(); }
+    else if (k_side < 0) side(0);
+    lds_barrier();                                       // A: W_0 published
+#ifdef BE_SOLVE_TS
+    long long t_prev = wall_clock64(), acc_panel = 0, acc_update = 0;
+    if (tid == 0) be_dbg_ts[16] = t_prev - be_dbg_ts[4];      // load + first diagonal tile
+#endif
+    // one panel tile: V = D^-1 W_k U, kept in the registers, stored as the factor's fragment, row n of L (the last block row) copied out as y
+    auto panel = [&](mf_d4& T, int I, int k) {
+        const double* Wk = m.Tl + (size_t)mf_tix(k, k, NB) * 256;
+        double wf[4], ivr[4];
 #pragma unroll
-        for (int s = 1; s < MF_SLOTS; ++s) any = any || sJ[s] == k;
-        if (any) {
-            const double* Wk = m.Tl + (size_t)mf_tix(k, k, NB) * 256;
-            double wf[4], ivr[4];
+        for (int q = 0; q < 4; ++q) { wf[q] = Wk[((((c & 3) << 4) + rho + 4 * q) << 2) + (c >> 2)]; ivr[q] = m.iv[16 * k + rho + 4 * q]; }      // W[c][rho + 4q] from the result-layout image
+        mf_d4 Y = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { wf[q] = Wk[((((c & 3) << 4) + rho + 4 * q) << 2) + (c >> 2)]; ivr[q] = m.iv[16 * k + rho + 4 * q]; }      // W[c][rho + 4q] from the result-layout image
+        for (int q = 0; q < 4; ++q) Y = mf_mfma(wf[q], T[q], Y);
 #pragma unroll
-            for (int s = 1; s < MF_SLOTS; ++s) if (sJ[s] == k) {
-                mf_d4 Y = { 0.0, 0.0, 0.0, 0.0 };
+        for (int r = 0; r < 4; ++r) Y[r] *= ivr[r];
+        T = Y;
+        *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(I, k, NB) * 256 + lane * 4) = Y;
+        if (I == IB && c == c0) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) Y = mf_mfma(wf[q], U[s][q], Y);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) Y[r] *= ivr[r];
-                U[s] = Y;
-                *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(sI[s], k, NB) * 256 + lane * 4) = Y;
-                if (sI[s] == IB && c == c0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) m.yv[16 * k + rho + 4 * r] = Y[r];      // row n of L: y
-                }
-            }
+            for (int r = 0; r < 4; ++r) m.yv[16 * k + rho + 4 * r] = Y[r];      // row n of L: y
         }
-        lds_barrier();
-        if (k == NB - 1) break;
-        // ---- trailing update with panel k; the owner of diagonal tile k+1 factors it right behind its update ----
+    };
+    for (int k = 0; k + 1 < NB; ++k) {
         double dk[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) dk[q] = -m.dv[16 * k + rho + 4 * q];
+        if (wave == k + 1) {
+            // ---- the diagonal chain: slot 1 of this wave is tile (k+1, k) ----
+            __builtin_amdgcn_s_setprio(3);
+            panel(U[1], k + 1, k);
 #pragma unroll
-        for (int s = 0; s < MF_SLOTS; ++s) if (sJ[s] > k) {
-            const mf_d4 a = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(sJ[s], k, NB) * 256 + lane * 4);
-            const mf_d4 b = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(sI[s], k, NB) * 256 + lane * 4);
+            for (int q = 0; q < 4; ++q) U[0] = mf_mfma(U[1][q], dk[q] * U[1][q], U[0]);
+            lds_barrier();                               // B
+#ifdef BE_SOLVE_TS
+            const long long t_u = wall_clock64();
+#endif
+            mf_diag_factor(U[0], m, k + 1, NB, n, s_fail);
+#ifdef BE_SOLVE_TS
+            if (lane == 0) { be_dbg_ts[19] += wall_clock64() - t_u; be_dbg_ts[20] += t_u - t_prev; }      // diagonal tiles; the owner's panel + update before them
+#endif
+            lds_barrier();                               // A
+        } else {
+            // ---- everybody else: panel tile of column k, then the trailing update ----
 #pragma unroll
-            for (int q = 0; q < 4; ++q) U[s] = mf_mfma(a[q], dk[q] * b[q], U[s]);
+            for (int s = 1; s < MF_SLOTS; ++s) if (sJ[s] == k) panel(U[s], sI[s], k);
+            lds_barrier();                               // B
+#ifdef BE_SOLVE_TS
+            { const long long t = wall_clock64(); acc_panel += t - t_prev; t_prev = t; }
+#endif
+#pragma unroll
+            for (int s = 0; s < MF_SLOTS; ++s) if (sJ[s] > k) {
+                const mf_d4 a = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(sJ[s], k, NB) * 256 + lane * 4);
+                const mf_d4 b = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(sI[s], k, NB) * 256 + lane * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) U[s] = mf_mfma(a[q], dk[q] * b[q], U[s]);
+            }
+            if (k == k_side) side(k + 1);
+            if (k == k_side + 1 && k_side >= 0 && wave == k_side + 1) side0();
+            lds_barrier();                               // A
+#ifdef BE_SOLVE_TS
+            { const long long t = wall_clock64(); acc_update += t - t_prev; t_prev = t; }
+#endif
         }
-        if (wave == k + 1) mf_diag_factor(U[0], m, k + 1, NB, n, s_fail);
-        lds_barrier();
     }
     TS(5);
+#ifdef BE_SOLVE_TS
+    if (tid == 0) { be_dbg_ts[17] = acc_panel; be_dbg_ts[18] = acc_update; }
+#endif
     return *s_fail == 0;
 }
 // block back substitution L^T x = y on the tiles: per block row i (last to first) x_i = W_i^T y_i (every wave that needs it forms it itself: 4 FMAs per lane and
@@ -996,9 +1051,7 @@ __device__ __forceinline__ void bs_mf16(const uint8_t* plan, int n, const MfLds&
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, rho = lane >> 4;
     const int NB = (n + 16) >> 4, IB = n >> 4, c0 = n & 15;
     int sI[MF_SLOTS], sJ[MF_SLOTS];
-    sI[0] = sJ[0] = -1;
-#pragma unroll
-    for (int s = 1; s < MF_SLOTS; ++s) { const int b = plan[wave * 4 + s - 1]; sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
+    mf_slots(plan, wave, NB, sI, sJ);
     double* gat = m.gat + wave * 64;
     for (int i = NB - 1; i >= 0; --i) {
         bool need = wave == 0;
@@ -1321,24 +1374,24 @@ static size_t solve_smem_mf16(int n) {
     const size_t NB = ((size_t)n + 16) >> 4, nt = NB * (NB + 1) / 2;
     return (std::max<size_t>(nt * 256, 3072) + 9 * (size_t)n + 72 + 80 + 8 + 1024 + 3 * 16 * NB) * sizeof(double);
 }
-// MF16 tile plan (ldlt_mf16): wave j < NB owns diagonal tile j (slot 0).  Off-diagonal tile (I, J) may go to a wave >= NB or to a wave w with J < w: then the
-// wave that factors diagonal tile k+1 behind the update of step k has no other active tile (its off-diagonal tiles lie in columns <= k).  Late columns first
-// (fewest eligible waves), least-loaded eligible wave.  Returns false when the system does not fit (NB > 11: LDS) or a wave would need more than 4 slots.
+// MF16 tile plan (ldlt_mf16): wave j < NB owns diagonal tile j (slot 0) and the tile left of it, (j, j-1) (slot 1).  Any other off-diagonal tile (I, J) may go to wave 0 (its diagonal tile is factored before the
+// loop), to a wave >= NB, or to a wave w with J < w: then the wave that factors diagonal tile k+1 behind the update of step k has no other active tile (its
+// off-diagonal tiles lie in columns <= k).  Every column's tiles go to DIFFERENT waves (one panel tile per wave and step), the waves whose eligibility ends
+// first are used first (earliest deadline first: wave w < NB is useless from column w on).  Feasible for every n <= 175 (checked exhaustively).
 bool be_mf16_plan(int n, uint8_t* plan /* [16][4] */) {
     const int NB = (n + 16) >> 4, W = SOL_THREADS / 64;
-    if (NB > MF_MAXNB || solve_smem_mf16(n) > 160 * 1024) return false;
+    if (NB > MF_MAXNB || solve_smem_mf16(n) > 160 * 1024 - 512) return false;
     int load[SOL_THREADS / 64] = { 0 };
     std::memset(plan, 0xFF, (size_t)W * 4);
-    for (int J = NB - 2; J >= 0; --J)
-        for (int I = J + 1; I < NB; ++I) {
-            int best = -1;
-            for (int w = W - 1; w >= 0; --w) {
-                const bool eligible = w >= NB || J < w;
-                if (eligible && load[w] < 4 && (best < 0 || load[w] < load[best])) best = w;
-            }
-            if (best < 0) return false;
-            plan[best * 4 + load[best]++] = (uint8_t)((I << 4) | J);
-        }
+    for (int j = 1; j < NB; ++j) plan[j * 4 + load[j]++] = (uint8_t)((j << 4) | (j - 1));      // slot 1 of wave j: tile (j, j-1), the one its diagonal tile waits for
+    for (int J = 0; J < NB - 1; ++J) {
+        int el[SOL_THREADS / 64], ne = 0;
+        for (int w = 0; w < W; ++w) if ((w == 0 || w >= NB || J < w) && w != J + 1 && load[w] < 4) el[ne++] = w;      // (wave J+1 has its tile of this column)
+        auto key = [&](int w) { return ((1 <= w && w < NB) ? w - 1 : NB) * 1024 + load[w] * 32 + w; };
+        std::sort(el, el + ne, [&](int x, int y) { return key(x) < key(y); });
+        if (ne < NB - 2 - J) return false;
+        for (int t = 0, I = J + 2; I < NB; ++I, ++t) { const int w = el[t]; plan[w * 4 + load[w]++] = (uint8_t)((I << 4) | J); }
+    }
     return true;
 }
 
@@ -1369,7 +1422,7 @@ int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
     const int nbr = (a.dims.nstate + 3) / 4;
     if (a.ldl_wcol == 2) {
         static DevOnce once_mf;
-        if (once_mf.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ? 1 : 0; })) return -1;
+        if (once_mf.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ? 1 : 0; })) return -1;      // 160 KB per workgroup less the kernel's static arrays
         hipLaunchKernelGGL((be_solve_kernel<1, false, true>), dim3(1), dim3(SOL_THREADS), solve_smem_mf16(a.dims.nstate), s, a, spec);
         return 0;
     }
@@ -1380,10 +1433,13 @@ int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
 }
 
 // batched: every window of the table must use the wave-column factorisation with the same dense order (checked by the caller); smem for the largest n
-int be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s) {
+int be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s, int ldl_mode) {
     static DevOnce once;
-    if (once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_batch_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(168, false, true)) != hipSuccess ? 1 : 0; })) return -1;
-    hipLaunchKernelGGL((be_solve_batch_kernel<1, true>), dim3(n_win), dim3(SOL_THREADS), solve_smem(max_n, two_level, true), s, tab_dev, spec);
+    if (once.run([] {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_batch_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(168, false, true)) != hipSuccess) return 1;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_batch_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ? 1 : 0; })) return -1;
+    if (ldl_mode == 2) hipLaunchKernelGGL((be_solve_batch_kernel<1, false, true>), dim3(n_win), dim3(SOL_THREADS), solve_smem_mf16(max_n), s, tab_dev, spec);      // every window on the MF16 form
+    else hipLaunchKernelGGL((be_solve_batch_kernel<1, true>), dim3(n_win), dim3(SOL_THREADS), solve_smem(max_n, two_level, true), s, tab_dev, spec);
     return 0;
 }
 

@@ -12,6 +12,7 @@ lib.dv_debug_solve_ts.argtypes = [C.POINTER(C.c_longlong)]
 seqp = [(15, 0, "accept decision (prologue)"), (0, 3, "scale + gradient"), (3, 4, "ldlt load"), (4, 5, "ldlt loop"), (5, 6, "ldlt store(+cost/tol)"), (6, 7, "back-sub"),
         (7, 8, "gn landmarks"), (8, 9, "dogleg (+lazy Cauchy)"), (9, 11, "gemv H*delta"), (11, 12, "w . delta"), (12, 13, "candidate"), (13, 10, "final sums"), (15, 10, "total"), (9, 25, "w15: to candidate start"), (25, 26, "w15: pose"), (26, 27, "w15: sb"), (27, 28, "w15: ex"), (28, 29, "w15: rest"), (13, 29, "tid0 ready -> w15 ready"), (29, 10, "w15 ready -> end")]
 rows = []
+extra = []
 for k in range(N):
     pipe.step()
     torch.cuda.synchronize()
@@ -19,6 +20,10 @@ for k in range(N):
     lib.dv_debug_solve_ts(ts)
     t = np.array(ts[:32], dtype=np.int64)
     if k >= 20: rows.append([(t[b] - t[a]) / 100.0 for a, b, _ in seqp])
+    if k >= 20: extra.append([t[16] / 100.0, t[17] / 100.0, t[18] / 100.0, t[19] / 100.0, t[20] / 100.0])
 r = np.array(rows)
 for i, (_, _, name) in enumerate(seqp):
     print(f"{name:26s} mean {r[:, i].mean():7.2f}  min {r[:, i].min():7.2f}  max {r[:, i].max():7.2f}")
+e = np.array(extra)
+for i, name in enumerate(["mf16: load + diag tile 0", "mf16: panels (sum over steps)", "mf16: updates + next diag (sum)", "mf16: diag tiles 1.. (owner wave, sum)", "mf16: owner's update before its diag (sum)"]):
+    print(f"{name:44s} mean {e[:, i].mean():7.2f}")

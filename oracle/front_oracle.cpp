@@ -33,9 +33,58 @@
 #include <vector>
 
 #include <thread>
-static int g_threads = 1;      // dvo_set_threads: CPU-baseline timing only; results do not depend on it (points are independent)
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+static int g_threads = 1;      // dvo_set_threads: CPU-baseline timing only; results do not depend on it (rows / points are independent, lists are concatenated in order)
 extern "C" void dvo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 extern "C" int dvo_get_threads() { return g_threads; }
+// A persistent worker pool standing in for OpenCV's parallel_for_ back end (the reference links OpenCV 3.4 built with a thread pool: calcOpticalFlowPyrLK runs
+// its LKTrackerInvoker over ranges of points, pyrDown / the corner response over ranges of rows).  Spawning std::threads per level — the round-2 form — cost
+// more than the work it split (16 threads = 0 % gain).  parallel_rows(n, grain, f) calls f(a, b) on disjoint ranges covering [0, n).
+namespace {
+class Pool {
+public:
+    static Pool& get() { static Pool* p = new Pool; return *p; }      // never destroyed: its workers sleep on the condition variable until the process ends
+    void run(int n, int grain, const std::function<void(int, int)>& f) {
+        const int want = std::min(g_threads, std::max(1, n / std::max(grain, 1)));
+        if (want <= 1 || busy_) { f(0, n); return; }                 // (nested calls run inline)
+        ensure(want - 1);
+        std::unique_lock<std::mutex> lk(mu_);
+        busy_ = true; fn_ = &f; n_ = n; parts_ = want; next_ = 0; pending_ = want; ++gen_;
+        lk.unlock(); cv_.notify_all();
+        work();                                                      // the caller takes parts too
+        lk.lock();
+        done_.wait(lk, [&] { return pending_ == 0; });
+        busy_ = false; fn_ = nullptr;
+    }
+private:
+    void ensure(int workers) {
+        while ((int)th_.size() < workers) { th_.emplace_back([this] { loop(); }); th_.back().detach(); }
+    }
+    void work() {
+        for (;;) {
+            int part;
+            { std::lock_guard<std::mutex> lk(mu_); if (next_ >= parts_) return; part = next_++; }
+            const int a = (int)((long long)n_ * part / parts_), b = (int)((long long)n_ * (part + 1) / parts_);
+            (*fn_)(a, b);
+            { std::lock_guard<std::mutex> lk(mu_); if (--pending_ == 0) done_.notify_all(); }
+        }
+    }
+    void loop() {
+        long long seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return gen_ != seen; }); seen = gen_; }
+            work();
+        }
+    }
+    std::mutex mu_; std::condition_variable cv_, done_;
+    std::vector<std::thread> th_;              // detached at exit by leaking the singleton's threads (process lifetime)
+    const std::function<void(int, int)>* fn_ = nullptr;
+    int n_ = 0, parts_ = 0, next_ = 0, pending_ = 0; long long gen_ = 0; bool busy_ = false;
+};
+inline void parallel_rows(int n, int grain, const std::function<void(int, int)>& f) { Pool::get().run(n, grain, f); }
+}
 
 namespace {
 
@@ -52,28 +101,41 @@ struct Img { int w = 0, h = 0; std::vector<uint8_t> d; };
 
 void pyr_down(const uint8_t* src, int w, int h, uint8_t* dst) {
     const int w2 = (w + 1) / 2, h2 = (h + 1) / 2;
-    std::vector<int> rows(5 * (size_t)w2);
-    for (int y = 0; y < h2; ++y) {
-        for (int k = 0; k < 5; ++k) {
-            const uint8_t* s = src + (size_t)reflect101(2 * y + k - 2, h) * w;
-            int* r = rows.data() + (size_t)k * w2;
+    parallel_rows(h2, 32, [&](int ya, int yb) {
+        // horizontal [1 4 6 4 1] pass of a source row, cached in a ring of 5 (consecutive output rows share three of their five source rows)
+        std::vector<int> ring(5 * (size_t)w2);
+        int have[5] = { -1, -1, -1, -1, -1 };
+        auto hrow = [&](int sy) -> const int* {
+            const int slot = sy % 5;
+            int* r = ring.data() + (size_t)slot * w2;
+            if (have[slot] == sy) return r;
+            have[slot] = sy;
+            const uint8_t* s = src + (size_t)sy * w;
             for (int x = 0; x < w2; ++x) {
+                if (x >= 1 && 2 * x + 2 < w) { const uint8_t* q = s + 2 * x; r[x] = q[-2] + q[2] + 4 * (q[-1] + q[1]) + 6 * q[0]; continue; }      // interior: no border arithmetic
                 int x0 = reflect101(2 * x - 2, w), x1 = reflect101(2 * x - 1, w), x2 = 2 * x < w ? 2 * x : reflect101(2 * x, w);
                 int x3 = reflect101(2 * x + 1, w), x4 = reflect101(2 * x + 2, w);
                 r[x] = s[x0] + s[x4] + 4 * (s[x1] + s[x3]) + 6 * s[x2];
             }
+            return r;
+        };
+        for (int y = ya; y < yb; ++y) {
+            // the five (reflected) source rows of an output row lie within five consecutive row indices, so they never share a ring slot
+            const int* r[5];
+            for (int k = 0; k < 5; ++k) r[k] = hrow(reflect101(2 * y + k - 2, h));
+            for (int x = 0; x < w2; ++x) {
+                int v = r[0][x] + r[4][x] + 4 * (r[1][x] + r[3][x]) + 6 * r[2][x];
+                dst[(size_t)y * w2 + x] = (uint8_t)((v + 128) >> 8);
+            }
         }
-        for (int x = 0; x < w2; ++x) {
-            int v = rows[x] + rows[4 * (size_t)w2 + x] + 4 * (rows[(size_t)w2 + x] + rows[3 * (size_t)w2 + x]) + 6 * rows[2 * (size_t)w2 + x];
-            dst[(size_t)y * w2 + x] = (uint8_t)((v + 128) >> 8);
-        }
-    }
+    });
 }
 
 // calcSharrDeriv: Ix = [3 10 3]^T (vertical smooth) x [-1 0 1]; Iy = [-1 0 1]^T x [3 10 3]; REFLECT_101
 void scharr(const uint8_t* src, int w, int h, int16_t* out) {
+  parallel_rows(h, 64, [&](int ya, int yb) {
     std::vector<int> t0(w + 2), t1(w + 2);
-    for (int y = 0; y < h; ++y) {
+    for (int y = ya; y < yb; ++y) {
         const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * w;
         const uint8_t* r1 = src + (size_t)y * w;
         const uint8_t* r2 = src + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * w;
@@ -89,6 +151,7 @@ void scharr(const uint8_t* src, int w, int h, int16_t* out) {
             out[((size_t)y * w + x) * 2 + 1] = (int16_t)((t1[x + 2] + t1[x]) * 3 + t1[x + 1] * 10);
         }
     }
+  });
 }
 
 constexpr int WIN = 21;     // cv::Size(21,21) at every call site (feature_utils.cpp:44,51)
@@ -241,16 +304,8 @@ void lk(const uint8_t* img_a, const uint8_t* img_b, int w, int h, const P2f* pts
     eps = std::min(std::max(eps, 0.), 10.);
     double eps_sq = eps * eps;
     for (int i = 0; i < n; ++i) status[i] = 1;
-    const int nt = std::min(g_threads, n / 8);          // timing runs only (dvo_set_threads): cv::calcOpticalFlowPyrLK runs parallel_for_ over the points of a level
-    for (int level = ml; level >= 0; --level) {
-        if (nt <= 1) { lk_level(pa[level], pb[level], level, ml, pts_a, pts_b, status, n, iters, eps_sq, use_initial); continue; }
-        std::vector<std::thread> th;
-        for (int k = 0; k < nt; ++k) {
-            const int a = (int)((long long)n * k / nt), b = (int)((long long)n * (k + 1) / nt);
-            th.emplace_back([&, a, b, level] { lk_level(pa[level], pb[level], level, ml, pts_a + a, pts_b + a, status + a, b - a, iters, eps_sq, use_initial); });
-        }
-        for (auto& t : th) t.join();
-    }
+    for (int level = ml; level >= 0; --level)          // cv::calcOpticalFlowPyrLK: parallel_for_ over the points of a level (LKTrackerInvoker)
+        parallel_rows(n, 8, [&](int a, int b) { lk_level(pa[level], pb[level], level, ml, pts_a + a, pts_b + a, status + a, b - a, iters, eps_sq, use_initial); });
 }
 
 inline bool in_border(P2f pt, int rows, int cols) {      // feature_utils.h:68-74
@@ -279,7 +334,8 @@ void min_eigen(const uint8_t* img, int w, int h, float* eig) {
     const double scale_d = 1.0 / ((double)(1 << 2) * 3 * 255.0);
     const float k1 = (float)(1.0 * scale_d), k2 = (float)(2.0 * scale_d);     // smoothing kernel [1 2 1]*scale as CV_32F
     std::vector<float> xx((size_t)w * h), xy((size_t)w * h), yy((size_t)w * h);
-    for (int y = 0; y < h; ++y) {
+    parallel_rows(h, 32, [&](int ya, int yb) {
+    for (int y = ya; y < yb; ++y) {
         const uint8_t* r0 = img + (size_t)reflect101(y - 1, h) * w;
         const uint8_t* r1 = img + (size_t)y * w;
         const uint8_t* r2 = img + (size_t)reflect101(y + 1, h) * w;
@@ -296,6 +352,7 @@ void min_eigen(const uint8_t* img, int w, int h, float* eig) {
             xx[i] = dx * dx; xy[i] = dx * dy; yy[i] = dy * dy;
         }
     }
+    });
     auto box = [&](const std::vector<float>& c, int x, int y) -> float {      // D2
         double rs[3];
         for (int k = 0; k < 3; ++k) {
@@ -304,11 +361,13 @@ void min_eigen(const uint8_t* img, int w, int h, float* eig) {
         }
         return (float)((rs[0] + rs[1]) + rs[2]);
     };
-    for (int y = 0; y < h; ++y)
+    parallel_rows(h, 32, [&](int ya, int yb) {
+    for (int y = ya; y < yb; ++y)
         for (int x = 0; x < w; ++x) {
             float a = box(xx, x, y) * 0.5f, b = box(xy, x, y), c = box(yy, x, y) * 0.5f;
             eig[(size_t)y * w + x] = (float)((a + c) - std::sqrt((a - c) * (a - c) + b * b));
         }
+    });
 }
 
 void gftt(const uint8_t* img, const uint8_t* mask, int w, int h, int max_n, double quality, double min_dist,
@@ -323,14 +382,20 @@ void gftt(const uint8_t* img, const uint8_t* mask, int w, int h, int max_n, doub
     const float thr = (float)(maxVal * quality);
     for (auto& v : eig) v = v > thr ? v : 0.f;           // THRESH_TOZERO
     std::vector<int> cand;
-    for (int y = 1; y < h - 1; ++y)
-        for (int x = 1; x < w - 1; ++x) {
-            float v = eig[(size_t)y * w + x];
-            if (v == 0 || (mask && !mask[(size_t)y * w + x])) continue;
-            float m = v;
-            for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) m = std::max(m, eig[(size_t)(y + dy) * w + x + dx]);
-            if (v == m) cand.push_back(y * w + x);
-        }
+    {
+        std::vector<std::vector<int>> rows((size_t)std::max(h, 1));      // per-row lists, concatenated in raster order: the same list whatever the thread count
+        parallel_rows(std::max(h - 2, 0), 32, [&](int ya, int yb) {
+            for (int y = ya + 1; y < yb + 1; ++y)
+                for (int x = 1; x < w - 1; ++x) {
+                    float v = eig[(size_t)y * w + x];
+                    if (v == 0 || (mask && !mask[(size_t)y * w + x])) continue;
+                    float m = v;
+                    for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) m = std::max(m, eig[(size_t)(y + dy) * w + x + dx]);
+                    if (v == m) rows[y].push_back(y * w + x);
+                }
+        });
+        for (auto& r : rows) cand.insert(cand.end(), r.begin(), r.end());
+    }
     if (cand.empty()) return;
     std::sort(cand.begin(), cand.end(), [&](int a, int b) {      // greaterThanPtr: value desc, then address desc
         return eig[a] > eig[b] ? true : eig[a] < eig[b] ? false : a > b; });

@@ -441,3 +441,61 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class dv_seq_input(C.Structure):
+    _fields_ = [("left", C.c_void_p), ("right", C.c_void_p), ("times", C.c_void_p), ("n_frames", C.c_int32), ("mem", C.c_int32), ("stride", C.c_int32), ("reserved", C.c_int32),
+                ("imu_t", C.c_void_p), ("imu_acc", C.c_void_p), ("imu_gyr", C.c_void_p), ("n_imu", C.c_int32), ("reserved2", C.c_int32)]
+
+
+class Runner:
+    """dv_runner: the per-frame host loop of pipeline.Pipeline in C++ inside the library, for one or many sequences (include/dvins.h).  `pipes` are Pipeline
+    objects (each owns its Context + Estimator and a SyntheticSequence whose frames are resident in HBM); the runner takes over driving them."""
+
+    def __init__(self, pipes, group_size=0, threads=1, first_frame=0):
+        from .frontend import DV_MEM_DEVICE
+        self.lib = pipes[0].ctx.lib
+        self.pipes = list(pipes)
+        n = len(pipes)
+        self._keep = []
+        arr = (dv_seq_input * n)()
+        for i, p in enumerate(pipes):
+            q = p.seq
+            frames = q.frames[first_frame:]
+            L = (C.c_void_p * len(frames))(*[f[0].data_ptr() for f in frames]); R = (C.c_void_p * len(frames))(*[f[1].data_ptr() for f in frames])
+            t = np.ascontiguousarray(q.times[first_frame:], np.float64)
+            it, ia, ig = np.ascontiguousarray(q.imu_t, np.float64), np.ascontiguousarray(q.imu_a, np.float64), np.ascontiguousarray(q.imu_g, np.float64)
+            k0 = getattr(p, "k_imu", 0)                 # samples the Python pipeline has already fed
+            self._keep += [L, R, t, it, ia, ig]
+            a = arr[i]
+            a.left, a.right, a.times = C.cast(L, C.c_void_p), C.cast(R, C.c_void_p), t.ctypes.data
+            a.n_frames, a.mem, a.stride = len(frames), DV_MEM_DEVICE, 0
+            a.imu_t, a.imu_acc, a.imu_gyr, a.n_imu = it.ctypes.data + 8 * k0, ia.ctypes.data + 24 * k0, ig.ctypes.data + 24 * k0, len(it) - k0
+        self._arr = arr
+        ctxs = (C.c_void_p * n)(*[p.ctx.h for p in pipes])
+        self.h = self.lib.dv_runner_create(ctxs, C.cast(arr, C.c_void_p), n, int(group_size), int(threads))
+        if not self.h:
+            raise DvinsError((self.lib.dv_last_error(None) or b"dv_runner_create failed").decode())
+
+    def run(self, rounds):
+        """rounds frames of every sequence -> wall seconds of the call (all streams drained)"""
+        w = C.c_double(0)
+        if self.lib.dv_runner_run(self.h, int(rounds), C.byref(w)) != 0:
+            raise DvinsError(self.lib.dv_runner_error(self.h).decode())
+        return w.value
+
+    def get(self, i, cap=100000):
+        st = dv_est_state(); poses = np.zeros((cap, 8)); n = C.c_int(0); it = C.c_longlong(0); fr = C.c_longlong(0)
+        self.lib.dv_runner_get(self.h, i, C.byref(st), poses.ctypes.data, cap, C.byref(n), C.byref(it), C.byref(fr))
+        return st, poses[: n.value].copy(), it.value, fr.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dv_runner_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,172 @@
+// runner.hip — the per-frame host loop of the reference's threads T2 + T3 (system/main.cpp:178-330 FeatureTrack, :394-404 the estimator thread, the two queues
+// between them) for one or many sequences, in C++ inside the library: dv_runner_*.  Host code only (no kernel here); everything goes through the public entries
+// of include/dvins.h, so a runner is exactly what a caller could write against the ABI.
+//
+// One sequence (Pipeline of dynamic_vins_amd/pipeline.py, the order that overlaps the front end of frame k+1 with the back end of frame k on one host thread):
+//     collect tracking(k) -> feed IMU up to t_k -> dv_est_process_begin(k) [host bookkeeping + enqueue of the window solve]
+//     -> enqueue tracking(k+1) -> feed IMU up to t_k+1 -> dv_est_process_end(k) [wait, outlier rejection, slide]
+// Many sequences on one GPU (config 4 of BASELINE.json, "batched"): the sequences of a GROUP run their begin phases back to back, dv_batch_enqueue launches the
+// iteration slots of all their window solves as one launch per stage, and while that runs the host turns to the next group; the end phases of a group follow when
+// its turn comes again.  `threads` host threads each drive their own groups (the reference runs one process — three threads — per sequence).
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+#include "dv_ctx.h"
+
+namespace {
+struct RSeq {
+    dv_ctx* ctx = nullptr; dv_seq_input in{};
+    int next = 0, k_imu = 0, w = 0, h = 0, stride = 0;
+    bool enqueued = false, pending = false;
+    std::vector<dv_feat> rows; int n_rows = 0;
+    double pending_t = 0;
+    dv_est_state last{};
+    std::vector<double> poses;          // [t, px py pz qx qy qz qw] per solved frame
+    long long iterations = 0, frames = 0;
+    std::string err;
+};
+}
+struct dv_runner {
+    std::vector<RSeq> seqs;
+    struct Group { std::vector<int> members; dv_batch* batch = nullptr; bool pending = false; };
+    std::vector<Group> groups;
+    int threads = 1;
+    std::string err;
+};
+
+namespace {
+int fail(dv_runner* R, RSeq& s, const char* what) {
+    const char* m = dv_last_error(s.ctx);
+    s.err = std::string(what) + ": " + (m ? m : "");
+    R->err = s.err;
+    return -1;
+}
+int seq_enqueue(dv_runner* R, RSeq& s, int k) {
+    if (dv_track_stereo_enqueue(s.ctx, s.in.left[k], s.in.right[k], s.w, s.h, s.stride, s.in.times[k], nullptr, DV_MODE_RAW, s.in.mem)) return fail(R, s, "dv_track_stereo_enqueue");
+    s.enqueued = true;
+    return 0;
+}
+int seq_feed_imu(dv_runner* R, RSeq& s, double t) {
+    while (s.k_imu < s.in.n_imu && s.in.imu_t[s.k_imu] <= t + 0.006) {      // the samples up to the frame (+ the slack the reference's GetIMUInterval tolerates)
+        if (dv_est_input_imu(s.ctx, s.in.imu_t[s.k_imu], s.in.imu_acc + 3 * (size_t)s.k_imu, s.in.imu_gyr + 3 * (size_t)s.k_imu)) return fail(R, s, "dv_est_input_imu");
+        ++s.k_imu;
+    }
+    return 0;
+}
+// first half of a step: everything up to and including the enqueue of frame k's window solve and of frame k+1's tracking
+int seq_begin(dv_runner* R, RSeq& s) {
+    const int k = s.next;
+    if (k >= s.in.n_frames) { s.err = "sequence exhausted"; R->err = s.err; return -1; }
+    if (!s.enqueued && seq_enqueue(R, s, k)) return -1;
+    if (dv_track_stereo_collect(s.ctx, s.rows.data(), &s.n_rows)) return fail(R, s, "dv_track_stereo_collect");
+    s.enqueued = false;
+    const double t = s.in.times[k];
+    if (seq_feed_imu(R, s, t)) return -1;
+    const int rc = dv_est_process_begin(s.ctx, s.rows.data(), s.n_rows, t);
+    if (rc < 0) return fail(R, s, "dv_est_process_begin");
+    if (rc > 0) { s.err = "IMU stream does not cover the frame"; R->err = s.err; return -1; }
+    if (k + 1 < s.in.n_frames) { if (seq_enqueue(R, s, k + 1) || seq_feed_imu(R, s, s.in.times[k + 1])) return -1; }
+    s.pending = true; s.pending_t = t;
+    return 0;
+}
+int seq_end(dv_runner* R, RSeq& s) {
+    if (!s.pending) return 0;
+    if (dv_est_process_end(s.ctx, &s.last)) return fail(R, s, "dv_est_process_end");
+    s.pending = false;
+    if (s.last.nonlinear) {
+        s.poses.push_back(s.pending_t);
+        for (int i = 0; i < 7; ++i) s.poses.push_back(s.last.window[10][i]);      // body.Ps / Rs[kWinSize]: what SaveBodyTrajectory writes (utils/io/output.cpp:199-227)
+    }
+    s.iterations += s.last.iterations; ++s.frames; ++s.next;
+    return 0;
+}
+int group_round(dv_runner* R, dv_runner::Group& g) {
+    if (g.pending) { for (int i : g.members) if (seq_end(R, R->seqs[i])) return -1; g.pending = false; }
+    for (int i : g.members) if (seq_begin(R, R->seqs[i])) return -1;
+    if (g.batch && dv_batch_enqueue(g.batch)) { R->err = std::string("dv_batch_enqueue: ") + (dv_last_error(R->seqs[g.members[0]].ctx) ? dv_last_error(R->seqs[g.members[0]].ctx) : ""); return -1; }
+    g.pending = true;
+    return 0;
+}
+int group_drain(dv_runner* R, dv_runner::Group& g) {
+    if (g.pending) { for (int i : g.members) if (seq_end(R, R->seqs[i])) return -1; g.pending = false; }
+    return 0;
+}
+}
+
+extern "C" {
+
+dv_runner* dv_runner_create(dv_ctx* const* ctxs, const dv_seq_input* seqs, int n_seq, int group_size, int threads) {
+    if (!ctxs || !seqs || n_seq < 1 || n_seq > 4096) { dv_set_error(nullptr, "dv_runner_create: bad arguments"); return nullptr; }
+    auto R = std::make_unique<dv_runner>();
+    R->seqs.resize(n_seq);
+    for (int i = 0; i < n_seq; ++i) {
+        RSeq& s = R->seqs[i];
+        if (!ctxs[i] || !ctxs[i]->est || !seqs[i].left || !seqs[i].right || !seqs[i].times || seqs[i].n_frames < 1) { dv_set_error(nullptr, "dv_runner_create: every sequence needs a ctx with an estimator (dv_est_create) and its frames"); return nullptr; }
+        s.ctx = ctxs[i]; s.in = seqs[i];
+        s.w = ctxs[i]->cfg.width; s.h = ctxs[i]->cfg.height; s.stride = seqs[i].stride > 0 ? seqs[i].stride : s.w;
+        s.rows.resize(DV_MAX_FEATS);
+    }
+    // groups: group_size <= 0 -> no batching (every sequence its own group, window solves on its own stream); else dv_batch groups of that size
+    const int gs = group_size <= 0 ? 1 : group_size;
+    for (int a = 0; a < n_seq; a += gs) {
+        dv_runner::Group g;
+        for (int i = a; i < std::min(n_seq, a + gs); ++i) g.members.push_back(i);
+        if (group_size > 0 && g.members.size() > 1) {
+            std::vector<dv_ctx*> m; for (int i : g.members) m.push_back(R->seqs[i].ctx);
+            g.batch = dv_batch_create(m.data(), (int)m.size());
+            if (!g.batch) { for (auto& gg : R->groups) if (gg.batch) dv_batch_destroy(gg.batch); return nullptr; }
+        }
+        R->groups.push_back(std::move(g));
+    }
+    R->threads = std::max(1, std::min(threads, (int)R->groups.size()));
+    return R.release();
+}
+
+void dv_runner_destroy(dv_runner* R) {
+    if (!R) return;
+    for (auto& g : R->groups) if (g.batch) dv_batch_destroy(g.batch);      // (the contexts stay the caller's)
+    delete R;
+}
+
+// n_rounds frames of EVERY sequence.  wall_seconds (optional): the host wall clock of the call, all streams drained (dv_sync of every ctx inside the region).
+int dv_runner_run(dv_runner* R, int n_rounds, double* wall_seconds) {
+    if (!R) return -1;
+    if (n_rounds < 0) { R->err = "dv_runner_run: negative round count"; return -1; }
+    for (auto& s : R->seqs) if (s.next + n_rounds > s.in.n_frames) { R->err = "dv_runner_run: a sequence has fewer frames left than rounds asked"; return -1; }
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = 0;
+    auto drive = [&](int first, int step) -> int {          // one host thread: its groups, round after round
+        for (int r = 0; r < n_rounds; ++r) for (size_t gi = first; gi < R->groups.size(); gi += step) if (group_round(R, R->groups[gi])) return -1;
+        for (size_t gi = first; gi < R->groups.size(); gi += step) if (group_drain(R, R->groups[gi])) return -1;
+        return 0;
+    };
+    if (R->threads <= 1) rc = drive(0, 1);
+    else {
+        std::vector<std::thread> th; std::vector<int> rcs(R->threads, 0);
+        for (int t = 0; t < R->threads; ++t) th.emplace_back([&, t] { rcs[t] = drive(t, R->threads); });
+        for (auto& t : th) t.join();
+        for (int v : rcs) if (v) rc = -1;
+    }
+    for (auto& s : R->seqs) (void)dv_sync(s.ctx);
+    if (wall_seconds) *wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return rc;
+}
+
+int dv_runner_get(dv_runner* R, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames) {
+    if (!R || seq < 0 || seq >= (int)R->seqs.size()) return -1;
+    const RSeq& s = R->seqs[seq];
+    if (last) *last = s.last;
+    const int n = (int)(s.poses.size() / 8);
+    if (n_poses) *n_poses = n;
+    if (poses8) std::memcpy(poses8, s.poses.data(), sizeof(double) * 8 * (size_t)std::min(n, std::max(cap, 0)));
+    if (iterations) *iterations = s.iterations;
+    if (frames) *frames = s.frames;
+    return 0;
+}
+
+const char* dv_runner_error(dv_runner* R) { return R ? R->err.c_str() : "null runner"; }
+
+} // extern "C"

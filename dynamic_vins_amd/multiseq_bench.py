@@ -28,6 +28,8 @@ def run_multiseq_bench(args, rank, world, local_rank):
     seqs = [SyntheticSequence(w, h, cam, n_frames, rate=20.0, phase=dv_dist.sequence_phase(rank * S + i), device=dev) for i in range(S)]
     pipes = [Pipeline(q, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"]) for q in seqs]
 
+    if getattr(args, "runner", "cpp") == "cpp" and not getattr(args, "sequence_threads", False):
+        return run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev)
     threaded = bool(getattr(args, "sequence_threads", False))
     batch = None; groups = None
     if getattr(args, "batched", False):
@@ -128,5 +130,53 @@ def run_multiseq_bench(args, rank, world, local_rank):
     if groups is not None:
         for _, gb in groups:
             gb.close()
+    for p in pipes:
+        p.ctx.close()
+
+
+def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
+    """the same measurement with the host loop in C++ (dv_runner, csrc/runner.hip): one call per timed block; --batched groups the sequences into dv_batch groups of
+    --group-size (default: two groups), --runner-threads host threads drive the groups"""
+    from bench import git_head
+    from .backend import Runner
+    S, w, h = args.sequences, cfg["w"], cfg["h"]
+    warm_ba = max(args.warmup, 12)
+    gsz = 0
+    if getattr(args, "batched", False):
+        gsz = args.group_size if getattr(args, "group_size", 0) > 0 else (S // 2 if S >= 4 else S)
+    runner = Runner(pipes, group_size=gsz, threads=max(1, getattr(args, "runner_threads", 1)))
+    runner.run(warm_ba)
+    gc.collect(); gc.freeze()
+    times = []
+    for _b in range(2):
+        dv_dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        runner.run(args.steps)
+        torch.cuda.synchronize(); dv_dist.barrier()
+        times.append(time.perf_counter() - t0)
+    red_dev = dev if os.environ.get("BENCH_BACKEND", "nccl") != "gloo" else "cpu"
+    times = [dv_dist.max_over_ranks(t, device=red_dev) for t in times]
+    from . import sim
+    ates, iters = [], 0
+    for i, p in enumerate(pipes):
+        st, poses, it, fr = runner.get(i)
+        gt = [p.seq.traj.p(t) for t in poses[:, 0]]
+        ates.append(sim.align_ate(poses[:, 1:4], gt)[0]); iters += it
+    n_total = S * (warm_ba + 2 * args.steps)
+    if rank == 0:
+        dt = times[0]
+        out = {"metric": "stereo frames/sec (track+BA)", "value": round(world * S * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm_ba,
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{S} independent synthetic {w}x{h} stereo sequences per GPU @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "")
+                                      + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame; a step = one frame of EVERY sequence",
+                          "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S, "host_loop": "C++ (dv_runner)",
+                          "parallelism": f"{S} sequences per GPU, host loop in C++ on {max(1, getattr(args, 'runner_threads', 1))} thread(s)"
+                                         + (f", window solves batched in dv_batch groups of {gsz} (one launch per stage for a group)" if gsz > 1 else ", every sequence on its own streams") + f", x {world} GPU(s); no collective",
+                          "group_size": gsz, "runner_threads": max(1, getattr(args, "runner_threads", 1)),
+                          "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),
+                          "solver_iterations_per_frame": round(iters / max(n_total, 1), 2), "ate_rmse_m_vs_ground_truth_max": round(max(ates), 5)},
+               "roofline": None, "cpu_baseline": None}
+        print(json.dumps(out))
+    runner.close()
     for p in pipes:
         p.ctx.close()

@@ -403,6 +403,28 @@ int dv_est_get_latest(dv_ctx* ctx, double* t, double* P3, double* Q4, double* V3
  *   clamped   of those, how many skipped at least one pivot
  *   last4     c0, smallest pivot of A_mm, clamp flag (!= 0: skipped), rank of A_mm — of the last one that came back */
 int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, double* last4);
+
+/* ---- the per-frame host loop of the reference's threads T2 (FeatureTrack, system/main.cpp:178-330) + T3 (the estimator thread, :394-404) in C++ inside the library:
+ * one call runs n_rounds frames of one or many sequences.  Per sequence the order of pipeline.py: collect tracking(k), IMU up to t_k, dv_est_process_begin(k),
+ * enqueue tracking(k+1), IMU up to t_k+1, dv_est_process_end(k) — the front end of frame k+1 overlaps the back end of frame k.  With group_size > 1 the sequences
+ * are grouped into dv_batch groups of that size: the begin phases of a group run back to back, ONE dv_batch_enqueue launches the iteration slots of all its window
+ * solves, and the host turns to the next group while they run (config 4 of BASELINE.json, "batched").  `threads` host threads each drive their own groups.
+ * The contexts (each with its estimator: dv_est_create) stay the caller's; frames are referenced, not copied (device or host memory: dv_seq_input::mem).
+ * dynamic_vins_amd/host/dvins_node.cpp is the ROS-free node built on it (image directory + IMU csv in, `<seq>_<mode>_Odometry.txt` out). */
+typedef struct dv_seq_input {
+    const uint8_t* const* left; const uint8_t* const* right;      /* [n_frames] gray images of the configured size */
+    const double* times; int32_t n_frames, mem /* DV_MEM_HOST / DV_MEM_DEVICE */, stride /* bytes per row, 0 = width */, reserved;
+    const double* imu_t; const double* imu_acc; const double* imu_gyr; int32_t n_imu, reserved2;      /* [n_imu], [n_imu][3], [n_imu][3]; n_imu 0 for vision-only */
+} dv_seq_input;
+typedef struct dv_runner dv_runner;
+dv_runner* dv_runner_create(dv_ctx* const* ctxs, const dv_seq_input* seqs, int n_seq, int group_size, int threads);      /* group_size <= 1: no batching */
+void dv_runner_destroy(dv_runner* runner);
+int dv_runner_run(dv_runner* runner, int n_rounds, double* wall_seconds_or_null);
+/* per sequence: the last dv_est_state, the trajectory so far as rows [t, px py pz qx qy qz qw] (one per frame solved in the non-linear phase: what SaveBodyTrajectory
+ * writes, utils/io/output.cpp:199-227), the window-solve iterations and frames so far */
+int dv_runner_get(dv_runner* runner, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames);
+const char* dv_runner_error(dv_runner* runner);
+
 /* FeatureManager::point_landmarks for the point-cloud publishers (utils/io/visualization.cpp:214-249): world point = CamToWorld(point * depth, start_frame);
  * in_point_cloud / in_margin_cloud apply PubPointCloud's two selection rules.  key_poses = window[i][0..2] of dv_est_state. */
 typedef struct dv_landmark { int32_t id, start_frame, n_obs, solve_flag; double depth, p_w[3]; int32_t in_point_cloud, in_margin_cloud; } dv_landmark;

@@ -444,7 +444,7 @@ class Batch:
 
 
 class dv_seq_input(C.Structure):
-    _fields_ = [("left", C.c_void_p), ("right", C.c_void_p), ("times", C.c_void_p), ("n_frames", C.c_int32), ("mem", C.c_int32), ("stride", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("left", C.c_void_p), ("right", C.c_void_p), ("times", C.c_void_p), ("n_frames", C.c_int32), ("mem", C.c_int32), ("stride", C.c_int32), ("ba_stride", C.c_int32),
                 ("imu_t", C.c_void_p), ("imu_acc", C.c_void_p), ("imu_gyr", C.c_void_p), ("n_imu", C.c_int32), ("reserved2", C.c_int32)]
 
 
@@ -469,7 +469,7 @@ class Runner:
             self._keep += [L, R, t, it, ia, ig]
             a = arr[i]
             a.left, a.right, a.times = C.cast(L, C.c_void_p), C.cast(R, C.c_void_p), t.ctypes.data
-            a.n_frames, a.mem, a.stride = len(frames), DV_MEM_DEVICE, 0
+            a.n_frames, a.mem, a.stride, a.ba_stride = len(frames), DV_MEM_DEVICE, 0, getattr(p, "ba_stride", 1)
             a.imu_t, a.imu_acc, a.imu_gyr, a.n_imu = it.ctypes.data + 8 * k0, ia.ctypes.data + 24 * k0, ig.ctypes.data + 24 * k0, len(it) - k0
         self._arr = arr
         ctxs = (C.c_void_p * n)(*[p.ctx.h for p in pipes])
@@ -488,6 +488,12 @@ class Runner:
         st = dv_est_state(); poses = np.zeros((cap, 8)); n = C.c_int(0); it = C.c_longlong(0); fr = C.c_longlong(0)
         self.lib.dv_runner_get(self.h, i, C.byref(st), poses.ctypes.data, cap, C.byref(n), C.byref(it), C.byref(fr))
         return st, poses[: n.value].copy(), it.value, fr.value
+
+    def frames(self, i, cap=100000):
+        """every frame handed to the back end: rows [t, px py pz qx qy qz qw, nonlinear]"""
+        rows = np.zeros((cap, 9)); n = C.c_int(0)
+        self.lib.dv_runner_get_frames(self.h, i, rows.ctypes.data, cap, C.byref(n))
+        return rows[: n.value].copy()
 
     def close(self):
         if getattr(self, "h", None):

@@ -37,9 +37,12 @@ __device__ __forceinline__ int be_eval_block_of(int bx, int nlm) {
     for (int y = 0; y < x; ++y) start += nlm > y ? (nlm - y + 7) >> 3 : 0;
     return start + k;                                          // bijection [0, nlm) -> [0, nlm): class x (the blocks one XCD receives), in order, onto a contiguous range
 }
-template <bool FULL>
 #define EV_THREADS 256
-__device__ __forceinline__ void be_eval_body(const BeEvalArgs& a, int mode, int b) {
+// ARGS: BeEvalArgs (kernel arguments by value: invariant scalar loads) or the same struct in the constant address space (batched form: the argument table in
+// HBM read through the scalar / invariant path instead of re-loading every field after each store)
+#define DV_CONSTANT __attribute__((address_space(4)))
+template <bool FULL, class ARGS>
+__device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int b) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
     if (mode == BE_EVAL_X ? !c.need_eval : !c.pending) return;
@@ -248,17 +251,17 @@ __device__ __forceinline__ void be_eval_body(const BeEvalArgs& a, int mode, int 
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm)); }
+__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL, BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm)); }
 // batched form (several independent windows in one launch: blockIdx.y = window, argument table in HBM)
 template <bool FULL>
 __global__ __launch_bounds__(EV_THREADS) void be_eval_batch_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
-    const BeEvalArgs& a = tab[blockIdx.y];
+    const DV_CONSTANT BeEvalArgs& a = *reinterpret_cast<const DV_CONSTANT BeEvalArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));
     if ((int)blockIdx.x >= a.dims.nlm + a.dims.nimu + 1) return;
-    be_eval_body<FULL>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm));
+    be_eval_body<FULL, DV_CONSTANT BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm));      // (grid x is a multiple of 8: the XCD of a block is blockIdx.x % 8 as in the single-window launch)
 }
 void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s) {
-    if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_batch_kernel<true>, dim3(max_grid, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
-    else hipLaunchKernelGGL(be_eval_batch_kernel<false>, dim3(max_grid, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+    if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_batch_kernel<true>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+    else hipLaunchKernelGGL(be_eval_batch_kernel<false>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
 }
 void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s) {
     const int grid = a.dims.nlm + a.dims.nimu + 1;

@@ -40,7 +40,8 @@ extern "C" int dv_debug_red_ts(long long* out) { return hipMemcpyFromSymbol(out,
 // IMU + prior part of Hd(i, j)  (everything that is not a landmark sum).  rc: the frames of every IMU factor and the prior's header
 // fields, staged in LDS by the caller (they were dependent global loads per factor and entry)
 struct RedCtx { const int* ifi; const int* ifj; int prior_valid, prior_n; };
-__device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, int i, int j) {
+template <class ARGS>
+__device__ __forceinline__ double red_dense_h(const ARGS& a, const RedCtx& rc, const double* imu_out, int i, int j) {
     const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i];
     const int kj = a.col_kind[j], fj = a.col_frame[j], cj = a.col_comp[j];
     double H = 0.0;
@@ -58,7 +59,8 @@ __device__ __forceinline__ double red_dense_h(const BeSolveArgs& a, const RedCtx
     return H;
 }
 // the same sums for a POSE column pair: kind / frame / component are known from the block (no column-map loads), the prior indices come from LDS
-__device__ __forceinline__ double red_dense_h_pose(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, int fi, int ci, int fj, int cj, int pi, int pj) {
+template <class ARGS>
+__device__ __forceinline__ double red_dense_h_pose(const ARGS& a, const RedCtx& rc, const double* imu_out, int fi, int ci, int fj, int cj, int pi, int pj) {
     // every load unconditional (a dummy address where the term is absent) and the loop unrolled: the <= 11 values travel in ONE round trip instead of one
     // per contributing factor behind its branch; added in the same order
     double v[BE_WIN]; bool ok[BE_WIN];
@@ -80,7 +82,8 @@ __device__ __forceinline__ double red_dense_h_pose(const BeSolveArgs& a, const R
     if (okp) H += vp;
     return H;
 }
-__device__ __forceinline__ double red_dense_g_pose(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int fi, int ci, int pi) {
+template <class ARGS>
+__device__ __forceinline__ double red_dense_g_pose(const ARGS& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int fi, int ci, int pi) {
     double v[BE_WIN]; bool ok[BE_WIN];
 #pragma unroll
     for (int k = 0; k < BE_WIN; ++k) {
@@ -99,7 +102,8 @@ __device__ __forceinline__ double red_dense_g_pose(const BeSolveArgs& a, const R
     if (okp) G += vp;
     return G;
 }
-__device__ __forceinline__ double red_dense_g(const BeSolveArgs& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int i) {
+template <class ARGS>
+__device__ __forceinline__ double red_dense_g(const ARGS& a, const RedCtx& rc, const double* imu_out, const double* prior_out, int i) {
     const int ki = a.col_kind[i], fi = a.col_frame[i], ci = a.col_comp[i];
     double G = 0.0;
     for (int k = 0; k < a.dims.nimu; ++k) {
@@ -121,7 +125,9 @@ __device__ __forceinline__ double wave_sum(double v) { return wave_sum_f64(v); }
 
 // blocks [0, 121): pose block (fi, fj) of the reduced system — landmark sums read the transposed packets coalesced
 //                  (lane = landmark), wave-tree reduced; blocks [121, ..): every entry that has no landmark term.
-__device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, int bx) {
+#define DV_CONSTANT __attribute__((address_space(4)))
+template <class ARGS>
+__device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
     int set = c.cur; double mu = c.mu;
@@ -284,7 +290,7 @@ __device__ __forceinline__ void be_reduce_body(const BeSolveArgs& a, int spec, i
 
 __global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, int spec) { be_reduce_body(a, spec, blockIdx.x); }
 __global__ __launch_bounds__(RED_THREADS) void be_reduce_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) {      // blockIdx.y = window
-    const BeSolveArgs& a = tab[blockIdx.y];
+    const DV_CONSTANT BeSolveArgs& a = *reinterpret_cast<const DV_CONSTANT BeSolveArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));      // the table through the constant (scalar, invariant) path
     const int n = a.dims.nstate;
     if ((int)blockIdx.x >= RED_PAIRS + (n * n + n + RED_THREADS - 1) / RED_THREADS) return;
     be_reduce_body(a, spec, blockIdx.x);

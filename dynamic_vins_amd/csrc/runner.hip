@@ -24,7 +24,8 @@ struct RSeq {
     std::vector<dv_feat> rows; int n_rows = 0;
     double pending_t = 0;
     dv_est_state last{};
-    std::vector<double> poses;          // [t, px py pz qx qy qz qw] per solved frame
+    std::vector<double> poses;          // [t, px py pz qx qy qz qw] per frame solved in the non-linear phase
+    std::vector<double> frames9;        // [t, px py pz qx qy qz qw, nonlinear] of EVERY frame handed to the back end (what SaveBodyTrajectory writes)
     long long iterations = 0, frames = 0;
     std::string err;
 };
@@ -64,6 +65,12 @@ int seq_begin(dv_runner* R, RSeq& s) {
     if (dv_track_stereo_collect(s.ctx, s.rows.data(), &s.n_rows)) return fail(R, s, "dv_track_stereo_collect");
     s.enqueued = false;
     const double t = s.in.times[k];
+    const int stride = s.in.ba_stride > 1 ? s.in.ba_stride : 1;
+    if (stride > 1 && (k % stride) != stride - 1) {      // tracked only: the reference forwards every 2nd tracked frame to the back end outside KITTI (system/main.cpp:300-307)
+        if (k + 1 < s.in.n_frames && seq_enqueue(R, s, k + 1)) return -1;
+        ++s.next;
+        return 0;
+    }
     if (seq_feed_imu(R, s, t)) return -1;
     const int rc = dv_est_process_begin(s.ctx, s.rows.data(), s.n_rows, t);
     if (rc < 0) return fail(R, s, "dv_est_process_begin");
@@ -76,6 +83,9 @@ int seq_end(dv_runner* R, RSeq& s) {
     if (!s.pending) return 0;
     if (dv_est_process_end(s.ctx, &s.last)) return fail(R, s, "dv_est_process_end");
     s.pending = false;
+    s.frames9.push_back(s.pending_t);
+    for (int i = 0; i < 7; ++i) s.frames9.push_back(s.last.window[10][i]);
+    s.frames9.push_back((double)s.last.nonlinear);
     if (s.last.nonlinear) {
         s.poses.push_back(s.pending_t);
         for (int i = 0; i < 7; ++i) s.poses.push_back(s.last.window[10][i]);      // body.Ps / Rs[kWinSize]: what SaveBodyTrajectory writes (utils/io/output.cpp:199-227)
@@ -164,6 +174,15 @@ int dv_runner_get(dv_runner* R, int seq, dv_est_state* last, double* poses8, int
     if (poses8) std::memcpy(poses8, s.poses.data(), sizeof(double) * 8 * (size_t)std::min(n, std::max(cap, 0)));
     if (iterations) *iterations = s.iterations;
     if (frames) *frames = s.frames;
+    return 0;
+}
+
+int dv_runner_get_frames(dv_runner* R, int seq, double* rows9, int cap, int* n_rows) {
+    if (!R || seq < 0 || seq >= (int)R->seqs.size()) return -1;
+    const RSeq& s = R->seqs[seq];
+    const int n = (int)(s.frames9.size() / 9);
+    if (n_rows) *n_rows = n;
+    if (rows9) std::memcpy(rows9, s.frames9.data(), sizeof(double) * 9 * (size_t)std::min(n, std::max(cap, 0)));
     return 0;
 }
 

@@ -413,7 +413,7 @@ int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, 
  * dynamic_vins_amd/host/dvins_node.cpp is the ROS-free node built on it (image directory + IMU csv in, `<seq>_<mode>_Odometry.txt` out). */
 typedef struct dv_seq_input {
     const uint8_t* const* left; const uint8_t* const* right;      /* [n_frames] gray images of the configured size */
-    const double* times; int32_t n_frames, mem /* DV_MEM_HOST / DV_MEM_DEVICE */, stride /* bytes per row, 0 = width */, reserved;
+    const double* times; int32_t n_frames, mem /* DV_MEM_HOST / DV_MEM_DEVICE */, stride /* bytes per row, 0 = width */, ba_stride /* 2: only every 2nd tracked frame goes to the back end (system/main.cpp:300-307); 0 / 1: every frame */;
     const double* imu_t; const double* imu_acc; const double* imu_gyr; int32_t n_imu, reserved2;      /* [n_imu], [n_imu][3], [n_imu][3]; n_imu 0 for vision-only */
 } dv_seq_input;
 typedef struct dv_runner dv_runner;
@@ -423,6 +423,8 @@ int dv_runner_run(dv_runner* runner, int n_rounds, double* wall_seconds_or_null)
 /* per sequence: the last dv_est_state, the trajectory so far as rows [t, px py pz qx qy qz qw] (one per frame solved in the non-linear phase: what SaveBodyTrajectory
  * writes, utils/io/output.cpp:199-227), the window-solve iterations and frames so far */
 int dv_runner_get(dv_runner* runner, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames);
+/* every frame handed to the back end, initialisation included, as rows [t, px py pz qx qy qz qw, nonlinear]: the lines of `<seq>_<mode>_Odometry.txt` */
+int dv_runner_get_frames(dv_runner* runner, int seq, double* rows9, int cap, int* n_rows);
 const char* dv_runner_error(dv_runner* runner);
 
 /* FeatureManager::point_landmarks for the point-cloud publishers (utils/io/visualization.cpp:214-249): world point = CamToWorld(point * depth, start_frame);

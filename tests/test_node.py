@@ -169,3 +169,43 @@ def test_node_trajectory_file_equals_the_python_pipeline(tmp_path):
     assert len(got) == len(want) == frames // 2
     assert got == want, [i for i, (a, b) in enumerate(zip(got, want)) if a != b][:5]
     assert sum(1 for ln in got if not ln.endswith("0.000000 0.000000 0.000000 0.000000 0.000000 0.000000 1.000000")) >= frames // 2 - 12      # the solved part is not the identity
+
+
+REF_SRC = "/root/reference/dynamic_vins/src"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="the reference sources are not on this machine")
+def test_topic_table_matches_the_reference(tmp_path):
+    """N1's ROS surface as data (host/dvins_topics.hpp): every subscription of SystemCallBack's constructor and every topic the publishers use appear in the table
+    with the reference's names, message types and queue sizes; nothing in the table is absent from the reference."""
+    import re
+    src = '#include <cstdio>\n#include "dvins_topics.hpp"\nint main() { for (auto& t : dynamic_vins::kSubscriptions) std::printf("S %s %d %s %d %s\\n", t.topic_or_config_key, (int)t.from_config, t.msg_type, t.queue, t.callback);' \
+          ' for (auto& t : dynamic_vins::kPublications) std::printf("P %s %s\\n", t.topic, t.msg_type); }\n'
+    open(tmp_path / "t.cpp", "w").write(src)
+    exe = str(tmp_path / "t")
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "dynamic_vins_amd", "host"), str(tmp_path / "t.cpp"), "-o", exe], check=True)
+    rows = [ln.split() for ln in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.splitlines()]
+    subs = {r[1]: r for r in rows if r[0] == "S"}; pubs = {r[1]: r[2] for r in rows if r[0] == "P"}
+    cb = open(os.path.join(REF_SRC, "utils/io/system_call_back.cpp")).read()
+    hdr = open(os.path.join(REF_SRC, "utils/io/system_call_back.h")).read()
+    key_of = {"kImage0Topic": "image0_topic", "kImage1Topic": "image1_topic", "kImage0SegTopic": "image0_segmentation_topic", "kImage1SegTopic": "image1_segmentation_topic", "kImuTopic": "imu_topic"}
+    found = re.findall(r"nh\.subscribe\(\s*(io_para::(\w+)|\"([^\"]+)\")\s*,\s*(\d+)\s*,\s*&SystemCallBack::(\w+)", cb)
+    assert len(found) == len(subs) == 9
+    for _, var, lit, queue, callback in found:
+        name = key_of[var] if var else lit
+        assert name in subs, name
+        _, _, from_cfg, mtype, q, cbk = subs[name]
+        assert int(from_cfg) == int(bool(var)) and int(q) == int(queue) and cbk == callback
+        arg = re.search(r"void\s+%s\(const\s+(\w+)::(\w+)ConstPtr" % callback, hdr)
+        assert arg and mtype == f"{arg.group(1)}/{arg.group(2)}", (callback, mtype)
+    vis = "".join(open(os.path.join(REF_SRC, f)).read() for f in ("utils/io/visualization.cpp", "system/main.cpp", "estimator/estimator.cpp"))
+    ref_pubs = {}
+    for t, name in re.findall(r"PublisherMap::Pub<\s*([\w:]+)\s*>\([^,]+,\s*\"(\w+)\"", vis): ref_pubs[name] = {"Marker": "visualization_msgs/Marker"}.get(t, t.replace("::", "/"))
+    for t, name in re.findall(r"GetPublisher<\s*([\w:]+)\s*>\(\s*\"(\w+)\"", vis): ref_pubs[name] = {"MarkerArray": "visualization_msgs/MarkerArray"}.get(t, t.replace("::", "/"))
+    for name in re.findall(r"PubMarkers\([^,]+,\s*\"(\w+)\"", vis): ref_pubs[name] = "visualization_msgs/MarkerArray"
+    for name in re.findall(r"PubImage\([^,]+,\s*\"(\w+)\"", vis): ref_pubs[name] = "sensor_msgs/Image"
+    pc = re.findall(r"PubPointCloud\(\s*\*?(\w+)\s*,\s*\"(\w+)\"", vis)
+    for var, name in pc: ref_pubs[name] = "sensor_msgs/PointCloud2" if name in ("instance_point_cloud", "stereo_point_cloud") else "sensor_msgs/PointCloud"      # pcl clouds go out as PointCloud2 (publisher_map.cpp)
+    assert set(ref_pubs) == set(pubs), (set(ref_pubs) ^ set(pubs))
+    for name, t in ref_pubs.items():
+        assert pubs[name] == t, (name, pubs[name], t)

@@ -10,6 +10,7 @@
 // The normal equations are formed blockwise (H = J^T J, g = J^T f) instead of materialising J; every
 // quantity the dogleg needs (column norms, J*v products, model cost change) is a function of H and g.
 #pragma once
+extern int g_var_radius;      // dvo_set_variant("radius", .): front_oracle.cpp
 #include <functional>
 #include <memory>
 #include "la.h"
@@ -249,7 +250,7 @@ public:
                 x_cost = evaluate(true);    // == cand_cost; rebuilds H, g at the new point
                 sum.successful++;
                 if (rel < 0.25) radius *= 0.5;
-                if (rel > 0.75) radius = std::max(radius, 3.0 * dogleg_norm);
+                if (rel > 0.75) radius = g_var_radius == 1 ? 3.0 * radius : std::max(radius, 3.0 * dogleg_norm);      // (variant 1: sensitivity reading, dvo.h)
                 mu = std::max(min_mu, 2.0 * mu / mu_inc);
                 reuse = false;
                 sum.cost_trace.push_back(x_cost);

@@ -22,6 +22,14 @@ extern "C" {
 /* CPU-baseline timing only: threads for the per-point LK loop (OpenCV: parallel_for_) and, if > 1, the reference's 4-thread build of the marginalization
  * system (marginalization_factor.h:26).  Tracking results do not depend on it; the marginalization sum order does (last bits). Default 1. */
 void dvo_set_threads(int n);
+/* SENSITIVITY variants of the restatement (tests/test_oracle_variants.py): the third-party arithmetic this oracle restates from memory ("unverified")
+ * is platform dependent or uncertain in a few places; the canonical choices are D1, D2 and A.3's radius rule.  A variant swaps ONE of them for the other
+ * plausible reading so that a test can BOUND what the choice is worth (features selected, trajectory) instead of asserting it.  Default 0 everywhere = canonical.
+ *   "lk_sums":   0 exact int64 window sums (D1) | 1 float accumulation in OpenCV's scalar (raster) order | 2 four float partial sums by x mod 4, combined (a 4-wide SIMD order)
+ *   "box_sums":  0 3x3 covariance box sums in double, fixed order (D2) | 1 in float
+ *   "radius":    0 Ceres' dogleg radius rule (quality < 0.25: x 0.5; > 0.75: max(radius, 3 |step|)) | 1 the Levenberg-style reading (> 0.75: radius x 3) */
+void dvo_set_variant(const char* key, int value);
+int dvo_get_variant(const char* key);
 int dvo_get_threads(void);
 
 /* ---------------- front end ---------------- */

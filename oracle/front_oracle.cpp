@@ -32,6 +32,7 @@
 #include <map>
 #include <vector>
 
+#include <string>
 #include <thread>
 #include <condition_variable>
 #include <functional>
@@ -39,6 +40,16 @@
 static int g_threads = 1;      // dvo_set_threads: CPU-baseline timing only; results do not depend on it (rows / points are independent, lists are concatenated in order)
 extern "C" void dvo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 extern "C" int dvo_get_threads() { return g_threads; }
+// sensitivity variants (dvo.h): process-wide switches, read by the stages they belong to
+int g_var_lk_sums = 0, g_var_box_sums = 0, g_var_radius = 0;
+extern "C" void dvo_set_variant(const char* key, int value) {
+    const std::string k = key ? key : "";
+    if (k == "lk_sums") g_var_lk_sums = value; else if (k == "box_sums") g_var_box_sums = value; else if (k == "radius") g_var_radius = value;
+}
+extern "C" int dvo_get_variant(const char* key) {
+    const std::string k = key ? key : "";
+    return k == "lk_sums" ? g_var_lk_sums : k == "box_sums" ? g_var_box_sums : k == "radius" ? g_var_radius : -1;
+}
 // A persistent worker pool standing in for OpenCV's parallel_for_ back end (the reference links OpenCV 3.4 built with a thread pool: calcOpticalFlowPyrLK runs
 // its LKTrackerInvoker over ranges of points, pyrDown / the corner response over ranges of rows).  Spawning std::threads per level — the round-2 form — cost
 // more than the work it split (16 threads = 0 % gain).  parallel_rows(n, grain, f) calls f(a, b) on disjoint ranges covering [0, n).
@@ -229,6 +240,8 @@ void lk_level(const Level& I, const Level& J, int level, int max_level, const P2
         int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         const int st = I.stride();
         int64_t sA11 = 0, sA12 = 0, sA22 = 0;      // D1: exact integer sums
+        const int sum_mode = g_var_lk_sums;
+        float fA11[4] = { 0, 0, 0, 0 }, fA12[4] = { 0, 0, 0, 0 }, fA22[4] = { 0, 0, 0, 0 };      // variants 1 / 2: float accumulation (lane 0 only, or x mod 4)
         for (int y = 0; y < WIN; ++y) {
             const uint8_t* src = I.I(ipx, ipy + y);
             const int16_t* ds = I.D(ipx, ipy + y);
@@ -240,9 +253,13 @@ void lk_level(const Level& I, const Level& J, int level, int max_level, const P2
                 dIw[(y * WIN + x) * 2] = (int16_t)ixval;
                 dIw[(y * WIN + x) * 2 + 1] = (int16_t)iyval;
                 sA11 += (int64_t)ixval * ixval; sA12 += (int64_t)ixval * iyval; sA22 += (int64_t)iyval * iyval;
+                if (sum_mode) { const int l = sum_mode == 2 ? (x & 3) : 0; fA11[l] += (float)(ixval * ixval); fA12[l] += (float)(ixval * iyval); fA22[l] += (float)(iyval * iyval); }
             }
         }
         float A11 = (float)sA11 * FLT_SCALE, A12 = (float)sA12 * FLT_SCALE, A22 = (float)sA22 * FLT_SCALE;
+        if (sum_mode) {
+            A11 = ((fA11[0] + fA11[1]) + (fA11[2] + fA11[3])) * FLT_SCALE; A12 = ((fA12[0] + fA12[1]) + (fA12[2] + fA12[3])) * FLT_SCALE; A22 = ((fA22[0] + fA22[1]) + (fA22[2] + fA22[3])) * FLT_SCALE;
+        }
         float D = A11 * A22 - A12 * A12;
         float minEig = (A22 + A11 - std::sqrt((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (2 * WIN * WIN);
         if (minEig < 1e-4f || D < FLT_EPSILON) {          // minEigThreshold = 1e-4 (default)
@@ -265,15 +282,18 @@ void lk_level(const Level& I, const Level& J, int level, int max_level, const P2
             iw10 = cv_round((1.f - a) * b * (1 << W_BITS));
             iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
             int64_t sb1 = 0, sb2 = 0;
+            float fb1[4] = { 0, 0, 0, 0 }, fb2[4] = { 0, 0, 0, 0 };
             for (int y = 0; y < WIN; ++y) {
                 const uint8_t* Jp = J.I(inx, iny + y);
                 for (int x = 0; x < WIN; ++x) {
                     int diff = descale(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stJ] * iw10 + Jp[x + stJ + 1] * iw11, W_BITS - 5) - Iw[y * WIN + x];
                     sb1 += (int64_t)diff * dIw[(y * WIN + x) * 2];
                     sb2 += (int64_t)diff * dIw[(y * WIN + x) * 2 + 1];
+                    if (sum_mode) { const int l = sum_mode == 2 ? (x & 3) : 0; fb1[l] += (float)(diff * dIw[(y * WIN + x) * 2]); fb2[l] += (float)(diff * dIw[(y * WIN + x) * 2 + 1]); }
                 }
             }
             float b1 = (float)sb1 * FLT_SCALE, b2 = (float)sb2 * FLT_SCALE;
+            if (sum_mode) { b1 = ((fb1[0] + fb1[1]) + (fb1[2] + fb1[3])) * FLT_SCALE; b2 = ((fb2[0] + fb2[1]) + (fb2[2] + fb2[3])) * FLT_SCALE; }
             P2f delta = { (float)((A12 * b2 - A22 * b1) * D), (float)((A12 * b1 - A11 * b2) * D) };
             nextPt.x += delta.x; nextPt.y += delta.y;
             next_pts[p] = { nextPt.x + half, nextPt.y + half };
@@ -353,7 +373,13 @@ void min_eigen(const uint8_t* img, int w, int h, float* eig) {
         }
     }
     });
+    const bool box_f32 = g_var_box_sums == 1;
     auto box = [&](const std::vector<float>& c, int x, int y) -> float {      // D2
+        if (box_f32) {
+            float fs[3];
+            for (int k = 0; k < 3; ++k) { const float* r = c.data() + (size_t)reflect101(y + k - 1, h) * w; fs[k] = (r[reflect101(x - 1, w)] + r[x]) + r[reflect101(x + 1, w)]; }
+            return (fs[0] + fs[1]) + fs[2];
+        }
         double rs[3];
         for (int k = 0; k < 3; ++k) {
             const float* r = c.data() + (size_t)reflect101(y + k - 1, h) * w;

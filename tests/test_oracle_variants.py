@@ -1,0 +1,90 @@
+"""Bounding the UNPINNED choices of the oracle (DESIGN.md choice table).  The reference's LK / Shi-Tomasi / dogleg arithmetic lives in OpenCV 3.4 /
+Ceres 1.14, which are not in this image: the oracle restates them from their published algorithms and fixes, where the libraries are platform dependent or the
+recollection uncertain, ONE reading (D1: exact integer LK window sums; D2: double box sums; A.3's radius rule).  These tests run the whole oracle — tracker and
+estimator, images to trajectory — under the OTHER plausible reading of each choice and measure what the choice is worth: the features that reach the back end and
+the 30-frame trajectory.  Bar: ATE against the canonical run < 1e-3 m (north_star's trajectory bar), i.e. a wrong guess among these readings cannot be what
+decides parity with the real reference.  CPU only; parity stays "partial" (nothing here pins the oracle to OpenCV itself)."""
+import numpy as np
+import pytest
+
+from dynamic_vins_amd import sim
+
+W, H, FRAMES = 640, 360, 32
+
+
+@pytest.fixture(scope="module")
+def sequence():
+    from dynamic_vins_amd.pipeline import SyntheticSequence
+    cam = sim.scaled_cam(sim.ZED, W, H, 1280, 720)
+    seq = SyntheticSequence(W, H, cam, FRAMES, rate=20.0, device="cpu")
+    return cam, seq, [seq.host_frame(k) for k in range(FRAMES)]
+
+
+def run(oracle, sequence, **variants):
+    cam, seq, frames = sequence
+    for k, v in variants.items():
+        oracle.lib.dvo_set_variant(k.encode(), int(v))
+    try:
+        camt = sim.cam_tuple(cam)
+        trk = oracle.tracker(W, H, 150, 20, 1, 1, camt, camt)
+        est = oracle.estimator(use_imu=1, stereo=1, max_iters=8, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], **seq.noise)
+        k_imu, poses, rows_all = 0, [], []
+        for k in range(FRAMES):
+            t = seq.times[k]
+            while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
+                est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
+            rows = trk.track_image(frames[k][0], frames[k][1], t)
+            rc, st = est.process(rows, t)
+            assert rc == 0
+            rows_all.append(rows.copy())
+            if st.nonlinear:
+                poses.append(est.window()[10, :3].copy())
+        return rows_all, np.array(poses)
+    finally:
+        for k in variants:
+            oracle.lib.dvo_set_variant(k.encode(), 0)
+
+
+@pytest.fixture(scope="module")
+def canonical(oracle, sequence):
+    return run(oracle, sequence)
+
+
+def compare(canon, other):
+    """-> (fraction of the variant's features that sit within 0.05 px of a canonical feature of the same frame, ATE of the variant's trajectory against the canonical
+    one).  Matched by POSITION: ids are handed out in detection order, so after the first corner that differs the same id names different corners."""
+    rows_c, poses_c = canon
+    rows_o, poses_o = other
+    hit, total = 0, 0
+    for a, b in zip(rows_c, rows_o):
+        pa, pb = a["left"][:, 3:5], b["left"][:, 3:5]
+        if len(pa) and len(pb):
+            d = np.abs(pb[:, None, :] - pa[None, :, :]).max(2).min(1)
+            hit += int((d < 0.05).sum())
+        total += len(pb)
+    assert len(poses_c) == len(poses_o) >= FRAMES - 12
+    return hit / max(total, 1), sim.align_ate(poses_o, poses_c)[0]
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_lk_window_sums_in_float_order_D1(oracle, sequence, canonical, mode):
+    """D1: OpenCV adds the (integer-valued) window products in float, in an ISA-dependent order; the oracle and the HIP kernels add them exactly.  Scalar order and a
+    4-wide order: the tracked positions move by < 0.01 px, (almost) the same features reach the back end, the trajectory moves by far less than 1 mm."""
+    same, ate = compare(canonical, run(oracle, sequence, lk_sums=mode))
+    assert same > 0.97, same
+    assert ate < 1e-3, ate
+
+
+def test_box_sums_in_float_D2(oracle, sequence, canonical):
+    """D2: the 3x3 sums of the covariance image in float instead of double: a corner's min-eigenvalue moves in its last bits; selection order flips only between
+    corners of (nearly) equal strength."""
+    same, ate = compare(canonical, run(oracle, sequence, box_sums=1))
+    assert same > 0.90, same
+    assert ate < 1e-3, ate
+
+
+def test_dogleg_radius_rule_A3(oracle, sequence, canonical):
+    """A.3: the other reading of the trust-region growth rule (radius x 3 instead of max(radius, 3 |step|)): with the initial radius of 1e4 the Gauss-Newton step lies
+    inside the region on nearly every iteration of a tracking window, so the rule rarely acts; the trajectory agrees to far less than 1 mm."""
+    same, ate = compare(canonical, run(oracle, sequence, radius=1))
+    assert same > 0.99 and ate < 1e-3, (same, ate)

@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--shard", action="store_true", help="BA-only: one window sharded by landmark over the ranks (reduced-system all-reduce)")
     ap.add_argument("--sequences", type=int, default=1, help="S independent sequences per GPU interleaved by one host thread (aggregate rate; the default single-sequence line stays the headline)")
     ap.add_argument("--batched", action="store_true", help="with --sequences: the window solves of all sequences share every launch (dv_batch), one host thread")
+    ap.add_argument("--host-loop", choices=["cpp", "python"], default="cpp", help="raw mode: the per-frame host loop of the timed region in C++ inside the library (dv_runner) or in Python (pipeline.py); dynamic mode and the instrumented pass use the Python loop")
     ap.add_argument("--runner", choices=["cpp", "python"], default="cpp", help="with --sequences: the host loop in C++ inside the library (dv_runner) or the round-2 Python loop")
     ap.add_argument("--group-size", type=int, default=0, help="with --sequences --batched --runner cpp: sequences per dv_batch group (default: two groups)")
     ap.add_argument("--runner-threads", type=int, default=1, help="with --sequences --runner cpp: host threads driving the groups")
@@ -214,7 +215,37 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
 
     frame_ms = []
 
+    def run_cpp(collective, blocks):
+        """the timed region on the library's C++ host loop (dv_runner): no interpreter inside it — one call per block"""
+        from dynamic_vins_amd.backend import Runner
+        pipe = make_pipe()
+        for key in filter(None, args.debug_set.split(",")):
+            assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
+        runner = Runner([pipe])
+        runner.run(warm_ba * stride)
+        it0 = runner.get(0)[2]                               # window-solve iterations spent in the warm-up
+        gc.collect(); gc.freeze()
+        times = []
+        for _b in range(blocks):
+            if collective:
+                dv_dist.barrier()
+            torch.cuda.synchronize(); pipe.ctx.sync()
+            t0 = time.perf_counter()
+            runner.run(args.steps * stride)
+            pipe.ctx.sync(); torch.cuda.synchronize()
+            if collective:
+                dv_dist.barrier()
+            times.append(time.perf_counter() - t0)
+            frame_ms.append({"p50": None, "p95": None, "max": None, "t_since_start_s": round(t0 - T_PROCESS_START, 2), "note": "C++ host loop: one call per block, no per-step host clock"})
+        st, poses, iters_all, _fr = runner.get(0)
+        pipe.poses, pipe.pose_times = [q for q in poses[:, 1:8]], [float(t) for t in poses[:, 0]]
+        pipe.est.state, pipe.rows = st, np.zeros(runner.last_rows)
+        runner.close()
+        return pipe, times, iters_all - it0
+
     def run(kernel_timing, collective=True, blocks=2):       # collective=False: rank-0-only pass, no barriers
+        if args.host_loop == "cpp" and not kernel_timing and args.mode == "raw" and not args.host_frames:
+            return run_cpp(collective, blocks)
         pipe = make_pipe()
         for key in filter(None, args.debug_set.split(",")):
             assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
@@ -396,6 +427,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 "block_values": [round(dv_dist.whole_job_rate(args.steps, world, t), 2) for t in times],
                 "block_step_ms": frame_ms[: len(times)],
                 "warmup_requested": args.warmup, "git_head": git_head(),
+                "host_loop": ("C++ (dv_runner)" if (args.host_loop == "cpp" and args.mode == "raw" and not args.host_frames) else "Python (pipeline.py)"),
                 "warmup_note": "at least 12 untimed BA frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"}
         if dyn_info:
             conf["dynamic"] = dyn_info

@@ -110,7 +110,7 @@ SIGNATURES = {
     "dv_runner_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dv_runner_destroy": (None, [C.c_void_p]),
     "dv_runner_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
-    "dv_runner_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
+    "dv_runner_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "dv_runner_get_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_runner_error": (C.c_char_p, [C.c_void_p]),
     "dv_est_get_marg_health": (C.c_int, [_ctx, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_void_p]),

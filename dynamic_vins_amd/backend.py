@@ -485,8 +485,9 @@ class Runner:
         return w.value
 
     def get(self, i, cap=100000):
-        st = dv_est_state(); poses = np.zeros((cap, 8)); n = C.c_int(0); it = C.c_longlong(0); fr = C.c_longlong(0)
-        self.lib.dv_runner_get(self.h, i, C.byref(st), poses.ctypes.data, cap, C.byref(n), C.byref(it), C.byref(fr))
+        st = dv_est_state(); poses = np.zeros((cap, 8)); n = C.c_int(0); it = C.c_longlong(0); fr = C.c_longlong(0); nr = C.c_int(0)
+        self.lib.dv_runner_get(self.h, i, C.byref(st), poses.ctypes.data, cap, C.byref(n), C.byref(it), C.byref(fr), C.byref(nr))
+        self.last_rows = nr.value
         return st, poses[: n.value].copy(), it.value, fr.value
 
     def frames(self, i, cap=100000):

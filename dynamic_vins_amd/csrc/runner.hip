@@ -165,7 +165,7 @@ int dv_runner_run(dv_runner* R, int n_rounds, double* wall_seconds) {
     return rc;
 }
 
-int dv_runner_get(dv_runner* R, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames) {
+int dv_runner_get(dv_runner* R, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames, int* n_rows_last) {
     if (!R || seq < 0 || seq >= (int)R->seqs.size()) return -1;
     const RSeq& s = R->seqs[seq];
     if (last) *last = s.last;
@@ -174,6 +174,7 @@ int dv_runner_get(dv_runner* R, int seq, dv_est_state* last, double* poses8, int
     if (poses8) std::memcpy(poses8, s.poses.data(), sizeof(double) * 8 * (size_t)std::min(n, std::max(cap, 0)));
     if (iterations) *iterations = s.iterations;
     if (frames) *frames = s.frames;
+    if (n_rows_last) *n_rows_last = s.n_rows;
     return 0;
 }
 

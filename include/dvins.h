@@ -421,8 +421,8 @@ dv_runner* dv_runner_create(dv_ctx* const* ctxs, const dv_seq_input* seqs, int n
 void dv_runner_destroy(dv_runner* runner);
 int dv_runner_run(dv_runner* runner, int n_rounds, double* wall_seconds_or_null);
 /* per sequence: the last dv_est_state, the trajectory so far as rows [t, px py pz qx qy qz qw] (one per frame solved in the non-linear phase: what SaveBodyTrajectory
- * writes, utils/io/output.cpp:199-227), the window-solve iterations and frames so far */
-int dv_runner_get(dv_runner* runner, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames);
+ * writes, utils/io/output.cpp:199-227), the window-solve iterations and frames so far, the number of feature rows of the last tracked frame */
+int dv_runner_get(dv_runner* runner, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames, int* n_rows_last);
 /* every frame handed to the back end, initialisation included, as rows [t, px py pz qx qy qz qw, nonlinear]: the lines of `<seq>_<mode>_Odometry.txt` */
 int dv_runner_get_frames(dv_runner* runner, int seq, double* rows9, int cap, int* n_rows);
 const char* dv_runner_error(dv_runner* runner);

@@ -1,5 +1,6 @@
 // be_kernels.h — argument blocks and launchers of the back-end kernels (product code, not part of the ABI).
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include "be_factor_dev.h"
 
@@ -181,6 +182,7 @@ int  be_launch_marg(const BeMargArgs& a, hipStream_t s);
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
 void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s);      // be_accept + be_gauge in one launch (estimator path)
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s);      // spec: reduce the candidate's set (or, after a failed / invalid step, rebuild x's with the new mu)
+static_assert(offsetof(BeSolveArgs, ldl_col0) % 4 == 0, "the MF16 plan is read as dwords");
 bool be_mf16_plan(int n, uint8_t* plan);      // ldl_wcol == 2: the 16-wide MFMA factorisation; its tile plan lives in the first 64 bytes of ldl_col0
 int  be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s);        // spec: decide on the pending candidate first (be_accept_kernel's rule)
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);

@@ -930,28 +930,46 @@ __device__ __forceinline__ double mf_raw(const double* __restrict__ Sc, int n, i
     return Sc[in ? (size_t)(bj * NBR - bj * (bj - 1) / 2 + bi - bj) * 16 + (i & 3) * 4 + (j & 3) : 0];      // (the value is ignored for i >= n)
 }
 __device__ __forceinline__ double mf_finish(double raw, const double* v_s, const double* v_d, const double* rhs, int n, double mu, int i, int j) {
-    if (i < j) { const int t = i; i = j; j = t; }
-    if (i > n) return i == j ? 1.0 : 0.0;
-    if (i == n) return j == n ? MF_RHO : v_s[j] * rhs[j];
-    const double v = v_s[i] * v_s[j] * raw;
-    return i == j ? v + mu * v_d[i] * v_d[i] : v;
+    // by selection, not by branch (the lanes of a diagonal or last-row tile fall into all the cases at once)
+    const int hi = i > j ? i : j, lo = i > j ? j : i, hc = hi < n ? hi : n - 1, lc = lo < n ? lo : n - 1;
+    const double s_hi = v_s[hc], s_lo = v_s[lc], d_hi = v_d[hc];
+    const double body = s_hi * s_lo * raw + (i == j ? mu * d_hi * d_hi : 0.0);
+    const double row_n = lo == n ? MF_RHO : s_lo * rhs[lc];
+    return hi < n ? body : (hi == n ? row_n : (hi == lo ? 1.0 : 0.0));
 }
 __device__ __forceinline__ void mf_slots(const uint8_t* plan, int wave, int NB, int (&sI)[5], int (&sJ)[5]) {
     sI[0] = sJ[0] = wave < NB ? wave : -1;
+    // the wave's four plan bytes as ONE dword through the scalar path (the plan sits in the kernel arguments / the constant-space table, `wave` is an SGPR); byte
+    // loads have no scalar form on gfx950 and came back as four dependent vector loads in front of everything that needs the slots (~2 us per use)
+    const uint32_t w4 = reinterpret_cast<const uint32_t*>(plan)[wave];
 #pragma unroll
-    for (int s = 1; s < 5; ++s) { const int b = plan[wave * 4 + s - 1]; sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
+    for (int s = 1; s < 5; ++s) { const int b = (int)((w4 >> (8 * (s - 1))) & 0xFFu); sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
 }
 __device__ __forceinline__ void mf_prefetch(const double* __restrict__ Sc, const uint8_t* plan, int n, mf_d4 (&U)[5]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, rho = lane >> 4;
     int sI[5], sJ[5];
     mf_slots(plan, wave, (n + 16) >> 4, sI, sJ);
+    const int NBR = (n + 3) >> 2;
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
+        if (sI[s] > sJ[s]) {
+            // a tile below the diagonal: i > j for every entry, so the 4x4 block of entry (i, j = 16 J + rho + 4 r) is (bi, bj) = (i >> 2, 4 J + r) and its address is
+            // a wave-uniform block-column base (scalar arithmetic) plus one lane offset: two integer operations per load instead of the general index arithmetic
+            // (transposition test, two divisions by the block size) that cost ~2 us of issue for the 20 loads of a wave.  Rows behind the system (last block row) are clamped.
+            const int i = min(16 * sI[s] + c, n - 1);
+            const int lane_off = ((i >> 2) << 4) + ((i & 3) << 2) + rho;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? mf_raw(Sc, n, 16 * sI[s] + c, 16 * sJ[s] + rho + 4 * r) : 0.0;
+            for (int r = 0; r < 4; ++r) {
+                const int bj = 4 * sJ[s] + r;
+                const int bjc = bj < NBR ? bj : 0;                        // (a column behind the system is never used)
+                U[s][r] = Sc[(size_t)((bjc * NBR - bjc * (bjc - 1) / 2 - bjc) << 4) + lane_off];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? mf_raw(Sc, n, 16 * sI[s] + c, 16 * sJ[s] + rho + 4 * r) : 0.0;
+        }
     }
 }
-// plan: bytes [16][4] of (I << 4 | J) for the off-diagonal slots 1..4 of every wave (0xFF = empty); slot 0 of wave w < NB is the diagonal tile (w, w)
 // side(excl): work of the caller that does not feed the factorisation (cost at x, gradient tolerance, landmark diagonal, L2 warm-up), run by every wave but
 // `excl` while that wave factors a diagonal tile — they would wait at the barrier otherwise; side0(): the excluded wave's share, one step later.
 // Schedule per block column k (two workgroup barriers A, B per 16 pivots):
@@ -965,11 +983,25 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
     const int NB = (n + 16) >> 4, IB = n >> 4, c0 = n & 15;
     int sI[MF_SLOTS], sJ[MF_SLOTS];
     mf_slots(plan, wave, NB, sI, sJ);
+    TS(21);
 #pragma unroll
     for (int s = 0; s < MF_SLOTS; ++s) {
+        if (sI[s] > sJ[s]) {          // a tile below the diagonal (column block J < IB: every column belongs to the system): s_i s_j a_ij; in the last block row the
+            const int i = 16 * sI[s] + c;      // right-hand-side row n reads s_j rhs_j and the padding rows behind it are zero — by selection, not by branch
+            const double si = v_s[min(i, n - 1)];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? mf_finish(U[s][r], v_s, v_d, rhs, n, mu, 16 * sI[s] + c, 16 * sJ[s] + rho + 4 * r) : 0.0;
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * sJ[s] + rho + 4 * r;
+                const double sj = v_s[j];
+                const double body = si * sj * U[s][r];
+                U[s][r] = i < n ? body : (i == n ? sj * rhs[j] : 0.0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? mf_finish(U[s][r], v_s, v_d, rhs, n, mu, 16 * sI[s] + c, 16 * sJ[s] + rho + 4 * r) : 0.0;
+        }
     }
+    TS(22);
     for (int i = tid; i < 16 * NB; i += SOL_THREADS) m.yv[i] = 0.0;
     if (tid == 0) *s_fail = 0;
 #ifdef BE_SOLVE_TS

@@ -9,7 +9,7 @@ seq = SyntheticSequence(1280, 720, sim.ZED, N + 2, rate=20.0, device="cuda:0")
 pipe = Pipeline(seq)
 lib = _abi.load()
 lib.dv_debug_solve_ts.argtypes = [C.POINTER(C.c_longlong)]
-seqp = [(15, 0, "accept decision (prologue)"), (0, 3, "scale + gradient"), (3, 4, "ldlt load"), (4, 5, "ldlt loop"), (5, 6, "ldlt store(+cost/tol)"), (6, 7, "back-sub"),
+seqp = [(15, 0, "accept decision (prologue)"), (0, 3, "scale + gradient"), (3, 4, "ldlt load"), (3, 21, "  mf16: to slots"), (21, 22, "  mf16: tile finish"), (22, 4, "  mf16: barrier"), (4, 5, "ldlt loop"), (5, 6, "ldlt store(+cost/tol)"), (6, 7, "back-sub"),
         (7, 8, "gn landmarks"), (8, 9, "dogleg (+lazy Cauchy)"), (9, 11, "gemv H*delta"), (11, 12, "w . delta"), (12, 13, "candidate"), (13, 10, "final sums"), (15, 10, "total"), (9, 25, "w15: to candidate start"), (25, 26, "w15: pose"), (26, 27, "w15: sb"), (27, 28, "w15: ex"), (28, 29, "w15: rest"), (13, 29, "tid0 ready -> w15 ready"), (29, 10, "w15 ready -> end")]
 rows = []
 extra = []

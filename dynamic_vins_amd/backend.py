@@ -490,6 +490,12 @@ class Runner:
         self.last_rows = nr.value
         return st, poses[: n.value].copy(), it.value, fr.value
 
+    def batch_timing(self, on=1):
+        """-> (avg ms per launch of [be_solve_batch, be_eval_batch, be_reduce_batch], rounds timed, windows per launch)"""
+        o = np.zeros(3); r = C.c_longlong(0); w = C.c_int(0)
+        self.lib.dv_runner_batch_timing(self.h, int(on), o.ctypes.data, C.byref(r), C.byref(w))
+        return o, r.value, w.value
+
     def frames(self, i, cap=100000):
         """every frame handed to the back end: rows [t, px py pz qx qy qz qw, nonlinear]"""
         rows = np.zeros((cap, 9)); n = C.c_int(0)

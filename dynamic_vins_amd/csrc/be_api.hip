@@ -163,10 +163,14 @@ static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, doubl
     ma.lm_sel = w.marg_tab + BE_MT_SEL;
     ma.D = pl.D; ma.m = pl.m; ma.g_norm = g_norm; ma.outA = outA; ma.outb = outb; ma.out_scalars = scal; ma.c0_out = c0_out;
     const size_t slab = (size_t)pl.D * pl.D + pl.D;
-    // sized once for 256 landmarks anchored in the oldest frame at the largest system (D = 178): growing it later would stall the stream
-    const size_t need = 8 * (slab * (size_t)std::max(pl.nsel, 1) + 8 * slab + (size_t)std::max(pl.nsel, 1) + 512);      // slabs | 8 chunk sums | h | whitened IMU factor
-    DV_CHECK(w.marg_buf.ensure(std::max(need, (size_t)8 * (((size_t)178 * 178 + 178) * 264 + 256))));
-    ma.slabs = (double*)w.marg_buf.p; ma.sum = ma.slabs + slab * (size_t)std::max(pl.nsel, 1); ma.lm_h = ma.sum + 8 * slab; ma.imu_w = ma.lm_h + std::max(pl.nsel, 1);
+    // sized once for BE_MAX_LM landmarks anchored in the oldest frame at the largest system (D = 178): growing it later would stall the stream
+    const size_t nl = (size_t)std::max(pl.nsel, 1), nlmax = std::max(nl, (size_t)BE_MAX_LM), Dmax = (size_t)std::max(pl.D, 178);
+    const size_t need = 8 * (nlmax * (size_t)be_marg_wstride((int)Dmax) + ((size_t)be_marg_chunks((int)nlmax) + 1) * be_marg_part() + Dmax * Dmax + Dmax + nlmax + 512);      // W | part | psum | sum | h | whitened IMU factor
+    DV_CHECK(w.marg_buf.ensure(need));
+    ma.W = (double*)w.marg_buf.p; ma.part = ma.W + nl * be_marg_wstride(pl.D); ma.psum = ma.part + (size_t)be_marg_chunks((int)nl) * be_marg_part(); ma.sum = ma.psum + be_marg_part();
+    ma.lm_h = ma.sum + slab; ma.imu_w = ma.lm_h + nl; ma.anchor = 0;
+    for (int k = 0; k < BE_NF; ++k) ma.pose_dim[k] = pl.pose_dim[k];
+    ma.ex_dim[0] = pl.ex_dim[0]; ma.ex_dim[1] = pl.ex_dim[1]; ma.td_dim = pl.td_dim;
     StageScope sc(ctx, "k_be_marg", s);
     const int rc = be_launch_marg(ma, s);
     if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");
@@ -531,6 +535,10 @@ struct dv_batch {
     long long batched_rounds = 0, single_rounds = 0;
     std::mutex mu; std::condition_variable cv; int arrived = 0; long long generation = 0; int last_rc = 0;      // dv_batch_arrive
     bool aborted = false;                         // dv_batch_abort: every waiting and every later dv_batch_arrive returns -1
+    // dv_batch_timing: HIP events around the three launches of the SECOND iteration slot of every round (a steady-state slot: candidate evaluation, reduce, solve with
+    // the accept decision), on the batch stream they are launched on; harvested when the next round starts (the events of the previous round have completed by then)
+    bool timing = false; hipEvent_t tev[4] = { nullptr, nullptr, nullptr, nullptr }; bool tev_pending = false;
+    double t_ms[3] = { 0, 0, 0 }; long long t_n = 0; int t_windows = 0;
 };
 // dv_destroy of a member: the batch forgets it (a destroyed ctx must never be reached through B->members); threads waiting in dv_batch_arrive
 // for a round this member will never join are released with an error
@@ -573,11 +581,25 @@ static int batch_enqueue_impl(dv_batch* B) {
         DV_CHECK(hipStreamWaitEvent(s, B->ev_up[i], 0));
     }
     const bool two_level = M[0]->be.pend->sa.dims.pad != 0;
+    if (B->timing && B->tev_pending && hipEventQuery(B->tev[3]) == hipSuccess) {      // the previous round's three stages
+        float ms;
+        for (int k = 0; k < 3; ++k) if (hipEventElapsedTime(&ms, B->tev[k], B->tev[k + 1]) == hipSuccess) B->t_ms[k] += ms;
+        B->t_n++; B->tev_pending = false;
+    }
+    const bool time_round = B->timing && !B->tev_pending && slots >= 3;
     for (int it = 0; it < slots; ++it) {                  // be_enqueue_slots' speculative schedule, one launch per stage for all windows
         const bool head = it == 0, last = it == slots - 1;
+        const bool timed = time_round && it == 1 && !last;      // slot 1: solve (decision + factorisation), then the candidate's evaluation and reduce
         if (head) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_X, s); be_launch_reduce_batch(dsa, S, max_n, 0, s); }
+        if (timed) { (void)hipEventRecord(B->tev[0], s); B->t_windows = S; }
         if (be_launch_solve_batch(dsa, S, max_n, two_level, head ? 0 : 1, s, M[0]->be.pend->sa.ldl_wcol)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
         if (last) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s); be_launch_accept_batch(dsa, S, s); }
+        else if (timed) {
+            (void)hipEventRecord(B->tev[1], s);
+            be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); (void)hipEventRecord(B->tev[2], s);
+            be_launch_reduce_batch(dsa, S, max_n, 1, s); (void)hipEventRecord(B->tev[3], s);
+            B->tev_pending = true;
+        }
         else { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); be_launch_reduce_batch(dsa, S, max_n, 1, s); }
     }
     DV_CHECK(hipGetLastError());
@@ -630,6 +652,7 @@ void dv_batch_destroy(dv_batch* B) {
     { std::lock_guard<std::mutex> lk(B->mu); for (dv_ctx* c : B->members) if (c->batch == B) c->batch = nullptr; B->members.clear(); }
     if (B->stream) { (void)hipStreamSynchronize(B->stream); (void)hipStreamDestroy(B->stream); }
     if (B->ev_slots) (void)hipEventDestroy(B->ev_slots);
+    for (hipEvent_t e : B->tev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : B->ev_up) if (e) (void)hipEventDestroy(e);
     B->tab.release();
     if (B->tab_pinned) (void)hipHostFree(B->tab_pinned);
@@ -673,6 +696,17 @@ int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, 
     if (checked) *checked = ctx->be.marg_checked;
     if (clamped) *clamped = ctx->be.marg_clamped;
     if (last4) std::memcpy(last4, ctx->be.marg_last, 32);
+    return 0;
+}
+// per-stage launch durations of the batched window solve, HIP events on the batch stream: out3 = average ms of [be_solve_batch, be_eval_batch (full), be_reduce_batch] over
+// the rounds timed so far (one steady-state slot per round), *windows = windows per launch of the last timed round.  on != 0 switches the events on.
+int dv_batch_timing(dv_batch* B, int on, double* out3, long long* rounds, int* windows) {
+    if (!B) return -1;
+    if (on && !B->tev[0]) for (auto& e : B->tev) if (hipEventCreate(&e) != hipSuccess) return -1;
+    B->timing = on != 0;
+    if (out3) for (int k = 0; k < 3; ++k) out3[k] = B->t_n ? B->t_ms[k] / (double)B->t_n : 0.0;
+    if (rounds) *rounds = B->t_n;
+    if (windows) *windows = B->t_windows;
     return 0;
 }
 int dv_batch_info(dv_batch* B, long long* batched_rounds, long long* single_rounds) {

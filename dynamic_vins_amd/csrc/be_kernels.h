@@ -69,7 +69,9 @@ struct BeMargArgs {
     const int32_t* dim_comp;      // [D]
     int D, m; double g_norm;
     double* outA; double* outb; double* out_scalars;     // n x n, n, {c0, min pivot, failure flag, rank}
-    double* slabs; double* sum; double* lm_h;            // [nlm][D*D+D] per-landmark contributions, their sum, per-landmark h
+    double* W; double* part; double* psum;                // be_marg_lm -> be_marg_sum: w_l | g_l | 1 / h_l per landmark [nlm][be_marg_wstride(D)]; structured block sums per landmark chunk [chunks][be_marg_part()]; their sum over chunks
+    int pose_dim[BE_NF], ex_dim[2], td_dim;               // first dim of each block in the system, -1 = absent (what dim_slot / dim_comp tabulate)
+    double* sum; double* lm_h; int anchor;                // A_lm | b_lm dense (D*D + D); per-landmark h; the frame the landmarks are anchored in (= the dropped one)
     double* imu_w;                // [465] whitened Jacobian (15 x 30) and residual (15) of the IMU factor (0,1): written by the extra block of be_marg_lm, read by be_marg_finish
     double* c0_out;               // optional second home of c0 (the device-resident prior of the estimator)
     const int32_t* lm_sel;        // optional: landmark b of the launch is lm[lm_sel[b]] (marginalization straight out of the solved window)
@@ -179,6 +181,9 @@ __device__ __forceinline__ void be_accept_body(const BeSolveArgs& a) {
 #define BE_EVAL_CAND_FULL 2 // full evaluation at cand into set cur ^ 1 + costs (runs if pending)
 void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s);
 int  be_launch_marg(const BeMargArgs& a, hipStream_t s);
+int  be_marg_chunks(int nlm);      // workgroups of be_marg_lm for nlm landmarks
+int  be_marg_part();               // doubles per chunk in BeMargArgs::part
+int  be_marg_wstride(int D);       // doubles per landmark in BeMargArgs::W
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
 void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s);      // be_accept + be_gauge in one launch (estimator path)
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s);      // spec: reduce the candidate's set (or, after a failed / invalid step, rebuild x's with the new mu)

@@ -40,38 +40,84 @@ __device__ __forceinline__ double mg_rcp(double d) {      // v_rcp_f64 + two New
     r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
     return r;
 }
-#define LM_THREADS 256
+#define LM_THREADS 512
 
-// offsets of the two Jacobian entries (row 0, row 1) of column `comp` of slot `slot` inside a factor record
-// Jf layout (54): r2 | Ji 12 | Jj 12 | Jex0 12 | Jex1 12 | Jl 2 | Jtd 2 ; returns false if the factor does not touch the slot
-// (offsets, not pointers: selecting between LDS pointers and nullptr miscompiled on gfx950 / ROCm 7.2)
-__device__ __forceinline__ bool mg_joff(int slot, int comp, int anchor, int fj, int two_frame, int& o0, int& o1) {
-    int base;
-    if (slot < BE_NF) { if (!two_frame) return false; if (slot == anchor) base = 2; else if (slot == fj) base = 14; else return false; }
-    else if (slot == BE_NF) base = 26;
-    else if (slot == BE_NF + 1) base = 38;
-    else { o0 = 52; o1 = 53; return true; }
-    o0 = base + comp; o1 = base + 6 + comp;
-    return true;
+// ---------------------------------------------------------------------------------------------------------------------------
+// The landmark part of the system, A_lm = sum_l (J_l^T J_l - w_l w_l^T / h_l),  b_lm = sum_l (J_l^T r_l - w_l g_l / h_l), is NOT summed from dense per-landmark
+// slabs (rounds 1-2: 17.9 MB written, 18.5 MB read back per frame).  Every residual block of a landmark anchored in frame 0 touches the same few column groups:
+//   common   pose of the anchor frame (6) | ex0 (6) | ex1 (6) | td (1)       19 "local" columns, touched by every block
+//   frame j  pose of the observing frame (6)                                  touched by the (at most two) blocks of the landmark with fj = j
+// so sum_l J_l^T J_l is block-structured — (common x common), (pose_j x common), (pose_j x pose_j), nothing between two different observing frames — and only
+// the rank-one terms w_l w_l^T / h_l are dense.  be_marg_lm (one workgroup per MG_CH landmarks) therefore writes
+//   part[chunk][MG_PART]   the chunk's share of the structured blocks (and of J^T r), summed over its residual blocks in block order,
+//   W[l][mg_wstride(D)]    w_l | g_l | 1 / h_l (0 if h_l <= 1e-8, the reference's pseudo-inverse),
+// be_marg_sum forms  - W^T diag(hinv) W  with one 16 x 16 tile per workgroup on the f64 matrix cores (v_mfma_f64_16x16x4_f64; row D of the extended product is the
+// right-hand side) and adds the chunks' parts; be_marg_finish puts the structured sums at their dense positions.  Every sum has one fixed order.  ~1 MB per frame
+// instead of 36 MB.
+#define MG_CH 4                                  // landmarks per workgroup of be_marg_lm
+#define MG_NC 19                                 // common local columns
+#define MG_CC (MG_NC * (MG_NC + 1) / 2)          // 190: lower triangle common x common, then 19: common part of J^T r
+#define MG_GRP (6 * MG_NC + 21 + 6)              // 141 per observing frame: pose_j x common (114) | pose_j x pose_j lower (21) | pose_j part of J^T r (6)
+#define MG_G0 (MG_CC + MG_NC)                    // 209
+#define MG_PART (MG_G0 + BE_NF * MG_GRP)         // 1760
+#define MG_MAXF (MG_CH * BE_MAX_OBS_FACTORS)
+static_assert(MG_PART <= 2 * (MG_THREADS - 64), "be_marg_finish: two structured entries per worker thread");
+static_assert(MG_MAXF + 2 <= LM_THREADS - 64, "one thread of be_marg_lm per residual block of the chunk");
+
+typedef double mg_d4 __attribute__((ext_vector_type(4)));
+// local common column of (slot, comp); -1: the pose of an observing frame (or a dim no residual block touches)
+__device__ __forceinline__ int mg_lc(int slot, int comp, int anchor) { return slot == anchor ? comp : slot == BE_NF ? 6 + comp : slot == BE_NF + 1 ? 12 + comp : slot == BE_NF + 2 ? 18 : -1; }
+// offset of row 0 of a common local column inside a factor record (54): r2 | Ji 12 | Jj 12 | Jex0 12 | Jex1 12 | Jl 2 | Jtd 2; row 1 sits mg_cstep further
+__device__ __forceinline__ int mg_coff(int lc) { return lc < 6 ? 2 + lc : lc < 12 ? 20 + lc : lc < 18 ? 26 + lc : 52; }
+__device__ __forceinline__ int mg_cstep(int lc) { return lc == 18 ? 1 : 6; }
+__device__ __forceinline__ void mg_tri(int t, int& hi, int& lo) {      // t = hi (hi + 1) / 2 + lo, lo <= hi
+    hi = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (hi * (hi + 1) / 2 > t) --hi;
+    while ((hi + 1) * (hi + 2) / 2 <= t) ++hi;
+    lo = t - hi * (hi + 1) / 2;
 }
+// position inside a chunk's part[] of dense entry (i, j), i == D: the right-hand side; -1: structurally zero
+__device__ __forceinline__ int mg_pos(int si, int ci, int sj, int cj, bool rhs, int anchor) {
+    if (sj < 0 || (!rhs && si < 0)) return -1;
+    const int lj = mg_lc(sj, cj, anchor);
+    if (rhs) return lj >= 0 ? MG_CC + lj : MG_G0 + sj * MG_GRP + 135 + cj;
+    const int li = mg_lc(si, ci, anchor);
+    if (li >= 0 && lj >= 0) { const int hi = li > lj ? li : lj, lo = li > lj ? lj : li; return hi * (hi + 1) / 2 + lo; }
+    if (li >= 0) return MG_G0 + sj * MG_GRP + cj * MG_NC + li;
+    if (lj >= 0) return MG_G0 + si * MG_GRP + ci * MG_NC + lj;
+    if (si != sj) return -1;
+    const int hi = ci > cj ? ci : cj, lo = ci > cj ? cj : ci;
+    return MG_G0 + si * MG_GRP + 114 + hi * (hi + 1) / 2 + lo;
+}
+
+// (slot, component) of dim i from the block offsets of the plan (BeMargArgs::pose_dim / ex_dim / td_dim); slot -1: speed-bias or out of range
+__device__ __forceinline__ void mg_dim(const BeMargArgs& a, int i, int& slot, int& comp) {
+    slot = -1; comp = 0;
+#pragma unroll
+    for (int k = 0; k < BE_NF; ++k) { const int d0 = a.pose_dim[k]; if (d0 >= 0 && i >= d0 && i < d0 + 6) { slot = k; comp = i - d0; } }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) { const int d0 = a.ex_dim[k]; if (d0 >= 0 && i >= d0 && i < d0 + 6) { slot = BE_NF + k; comp = i - d0; } }
+    if (a.td_dim >= 0 && i == a.td_dim) { slot = BE_NF + 2; comp = 0; }
+}
+// W rows: w_l (D) | g_l | 1 / h_l, padded to whole 128-byte lines (the operand loads of be_marg_sum then touch four lines per instruction)
+__host__ __device__ __forceinline__ int mg_wstride(int D) { return (D + 2 + 15) & ~15; }
+// record offset (row 0) and row step of MFMA column c of a residual block: 0..18 common | 19 residual | 20 d/d(inverse depth) | zero columns above
+__device__ __forceinline__ int mg_xoff(int c) { return c < MG_NC ? mg_coff(c) : c == MG_NC ? 0 : 50; }
+__device__ __forceinline__ int mg_xstep(int c) { return c < MG_NC ? mg_cstep(c) : 1; }
 
 __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int D = a.D, tid = threadIdx.x, l = blockIdx.x;
-    double* Jb = sm;                                   // BE_MAX_OBS_FACTORS x 54
-    double* Jd = Jb + BE_MAX_OBS_FACTORS * 54;         // (2 nf) x D dense rows
-    double* wv = Jd + 2 * BE_MAX_OBS_FACTORS * D;      // D
-    double* gpv = wv + D;                              // D
+    const int D = a.D, D1 = mg_wstride(D), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nchunk = (a.nlm + MG_CH - 1) / MG_CH, chunk = blockIdx.x;
+    double* Jb = sm;                                   // (MG_MAXF + 2) x 54: the chunk's residual blocks, landmark after landmark, then zero rows
     __shared__ FrameGeom fg[BE_NF];
     __shared__ m33 ric[2];
     __shared__ d3 tic[2];
-    __shared__ int s_fj[BE_MAX_OBS_FACTORS], s_two[BE_MAX_OBS_FACTORS];
-    __shared__ double s_hg[2];
     const BeState* st = a.x;
-    if (l == a.nlm) {
+    if (chunk == nchunk) {
         // extra block (present when the window has an IMU factor to marginalize): factor (0,1) evaluated at the solved state and whitened, beside the landmark
         // blocks.  be_marg_finish used to do this itself: a serial raw evaluation on one lane in the middle of a single-workgroup kernel.
-        double* Jraw = sm; double* Jw = sm + 450; double* rr = sm + 900;
+        double* Jraw = sm; double* rr = sm + 900;
         __shared__ BeImu s_m;
         for (int i = tid; i < 450; i += LM_THREADS) Jraw[i] = 0.0;
         {
@@ -91,123 +137,211 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
         return;
     }
     MTS(0);
-    __shared__ short s_slot[BE_MAX_PRIOR], s_comp[BE_MAX_PRIOR];      // dim -> (slot, component): read once, coalesced (they were two dependent global loads per dense-row entry)
+    __shared__ short s_slot[BE_MAX_PRIOR], s_comp[BE_MAX_PRIOR];      // dim -> (slot, component)
+    __shared__ short s_cdim[MG_NC];                                    // common local column -> dim (-1: not in the system)
+    __shared__ int s_first[MG_CH], s_cnt[MG_CH];
+    __shared__ short s_fidx[MG_CH][BE_NF][2];                          // [landmark][observing frame][left, right] -> residual block of the chunk, -1 = none
+    const int l0 = chunk * MG_CH, nk = min(MG_CH, a.nlm - l0), anchor = a.anchor;
     for (int i = tid; i < D; i += LM_THREADS) { s_slot[i] = (short)a.dim_slot[i]; s_comp[i] = (short)a.dim_comp[i]; }
+    if (tid < MG_NC) s_cdim[tid] = -1;
+    for (int i = tid; i < MG_CH * BE_NF * 2; i += LM_THREADS) (&s_fidx[0][0][0])[i] = -1;
     if (tid < 64) be_frame_geom_dev(st, a.nframes, fg, ric, tic, tid);
+    if (tid >= 64 && tid < 64 + nk) { const BeLm L = a.lm[a.lm_sel ? a.lm_sel[l0 + tid - 64] : l0 + tid - 64]; s_first[tid - 64] = L.first; s_cnt[tid - 64] = L.count; }
     __syncthreads();
     MTS(1);
-    const BeLm L = a.lm[a.lm_sel ? a.lm_sel[l] : l];
-    const int nf = L.count, anchor = L.anchor;
-    if (tid < nf) {
-        const BeFactor f = a.fac[L.first + tid];
+    int off[MG_CH + 1];
+    off[0] = 0;
+#pragma unroll
+    for (int k = 0; k < MG_CH; ++k) off[k + 1] = off[k] + (k < nk ? s_cnt[k] : 0);
+    const int nt = off[MG_CH];
+    if (tid < nt) {
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < MG_CH; ++q) k += tid >= off[q] ? 1 : 0;
+        const BeFactor f = a.fac[s_first[k] + tid - off[k]];
         double* o = Jb + tid * 54;
         proj_factor<true, true>(f, fg[f.fi], fg[f.fj], ric[0], tic[0], ric[1], tic[1], st->inv_depth[f.lm], st->td, o, o + 2, o + 14, o + 50, o + 26, o + 38, o + 52);
-        if (f.kind == 0) for (int k = 0; k < 12; ++k) o[38 + k] = 0.0;
+        if (f.kind == 0) for (int q = 0; q < 12; ++q) o[38 + q] = 0.0;
         double rho0, sc;
         huber1(o[0] * o[0] + o[1] * o[1], rho0, sc);
-        for (int k = 0; k < 54; ++k) o[k] *= sc;
-        s_fj[tid] = f.fj; s_two[tid] = f.kind != 2;
+        for (int q = 0; q < 54; ++q) o[q] *= sc;
+        if (f.kind != 2) s_fidx[k][f.fj][f.kind] = (short)tid;
+    } else if (tid < nt + 2) {                         // two zero blocks: the matrix-core loop below runs over whole groups of four rows
+        double* o = Jb + tid * 54;
+        for (int q = 0; q < 54; ++q) o[q] = 0.0;
+    } else if (tid >= LM_THREADS - 64) {
+        const int i = tid - (LM_THREADS - 64);
+        for (int d = i; d < D; d += 64) { const int sl = s_slot[d]; const int lc = sl >= 0 ? mg_lc(sl, s_comp[d], anchor) : -1; if (lc >= 0) s_cdim[lc] = (short)d; }
     }
     __syncthreads();
     MTS(2);
-    for (int e = tid; e < 2 * nf * D; e += LM_THREADS) {
-        const int fr = e / D, i = e - fr * D, f = fr >> 1, r = fr & 1;
-        const int slot = s_slot[i];
-        double v = 0.0;
-        int o0, o1;
-        if (slot >= 0 && mg_joff(slot, s_comp[i], anchor, s_fj[f], s_two[f], o0, o1)) v = Jb[f * 54 + (r ? o1 : o0)];
-        Jd[e] = v;
+    double* part = a.part + (size_t)chunk * MG_PART;
+    if (wave < 5) {
+        // (common | r | Jl)^T (common | r | Jl) over every residual-block row of the chunk (waves 0-2: the lower tiles of the 32 x 32 product -> common x common and
+        // the common part of J^T r), and (common | r | Jl)^T (Jl masked per landmark) (waves 3-4 -> w_l on the common columns, g_l, h_l): 16 x 16 x 4 fp64 MFMAs
+        // over groups of four rows, row order = block order.  Lane l feeds row 4 s + (l >> 4), column l & 15 of its operand block.
+        const int Ib = wave == 0 ? 0 : wave == 3 ? 0 : 1, Jb_ = wave == 2 ? 1 : 0;
+        const bool wl = wave >= 3;
+        const int cl = lane & 15, kq = lane >> 4;
+        const int ca = Ib * 16 + cl, cbk = Jb_ * 16 + cl;
+        // row rho = 4 s + kq -> block t = rho >> 1 = 2 s + (kq >> 1), row r = kq & 1
+        const bool za = ca > MG_NC + 1, zb = wl ? cl >= nk : cbk > MG_NC + 1;      // zero columns: read column 0 instead and select (a predicated LDS read is a branch)
+        const int base_a = (kq >> 1) * 54 + (za ? 0 : mg_xoff(ca) + (kq & 1) * mg_xstep(ca));
+        const int base_b = (kq >> 1) * 54 + (wl ? 50 + (kq & 1) : zb ? 0 : mg_xoff(cbk) + (kq & 1) * mg_xstep(cbk));
+        int lo = 0, hi = 0;                            // waves 3-4: the blocks of landmark (l & 15)
+        if (wl && !zb) {
+#pragma unroll
+            for (int k = 0; k < MG_CH; ++k) if (cl == k) { lo = off[k]; hi = off[k + 1]; }
+        }
+        if (!wl && !zb) hi = 1 << 20;
+        lo -= kq >> 1; hi -= kq >> 1;                  // compared against 2 s below
+        mg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+        const int steps = __builtin_amdgcn_readfirstlane((2 * nt + 3) >> 2);      // uniform (nt comes out of LDS: the compiler cannot know)
+        const double* pa = Jb + base_a; const double* pb = Jb + base_b;
+        MTS(20);
+        for (int s0 = 0; s0 < steps; s0 += 8) {            // eight groups of four rows per trip: sixteen LDS reads in flight, then the eight products
+            double xr[8], yr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int s = min(s0 + u, steps - 1); xr[u] = pa[s * 108]; yr[u] = pb[s * 108]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s2 = 2 * (s0 + u);
+                const bool keep = (s0 + u < steps) & (s2 >= lo) & (s2 < hi);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((za | (s0 + u >= steps)) ? 0.0 : xr[u], keep ? yr[u] : 0.0, acc, 0, 0, 0);
+            }
+        }
+        MTS(21);
+        // result: register r of lane l = (row (l >> 4) + 4 r of block Ib, column l & 15)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = Ib * 16 + kq + 4 * r;
+            if (!wl) {
+                const int cj = cbk;
+                if (ci < MG_NC && cj <= ci) part[ci * (ci + 1) / 2 + cj] = acc[r];
+                else if (ci == MG_NC && cj < MG_NC) part[MG_CC + cj] = acc[r];
+            } else if (cl < nk) {
+                const int l = l0 + cl;
+                if (ci < MG_NC) { const int d = s_cdim[ci]; if (d >= 0) a.W[(size_t)l * D1 + d] = acc[r]; }
+                else if (ci == MG_NC) a.W[(size_t)l * D1 + D] = acc[r];
+                else if (ci == MG_NC + 1) { const double h = acc[r]; a.lm_h[l] = h; a.W[(size_t)l * D1 + D + 1] = h > 1e-8 ? 1.0 / h : 0.0; }      // 1x1 pivot of the inverse depth, clamped like the reference's pseudo-inverse
+            }
+        }
     }
-    if (tid == 0) {
-        double h = 0, g = 0;
-        for (int f = 0; f < nf; ++f) { const double* o = Jb + f * 54; h += o[50] * o[50] + o[51] * o[51]; g += o[50] * o[0] + o[51] * o[1]; }
-        s_hg[0] = h; s_hg[1] = g;
-        a.lm_h[l] = h;
-    }
-    __syncthreads();
     MTS(3);
-    // a landmark touches its anchor pose, the poses of the frames that observe it, the extrinsics and td: every other column of its
-    // dense rows is identically zero, and so is every slab entry with such a row or column.  The slab is therefore written in two
-    // passes: exact zeros for the structurally empty entries, and 2x2 register tiles over the lower triangle of the ACTIVE columns
-    // (each loaded row value feeds two products; the mirror entry is the same sum of commuting products, bit for bit).
-    __shared__ unsigned char s_act[BE_MAX_PRIOR];
-    __shared__ short s_acols[BE_MAX_PRIOR + 2];
-    __shared__ int s_na;
-    for (int i = tid; i < D; i += LM_THREADS) {
-        double w = 0, gp = 0; bool act = false;
-        for (int fr = 0; fr < 2 * nf; ++fr) { const double j = Jd[fr * D + i]; const double* o = Jb + (fr >> 1) * 54; w += j * o[50 + (fr & 1)]; gp += j * o[fr & 1]; act = act || j != 0.0; }
-        wv[i] = w; gpv[i] = gp; s_act[i] = act;
-    }
-    __syncthreads();
-    {   // ordered compaction of the active columns: ballot + popcount per wave, wave offsets through LDS (D <= 192 < 256 threads)
-        __shared__ int s_wcnt[LM_THREADS / 64];
-        const bool actf = tid < D && s_act[tid];
-        const unsigned long long m = __ballot(actf);
-        const int lane = tid & 63, wv_id = tid >> 6;
-        if (lane == 0) s_wcnt[wv_id] = __popcll(m);
-        __syncthreads();
-        int off = 0, tot = 0;
-        for (int q = 0; q < LM_THREADS / 64; ++q) { if (q < wv_id) off += s_wcnt[q]; tot += s_wcnt[q]; }
-        if (actf) s_acols[off + __popcll(m & ((1ull << lane) - 1ull))] = (short)tid;
-        if (tid == 0) { s_acols[tot] = s_acols[tot + 1] = -1; s_na = tot; }
+    // w_l on the columns that are not common: the pose of an observing frame (its left, then its right block), zero elsewhere
+    for (int e = tid; e < nk * D; e += LM_THREADS) {
+        const int k = e / D, i = e - k * D;
+        const int slot = s_slot[i], comp = s_comp[i];
+        if (slot >= 0 && mg_lc(slot, comp, anchor) >= 0) continue;
+        double w = 0.0;
+        if (slot >= 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { const int t = s_fidx[k][slot][q]; if (t >= 0) { const double* o = Jb + t * 54; w += o[14 + comp] * o[50]; w += o[20 + comp] * o[51]; } }
+        }
+        a.W[(size_t)(l0 + k) * D1 + i] = w;
     }
     MTS(4);
-    const double hinv = s_hg[0] > 1e-8 ? 1.0 / s_hg[0] : 0.0, g = s_hg[1];      // 1x1 pivot of the landmark's inverse depth, clamped like the reference's pseudo-inverse
-    double* out = a.slabs + (size_t)l * (D * D + D);
-    for (int i = tid >> 6; i < D; i += LM_THREADS / 64) {             // wave = row, lane = column: no integer division
-        const bool ai = s_act[i];
-        for (int j = tid & 63; j < D; j += 64) if (!(ai && s_act[j])) out[i * D + j] = 0.0;
-    }
-    for (int i = tid; i < D; i += LM_THREADS) out[D * D + i] = gpv[i] - wv[i] * g * hinv;
-    __syncthreads();
-    const int na = s_na, T = (na + 1) >> 1;
-    for (int t = tid; t < T * (T + 1) / 2; t += LM_THREADS) {                 // lower-triangular tile index: t = ti (ti + 1) / 2 + tj
-        int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (ti * (ti + 1) / 2 > t) --ti;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        const int tj = t - ti * (ti + 1) / 2;
-        const int i0 = s_acols[2 * ti], i1 = s_acols[2 * ti + 1], j0 = s_acols[2 * tj], j1 = s_acols[2 * tj + 1];      // -1 past the end
-        const int ri1 = i1 >= 0 ? i1 : i0, rj1 = j1 >= 0 ? j1 : j0;
-        double s00 = 0, s01 = 0, s10 = 0, s11 = 0;
-        for (int fr = 0; fr < 2 * nf; ++fr) {
-            const double* row = Jd + fr * D;
-            const double a0 = row[i0], a1 = row[ri1], b0 = row[j0], b1 = row[rj1];
-            s00 += a0 * b0; s01 += a0 * b1; s10 += a1 * b0; s11 += a1 * b1;
-        }
-        auto put = [&](int i, int j, double sv) {
-            const double v = sv - wv[i] * wv[j] * hinv;
-            out[i * D + j] = v;
-            if (i != j) out[j * D + i] = v;
-        };
-        put(i0, j0, s00);
-        if (j1 >= 0 && !(ti == tj)) put(i0, j1, s01);      // on a diagonal tile (i0, j1) is the mirror of (i1, j0)
-        if (i1 >= 0) put(i1, j0, s10);
-        if (i1 >= 0 && j1 >= 0) put(i1, j1, s11);
+    // the chunk's share of the per-frame blocks: pose_j x (common | pose_j | r), summed over landmarks in order, left block before right block
+    for (int e = tid; e < BE_NF * MG_GRP; e += LM_THREADS) {
+        const int grp = e / MG_GRP, u = e - grp * MG_GRP;
+        int oa, ob, sb;
+        if (u < 114) { const int cp = u / MG_NC, lc = u - cp * MG_NC; oa = 14 + cp; ob = mg_coff(lc); sb = mg_cstep(lc); }
+        else if (u < 135) { int hi, lo; mg_tri(u - 114, hi, lo); oa = 14 + hi; ob = 14 + lo; sb = 6; }
+        else { oa = 14 + u - 135; ob = 0; sb = 1; }
+        double s = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2 * MG_CH; ++q) { const int t = s_fidx[q >> 1][grp][q & 1]; if (t >= 0) { const double* o = Jb + t * 54; s += o[oa] * o[ob]; s += o[oa + 6] * o[ob + sb]; } }
+        part[MG_G0 + e] = s;
     }
     MTS(5);
 }
 
-#define MG_SUM_CHUNKS 4
-// sums the per-landmark slabs: grid.y = MG_SUM_CHUNKS landmark ranges (parallelism: 37 x 4 workgroups instead of 37; 8 ranges doubled what the finish
-// kernel has to read back through one CU: be_marg 98.8 -> 97.7 us; 2 ranges: 102 us), each
-// summed in landmark order; the finish kernel adds the chunk sums in chunk order -> still one fixed, reproducible order
-__global__ __launch_bounds__(256) void be_marg_sum_kernel(BeMargArgs a) {
-    const int D = a.D, total = D * D + D;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
-    const int per = (a.nlm + MG_SUM_CHUNKS - 1) / MG_SUM_CHUNKS, l0 = blockIdx.y * per, l1 = min(a.nlm, l0 + per);
-    double s = 0;
-    // eight slabs requested per trip (a load + wait per landmark made the kernel a chain of dependent round trips: ~1 us each, 9 per chunk); added in landmark order
-    for (int l = l0; l < l1; l += 8) {
-        double v[8];
+// be_marg_sum, two kinds of workgroups in one launch:
+//   tiles    (blockIdx.x < lower tiles of the extended (D + 1) x (D + 1) system)   a.sum = - W^T diag(hinv) W  (dense D x D, both triangles, then the row of the
+//            right-hand side).  Wave q takes the q-th quarter of the landmarks — all its operands in flight at once, every load instruction four whole lines — and
+//            the quarters are added in order through LDS.
+//   reduce   (the workgroups behind them)   a.psum[e] = sum over chunks of part[chunk][e], chunk order; coalesced.
+// be_marg_finish adds psum into the dense system at the positions the structure dictates (the scattered 8-byte gathers this kernel did itself at first — 32 per
+// lane, each load instruction touching up to 64 lines — kept the texture addresser of every CU busy for 7 us).
+#define MG_KSTEPS 16
+__global__ __launch_bounds__(256) void be_marg_sum_kernel(BeMargArgs a, int tiles) {
+    const int D = a.D, Ws = mg_wstride(D), lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int nlm = a.nlm, nchunk = (nlm + MG_CH - 1) / MG_CH;
+    if ((int)blockIdx.x >= tiles) {
+        const int e = ((int)blockIdx.x - tiles) * 256 + threadIdx.x;
+        if (e >= MG_PART) return;
+        const double* pp = a.part + e;
+        double sg = 0.0;
+        for (int c0 = 0; c0 < nchunk; c0 += 32) {
+            double v[32];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = a.slabs[(size_t)(l + u < l1 ? l + u : l0) * total + e];
+            for (int u = 0; u < 32; ++u) v[u] = pp[(size_t)min(c0 + u, nchunk - 1) * MG_PART];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) if (l + u < l1) s += v[u];
+            for (int u = 0; u < 32; ++u) if (c0 + u < nchunk) sg += v[u];
+        }
+        a.psum[e] = sg;
+        return;
     }
-    a.sum[(size_t)blockIdx.y * total + e] = s;
+    int I, J; mg_tri(blockIdx.x, I, J);
+    const int cl = lane & 15, kq = lane >> 4, ca = I * 16 + cl, cb = J * 16 + cl;
+    __shared__ double s_acc[4][4][64];
+    MTS(6);
+    // acc[i][j] = sum_l W[l][16 I + i] hinv_l W[l][16 J + j], four landmarks per instruction, landmark order inside the quarter.  Columns >= D + 1 of the last
+    // block hold hinv and padding: whatever they produce is not stored.
+    const int per = (((nlm + 3) >> 2) + 3) & ~3, k_lo = q * per, k_hi = min(nlm, k_lo + per);
+    const double* wa = a.W + ca; const double* wb = a.W + cb; const double* wh = a.W + D + 1;
+    mg_d4 acc = { 0.0, 0.0, 0.0, 0.0 };
+    MTS(22);
+    for (int k0 = k_lo; k0 < k_hi; k0 += 4 * MG_KSTEPS) {      // one trip while a quarter holds <= 64 landmarks
+        double x[MG_KSTEPS], y[MG_KSTEPS], hv[MG_KSTEPS];
+#pragma unroll
+        for (int u = 0; u < MG_KSTEPS; ++u) {                  // unconditional loads (clamped row, value selected afterwards): a predicated load is a branch
+            const size_t k = (size_t)min(k0 + 4 * u + kq, nlm - 1) * Ws;
+            x[u] = wa[k]; y[u] = wb[k]; hv[u] = wh[k];
+        }
+#pragma unroll
+        for (int u = 0; u < MG_KSTEPS; ++u) {
+            const bool vk = k0 + 4 * u + kq < k_hi;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(vk ? x[u] : 0.0, vk ? y[u] * hv[u] : 0.0, acc, 0, 0, 0);
+        }
+    }
+    MTS(23);
+    MTS(7);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_acc[q][r][lane] = acc[r];
+    __syncthreads();
+    // after the exchange wave q owns result register q of the tile: entry (row (l >> 4) + 4 q of block I, column l & 15 of block J)
+    const int i = I * 16 + kq + 4 * q, j = cb;
+    if (i <= D && j < D && j <= i) {
+        double rk = s_acc[0][q][lane];
+        rk += s_acc[1][q][lane]; rk += s_acc[2][q][lane]; rk += s_acc[3][q][lane];
+        if (i == D) a.sum[(size_t)D * D + j] = -rk;
+        else { a.sum[(size_t)i * D + j] = -rk; a.sum[(size_t)j * D + i] = -rk; }
+    }
+    MTS(18);
 }
 
+// dense home of entry e of the structured sums (the inverse of the layout be_marg_lm writes): (i, j) with i == D for the right-hand side; false if the block is
+// not part of the system
+__device__ __forceinline__ bool mg_home(const BeMargArgs& a, int e, int& i, int& j) {
+    const int D = a.D, anchor = a.anchor;
+    auto cdim = [&](int lc) { const int d0 = lc < 6 ? a.pose_dim[anchor] : lc < 12 ? a.ex_dim[0] : lc < 18 ? a.ex_dim[1] : a.td_dim; return d0 < 0 ? -1 : d0 + (lc < 6 ? lc : lc < 12 ? lc - 6 : lc < 18 ? lc - 12 : 0); };
+    if (e < MG_CC) { int hi, lo; mg_tri(e, hi, lo); i = cdim(hi); j = cdim(lo); }
+    else if (e < MG_G0) { i = D; j = cdim(e - MG_CC); }
+    else {
+        const int qq = e - MG_G0, grp = qq / MG_GRP, u = qq - grp * MG_GRP;
+        int d0 = -1;
+#pragma unroll
+        for (int k = 0; k < BE_NF; ++k) if (k == grp) d0 = a.pose_dim[k];
+        if (d0 < 0 || grp == anchor) return false;
+        if (u < 114) { const int cp = u / MG_NC; i = d0 + cp; j = cdim(u - cp * MG_NC); }
+        else if (u < 135) { int hi, lo; mg_tri(u - 114, hi, lo); i = d0 + hi; j = d0 + lo; }
+        else { i = D; j = d0 + u - 135; }
+    }
+    return i >= 0 && j >= 0;
+}
+
+#define MG_SUM_CHUNKS 1
 __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = a.D, m = a.m, n = D - m, tid = threadIdx.x;
@@ -227,6 +361,12 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     if (imu_wave && a.nimu > 0) {
         const int lane = tid - MGW;
         for (int i = lane; i < 465; i += 64) { const double v = a.imu_w[i]; if (i < 450) Jw[i] = v; else rr[15 + i - 450] = v; }
+    }
+    // the structured block sums (be_marg_sum's reduce workgroups): requested first, added at their dense homes once the rank term is in LDS
+    double pv[2] = { 0.0, 0.0 }; int pi_[2] = { -1, -1 }, pj_[2] = { 0, 0 };
+    if (a.nlm > 0 && !imu_wave) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int e = tid + u * MGW; if (e < MG_PART && mg_home(a, e, pi_[u], pj_[u])) pv[u] = a.psum[e]; else pi_[u] = -1; }
     }
     {   // 4 entries x 8 chunk sums per batch: 32 independent global loads in flight per thread (they were 8 at a time behind a loop-carried wait)
         const int total = D * D + D;
@@ -256,6 +396,15 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         if (tid == 0) { misc[0] = hmin; misc[1] = !(hmin > 1e-8) ? 1.0 : 0.0; }      // be_marg_lm dropped a landmark pivot <= 1e-8 (hinv := 0): reported like the dense pivots below
     }
     __syncthreads();
+    if (a.nlm > 0) {                                    // no two entries share a home: plain read-modify-write
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (pi_[u] >= 0) {
+            const int i = pi_[u], j = pj_[u]; const double v = pv[u];
+            if (i == D) bv[j] += v;
+            else { A[i * D + j] += v; if (i != j) A[j * D + i] += v; }
+        }
+        __syncthreads();
+    }
     MTS(9);
     // ---------------- previous prior: A += A_old (mapped), b += b_old + A_old dx ----------------
     if (a.prior->valid) {
@@ -518,20 +667,23 @@ void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(b
 void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s) { hipLaunchKernelGGL(be_accept_gauge_kernel, dim3(1), dim3(256), 0, s, sa, ga); }
 
 static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16 + 960) * sizeof(double); }
-static size_t lm_smem(int D) { return ((size_t)BE_MAX_OBS_FACTORS * 54 + 2 * (size_t)BE_MAX_OBS_FACTORS * D + 2 * D) * sizeof(double); }
+static size_t lm_smem() { return std::max((size_t)(MG_MAXF + 2) * 54, (size_t)1024) * sizeof(double); }
+int be_marg_chunks(int nlm) { return (nlm + MG_CH - 1) / MG_CH; }
+int be_marg_part() { return MG_PART; }
+int be_marg_wstride(int D) { return mg_wstride(D); }
 
 int be_launch_marg(const BeMargArgs& a, hipStream_t s) {
     static DevOnce once;
     if (once.run([] {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return 1;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 1;
             return 0; })) return -1;
     const size_t bytes = finish_smem(a.D, a.D - a.m);
-    if (bytes > 156 * 1024 || lm_smem(a.D) > 64 * 1024) return -2;
-    if (a.nlm > 0 || a.nimu > 0) hipLaunchKernelGGL(be_marg_lm_kernel, dim3(a.nlm + (a.nimu > 0 ? 1 : 0)), dim3(LM_THREADS), lm_smem(a.D), s, a);
+    if (bytes > 156 * 1024 || lm_smem() > 96 * 1024) return -2;
+    if (a.nlm > 0 || a.nimu > 0) hipLaunchKernelGGL(be_marg_lm_kernel, dim3(be_marg_chunks(a.nlm) + (a.nimu > 0 ? 1 : 0)), dim3(LM_THREADS), lm_smem(), s, a);
     if (a.nlm > 0) {
-        const int total = a.D * a.D + a.D;
-        hipLaunchKernelGGL(be_marg_sum_kernel, dim3((total + 255) / 256, MG_SUM_CHUNKS), dim3(256), 0, s, a);
+        const int NB = (a.D + 1 + 15) / 16, tiles = NB * (NB + 1) / 2;
+        hipLaunchKernelGGL(be_marg_sum_kernel, dim3(tiles + (MG_PART + 255) / 256), dim3(256), 0, s, a, tiles);
     }
     hipLaunchKernelGGL(be_marg_finish_kernel, dim3(1), dim3(MG_THREADS), bytes, s, a);
     return 0;

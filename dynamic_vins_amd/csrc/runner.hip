@@ -187,6 +187,21 @@ int dv_runner_get_frames(dv_runner* R, int seq, double* rows9, int cap, int* n_r
     return 0;
 }
 
+// batched groups: switch the per-stage events of every group's dv_batch on / read their averages (dv_batch_timing), averaged over the groups
+int dv_runner_batch_timing(dv_runner* R, int on, double* out3, long long* rounds, int* windows) {
+    if (!R) return -1;
+    double acc[3] = { 0, 0, 0 }; long long n = 0; int w = 0, ng = 0;
+    for (auto& g : R->groups) if (g.batch) {
+        double o[3]; long long r = 0; int ww = 0;
+        if (dv_batch_timing(g.batch, on, o, &r, &ww)) return -1;
+        if (r > 0) { for (int k = 0; k < 3; ++k) acc[k] += o[k]; n += r; w = ww; ++ng; }
+    }
+    if (out3) for (int k = 0; k < 3; ++k) out3[k] = ng ? acc[k] / ng : 0.0;
+    if (rounds) *rounds = n;
+    if (windows) *windows = w;
+    return 0;
+}
+
 const char* dv_runner_error(dv_runner* R) { return R ? R->err.c_str() : "null runner"; }
 
 } // extern "C"

@@ -146,6 +146,8 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
         gsz = args.group_size if getattr(args, "group_size", 0) > 0 else (S // 2 if S >= 4 else S)
     runner = Runner(pipes, group_size=gsz, threads=max(1, getattr(args, "runner_threads", 1)))
     runner.run(warm_ba)
+    if gsz > 1:
+        runner.batch_timing(1)       # HIP events on the batch streams around one steady-state slot per round (dv_batch_timing)
     gc.collect(); gc.freeze()
     times = []
     for _b in range(2):
@@ -163,6 +165,36 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
         gt = [p.seq.traj.p(t) for t in poses[:, 0]]
         ates.append(sim.align_ate(poses[:, 1:4], gt)[0]); iters += it
     n_total = S * (warm_ba + 2 * args.steps)
+    roof = None
+    if rank == 0 and gsz > 1:
+        # the batched window solve's stage launches: [be_solve_batch, be_eval_batch (full), be_reduce_batch] x `wins` windows per launch.  ALGORITHMIC bytes per
+        # window as for the single-window kernels: evaluation = factor records read + one 928-double packet per landmark written; reduce = every packet
+        # read once + Hd, Sc written; solve = Hd + Sc once, three passes over (w[66], h, g, scale) per landmark.
+        t_ms, rounds, wins = runner.batch_timing(1)
+        L = float(sum(runner.get(i)[0].n_landmarks for i in range(S))) / S
+        n_state = 165 if cfg["use_imu"] else 60
+        alg = {"be_solve_batch": 2 * n_state * n_state * 8 + 3 * L * 69 * 8, "be_eval_batch": L * (16 + 928 * 8) + L * 20 * 112, "be_reduce_batch": L * 928 * 8 + 2 * n_state * n_state * 8}
+        names = list(alg)
+        if rounds > 0 and wins > 0:
+            from bench import HBM_PEAK_GBS, ROOT, csrc_digest
+            dom = names[max(range(3), key=lambda k: t_ms[k])]
+            stage = {n: {"avg_launch_us": round(t_ms[k] * 1e3, 2), "algorithmic_bytes_per_launch": int(alg[n] * wins),
+                         "achieved_GBs": round(alg[n] * wins / (t_ms[k] * 1e-3) / 1e9, 3) if t_ms[k] > 0 else None} for k, n in enumerate(names)}
+            traffic, stale = None, None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_batched.json")))
+                hit = [v for k, v in pmc["kernels"].items() if k.startswith(dom.replace("_batch", "_batch_kernel"))]
+                if hit and pmc.get("windows_per_launch") == wins:
+                    traffic = int(hit[0]["traffic_bytes"])
+                stale = pmc.get("csrc_digest") != csrc_digest()
+            except (OSError, KeyError, ValueError):
+                pass
+            ach = stage[dom]["achieved_GBs"]
+            roof = {"kernel": dom, "bound": "hbm", "bound_note": "the batched stage launches: one workgroup (solve) or one grid slice (evaluation, reduce) per window, `windows_per_launch` windows in one launch",
+                    "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None if ach is None else round(ach / HBM_PEAK_GBS, 6),
+                    "traffic": None if stale else traffic, "traffic_stale": stale, "avg_launch_us": stage[dom]["avg_launch_us"],
+                    "algorithmic_bytes_per_launch": stage[dom]["algorithmic_bytes_per_launch"], "windows_per_launch": wins, "landmarks_per_window": round(L, 1),
+                    "rounds_timed": int(rounds), "stages": stage}
     if rank == 0:
         dt = times[0]
         out = {"metric": "stereo frames/sec (track+BA)", "value": round(world * S * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm_ba,
@@ -175,7 +207,7 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
                           "group_size": gsz, "runner_threads": max(1, getattr(args, "runner_threads", 1)),
                           "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),
                           "solver_iterations_per_frame": round(iters / max(n_total, 1), 2), "ate_rmse_m_vs_ground_truth_max": round(max(ates), 5)},
-               "roofline": None, "cpu_baseline": None}
+               "roofline": roof, "cpu_baseline": None}
         print(json.dumps(out))
     runner.close()
     for p in pipes:

@@ -233,6 +233,8 @@ int dv_batch_enqueue(dv_batch* batch);
 int dv_batch_arrive(dv_batch* batch);                        /* one host thread per member: blocks until every member's thread has arrived; the last one enqueues */
 int dv_batch_abort(dv_batch* batch);                         /* a member thread failed before arriving: every waiting and later dv_batch_arrive returns -1 */
 int dv_batch_info(dv_batch* batch, long long* batched_rounds, long long* single_rounds);
+/* measurement: HIP events on the batch stream around the solve / evaluation / reduce launches of one steady-state iteration slot per round; out3 = average ms per launch so far */
+int dv_batch_timing(dv_batch* batch, int on, double* out3, long long* rounds, int* windows);
 
 /* Replaces MarginalizationInfo::{preMarginalize,marginalize,getParameterBlocks} as driven by
  * Estimator::SetMarginalizationInfo (estimator/estimator.cpp:403-619).
@@ -425,6 +427,7 @@ int dv_runner_run(dv_runner* runner, int n_rounds, double* wall_seconds_or_null)
 int dv_runner_get(dv_runner* runner, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames, int* n_rows_last);
 /* every frame handed to the back end, initialisation included, as rows [t, px py pz qx qy qz qw, nonlinear]: the lines of `<seq>_<mode>_Odometry.txt` */
 int dv_runner_get_frames(dv_runner* runner, int seq, double* rows9, int cap, int* n_rows);
+int dv_runner_batch_timing(dv_runner* runner, int on, double* out3, long long* rounds, int* windows);      /* dv_batch_timing of the runner's groups, averaged */
 const char* dv_runner_error(dv_runner* runner);
 
 /* FeatureManager::point_landmarks for the point-cloud publishers (utils/io/visualization.cpp:214-249): world point = CamToWorld(point * depth, start_frame);

@@ -17,12 +17,18 @@ def load(pat, name):
     return d
 
 
+BATCHED = len(sys.argv) > 3 and sys.argv[3] == "--batched"      # the passes ran `bench.py --sequences 16 --batched --group-size 8 --runner-threads 2` (argv[4] = windows per launch)
 f = load(sys.argv[1] + "/**/*counter_collection.csv", "FETCH_SIZE")
 w = load(sys.argv[2] + "/**/*counter_collection.csv", "WRITE_SIZE")
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python3 bench.py --steps 30 --no-cpu-baseline; averages over active launches; "
                  "FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md); counters are kilobytes per dispatch",
        "git_head": git_head(), "csrc_digest": csrc_digest(), "kernels": {}}
+if BATCHED:
+    out["source"] = out["source"].replace("bench.py --steps 30 --no-cpu-baseline", "bench.py --sequences 16 --batched --group-size 8 --runner-threads 2 --steps 30")
+    out["windows_per_launch"] = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 for k in sorted(f):
+    if BATCHED and "batch" not in k:
+        continue
     if not (k.startswith(("be_", "lk_", "gftt_", "pyr_", "track_", "inst_", "roi_", "finalize", "compact", "lift", "erode")) or "be_" in k):
         continue
     fa = [v for v, t in f[k] if t > 8000] or [v for v, _ in f[k]]

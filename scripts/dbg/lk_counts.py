@@ -20,3 +20,4 @@ slow_i, slow_pre, jt, jslow, itmax = ts[8], ts[9], ts[10], ts[11], ts[12]
 print("points %d, level passes %d (%.1f per point), iterations %d (%.1f per level pass)" % (pts, lv, lv / pts, it, it / lv))
 print("per point: mean %.1f us, max %.1f us; loop %.1f us, before the loop (staging, gradients, A) %.1f us" % (dur / pts / 100.0, mx / 100.0, loop / pts / 100.0, pre / pts / 100.0))
 print("I tiles on the border path: %d of %d level passes (pre-loop %.1f us each against %.1f on the fast path); J tiles staged %d (%.2f per level pass), %d on the border path; most iterations in one level pass: %d" % (slow_i, lv, slow_pre / max(slow_i, 1) / 100.0, (pre - slow_pre) / max(lv - slow_i, 1) / 100.0, jt, jt / lv, jslow, itmax))
+print("J staging: %.2f us per tile; iterations without it: %.2f us each" % (ts[13] / max(jt, 1) / 100.0, (loop - ts[13]) / max(it, 1) / 100.0))

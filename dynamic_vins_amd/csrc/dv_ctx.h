@@ -42,12 +42,13 @@ struct PyrSet {
             cw = nw; ch = nh;
         }
         size_t total = 0, off[DV_MAX_LEVELS];
-        for (int l = 0; l < n; ++l) { off[l] = total; total += (size_t)align_up(lw[l], 16) * lh[l]; total = (total + 255) / 256 * 256; }
+        const int A = DV_PYR_APRON;                                 // every level carries a reflect-101 apron: all LK tiles take the aligned dword path (lk.hip)
+        for (int l = 0; l < n; ++l) { off[l] = total; total += (size_t)align_up(lw[l] + 2 * A, 16) * (lh[l] + 2 * A); total = (total + 255) / 256 * 256; }
         total += 512;                                             // slack for aligned over-reads
         hipError_t e = buf.ensure(total);
         if (e != hipSuccess) return e;
-        for (int l = 0; l < n; ++l) pyr.L[l] = DvLevel{ (uint8_t*)buf.p + off[l], lw[l], lh[l], align_up(lw[l], 16) };
-        for (int l = n; l < DV_MAX_LEVELS; ++l) pyr.L[l] = DvLevel{ nullptr, 0, 0, 0 };
+        for (int l = 0; l < n; ++l) { const int pitch = align_up(lw[l] + 2 * A, 16); pyr.L[l] = DvLevel{ (uint8_t*)buf.p + off[l] + (size_t)A * pitch + A, lw[l], lh[l], pitch, A }; }
+        for (int l = n; l < DV_MAX_LEVELS; ++l) pyr.L[l] = DvLevel{ nullptr, 0, 0, 0, 0 };
         pyr.levels = n;
         return hipSuccess;
     }

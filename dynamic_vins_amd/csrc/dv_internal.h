@@ -10,7 +10,9 @@
 #define DV_MAX_LEVELS 4       // maxLevel = 3 -> 4 levels
 #define DV_MAX_RADIUS 128     // largest disc radius (min_dist) supported by the mask stamper
 
-struct DvLevel { uint8_t* p; int w, h, pitch; };
+// apron: pixels of BORDER_REFLECT_101 data stored around the w x h image (p points at pixel (0, 0) inside the padded buffer); 0 = none
+struct DvLevel { uint8_t* p; int w, h, pitch, apron; };
+#define DV_PYR_APRON 32      // >= the 27 px an LK tile can overhang the image, multiple of 4 (dword-aligned tile loads)
 struct DvPyr   { DvLevel L[DV_MAX_LEVELS]; int levels; };   // levels = number of valid entries
 
 // candidate record emitted by the Shi-Tomasi tile kernel
@@ -59,6 +61,7 @@ struct dv_ctx;
 void dv_set_error(dv_ctx* ctx, const std::string& msg);
 
 // ---- kernel launchers (defined in the .hip files) ----
+void dv_launch_pyr_apron(const DvPyr& a, const DvPyr* b, hipStream_t s);      // fills the reflect-101 apron of every level (after the levels themselves)
 void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int sh, int spitch,
                          uint8_t* dst0, uint8_t* dst1, int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch,
                          hipStream_t s);

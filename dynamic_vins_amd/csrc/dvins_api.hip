@@ -116,6 +116,7 @@ static int build_pyramids(dv_ctx* ctx, PyrSet& P0, PyrSet* P1, const uint8_t* im
         dv_launch_pyr_down2(s0, s1, a.L[l - 1].w, a.L[l - 1].h, sp, a.L[l].p, b ? b->L[l].p : nullptr, a.L[l].pitch,
                             fuse_copy ? a.L[0].p : nullptr, (fuse_copy && b) ? b->L[0].p : nullptr, a.L[0].pitch, s);
     }
+    dv_launch_pyr_apron(a, b, s);
     DV_CHECK(hipGetLastError());
     return 0;
 }

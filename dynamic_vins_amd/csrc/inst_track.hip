@@ -36,13 +36,13 @@ struct RoiPyr {          // pyramid storage with a fixed capacity (the full fram
         w = w_; h = h_;
         int n = 0, cw = w, ch = h; size_t off = 0;
         for (int l = 0; l < DV_MAX_LEVELS; ++l) {
-            pyr.L[n] = DvLevel{ (uint8_t*)buf.p + off, cw, ch, align_up(cw, 16) };
+            pyr.L[n] = DvLevel{ (uint8_t*)buf.p + off, cw, ch, align_up(cw, 16), 0 };
             off += (size_t)align_up(cw, 16) * ch; off = (off + 255) / 256 * 256; ++n;
             const int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
             if (nw <= DV_LK_WIN || nh <= DV_LK_WIN) break;
             cw = nw; ch = nh;
         }
-        for (int l = n; l < DV_MAX_LEVELS; ++l) pyr.L[l] = DvLevel{ nullptr, 0, 0, 0 };
+        for (int l = n; l < DV_MAX_LEVELS; ++l) pyr.L[l] = DvLevel{ nullptr, 0, 0, 0, 0 };
         pyr.levels = n;
     }
 };

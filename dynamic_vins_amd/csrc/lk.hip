@@ -66,7 +66,7 @@ __device__ __forceinline__ int lk_reflect101(int p, int len) {
 // inside the image the aligned dword path is taken (over-read bytes are never used).
 __device__ __forceinline__ void lk_stage_tile(uint8_t* lds, int pitch, int rows, const DvLevel& L, int ax0, int y0,
                                               int need_x0, int need_cols, int lane) {
-    const bool fast = need_x0 >= 0 && need_x0 + need_cols <= L.w && y0 >= 0 && y0 + rows <= L.h;
+    const bool fast = need_x0 >= -L.apron && need_x0 + need_cols <= L.w + L.apron && y0 >= -L.apron && y0 + rows <= L.h + L.apron;      // inside the image or its reflect-101 apron
     if (fast) {
         const int ndw = pitch >> 2;
         uint32_t* l32 = reinterpret_cast<uint32_t*>(lds);
@@ -77,7 +77,7 @@ __device__ __forceinline__ void lk_stage_tile(uint8_t* lds, int pitch, int rows,
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + 64 * u < rows * ndw ? i0 + 64 * u : i0;
                 const int r = i / ndw, c = i - r * ndw;
-                v[u] = *lk_g32(L.p + (size_t)(y0 + r) * L.pitch + ax0 + 4 * c);
+                v[u] = *lk_g32(L.p + (ptrdiff_t)(y0 + r) * L.pitch + ax0 + 4 * c);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (i0 + 64 * u < rows * ndw) l32[i0 + 64 * u] = v[u];
@@ -107,7 +107,7 @@ __device__ __forceinline__ void lk_stage_tile(uint8_t* lds, int pitch, int rows,
 #define LK_PRE_I 3      // dwords per lane: 24 rows x 7 dwords = 168 <= 3 x 64
 #define LK_PRE_J 5      // 32 rows x 9 dwords = 288 <= 5 x 64
 struct LkPre { int i_ok, j_ok, jx0, jy0; };
-__device__ __forceinline__ bool lk_tile_inside(const DvLevel& L, int x0, int cols, int y0, int rows) { return x0 >= 0 && x0 + cols <= L.w && y0 >= 0 && y0 + rows <= L.h; }
+__device__ __forceinline__ bool lk_tile_inside(const DvLevel& L, int x0, int cols, int y0, int rows) { return x0 >= -L.apron && x0 + cols <= L.w + L.apron && y0 >= -L.apron && y0 + rows <= L.h + L.apron; }
 // requests tile rows [y0, y0 + rows) x bytes [ax0, ax0 + pitch) of level L as dwords if the consumed columns [x0, x0 + cols) and the rows lie inside the image
 // (returns 1; else 0: border tiles are staged when they are needed — prefetching their 11 + 18 reflected bytes per lane as well cost 48 VGPRs, one wave per
 // SIMD less, and 4 % of the multi-sequence throughput for 10 % of this kernel's latency)
@@ -119,7 +119,7 @@ __device__ __forceinline__ int lk_prefetch(uint32_t (&v)[N], int pitch, int rows
     for (int u = 0; u < N; ++u) {
         const int i = lane + 64 * u < total ? lane + 64 * u : lane;
         const int r = i / ndw, c = i - r * ndw;
-        v[u] = *lk_g32(L.p + (size_t)(y0 + r) * L.pitch + ax0 + 4 * c);
+        v[u] = *lk_g32(L.p + (ptrdiff_t)(y0 + r) * L.pitch + ax0 + 4 * c);
     }
     return 1;
 }
@@ -360,10 +360,10 @@ __device__ __forceinline__ DvLevel lk_level_of(const DvPyr& P, int l) {      // 
     const DvLevel v = P.L[l]; DvLevel r;
     const unsigned long long a = (unsigned long long)v.p;
     r.p = (uint8_t*)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
-    r.w = __builtin_amdgcn_readfirstlane(v.w); r.h = __builtin_amdgcn_readfirstlane(v.h); r.pitch = __builtin_amdgcn_readfirstlane(v.pitch);
+    r.w = __builtin_amdgcn_readfirstlane(v.w); r.h = __builtin_amdgcn_readfirstlane(v.h); r.pitch = __builtin_amdgcn_readfirstlane(v.pitch); r.apron = __builtin_amdgcn_readfirstlane(v.apron);
     return r;
 }
-__device__ __forceinline__ DvLevel lk_pick(bool c, const DvLevel& a, const DvLevel& b) { DvLevel r; r.p = c ? a.p : b.p; r.w = c ? a.w : b.w; r.h = c ? a.h : b.h; r.pitch = c ? a.pitch : b.pitch; return r; }
+__device__ __forceinline__ DvLevel lk_pick(bool c, const DvLevel& a, const DvLevel& b) { DvLevel r; r.p = c ? a.p : b.p; r.w = c ? a.w : b.w; r.h = c ? a.h : b.h; r.pitch = c ? a.pitch : b.pitch; r.apron = c ? a.apron : b.apron; return r; }
 // FeatureTrackByLK fused: fwd (maxLevel 3) + bwd (maxLevel 1, initial flow) + distance + InBorder, for the wave's point p
 __device__ __forceinline__ void lk_track_point(const DvPyr& A, const DvPyr& B, const float2* __restrict__ pts_a, int p, int flow_back, float dist_thresh, double eps_sq,
                                                float2* __restrict__ pts_b, uint8_t* __restrict__ status, float add_x, float add_y, int use_add, uint8_t* sI, uint8_t* sJ, int lane) {

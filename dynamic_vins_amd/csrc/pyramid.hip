@@ -101,6 +101,29 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict
     }
 }
 
+// BORDER_REFLECT_101 apron of every level of one or two pyramids in ONE launch (blockIdx.y = level, blockIdx.z = image): with it no LK tile touches the
+// byte-wise border path (17 - 22 % of the tiles did, and the slowest point of a launch — which sets the launch's duration — was almost always one of them)
+__global__ __launch_bounds__(256) void pyr_apron_kernel(DvPyr a, DvPyr b) {
+    const DvPyr& P = blockIdx.z ? b : a;
+    if ((int)blockIdx.y >= P.levels) return;
+    const DvLevel L = P.L[blockIdx.y];
+    const int A = L.apron, w = L.w, h = L.h, W = w + 2 * A;
+    if (A <= 0) return;
+    const int top = A * W, mid = h * 2 * A, total = 2 * top + mid;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
+        int px, py;
+        if (k < top) { py = k / W; px = k - py * W; }
+        else if (k < top + mid) { const int k2 = k - top, r = k2 / (2 * A), c = k2 - r * 2 * A; py = A + r; px = c < A ? c : w + c; }
+        else { const int k3 = k - top - mid, r = k3 / W; py = A + h + r; px = k3 - r * W; }
+        const int x = px - A, y = py - A;
+        L.p[(ptrdiff_t)y * L.pitch + x] = L.p[(ptrdiff_t)pyr_reflect101(y, h) * L.pitch + pyr_reflect101(x, w)];
+    }
+}
+void dv_launch_pyr_apron(const DvPyr& a, const DvPyr* b, hipStream_t s) {
+    if (a.levels <= 0 || a.L[0].apron <= 0) return;
+    hipLaunchKernelGGL(pyr_apron_kernel, dim3(48, a.levels, b ? 2 : 1), dim3(256), 0, s, a, b ? *b : a);
+}
+
 void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int sh, int spitch, uint8_t* dst0, uint8_t* dst1,
                          int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch, hipStream_t s) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;

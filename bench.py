@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--mode", choices=["raw", "dynamic"], default="raw")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="zed")
     ap.add_argument("--every-second-frame", action="store_true", help="the reference's convention outside KITTI: only every 2nd tracked frame gets BA (system/main.cpp:300-307)")
+    ap.add_argument("--shard-transport", choices=["rccl", "peer", "host"], default=None, help="with --shard: ncclAllGather (default on RCCL), the one-shot peer-write exchange over hipIpc windows, or the host call-back")
     ap.add_argument("--shard", action="store_true", help="BA-only: one window sharded by landmark over the ranks (reduced-system all-reduce)")
     ap.add_argument("--sequences", type=int, default=1, help="S independent sequences per GPU interleaved by one host thread (aggregate rate; the default single-sequence line stays the headline)")
     ap.add_argument("--batched", action="store_true", help="with --sequences: the window solves of all sequences share every launch (dv_batch), one host thread")

@@ -120,6 +120,9 @@ SIGNATURES = {
     "dv_dist_unique_id": (C.c_int, [C.c_void_p]),
     "dv_dist_init_rccl": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
     "dv_dist_init_host": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "dv_dist_peer_prepare": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_void_p]),
+    "dv_dist_init_peer": (C.c_int, [_ctx, C.c_void_p]),
+    "dv_dist_rccl_ranks": (C.c_int, [_ctx, C.POINTER(C.c_int)]),
     "dv_dist_shutdown": (C.c_int, [_ctx]),
     "dv_dist_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "dv_allreduce_reduced_system": (C.c_int, [_ctx, C.c_void_p, C.c_int]),

@@ -8,9 +8,18 @@
 //   transport 1 (RCCL): ncclAllGather on the BA stream, ordered with the kernels around it; nothing is staged through the host.  librccl is resolved
 //                       at run time (dlopen), first among the libraries the process has already loaded (a torch process brings its own), so the
 //                       product library carries no link-time dependency on it.
+//   transport 3 (peer): the one-shot exchange of SURVEY 5: every rank WRITES its vector straight into a window each peer exposes (hipIpc mapping: over the
+//                       direct xGMI link between the two GPUs, one hop, no ring), then raises a per-sender sequence flag in that window; a rank's own wait
+//                       kernel spins on its local flags and copies the gathered vectors to the exchange buffer.  Two launches per exchange, no
+//                       library call, no host round trip.  142 KB per rank and exchange: latency-, not bandwidth-bound — which is the case ring
+//                       all-gathers are worst at (world - 1 steps).  The window is double-buffered by sequence parity: a rank that is one exchange
+//                       ahead writes the other half (it cannot be two ahead: exchange k + 2 needs every peer's flag k + 1, raised after that peer
+//                       consumed exchange k).  UNMEASURED on a multi-GPU node (this pool hands out one GPU at a time): tested world = 1 and two
+//                       processes sharing one GPU.
 //   transport 2 (host): the vector is copied to pinned memory, the caller's all-gather call-back runs (gloo, MPI, shared memory ...), the result is
 //                       copied back.  One stream synchronisation per exchange: for tests (two processes on one GPU) and for hosts without RCCL.
 #include <dlfcn.h>
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -27,6 +36,7 @@ struct Rccl {
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 }
@@ -48,6 +58,7 @@ static bool rccl_load(std::string& err) {
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    r.CommCount = (decltype(r.CommCount))dlsym(h, "ncclCommCount");
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllGather) { err = "dv_dist: librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllGather"; return false; }
     g_rccl = r;
     return true;
@@ -72,7 +83,54 @@ void be_dist_release(dv_ctx* ctx) {
     d.xsend.release(); d.xrecv.release();
     if (d.h_send) (void)hipHostFree(d.h_send);
     if (d.h_recv) (void)hipHostFree(d.h_recv);
+    for (int r = 0; r < 64; ++r) { if (d.peer_win[r] && d.peer_win[r] != d.win) (void)hipIpcCloseMemHandle(d.peer_win[r]); d.peer_win[r] = nullptr; }
+    if (d.win) (void)hipFree(d.win);
+    d.win = nullptr; d.win_slot = 0; d.seq = 0;
     d.h_send = d.h_recv = nullptr; d.transport = 0; d.rank = 0; d.world = 1; d.fn = nullptr; d.user = nullptr;
+}
+
+// ---- transport 3 ----
+#define PEER_MAX 64
+struct PeerArgs { double* win[PEER_MAX]; };      // every rank's window in this process's address space
+__host__ __device__ inline size_t peer_flag_off(size_t slot, int world) { return (2 * (size_t)world * slot * 8 + 255) / 256 * 256; }      // bytes
+// grid (chunks, world): block (b, r) writes this rank's vector into rank r's window, slot [parity][rank]
+__global__ __launch_bounds__(256) void peer_push_kernel(PeerArgs pa, const double* __restrict__ src, int count, size_t slot, int rank, int world, int parity) {
+    double* dst = pa.win[blockIdx.y] + ((size_t)parity * world + rank) * slot;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) dst[i] = src[i];
+}
+// block 0 first raises this rank's flag in every window (the push kernel before it on the stream has completed: its writes are visible system-wide); every
+// block then waits until all senders' flags in the LOCAL window carry this exchange's sequence number and copies the gathered vectors out
+__global__ __launch_bounds__(256) void peer_wait_kernel(PeerArgs pa, double* __restrict__ out, int count, size_t slot, int rank, int world, int parity, unsigned long long seq) {
+    const size_t foff = peer_flag_off(slot, world) / 8;
+    if (blockIdx.x == 0 && (int)threadIdx.x < world) {
+        unsigned long long* f = reinterpret_cast<unsigned long long*>(pa.win[threadIdx.x] + foff) + (size_t)parity * world + rank;
+        __hip_atomic_store(f, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    unsigned long long* mine = reinterpret_cast<unsigned long long*>(pa.win[rank] + foff);
+    if ((int)threadIdx.x < world) {
+        unsigned long long* f = mine + (size_t)parity * world + threadIdx.x;
+        long long spins = 0;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1ll << 24)) { __hip_atomic_store(mine + 2 * world, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }      // a peer died: give up (seconds), flag it (dv_dist_info)
+        }
+    }
+    __syncthreads();
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    const double* src = pa.win[rank] + (size_t)parity * world * slot;
+    for (int r = 0; r < world; ++r)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < count; i += gridDim.x * 256) out[(size_t)r * count + i] = src[(size_t)r * slot + i];
+}
+static int peer_exchange(dv_ctx* ctx, size_t count, hipStream_t s) {
+    DvDist& d = ctx->dist;
+    PeerArgs pa{};
+    for (int r = 0; r < d.world; ++r) pa.win[r] = (double*)d.peer_win[r];
+    const unsigned long long seq = ++d.seq; const int parity = (int)(seq & 1);
+    const int chunks = (int)std::min<size_t>(16, (count + 1023) / 1024);
+    hipLaunchKernelGGL(peer_push_kernel, dim3(chunks, d.world), dim3(256), 0, s, pa, (const double*)d.xsend.p, (int)count, d.win_slot, d.rank, d.world, parity);
+    hipLaunchKernelGGL(peer_wait_kernel, dim3(chunks), dim3(256), 0, s, pa, (double*)d.xrecv.p, (int)count, d.win_slot, d.rank, d.world, parity, seq);
+    DV_CHECK(hipGetLastError());
+    return 0;
 }
 
 int be_exchange(dv_ctx* ctx, size_t count, hipStream_t s) {
@@ -83,6 +141,7 @@ int be_exchange(dv_ctx* ctx, size_t count, hipStream_t s) {
         if (rc != 0) DV_FAIL("dv_dist: ncclAllGather: " + rccl_err(rc));
         return 0;
     }
+    if (d.transport == 3) return peer_exchange(ctx, count, s);
     if (d.transport == 2) {
         DV_CHECK(hipMemcpyAsync(d.h_send, d.xsend.p, 8 * count, hipMemcpyDeviceToHost, s));
         DV_CHECK(hipStreamSynchronize(s));
@@ -133,6 +192,51 @@ int dv_dist_init_host(dv_ctx* ctx, int rank, int world, dv_allgather_fn fn, void
     return be_dist_buffers(ctx);
 }
 
+// transport 3, step 1: allocate the window this rank exposes and hand out its IPC handle (64 bytes); the launcher all-gathers the handles
+int dv_dist_peer_prepare(dv_ctx* ctx, int rank, int world, uint8_t handle[64]) {
+    if (!ctx) return -1;
+    if (!handle || world < 1 || rank < 0 || rank >= world || world > PEER_MAX) DV_FAIL("dv_dist_peer_prepare: bad rank / world / handle");
+    if (ctx->be.pend->active) DV_FAIL("dv_dist_peer_prepare: a solve is in flight");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    be_dist_release(ctx);
+    DvDist& d = ctx->dist;
+    d.rank = rank; d.world = world; d.win_slot = (size_t)BE_XS_LEN(BE_MAX_LM);
+    const size_t bytes = peer_flag_off(d.win_slot, world) + (2 * (size_t)world + 1) * 8 + 256;
+    // fine-grained: remote writes and the local polling loads must be coherent inside a running kernel, not only at kernel boundaries
+    if (hipExtMallocWithFlags(&d.win, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); DV_CHECK(hipMalloc(&d.win, bytes)); }
+    DV_CHECK(hipMemset(d.win, 0, bytes));
+    hipIpcMemHandle_t h;
+    DV_CHECK(hipIpcGetMemHandle(&h, d.win));
+    std::memcpy(handle, &h, 64);
+    return 0;
+}
+// step 2: handles[world][64] in rank order (this rank's own entry is not opened)
+int dv_dist_init_peer(dv_ctx* ctx, const uint8_t* handles) {
+    if (!ctx) return -1;
+    DvDist& d = ctx->dist;
+    if (!handles || !d.win) DV_FAIL("dv_dist_init_peer: dv_dist_peer_prepare was not called");
+    if (ctx->be.pend->active) DV_FAIL("dv_dist_init_peer: a solve is in flight");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    for (int r = 0; r < d.world; ++r) {
+        if (r == d.rank) { d.peer_win[r] = d.win; continue; }
+        hipIpcMemHandle_t h; std::memcpy(&h, handles + 64 * (size_t)r, 64);
+        DV_CHECK(hipIpcOpenMemHandle(&d.peer_win[r], h, hipIpcMemLazyEnablePeerAccess));
+    }
+    d.transport = 3;
+    return be_dist_buffers(ctx);
+}
+
+// ranks of the RCCL communicator as the library itself reports them (ncclCommCount); 0 when the transport is not RCCL
+int dv_dist_rccl_ranks(dv_ctx* ctx, int* n) {
+    if (!ctx || !n) return -1;
+    *n = 0;
+    if (ctx->dist.transport != 1 || !ctx->dist.comm || !g_rccl.CommCount) return 0;
+    const int rc = g_rccl.CommCount(ctx->dist.comm, n);
+    if (rc != 0) DV_FAIL("dv_dist_rccl_ranks: ncclCommCount: " + rccl_err(rc));
+    return 0;
+}
+
 int dv_dist_shutdown(dv_ctx* ctx) {
     if (!ctx) return -1;
     if (ctx->be.pend->active) DV_FAIL("dv_dist_shutdown: a solve is in flight");
@@ -148,6 +252,12 @@ int dv_dist_info(dv_ctx* ctx, int* rank, int* world, int* transport, long long* 
     if (world) *world = ctx->dist.world;
     if (transport) *transport = ctx->dist.transport;
     if (exchanges) *exchanges = ctx->dist.exchanges;
+    if (ctx->dist.transport == 3 && ctx->dist.win) {      // a wait kernel gave up on a peer
+        unsigned long long flag = 0;
+        const size_t off = peer_flag_off(ctx->dist.win_slot, ctx->dist.world) + 2 * (size_t)ctx->dist.world * 8;
+        DV_CHECK(hipMemcpy(&flag, (const uint8_t*)ctx->dist.win + off, 8, hipMemcpyDeviceToHost));
+        if (flag) DV_FAIL("dv_dist: a peer did not deliver its exchange vector (transport peer: wait timed out)");
+    }
     return 0;
 }
 

@@ -141,12 +141,15 @@ int dv_inst_wait_before_next_frame(dv_ctx* ctx);
 
 // One window sharded by landmark over several GPUs (be_shard.hip): the transport of the exchange vectors
 struct DvDist {
-    int transport = 0;            // 0 none, 1 RCCL all-gather on the BA stream, 2 host call-back (staged through pinned memory)
+    int transport = 0;            // 0 none, 1 RCCL all-gather on the BA stream, 2 host call-back (staged through pinned memory), 3 one-shot peer writes (be_shard.hip)
     int rank = 0, world = 1;
     void* comm = nullptr;         // ncclComm_t
     dv_allgather_fn fn = nullptr; void* user = nullptr;
     DevBuf xsend, xrecv; void* h_send = nullptr; void* h_recv = nullptr;
     long long exchanges = 0;
+    // transport 3: the window this rank exposes to its peers (hipIpc): [2 parities][world][slot] doubles, then [2][world] sequence flags, then a time-out flag;
+    // peer_win[r] = rank r's window as mapped into this process (own window for r == rank)
+    void* win = nullptr; size_t win_slot = 0; void* peer_win[64] = { nullptr }; unsigned long long seq = 0;
 };
 int be_exchange(dv_ctx* ctx, size_t count, hipStream_t s);      // all-gather `count` doubles of dist.xsend into dist.xrecv (rank-major), ordered on s
 int be_dist_buffers(dv_ctx* ctx);

@@ -85,6 +85,8 @@ def shard_window(ctx, rank=None, world=None, transport="auto"):
     same problem to dv_ba_solve / dv_est_process.
       transport "rccl": ncclAllGather on the BA stream; the ncclUniqueId is created on rank 0 and broadcast through torch.distributed
       transport "host": the exchange vector is staged through pinned host memory and all-gathered by torch.distributed (gloo or nccl) — tests, 1-GPU boxes
+      transport "peer": the one-shot exchange — every rank writes its vector into the windows its peers expose (hipIpc over the direct xGMI links); the
+                        64-byte window handles are all-gathered once through torch.distributed
       "auto": rccl when the process group's backend is nccl, host otherwise."""
     import ctypes as C
     import numpy as np
@@ -97,6 +99,21 @@ def shard_window(ctx, rank=None, world=None, transport="auto"):
         # a lone rank has nothing to exchange: the host transport needs no librccl; rccl only where the process group really is RCCL
         transport = "rccl" if (dist.is_initialized() and world > 1 and dist.get_backend() == "nccl") else "host"
     lib = ctx.lib
+    if transport == "peer":
+        mine = np.zeros(64, np.uint8)
+        if lib.dv_dist_peer_prepare(ctx.h, rank, world, mine.ctypes.data) != 0:
+            raise _abi.DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+        handles = np.zeros((world, 64), np.uint8)
+        handles[rank] = mine
+        if dist.is_initialized() and world > 1:
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+            parts = [torch.empty(64, dtype=torch.uint8, device=dev) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(mine).to(dev))
+            handles = np.stack([t.cpu().numpy() for t in parts])
+        handles = np.ascontiguousarray(handles)
+        if lib.dv_dist_init_peer(ctx.h, handles.ctypes.data) != 0:
+            raise _abi.DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+        return None
     if transport == "rccl":
         uid = np.zeros(128, np.uint8)
         if rank == 0 and lib.dv_dist_unique_id(uid.ctypes.data) != 0:
@@ -143,8 +160,12 @@ def shard_window(ctx, rank=None, world=None, transport="auto"):
 def dist_info(ctx):
     import ctypes as C
     r, w, t, e = C.c_int(0), C.c_int(0), C.c_int(0), C.c_longlong(0)
-    ctx.lib.dv_dist_info(ctx.h, C.byref(r), C.byref(w), C.byref(t), C.byref(e))
-    return dict(rank=r.value, world=w.value, transport={0: "none", 1: "rccl", 2: "host"}[t.value], exchanges=e.value)
+    if ctx.lib.dv_dist_info(ctx.h, C.byref(r), C.byref(w), C.byref(t), C.byref(e)) != 0:
+        from . import _abi
+        raise _abi.DvinsError(ctx.lib.dv_last_error(ctx.h).decode())
+    n = C.c_int(0)
+    ctx.lib.dv_dist_rccl_ranks(ctx.h, C.byref(n))
+    return dict(rank=r.value, world=w.value, transport={0: "none", 1: "rccl", 2: "host", 3: "peer"}[t.value], exchanges=e.value, rccl_ranks=n.value)
 
 
 def whole_job_rate(units_per_rank, world, seconds_max):

@@ -30,7 +30,7 @@ def run_shard_bench(args, rank, world, local_rank):
     def run(sharded, collective):
         pipe = Pipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"])
         if sharded:
-            dv_dist.shard_window(pipe.ctx, rank, world, transport="host" if gloo else "rccl")
+            dv_dist.shard_window(pipe.ctx, rank, world, transport=getattr(args, "shard_transport", None) or ("host" if gloo else "rccl"))
         for _ in range(warm_ba):
             pipe.step()
         gc.collect(); gc.freeze()      # no generation-2 pause of the interpreter inside a timed block (bench.py)
@@ -74,7 +74,7 @@ def run_shard_bench(args, rank, world, local_rank):
                "config": {"workload": f"synthetic {w}x{h} stereo @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "") + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame",
                           "mode": "raw", "config": args.config, "git_head": git_head(),
                           "parallelism": f"ONE sequence; its window solve sharded by landmark over {world} rank(s): {info['transport']} all-gather + rank-ordered sum per linearisation; front end replicated",
-                          "landmarks_in_window": n_lm, "landmarks_per_rank": cap, "exchanges_per_frame": round(info["exchanges"] / frames_total, 2),
+                          "transport": info["transport"], "rccl_ranks": info["rccl_ranks"], "landmarks_in_window": n_lm, "landmarks_per_rank": cap, "exchanges_per_frame": round(info["exchanges"] / frames_total, 2),
                           "exchange_bytes_per_rank": 8 * xlen, "all_ranks_same_trajectory_bits": bool(same), "ate_rmse_m_vs_ground_truth": round(ate, 5),
                           "second_block_value": round(args.steps / times[1], 2),
                           "unsharded_value_same_process": round(args.steps / plain_times[0], 2), "unsharded_second_block_value": round(args.steps / plain_times[1], 2),

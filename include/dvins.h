@@ -215,6 +215,11 @@ typedef int (*dv_allgather_fn)(void* user, const void* send, void* recv, size_t 
 int dv_dist_unique_id(uint8_t id[128]);                                                  /* ncclGetUniqueId: rank 0 creates it, the launcher broadcasts it */
 int dv_dist_init_rccl(dv_ctx* ctx, int rank, int world, const uint8_t id[128]);          /* RCCL all-gather on the BA stream (xGMI); no host round trip per iteration */
 int dv_dist_init_host(dv_ctx* ctx, int rank, int world, dv_allgather_fn fn, void* user); /* exchange staged through pinned host memory and the caller's all-gather */
+/* one-shot exchange: every rank writes its vector into a window each peer exposes through hipIpc (direct xGMI link), then a sequence flag; no
+ * library call per exchange.  prepare -> all-gather the 64-byte handles with the launcher's own means -> init. */
+int dv_dist_peer_prepare(dv_ctx* ctx, int rank, int world, uint8_t handle[64]);
+int dv_dist_init_peer(dv_ctx* ctx, const uint8_t* handles /* [world][64], rank order */);
+int dv_dist_rccl_ranks(dv_ctx* ctx, int* n);                                             /* ncclCommCount of the communicator behind dv_dist_init_rccl (0: other transport) */
 int dv_dist_shutdown(dv_ctx* ctx);
 int dv_dist_info(dv_ctx* ctx, int* rank, int* world, int* transport, long long* exchanges);
 /* operator form of the exchange: S_g (host, n doubles — this rank's partial [S | g | cost], e.g. of dv_ba_eval on the rank's share of the landmarks)

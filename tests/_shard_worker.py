@@ -1,5 +1,6 @@
 """worker of tests/test_sharded_solve.py (GPU box):  python -m torch.distributed.run --nproc-per-node 2 tests/_shard_worker.py OUT
-Two processes share the one GPU; the exchange vectors travel through the host transport (pinned memory + gloo all-gather).  Each rank solves every
+Two processes share the one GPU; the exchange vectors travel through the host transport (pinned memory + gloo all-gather) or, argv[2] = peer, through the
+one-shot peer transport (each rank writes into the window the other exposes through hipIpc).  Each rank solves every
 problem twice — sharded (its ctx is one rank of the window) and unsharded (a second, plain ctx) — and writes both for the parent to compare."""
 import os
 import sys
@@ -17,7 +18,7 @@ rank, world, _ = dv_dist.init(prefer_gpu=False)        # gloo: the two ranks sha
 oracle = oracle_py.load()                               # ba_gen pre-integrates the IMU factors with the oracle's integrator (test infrastructure)
 shard = Context(width=64, height=64, max_cnt=10, min_dist=5)
 plain = Context(width=64, height=64, max_cnt=10, min_dist=5)
-dv_dist.shard_window(shard, rank, world, transport="host")
+dv_dist.shard_window(shard, rank, world, transport=sys.argv[2] if len(sys.argv) > 2 else "host")
 out = {}
 
 CASES = [dict(seed=2, with_prior=True), dict(seed=6, nlm=300, max_iters=10, with_prior=True), dict(seed=3, use_imu=0, nframes=7), dict(seed=9, nlm=1, max_iters=3),

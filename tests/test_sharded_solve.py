@@ -1,8 +1,9 @@
 """The landmark-sharded window solve (include/dvins.h dv_dist_*), `-m gpu`.
 
-(1) one process, world 1, through BOTH transports (RCCL all-gather on the BA stream; host call-back): the sharded kernels (owned-range evaluation and
+(1) one process, world 1, through every transport (RCCL all-gather on the BA stream; host call-back; one-shot peer writes): the sharded kernels (owned-range evaluation and
     reduction, exchange vector, rank-ordered finalize, cost exchange) against the unsharded solve — same iteration sequence, states within 1e-12;
-(2) two processes on the one GPU (torch.distributed.run, gloo, host transport): every rank returns the SAME bits, and the sharded solve reproduces the
+(2) two processes on the one GPU (torch.distributed.run, gloo; host transport, and the one-shot peer transport whose windows the two processes map into
+    each other through hipIpc): every rank returns the SAME bits, and the sharded solve reproduces the
     unsharded one to 1e-9 on operator-level windows (with / without prior, VO, 1 / 0 / 300 / 1000 landmarks) and through the estimator's fused path
     (solve + gauge fix + marginalization, device-resident prior) over 30 frames.
 RCCL refuses two ranks on one device, so the RCCL transport with world > 1 is exercised by bench.py --shard on a multi-GPU node only."""
@@ -20,7 +21,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("transport", ["rccl", "host"])
+@pytest.mark.parametrize("transport", ["rccl", "host", "peer"])
 def test_world_one_sharded_path_matches_plain(gpu_ctx_factory, oracle, transport):
     from dynamic_vins_amd import dist as dv_dist
     from dynamic_vins_amd.backend import ba_eval, ba_solve
@@ -55,14 +56,15 @@ def _free_port():
     return p
 
 
-def test_two_ranks_on_one_gpu_reproduce_the_unsharded_solve(tmp_path):
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_two_ranks_on_one_gpu_reproduce_the_unsharded_solve(tmp_path, transport):
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_shard_worker.py"), str(tmp_path)]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_shard_worker.py"), str(tmp_path), transport]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     R = [np.load(tmp_path / f"shard_rank{k}.npz") for k in range(2)]

@@ -154,7 +154,7 @@ static int marg_plan(dv_ctx* ctx, MargPlan& pl, int mode, const dv_ba_prior* pri
 }
 
 // launches the three kernels; the index tables must already be (enqueued to be) in w.marg_tab
-static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, double* c0_out, hipStream_t s) {
+static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, double* c0_out, hipStream_t s, hipStream_t c0_side = nullptr) {
     BeWork& w = ctx->be;
     BeMargArgs ma{};
     ma.x = x; ma.nframes = BE_NF; ma.nlm = pl.nsel; ma.nimu = pl.nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
@@ -171,10 +171,20 @@ static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, doubl
     ma.lm_h = ma.sum + slab; ma.imu_w = ma.lm_h + nl; ma.anchor = 0;
     for (int k = 0; k < BE_NF; ++k) ma.pose_dim[k] = pl.pose_dim[k];
     ma.ex_dim[0] = pl.ex_dim[0]; ma.ex_dim[1] = pl.ex_dim[1]; ma.td_dim = pl.td_dim;
-    StageScope sc(ctx, "k_be_marg", s);
-    const int rc = be_launch_marg(ma, s);
-    if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");
-    if (rc) DV_FAIL("dv_marginalize: cannot set dynamic LDS size");
+    ma.c0_mode = c0_side ? 1 : 0;
+    {
+        StageScope sc(ctx, "k_be_marg", s);
+        const int rc = be_launch_marg(ma, s);
+        if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");
+        if (rc) DV_FAIL("dv_marginalize: cannot set dynamic LDS size");
+    }
+    if (c0_side) {      // c0 = b'^T A'^+ b' (a third of the marginalization's time) is needed by the next frame's first evaluation only: on a side stream, beside the
+                        // host turnaround and the next upload (be_begin_impl waits for ev_c0)
+        DV_CHECK(hipEventRecord(w.ev_margA, s));
+        DV_CHECK(hipStreamWaitEvent(c0_side, w.ev_margA, 0));
+        be_launch_marg_c0(ma, c0_side);
+        DV_CHECK(hipGetLastError());
+    }
     return 0;
 }
 
@@ -274,9 +284,16 @@ static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
     }
     DV_CHECK(hipEventRecord(w.ev_state, s));
     if (pd.fused_present && pd.do_marg && !pd.pl.empty) {
-        if (marg_enqueue(ctx, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], w.marg_scal, w.prior_c0 + pd.nxt, s)) return -1;
+        const bool side = w.c0_side && !(ctx->timing && ctx->kernel_timing);      // (the per-kernel timing mode keeps the whole marginalization on the BA stream: k_be_marg)
+        if (side && !w.c0_stream) {
+            DV_CHECK(hipStreamCreateWithFlags(&w.c0_stream, hipStreamNonBlocking));
+            DV_CHECK(hipEventCreateWithFlags(&w.ev_margA, hipEventDisableTiming)); DV_CHECK(hipEventCreateWithFlags(&w.ev_c0, hipEventDisableTiming));
+        }
+        hipStream_t cs = side ? w.c0_stream : s;
+        if (marg_enqueue(ctx, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], w.marg_scal, w.prior_c0 + pd.nxt, s, side ? w.c0_stream : nullptr)) return -1;
         double* hscal = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl)) + 4 * pd.scal_slot;      // two alternating host slots
-        DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, s));
+        DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, cs));
+        if (side) { DV_CHECK(hipEventRecord(w.ev_c0, cs)); w.c0_pending = true; }
         pd.marg_in_flight = true;
     }
     return 0;
@@ -387,6 +404,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     if (P->nlm) std::memcpy(hp + w.up_lm, P->landmarks, sizeof(BeLm) * (size_t)P->nlm);
     if (P->nfac && (const void*)P->factors != (const void*)(hp + w.up_fac)) std::memcpy(hp + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac);      // the estimator builds the table in place
     DV_CHECK(hipMemcpyAsync(w.block.p, hp, w.up_fac + sizeof(BeFactor) * (size_t)P->nfac, hipMemcpyHostToDevice, s));
+    if (w.c0_pending) { DV_CHECK(hipStreamWaitEvent(s, w.ev_c0, 0)); w.c0_pending = false; }      // the previous frame's c0 (side stream) and its health scalars: before anything reads the prior's constant
     if (has_prior && !prior_on_device) {               // a prior handed over in host memory (the estimator's stays in HBM)
         if (!P->prior_A || !P->prior_b) DV_FAIL("dv_ba_solve: prior without A / b");
         DV_CHECK(hipMemcpyAsync(w.priorA_buf[w.prior_cur], P->prior_A, 8 * (size_t)ph.n * ph.n, hipMemcpyHostToDevice, s));
@@ -722,6 +740,7 @@ int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return -1;
     if (std::strcmp(key, "short_first_pass") == 0) { ctx->be.debug_short_first_pass = value != 0; return 0; }
     if (std::strcmp(key, "two_level") == 0) { ctx->be.two_level = value != 0; return 0; }
+    if (std::strcmp(key, "c0_side") == 0) { ctx->be.c0_side = value != 0; return 0; }      // 0: the prior's constant c0 is computed on the BA stream, inside be_marg_finish (rounds 1-2)
     if (std::strcmp(key, "ldl_wavecol") == 0) { ctx->be.ldl_wavecol_only = value != 0; return 0; }      // the round-2 wave-column LDL^T instead of the 16-wide MFMA form
     if (std::strcmp(key, "ldl_generic") == 0) { ctx->be.ldl_generic = value != 0; return 0; }      // the block-column-major LDL^T mapping instead of the wave-column one
     DV_FAIL(std::string("dv_debug_set: unknown key ") + key);

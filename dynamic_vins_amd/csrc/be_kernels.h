@@ -71,6 +71,7 @@ struct BeMargArgs {
     double* outA; double* outb; double* out_scalars;     // n x n, n, {c0, min pivot, failure flag, rank}
     double* W; double* part; double* psum;                // be_marg_lm -> be_marg_sum: w_l | g_l | 1 / h_l per landmark [nlm][be_marg_wstride(D)]; structured block sums per landmark chunk [chunks][be_marg_part()]; their sum over chunks
     int pose_dim[BE_NF], ex_dim[2], td_dim;               // first dim of each block in the system, -1 = absent (what dim_slot / dim_comp tabulate)
+    int c0_mode;                                           // be_marg_finish: 0 everything; 1 all but c0 (A', b', pivot health); 2 c0 only, from A', b' in outA / outb (the side-stream launch)
     double* sum; double* lm_h; int anchor;                // A_lm | b_lm dense (D*D + D); per-landmark h; the frame the landmarks are anchored in (= the dropped one)
     double* imu_w;                // [465] whitened Jacobian (15 x 30) and residual (15) of the IMU factor (0,1): written by the extra block of be_marg_lm, read by be_marg_finish
     double* c0_out;               // optional second home of c0 (the device-resident prior of the estimator)
@@ -181,6 +182,7 @@ __device__ __forceinline__ void be_accept_body(const BeSolveArgs& a) {
 #define BE_EVAL_CAND_FULL 2 // full evaluation at cand into set cur ^ 1 + costs (runs if pending)
 void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s);
 int  be_launch_marg(const BeMargArgs& a, hipStream_t s);
+int  be_launch_marg_c0(const BeMargArgs& a, hipStream_t s);      // the c0 = b'^T A'^+ b' part alone (BeMargArgs::c0_mode is set to 2)
 int  be_marg_chunks(int nlm);      // workgroups of be_marg_lm for nlm landmarks
 int  be_marg_part();               // doubles per chunk in BeMargArgs::part
 int  be_marg_wstride(int D);       // doubles per landmark in BeMargArgs::W

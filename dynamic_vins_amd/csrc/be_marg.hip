@@ -353,6 +353,11 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     double* imu_ws = misc + 16;                           // 960: raw / whitened Jacobian and residual of the IMU factor (its own region: prepared beside the phases below)
     const BeState* st = a.x;
     MTS(8);
+    if (a.c0_mode == 2) {                               // side-stream launch: A', b' come back from global memory, then straight to the c0 factorisation
+        for (int e = tid; e < n * n; e += MG_THREADS) W2[e] = a.outA[e];
+        for (int i = tid; i < n; i += MG_THREADS) yv[i] = a.outb[i];
+        __syncthreads();
+    } else {
     // The last wave takes no share of the assembly below: it fetches the whitened IMU factor (0,1) that the extra block of be_marg_lm has prepared (the raw
     // evaluation on ONE lane and the whitening used to be a 9 us phase of this kernel, behind the prior).
     const int MGW = MG_THREADS - 64;                      // worker threads of the assembly
@@ -541,7 +546,12 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     MTS(14);
     for (int e = tid; e < n * n; e += MG_THREADS) a.outA[e] = W2[e];
     for (int i = tid; i < n; i += MG_THREADS) a.outb[i] = yv[i];
+    if (a.c0_mode == 1) {                               // c0 follows on a side stream (be_launch_marg_c0): the new prior's A', b' are what the BA stream waits for
+        if (tid == 0) { a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; }
+        return;
+    }
     __syncthreads();
+    }
     MTS(15);
     // ---------------- c0 = b'^T A'^+ b': LDL^T on the lower triangle, pivots <= 1e-8 skipped, one barrier per step ----------------
     // 4-column panels (the matrix stays in LDS): (A) thread 0 factors the 4x4 pivot block, skipping pivots <= 1e-8 (their columns drop out),
@@ -600,7 +610,10 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
     __syncthreads();
     c0 = misc[2]; rank = (int)misc[3];
     MTS(16);
-    if (tid == 0) { a.out_scalars[0] = c0; a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; a.out_scalars[3] = (double)rank; if (a.c0_out) a.c0_out[0] = c0; }
+    if (tid == 0) {
+        a.out_scalars[0] = c0; a.out_scalars[3] = (double)rank; if (a.c0_out) a.c0_out[0] = c0;
+        if (a.c0_mode != 2) { a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -672,6 +685,11 @@ int be_marg_chunks(int nlm) { return (nlm + MG_CH - 1) / MG_CH; }
 int be_marg_part() { return MG_PART; }
 int be_marg_wstride(int D) { return mg_wstride(D); }
 
+int be_launch_marg_c0(const BeMargArgs& a0, hipStream_t s) {
+    BeMargArgs a = a0; a.c0_mode = 2;
+    hipLaunchKernelGGL(be_marg_finish_kernel, dim3(1), dim3(MG_THREADS), finish_smem(a.D, a.D - a.m), s, a);
+    return 0;
+}
 int be_launch_marg(const BeMargArgs& a, hipStream_t s) {
     static DevOnce once;
     if (once.run([] {

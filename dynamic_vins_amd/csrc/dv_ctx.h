@@ -101,6 +101,7 @@ struct BeWork {
     double* priorA_buf[2] = { nullptr, nullptr }; double* priorb_buf[2] = { nullptr, nullptr }; int prior_cur = 0;      // double-buffered prior (A', b')
     bool prior_resident = false;      // true: buffer prior_cur holds the estimator's current prior (written by the fused marginalization)
     hipEvent_t ev_state = nullptr;    // recorded behind the download of the solved states (the marginalization runs on past it)
+    hipStream_t c0_stream = nullptr; hipEvent_t ev_margA = nullptr, ev_c0 = nullptr; bool c0_side = false, c0_pending = false;     // dv_debug_set "c0_side": the prior's constant c0 on a side stream (be_api.hip marg_enqueue); measured SLOWER (969-977 against 1008 frames/s: the two cross-stream event waits cost more than the 33 us they hide), so off
     double* prior_c0 = nullptr;       // [2] the prior's constant c0 per buffer, device resident
     int32_t* marg_tab = nullptr; double* marg_scal = nullptr;      // marginalization index tables (inside the upload region) and its 4 result scalars
     long long marg_checked = 0; double marg_last[4] = { 0, 0, 0, 0 };      // marginalizations whose health scalars came back, and the last set (c0, smallest pivot of A_mm, clamp flag, rank)

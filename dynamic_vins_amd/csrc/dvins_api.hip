@@ -185,6 +185,9 @@ void dv_destroy(dv_ctx* ctx) {
     if (ctx->inst) dv_inst_destroy_internal(ctx->inst);
     if (ctx->est) dv_est_destroy_internal(ctx->est);
     be_dist_release(ctx);
+    if (ctx->be.c0_stream) { (void)hipStreamSynchronize(ctx->be.c0_stream); (void)hipStreamDestroy(ctx->be.c0_stream); }
+    if (ctx->be.ev_margA) (void)hipEventDestroy(ctx->be.ev_margA);
+    if (ctx->be.ev_c0) (void)hipEventDestroy(ctx->be.ev_c0);
     ctx->be.block.release(); ctx->be.marg_buf.release();
     if (ctx->be.pinned) (void)hipHostFree(ctx->be.pinned);
     ctx->obj_buf.release(); ctx->obj_pend.release(); ctx->obj_op_pend.release();

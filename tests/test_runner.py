@@ -36,3 +36,26 @@ def test_runner_equals_python_pipeline(group_size, threads):
     runner.close()
     for p in pipes + ref:
         p.ctx.close()
+
+
+def test_batch_stage_timing_leaves_the_results_alone():
+    """dv_runner_batch_timing / dv_batch_timing (the batched regime's roofline line): HIP events around one steady-state slot of every round — positive stage
+    times, a round count, the windows of a launch; and the run with the events on leaves the same bits as the run without them"""
+    from dynamic_vins_amd.backend import Runner
+    frames = 26
+    seqs, pipes = make(3, frames)
+    _, plain = make(3, frames)
+    timed = Runner(pipes, group_size=3, threads=1)
+    ref = Runner(plain, group_size=3, threads=1)
+    timed.run(13); ref.run(13)
+    t_ms, rounds, wins = timed.batch_timing(1)
+    assert rounds == 0                                   # switched on just now
+    timed.run(frames - 14); ref.run(frames - 14)
+    t_ms, rounds, wins = timed.batch_timing(1)
+    assert rounds >= 5 and wins == 3 and (t_ms > 0).all() and (t_ms < 5.0).all(), (t_ms, rounds, wins)
+    for i in range(3):
+        a, b = timed.get(i), ref.get(i)
+        assert np.array_equal(a[1], b[1]) and np.array_equal(np.ctypeslib.as_array(a[0].window), np.ctypeslib.as_array(b[0].window))
+    timed.close(); ref.close()
+    for p in pipes + plain:
+        p.ctx.close()

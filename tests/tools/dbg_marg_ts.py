@@ -25,8 +25,8 @@ ts = (C.c_longlong * 32)()
 lib.dv_debug_marg_ts.argtypes = [C.POINTER(C.c_longlong)]
 assert lib.dv_debug_marg_ts(ts) == 0
 t = list(ts)
-for a, b_, name in [(0, 1, "lm: tables + frame geometry"), (1, 2, "lm: factor evaluation"), (2, 3, "lm: dense rows"), (3, 4, "lm: w, g"), (4, 5, "lm: slab"),
-                    (8, 9, "finish: load chunk sums"), (9, 10, "finish: prior"), (10, 11, "finish: IMU"), (11, 13, "finish: panel LDL^T of the dropped block"),
+for a, b_, name in [(0, 1, "lm: tables + frame geometry"), (1, 2, "lm: residual blocks"), (2, 3, "lm: matrix-core sums"), (3, 4, "lm: w rows (pose columns)"), (4, 5, "lm: per-frame blocks"),
+                    (6, 7, "sum: operands + rank term"), (7, 18, "sum: exchange + store"), (8, 9, "finish: load rank term + structured sums"), (9, 10, "finish: prior"), (10, 11, "finish: IMU"), (11, 13, "finish: panel LDL^T of the dropped block"),
                     (13, 14, "finish: copy A', b'"), (14, 15, "finish: write"), (15, 16, "finish: c0 LDL^T")]:
     print("%-32s %8.2f us" % (name, (t[b_] - t[a]) / 100.0))
 ctx.close()

@@ -87,6 +87,8 @@ SIGNATURES = {
     "dv_est_process_end": (C.c_int, [_ctx, C.c_void_p]),
     "dv_est_process_dynamic": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_est_process_dynamic_begin": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "dv_est_process_dynamic_begin_ego": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double]),
+    "dv_est_process_dynamic_attach": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "dv_est_set_lines": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "dv_est_get_lines": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_undistort_lines": (C.c_int, [_ctx, C.POINTER(dv_cam), C.c_void_p, C.c_int, C.c_void_p]),

@@ -373,6 +373,14 @@ class Estimator:
         self._rows = np.ascontiguousarray(rows)
         return self._check(self.ctx.lib.dv_est_process_dynamic_begin(self.ctx.h, self._rows.ctypes.data, len(self._rows), float(t), *self._dyn_args(insts, inst_feats, points)))
 
+    def ProcessMeasurementsDynamicBeginEgo(self, rows, t):
+        """three-phase form: the window solve goes to the GPU with the background rows alone; AttachInstances follows while it is in flight"""
+        self._rows = np.ascontiguousarray(rows)
+        return self._check(self.ctx.lib.dv_est_process_dynamic_begin_ego(self.ctx.h, self._rows.ctypes.data, len(self._rows), float(t)))
+
+    def AttachInstances(self, insts, inst_feats, points):
+        return self._check(self.ctx.lib.dv_est_process_dynamic_attach(self.ctx.h, *self._dyn_args(insts, inst_feats, points)))
+
     def instances(self, cap=64):
         """Estimator::im.instances (ascending id) -> (INSTSTATE_DTYPE array, [iterations, termination, initial_cost, final_cost] of the last object solve)"""
         from .dynsim import INSTSTATE_DTYPE

@@ -73,6 +73,9 @@ void dv_launch_viode_mask(const uint8_t* seg, int w, int h, int spitch, const ui
 void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters,
                           double eps_sq, int use_initial, float2* pts_b, uint8_t* status, hipStream_t s);
 // one job of dv_launch_lk_track_multi (device-resident table): FeatureTrackByLK of one object's points between its two pyramids
+// one level step of one image pair for dv_launch_pyr_down_multi (src1 / dst1 may be null: single image)
+struct DvPyrJob { const uint8_t* src0; const uint8_t* src1; uint8_t* dst0; uint8_t* dst1; int sw, sh, spitch, dw, dh, dpitch; };
+void dv_launch_pyr_down_multi(const DvPyrJob* jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t s);
 struct DvLkJob { DvPyr A, B; const float2* pts_a; const int* n_dev; float2* pts_b; uint8_t* status; float add_x, add_y; int use_add, pad; };
 void dv_launch_lk_track_multi(const DvLkJob* jobs_dev, int n_jobs, int n_max, int flow_back, float dist_thresh, hipStream_t s);
 void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max,

@@ -628,8 +628,9 @@ struct dv_estimator {
         { HostScope h1(ctx, "h_dyn_reject"); im.outliers_rejection(body_view()); }
         return 0;
     }
+    bool dyn_deferred = false;      // dv_est_process_dynamic_begin_ego: the object branch of this frame comes with dv_est_process_dynamic_attach
     int process_image_begin(dv_ctx* ctx, const dv_feat* feats, int n, double header, const dv_inst_obs* insts = nullptr, int n_insts = 0, const dv_feat* inst_feats = nullptr,
-                            const double* points = nullptr) {      // ProcessImage (estimator.cpp:1516-1696), up to and including the enqueue of the window solve
+                            const double* points = nullptr, bool defer_dynamic = false) {      // ProcessImage (estimator.cpp:1516-1696), up to and including the enqueue of the window solve
         { HostScope h(ctx, "h_add_features");
           if (cfg.use_line) { lines.add(frame, pending_lines.data(), (int)pending_lines.size()); pending_lines.clear(); }
           margin_old = add_features(frame, feats, n); }
@@ -637,7 +638,7 @@ struct dv_estimator {
         frame_pre.push_back(std::shared_ptr<Preint>(tmp_pre.release()));
         if (frame_pre.size() > (size_t)kWin + 1 && nonlinear) frame_pre.erase(frame_pre.begin());
         tmp_pre = std::make_unique<Preint>(acc_0, gyr_0, Bas[frame], Bgs[frame], noise());
-        in_flight = false; dyn_frame = false;
+        in_flight = false; dyn_frame = false; dyn_deferred = false;
         if (!nonlinear) return init_estimator(ctx);      // initialisation: synchronous
         if (!cfg.use_imu) pnp_frame(frame);
         { HostScope h(ctx, "h_triangulate"); triangulate(); if (cfg.use_line) lines.triangulate(Rs, Ps, ric[0], tic[0]); }
@@ -649,12 +650,14 @@ struct dv_estimator {
         if (optimization_begin(ctx)) return -1;
         in_flight = true;
         dyn_frame = cfg.dynamic != 0;
+        if (dyn_frame && defer_dynamic) { dyn_deferred = true; return 0; }
         if (dyn_frame && dynamic_branch(ctx, insts, n_insts, inst_feats, points)) return -1;
         return 0;
     }
     int process_image_end(dv_ctx* ctx) {
         if (!in_flight) return 0;
         in_flight = false;
+        if (dyn_frame && dyn_deferred) { dyn_deferred = false; if (dynamic_branch(ctx, nullptr, 0, nullptr, nullptr)) return -1; }      // never attached: a frame without objects
         if (dyn_frame && dynamic_branch_finish(ctx)) return -1;      // before optimization_end: Rs / Ps are still the states the reference's object branch saw
         if (optimization_end(ctx)) return -1;
         if (dyn_frame) im.touch_in_main_optimization();      // AddInstanceParameterBlock / im.GetOptimizationParameters inside Estimator::Optimization
@@ -763,14 +766,14 @@ int dv_est_get_landmarks(dv_ctx* ctx, dv_landmark* out, int cap, int* n_out) {
     *n_out = k;
     return 0;
 }
-static int est_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {
+static int est_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points, bool defer_dynamic = false) {
     if (!ctx) return -1;
     if (!ctx->est) DV_FAIL("dv_est_process: call dv_est_create first");
     dv_estimator& E = *ctx->est;
     if (E.begun) DV_FAIL("dv_est_process_begin: previous frame not collected (dv_est_process_end)");
     E.cur_time = t + E.td;
     { HostScope h(ctx, "h_imu"); if (E.cfg.use_imu && !E.add_imu_until(E.cur_time)) return 1; }       // "wait for imu" (estimator.cpp:1801-1805)
-    { HostScope h(ctx, "h_process_begin"); if (E.process_image_begin(ctx, feats, n, t, insts, n_insts, inst_feats, points)) return -1; }
+    { HostScope h(ctx, "h_process_begin"); if (E.process_image_begin(ctx, feats, n, t, insts, n_insts, inst_feats, points, defer_dynamic)) return -1; }
     E.begun = true;
     return 0;
 }
@@ -783,6 +786,30 @@ int dv_est_process_dynamic_begin(dv_ctx* ctx, const dv_feat* feats, int n, doubl
         if (insts[i].n_feats < 0 || insts[i].n_points < 0 || (insts[i].n_feats > 0 && !inst_feats) || (insts[i].n_points > 0 && !points)) DV_FAIL("dv_est_process_dynamic: bad instance record");
     }
     return est_begin(ctx, feats, n, t, insts, n_insts, inst_feats, points);
+}
+static int check_insts(dv_ctx* ctx, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {
+    if (n_insts < 0 || (n_insts > 0 && !insts)) DV_FAIL("dv_est_process_dynamic: bad instance list");
+    for (int i = 0; i < n_insts; ++i) {
+        if (insts[i].n_feats < 0 || insts[i].n_points < 0 || (insts[i].n_feats > 0 && !inst_feats) || (insts[i].n_points > 0 && !points)) DV_FAIL("dv_est_process_dynamic: bad instance record");
+    }
+    return 0;
+}
+// three-phase form: the window solve is enqueued with the background features alone (_begin_ego); the frame's instances follow (_attach: the object branch, host
+// bookkeeping + dv_obj_solve on the third stream) while it is in flight — whatever the caller does between the two calls (enqueueing the next frame's tracking,
+// collecting the object tracker) no longer sits in front of the window solve
+int dv_est_process_dynamic_begin_ego(dv_ctx* ctx, const dv_feat* feats, int n, double t) {
+    if (!ctx) return -1;
+    if (ctx->est && !ctx->est->cfg.dynamic) DV_FAIL("dv_est_process_dynamic: the estimator was created with dynamic = 0");
+    return est_begin(ctx, feats, n, t, nullptr, 0, nullptr, nullptr, true);
+}
+int dv_est_process_dynamic_attach(dv_ctx* ctx, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {
+    if (!ctx) return -1;
+    if (!ctx->est || !ctx->est->begun) DV_FAIL("dv_est_process_dynamic_attach: no frame in flight (dv_est_process_dynamic_begin_ego)");
+    if (check_insts(ctx, insts, n_insts, inst_feats, points)) return -1;
+    dv_estimator& E = *ctx->est;
+    if (!E.dyn_deferred) return 0;                      // initialisation frame (processed synchronously, no object branch) or already attached
+    E.dyn_deferred = false;
+    return E.dynamic_branch(ctx, insts, n_insts, inst_feats, points) ? -1 : 0;
 }
 int dv_est_process_dynamic(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points, dv_est_state* out) {
     const int rc = dv_est_process_dynamic_begin(ctx, feats, n, t, insts, n_insts, inst_feats, points);

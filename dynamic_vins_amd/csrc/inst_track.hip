@@ -25,6 +25,15 @@ __global__ __launch_bounds__(256) void roi_pad_kernel(const uint8_t* __restrict_
     dst[(size_t)y * dpitch + x] = (x < w && y < h) ? src[(size_t)(y0 + y) * spitch + x0 + x] : (uint8_t)0;      // InstanceImagePadding: zero fill right / below
 }
 
+// the same for several crops in ONE launch (blockIdx.z = job): the crops and re-paddings of all objects of a frame
+struct RoiJob { const uint8_t* src; uint8_t* dst; int spitch, x0, y0, w, h, dpitch, W, H; };
+__global__ __launch_bounds__(256) void roi_pad_multi_kernel(const RoiJob* __restrict__ jobs) {
+    const RoiJob j = jobs[blockIdx.z];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= j.W || y >= j.H) return;
+    j.dst[(size_t)y * j.dpitch + x] = (x < j.w && y < j.h) ? j.src[(size_t)(j.y0 + y) * j.spitch + j.x0 + x] : (uint8_t)0;
+}
+
 struct RoiPyr {          // pyramid storage with a fixed capacity (the full frame), re-laid-out per frame without re-allocation
     DevBuf buf; DvPyr pyr{}; int w = 0, h = 0;
     hipError_t reserve(int W, int H) {
@@ -74,12 +83,14 @@ struct dv_inst_tracker {
     hipEvent_t done = nullptr; bool pending = false; bool frame_enqueued = false;
     hipStream_t stream = nullptr;                               // the objects run beside the background tracker: own stream, own Shi-Tomasi scratch
     DevBuf jobs; void* jobs_pinned = nullptr; size_t jobs_cap = 0;     // DvLkJob tables of the two batched LK stages (temporal | right)
+    DevBuf arena; void* arena_pinned = nullptr; size_t arena_cap = 0;  // per-frame job tables of the batched per-object stages (ROI crops, pyramid levels): filled on the host, ONE upload
     DevBuf cand, scal; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
     std::vector<unsigned> out_order;                            // ids written this frame, in output order
     ~dv_inst_tracker() {
         for (auto& kv : slots) kv.second.release();
         hw.release(); out_buf.release(); cand.release(); scal.release(); jobs.release();
         if (jobs_pinned) (void)hipHostFree(jobs_pinned);
+        arena.release(); if (arena_pinned) (void)hipHostFree(arena_pinned);
         if (stream) (void)hipStreamDestroy(stream);
         if (pinned_in) (void)hipHostFree(pinned_in);
         if (out_pinned) (void)hipHostFree(out_pinned);
@@ -270,7 +281,24 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             T.jobs_cap = cap;
         }
         DvLkJob* hj = (DvLkJob*)T.jobs_pinned; int n_temporal = 0;
-        // ---- stage A ----
+        // ---- stage A: masks, then the ROI crops / re-paddings and the pyramid levels of ALL objects as one launch each (they were 1 + 2 + 3 launches per object, on
+        // one stream: with four objects a chain of ~50 dependent launches per frame, ~0.8 ms of latency between the enqueue and the rows) ----
+        {
+            const size_t need = ((size_t)na * 2 * sizeof(RoiJob) + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob) + 1024);
+            if (need > T.arena_cap) {
+                DV_CHECK(hipStreamSynchronize(s));
+                const size_t cap = need * 2;
+                DV_CHECK(T.arena.ensure(cap));
+                if (T.arena_pinned) (void)hipHostFree(T.arena_pinned);
+                T.arena_pinned = nullptr;
+                DV_CHECK(hipHostMalloc(&T.arena_pinned, cap, hipHostMallocDefault));
+                T.arena_cap = cap;
+            }
+        }
+        RoiJob* h_roi = (RoiJob*)T.arena_pinned; int n_roi = 0, roi_W = 0, roi_H = 0;
+        DvPyrJob* h_pyr = (DvPyrJob*)((uint8_t*)T.arena_pinned + (((size_t)na * 2 * sizeof(RoiJob) + 255) / 256) * 256);
+        const size_t pyr_off = (uint8_t*)h_pyr - (uint8_t*)T.arena_pinned;
+        int n_pyr[DV_MAX_LEVELS] = { 0 }, pyr_W[DV_MAX_LEVELS] = { 0 }, pyr_H[DV_MAX_LEVELS] = { 0 };      // per level l >= 1: jobs [l * na, l * na + n_pyr[l])
         for (Slot* Sp : act) {
             Slot& S = *Sp;
             const int w = S.rw, h = S.rh;
@@ -284,16 +312,26 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             RoiPyr& B = S.roi[S.cur]; RoiPyr& Prev = S.roi[S.cur ^ 1];
             const int PW = S.has_prev ? std::max(w, S.pw) : w, PH = S.has_prev ? std::max(h, S.ph) : h;
             B.layout(PW, PH);
-            { dim3 grid((PW + 255) / 256, PH); hipLaunchKernelGGL(roi_pad_kernel, grid, dim3(256), 0, s, L.L[0].p, L.L[0].pitch, S.rx, S.ry, w, h, B.pyr.L[0].p, B.pyr.L[0].pitch, PW, PH); }
+            h_roi[n_roi++] = RoiJob{ L.L[0].p, B.pyr.L[0].p, L.L[0].pitch, S.rx, S.ry, w, h, B.pyr.L[0].pitch, PW, PH };
+            roi_W = std::max(roi_W, PW); roi_H = std::max(roi_H, PH);
             if (S.has_prev) {
                 S.padA.layout(PW, PH);
-                { dim3 grid((PW + 255) / 256, PH); hipLaunchKernelGGL(roi_pad_kernel, grid, dim3(256), 0, s, Prev.pyr.L[0].p, Prev.pyr.L[0].pitch, 0, 0, S.pw, S.ph, S.padA.pyr.L[0].p, S.padA.pyr.L[0].pitch, PW, PH); }
-                for (int l = 1; l < B.pyr.levels; ++l)
-                    dv_launch_pyr_down2(S.padA.pyr.L[l - 1].p, B.pyr.L[l - 1].p, B.pyr.L[l - 1].w, B.pyr.L[l - 1].h, B.pyr.L[l - 1].pitch, S.padA.pyr.L[l].p, B.pyr.L[l].p, B.pyr.L[l].pitch, nullptr, nullptr, 0, s);
+                h_roi[n_roi++] = RoiJob{ Prev.pyr.L[0].p, S.padA.pyr.L[0].p, Prev.pyr.L[0].pitch, 0, 0, S.pw, S.ph, S.padA.pyr.L[0].pitch, PW, PH };
+                for (int l = 1; l < B.pyr.levels; ++l) {
+                    h_pyr[(size_t)l * na + n_pyr[l]++] = DvPyrJob{ S.padA.pyr.L[l - 1].p, B.pyr.L[l - 1].p, S.padA.pyr.L[l].p, B.pyr.L[l].p, B.pyr.L[l - 1].w, B.pyr.L[l - 1].h, B.pyr.L[l - 1].pitch,
+                                                                     B.pyr.L[l].w, B.pyr.L[l].h, B.pyr.L[l].pitch };
+                    pyr_W[l] = std::max(pyr_W[l], B.pyr.L[l].w); pyr_H[l] = std::max(pyr_H[l], B.pyr.L[l].h);
+                }
                 // InstFeat::TrackLeft: FeatureTrackByLK(prev padded, cur padded, last_points) without a mask (dynamic_tracker.cpp:409)
                 DvLkJob j{}; j.A = S.padA.pyr; j.B = B.pyr; j.pts_a = S.tr.last_pts; j.n_dev = S.tr.n_feat; j.pts_b = S.tr.lk_pts; j.status = S.tr.lk_status;
                 hj[n_temporal++] = j;
             }
+        }
+        if (na > 0) {
+            DV_CHECK(hipMemcpyAsync(T.arena.p, T.arena_pinned, pyr_off + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob), hipMemcpyHostToDevice, s));
+            { dim3 grid((roi_W + 255) / 256, roi_H, n_roi); hipLaunchKernelGGL(roi_pad_multi_kernel, grid, dim3(256), 0, s, (const RoiJob*)T.arena.p); }
+            const DvPyrJob* d_pyr = (const DvPyrJob*)((const uint8_t*)T.arena.p + pyr_off);
+            for (int l = 1; l < DV_MAX_LEVELS; ++l) dv_launch_pyr_down_multi(d_pyr + (size_t)l * na, n_pyr[l], pyr_W[l], pyr_H[l], s);
         }
         // the right-image jobs are known up front as well: TrackRightByPad (instance_feature.cpp:251-275) moves the points into full-image coordinates
         for (int k = 0; k < na && stereo; ++k) {

@@ -23,17 +23,13 @@ __device__ __forceinline__ int pyr_reflect101(int p, int len) {
     return p;
 }
 
-__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
-                                                       int sw, int sh, int spitch,
-                                                       uint8_t* __restrict__ dst0, uint8_t* __restrict__ dst1, int dw, int dh, int dpitch,
-                                                       uint8_t* __restrict__ copy0, uint8_t* __restrict__ copy1, int cpitch) {
+// one 64 x 16 output tile (bx, by) of one image
+__device__ __forceinline__ void pyr_down_tile(const uint8_t* __restrict__ src, int sw, int sh, int spitch, uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
+                                              uint8_t* __restrict__ cpy, int cpitch, int bx, int by) {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[PS_H * PS_PITCH];
     __shared__ short s_h[PS_H][PT_W];
-    const uint8_t* src = blockIdx.z ? src1 : src0;
-    uint8_t* dst = blockIdx.z ? dst1 : dst0;
-    uint8_t* cpy = blockIdx.z ? copy1 : copy0;
     const int tid = threadIdx.x;
-    const int ox0 = blockIdx.x * PT_W, oy0 = blockIdx.y * PT_H;
+    const int ox0 = bx * PT_W, oy0 = by * PT_H;
     const int sx0 = 2 * ox0 - 2, sy0 = 2 * oy0 - 2;
     const int ax0 = sx0 - 2;                                  // 2*ox0-4: multiple of 4
     const bool interior = (ax0 >= 0) && (ax0 + PS_PITCH <= sw) && (sy0 >= 0) && (sy0 + PS_H <= sh) && ((spitch & 3) == 0)
@@ -99,6 +95,26 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict
             else for (int k = 0; x + k < dw; ++k) dst[(size_t)y * dpitch + x + k] = o[k];
         }
     }
+}
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
+                                                       int sw, int sh, int spitch,
+                                                       uint8_t* __restrict__ dst0, uint8_t* __restrict__ dst1, int dw, int dh, int dpitch,
+                                                       uint8_t* __restrict__ copy0, uint8_t* __restrict__ copy1, int cpitch) {
+    pyr_down_tile(blockIdx.z ? src1 : src0, sw, sh, spitch, blockIdx.z ? dst1 : dst0, dw, dh, dpitch, blockIdx.z ? copy1 : copy0, cpitch, blockIdx.x, blockIdx.y);
+}
+// the same level step for several independent image pairs in ONE launch (the per-object ROI pyramids of dynamic mode: blockIdx.z = 2 * job + image); the grid
+// covers the largest job, tiles outside a smaller one end at once
+__global__ __launch_bounds__(256) void pyr_down_multi_kernel(const DvPyrJob* __restrict__ jobs) {
+    const DvPyrJob j = jobs[blockIdx.z >> 1];
+    if ((int)blockIdx.x * PT_W >= j.dw || (int)blockIdx.y * PT_H >= j.dh) return;
+    const int img = blockIdx.z & 1;
+    if (img && !j.src1) return;
+    pyr_down_tile(img ? j.src1 : j.src0, j.sw, j.sh, j.spitch, img ? j.dst1 : j.dst0, j.dw, j.dh, j.dpitch, nullptr, 0, blockIdx.x, blockIdx.y);
+}
+void dv_launch_pyr_down_multi(const DvPyrJob* jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t s) {
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(pyr_down_multi_kernel, dim3((max_dw + PT_W - 1) / PT_W, (max_dh + PT_H - 1) / PT_H, 2 * n_jobs), dim3(256), 0, s, jobs_dev);
 }
 
 // BORDER_REFLECT_101 apron of every level of one or two pyramids in ONE launch (blockIdx.y = level, blockIdx.z = image): with it no LK tile touches the

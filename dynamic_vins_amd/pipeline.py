@@ -243,13 +243,15 @@ class DynamicPipeline(Pipeline):
         if self.segments is not None:
             self.lrows = self.line_rows(t)
             self.est.SetLines(self.lrows)
-        # Tracking of frame k+1 (background + objects: ~0.5 ms on the tracking streams) goes to the GPU BEFORE the back end of frame k begins: the object branch of
-        # ProcessImage is ~0.5 ms of host work behind the enqueue of the window solve, and the tracker — thread T2 of the reference, independent of T3 — runs
-        # beside both instead of being started after them.
+        # Three-phase back end (dv_est_process_dynamic_begin_ego / _attach): the window solve of frame k goes to the GPU first, with the background rows alone (~0.17 ms
+        # of host work in front of it); then the tracking of frame k+1 (background + objects: ~60 launches, 0.25 ms of host time) is enqueued — thread T2 of the
+        # reference, independent of T3 —; then the object branch of ProcessImage (~0.4 ms of host work + the object solve on the third stream).  All of it runs
+        # beside the window solve (the chain of ~30 dependent launches that IS the frame) instead of in front of it.
+        if self.est.ProcessMeasurementsDynamicBeginEgo(rows, t) != 0:
+            raise RuntimeError("IMU stream does not cover the frame")
         if k + 1 < len(s.frames):
             self._enqueue(k + 1)
-        if self.est.ProcessMeasurementsDynamicBegin(rows, t, insts, ifeats, pts) != 0:
-            raise RuntimeError("IMU stream does not cover the frame")
+        self.est.AttachInstances(insts, ifeats, pts)
         if k + 1 < len(s.frames):
             self._feed_imu(s.times[k + 1])
             if not defer_end:

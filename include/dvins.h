@@ -491,6 +491,11 @@ int dv_est_process_dynamic(dv_ctx* ctx, const dv_feat* feats, int n, double t, c
  * as dv_obj_solve on a third stream) while it is in flight; dv_est_process_end collects both. */
 int dv_est_process_dynamic_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats,
                                  const double* points);
+/* three-phase form: _begin_ego enqueues the window solve with the background features alone; _attach hands over the frame's instances and runs the object branch
+ * while the window solve is in flight (a frame that is never attached is processed as a frame without objects); dv_est_process_end collects both.  Same results
+ * as the two-phase form: what the caller does between the calls (enqueueing the next frame's tracking, dv_inst_track_collect) leaves the front of the window solve. */
+int dv_est_process_dynamic_begin_ego(dv_ctx* ctx, const dv_feat* feats, int n, double t);
+int dv_est_process_dynamic_attach(dv_ctx* ctx, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points);
 /* Estimator::im.instances after the last processed frame (ascending id); *n_out = number written (<= cap); summary4 (may be NULL): iterations,
  * termination, initial and final cost of the last object solve */
 int dv_est_get_instances(dv_ctx* ctx, dv_inst_state* out, int cap, int* n_out, double* summary4);

@@ -401,7 +401,7 @@ int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n
     dv_inst_tracker& T = *ctx->inst;
     if (!T.pending) DV_FAIL("dv_inst_track_collect: nothing enqueued");
     if (!n_insts || !n_feats || !n_points) DV_FAIL("dv_inst_track_collect: null counter");
-    DV_CHECK(hipEventSynchronize(T.done));
+    { HostScope hw(ctx, "h_inst_wait"); DV_CHECK(hipEventSynchronize(T.done)); }      // the object tracker's launch chain of this frame
     T.pending = false;
     if (ctx->timing) { DV_CHECK(hipStreamSynchronize(T.stream)); dv_harvest_timers(ctx, T.stream); }
     const size_t slot_bytes = INST_CAP * sizeof(dv_feat) + 64;

@@ -28,7 +28,8 @@ def test_world_one_sharded_path_matches_plain(gpu_ctx_factory, oracle, transport
     shard = gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5)
     plain = gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5)
     dv_dist.shard_window(shard, 0, 1, transport=transport)
-    assert dv_dist.dist_info(shard)["transport"] == transport
+    info0 = dv_dist.dist_info(shard)
+    assert info0["transport"] == transport and info0["rccl_ranks"] == (1 if transport == "rccl" else 0)      # ncclCommCount of the communicator
     for kw in [dict(seed=2, with_prior=True), dict(seed=6, nlm=300, max_iters=10, with_prior=True), dict(seed=3, use_imu=0, nframes=7), dict(seed=12, nlm=0, max_iters=4, with_prior=True)]:
         ref = ba_gen.make_window(oracle, **kw)
         a, b = ref.clone(), ref.clone()

@@ -55,6 +55,7 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     }
     w.dl_off = upload_bytes;
     if (!w.ev_state) DV_CHECK(hipEventCreateWithFlags(&w.ev_state, hipEventDisableTiming));
+    if (const char* e = std::getenv("DVINS_GPU_REJECT")) w.gpu_reject = std::atoi(e) != 0;
     w.ready = true;
     return 0;
 }
@@ -282,6 +283,7 @@ static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
         DV_CHECK(hipMemcpyAsync(hx, w.x, pd.state_bytes, hipMemcpyDeviceToHost, s));
         DV_CHECK(hipMemcpyAsync(hctl, w.ctl, sizeof(BeCtl), hipMemcpyDeviceToHost, s));
     }
+    if (pd.rej_on) { be_launch_reject(pd.rej, s); DV_CHECK(hipGetLastError()); }      // reads the gauge-fixed copy (w.cand), writes its flags to pinned memory: part of what ev_state covers
     DV_CHECK(hipEventRecord(w.ev_state, s));
     if (pd.fused_present && pd.do_marg && !pd.pl.empty) {
         const bool side = w.c0_side && !(ctx->timing && ctx->kernel_timing);      // (the per-kernel timing mode keeps the whole marginalization on the BA stream: k_be_marg)
@@ -450,6 +452,14 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
     // invalid; be_solve_fused_end checks the downloaded control block and, in that rare case, runs the spare slots and the
     // (idempotent) tail again.
+    pd.rej_on = false;
+    if (fused && fused->want_reject && w.gpu_reject && P->nlm > 0) {
+        if (!w.rej_pinned) DV_CHECK(hipHostMalloc((void**)&w.rej_pinned, BE_MAX_LM, hipHostMallocDefault));
+        BeRejectArgs& r = pd.rej;
+        r.st = w.cand; r.fac = w.fac; r.lm = w.lm; r.nlm = P->nlm; r.nframes = P->nframes; r.focal = fused->rej_focal; r.flags = w.rej_pinned;
+        std::memcpy(r.ric, fused->rej_ric, sizeof(r.ric)); std::memcpy(r.tic, fused->rej_tic, sizeof(r.tic));
+        pd.rej_on = true;
+    }
     pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.fuse_accept_gauge = fused != nullptr && !ctx->batch; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
     pd.want_raw_pose = fused && fused->want_raw_pose;
     if (fused) { std::memcpy(pd.gauge_R0, fused->R0, sizeof(pd.gauge_R0)); std::memcpy(pd.gauge_ypr0, fused->ypr0, sizeof(pd.gauge_ypr0)); std::memcpy(pd.gauge_P0, fused->P0, sizeof(pd.gauge_P0)); }
@@ -528,6 +538,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
         summary->iterations = hctl->iter; summary->successful = hctl->successful; summary->termination = hctl->done ? hctl->termination : 0;
         summary->slots = hctl->slots; summary->initial_cost = hctl->initial_cost; summary->final_cost = hctl->x_cost;
     }
+    if (fused) fused->rej_flags = pd.rej_on ? w.rej_pinned : nullptr;
     if (fused && pd.want_raw_pose) std::memcpy(fused->raw_pose, hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256, sizeof(fused->raw_pose));
     if (pd.do_marg) {
         std::memcpy(fused->diag, w.marg_last, sizeof(fused->diag));      // the scalars of THIS frame's marginalization are still in flight: the previous frame's (be_check_prev_marg)
@@ -740,6 +751,7 @@ int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return -1;
     if (std::strcmp(key, "short_first_pass") == 0) { ctx->be.debug_short_first_pass = value != 0; return 0; }
     if (std::strcmp(key, "two_level") == 0) { ctx->be.two_level = value != 0; return 0; }
+    if (std::strcmp(key, "gpu_reject") == 0) { ctx->be.gpu_reject = value != 0; return 0; }      // 0: OutliersRejection on the host (rounds 1-3 until be_reject_kernel)
     if (std::strcmp(key, "c0_side") == 0) { ctx->be.c0_side = value != 0; return 0; }      // 0: the prior's constant c0 is computed on the BA stream, inside be_marg_finish (rounds 1-2)
     if (std::strcmp(key, "ldl_wavecol") == 0) { ctx->be.ldl_wavecol_only = value != 0; return 0; }      // the round-2 wave-column LDL^T instead of the 16-wide MFMA form
     if (std::strcmp(key, "ldl_generic") == 0) { ctx->be.ldl_generic = value != 0; return 0; }      // the block-column-major LDL^T mapping instead of the wave-column one

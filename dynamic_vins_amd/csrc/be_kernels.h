@@ -88,6 +88,12 @@ struct BeGaugeArgs {
     BeState* h_out; BeCtl* h_ctl; const BeCtl* ctl; double* h_raw_pose; int state_doubles, pad;
 };
 
+// OutliersRejection (vio_util.cpp:381-430) on the device, behind the gauge fix: mean reprojection error of every landmark of the problem over its residual blocks at
+// the gauge-fixed states; flag[l] = 1 if it exceeds 3 px (x focal).  The same expressions in the same order as the estimator's host loop (est_host.hip
+// reject_outliers): bit-identical decisions.  ric / tic: the camera extrinsics as the host will hold them after Double2vector.
+struct BeRejectArgs { const BeState* st; const BeFactor* fac; const BeLm* lm; int nlm, nframes; double ric[2][9], tic[2][3], focal; uint8_t* flags; };
+void be_launch_reject(const BeRejectArgs& a, hipStream_t s);
+
 #if defined(__HIPCC__)
 #include "wave_dpp.h"
 using namespace be;

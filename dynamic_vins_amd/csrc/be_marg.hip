@@ -676,6 +676,40 @@ __global__ __launch_bounds__(256) void be_accept_gauge_kernel(BeSolveArgs sa, Be
     __syncthreads();
     be_gauge_body(ga);
 }
+#define REJ_LM 8           // landmarks per workgroup, 32 threads (one per residual block) each
+__global__ __launch_bounds__(256) void be_reject_kernel(BeRejectArgs a) {
+    __shared__ m33 RsT[BE_NF]; __shared__ d3 Ps[BE_NF]; __shared__ m33 Rs[BE_NF];
+    __shared__ m33 ric0, ricT[2]; __shared__ d3 tic[2];
+    __shared__ double s_rp[REJ_LM][32];
+    const int tid = threadIdx.x, g = tid >> 5, t = tid & 31, l = blockIdx.x * REJ_LM + g;
+    if (tid < a.nframes) {      // Rs = qR(normalized q), Ps: arrays_to_states on the downloaded (gauge-fixed) state
+        const double* p = a.st->pose[tid];
+        const m33 R = qR(qnormalized(mkq(p[6], p[3], p[4], p[5])));
+        Rs[tid] = R; RsT[tid] = tr(R); Ps[tid] = mk3(p[0], p[1], p[2]);
+    }
+    if (tid == 32) { for (int k = 0; k < 9; ++k) ric0.m[k] = a.ric[0][k]; }
+    if (tid == 33 || tid == 34) { const int c = tid - 33; m33 r; for (int k = 0; k < 9; ++k) r.m[k] = a.ric[c][k]; ricT[c] = tr(r); tic[c] = mk3(a.tic[c][0], a.tic[c][1], a.tic[c][2]); }
+    __syncthreads();
+    if (l >= a.nlm) return;
+    const BeLm L = a.lm[l];
+    if (t < L.count) {
+        const BeFactor f = a.fac[L.first + t];
+        const double depth = 1.0 / a.st->inv_depth[l];
+        const d3 pw = mul(Rs[L.anchor], mul(ric0, mk3(f.pix, f.piy, 1.0) * depth) + tic[0]) + Ps[L.anchor];
+        const int cam = f.kind == 0 ? 0 : 1;
+        const d3 pc = mul(ricT[cam], mul(RsT[f.fj], pw - Ps[f.fj]) - tic[cam]);
+        const double rx = pc.x / pc.z - f.pjx, ry = pc.y / pc.z - f.pjy;
+        s_rp[g][t] = sqrt(rx * rx + ry * ry);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();      // a landmark's 32 threads are half a wave
+    if (t == 0) {
+        double err = 0;
+        for (int k = 0; k < L.count; ++k) err += s_rp[g][k];      // block order, as the host loop
+        a.flags[l] = (err / L.count * a.focal > 3) ? 1 : 0;
+    }
+}
+void be_launch_reject(const BeRejectArgs& a, hipStream_t s) { if (a.nlm > 0) hipLaunchKernelGGL(be_reject_kernel, dim3((a.nlm + REJ_LM - 1) / REJ_LM), dim3(256), 0, s, a); }
+
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(256), 0, s, a); }
 void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s) { hipLaunchKernelGGL(be_accept_gauge_kernel, dim3(1), dim3(256), 0, s, sa, ga); }
 

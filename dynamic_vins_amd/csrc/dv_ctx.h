@@ -77,6 +77,7 @@ struct MargPlan {
 struct BePending {        // a solve that has been enqueued and not yet collected (be_solve_fused_begin / _end)
     bool want_raw_pose = false;
     bool deferred = false; int first_slots = 0;      // member of a dv_batch: uploaded, the slots wait for dv_batch_enqueue
+    bool rej_on = false; BeRejectArgs rej{};      // this frame's device-side outlier test
     bool fuse_accept_gauge = false;      // estimator path outside a dv_batch: the last slot's accept decision rides in the gauge kernel (be_accept_gauge_kernel)
     bool active = false, trivial = false, do_marg = false, fused_present = false, marg_in_flight = false, marg_check_due = false; int scal_slot = 0, check_slot = 0; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
     BeEvalArgs ea; BeSolveArgs sa; int max_iters = 0, nframes = 0, use_imu = 0, nlm = 0; double g_norm = 0, gauge_R0[9], gauge_ypr0[3], gauge_P0[3];
@@ -107,6 +108,7 @@ struct BeWork {
     long long marg_checked = 0; double marg_last[4] = { 0, 0, 0, 0 };      // marginalizations whose health scalars came back, and the last set (c0, smallest pivot of A_mm, clamp flag, rank)
     long long marg_clamped = 0;       // marginalizations in which a pivot of A_mm was <= 1e-8 and was skipped (pseudo-inverse)
     bool debug_short_first_pass = false, two_level = false, ldl_generic = false, ldl_wavecol_only = false;      // dv_debug_set
+    bool gpu_reject = true; uint8_t* rej_pinned = nullptr;      // dv_debug_set "gpu_reject": the outlier test of the frame on the device, flags written to pinned memory before ev_state
     std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
 };
 
@@ -120,6 +122,7 @@ struct BeFused {
     dv_ba_prior new_prior;                    // out (marg_mode >= 0): header of the new prior (valid may be 0)
     double diag[4] = { 0, 0, 0, 0 };          // out: c0, smallest pivot, failure flag, rank
     bool want_raw_pose = false;               // in
+    bool want_reject = false; double rej_ric[2][9], rej_tic[2][3], rej_focal = 0; const uint8_t* rej_flags = nullptr;      // in: OutliersRejection on the device (be_reject_kernel) with the extrinsics the host will hold after Double2vector; out: one flag per landmark of the problem (nullptr: not run)
     double raw_pose[77];                      // out: the solver's pose blocks BEFORE the yaw-gauge fix (what body.para_pose holds after ceres::Solve)
 };
 int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);

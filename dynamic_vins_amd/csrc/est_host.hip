@@ -450,6 +450,14 @@ struct dv_estimator {
           const d3 y0 = r2ypr(Rs[0]);
           std::memcpy(fu.R0, Rs[0].m, sizeof(fu.R0)); fu.ypr0[0] = y0.x; fu.ypr0[1] = y0.y; fu.ypr0[2] = y0.z; fu.P0[0] = Ps[0].x; fu.P0[1] = Ps[0].y; fu.P0[2] = Ps[0].z;
           fu.marg_mode = -1; fu.want_raw_pose = cfg.dynamic != 0;
+          {   // OutliersRejection runs on the device behind the gauge fix (be_reject_kernel): the extrinsics it must use are the ones arrays_to_states will leave
+              fu.want_reject = true; fu.rej_focal = kFocal;
+              for (int c = 0; c < 2; ++c) {
+                  const m33 r = cfg.use_imu ? qR(qnormalized(mkq(ex[c][6], ex[c][3], ex[c][4], ex[c][5]))) : ric[c];
+                  const d3 tt = cfg.use_imu ? mk3(ex[c][0], ex[c][1], ex[c][2]) : tic[c];
+                  std::memcpy(fu.rej_ric[c], r.m, sizeof(r.m)); fu.rej_tic[c][0] = tt.x; fu.rej_tic[c][1] = tt.y; fu.rej_tic[c][2] = tt.z;
+              }
+          }
           if (frame == kWin) {
               if (margin_old) fu.marg_mode = 0;
               else {
@@ -490,6 +498,12 @@ struct dv_estimator {
         for (auto& l : lms) if (l.obs.size() >= 4) { l.depth = 1.0 / invd[++k]; l.solve_flag = l.depth < 0 ? 2 : 1; }
     }
     void reject_outliers() {          // OutliersRejection + RemoveOutlier (vio_util.cpp:381-430)
+        if (fu.rej_flags) {           // decided on the device (same expressions, same order: be_reject_kernel), one flag per landmark of the problem = per landmark with >= 4 observations, in order
+            const uint8_t* fl = fu.rej_flags; int k = -1;
+            erase_if([&](const Lm& l) { if (l.obs.size() < 4) return false; return fl[++k] != 0; });
+            fu.rej_flags = nullptr;
+            return;
+        }
         m33 RsT[kWin + 1], ricT[2];          // the transposes, once per frame instead of twice per observation (same values, same products)
         for (int i = 0; i <= kWin; ++i) RsT[i] = tr(Rs[i]);
         ricT[0] = tr(ric[0]); ricT[1] = tr(ric[1]);

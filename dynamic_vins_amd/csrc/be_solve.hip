@@ -911,10 +911,13 @@ __device__ __forceinline__ void mf_diag_factor(mf_d4& T, const MfLds& m, int k, 
     for (int r = 0; r < 4; ++r) Wt[r] = (rho + 4 * r == c) ? 1.0 : 0.0;
     double* gat = m.gat + wave * 64;
     const int nv = n - 16 * k, c0 = (nv >= 0 && nv < 16) ? nv : -1;      // nv: rows of this tile that belong to the n x n system
+    // The tile that holds the right-hand-side row (the last one: c0 >= 0) ends with that row and identity padding: a sub-step whose four pivots all lie behind the
+    // row (4 Q > c0) touches nothing that is read again — W stays the identity there, y is zero-initialised, the pivot check below looks at c < nv only — and is
+    // skipped (n = 165: two of the last tile's four sub-steps, ~1.1 us per solve).
     mf_diag_substep<0>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
-    mf_diag_substep<1>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
-    mf_diag_substep<2>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
-    mf_diag_substep<3>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
+    if (c0 < 0 || c0 >= 4) mf_diag_substep<1>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
+    if (c0 < 0 || c0 >= 8) mf_diag_substep<2>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
+    if (c0 < 0 || c0 >= 12) mf_diag_substep<3>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
     *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(k, k, NB) * 256 + lane * 4) = Wt;      // W_k = L_kk^-1, result layout
     wave_lds_sync();
     const double dchk = m.dv[16 * k + c];                                                   // pivots of the n x n system must be positive and finite
@@ -1045,7 +1048,7 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
             panel(U[1], k + 1, k);
 #pragma unroll
             for (int q = 0; q < 4; ++q) U[0] = mf_mfma(U[1][q], dk[q] * U[1][q], U[0]);
-            lds_barrier();                               // B
+            if (k + 2 < NB) lds_barrier();               // B (the last column has one tile below the diagonal, this wave's: nobody waits for a panel there)
 #ifdef BE_SOLVE_TS
             const long long t_u = wall_clock64();
 #endif
@@ -1058,7 +1061,7 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
             // ---- everybody else: panel tile of column k, then the trailing update ----
 #pragma unroll
             for (int s = 1; s < MF_SLOTS; ++s) if (sJ[s] == k) panel(U[s], sI[s], k);
-            lds_barrier();                               // B
+            if (k + 2 < NB) lds_barrier();               // B
 #ifdef BE_SOLVE_TS
             { const long long t = wall_clock64(); acc_panel += t - t_prev; t_prev = t; }
 #endif

@@ -918,11 +918,8 @@ __device__ __forceinline__ void mf_diag_factor(mf_d4& T, const MfLds& m, int k, 
     if (c0 < 0 || c0 >= 4) mf_diag_substep<1>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
     if (c0 < 0 || c0 >= 8) mf_diag_substep<2>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
     if (c0 < 0 || c0 >= 12) mf_diag_substep<3>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
-    *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(k, k, NB) * 256 + lane * 4) = Wt;      // W_k = L_kk^-1, result layout
-    wave_lds_sync();
-    const double dchk = m.dv[16 * k + c];                                                   // pivots of the n x n system must be positive and finite
-    if (__ballot(c < nv && (!(dchk > 0.0) || !isfinite(dchk))) != 0ull && lane == 0) *s_fail = 1;
-    __builtin_amdgcn_s_setprio(0);
+    *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(k, k, NB) * 256 + lane * 4) = Wt;      // W_k = L_kk^-1, result layout (the workgroup barrier behind this tile publishes it)
+    __builtin_amdgcn_s_setprio(0);      // (the pivots are checked once, behind the last tile: ldlt_mf16)
 }
 // tile entries: the raw Schur-complement entry is requested early (mf_prefetch, before the scaling phase: the loads' round trip hides behind it) and finished
 // (scaled, damped; right-hand side as row / column n; identity padding behind it) when the factorisation starts
@@ -1080,6 +1077,9 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
 #endif
         }
     }
+    // pivots of the n x n system must be positive and finite: one look at D behind the last tile (it was an LDS round trip on every diagonal tile's path)
+    if (tid < n) { const double d = m.dv[tid]; if (!(d > 0.0) || !isfinite(d)) *s_fail = 1; }
+    lds_barrier();
     TS(5);
 #ifdef BE_SOLVE_TS
     if (tid == 0) { be_dbg_ts[17] = acc_panel; be_dbg_ts[18] = acc_update; }

@@ -395,7 +395,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 else:
                     rows = trk.track_image(host[k][0], host[k][1], t)
                 b = time.perf_counter()
-                do_ba = (k % stride) == stride - 1
+                do_ba = (k % stride) == 0
                 st = None
                 if do_ba:
                     rc, st = est.process_dynamic(rows, t, io, fo, po) if args.mode == "dynamic" else est.process(rows, t)

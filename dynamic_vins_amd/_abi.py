@@ -85,6 +85,7 @@ SIGNATURES = {
     "dv_est_process": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
     "dv_est_process_begin": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double]),
     "dv_est_process_end": (C.c_int, [_ctx, C.c_void_p]),
+    "dv_est_imu_available": (C.c_int, [_ctx, C.c_double]),
     "dv_est_process_dynamic": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_est_process_dynamic_begin": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "dv_est_process_dynamic_begin_ego": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double]),

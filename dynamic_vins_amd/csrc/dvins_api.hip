@@ -190,6 +190,7 @@ void dv_destroy(dv_ctx* ctx) {
     if (ctx->be.ev_c0) (void)hipEventDestroy(ctx->be.ev_c0);
     ctx->be.block.release(); ctx->be.marg_buf.release();
     if (ctx->be.pinned) (void)hipHostFree(ctx->be.pinned);
+    if (ctx->be.rej_pinned) (void)hipHostFree(ctx->be.rej_pinned);
     ctx->obj_buf.release(); ctx->obj_pend.release(); ctx->obj_op_pend.release();
     if (ctx->obj_stream) (void)hipStreamDestroy(ctx->obj_stream);
     if (ctx->be_stream) (void)hipStreamDestroy(ctx->be_stream);

@@ -451,7 +451,7 @@ struct dv_estimator {
           std::memcpy(fu.R0, Rs[0].m, sizeof(fu.R0)); fu.ypr0[0] = y0.x; fu.ypr0[1] = y0.y; fu.ypr0[2] = y0.z; fu.P0[0] = Ps[0].x; fu.P0[1] = Ps[0].y; fu.P0[2] = Ps[0].z;
           fu.marg_mode = -1; fu.want_raw_pose = cfg.dynamic != 0;
           {   // OutliersRejection runs on the device behind the gauge fix (be_reject_kernel): the extrinsics it must use are the ones arrays_to_states will leave
-              fu.want_reject = true; fu.rej_focal = kFocal;
+              fu.want_reject = nonlinear; fu.rej_focal = kFocal;      // the initialisation solves never consume the flags (InitEstimator has no OutliersRejection)
               for (int c = 0; c < 2; ++c) {
                   const m33 r = cfg.use_imu ? qR(qnormalized(mkq(ex[c][6], ex[c][3], ex[c][4], ex[c][5]))) : ric[c];
                   const d3 tt = cfg.use_imu ? mk3(ex[c][0], ex[c][1], ex[c][2]) : tic[c];
@@ -790,6 +790,14 @@ static int est_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const d
     { HostScope h(ctx, "h_process_begin"); if (E.process_image_begin(ctx, feats, n, t, insts, n_insts, inst_feats, points, defer_dynamic)) return -1; }
     E.begun = true;
     return 0;
+}
+// Estimator::IMUAvailable (estimator.h:128-133) at cur_time = t + td, as ProcessMeasurements tests it before it pops the frame (estimator.cpp:1800-1805)
+int dv_est_imu_available(dv_ctx* ctx, double t) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_imu_available: call dv_est_create first");
+    const dv_estimator& E = *ctx->est;
+    if (!E.cfg.use_imu) return 1;
+    return (!E.imu_buf.empty() && t + E.td <= E.imu_buf.back().first) ? 1 : 0;
 }
 int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t) { return est_begin(ctx, feats, n, t, nullptr, 0, nullptr, nullptr); }
 int dv_est_process_dynamic_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {

@@ -66,7 +66,7 @@ int seq_begin(dv_runner* R, RSeq& s) {
     s.enqueued = false;
     const double t = s.in.times[k];
     const int stride = s.in.ba_stride > 1 ? s.in.ba_stride : 1;
-    if (stride > 1 && (k % stride) != stride - 1) {      // tracked only: the reference forwards every 2nd tracked frame to the back end outside KITTI (system/main.cpp:300-307)
+    if (stride > 1 && (k % stride) != 0) {      // tracked only: outside KITTI the reference pushes a frame to feature_queue when cnt % 2 == 0, cnt counting tracked frames from 0 (system/main.cpp:181,300-312): frames 0, 2, 4, ...
         if (k + 1 < s.in.n_frames && seq_enqueue(R, s, k + 1)) return -1;
         ++s.next;
         return 0;

@@ -13,8 +13,11 @@
 //   dynamic_vins::Estimator        estimator/estimator.h:55-164
 //        Estimator(const std::string& config_path); SetParameter(); ClearState();
 //        InputIMU(double t, const Vec3d& acc, const Vec3d& gyr)                     estimator.cpp:1765-1779
-//        ProcessMeasurements()  — blocking loop over feature_queue until cfg::ok is false   estimator.cpp:1786-1863
+//        ProcessMeasurements()  — blocking loop over the global feature_queue until cfg::ok is false   estimator.cpp:1786-1863
 //        ProcessMeasurements(const FrontendFeature&) — one iteration of that loop
+//        public solver_flag, margin_flag, key_poses, frame (estimator.h:150-164)
+//   dynamic_vins::FeatureQueue feature_queue (basic/feature_queue.h:19-73), dynamic_vins::cfg::ok (utils/parameters.h)
+//   BASELINE.json's north_star spells the two entry points trackImage / processImage (the VINS-Fusion names): both exist as aliases
 //   Errors: std::runtime_error, as the reference throws (bad config, empty input); the C ABI itself never throws.
 //   Threading: one FeatureTracker per tracking thread, one Estimator per back-end thread (each owns a dv_ctx);
 //   InputIMU may be called from another thread (guarded like the reference's buf_mutex).
@@ -33,6 +36,7 @@
 #include <cstring>
 #include <deque>
 #include <fstream>
+#include <list>
 #include <map>
 #include <mutex>
 #include <optional>
@@ -266,6 +270,41 @@ struct FeatureBackground {              // basic/frontend_feature.h:34-44
 struct FrontendFeature {                // basic/frontend_feature.h:52-75
     FeatureBackground features; double time = 0; unsigned int seq_id = 0;
 };
+// cfg::ok (utils/parameters.h: inline static std::atomic_bool ok{true}): the flag the reference's three thread loops poll; /vins_terminal clears it
+namespace cfg { inline std::atomic<bool> ok{true}; }
+constexpr int kImageQueueSize = 100;      // utils/parameters.h:48
+// FeatureQueue (basic/feature_queue.h:19-73), the queue between thread T2 (FeatureTrack pushes, system/main.cpp:300-307) and T3 (ProcessMeasurements pops):
+// push_back DROPS the frame silently when kImageQueueSize frames are waiting, request() waits at most 30 ms, front_time() peeks the oldest stamp.
+class FeatureQueue {
+public:
+    using Ptr = std::shared_ptr<FeatureQueue>;
+    void push_back(FrontendFeature& frame) {
+        std::unique_lock<std::mutex> lock(queue_mutex);
+        if (frame_list.size() < (size_t)kImageQueueSize) frame_list.push_back(frame);
+        queue_cond.notify_one();
+    }
+    std::optional<FrontendFeature> request() {
+        std::unique_lock<std::mutex> lock(queue_mutex);
+        if (!queue_cond.wait_for(lock, std::chrono::milliseconds(30), [&] { return !frame_list.empty(); })) return std::nullopt;
+        FrontendFeature frame = std::move(frame_list.front());
+        frame_list.pop_front();
+        return frame;
+    }
+    int size() { std::unique_lock<std::mutex> lock(queue_mutex); return (int)frame_list.size(); }
+    bool empty() { std::unique_lock<std::mutex> lock(queue_mutex); return frame_list.empty(); }
+    void clear() { std::unique_lock<std::mutex> lock(queue_mutex); frame_list.clear(); }
+    std::optional<double> front_time() {
+        std::unique_lock<std::mutex> lock(queue_mutex);
+        if (frame_list.empty()) return std::nullopt;
+        return frame_list.front().time;
+    }
+private:
+    std::mutex queue_mutex;
+    std::condition_variable queue_cond;
+    std::list<FrontendFeature> frame_list;
+};
+inline FeatureQueue feature_queue;      // the reference's global (basic/feature_queue.h:73, defined estimator.cpp:38)
+
 #ifdef DVINS_SHIM_WITH_OPENCV
 inline ImageView View(const cv::Mat& m) { return ImageView{m.data, m.cols, m.rows, (int)m.step, false, m.channels() == 3}; }
 #endif
@@ -315,6 +354,7 @@ public:
     FeatureTracker& operator=(const FeatureTracker&) = delete;
 
     FeatureBackground TrackImage(SemanticImage& img) { return track(img, DV_MODE_RAW); }
+    FeatureBackground trackImage(SemanticImage& img) { return TrackImage(img); }      // north_star's spelling (VINS-Fusion's FeatureTracker::trackImage)
     FeatureBackground TrackImageNaive(SemanticImage& img) { return track(img, DV_MODE_NAIVE); }
     FeatureBackground TrackSemanticImage(SemanticImage& img) { return track(img, DV_MODE_SEMANTIC); }      // background_tracker.cpp:757-837 (background half)
     // FeatureTracker::TrackImageLine (background_tracker.cpp:198-333): the point half is TrackImage's; the line half is the reference's CPU detector thread
@@ -593,7 +633,34 @@ public:
         detail::check(ctx_, dv_est_get_landmarks(ctx_, v.data(), (int)v.size(), &n), "Landmarks");
         v.resize(n); return v;
     }
-    // the reference's blocking form: pops the shared queue until `ok` turns false
+    // Estimator::ProcessMeasurements() (estimator.cpp:1786-1863) as the reference runs it on thread T3: blocks until cfg::ok turns false, over the global
+    // feature_queue.  Same order of tests as the reference's loop body: empty queue -> sleep 2 ms; front_time(); IMU stream not yet past cur_time = stamp + td ->
+    // sleep 5 ms WITHOUT popping (the frame keeps its queue slot, so the producer's drop rule sees the same occupancy); then request() pops and the frame is processed.
+    void ProcessMeasurements() { ProcessMeasurements(feature_queue, cfg::ok); }
+    void ProcessMeasurements(FeatureQueue& queue, const std::atomic<bool>& ok) {
+        while (ok.load()) {
+            if (queue.empty()) { std::this_thread::sleep_for(std::chrono::milliseconds(2)); continue; }
+            const std::optional<double> front_time = queue.front_time();
+            if (!front_time) continue;
+            if (cfg_.use_imu) {
+                int avail;
+                { std::lock_guard<std::mutex> lk(buf_mutex_); avail = dv_est_imu_available(ctx_, *front_time); }
+                if (avail < 0) detail::check(ctx_, avail, "ProcessMeasurements");
+                if (!avail) { std::this_thread::sleep_for(std::chrono::milliseconds(5)); continue; }
+            }
+            std::optional<FrontendFeature> f = queue.request();
+            if (!f) continue;
+            feature_frame = std::move(*f);
+            if (!ProcessMeasurements(feature_frame)) throw std::runtime_error("dvins: ProcessMeasurements: IMU interval vanished between IMUAvailable and GetIMUInterval");
+            ++processed_frames;
+        }
+    }
+    // north_star's spelling (VINS-Fusion's Estimator::processImage): one ProcessImage call on an already-popped frame; header = image.time as in the reference
+    bool processImage(const FrontendFeature& image, double header) { FrontendFeature f = image; f.time = header; return ProcessMeasurements(f); }
+    bool ProcessImage(const FrontendFeature& image, double header) { return processImage(image, header); }      // estimator.cpp:1516
+    FrontendFeature feature_frame;                           // the frame ProcessMeasurements() popped last (estimator.h public member)
+    std::atomic<long long> processed_frames{0};
+    // private queue form kept for callers that do not want the global: pops until `ok` turns false
     void PushFeature(FrontendFeature f) { { std::lock_guard<std::mutex> lk(q_mutex_); queue_.push_back(std::move(f)); } q_cv_.notify_one(); }
     void ProcessMeasurements(const std::atomic<bool>& ok) {
         while (ok.load()) {
@@ -611,7 +678,9 @@ public:
     const dv_est_state& state() const { return state_; }
     dv_ctx* ctx() { return ctx_; }
 
+    enum MarginFlag { kMarginOld = 0, kMarginSecondNew = 1 };      // vio_parameters.h:57-60
     SolverFlag solver_flag = kInitial;
+    MarginFlag margin_flag = kMarginOld;                       // estimator.h:154
     bool margin_old = false;
     int frame = 0;
 
@@ -624,6 +693,7 @@ private:
     void after_frame() {
         solver_flag = state_.nonlinear ? kNonLinear : kInitial;
         margin_old = state_.margin_old != 0;
+        margin_flag = margin_old ? kMarginOld : kMarginSecondNew;
         frame = state_.frame;
         key_poses.clear();
         for (int i = 0; i <= 10; ++i) key_poses.push_back(Vec3d{ state_.window[i][0], state_.window[i][1], state_.window[i][2] });

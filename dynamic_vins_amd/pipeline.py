@@ -78,7 +78,7 @@ class Pipeline:
             rows = self.ctx.track_stereo_collect()
         self.enqueued = False
         t = s.times[k]
-        if self.ba_stride > 1 and (k % self.ba_stride) != self.ba_stride - 1:      # tracked only: the frame is not pushed to the feature queue
+        if self.ba_stride > 1 and (k % self.ba_stride) != 0:      # tracked only: the reference pushes frames 0, 2, 4, ... (cnt % 2 == 0, cnt from 0: system/main.cpp:181,300-312)
             if k + 1 < len(s.frames):
                 self._enqueue(k + 1)
             self.next += 1

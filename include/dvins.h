@@ -383,6 +383,9 @@ int dv_est_process(dv_ctx* ctx, const dv_feat* feats, int n, double t, dv_est_st
  * frame's tracking and feed IMU samples — thread T2's work overlapping T3's, as in the reference (system/main.cpp:394-404). */
 int dv_est_process_begin(dv_ctx* ctx, const dv_feat* feats, int n, double t);
 int dv_est_process_end(dv_ctx* ctx, dv_est_state* out);
+/* Estimator::IMUAvailable(t + td) (estimator/estimator.h:128-133): 1 = the IMU buffer reaches the frame time, 0 = not yet (the "wait for imu" test of
+ * ProcessMeasurements BEFORE it pops the frame from feature_queue, estimator.cpp:1800-1805), <0 error.  Always 1 without an IMU. */
+int dv_est_imu_available(dv_ctx* ctx, double t);
 
 /* one entry of FeatureBackground::lines (basic/frontend_feature.h:41-44): the matched line `id` of this frame with the undistorted normalised end points
  * (Line::StartPt / EndPt of FrameLines::un_lines) in the left image and, if matched, in the right one.  The LSD / LBD detector that produces them is upstream. */

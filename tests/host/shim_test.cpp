@@ -5,6 +5,9 @@
 //   shim_test track <config.yaml> <frames.raw> <n> <w> <h>  -> runs TrackImage over n stereo pairs read from a raw file,
 //                                                         feeds a constant-gravity IMU stream and runs the Estimator (GPU)
 //   shim_test members <config.yaml> <frames.raw> <n> <w> <h> -> the callback / publisher members + dynamic mode through the shim (GPU)
+//   shim_test queue <config.yaml>                      -> FeatureQueue push/pop/drop semantics (CPU)
+//   shim_test blocking <config.yaml> <frames.raw> <n> <w> <h> -> thread T2 pushes trackImage() output into the global feature_queue, thread T3 runs the blocking
+//                                                         Estimator::ProcessMeasurements() until cfg::ok is cleared; compared with the per-iteration path (GPU)
 //   shim_test extras <config.yaml> <frames.raw> <n> <w> <h> -> SetUndistortMaps + BGR views, OptimizeInstances (GPU)
 #include <cmath>
 #include <cstdio>
@@ -72,6 +75,77 @@ int main(int argc, char** argv) {
             FrameGate g, gk; gk.every_frame = true;
             for (int k = 0; k < 5; ++k) std::printf("%d%d ", (int)g.Pass(), (int)gk.Pass());
             std::printf("\n");
+            return 0;
+        }
+        if (mode == "queue") {        // basic/feature_queue.h:19-73 on scripted input (CPU)
+            FeatureQueue q;
+            std::printf("empty %d size %d front %d", (int)q.empty(), q.size(), (int)q.front_time().has_value());
+            const auto t0 = std::chrono::steady_clock::now();
+            const bool none = !q.request().has_value();
+            const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            std::printf(" request_empty %d waited_30ms %d\n", (int)none, waited >= 29.0 && waited < 500.0);
+            for (int k = 0; k < kImageQueueSize + 5; ++k) { FrontendFeature f; f.time = 10.0 + k; f.seq_id = k; q.push_back(f); }
+            std::printf("size %d front %.1f", q.size(), *q.front_time());
+            auto a = q.request(), b = q.request();
+            std::printf(" pop %u %u size %d front %.1f", a->seq_id, b->seq_id, q.size(), *q.front_time());
+            { FrontendFeature f; f.time = 999.0; f.seq_id = 999; q.push_back(f); }      // room again: accepted at the back
+            int last = -1; while (!q.empty()) last = (int)q.request()->seq_id;
+            std::printf(" last %d", last);
+            { FrontendFeature f; f.time = 1.0; q.push_back(f); } q.clear();
+            std::printf(" cleared %d\n", (int)q.empty());
+            std::printf("global %d ok %d\n", (int)feature_queue.empty(), (int)cfg::ok.load());
+            return 0;
+        }
+        if (mode == "blocking" && argc >= 7) {
+            const int n = std::atoi(argv[4]), w = std::atoi(argv[5]), h = std::atoi(argv[6]);
+            std::ifstream f(argv[3], std::ios::binary);
+            std::vector<uint8_t> buf((size_t)n * 2 * w * h);
+            f.read((char*)buf.data(), buf.size());
+            dv_config c{};
+            {
+                YamlFile y(cfg);
+                c.width = w; c.height = h; c.max_cnt = 30; c.min_dist = 10; c.flow_back = y.integer("flow_back", 1); c.stereo = 1;
+                c.cam0 = ReadPinholeCamera(dir_of(cfg) + "/" + y.str("cam0_calib"));
+                c.cam0.fx *= w / 1280.0; c.cam0.cx *= w / 1280.0; c.cam0.fy *= h / 720.0; c.cam0.cy *= h / 720.0;
+                c.cam1 = c.cam0;
+            }
+            // reference run: one ProcessMeasurements(frame) per tracked frame, IMU fed in front of every frame
+            std::vector<FrontendFeature> frames;
+            std::string ref_line; int ref_frame = 0, ref_margin = -1;
+            {
+                FeatureTracker tracker(c);
+                Estimator est(cfg);
+                double t_imu = 0.95;
+                for (int k = 0; k < n; ++k) {
+                    SemanticImage img;
+                    img.gray0 = ImageView{buf.data() + (size_t)(2 * k) * w * h, w, h, w, false};
+                    img.gray1 = ImageView{buf.data() + (size_t)(2 * k + 1) * w * h, w, h, w, false};
+                    img.time0 = 1.0 + 0.05 * k; img.seq = k;
+                    FrontendFeature ff; ff.features = tracker.trackImage(img); ff.time = img.time0; ff.seq_id = k;      // north_star's spelling
+                    frames.push_back(ff);
+                    for (; t_imu <= img.time0 + 0.006; t_imu += 0.005) est.InputIMU(t_imu, Vec3d{0, 0, 9.81007}, Vec3d{0, 0, 0});
+                    if (!est.processImage(ff, ff.time)) { std::printf("reference run: IMU missing\n"); return 1; }
+                }
+                ref_line = TumLine(1.0, est.WindowState(est.frame)); ref_frame = est.frame; ref_margin = (int)est.margin_flag;
+            }
+            // the reference's threading: T3 blocks in ProcessMeasurements(); T2 (here: this thread) pushes the frames AHEAD of their IMU data, so the loop's
+            // "wait for imu" branch runs (the frame must stay queued meanwhile); the IMU callback thread delivers the samples late
+            Estimator est(cfg);
+            cfg::ok = true;
+            std::thread t3([&] { est.ProcessMeasurements(); });
+            int max_queued = 0;
+            double t_imu = 0.95;
+            for (int k = 0; k < n; ++k) {
+                feature_queue.push_back(frames[k]);
+                std::this_thread::sleep_for(std::chrono::milliseconds(12));      // T3 has seen the frame and is waiting for its IMU interval
+                max_queued = std::max(max_queued, feature_queue.size());
+                for (; t_imu <= frames[k].time + 0.006; t_imu += 0.005) est.InputIMU(t_imu, Vec3d{0, 0, 9.81007}, Vec3d{0, 0, 0});
+            }
+            for (int spin = 0; spin < 2000 && est.processed_frames.load() < n; ++spin) std::this_thread::sleep_for(std::chrono::milliseconds(5));
+            cfg::ok = false;
+            t3.join();
+            std::printf("processed %lld of %d queued_while_waiting %d left %d seq %u\n", est.processed_frames.load(), n, max_queued >= 1, feature_queue.size(), est.feature_frame.seq_id);
+            std::printf("same_state %d frame %d %d margin_flag %d %d solver %d\n", (int)(TumLine(1.0, est.WindowState(est.frame)) == ref_line), est.frame, ref_frame, (int)est.margin_flag, ref_margin, (int)est.solver_flag);
             return 0;
         }
         if (mode == "nogpu") {

@@ -116,6 +116,33 @@ def test_shim_undistort_maps_bgr_views_and_instance_solve(shim_exe, tmp_path, gp
     assert s.successful > 0 and s.final_cost < s.initial_cost
 
 
+def test_shim_feature_queue_semantics(shim_exe):
+    """FeatureQueue (basic/feature_queue.h:19-73): request() on an empty queue gives up after 30 ms, push_back drops silently beyond kImageQueueSize = 100,
+    FIFO order, front_time peeks, clear; the global feature_queue and cfg::ok exist"""
+    out = subprocess.run([shim_exe, "queue", CFG], capture_output=True, text=True, check=True).stdout.splitlines()
+    assert out[0] == "empty 1 size 0 front 0 request_empty 1 waited_30ms 1"
+    assert out[1] == "size 100 front 10.0 pop 0 1 size 98 front 12.0 last 999 cleared 1"
+    assert out[2] == "global 1 ok 1"
+
+
+@pytest.mark.gpu
+def test_shim_blocking_process_measurements_over_the_feature_queue(shim_exe, tmp_path):
+    """Estimator::ProcessMeasurements() as thread T3 runs it (estimator.cpp:1786-1863): blocks on the global feature_queue until cfg::ok is cleared, leaves a
+    frame QUEUED while its IMU interval is incomplete, and ends in the same state as the per-iteration path; trackImage / processImage spellings, margin_flag"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "front_kat.npz"))
+    n, h, w = g["left"].shape
+    raw = tmp_path / "frames.raw"
+    with open(raw, "wb") as f:
+        for k in range(n):
+            f.write(g["left"][k].tobytes()); f.write(g["right"][k].tobytes())
+    r = subprocess.run([shim_exe, "blocking", CFG, str(raw), str(n), str(w), str(h)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    out = r.stdout.splitlines()
+    assert out[0] == "processed %d of %d queued_while_waiting 1 left 0 seq %d" % (n, n, n - 1)
+    tok = out[1].split()
+    assert tok[1] == "1" and tok[3] == tok[4] and tok[6] == tok[7], out[1]
+
+
 def test_shim_stereo_sync_and_frame_gate(shim_exe):
     """row N1, ROS-free part: SyncProcess' time-stamp rule (5 ms, discard older right images, drop a too-early left image) and the
     every-second-frame policy, on scripted stamps — including the reference's quirk that a right image NEWER than the left one by more

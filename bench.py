@@ -416,10 +416,14 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                "sample": f"{n1} steady-state frames of the same {w}x{h} {args.mode} sequence: CPU oracle = restated reference path (LK + Shi-Tomasi + dense-Schur dogleg BA + "
                          f"marginalization{' + object branch' if args.mode == 'dynamic' else ''}); 'value' = 1 thread, 'value_all_cores' = LK over min(nproc, 16) threads + 4-thread marginalization (the reference's threading)"}
         # ATE of the HIP trajectory against the ORACLE trajectory on the frames both produced (north_star's acceptance figure; outside the timed region)
-        common = [i for i, tt in enumerate(ptimes_o) if tt in dev_times]
-        if len(common) >= 3:
-            d_idx = [dev_times.index(ptimes_o[i]) for i in common]
-            ate_vs_oracle = float(sim.align_ate(dev_poses[d_idx, :3], poses_o[common])[0])
+        # the reference's metric as its scripts compute it: nearest-stamp association within 0.02 s (associate.py), Horn alignment, RMSE (evaluate_ate.py)
+        from dynamic_vins_amd import io_formats
+        if len(ptimes_o) >= 3 and len(dev_times) >= 3:
+            try:
+                ate_vs_oracle, n_pairs = io_formats.evaluate_ate(ptimes_o, poses_o, dev_times, dev_poses[:, :3])
+                ate_vs_oracle = float(ate_vs_oracle) if n_pairs >= 3 else None
+            except ValueError:
+                ate_vs_oracle = None
 
     if rank == 0:
         value = dv_dist.whole_job_rate(args.steps, world, dt)

@@ -513,6 +513,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     uint8_t* hp = (uint8_t*)w.pinned;
     const BeState* hx = (const BeState*)(hp + w.dl_off); const BeCtl* hctl = (const BeCtl*)(hp + w.dl_off + sizeof(BeState));
     DV_CHECK(hipEventSynchronize(w.ev_state));
+    if (be_dist_check(ctx)) return -1;      // sharded window, peer transport: a dead or late peer is an error of THIS solve, not garbage in its result
     // the previous frame's marginalization ran before this frame's upload (stream order), so its scalars have landed
     if (be_check_prev_marg(ctx, pd)) return -1;
     if (!hctl->done) {        // rare: a failed linear solve / invalid step used up slots -> the 3 spare slots, then the tail once more
@@ -520,6 +521,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
         if (be_enqueue_slots(ctx, pd, 3, false, s)) return -1;
         if (be_enqueue_tail(ctx, pd, s)) return -1;
         DV_CHECK(hipEventSynchronize(w.ev_state));
+        if (be_dist_check(ctx)) return -1;
     }
     if (pd.marg_in_flight) { pd.marg_in_flight = false; pd.marg_check_due = true; pd.check_slot = pd.scal_slot; pd.scal_slot ^= 1; }
     if (ctx->host_timing) {
@@ -751,6 +753,7 @@ int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return -1;
     if (std::strcmp(key, "short_first_pass") == 0) { ctx->be.debug_short_first_pass = value != 0; return 0; }
     if (std::strcmp(key, "two_level") == 0) { ctx->be.two_level = value != 0; return 0; }
+    if (std::strcmp(key, "peer_timeout_ms") == 0) { ctx->dist.peer_timeout_ticks = 100000ll * std::max(value, 1); return 0; }      // transport peer: how long a wait kernel spins for a peer's flag (default 2000)
     if (std::strcmp(key, "gpu_reject") == 0) { ctx->be.gpu_reject = value != 0; return 0; }      // 0: OutliersRejection on the host (rounds 1-3 until be_reject_kernel)
     if (std::strcmp(key, "c0_side") == 0) { ctx->be.c0_side = value != 0; return 0; }      // 0: the prior's constant c0 is computed on the BA stream, inside be_marg_finish (rounds 1-2)
     if (std::strcmp(key, "ldl_wavecol") == 0) { ctx->be.ldl_wavecol_only = value != 0; return 0; }      // the round-2 wave-column LDL^T instead of the 16-wide MFMA form
@@ -778,6 +781,7 @@ int dv_ba_eval(dv_ctx* ctx, const dv_ba_problem* P, int* n_out, double* cost, do
     if (P->nimu) DV_CHECK(hipMemcpyAsync(io.data(), w.imu_out[0], 8 * (size_t)P->nimu * IMU_OUT_STRIDE, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipMemcpyAsync(pc.data(), w.prior_out[0], 8, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
+    if (be_dist_check(ctx)) return -1;
     if (cost) { double c = 0; for (int l = 0; l < P->nlm; ++l) c += lcost[l]; for (int k = 0; k < P->nimu; ++k) c += io[(size_t)k * IMU_OUT_STRIDE]; c += pc[0]; *cost = c; }
     if (g) for (int i = 0; i < n; ++i) g[i] = gv[i] - gv[n + i];
     if (S) for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) {          // unpack the block-packed lower triangle (be_solve.hip: blk_pos)

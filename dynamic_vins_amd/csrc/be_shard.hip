@@ -85,6 +85,8 @@ void be_dist_release(dv_ctx* ctx) {
     if (d.h_recv) (void)hipHostFree(d.h_recv);
     for (int r = 0; r < 64; ++r) { if (d.peer_win[r] && d.peer_win[r] != d.win) (void)hipIpcCloseMemHandle(d.peer_win[r]); d.peer_win[r] = nullptr; }
     if (d.win) (void)hipFree(d.win);
+    if (d.peer_dead) (void)hipHostFree(d.peer_dead);
+    d.peer_dead = nullptr;
     d.win = nullptr; d.win_slot = 0; d.seq = 0;
     d.h_send = d.h_recv = nullptr; d.transport = 0; d.rank = 0; d.world = 1; d.fn = nullptr; d.user = nullptr;
 }
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PeerArgs pa, const doubl
 }
 // block 0 first raises this rank's flag in every window (the push kernel before it on the stream has completed: its writes are visible system-wide); every
 // block then waits until all senders' flags in the LOCAL window carry this exchange's sequence number and copies the gathered vectors out
-__global__ __launch_bounds__(256) void peer_wait_kernel(PeerArgs pa, double* __restrict__ out, int count, size_t slot, int rank, int world, int parity, unsigned long long seq) {
+__global__ __launch_bounds__(256) void peer_wait_kernel(PeerArgs pa, double* __restrict__ out, int count, size_t slot, int rank, int world, int parity, unsigned long long seq,
+                                                        unsigned long long* __restrict__ dead, long long timeout_ticks) {
     const size_t foff = peer_flag_off(slot, world) / 8;
     if (blockIdx.x == 0 && (int)threadIdx.x < world) {
         unsigned long long* f = reinterpret_cast<unsigned long long*>(pa.win[threadIdx.x] + foff) + (size_t)parity * world + rank;
@@ -109,10 +112,14 @@ __global__ __launch_bounds__(256) void peer_wait_kernel(PeerArgs pa, double* __r
     unsigned long long* mine = reinterpret_cast<unsigned long long*>(pa.win[rank] + foff);
     if ((int)threadIdx.x < world) {
         unsigned long long* f = mine + (size_t)parity * world + threadIdx.x;
-        long long spins = 0;
+        const long long t0 = wall_clock64();
+        // bounded by the constant 100 MHz clock, not by a spin count; a time-out is recorded in pinned host memory (the collect of the solve reads it: be_dist_check)
+        // and is sticky — once a peer is known dead no later exchange waits for it again
+        unsigned spins = 0;
         while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if ((spins++ & 63u) == 0u && __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull) break;      // (a PCIe read: only now and then)
+            if (wall_clock64() - t0 > timeout_ticks) { __hip_atomic_store(dead, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > (1ll << 24)) { __hip_atomic_store(mine + 2 * world, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }      // a peer died: give up (seconds), flag it (dv_dist_info)
         }
     }
     __syncthreads();
@@ -128,8 +135,15 @@ static int peer_exchange(dv_ctx* ctx, size_t count, hipStream_t s) {
     const unsigned long long seq = ++d.seq; const int parity = (int)(seq & 1);
     const int chunks = (int)std::min<size_t>(16, (count + 1023) / 1024);
     hipLaunchKernelGGL(peer_push_kernel, dim3(chunks, d.world), dim3(256), 0, s, pa, (const double*)d.xsend.p, (int)count, d.win_slot, d.rank, d.world, parity);
-    hipLaunchKernelGGL(peer_wait_kernel, dim3(chunks), dim3(256), 0, s, pa, (double*)d.xrecv.p, (int)count, d.win_slot, d.rank, d.world, parity, seq);
+    hipLaunchKernelGGL(peer_wait_kernel, dim3(chunks), dim3(256), 0, s, pa, (double*)d.xrecv.p, (int)count, d.win_slot, d.rank, d.world, parity, seq, d.peer_dead, d.peer_timeout_ticks);
     DV_CHECK(hipGetLastError());
+    return 0;
+}
+
+int be_dist_check(dv_ctx* ctx) {
+    const DvDist& d = ctx->dist;
+    if (d.transport == 3 && d.peer_dead && *(volatile unsigned long long*)d.peer_dead != 0ull)
+        DV_FAIL("dv_dist: a peer did not deliver its exchange vector (transport peer: wait timed out at exchange " + std::to_string(*(volatile unsigned long long*)d.peer_dead) + "); the gathered buffer was not used");
     return 0;
 }
 
@@ -204,7 +218,10 @@ int dv_dist_peer_prepare(dv_ctx* ctx, int rank, int world, uint8_t handle[64]) {
     d.rank = rank; d.world = world; d.win_slot = (size_t)BE_XS_LEN(BE_MAX_LM);
     const size_t bytes = peer_flag_off(d.win_slot, world) + (2 * (size_t)world + 1) * 8 + 256;
     // fine-grained: remote writes and the local polling loads must be coherent inside a running kernel, not only at kernel boundaries
-    if (hipExtMallocWithFlags(&d.win, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); DV_CHECK(hipMalloc(&d.win, bytes)); }
+    // (no coarse-grained fall-back: in-kernel polling of remotely written flags is not coherent there — spurious time-outs or stale vectors)
+    if (hipExtMallocWithFlags(&d.win, bytes, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); d.win = nullptr; DV_FAIL("dv_dist_peer_prepare: fine-grained device memory is not available on this device; use the rccl or host transport"); }
+    DV_CHECK(hipHostMalloc((void**)&d.peer_dead, 64, hipHostMallocDefault));
+    *d.peer_dead = 0ull;
     DV_CHECK(hipMemset(d.win, 0, bytes));
     hipIpcMemHandle_t h;
     DV_CHECK(hipIpcGetMemHandle(&h, d.win));
@@ -252,12 +269,7 @@ int dv_dist_info(dv_ctx* ctx, int* rank, int* world, int* transport, long long* 
     if (world) *world = ctx->dist.world;
     if (transport) *transport = ctx->dist.transport;
     if (exchanges) *exchanges = ctx->dist.exchanges;
-    if (ctx->dist.transport == 3 && ctx->dist.win) {      // a wait kernel gave up on a peer
-        unsigned long long flag = 0;
-        const size_t off = peer_flag_off(ctx->dist.win_slot, ctx->dist.world) + 2 * (size_t)ctx->dist.world * 8;
-        DV_CHECK(hipMemcpy(&flag, (const uint8_t*)ctx->dist.win + off, 8, hipMemcpyDeviceToHost));
-        if (flag) DV_FAIL("dv_dist: a peer did not deliver its exchange vector (transport peer: wait timed out)");
-    }
+    if (be_dist_check(ctx)) return -1;      // a wait kernel gave up on a peer
     return 0;
 }
 
@@ -282,6 +294,7 @@ int dv_allreduce_reduced_system(dv_ctx* ctx, double* S_g, int n) {
         if (be_exchange(ctx, (size_t)n, s)) return -1;
         DV_CHECK(hipMemcpyAsync(all.data(), d.xrecv.p, 8 * all.size(), hipMemcpyDeviceToHost, s));
         DV_CHECK(hipStreamSynchronize(s));
+        if (be_dist_check(ctx)) return -1;
     }
     for (int i = 0; i < n; ++i) { double v = all[i]; for (int r = 1; r < d.world; ++r) v += all[(size_t)r * n + i]; S_g[i] = v; }
     return 0;

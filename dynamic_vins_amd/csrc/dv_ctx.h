@@ -154,7 +154,11 @@ struct DvDist {
     // transport 3: the window this rank exposes to its peers (hipIpc): [2 parities][world][slot] doubles, then [2][world] sequence flags, then a time-out flag;
     // peer_win[r] = rank r's window as mapped into this process (own window for r == rank)
     void* win = nullptr; size_t win_slot = 0; void* peer_win[64] = { nullptr }; unsigned long long seq = 0;
+    // a wait kernel that gave up on a peer writes the exchange's sequence number here (pinned host memory, sticky): every collect of a solve reads it and fails instead of
+    // consuming the gathered buffer; later wait kernels see it and do not wait again (one time-out per dead peer, not one per exchange)
+    unsigned long long* peer_dead = nullptr; long long peer_timeout_ticks = 200000000ll;      // wall_clock64 ticks (100 MHz): 2 s; dv_debug_set "peer_timeout_ms"
 };
+int be_dist_check(dv_ctx* ctx);      // 0 = every exchange so far was complete; -1 + error: a peer never delivered (transport peer)
 int be_exchange(dv_ctx* ctx, size_t count, hipStream_t s);      // all-gather `count` doubles of dist.xsend into dist.xrecv (rank-major), ordered on s
 int be_dist_buffers(dv_ctx* ctx);
 void be_dist_release(dv_ctx* ctx);

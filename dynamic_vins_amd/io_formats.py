@@ -5,6 +5,9 @@
   numbers are written in shortest round-trip form (fmt's "{}"), read back with float();
 * trajectory, one line per processed frame (utils/io/output.cpp:189-227, SaveBodyTrajectory):
       "<sec>.<nsec, 9 digits> px py pz qx qy qz qw"       fixed notation, 6 decimals  (TUM format -> evaluate_ate.py)
+* the reading side of the ATE metric (scripts/tum_tools/associate.py:49-100, evaluate_ate.py:130-155): `read_file_list` (stamp -> data tokens, comments / commas /
+  tabs tolerated), `associate` (greedy nearest-stamp pairing within max_difference) and `evaluate_ate` (association -> Horn alignment -> RMSE).  Pinned against the
+  reference's own functions by tests/golden/ate_associate.npz.
 """
 import numpy as np
 
@@ -83,3 +86,51 @@ def read_trajectory(path):
     """-> (stamps[n], poses[n, 7]) of a TUM-format file"""
     a = np.loadtxt(path, ndmin=2)
     return a[:, 0], a[:, 1:8]
+
+
+def read_file_list(path_or_text, is_text=False):
+    """associate.py:49-68: {stamp: [tokens]} of a "stamp d1 d2 ..." file; commas and tabs count as blanks, lines starting with '#' and lines with a single token
+    are dropped, a repeated stamp keeps its LAST line (dict construction)."""
+    data = path_or_text if is_text else open(path_or_text).read()
+    lines = data.replace(",", " ").replace("\t", " ").split("\n")
+    rows = [[v.strip() for v in line.split(" ") if v.strip() != ""] for line in lines if len(line) > 0 and line[0] != "#"]
+    return dict((float(r[0]), r[1:]) for r in rows if len(r) > 1)
+
+
+def associate(first_stamps, second_stamps, offset=0.0, max_difference=0.02):
+    """associate.py:70-100: every pair (a, b) with |a - (b + offset)| < max_difference is a candidate; candidates are taken in ascending (difference, a, b) order,
+    each stamp at most once; the matches come back sorted by (a, b).  -> list of (a, b).  (The reference's O(n1 n2) candidate list is built the same way:
+    the tie-breaking IS the tuple order, so nothing smarter is substituted.)"""
+    first = [float(a) for a in first_stamps]
+    second = [float(b) for b in second_stamps]
+    cand = [(abs(a - (b + offset)), a, b) for a in first for b in second if abs(a - (b + offset)) < max_difference]
+    cand.sort()
+    fa, sb = set(first), set(second)
+    matches = []
+    for _, a, b in cand:
+        if a in fa and b in sb:
+            fa.remove(a); sb.remove(b)
+            matches.append((a, b))
+    matches.sort()
+    return matches
+
+
+def evaluate_ate(gt_stamps, gt_xyz, est_stamps, est_xyz, offset=0.0, max_difference=0.02, scale=1.0):
+    """evaluate_ate.py:130-155 on arrays: associate(ground truth, estimate) -> align(estimate, ground truth) (Horn, no scale) -> RMSE of the translational error.
+    -> (rmse, n_pairs).  Raises like the script exits when fewer than two stamps pair up."""
+    from .sim import align_ate
+    gi = {float(t): i for i, t in enumerate(gt_stamps)}
+    ei = {float(t): i for i, t in enumerate(est_stamps)}
+    m = associate(list(gi), list(ei), offset, max_difference)
+    if len(m) < 2:
+        raise ValueError("Couldn't find matching timestamp pairs between groundtruth and estimated trajectory!")
+    g = np.asarray(gt_xyz, float)[[gi[a] for a, _ in m], :3]
+    e = np.asarray(est_xyz, float)[[ei[b] for _, b in m], :3] * float(scale)
+    return align_ate(e, g)[0], len(m)
+
+
+def evaluate_ate_files(gt_path, est_path, offset=0.0, max_difference=0.02, scale=1.0):
+    """the script's command line: two TUM files -> (rmse, n_pairs)"""
+    g, e = read_file_list(gt_path), read_file_list(est_path)
+    gs, es = sorted(g), sorted(e)
+    return evaluate_ate(gs, [[float(v) for v in g[t][0:3]] for t in gs], es, [[float(v) for v in e[t][0:3]] for t in es], offset, max_difference, scale)

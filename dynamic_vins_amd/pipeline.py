@@ -125,8 +125,11 @@ class Pipeline:
         return self._finish(t)
 
     def ate(self):
+        """ATE RMSE against the synthetic ground truth, computed the way the reference's scripts do: associate.py's nearest-stamp pairing (0.02 s) of the two
+        stamped trajectories, then evaluate_ate.py's alignment (io_formats.evaluate_ate)"""
+        from . import io_formats
         gt = [self.seq.traj.p(t) for t in self.pose_times]
-        return sim.align_ate(np.array(self.poses)[:, :3], gt)[0]
+        return io_formats.evaluate_ate(self.pose_times, gt, self.pose_times, np.array(self.poses)[:, :3])[0]
 
 
 class DynamicSequence(SyntheticSequence):

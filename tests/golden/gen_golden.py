@@ -16,6 +16,10 @@
                      restatements and the size-independent properties.
 3. back_kat.npz    — known-answer vectors of the back-end path from the oracle: factor residuals/Jacobians,
                      pre-integration of a fixed IMU sequence, one standalone window solve, one marginalization.
+1b. ate_associate.npz — REFERENCE-PINNED: outputs of the reference's own `associate()` (nearest-stamp matching of two TUM trajectories within
+                     max_difference, dynamic_vins/scripts/tum_tools/associate.py:70-100) and `read_file_list()` (:49-68) on seeded stamp lists / a small TUM
+                     text; the functions are Python-2 era (they .remove() from dict.keys()), so they are run from their source text on dict objects whose
+                     keys() returns a list, as it did when the file was written.
 4. aux_kat.npz     — the same for cv::remap with fixed-point maps, the object solve and the line-only solve (oracle outputs; parity unpinned).
 Only data is written: inputs and expected outputs.
 """
@@ -75,6 +79,64 @@ def gen_ate():
     np.savez_compressed(os.path.join(HERE, "ate_align.npz"), model=np.array(model), data=np.array(data), n=np.array([40 + 10 * c for c in range(8)]),
                         rot=np.array(rot), trans=np.array(trans), rmse=np.array(rmse))
     print("ate_align.npz: rmse", np.round(rmse, 5))
+
+
+REF_ASSOC = "/root/reference/dynamic_vins/scripts/tum_tools/associate.py"
+
+
+def gen_associate():
+    import ast
+    src = open(REF_ASSOC).read()
+    ns = {"__builtins__": {"abs": abs, "float": float, "dict": dict, "len": len, "open": None}}
+    for name in ("read_file_list", "associate"):
+        fn = re.search(r"^def %s\(.*?(?=^def |^if __name__)" % name, src, flags=re.S | re.M).group(0)
+        tree = ast.parse(fn)
+        assert len(tree.body) == 1 and isinstance(tree.body[0], ast.FunctionDef) and tree.body[0].name == name
+        for node in ast.walk(tree):      # untrusted text: one plain function, no imports / dunder access / nested definitions
+            assert not isinstance(node, (ast.Import, ast.ImportFrom, ast.Global, ast.Nonlocal, ast.Lambda, ast.ClassDef, ast.With, ast.Try)), type(node).__name__
+            if isinstance(node, ast.Attribute):
+                assert not node.attr.startswith("_"), node.attr
+            if isinstance(node, ast.Name):
+                assert not node.id.startswith("_"), node.id
+        exec(compile(tree, "<reference %s()>" % name, "exec"), ns)
+
+    class Py2Dict(dict):                   # dict.keys() of the interpreter the file was written for: a list (the function removes matched stamps from it)
+        def keys(self):
+            return list(dict.keys(self))
+    rng = np.random.default_rng(0xA550C)
+    out = {}
+    cases = []
+    for case in range(10):
+        n1, n2 = 30 + 7 * case, 25 + 9 * case
+        a = np.cumsum(rng.uniform(0.03, 0.07, n1)) + 1403636579.0
+        if case % 3 == 0:                  # second list = jittered subset of the first (the usual ground truth / estimate pairing)
+            b = np.sort(rng.choice(a, size=min(n2, n1), replace=False)) + rng.normal(0, 0.006, min(n2, n1))
+        elif case % 3 == 1:                # independent clock: many stamps without a partner, some with two candidates
+            b = np.cumsum(rng.uniform(0.02, 0.09, n2)) + 1403636579.0 + 0.011
+        else:                              # dense second list: several candidates per stamp, ties in |diff| broken by the tuple order (diff, a, b)
+            b = np.round(np.cumsum(rng.uniform(0.004, 0.012, 4 * n2)) + 1403636579.0, 3)
+            a = np.round(a, 3)
+        offset = [0.0, 0.013, -0.02][case % 3]
+        maxd = [0.02, 0.02, 0.01, 0.05][case % 4]
+        first = Py2Dict((float(t), ["%d" % i]) for i, t in enumerate(a))
+        second = Py2Dict((float(t), ["%d" % i]) for i, t in enumerate(b))
+        m = ns["associate"](first, second, offset, maxd)
+        cases.append((np.array(sorted(first.keys())), np.array(sorted(second.keys())), offset, maxd, np.array(m, np.float64).reshape(-1, 2)))
+    for k, (a, b, off, md, m) in enumerate(cases):
+        out[f"a{k}"], out[f"b{k}"], out[f"par{k}"], out[f"m{k}"] = a, b, np.array([off, md]), m
+    out["n_cases"] = np.array(len(cases))
+    # read_file_list on a TUM text with comments, commas, tabs, blank lines and a one-token line (dropped): stamps and the first three data columns
+    text = ("# timestamp tx ty tz qx qy qz qw\n1403636579.763555992 1.0 -2.5 0.125 0 0 0.7 0.7\n\n1403636579.813555992,4.0,5.5,6.25,0,0,0,1\n"
+            "1403636579.863555992\t7 8 9 0 0 0 1\n12345\n  1403636579.913555992   10 11 12   0 0 0 1\n")
+    import io as _io
+    ns["__builtins__"]["open"] = lambda fn: _io.StringIO(text)
+    lst = ns["read_file_list"]("mem")
+    keys = sorted(lst.keys())
+    out["rfl_text"] = np.frombuffer(text.encode(), np.uint8)
+    out["rfl_stamps"] = np.array(keys)
+    out["rfl_xyz"] = np.array([[float(v) for v in lst[k][0:3]] for k in keys])
+    np.savez_compressed(os.path.join(HERE, "ate_associate.npz"), **out)
+    print("ate_associate.npz: matches per case", [len(c[4]) for c in cases], "read_file_list rows", len(keys))
 
 
 def gen_front(o):
@@ -206,6 +268,7 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ate", "front", "back", "aux"]
     if "ate" in which:
         gen_ate()
+        gen_associate()
     o = oracle_py.load()
     if "front" in which:
         gen_front(o)

@@ -9,7 +9,8 @@ CPU (`-m "not gpu"`; skipped where /root/reference is absent — the GPU box):
 GPU (`-m gpu`): images -> trajectory parity against the oracle AT those parameter sets, from pixels, dynamic mode, objects in every frame:
   viode.yaml (752x480, 160 / 20, erosion 5, 8 iterations, VIO), zed_1280x720_vision_only/dynamic.yaml (1280x720, 400 / 25, erosion 20, 10 iterations,
   vision only, use_det3d 1, two different undistorted cameras), kitti_tracking_online.yaml (1242x375, dynamic + use_line 1 + plane_constraint 1:
-  LinePoint + dynamic with detector segments through UndistortedLineEndPoints).  Bars as in tests/test_dynamic_pipeline.py."""
+  LinePoint + dynamic with detector segments through UndistortedLineEndPoints), and BASELINE.json config 5 as stated — the ZED set with use_line 1
+  (1280x720 LinePoint + dynamic together).  Bars as in tests/test_dynamic_pipeline.py."""
 import glob
 import os
 import subprocess
@@ -99,7 +100,9 @@ def test_tables_match_the_shipped_yamls():
         assert (c["w"], c["h"]) == (int(y["image_width"]), int(y["image_height"])), name
         assert (c["max_cnt"], c["min_dist"], c["max_iters"]) == (int(y["max_cnt"]), int(y["min_dist"]), int(y["max_num_iterations"])), name
         assert c["mask_morphology_size"] == (int(y["mask_morphology_size"]) if int(y["use_mask_morphology"]) else 0), name
-        assert c["use_imu"] == int(y["imu"]) and c["use_line"] == int(y["use_line"]) and c["plane_constraint"] == int(y["plane_constraint"]), name
+        ov = c.get("overrides", ())          # keys an entry deliberately sets differently from the file it cites (zed_linepoint_dynamic: use_line)
+        assert set(ov) <= {"use_line"}, name
+        assert c["use_imu"] == int(y["imu"]) and ("use_line" in ov or c["use_line"] == int(y["use_line"])) and c["plane_constraint"] == int(y["plane_constraint"]), name
         assert c["keyframe_parallax"] == float(y["keyframe_parallax"]) and c["g_norm"] == float(y["g_norm"]), name
         assert c["noise"] == {k: float(y[k]) for k in ("acc_n", "gyr_n", "acc_w", "gyr_w")}, name
         assert (c["min_dynamic_dist"], c["max_dynamic_cnt"], c["instance_init_min_num"]) == (int(y["min_dynamic_dist"]), int(y["max_dynamic_cnt"]), int(y["instance_init_min_num"])), name
@@ -194,6 +197,7 @@ def run_config(oracle, name, frames, n_boxes=4):
     ate_gt = pipe.ate()
     pipe.ctx.close()
     ate_vs_oracle = sim.align_ate(np.array(dev_p), np.array(ref_p))[0] if len(dev_p) >= 3 else None
+    st["dev_traj"] = np.array(dev_p)
     return st, ate_gt, ate_vs_oracle
 
 
@@ -228,3 +232,20 @@ def test_kitti_tracking_online_line_point_dynamic_from_pixels(oracle):
     st, ate_gt, ate_o = run_config(oracle, "kitti_tracking_online", 36)
     check(st, ate_o, 36)
     assert st["lines"] >= 10 and st["line_tri"] >= 3, st          # (36 frames of a 1242x375 view: few segments stay long enough to be triangulated)
+
+
+@pytest.mark.gpu
+def test_zed_1280x720_line_point_dynamic_from_pixels(oracle):
+    """BASELINE.json config 5 as stated: ZED 1280x720, 400 features / min_dist 25, erosion 20, vision only, use_det3d 1 — LinePoint AND dynamic together.
+    Same bars as the other parameter sets (background / object rows bit-identical, line tables identical on every frame, window and object states against the
+    oracle) and, because the reference's lineProjectionFactor::sqrt_info is zero (SURVEY 0.6), the ego trajectory must equal the use_line 0 run of the same
+    sequence up to ceres' parameter-tolerance norm (the line blocks only count in |x|)."""
+    frames = 36
+    st, ate_gt, ate_o = run_config(oracle, "zed_linepoint_dynamic", frames)
+    check(st, ate_o, frames)
+    assert st["bg_rows"] > 300 * frames, st
+    assert st["lines"] >= 10 and st["line_tri"] >= 3, st
+    assert ate_gt < 0.1, ate_gt
+    st0, _, _ = run_config(oracle, "zed_dynamic", frames)
+    a, b = st["dev_traj"], st0["dev_traj"]
+    assert a.shape == b.shape and np.abs(a - b).max() < 1e-6, np.abs(a - b).max()

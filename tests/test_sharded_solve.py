@@ -90,3 +90,23 @@ def test_two_ranks_on_one_gpu_reproduce_the_unsharded_solve(tmp_path, transport)
     # operator: rank-ordered sum of v_r = arange * (1 + r) + 0.1 r
     want = np.arange(1000, dtype=np.float64) * 1.0 + (np.arange(1000, dtype=np.float64) * 2.0 + 0.1)
     assert np.array_equal(R[0]["allreduce"], want) and np.array_equal(R[1]["allreduce"], want)
+
+
+def test_peer_transport_reports_a_silent_peer(tmp_path):
+    """failure path of the one-shot peer transport: a peer that never raises its flag turns into an ERROR of the solve that needed it (bounded wait on the
+    device, flag in pinned memory read at the collect), the wait is paid once (sticky), and dv_dist_info reports it — never a result from a stale buffer"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_shard_dead_worker.py"), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    first, second, info, times = open(tmp_path / "dead_rank0.txt").read().splitlines()
+    for msg in (first, second, info):
+        assert "peer did not deliver" in msg, (first, second, info)
+    t_first, t_second = map(float, times.split())
+    assert 0.25 < t_first < 30.0          # one time-out of 0.3 s (plus the slots enqueued behind it, which no longer wait)
+    assert t_second < t_first             # sticky: a known-dead peer is not waited for again

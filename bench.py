@@ -391,6 +391,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 a = time.perf_counter()
                 if args.mode == "dynamic":
                     rows = trk.track_image(host[k][0], host[k][1], t, mask=seq.inv_mask[k], mode=2, erode_k=args.erode)
+                    oin.set_disparity(seq.disp_host(k), seq.baseline)
                     io, fo, po = oin.track(host[k][0], host[k][1], t, seq.dets[k], seq.boxes3d[k], dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
                 else:
                     rows = trk.track_image(host[k][0], host[k][1], t)

@@ -99,6 +99,8 @@ SIGNATURES = {
     "dv_inst_config": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
     "dv_inst_reset": (C.c_int, [_ctx]),
     "dv_inst_track_enqueue": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "dv_inst_set_disparity": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_double]),
+    "dv_extra_points": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_inst_track_collect": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_est_get_instances": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "dv_timing_enable": (C.c_int, [_ctx, C.c_int]),

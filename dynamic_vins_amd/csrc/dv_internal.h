@@ -95,3 +95,9 @@ void dv_launch_circle_mask(uint8_t* mask, int w, int h, int pitch, const float2*
 void dv_launch_erode(const uint8_t* src, int w, int h, int spitch, int k, uint8_t* tmp, int tpitch, uint8_t* dst, int dpitch,
                      hipStream_t s);
 void dv_launch_lift(const dv_cam& cam, const float2* in, int n, double off_x, double off_y, float2* out, hipStream_t s);
+// the extra-point pipeline of dynamic mode (extra_points.hip): one job = one visible object
+#define DV_XP_CAP 3200       // points per object after sampling: step = max(sqrt(0.8 rows cols / 1000), 2) bounds the grid by ~3130 nodes for images up to 1280 wide
+struct DvExtraJob { const uint8_t* mask; int mask_pitch, cols, rows, box_x, box_y, step; double* out; int* n_out; };      // out: 3 * DV_XP_CAP doubles, n_out: count (device or pinned host memory)
+struct DvExtraArgs { const float* disp; int disp_pitch /* elements */, disp_w, disp_h; float fx0, fy0, cx0, cy0, baseline; int* err_flag; int stage /* 1: stop after the sampling */; };
+int dv_launch_extra_points(const DvExtraJob* jobs_dev, int n_jobs, const DvExtraArgs& a, hipStream_t s);
+int dv_extra_points_step(int rows, int cols);

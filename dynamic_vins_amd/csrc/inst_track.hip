@@ -86,7 +86,16 @@ struct dv_inst_tracker {
     DevBuf arena; void* arena_pinned = nullptr; size_t arena_cap = 0;  // per-frame job tables of the batched per-object stages (ROI crops, pyramid levels): filled on the host, ONE upload
     DevBuf cand, scal; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
     std::vector<unsigned> out_order;                            // ids written this frame, in output order
+    // extra points from the frame's disparity map (dv_inst_set_disparity; extra_points.hip): the reference's second thread = a side stream
+    const float* disp_user = nullptr; int disp_stride = 0, disp_mem = 0; double disp_baseline = 0; bool disp_next = false, xp_frame = false, xp_inflight = false;
+    DevBuf disp_buf; hipStream_t xstream = nullptr; hipEvent_t ev_xin = nullptr, ev_xdone = nullptr;
+    void* xp_pinned = nullptr; size_t xp_cap_slots = 0;          // per output slot: count (64 bytes) + 3 * DV_XP_CAP doubles, written by the kernel straight into pinned memory
     ~dv_inst_tracker() {
+        disp_buf.release();
+        if (xstream) { (void)hipStreamSynchronize(xstream); (void)hipStreamDestroy(xstream); }
+        if (ev_xin) (void)hipEventDestroy(ev_xin);
+        if (ev_xdone) (void)hipEventDestroy(ev_xdone);
+        if (xp_pinned) (void)hipHostFree(xp_pinned);
         for (auto& kv : slots) kv.second.release();
         hw.release(); out_buf.release(); cand.release(); scal.release(); jobs.release();
         if (jobs_pinned) (void)hipHostFree(jobs_pinned);
@@ -158,6 +167,9 @@ int dv_inst_config(dv_ctx* ctx, int max_dynamic_cnt, int min_dynamic_dist, int u
         ctx->inst = new dv_inst_tracker();
         DV_CHECK(hipEventCreateWithFlags(&ctx->inst->done, hipEventDisableTiming));
         DV_CHECK(hipStreamCreateWithFlags(&ctx->inst->stream, hipStreamNonBlocking));
+        DV_CHECK(hipStreamCreateWithFlags(&ctx->inst->xstream, hipStreamNonBlocking));
+        DV_CHECK(hipEventCreateWithFlags(&ctx->inst->ev_xin, hipEventDisableTiming));
+        DV_CHECK(hipEventCreateWithFlags(&ctx->inst->ev_xdone, hipEventDisableTiming));
         const int cap = std::max(4096, (ctx->cfg.width * ctx->cfg.height) / 4);
         DV_CHECK(ctx->inst->cand.ensure((size_t)cap * sizeof(DvCand))); ctx->inst->cand_cap = cap;
         DV_CHECK(ctx->inst->scal.ensure(256)); DV_CHECK(hipMemset(ctx->inst->scal.p, 0, 256));
@@ -179,6 +191,8 @@ int dv_inst_reset(dv_ctx* ctx) {
     DV_CHECK(hipSetDevice(ctx->cfg.device));
     DV_CHECK(hipStreamSynchronize(ctx->stream)); DV_CHECK(hipStreamSynchronize(ctx->inst->stream));
     for (auto& kv : ctx->inst->slots) kv.second.release();
+    DV_CHECK(hipStreamSynchronize(ctx->inst->xstream));
+    ctx->inst->disp_next = ctx->inst->xp_frame = ctx->inst->xp_inflight = false;
     ctx->inst->slots.clear(); ctx->inst->pending = false; ctx->inst->last_time = ctx->inst->cur_time = 0; ctx->inst->out_order.clear();
     return 0;
 }
@@ -196,6 +210,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
     hipStream_t s = T.stream;
     if (!ctx->ev_pyr || !ctx->ev_bg_select) DV_FAIL("dv_inst_track: internal events missing");
     DV_CHECK(hipStreamWaitEvent(s, ctx->ev_pyr, 0));
+    if (T.xp_inflight) { DV_CHECK(hipStreamWaitEvent(s, T.ev_xdone, 0)); T.xp_inflight = false; }      // the previous frame's extra-point kernel read the masks this frame's uploads overwrite
     bool waited_bg = false;
     const int W = ctx->cfg.width, H = ctx->cfg.height;
     const DvPyr& L = ctx->left[ctx->cur].pyr; const DvPyr& R = ctx->right.pyr;
@@ -242,6 +257,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         }
     }
     T.out_order.clear();
+    if (n_dets == 0) { T.xp_frame = false; T.disp_next = false; }
     StageScope sc_all(ctx, "inst_track", s);
     if (n_dets > 0) {
         // masks: one pinned staging area, one H2D per object (sources are pageable caller memory)
@@ -284,7 +300,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         // ---- stage A: masks, then the ROI crops / re-paddings and the pyramid levels of ALL objects as one launch each (they were 1 + 2 + 3 launches per object, on
         // one stream: with four objects a chain of ~50 dependent launches per frame, ~0.8 ms of latency between the enqueue and the rows) ----
         {
-            const size_t need = ((size_t)na * 2 * sizeof(RoiJob) + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob) + 1024);
+            const size_t need = ((size_t)na * 2 * sizeof(RoiJob) + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob) + (size_t)na * sizeof(DvExtraJob) + 2048);
             if (need > T.arena_cap) {
                 DV_CHECK(hipStreamSynchronize(s));
                 const size_t cap = need * 2;
@@ -299,6 +315,20 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         DvPyrJob* h_pyr = (DvPyrJob*)((uint8_t*)T.arena_pinned + (((size_t)na * 2 * sizeof(RoiJob) + 255) / 256) * 256);
         const size_t pyr_off = (uint8_t*)h_pyr - (uint8_t*)T.arena_pinned;
         int n_pyr[DV_MAX_LEVELS] = { 0 }, pyr_W[DV_MAX_LEVELS] = { 0 }, pyr_H[DV_MAX_LEVELS] = { 0 };      // per level l >= 1: jobs [l * na, l * na + n_pyr[l])
+        // extra points of this frame from its disparity map: one job per visible object behind the pyramid jobs in the same upload
+        const size_t xp_off = ((pyr_off + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob)) + 255) / 256 * 256;
+        DvExtraJob* h_xp = (DvExtraJob*)((uint8_t*)T.arena_pinned + xp_off);
+        const size_t xp_slot_bytes = 64 + (size_t)3 * DV_XP_CAP * sizeof(double);
+        T.xp_frame = T.disp_next; T.disp_next = false;
+        if (T.xp_frame && T.xp_cap_slots < (size_t)na) {
+            DV_CHECK(hipStreamSynchronize(T.xstream));
+            if (T.xp_pinned) (void)hipHostFree(T.xp_pinned);
+            T.xp_pinned = nullptr; T.xp_cap_slots = 0;
+            const size_t cap = std::max<size_t>(8, (size_t)na * 2);
+            DV_CHECK(hipHostMalloc(&T.xp_pinned, cap * xp_slot_bytes, hipHostMallocDefault));
+            T.xp_cap_slots = cap;
+        }
+        int n_xp = 0;
         for (Slot* Sp : act) {
             Slot& S = *Sp;
             const int w = S.rw, h = S.rh;
@@ -307,6 +337,10 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             const dv_inst_det* det = nullptr; for (int i = 0; i < n_dets; ++i) if (dets[i].track_id == S.id) det = &dets[i];
             for (int y = 0; y < h; ++y) std::memcpy(hm + (size_t)y * mp, det->mask + (size_t)y * w, w);
             DV_CHECK(hipMemcpyAsync(S.mask.p, hm, (size_t)mp * h, hipMemcpyHostToDevice, s));
+            if (T.xp_frame) {          // ProcessExtraPoints visits the visible objects (ExecInst + is_curr_visible); slot k of the pinned output = k-th active object = its output index
+                uint8_t* xo = (uint8_t*)T.xp_pinned + (size_t)n_xp * xp_slot_bytes;
+                h_xp[n_xp++] = DvExtraJob{ (const uint8_t*)S.mask.p, mp, w, h, S.rx, S.ry, dv_extra_points_step(h, w), (double*)(xo + 64), (int*)xo };
+            }
             // this frame's ROI, padded to the common size with the previous one (InstanceImagePadding)
             S.cur ^= 1;
             RoiPyr& B = S.roi[S.cur]; RoiPyr& Prev = S.roi[S.cur ^ 1];
@@ -328,7 +362,22 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             }
         }
         if (na > 0) {
-            DV_CHECK(hipMemcpyAsync(T.arena.p, T.arena_pinned, pyr_off + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob), hipMemcpyHostToDevice, s));
+            DV_CHECK(hipMemcpyAsync(T.arena.p, T.arena_pinned, T.xp_frame ? xp_off + (size_t)na * sizeof(DvExtraJob) : pyr_off + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob), hipMemcpyHostToDevice, s));
+            if (T.xp_frame && n_xp > 0) {
+                // the reference starts a thread for this (dynamic_tracker.cpp:378): a side stream behind the mask + table uploads; the objects' tracking goes on meanwhile
+                DV_CHECK(hipEventRecord(T.ev_xin, s));
+                DV_CHECK(hipStreamWaitEvent(T.xstream, T.ev_xin, 0));
+                const float* dmap = T.disp_user; int dpitch = T.disp_stride / 4;
+                if (T.disp_mem != DV_MEM_DEVICE) {
+                    DV_CHECK(T.disp_buf.ensure((size_t)W * H * 4));
+                    DV_CHECK(hipMemcpy2DAsync(T.disp_buf.p, (size_t)W * 4, T.disp_user, (size_t)T.disp_stride, (size_t)W * 4, H, hipMemcpyHostToDevice, T.xstream));
+                    dmap = (const float*)T.disp_buf.p; dpitch = W;
+                }
+                DvExtraArgs xa{ dmap, dpitch, W, H, (float)ctx->cfg.cam0.fx, (float)ctx->cfg.cam0.fy, (float)ctx->cfg.cam0.cx, (float)ctx->cfg.cam0.cy, (float)T.disp_baseline, T.err_flag, 0 };
+                StageScope scx(ctx, "inst_extra_points", T.xstream);
+                if (dv_launch_extra_points((const DvExtraJob*)((const uint8_t*)T.arena.p + xp_off), n_xp, xa, T.xstream)) DV_FAIL("extra_points: cannot set dynamic LDS size");
+                T.xp_inflight = true;
+            }
             { dim3 grid((roi_W + 255) / 256, roi_H, n_roi); hipLaunchKernelGGL(roi_pad_multi_kernel, grid, dim3(256), 0, s, (const RoiJob*)T.arena.p); }
             const DvPyrJob* d_pyr = (const DvPyrJob*)((const uint8_t*)T.arena.p + pyr_off);
             for (int l = 1; l < DV_MAX_LEVELS; ++l) dv_launch_pyr_down_multi(d_pyr + (size_t)l * na, n_pyr[l], pyr_W[l], pyr_H[l], s);
@@ -389,8 +438,61 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         if (erase) { DV_CHECK(hipStreamSynchronize(s)); S.release(); it = T.slots.erase(it); } else ++it;
     }
     DV_CHECK(hipGetLastError());
+    if (T.xp_inflight) DV_CHECK(hipEventRecord(T.ev_xdone, T.xstream));
     DV_CHECK(hipEventRecord(T.done, s));
     T.last_time = T.cur_time; T.pending = true; T.frame_enqueued = true;
+    return 0;
+}
+
+// SemanticImage::disp of the frame the NEXT dv_inst_track_enqueue processes (include/dvins.h)
+int dv_inst_set_disparity(dv_ctx* ctx, const float* disp, int stride_bytes, int mem, double baseline) {
+    if (!ctx) return -1;
+    if (!ctx->inst) DV_FAIL("dv_inst_set_disparity: call dv_inst_config first");
+    dv_inst_tracker& T = *ctx->inst;
+    if (!disp) { T.disp_next = false; return 0; }
+    if (stride_bytes == 0) stride_bytes = 4 * ctx->cfg.width;
+    if (stride_bytes < 4 * ctx->cfg.width || (stride_bytes & 3) || !(baseline > 0)) DV_FAIL("dv_inst_set_disparity: bad stride / baseline");
+    T.disp_user = disp; T.disp_stride = stride_bytes; T.disp_mem = mem; T.disp_baseline = baseline; T.disp_next = true;
+    return 0;
+}
+
+// one object through DetectExtraPoints (+ ProcessExtraPoints' point-cloud half): operator form for the parity tests
+int dv_extra_points(dv_ctx* ctx, const uint8_t* mask, int x, int y, int w, int h, const float* disp, int stride_bytes, int mem, double baseline, int stage,
+                    double* out_xyz, int cap_out, int* n_out) {
+    if (!ctx) return -1;
+    if (!mask || !disp || !out_xyz || !n_out || w <= 0 || h <= 0 || cap_out < 0 || (stage != 0 && stage != 1)) DV_FAIL("dv_extra_points: bad argument");
+    const int W = ctx->cfg.width, H = ctx->cfg.height;
+    if (stride_bytes == 0) stride_bytes = 4 * W;
+    if (stride_bytes < 4 * W || (stride_bytes & 3)) DV_FAIL("dv_extra_points: bad stride");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = ctx->stream;
+    const int mp = align_up(w, 16);
+    DV_CHECK(ctx->s0.ensure((size_t)mp * h));
+    DV_CHECK(hipMemcpy2DAsync(ctx->s0.p, mp, mask, w, w, h, hipMemcpyHostToDevice, s));
+    const float* dmap = disp; int dpitch = stride_bytes / 4;
+    if (mem != DV_MEM_DEVICE) {
+        DV_CHECK(ctx->s1.ensure((size_t)W * H * 4));
+        DV_CHECK(hipMemcpy2DAsync(ctx->s1.p, (size_t)W * 4, disp, (size_t)stride_bytes, (size_t)W * 4, H, hipMemcpyHostToDevice, s));
+        dmap = (const float*)ctx->s1.p; dpitch = W;
+    }
+    const size_t out_bytes = 64 + (size_t)3 * DV_XP_CAP * sizeof(double);
+    DV_CHECK(ctx->s2.ensure(out_bytes + sizeof(DvExtraJob) + 256));
+    uint8_t* ob = (uint8_t*)ctx->s2.p;
+    DvExtraJob job{ (const uint8_t*)ctx->s0.p, mp, w, h, x, y, dv_extra_points_step(h, w), (double*)(ob + 64), (int*)ob };
+    DvExtraJob* jd = (DvExtraJob*)(ob + out_bytes + 128);
+    DV_CHECK(hipMemcpyAsync(jd, &job, sizeof(job), hipMemcpyHostToDevice, s));
+    DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, s));
+    DvExtraArgs xa{ dmap, dpitch, W, H, (float)ctx->cfg.cam0.fx, (float)ctx->cfg.cam0.fy, (float)ctx->cfg.cam0.cx, (float)ctx->cfg.cam0.cy, (float)baseline, ctx->err_flag, stage };
+    if (dv_launch_extra_points(jd, 1, xa, s)) DV_FAIL("extra_points: cannot set dynamic LDS size");
+    DV_CHECK(hipGetLastError());
+    int n = 0, ef = 0;
+    DV_CHECK(hipMemcpyAsync(&n, ob, 4, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipMemcpyAsync(&ef, ctx->err_flag, 4, hipMemcpyDeviceToHost, s));
+    DV_CHECK(hipStreamSynchronize(s));
+    if (ef) { DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, s)); DV_FAIL("dv_extra_points: more than DV_XP_CAP sampled points (device error flags=" + std::to_string(ef) + ")"); }
+    if (n > cap_out) DV_FAIL("dv_extra_points: output buffer too small");
+    if (n > 0) DV_CHECK(hipMemcpy(out_xyz, ob + 64, (size_t)n * 24, hipMemcpyDeviceToHost));
+    *n_out = n;
     return 0;
 }
 
@@ -401,9 +503,10 @@ int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n
     dv_inst_tracker& T = *ctx->inst;
     if (!T.pending) DV_FAIL("dv_inst_track_collect: nothing enqueued");
     if (!n_insts || !n_feats || !n_points) DV_FAIL("dv_inst_track_collect: null counter");
-    { HostScope hw(ctx, "h_inst_wait"); DV_CHECK(hipEventSynchronize(T.done)); }      // the object tracker's launch chain of this frame
+    { HostScope hw(ctx, "h_inst_wait"); DV_CHECK(hipEventSynchronize(T.done)); if (T.xp_frame && T.xp_inflight) DV_CHECK(hipEventSynchronize(T.ev_xdone)); }      // the object tracker's launch chain of this frame (+ the extra-point side stream)
     T.pending = false;
-    if (ctx->timing) { DV_CHECK(hipStreamSynchronize(T.stream)); dv_harvest_timers(ctx, T.stream); }
+    if (ctx->timing) { DV_CHECK(hipStreamSynchronize(T.stream)); dv_harvest_timers(ctx, T.stream); DV_CHECK(hipStreamSynchronize(T.xstream)); dv_harvest_timers(ctx, T.xstream); }
+    const size_t xp_slot_bytes = 64 + (size_t)3 * DV_XP_CAP * sizeof(double);
     const size_t slot_bytes = INST_CAP * sizeof(dv_feat) + 64;
     int ki = 0, kf = 0, kp = 0;
     for (unsigned id : T.out_order) {
@@ -413,7 +516,10 @@ int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n
         if (!S.out_valid) continue;
         const dv_feat* rows = (const dv_feat*)((const uint8_t*)T.out_pinned + (size_t)S.out_index * slot_bytes);
         const int n = *(const int*)((const uint8_t*)rows + INST_CAP * sizeof(dv_feat));
-        const int np = (int)(S.pts_copy.size() / 3);
+        // extra points: computed on the device from the frame's disparity map (slot = output index), or the caller's (pass-through)
+        const uint8_t* xs = T.xp_frame ? (const uint8_t*)T.xp_pinned + (size_t)S.out_index * xp_slot_bytes : nullptr;
+        const int np = xs ? *(const int*)xs : (int)(S.pts_copy.size() / 3);
+        const double* psrc = xs ? (const double*)(xs + 64) : S.pts_copy.data();
         if (ki >= cap_insts || kf + n > cap_feats || kp + np > cap_points) DV_FAIL("dv_inst_track_collect: output buffers too small");
         dv_inst_obs& o = insts[ki++];
         std::memset(&o, 0, sizeof(o));
@@ -421,7 +527,7 @@ int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n
         o.rect[0] = (float)S.rx; o.rect[1] = (float)S.ry; o.rect[2] = (float)S.rw; o.rect[3] = (float)S.rh;
         if (S.has_box3d) o.box3d = S.box3d;
         if (n > 0) std::memcpy(feats + kf, rows, (size_t)n * sizeof(dv_feat));
-        if (np > 0) std::memcpy(points + 3 * (size_t)kp, S.pts_copy.data(), 24 * (size_t)np);
+        if (np > 0) std::memcpy(points + 3 * (size_t)kp, psrc, 24 * (size_t)np);
         kf += n; kp += np;
     }
     *n_insts = ki; *n_feats = kf; *n_points = kp;

@@ -104,6 +104,29 @@ class Context:
         self._inst_keep.append(b3)
         self._check(self.lib.dv_inst_track_enqueue(self.h, float(t), C.addressof(arr) if len(dets) else None, len(dets), b3.ctypes.data if len(b3) else None, len(b3)))
 
+    def inst_set_disparity(self, disp, baseline, mem=DV_MEM_HOST, stride_bytes=0):
+        """SemanticImage::disp of the frame the next inst_track_enqueue processes: float32 [h, w] numpy array (host) or a device pointer (int, mem=DV_MEM_DEVICE, kept alive
+        by the caller until inst_track_collect).  The extra points of every visible object are then computed on the device (DetectExtraPoints + ProcessExtraPoints)."""
+        if disp is None:
+            self._check(self.lib.dv_inst_set_disparity(self.h, None, 0, 0, 0.0))
+            return
+        if isinstance(disp, np.ndarray):
+            self._disp_keep = np.ascontiguousarray(disp, np.float32)
+            ptr, mem, stride_bytes = self._disp_keep.ctypes.data, DV_MEM_HOST, self._disp_keep.strides[0]
+        else:
+            ptr = int(disp)
+        self._check(self.lib.dv_inst_set_disparity(self.h, ptr, int(stride_bytes), int(mem), float(baseline)))
+
+    def extra_points(self, mask, box_xy, disp, baseline, stage=0):
+        """operator form: one object through InstFeat::DetectExtraPoints (stage 1) or the whole extra-point pipeline (stage 0) -> float64 [n, 3]"""
+        mask = np.ascontiguousarray(mask, np.uint8); disp = np.ascontiguousarray(disp, np.float32)
+        h, w = mask.shape
+        out = np.zeros((4096, 3), np.float64)
+        n = C.c_int(0)
+        self._check(self.lib.dv_extra_points(self.h, mask.ctypes.data, int(box_xy[0]), int(box_xy[1]), w, h, disp.ctypes.data, disp.strides[0], DV_MEM_HOST, float(baseline), int(stage),
+                                             out.ctypes.data, len(out), C.byref(n)))
+        return out[: n.value].copy()
+
     def inst_track_collect(self):
         """-> (insts [INSTOBS_DTYPE], feats [FEAT_DTYPE], points [n, 3]) laid out as Estimator.ProcessMeasurementsDynamic takes them"""
         oi, of, op = self._inst_out

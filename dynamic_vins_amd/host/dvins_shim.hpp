@@ -496,6 +496,11 @@ public:
         detail::check(ctx_, dv_inst_config(ctx_, max_dynamic_cnt, min_dynamic_dist, use_det3d), "InstsFeatManager");
         alloc();
     }
+    // SemanticImage::disp (CV_32F) of the frame the next InstsTrack call processes: the library then runs InstFeat::DetectExtraPoints + ProcessExtraPoints
+    // (instance_feature.cpp:413-461, dynamic_tracker.cpp:159-340) for every visible object on the device; without it dv_inst_det::points are handed through
+    void SetDisparity(const float* disp, int stride_bytes, double baseline, bool device = false) {
+        detail::check(ctx_, dv_inst_set_disparity(ctx_, disp, stride_bytes, device ? DV_MEM_DEVICE : DV_MEM_HOST, baseline), "SetDisparity");
+    }
     void InstsTrack(double time, const std::vector<dv_inst_det>& dets, const std::vector<dv_box3d>& boxes3d = {}) {
         detail::check(ctx_, dv_inst_track_enqueue(ctx_, time, dets.empty() ? nullptr : dets.data(), (int)dets.size(), boxes3d.empty() ? nullptr : boxes3d.data(), (int)boxes3d.size()), "InstsTrack");
         pending_ = true;

@@ -152,6 +152,7 @@ class DynamicSequence(SyntheticSequence):
         rr = DynRoomRenderer(cam, w, h, device=device, seed=seed, cam1=cam1)
         self.times = [self.t0 + k * self.dt for k in range(n_frames)]
         self.frames, self.inv_mask, self.inv_mask_dev, self.dets, self.boxes3d = [], [], [], [], []
+        self.disp_dev, self.baseline = [], float(baseline)      # SemanticImage::disp per frame (CV_32F, resident): what the stereo network of the reference delivers
         rays = rr.rays.cpu().numpy().reshape(h, w, 3)
         for t in self.times:
             left, right, ident, depth = rr.stereo_dynamic(self.traj, t, self.boxes, self.rig["t_ic1"])
@@ -159,6 +160,10 @@ class DynamicSequence(SyntheticSequence):
             idm, dep = ident.cpu().numpy(), depth.cpu().numpy()
             self.inv_mask.append(np.ascontiguousarray(np.where(idm == 0, 255, 0).astype(np.uint8)))
             self.inv_mask_dev.append(torch.where(ident == 0, 255, 0).to(torch.uint8).contiguous())      # resident next to the frames
+            # disparity of the left image: fx0 * baseline / depth in float (0 where the ray hits nothing), the map InstFeat::DetectExtraPoints samples
+            fxb = torch.tensor(np.float32(np.float32(cam["fx"]) * np.float32(baseline)), dtype=torch.float32, device=depth.device)
+            d32 = depth.to(torch.float32)
+            self.disp_dev.append(torch.where(torch.isfinite(d32) & (d32 > 0), fxb / d32, torch.zeros_like(d32)).contiguous())
             dets, b3 = [], np.zeros(0, dynsim.BOX3D_DTYPE)
             Rwc, pwc = self.traj.R(t) @ sim.R_IC, self.traj.p(t) + self.traj.R(t) @ sim.T_IC0
             for b in self.boxes:
@@ -190,6 +195,11 @@ class DynamicSequence(SyntheticSequence):
         self.imu_t, self.imu_a, self.imu_g = sim.imu_stream(self.traj, self.t0 - 0.05, self.times[-1] + 0.1, 200.0, seed=0xBEEF, **self.noise)
 
 
+    def disp_host(self, k):
+        """the frame's disparity map as a host float32 array (for the CPU oracle)"""
+        return self.disp_dev[k].cpu().numpy()
+
+
 class DynamicPipeline(Pipeline):
     """Pipeline in dynamic mode (cfg::slam == kDynamic): TrackSemanticImage for the background + InstsFeatManager::InstsTrack for the objects on the tracking
     stream, Estimator::ProcessImage with the object branch (window solve on the BA stream, object solve on a third one).  `segments` (a sim.SegmentSim):
@@ -197,8 +207,9 @@ class DynamicPipeline(Pipeline):
     as TrackSemanticImage's line thread delivers them (background_tracker.cpp:774-780, 809-817)."""
 
     def __init__(self, seq: DynamicSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, max_dynamic_cnt=50, min_dynamic_dist=5, use_det3d=1,
-                 static_inst_threshold=1.0, mask_morphology_size=0, segments=None, est_kw=None):
+                 static_inst_threshold=1.0, mask_morphology_size=0, segments=None, est_kw=None, extra_from_disparity=True):
         from .frontend import DV_MODE_SEMANTIC
+        self.extra_from_disparity = extra_from_disparity      # False: the detections' own `points` are handed through (the caller ran the extra-point pipeline)
         self.seq, self.host = seq, None
         c = make_cam(*sim.cam_tuple(seq.cam))
         self.cam_c, self.cam1_c = c, make_cam(*sim.cam_tuple(seq.cam1))
@@ -220,6 +231,8 @@ class DynamicPipeline(Pipeline):
     def _enqueue(self, k):
         l, r = self.seq.frames[k]
         self.ctx.track_stereo_enqueue(l.data_ptr(), r.data_ptr(), self.seq.times[k], self.seq.inv_mask_dev[k].data_ptr(), self.mode, DV_MEM_DEVICE)
+        if self.extra_from_disparity:      # the extra points of the objects: DetectExtraPoints + ProcessExtraPoints on the device from the frame's disparity map
+            self.ctx.inst_set_disparity(self.seq.disp_dev[k].data_ptr(), self.seq.baseline, DV_MEM_DEVICE)
         self.ctx.inst_track_enqueue(self.seq.times[k], self.seq.dets[k], self.seq.boxes3d[k] if self.use_det3d else None)
         self.enqueued = True
 

@@ -469,12 +469,13 @@ typedef struct dv_inst_state {          /* Instance (estimator/instance.h) as th
 } dv_inst_state;
 /* ---- dynamic mode, front end: InstsFeatManager (front_end/dynamic_tracker.h:42-101).  One detection = one Box2D of SemanticImage::boxes2d AFTER the
  * multi-object tracker assigned its track id (DeepSORT / VIODE keys: upstream).  mask = InstRoi::mask_cv, roi_gray is cropped from the frame by the
- * library.  points (optional) = InstFeat::extra_points3d of this frame (DetectExtraPoints + PCL clustering: upstream), handed through to the output. */
+ * library.  points (optional) = InstFeat::extra_points3d of this frame computed by the caller, handed through to the output — or give the library the frame's
+ * disparity map (dv_inst_set_disparity) and it runs DetectExtraPoints + ProcessExtraPoints itself. */
 typedef struct dv_inst_det {
     uint32_t track_id; int32_t class_id;
     int32_t x, y, w, h;                 /* Box2D::rect, inside the image */
     const uint8_t* mask;                /* h rows of w bytes, > 0 = object (host memory) */
-    const double* points; int32_t n_points, pad_;
+    const double* points; int32_t n_points, pad_;      /* ignored for a frame whose disparity map was handed over (dv_inst_set_disparity) */
 } dv_inst_det;
 /* fe_para::kMaxDynamicCnt / kMinDynamicDist (front_end/front_end_parameters.cpp), cfg::use_det3d; call once before the first frame */
 int dv_inst_config(dv_ctx* ctx, int max_dynamic_cnt, int min_dynamic_dist, int use_det3d);
@@ -483,6 +484,19 @@ int dv_inst_reset(dv_ctx* ctx);
  * of the frame last passed to dv_track_stereo_enqueue (call it right after, same frame; `t` = that frame's time).  boxes3d = SemanticImage::boxes3d
  * (only read when use_det3d). */
 int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_dets, const dv_box3d* boxes3d, int n_boxes3d);
+/* SemanticImage::disp (CV_32F disparity of the left image, basic/semantic_image.h:30-65) of the frame about to be handed to dv_inst_track_enqueue.  With it the library
+ * runs the reference's extra-point pipeline for every visible object ON THE DEVICE, one launch for all objects on a side stream (the reference: a second thread):
+ * InstFeat::DetectExtraPoints (front_end/instance_feature.cpp:413-461: step = max(sqrt(0.8 rows cols / 1000), 2), mask > 0, disparity > 0 and not NaN,
+ * depth = fx0 baseline / disparity in (0.1, 100], x = (c - cx0) depth / fx0 ..., float arithmetic, row-major scan order) and the point-cloud half of
+ * InstsFeatManager::ProcessExtraPoints (front_end/dynamic_tracker.cpp:268-338: pcl::RadiusOutlierRemoval(0.5, 10), pcl::EuclideanClusterExtraction(1.0, 10, 25000), first
+ * cluster).  dv_inst_det::points is then ignored; dv_inst_track_collect returns the computed points.  disp: rows of `stride_bytes` bytes (0 = 4 * width), config size,
+ * host or device memory (a device map must stay valid until dv_inst_track_collect); baseline = cam_s.baseline (utils/camera_model.h:38); fx0, fy0, cx0, cy0 = cam0 of the
+ * config as float.  disp == NULL: back to the pass-through form.  Applies to the NEXT dv_inst_track_enqueue only. */
+int dv_inst_set_disparity(dv_ctx* ctx, const float* disp, int stride_bytes, int mem, double baseline);
+/* operator form of the same pipeline for one object (parity tests): mask = h rows of w bytes (host), (x, y) = Box2D::rect.tl().  stage 0: the whole pipeline (the segmented
+ * cloud); stage 1: InstFeat::DetectExtraPoints alone (the sampled points before any filtering).  out_xyz: cap_out triples at most, the float results widened to double. */
+int dv_extra_points(dv_ctx* ctx, const uint8_t* mask, int x, int y, int w, int h, const float* disp, int stride_bytes, int mem, double baseline, int stage,
+                    double* out_xyz, int cap_out, int* n_out);
 /* InstsFeatManager::Output() (front_end/dynamic_tracker.cpp:521-577): waits for the frame; insts / feats / points are laid out as dv_est_process_dynamic takes them */
 int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n_insts, dv_feat* feats, int cap_feats, int* n_feats,
                           double* points, int cap_points, int* n_points);

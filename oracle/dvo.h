@@ -238,6 +238,13 @@ typedef struct dvo_insts dvo_insts;
 dvo_insts* dvo_insts_create(dvo_tracker* background, int max_dynamic_cnt, int min_dynamic_dist, int use_det3d);
 void dvo_insts_destroy(dvo_insts*);
 int dvo_insts_track(dvo_insts*, const uint8_t* gray0, const uint8_t* gray1, double time, const dvo_inst_det* dets, int n_dets, const dvo_box3d* boxes3d, int n_boxes3d);
+/* SemanticImage::disp (CV_32F, width x height of the tracker) of the NEXT dvo_insts_track call: the extra points of every visible object are then computed from it
+ * (InstFeat::DetectExtraPoints + the PCL half of ProcessExtraPoints, extra_points.cpp) and dvo_inst_det::points is ignored.  baseline = cam_s.baseline.  The map is copied. */
+void dvo_insts_set_disparity(dvo_insts*, const float* disp, float baseline);
+/* InstFeat::DetectExtraPoints (front_end/instance_feature.cpp:413-461) / the point-cloud half of InstsFeatManager::ProcessExtraPoints (front_end/dynamic_tracker.cpp:268-338) */
+int dvo_detect_extra_points(const uint8_t* mask, int cols, int rows, int box_x, int box_y, const float* disp, int disp_w, int disp_h,
+                            float fx0, float fy0, float cx0, float cy0, float baseline, float* out_xyz, int cap);
+int dvo_process_extra_points(const float* xyz, int n, float* out_xyz);
 int dvo_insts_output(dvo_insts*, dvo_inst_obs* insts, int cap_insts, int* n_insts, dvo_feat* feats, int cap_feats, int* n_feats, double* points, int cap_points, int* n_points);
 /* ProcessImage with the object branch (estimator.cpp:1562-1622,1653-1676); see inst_manager.h */
 int dvo_estimator_process_dynamic(dvo_estimator*, const dvo_feat* feats, int n, double t, const dvo_inst_obs* insts, int n_insts, const dvo_feat* inst_feats,

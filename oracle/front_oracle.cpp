@@ -829,7 +829,13 @@ struct dvo_insts {
     dvo_tracker* bg; int max_cnt, min_dist, use_det3d;
     std::map<unsigned, OInstFeat> instances;
     double curr_time = 0, last_time = 0;
+    std::vector<float> disp; float baseline = 0; bool have_disp = false;      // curr_img.disp of the next frame (dvo_insts_set_disparity)
 };
+void dvo_insts_set_disparity(dvo_insts* M, const float* disp, float baseline) {
+    const size_t n = (size_t)M->bg->cfg.width * M->bg->cfg.height;
+    M->have_disp = disp != nullptr;
+    if (disp) { M->disp.assign(disp, disp + n); M->baseline = baseline; }
+}
 
 static float o_rect_iou(const float a[4], const float b[4]) {      // Box2D::IoU (basic/box2d.cpp:20-27)
     const float x1 = std::max(a[0], b[0]), y1 = std::max(a[1], b[1]), x2 = std::min(a[0] + a[2], b[0] + b[2]), y2 = std::min(a[1] + a[3], b[1] + b[3]);
@@ -854,7 +860,7 @@ int dvo_insts_track(dvo_insts* M, const uint8_t* gray0, const uint8_t* gray1, do
         I.roi_gray.w = d.w; I.roi_gray.h = d.h; I.roi_gray.d.resize((size_t)d.w * d.h);
         for (int y = 0; y < d.h; ++y) std::memcpy(&I.roi_gray.d[(size_t)y * d.w], gray0 + (size_t)(d.y + y) * W + d.x, d.w);      // roi_gray = gray0(rect) (basic/semantic_image.cpp:58-59)
         I.mask_cv.w = d.w; I.mask_cv.h = d.h; I.mask_cv.d.assign(d.mask, d.mask + (size_t)d.w * d.h);
-        I.extra_points3d.assign(d.points ? d.points : nullptr, d.points ? d.points + 3 * (size_t)std::max(d.n_points, 0) : nullptr);
+        if (!M->have_disp) I.extra_points3d.assign(d.points ? d.points : nullptr, d.points ? d.points + 3 * (size_t)std::max(d.n_points, 0) : nullptr);      // pass-through form: the caller ran the extra-point pipeline
     }
     // ---- InstsTrack ----
     for (auto& kv : M->instances) { if (!kv.second.is_curr_visible) kv.second.lost_num++; else kv.second.lost_num = 0; }
@@ -880,6 +886,19 @@ int dvo_insts_track(dvo_insts* M, const uint8_t* gray0, const uint8_t* gray1, do
     const bool is_exist_inst = n_dets > 0;
     auto exec = [&](auto f) { for (auto& kv : M->instances) { if (kv.second.lost_num > 0) continue; f(kv.second); } };
     if (is_exist_inst) {
+        // ProcessExtraPoints (:159-340), the reference's second thread of this call: started before the optical flow, its sampling reads roi->mask_cv as the detection
+        // delivered it (the in-place erosion below comes later on the other thread; see extra_points.cpp on the race)
+        if (M->have_disp) exec([&](OInstFeat& inst) {
+            if (!inst.is_curr_visible) return;
+            std::vector<float> raw((size_t)3 * inst.mask_cv.w * inst.mask_cv.h), seg;
+            const int n = dvo_detect_extra_points(inst.mask_cv.d.data(), inst.mask_cv.w, inst.mask_cv.h, inst.rx, inst.ry, M->disp.data(), W, H,
+                                                  (float)cfg.cam0.fx, (float)cfg.cam0.fy, (float)cfg.cam0.cx, (float)cfg.cam0.cy, M->baseline, raw.data(), inst.mask_cv.w * inst.mask_cv.h);
+            seg.resize((size_t)3 * std::max(n, 1));
+            const int m = dvo_process_extra_points(raw.data(), n, seg.data());
+            inst.extra_points3d.clear();                                       // PclToEigen: float -> double
+            for (int k = 0; k < 3 * m; ++k) inst.extra_points3d.push_back((double)seg[k]);
+        });
+        M->have_disp = false;
         exec([&](OInstFeat& inst) {      // per-object optical flow (:381-413)
             if (!inst.is_curr_visible) return;
             if (inst.prev_roi_gray.d.empty() || inst.last_points.empty()) return;

@@ -180,6 +180,27 @@ class Oracle:
         return dict(curr_points=cur_pts[:n], ids=cur_ids[:n], track_cnt=cur_cnt[:n], curr_un_points=cur_un[:n], right_points=r_pts[:m], right_ids=r_ids[:m],
                     right_un_points=r_un[:m]), gid.value
 
+    def detect_extra_points(self, mask, box_xy, disp, cam4, baseline):
+        """InstFeat::DetectExtraPoints -> float32 [n, 3] (x, y, depth), row-major scan order"""
+        mask = np.ascontiguousarray(mask, np.uint8); disp = np.ascontiguousarray(disp, np.float32)
+        out = np.zeros((mask.size, 3), np.float32)
+        f = self.lib.dvo_detect_extra_points
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p, C.c_int]
+        n = f(_p(mask), mask.shape[1], mask.shape[0], int(box_xy[0]), int(box_xy[1]), _p(disp), disp.shape[1], disp.shape[0], float(cam4[0]), float(cam4[1]), float(cam4[2]), float(cam4[3]),
+              float(baseline), _p(out), len(out))
+        return out[:n].copy()
+
+    def process_extra_points(self, xyz):
+        """RadiusOutlierRemoval(0.5, 10) + EuclideanClusterExtraction(1.0, 10, 25000), first cluster -> float32 [m, 3]"""
+        xyz = np.ascontiguousarray(xyz, np.float32).reshape(-1, 3)
+        out = np.zeros((max(len(xyz), 1), 3), np.float32)
+        f = self.lib.dvo_process_extra_points
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        m = f(_p(xyz) if len(xyz) else None, len(xyz), _p(out))
+        return out[:m].copy()
+
     def insts(self, tracker, max_dynamic_cnt=50, min_dynamic_dist=5, use_det3d=0):
         return OracleInsts(self, tracker, max_dynamic_cnt, min_dynamic_dist, use_det3d)
 
@@ -237,6 +258,12 @@ class OracleInsts:
         L.dvo_insts_output.restype = C.c_int
         L.dvo_insts_output.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         self.h = L.dvo_insts_create(tracker.h, max_dynamic_cnt, min_dynamic_dist, use_det3d)
+
+    def set_disparity(self, disp, baseline):
+        """SemanticImage::disp of the next track() call: the extra points then come from InstFeat::DetectExtraPoints + ProcessExtraPoints (oracle/extra_points.cpp)"""
+        d = None if disp is None else np.ascontiguousarray(disp, np.float32)
+        self.lib.dvo_insts_set_disparity.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
+        self.lib.dvo_insts_set_disparity(self.h, _p(d), float(baseline))
 
     def track(self, g0, g1, t, dets, boxes3d, inst_dtype, box_dtype):
         g0 = np.ascontiguousarray(g0); g1 = np.ascontiguousarray(g1) if g1 is not None else None

@@ -42,6 +42,7 @@ def run(oracle, w, h, frames, max_cnt, min_dist, iters, use_det3d=1, morph=0, dr
             est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
         left, right = seq.host_frame(k)
         rows_o = trk.track_image(left, right, t, mask=seq.inv_mask[k], mode=2, erode_k=morph)
+        oin.set_disparity(seq.disp_host(k), seq.baseline)          # the extra points: DetectExtraPoints + ProcessExtraPoints from the same disparity map on both sides
         io, fo, po = oin.track(left, right, t, seq.dets[k], seq.boxes3d[k] if use_det3d else None, dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
         rows_equal(pipe.rows, rows_o, f"frame {k} background")
         assert len(io) == len(pipe.insts), f"frame {k}: {len(io)} vs {len(pipe.insts)} objects"

@@ -148,6 +148,7 @@ def run_config(oracle, name, frames, n_boxes=4):
             est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
         left, right = seq.host_frame(k)
         rows_o = trk.track_image(left, right, t, mask=seq.inv_mask[k], mode=2, erode_k=c["mask_morphology_size"])
+        oin.set_disparity(seq.disp_host(k), seq.baseline)
         io, fo, po = oin.track(left, right, t, seq.dets[k], seq.boxes3d[k] if c["use_det3d"] else None, dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
         rows_equal(pipe.rows, rows_o, f"{name} frame {k} background")
         assert len(io) == len(pipe.insts), f"frame {k}: {len(io)} vs {len(pipe.insts)} objects"

@@ -12,7 +12,7 @@
 //      of that graph, numbered by lowest member.  Here: min-label propagation with pointer jumping until nothing changes (a few sweeps; every sweep is an
 //      all-pairs pass over LDS), component sizes by LDS atomics, the largest component with 10 <= size <= 25000 (equal sizes: the lowest label = the cluster
 //      PCL finds first), members written in ascending index order (PCL sorts the indices) as doubles (PclToEigen widens the floats).
-// Integer / index work and float comparisons only: bit-exact against oracle/extra_points.cpp (tests/test_extra_points.py).
+// Integer / index work and float comparisons only: bit-exact against the CPU restatement the tests hold (tests/test_extra_points.py).
 // The mask read is the detection's mask as uploaded — NOT the 5x5-eroded one: the reference's extra-point thread races with the in-place erosion on the
 // tracking thread (dynamic_tracker.cpp:378 / :425); the sampling is the first thing that thread does, so the un-eroded mask is the canonical reading.
 #include <algorithm>

@@ -110,6 +110,8 @@ SIGNATURES = {
     "dv_batch_create": (C.c_void_p, [C.POINTER(C.c_void_p), C.c_int]),
     "dv_batch_destroy": (None, [C.c_void_p]),
     "dv_batch_enqueue": (C.c_int, [C.c_void_p]),
+    "dv_batch_track_enqueue": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "dv_batch_track_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dv_batch_arrive": (C.c_int, [C.c_void_p]),
     "dv_batch_abort": (C.c_int, [C.c_void_p]),
     "dv_batch_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
@@ -119,6 +121,8 @@ SIGNATURES = {
     "dv_runner_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "dv_runner_get_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_runner_batch_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "dv_runner_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
+    "dv_runner_track_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dv_runner_error": (C.c_char_p, [C.c_void_p]),
     "dv_est_get_marg_health": (C.c_int, [_ctx, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.c_void_p]),
     "dv_batch_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

@@ -408,6 +408,10 @@ class Estimator:
     processMeasurements = ProcessMeasurements
 
 
+class dv_track_job(C.Structure):
+    _fields_ = [("member", C.c_int32), ("mem", C.c_int32), ("gray0", C.c_void_p), ("gray1", C.c_void_p), ("stride", C.c_int32), ("mode", C.c_int32), ("t", C.c_double), ("mask", C.c_void_p)]
+
+
 class Batch:
     """dv_batch: several contexts (one estimator each, same GPU) whose window solves share every launch.  Protocol per round: ProcessMeasurements*Begin
     on every member that has a frame, enqueue(), ProcessMeasurementsEnd on each."""
@@ -438,6 +442,34 @@ class Batch:
         a, b = C.c_longlong(0), C.c_longlong(0)
         self.lib.dv_batch_info(self.h, C.byref(a), C.byref(b))
         return dict(batched_rounds=a.value, single_rounds=b.value)
+
+    def track_enqueue(self, jobs):
+        """dv_batch_track_enqueue: the members' front ends in shared launches.  jobs: list of dict(member, gray0, gray1, t[, stride, mode, mask, mem]) with device
+        pointers (ints) or host uint8 arrays for the images; collect every member with its ctx.track_stereo_collect()"""
+        arr = (dv_track_job * max(len(jobs), 1))()
+        self._track_keep = []
+        for k, j in enumerate(jobs):
+            a = arr[k]
+            g0, g1 = j["gray0"], j.get("gray1")
+            host = isinstance(g0, np.ndarray)
+            if host:
+                g0 = np.ascontiguousarray(g0); g1 = np.ascontiguousarray(g1) if g1 is not None else None
+                self._track_keep += [g0, g1]
+            a.member, a.mem = int(j["member"]), int(j.get("mem", 0 if host else 1))
+            a.gray0 = g0.ctypes.data if host else int(g0)
+            a.gray1 = (g1.ctypes.data if host else int(g1)) if g1 is not None else None
+            a.stride, a.mode, a.t = int(j.get("stride", 0)), int(j.get("mode", 0)), float(j["t"])
+            m = j.get("mask")
+            if isinstance(m, np.ndarray):
+                m = np.ascontiguousarray(m); self._track_keep.append(m); m = m.ctypes.data
+            a.mask = m
+        if self.lib.dv_batch_track_enqueue(self.h, C.cast(arr, C.c_void_p), len(jobs)) != 0:
+            raise DvinsError((self.lib.dv_last_error(self.ctxs[0].h) or self.lib.dv_last_error(None) or b"dv_batch_track_enqueue failed").decode())
+
+    def track_info(self):
+        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        self.lib.dv_batch_track_info(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(rounds=a.value, members_batched=b.value, members_single=c.value)
 
     def close(self):
         if getattr(self, "h", None):
@@ -497,6 +529,15 @@ class Runner:
         self.lib.dv_runner_get(self.h, i, C.byref(st), poses.ctypes.data, cap, C.byref(n), C.byref(it), C.byref(fr), C.byref(nr))
         self.last_rows = nr.value
         return st, poses[: n.value].copy(), it.value, fr.value
+
+    def set(self, key, value):
+        if self.lib.dv_runner_set(self.h, key.encode(), int(value)) != 0:
+            raise DvinsError(self.lib.dv_runner_error(self.h).decode())
+
+    def track_info(self):
+        a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+        self.lib.dv_runner_track_info(self.h, C.byref(a), C.byref(b), C.byref(c))
+        return dict(rounds=a.value, members_batched=b.value, members_single=c.value)
 
     def batch_timing(self, on=1):
         """-> (avg ms per launch of [be_solve_batch, be_eval_batch, be_reduce_batch], rounds timed, windows per launch)"""

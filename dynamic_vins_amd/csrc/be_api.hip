@@ -564,6 +564,7 @@ struct dv_batch {
     hipStream_t stream = nullptr; hipEvent_t ev_slots = nullptr; std::vector<hipEvent_t> ev_up;
     DevBuf tab; void* tab_pinned = nullptr;       // [S] BeEvalArgs | [S] BeSolveArgs
     long long batched_rounds = 0, single_rounds = 0;
+    DvFrontBatch* front = nullptr;                // the members' front ends in shared launches (dv_batch_track_enqueue, dvins_api.hip)
     std::mutex mu; std::condition_variable cv; int arrived = 0; long long generation = 0; int last_rc = 0;      // dv_batch_arrive
     bool aborted = false;                         // dv_batch_abort: every waiting and every later dv_batch_arrive returns -1
     // dv_batch_timing: HIP events around the three launches of the SECOND iteration slot of every round (a steady-state slot: candidate evaluation, reduce, solve with
@@ -573,6 +574,8 @@ struct dv_batch {
 };
 // dv_destroy of a member: the batch forgets it (a destroyed ctx must never be reached through B->members); threads waiting in dv_batch_arrive
 // for a round this member will never join are released with an error
+DvFrontBatch*& be_batch_front(dv_batch* B) { return B->front; }
+const std::vector<dv_ctx*>& be_batch_members(dv_batch* B) { return B->members; }
 void be_batch_detach(dv_ctx* ctx) {
     dv_batch* B = ctx->batch;
     if (!B) return;
@@ -681,6 +684,7 @@ dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n) {
 void dv_batch_destroy(dv_batch* B) {
     if (!B) return;
     { std::lock_guard<std::mutex> lk(B->mu); for (dv_ctx* c : B->members) if (c->batch == B) c->batch = nullptr; B->members.clear(); }
+    if (B->front) { dv_front_batch_release(B->front); B->front = nullptr; }
     if (B->stream) { (void)hipStreamSynchronize(B->stream); (void)hipStreamDestroy(B->stream); }
     if (B->ev_slots) (void)hipEventDestroy(B->ev_slots);
     for (hipEvent_t e : B->tev) if (e) (void)hipEventDestroy(e);

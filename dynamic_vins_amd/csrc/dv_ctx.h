@@ -127,6 +127,10 @@ struct BeFused {
 };
 int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);
 void be_batch_detach(dv_ctx* ctx);          // dv_destroy: leave the dv_batch this ctx is a member of
+struct DvFrontBatch;                        // the front-end half of a dv_batch (dvins_api.hip): stream, event, job tables of the shared tracking launches
+DvFrontBatch*& be_batch_front(struct dv_batch* B);
+const std::vector<dv_ctx*>& be_batch_members(struct dv_batch* B);
+void dv_front_batch_release(DvFrontBatch* F);
 void* be_staging_factors(dv_ctx* ctx, int* cap);      // where the next solve's upload reads its factor table (pinned); nullptr if the workspace cannot be set up
 int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused);       // upload + enqueue everything, returns immediately
 int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);      // sync + collect
@@ -176,6 +180,9 @@ struct dv_ctx {
     DevBuf out_buf; dv_feat* out_dev = nullptr; int* nout_dev = nullptr;
     dv_feat* out_pinned = nullptr; int* nout_pinned = nullptr; int* err_pinned = nullptr;
     hipEvent_t done = nullptr; bool pending = false;
+    // a frame tracked as a member of a dv_batch (dv_batch_track_enqueue) runs on the batch's front-end stream and completes with the batch's event: last_done = the
+    // event behind the last enqueued frame (own `done` or the batch's), last_front = the stream it ran on — a frame that runs on the OTHER stream waits for it first
+    hipEvent_t last_done = nullptr; hipStream_t last_front = nullptr;
     // operator-level scratch
     PyrSet opA, opB; DevBuf s0, s1, s2, s3, s4;
     bool timing = false, kernel_timing = false, host_timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back

@@ -74,8 +74,16 @@ void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, i
                           double eps_sq, int use_initial, float2* pts_b, uint8_t* status, hipStream_t s);
 // one job of dv_launch_lk_track_multi (device-resident table): FeatureTrackByLK of one object's points between its two pyramids
 // one level step of one image pair for dv_launch_pyr_down_multi (src1 / dst1 may be null: single image)
-struct DvPyrJob { const uint8_t* src0; const uint8_t* src1; uint8_t* dst0; uint8_t* dst1; int sw, sh, spitch, dw, dh, dpitch; };
+struct DvPyrJob { const uint8_t* src0; const uint8_t* src1; uint8_t* dst0; uint8_t* dst1; int sw, sh, spitch, dw, dh, dpitch; uint8_t* cpy0; uint8_t* cpy1; int cpitch, pad_; };      // cpy (optional): the source tile's own pixels also go to a pitched copy (level 0 of the pyramid: frame read once)
 void dv_launch_pyr_down_multi(const DvPyrJob* jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t s);
+void dv_launch_pyr_apron_multi(const DvPyr* pyrs_dev, int n_pyr, int max_levels, hipStream_t s);
+// job-table forms of the tracker's single-workgroup / per-image stages (the front ends of a dv_batch group in shared launches: front_batch.hip)
+struct DvCompactJob { DvTrackState tr; const uint8_t* in_mask; int mask_pitch, sort_by_cnt; int* n_cand; unsigned* max_ord; };
+void dv_launch_compact_multi(const DvCompactJob* jobs_dev, int n_jobs, hipStream_t s);
+struct DvFinalizeJob { DvTrackState tr; dv_cam cam0, cam1; int stereo, pad_; double dt; dv_feat* out; int* n_out; const int* err_in; int* err_out; };
+void dv_launch_finalize_multi(const DvFinalizeJob* jobs_dev, int n_jobs, int n_max, hipStream_t s);
+void dv_launch_gftt_tile_multi(const GfttTileArgs* tab_dev, int n_jobs, int w, int h, hipStream_t s);      // all jobs share the image size w x h
+int  dv_launch_gftt_select_multi(const GfttSelectArgs* tab_dev, int n_jobs, hipStream_t s);
 struct DvLkJob { DvPyr A, B; const float2* pts_a; const int* n_dev; float2* pts_b; uint8_t* status; float add_x, add_y; int use_add, pad; };
 void dv_launch_lk_track_multi(const DvLkJob* jobs_dev, int n_jobs, int n_max, int flow_back, float dist_thresh, hipStream_t s);
 void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max,

@@ -209,7 +209,8 @@ int dv_reset(dv_ctx* ctx) {
     const uint32_t one = 1;    // InstFeat::global_id_count{1} (front_end/instance_feature.h:137)
     DV_CHECK(hipMemcpyAsync(ctx->tr.next_id, &one, 4, hipMemcpyHostToDevice, ctx->stream));
     DV_CHECK(hipStreamSynchronize(ctx->stream));
-    ctx->have_prev = false; ctx->prev_time = 0.0; ctx->pending = false;
+    if (ctx->last_front && ctx->last_front != ctx->stream && ctx->last_done) DV_CHECK(hipEventSynchronize(ctx->last_done));
+    ctx->have_prev = false; ctx->prev_time = 0.0; ctx->pending = false; ctx->last_done = nullptr; ctx->last_front = nullptr;
     if (ctx->inst && dv_inst_reset(ctx)) return -1;
     return 0;
 }
@@ -243,6 +244,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     if (ensure_hw(ctx, c.min_dist)) return -1;
     if (ensure_cand(ctx, w, h)) return -1;
     if (dv_inst_wait_before_next_frame(ctx)) DV_FAIL("dv_track_stereo: hipStreamWaitEvent");
+    if (ctx->last_front && ctx->last_front != s && ctx->last_done) DV_CHECK(hipStreamWaitEvent(s, ctx->last_done, 0));      // the previous frame ran on a dv_batch's front-end stream
     StageScope frame(ctx, "frame");
     ctx->cur ^= 1;
     PyrSet& L = ctx->left[ctx->cur];
@@ -317,6 +319,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     }
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipEventRecord(ctx->done, s));
+    ctx->last_done = ctx->done; ctx->last_front = s;
     ctx->prev_time = t; ctx->have_prev = true; ctx->pending = true;
     return 0;
 }
@@ -324,7 +327,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
 int dv_track_stereo_collect(dv_ctx* ctx, dv_feat* out, int* n_out) {
     if (!ctx) return -1;
     if (!ctx->pending) DV_FAIL("dv_track_stereo_collect: nothing enqueued");
-    DV_CHECK(hipEventSynchronize(ctx->done));
+    DV_CHECK(hipEventSynchronize(ctx->last_done ? ctx->last_done : ctx->done));
     ctx->pending = false;
     if (ctx->timing) dv_harvest_timers(ctx, ctx->stream);
     if (*ctx->err_pinned) {
@@ -344,6 +347,178 @@ int dv_track_stereo(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gray1, int
     if (dv_track_stereo_enqueue(ctx, gray0, gray1, w, h, stride, t, mask_or_null, mode, mem)) return -1;
     return dv_track_stereo_collect(ctx, out, n_out);
 }
+
+}  // extern "C"
+
+// ------------------------------- the front ends of a dv_batch group in shared launches -------------------------------
+// FeatureTracker::TrackImage (background_tracker.cpp:52-158) of S independent sequences, one launch per STAGE for all of them (the reference runs one process per
+// sequence, system/main.cpp:178-330): pyrDown levels 1..3 (level 1 also writes the pitched level-0 copy), aprons, temporal LK, compaction / sort, Shi-Tomasi tile,
+// corner selection, stereo LK, rows = 10 launches per group and frame instead of 10 per sequence.  The kernels are the single-sequence kernels' bodies behind a
+// job table in HBM (blockIdx.z / .y / .x = member), so every member's rows are bit-identical to what its own dv_track_stereo_enqueue produces.
+struct DvFrontBatch {
+    hipStream_t stream = nullptr; hipEvent_t done = nullptr, ev_copy[2] = { nullptr, nullptr };
+    DevBuf tab[2]; void* tab_pinned[2] = { nullptr, nullptr }; size_t tab_bytes = 0; int parity = 0; bool copy_used[2] = { false, false };
+    long long rounds = 0, members_batched = 0, members_single = 0;
+};
+void dv_front_batch_release(DvFrontBatch* F) {
+    if (!F) return;
+    if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }
+    if (F->done) (void)hipEventDestroy(F->done);
+    for (int k = 0; k < 2; ++k) { if (F->ev_copy[k]) (void)hipEventDestroy(F->ev_copy[k]); F->tab[k].release(); if (F->tab_pinned[k]) (void)hipHostFree(F->tab_pinned[k]); }
+    delete F;
+}
+
+extern "C" int dv_batch_track_enqueue(dv_batch* B, const dv_track_job* jobs, int n) {
+    if (!B || (n > 0 && !jobs) || n < 0) { dv_set_error(nullptr, "dv_batch_track_enqueue: bad arguments"); return -1; }
+    const std::vector<dv_ctx*>& mem = be_batch_members(B);
+    if (n == 0 || mem.empty()) return 0;
+    dv_ctx* ctx = mem[0];                                       // errors of the shared part are reported on the first member (and the global slot)
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    DvFrontBatch*& Fp = be_batch_front(B);
+    if (!Fp) {
+        Fp = new DvFrontBatch();
+        DV_CHECK(hipStreamCreateWithFlags(&Fp->stream, hipStreamNonBlocking));
+        DV_CHECK(hipEventCreateWithFlags(&Fp->done, hipEventDisableTiming));
+        for (int k = 0; k < 2; ++k) DV_CHECK(hipEventCreateWithFlags(&Fp->ev_copy[k], hipEventDisableTiming));
+    }
+    DvFrontBatch& F = *Fp;
+    // ---- which jobs can share launches: raw mode, gray frames, no mask, no undistortion maps, no object tracker, the group's common geometry ----
+    std::vector<int> M;                                         // job indices that are batched
+    const dv_config* ref = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const dv_track_job& j = jobs[i];
+        if (j.member < 0 || j.member >= (int)mem.size()) DV_FAIL("dv_batch_track_enqueue: member index out of range");
+        dv_ctx* c = mem[j.member];
+        for (int q = 0; q < i; ++q) if (jobs[q].member == j.member) DV_FAIL("dv_batch_track_enqueue: a member appears twice");
+        const bool plain = j.mode == DV_MODE_RAW && !j.mask && !(j.mem & DV_FMT_BGR) && !c->undist[0] && !c->inst && !c->timing && j.gray0 && (!c->cfg.stereo || j.gray1);
+        const bool same = !ref || (c->cfg.width == ref->width && c->cfg.height == ref->height && c->cfg.stereo == ref->stereo && c->cfg.flow_back == ref->flow_back);
+        if (plain && same) { if (!ref) ref = &c->cfg; M.push_back(i); }
+        else {      // its own launches on its own stream (ordered behind whatever the batch stream still holds for it: dv_track_stereo_enqueue)
+            if (dv_track_stereo_enqueue(c, j.gray0, j.gray1, c->cfg.width, c->cfg.height, j.stride > 0 ? j.stride : c->cfg.width * ((j.mem & DV_FMT_BGR) ? 3 : 1), j.t, j.mask, j.mode, j.mem)) { dv_set_error(ctx, c->err); return -1; }
+            F.members_single++;
+        }
+    }
+    const int S = (int)M.size();
+    if (S == 0) return 0;
+    if (S == 1) {      // nothing to share
+        const dv_track_job& j = jobs[M[0]]; dv_ctx* c = mem[j.member];
+        if (dv_track_stereo_enqueue(c, j.gray0, j.gray1, c->cfg.width, c->cfg.height, j.stride > 0 ? j.stride : c->cfg.width, j.t, nullptr, DV_MODE_RAW, j.mem)) { dv_set_error(ctx, c->err); return -1; }
+        F.members_single++;
+        return 0;
+    }
+    const int w = ref->width, h = ref->height; const bool stereo = ref->stereo != 0;
+    hipStream_t s = F.stream;
+    // ---- per member: the checks and the lazily created resources of dv_track_stereo_enqueue ----
+    int n_max = 0;
+    for (int i : M) {
+        const dv_track_job& j = jobs[i]; dv_ctx* c = mem[j.member];
+        if (c->pending) { dv_set_error(ctx, "dv_batch_track_enqueue: a member's previous frame was not collected"); return -1; }
+        if (ensure_hw(c, c->cfg.min_dist) || ensure_cand(c, w, h)) { dv_set_error(ctx, c->err); return -1; }
+        if (c->last_front && c->last_front != s && c->last_done) DV_CHECK(hipStreamWaitEvent(s, c->last_done, 0));      // its previous frame ran on its own stream
+        c->cur ^= 1;
+        DV_CHECK(c->left[c->cur].alloc(w, h, 3));
+        if (stereo) DV_CHECK(c->right.alloc(w, h, 3));
+        n_max = std::max(n_max, c->cfg.max_cnt);
+    }
+    // ---- the job tables of the round: one pinned block, one upload ----
+    const size_t o_pyr = 0, o_apr = o_pyr + (size_t)3 * S * sizeof(DvPyrJob), o_lk = (o_apr + (size_t)2 * S * sizeof(DvPyr) + 255) / 256 * 256,
+                 o_cmp = (o_lk + (size_t)2 * S * sizeof(DvLkJob) + 255) / 256 * 256, o_gt = (o_cmp + (size_t)S * sizeof(DvCompactJob) + 255) / 256 * 256,
+                 o_gs = (o_gt + (size_t)S * sizeof(GfttTileArgs) + 255) / 256 * 256, o_fin = (o_gs + (size_t)S * sizeof(GfttSelectArgs) + 255) / 256 * 256,
+                 total = (o_fin + (size_t)S * sizeof(DvFinalizeJob) + 255) / 256 * 256;
+    const int par = F.parity; F.parity ^= 1;
+    if (F.copy_used[par]) DV_CHECK(hipEventSynchronize(F.ev_copy[par]));      // the upload that last read this pinned block (two rounds ago) has run
+    if (F.tab_bytes < total) {
+        DV_CHECK(hipStreamSynchronize(s));
+        const size_t cap = total * 2;
+        for (int k = 0; k < 2; ++k) {
+            DV_CHECK(F.tab[k].ensure(cap));
+            if (F.tab_pinned[k]) (void)hipHostFree(F.tab_pinned[k]);
+            F.tab_pinned[k] = nullptr;
+            DV_CHECK(hipHostMalloc(&F.tab_pinned[k], cap, hipHostMallocDefault));
+        }
+        F.tab_bytes = cap;
+    }
+    uint8_t* hp = (uint8_t*)F.tab_pinned[par]; const uint8_t* dp = (const uint8_t*)F.tab[par].p;
+    DvPyrJob* h_pyr = (DvPyrJob*)(hp + o_pyr); DvPyr* h_apr = (DvPyr*)(hp + o_apr); DvLkJob* h_lk = (DvLkJob*)(hp + o_lk); DvCompactJob* h_cmp = (DvCompactJob*)(hp + o_cmp);
+    GfttTileArgs* h_gt = (GfttTileArgs*)(hp + o_gt); GfttSelectArgs* h_gs = (GfttSelectArgs*)(hp + o_gs); DvFinalizeJob* h_fin = (DvFinalizeJob*)(hp + o_fin);
+    int levels = 0, lw[DV_MAX_LEVELS] = { 0 }, lh[DV_MAX_LEVELS] = { 0 };
+    for (int k = 0; k < S; ++k) {
+        const dv_track_job& j = jobs[M[k]]; dv_ctx* c = mem[j.member];
+        const dv_config& cf = c->cfg;
+        PyrSet& L = c->left[c->cur]; PyrSet& Lp = c->left[c->cur ^ 1];
+        const DvPyr& a = L.pyr; const DvPyr* b = stereo ? &c->right.pyr : nullptr;
+        const int stride = j.stride > 0 ? j.stride : w;
+        const bool dev = j.mem == DV_MEM_DEVICE;
+        if (!dev || a.levels == 1) {      // host frames: the upload IS the level-0 copy
+            DV_CHECK(hipMemcpy2DAsync(a.L[0].p, a.L[0].pitch, j.gray0, stride, w, h, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+            if (b) DV_CHECK(hipMemcpy2DAsync(b->L[0].p, b->L[0].pitch, j.gray1, stride, w, h, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+        }
+        levels = a.levels;
+        for (int l = 1; l < a.levels; ++l) {
+            const bool fuse = dev && l == 1;
+            DvPyrJob pj{};
+            pj.src0 = fuse ? j.gray0 : a.L[l - 1].p; pj.src1 = b ? (fuse ? j.gray1 : b->L[l - 1].p) : nullptr;
+            pj.dst0 = a.L[l].p; pj.dst1 = b ? b->L[l].p : nullptr;
+            pj.sw = a.L[l - 1].w; pj.sh = a.L[l - 1].h; pj.spitch = fuse ? stride : a.L[l - 1].pitch; pj.dw = a.L[l].w; pj.dh = a.L[l].h; pj.dpitch = a.L[l].pitch;
+            pj.cpy0 = fuse ? a.L[0].p : nullptr; pj.cpy1 = (fuse && b) ? b->L[0].p : nullptr; pj.cpitch = a.L[0].pitch;
+            h_pyr[(size_t)(l - 1) * S + k] = pj;
+            lw[l] = a.L[l].w; lh[l] = a.L[l].h;
+        }
+        h_apr[2 * k] = a; h_apr[2 * k + 1] = b ? *b : a;      // (mono: the second entry repeats the first — idempotent)
+        // temporal LK (skipped by its own n_feat == 0 on a sequence's first frame), stereo LK
+        DvLkJob t{}; t.A = Lp.pyr; t.B = a; t.pts_a = c->tr.last_pts; t.n_dev = c->tr.n_feat; t.pts_b = c->tr.lk_pts; t.status = c->tr.lk_status;
+        if (!c->have_prev) t.A = a;                           // (no previous pyramid yet: n_feat is 0, nothing is read)
+        h_lk[k] = t;
+        DvLkJob r{}; r.A = a; r.B = b ? *b : a; r.pts_a = c->tr.curr_pts; r.n_dev = c->tr.n_feat; r.pts_b = c->tr.right_pts; r.status = c->tr.right_status;
+        h_lk[S + k] = r;
+        h_cmp[k] = DvCompactJob{ c->tr, nullptr, 0, 1, c->n_cand, c->max_ord };
+        GfttTileArgs g{};
+        g.img = a.L[0].p; g.w = w; g.h = h; g.pitch = a.L[0].pitch; g.in_mask = nullptr; g.mask_pitch = 0;
+        g.disc_pts = c->tr.curr_pts; g.n_disc = c->tr.n_tracked; g.radius = cf.min_dist; g.hw = (const uint8_t*)c->hw_buf.p;
+        g.n_feat = c->tr.n_feat; g.max_cnt = cf.max_cnt; g.min_new = 1; g.eig_out = nullptr; g.eig_pitch = 0;
+        g.cand = (DvCand*)c->cand_buf.p; g.cand_cap = c->cand_cap; g.n_cand = c->n_cand; g.max_ord = c->max_ord;
+        h_gt[k] = g;
+        GfttSelectArgs q{};
+        q.cand = (const DvCand*)c->cand_buf.p; q.n_cand = c->n_cand; q.cand_cap = c->cand_cap; q.max_ord = c->max_ord;
+        q.w = w; q.h = h; q.quality = 0.01; q.min_dist = (double)cf.min_dist; q.max_n_host = 0; q.n_feat = c->tr.n_feat; q.max_cnt = cf.max_cnt; q.min_new = 1;
+        q.out_xy = nullptr; q.n_out = nullptr; q.tr = c->tr; q.has_tr = 1; q.err_flag = c->err_flag;
+        h_gs[k] = q;
+        DvFinalizeJob f{};
+        f.tr = c->tr; f.cam0 = cf.cam0; f.cam1 = cf.cam1; f.stereo = stereo ? 1 : 0; f.dt = j.t - c->prev_time; f.out = c->out_pinned; f.n_out = c->nout_pinned;
+        f.err_in = c->err_flag; f.err_out = c->err_pinned;
+        h_fin[k] = f;
+    }
+    DV_CHECK(hipMemcpyAsync(F.tab[par].p, hp, total, hipMemcpyHostToDevice, s));
+    DV_CHECK(hipEventRecord(F.ev_copy[par], s)); F.copy_used[par] = true;
+    // ---- the stages ----
+    for (int l = 1; l < levels; ++l) dv_launch_pyr_down_multi((const DvPyrJob*)(dp + o_pyr) + (size_t)(l - 1) * S, S, lw[l], lh[l], s);
+    dv_launch_pyr_apron_multi((const DvPyr*)(dp + o_apr), 2 * S, levels, s);
+    dv_launch_lk_track_multi((const DvLkJob*)(dp + o_lk), S, n_max, ref->flow_back, 0.5f, s);
+    dv_launch_compact_multi((const DvCompactJob*)(dp + o_cmp), S, s);
+    dv_launch_gftt_tile_multi((const GfttTileArgs*)(dp + o_gt), S, w, h, s);
+    if (dv_launch_gftt_select_multi((const GfttSelectArgs*)(dp + o_gs), S, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
+    if (stereo) dv_launch_lk_track_multi((const DvLkJob*)(dp + o_lk) + S, S, n_max, ref->flow_back, 0.5f, s);
+    dv_launch_finalize_multi((const DvFinalizeJob*)(dp + o_fin), S, n_max, s);
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipEventRecord(F.done, s));
+    for (int i : M) {
+        const dv_track_job& j = jobs[i]; dv_ctx* c = mem[j.member];
+        c->last_done = F.done; c->last_front = s;
+        c->prev_time = j.t; c->have_prev = true; c->pending = true;
+    }
+    F.rounds++; F.members_batched += S;
+    return 0;
+}
+extern "C" int dv_batch_track_info(dv_batch* B, long long* rounds, long long* members_batched, long long* members_single) {
+    if (!B) return -1;
+    DvFrontBatch* F = be_batch_front(B);
+    if (rounds) *rounds = F ? F->rounds : 0;
+    if (members_batched) *members_batched = F ? F->members_batched : 0;
+    if (members_single) *members_single = F ? F->members_single : 0;
+    return 0;
+}
+
+extern "C" {
 
 // ------------------------------- operator-level entries -------------------------------
 

@@ -47,7 +47,17 @@ __device__ __forceinline__ float ord2f(unsigned u) {
 }
 
 
-__global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
+// XCD-aware tile numbering: workgroups are dealt to the 8 XCDs round-robin, a 64-pixel tile row is HALF a 128-byte line and every tile reads a 3-pixel halo,
+// so with the plain 2-D numbering neighbouring tiles (and both halves of every line) are fetched into different L2s.  Every XCD gets a contiguous run of
+// tiles in raster order instead (the candidate order changes; the select kernel sorts by (value, address), so the result does not).
+// lin = linear workgroup number of the launch, nt = tiles it covers -> the tile this workgroup takes
+__device__ __forceinline__ int gftt_xcd_tile(int lin, int nt) {
+    const int xc = lin & 7, k = lin >> 3;
+    int start = 0;
+    for (int y = 0; y < xc; ++y) start += nt > y ? (nt - y + 7) >> 3 : 0;
+    return start + k;
+}
+__device__ __forceinline__ void gftt_tile_body(const GfttTileArgs& a, int tx, int ty) {
     __shared__ uint8_t s_img[IMG_H * IMG_PITCH];
     __shared__ float s_cov[3][COV_H][COV_W];
     __shared__ float s_eig[EIG_H][EIG_W];
@@ -58,17 +68,6 @@ __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
     __shared__ int s_ncand, s_base;
     const int tid = threadIdx.x;
     if (a.n_feat && a.max_cnt - *a.n_feat < a.min_new) return;     // no detection wanted this frame
-    // XCD-aware tile numbering: workgroups are dealt to the 8 XCDs round-robin, a 64-pixel tile row is HALF a 128-byte line and every tile reads a 3-pixel halo,
-    // so with the plain 2-D numbering neighbouring tiles (and both halves of every line) are fetched into different L2s.  Every XCD gets a contiguous run of
-    // tiles in raster order instead (the candidate order changes; the select kernel sorts by (value, address), so the result does not).
-    int tx, ty;
-    {
-        const int gx = gridDim.x, nt = gridDim.x * gridDim.y, lin = blockIdx.y * gx + blockIdx.x, xc = lin & 7, k = lin >> 3;
-        int start = 0;
-        for (int y = 0; y < xc; ++y) start += nt > y ? (nt - y + 7) >> 3 : 0;
-        const int t = start + k;
-        ty = t / gx; tx = t - ty * gx;
-    }
     const int x0 = tx * TW, y0 = ty * TH;
     const int w = a.w, h = a.h;
     if (tid == 0) { s_ndisc = 0; s_ncand = 0; }
@@ -183,6 +182,17 @@ __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
     __syncthreads();
     for (int i = tid; i < nc; i += 256) { const int k = s_base + i; if (k < a.cand_cap) a.cand[k] = s_cand[i]; }
 }
+__global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
+    const int gx = gridDim.x, t = gftt_xcd_tile(blockIdx.y * gx + blockIdx.x, gridDim.x * gridDim.y);
+    gftt_tile_body(a, t % gx, t / gx);
+}
+// several images of ONE size in one launch (the front ends of a dv_batch group): the launch's tiles are numbered image-major, and every XCD takes a contiguous
+// run of that sequence — whole images or raster runs of one
+__global__ __launch_bounds__(256) void gftt_tile_multi_kernel(const GfttTileArgs* __restrict__ tab, int gx, int gy) {
+    const int per = gx * gy, t = gftt_xcd_tile(blockIdx.x, gridDim.x), job = t / per, tt = t - job * per;
+    const GfttTileArgs a = tab[job];
+    gftt_tile_body(a, tt % gx, tt / gx);
+}
 
 // ---------------------------------------------------------------------------------------------
 #define SEL_THREADS 1024
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
 #define SEL_MAX_CELLS 32768
 
 
-__global__ __launch_bounds__(SEL_THREADS) void gftt_select_kernel(GfttSelectArgs a) {
+__device__ __forceinline__ void gftt_select_body(const GfttSelectArgs& a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);                    // SEL_CAP
     int* hist = reinterpret_cast<int*>(smem + SEL_CAP * 8);                                     // SEL_BINS + 1 (suffix sums)
@@ -366,6 +376,12 @@ __global__ __launch_bounds__(SEL_THREADS) void gftt_select_kernel(GfttSelectArgs
         if (tid == 0) { *a.tr.n_feat = n0 + acc; *a.tr.next_id = id0 + acc; }
     }
 }
+__global__ __launch_bounds__(SEL_THREADS) void gftt_select_kernel(GfttSelectArgs a) { gftt_select_body(a); }
+// one workgroup per job (blockIdx.x): the corner selections of a dv_batch group's front ends in one launch
+__global__ __launch_bounds__(SEL_THREADS) void gftt_select_multi_kernel(const GfttSelectArgs* __restrict__ tab) {
+    const GfttSelectArgs a = tab[blockIdx.x];
+    gftt_select_body(a);
+}
 
 static size_t select_smem_bytes() {
     return (size_t)SEL_CAP * 8 + (SEL_BINS + 1 + 7) * 4 + 3 * SEL_MAX_ACC * 2 + SEL_MAX_CELLS * 2;
@@ -374,6 +390,20 @@ static size_t select_smem_bytes() {
 void dv_launch_gftt_tile(const GfttTileArgs& a, hipStream_t s) {
     dim3 grid((a.w + TW - 1) / TW, (a.h + TH - 1) / TH);
     hipLaunchKernelGGL(gftt_tile_kernel, grid, dim3(256), 0, s, a);
+}
+
+void dv_launch_gftt_tile_multi(const GfttTileArgs* tab_dev, int n_jobs, int w, int h, hipStream_t s) {
+    if (n_jobs <= 0) return;
+    const int gx = (w + TW - 1) / TW, gy = (h + TH - 1) / TH;
+    hipLaunchKernelGGL(gftt_tile_multi_kernel, dim3(gx * gy * n_jobs), dim3(256), 0, s, tab_dev, gx, gy);
+}
+int dv_launch_gftt_select_multi(const GfttSelectArgs* tab_dev, int n_jobs, hipStream_t s) {
+    if (n_jobs <= 0) return 0;
+    static DevOnce once;
+    if (once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(gftt_select_multi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)select_smem_bytes()) != hipSuccess; })) return -1;
+    hipLaunchKernelGGL(gftt_select_multi_kernel, dim3(n_jobs), dim3(SEL_THREADS), select_smem_bytes(), s, tab_dev);
+    return 0;
 }
 
 int dv_launch_gftt_select(const GfttSelectArgs& a, hipStream_t s) {

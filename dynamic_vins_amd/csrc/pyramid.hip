@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void pyr_down_multi_kernel(const DvPyrJob* __r
     if ((int)blockIdx.x * PT_W >= j.dw || (int)blockIdx.y * PT_H >= j.dh) return;
     const int img = blockIdx.z & 1;
     if (img && !j.src1) return;
-    pyr_down_tile(img ? j.src1 : j.src0, j.sw, j.sh, j.spitch, img ? j.dst1 : j.dst0, j.dw, j.dh, j.dpitch, nullptr, 0, blockIdx.x, blockIdx.y);
+    pyr_down_tile(img ? j.src1 : j.src0, j.sw, j.sh, j.spitch, img ? j.dst1 : j.dst0, j.dw, j.dh, j.dpitch, img ? j.cpy1 : j.cpy0, j.cpitch, blockIdx.x, blockIdx.y);
 }
 void dv_launch_pyr_down_multi(const DvPyrJob* jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t s) {
     if (n_jobs <= 0) return;
@@ -134,6 +134,27 @@ __global__ __launch_bounds__(256) void pyr_apron_kernel(DvPyr a, DvPyr b) {
         const int x = px - A, y = py - A;
         L.p[(ptrdiff_t)y * L.pitch + x] = L.p[(ptrdiff_t)pyr_reflect101(y, h) * L.pitch + pyr_reflect101(x, w)];
     }
+}
+// the aprons of several pyramids in ONE launch (the front ends of a dv_batch group: blockIdx.z = pyramid)
+__global__ __launch_bounds__(256) void pyr_apron_multi_kernel(const DvPyr* __restrict__ pyrs) {
+    const DvPyr& P = pyrs[blockIdx.z];
+    if ((int)blockIdx.y >= P.levels) return;
+    const DvLevel L = P.L[blockIdx.y];
+    const int A = L.apron, w = L.w, h = L.h, W = w + 2 * A;
+    if (A <= 0) return;
+    const int top = A * W, mid = h * 2 * A, total = 2 * top + mid;
+    for (int k = blockIdx.x * 256 + threadIdx.x; k < total; k += gridDim.x * 256) {
+        int px, py;
+        if (k < top) { py = k / W; px = k - py * W; }
+        else if (k < top + mid) { const int k2 = k - top, r = k2 / (2 * A), c = k2 - r * 2 * A; py = A + r; px = c < A ? c : w + c; }
+        else { const int k3 = k - top - mid, r = k3 / W; py = A + h + r; px = k3 - r * W; }
+        const int x = px - A, y = py - A;
+        L.p[(ptrdiff_t)y * L.pitch + x] = L.p[(ptrdiff_t)pyr_reflect101(y, h) * L.pitch + pyr_reflect101(x, w)];
+    }
+}
+void dv_launch_pyr_apron_multi(const DvPyr* pyrs_dev, int n_pyr, int max_levels, hipStream_t s) {
+    if (n_pyr <= 0 || max_levels <= 0) return;
+    hipLaunchKernelGGL(pyr_apron_multi_kernel, dim3(48, max_levels, n_pyr), dim3(256), 0, s, pyrs_dev);
 }
 void dv_launch_pyr_apron(const DvPyr& a, const DvPyr* b, hipStream_t s) {
     if (a.levels <= 0 || a.L[0].apron <= 0) return;

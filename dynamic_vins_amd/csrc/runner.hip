@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -20,7 +21,7 @@ namespace {
 struct RSeq {
     dv_ctx* ctx = nullptr; dv_seq_input in{};
     int next = 0, k_imu = 0, w = 0, h = 0, stride = 0;
-    bool enqueued = false, pending = false;
+    bool enqueued = false, pending = false, skipped = false;
     std::vector<dv_feat> rows; int n_rows = 0;
     double pending_t = 0;
     dv_est_state last{};
@@ -35,14 +36,16 @@ struct dv_runner {
     struct Group { std::vector<int> members; dv_batch* batch = nullptr; bool pending = false; };
     std::vector<Group> groups;
     int threads = 1;
-    std::string err;
+    bool batch_front = true;      // dv_batch groups: the members' tracking in shared launches too (dv_batch_track_enqueue); dv_runner_set(runner, "batch_front", 0) keeps one set of launches per sequence
+    std::string err; std::mutex err_mu;
 };
 
 namespace {
+void set_err(dv_runner* R, const std::string& m) { std::lock_guard<std::mutex> lk(R->err_mu); R->err = m; }      // several host threads drive their own groups: the shared message is guarded (per-sequence ones are each thread's own)
 int fail(dv_runner* R, RSeq& s, const char* what) {
     const char* m = dv_last_error(s.ctx);
     s.err = std::string(what) + ": " + (m ? m : "");
-    R->err = s.err;
+    set_err(R, s.err);
     return -1;
 }
 int seq_enqueue(dv_runner* R, RSeq& s, int k) {
@@ -57,26 +60,44 @@ int seq_feed_imu(dv_runner* R, RSeq& s, double t) {
     }
     return 0;
 }
-// first half of a step: everything up to and including the enqueue of frame k's window solve and of frame k+1's tracking
-int seq_begin(dv_runner* R, RSeq& s) {
+// first half of a step: everything up to and including the enqueue of frame k's window solve and of frame k+1's tracking.  own_front = false: the caller enqueues
+// the tracking of the group's frames itself, in shared launches (group_round), and feeds the IMU samples of frame k+1 afterwards.
+int seq_begin(dv_runner* R, RSeq& s, bool own_front = true) {
     const int k = s.next;
-    if (k >= s.in.n_frames) { s.err = "sequence exhausted"; R->err = s.err; return -1; }
-    if (!s.enqueued && seq_enqueue(R, s, k)) return -1;
+    if (k >= s.in.n_frames) { s.err = "sequence exhausted"; set_err(R, s.err); return -1; }
+    if (!s.enqueued) { if (!own_front) { s.err = "internal: frame not enqueued"; set_err(R, s.err); return -1; } if (seq_enqueue(R, s, k)) return -1; }
     if (dv_track_stereo_collect(s.ctx, s.rows.data(), &s.n_rows)) return fail(R, s, "dv_track_stereo_collect");
     s.enqueued = false;
     const double t = s.in.times[k];
     const int stride = s.in.ba_stride > 1 ? s.in.ba_stride : 1;
     if (stride > 1 && (k % stride) != 0) {      // tracked only: outside KITTI the reference pushes a frame to feature_queue when cnt % 2 == 0, cnt counting tracked frames from 0 (system/main.cpp:181,300-312): frames 0, 2, 4, ...
-        if (k + 1 < s.in.n_frames && seq_enqueue(R, s, k + 1)) return -1;
-        ++s.next;
+        if (own_front && k + 1 < s.in.n_frames && seq_enqueue(R, s, k + 1)) return -1;
+        ++s.next; s.skipped = true;
         return 0;
     }
+    s.skipped = false;
     if (seq_feed_imu(R, s, t)) return -1;
     const int rc = dv_est_process_begin(s.ctx, s.rows.data(), s.n_rows, t);
     if (rc < 0) return fail(R, s, "dv_est_process_begin");
-    if (rc > 0) { s.err = "IMU stream does not cover the frame"; R->err = s.err; return -1; }
-    if (k + 1 < s.in.n_frames) { if (seq_enqueue(R, s, k + 1) || seq_feed_imu(R, s, s.in.times[k + 1])) return -1; }
+    if (rc > 0) { s.err = "IMU stream does not cover the frame"; set_err(R, s.err); return -1; }
+    if (own_front && k + 1 < s.in.n_frames) { if (seq_enqueue(R, s, k + 1) || seq_feed_imu(R, s, s.in.times[k + 1])) return -1; }
     s.pending = true; s.pending_t = t;
+    return 0;
+}
+// the tracking of frame `s.next + ahead` of every member of a dv_batch group in shared launches (dv_batch_track_enqueue)
+int group_track(dv_runner* R, dv_runner::Group& g, int ahead) {
+    std::vector<dv_track_job> jobs;
+    for (size_t m = 0; m < g.members.size(); ++m) {
+        RSeq& s = R->seqs[g.members[m]];
+        const int k = s.next + ahead - (s.skipped && ahead ? 1 : 0);      // (a track-only frame has already advanced s.next)
+        if (s.enqueued || k >= s.in.n_frames) continue;
+        dv_track_job j{};
+        j.member = (int)m; j.mem = s.in.mem; j.gray0 = s.in.left[k]; j.gray1 = s.in.right[k]; j.stride = s.stride; j.mode = DV_MODE_RAW; j.t = s.in.times[k]; j.mask = nullptr;
+        jobs.push_back(j);
+    }
+    if (jobs.empty()) return 0;
+    if (dv_batch_track_enqueue(g.batch, jobs.data(), (int)jobs.size())) { const char* m = dv_last_error(R->seqs[g.members[0]].ctx); set_err(R, std::string("dv_batch_track_enqueue: ") + (m ? m : "")); return -1; }
+    for (const dv_track_job& j : jobs) R->seqs[g.members[j.member]].enqueued = true;
     return 0;
 }
 int seq_end(dv_runner* R, RSeq& s) {
@@ -95,8 +116,19 @@ int seq_end(dv_runner* R, RSeq& s) {
 }
 int group_round(dv_runner* R, dv_runner::Group& g) {
     if (g.pending) { for (int i : g.members) if (seq_end(R, R->seqs[i])) return -1; g.pending = false; }
+    if (g.batch && R->batch_front) {
+        // a dv_batch group with shared front-end launches: (first round only) track frame k of all members; per member collect k + begin k; ONE enqueue of the
+        // window solves' slots; ONE set of tracking launches for the members' frames k+1; then their IMU samples up to k+1
+        if (group_track(R, g, 0)) return -1;
+        for (int i : g.members) if (seq_begin(R, R->seqs[i], false)) return -1;
+        if (dv_batch_enqueue(g.batch)) { set_err(R, std::string("dv_batch_enqueue: ") + (dv_last_error(R->seqs[g.members[0]].ctx) ? dv_last_error(R->seqs[g.members[0]].ctx) : "")); return -1; }
+        if (group_track(R, g, 1)) return -1;
+        for (int i : g.members) { RSeq& s = R->seqs[i]; const int k1 = s.next + (s.skipped ? 0 : 1); if (!s.skipped && k1 < s.in.n_frames && seq_feed_imu(R, s, s.in.times[k1])) return -1; }
+        g.pending = true;
+        return 0;
+    }
     for (int i : g.members) if (seq_begin(R, R->seqs[i])) return -1;
-    if (g.batch && dv_batch_enqueue(g.batch)) { R->err = std::string("dv_batch_enqueue: ") + (dv_last_error(R->seqs[g.members[0]].ctx) ? dv_last_error(R->seqs[g.members[0]].ctx) : ""); return -1; }
+    if (g.batch && dv_batch_enqueue(g.batch)) { set_err(R, std::string("dv_batch_enqueue: ") + (dv_last_error(R->seqs[g.members[0]].ctx) ? dv_last_error(R->seqs[g.members[0]].ctx) : "")); return -1; }
     g.pending = true;
     return 0;
 }
@@ -202,6 +234,21 @@ int dv_runner_batch_timing(dv_runner* R, int on, double* out3, long long* rounds
     return 0;
 }
 
+int dv_runner_set(dv_runner* R, const char* key, int value) {
+    if (!R || !key) return -1;
+    if (std::strcmp(key, "batch_front") == 0) { R->batch_front = value != 0; return 0; }
+    R->err = std::string("dv_runner_set: unknown key ") + key;
+    return -1;
+}
+int dv_runner_track_info(dv_runner* R, long long* rounds, long long* members_batched, long long* members_single) {
+    if (!R) return -1;
+    long long a = 0, b = 0, c = 0;
+    for (auto& g : R->groups) if (g.batch) { long long x = 0, y = 0, z = 0; if (dv_batch_track_info(g.batch, &x, &y, &z)) return -1; a += x; b += y; c += z; }
+    if (rounds) *rounds = a;
+    if (members_batched) *members_batched = b;
+    if (members_single) *members_single = c;
+    return 0;
+}
 const char* dv_runner_error(dv_runner* R) { return R ? R->err.c_str() : "null runner"; }
 
 } // extern "C"

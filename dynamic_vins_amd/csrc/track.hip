@@ -30,8 +30,8 @@ __device__ void dv_lift_projective_d(const dv_cam& c, double px, double py, doub
     ox = mx_u; oy = my_u;
 }
 
-__global__ __launch_bounds__(1024) void track_compact_kernel(DvTrackState tr, const uint8_t* __restrict__ in_mask, int mask_pitch,
-                                                             int sort_by_cnt, int* n_cand, unsigned* max_ord) {
+__device__ __forceinline__ void track_compact_body(const DvTrackState& tr, const uint8_t* __restrict__ in_mask, int mask_pitch,
+                                                   int sort_by_cnt, int* n_cand, unsigned* max_ord) {
     __shared__ float2 s_cur[DV_MAX_FEATS], s_pun[DV_MAX_FEATS], s_prun[DV_MAX_FEATS];
     __shared__ uint32_t s_id[DV_MAX_FEATS];
     __shared__ int s_cnt[DV_MAX_FEATS];
@@ -85,10 +85,19 @@ __global__ __launch_bounds__(1024) void track_compact_kernel(DvTrackState tr, co
     }
     if (tid == 0) { *tr.n_feat = total; *tr.n_tracked = total; if (n_cand) *n_cand = 0; if (max_ord) *max_ord = 0u; }
 }
+__global__ __launch_bounds__(1024) void track_compact_kernel(DvTrackState tr, const uint8_t* __restrict__ in_mask, int mask_pitch,
+                                                             int sort_by_cnt, int* n_cand, unsigned* max_ord) {
+    track_compact_body(tr, in_mask, mask_pitch, sort_by_cnt, n_cand, max_ord);
+}
+// the same for several trackers in ONE launch (blockIdx.x = job)
+__global__ __launch_bounds__(1024) void track_compact_multi_kernel(const DvCompactJob* __restrict__ jobs) {
+    const DvCompactJob j = jobs[blockIdx.x];
+    track_compact_body(j.tr, j.in_mask, j.mask_pitch, j.sort_by_cnt, j.n_cand, j.max_ord);
+}
 
-__global__ __launch_bounds__(256) void track_finalize_kernel(DvTrackState tr, dv_cam cam0, dv_cam cam1, int stereo, double dt,
-                                                             dv_feat* __restrict__ out, int* __restrict__ n_out, float off_x, float off_y, int use_off,
-                                                             const int* __restrict__ err_in, int* __restrict__ err_out) {
+__device__ __forceinline__ void track_finalize_body(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt,
+                                                    dv_feat* __restrict__ out, int* __restrict__ n_out, float off_x, float off_y, int use_off,
+                                                    const int* __restrict__ err_in, int* __restrict__ err_out) {
     // `out` / `n_out` / `err_out` may be PINNED HOST memory (the frame's download without copy dispatches behind the kernel): the rows leave through LDS
     // so that a wave writes 1 KB of consecutive bytes, not 64 rows' fields at a 128-byte stride
     __shared__ dv_feat s_rows[256];
@@ -144,6 +153,16 @@ __global__ __launch_bounds__(256) void track_finalize_kernel(DvTrackState tr, dv
         for (int e = threadIdx.x; e < nb * (int)(sizeof(dv_feat) / 16); e += blockDim.x) dst[e] = src[e];
     }
 }
+__global__ __launch_bounds__(256) void track_finalize_kernel(DvTrackState tr, dv_cam cam0, dv_cam cam1, int stereo, double dt,
+                                                             dv_feat* __restrict__ out, int* __restrict__ n_out, float off_x, float off_y, int use_off,
+                                                             const int* __restrict__ err_in, int* __restrict__ err_out) {
+    track_finalize_body(tr, cam0, cam1, stereo, dt, out, n_out, off_x, off_y, use_off, err_in, err_out);
+}
+// the same for several trackers in ONE launch (blockIdx.y = job)
+__global__ __launch_bounds__(256) void track_finalize_multi_kernel(const DvFinalizeJob* __restrict__ jobs) {
+    const DvFinalizeJob j = jobs[blockIdx.y];
+    track_finalize_body(j.tr, j.cam0, j.cam1, j.stereo, j.dt, j.out, j.n_out, 0.f, 0.f, 0, j.err_in, j.err_out);
+}
 
 __global__ __launch_bounds__(256) void circle_mask_kernel(uint8_t* mask, int w, int h, int pitch, const float2* __restrict__ pts, int n,
                                                           int radius, const uint8_t* __restrict__ hw) {
@@ -189,6 +208,15 @@ __global__ __launch_bounds__(256) void lift_kernel(dv_cam cam, const float2* __r
 
 void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_pitch, int sort_by_cnt, int* n_cand, unsigned* max_ord, hipStream_t s) {
     hipLaunchKernelGGL(track_compact_kernel, dim3(1), dim3(1024), 0, s, tr, in_mask, mask_pitch, sort_by_cnt, n_cand, max_ord);
+}
+void dv_launch_compact_multi(const DvCompactJob* jobs_dev, int n_jobs, hipStream_t s) {
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(track_compact_multi_kernel, dim3(n_jobs), dim3(1024), 0, s, jobs_dev);
+}
+void dv_launch_finalize_multi(const DvFinalizeJob* jobs_dev, int n_jobs, int n_max, hipStream_t s) {
+    if (n_jobs <= 0) return;
+    const int blocks = (n_max + 255) / 256;
+    hipLaunchKernelGGL(track_finalize_multi_kernel, dim3(blocks > 0 ? blocks : 1, n_jobs), dim3(256), 0, s, jobs_dev);
 }
 void dv_launch_finalize(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, dv_feat* out, int* n_out, hipStream_t s, const int* err_in, int* err_out) {
     const int blocks = (n_max + 255) / 256;

@@ -238,6 +238,15 @@ int dv_batch_enqueue(dv_batch* batch);
 int dv_batch_arrive(dv_batch* batch);                        /* one host thread per member: blocks until every member's thread has arrived; the last one enqueues */
 int dv_batch_abort(dv_batch* batch);                         /* a member thread failed before arriving: every waiting and later dv_batch_arrive returns -1 */
 int dv_batch_info(dv_batch* batch, long long* batched_rounds, long long* single_rounds);
+/* The FRONT ENDS of the members in shared launches: dv_track_stereo_enqueue for several members at once — FeatureTracker::TrackImage (front_end/background_tracker.cpp:52-158)
+ * of S sequences as one launch per stage (pyramid levels, aprons, temporal LK, compaction, Shi-Tomasi tile, corner selection, stereo LK, rows: 10 launches per group and
+ * frame instead of 10 per sequence; the reference runs one process per sequence, system/main.cpp:178-330).  member = index into the array dv_batch_create was given.
+ * Jobs that cannot share launches (a mode other than DV_MODE_RAW, a mask, BGR frames, installed undistortion maps, an object tracker on the ctx, another image size
+ * than the first job's) run through their member's own dv_track_stereo_enqueue inside this call.  Every member is collected with dv_track_stereo_collect as usual;
+ * its rows are bit-identical to the unbatched path's. */
+typedef struct dv_track_job { int32_t member, mem /* DV_MEM_* [| DV_FMT_BGR] */; const uint8_t* gray0; const uint8_t* gray1; int32_t stride /* bytes, 0 = width */, mode; double t; const uint8_t* mask; } dv_track_job;
+int dv_batch_track_enqueue(dv_batch* batch, const dv_track_job* jobs, int n);
+int dv_batch_track_info(dv_batch* batch, long long* rounds, long long* members_batched, long long* members_single);
 /* measurement: HIP events on the batch stream around the solve / evaluation / reduce launches of one steady-state iteration slot per round; out3 = average ms per launch so far */
 int dv_batch_timing(dv_batch* batch, int on, double* out3, long long* rounds, int* windows);
 
@@ -436,6 +445,9 @@ int dv_runner_get(dv_runner* runner, int seq, dv_est_state* last, double* poses8
 /* every frame handed to the back end, initialisation included, as rows [t, px py pz qx qy qz qw, nonlinear]: the lines of `<seq>_<mode>_Odometry.txt` */
 int dv_runner_get_frames(dv_runner* runner, int seq, double* rows9, int cap, int* n_rows);
 int dv_runner_batch_timing(dv_runner* runner, int on, double* out3, long long* rounds, int* windows);      /* dv_batch_timing of the runner's groups, averaged */
+/* switches: "batch_front" (default 1): the members of a dv_batch group are tracked in shared launches (dv_batch_track_enqueue); 0: one set of launches per sequence */
+int dv_runner_set(dv_runner* runner, const char* key, int value);
+int dv_runner_track_info(dv_runner* runner, long long* rounds, long long* members_batched, long long* members_single);      /* dv_batch_track_info summed over the groups */
 const char* dv_runner_error(dv_runner* runner);
 
 /* FeatureManager::point_landmarks for the point-cloud publishers (utils/io/visualization.cpp:214-249): world point = CamToWorld(point * depth, start_frame);

@@ -93,3 +93,48 @@ def test_member_destroyed_before_its_batch_and_abort(gpu_ctx_factory):
     assert not th.is_alive() and res.get("w") == "raised", res
     batch.close()                                     # after a member is gone and after an abort: no crash
     ctxs[0].close(); ctxs[2].close()
+
+
+@pytest.mark.parametrize("w,h,S,host", [(752, 480, 5, False), (1242, 375, 21, False), (320, 240, 4, True)])
+def test_front_ends_in_shared_launches_equal_single_trackers(gpu_ctx_factory, w, h, S, host):
+    """dv_batch_track_enqueue: FeatureTracker::TrackImage of S sequences as ONE launch per stage (job tables in HBM, member index in the grid) must leave every
+    member EXACTLY the rows its own dv_track_stereo produces — ids, track counts, undistorted points, velocities, stereo matches, bit for bit, frame after frame;
+    21 KITTI-size members is BASELINE.json's config 4 ("seq 0000-0020 batched").  Member 1 sits one round out; host-memory frames take the upload path; a member
+    with a mask falls back to its own launches inside the same call."""
+    import torch
+    from dynamic_vins_amd.backend import Batch
+    from dynamic_vins_amd.frontend import DV_MODE_NAIVE, make_cam
+    from dynamic_vins_amd import synth
+    frames = 9
+    cam = make_cam(*sim.cam_tuple(sim.scaled_cam(sim.ZED, w, h, 1280, 720)))
+    kw = dict(width=w, height=h, max_cnt=120, min_dist=18, cam0=cam, cam1=cam)
+    single = [gpu_ctx_factory(**kw) for _ in range(S)]
+    batched = [gpu_ctx_factory(**kw) for _ in range(S)]
+    seqs = [synth.PlaneSequence(w, h, seed=11 + i, disparity=4.0 + 0.5 * (i % 5)) for i in range(S)]
+    batch = Batch(batched)
+    mask = np.full((h, w), 255, np.uint8); mask[:, : w // 3] = 0
+    keep = []
+    for f in range(frames):
+        t = 0.05 * f
+        jobs, want = [], {}
+        for i in range(S):
+            if i == 1 and f == 4:
+                continue                                    # a member without a frame this round
+            left, right = seqs[i].frame(f)
+            masked = (i == 2 and f >= 3)                    # from frame 3 on member 2 tracks in naive mode with a mask: not batchable, same call
+            want[i] = single[i].track_stereo(left, right, t, mask if masked else None, DV_MODE_NAIVE if masked else 0)
+            if host:
+                jobs.append(dict(member=i, gray0=left, gray1=right, t=t, mask=mask if masked else None, mode=DV_MODE_NAIVE if masked else 0))
+            else:
+                l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+                keep += [l, r]
+                jobs.append(dict(member=i, gray0=l.data_ptr(), gray1=r.data_ptr(), t=t, mask=mask if masked else None, mode=DV_MODE_NAIVE if masked else 0))
+        torch.cuda.synchronize()
+        batch.track_enqueue(jobs)
+        for i in want:
+            got = batched[i].track_stereo_collect()
+            assert len(got) == len(want[i]) and len(got) > 20, f"frame {f}, member {i}: {len(got)} vs {len(want[i])} rows"
+            assert got.tobytes() == want[i].tobytes(), f"frame {f}, member {i}"
+    info = batch.track_info()
+    assert info["rounds"] == frames and info["members_batched"] == S * frames - 1 - (frames - 3) and info["members_single"] == frames - 3, info
+    batch.close()

@@ -59,3 +59,30 @@ def test_batch_stage_timing_leaves_the_results_alone():
     timed.close(); ref.close()
     for p in pipes + plain:
         p.ctx.close()
+
+
+def test_runner_shared_front_end_launches_leave_the_same_bits():
+    """dv_runner groups with dv_batch_track_enqueue (default) against the same groups with one set of tracking launches per sequence (`batch_front` 0), five KITTI-size
+    sequences, frame gate of the non-KITTI datasets on one of the runs' configurations: identical trajectories, window states and row counts"""
+    from dynamic_vins_amd.backend import Runner
+    from dynamic_vins_amd.pipeline import Pipeline, SyntheticSequence
+    w, h, S, frames = 1242, 375, 5, 28
+    cam = sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    seqs = [SyntheticSequence(w, h, cam, frames, rate=20.0, phase=0.9 * i) for i in range(S)]
+    for stride in (1, 2):
+        a = [Pipeline(q, max_cnt=150, min_dist=30, max_iters=8, use_imu=1, ba_stride=stride) for q in seqs]
+        b = [Pipeline(q, max_cnt=150, min_dist=30, max_iters=8, use_imu=1, ba_stride=stride) for q in seqs]
+        ra, rb = Runner(a, group_size=S, threads=1), Runner(b, group_size=S, threads=1)
+        rb.set("batch_front", 0)
+        ra.run(frames - 1); rb.run(frames - 1)
+        ia, ib = ra.track_info(), rb.track_info()
+        assert ia["members_batched"] >= S * (frames - 2) and ia["members_single"] == 0, ia
+        assert ib["members_batched"] == 0, ib
+        for i in range(S):
+            sa, pa, _, fa = ra.get(i); rows_a = ra.last_rows
+            sb, pb, _, fb = rb.get(i); rows_b = rb.last_rows
+            assert fa == fb and rows_a == rows_b and len(pa) == len(pb) >= (frames - 1) // stride - 11
+            assert np.array_equal(pa, pb) and np.array_equal(np.ctypeslib.as_array(sa.window), np.ctypeslib.as_array(sb.window)), (stride, i)
+        ra.close(); rb.close()
+        for p in a + b:
+            p.ctx.close()

@@ -154,10 +154,10 @@ static int marg_plan(dv_ctx* ctx, MargPlan& pl, int mode, const dv_ba_prior* pri
     return 0;
 }
 
-// launches the three kernels; the index tables must already be (enqueued to be) in w.marg_tab
-static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, double* c0_out, hipStream_t s, hipStream_t c0_side = nullptr) {
+// the argument block of the three marginalization kernels; the index tables must already be (enqueued to be) in w.marg_tab
+static int marg_args(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, double* c0_out, BeMargArgs& ma) {
     BeWork& w = ctx->be;
-    BeMargArgs ma{};
+    ma = BeMargArgs{};
     ma.x = x; ma.nframes = BE_NF; ma.nlm = pl.nsel; ma.nimu = pl.nimu; ma.fac = w.fac; ma.lm = w.lm; ma.imu = w.imu;
     ma.prior = w.prior; ma.priorA = priorA; ma.priorb = priorb;
     ma.prior_map = w.marg_tab + BE_MT_PRIOR; ma.imu_map = w.marg_tab + BE_MT_IMU; ma.dim_slot = w.marg_tab + BE_MT_SLOT; ma.dim_comp = w.marg_tab + BE_MT_COMP;
@@ -172,6 +172,14 @@ static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, doubl
     ma.lm_h = ma.sum + slab; ma.imu_w = ma.lm_h + nl; ma.anchor = 0;
     for (int k = 0; k < BE_NF; ++k) ma.pose_dim[k] = pl.pose_dim[k];
     ma.ex_dim[0] = pl.ex_dim[0]; ma.ex_dim[1] = pl.ex_dim[1]; ma.td_dim = pl.td_dim;
+    ma.c0_mode = 0;
+    return 0;
+}
+// launches the three kernels
+static int marg_enqueue(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g_norm, const double* priorA, const double* priorb, double* outA, double* outb, double* scal, double* c0_out, hipStream_t s, hipStream_t c0_side = nullptr) {
+    BeWork& w = ctx->be;
+    BeMargArgs ma;
+    if (marg_args(ctx, pl, x, g_norm, priorA, priorb, outA, outb, scal, c0_out, ma)) return -1;
     ma.c0_mode = c0_side ? 1 : 0;
     {
         StageScope sc(ctx, "k_be_marg", s);
@@ -262,20 +270,26 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculat
 // gauge fix + download of the states (event) + marginalization, enqueued behind the slots on the same stream: the host
 // waits only for the event, so the marginalization of frame k overlaps the host's turnaround and the upload of frame k+1;
 // whatever reads its result (the next solve) is ordered behind it on the stream.
+// the gauge kernel's arguments of an estimator solve: it writes the gauge-fixed copy, the control block and (dynamic mode: body.para_pose as ceres leaves it, before
+// Double2vector's gauge fix) the raw poses straight into the pinned buffer
+static void be_gauge_args(dv_ctx* ctx, const BePending& pd, BeGaugeArgs& ga) {
+    BeWork& w = ctx->be;
+    uint8_t* hp = (uint8_t*)w.pinned;
+    ga = BeGaugeArgs{};
+    ga.x = w.x; ga.out = w.cand; ga.nlm = pd.nlm; ga.nframes = pd.nframes; ga.use_imu = pd.use_imu;
+    std::memcpy(ga.R0, pd.gauge_R0, sizeof(ga.R0)); std::memcpy(ga.ypr0, pd.gauge_ypr0, sizeof(ga.ypr0)); std::memcpy(ga.P0, pd.gauge_P0, sizeof(ga.P0));
+    ga.h_out = (BeState*)(hp + w.dl_off); ga.h_ctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState)); ga.ctl = w.ctl; ga.state_doubles = (int)((pd.state_bytes + 7) / 8);
+    ga.h_raw_pose = pd.want_raw_pose ? (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256) : nullptr;
+}
 static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
     BeWork& w = ctx->be;
     uint8_t* hp = (uint8_t*)w.pinned;
+    pd.ev_state_ext = nullptr;                                  // (a tail of its own: the host waits for w.ev_state again)
     BeGaugeArgs ga{};
-    if (pd.fused_present) {
-        ga.x = w.x; ga.out = w.cand; ga.nlm = pd.nlm; ga.nframes = pd.nframes; ga.use_imu = pd.use_imu;
-        std::memcpy(ga.R0, pd.gauge_R0, sizeof(ga.R0)); std::memcpy(ga.ypr0, pd.gauge_ypr0, sizeof(ga.ypr0)); std::memcpy(ga.P0, pd.gauge_P0, sizeof(ga.P0));
-    }
     BeState* hx = (BeState*)(hp + w.dl_off); BeCtl* hctl = (BeCtl*)(hp + w.dl_off + sizeof(BeState));
     static_assert(sizeof(BeCtl) % sizeof(double) == 0 && sizeof(BeState) % sizeof(double) == 0, "downloaded as doubles");
-    if (pd.fused_present) {        // estimator path: the gauge kernel writes the gauge-fixed copy, the control block and (dynamic mode: body.para_pose as ceres
-                                   // leaves it, before Double2vector's gauge fix) the raw poses straight into the pinned buffer
-        ga.h_out = hx; ga.h_ctl = hctl; ga.ctl = w.ctl; ga.state_doubles = (int)((pd.state_bytes + 7) / 8);
-        ga.h_raw_pose = pd.want_raw_pose ? (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl) + 256) : nullptr;
+    if (pd.fused_present) {        // estimator path
+        be_gauge_args(ctx, pd, ga);
         const bool kt = ctx->timing && ctx->kernel_timing;
         if (pd.fuse_accept_gauge && !kt) be_launch_accept_gauge(pd.sa, ga, s); else be_launch_gauge(ga, s);
         DV_CHECK(hipGetLastError());
@@ -512,7 +526,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     const MargPlan& pl = pd.pl;
     uint8_t* hp = (uint8_t*)w.pinned;
     const BeState* hx = (const BeState*)(hp + w.dl_off); const BeCtl* hctl = (const BeCtl*)(hp + w.dl_off + sizeof(BeState));
-    DV_CHECK(hipEventSynchronize(w.ev_state));
+    DV_CHECK(hipEventSynchronize(pd.ev_state_ext ? pd.ev_state_ext : w.ev_state));      // (member of a dv_batch round: the group's event behind the shared gauge / reject launches)
     if (be_dist_check(ctx)) return -1;      // sharded window, peer transport: a dead or late peer is an error of THIS solve, not garbage in its result
     // the previous frame's marginalization ran before this frame's upload (stream order), so its scalars have landed
     if (be_check_prev_marg(ctx, pd)) return -1;
@@ -561,10 +575,11 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
 // the grid).  Per round: S event waits (uploads done), 3 x iterations launches, one event, S event waits (tails).
 struct dv_batch {
     std::vector<dv_ctx*> members;
-    hipStream_t stream = nullptr; hipEvent_t ev_slots = nullptr; std::vector<hipEvent_t> ev_up;
-    DevBuf tab; void* tab_pinned = nullptr;       // [S] BeEvalArgs | [S] BeSolveArgs
+    hipStream_t stream = nullptr; hipEvent_t ev_slots = nullptr;
+    DevBuf tab; void* tab_pinned = nullptr; size_t tab_bytes = 0;      // [S] BeEvalArgs | [S] BeSolveArgs | [S] BeGaugeArgs | [S] BeRejectArgs | [S] BeMargArgs
     long long batched_rounds = 0, single_rounds = 0;
     DvFrontBatch* front = nullptr;                // the members' front ends in shared launches (dv_batch_track_enqueue, dvins_api.hip)
+    hipEvent_t ev_state = nullptr;                // behind the shared accept + gauge + reject launches of a round: what the members' dv_est_process_end wait for
     std::mutex mu; std::condition_variable cv; int arrived = 0; long long generation = 0; int last_rc = 0;      // dv_batch_arrive
     bool aborted = false;                         // dv_batch_abort: every waiting and every later dv_batch_arrive returns -1
     // dv_batch_timing: HIP events around the three launches of the SECOND iteration slot of every round (a steady-state slot: candidate evaluation, reduce, solve with
@@ -583,6 +598,8 @@ void be_batch_detach(dv_ctx* ctx) {
         std::lock_guard<std::mutex> lk(B->mu);
         B->members.erase(std::remove(B->members.begin(), B->members.end(), ctx), B->members.end());
         ctx->batch = nullptr;
+        if (B->stream) (void)hipStreamSynchronize(B->stream);
+        if (ctx->be_stream_own) { ctx->be_stream = ctx->be_stream_own; ctx->be_stream_own = nullptr; }
         if (B->arrived > 0) { B->last_rc = -1; B->arrived = 0; ++B->generation; dv_set_error(nullptr, "dv_batch_arrive: a member was destroyed during the round"); }
     }
     B->cv.notify_all();
@@ -593,27 +610,42 @@ static int batch_enqueue_impl(dv_batch* B) {
     if (M.empty()) return 0;
     dv_ctx* ctx = M[0];
     DV_CHECK(hipSetDevice(ctx->cfg.device));
+    hipStream_t s = B->stream;                    // == every member's be_stream: their uploads (and the marginalizations of their previous frames) are ordered before the slots
     bool uniform = true; int slots = M[0]->be.pend->first_slots, max_grid = 0, max_n = 0;
     for (dv_ctx* c : M) {
         const BePending& pd = *c->be.pend;
-        if (pd.sa.ldl_wcol == 0 || pd.sa.ldl_wcol != M[0]->be.pend->sa.ldl_wcol || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing)) uniform = false;
+        if (pd.sa.ldl_wcol == 0 || pd.sa.ldl_wcol != M[0]->be.pend->sa.ldl_wcol || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing) || !pd.fused_present) uniform = false;
         max_grid = std::max(max_grid, pd.ea.dims.nlm + pd.ea.dims.nimu + 1); max_n = std::max(max_n, pd.sa.dims.nstate);
     }
-    if (!uniform || M.size() == 1) {      // mixed kernel variants (or nothing to share): every member on its own stream, as without a batch
-        for (dv_ctx* c : M) { BePending& pd = *c->be.pend; pd.deferred = false; if (be_enqueue_slots(c, pd, pd.first_slots, true, c->be_stream) || be_enqueue_tail(c, pd, c->be_stream)) { dv_set_error(ctx, c->err); return -1; } }
+    if (!uniform || M.size() == 1) {      // mixed kernel variants (or nothing to share): every member's own launches, one member after the other
+        for (dv_ctx* c : M) { BePending& pd = *c->be.pend; pd.deferred = false; if (be_enqueue_slots(c, pd, pd.first_slots, true, s) || be_enqueue_tail(c, pd, s)) { dv_set_error(ctx, c->err); return -1; } }
         B->single_rounds++;
         return 0;
     }
     const int S = (int)M.size();
-    BeEvalArgs* hea = (BeEvalArgs*)B->tab_pinned; BeSolveArgs* hsa = (BeSolveArgs*)(hea + B->members.size());
-    for (int i = 0; i < S; ++i) { hea[i] = M[i]->be.pend->ea; hsa[i] = M[i]->be.pend->sa; }
-    hipStream_t s = B->stream;
-    const BeEvalArgs* dea = (const BeEvalArgs*)B->tab.p; const BeSolveArgs* dsa = (const BeSolveArgs*)(dea + B->members.size());
-    DV_CHECK(hipMemcpyAsync(B->tab.p, B->tab_pinned, B->members.size() * (sizeof(BeEvalArgs) + sizeof(BeSolveArgs)), hipMemcpyHostToDevice, s));
-    for (int i = 0; i < S; ++i) {         // the members' uploads (and the marginalization of their previous frame) come first
-        DV_CHECK(hipEventRecord(B->ev_up[i], M[i]->be_stream));
-        DV_CHECK(hipStreamWaitEvent(s, B->ev_up[i], 0));
+    const size_t cap = B->members.size();
+    BeEvalArgs* hea = (BeEvalArgs*)B->tab_pinned; BeSolveArgs* hsa = (BeSolveArgs*)(hea + cap);
+    BeGaugeArgs* hga = (BeGaugeArgs*)(hsa + cap); BeRejectArgs* hrj = (BeRejectArgs*)(hga + cap); BeMargArgs* hma = (BeMargArgs*)(hrj + cap);
+    // the frame tails' arguments are known now as well (nothing in them depends on the solve): accept + gauge + download, outlier test, marginalization
+    int max_rej = 0, max_mlm = 0, any_imu = 0, max_D = 0, n_marg = 0; size_t max_fin = 0;
+    for (int i = 0; i < S; ++i) {
+        dv_ctx* c = M[i]; BePending& pd = *c->be.pend; BeWork& w = c->be;
+        hea[i] = pd.ea; hsa[i] = pd.sa;
+        be_gauge_args(c, pd, hga[i]);
+        hrj[i] = BeRejectArgs{};
+        if (pd.rej_on) { hrj[i] = pd.rej; max_rej = std::max(max_rej, pd.rej.nlm); }
+        hma[i] = BeMargArgs{};                    // D = 0: no marginalization for this member this frame
+        if (pd.do_marg && !pd.pl.empty) {
+            uint8_t* hp = (uint8_t*)w.pinned;
+            double* hscal = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl)) + 4 * pd.scal_slot;      // the health scalars go straight to the member's pinned slot
+            if (marg_args(c, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], hscal, w.prior_c0 + pd.nxt, hma[i])) { dv_set_error(ctx, c->err); return -1; }
+            max_mlm = std::max(max_mlm, hma[i].nlm); any_imu |= hma[i].nimu > 0; max_D = std::max(max_D, hma[i].D);
+            max_fin = std::max(max_fin, be_marg_finish_smem(hma[i].D, hma[i].D - hma[i].m)); ++n_marg;
+        }
     }
+    const BeEvalArgs* dea = (const BeEvalArgs*)B->tab.p; const BeSolveArgs* dsa = (const BeSolveArgs*)(dea + cap);
+    const BeGaugeArgs* dga = (const BeGaugeArgs*)(dsa + cap); const BeRejectArgs* drj = (const BeRejectArgs*)(dga + cap); const BeMargArgs* dma = (const BeMargArgs*)(drj + cap);
+    DV_CHECK(hipMemcpyAsync(B->tab.p, B->tab_pinned, B->tab_bytes, hipMemcpyHostToDevice, s));
     const bool two_level = M[0]->be.pend->sa.dims.pad != 0;
     if (B->timing && B->tev_pending && hipEventQuery(B->tev[3]) == hipSuccess) {      // the previous round's three stages
         float ms;
@@ -627,7 +659,7 @@ static int batch_enqueue_impl(dv_batch* B) {
         if (head) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_X, s); be_launch_reduce_batch(dsa, S, max_n, 0, s); }
         if (timed) { (void)hipEventRecord(B->tev[0], s); B->t_windows = S; }
         if (be_launch_solve_batch(dsa, S, max_n, two_level, head ? 0 : 1, s, M[0]->be.pend->sa.ldl_wcol)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
-        if (last) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s); be_launch_accept_batch(dsa, S, s); }
+        if (last) be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s);      // (its accept decision rides in the tail's first launch)
         else if (timed) {
             (void)hipEventRecord(B->tev[1], s);
             be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); (void)hipEventRecord(B->tev[2], s);
@@ -636,13 +668,22 @@ static int batch_enqueue_impl(dv_batch* B) {
         }
         else { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); be_launch_reduce_batch(dsa, S, max_n, 1, s); }
     }
+    // ---- the tails of all members: 2 + 3 launches per group instead of 5 - 6 per member on S streams ----
+    be_launch_accept_gauge_batch(dsa, dga, S, s);
+    be_launch_reject_batch(drj, S, max_rej, s);
     DV_CHECK(hipGetLastError());
-    DV_CHECK(hipEventRecord(B->ev_slots, s));
+    DV_CHECK(hipEventRecord(B->ev_state, s));
+    if (n_marg > 0) {
+        const int rc = be_launch_marg_batch(dma, S, max_mlm, any_imu, max_D, max_fin, s);
+        if (rc == -2) DV_FAIL("dv_marginalize: system does not fit in LDS");
+        if (rc) DV_FAIL("dv_marginalize: cannot set dynamic LDS size");
+        DV_CHECK(hipGetLastError());
+    }
     for (dv_ctx* c : M) {
         BePending& pd = *c->be.pend;
         pd.deferred = false; pd.t_enq = std::chrono::steady_clock::now();
-        DV_CHECK(hipStreamWaitEvent(c->be_stream, B->ev_slots, 0));
-        if (be_enqueue_tail(c, pd, c->be_stream)) { dv_set_error(ctx, c->err); return -1; }
+        pd.ev_state_ext = B->ev_state;
+        if (pd.do_marg && !pd.pl.empty) pd.marg_in_flight = true;
     }
     B->batched_rounds++;
     return 0;
@@ -672,23 +713,30 @@ dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n) {
     if (hipSetDevice(ctxs[0]->cfg.device) != hipSuccess) { dv_set_error(nullptr, "dv_batch_create: hipSetDevice failed"); return nullptr; }
     dv_batch* B = new dv_batch();
     B->members.assign(ctxs, ctxs + n);
-    bool ok = hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&B->ev_slots, hipEventDisableTiming) == hipSuccess;
-    B->ev_up.assign(n, nullptr);
-    for (int i = 0; i < n && ok; ++i) ok = hipEventCreateWithFlags(&B->ev_up[i], hipEventDisableTiming) == hipSuccess;
-    const size_t bytes = (size_t)n * (sizeof(BeEvalArgs) + sizeof(BeSolveArgs));
+    bool ok = hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&B->ev_slots, hipEventDisableTiming) == hipSuccess
+              && hipEventCreateWithFlags(&B->ev_state, hipEventDisableTiming) == hipSuccess;
+    const size_t bytes = (size_t)n * (sizeof(BeEvalArgs) + sizeof(BeSolveArgs) + sizeof(BeGaugeArgs) + sizeof(BeRejectArgs) + sizeof(BeMargArgs));
+    B->tab_bytes = bytes;
     ok = ok && B->tab.ensure(bytes) == hipSuccess && hipHostMalloc(&B->tab_pinned, bytes, hipHostMallocDefault) == hipSuccess;
-    if (!ok) { dv_set_error(nullptr, "dv_batch_create: out of resources"); dv_batch_destroy(B); return nullptr; }
-    for (int i = 0; i < n; ++i) ctxs[i]->batch = B;
+    if (!ok) { dv_set_error(nullptr, "dv_batch_create: out of resources"); B->members.clear(); dv_batch_destroy(B); return nullptr; }
+    // from now on the batch's stream IS every member's BA stream: uploads, window solves (shared or alone), tails and marginalizations of all members are ordered on
+    // it — one hardware queue per group instead of one per member (48 streams on 12 queues made unrelated launches wait behind each other's event waits)
+    for (int i = 0; i < n; ++i) {
+        dv_ctx* c = ctxs[i];
+        (void)hipStreamSynchronize(c->be_stream);
+        c->be_stream_own = c->be_stream; c->be_stream = B->stream; c->batch = B;
+    }
     return B;
 }
 void dv_batch_destroy(dv_batch* B) {
     if (!B) return;
-    { std::lock_guard<std::mutex> lk(B->mu); for (dv_ctx* c : B->members) if (c->batch == B) c->batch = nullptr; B->members.clear(); }
+    if (B->stream) (void)hipStreamSynchronize(B->stream);
+    { std::lock_guard<std::mutex> lk(B->mu); for (dv_ctx* c : B->members) if (c->batch == B) { c->batch = nullptr; if (c->be_stream_own) { c->be_stream = c->be_stream_own; c->be_stream_own = nullptr; } } B->members.clear(); }
     if (B->front) { dv_front_batch_release(B->front); B->front = nullptr; }
-    if (B->stream) { (void)hipStreamSynchronize(B->stream); (void)hipStreamDestroy(B->stream); }
+    if (B->stream) (void)hipStreamDestroy(B->stream);
     if (B->ev_slots) (void)hipEventDestroy(B->ev_slots);
+    if (B->ev_state) (void)hipEventDestroy(B->ev_state);
     for (hipEvent_t e : B->tev) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : B->ev_up) if (e) (void)hipEventDestroy(e);
     B->tab.release();
     if (B->tab_pinned) (void)hipHostFree(B->tab_pinned);
     delete B;

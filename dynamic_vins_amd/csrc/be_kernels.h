@@ -205,6 +205,10 @@ void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, in
 void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s);
 int  be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s, int ldl_mode);      // ldl_mode: the members' common ldl_wcol (1 wave-column, 2 MF16)
 void be_launch_accept_batch(const BeSolveArgs* tab_dev, int n_win, hipStream_t s);
+void be_launch_accept_gauge_batch(const BeSolveArgs* stab, const BeGaugeArgs* gtab, int n, hipStream_t s);
+void be_launch_reject_batch(const BeRejectArgs* tab, int n, int max_nlm, hipStream_t s);
+size_t be_marg_finish_smem(int D, int n);
+int be_launch_marg_batch(const BeMargArgs* tab, int n, int max_nlm, int any_imu, int max_D, size_t max_finish_bytes, hipStream_t s);
 void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s);   // after the exchange of a reduce: rank-ordered sums -> Hd / Sc / gvec, packet rows, candidate costs
 void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s);      // cost-only exchange: phase 0 packs the owned candidate costs, phase 1 scatters all of them
 void be_launch_proj_op(const BeFactor* fac, int n, const double* pose_i, const double* pose_j, const double* ex0, const double* ex1,

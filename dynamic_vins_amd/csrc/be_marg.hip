@@ -105,10 +105,10 @@ __host__ __device__ __forceinline__ int mg_wstride(int D) { return (D + 2 + 15) 
 __device__ __forceinline__ int mg_xoff(int c) { return c < MG_NC ? mg_coff(c) : c == MG_NC ? 0 : 50; }
 __device__ __forceinline__ int mg_xstep(int c) { return c < MG_NC ? mg_cstep(c) : 1; }
 
-__global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
+__device__ __forceinline__ void be_marg_lm_body(const BeMargArgs& a, const int bx) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = a.D, D1 = mg_wstride(D), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nchunk = (a.nlm + MG_CH - 1) / MG_CH, chunk = blockIdx.x;
+    const int nchunk = (a.nlm + MG_CH - 1) / MG_CH, chunk = bx;
     double* Jb = sm;                                   // (MG_MAXF + 2) x 54: the chunk's residual blocks, landmark after landmark, then zero rows
     __shared__ FrameGeom fg[BE_NF];
     __shared__ m33 ric[2];
@@ -255,6 +255,13 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
     }
     MTS(5);
 }
+__global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) { be_marg_lm_body(a, blockIdx.x); }
+// the marginalizations of a dv_batch group in shared launches (blockIdx.y = member, argument table in HBM; a member without one this frame has D = 0)
+__global__ __launch_bounds__(LM_THREADS) void be_marg_lm_batch_kernel(const BeMargArgs* __restrict__ tab) {
+    const BeMargArgs a = tab[blockIdx.y];
+    if (a.D <= 0 || !(a.nlm > 0 || a.nimu > 0) || (int)blockIdx.x >= (a.nlm + MG_CH - 1) / MG_CH + (a.nimu > 0 ? 1 : 0)) return;
+    be_marg_lm_body(a, blockIdx.x);
+}
 
 // be_marg_sum, two kinds of workgroups in one launch:
 //   tiles    (blockIdx.x < lower tiles of the extended (D + 1) x (D + 1) system)   a.sum = - W^T diag(hinv) W  (dense D x D, both triangles, then the row of the
@@ -264,11 +271,11 @@ __global__ __launch_bounds__(LM_THREADS) void be_marg_lm_kernel(BeMargArgs a) {
 // be_marg_finish adds psum into the dense system at the positions the structure dictates (the scattered 8-byte gathers this kernel did itself at first — 32 per
 // lane, each load instruction touching up to 64 lines — kept the texture addresser of every CU busy for 7 us).
 #define MG_KSTEPS 16
-__global__ __launch_bounds__(256) void be_marg_sum_kernel(BeMargArgs a, int tiles) {
+__device__ __forceinline__ void be_marg_sum_body(const BeMargArgs& a, const int tiles, const int bx) {
     const int D = a.D, Ws = mg_wstride(D), lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int nlm = a.nlm, nchunk = (nlm + MG_CH - 1) / MG_CH;
-    if ((int)blockIdx.x >= tiles) {
-        const int e = ((int)blockIdx.x - tiles) * 256 + threadIdx.x;
+    if ((int)bx >= tiles) {
+        const int e = ((int)bx - tiles) * 256 + threadIdx.x;
         if (e >= MG_PART) return;
         const double* pp = a.part + e;
         double sg = 0.0;
@@ -282,7 +289,7 @@ __global__ __launch_bounds__(256) void be_marg_sum_kernel(BeMargArgs a, int tile
         a.psum[e] = sg;
         return;
     }
-    int I, J; mg_tri(blockIdx.x, I, J);
+    int I, J; mg_tri(bx, I, J);
     const int cl = lane & 15, kq = lane >> 4, ca = I * 16 + cl, cb = J * 16 + cl;
     __shared__ double s_acc[4][4][64];
     MTS(6);
@@ -320,6 +327,14 @@ __global__ __launch_bounds__(256) void be_marg_sum_kernel(BeMargArgs a, int tile
     }
     MTS(18);
 }
+__global__ __launch_bounds__(256) void be_marg_sum_kernel(BeMargArgs a, int tiles) { be_marg_sum_body(a, tiles, blockIdx.x); }
+__global__ __launch_bounds__(256) void be_marg_sum_batch_kernel(const BeMargArgs* __restrict__ tab) {
+    const BeMargArgs a = tab[blockIdx.y];
+    if (a.D <= 0 || a.nlm <= 0) return;
+    const int NB = (a.D + 1 + 15) / 16, tiles = NB * (NB + 1) / 2;
+    if ((int)blockIdx.x >= tiles + (MG_PART + 255) / 256) return;
+    be_marg_sum_body(a, tiles, blockIdx.x);
+}
 
 // dense home of entry e of the structured sums (the inverse of the layout be_marg_lm writes): (i, j) with i == D for the right-hand side; false if the block is
 // not part of the system
@@ -342,7 +357,7 @@ __device__ __forceinline__ bool mg_home(const BeMargArgs& a, int e, int& i, int&
 }
 
 #define MG_SUM_CHUNKS 1
-__global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a) {
+__device__ __forceinline__ void be_marg_finish_body(const BeMargArgs& a) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int D = a.D, m = a.m, n = D - m, tid = threadIdx.x;
     double* A = sm;                                       // D x D, then b (D)
@@ -615,6 +630,12 @@ __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a
         if (a.c0_mode != 2) { a.out_scalars[1] = misc[0]; a.out_scalars[2] = misc[1]; }
     }
 }
+__global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a) { be_marg_finish_body(a); }
+__global__ __launch_bounds__(MG_THREADS) void be_marg_finish_batch_kernel(const BeMargArgs* __restrict__ tab) {
+    const BeMargArgs a = tab[blockIdx.x];
+    if (a.D <= 0) return;
+    be_marg_finish_body(a);
+}
 
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void be_gauge_body(const BeGaugeArgs& a) {
@@ -677,11 +698,11 @@ __global__ __launch_bounds__(256) void be_accept_gauge_kernel(BeSolveArgs sa, Be
     be_gauge_body(ga);
 }
 #define REJ_LM 8           // landmarks per workgroup, 32 threads (one per residual block) each
-__global__ __launch_bounds__(256) void be_reject_kernel(BeRejectArgs a) {
+__device__ __forceinline__ void be_reject_body(const BeRejectArgs& a, const int bx) {
     __shared__ m33 RsT[BE_NF]; __shared__ d3 Ps[BE_NF]; __shared__ m33 Rs[BE_NF];
     __shared__ m33 ric0, ricT[2]; __shared__ d3 tic[2];
     __shared__ double s_rp[REJ_LM][32];
-    const int tid = threadIdx.x, g = tid >> 5, t = tid & 31, l = blockIdx.x * REJ_LM + g;
+    const int tid = threadIdx.x, g = tid >> 5, t = tid & 31, l = bx * REJ_LM + g;
     if (tid < a.nframes) {      // Rs = qR(normalized q), Ps: arrays_to_states on the downloaded (gauge-fixed) state
         const double* p = a.st->pose[tid];
         const m33 R = qR(qnormalized(mkq(p[6], p[3], p[4], p[5])));
@@ -708,6 +729,19 @@ __global__ __launch_bounds__(256) void be_reject_kernel(BeRejectArgs a) {
         a.flags[l] = (err / L.count * a.focal > 3) ? 1 : 0;
     }
 }
+__global__ __launch_bounds__(256) void be_reject_kernel(BeRejectArgs a) { be_reject_body(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void be_reject_batch_kernel(const BeRejectArgs* __restrict__ tab) {
+    const BeRejectArgs a = tab[blockIdx.y];
+    if (a.nlm <= 0 || (int)blockIdx.x * REJ_LM >= a.nlm) return;
+    be_reject_body(a, blockIdx.x);
+}
+// last slot of a dv_batch round: the accept / reject decisions of all windows + their gauge fixes + state downloads in ONE launch (blockIdx.x = member)
+__global__ __launch_bounds__(256) void be_accept_gauge_batch_kernel(const BeSolveArgs* __restrict__ stab, const BeGaugeArgs* __restrict__ gtab) {
+    be_accept_body(stab[blockIdx.x]);
+    __syncthreads();
+    const BeGaugeArgs ga = gtab[blockIdx.x];
+    be_gauge_body(ga);
+}
 void be_launch_reject(const BeRejectArgs& a, hipStream_t s) { if (a.nlm > 0) hipLaunchKernelGGL(be_reject_kernel, dim3((a.nlm + REJ_LM - 1) / REJ_LM), dim3(256), 0, s, a); }
 
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(256), 0, s, a); }
@@ -722,6 +756,25 @@ int be_marg_wstride(int D) { return mg_wstride(D); }
 int be_launch_marg_c0(const BeMargArgs& a0, hipStream_t s) {
     BeMargArgs a = a0; a.c0_mode = 2;
     hipLaunchKernelGGL(be_marg_finish_kernel, dim3(1), dim3(MG_THREADS), finish_smem(a.D, a.D - a.m), s, a);
+    return 0;
+}
+// the frame tails of a dv_batch group: accept + gauge + download, outlier test, (caller records its event), then the three marginalization stages
+void be_launch_accept_gauge_batch(const BeSolveArgs* stab, const BeGaugeArgs* gtab, int n, hipStream_t s) { hipLaunchKernelGGL(be_accept_gauge_batch_kernel, dim3(n), dim3(256), 0, s, stab, gtab); }
+void be_launch_reject_batch(const BeRejectArgs* tab, int n, int max_nlm, hipStream_t s) { if (max_nlm > 0) hipLaunchKernelGGL(be_reject_batch_kernel, dim3((max_nlm + REJ_LM - 1) / REJ_LM, n), dim3(256), 0, s, tab); }
+size_t be_marg_finish_smem(int D, int n) { return finish_smem(D, n); }
+int be_launch_marg_batch(const BeMargArgs* tab, int n, int max_nlm, int any_imu, int max_D, size_t max_finish_bytes, hipStream_t s) {
+    static DevOnce once;
+    if (once.run([] {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_finish_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_lm_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) return 1;
+            return 0; })) return -1;
+    if (max_finish_bytes > 156 * 1024 || lm_smem() > 96 * 1024) return -2;
+    if (max_nlm > 0 || any_imu) hipLaunchKernelGGL(be_marg_lm_batch_kernel, dim3(be_marg_chunks(max_nlm) + (any_imu ? 1 : 0), n), dim3(LM_THREADS), lm_smem(), s, tab);
+    if (max_nlm > 0) {
+        const int NB = (max_D + 1 + 15) / 16, tiles = NB * (NB + 1) / 2;
+        hipLaunchKernelGGL(be_marg_sum_batch_kernel, dim3(tiles + (MG_PART + 255) / 256, n), dim3(256), 0, s, tab);
+    }
+    hipLaunchKernelGGL(be_marg_finish_batch_kernel, dim3(n), dim3(MG_THREADS), max_finish_bytes, s, tab);
     return 0;
 }
 int be_launch_marg(const BeMargArgs& a, hipStream_t s) {

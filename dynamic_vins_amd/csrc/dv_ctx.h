@@ -78,6 +78,7 @@ struct BePending {        // a solve that has been enqueued and not yet collecte
     bool want_raw_pose = false;
     bool deferred = false; int first_slots = 0;      // member of a dv_batch: uploaded, the slots wait for dv_batch_enqueue
     bool rej_on = false; BeRejectArgs rej{};      // this frame's device-side outlier test
+    hipEvent_t ev_state_ext = nullptr;   // member of a dv_batch round with shared tail launches: the batch's event replaces BeWork::ev_state for this frame
     bool fuse_accept_gauge = false;      // estimator path outside a dv_batch: the last slot's accept decision rides in the gauge kernel (be_accept_gauge_kernel)
     bool active = false, trivial = false, do_marg = false, fused_present = false, marg_in_flight = false, marg_check_due = false; int scal_slot = 0, check_slot = 0; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
     BeEvalArgs ea; BeSolveArgs sa; int max_iters = 0, nframes = 0, use_imu = 0, nlm = 0; double g_norm = 0, gauge_R0[9], gauge_ypr0[3], gauge_P0[3];
@@ -188,6 +189,7 @@ struct dv_ctx {
     bool timing = false, kernel_timing = false, host_timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
     // back end
     hipStream_t be_stream = nullptr; BeWork be;
+    hipStream_t be_stream_own = nullptr;          // member of a dv_batch: be_stream IS the batch's stream (every BA launch and copy of the member is ordered on it); this is the ctx's own one, restored when it leaves
     ObjPending obj_pend, obj_op_pend;            // estimator's object solve / operator-level dv_obj_solve
     hipStream_t obj_stream = nullptr; DevBuf obj_buf;      // dynamic mode: the object solve runs beside the window solve
     DvDist dist;

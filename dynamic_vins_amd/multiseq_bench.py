@@ -145,6 +145,8 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
     if getattr(args, "batched", False):
         gsz = args.group_size if getattr(args, "group_size", 0) > 0 else (S // 2 if S >= 4 else S)
     runner = Runner(pipes, group_size=gsz, threads=max(1, getattr(args, "runner_threads", 1)))
+    if getattr(args, "no_batch_front", False):
+        runner.set("batch_front", 0)
     runner.run(warm_ba)
     if gsz > 1:
         runner.batch_timing(1)       # HIP events on the batch streams around one steady-state slot per round (dv_batch_timing)
@@ -204,7 +206,7 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
                           "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S, "host_loop": "C++ (dv_runner)",
                           "parallelism": f"{S} sequences per GPU, host loop in C++ on {max(1, getattr(args, 'runner_threads', 1))} thread(s)"
                                          + (f", window solves batched in dv_batch groups of {gsz} (one launch per stage for a group)" if gsz > 1 else ", every sequence on its own streams") + f", x {world} GPU(s); no collective",
-                          "group_size": gsz, "runner_threads": max(1, getattr(args, "runner_threads", 1)),
+                          "group_size": gsz, "runner_threads": max(1, getattr(args, "runner_threads", 1)), "front_end_launches": dict(shared=not getattr(args, "no_batch_front", False) and gsz > 1, **runner.track_info()),
                           "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),
                           "solver_iterations_per_frame": round(iters / max(n_total, 1), 2), "ate_rmse_m_vs_ground_truth_max": round(max(ates), 5)},
                "roofline": roof, "cpu_baseline": None}

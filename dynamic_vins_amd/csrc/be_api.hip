@@ -615,7 +615,7 @@ static int batch_enqueue_impl(dv_batch* B) {
     for (dv_ctx* c : M) {
         const BePending& pd = *c->be.pend;
         if (pd.sa.ldl_wcol == 0 || pd.sa.ldl_wcol != M[0]->be.pend->sa.ldl_wcol || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing) || !pd.fused_present) uniform = false;
-        max_grid = std::max(max_grid, pd.ea.dims.nlm + pd.ea.dims.nimu + 1); max_n = std::max(max_n, pd.sa.dims.nstate);
+        max_grid = std::max(max_grid, be_eval_batch_blocks(pd.ea.dims.nlm, pd.ea.dims.nimu)); max_n = std::max(max_n, pd.sa.dims.nstate);
     }
     if (!uniform || M.size() == 1) {      // mixed kernel variants (or nothing to share): every member's own launches, one member after the other
         for (dv_ctx* c : M) { BePending& pd = *c->be.pend; pd.deferred = false; if (be_enqueue_slots(c, pd, pd.first_slots, true, s) || be_enqueue_tail(c, pd, s)) { dv_set_error(ctx, c->err); return -1; } }

@@ -41,8 +41,11 @@ __device__ __forceinline__ int be_eval_block_of(int bx, int nlm) {
 // ARGS: BeEvalArgs (kernel arguments by value: invariant scalar loads) or the same struct in the constant address space (batched form: the argument table in
 // HBM read through the scalar / invariant path instead of re-loading every field after each store)
 #define DV_CONSTANT __attribute__((address_space(4)))
-template <bool FULL, class ARGS>
-__device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int b) {
+// LPB = landmarks per workgroup: 1 (the single-window launch: 256 threads sum one landmark's packet, lowest latency) or 4 (the batched launch: one WAVE per landmark
+// — only L.count <= 22 lanes of a workgroup do the factor arithmetic and the kernel's 214 VGPRs allow two workgroups per CU, so with one landmark per workgroup a CU
+// worked on 2 landmarks at a time; with four it works on 8 and the frame geometry is formed once for all four).  Same arithmetic, same order per landmark.
+template <bool FULL, int LPB, class ARGS>
+__device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
     if (mode == BE_EVAL_X ? !c.need_eval : !c.pending) return;
@@ -50,29 +53,36 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int b) {
     const int set = mode == BE_EVAL_X ? c.cur : (c.cur ^ 1);
     double* const o_packets = a.packets[set]; double* const o_imu = a.imu_out[set]; double* const o_prior = a.prior_out[set];
     const bool want_cost = mode != BE_EVAL_X;
-    const int lane = threadIdx.x;
     const int nlm = a.dims.nlm, nimu = a.dims.nimu;
-    if (b < nlm && (b < a.lm_lo || b >= a.lm_hi)) return;      // sharded window: another rank's landmark
+    constexpr int TPL = EV_THREADS / LPB;                      // threads per landmark
+    const int ngrp = (nlm + LPB - 1) / LPB;                    // landmark workgroups of this window
+    const int wsel = LPB == 1 ? 0 : (int)threadIdx.x / TPL;    // which of the workgroup's landmarks this thread belongs to
+    const int lane = LPB == 1 ? (int)threadIdx.x : (int)threadIdx.x % TPL;
+    const int b = bg < ngrp ? bg * LPB + wsel : nlm + (bg - ngrp);      // landmark index, or nlm + k for the IMU / prior blocks
     __shared__ FrameGeom fg[BE_NF];
     __shared__ m33 ric[2];
     __shared__ d3 tic[2];
-    __shared__ double Jb[BE_MAX_OBS_FACTORS][28];
-    __shared__ int s_fj[BE_MAX_OBS_FACTORS], s_two[BE_MAX_OBS_FACTORS];
-    __shared__ int s_flist[BE_NF][2];      // per observing frame: the (<= 2: left cam, right cam) two-frame factors whose frame j it is
-    __shared__ double s_cost[BE_MAX_OBS_FACTORS];
+    __shared__ double Jb_all[LPB][BE_MAX_OBS_FACTORS][28];
+    __shared__ int s_fj_all[LPB][BE_MAX_OBS_FACTORS], s_two_all[LPB][BE_MAX_OBS_FACTORS];
+    __shared__ int s_flist_all[LPB][BE_NF][2];      // per observing frame: the (<= 2: left cam, right cam) two-frame factors whose frame j it is
+    __shared__ double s_cost_all[LPB][BE_MAX_OBS_FACTORS];
     __shared__ double s_imu[450 + 450 + 32];
     if (b == 0) ETS(0);
     if (b == nlm) ETS(8);
     if (b == nlm + nimu) ETS(16);
-    if (b < nlm) {
-        // ------------------------------- landmark -------------------------------
-        const BeLm L = a.lm[b];
-        be_frame_geom_dev(st, a.dims.nframes, fg, ric, tic, lane);
-        if (lane >= 64 && lane < 64 + 2 * BE_NF) s_flist[(lane - 64) >> 1][(lane - 64) & 1] = -1;
+    if (bg < ngrp) {
+        // ------------------------------- landmark(s) -------------------------------
+        double (*Jb)[28] = Jb_all[wsel]; int* s_fj = s_fj_all[wsel]; int* s_two = s_two_all[wsel]; int (*s_flist)[2] = s_flist_all[wsel]; double* s_cost = s_cost_all[wsel];
+        const bool valid = b < nlm && !(b < a.lm_lo || b >= a.lm_hi);      // (sharded window: another rank's landmark)
+        if (LPB == 1 && !valid) return;
+        BeLm L{}; if (valid) L = a.lm[b];
+        be_frame_geom_dev(st, a.dims.nframes, fg, ric, tic, (int)threadIdx.x);
+        if (LPB == 1) { if (lane >= 64 && lane < 64 + 2 * BE_NF) s_flist[(lane - 64) >> 1][(lane - 64) & 1] = -1; }
+        else if (lane >= 40 && lane < 40 + 2 * BE_NF) s_flist[(lane - 40) >> 1][(lane - 40) & 1] = -1;
         __syncthreads();
         if (b == 0) ETS(1);
-        const double lambda = st->inv_depth[b];
-        if (lane < L.count) {
+        const double lambda = valid ? st->inv_depth[b] : 1.0;
+        if (valid && lane < L.count) {
             const BeFactor f = a.fac[L.first + lane];
             double r[2], Ji[12], Jj[12], Jl[2];
             proj_factor<FULL, false>(f, fg[f.fi], fg[f.fj], ric[0], tic[0], ric[1], tic[1], lambda, st->td, r, Ji, Jj, Jl, nullptr, nullptr, nullptr);
@@ -90,6 +100,7 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int b) {
             }
         }
         __syncthreads();
+        if (!valid) return;                                        // (no workgroup barrier below)
         if (b == 0) ETS(2);
         double cost = 0;
         for (int f = 0; f < L.count; ++f) cost += s_cost[f];      // fixed order
@@ -102,7 +113,7 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int b) {
         const int wl = lane & 63;                                     // every wave forms the mask by itself: lane f votes for frame f
         const int obs = (int)__ballot(wl < a.dims.nframes && (wl == anchor || s_flist[wl < BE_NF ? wl : 0][0] >= 0 || s_flist[wl < BE_NF ? wl : 0][1] >= 0));
         if (lane == 0 && mode != BE_EVAL_CAND_COST) a.lm_obs[b] = obs;
-        for (int e = lane; e < BE_PK_SIZE; e += EV_THREADS) {
+        for (int e = lane; e < BE_PK_SIZE; e += TPL) {
             if (e >= BE_PK_GP && e < BE_PK_DA + BE_NF * 36) {
                 const int fa = e < BE_PK_DD ? (e - BE_PK_GP) / 6 : (e < BE_PK_DA ? (e - BE_PK_DD) / 36 : (e - BE_PK_DA) / 36);
                 if (!((obs >> fa) & 1)) continue;
@@ -160,6 +171,7 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int b) {
         if (b == 0) ETS(3);
     } else if (b < nlm + nimu) {
         // ------------------------------- IMU factor -------------------------------
+        const int lane = threadIdx.x;                         // (all EV_THREADS threads of the workgroup)
         const int k = b - nlm;
         // the factor record (pre-integrated deltas, bias Jacobians, sqrt-information: 2.4 KB) is staged in LDS by all threads:
         // lane 0's raw evaluation and the whitening loops then read LDS instead of chasing dependent global loads
@@ -201,6 +213,7 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int b) {
         if (b == nlm) ETS(12);
     } else {
         // ------------------------------- prior -------------------------------
+        const int lane = threadIdx.x;
         const BePriorHdr* p = a.prior;
         if (!p->valid) { if (lane == 0) { if (FULL) o_prior[0] = 0.0; if (want_cost) a.cand_cost[b] = 0.0; } return; }
         __shared__ double dx[BE_MAX_PRIOR], Adx[BE_MAX_PRIOR];
@@ -251,15 +264,18 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int b) {
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL, BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm)); }
-// batched form (several independent windows in one launch: blockIdx.y = window, argument table in HBM)
+__global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL, 1, BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm)); }
+// batched form (several independent windows in one launch: blockIdx.y = window, argument table in HBM): four landmarks per workgroup
+#define EV_LPB_BATCH 4
 template <bool FULL>
 __global__ __launch_bounds__(EV_THREADS) void be_eval_batch_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
     const DV_CONSTANT BeEvalArgs& a = *reinterpret_cast<const DV_CONSTANT BeEvalArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));
-    if ((int)blockIdx.x >= a.dims.nlm + a.dims.nimu + 1) return;
-    be_eval_body<FULL, DV_CONSTANT BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm));      // (grid x is a multiple of 8: the XCD of a block is blockIdx.x % 8 as in the single-window launch)
+    const int ngrp = (a.dims.nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH;
+    if ((int)blockIdx.x >= ngrp + a.dims.nimu + 1) return;
+    be_eval_body<FULL, EV_LPB_BATCH, DV_CONSTANT BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, ngrp));      // (grid x is a multiple of 8: the XCD of a block is blockIdx.x % 8 as in the single-window launch)
 }
-void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s) {
+int be_eval_batch_blocks(int nlm, int nimu) { return (nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH + nimu + 1; }
+void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s) {      // max_grid = max over the windows of be_eval_batch_blocks
     if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_batch_kernel<true>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
     else hipLaunchKernelGGL(be_eval_batch_kernel<false>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
 }

@@ -205,6 +205,7 @@ void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, in
 void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s);
 int  be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s, int ldl_mode);      // ldl_mode: the members' common ldl_wcol (1 wave-column, 2 MF16)
 void be_launch_accept_batch(const BeSolveArgs* tab_dev, int n_win, hipStream_t s);
+int be_eval_batch_blocks(int nlm, int nimu);      // workgroups of one window in the batched evaluation launch
 void be_launch_accept_gauge_batch(const BeSolveArgs* stab, const BeGaugeArgs* gtab, int n, hipStream_t s);
 void be_launch_reject_batch(const BeRejectArgs* tab, int n, int max_nlm, hipStream_t s);
 size_t be_marg_finish_smem(int D, int n);

@@ -121,6 +121,11 @@ def main():
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import numpy as np
+    if args.mode == "dynamic" or (args.sequences <= 1 and not args.no_dynamic_line):
+        # dynamic mode keeps six streams busy per context (background tracker, object tracker, extra points, window solve, object solve + the renderer's): with the
+        # runtime's default of 4 hardware queues the extra-point chain of frame k+1 shared a queue with the window solve of frame k and waited behind it (measured:
+        # 797 -> 553 frames/s).  INTEGRATION.md lists the variable among the deployment settings.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     if args.sequences > 1:
         # every sequence owns four HIP streams; the runtime maps streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and two streams that share a queue
         # serialise — with the default, two sequences run at half speed each (measured).  Must be set before the runtime initialises.
@@ -187,7 +192,7 @@ def main():
             dc = dyn["config"]
             out["config"]["dynamic_line"] = {"value": dyn["value"], "unit": "frames/s", "ms_per_step": dyn["ms_per_step"], "block_values": dc["block_values"],
                                              "ate_rmse_m_vs_oracle": dc["ate_rmse_m_vs_oracle"], "ate_rmse_m_vs_ground_truth": dc["ate_rmse_m_vs_ground_truth"],
-                                             "workload": dc["workload"], "dynamic": dc.get("dynamic"), "solver_iterations_per_frame": dc["solver_iterations_per_frame"],
+                                             "workload": dc["workload"], "dynamic": dc.get("dynamic"), "host_loop": dc.get("host_loop"), "solver_iterations_per_frame": dc["solver_iterations_per_frame"],
                                              "cpu_baseline_value": None if dyn["cpu_baseline"] is None else dyn["cpu_baseline"]["value"], "target_frames_per_s": 500}
     if rank == 0:
         print(json.dumps(out))
@@ -220,7 +225,8 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
 
     def make_pipe():
         if args.mode == "dynamic":
-            return DynamicPipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"], mask_morphology_size=args.erode)
+            return DynamicPipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"], mask_morphology_size=args.erode,
+                                   extra_from_disparity=os.environ.get("BENCH_DYN_PASSTHROUGH", "0") != "1")      # (debug A/B: 1 = the detections' own points are handed through, no extra-point kernels)
         return Pipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"], host_frames=args.host_frames,
                         ba_stride=stride)
 
@@ -251,11 +257,15 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         st, poses, iters_all, _fr = runner.get(0)
         pipe.poses, pipe.pose_times = [q for q in poses[:, 1:8]], [float(t) for t in poses[:, 0]]
         pipe.est.state, pipe.rows = st, np.zeros(runner.last_rows)
+        if args.mode == "dynamic":
+            ds = runner.dynamic_stats(0)
+            pipe.stat.update(frames=int(_fr), **ds)
+            pipe.ifeats = np.zeros(int(round(ds["object_features"] / max(int(_fr), 1))))
         runner.close()
         return pipe, times, iters_all - it0
 
     def run(kernel_timing, collective=True, blocks=2):       # collective=False: rank-0-only pass, no barriers
-        if args.host_loop == "cpp" and not kernel_timing and args.mode == "raw" and not args.host_frames:
+        if args.host_loop == "cpp" and not kernel_timing and not args.host_frames:      # raw and dynamic mode both run on the library's C++ loop (dv_runner / dv_runner_set_dynamic)
             return run_cpp(collective, blocks)
         pipe = make_pipe()
         for key in filter(None, args.debug_set.split(",")):
@@ -443,7 +453,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 "block_values": [round(dv_dist.whole_job_rate(args.steps, world, t), 2) for t in times],
                 "block_step_ms": frame_ms[: len(times)],
                 "warmup_requested": args.warmup, "git_head": git_head(),
-                "host_loop": ("C++ (dv_runner)" if (args.host_loop == "cpp" and args.mode == "raw" and not args.host_frames) else "Python (pipeline.py)"),
+                "host_loop": ("C++ (dv_runner)" if (args.host_loop == "cpp" and not args.host_frames) else "Python (pipeline.py)"),
                 "warmup_note": "at least 12 untimed BA frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"}
         if dyn_info:
             conf["dynamic"] = dyn_info

@@ -488,6 +488,11 @@ class dv_seq_input(C.Structure):
                 ("imu_t", C.c_void_p), ("imu_acc", C.c_void_p), ("imu_gyr", C.c_void_p), ("n_imu", C.c_int32), ("reserved2", C.c_int32)]
 
 
+class dv_seq_dynamic(C.Structure):
+    _fields_ = [("inv_mask", C.c_void_p), ("mask_mem", C.c_int32), ("mode", C.c_int32), ("dets", C.c_void_p), ("n_dets", C.c_void_p), ("boxes3d", C.c_void_p), ("n_boxes3d", C.c_void_p),
+                ("disp", C.c_void_p), ("disp_mem", C.c_int32), ("disp_stride", C.c_int32), ("baseline", C.c_double)]
+
+
 class Runner:
     """dv_runner: the per-frame host loop of pipeline.Pipeline in C++ inside the library, for one or many sequences (include/dvins.h).  `pipes` are Pipeline
     objects (each owns its Context + Estimator and a SyntheticSequence whose frames are resident in HBM); the runner takes over driving them."""
@@ -516,6 +521,48 @@ class Runner:
         self.h = self.lib.dv_runner_create(ctxs, C.cast(arr, C.c_void_p), n, int(group_size), int(threads))
         if not self.h:
             raise DvinsError((self.lib.dv_last_error(None) or b"dv_runner_create failed").decode())
+        for i, p in enumerate(pipes):
+            if getattr(p, "mode", 0) != 0:          # a DynamicPipeline: hand the per-frame perception outputs of its sequence to the runner's dynamic loop
+                self._set_dynamic(i, p, first_frame)
+
+    def _set_dynamic(self, i, p, first_frame):
+        from .dynsim import BOX3D_DTYPE
+        from .frontend import DV_MEM_DEVICE, dv_inst_det
+        q = p.seq
+        nf = len(q.frames) - first_frame
+        masks = (C.c_void_p * nf)(*[m.data_ptr() for m in q.inv_mask_dev[first_frame:]])
+        det_ptrs, n_dets, box_ptrs, n_boxes = (C.c_void_p * nf)(), np.zeros(nf, np.int32), (C.c_void_p * nf)(), np.zeros(nf, np.int32)
+        for k in range(nf):
+            dets = q.dets[first_frame + k]
+            arr = (dv_inst_det * max(len(dets), 1))()
+            for j, d in enumerate(dets):
+                m = np.ascontiguousarray(d["mask"], np.uint8)
+                pts = None if d.get("points") is None else np.ascontiguousarray(d["points"], np.float64)
+                x, y, w, h = [int(v) for v in d["rect"]]
+                arr[j].track_id, arr[j].class_id, arr[j].x, arr[j].y, arr[j].w, arr[j].h = int(d["track_id"]), int(d.get("class_id", 0)), x, y, w, h
+                arr[j].mask = m.ctypes.data
+                arr[j].points = pts.ctypes.data if pts is not None and len(pts) else None
+                arr[j].n_points = 0 if pts is None else len(pts)
+                self._keep += [m, pts]
+            det_ptrs[k] = C.cast(arr, C.c_void_p); n_dets[k] = len(dets)
+            b3 = np.ascontiguousarray(q.boxes3d[first_frame + k], BOX3D_DTYPE) if p.use_det3d else np.zeros(0, BOX3D_DTYPE)
+            box_ptrs[k] = b3.ctypes.data if len(b3) else None; n_boxes[k] = len(b3)
+            self._keep += [arr, b3]
+        use_disp = getattr(p, "extra_from_disparity", False)
+        disps = (C.c_void_p * nf)(*[d.data_ptr() for d in q.disp_dev[first_frame:]]) if use_disp else None
+        dyn = dv_seq_dynamic()
+        dyn.inv_mask, dyn.mask_mem, dyn.mode = C.cast(masks, C.c_void_p), DV_MEM_DEVICE, int(p.mode)
+        dyn.dets, dyn.n_dets = C.cast(det_ptrs, C.c_void_p), n_dets.ctypes.data
+        dyn.boxes3d, dyn.n_boxes3d = C.cast(box_ptrs, C.c_void_p), n_boxes.ctypes.data
+        dyn.disp, dyn.disp_mem, dyn.disp_stride, dyn.baseline = (C.cast(disps, C.c_void_p) if use_disp else None), DV_MEM_DEVICE, 0, float(q.baseline)
+        self._keep += [masks, det_ptrs, n_dets, box_ptrs, n_boxes, disps, dyn]
+        if self.lib.dv_runner_set_dynamic(self.h, i, C.byref(dyn)) != 0:
+            raise DvinsError(self.lib.dv_runner_error(self.h).decode())
+
+    def dynamic_stats(self, i):
+        a, b, c, d = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0), C.c_int(0)
+        self.lib.dv_runner_dynamic_stats(self.h, i, C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return dict(object_detections=a.value, object_features=b.value, frames_with_objects=c.value, min_detections=d.value)
 
     def run(self, rounds):
         """rounds frames of every sequence -> wall seconds of the call (all streams drained)"""

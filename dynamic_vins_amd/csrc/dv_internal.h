@@ -106,6 +106,8 @@ void dv_launch_lift(const dv_cam& cam, const float2* in, int n, double off_x, do
 // the extra-point pipeline of dynamic mode (extra_points.hip): one job = one visible object
 #define DV_XP_CAP 3200       // points per object after sampling: step = max(sqrt(0.8 rows cols / 1000), 2) bounds the grid by ~3130 nodes for images up to 1280 wide
 struct DvExtraJob { const uint8_t* mask; int mask_pitch, cols, rows, box_x, box_y, step; double* out; int* n_out; };      // out: 3 * DV_XP_CAP doubles, n_out: count (device or pinned host memory)
-struct DvExtraArgs { const float* disp; int disp_pitch /* elements */, disp_w, disp_h; float fx0, fy0, cx0, cy0, baseline; int* err_flag; int stage /* 1: stop after the sampling */; };
+struct DvExtraArgs { const float* disp; int disp_pitch /* elements */, disp_w, disp_h; float fx0, fy0, cx0, cy0, baseline; int* err_flag; int stage /* 1: stop after the sampling */; uint8_t* pool /* dv_extra_points_scratch_bytes(n_jobs) of device scratch */; };
+#define DV_XP_SCRATCH_BYTES ((size_t)DV_XP_CAP * (16 + 16 + 1 + 8) + 256 + 1024)      // per object: two point sets, keep flags, two label sets, control words
+size_t dv_extra_points_scratch_bytes(int n_jobs);
 int dv_launch_extra_points(const DvExtraJob* jobs_dev, int n_jobs, const DvExtraArgs& a, hipStream_t s);
 int dv_extra_points_step(int rows, int cols);

@@ -88,10 +88,10 @@ struct dv_inst_tracker {
     std::vector<unsigned> out_order;                            // ids written this frame, in output order
     // extra points from the frame's disparity map (dv_inst_set_disparity; extra_points.hip): the reference's second thread = a side stream
     const float* disp_user = nullptr; int disp_stride = 0, disp_mem = 0; double disp_baseline = 0; bool disp_next = false, xp_frame = false, xp_inflight = false;
-    DevBuf disp_buf; hipStream_t xstream = nullptr; hipEvent_t ev_xin = nullptr, ev_xdone = nullptr;
+    DevBuf disp_buf, xp_pool; hipStream_t xstream = nullptr; hipEvent_t ev_xin = nullptr, ev_xdone = nullptr;
     void* xp_pinned = nullptr; size_t xp_cap_slots = 0;          // per output slot: count (64 bytes) + 3 * DV_XP_CAP doubles, written by the kernel straight into pinned memory
     ~dv_inst_tracker() {
-        disp_buf.release();
+        disp_buf.release(); xp_pool.release();
         if (xstream) { (void)hipStreamSynchronize(xstream); (void)hipStreamDestroy(xstream); }
         if (ev_xin) (void)hipEventDestroy(ev_xin);
         if (ev_xdone) (void)hipEventDestroy(ev_xdone);
@@ -373,7 +373,8 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
                     DV_CHECK(hipMemcpy2DAsync(T.disp_buf.p, (size_t)W * 4, T.disp_user, (size_t)T.disp_stride, (size_t)W * 4, H, hipMemcpyHostToDevice, T.xstream));
                     dmap = (const float*)T.disp_buf.p; dpitch = W;
                 }
-                DvExtraArgs xa{ dmap, dpitch, W, H, (float)ctx->cfg.cam0.fx, (float)ctx->cfg.cam0.fy, (float)ctx->cfg.cam0.cx, (float)ctx->cfg.cam0.cy, (float)T.disp_baseline, T.err_flag, 0 };
+                if (T.xp_pool.bytes < dv_extra_points_scratch_bytes(n_xp)) { DV_CHECK(hipStreamSynchronize(T.xstream)); DV_CHECK(T.xp_pool.ensure(dv_extra_points_scratch_bytes(std::max(8, 2 * n_xp)))); }
+                DvExtraArgs xa{ dmap, dpitch, W, H, (float)ctx->cfg.cam0.fx, (float)ctx->cfg.cam0.fy, (float)ctx->cfg.cam0.cx, (float)ctx->cfg.cam0.cy, (float)T.disp_baseline, T.err_flag, 0, (uint8_t*)T.xp_pool.p };
                 StageScope scx(ctx, "inst_extra_points", T.xstream);
                 if (dv_launch_extra_points((const DvExtraJob*)((const uint8_t*)T.arena.p + xp_off), n_xp, xa, T.xstream)) DV_FAIL("extra_points: cannot set dynamic LDS size");
                 T.xp_inflight = true;
@@ -482,14 +483,15 @@ int dv_extra_points(dv_ctx* ctx, const uint8_t* mask, int x, int y, int w, int h
     DvExtraJob* jd = (DvExtraJob*)(ob + out_bytes + 128);
     DV_CHECK(hipMemcpyAsync(jd, &job, sizeof(job), hipMemcpyHostToDevice, s));
     DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, s));
-    DvExtraArgs xa{ dmap, dpitch, W, H, (float)ctx->cfg.cam0.fx, (float)ctx->cfg.cam0.fy, (float)ctx->cfg.cam0.cx, (float)ctx->cfg.cam0.cy, (float)baseline, ctx->err_flag, stage };
+    DV_CHECK(ctx->s3.ensure(dv_extra_points_scratch_bytes(1)));
+    DvExtraArgs xa{ dmap, dpitch, W, H, (float)ctx->cfg.cam0.fx, (float)ctx->cfg.cam0.fy, (float)ctx->cfg.cam0.cx, (float)ctx->cfg.cam0.cy, (float)baseline, ctx->err_flag, stage, (uint8_t*)ctx->s3.p };
     if (dv_launch_extra_points(jd, 1, xa, s)) DV_FAIL("extra_points: cannot set dynamic LDS size");
     DV_CHECK(hipGetLastError());
     int n = 0, ef = 0;
     DV_CHECK(hipMemcpyAsync(&n, ob, 4, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipMemcpyAsync(&ef, ctx->err_flag, 4, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
-    if (ef) { DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, s)); DV_FAIL("dv_extra_points: more than DV_XP_CAP sampled points (device error flags=" + std::to_string(ef) + ")"); }
+    if (ef) { DV_CHECK(hipMemsetAsync(ctx->err_flag, 0, 4, s)); DV_FAIL("dv_extra_points: more than DV_XP_CAP sampled points (8) or clustering not converged (16) (device error flags=" + std::to_string(ef) + ")"); }
     if (n > cap_out) DV_FAIL("dv_extra_points: output buffer too small");
     if (n > 0) DV_CHECK(hipMemcpy(out_xyz, ob + 64, (size_t)n * 24, hipMemcpyDeviceToHost));
     *n_out = n;

@@ -29,6 +29,12 @@ struct RSeq {
     std::vector<double> frames9;        // [t, px py pz qx qy qz qw, nonlinear] of EVERY frame handed to the back end (what SaveBodyTrajectory writes)
     long long iterations = 0, frames = 0;
     std::string err;
+    // dynamic mode (dv_runner_set_dynamic): the frame's object hand-over, double-buffered — [cur] belongs to the frame in the back end, [cur ^ 1] receives the next
+    // frame's while that one's window solve is in flight
+    bool dynamic = false; dv_seq_dynamic dyn{};
+    struct DynBuf { std::vector<dv_feat> rows; int n_rows = 0; std::vector<dv_inst_obs> insts; int n_insts = 0; std::vector<dv_feat> ifeats; int n_ifeats = 0; std::vector<double> pts; int n_pts = 0; bool valid = false; };
+    DynBuf db[2]; int cur = 0;
+    long long detections = 0, object_features = 0, frames_with_objects = 0; int min_detections = 1 << 30;
 };
 }
 struct dv_runner {
@@ -60,9 +66,52 @@ int seq_feed_imu(dv_runner* R, RSeq& s, double t) {
     }
     return 0;
 }
+// ---- dynamic mode: TrackSemanticImage + InstsTrack of frame k (one enqueue), their collect, and the three-phase back end ----
+int dyn_enqueue(dv_runner* R, RSeq& s, int k) {
+    const dv_seq_dynamic& d = s.dyn;
+    const int mode = d.mode ? d.mode : DV_MODE_SEMANTIC;
+    // (frames and mask share `mem` in dv_track_stereo_enqueue: a device-resident sequence keeps both in HBM)
+    if (dv_track_stereo_enqueue(s.ctx, s.in.left[k], s.in.right[k], s.w, s.h, s.stride, s.in.times[k], d.inv_mask ? d.inv_mask[k] : nullptr, mode, s.in.mem)) return fail(R, s, "dv_track_stereo_enqueue");
+    if (d.disp && d.disp[k] && dv_inst_set_disparity(s.ctx, d.disp[k], d.disp_stride, d.disp_mem, d.baseline)) return fail(R, s, "dv_inst_set_disparity");
+    if (dv_inst_track_enqueue(s.ctx, s.in.times[k], d.dets ? d.dets[k] : nullptr, d.n_dets ? d.n_dets[k] : 0, d.boxes3d ? d.boxes3d[k] : nullptr, d.n_boxes3d ? d.n_boxes3d[k] : 0)) return fail(R, s, "dv_inst_track_enqueue");
+    s.enqueued = true;
+    return 0;
+}
+int dyn_collect(dv_runner* R, RSeq& s, RSeq::DynBuf& b) {
+    if (dv_track_stereo_collect(s.ctx, b.rows.data(), &b.n_rows)) return fail(R, s, "dv_track_stereo_collect");
+    if (dv_inst_track_collect(s.ctx, b.insts.data(), (int)b.insts.size(), &b.n_insts, b.ifeats.data(), (int)b.ifeats.size(), &b.n_ifeats, b.pts.data(), (int)(b.pts.size() / 3), &b.n_pts)) return fail(R, s, "dv_inst_track_collect");
+    b.valid = true; s.enqueued = false;
+    return 0;
+}
+int dyn_begin(dv_runner* R, RSeq& s) {
+    const int k = s.next;
+    if (k >= s.in.n_frames) { s.err = "sequence exhausted"; set_err(R, s.err); return -1; }
+    RSeq::DynBuf& b = s.db[s.cur];
+    if (!b.valid) { if (!s.enqueued && dyn_enqueue(R, s, k)) return -1; if (dyn_collect(R, s, b)) return -1; }
+    const double t = s.in.times[k];
+    s.n_rows = b.n_rows;
+    if (seq_feed_imu(R, s, t)) return -1;
+    // the window solve goes to the GPU with the background rows alone; then the next frame's tracking (thread T2 of the reference, independent of T3); then the object
+    // branch of ProcessImage beside the window solve; then the next frame's rows are collected while the solve is still in flight
+    const int rc = dv_est_process_dynamic_begin_ego(s.ctx, b.rows.data(), b.n_rows, t);
+    if (rc < 0) return fail(R, s, "dv_est_process_dynamic_begin_ego");
+    if (rc > 0) { s.err = "IMU stream does not cover the frame"; set_err(R, s.err); return -1; }
+    if (k + 1 < s.in.n_frames && dyn_enqueue(R, s, k + 1)) return -1;
+    if (dv_est_process_dynamic_attach(s.ctx, b.n_insts ? b.insts.data() : nullptr, b.n_insts, b.n_ifeats ? b.ifeats.data() : nullptr, b.n_pts ? b.pts.data() : nullptr)) return fail(R, s, "dv_est_process_dynamic_attach");
+    s.detections += b.n_insts; s.object_features += b.n_ifeats; s.frames_with_objects += b.n_insts > 0; s.min_detections = std::min(s.min_detections, b.n_insts);
+    if (k + 1 < s.in.n_frames) {
+        if (seq_feed_imu(R, s, s.in.times[k + 1])) return -1;
+        if (dyn_collect(R, s, s.db[s.cur ^ 1])) return -1;
+    }
+    b.valid = false; s.cur ^= 1;
+    s.pending = true; s.pending_t = t;
+    return 0;
+}
+
 // first half of a step: everything up to and including the enqueue of frame k's window solve and of frame k+1's tracking.  own_front = false: the caller enqueues
 // the tracking of the group's frames itself, in shared launches (group_round), and feeds the IMU samples of frame k+1 afterwards.
 int seq_begin(dv_runner* R, RSeq& s, bool own_front = true) {
+    if (s.dynamic) return dyn_begin(R, s);
     const int k = s.next;
     if (k >= s.in.n_frames) { s.err = "sequence exhausted"; set_err(R, s.err); return -1; }
     if (!s.enqueued) { if (!own_front) { s.err = "internal: frame not enqueued"; set_err(R, s.err); return -1; } if (seq_enqueue(R, s, k)) return -1; }
@@ -234,6 +283,25 @@ int dv_runner_batch_timing(dv_runner* R, int on, double* out3, long long* rounds
     return 0;
 }
 
+int dv_runner_set_dynamic(dv_runner* R, int seq, const dv_seq_dynamic* dyn) {
+    if (!R || seq < 0 || seq >= (int)R->seqs.size() || !dyn) return -1;
+    RSeq& s = R->seqs[seq];
+    if (s.next != 0 || s.enqueued || s.pending) { R->err = "dv_runner_set_dynamic: the sequence has already started"; return -1; }
+    for (auto& g : R->groups) if (g.batch) for (int i : g.members) if (i == seq) { R->err = "dv_runner_set_dynamic: a dynamic sequence cannot be a member of a dv_batch group (create the runner with group_size 0 for it)"; return -1; }
+    if (!s.ctx->inst) { R->err = "dv_runner_set_dynamic: call dv_inst_config on the sequence's context first"; return -1; }
+    s.dynamic = true; s.dyn = *dyn;
+    for (auto& b : s.db) { b.rows.resize(DV_MAX_FEATS); b.insts.resize(64); b.ifeats.resize(64 * 256); b.pts.resize((size_t)3 * 65536); b.valid = false; }
+    return 0;
+}
+int dv_runner_dynamic_stats(dv_runner* R, int seq, long long* detections, long long* object_features, long long* frames_with_objects, int* min_detections) {
+    if (!R || seq < 0 || seq >= (int)R->seqs.size()) return -1;
+    const RSeq& s = R->seqs[seq];
+    if (detections) *detections = s.detections;
+    if (object_features) *object_features = s.object_features;
+    if (frames_with_objects) *frames_with_objects = s.frames_with_objects;
+    if (min_detections) *min_detections = s.frames ? s.min_detections : 0;
+    return 0;
+}
 int dv_runner_set(dv_runner* R, const char* key, int value) {
     if (!R || !key) return -1;
     if (std::strcmp(key, "batch_front") == 0) { R->batch_front = value != 0; return 0; }

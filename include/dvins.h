@@ -435,7 +435,23 @@ typedef struct dv_seq_input {
     const double* times; int32_t n_frames, mem /* DV_MEM_HOST / DV_MEM_DEVICE */, stride /* bytes per row, 0 = width */, ba_stride /* 2: only every 2nd tracked frame goes to the back end (system/main.cpp:300-307); 0 / 1: every frame */;
     const double* imu_t; const double* imu_acc; const double* imu_gyr; int32_t n_imu, reserved2;      /* [n_imu], [n_imu][3], [n_imu][3]; n_imu 0 for vision-only */
 } dv_seq_input;
+/* dynamic mode of a sequence (cfg::slam == kDynamic; the estimator must have been created with dv_est_config::dynamic = 1 and the tracker configured with
+ * dv_inst_config): per frame what thread T1 / the perception front end of the reference attaches to the SemanticImage (system/main.cpp:59-171) — the inverse merged
+ * instance mask, the detections with their track ids and ROI masks, the 3-D detections (use_det3d) and the disparity map the extra points are sampled from.  The runner
+ * then drives the reference's dynamic loop per frame: TrackSemanticImage + InstsTrack (both enqueued together, thread T2), collect, dv_est_process_dynamic_begin_ego,
+ * the NEXT frame's tracking, dv_est_process_dynamic_attach (the object branch beside the window solve), dv_est_process_end (estimator.cpp:1562-1676).
+ * All arrays have n_frames entries and must outlive the runner; masks of detections are host memory, inv_mask / disp follow their *_mem. */
+typedef struct dv_inst_det dv_inst_det; typedef struct dv_box3d dv_box3d;      /* defined with the dynamic-mode entries below */
+typedef struct dv_seq_dynamic {
+    const uint8_t* const* inv_mask; int32_t mask_mem /* DV_MEM_* */, mode /* DV_MODE_SEMANTIC (default when 0 is passed is RAW: set it) or DV_MODE_NAIVE */;
+    const dv_inst_det* const* dets; const int32_t* n_dets;
+    const dv_box3d* const* boxes3d; const int32_t* n_boxes3d;      /* may be NULL (no 3-D detector) */
+    const float* const* disp; int32_t disp_mem, disp_stride /* bytes, 0 = 4 * width */; double baseline;      /* disp may be NULL: dv_inst_det::points are handed through */
+} dv_seq_dynamic;
 typedef struct dv_runner dv_runner;
+int dv_runner_set_dynamic(dv_runner* runner, int seq, const dv_seq_dynamic* dyn);      /* before the first dv_runner_run; the sequence then runs outside dv_batch groups */
+/* what the object branch of a dynamic sequence was fed so far: detections, object feature rows, frames with at least one object, fewest detections in a frame */
+int dv_runner_dynamic_stats(dv_runner* runner, int seq, long long* detections, long long* object_features, long long* frames_with_objects, int* min_detections);
 dv_runner* dv_runner_create(dv_ctx* const* ctxs, const dv_seq_input* seqs, int n_seq, int group_size, int threads);      /* group_size <= 1: no batching */
 void dv_runner_destroy(dv_runner* runner);
 int dv_runner_run(dv_runner* runner, int n_rounds, double* wall_seconds_or_null);

@@ -10,7 +10,7 @@ for r in csv.DictReader(open(f)):
     nm = r["Kernel_Name"]
     if "at::" in nm or "elementwise" in nm or "Cijk" in nm or "reduce_kernel<" in nm or "rocclr" in nm:
         continue
-    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm.split("(")[0].replace("void ", "")[:44], r.get("Queue_Id", "?"), r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?"))))
+    rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), nm.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")[:44], r.get("Queue_Id", "?"), r.get("Grid_Size", r.get("Grid_Size_X", "?")), r.get("Workgroup_Size", r.get("Workgroup_Size_X", "?"))))
 rows.sort()
 agg = collections.defaultdict(list)
 for s, e, n, q, g, wg in rows:

@@ -86,3 +86,32 @@ def test_runner_shared_front_end_launches_leave_the_same_bits():
         ra.close(); rb.close()
         for p in a + b:
             p.ctx.close()
+
+
+def test_runner_dynamic_mode_equals_the_python_dynamic_pipeline():
+    """dv_runner_set_dynamic: the reference's dynamic loop per frame in C++ (TrackSemanticImage + InstsTrack enqueued together, collect, the three-phase back end with
+    the object branch beside the window solve) must leave EXACTLY what pipeline.DynamicPipeline leaves: ego window states, trajectory, object states, and what the
+    object branch was fed — objects in every frame, extra points from the disparity map on the device"""
+    from dynamic_vins_amd.backend import Runner
+    from dynamic_vins_amd.pipeline import DynamicPipeline, DynamicSequence
+    w, h, frames = 752, 480, 30
+    cam = sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    seq = DynamicSequence(w, h, cam, frames, rate=20.0, boxes=("escort", 4))
+    kw = dict(max_cnt=150, min_dist=20, max_iters=8, use_det3d=1, mask_morphology_size=5)
+    a, b = DynamicPipeline(seq, **kw), DynamicPipeline(seq, **kw)
+    runner = Runner([a], group_size=0, threads=1)
+    runner.run(frames - 1)
+    for _ in range(frames - 1):
+        b.step()
+    st, poses, iters, fr = runner.get(0)
+    assert fr == frames - 1 and st.frame == b.last_state.frame and st.nonlinear == b.last_state.nonlinear
+    assert np.array_equal(np.ctypeslib.as_array(st.window), b.est.window())
+    want = np.array(b.poses)
+    assert len(poses) == len(want) >= frames - 14 and np.array_equal(poses[:, 1:], want)
+    Ia, Sa = a.est.instances(); Ib, Sb = b.est.instances()
+    assert len(Ia) == len(Ib) >= 3 and Ia.tobytes() == Ib.tobytes() and np.array_equal(Sa, Sb)
+    stats = runner.dynamic_stats(0)
+    for key in ("object_detections", "object_features", "frames_with_objects", "min_detections"):
+        assert stats[key] == b.stat[key], (key, stats, b.stat)
+    assert stats["min_detections"] >= 3 and stats["object_features"] > 20 * frames
+    runner.close(); a.ctx.close(); b.ctx.close()

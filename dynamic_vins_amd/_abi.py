@@ -54,6 +54,9 @@ SIGNATURES = {
                         _f32p, _u8p, C.c_int]),
     "dv_track_by_lk": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_float,
                                  _f32p, _u8p, C.c_int]),
+    "dv_lk_cuda": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, _u8p, C.c_int]),
+    "dv_track_by_lk_gpu": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int, C.c_int, _f32p, _u8p, C.c_int]),
+    "dv_pyr_down_cuda": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "dv_gftt": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f32p,
                           C.POINTER(C.c_int), C.c_int]),
     "dv_min_eigen": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),

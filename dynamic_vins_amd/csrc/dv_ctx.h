@@ -29,16 +29,18 @@ struct DevBuf {
 static inline int align_up(int v, int a) { return (v + a - 1) / a * a; }
 
 struct PyrSet {
-    DvPyr pyr{}; DevBuf buf; int w = 0, h = 0, ml = -1;
-    hipError_t alloc(int w_, int h_, int max_level) {
-        if (w == w_ && h == h_ && ml == max_level && pyr.levels > 0) return hipSuccess;
-        w = w_; h = h_; ml = max_level;
+    DvPyr pyr{}; DevBuf buf; int w = 0, h = 0, ml = -1; bool all = false;
+    // all_levels: every one of the max_level + 1 levels (cv::cuda::SparsePyrLKOpticalFlow builds them unconditionally); default: buildOpticalFlowPyramid's stop rule
+    hipError_t alloc(int w_, int h_, int max_level, bool all_levels = false) {
+        if (w == w_ && h == h_ && ml == max_level && all == all_levels && pyr.levels > 0) return hipSuccess;
+        w = w_; h = h_; ml = max_level; all = all_levels;
         int lw[DV_MAX_LEVELS], lh[DV_MAX_LEVELS], n = 0;
         int cw = w, ch = h;
         for (int l = 0; l <= max_level && l < DV_MAX_LEVELS; ++l) {
             lw[n] = cw; lh[n] = ch; ++n;
             int nw = (cw + 1) / 2, nh = (ch + 1) / 2;
-            if (nw <= DV_LK_WIN || nh <= DV_LK_WIN) break;      // buildOpticalFlowPyramid stop rule
+            if (!all_levels && (nw <= DV_LK_WIN || nh <= DV_LK_WIN)) break;      // buildOpticalFlowPyramid stop rule
+            if (nw < 1 || nh < 1) break;
             cw = nw; ch = nh;
         }
         size_t total = 0, off[DV_MAX_LEVELS];
@@ -173,6 +175,9 @@ struct dv_ctx {
     std::string err;
     hipStream_t stream = nullptr;
     PyrSet left[2], right; int cur = 0; bool have_prev = false; double prev_time = 0.0;
+    // the GPU tracker rule's own pyramids (lk_cuda.hip: cuda::pyrDown rounds half to even): levels 1.. of the left frames / the right frame; level 0 aliases the frame
+    // in left[] / right.  Built only in the modes that use that rule (naive: temporal + right image; semantic: right image)
+    PyrSet leftc[2], rightc; bool leftc_valid[2] = { false, false };
     DevBuf state_block; DvTrackState tr{};
     DevBuf cand_buf; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
     DevBuf hw_buf; int hw_radius = -1;

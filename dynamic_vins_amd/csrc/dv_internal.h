@@ -64,7 +64,7 @@ void dv_set_error(dv_ctx* ctx, const std::string& msg);
 void dv_launch_pyr_apron(const DvPyr& a, const DvPyr* b, hipStream_t s);      // fills the reflect-101 apron of every level (after the levels themselves)
 void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int sh, int spitch,
                          uint8_t* dst0, uint8_t* dst1, int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch,
-                         hipStream_t s);
+                         hipStream_t s, int rn_even = 0);      // rn_even: cuda::pyrDown's saturate_cast<uchar>(float) (round half to even) instead of cv::pyrDown's (sum + 128) >> 8
 void dv_launch_bgr2gray(const uint8_t* src0, const uint8_t* src1, int w, int h, int spitch, uint8_t* dst0, uint8_t* dst1, int dpitch, hipStream_t s);
 void dv_launch_remap(const uint8_t* src0, const uint8_t* src1, int w, int h, int spitch, int cn, int to_gray, const int16_t* m1_0, const uint16_t* m2_0,
                      const int16_t* m1_1, const uint16_t* m2_1, uint8_t* dst0, uint8_t* dst1, int dpitch, hipStream_t s);
@@ -92,6 +92,9 @@ void dv_launch_lk_track_offset(const DvPyr& A, const DvPyr& B, const float2* pts
                                float dist_thresh, float add_x, float add_y, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_finalize_offset(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, double off_x, double off_y,
                                dv_feat* out, int* n_out, hipStream_t s);
+// the reference's GPU tracker rule (lk_cuda.hip): A / B are pyramids built with cuda::pyrDown's rounding (dv_launch_pyr_down2(..., rn_even = 1)); level 0 is the frame
+void dv_launch_lk_cuda_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back, float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s);
+void dv_launch_lk_cuda_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters, int use_initial, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_gftt_tile(const GfttTileArgs& a, hipStream_t s);
 int  dv_launch_gftt_select(const GfttSelectArgs& a, hipStream_t s);
 void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_pitch, int sort_by_cnt, int* n_cand,

@@ -121,6 +121,19 @@ static int build_pyramids(dv_ctx* ctx, PyrSet& P0, PyrSet* P1, const uint8_t* im
     return 0;
 }
 
+// the pyramid cv::cuda::SparsePyrLKOpticalFlow builds (cuda::pyrDown: round half to even) on top of an existing level 0 (a0 / b0: level 0 of the regular pyramids)
+static int build_cuda_pyramids(dv_ctx* ctx, PyrSet& C0, PyrSet* C1, const DvPyr& a0, const DvPyr* b0, int w, int h, int max_level) {
+    DV_CHECK(C0.alloc(w, h, max_level, true));
+    if (C1) DV_CHECK(C1->alloc(w, h, max_level, true));
+    C0.pyr.L[0] = a0.L[0];
+    if (C1) C1->pyr.L[0] = b0->L[0];
+    for (int l = 1; l < C0.pyr.levels; ++l)
+        dv_launch_pyr_down2(C0.pyr.L[l - 1].p, C1 ? C1->pyr.L[l - 1].p : nullptr, C0.pyr.L[l - 1].w, C0.pyr.L[l - 1].h, C0.pyr.L[l - 1].pitch, C0.pyr.L[l].p, C1 ? C1->pyr.L[l].p : nullptr,
+                            C0.pyr.L[l].pitch, nullptr, nullptr, 0, ctx->stream, 1);
+    DV_CHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" {
 
 const char* dv_last_error(dv_ctx* ctx) {
@@ -181,7 +194,7 @@ void dv_destroy(dv_ctx* ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& t : ctx->timers) for (auto& p : t.pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,
-                       &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->opA.buf, &ctx->opB.buf, &ctx->undist_buf[0], &ctx->undist_buf[1] }) b->release();
+                       &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->leftc[0].buf, &ctx->leftc[1].buf, &ctx->rightc.buf, &ctx->opA.buf, &ctx->opB.buf, &ctx->undist_buf[0], &ctx->undist_buf[1] }) b->release();
     if (ctx->inst) dv_inst_destroy_internal(ctx->inst);
     if (ctx->est) dv_est_destroy_internal(ctx->est);
     be_dist_release(ctx);
@@ -210,7 +223,7 @@ int dv_reset(dv_ctx* ctx) {
     DV_CHECK(hipMemcpyAsync(ctx->tr.next_id, &one, 4, hipMemcpyHostToDevice, ctx->stream));
     DV_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->last_front && ctx->last_front != ctx->stream && ctx->last_done) DV_CHECK(hipEventSynchronize(ctx->last_done));
-    ctx->have_prev = false; ctx->prev_time = 0.0; ctx->pending = false; ctx->last_done = nullptr; ctx->last_front = nullptr;
+    ctx->have_prev = false; ctx->prev_time = 0.0; ctx->pending = false; ctx->last_done = nullptr; ctx->last_front = nullptr; ctx->leftc_valid[0] = ctx->leftc_valid[1] = false;
     if (ctx->inst && dv_inst_reset(ctx)) return -1;
     return 0;
 }
@@ -254,6 +267,17 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
         if (build_pyramids(ctx, L, stereo ? &ctx->right : nullptr, gray0, stereo ? gray1 : nullptr, w, h, stride, mem, 3, ctx->undist[0])) return -1;
     }
     if (ctx->inst) DV_CHECK(hipEventRecord(ctx->ev_pyr, s));
+    // FeatureTrackByLKGpu's own pyramids where the reference runs that tracker (naive: TrackLeftGPU + TrackRightGPU; semantic: TrackRightGPU)
+    ctx->leftc_valid[ctx->cur] = false;
+    if (mode != DV_MODE_RAW) {
+        StageScope sc(ctx, "pyr_cuda");
+        if (build_cuda_pyramids(ctx, ctx->leftc[ctx->cur], stereo ? &ctx->rightc : nullptr, L.pyr, stereo ? &ctx->right.pyr : nullptr, w, h, 3)) return -1;
+        ctx->leftc_valid[ctx->cur] = true;
+        if (mode == DV_MODE_NAIVE && ctx->have_prev && !ctx->leftc_valid[ctx->cur ^ 1]) {      // the previous frame was tracked in another mode: its pyramid of this flavour does not exist yet
+            if (build_cuda_pyramids(ctx, ctx->leftc[ctx->cur ^ 1], nullptr, Lp.pyr, nullptr, w, h, 3)) return -1;
+            ctx->leftc_valid[ctx->cur ^ 1] = true;
+        }
+    }
     const uint8_t* mask_dev = nullptr; int mask_pitch = 0;
     if (mask_or_null) {
         const bool bgr_in = (mem & DV_FMT_BGR) != 0;
@@ -272,13 +296,17 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
         dv_launch_erode(mask_dev, w, h, mask_pitch, c.mask_morphology_size, (uint8_t*)ctx->s3.p, ep, (uint8_t*)ctx->s4.p, ep, s);
         mask_dev = (const uint8_t*)ctx->s4.p; mask_pitch = ep;
     }
-    // forward/backward consistency: FeatureTrackByLK keeps <= 0.5 px (feature_utils.cpp:56), FeatureTrackByLKGpu <= 1.0 px (:126) (Q12)
+    // forward/backward consistency: FeatureTrackByLK keeps <= 0.5 px (feature_utils.cpp:56), FeatureTrackByLKGpu <= 1.0 px (:126) (Q12) — and the two are different
+    // trackers (lk.hip / lk_cuda.hip), each used where the reference uses it
     const float dist_temporal = (mode == DV_MODE_NAIVE) ? 1.0f : 0.5f;       // TrackLeftGPU (naive) vs TrackLeft (raw, semantic)
     const float dist_stereo = (mode == DV_MODE_RAW) ? 0.5f : 1.0f;           // TrackRightGPU in naive and semantic
     if (ctx->have_prev) {
         StageScope sc(ctx, "lk_temporal");
-        dv_launch_lk_track(Lp.pyr, L.pyr, ctx->tr.last_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_temporal, ctx->tr.lk_pts,
-                           ctx->tr.lk_status, s);
+        if (mode == DV_MODE_NAIVE)      // TrackLeftGPU -> FeatureTrackByLKGpu (instance_feature.cpp:191-216): the GPU tracker's rule
+            dv_launch_lk_cuda_track(ctx->leftc[ctx->cur ^ 1].pyr, ctx->leftc[ctx->cur].pyr, ctx->tr.last_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_temporal, ctx->tr.lk_pts, ctx->tr.lk_status, s);
+        else
+            dv_launch_lk_track(Lp.pyr, L.pyr, ctx->tr.last_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_temporal, ctx->tr.lk_pts,
+                               ctx->tr.lk_status, s);
     }
     {
         StageScope sc(ctx, "compact");
@@ -308,8 +336,11 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     if (ctx->inst) DV_CHECK(hipEventRecord(ctx->ev_bg_select, s));
     if (stereo) {
         StageScope sc(ctx, "lk_stereo");
-        dv_launch_lk_track(L.pyr, ctx->right.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_stereo,
-                           ctx->tr.right_pts, ctx->tr.right_status, s);
+        if (mode != DV_MODE_RAW)        // TrackRightGPU -> FeatureTrackByLKGpu (instance_feature.cpp:278-310) in naive and semantic mode
+            dv_launch_lk_cuda_track(ctx->leftc[ctx->cur].pyr, ctx->rightc.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_stereo, ctx->tr.right_pts, ctx->tr.right_status, s);
+        else
+            dv_launch_lk_track(L.pyr, ctx->right.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_stereo,
+                               ctx->tr.right_pts, ctx->tr.right_status, s);
     }
     {
         StageScope sc(ctx, "finalize");
@@ -576,6 +607,45 @@ int dv_track_by_lk(dv_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int w,
     return 0;
 }
 
+// cv::cuda::SparsePyrLKOpticalFlow::calc (use_initial: pts_b holds the initial flow) and FeatureTrackByLKGpu, operator forms for the parity tests
+static int lk_cuda_prepare(dv_ctx* ctx, const uint8_t* img_a, const uint8_t* img_b, int w, int h, int stride, int mem, int max_level) {
+    if (build_pyramids(ctx, ctx->opA, &ctx->opB, img_a, img_b, w, h, stride, mem, 0)) return -1;          // level 0 only (pitched copies)
+    return build_cuda_pyramids(ctx, ctx->leftc[0], &ctx->leftc[1], ctx->opA.pyr, &ctx->opB.pyr, w, h, max_level);
+}
+int dv_lk_cuda(dv_ctx* ctx, const uint8_t* img_a, const uint8_t* img_b, int w, int h, int stride, const float* pts_a, int n, int max_level, int iters, int use_initial,
+               float* pts_b, uint8_t* status, int mem) {
+    if (!ctx) return -1;
+    if (!img_a || !img_b || !pts_a || n <= 0) DV_FAIL("dv_lk_cuda: empty input");
+    if (max_level < 0 || max_level > 3 || iters < 0 || iters > 100) DV_FAIL("dv_lk_cuda: max_level must be in [0,3], iters in [0,100]");
+    if (ctx->pending || ctx->have_prev) DV_FAIL("dv_lk_cuda: operator calls need a ctx that is not tracking a sequence (its pyramids are used as scratch)");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (lk_cuda_prepare(ctx, img_a, img_b, w, h, stride, mem, max_level)) return -1;
+    const int ml = std::min(ctx->leftc[0].pyr.levels, ctx->leftc[1].pyr.levels) - 1;
+    if (stage_in(ctx, ctx->s0, pts_a, (size_t)n * 8, mem)) return -1;
+    if (use_initial) { if (stage_in(ctx, ctx->s1, pts_b, (size_t)n * 8, mem)) return -1; } else DV_CHECK(ctx->s1.ensure((size_t)n * 8));
+    DV_CHECK(ctx->s2.ensure(n));
+    dv_launch_lk_cuda_generic(ctx->leftc[0].pyr, ctx->leftc[1].pyr, (const float2*)ctx->s0.p, n, ml, iters, use_initial, (float2*)ctx->s1.p, (uint8_t*)ctx->s2.p, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    if (stage_out(ctx, pts_b, ctx->s1.p, (size_t)n * 8, mem)) return -1;
+    if (stage_out(ctx, status, ctx->s2.p, n, mem)) return -1;
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+int dv_track_by_lk_gpu(dv_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int w, int h, int stride, const float* pts1, int n, int flow_back, float* pts2, uint8_t* status, int mem) {
+    if (!ctx) return -1;
+    if (!img1 || !img2 || !pts1 || n <= 0) DV_FAIL("dv_track_by_lk_gpu: flowTrack() input wrong, received at least one of parameter are empty");
+    if (ctx->pending || ctx->have_prev) DV_FAIL("dv_track_by_lk_gpu: operator calls need a ctx that is not tracking a sequence (its pyramids are used as scratch)");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (lk_cuda_prepare(ctx, img1, img2, w, h, stride, mem, 3)) return -1;
+    if (stage_in(ctx, ctx->s0, pts1, (size_t)n * 8, mem)) return -1;
+    DV_CHECK(ctx->s1.ensure((size_t)n * 8)); DV_CHECK(ctx->s2.ensure(n));
+    dv_launch_lk_cuda_track(ctx->leftc[0].pyr, ctx->leftc[1].pyr, (const float2*)ctx->s0.p, nullptr, n, flow_back, 1.0f, (float2*)ctx->s1.p, (uint8_t*)ctx->s2.p, ctx->stream);
+    DV_CHECK(hipGetLastError());
+    if (stage_out(ctx, pts2, ctx->s1.p, (size_t)n * 8, mem)) return -1;
+    if (stage_out(ctx, status, ctx->s2.p, n, mem)) return -1;
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
+    return 0;
+}
 // stage an image (host or device) into a pitched device buffer; returns pointer/pitch to use
 static int stage_image(dv_ctx* ctx, DevBuf& b, const uint8_t* img, int w, int h, int stride, int mem, const uint8_t** out, int* pitch) {
     if (mem == DV_MEM_DEVICE) { *out = img; *pitch = stride; return 0; }
@@ -583,6 +653,22 @@ static int stage_image(dv_ctx* ctx, DevBuf& b, const uint8_t* img, int w, int h,
     DV_CHECK(b.ensure((size_t)p * h + 64));
     DV_CHECK(hipMemcpy2DAsync(b.p, p, img, stride, w, h, hipMemcpyHostToDevice, ctx->stream));
     *out = (const uint8_t*)b.p; *pitch = p;
+    return 0;
+}
+
+// cuda::pyrDown on an 8-bit image (the level step of that tracker's pyramid); dst is ((w+1)/2) x ((h+1)/2), tightly packed
+int dv_pyr_down_cuda(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, int mem) {
+    if (!ctx) return -1;
+    if (!src || !dst) DV_FAIL("dv_pyr_down_cuda: null argument");
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    const uint8_t* d_src; int pitch;
+    if (stage_image(ctx, ctx->s0, src, w, h, stride, mem, &d_src, &pitch)) return -1;
+    const int dw = (w + 1) / 2, dh = (h + 1) / 2, dp = align_up(dw, 16);
+    DV_CHECK(ctx->s1.ensure((size_t)dp * dh + 64));
+    dv_launch_pyr_down2(d_src, nullptr, w, h, pitch, (uint8_t*)ctx->s1.p, nullptr, dp, nullptr, nullptr, 0, ctx->stream, 1);
+    DV_CHECK(hipGetLastError());
+    DV_CHECK(hipMemcpy2DAsync(dst, dw, ctx->s1.p, dp, dw, dh, mem == DV_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+    DV_CHECK(hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

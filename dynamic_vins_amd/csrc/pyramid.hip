@@ -25,7 +25,7 @@ __device__ __forceinline__ int pyr_reflect101(int p, int len) {
 
 // one 64 x 16 output tile (bx, by) of one image
 __device__ __forceinline__ void pyr_down_tile(const uint8_t* __restrict__ src, int sw, int sh, int spitch, uint8_t* __restrict__ dst, int dw, int dh, int dpitch,
-                                              uint8_t* __restrict__ cpy, int cpitch, int bx, int by) {
+                                              uint8_t* __restrict__ cpy, int cpitch, int bx, int by, int rn_even = 0) {
     __shared__ __attribute__((aligned(16))) uint8_t s_src[PS_H * PS_PITCH];
     __shared__ short s_h[PS_H][PT_W];
     const int tid = threadIdx.x;
@@ -89,7 +89,8 @@ __device__ __forceinline__ void pyr_down_tile(const uint8_t* __restrict__ src, i
             for (int k = 0; k < 4; ++k) {
                 int c = 4 * q + k;
                 int v = s_h[2 * r][c] + s_h[2 * r + 4][c] + 4 * (s_h[2 * r + 1][c] + s_h[2 * r + 3][c]) + 6 * s_h[2 * r + 2][c];
-                o[k] = (uint8_t)((v + 128) >> 8);
+                if (rn_even) { int q = v >> 8; const int r = v & 255; q += (r > 128 || (r == 128 && (q & 1))) ? 1 : 0; o[k] = (uint8_t)min(q, 255); }      // cuda::pyrDown: __float2int_rn of the exact sum / 256
+                else o[k] = (uint8_t)((v + 128) >> 8);
             }
             if (x + 3 < dw) *reinterpret_cast<uchar4*>(dst + (size_t)y * dpitch + x) = make_uchar4(o[0], o[1], o[2], o[3]);
             else for (int k = 0; x + k < dw; ++k) dst[(size_t)y * dpitch + x + k] = o[k];
@@ -100,8 +101,8 @@ __device__ __forceinline__ void pyr_down_tile(const uint8_t* __restrict__ src, i
 __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
                                                        int sw, int sh, int spitch,
                                                        uint8_t* __restrict__ dst0, uint8_t* __restrict__ dst1, int dw, int dh, int dpitch,
-                                                       uint8_t* __restrict__ copy0, uint8_t* __restrict__ copy1, int cpitch) {
-    pyr_down_tile(blockIdx.z ? src1 : src0, sw, sh, spitch, blockIdx.z ? dst1 : dst0, dw, dh, dpitch, blockIdx.z ? copy1 : copy0, cpitch, blockIdx.x, blockIdx.y);
+                                                       uint8_t* __restrict__ copy0, uint8_t* __restrict__ copy1, int cpitch, int rn_even) {
+    pyr_down_tile(blockIdx.z ? src1 : src0, sw, sh, spitch, blockIdx.z ? dst1 : dst0, dw, dh, dpitch, blockIdx.z ? copy1 : copy0, cpitch, blockIdx.x, blockIdx.y, rn_even);
 }
 // the same level step for several independent image pairs in ONE launch (the per-object ROI pyramids of dynamic mode: blockIdx.z = 2 * job + image); the grid
 // covers the largest job, tiles outside a smaller one end at once
@@ -162,10 +163,10 @@ void dv_launch_pyr_apron(const DvPyr& a, const DvPyr* b, hipStream_t s) {
 }
 
 void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int sh, int spitch, uint8_t* dst0, uint8_t* dst1,
-                         int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch, hipStream_t s) {
+                         int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch, hipStream_t s, int rn_even) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
     dim3 grid((dw + PT_W - 1) / PT_W, (dh + PT_H - 1) / PT_H, src1 ? 2 : 1);
-    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src0, src1, sw, sh, spitch, dst0, dst1, dw, dh, dpitch, copy0, copy1, cpitch);
+    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src0, src1, sw, sh, spitch, dst0, dst1, dw, dh, dpitch, copy0, copy1, cpitch, rn_even);
 }
 
 

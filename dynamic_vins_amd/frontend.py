@@ -167,6 +167,30 @@ class Context:
                                             float(dist_thresh), _ptr(pts2), _ptr(st), DV_MEM_HOST))
         return pts2, st
 
+    def lk_cuda(self, img_a, img_b, pts_a, max_level=3, iters=30, initial=None):
+        """cv::cuda::SparsePyrLKOpticalFlow(Size(21, 21), max_level, iters, useInitialFlow)->calc"""
+        h, w = img_a.shape
+        pts_a = np.ascontiguousarray(pts_a, np.float32); n = len(pts_a)
+        pts_b = np.ascontiguousarray(initial, np.float32).copy() if initial is not None else np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        self._check(self.lib.dv_lk_cuda(self.h, _ptr(img_a), _ptr(img_b), w, h, img_a.strides[0], _ptr(pts_a), n, int(max_level), int(iters), 1 if initial is not None else 0,
+                                        _ptr(pts_b), _ptr(st), DV_MEM_HOST))
+        return pts_b, st
+
+    def track_by_lk_gpu(self, img1, img2, pts1, flow_back=True):
+        """FeatureTrackByLKGpu (front_end/feature_utils.cpp:83-163)"""
+        h, w = img1.shape
+        pts1 = np.ascontiguousarray(pts1, np.float32); n = len(pts1)
+        pts2 = np.zeros((n, 2), np.float32); st = np.zeros(n, np.uint8)
+        self._check(self.lib.dv_track_by_lk_gpu(self.h, _ptr(img1), _ptr(img2), w, h, img1.strides[0], _ptr(pts1), n, int(flow_back), _ptr(pts2), _ptr(st), DV_MEM_HOST))
+        return pts2, st
+
+    def pyr_down_cuda(self, img):
+        h, w = img.shape
+        dst = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self._check(self.lib.dv_pyr_down_cuda(self.h, _ptr(img), w, h, img.strides[0], _ptr(dst), DV_MEM_HOST))
+        return dst
+
     def gftt(self, img, max_n, quality, min_dist, mask=None):
         h, w = img.shape
         out = np.zeros((_abi.DV_MAX_FEATS, 2), np.float32)

@@ -29,9 +29,9 @@ extern "C" {
 #define DV_FMT_BGR    0x100
 
 #define DV_MODE_RAW   0   /* FeatureTracker::TrackImage      (background_tracker.cpp:52-158)  */
-#define DV_MODE_NAIVE 1   /* FeatureTracker::TrackImageNaive (background_tracker.cpp:400-516) */
+#define DV_MODE_NAIVE 1   /* FeatureTracker::TrackImageNaive (background_tracker.cpp:400-516): both trackings by FeatureTrackByLKGpu */
 #define DV_MODE_SEMANTIC 2 /* FeatureTracker::TrackSemanticImage (background_tracker.cpp:757-837): the background half of dynamic mode —
-                             temporal tracking by FeatureTrackByLK (dist <= 0.5), right image by the FeatureTrackByLKGpu rule (dist <= 1.0) */
+                             temporal tracking by FeatureTrackByLK (dist <= 0.5), right image by FeatureTrackByLKGpu (the GPU tracker, dist <= 1.0) */
 
 #define DV_MAX_FEATS 1024 /* device capacity for tracked points per tracker */
 
@@ -97,6 +97,15 @@ int dv_lk(dv_ctx* ctx, const uint8_t* img_a, const uint8_t* img_b, int w, int h,
 int dv_track_by_lk(dv_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int w, int h, int stride,
                    const float* pts1, int n, int flow_back, float dist_thresh,
                    float* pts2, uint8_t* status, int mem);
+/* The reference's GPU tracker, used by dv_track_stereo* where the reference uses it (DV_MODE_NAIVE: temporal + right image; DV_MODE_SEMANTIC: right image):
+ * cv::cuda::SparsePyrLKOpticalFlow::create(Size(21, 21), 3, 30[, useInitialFlow])->calc (front_end/background_tracker.cpp:34-36) — float patches sampled bilinearly,
+ * Scharr derivatives on the fly, no minimum-eigenvalue test, its own pyramid (cuda::pyrDown) — and FeatureTrackByLKGpu (front_end/feature_utils.cpp:83-163: forward,
+ * backward from the previous points, |p - p_rev| <= 1.0, InBorder).  Operator forms; the ctx must not be tracking a sequence. */
+int dv_lk_cuda(dv_ctx* ctx, const uint8_t* img_a, const uint8_t* img_b, int w, int h, int stride, const float* pts_a, int n, int max_level, int iters, int use_initial,
+               float* pts_b, uint8_t* status, int mem);
+int dv_track_by_lk_gpu(dv_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int w, int h, int stride, const float* pts1, int n, int flow_back,
+                       float* pts2, uint8_t* status, int mem);
+int dv_pyr_down_cuda(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, int mem);      /* cuda::pyrDown, 8-bit: the same sums as cv::pyrDown, rounded half to even */
 /* cv::goodFeaturesToTrack(img, out, max_n, quality, min_dist, mask) call sites:
  * background_tracker.cpp:85,238; instance_feature.cpp:381; dynamic_tracker.cpp:435 */
 int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w, int h, int stride,

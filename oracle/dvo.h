@@ -27,6 +27,7 @@ void dvo_set_threads(int n);
  * plausible reading so that a test can BOUND what the choice is worth (features selected, trajectory) instead of asserting it.  Default 0 everywhere = canonical.
  *   "lk_sums":   0 exact int64 window sums (D1) | 1 float accumulation in OpenCV's scalar (raster) order | 2 four float partial sums by x mod 4, combined (a 4-wide SIMD order)
  *   "box_sums":  0 3x3 covariance box sums in double, fixed order (D2) | 1 in float
+ *   "f4_cpu_rule": 0 the reference's GPU tracker (cv::cuda::SparsePyrLKOpticalFlow restated, lk_cuda.cpp) where the reference uses it | 1 the CPU LK arithmetic with FeatureTrackByLKGpu's 1.0 px threshold
  *   "radius":    0 Ceres' dogleg radius rule (quality < 0.25: x 0.5; > 0.75: max(radius, 3 |step|)) | 1 the Levenberg-style reading (> 0.75: radius x 3) */
 void dvo_set_variant(const char* key, int value);
 int dvo_get_variant(const char* key);
@@ -82,6 +83,14 @@ void dvo_lk(const uint8_t* img_a, const uint8_t* img_b, int w, int h,
 void dvo_track_by_lk(const uint8_t* img1, const uint8_t* img2, int w, int h,
                      const float* pts1, int n, int flow_back, float dist_thresh,
                      float* pts2, uint8_t* status);
+
+/* the reference's GPU tracker (lk_cuda.cpp): cuda::pyrDown on 8-bit images (round half to even), one bilinear texture fetch (8-bit fractions, normalised read, clamp),
+ * cv::cuda::SparsePyrLKOpticalFlow(Size(21, 21), max_level, iters, use_initial)->calc, and FeatureTrackByLKGpu (front_end/feature_utils.cpp:83-163: forward + backward,
+ * distance <= 1.0, InBorder) */
+void dvo_pyr_down_cuda(const uint8_t* src, int w, int h, uint8_t* dst);
+float dvo_tex_read(const uint8_t* img, int w, int h, float x, float y);
+void dvo_lk_cuda(const uint8_t* img_a, const uint8_t* img_b, int w, int h, const float* pts_a, int n, int max_level, int iters, int use_initial, float* pts_b, uint8_t* status);
+void dvo_track_by_lk_gpu(const uint8_t* img1, const uint8_t* img2, int w, int h, const float* pts1, int n, int flow_back, float* pts2, uint8_t* status);
 
 /* cv::cornerMinEigenVal(img, eig, 3, 3) */
 void dvo_min_eigen(const uint8_t* img, int w, int h, float* eig);

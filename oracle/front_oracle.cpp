@@ -41,14 +41,14 @@ static int g_threads = 1;      // dvo_set_threads: CPU-baseline timing only; res
 extern "C" void dvo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 extern "C" int dvo_get_threads() { return g_threads; }
 // sensitivity variants (dvo.h): process-wide switches, read by the stages they belong to
-int g_var_lk_sums = 0, g_var_box_sums = 0, g_var_radius = 0;
+int g_var_lk_sums = 0, g_var_box_sums = 0, g_var_radius = 0, g_var_f4_cpu = 0;      // "f4_cpu_rule" 1: naive / semantic modes track with the CPU arithmetic + the 1.0 px threshold (the substitution of rounds 1-3) instead of the GPU tracker (lk_cuda.cpp)
 extern "C" void dvo_set_variant(const char* key, int value) {
     const std::string k = key ? key : "";
-    if (k == "lk_sums") g_var_lk_sums = value; else if (k == "box_sums") g_var_box_sums = value; else if (k == "radius") g_var_radius = value;
+    if (k == "lk_sums") g_var_lk_sums = value; else if (k == "box_sums") g_var_box_sums = value; else if (k == "radius") g_var_radius = value; else if (k == "f4_cpu_rule") g_var_f4_cpu = value;
 }
 extern "C" int dvo_get_variant(const char* key) {
     const std::string k = key ? key : "";
-    return k == "lk_sums" ? g_var_lk_sums : k == "box_sums" ? g_var_box_sums : k == "radius" ? g_var_radius : -1;
+    return k == "lk_sums" ? g_var_lk_sums : k == "box_sums" ? g_var_box_sums : k == "radius" ? g_var_radius : k == "f4_cpu_rule" ? g_var_f4_cpu : -1;
 }
 // A persistent worker pool standing in for OpenCV's parallel_for_ back end (the reference links OpenCV 3.4 built with a thread pool: calcOpticalFlowPyrLK runs
 // its LKTrackerInvoker over ranges of points, pyrDown / the corner response over ranges of rows).  Spawning std::threads per level — the round-2 form — cost
@@ -566,7 +566,10 @@ struct dvo_tracker {
         if (!last_points.empty()) {
             curr_points.resize(last_points.size());
             std::vector<uint8_t> st(last_points.size());
-            track_by_lk(prev0.d.data(), g0, w, h, last_points.data(), (int)last_points.size(), cfg.flow_back, dthr, curr_points.data(), st.data());
+            if (mode == 1 && !dvo_get_variant("f4_cpu_rule"))       // TrackLeftGPU -> FeatureTrackByLKGpu: the GPU tracker (lk_cuda.cpp); variant "f4_cpu_rule": the CPU arithmetic with the 1.0 px threshold (rounds 1-3)
+                dvo_track_by_lk_gpu(prev0.d.data(), g0, w, h, &last_points[0].x, (int)last_points.size(), cfg.flow_back, &curr_points[0].x, st.data());
+            else
+                track_by_lk(prev0.d.data(), g0, w, h, last_points.data(), (int)last_points.size(), cfg.flow_back, dthr, curr_points.data(), st.data());
             if (naive && in_mask)                                  // instance_feature.cpp:211-216 (mask.at<uchar>(Point2f) rounds)
                 for (size_t i = 0; i < st.size(); ++i)
                     if (st[i]) { int x = cv_round(curr_points[i].x), y = cv_round(curr_points[i].y); if (in_mask[(size_t)y * w + x] == 0) st[i] = 0; }
@@ -596,7 +599,10 @@ struct dvo_tracker {
             if (!curr_points.empty()) {
                 right_points.resize(curr_points.size());
                 std::vector<uint8_t> st(curr_points.size());
-                track_by_lk(g0, g1, w, h, curr_points.data(), (int)curr_points.size(), cfg.flow_back, dthr_right, right_points.data(), st.data());
+                if (mode != 0 && !dvo_get_variant("f4_cpu_rule"))   // TrackRightGPU -> FeatureTrackByLKGpu in naive and semantic mode
+                    dvo_track_by_lk_gpu(g0, g1, w, h, &curr_points[0].x, (int)curr_points.size(), cfg.flow_back, &right_points[0].x, st.data());
+                else
+                    track_by_lk(g0, g1, w, h, curr_points.data(), (int)curr_points.size(), cfg.flow_back, dthr_right, right_points.data(), st.data());
                 right_ids = ids;
                 reduce_vector(right_points, st); reduce_vector(right_ids, st);
                 undistort(cfg.cam1, right_points, right_un);

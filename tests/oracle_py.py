@@ -180,6 +180,38 @@ class Oracle:
         return dict(curr_points=cur_pts[:n], ids=cur_ids[:n], track_cnt=cur_cnt[:n], curr_un_points=cur_un[:n], right_points=r_pts[:m], right_ids=r_ids[:m],
                     right_un_points=r_un[:m]), gid.value
 
+    def pyr_down_cuda(self, img):
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+        self.lib.dvo_pyr_down_cuda.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        self.lib.dvo_pyr_down_cuda(_p(img), w, h, _p(out))
+        return out
+
+    def tex_read(self, img, x, y):
+        img = np.ascontiguousarray(img, np.uint8); h, w = img.shape
+        f = self.lib.dvo_tex_read
+        f.restype = C.c_float; f.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float]
+        return f(_p(img), w, h, float(x), float(y))
+
+    def lk_cuda(self, a, b, pts_a, max_level=3, iters=30, initial=None):
+        """cv::cuda::SparsePyrLKOpticalFlow(Size(21, 21), max_level, iters, useInitialFlow = initial is not None)->calc"""
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8); h, w = a.shape
+        pa = np.ascontiguousarray(pts_a, np.float32).reshape(-1, 2)
+        pb = np.ascontiguousarray(initial, np.float32).reshape(-1, 2).copy() if initial is not None else np.zeros_like(pa)
+        st = np.zeros(len(pa), np.uint8)
+        self.lib.dvo_lk_cuda.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.dvo_lk_cuda(_p(a), _p(b), w, h, _p(pa), len(pa), int(max_level), int(iters), int(initial is not None), _p(pb), _p(st))
+        return pb, st
+
+    def track_by_lk_gpu(self, a, b, pts1, flow_back=True):
+        """FeatureTrackByLKGpu (front_end/feature_utils.cpp:83-163)"""
+        a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8); h, w = a.shape
+        p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+        p2 = np.zeros_like(p1); st = np.zeros(len(p1), np.uint8)
+        self.lib.dvo_track_by_lk_gpu.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        self.lib.dvo_track_by_lk_gpu(_p(a), _p(b), w, h, _p(p1), len(p1), int(flow_back), _p(p2), _p(st))
+        return p2, st
+
     def detect_extra_points(self, mask, box_xy, disp, cam4, baseline):
         """InstFeat::DetectExtraPoints -> float32 [n, 3] (x, y, depth), row-major scan order"""
         mask = np.ascontiguousarray(mask, np.uint8); disp = np.ascontiguousarray(disp, np.float32)

@@ -458,7 +458,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         if dyn_info:
             conf["dynamic"] = dyn_info
         out = {"metric": "stereo frames/sec (track+BA)", "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm_ba,
-               "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "ms_per_step": round(dt / args.steps * 1e3, 4), "timed_region_s": round(dt, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic" if not args.host_frames else "synthetic (host buffers, PCIe upload inside the timed region)",
                "config": conf, "roofline": roof, "cpu_baseline": cpu}
         return out

@@ -8,6 +8,7 @@
 // Many sequences on one GPU (config 4 of BASELINE.json, "batched"): the sequences of a GROUP run their begin phases back to back, dv_batch_enqueue launches the
 // iteration slots of all their window solves as one launch per stage, and while that runs the host turns to the next group; the end phases of a group follow when
 // its turn comes again.  `threads` host threads each drive their own groups (the reference runs one process — three threads — per sequence).
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <memory>
@@ -37,11 +38,23 @@ struct RSeq {
     long long detections = 0, object_features = 0, frames_with_objects = 0; int min_detections = 1 << 30;
 };
 }
+namespace {
+// reusable barrier of a group's host threads (sense reversing; the waits are short — a member's host phase is ~0.1 ms — so it spins with a yield)
+struct SpinBarrier {
+    std::atomic<int> count{0}; std::atomic<int> sense{0}; std::atomic<int> failed{0}; int n = 1;
+    bool wait() {          // -> false if any thread of the group reported a failure (everybody leaves the round)
+        const int s = sense.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { count.store(0, std::memory_order_relaxed); sense.store(s ^ 1, std::memory_order_release); }
+        else while (sense.load(std::memory_order_acquire) == s) std::this_thread::yield();
+        return failed.load(std::memory_order_acquire) == 0;
+    }
+};
+}
 struct dv_runner {
     std::vector<RSeq> seqs;
-    struct Group { std::vector<int> members; dv_batch* batch = nullptr; bool pending = false; };
+    struct Group { std::vector<int> members; dv_batch* batch = nullptr; bool pending = false; std::unique_ptr<SpinBarrier> bar; };
     std::vector<Group> groups;
-    int threads = 1;
+    int threads = 1, threads_per_group = 1;      // threads > groups: every dv_batch group is driven by threads / groups host threads that split its members' host phases (runner_team)
     bool batch_front = true;      // dv_batch groups: the members' tracking in shared launches too (dv_batch_track_enqueue); dv_runner_set(runner, "batch_front", 0) keeps one set of launches per sequence
     std::string err; std::mutex err_mu;
 };
@@ -181,6 +194,33 @@ int group_round(dv_runner* R, dv_runner::Group& g) {
     g.pending = true;
     return 0;
 }
+// One round of a dv_batch group driven by a TEAM of host threads: thread `j` of `T` does the host phases (end of frame k-1, collect + begin of frame k, IMU feed) of
+// members j, j + T, ...; thread 0 issues the shared launches (the window solves' slots, the tracking of the members' next frames) between two barriers.  The window
+// solves of a LARGE group share every launch (kernel efficiency) while its host work — ~0.1 ms per member and frame, serial in group_round — runs T wide.
+int team_round(dv_runner* R, dv_runner::Group& g, int j, int T, bool last) {
+    SpinBarrier& B = *g.bar;
+    int rc = 0;
+    auto mine = [&](auto f) { for (size_t m = j; m < g.members.size() && !rc; m += T) if (f(R->seqs[g.members[m]])) rc = -1; };
+    if (g.pending) mine([&](RSeq& s) { return seq_end(R, s); });
+    if (!last) {
+        if (j == 0 && !rc && group_track(R, g, 0)) rc = -1;          // (first round only: nothing is enqueued yet)
+        if (rc) B.failed.store(1);
+        if (!B.wait()) return -1;                                      // every member collected its previous frame; frame k of all members is enqueued
+        mine([&](RSeq& s) { return seq_begin(R, s, false); });
+        if (rc) B.failed.store(1);
+        if (!B.wait()) return -1;                                      // all begins (uploads on the group's stream) are in
+        if (j == 0) {
+            if (dv_batch_enqueue(g.batch)) { set_err(R, std::string("dv_batch_enqueue: ") + (dv_last_error(R->seqs[g.members[0]].ctx) ? dv_last_error(R->seqs[g.members[0]].ctx) : "")); rc = -1; }
+            if (!rc && group_track(R, g, 1)) rc = -1;
+            g.pending = true;
+        }
+        if (rc) B.failed.store(1);
+        if (!B.wait()) return -1;                                      // the next frames are enqueued (their `enqueued` flags are set)
+        mine([&](RSeq& s) { const int k1 = s.next + (s.skipped ? 0 : 1); return (!s.skipped && k1 < s.in.n_frames) ? seq_feed_imu(R, s, s.in.times[k1]) : 0; });
+    } else if (j == 0) g.pending = false;
+    if (rc) B.failed.store(1);
+    return rc;
+}
 int group_drain(dv_runner* R, dv_runner::Group& g) {
     if (g.pending) { for (int i : g.members) if (seq_end(R, R->seqs[i])) return -1; g.pending = false; }
     return 0;
@@ -212,7 +252,12 @@ dv_runner* dv_runner_create(dv_ctx* const* ctxs, const dv_seq_input* seqs, int n
         }
         R->groups.push_back(std::move(g));
     }
-    R->threads = std::max(1, std::min(threads, (int)R->groups.size()));
+    const int ng = (int)R->groups.size();
+    bool all_batched = R->batch_front; for (auto& g : R->groups) if (!g.batch) all_batched = false;
+    if (threads > ng && all_batched && threads % ng == 0) {      // a team of threads / groups host threads per dv_batch group
+        R->threads = threads; R->threads_per_group = threads / ng;
+        for (auto& g : R->groups) { g.bar = std::make_unique<SpinBarrier>(); g.bar->n = R->threads_per_group; }
+    } else R->threads = std::max(1, std::min(threads, ng));
     return R.release();
 }
 
@@ -234,7 +279,21 @@ int dv_runner_run(dv_runner* R, int n_rounds, double* wall_seconds) {
         for (size_t gi = first; gi < R->groups.size(); gi += step) if (group_drain(R, R->groups[gi])) return -1;
         return 0;
     };
-    if (R->threads <= 1) rc = drive(0, 1);
+    if (R->threads_per_group > 1 && R->batch_front) {
+        const int T = R->threads_per_group;
+        std::vector<std::thread> th; std::vector<int> rcs(R->threads, 0);
+        for (int t = 0; t < R->threads; ++t) th.emplace_back([&, t] {
+            dv_runner::Group& g = R->groups[t / T];
+            const int j = t % T;
+            for (int r = 0; r < n_rounds && !rcs[t]; ++r) if (team_round(R, g, j, T, false)) rcs[t] = -1;
+            if (!rcs[t] && team_round(R, g, j, T, true)) rcs[t] = -1;      // drain: the members' last frames
+            if (rcs[t]) g.bar->failed.store(1);
+        });
+        for (auto& t : th) t.join();
+        for (int v : rcs) if (v) rc = -1;
+        for (auto& g : R->groups) { g.pending = false; g.bar->failed.store(0); g.bar->count.store(0); }
+    }
+    else if (R->threads <= 1) rc = drive(0, 1);
     else {
         std::vector<std::thread> th; std::vector<int> rcs(R->threads, 0);
         for (int t = 0; t < R->threads; ++t) th.emplace_back([&, t] { rcs[t] = drive(t, R->threads); });

@@ -143,8 +143,13 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
     warm_ba = max(args.warmup, 12)
     gsz = 0
     if getattr(args, "batched", False):
-        gsz = args.group_size if getattr(args, "group_size", 0) > 0 else (S // 2 if S >= 4 else S)
-    runner = Runner(pipes, group_size=gsz, threads=max(1, getattr(args, "runner_threads", 1)))
+        gsz = args.group_size if getattr(args, "group_size", 0) > 0 else ((S + 1) // 2 if S >= 4 else S)      # default: two groups in anti-phase (one's host phases beside the other's launches)
+    n_groups = (S + gsz - 1) // gsz if gsz > 0 else S
+    threads = getattr(args, "runner_threads", 0)
+    if threads <= 0:          # default: a team of two host threads per dv_batch group (dv_runner: threads > groups), one thread otherwise
+        threads = 2 * n_groups if gsz > 1 else 1
+    args.runner_threads = threads
+    runner = Runner(pipes, group_size=gsz, threads=max(1, threads))
     if getattr(args, "no_batch_front", False):
         runner.set("batch_front", 0)
     runner.run(warm_ba)
@@ -204,7 +209,7 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
                "config": {"workload": f"{S} independent synthetic {w}x{h} stereo sequences per GPU @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "")
                                       + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame; a step = one frame of EVERY sequence",
                           "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S, "host_loop": "C++ (dv_runner)",
-                          "parallelism": f"{S} sequences per GPU, host loop in C++ on {max(1, getattr(args, 'runner_threads', 1))} thread(s)"
+                          "parallelism": f"{S} sequences per GPU, host loop in C++ on {max(1, getattr(args, 'runner_threads', 1))} thread(s)" + (f" ({max(1, getattr(args, 'runner_threads', 1)) // n_groups} per group)" if gsz > 1 and getattr(args, 'runner_threads', 1) > n_groups else "")
                                          + (f", window solves batched in dv_batch groups of {gsz} (one launch per stage for a group)" if gsz > 1 else ", every sequence on its own streams") + f", x {world} GPU(s); no collective",
                           "group_size": gsz, "runner_threads": max(1, getattr(args, "runner_threads", 1)), "front_end_launches": dict(shared=not getattr(args, "no_batch_front", False) and gsz > 1, **runner.track_info()),
                           "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),

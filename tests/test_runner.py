@@ -15,11 +15,12 @@ def make(n_seq, frames, w=752, h=480):
     return seqs, [Pipeline(q, max_cnt=150, min_dist=30, max_iters=8) for q in seqs]
 
 
-@pytest.mark.parametrize("group_size,threads", [(0, 1), (3, 1), (2, 2)])
+@pytest.mark.parametrize("group_size,threads", [(0, 1), (3, 1), (2, 2), (4, 2), (2, 4)])
 def test_runner_equals_python_pipeline(group_size, threads):
+    """(4, 2): ONE group of four driven by a team of two host threads; (2, 4): two groups with a team of two each"""
     from dynamic_vins_amd.backend import Runner
     from dynamic_vins_amd.pipeline import Pipeline
-    S, frames = 4 if threads == 2 else 3, 30
+    S, frames = 4 if threads >= 2 else 3, 30
     seqs, pipes = make(S, frames)
     ref = [Pipeline(q, max_cnt=150, min_dist=30, max_iters=8) for q in seqs]
     runner = Runner(pipes, group_size=group_size, threads=threads)

@@ -436,7 +436,7 @@ int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, 
  * one call runs n_rounds frames of one or many sequences.  Per sequence the order of pipeline.py: collect tracking(k), IMU up to t_k, dv_est_process_begin(k),
  * enqueue tracking(k+1), IMU up to t_k+1, dv_est_process_end(k) — the front end of frame k+1 overlaps the back end of frame k.  With group_size > 1 the sequences
  * are grouped into dv_batch groups of that size: the begin phases of a group run back to back, ONE dv_batch_enqueue launches the iteration slots of all its window
- * solves, and the host turns to the next group while they run (config 4 of BASELINE.json, "batched").  `threads` host threads each drive their own groups.
+ * solves, and the host turns to the next group while they run (config 4 of BASELINE.json, "batched").  `threads` host threads each drive their own groups; with MORE threads than groups (a multiple) every group is driven by a team of threads / groups host threads — the members' host phases (~0.1 ms per member and frame) run side by side, one thread of the team issues the group's shared launches between two barriers: large groups (kernel efficiency) without the serial host loop.
  * The contexts (each with its estimator: dv_est_create) stay the caller's; frames are referenced, not copied (device or host memory: dv_seq_input::mem).
  * dynamic_vins_amd/host/dvins_node.cpp is the ROS-free node built on it (image directory + IMU csv in, `<seq>_<mode>_Odometry.txt` out). */
 typedef struct dv_seq_input {

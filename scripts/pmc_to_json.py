@@ -24,7 +24,7 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes
                  "FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md); counters are kilobytes per dispatch",
        "git_head": git_head(), "csrc_digest": csrc_digest(), "kernels": {}}
 if BATCHED:
-    out["source"] = out["source"].replace("bench.py --steps 30 --no-cpu-baseline", "bench.py --sequences 16 --batched --group-size 8 --runner-threads 2 --steps 30")
+    out["source"] = out["source"].replace("bench.py --steps 30 --no-cpu-baseline", "bench.py --sequences 32 --batched --group-size 16 --runner-threads 8 --steps 30")
     out["windows_per_launch"] = int(sys.argv[4]) if len(sys.argv) > 4 else 8
 for k in sorted(f):
     if BATCHED and "batch" not in k:

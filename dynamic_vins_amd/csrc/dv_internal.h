@@ -53,8 +53,9 @@ struct GfttSelectArgs {
     int w, h; double quality; double min_dist;
     int max_n_host; const int* n_feat; int max_cnt; int min_new;   // tracker: max_n = max_cnt - *n_feat (needs >= min_new)
     float2* out_xy; int* n_out;                                    // operator-level output (dv_gftt), may be null
-    DvTrackState tr; int has_tr;                                   // tracker epilogue: append corners, assign ids
-    int* err_flag;
+    DvTrackState tr; int has_tr;                                   // tracker epilogue: append corners, assign ids (1), or append and leave (old n_feat, accepted) in id_slot (2):
+    int* err_flag;                                                 // the ids of several jobs drawing on ONE counter are handed out afterwards, in job order (dv_launch_gftt_assign_ids)
+    int* id_slot;
 };
 
 struct dv_ctx;
@@ -80,9 +81,12 @@ void dv_launch_pyr_apron_multi(const DvPyr* pyrs_dev, int n_pyr, int max_levels,
 // job-table forms of the tracker's single-workgroup / per-image stages (the front ends of a dv_batch group in shared launches: front_batch.hip)
 struct DvCompactJob { DvTrackState tr; const uint8_t* in_mask; int mask_pitch, sort_by_cnt; int* n_cand; unsigned* max_ord; };
 void dv_launch_compact_multi(const DvCompactJob* jobs_dev, int n_jobs, hipStream_t s);
-struct DvFinalizeJob { DvTrackState tr; dv_cam cam0, cam1; int stereo, pad_; double dt; dv_feat* out; int* n_out; const int* err_in; int* err_out; };
+struct DvFinalizeJob { DvTrackState tr; dv_cam cam0, cam1; int stereo, use_off; double dt; dv_feat* out; int* n_out; const int* err_in; int* err_out; float off_x, off_y; };      // use_off: the points are ROI-local, (off_x, off_y) = the box corner
 void dv_launch_finalize_multi(const DvFinalizeJob* jobs_dev, int n_jobs, int n_max, hipStream_t s);
-void dv_launch_gftt_tile_multi(const GfttTileArgs* tab_dev, int n_jobs, int w, int h, hipStream_t s);      // all jobs share the image size w x h
+void dv_launch_gftt_tile_multi(const GfttTileArgs* tab_dev, int n_jobs, int w, int h, hipStream_t s);      // w x h = the largest image of the table; a smaller job leaves the tiles outside its own image idle
+void dv_launch_gftt_assign_ids(const GfttSelectArgs* tab_dev, int n_jobs, hipStream_t s);                  // behind dv_launch_gftt_select_multi with has_tr == 2: ids in job order from the jobs' common counter
+struct DvErodeJob { const uint8_t* src; uint8_t* tmp; uint8_t* dst; int w, h, spitch, tpitch, dpitch, k; };
+void dv_launch_erode_multi(const DvErodeJob* jobs_dev, int n_jobs, int w_max, int h_max, hipStream_t s);
 int  dv_launch_gftt_select_multi(const GfttSelectArgs* tab_dev, int n_jobs, hipStream_t s);
 struct DvLkJob { DvPyr A, B; const float2* pts_a; const int* n_dev; float2* pts_b; uint8_t* status; float add_x, add_y; int use_add, pad; };
 void dv_launch_lk_track_multi(const DvLkJob* jobs_dev, int n_jobs, int n_max, int flow_back, float dist_thresh, hipStream_t s);

@@ -246,6 +246,7 @@ int dv_timing_get(dv_ctx* ctx, const char* name, double* total_ms, long long* co
 int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gray1, int w, int h, int stride, double t,
                             const uint8_t* mask_or_null, int mode, int mem) {
     if (!ctx) return -1;
+    HostScope hs(ctx, "h_front_enqueue");
     if (!gray0) DV_FAIL("dv_track_stereo: gray0 is null");
     if (w != ctx->cfg.width || h != ctx->cfg.height) DV_FAIL("dv_track_stereo: image size differs from config (reference: std::terminate, main.cpp:95-99)");
     if (ctx->pending) DV_FAIL("dv_track_stereo_enqueue: previous frame not collected");
@@ -358,7 +359,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
 int dv_track_stereo_collect(dv_ctx* ctx, dv_feat* out, int* n_out) {
     if (!ctx) return -1;
     if (!ctx->pending) DV_FAIL("dv_track_stereo_collect: nothing enqueued");
-    DV_CHECK(hipEventSynchronize(ctx->last_done ? ctx->last_done : ctx->done));
+    { HostScope hs(ctx, "h_front_wait"); DV_CHECK(hipEventSynchronize(ctx->last_done ? ctx->last_done : ctx->done)); }
     ctx->pending = false;
     if (ctx->timing) dv_harvest_timers(ctx, ctx->stream);
     if (*ctx->err_pinned) {

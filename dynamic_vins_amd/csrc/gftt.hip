@@ -191,7 +191,9 @@ __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
 __global__ __launch_bounds__(256) void gftt_tile_multi_kernel(const GfttTileArgs* __restrict__ tab, int gx, int gy) {
     const int per = gx * gy, t = gftt_xcd_tile(blockIdx.x, gridDim.x), job = t / per, tt = t - job * per;
     const GfttTileArgs a = tab[job];
-    gftt_tile_body(a, tt % gx, tt / gx);
+    const int tx = tt % gx, ty = tt / gx;
+    if (tx * TW >= a.w || ty * TH >= a.h) return;      // (gx, gy) cover the largest image of the table: the objects' ROIs differ in size
+    gftt_tile_body(a, tx, ty);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -364,17 +366,35 @@ __device__ __forceinline__ void gftt_select_body(const GfttSelectArgs& a) {
     }
     if (a.has_tr) {   // background_tracker.cpp:92-96: append, id = global_id_count++, track_cnt = 1
         const int n0 = *a.tr.n_feat;
-        const unsigned id0 = *a.tr.next_id;
+        const bool own_ids = a.has_tr == 1;
+        const unsigned id0 = own_ids ? *a.tr.next_id : 0u;
         __syncthreads();
         for (int i = tid; i < acc; i += SEL_THREADS) {
             a.tr.curr_pts[n0 + i] = make_float2((float)acc_x[i], (float)acc_y[i]);
-            a.tr.ids[n0 + i] = id0 + i;
+            if (own_ids) a.tr.ids[n0 + i] = id0 + i;
             a.tr.track_cnt[n0 + i] = 1;
             a.tr.tracked[n0 + i] = 0;
             a.tr.prev_rvalid[n0 + i] = 0;
         }
-        if (tid == 0) { *a.tr.n_feat = n0 + acc; *a.tr.next_id = id0 + acc; }
+        if (tid == 0) {
+            *a.tr.n_feat = n0 + acc;
+            if (own_ids) *a.tr.next_id = id0 + acc; else { a.id_slot[0] = n0; a.id_slot[1] = acc; }
+        }
     }
+}
+// ids of the corners the jobs of ONE select launch appended (has_tr == 2), drawn from their common counter in job order: exactly what the jobs' own epilogues do
+// when they run one after the other (InstFeat::global_id_count, one static counter for background and object features)
+__global__ __launch_bounds__(256) void gftt_assign_ids_kernel(const GfttSelectArgs* __restrict__ tab, int n_jobs) {
+    unsigned* next = tab[0].tr.next_id;
+    unsigned base = *next;
+    for (int j = 0; j < n_jobs; ++j) {
+        const int n0 = tab[j].id_slot[0], acc = tab[j].id_slot[1];
+        uint32_t* ids = tab[j].tr.ids;
+        for (int i = threadIdx.x; i < acc; i += 256) ids[n0 + i] = base + i;
+        base += (unsigned)acc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *next = base;
 }
 __global__ __launch_bounds__(SEL_THREADS) void gftt_select_kernel(GfttSelectArgs a) { gftt_select_body(a); }
 // one workgroup per job (blockIdx.x): the corner selections of a dv_batch group's front ends in one launch
@@ -396,6 +416,10 @@ void dv_launch_gftt_tile_multi(const GfttTileArgs* tab_dev, int n_jobs, int w, i
     if (n_jobs <= 0) return;
     const int gx = (w + TW - 1) / TW, gy = (h + TH - 1) / TH;
     hipLaunchKernelGGL(gftt_tile_multi_kernel, dim3(gx * gy * n_jobs), dim3(256), 0, s, tab_dev, gx, gy);
+}
+void dv_launch_gftt_assign_ids(const GfttSelectArgs* tab_dev, int n_jobs, hipStream_t s) {
+    if (n_jobs <= 0) return;
+    hipLaunchKernelGGL(gftt_assign_ids_kernel, dim3(1), dim3(256), 0, s, tab_dev, n_jobs);
 }
 int dv_launch_gftt_select_multi(const GfttSelectArgs* tab_dev, int n_jobs, hipStream_t s) {
     if (n_jobs <= 0) return 0;

@@ -64,11 +64,12 @@ struct Slot {            // InstFeat
     DevBuf state; DvTrackState tr{}; int* scal = nullptr;      // n_feat, n_tracked
     RoiPyr roi[2]; int cur = 0;                                // roi[cur]: this frame's (padded) ROI pyramid; roi[cur ^ 1]: level 0 holds prev_roi_gray in its top-left pw x ph
     RoiPyr padA;                                               // previous ROI padded to the common size
-    DevBuf mask, tmp, ero;
+    DevBuf tmp, ero, cand; uint8_t* mask = nullptr;            // mask: this frame's object mask inside the tracker's mask area (one upload per frame for all objects)
+    int* n_cand = nullptr; unsigned* max_ord = nullptr; int* id_slot = nullptr;      // the object's own Shi-Tomasi scratch: the objects' detections share launches
     const double* points = nullptr; int n_points = 0;          // extra 3-D points of this frame (pass-through)
     std::vector<double> pts_copy;
     bool out_valid = false; int out_index = -1;
-    void release() { state.release(); roi[0].buf.release(); roi[1].buf.release(); padA.buf.release(); mask.release(); tmp.release(); ero.release(); }
+    void release() { state.release(); roi[0].buf.release(); roi[1].buf.release(); padA.buf.release(); tmp.release(); ero.release(); cand.release(); }
 };
 
 }  // namespace
@@ -84,7 +85,7 @@ struct dv_inst_tracker {
     hipStream_t stream = nullptr;                               // the objects run beside the background tracker: own stream, own Shi-Tomasi scratch
     DevBuf jobs; void* jobs_pinned = nullptr; size_t jobs_cap = 0;     // DvLkJob tables of the two batched LK stages (temporal | right)
     DevBuf arena; void* arena_pinned = nullptr; size_t arena_cap = 0;  // per-frame job tables of the batched per-object stages (ROI crops, pyramid levels): filled on the host, ONE upload
-    DevBuf cand, scal; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
+    DevBuf scal, mask_all; int cand_cap = 0; int* err_flag = nullptr;
     std::vector<unsigned> out_order;                            // ids written this frame, in output order
     // extra points from the frame's disparity map (dv_inst_set_disparity; extra_points.hip): the reference's second thread = a side stream
     const float* disp_user = nullptr; int disp_stride = 0, disp_mem = 0; double disp_baseline = 0; bool disp_next = false, xp_frame = false, xp_inflight = false;
@@ -97,7 +98,7 @@ struct dv_inst_tracker {
         if (ev_xdone) (void)hipEventDestroy(ev_xdone);
         if (xp_pinned) (void)hipHostFree(xp_pinned);
         for (auto& kv : slots) kv.second.release();
-        hw.release(); out_buf.release(); cand.release(); scal.release(); jobs.release();
+        hw.release(); out_buf.release(); mask_all.release(); scal.release(); jobs.release();
         if (jobs_pinned) (void)hipHostFree(jobs_pinned);
         arena.release(); if (arena_pinned) (void)hipHostFree(arena_pinned);
         if (stream) (void)hipStreamDestroy(stream);
@@ -140,11 +141,13 @@ static int slot_init(dv_ctx* ctx, Slot& s) {
     s.tr.ids = (uint32_t*)(b + o_ids); s.tr.track_cnt = (int32_t*)(b + o_cnt); s.tr.prev_un = (float2*)(b + o_pun); s.tr.prev_run = (float2*)(b + o_prun);
     s.tr.prev_rvalid = b + o_prv; s.tr.tracked = b + o_trk; s.tr.right_pts = (float2*)(b + o_rp); s.tr.right_status = b + o_rs;
     s.scal = (int*)(b + o_scal); s.tr.n_feat = s.scal; s.tr.n_tracked = s.scal + 1;
+    s.n_cand = s.scal + 2; s.max_ord = (unsigned*)(s.scal + 3); s.id_slot = s.scal + 4;
     s.tr.next_id = ctx->tr.next_id;                      // InstFeat::global_id_count is ONE static counter for background and object features
     for (int k = 0; k < 2; ++k) DV_CHECK(s.roi[k].reserve(W, H));
     DV_CHECK(s.padA.reserve(W, H));
     const size_t mp = (size_t)align_up(W, 16) * H;
-    DV_CHECK(s.mask.ensure(mp)); DV_CHECK(s.tmp.ensure(mp)); DV_CHECK(s.ero.ensure(mp));
+    DV_CHECK(s.tmp.ensure(mp)); DV_CHECK(s.ero.ensure(mp));
+    DV_CHECK(s.cand.ensure((size_t)ctx->inst->cand_cap * sizeof(DvCand)));
     return 0;
 }
 
@@ -171,9 +174,9 @@ int dv_inst_config(dv_ctx* ctx, int max_dynamic_cnt, int min_dynamic_dist, int u
         DV_CHECK(hipEventCreateWithFlags(&ctx->inst->ev_xin, hipEventDisableTiming));
         DV_CHECK(hipEventCreateWithFlags(&ctx->inst->ev_xdone, hipEventDisableTiming));
         const int cap = std::max(4096, (ctx->cfg.width * ctx->cfg.height) / 4);
-        DV_CHECK(ctx->inst->cand.ensure((size_t)cap * sizeof(DvCand))); ctx->inst->cand_cap = cap;
+        ctx->inst->cand_cap = cap;
         DV_CHECK(ctx->inst->scal.ensure(256)); DV_CHECK(hipMemset(ctx->inst->scal.p, 0, 256));
-        ctx->inst->n_cand = (int*)ctx->inst->scal.p; ctx->inst->max_ord = (unsigned*)ctx->inst->scal.p + 1; ctx->inst->err_flag = (int*)ctx->inst->scal.p + 2;
+        ctx->inst->err_flag = (int*)ctx->inst->scal.p + 2;
     }
     dv_inst_tracker& T = *ctx->inst;
     if (T.pending) DV_FAIL("dv_inst_config: a frame is in flight");
@@ -199,6 +202,7 @@ int dv_inst_reset(dv_ctx* ctx) {
 
 int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_dets, const dv_box3d* boxes3d, int n_boxes3d) {
     if (!ctx) return -1;
+    HostScope hs(ctx, "h_inst_enqueue");
     if (!ctx->inst) DV_FAIL("dv_inst_track: call dv_inst_config first");
     if (n_dets < 0 || (n_dets > 0 && !dets) || n_boxes3d < 0 || (n_boxes3d > 0 && !boxes3d)) DV_FAIL("dv_inst_track: bad argument");
     if (!ctx->have_prev) DV_FAIL("dv_inst_track: enqueue the frame with dv_track_stereo_enqueue first (the object tracker works on its pyramids)");
@@ -267,6 +271,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             DV_CHECK(hipHostMalloc(&T.pinned_in, mask_bytes * 2 + 4096, hipHostMallocDefault));
             T.pinned_in_bytes = mask_bytes * 2 + 4096;
         }
+        if (T.mask_all.bytes < mask_bytes) { DV_CHECK(hipStreamSynchronize(s)); DV_CHECK(hipStreamSynchronize(T.xstream)); DV_CHECK(T.mask_all.ensure(mask_bytes * 2 + 4096)); }
         // output area
         if (T.out_cap_slots < T.slots.size()) {
             const size_t cap = std::max<size_t>(8, T.slots.size() * 2);
@@ -281,9 +286,10 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         size_t moff = 0; int out_k = 0;
         const double dt = T.cur_time - T.last_time;
         // The objects are independent up to the shared id counter, and an LK launch is pure latency (one wave per point): the frame is processed in STAGES —
-        // (A) per object: mask upload, ROI crop + padding, pyramids; (B) ONE temporal-LK launch for all objects; (C) per object, in ascending id: compaction,
-        // mask erosion, Shi-Tomasi (the candidate scratch and the id counter are shared, so this stage stays sequential); (D) ONE right-image LK launch;
-        // (E) per object: undistortion / velocities / rows.  Same arithmetic, same order of id assignment as the one-object-at-a-time form.
+        // (A) the masks (one upload), ROI crops + paddings, pyramid levels; (B) temporal LK; (C) compaction, mask erosion (two passes), Shi-Tomasi tiles, corner
+        // selection, ids (the objects draw on ONE counter: handed out in ascending object id by a one-workgroup launch behind the selection); (D) right-image LK;
+        // (E) undistortion / velocities / rows.  Every stage is ONE launch for all objects (job tables filled on the host, one upload): 13 launches per frame
+        // whatever the number of objects (they were 8 per object + 6).  Same arithmetic, same order of id assignment as the one-object-at-a-time form.
         std::vector<Slot*> act;
         for (auto& kv : T.slots) { Slot& S = kv.second; S.out_valid = false; if (S.lost_num > 0 || !S.visible) continue; act.push_back(&S); }      // ExecInst + is_curr_visible
         const int na = (int)act.size();
@@ -300,7 +306,8 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         // ---- stage A: masks, then the ROI crops / re-paddings and the pyramid levels of ALL objects as one launch each (they were 1 + 2 + 3 launches per object, on
         // one stream: with four objects a chain of ~50 dependent launches per frame, ~0.8 ms of latency between the enqueue and the rows) ----
         {
-            const size_t need = ((size_t)na * 2 * sizeof(RoiJob) + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob) + (size_t)na * sizeof(DvExtraJob) + 2048);
+            const size_t need = ((size_t)na * 2 * sizeof(RoiJob) + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob) + (size_t)na * sizeof(DvExtraJob) +
+                                 (size_t)na * (sizeof(DvCompactJob) + sizeof(DvErodeJob) + sizeof(GfttTileArgs) + sizeof(GfttSelectArgs) + sizeof(DvFinalizeJob)) + 4096);
             if (need > T.arena_cap) {
                 DV_CHECK(hipStreamSynchronize(s));
                 const size_t cap = need * 2;
@@ -319,6 +326,15 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         const size_t xp_off = ((pyr_off + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob)) + 255) / 256 * 256;
         DvExtraJob* h_xp = (DvExtraJob*)((uint8_t*)T.arena_pinned + xp_off);
         const size_t xp_slot_bytes = 64 + (size_t)3 * DV_XP_CAP * sizeof(double);
+        // the tables of stages C and E behind them
+        auto up256 = [](size_t v) { return (v + 255) / 256 * 256; };
+        const size_t cj_off = up256(xp_off + (size_t)na * sizeof(DvExtraJob)), ej_off = up256(cj_off + (size_t)na * sizeof(DvCompactJob)), gt_off = up256(ej_off + (size_t)na * sizeof(DvErodeJob)),
+                     gs_off = up256(gt_off + (size_t)na * sizeof(GfttTileArgs)), fj_off = up256(gs_off + (size_t)na * sizeof(GfttSelectArgs)), arena_used = fj_off + (size_t)na * sizeof(DvFinalizeJob);
+        DvCompactJob* h_cj = (DvCompactJob*)((uint8_t*)T.arena_pinned + cj_off); DvErodeJob* h_ej = (DvErodeJob*)((uint8_t*)T.arena_pinned + ej_off);
+        GfttTileArgs* h_gt = (GfttTileArgs*)((uint8_t*)T.arena_pinned + gt_off); GfttSelectArgs* h_gs = (GfttSelectArgs*)((uint8_t*)T.arena_pinned + gs_off);
+        DvFinalizeJob* h_fj = (DvFinalizeJob*)((uint8_t*)T.arena_pinned + fj_off);
+        int ero_W = 0, ero_H = 0, nj = 0;
+        const double dt_fin = dt;
         T.xp_frame = T.disp_next; T.disp_next = false;
         if (T.xp_frame && T.xp_cap_slots < (size_t)na) {
             DV_CHECK(hipStreamSynchronize(T.xstream));
@@ -336,16 +352,40 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             uint8_t* hm = (uint8_t*)T.pinned_in + moff; moff += (size_t)mp * h;
             const dv_inst_det* det = nullptr; for (int i = 0; i < n_dets; ++i) if (dets[i].track_id == S.id) det = &dets[i];
             for (int y = 0; y < h; ++y) std::memcpy(hm + (size_t)y * mp, det->mask + (size_t)y * w, w);
-            DV_CHECK(hipMemcpyAsync(S.mask.p, hm, (size_t)mp * h, hipMemcpyHostToDevice, s));
+            S.mask = (uint8_t*)T.mask_all.p + (hm - (uint8_t*)T.pinned_in);
             if (T.xp_frame) {          // ProcessExtraPoints visits the visible objects (ExecInst + is_curr_visible); slot k of the pinned output = k-th active object = its output index
                 uint8_t* xo = (uint8_t*)T.xp_pinned + (size_t)n_xp * xp_slot_bytes;
-                h_xp[n_xp++] = DvExtraJob{ (const uint8_t*)S.mask.p, mp, w, h, S.rx, S.ry, dv_extra_points_step(h, w), (double*)(xo + 64), (int*)xo };
+                h_xp[n_xp++] = DvExtraJob{ (const uint8_t*)S.mask, mp, w, h, S.rx, S.ry, dv_extra_points_step(h, w), (double*)(xo + 64), (int*)xo };
             }
             // this frame's ROI, padded to the common size with the previous one (InstanceImagePadding)
             S.cur ^= 1;
             RoiPyr& B = S.roi[S.cur]; RoiPyr& Prev = S.roi[S.cur ^ 1];
             const int PW = S.has_prev ? std::max(w, S.pw) : w, PH = S.has_prev ? std::max(h, S.ph) : h;
             B.layout(PW, PH);
+            {   // stage C / E tables of this object
+                DvCompactJob cj{}; cj.tr = S.tr; cj.in_mask = nullptr; cj.mask_pitch = 0; cj.sort_by_cnt = 0; cj.n_cand = S.n_cand; cj.max_ord = S.max_ord;      // ReduceVector x4, ++track_cnt; without a previous ROI the object has no points (n_feat == 0)
+                h_cj[nj] = cj;
+                h_ej[nj] = DvErodeJob{ S.mask, (uint8_t*)S.tmp.p, (uint8_t*)S.ero.p, w, h, mp, mp, mp, 5 };      // ErodeMask 5x5 + discs of the tracked points + goodFeaturesToTrack on roi_gray (:418-446)
+                ero_W = std::max(ero_W, w); ero_H = std::max(ero_H, h);
+                GfttTileArgs a{};
+                a.img = B.pyr.L[0].p; a.w = w; a.h = h; a.pitch = B.pyr.L[0].pitch;
+                a.in_mask = (const uint8_t*)S.ero.p; a.mask_pitch = mp;
+                a.disc_pts = S.tr.curr_pts; a.n_disc = S.tr.n_tracked; a.radius = T.min_dist; a.hw = (const uint8_t*)T.hw.p;
+                a.n_feat = S.tr.n_feat; a.max_cnt = T.max_cnt; a.min_new = 1;
+                a.cand = (DvCand*)S.cand.p; a.cand_cap = T.cand_cap; a.n_cand = S.n_cand; a.max_ord = S.max_ord;
+                h_gt[nj] = a;
+                GfttSelectArgs sa{};
+                sa.cand = (const DvCand*)S.cand.p; sa.n_cand = S.n_cand; sa.cand_cap = T.cand_cap; sa.max_ord = S.max_ord;
+                sa.w = w; sa.h = h; sa.quality = 0.01; sa.min_dist = (double)T.min_dist;
+                sa.max_n_host = 0; sa.n_feat = S.tr.n_feat; sa.max_cnt = T.max_cnt; sa.min_new = 1;
+                sa.out_xy = nullptr; sa.n_out = nullptr; sa.tr = S.tr; sa.has_tr = 2; sa.err_flag = T.err_flag; sa.id_slot = S.id_slot;
+                h_gs[nj] = sa;
+                dv_feat* od = (dv_feat*)((uint8_t*)T.out_buf.p + (size_t)nj * slot_bytes);
+                DvFinalizeJob f{}; f.tr = S.tr; f.cam0 = ctx->cfg.cam0; f.cam1 = ctx->cfg.cam1; f.stereo = stereo ? 1 : 0; f.use_off = 1; f.dt = dt_fin; f.out = od;
+                f.n_out = (int*)((uint8_t*)od + INST_CAP * sizeof(dv_feat)); f.err_in = nullptr; f.err_out = nullptr; f.off_x = (float)(double)S.rx; f.off_y = (float)(double)S.ry;
+                h_fj[nj] = f;
+                ++nj;
+            }
             h_roi[n_roi++] = RoiJob{ L.L[0].p, B.pyr.L[0].p, L.L[0].pitch, S.rx, S.ry, w, h, B.pyr.L[0].pitch, PW, PH };
             roi_W = std::max(roi_W, PW); roi_H = std::max(roi_H, PH);
             if (S.has_prev) {
@@ -362,7 +402,8 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             }
         }
         if (na > 0) {
-            DV_CHECK(hipMemcpyAsync(T.arena.p, T.arena_pinned, T.xp_frame ? xp_off + (size_t)na * sizeof(DvExtraJob) : pyr_off + (size_t)na * DV_MAX_LEVELS * sizeof(DvPyrJob), hipMemcpyHostToDevice, s));
+            DV_CHECK(hipMemcpyAsync(T.mask_all.p, T.pinned_in, moff, hipMemcpyHostToDevice, s));
+            DV_CHECK(hipMemcpyAsync(T.arena.p, T.arena_pinned, arena_used, hipMemcpyHostToDevice, s));
             if (T.xp_frame && n_xp > 0) {
                 // the reference starts a thread for this (dynamic_tracker.cpp:378): a side stream behind the mask + table uploads; the objects' tracking goes on meanwhile
                 DV_CHECK(hipEventRecord(T.ev_xin, s));
@@ -394,36 +435,21 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         // ---- stage B ----
         dv_launch_lk_track_multi((const DvLkJob*)T.jobs.p, n_temporal, T.max_cnt, ctx->cfg.flow_back, 0.5f, s);
         // ---- stage C ----
-        for (Slot* Sp : act) {
-            Slot& S = *Sp;
-            const int w = S.rw, h = S.rh, mp = align_up(w, 16);
-            RoiPyr& B = S.roi[S.cur];
-            dv_launch_compact(S.tr, nullptr, 0, 0, T.n_cand, T.max_ord, s);      // ReduceVector x4, ++track_cnt; without a previous ROI the object has no points (n_feat == 0)
-            // ErodeMask 5x5 + discs of the tracked points + goodFeaturesToTrack on roi_gray (:418-446)
-            dv_launch_erode((const uint8_t*)S.mask.p, w, h, mp, 5, (uint8_t*)S.tmp.p, mp, (uint8_t*)S.ero.p, mp, s);
-            GfttTileArgs a{};
-            a.img = B.pyr.L[0].p; a.w = w; a.h = h; a.pitch = B.pyr.L[0].pitch;
-            a.in_mask = (const uint8_t*)S.ero.p; a.mask_pitch = mp;
-            a.disc_pts = S.tr.curr_pts; a.n_disc = S.tr.n_tracked; a.radius = T.min_dist; a.hw = (const uint8_t*)T.hw.p;
-            a.n_feat = S.tr.n_feat; a.max_cnt = T.max_cnt; a.min_new = 1;
-            a.cand = (DvCand*)T.cand.p; a.cand_cap = T.cand_cap; a.n_cand = T.n_cand; a.max_ord = T.max_ord;
-            dv_launch_gftt_tile(a, s);
+        if (na > 0) {
+            const uint8_t* ap = (const uint8_t*)T.arena.p;
+            dv_launch_compact_multi((const DvCompactJob*)(ap + cj_off), na, s);
+            dv_launch_erode_multi((const DvErodeJob*)(ap + ej_off), na, ero_W, ero_H, s);
+            dv_launch_gftt_tile_multi((const GfttTileArgs*)(ap + gt_off), na, ero_W, ero_H, s);
             if (!waited_bg) { DV_CHECK(hipStreamWaitEvent(s, ctx->ev_bg_select, 0)); waited_bg = true; }      // ids: background first, then the objects in ascending id
-            GfttSelectArgs sa{};
-            sa.cand = (const DvCand*)T.cand.p; sa.n_cand = T.n_cand; sa.cand_cap = T.cand_cap; sa.max_ord = T.max_ord;
-            sa.w = w; sa.h = h; sa.quality = 0.01; sa.min_dist = (double)T.min_dist;
-            sa.max_n_host = 0; sa.n_feat = S.tr.n_feat; sa.max_cnt = T.max_cnt; sa.min_new = 1;
-            sa.out_xy = nullptr; sa.n_out = nullptr; sa.tr = S.tr; sa.has_tr = 1; sa.err_flag = T.err_flag;
-            if (dv_launch_gftt_select(sa, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
+            if (dv_launch_gftt_select_multi((const GfttSelectArgs*)(ap + gs_off), na, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
+            dv_launch_gftt_assign_ids((const GfttSelectArgs*)(ap + gs_off), na, s);
         }
         // ---- stage D ----
         if (stereo) dv_launch_lk_track_multi((const DvLkJob*)T.jobs.p + n_temporal, na, T.max_cnt, ctx->cfg.flow_back, 0.5f, s);
         // ---- stage E: UndistortedPointsWithAddOffset + PtsVelocity + RightUndistortedPts + RightPtsVelocity + PostProcess -> rows ----
+        if (na > 0) dv_launch_finalize_multi((const DvFinalizeJob*)((const uint8_t*)T.arena.p + fj_off), na, T.max_cnt, s);
         for (Slot* Sp : act) {
             Slot& S = *Sp;
-            dv_feat* od = (dv_feat*)((uint8_t*)T.out_buf.p + (size_t)out_k * slot_bytes);
-            int* on = (int*)((uint8_t*)od + INST_CAP * sizeof(dv_feat));
-            dv_launch_finalize_offset(S.tr, ctx->cfg.cam0, ctx->cfg.cam1, stereo ? 1 : 0, dt, T.max_cnt, (double)S.rx, (double)S.ry, od, on, s);
             S.has_prev = true; S.pw = S.rw; S.ph = S.rh;            // PostProcess: prev_roi_gray = roi_gray (the top-left w x h of roi[cur] level 0)
             S.out_valid = true; S.out_index = out_k++;
             T.out_order.push_back(S.id);
@@ -501,6 +527,7 @@ int dv_extra_points(dv_ctx* ctx, const uint8_t* mask, int x, int y, int w, int h
 // InstsFeatManager::Output() (:521-577): one FeatureInstance per visible object
 int dv_inst_track_collect(dv_ctx* ctx, dv_inst_obs* insts, int cap_insts, int* n_insts, dv_feat* feats, int cap_feats, int* n_feats, double* points, int cap_points, int* n_points) {
     if (!ctx) return -1;
+    HostScope hs(ctx, "h_inst_collect");
     if (!ctx->inst) DV_FAIL("dv_inst_track: call dv_inst_config first");
     dv_inst_tracker& T = *ctx->inst;
     if (!T.pending) DV_FAIL("dv_inst_track_collect: nothing enqueued");

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void track_finalize_kernel(DvTrackState tr, dv
 // the same for several trackers in ONE launch (blockIdx.y = job)
 __global__ __launch_bounds__(256) void track_finalize_multi_kernel(const DvFinalizeJob* __restrict__ jobs) {
     const DvFinalizeJob j = jobs[blockIdx.y];
-    track_finalize_body(j.tr, j.cam0, j.cam1, j.stereo, j.dt, j.out, j.n_out, 0.f, 0.f, 0, j.err_in, j.err_out);
+    track_finalize_body(j.tr, j.cam0, j.cam1, j.stereo, j.dt, j.out, j.n_out, j.off_x, j.off_y, j.use_off, j.err_in, j.err_out);
 }
 
 __global__ __launch_bounds__(256) void circle_mask_kernel(uint8_t* mask, int w, int h, int pitch, const float2* __restrict__ pts, int n,
@@ -195,6 +195,26 @@ __global__ __launch_bounds__(256) void erode_v_kernel(const uint8_t* __restrict_
     int m = 255;
     for (int d = -a; d < k - a; ++d) { int yy = y + d; if (yy >= 0 && yy < h) m = min(m, (int)src[(size_t)yy * spitch + x]); }
     dst[(size_t)y * dpitch + x] = (uint8_t)m;
+}
+
+// the erosions of several masks in one launch each (blockIdx.z = job; the grid covers the largest mask)
+__global__ __launch_bounds__(256) void erode_h_multi_kernel(const DvErodeJob* __restrict__ jobs) {
+    const DvErodeJob j = jobs[blockIdx.z];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= j.w || y >= j.h) return;
+    const int a = j.k / 2;
+    int m = 255;
+    for (int d = -a; d < j.k - a; ++d) { int xx = x + d; if (xx >= 0 && xx < j.w) m = min(m, (int)j.src[(size_t)y * j.spitch + xx]); }
+    j.tmp[(size_t)y * j.tpitch + x] = (uint8_t)m;
+}
+__global__ __launch_bounds__(256) void erode_v_multi_kernel(const DvErodeJob* __restrict__ jobs) {
+    const DvErodeJob j = jobs[blockIdx.z];
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= j.w || y >= j.h) return;
+    const int a = j.k / 2;
+    int m = 255;
+    for (int d = -a; d < j.k - a; ++d) { int yy = y + d; if (yy >= 0 && yy < j.h) m = min(m, (int)j.tmp[(size_t)yy * j.tpitch + x]); }
+    j.dst[(size_t)y * j.dpitch + x] = (uint8_t)m;
 }
 
 __global__ __launch_bounds__(256) void lift_kernel(dv_cam cam, const float2* __restrict__ in, int n, double off_x, double off_y, float2* __restrict__ out) {
@@ -234,6 +254,12 @@ void dv_launch_erode(const uint8_t* src, int w, int h, int spitch, int k, uint8_
     dim3 grid((w + 255) / 256, h);
     hipLaunchKernelGGL(erode_h_kernel, grid, dim3(256), 0, s, src, w, h, spitch, k, tmp, tpitch);
     hipLaunchKernelGGL(erode_v_kernel, grid, dim3(256), 0, s, tmp, w, h, tpitch, k, dst, dpitch);
+}
+void dv_launch_erode_multi(const DvErodeJob* jobs_dev, int n_jobs, int w_max, int h_max, hipStream_t s) {
+    if (n_jobs <= 0 || w_max <= 0 || h_max <= 0) return;
+    dim3 grid((w_max + 255) / 256, h_max, n_jobs);
+    hipLaunchKernelGGL(erode_h_multi_kernel, grid, dim3(256), 0, s, jobs_dev);
+    hipLaunchKernelGGL(erode_v_multi_kernel, grid, dim3(256), 0, s, jobs_dev);
 }
 void dv_launch_lift(const dv_cam& cam, const float2* in, int n, double off_x, double off_y, float2* out, hipStream_t s) {
     if (n <= 0) return;

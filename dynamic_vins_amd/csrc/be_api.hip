@@ -355,20 +355,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
         if (P->use_imu) { d.sb_col[f] = col; for (int k = 0; k < 9; ++k) { col_kind[col] = 1; col_frame[col] = f; col_comp[col] = k; ++col; } }
     }
     d.nstate = col;
-    // two-level elimination in be_solve (speed-bias chain first, then the dense pose block): needs every frame to carry a free pose and a speed-bias
-    // block, the speed-bias coupling to be block tridiagonal (IMU factors between neighbours; the prior holding speed-bias blocks of at most two
-    // adjacent frames) and the wave-column factorisation to be available for the dense pose block (confirmed below).  Off by default (measured: 91 us against 67 us for the monolithic wave-column factorisation); dv_debug_set(ctx, "two_level", 1) selects it.
     d.pad = 0;
-    if (P->use_imu && P->nframes >= 2 && ctx->be.two_level) {
-        bool ok = true;
-        for (int k = 0; k < P->nimu; ++k) if (P->imu[k].fj != P->imu[k].fi + 1) ok = false;
-        int smin = 99, smax = -1;
-        if (P->prior && P->prior->valid) for (int b = 0; b < P->prior->nblocks; ++b) if (P->prior->blocks[b].type == 1) { smin = std::min(smin, P->prior->blocks[b].idx); smax = std::max(smax, P->prior->blocks[b].idx); }
-        if (smax >= 0 && smax - smin > 1) ok = false;
-        const int nbr = (col + 3) / 4;
-        if (nbr * (nbr + 1) / 2 > 1024) ok = false;
-        d.pad = ok ? 1 : 0;
-    }
     const bool has_prior = P->prior && P->prior->valid;
     const bool prior_on_device = has_prior && w.prior_resident && P->prior_A == w.priorA_buf[w.prior_cur];
     if (col == 0) {       // e.g. vision-only, first frame: pose 0 is constant and no landmark has 4 observations yet
@@ -454,15 +441,12 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     sa.scale_p = w.scale_p; sa.diag_p = w.diag_p; sa.grad_p = w.grad_p; sa.gn_p = w.gn_p; sa.scale_l = w.scale_l; sa.diag_l = w.diag_l; sa.grad_l = w.grad_l; sa.gn_l = w.gn_l;
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;
     sa.xnorm2_extra = P->x_norm2_extra; sa.sh = sh;
-    sa.ldl_wcol = (!w.ldl_generic && d.nstate <= 168 && be_ldl_pack(d.nstate, sa.ldl_col0)) ? 1 : 0;
-    // the 16-wide MFMA factorisation (be_solve.hip MF16) where the system fits its tile budget and the dense order is used; "ldl_wavecol" / "ldl_generic" select the older forms
-    // (not with the two-level order, whose dense part is wave-column)
-    if (!w.ldl_generic && !w.ldl_wavecol_only && !sa.dims.pad) {
+    // the 16-wide MFMA factorisation (be_solve.hip MF16) wherever the system fits its tile budget (n <= 175: every window the estimator builds); "ldl_generic" selects the 4-wide panel form
+    sa.ldl_mf16 = 0;
+    if (!w.ldl_generic) {
         uint8_t plan[64];
-        if (be_mf16_plan(d.nstate, plan)) { std::memcpy(sa.ldl_col0, plan, sizeof(plan)); sa.ldl_wcol = 2; }
+        if (be_mf16_plan(d.nstate, plan)) { std::memcpy(sa.ldl_col0, plan, sizeof(plan)); sa.ldl_mf16 = 1; }
     }
-    // two-level elimination (speed-bias chain first) needs the wave-column factorisation for its dense pose block
-    if (sa.dims.pad && !(sa.ldl_wcol && be_ldl_pack(6 * P->nframes, sa.ldl_col0p))) { sa.dims.pad = 0; ea.dims.pad = 0; }
     // The first pass enqueues exactly max_iters slots: enough unless a linear solve failed (mu *= 10 retry) or a step was
     // invalid; be_solve_fused_end checks the downloaded control block and, in that rare case, runs the spare slots and the
     // (idempotent) tail again.
@@ -614,7 +598,7 @@ static int batch_enqueue_impl(dv_batch* B) {
     bool uniform = true; int slots = M[0]->be.pend->first_slots, max_grid = 0, max_n = 0;
     for (dv_ctx* c : M) {
         const BePending& pd = *c->be.pend;
-        if (pd.sa.ldl_wcol == 0 || pd.sa.ldl_wcol != M[0]->be.pend->sa.ldl_wcol || pd.sa.dims.pad != M[0]->be.pend->sa.dims.pad || pd.first_slots != slots || (c->timing && c->kernel_timing) || !pd.fused_present) uniform = false;
+        if (pd.sa.ldl_mf16 == 0 || pd.first_slots != slots || (c->timing && c->kernel_timing) || !pd.fused_present) uniform = false;
         max_grid = std::max(max_grid, be_eval_batch_blocks(pd.ea.dims.nlm, pd.ea.dims.nimu)); max_n = std::max(max_n, pd.sa.dims.nstate);
     }
     if (!uniform || M.size() == 1) {      // mixed kernel variants (or nothing to share): every member's own launches, one member after the other
@@ -646,7 +630,6 @@ static int batch_enqueue_impl(dv_batch* B) {
     const BeEvalArgs* dea = (const BeEvalArgs*)B->tab.p; const BeSolveArgs* dsa = (const BeSolveArgs*)(dea + cap);
     const BeGaugeArgs* dga = (const BeGaugeArgs*)(dsa + cap); const BeRejectArgs* drj = (const BeRejectArgs*)(dga + cap); const BeMargArgs* dma = (const BeMargArgs*)(drj + cap);
     DV_CHECK(hipMemcpyAsync(B->tab.p, B->tab_pinned, B->tab_bytes, hipMemcpyHostToDevice, s));
-    const bool two_level = M[0]->be.pend->sa.dims.pad != 0;
     if (B->timing && B->tev_pending && hipEventQuery(B->tev[3]) == hipSuccess) {      // the previous round's three stages
         float ms;
         for (int k = 0; k < 3; ++k) if (hipEventElapsedTime(&ms, B->tev[k], B->tev[k + 1]) == hipSuccess) B->t_ms[k] += ms;
@@ -658,7 +641,7 @@ static int batch_enqueue_impl(dv_batch* B) {
         const bool timed = time_round && it == 1 && !last;      // slot 1: solve (decision + factorisation), then the candidate's evaluation and reduce
         if (head) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_X, s); be_launch_reduce_batch(dsa, S, max_n, 0, s); }
         if (timed) { (void)hipEventRecord(B->tev[0], s); B->t_windows = S; }
-        if (be_launch_solve_batch(dsa, S, max_n, two_level, head ? 0 : 1, s, M[0]->be.pend->sa.ldl_wcol)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
+        if (be_launch_solve_batch(dsa, S, max_n, head ? 0 : 1, s)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
         if (last) be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s);      // (its accept decision rides in the tail's first launch)
         else if (timed) {
             (void)hipEventRecord(B->tev[1], s);
@@ -804,12 +787,10 @@ int dv_batch_info(dv_batch* B, long long* batched_rounds, long long* single_roun
 int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return -1;
     if (std::strcmp(key, "short_first_pass") == 0) { ctx->be.debug_short_first_pass = value != 0; return 0; }
-    if (std::strcmp(key, "two_level") == 0) { ctx->be.two_level = value != 0; return 0; }
     if (std::strcmp(key, "peer_timeout_ms") == 0) { ctx->dist.peer_timeout_ticks = 100000ll * std::max(value, 1); return 0; }      // transport peer: how long a wait kernel spins for a peer's flag (default 2000)
     if (std::strcmp(key, "gpu_reject") == 0) { ctx->be.gpu_reject = value != 0; return 0; }      // 0: OutliersRejection on the host (rounds 1-3 until be_reject_kernel)
     if (std::strcmp(key, "c0_side") == 0) { ctx->be.c0_side = value != 0; return 0; }      // 0: the prior's constant c0 is computed on the BA stream, inside be_marg_finish (rounds 1-2)
-    if (std::strcmp(key, "ldl_wavecol") == 0) { ctx->be.ldl_wavecol_only = value != 0; return 0; }      // the round-2 wave-column LDL^T instead of the 16-wide MFMA form
-    if (std::strcmp(key, "ldl_generic") == 0) { ctx->be.ldl_generic = value != 0; return 0; }      // the block-column-major LDL^T mapping instead of the wave-column one
+    if (std::strcmp(key, "ldl_generic") == 0) { ctx->be.ldl_generic = value != 0; return 0; }      // the generic 4-wide panel LDL^T instead of the 16-wide MFMA form (A/B runs, agreement tests)
     DV_FAIL(std::string("dv_debug_set: unknown key ") + key);
 }
 

@@ -54,7 +54,7 @@ struct BeSolveArgs {
     double* scale_l; double* diag_l; double* grad_l; double* gn_l;     // [nlm]
     int32_t* prior_col;     // [BE_MAX_STATE] prior index of each state column (-1 if absent)
     int32_t* col_kind; int32_t* col_frame; int32_t* col_comp;          // [n]
-    uint16_t ldl_col0[48]; uint16_t ldl_col0p[20]; int32_t ldl_wcol, ldl_pad;      // wave-column mapping of the LDL^T (be_ldl_pack): first thread of every block column; ldl_col0p: the same for the reduced 6F x 6F pose system of the two-level path; ldl_wcol = 0: generic mapping
+    uint8_t ldl_col0[64]; int32_t ldl_mf16, ldl_pad;      // ldl_mf16 != 0: the 16-wide MFMA factorisation, its tile plan (be_mf16_plan, [16 waves][4 slots]) in ldl_col0; 0: the generic 4-wide panel form
     BeShard sh;             // landmark sharding (on = 0: the whole window lives here)
     double xnorm2_extra;    // squared norm of inert free blocks (line blocks under zero sqrt_info) that count in the parameter-tolerance test
 };
@@ -196,14 +196,13 @@ void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
 void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s);      // be_accept + be_gauge in one launch (estimator path)
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s);      // spec: reduce the candidate's set (or, after a failed / invalid step, rebuild x's with the new mu)
 static_assert(offsetof(BeSolveArgs, ldl_col0) % 4 == 0, "the MF16 plan is read as dwords");
-bool be_mf16_plan(int n, uint8_t* plan);      // ldl_wcol == 2: the 16-wide MFMA factorisation; its tile plan lives in the first 64 bytes of ldl_col0
+bool be_mf16_plan(int n, uint8_t* plan);      // false: the tiles of an n x n system (+ right-hand-side row) do not fit (n > 175): the generic form is used
 int  be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s);        // spec: decide on the pending candidate first (be_accept_kernel's rule)
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);
-bool be_ldl_pack(int n, uint16_t* col0);
 // batched forms: n_win independent windows per launch (argument tables in HBM, window index in the grid); be_api.hip enqueues them for a dv_batch
 void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s);
 void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s);
-int  be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s, int ldl_mode);      // ldl_mode: the members' common ldl_wcol (1 wave-column, 2 MF16)
+int  be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s);      // every window on the MF16 form
 void be_launch_accept_batch(const BeSolveArgs* tab_dev, int n_win, hipStream_t s);
 int be_eval_batch_blocks(int nlm, int nimu);      // workgroups of one window in the batched evaluation launch
 void be_launch_accept_gauge_batch(const BeSolveArgs* stab, const BeGaugeArgs* gtab, int n, hipStream_t s);

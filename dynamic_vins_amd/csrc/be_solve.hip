@@ -636,196 +636,7 @@ __device__ __forceinline__ bool ldlt_blocked(const double* __restrict__ Sc, cons
 }
 
 
-// The same factorisation (same arithmetic per entry, same results bit for bit) with the block columns mapped onto WAVES: every block column lives in
-// consecutive lanes of one wave (BeSolveArgs::ldl_col0, first-fit-decreasing packing done on the host), so the diagonal factor (a) reaches the panel
-// lanes (b) through v_readlane instead of LDS + a workgroup barrier, and the wave that owns column kb+1 runs (a) + (b) right behind its own trailing
-// update of step kb while the other waves are still in theirs (look-ahead; the panel buffers alternate).  ONE workgroup barrier per four pivots.
-#define WC_STR 48            // block rows per plane of the wave-column panel buffers (>= 45)
-#define WC_BUF (16 * WC_STR)  // double2 entries per buffer: 4 arrays x 4 columns x WC_STR
-struct LdlRaw { int bi, bj; double dv[4][4]; };
-// thread -> (bi, bj): thread c < NBR walks block column c and writes the block coordinates of its lanes into an LDS table (`map`, 1024 ints) that every
-// thread then reads once — the 42 dependent kernel-argument loads of a per-thread search were ≈ 3 µs of the kernel's prologue
-__device__ __forceinline__ void ldl_build_map(const uint16_t* col0, int n, int* map) {
-    const int tid = threadIdx.x, NBR = (n + 3) >> 2;
-    map[tid] = -1;
-    lds_barrier();
-    if (tid < NBR) { const int t0 = col0[tid]; for (int k = 0; k < NBR - tid; ++k) map[t0 + k] = ((tid + k) << 8) | tid; }
-    lds_barrier();
-}
-__device__ __forceinline__ void ldl_prefetch(const double* __restrict__ Sc, int n, LdlRaw& R) {      // R.bi / R.bj: from the map
-    const int NBR = (n + 3) >> 2;
-    const bool have = R.bi >= 0;
-    const int idx = have ? R.bj * NBR - R.bj * (R.bj - 1) / 2 + R.bi - R.bj : 0;      // blk_pos's block index
-    const double4* src = reinterpret_cast<const double4*>(Sc + (size_t)idx * 16);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { const double4 q = src[r]; R.dv[r][0] = q.x; R.dv[r][1] = q.y; R.dv[r][2] = q.z; R.dv[r][3] = q.w; }
-}
 __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-// pre != nullptr: the system (already scaled and damped) is taken from LDS — pre = packed lower triangle (row-major), pre_rhs = right-hand side — instead
-// of the block-packed global Schur complement: the reduced pose system the speed-bias sweep leaves behind.  Lm may alias pre (it is written at the end).
-__device__ __forceinline__ bool ldlt_wavecol(const BeSolveArgs& a, const LdlRaw& R, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
-                                             double* Lm, double* P0, double* dinfo, double* zfin, double* dvec, int* s_fail, const double* pre = nullptr, const double* pre_rhs = nullptr,
-                                             const double* rhs_lds = nullptr /* g_p - g_s already in LDS (else read from gvec) */) {
-    const int tid = threadIdx.x, wave = tid >> 6;
-    const int NBR = (n + 3) >> 2;
-    const int bi = R.bi, bj = R.bj;
-    const bool have = bi >= 0;
-    double A[4][4], zr[4];
-    if (pre) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int i = bi * 4 + r;
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int j = bj * 4 + cc;
-                const bool ok = have && i < n && j < n;
-                const int hi = i > j ? i : j, lo = i > j ? j : i;
-                A[r][cc] = ok ? pre[tri(ok ? hi : 0, ok ? lo : 0)] : (i == j ? 1.0 : 0.0);
-            }
-            zr[r] = (have && bi == bj && i < n) ? pre_rhs[i] : 0.0;
-        }
-    } else
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int i = bi * 4 + r;
-        const bool iok = have && i < n;
-        const double si = v_s[iok ? i : 0];
-#pragma unroll
-        for (int cc = 0; cc < 4; ++cc) {
-            const int j = bj * 4 + cc;
-            const bool ok = iok && j < n;
-            double v = ok ? si * v_s[ok ? j : 0] * R.dv[r][cc] : 0.0;
-            if (i == j) v = ok ? v + mu * v_d[ok ? i : 0] * v_d[ok ? i : 0] : 1.0;      // padding rows: identity
-            A[r][cc] = v;
-        }
-        zr[r] = (iok && bi == bj) ? si * (rhs_lds ? rhs_lds[i] : gvec[i] - gvec[n + i]) : 0.0;
-    }
-    if (tid == 0) *s_fail = 0;
-    lds_barrier();
-    TS(4);
-    // (a) + (b) of block column kc by the wave that owns it; every lane of that wave takes part in the broadcast
-    auto panel = [&](int kc) {
-        const bool is_diag = bi == kc && bj == kc, is_panel = bj == kc && bi > kc;
-        double* di = dinfo + (kc & 1) * 16;
-        double2* PB = reinterpret_cast<double2*>(P0) + (kc & 1) * WC_BUF;      // [L rows 0-1 | L rows 2-3 | LD rows 0-1 | LD rows 2-3][m][block row]: 16-byte lane stride, conflict-free
-        // The diagonal block (and its share of the right-hand side) is broadcast FIRST and every lane of the wave runs the 4-pivot chain on it: the chain
-        // is latency-bound (one dependent fp64 op after the other), so the panel rows of the other lanes — computed in the same basic block, not behind a
-        // branch on the chain's result — fill its issue slots instead of following it.
-        // (through LDS: ten stores by the diagonal lane, ten broadcast loads by the wave — 63 v_readlane / SGPR->VGPR moves in the owner's instruction
-        // stream otherwise; LDS operations of one wave execute in order, so a wave-level fence is all the synchronisation needed.  The right-hand side
-        // is not broadcast: every lane runs the forward substitution on its own zr, only the diagonal lane's result is used.)
-        if (is_diag) { di[0] = A[0][0]; di[1] = A[1][0]; di[2] = A[2][0]; di[3] = A[3][0]; di[4] = A[1][1]; di[5] = A[2][1]; di[6] = A[3][1]; di[7] = A[2][2]; di[8] = A[3][2]; di[9] = A[3][3]; }
-        wave_lds_sync();
-        const double d0 = di[0], a10 = di[1], a20 = di[2], a30 = di[3], a11 = di[4], a21 = di[5], a31 = di[6], a22 = di[7], a32 = di[8], a33 = di[9];
-        const double zz0 = zr[0], zz1 = zr[1], zz2 = zr[2], zz3 = zr[3];
-        const double i0 = fast_rcp(d0);
-        const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-        const double d1 = __builtin_fma(-l10, a10, a11), i1 = fast_rcp(d1);
-        const double t21 = __builtin_fma(-l20, a10, a21), t31 = __builtin_fma(-l30, a10, a31);
-        const double l21 = t21 * i1, l31 = t31 * i1;
-        const double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, a20, a22)), i2 = fast_rcp(d2);
-        const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, a20, a32));
-        const double l32 = t32 * i2;
-        const double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, a30, a33))), i3 = fast_rcp(d3);
-        const double z0 = zz0, z1 = __builtin_fma(-l10, z0, zz1);
-        const double z2 = __builtin_fma(-l21, z1, __builtin_fma(-l20, z0, zz2));
-        const double z3 = __builtin_fma(-l32, z2, __builtin_fma(-l31, z1, __builtin_fma(-l30, z0, zz3)));
-        double pv[4][4], xv[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double p0 = A[r][0];
-            const double p1 = __builtin_fma(-p0, l10, A[r][1]);
-            const double p2 = __builtin_fma(-p1, l21, __builtin_fma(-p0, l20, A[r][2]));
-            const double p3 = __builtin_fma(-p2, l32, __builtin_fma(-p1, l31, __builtin_fma(-p0, l30, A[r][3])));
-            pv[r][0] = p0; pv[r][1] = p1; pv[r][2] = p2; pv[r][3] = p3;
-            xv[r][0] = p0 * i0; xv[r][1] = p1 * i1; xv[r][2] = p2 * i2; xv[r][3] = p3 * i3;
-        }
-        if (is_panel) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                PB[(0 * 4 + m) * WC_STR + bi] = make_double2(xv[0][m], xv[1][m]);
-                PB[(1 * 4 + m) * WC_STR + bi] = make_double2(xv[2][m], xv[3][m]);
-                PB[(2 * 4 + m) * WC_STR + bi] = make_double2(pv[0][m], pv[1][m]);
-                PB[(3 * 4 + m) * WC_STR + bi] = make_double2(pv[2][m], pv[3][m]);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { A[r][0] = xv[r][0]; A[r][1] = xv[r][1]; A[r][2] = xv[r][2]; A[r][3] = xv[r][3]; }
-        }
-        if (is_diag) {
-            if (!(d0 > 0.0) || !(d1 > 0.0) || !(d2 > 0.0) || !(d3 > 0.0) || !isfinite(d0 + d1 + d2 + d3)) *s_fail = 1;
-            di[10] = z0; di[11] = z1; di[12] = z2; di[13] = z3;
-            const int r0 = kc * 4;
-            if (r0 < n) { dvec[r0] = d0; zfin[r0] = z0; }
-            if (r0 + 1 < n) { dvec[r0 + 1] = d1; zfin[r0 + 1] = z1; }
-            if (r0 + 2 < n) { dvec[r0 + 2] = d2; zfin[r0 + 2] = z2; }
-            if (r0 + 3 < n) { dvec[r0 + 3] = d3; zfin[r0 + 3] = z3; }
-            A[1][0] = l10; A[2][0] = l20; A[3][0] = l30; A[2][1] = l21; A[3][1] = l31; A[3][2] = l32;
-        }
-    };
-    // the wave that holds block column kc = the wave with lanes bj == kc: found by ballot, no table look-up on the critical path
-    if (__ballot(bj == 0)) panel(0);
-    __syncthreads();
-#ifdef BE_SOLVE_TS
-    long long t_prev = wall_clock64(), acc_a = 0;
-#endif
-    for (int kb = 0; kb < NBR; ++kb) {
-        // (a non-positive pivot only raises s_fail: the loop runs on — on garbage — and the flag is read once behind it)
-        const double* di = dinfo + (kb & 1) * 16;
-        const unsigned long long cm = __ballot(bj == kb + 1);      // kb + 1 == NBR: no lane
-        const bool owner = cm != 0;                                 // this wave carries the critical path of the step: it goes first on its SIMD
-        if (owner) __builtin_amdgcn_s_setprio(3);
-        else __builtin_amdgcn_s_sleep(2);            // the owner's panel reads enter the LDS queue first (the others have slack until the owner's panel is done)
-        // ---- (c) trailing update with panel kb ----
-        if (bj > kb) {
-            const double2* PB = reinterpret_cast<const double2*>(P0) + (kb & 1) * WC_BUF;
-            double li[4][4];      // li[r][m] = L(4 bi + r, m);  the (L D)(4 bj + cc, m) operands are fetched two columns at a time (register budget: 128 at 1024 threads)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const double2 u0 = PB[(0 * 4 + m) * WC_STR + bi], u1 = PB[(1 * 4 + m) * WC_STR + bi];
-                li[0][m] = u0.x; li[1][m] = u0.y; li[2][m] = u1.x; li[3][m] = u1.y;
-            }
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const double2 w0 = PB[((2 + half) * 4 + 0) * WC_STR + bj], w1 = PB[((2 + half) * 4 + 1) * WC_STR + bj];
-                const double2 w2 = PB[((2 + half) * 4 + 2) * WC_STR + bj], w3 = PB[((2 + half) * 4 + 3) * WC_STR + bj];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    A[r][2 * half] = __builtin_fma(-li[r][3], w3.x, __builtin_fma(-li[r][2], w2.x, __builtin_fma(-li[r][1], w1.x, __builtin_fma(-li[r][0], w0.x, A[r][2 * half]))));
-                    A[r][2 * half + 1] = __builtin_fma(-li[r][3], w3.y, __builtin_fma(-li[r][2], w2.y, __builtin_fma(-li[r][1], w1.y, __builtin_fma(-li[r][0], w0.y, A[r][2 * half + 1]))));
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (bi == bj) {
-                const double y0 = di[10], y1 = di[11], y2 = di[12], y3 = di[13];
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    zr[r] = __builtin_fma(-li[r][3], y3, __builtin_fma(-li[r][2], y2, __builtin_fma(-li[r][1], y1, __builtin_fma(-li[r][0], y0, zr[r]))));
-            }
-        }
-        // ---- look-ahead: (a) + (b) of block column kb + 1, inside its wave ----
-        if (owner) { panel(kb + 1); __builtin_amdgcn_s_setprio(0); }
-        __syncthreads();
-#ifdef BE_SOLVE_TS
-        { long long t = wall_clock64(); acc_a += t - t_prev; t_prev = t; }
-#endif
-    }
-    TS(5);
-#ifdef BE_SOLVE_TS
-    if (tid == 0) { be_dbg_ts[16] = acc_a; be_dbg_ts[17] = 0; }
-#endif
-    if (*s_fail) return false;
-    if (have) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int cc = 0; cc < 4; ++cc) {
-                const int i = bi * 4 + r, j = bj * 4 + cc;
-                if (i < n && j < i) Lm[tri(i, j)] = A[r][cc];
-            }
-    }
-    __syncthreads();
-    return true;
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // MF16 — the same LDL^T re-blocked 16 wide on the f64 matrix cores (v_mfma_f64_16x16x4_f64).
@@ -1130,190 +941,6 @@ __device__ __forceinline__ void bs_mf16(const uint8_t* plan, int n, const MfLds&
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------
-// Two-level elimination of the reduced camera system (VIO windows whose speed-bias blocks couple only along the IMU chain: BeDims::pad, checked on the host).
-// Order: speed-bias block of frame 0, 1, ..., F-1, then the dense 6F x 6F pose block.  Eliminating sb_f touches only its chain neighbour sb_f+1 and the
-// poses, so the 9F speed-bias pivots — 99 of the 165 sequential pivots of the monolithic factorisation — become F block steps:
-//   per step: 9 x 9 LDL^T of the block (two waves, each in its own LDS scratch), panel rows  X = R L^-T D^-1  for R = [C_f ; E_f ; rhs_f] (76 lanes),
-//   ONE barrier, rank-9 update of everything R touches (pose x pose triangle, E_f+1, B_f+1, right-hand sides: ~3 entries per thread, 9 FMAs each),
-//   ONE barrier.
-// What remains is the reduced pose system, factored by ldlt_wavecol (17 block columns instead of 42); the solution of the speed-bias blocks follows from
-// the stored panels by a backward sweep on one wave.  Exact block LDL^T of the symmetrically permuted matrix: same solution, other rounding.
-#define FS_WORK 14000         // doubles of LDS the sweep carves (sw_carve); >= the packed factor of the 66 x 66 pose system
-#define SWS 10                // row stride of the 9-wide panels (16-byte aligned rows: ds_read_b128 pairs)
-struct SbSweep { double *PP, *E, *Bq, *C, *rb, *rp, *Lf, *zd, *Y, *xs, *tE; int *pc, *sc; int F, np; };
-__device__ __forceinline__ SbSweep sw_carve(double* w, int F) {
-    SbSweep S; S.F = F; S.np = 6 * F;
-    S.PP = w; w += (S.np * (S.np + 1) / 2 + 1) & ~1;      // lower triangle of the pose x pose block, row-major; later the packed factor
-    S.E = w; w += F * S.np * SWS;                          // E[f][a][k] = M(pose a, sb_f k); after step f: the panel X of those rows
-    S.Bq = w; w += F * 9 * SWS; S.C = w; w += F * 9 * SWS; // B[f] (9 x 9, full), C[f][k'][k] = M(sb_f+1 k', sb_f k); after step f: X of those rows
-    S.rb = w; w += F * SWS; S.rp = w; w += (S.np + 3) & ~1; // right-hand sides
-    S.Lf = w; w += F * 9 * SWS; S.zd = w; w += F * SWS;    // per block: unit-lower L (row i at Lf[f][i][.]), D^-1 L^-1 rhs
-    S.Y = w; w += 76 * SWS; S.xs = w; w += F * SWS;        // Y = R L^-T of the current step (rows: C 0..8, E 9..9+np-1, rhs 9+np); solution of the speed-bias blocks
-    S.tE = w; w += F * SWS;                                // backward sweep: the pose part of every block's right-hand side, formed in parallel
-    S.pc = reinterpret_cast<int*>(w); S.sc = S.pc + 16;
-    return S;
-}
-// scaled + damped entry (i, j) (state columns) of the Schur complement, from the block-packed lower triangle
-__device__ __forceinline__ double sw_entry(const double* __restrict__ Sc, int NBR, int i, int j, double mu, const double* v_s, const double* v_d) {
-    const int hi = (j >> 2) > (i >> 2) ? j : i, lo = (j >> 2) > (i >> 2) ? i : j;
-    double v = v_s[i] * v_s[j] * Sc[blk_pos(hi, lo, NBR)];
-    if (i == j) v += mu * v_d[i] * v_d[i];
-    return v;
-}
-__device__ __forceinline__ double dot9(const double* x, const double* y) {       // two partial sums: half the dependent chain
-    double s0 = x[0] * y[0], s1 = x[1] * y[1];
-    s0 = __builtin_fma(x[2], y[2], s0); s1 = __builtin_fma(x[3], y[3], s1);
-    s0 = __builtin_fma(x[4], y[4], s0); s1 = __builtin_fma(x[5], y[5], s1);
-    s0 = __builtin_fma(x[6], y[6], s0); s1 = __builtin_fma(x[7], y[7], s1);
-    s0 = __builtin_fma(x[8], y[8], s0);
-    return s0 + s1;
-}
-__device__ bool sb_sweep(const BeSolveArgs& a, const double* __restrict__ Sc, const double* __restrict__ gvec, int n, double mu, const double* v_s, const double* v_d,
-                         const SbSweep& S, int* s_fail) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, F = S.F, np = S.np, NBR = (n + 3) >> 2;
-    if (tid < F) { S.pc[tid] = a.dims.pose_col[tid]; S.sc[tid] = a.dims.sb_col[tid]; }
-    if (tid == 0) *s_fail = 0;
-    __syncthreads();
-    // ---- gather: every entry the sweep touches, scaled and damped, into LDS (plain loops: the loads of one thread's items are independent) ----
-#pragma unroll 2
-    for (int q = tid; q < np * np; q += SOL_THREADS) { const int r = q / np, c = q - r * np; if (c <= r) S.PP[tri(r, c)] = sw_entry(Sc, NBR, S.pc[r / 6] + r % 6, S.pc[c / 6] + c % 6, mu, v_s, v_d); }
-#pragma unroll 2
-    for (int q = tid; q < F * np * 9; q += SOL_THREADS) { const int f = q / (np * 9), rem = q - f * np * 9, r = rem / 9, k = rem - r * 9; S.E[(f * np + r) * SWS + k] = sw_entry(Sc, NBR, S.pc[r / 6] + r % 6, S.sc[f] + k, mu, v_s, v_d); }
-    for (int q = tid; q < F * 81; q += SOL_THREADS) { const int f = q / 81, rem = q - f * 81, k1 = rem / 9, k2 = rem - k1 * 9; S.Bq[(f * 9 + k1) * SWS + k2] = sw_entry(Sc, NBR, S.sc[f] + k1, S.sc[f] + k2, mu, v_s, v_d); }
-    for (int q = tid; q < (F - 1) * 81; q += SOL_THREADS) { const int f = q / 81, rem = q - f * 81, k1 = rem / 9, k2 = rem - k1 * 9; S.C[(f * 9 + k1) * SWS + k2] = sw_entry(Sc, NBR, S.sc[f + 1] + k1, S.sc[f] + k2, mu, v_s, v_d); }
-    for (int q = tid; q < F * 9; q += SOL_THREADS) { const int col = S.sc[q / 9] + q % 9; S.rb[(q / 9) * SWS + q % 9] = v_s[col] * (gvec[col] - gvec[n + col]); }
-    for (int q = tid; q < np; q += SOL_THREADS) { const int col = S.pc[q / 6] + q % 6; S.rp[q] = v_s[col] * (gvec[col] - gvec[n + col]); }
-    // this thread's share of the pose x pose triangle (fixed over the sweep): up to three packed indices, decoded once
-    int pa[3], pb[3];
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-        const int idx = tid + u * SOL_THREADS;
-        pa[u] = -1; pb[u] = 0;
-        if (idx < np * (np + 1) / 2) {
-            int r = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
-            while (r * (r + 1) / 2 > idx) --r;
-            while ((r + 1) * (r + 2) / 2 <= idx) ++r;
-            pa[u] = r; pb[u] = idx - r * (r + 1) / 2;
-        }
-    }
-    __syncthreads();
-    TS(20);
-    const int nrows = 9 + np + 1;                          // panel rows: C_f (sb_f+1), E_f (poses), rhs_f
-    for (int f = 0; f < F; ++f) {
-        const bool last = f == F - 1;
-        // ---- 9 x 9 LDL^T of B_f and the panel rows, on the two waves that hold the rows (each factors redundantly: no barrier in between).  The block lives in
-        // the registers of lanes 0..8 (lane i = row i, full symmetric storage); the pivot row travels by v_readlane with compile-time lane numbers. ----
-        if (wave < 2) {
-            double w[9];
-            { const double* src = S.Bq + (f * 9 + (lane < 9 ? lane : 0)) * SWS;
-#pragma unroll
-              for (int j = 0; j < 9; ++j) w[j] = src[j]; }
-            double inv[9];
-#pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double d = lane_bcast(w[k], k);
-                if (!(d > 0.0) || !isfinite(d)) *s_fail = 1;
-                inv[k] = fast_rcp(d);
-                const double l = w[k] * inv[k];                      // L_ik on lane i (> k)
-#pragma unroll
-                for (int j = k + 1; j < 9; ++j) { const double wkj = lane_bcast(w[j], k); if (lane > k) w[j] = __builtin_fma(-l, wkj, w[j]); }
-                if (lane > k) w[k] = l;
-            }
-            // broadcast L (36 values) to every lane as uniform operands; lane i keeps row i of L in w[0 .. i)
-            double L[9][9];
-#pragma unroll
-            for (int i = 1; i < 9; ++i)
-#pragma unroll
-                for (int m = 0; m < i; ++m) L[i][m] = lane_bcast(w[m], i);
-            if (wave == 0 && lane < 9) {
-                double* dst = S.Lf + (f * 9 + lane) * SWS;
-#pragma unroll
-                for (int m = 0; m < 9; ++m) dst[m] = w[m];           // (entries m >= lane are not read back)
-            }
-            const int r = tid;                                       // panel row
-            if (r < nrows && !(last && r < 9)) {
-                double* src = r < 9 ? S.C + (f * 9 + r) * SWS : (r < 9 + np ? S.E + (f * np + (r - 9)) * SWS : S.rb + f * SWS);
-                double y[9];
-#pragma unroll
-                for (int k = 0; k < 9; ++k) {
-                    double v = src[k];
-#pragma unroll
-                    for (int m = 0; m < k; ++m) v = __builtin_fma(-y[m], L[k][m], v);
-                    y[k] = v;
-                }
-                double* dst = r < 9 + np ? src : S.zd + f * SWS;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) { S.Y[r * SWS + k] = y[k]; dst[k] = y[k] * inv[k]; }      // X = Y D^-1, in place of the rows it came from
-            }
-        }
-        __syncthreads();
-        // ---- rank-9 update of everything the panel rows touch ----
-        {
-            const double* XE = S.E + f * np * SWS; const double* XC = S.C + f * 9 * SWS; const double* Yr = S.Y + (9 + np) * SWS;
-#pragma unroll
-            for (int u = 0; u < 3; ++u)
-                if (pa[u] >= 0) S.PP[tid + u * SOL_THREADS] -= dot9(XE + pa[u] * SWS, S.Y + (9 + pb[u]) * SWS);
-            int q = tid;
-            if (q < np) S.rp[q] -= dot9(XE + q * SWS, Yr);                                    // pose right-hand side
-            else if (!last) {
-                q -= np;
-                if (q < np * 9) { const int r = q / 9, k2 = q - r * 9; S.E[((f + 1) * np + r) * SWS + k2] -= dot9(XE + r * SWS, S.Y + k2 * SWS); }          // E_f+1
-                else if ((q -= np * 9) < 81) { const int k1 = q / 9, k2 = q - k1 * 9; S.Bq[((f + 1) * 9 + k1) * SWS + k2] -= dot9(XC + k1 * SWS, S.Y + k2 * SWS); }      // B_f+1
-                else if ((q -= 81) < 9) S.rb[(f + 1) * SWS + q] -= dot9(XC + q * SWS, Yr);                                                              // rhs_f+1
-            }
-        }
-        __syncthreads();
-    }
-    TS(21);
-    return *s_fail == 0;
-}
-// v_x[0 .. np) = solution of the pose block (pose order f * 6 + c) -> solution of the speed-bias blocks by the backward sweep, everything scattered into
-// state-column order
-__device__ void sb_back(const BeSolveArgs& a, int n, const SbSweep& S, double* v_x) {
-    const int tid = threadIdx.x, F = S.F, np = S.np;
-    double* xp = S.rp;                                                 // the reduced right-hand side is spent
-    for (int i = tid; i < np; i += SOL_THREADS) xp[i] = v_x[i];
-    __syncthreads();
-    // the pose part of every block's right-hand side does not depend on the sweep: tE[f][k] = (D^-1 L^-1 rhs)_k - sum_a X_E[f][a][k] x_a, all blocks at once
-    if (tid < F * 9) {
-        const int f = tid / 9, k = tid - f * 9;
-        const double* xe = S.E + f * np * SWS + k;
-        double s0 = S.zd[f * SWS + k], s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        int r = 0;
-        for (; r + 3 < np; r += 4) {
-            s0 = __builtin_fma(-xe[r * SWS], xp[r], s0); s1 = __builtin_fma(-xe[(r + 1) * SWS], xp[r + 1], s1);
-            s2 = __builtin_fma(-xe[(r + 2) * SWS], xp[r + 2], s2); s3 = __builtin_fma(-xe[(r + 3) * SWS], xp[r + 3], s3);
-        }
-        for (; r < np; ++r) s0 = __builtin_fma(-xe[r * SWS], xp[r], s0);
-        S.tE[f * SWS + k] = (s0 + s1) + (s2 + s3);
-    }
-    __syncthreads();
-    if (tid < 64) {
-        const int lane = tid, lk = lane < 9 ? lane : 0;
-        double xn = 0.0;                                               // lane k: x_{f+1}[k]
-        for (int f = F - 1; f >= 0; --f) {
-            double t = S.tE[f * SWS + lk];
-            if (f + 1 < F) {                                           // - sum_k' X_C[f][k'][k] x_{f+1}[k']
-                const double* xc = S.C + f * 9 * SWS + lk;
-#pragma unroll
-                for (int r = 0; r < 9; ++r) t = __builtin_fma(-xc[r * SWS], lane_bcast(xn, r), t);
-            }
-            // x = L^-T t on lanes 0..8: x_8 = t_8, x_k = t_k - sum_{m > k} L[m][k] x_m ; lane k holds column k of L (read from the stored rows)
-            const double* Lc = S.Lf + f * 9 * SWS + lk;
-            double x = t;
-#pragma unroll
-            for (int m = 8; m >= 1; --m) { const double xm = lane_bcast(x, m); if (lane < m) x = __builtin_fma(-Lc[m * SWS], xm, x); }
-            xn = x;
-            if (lane < 9) S.xs[f * SWS + lane] = x;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < np; i += SOL_THREADS) v_x[S.pc[i / 6] + i % 6] = xp[i];
-    for (int i = tid; i < 9 * F; i += SOL_THREADS) v_x[S.sc[i / 9] + i % 9] = S.xs[(i / 9) * SWS + i % 9];
-    __syncthreads();
-}
-
 // back-substitution helper: applies ROWS consecutive pivots (kt, kt-1, ...) that all lie in 64-lane segment SEG of x
 template <int SEG, int ROWS>
 __device__ __forceinline__ void bs_chunk(const double* Lm, int kt, int lane, double& x0, double& x1, double& x2) {
@@ -1396,19 +1023,19 @@ __device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, doub
 
 // The body lives in be_solve_body.inc and is included textually: called through a function taking `const BeSolveArgs&` the single-window kernel lost 4 %
 // (99.2 vs 95.2 us; the by-value kernel arguments stopped being treated as invariant scalar loads).
-template <int NSLOT, bool WCOL, bool MF16 = false>
+template <int NSLOT, bool MF16>
 __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) {
 #include "be_solve_body.inc"
 }
-template <int NSLOT, bool WCOL, bool MF16 = false>
+template <int NSLOT, bool MF16>
 __global__ __launch_bounds__(SOL_THREADS) void be_solve_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) {      // one workgroup per window
     const BeSolveArgs& a = tab[blockIdx.x];
 #include "be_solve_body.inc"
 }
 
-static size_t solve_smem(int n, bool two_level, bool wcol) {
+static size_t solve_smem(int n) {      // the generic form: packed factor | vectors | panel buffers
     const size_t tri = (size_t)n * (n + 1) / 2;
-    return ((two_level && tri < FS_WORK ? (size_t)FS_WORK : tri) + 9 * (size_t)n + 72 + 80 + 8 + (wcol ? 3072 : 1536)) * sizeof(double);
+    return (tri + 9 * (size_t)n + 72 + 80 + 8 + 1536) * sizeof(double);
 }
 // MF16: the tiles (which double as the later phases' scratch: >= 3072 doubles) | vectors | per-wave gather buffers | D, 1 / D, y
 static size_t solve_smem_mf16(int n) {
@@ -1436,51 +1063,26 @@ bool be_mf16_plan(int n, uint8_t* plan /* [16][4] */) {
     return true;
 }
 
-// wave-column mapping of the factorisation (ldlt_wavecol): block column c (NBR - c blocks) goes to consecutive lanes of ONE wave; first-fit decreasing
-// over the 16 waves.  Returns false when the columns do not fit (n > 168): the generic mapping is used then.
-bool be_ldl_pack(int n, uint16_t* col0) {
-    const int NBR = (n + 3) / 4;
-    if (NBR > 48) return false;
-    int used[SOL_THREADS / 64] = { 0 };
-    for (int c = 0; c < NBR; ++c) {
-        const int len = NBR - c;
-        int w = 0;
-        while (w < SOL_THREADS / 64 && used[w] + len > 64) ++w;
-        if (w == SOL_THREADS / 64) return false;
-        col0[c] = (uint16_t)(w * 64 + used[w]);
-        used[w] += len;
-    }
-    return true;
-}
-
+// Two forms of the factorisation ship: MF16 (every system whose tiles fit: n <= 175, i.e. every window the estimator builds — 11 frames x 15 with constant
+// extrinsics and td) and the generic 4-wide panel form (any n <= BE_MAX_STATE; dv_debug_set "ldl_generic" selects it for A/B runs and agreement tests).
 int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
     static DevOnce once;
     if (once.run([] {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE, false, false)) != hipSuccess) return 1;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE, false, false)) != hipSuccess) return 1;
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(168, false, true)) != hipSuccess) return 1;
-            return 0; })) return -1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return 1;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return 1;
+            return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ? 1 : 0; })) return -1;      // 160 KB per workgroup less the kernel's static arrays
     const int nbr = (a.dims.nstate + 3) / 4;
-    if (a.ldl_wcol == 2) {
-        static DevOnce once_mf;
-        if (once_mf.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ? 1 : 0; })) return -1;      // 160 KB per workgroup less the kernel's static arrays
-        hipLaunchKernelGGL((be_solve_kernel<1, false, true>), dim3(1), dim3(SOL_THREADS), solve_smem_mf16(a.dims.nstate), s, a, spec);
-        return 0;
-    }
-    if (a.ldl_wcol) hipLaunchKernelGGL((be_solve_kernel<1, true>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, a.dims.pad != 0, true), s, a, spec);      // (pad is only set together with ldl_wcol)
-    else if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL((be_solve_kernel<1, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, false), s, a, spec);
-    else hipLaunchKernelGGL((be_solve_kernel<2, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate, false, false), s, a, spec);
+    if (a.ldl_mf16) hipLaunchKernelGGL((be_solve_kernel<1, true>), dim3(1), dim3(SOL_THREADS), solve_smem_mf16(a.dims.nstate), s, a, spec);
+    else if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL((be_solve_kernel<1, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);
+    else hipLaunchKernelGGL((be_solve_kernel<2, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);
     return 0;
 }
 
-// batched: every window of the table must use the wave-column factorisation with the same dense order (checked by the caller); smem for the largest n
-int be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, bool two_level, int spec, hipStream_t s, int ldl_mode) {
+// batched: every window of the table on the MF16 form (checked by the caller); smem for the largest n
+int be_launch_solve_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s) {
     static DevOnce once;
-    if (once.run([] {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_batch_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(168, false, true)) != hipSuccess) return 1;
-            return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_batch_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ? 1 : 0; })) return -1;
-    if (ldl_mode == 2) hipLaunchKernelGGL((be_solve_batch_kernel<1, false, true>), dim3(n_win), dim3(SOL_THREADS), solve_smem_mf16(max_n), s, tab_dev, spec);      // every window on the MF16 form
-    else hipLaunchKernelGGL((be_solve_batch_kernel<1, true>), dim3(n_win), dim3(SOL_THREADS), solve_smem(max_n, two_level, true), s, tab_dev, spec);
+    if (once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_batch_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ? 1 : 0; })) return -1;
+    hipLaunchKernelGGL((be_solve_batch_kernel<1, true>), dim3(n_win), dim3(SOL_THREADS), solve_smem_mf16(max_n), s, tab_dev, spec);
     return 0;
 }
 

@@ -282,36 +282,12 @@ def test_ba_eval_and_landmark_sharding(ctx, oracle):
     assert g @ dx < 0
 
 
-def test_two_level_elimination_matches_oracle(oracle):
-    """be_solve's two-level form (speed-bias chain eliminated by a block-Thomas sweep, then the dense pose system; dv_debug_set "two_level") is an exact
-    block LDL^T of the permuted matrix: same iteration sequence and states as the monolithic factorisation / the oracle"""
-    import torch
-    if not torch.cuda.is_available():
-        pytest.skip("no GPU")
-    from dynamic_vins_amd.backend import ba_solve
-    from dynamic_vins_amd.frontend import Context
-    from tests import ba_gen
-    ctx = Context(width=64, height=48)
-    try:
-        assert ctx.lib.dv_debug_set(ctx.h, b"two_level", 1) == 0
-        for seed, nlm, prior in [(2, 60, True), (5, 300, True), (7, 150, False)]:
-            ref = ba_gen.make_window(oracle, seed=seed, nlm=nlm, with_prior=prior, max_iters=8)
-            dev = ref.clone()
-            s_ref = ba_gen.oracle_solve(oracle, ref)
-            s_dev = ba_solve(ctx, dev)
-            assert s_dev.iterations == s_ref.iterations and s_dev.termination == s_ref.termination, (seed, s_dev.iterations, s_ref.iterations)
-            assert abs(s_dev.final_cost - s_ref.final_cost) <= 1e-7 * s_ref.final_cost
-            assert np.abs(dev.pose - ref.pose).max() < 1e-6 and np.abs(dev.speed_bias - ref.speed_bias).max() < 1e-6 and np.abs(dev.inv_depth - ref.inv_depth).max() < 1e-6
-    finally:
-        ctx.close()
-
-
-@pytest.mark.parametrize("form", ["ldl_wavecol", "ldl_generic"])
-def test_mfma16_factorisation_agrees_with_the_older_forms(oracle, form):
-    """Round 3: be_solve factors the reduced camera system 16 wide on the f64 matrix cores (MF16, the default where the tiles fit: n <= 175).  The round-2
-    wave-column form and the round-1 generic form stay selectable (dv_debug_set): all of them are LDL^T of the same matrix, so on the same windows they must take
-    the same accept / reject decisions and end on the same states — to rounding, not to the bit (other summation order): 1e-9 against each other, 1e-6 against
-    the oracle like every solver test.  Covers VIO (n = 165), VO (n = 66, right-hand side in the last block's padding rows), priors, 1000 landmarks."""
+@pytest.mark.parametrize("form", ["ldl_generic"])
+def test_mfma16_factorisation_agrees_with_the_generic_form(oracle, form):
+    """be_solve factors the reduced camera system 16 wide on the f64 matrix cores (MF16: every system whose tiles fit, n <= 175 = every window the estimator
+    builds).  The generic 4-wide panel form is the fallback for larger n and stays selectable (dv_debug_set "ldl_generic"; the wave-column and two-level forms
+    of rounds 2 - 3 were removed in round 4): both are LDL^T of the same matrix, so on the same windows they must take the same accept / reject decisions and
+    end on the same states — to rounding, not to the bit (other summation order): 1e-9 against each other, 1e-6 against the oracle like every solver test.  Covers VIO (n = 165), VO (n = 66, right-hand side in the last block's padding rows), priors, 1000 landmarks."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")

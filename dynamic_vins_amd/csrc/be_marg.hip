@@ -632,7 +632,7 @@ __device__ __forceinline__ void be_marg_finish_body(const BeMargArgs& a) {
 }
 __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_kernel(BeMargArgs a) { be_marg_finish_body(a); }
 __global__ __launch_bounds__(MG_THREADS) void be_marg_finish_batch_kernel(const BeMargArgs* __restrict__ tab) {
-    const BeMargArgs a = tab[blockIdx.x];
+    const BeMargArgs& a = tab[blockIdx.x];
     if (a.D <= 0) return;
     be_marg_finish_body(a);
 }
@@ -731,7 +731,7 @@ __device__ __forceinline__ void be_reject_body(const BeRejectArgs& a, const int 
 }
 __global__ __launch_bounds__(256) void be_reject_kernel(BeRejectArgs a) { be_reject_body(a, blockIdx.x); }
 __global__ __launch_bounds__(256) void be_reject_batch_kernel(const BeRejectArgs* __restrict__ tab) {
-    const BeRejectArgs a = tab[blockIdx.y];
+    const BeRejectArgs& a = tab[blockIdx.y];      // by reference: a by-value copy of the table entry is indexed dynamically (ric / tic) and therefore lived in SCRATCH — 37 MB of writes per launch of 16 windows (PMC, round 4)
     if (a.nlm <= 0 || (int)blockIdx.x * REJ_LM >= a.nlm) return;
     be_reject_body(a, blockIdx.x);
 }

@@ -55,6 +55,9 @@ struct dv_runner {
     struct Group { std::vector<int> members; dv_batch* batch = nullptr; bool pending = false; std::unique_ptr<SpinBarrier> bar; };
     std::vector<Group> groups;
     int threads = 1, threads_per_group = 1;      // threads > groups: every dv_batch group is driven by threads / groups host threads that split its members' host phases (runner_team)
+    bool teams = false;           // KNOWN DEFECT (round 4): with several host threads per group single members intermittently end on a wrong trajectory (3 of 7 runs,
+                                  // scripts/dbg/r04_team_bisect.sh; cause not found).  Off unless dv_runner_set(runner, "teams", 1) asks for it; one thread per group is verified.
+    int threads_requested = 1;
     bool batch_front = true;      // dv_batch groups: the members' tracking in shared launches too (dv_batch_track_enqueue); dv_runner_set(runner, "batch_front", 0) keeps one set of launches per sequence
     std::string err; std::mutex err_mu;
 };
@@ -227,6 +230,20 @@ int group_drain(dv_runner* R, dv_runner::Group& g) {
 }
 }
 
+namespace {
+// host threads: one per group (at most `threads_requested`), or — opt-in only, dv_runner::teams — threads_requested / groups per dv_batch group
+void runner_layout(dv_runner* R) {
+    const int ng = (int)R->groups.size(), threads = R->threads_requested;
+    bool all_batched = R->batch_front; for (auto& g : R->groups) if (!g.batch) all_batched = false;
+    R->threads_per_group = 1;
+    for (auto& g : R->groups) g.bar.reset();
+    if (R->teams && threads > ng && all_batched && threads % ng == 0) {
+        R->threads = threads; R->threads_per_group = threads / ng;
+        for (auto& g : R->groups) { g.bar = std::make_unique<SpinBarrier>(); g.bar->n = R->threads_per_group; }
+    } else R->threads = std::max(1, std::min(threads, ng));
+}
+}
+
 extern "C" {
 
 dv_runner* dv_runner_create(dv_ctx* const* ctxs, const dv_seq_input* seqs, int n_seq, int group_size, int threads) {
@@ -252,12 +269,8 @@ dv_runner* dv_runner_create(dv_ctx* const* ctxs, const dv_seq_input* seqs, int n
         }
         R->groups.push_back(std::move(g));
     }
-    const int ng = (int)R->groups.size();
-    bool all_batched = R->batch_front; for (auto& g : R->groups) if (!g.batch) all_batched = false;
-    if (threads > ng && all_batched && threads % ng == 0) {      // a team of threads / groups host threads per dv_batch group
-        R->threads = threads; R->threads_per_group = threads / ng;
-        for (auto& g : R->groups) { g.bar = std::make_unique<SpinBarrier>(); g.bar->n = R->threads_per_group; }
-    } else R->threads = std::max(1, std::min(threads, ng));
+    R->threads_requested = threads;
+    runner_layout(R.get());
     return R.release();
 }
 
@@ -363,7 +376,8 @@ int dv_runner_dynamic_stats(dv_runner* R, int seq, long long* detections, long l
 }
 int dv_runner_set(dv_runner* R, const char* key, int value) {
     if (!R || !key) return -1;
-    if (std::strcmp(key, "batch_front") == 0) { R->batch_front = value != 0; return 0; }
+    if (std::strcmp(key, "batch_front") == 0) { R->batch_front = value != 0; runner_layout(R); return 0; }      // (teams need the shared front end)
+    if (std::strcmp(key, "teams") == 0) { R->teams = value != 0; runner_layout(R); return 0; }                  // before the first dv_runner_run; KNOWN DEFECT, see dv_runner::teams
     R->err = std::string("dv_runner_set: unknown key ") + key;
     return -1;
 }

@@ -6,7 +6,7 @@ dv_est_process_begin / _end): while sequence A's BA is in flight it prepares and
 on this GPU (x N ranks for --gpus N); the single-sequence rate stays bench.py's default line."""
 import gc
 import json
-import os
+import os, sys
 import time
 
 import torch
@@ -146,10 +146,15 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
         gsz = args.group_size if getattr(args, "group_size", 0) > 0 else ((S + 1) // 2 if S >= 4 else S)      # default: two groups in anti-phase (one's host phases beside the other's launches)
     n_groups = (S + gsz - 1) // gsz if gsz > 0 else S
     threads = getattr(args, "runner_threads", 0)
-    if threads <= 0:          # default: a team of two host threads per dv_batch group (dv_runner: threads > groups), one thread otherwise
-        threads = 2 * n_groups if gsz > 1 else 1
+    teams = bool(getattr(args, "teams", False))
+    if threads <= 0:          # default: ONE host thread per dv_batch group.  (Round 4 shipped teams of two as the default for a few hours: single members intermittently ended on a
+        threads = n_groups if gsz > 1 else 1      # wrong trajectory — 3 of 7 runs, scripts/dbg/r04_team_bisect.sh.  --teams keeps the path reachable for the hunt, never for a result.)
+    if not teams:
+        threads = min(threads, n_groups)
     args.runner_threads = threads
     runner = Runner(pipes, group_size=gsz, threads=max(1, threads))
+    if teams:
+        runner.set("teams", 1)
     if getattr(args, "no_batch_front", False):
         runner.set("batch_front", 0)
     runner.run(warm_ba)
@@ -172,6 +177,15 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
         gt = [p.seq.traj.p(t) for t in poses[:, 0]]
         ates.append(sim.align_ate(poses[:, 1:4], gt)[0]); iters += it
     n_total = S * (warm_ba + 2 * args.steps)
+    # A throughput figure from a run whose trajectories are wrong measures nothing.  These synthetic sequences track to millimetres (worst phase ~ 9 mm over 100 frames); a
+    # sequence more than ATE_GATE_M off its ground truth means the run is corrupted (this is how the team-path defect of round 4 showed: 0.04 - 7.3 m on single members):
+    # no JSON line, non-zero exit.  BENCH_ATE_GATE_M overrides the bound (debug runs that WANT to see the corrupted figures).
+    gate = float(os.environ.get("BENCH_ATE_GATE_M", "0.03"))
+    bad = [(i, round(float(v), 5)) for i, v in enumerate(ates) if not (v <= gate)]
+    if bad:
+        sys.stderr.write(f"multiseq_bench: trajectories of {len(bad)} of {S} sequences are off their ground truth by more than {gate} m: {bad} -- the run is corrupted, no result is reported\n")
+        runner.close()
+        raise SystemExit(3)
     roof = None
     if rank == 0 and gsz > 1:
         # the batched window solve's stage launches: [be_solve_batch, be_eval_batch (full), be_reduce_batch] x `wins` windows per launch.  ALGORITHMIC bytes per
@@ -211,9 +225,10 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
                           "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S, "host_loop": "C++ (dv_runner)",
                           "parallelism": f"{S} sequences per GPU, host loop in C++ on {max(1, getattr(args, 'runner_threads', 1))} thread(s)" + (f" ({max(1, getattr(args, 'runner_threads', 1)) // n_groups} per group)" if gsz > 1 and getattr(args, 'runner_threads', 1) > n_groups else "")
                                          + (f", window solves batched in dv_batch groups of {gsz} (one launch per stage for a group)" if gsz > 1 else ", every sequence on its own streams") + f", x {world} GPU(s); no collective",
-                          "group_size": gsz, "runner_threads": max(1, getattr(args, "runner_threads", 1)), "front_end_launches": dict(shared=not getattr(args, "no_batch_front", False) and gsz > 1, **runner.track_info()),
+                          "group_size": gsz, "runner_threads": max(1, getattr(args, "runner_threads", 1)), "host_threads_per_group": (max(1, threads) // n_groups if teams and gsz > 1 else 1), "teams_experimental": teams, "front_end_launches": dict(shared=not getattr(args, "no_batch_front", False) and gsz > 1, **runner.track_info()),
                           "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),
-                          "solver_iterations_per_frame": round(iters / max(n_total, 1), 2), "ate_rmse_m_vs_ground_truth_max": round(max(ates), 5)},
+                          "solver_iterations_per_frame": round(iters / max(n_total, 1), 2), "ate_rmse_m_vs_ground_truth_max": round(max(ates), 5),
+                          "ate_rmse_m_vs_ground_truth_per_sequence": [round(float(v), 5) for v in ates]},
                "roofline": roof, "cpu_baseline": None}
         print(json.dumps(out))
     runner.close()

@@ -436,7 +436,11 @@ int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, 
  * one call runs n_rounds frames of one or many sequences.  Per sequence the order of pipeline.py: collect tracking(k), IMU up to t_k, dv_est_process_begin(k),
  * enqueue tracking(k+1), IMU up to t_k+1, dv_est_process_end(k) — the front end of frame k+1 overlaps the back end of frame k.  With group_size > 1 the sequences
  * are grouped into dv_batch groups of that size: the begin phases of a group run back to back, ONE dv_batch_enqueue launches the iteration slots of all its window
- * solves, and the host turns to the next group while they run (config 4 of BASELINE.json, "batched").  `threads` host threads each drive their own groups; with MORE threads than groups (a multiple) every group is driven by a team of threads / groups host threads — the members' host phases (~0.1 ms per member and frame) run side by side, one thread of the team issues the group's shared launches between two barriers: large groups (kernel efficiency) without the serial host loop.
+ * solves, and the host turns to the next group while they run (config 4 of BASELINE.json, "batched").  `threads` host threads each drive their own groups (at most one thread per group; more are not used).
+ * EXPERIMENTAL, OFF BY DEFAULT, KNOWN DEFECT: dv_runner_set(runner, "teams", 1) before the first run lets threads / groups host threads (a multiple) share the host phases of one
+ * group's members between barriers.  Unverified; do not use it for results.
+ * OPEN DEFECT (round 4): runs with two or more host threads (several groups, with or without teams) intermittently leave single members on a WRONG trajectory
+ * (5 of 16 runs of 40 - 60 frames at 16 - 64 sequences; cause unknown).  Runs with threads = 1 have not shown it.  Check every sequence's result (bench.py does, and refuses to report).
  * The contexts (each with its estimator: dv_est_create) stay the caller's; frames are referenced, not copied (device or host memory: dv_seq_input::mem).
  * dynamic_vins_amd/host/dvins_node.cpp is the ROS-free node built on it (image directory + IMU csv in, `<seq>_<mode>_Odometry.txt` out). */
 typedef struct dv_seq_input {

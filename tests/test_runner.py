@@ -17,7 +17,7 @@ def make(n_seq, frames, w=752, h=480):
 
 @pytest.mark.parametrize("group_size,threads", [(0, 1), (3, 1), (2, 2), (4, 2), (2, 4)])
 def test_runner_equals_python_pipeline(group_size, threads):
-    """(4, 2): ONE group of four driven by a team of two host threads; (2, 4): two groups with a team of two each"""
+    """(4, 2) / (2, 4): more threads than groups are asked for — the runner uses ONE thread per group (teams are an opt-in with a known defect, next test)"""
     from dynamic_vins_amd.backend import Runner
     from dynamic_vins_amd.pipeline import Pipeline
     S, frames = 4 if threads >= 2 else 3, 30
@@ -37,6 +37,33 @@ def test_runner_equals_python_pipeline(group_size, threads):
     runner.close()
     for p in pipes + ref:
         p.ctx.close()
+
+
+@pytest.mark.xfail(strict=False, reason="OPEN DEFECT (round 4): multi-sequence runs with >= 2 host threads intermittently leave single members on a wrong trajectory "
+                                        "(5 of 16 bench runs of 40 - 60 frames, with and without teams; cause unknown, DESIGN.md 0).  This case covers the team opt-in only")
+def test_team_path_is_bit_identical_to_one_thread_per_group():
+    """The experimental team path against the verified one (one host thread per group) on the SAME sequences, bit for bit, long enough and often enough to meet the
+    intermittent corruption that 30-frame runs of 4 members never showed: 8 members in one group, teams of 2 and of 4, 70 frames, three repetitions each."""
+    from dynamic_vins_amd.backend import Runner
+    S, frames = 8, 70
+    seqs, pipes = make(S, frames)
+    ref = Runner(pipes, group_size=S, threads=1)
+    ref.run(frames - 1)
+    want = [ref.get(i)[1].copy() for i in range(S)]
+    ref.close()
+    for p in pipes:
+        p.ctx.close()
+    for T in (2, 4, 2, 4, 2, 4):
+        _, pp = make(S, frames)
+        r = Runner(pp, group_size=S, threads=T)
+        r.set("teams", 1)
+        r.run(frames - 1)
+        got = [r.get(i)[1].copy() for i in range(S)]
+        r.close()
+        for p in pp:
+            p.ctx.close()
+        for i in range(S):
+            assert got[i].shape == want[i].shape and np.array_equal(got[i], want[i]), f"teams of {T}: sequence {i} differs from the one-thread-per-group run"
 
 
 def test_batch_stage_timing_leaves_the_results_alone():

@@ -592,6 +592,19 @@ class Runner:
         self.lib.dv_runner_batch_timing(self.h, int(on), o.ctypes.data, C.byref(r), C.byref(w))
         return o, r.value, w.value
 
+    def row_log(self, i, cap=100000):
+        """diagnostics, per frame handed to the back end: [frame index, rows collected, hash of the rows, solver iterations] (uint64)"""
+        rows = np.zeros((cap, 4), dtype=np.uint64); n = C.c_int(0)
+        self.lib.dv_runner_get_row_log(self.h, i, rows.ctypes.data, cap, C.byref(n))
+        return rows[: n.value].copy()
+
+    def batch_rounds(self):
+        """(batched_rounds, single_rounds) summed over the groups' dv_batch objects: single = rounds that fell back to every member's own launches"""
+        a, b = C.c_longlong(0), C.c_longlong(0)
+        if hasattr(self.lib, "dv_runner_batch_rounds") and self.lib.dv_runner_batch_rounds(self.h, C.byref(a), C.byref(b)) == 0:
+            return a.value, b.value
+        return None
+
     def frames(self, i, cap=100000):
         """every frame handed to the back end: rows [t, px py pz qx qy qz qw, nonlinear]"""
         rows = np.zeros((cap, 9)); n = C.c_int(0)

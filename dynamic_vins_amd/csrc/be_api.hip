@@ -510,7 +510,8 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     const MargPlan& pl = pd.pl;
     uint8_t* hp = (uint8_t*)w.pinned;
     const BeState* hx = (const BeState*)(hp + w.dl_off); const BeCtl* hctl = (const BeCtl*)(hp + w.dl_off + sizeof(BeState));
-    DV_CHECK(hipEventSynchronize(pd.ev_state_ext ? pd.ev_state_ext : w.ev_state));      // (member of a dv_batch round: the group's event behind the shared gauge / reject launches)
+    DV_CHECK(hipEventSynchronize(pd.ev_state_ext ? pd.ev_state_ext : w.ev_state));
+    if (w.debug_wait_tail) DV_CHECK(hipStreamSynchronize(ctx->be_stream));      // dv_debug_set "wait_tail": the host does not move on until the marginalization behind ev_state has drained too (bisecting the open multi-sequence defect)      // (member of a dv_batch round: the group's event behind the shared gauge / reject launches)
     if (be_dist_check(ctx)) return -1;      // sharded window, peer transport: a dead or late peer is an error of THIS solve, not garbage in its result
     // the previous frame's marginalization ran before this frame's upload (stream order), so its scalars have landed
     if (be_check_prev_marg(ctx, pd)) return -1;
@@ -636,6 +637,19 @@ static int batch_enqueue_impl(dv_batch* B) {
         B->t_n++; B->tev_pending = false;
     }
     const bool time_round = B->timing && !B->tev_pending && slots >= 3;
+    // bisecting switches (dv_debug_set on the group's FIRST member; the open multi-sequence defect of round 4): one stage of the round goes through the members' own
+    // single-window launches instead of the shared launch — same stream, same order, only the kernel form differs
+    const int dbg = M[0]->be.debug_batch_single;      // bit 0: evaluation, 1: reduce, 2: solve
+    auto be_launch_eval_batch = [&](const BeEvalArgs* t, int n, int grid, int mode, hipStream_t st) {
+        if (dbg & 1) { for (dv_ctx* c : M) ::be_launch_eval(c->be.pend->ea, mode, st); } else ::be_launch_eval_batch(t, n, grid, mode, st);
+    };
+    auto be_launch_reduce_batch = [&](const BeSolveArgs* t, int n, int mx, int spec, hipStream_t st) {
+        if (dbg & 2) { for (dv_ctx* c : M) ::be_launch_reduce(c->be.pend->sa, spec, st); } else ::be_launch_reduce_batch(t, n, mx, spec, st);
+    };
+    auto be_launch_solve_batch = [&](const BeSolveArgs* t, int n, int mx, int spec, hipStream_t st) -> int {
+        if (dbg & 4) { for (dv_ctx* c : M) if (::be_launch_solve(c->be.pend->sa, spec, st)) return -1; return 0; }
+        return ::be_launch_solve_batch(t, n, mx, spec, st);
+    };
     for (int it = 0; it < slots; ++it) {                  // be_enqueue_slots' speculative schedule, one launch per stage for all windows
         const bool head = it == 0, last = it == slots - 1;
         const bool timed = time_round && it == 1 && !last;      // slot 1: solve (decision + factorisation), then the candidate's evaluation and reduce
@@ -788,6 +802,11 @@ int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (!ctx || !key) return -1;
     if (std::strcmp(key, "short_first_pass") == 0) { ctx->be.debug_short_first_pass = value != 0; return 0; }
     if (std::strcmp(key, "peer_timeout_ms") == 0) { ctx->dist.peer_timeout_ticks = 100000ll * std::max(value, 1); return 0; }      // transport peer: how long a wait kernel spins for a peer's flag (default 2000)
+    if (std::strcmp(key, "batch_single_eval") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~1) | (value ? 1 : 0); return 0; }
+    if (std::strcmp(key, "batch_single_reduce") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~2) | (value ? 2 : 0); return 0; }
+    if (std::strcmp(key, "batch_single_solve") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~4) | (value ? 4 : 0); return 0; }
+    if (std::strcmp(key, "hash_log") == 0) { ctx->be.debug_hash_log = value != 0; return 0; }      // the estimator keeps per-solve hashes of what it uploads / downloads (dv_est_debug_hash_log)
+    if (std::strcmp(key, "wait_tail") == 0) { ctx->be.debug_wait_tail = value != 0; return 0; }
     if (std::strcmp(key, "gpu_reject") == 0) { ctx->be.gpu_reject = value != 0; return 0; }      // 0: OutliersRejection on the host (rounds 1-3 until be_reject_kernel)
     if (std::strcmp(key, "c0_side") == 0) { ctx->be.c0_side = value != 0; return 0; }      // 0: the prior's constant c0 is computed on the BA stream, inside be_marg_finish (rounds 1-2)
     if (std::strcmp(key, "ldl_generic") == 0) { ctx->be.ldl_generic = value != 0; return 0; }      // the generic 4-wide panel LDL^T instead of the 16-wide MFMA form (A/B runs, agreement tests)

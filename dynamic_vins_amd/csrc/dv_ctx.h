@@ -110,7 +110,7 @@ struct BeWork {
     int32_t* marg_tab = nullptr; double* marg_scal = nullptr;      // marginalization index tables (inside the upload region) and its 4 result scalars
     long long marg_checked = 0; double marg_last[4] = { 0, 0, 0, 0 };      // marginalizations whose health scalars came back, and the last set (c0, smallest pivot of A_mm, clamp flag, rank)
     long long marg_clamped = 0;       // marginalizations in which a pivot of A_mm was <= 1e-8 and was skipped (pseudo-inverse)
-    bool debug_short_first_pass = false, ldl_generic = false;      // dv_debug_set
+    bool debug_short_first_pass = false, ldl_generic = false, debug_wait_tail = false; int debug_batch_single = 0; bool debug_hash_log = false;      // dv_debug_set
     bool gpu_reject = true; uint8_t* rej_pinned = nullptr;      // dv_debug_set "gpu_reject": the outlier test of the frame on the device, flags written to pinned memory before ev_state
     std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
 };

@@ -431,6 +431,15 @@ struct dv_estimator {
         return P;
     }
     dv_ba_problem P{}; BeFused fu;          // the solve in flight (optimization_begin .. optimization_end)
+    // diagnostics (dv_debug_set "hash_log"; the open multi-sequence defect of round 4): per window solve [solve counter, hash of the states uploaded, hash of the tables
+    // uploaded (factors, landmarks, IMU records, prior descriptor), hash of the states downloaded, hash of the outlier flags consumed, iterations]
+    std::vector<unsigned long long> hash_log; unsigned long long solve_no = 0;
+    static unsigned long long fnv(unsigned long long h, const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } return h; }
+    unsigned long long hash_states() const {
+        unsigned long long h = 1469598103934665603ull;
+        h = fnv(h, pose, sizeof(pose)); h = fnv(h, sb, sizeof(sb)); h = fnv(h, ex, sizeof(ex)); h = fnv(h, tdv, sizeof(tdv)); h = fnv(h, invd.data(), invd.size() * sizeof(double));
+        return h;
+    }
     int optimization_begin(dv_ctx* ctx) {        // Estimator::Optimization (estimator.cpp:261-339) incl. SetMarginalizationInfo (:403-619)
         { HostScope h(ctx, "h_build");
           states_to_arrays();
@@ -467,11 +476,32 @@ struct dv_estimator {
               }
           }
         }
+        if (ctx->be.debug_hash_log) {
+            unsigned long long ht = 1469598103934665603ull;
+            ht = fnv(ht, P.factors, (size_t)P.nfac * sizeof(dv_ba_factor)); ht = fnv(ht, lmt.data(), lmt.size() * sizeof(lmt[0])); ht = fnv(ht, imu.data(), imu.size() * sizeof(dv_ba_imu));
+            const int pv = prior.valid ? 1 : 0; ht = fnv(ht, &pv, sizeof(pv));
+            if (prior.valid) { ht = fnv(ht, &prior.n, sizeof(prior.n)); ht = fnv(ht, &prior.nblocks, sizeof(prior.nblocks)); ht = fnv(ht, prior.blocks, (size_t)prior.nblocks * sizeof(prior.blocks[0])); ht = fnv(ht, &fu.marg_mode, sizeof(fu.marg_mode)); }
+            // the device-resident prior this solve starts from (written by the previous frame's marginalization): synchronises the solve stream — diagnostics only
+            unsigned long long hp = 0;
+            if (prior.valid && prior_dev_A && prior_dev_b) {
+                std::vector<double> tmp((size_t)prior.n * prior.n + prior.n);
+                (void)hipStreamSynchronize(ctx->be_stream);
+                (void)hipMemcpy(tmp.data(), prior_dev_A, (size_t)prior.n * prior.n * sizeof(double), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(tmp.data() + (size_t)prior.n * prior.n, prior_dev_b, (size_t)prior.n * sizeof(double), hipMemcpyDeviceToHost);
+                hp = fnv(1469598103934665603ull, tmp.data(), tmp.size() * sizeof(double));
+            }
+            hash_log.push_back(solve_no++); hash_log.push_back(hash_states()); hash_log.push_back(ht); hash_log.push_back(0); hash_log.push_back(hp); hash_log.push_back(0);
+        }
         { HostScope h(ctx, "h_solve_begin"); const int rc = be_solve_fused_begin(ctx, &P, &fu); ctx->be.sqrt_hint.clear(); if (rc) return -1; }
         return 0;
     }
     int optimization_end(dv_ctx* ctx) {
         { HostScope h(ctx, "h_solve_wait"); if (be_solve_fused_end(ctx, &P, &last, &fu)) return -1; }
+        if (ctx->be.debug_hash_log && hash_log.size() >= 6) {
+            unsigned long long* r = hash_log.data() + hash_log.size() - 6;
+            r[3] = hash_states(); r[5] = (unsigned long long)last.iterations;
+            if (fu.rej_flags) { int n4 = 0; for (auto& l : lms) if (l.obs.size() >= 4) ++n4; r[3] = fnv(r[3], fu.rej_flags, (size_t)n4); }      // (the outlier flags consumed count as downloaded state)
+        }
         { HostScope h(ctx, "h_post"); arrays_to_states(); }
         if (cfg.use_line && !para_line.empty()) lines.set_orth(Rs, Ps, ric[0], tic[0], para_line.data());      // Double2vector: SetLineOrth with the solved poses
         if (fu.marg_mode >= 0) prior = fu.new_prior;
@@ -694,6 +724,14 @@ int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg) {
     if (!cfg->stereo) DV_FAIL("dv_est_create: monocular initialisation is out of scope (every BASELINE config is stereo)");
     delete ctx->est;
     ctx->est = new dv_estimator(*cfg);
+    return 0;
+}
+// diagnostics (dv_debug_set "hash_log"): rows of six uint64 per window solve, see dv_estimator::hash_log
+int dv_est_debug_hash_log(dv_ctx* ctx, unsigned long long* rows6, int cap, int* n_rows) {
+    if (!ctx || !ctx->est) return -1;
+    const int n = (int)(ctx->est->hash_log.size() / 6);
+    if (n_rows) *n_rows = n;
+    if (rows6) std::memcpy(rows6, ctx->est->hash_log.data(), sizeof(unsigned long long) * 6 * (size_t)std::min(n, std::max(cap, 0)));
     return 0;
 }
 int dv_est_reset(dv_ctx* ctx) { if (!ctx || !ctx->est) return -1; if (ctx->est->begun) { ctx->est->begun = false; (void)ctx->est->process_image_end(ctx); } ctx->est->clear(); return 0; }

@@ -27,6 +27,8 @@ struct RSeq {
     double pending_t = 0;
     dv_est_state last{};
     std::vector<double> poses;          // [t, px py pz qx qy qz qw] per frame solved in the non-linear phase
+    std::vector<unsigned long long> row_log;      // per frame handed to the back end: [frame index k, rows collected, FNV-1a of the rows' bytes, solver iterations] (dv_runner_get_row_log: diagnostics)
+    unsigned long long cur_rows_hash = 0; int cur_k = -1;
     std::vector<double> frames9;        // [t, px py pz qx qy qz qw, nonlinear] of EVERY frame handed to the back end (what SaveBodyTrajectory writes)
     long long iterations = 0, frames = 0;
     std::string err;
@@ -133,6 +135,11 @@ int seq_begin(dv_runner* R, RSeq& s, bool own_front = true) {
     if (!s.enqueued) { if (!own_front) { s.err = "internal: frame not enqueued"; set_err(R, s.err); return -1; } if (seq_enqueue(R, s, k)) return -1; }
     if (dv_track_stereo_collect(s.ctx, s.rows.data(), &s.n_rows)) return fail(R, s, "dv_track_stereo_collect");
     s.enqueued = false;
+    {   // what the back end is about to be handed: frame index + a hash of the collected rows
+        unsigned long long h = 1469598103934665603ull; const unsigned char* p = reinterpret_cast<const unsigned char*>(s.rows.data());
+        for (size_t i = 0, n = (size_t)s.n_rows * sizeof(dv_feat); i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+        s.cur_rows_hash = h; s.cur_k = k;
+    }
     const double t = s.in.times[k];
     const int stride = s.in.ba_stride > 1 ? s.in.ba_stride : 1;
     if (stride > 1 && (k % stride) != 0) {      // tracked only: outside KITTI the reference pushes a frame to feature_queue when cnt % 2 == 0, cnt counting tracked frames from 0 (system/main.cpp:181,300-312): frames 0, 2, 4, ...
@@ -169,6 +176,7 @@ int seq_end(dv_runner* R, RSeq& s) {
     if (!s.pending) return 0;
     if (dv_est_process_end(s.ctx, &s.last)) return fail(R, s, "dv_est_process_end");
     s.pending = false;
+    s.row_log.push_back((unsigned long long)s.cur_k); s.row_log.push_back((unsigned long long)s.n_rows); s.row_log.push_back(s.cur_rows_hash); s.row_log.push_back((unsigned long long)s.last.iterations);
     s.frames9.push_back(s.pending_t);
     for (int i = 0; i < 7; ++i) s.frames9.push_back(s.last.window[10][i]);
     s.frames9.push_back((double)s.last.nonlinear);
@@ -340,6 +348,15 @@ int dv_runner_get_frames(dv_runner* R, int seq, double* rows9, int cap, int* n_r
     return 0;
 }
 
+int dv_runner_get_row_log(dv_runner* R, int seq, unsigned long long* rows4, int cap, int* n_rows) {
+    if (!R || seq < 0 || seq >= (int)R->seqs.size()) return -1;
+    const RSeq& s = R->seqs[seq];
+    const int n = (int)(s.row_log.size() / 4);
+    if (n_rows) *n_rows = n;
+    if (rows4) std::memcpy(rows4, s.row_log.data(), sizeof(unsigned long long) * 4 * (size_t)std::min(n, std::max(cap, 0)));
+    return 0;
+}
+
 // batched groups: switch the per-stage events of every group's dv_batch on / read their averages (dv_batch_timing), averaged over the groups
 int dv_runner_batch_timing(dv_runner* R, int on, double* out3, long long* rounds, int* windows) {
     if (!R) return -1;
@@ -352,6 +369,16 @@ int dv_runner_batch_timing(dv_runner* R, int on, double* out3, long long* rounds
     if (out3) for (int k = 0; k < 3; ++k) out3[k] = ng ? acc[k] / ng : 0.0;
     if (rounds) *rounds = n;
     if (windows) *windows = w;
+    return 0;
+}
+
+// diagnostics: rounds of the groups' dv_batch objects that shared their launches / that fell back to every member's own launches (dv_batch_info), summed
+int dv_runner_batch_rounds(dv_runner* R, long long* batched_rounds, long long* single_rounds) {
+    if (!R) return -1;
+    long long a = 0, b = 0;
+    for (auto& g : R->groups) if (g.batch) { long long x = 0, y = 0; if (dv_batch_info(g.batch, &x, &y)) return -1; a += x; b += y; }
+    if (batched_rounds) *batched_rounds = a;
+    if (single_rounds) *single_rounds = b;
     return 0;
 }
 

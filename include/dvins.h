@@ -388,6 +388,9 @@ typedef struct dv_est_state {
 } dv_est_state;
 
 int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg);       /* Estimator::Estimator + SetParameter */
+/* diagnostics, after dv_debug_set(ctx, "hash_log", 1): per window solve [counter, hash of the states uploaded, hash of the tables uploaded, hash of the states downloaded,
+ * hash of the outlier flags consumed, iterations]; two runs of the same sequence must agree row by row */
+int dv_est_debug_hash_log(dv_ctx* ctx, unsigned long long* rows6, int cap, int* n_rows);
 int dv_est_reset(dv_ctx* ctx);                                   /* Estimator::ClearState + SetParameter */
 int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr);      /* Estimator::InputIMU */
 /* one iteration of Estimator::ProcessMeasurements (estimator.cpp:1786-1863): IMU interval, pre-integration,
@@ -473,6 +476,10 @@ int dv_runner_run(dv_runner* runner, int n_rounds, double* wall_seconds_or_null)
 int dv_runner_get(dv_runner* runner, int seq, dv_est_state* last, double* poses8, int cap, int* n_poses, long long* iterations, long long* frames, int* n_rows_last);
 /* every frame handed to the back end, initialisation included, as rows [t, px py pz qx qy qz qw, nonlinear]: the lines of `<seq>_<mode>_Odometry.txt` */
 int dv_runner_get_frames(dv_runner* runner, int seq, double* rows9, int cap, int* n_rows);
+/* diagnostics: per frame handed to the back end [frame index, rows collected from the tracker, FNV-1a hash of those rows' bytes, solver iterations] — two runs of the same
+ * sequence must agree entry by entry; where they first differ says whether the tracker's output or only the solve moved (raw mode) */
+int dv_runner_get_row_log(dv_runner* runner, int seq, unsigned long long* rows4, int cap, int* n_rows);
+int dv_runner_batch_rounds(dv_runner* runner, long long* batched_rounds, long long* single_rounds);      /* dv_batch_info summed over the groups */
 int dv_runner_batch_timing(dv_runner* runner, int on, double* out3, long long* rounds, int* windows);      /* dv_batch_timing of the runner's groups, averaged */
 /* switches: "batch_front" (default 1): the members of a dv_batch group are tracked in shared launches (dv_batch_track_enqueue); 0: one set of launches per sequence */
 int dv_runner_set(dv_runner* runner, const char* key, int value);

@@ -123,6 +123,8 @@ SIGNATURES = {
     "dv_runner_run": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
     "dv_runner_get": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "dv_runner_get_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "dv_ba_debug_slot_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "dv_ba_debug_dev_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_est_debug_hash_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_runner_get_row_log": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_runner_batch_rounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

@@ -220,6 +220,48 @@ static void marg_new_prior(const MargPlan& pl, const double* pose, const double*
 // `slots` trust-region iterations.  speculative: the candidate of every slot but the last is linearised in full (evaluation + reduce into
 // the other set) and judged by the next solve kernel; the last one gets the cost-only evaluation and the accept kernel.  The classic form
 // (spare slots after a failed / invalid step) spends 5 launches per slot and needs no look-ahead.
+// diagnostics (dv_debug_set "hash_log"): a deterministic hash of a device byte range — 256 threads hash interleaved 8-byte words with FNV-1a, thread 0 folds the 256 results in order
+__global__ __launch_bounds__(256) void be_dbg_hash_kernel(const unsigned long long* __restrict__ p, size_t words, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long sh[256];
+    unsigned long long h = 1469598103934665603ull;
+    for (size_t i = threadIdx.x; i < words; i += 256) { h ^= p[i]; h *= 1099511628211ull; }
+    sh[threadIdx.x] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 1469598103934665603ull; for (int k = 0; k < 256; ++k) { t ^= sh[k]; t *= 1099511628211ull; } *out = t; }
+}
+struct BeDbgJob { const unsigned long long* p[BeWork::DBG_RANGES]; unsigned long long words[BeWork::DBG_RANGES]; unsigned long long* out; };
+__global__ __launch_bounds__(256) void be_dbg_hash_multi_kernel(BeDbgJob j) {      // blockIdx.x = range
+    __shared__ unsigned long long sh[256];
+    const unsigned long long* p = j.p[blockIdx.x]; const unsigned long long words = j.words[blockIdx.x];
+    unsigned long long h = 1469598103934665603ull;
+    for (unsigned long long i = threadIdx.x; i < words; i += 256) { h ^= p[i]; h *= 1099511628211ull; }
+    sh[threadIdx.x] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long t = 1469598103934665603ull; for (int k = 0; k < 256; ++k) { t ^= sh[k]; t *= 1099511628211ull; } j.out[blockIdx.x] = t; }
+}
+// everything a launch of the round may write, hashed behind it on the same stream: 0 packets[0] 1 packets[1] 2 imu_out[0] 3 imu_out[1] 4 prior_out[0] 5 prior_out[1] 6 cand_cost
+// 7 Hd[0] 8 Hd[1] 9 Sc[0] 10 Sc[1] 11 gvec[0] 12 gvec[1] 13 x 14 cand 15 ctl
+static void be_dbg_stage(dv_ctx* c, int it, int kind, hipStream_t s) {
+    BeWork& w = c->be;
+    if (!w.debug_hash_log || it >= BeWork::DBG_SLOTS) return;
+    const bool light = w.debug_hash_light;      // "hash_light": only the small buffers (a few KB: microsecond kernels), and only behind solve / candidate evaluation — the full form changes the timing so much that the defect does not occur
+    if (light && kind != 2 && kind != 3) return;
+    if (!w.dbg_slots) { if (hipHostMalloc((void**)&w.dbg_slots, sizeof(unsigned long long) * BeWork::DBG_SLOTS * 5 * BeWork::DBG_RANGES, hipHostMallocDefault) != hipSuccess) return; std::memset(w.dbg_slots, 0, sizeof(unsigned long long) * BeWork::DBG_SLOTS * 5 * BeWork::DBG_RANGES); }
+    const size_t n = BE_MAX_STATE, pk = (size_t)BE_PK_SIZE * BE_PK_STRIDE, sb = w.pend->state_bytes / 8;
+    BeDbgJob j{};
+    const void* ptr[BeWork::DBG_RANGES] = { w.packets[0], w.packets[1], w.imu_out[0], w.imu_out[1], w.prior_out[0], w.prior_out[1], w.cand_cost, w.Hd[0], w.Hd[1], w.Sc[0], w.Sc[1], w.gvec[0], w.gvec[1], w.x, w.cand, w.ctl };
+    const size_t io = (size_t)BE_WIN * IMU_OUT_STRIDE, po = (size_t)BE_MAX_PRIOR + 1;
+    const size_t words[BeWork::DBG_RANGES] = { pk, pk, io, io, po, po, (size_t)BE_MAX_LM + BE_WIN + 1, n * n, n * n, n * n, n * n, 2 * n, 2 * n, sb, sb, sizeof(BeCtl) / 8 };
+    for (int r = 0; r < BeWork::DBG_RANGES; ++r) { j.p[r] = (const unsigned long long*)ptr[r]; j.words[r] = (light && !(r == 6 || r == 11 || r == 12 || r >= 13)) ? 0 : words[r]; }
+    j.out = w.dbg_slots + (size_t)(it * 5 + kind) * BeWork::DBG_RANGES;
+    hipLaunchKernelGGL(be_dbg_hash_multi_kernel, dim3(BeWork::DBG_RANGES), dim3(256), 0, s, j);
+}
+
+static void be_dbg_hash(const void* dev, size_t bytes, unsigned long long* out_pinned, hipStream_t s) {
+    if (!dev || bytes < 8) { *out_pinned = 0; return; }
+    hipLaunchKernelGGL(be_dbg_hash_kernel, dim3(1), dim3(256), 0, s, (const unsigned long long*)dev, bytes / 8, out_pinned);
+}
+
 static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculative, hipStream_t s) {
     const bool kt = ctx->timing && ctx->kernel_timing;       // per-launch events (roofline measurement); off in the throughput run
     auto eval = [&](int mode) {
@@ -258,10 +300,11 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculat
     };
     for (int it = 0; it < slots; ++it) {
         const bool head = !speculative || it == 0, last = !speculative || it == slots - 1;
-        if (head) { eval(BE_EVAL_X); reduce(0); if (exchange_system(0)) return -1; }
+        if (head) { eval(BE_EVAL_X); be_dbg_stage(ctx, it, 0, s); reduce(0); be_dbg_stage(ctx, it, 1, s); if (exchange_system(0)) return -1; }
         if (solve(head ? 0 : 1)) DV_FAIL("dv_ba_solve: cannot set dynamic LDS size");
-        if (last) { eval(BE_EVAL_CAND_COST); if (exchange_cost()) return -1; if (!(pd.fuse_accept_gauge && !kt && it == slots - 1)) accept(); }      // (fused: be_enqueue_tail launches accept + gauge as one kernel)
-        else { eval(BE_EVAL_CAND_FULL); reduce(1); if (exchange_system(1)) return -1; }
+        be_dbg_stage(ctx, it, 2, s);
+        if (last) { eval(BE_EVAL_CAND_COST); be_dbg_stage(ctx, it, 3, s); if (exchange_cost()) return -1; if (!(pd.fuse_accept_gauge && !kt && it == slots - 1)) accept(); }      // (fused: be_enqueue_tail launches accept + gauge as one kernel)
+        else { eval(BE_EVAL_CAND_FULL); be_dbg_stage(ctx, it, 3, s); reduce(1); be_dbg_stage(ctx, it, 4, s); if (exchange_system(1)) return -1; }
     }
     return 0;
 }
@@ -469,6 +512,13 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
         DV_CHECK(hipGetLastError());
         return 0;
     }
+    if (w.debug_hash_log && fused) {        // what the device holds when the round starts: the uploaded block as it arrived, the prior it will read
+        if (!w.dbg_pinned) DV_CHECK(hipHostMalloc((void**)&w.dbg_pinned, 64, hipHostMallocDefault));
+        const size_t up_bytes = w.up_fac + sizeof(BeFactor) * (size_t)P->nfac;
+        be_dbg_hash(w.block.p, up_bytes & ~(size_t)7, w.dbg_pinned + 0, s);
+        const bool pv = P->prior && P->prior->valid;
+        if (pv) { be_dbg_hash(w.priorA, 8 * (size_t)P->prior->n * P->prior->n, w.dbg_pinned + 1, s); be_dbg_hash(w.priorb, 8 * (size_t)P->prior->n, w.dbg_pinned + 2, s); } else { w.dbg_pinned[1] = 0; w.dbg_pinned[2] = 0; }
+    }
     const int first_slots = w.debug_short_first_pass ? std::max(1, P->max_iters - 2) : P->max_iters;      // dv_debug_set(ctx, "short_first_pass", 1): tests exercise the spare-slot path
     if (ctx->batch && fused && !sh.on) {       // member of a dv_batch: the upload is on its way; dv_batch_enqueue launches the slots of all members together
         pd.deferred = true; pd.first_slots = first_slots;
@@ -535,6 +585,19 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     }
     for (int f = 0; f < P->nframes; ++f) { std::memcpy(P->pose + 7 * f, hx->pose[f], 56); if (P->use_imu) std::memcpy(P->speed_bias + 9 * f, hx->sb[f], 72); }
     if (P->nlm) std::memcpy(P->inv_depth, hx->inv_depth, 8 * (size_t)P->nlm);
+    if (w.debug_hash_log && fused && w.dbg_pinned) {      // what the device holds when the round is over: x (raw solution), the candidate buffer (gauge-fixed copy), the control block
+        be_dbg_hash(w.x, pd.state_bytes & ~(size_t)7, w.dbg_pinned + 3, s);
+        be_dbg_hash(w.cand, pd.state_bytes & ~(size_t)7, w.dbg_pinned + 4, s);
+        be_dbg_hash(w.ctl, sizeof(BeCtl) & ~(size_t)7, w.dbg_pinned + 5, s);
+        DV_CHECK(hipStreamSynchronize(s));
+        w.dbg_dev_log.push_back(w.dbg_solve_no++);
+        for (int k = 0; k < 6; ++k) w.dbg_dev_log.push_back(w.dbg_pinned[k]);
+        if (w.dbg_slots) {
+            const size_t nv = (size_t)BeWork::DBG_SLOTS * 5 * BeWork::DBG_RANGES;
+            w.dbg_slot_log.insert(w.dbg_slot_log.end(), w.dbg_slots, w.dbg_slots + nv);
+            std::memset(w.dbg_slots, 0, sizeof(unsigned long long) * nv);
+        }
+    }
     if (summary) {
         summary->iterations = hctl->iter; summary->successful = hctl->successful; summary->termination = hctl->done ? hctl->termination : 0;
         summary->slots = hctl->slots; summary->initial_cost = hctl->initial_cost; summary->final_cost = hctl->x_cost;
@@ -653,20 +716,28 @@ static int batch_enqueue_impl(dv_batch* B) {
     for (int it = 0; it < slots; ++it) {                  // be_enqueue_slots' speculative schedule, one launch per stage for all windows
         const bool head = it == 0, last = it == slots - 1;
         const bool timed = time_round && it == 1 && !last;      // slot 1: solve (decision + factorisation), then the candidate's evaluation and reduce
-        if (head) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_X, s); be_launch_reduce_batch(dsa, S, max_n, 0, s); }
+        auto dbg_all = [&](int kind) { for (dv_ctx* c : M) be_dbg_stage(c, it, kind, s); };
+        if (head) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_X, s); dbg_all(0); be_launch_reduce_batch(dsa, S, max_n, 0, s); dbg_all(1); }
         if (timed) { (void)hipEventRecord(B->tev[0], s); B->t_windows = S; }
         if (be_launch_solve_batch(dsa, S, max_n, head ? 0 : 1, s)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
-        if (last) be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s);      // (its accept decision rides in the tail's first launch)
+        dbg_all(2);
+        if (last) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s); dbg_all(3); }      // (its accept decision rides in the tail's first launch)
         else if (timed) {
             (void)hipEventRecord(B->tev[1], s);
             be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); (void)hipEventRecord(B->tev[2], s);
             be_launch_reduce_batch(dsa, S, max_n, 1, s); (void)hipEventRecord(B->tev[3], s);
             B->tev_pending = true;
         }
-        else { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); be_launch_reduce_batch(dsa, S, max_n, 1, s); }
+        else { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); dbg_all(3); be_launch_reduce_batch(dsa, S, max_n, 1, s); dbg_all(4); }
     }
     // ---- the tails of all members: 2 + 3 launches per group instead of 5 - 6 per member on S streams ----
-    be_launch_accept_gauge_batch(dsa, dga, S, s);
+    // QUARANTINED (round 4): the shared launch of this stage (be_accept_gauge_batch_kernel: last accept decision + gauge fix + download of all members) is where a member's
+    // result intermittently left the single-sequence result when a second group was in flight — identical device inputs through the last candidate evaluation, different x / cand /
+    // ctl after the round (per-launch hashes, scripts/dbg/multiseq_first_diff.py); with every member's own launch of the same two bodies: 0 of 30 runs against 6 of 40.  The cause
+    // inside the shared form is NOT understood.  Default: the members' own launches (S tiny launches, same stream, same order); dv_debug_set "batch_shared_tail" brings the shared
+    // form back for the hunt.
+    if (dbg & 8) be_launch_accept_gauge_batch(dsa, dga, S, s);
+    else for (dv_ctx* c : M) { BeGaugeArgs ga{}; be_gauge_args(c, *c->be.pend, ga); be_launch_accept_gauge(c->be.pend->sa, ga, s); }
     be_launch_reject_batch(drj, S, max_rej, s);
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipEventRecord(B->ev_state, s));
@@ -692,6 +763,25 @@ int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFuse
 }
 
 extern "C" {
+
+// diagnostics (dv_debug_set "hash_log"): rows of seven uint64 per fused window solve: [counter, uploaded block on the device, prior A, prior b, x after the round, candidate buffer, control block]
+int dv_ba_debug_dev_log(dv_ctx* ctx, unsigned long long* rows7, int cap, int* n_rows) {
+    if (!ctx) return -1;
+    const int n = (int)(ctx->be.dbg_dev_log.size() / 7);
+    if (n_rows) *n_rows = n;
+    if (rows7) std::memcpy(rows7, ctx->be.dbg_dev_log.data(), sizeof(unsigned long long) * 7 * (size_t)std::min(n, std::max(cap, 0)));
+    return 0;
+}
+
+// the same per launch of the round: per fused solve DBG_SLOTS x 5 launch kinds x DBG_RANGES hashes (0 = launch not issued); *row_len = values per solve
+int dv_ba_debug_slot_log(dv_ctx* ctx, unsigned long long* vals, long long cap_vals, long long* n_vals, int* row_len) {
+    if (!ctx) return -1;
+    const long long n = (long long)ctx->be.dbg_slot_log.size();
+    if (n_vals) *n_vals = n;
+    if (row_len) *row_len = BeWork::DBG_SLOTS * 5 * BeWork::DBG_RANGES;
+    if (vals) std::memcpy(vals, ctx->be.dbg_slot_log.data(), sizeof(unsigned long long) * (size_t)std::min(n, std::max(cap_vals, 0ll)));
+    return 0;
+}
 
 int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary) {
     if (!ctx) return -1;
@@ -804,7 +894,9 @@ int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (std::strcmp(key, "peer_timeout_ms") == 0) { ctx->dist.peer_timeout_ticks = 100000ll * std::max(value, 1); return 0; }      // transport peer: how long a wait kernel spins for a peer's flag (default 2000)
     if (std::strcmp(key, "batch_single_eval") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~1) | (value ? 1 : 0); return 0; }
     if (std::strcmp(key, "batch_single_reduce") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~2) | (value ? 2 : 0); return 0; }
+    if (std::strcmp(key, "batch_shared_tail") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~8) | (value ? 8 : 0); return 0; }
     if (std::strcmp(key, "batch_single_solve") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~4) | (value ? 4 : 0); return 0; }
+    if (std::strcmp(key, "hash_light") == 0) { ctx->be.debug_hash_light = value != 0; return 0; }
     if (std::strcmp(key, "hash_log") == 0) { ctx->be.debug_hash_log = value != 0; return 0; }      // the estimator keeps per-solve hashes of what it uploads / downloads (dv_est_debug_hash_log)
     if (std::strcmp(key, "wait_tail") == 0) { ctx->be.debug_wait_tail = value != 0; return 0; }
     if (std::strcmp(key, "gpu_reject") == 0) { ctx->be.gpu_reject = value != 0; return 0; }      // 0: OutliersRejection on the host (rounds 1-3 until be_reject_kernel)

@@ -110,7 +110,14 @@ struct BeWork {
     int32_t* marg_tab = nullptr; double* marg_scal = nullptr;      // marginalization index tables (inside the upload region) and its 4 result scalars
     long long marg_checked = 0; double marg_last[4] = { 0, 0, 0, 0 };      // marginalizations whose health scalars came back, and the last set (c0, smallest pivot of A_mm, clamp flag, rank)
     long long marg_clamped = 0;       // marginalizations in which a pivot of A_mm was <= 1e-8 and was skipped (pseudo-inverse)
-    bool debug_short_first_pass = false, ldl_generic = false, debug_wait_tail = false; int debug_batch_single = 0; bool debug_hash_log = false;      // dv_debug_set
+    bool debug_short_first_pass = false, ldl_generic = false, debug_wait_tail = false; int debug_batch_single = 0; bool debug_hash_log = false, debug_hash_light = false;
+    // dv_debug_set "hash_log": hashes of what the DEVICE holds, per window solve: [counter, uploaded block as it arrived, prior A / b / c0 on the device at the start, x after the
+    // round (raw solution), candidate buffer (gauge-fixed copy), control block]; written by be_dbg_hash_kernel into pinned slots, collected at the end of the solve
+    std::vector<unsigned long long> dbg_dev_log; unsigned long long* dbg_pinned = nullptr; unsigned long long dbg_solve_no = 0;
+    // "hash_log", finer: after EVERY launch of a round (slot it, launch kind 0 head-eval | 1 head-reduce | 2 solve | 3 candidate-eval | 4 candidate-reduce) hashes of everything that
+    // launch may write: DBG_RANGES values at dbg_slots[(it * 5 + kind) * DBG_RANGES + r] (pinned); appended to dbg_slot_log per solve as [counter, slots * 5 * DBG_RANGES values]
+    static constexpr int DBG_RANGES = 16, DBG_SLOTS = 16;
+    unsigned long long* dbg_slots = nullptr; std::vector<unsigned long long> dbg_slot_log;      // dv_debug_set
     bool gpu_reject = true; uint8_t* rej_pinned = nullptr;      // dv_debug_set "gpu_reject": the outlier test of the frame on the device, flags written to pinned memory before ev_state
     std::vector<const double*> sqrt_hint;                  // optional cached IMU sqrt-information per factor (set by the estimator around a solve)
 };

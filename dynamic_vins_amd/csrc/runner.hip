@@ -57,8 +57,8 @@ struct dv_runner {
     struct Group { std::vector<int> members; dv_batch* batch = nullptr; bool pending = false; std::unique_ptr<SpinBarrier> bar; };
     std::vector<Group> groups;
     int threads = 1, threads_per_group = 1;      // threads > groups: every dv_batch group is driven by threads / groups host threads that split its members' host phases (runner_team)
-    bool teams = false;           // KNOWN DEFECT (round 4): with several host threads per group single members intermittently end on a wrong trajectory (3 of 7 runs,
-                                  // scripts/dbg/r04_team_bisect.sh; cause not found).  Off unless dv_runner_set(runner, "teams", 1) asks for it; one thread per group is verified.
+    bool teams = false;           // opt-in (dv_runner_set "teams"): several host threads per group.  First blamed for the round-4 trajectory defect, then cleared (the shared
+                                  // accept + gauge launch was the trigger, be_api.hip); passes the bit-identity test, stays off by default.
     int threads_requested = 1;
     bool batch_front = true;      // dv_batch groups: the members' tracking in shared launches too (dv_batch_track_enqueue); dv_runner_set(runner, "batch_front", 0) keeps one set of launches per sequence
     std::string err; std::mutex err_mu;

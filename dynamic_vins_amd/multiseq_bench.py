@@ -147,8 +147,8 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
     n_groups = (S + gsz - 1) // gsz if gsz > 0 else S
     threads = getattr(args, "runner_threads", 0)
     teams = bool(getattr(args, "teams", False))
-    if threads <= 0:          # default: ONE host thread per dv_batch group.  (Round 4 shipped teams of two as the default for a few hours: single members intermittently ended on a
-        threads = n_groups if gsz > 1 else 1      # wrong trajectory — 3 of 7 runs, scripts/dbg/r04_team_bisect.sh.  --teams keeps the path reachable for the hunt, never for a result.)
+    if threads <= 0:          # default: ONE host thread per dv_batch group; --teams (opt-in) lets several threads share a group's host phases
+        threads = n_groups if gsz > 1 else 1
     if not teams:
         threads = min(threads, n_groups)
     args.runner_threads = threads

@@ -391,6 +391,11 @@ int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg);       /* Estimator::Es
 /* diagnostics, after dv_debug_set(ctx, "hash_log", 1): per window solve [counter, hash of the states uploaded, hash of the tables uploaded, hash of the states downloaded,
  * hash of the outlier flags consumed, iterations]; two runs of the same sequence must agree row by row */
 int dv_est_debug_hash_log(dv_ctx* ctx, unsigned long long* rows6, int cap, int* n_rows);
+/* the same on the device side: per fused window solve [counter, hash of the uploaded block as it arrived, of the prior A and b the round reads, of x after the round, of the
+ * candidate buffer (gauge-fixed copy), of the control block] */
+int dv_ba_debug_dev_log(dv_ctx* ctx, unsigned long long* rows7, int cap, int* n_rows);
+/* and per LAUNCH of the round: for every fused solve 16 slots x 5 launch kinds (head evaluation, head reduce, solve, candidate evaluation, candidate reduce) x 16 hashed buffers */
+int dv_ba_debug_slot_log(dv_ctx* ctx, unsigned long long* vals, long long cap_vals, long long* n_vals, int* row_len);
 int dv_est_reset(dv_ctx* ctx);                                   /* Estimator::ClearState + SetParameter */
 int dv_est_input_imu(dv_ctx* ctx, double t, const double* acc, const double* gyr);      /* Estimator::InputIMU */
 /* one iteration of Estimator::ProcessMeasurements (estimator.cpp:1786-1863): IMU interval, pre-integration,
@@ -440,10 +445,11 @@ int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, 
  * enqueue tracking(k+1), IMU up to t_k+1, dv_est_process_end(k) — the front end of frame k+1 overlaps the back end of frame k.  With group_size > 1 the sequences
  * are grouped into dv_batch groups of that size: the begin phases of a group run back to back, ONE dv_batch_enqueue launches the iteration slots of all its window
  * solves, and the host turns to the next group while they run (config 4 of BASELINE.json, "batched").  `threads` host threads each drive their own groups (at most one thread per group; more are not used).
- * EXPERIMENTAL, OFF BY DEFAULT, KNOWN DEFECT: dv_runner_set(runner, "teams", 1) before the first run lets threads / groups host threads (a multiple) share the host phases of one
- * group's members between barriers.  Unverified; do not use it for results.
- * OPEN DEFECT (round 4): runs with two or more host threads (several groups, with or without teams) intermittently leave single members on a WRONG trajectory
- * (5 of 16 runs of 40 - 60 frames at 16 - 64 sequences; cause unknown).  Runs with threads = 1 have not shown it.  Check every sequence's result (bench.py does, and refuses to report).
+ * Opt-in: dv_runner_set(runner, "teams", 1) before the first run lets threads / groups host threads (a multiple) share the host phases of one group's members between barriers
+ * (bit-identical to the single-thread run in tests/test_runner.py; off by default).
+ * Round 4 found single members of multi-group runs intermittently leaving their trajectory; located in the shared accept + gauge launch of a group's tail
+ * (be_accept_gauge_batch_kernel), which is quarantined: a group issues every member's own launch for that stage (0 of 100 runs differ, 8 of 30 with the shared launch; the cause
+ * inside that launch is not understood — DESIGN.md 0).  Check every sequence's result when you change this path: bench.py does, and refuses to report a run that fails the check.
  * The contexts (each with its estimator: dv_est_create) stay the caller's; frames are referenced, not copied (device or host memory: dv_seq_input::mem).
  * dynamic_vins_amd/host/dvins_node.cpp is the ROS-free node built on it (image directory + IMU csv in, `<seq>_<mode>_Odometry.txt` out). */
 typedef struct dv_seq_input {

@@ -39,31 +39,57 @@ def test_runner_equals_python_pipeline(group_size, threads):
         p.ctx.close()
 
 
-@pytest.mark.xfail(strict=False, reason="OPEN DEFECT (round 4): multi-sequence runs with >= 2 host threads intermittently leave single members on a wrong trajectory "
-                                        "(5 of 16 bench runs of 40 - 60 frames, with and without teams; cause unknown, DESIGN.md 0).  This case covers the team opt-in only")
-def test_team_path_is_bit_identical_to_one_thread_per_group():
-    """The experimental team path against the verified one (one host thread per group) on the SAME sequences, bit for bit, long enough and often enough to meet the
-    intermittent corruption that 30-frame runs of 4 members never showed: 8 members in one group, teams of 2 and of 4, 70 frames, three repetitions each."""
+def _trajectories(group_size, threads, S, frames, keys=(), teams=False):
     from dynamic_vins_amd.backend import Runner
-    S, frames = 8, 70
-    seqs, pipes = make(S, frames)
-    ref = Runner(pipes, group_size=S, threads=1)
-    ref.run(frames - 1)
-    want = [ref.get(i)[1].copy() for i in range(S)]
-    ref.close()
+    _, pipes = make(S, frames)
+    for p in pipes:
+        for k in keys:
+            assert p.ctx.lib.dv_debug_set(p.ctx.h, k.encode(), 1) == 0, k
+    r = Runner(pipes, group_size=group_size, threads=threads)
+    if teams:
+        r.set("teams", 1)
+    r.run(frames - 1)
+    out = [r.frames(i) for i in range(S)]
+    r.close()
     for p in pipes:
         p.ctx.close()
-    for T in (2, 4, 2, 4, 2, 4):
-        _, pp = make(S, frames)
-        r = Runner(pp, group_size=S, threads=T)
-        r.set("teams", 1)
-        r.run(frames - 1)
-        got = [r.get(i)[1].copy() for i in range(S)]
-        r.close()
-        for p in pp:
-            p.ctx.close()
+    return out
+
+
+def test_two_groups_in_flight_are_bit_identical_to_the_single_thread_run():
+    """The configuration class in which round 4 found single members leaving their trajectory (two dv_batch groups in flight, one host thread each): every member's per-frame
+    record [t, pose, flag] must equal the unbatched single-thread run's, bit for bit, over 60 frames, in each of four repetitions.  With the shared accept + gauge launch
+    (be_accept_gauge_batch_kernel, quarantined: next test) 8 of 30 such runs differed; with every member's own launch 0 of 100 (scripts/dbg/r04_tail_switch.sh)."""
+    S, frames = 8, 60
+    want = _trajectories(0, 1, S, frames)
+    for rep in range(4):
+        got = _trajectories(4, 2, S, frames)
         for i in range(S):
-            assert got[i].shape == want[i].shape and np.array_equal(got[i], want[i]), f"teams of {T}: sequence {i} differs from the one-thread-per-group run"
+            assert got[i].shape == want[i].shape and np.array_equal(got[i], want[i]), f"repetition {rep}: sequence {i} differs from the single-thread run"
+
+
+@pytest.mark.xfail(strict=False, reason="QUARANTINED kernel form (round 4): with dv_debug_set 'batch_shared_tail' the accept decision + gauge fix + download of a group run as ONE "
+                                        "launch (be_accept_gauge_batch_kernel); a member's result then intermittently leaves the single-thread result when a second group is in flight "
+                                        "(8 of 30 runs). Located by per-launch hashes; the cause inside the kernel is not understood. Not used by default")
+def test_shared_accept_gauge_launch_quarantined_form():
+    S, frames = 8, 60
+    want = _trajectories(0, 1, S, frames)
+    for rep in range(6):
+        got = _trajectories(4, 2, S, frames, keys=("batch_shared_tail",))
+        for i in range(S):
+            assert np.array_equal(got[i], want[i]), f"repetition {rep}: sequence {i} differs from the single-thread run"
+
+
+def test_team_path_is_bit_identical_to_the_single_thread_run():
+    """several host threads per group (dv_runner_set 'teams', opt-in): the failures first blamed on it (round 4) all had two groups in flight and the shared accept + gauge
+    launch; with that launch quarantined the team path must reproduce the single-thread run bit for bit — two groups of four with teams of two, and one group of eight with a
+    team of four, three repetitions each"""
+    S, frames = 8, 60
+    want = _trajectories(0, 1, S, frames)
+    for gs, T in ((4, 4), (8, 4), (4, 4), (8, 4), (4, 4), (8, 4)):
+        got = _trajectories(gs, T, S, frames, teams=True)
+        for i in range(S):
+            assert np.array_equal(got[i], want[i]), f"groups of {gs} on {T} threads: sequence {i} differs from the single-thread run"
 
 
 def test_batch_stage_timing_leaves_the_results_alone():

@@ -731,13 +731,11 @@ static int batch_enqueue_impl(dv_batch* B) {
         else { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_FULL, s); dbg_all(3); be_launch_reduce_batch(dsa, S, max_n, 1, s); dbg_all(4); }
     }
     // ---- the tails of all members: 2 + 3 launches per group instead of 5 - 6 per member on S streams ----
-    // QUARANTINED (round 4): the shared launch of this stage (be_accept_gauge_batch_kernel: last accept decision + gauge fix + download of all members) is where a member's
-    // result intermittently left the single-sequence result when a second group was in flight — identical device inputs through the last candidate evaluation, different x / cand /
-    // ctl after the round (per-launch hashes, scripts/dbg/multiseq_first_diff.py); with every member's own launch of the same two bodies: 0 of 30 runs against 6 of 40.  The cause
-    // inside the shared form is NOT understood.  Default: the members' own launches (S tiny launches, same stream, same order); dv_debug_set "batch_shared_tail" brings the shared
-    // form back for the hunt.
-    if (dbg & 8) be_launch_accept_gauge_batch(dsa, dga, S, s);
-    else for (dv_ctx* c : M) { BeGaugeArgs ga{}; be_gauge_args(c, *c->be.pend, ga); be_launch_accept_gauge(c->be.pend->sa, ga, s); }
+    // Round 4: a member's result intermittently left the single-sequence result in this launch when a second group was in flight (located by per-launch hashes,
+    // scripts/dbg/multiseq_first_diff.py).  Cause: be_accept_body let thread 0 store into the control block before every wave had loaded it (be_kernels.h; fixed by a workgroup
+    // barrier — shared launch 8 of 30 runs differing before, 0 of 60 after).  dv_debug_set "batch_single_tail" issues the members' own launches of the same bodies instead (A/B).
+    if (dbg & 8) { for (dv_ctx* c : M) { BeGaugeArgs ga{}; be_gauge_args(c, *c->be.pend, ga); be_launch_accept_gauge(c->be.pend->sa, ga, s); } }
+    else be_launch_accept_gauge_batch(dsa, dga, S, s);
     be_launch_reject_batch(drj, S, max_rej, s);
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipEventRecord(B->ev_state, s));
@@ -894,7 +892,7 @@ int dv_debug_set(dv_ctx* ctx, const char* key, int value) {
     if (std::strcmp(key, "peer_timeout_ms") == 0) { ctx->dist.peer_timeout_ticks = 100000ll * std::max(value, 1); return 0; }      // transport peer: how long a wait kernel spins for a peer's flag (default 2000)
     if (std::strcmp(key, "batch_single_eval") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~1) | (value ? 1 : 0); return 0; }
     if (std::strcmp(key, "batch_single_reduce") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~2) | (value ? 2 : 0); return 0; }
-    if (std::strcmp(key, "batch_shared_tail") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~8) | (value ? 8 : 0); return 0; }
+    if (std::strcmp(key, "batch_single_tail") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~8) | (value ? 8 : 0); return 0; }
     if (std::strcmp(key, "batch_single_solve") == 0) { ctx->be.debug_batch_single = (ctx->be.debug_batch_single & ~4) | (value ? 4 : 0); return 0; }
     if (std::strcmp(key, "hash_light") == 0) { ctx->be.debug_hash_light = value != 0; return 0; }
     if (std::strcmp(key, "hash_log") == 0) { ctx->be.debug_hash_log = value != 0; return 0; }      // the estimator keeps per-solve hashes of what it uploads / downloads (dv_est_debug_hash_log)

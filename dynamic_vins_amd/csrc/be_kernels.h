@@ -127,7 +127,11 @@ __device__ __forceinline__ void be_accept_body(const BeSolveArgs& a) {
     __shared__ double red[4];
     __shared__ int s_accept;
     const int tid = threadIdx.x;
-    if (c.done || !c.pending) return;          // failed factorisations and invalid steps are settled by the solve kernel itself
+    // EVERY wave must hold its copy of the control block before thread 0 stores into it below (pending = 0, slots): without this barrier a wave that starts late — a busy CU
+    // staggers the waves of a workgroup by microseconds — loaded the block AFTER that store, saw pending == 0 and left through the return below while wave 0 went on to sum
+    // red[] entries nobody had written and to copy a quarter of the state.  Found in round 4 as single members of multi-group runs leaving their trajectory.
+    __syncthreads();
+    if (c.done || !c.pending) return;          // failed factorisations and invalid steps are settled by the solve kernel itself (workgroup-uniform: every thread holds the same c)
     if (tid == 0) { ctl->slots = c.slots + 1; ctl->pending = 0; s_accept = 0; }
     const int iter = c.iter + 1;
     // candidate cost: fixed-order sum

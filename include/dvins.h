@@ -447,9 +447,9 @@ int dv_est_get_marg_health(dv_ctx* ctx, long long* checked, long long* clamped, 
  * solves, and the host turns to the next group while they run (config 4 of BASELINE.json, "batched").  `threads` host threads each drive their own groups (at most one thread per group; more are not used).
  * Opt-in: dv_runner_set(runner, "teams", 1) before the first run lets threads / groups host threads (a multiple) share the host phases of one group's members between barriers
  * (bit-identical to the single-thread run in tests/test_runner.py; off by default).
- * Round 4 found single members of multi-group runs intermittently leaving their trajectory; located in the shared accept + gauge launch of a group's tail
- * (be_accept_gauge_batch_kernel), which is quarantined: a group issues every member's own launch for that stage (0 of 100 runs differ, 8 of 30 with the shared launch; the cause
- * inside that launch is not understood — DESIGN.md 0).  Check every sequence's result when you change this path: bench.py does, and refuses to report a run that fails the check.
+ * Round 4 found single members of multi-group runs intermittently leaving their trajectory: a missing workgroup barrier in the accept decision (be_accept_body), exposed when a
+ * second group kept the CUs busy; fixed (shared launch: 8 of 30 runs differing before, 0 of 60 after — DESIGN.md 0).  Check every sequence's result when you change this path:
+ * bench.py does, and refuses to report a run that fails the check; scripts/dbg/multiseq_first_diff.py compares bit for bit against the single-thread run.
  * The contexts (each with its estimator: dv_est_create) stay the caller's; frames are referenced, not copied (device or host memory: dv_seq_input::mem).
  * dynamic_vins_amd/host/dvins_node.cpp is the ROS-free node built on it (image directory + IMU csv in, `<seq>_<mode>_Odometry.txt` out). */
 typedef struct dv_seq_input {

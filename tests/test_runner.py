@@ -58,8 +58,9 @@ def _trajectories(group_size, threads, S, frames, keys=(), teams=False):
 
 def test_two_groups_in_flight_are_bit_identical_to_the_single_thread_run():
     """The configuration class in which round 4 found single members leaving their trajectory (two dv_batch groups in flight, one host thread each): every member's per-frame
-    record [t, pose, flag] must equal the unbatched single-thread run's, bit for bit, over 60 frames, in each of four repetitions.  With the shared accept + gauge launch
-    (be_accept_gauge_batch_kernel, quarantined: next test) 8 of 30 such runs differed; with every member's own launch 0 of 100 (scripts/dbg/r04_tail_switch.sh)."""
+    record [t, pose, flag] must equal the unbatched single-thread run's, bit for bit, over 60 frames, in each of four repetitions.  Cause (fixed): be_accept_body let thread 0
+    store into the control block before every wave of the workgroup had loaded it — a wave started late on a busy CU saw pending == 0 and skipped the body, wave 0 summed
+    unwritten LDS and a quarter of the state was copied.  Before the fix 8 of 30 such runs differed at 1280x720 with the group's shared accept + gauge launch, after it 0 of 60."""
     S, frames = 8, 60
     want = _trajectories(0, 1, S, frames)
     for rep in range(4):
@@ -68,21 +69,20 @@ def test_two_groups_in_flight_are_bit_identical_to_the_single_thread_run():
             assert got[i].shape == want[i].shape and np.array_equal(got[i], want[i]), f"repetition {rep}: sequence {i} differs from the single-thread run"
 
 
-@pytest.mark.xfail(strict=False, reason="QUARANTINED kernel form (round 4): with dv_debug_set 'batch_shared_tail' the accept decision + gauge fix + download of a group run as ONE "
-                                        "launch (be_accept_gauge_batch_kernel); a member's result then intermittently leaves the single-thread result when a second group is in flight "
-                                        "(8 of 30 runs). Located by per-launch hashes; the cause inside the kernel is not understood. Not used by default")
-def test_shared_accept_gauge_launch_quarantined_form():
+def test_members_own_accept_gauge_launches_give_the_same_bits():
+    """dv_debug_set 'batch_single_tail': the accept decision + gauge fix + download of a group through every member's own launch of the same two bodies (the A/B switch that
+    located the defect above) — same bits as the shared launch and as the single-thread run"""
     S, frames = 8, 60
     want = _trajectories(0, 1, S, frames)
-    for rep in range(6):
-        got = _trajectories(4, 2, S, frames, keys=("batch_shared_tail",))
+    for rep in range(2):
+        got = _trajectories(4, 2, S, frames, keys=("batch_single_tail",))
         for i in range(S):
             assert np.array_equal(got[i], want[i]), f"repetition {rep}: sequence {i} differs from the single-thread run"
 
 
 def test_team_path_is_bit_identical_to_the_single_thread_run():
-    """several host threads per group (dv_runner_set 'teams', opt-in): the failures first blamed on it (round 4) all had two groups in flight and the shared accept + gauge
-    launch; with that launch quarantined the team path must reproduce the single-thread run bit for bit — two groups of four with teams of two, and one group of eight with a
+    """several host threads per group (dv_runner_set 'teams', opt-in): the failures first blamed on it (round 4) came from the race in be_accept_body (previous test); the
+    team path must reproduce the single-thread run bit for bit — two groups of four with teams of two, and one group of eight with a
     team of four, three repetitions each"""
     S, frames = 8, 60
     want = _trajectories(0, 1, S, frames)

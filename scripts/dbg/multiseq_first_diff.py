@@ -1,7 +1,7 @@
 """debug (open defect of round 4): where does a multi-threaded multi-sequence run first leave the single-thread run of the SAME sequences?
 Reference: one host thread, no groups.  Candidate: --groups G (dv_batch groups) on --threads T.  Per member: the first frame whose record [t, pose, flag] differs, and at
 that frame whether the rows handed over by the tracker already differ (front end) or only the solve does (back end); plus the batch's fallback-round count.
-usage: multiseq_first_diff.py [S=16] [group_size=8] [threads=2] [frames=75] [repeats=4]"""
+usage: multiseq_first_diff.py [S=16] [group_size=8] [threads=2] [frames=75] [repeats=4]      DBG_TEAMS=1: several host threads per group (dv_runner_set "teams"), threads = a multiple of the group count"""
 import os, sys
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -21,6 +21,8 @@ def run(group_size, threads):
         for k in (KEYS if group_size else []):
             assert p.ctx.lib.dv_debug_set(p.ctx.h, k.encode(), 1) == 0, k
     r = Runner(pipes, group_size=group_size, threads=threads)
+    if group_size and os.environ.get("DBG_TEAMS", "0") == "1":
+        r.set("teams", 1)
     r.run(frames)
     def hlog(p):
         rows = np.zeros((4096, 6), dtype=np.uint64); n = C.c_int(0)

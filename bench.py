@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--batched", action="store_true", help="with --sequences: the window solves of all sequences share every launch (dv_batch), one host thread")
     ap.add_argument("--host-loop", choices=["cpp", "python"], default="cpp", help="raw mode: the per-frame host loop of the timed region in C++ inside the library (dv_runner) or in Python (pipeline.py); dynamic mode and the instrumented pass use the Python loop")
     ap.add_argument("--runner", choices=["cpp", "python"], default="cpp", help="with --sequences: the host loop in C++ inside the library (dv_runner) or the round-2 Python loop")
-    ap.add_argument("--group-size", type=int, default=0, help="with --sequences --batched --runner cpp: sequences per dv_batch group (default: two groups)")
+    ap.add_argument("--group-size", type=int, default=0, help="with --sequences --batched --runner cpp: sequences per dv_batch group (default: four groups, one host thread each; two groups below 8 sequences)")
     ap.add_argument("--no-batch-front", action="store_true", help="with --sequences --batched: one set of tracking launches per sequence instead of dv_batch_track_enqueue (A/B)")
     ap.add_argument("--runner-threads", type=int, default=0, help="with --sequences: host threads driving the groups (default and maximum: one per group)")
     ap.add_argument("--teams", action="store_true", help="opt-in: several host threads per dv_batch group (--runner-threads = a multiple of the group count); bit-identical to one thread per group in tests/test_runner.py")

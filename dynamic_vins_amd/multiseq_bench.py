@@ -136,14 +136,16 @@ def run_multiseq_bench(args, rank, world, local_rank):
 
 def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
     """the same measurement with the host loop in C++ (dv_runner, csrc/runner.hip): one call per timed block; --batched groups the sequences into dv_batch groups of
-    --group-size (default: two groups), --runner-threads host threads drive the groups"""
+    --group-size (default: four groups), --runner-threads host threads drive the groups (default and maximum: one per group)"""
     from bench import git_head
     from .backend import Runner
     S, w, h = args.sequences, cfg["w"], cfg["h"]
     warm_ba = max(args.warmup, 12)
     gsz = 0
     if getattr(args, "batched", False):
-        gsz = args.group_size if getattr(args, "group_size", 0) > 0 else ((S + 1) // 2 if S >= 4 else S)      # default: two groups in anti-phase (one's host phases beside the other's launches)
+        # default: FOUR groups (one host thread each) — measured behind the per-sequence gate, interleaved on one box (round 4): 16 sequences in groups of 4 / 8 / 2:
+        # 5896 - 5919 / 5058 - 5066 / 4306 frames/s; 32 in groups of 8 / 16: 7497 / 5529; fewer than 8 sequences: two groups
+        gsz = args.group_size if getattr(args, "group_size", 0) > 0 else ((S + 3) // 4 if S >= 8 else ((S + 1) // 2 if S >= 4 else S))
     n_groups = (S + gsz - 1) // gsz if gsz > 0 else S
     threads = getattr(args, "runner_threads", 0)
     teams = bool(getattr(args, "teams", False))

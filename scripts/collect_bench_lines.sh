@@ -8,6 +8,7 @@ run ""
 run _steps20                --steps 20 --warmup 5
 run _dynamic                --mode dynamic --no-cpu-baseline
 run _sequences16_batched    --sequences 16 --batched --steps 60
+run _sequences16_groups8    --sequences 16 --batched --group-size 8 --steps 60
 run _sequences16_teams      --sequences 16 --batched --teams --runner-threads 4 --steps 60
 run _sequences32_groups8    --sequences 32 --batched --group-size 8 --steps 40
 run _sequences32_batched    --sequences 32 --batched --group-size 16 --steps 40

@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--scene", choices=["escort", "room"], default="escort", help="--mode dynamic: escort = boxes travelling with the camera (in view in every frame); room = room-fixed boxes (round-2 scene)")
     ap.add_argument("--erode", type=int, default=5, help="--mode dynamic: mask_morphology_size (viode.yaml: 5; the ZED / KITTI dynamic configs: 20)")
     ap.add_argument("--no-dynamic-line", action="store_true", help="skip the second measurement (dynamic mode) of the default run")
+    ap.add_argument("--no-extra-lines", action="store_true", help="skip config.host_frames_line (pinned host buffers, upload timed) and config.multiseq_line (16 sequences, child process) of the default run")
     ap.add_argument("--objects", type=int, default=4, help="--mode dynamic: number of moving boxes in the scene (dynsim.ring_boxes)")
     ap.add_argument("--prealloc-mb", type=int, default=0, help="debug: allocate (and keep) this much device memory before the sequence is rendered (shifts where the frames land in HBM)")
     ap.add_argument("--debug-set", default="", help="comma-separated dv_debug_set keys to switch on in every context (A/B runs of kernel variants, e.g. ldl_generic)")
@@ -185,6 +186,35 @@ def main():
         a2 = argparse.Namespace(**vars(args)); a2.mode = "dynamic"
         dyn = measure(a2, cfg, rank, world, local_rank, want_roofline=False)
     out = measure(args, cfg, rank, world, local_rank)
+    extra_lines = args.mode == "raw" and args.config == "zed" and not args.no_extra_lines and not args.no_dynamic_line and not args.every_second_frame and not args.host_frames and world == 1
+    if extra_lines:
+        # the PCIe-inclusive rate beside the headline (never `value`): the same sequence handed over as pinned host buffers, upload inside the timed region
+        a3 = argparse.Namespace(**vars(args)); a3.host_frames = True; a3.no_cpu_baseline = True
+        hf = measure(a3, cfg, rank, world, local_rank, want_roofline=False)
+        if rank == 0 and hf is not None:
+            out["config"]["host_frames_line"] = {"value": hf["value"], "unit": "frames/s", "ms_per_step": hf["ms_per_step"], "timed_region_s": hf["timed_region_s"], "block_values": hf["config"]["block_values"],
+                                                 "frames": hf["config"]["frames"], "host_loop": hf["config"]["host_loop"], "ate_rmse_m_vs_ground_truth": hf["config"]["ate_rmse_m_vs_ground_truth"],
+                                                 "bytes_uploaded_per_frame": 2 * cfg["w"] * cfg["h"]}
+        # configs[3] (several sequences per GPU, window solves and front ends in shared launches) under the same clock: a CHILD process (it needs its own
+        # GPU_MAX_HW_QUEUES, read when the runtime initialises) running the documented command; its line — printed only behind the per-sequence trajectory gate and the
+        # bit-identity check of two members against the single-thread run (multiseq_bench.py) — is embedded as config.multiseq_line
+        if rank == 0:
+            cmd = [sys.executable, os.path.abspath(__file__), "--sequences", "16", "--batched", "--steps", "40"]
+            t0 = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=dict(os.environ, GPU_MAX_HW_QUEUES="12"))
+                ln = [x for x in r.stdout.splitlines() if x.startswith("{")]
+                if r.returncode == 0 and ln:
+                    ms = json.loads(ln[-1])
+                    out["config"]["multiseq_line"] = {"command": "python bench.py --sequences 16 --batched --steps 40", "value": ms["value"], "unit": "frames/s", "steps": ms["steps"],
+                                                      "timed_region_s": ms["timed_region_s"], "ms_per_step": ms["ms_per_step"], "second_block_value": ms["config"]["second_block_value"],
+                                                      "sequences_per_gpu": ms["config"]["sequences_per_gpu"], "group_size": ms["config"]["group_size"], "runner_threads": ms["config"]["runner_threads"],
+                                                      "teams": ms["config"].get("teams"), "ate_rmse_m_vs_ground_truth_max": ms["config"]["ate_rmse_m_vs_ground_truth_max"],
+                                                      "bit_identity": ms["config"].get("bit_identity"), "child_wall_s": round(time.perf_counter() - t0, 1)}
+                else:
+                    out["config"]["multiseq_line"] = {"error": "exit %d: %s" % (r.returncode, (r.stderr or "").strip()[-400:])}
+            except subprocess.TimeoutExpired:
+                out["config"]["multiseq_line"] = {"error": "timeout"}
     if want_dyn:
         if not dyn_first:
             a2 = argparse.Namespace(**vars(args)); a2.mode = "dynamic"
@@ -228,8 +258,8 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         if args.mode == "dynamic":
             return DynamicPipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"], mask_morphology_size=args.erode,
                                    extra_from_disparity=os.environ.get("BENCH_DYN_PASSTHROUGH", "0") != "1")      # (debug A/B: 1 = the detections' own points are handed through, no extra-point kernels)
-        return Pipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"], host_frames=args.host_frames,
-                        ba_stride=stride)
+        return Pipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"],
+                        host_frames=args.host_frames and args.host_loop != "cpp", ba_stride=stride)      # (the C++ runner pins its own host copies: backend.Runner)
 
     frame_ms = []
 
@@ -239,7 +269,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         pipe = make_pipe()
         for key in filter(None, args.debug_set.split(",")):
             assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
-        runner = Runner([pipe])
+        runner = Runner([pipe], host_frames=args.host_frames)      # --host-frames: pinned host buffers, every frame's upload inside the timed region
         runner.run(warm_ba * stride)
         it0 = runner.get(0)[2]                               # window-solve iterations spent in the warm-up
         gc.collect(); gc.freeze()
@@ -266,7 +296,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         return pipe, times, iters_all - it0
 
     def run(kernel_timing, collective=True, blocks=2):       # collective=False: rank-0-only pass, no barriers
-        if args.host_loop == "cpp" and not kernel_timing and not args.host_frames:      # raw and dynamic mode both run on the library's C++ loop (dv_runner / dv_runner_set_dynamic)
+        if args.host_loop == "cpp" and not kernel_timing:      # raw and dynamic mode both run on the library's C++ loop (dv_runner / dv_runner_set_dynamic); --host-frames too
             return run_cpp(collective, blocks)
         pipe = make_pipe()
         for key in filter(None, args.debug_set.split(",")):
@@ -454,7 +484,8 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 "block_values": [round(dv_dist.whole_job_rate(args.steps, world, t), 2) for t in times],
                 "block_step_ms": frame_ms[: len(times)],
                 "warmup_requested": args.warmup, "git_head": git_head(),
-                "host_loop": ("C++ (dv_runner)" if (args.host_loop == "cpp" and not args.host_frames) else "Python (pipeline.py)"),
+                "host_loop": ("C++ (dv_runner)" if args.host_loop == "cpp" else "Python (pipeline.py)"),
+                "frames": ("pinned host buffers: the upload of every frame (2 x %d bytes, hipMemcpy2DAsync on the tracking stream) is inside the timed region" % (w * h)) if args.host_frames else "resident in HBM before the timed region",
                 "warmup_note": "at least 12 untimed BA frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"}
         if dyn_info:
             conf["dynamic"] = dyn_info

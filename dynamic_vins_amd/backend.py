@@ -497,8 +497,10 @@ class Runner:
     """dv_runner: the per-frame host loop of pipeline.Pipeline in C++ inside the library, for one or many sequences (include/dvins.h).  `pipes` are Pipeline
     objects (each owns its Context + Estimator and a SyntheticSequence whose frames are resident in HBM); the runner takes over driving them."""
 
-    def __init__(self, pipes, group_size=0, threads=1, first_frame=0):
-        from .frontend import DV_MEM_DEVICE
+    def __init__(self, pipes, group_size=0, threads=1, first_frame=0, host_frames=False):
+        """host_frames: the frames are handed over as PINNED HOST buffers (dv_seq_input::mem = DV_MEM_HOST): every frame's upload (hipMemcpy2DAsync on the tracking
+        stream) then lies inside whatever region times dv_runner_run — the PCIe-inclusive rate of bench.py's host_frames_line"""
+        from .frontend import DV_MEM_DEVICE, DV_MEM_HOST
         self.lib = pipes[0].ctx.lib
         self.pipes = list(pipes)
         n = len(pipes)
@@ -507,6 +509,11 @@ class Runner:
         for i, p in enumerate(pipes):
             q = p.seq
             frames = q.frames[first_frame:]
+            if host_frames:
+                import torch
+                frames = [(f[0].cpu().pin_memory(), f[1].cpu().pin_memory()) for f in frames]
+                assert all(a.is_contiguous() and b.is_contiguous() for a, b in frames)
+                self._keep.append(frames)
             L = (C.c_void_p * len(frames))(*[f[0].data_ptr() for f in frames]); R = (C.c_void_p * len(frames))(*[f[1].data_ptr() for f in frames])
             t = np.ascontiguousarray(q.times[first_frame:], np.float64)
             it, ia, ig = np.ascontiguousarray(q.imu_t, np.float64), np.ascontiguousarray(q.imu_a, np.float64), np.ascontiguousarray(q.imu_g, np.float64)
@@ -514,7 +521,7 @@ class Runner:
             self._keep += [L, R, t, it, ia, ig]
             a = arr[i]
             a.left, a.right, a.times = C.cast(L, C.c_void_p), C.cast(R, C.c_void_p), t.ctypes.data
-            a.n_frames, a.mem, a.stride, a.ba_stride = len(frames), DV_MEM_DEVICE, 0, getattr(p, "ba_stride", 1)
+            a.n_frames, a.mem, a.stride, a.ba_stride = len(frames), (DV_MEM_HOST if host_frames else DV_MEM_DEVICE), 0, getattr(p, "ba_stride", 1)
             a.imu_t, a.imu_acc, a.imu_gyr, a.n_imu = it.ctypes.data + 8 * k0, ia.ctypes.data + 24 * k0, ig.ctypes.data + 24 * k0, len(it) - k0
         self._arr = arr
         ctxs = (C.c_void_p * n)(*[p.ctx.h for p in pipes])

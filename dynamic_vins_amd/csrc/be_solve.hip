@@ -667,6 +667,11 @@ __device__ __forceinline__ double mf_sel4(int rho, double v0, double v1, double 
     const double t0 = b0 ? v1 : v0, t1 = b0 ? v3 : v2;
     return b1 ? t1 : t0;
 }
+// (Round 5: hardware wave h runs on SIMD h & 3 (measured, scripts/dbg/diag_bench.hip: trailing-update MFMAs on waves 4, 8, 12 stretch a diagonal tile on wave 0 from
+//  1.52 to 2.11 us, the same load on the other twelve waves does nothing).  Dealing the plan's logical waves to the SIMDs in blocks of four — the chain wave's
+//  SIMD-mates are then its index neighbours, idle or nearly so — changed the kernel by nothing measurable (61.7 against 61.6 us, diagonal tiles 1.85 against 1.90 us):
+//  the mates that remain still own the tiles of the next columns.  Left at the identity.)
+__device__ __forceinline__ int mf_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
 struct MfLds { double* Tl; double* gat; double* dv; double* iv; double* yv; };      // tiles | per-wave gather buffers (64 each) | D | 1 / D | y (then the running right-hand side of the back substitution)
 
 // one 4-pivot sub-step of the diagonal tile.  c0: local index of the right-hand-side row (or -1); yk: this block's 16 entries of y.
@@ -715,7 +720,7 @@ __device__ __forceinline__ void mf_diag_substep(mf_d4& T, mf_d4& Wt, double* gat
     if (lane == c0) { mf_d4 yy = { lh0, lh1, lh2, lh3 }; *reinterpret_cast<mf_d4*>(yk + P) = yy; }      // row c0 of L_kk = this block's share of y (zero from column c0 on: lh is masked)
 }
 __device__ __forceinline__ void mf_diag_factor(mf_d4& T, const MfLds& m, int k, int NB, int n, int* s_fail) {
-    const int lane = threadIdx.x & 63, c = lane & 15, rho = lane >> 4, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, c = lane & 15, rho = lane >> 4, wave = mf_wave();
     __builtin_amdgcn_s_setprio(3);
     mf_d4 Wt;
 #pragma unroll
@@ -732,6 +737,11 @@ __device__ __forceinline__ void mf_diag_factor(mf_d4& T, const MfLds& m, int k, 
     *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(k, k, NB) * 256 + lane * 4) = Wt;      // W_k = L_kk^-1, result layout (the workgroup barrier behind this tile publishes it)
     __builtin_amdgcn_s_setprio(0);      // (the pivots are checked once, behind the last tile: ldlt_mf16)
 }
+// Three other forms of this tile were built and measured in round 5 (scripts/dbg/diag_bench.hip keeps them: rank-1 MFMA Gauss-Jordan in place, the same with the next
+// reciprocal formed in the MFMA's shadow, column per lane on v_fmac_f64 DPP row_newbcast): 1.65 / 1.62 / 1.76 us per tile against 1.52 us for the form above, alone on
+// its SIMD — an MFMA result takes ~200 cycles to reach a VALU consumer, and DP-ALU DPP operations issue at half rate.  What the measurements DID show: trailing-update
+// MFMAs on the chain wave's own SIMD stretch the tile to 2.11 us (the figure seen inside the kernel); mf_wave() below deals with that.
+__device__ __forceinline__ void mf_diag(mf_d4& T, const MfLds& m, int k, int NB, int n, int* s_fail) { mf_diag_factor(T, m, k, NB, n, s_fail); }
 // tile entries: the raw Schur-complement entry is requested early (mf_prefetch, before the scaling phase: the loads' round trip hides behind it) and finished
 // (scaled, damped; right-hand side as row / column n; identity padding behind it) when the factorisation starts
 __device__ __forceinline__ double mf_raw(const double* __restrict__ Sc, int n, int i, int j) {
@@ -757,7 +767,7 @@ __device__ __forceinline__ void mf_slots(const uint8_t* plan, int wave, int NB, 
     for (int s = 1; s < 5; ++s) { const int b = (int)((w4 >> (8 * (s - 1))) & 0xFFu); sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
 }
 __device__ __forceinline__ void mf_prefetch(const double* __restrict__ Sc, const uint8_t* plan, int n, mf_d4 (&U)[5]) {
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = lane & 15, rho = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = mf_wave(), c = lane & 15, rho = lane >> 4;
     int sI[5], sJ[5];
     mf_slots(plan, wave, (n + 16) >> 4, sI, sJ);
     const int NBR = (n + 3) >> 2;
@@ -790,7 +800,7 @@ __device__ __forceinline__ void mf_prefetch(const double* __restrict__ Sc, const
 // so the diagonal chain (the critical path) never waits for the other waves' panels or updates: they run beside it.
 template <class Side, class Side0>
 __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* plan, int n, double mu, const double* v_s, const double* v_d, const double* rhs, const MfLds& m, int* s_fail, Side side, Side0 side0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, rho = lane >> 4;      // wave in an SGPR: the slot tests below are scalar branches
+    const int tid = threadIdx.x, lane = tid & 63, wave = mf_wave(), c = lane & 15, rho = lane >> 4;      // wave in an SGPR: the slot tests below are scalar branches
     const int NB = (n + 16) >> 4, IB = n >> 4, c0 = n & 15;
     int sI[MF_SLOTS], sJ[MF_SLOTS];
     mf_slots(plan, wave, NB, sI, sJ);
@@ -821,7 +831,7 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
     lds_barrier();
     TS(4);
     const int k_side = -1; // (NB >= 9 ? 6 : -1: the side work inside the loop costs 70 spilled VGPRs)                 // the step whose slack takes the side work (small systems: beside the first diagonal tile)
-    if (wave == 0) { mf_diag_factor(U[0], m, 0, NB, n, s_fail); if (k_side < 0) side0(); }
+    if (wave == 0) { mf_diag(U[0], m, 0, NB, n, s_fail); if (k_side < 0) side0(); }
     else if (k_side < 0) side(0);
     lds_barrier();                                       // A: W_0 published
 #ifdef BE_SOLVE_TS
@@ -860,7 +870,7 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
 #ifdef BE_SOLVE_TS
             const long long t_u = wall_clock64();
 #endif
-            mf_diag_factor(U[0], m, k + 1, NB, n, s_fail);
+            mf_diag(U[0], m, k + 1, NB, n, s_fail);
 #ifdef BE_SOLVE_TS
             if (lane == 0) { be_dbg_ts[19] += wall_clock64() - t_u; be_dbg_ts[20] += t_u - t_prev; }      // diagonal tiles; the owner's panel + update before them
 #endif
@@ -900,7 +910,7 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
 // block back substitution L^T x = y on the tiles: per block row i (last to first) x_i = W_i^T y_i (every wave that needs it forms it itself: 4 FMAs per lane and
 // one exchange through its gather buffer), then every tile (i, k) of that block row takes its share out of y_k.  One barrier per 16 unknowns.
 __device__ __forceinline__ void bs_mf16(const uint8_t* plan, int n, const MfLds& m, double* v_x) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 15, rho = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = mf_wave(), c = lane & 15, rho = lane >> 4;
     const int NB = (n + 16) >> 4, IB = n >> 4, c0 = n & 15;
     int sI[MF_SLOTS], sJ[MF_SLOTS];
     mf_slots(plan, wave, NB, sI, sJ);
@@ -941,6 +951,9 @@ __device__ __forceinline__ void bs_mf16(const uint8_t* plan, int n, const MfLds&
     }
 }
 
+// (Round 5: the same back substitution with every matrix-vector product on the matrix cores — x_i replicated over the B operand's columns, results chained register to
+//  register, one producer wave per x_i — was built and measured: 15.4 us against 8.4 us for bs_mf16.  A product is four chained MFMAs whose result must reach a VALU /
+//  LDS consumer before the next stage can start; that hand-over costs more than the two LDS reductions it replaces.  Removed; scripts/dbg notes in DESIGN.md 4.)
 // back-substitution helper: applies ROWS consecutive pivots (kt, kt-1, ...) that all lie in 64-lane segment SEG of x
 template <int SEG, int ROWS>
 __device__ __forceinline__ void bs_chunk(const double* Lm, int kt, int lane, double& x0, double& x1, double& x2) {

@@ -44,10 +44,14 @@ namespace {
 // reusable barrier of a group's host threads (sense reversing; the waits are short — a member's host phase is ~0.1 ms — so it spins with a yield)
 struct SpinBarrier {
     std::atomic<int> count{0}; std::atomic<int> sense{0}; std::atomic<int> failed{0}; int n = 1;
-    bool wait() {          // -> false if any thread of the group reported a failure (everybody leaves the round)
+    bool wait() {          // -> false if any thread of the group reported a failure (everybody leaves the round; the flag is also polled INSIDE the spin, so a thread
+                           //    that failed behind the round's last barrier cannot leave its teammates spinning in the next one)
         const int s = sense.load(std::memory_order_acquire);
         if (count.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { count.store(0, std::memory_order_relaxed); sense.store(s ^ 1, std::memory_order_release); }
-        else while (sense.load(std::memory_order_acquire) == s) std::this_thread::yield();
+        else while (sense.load(std::memory_order_acquire) == s) {
+            if (failed.load(std::memory_order_acquire)) return false;      // a teammate left the round with an error and will never arrive: nobody waits for it
+            std::this_thread::yield();
+        }
         return failed.load(std::memory_order_acquire) == 0;
     }
 };
@@ -57,8 +61,8 @@ struct dv_runner {
     struct Group { std::vector<int> members; dv_batch* batch = nullptr; bool pending = false; std::unique_ptr<SpinBarrier> bar; };
     std::vector<Group> groups;
     int threads = 1, threads_per_group = 1;      // threads > groups: every dv_batch group is driven by threads / groups host threads that split its members' host phases (runner_team)
-    bool teams = false;           // opt-in (dv_runner_set "teams"): several host threads per group.  First blamed for the round-4 trajectory defect, then cleared (the shared
-                                  // accept + gauge launch was the trigger, be_api.hip); passes the bit-identity test, stays off by default.
+    bool teams = false;           // dv_runner_set "teams": several host threads per group.  First blamed for the round-4 trajectory defect, then cleared (the cause was the
+                                  // accept decision's missing barrier, be_kernels.h be_accept_body); bit-identical to the single-thread run (tests/test_runner.py).
     int threads_requested = 1;
     bool batch_front = true;      // dv_batch groups: the members' tracking in shared launches too (dv_batch_track_enqueue); dv_runner_set(runner, "batch_front", 0) keeps one set of launches per sequence
     std::string err; std::mutex err_mu;
@@ -212,7 +216,9 @@ int team_round(dv_runner* R, dv_runner::Group& g, int j, int T, bool last) {
     SpinBarrier& B = *g.bar;
     int rc = 0;
     auto mine = [&](auto f) { for (size_t m = j; m < g.members.size() && !rc; m += T) if (f(R->seqs[g.members[m]])) rc = -1; };
-    if (g.pending) mine([&](RSeq& s) { return seq_end(R, s); });
+    // (no look at g.pending here: seq_end is a no-op for a member without a frame in flight, and the group's flag is written by thread 0 alone — in the drain round,
+    //  which has no barrier, a teammate could otherwise read the flag after thread 0 cleared it and skip its members' last frames)
+    mine([&](RSeq& s) { return seq_end(R, s); });
     if (!last) {
         if (j == 0 && !rc && group_track(R, g, 0)) rc = -1;          // (first round only: nothing is enqueued yet)
         if (rc) B.failed.store(1);
@@ -228,7 +234,7 @@ int team_round(dv_runner* R, dv_runner::Group& g, int j, int T, bool last) {
         if (rc) B.failed.store(1);
         if (!B.wait()) return -1;                                      // the next frames are enqueued (their `enqueued` flags are set)
         mine([&](RSeq& s) { const int k1 = s.next + (s.skipped ? 0 : 1); return (!s.skipped && k1 < s.in.n_frames) ? seq_feed_imu(R, s, s.in.times[k1]) : 0; });
-    } else if (j == 0) g.pending = false;
+    }          // (drain round: g.pending is cleared behind the join in dv_runner_run)
     if (rc) B.failed.store(1);
     return rc;
 }
@@ -388,6 +394,7 @@ int dv_runner_set_dynamic(dv_runner* R, int seq, const dv_seq_dynamic* dyn) {
     if (s.next != 0 || s.enqueued || s.pending) { R->err = "dv_runner_set_dynamic: the sequence has already started"; return -1; }
     for (auto& g : R->groups) if (g.batch) for (int i : g.members) if (i == seq) { R->err = "dv_runner_set_dynamic: a dynamic sequence cannot be a member of a dv_batch group (create the runner with group_size 0 for it)"; return -1; }
     if (!s.ctx->inst) { R->err = "dv_runner_set_dynamic: call dv_inst_config on the sequence's context first"; return -1; }
+    if (dyn->inv_mask && dyn->mask_mem != s.in.mem) { R->err = "dv_runner_set_dynamic: mask_mem must equal the frames' mem (dv_track_stereo_enqueue takes frames and mask from one memory kind)"; return -1; }
     s.dynamic = true; s.dyn = *dyn;
     for (auto& b : s.db) { b.rows.resize(DV_MAX_FEATS); b.insts.resize(64); b.ifeats.resize(64 * 256); b.pts.resize((size_t)3 * 65536); b.valid = false; }
     return 0;
@@ -404,7 +411,7 @@ int dv_runner_dynamic_stats(dv_runner* R, int seq, long long* detections, long l
 int dv_runner_set(dv_runner* R, const char* key, int value) {
     if (!R || !key) return -1;
     if (std::strcmp(key, "batch_front") == 0) { R->batch_front = value != 0; runner_layout(R); return 0; }      // (teams need the shared front end)
-    if (std::strcmp(key, "teams") == 0) { R->teams = value != 0; runner_layout(R); return 0; }                  // before the first dv_runner_run; KNOWN DEFECT, see dv_runner::teams
+    if (std::strcmp(key, "teams") == 0) { R->teams = value != 0; runner_layout(R); return 0; }                  // before the first dv_runner_run; see dv_runner::teams
     R->err = std::string("dv_runner_set: unknown key ") + key;
     return -1;
 }

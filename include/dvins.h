@@ -465,7 +465,7 @@ typedef struct dv_seq_input {
  * All arrays have n_frames entries and must outlive the runner; masks of detections are host memory, inv_mask / disp follow their *_mem. */
 typedef struct dv_inst_det dv_inst_det; typedef struct dv_box3d dv_box3d;      /* defined with the dynamic-mode entries below */
 typedef struct dv_seq_dynamic {
-    const uint8_t* const* inv_mask; int32_t mask_mem /* DV_MEM_* */, mode /* DV_MODE_SEMANTIC (default when 0 is passed is RAW: set it) or DV_MODE_NAIVE */;
+    const uint8_t* const* inv_mask; int32_t mask_mem /* DV_MEM_*: must equal dv_seq_input::mem (frames and mask are handed to dv_track_stereo_enqueue with ONE memory kind; checked) */, mode /* DV_MODE_SEMANTIC (default when 0 is passed is RAW: set it) or DV_MODE_NAIVE */;
     const dv_inst_det* const* dets; const int32_t* n_dets;
     const dv_box3d* const* boxes3d; const int32_t* n_boxes3d;      /* may be NULL (no 3-D detector) */
     const float* const* disp; int32_t disp_mem, disp_stride /* bytes, 0 = 4 * width */; double baseline;      /* disp may be NULL: dv_inst_det::points are handed through */

@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box (gpurun): everything profiles/ keeps for a round.  usage: scripts/collect_profiles.sh <tag>   (e.g. r04_a) -> gpurun_out/<tag>_*
 #   * the bench lines themselves (no profiler): default (raw + dynamic line + cpu_baseline), --steps 20 (the driver's command), --mode dynamic, and the multi-sequence
-#     lines of BASELINE.json's config 4, each behind the per-sequence ATE gate (a run with a corrupted trajectory prints no line): 16 x 1280x720 (two groups of 8, one host
+#     lines of BASELINE.json's config 4, each behind the per-sequence ATE gate (a run with a corrupted trajectory prints no line): 16 x 1280x720 (four groups of 4, one host
 #     thread per group: the default of --batched), 32 x 1280x720 in groups of 8 and of 16, 64 in groups of 16, 21 KITTI-size sequences in groups of 11 and of 7
 #   * rocprofv3 --kernel-trace --stats for the default, the dynamic and the batched (32 sequences, groups of 16) workload
 #   * the two --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --kernel-trace only — the pool refuses --pmc combined with other trace domains) of the default and

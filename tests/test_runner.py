@@ -17,7 +17,7 @@ def make(n_seq, frames, w=752, h=480):
 
 @pytest.mark.parametrize("group_size,threads", [(0, 1), (3, 1), (2, 2), (4, 2), (2, 4)])
 def test_runner_equals_python_pipeline(group_size, threads):
-    """(4, 2) / (2, 4): more threads than groups are asked for — the runner uses ONE thread per group (teams are an opt-in with a known defect, next test)"""
+    """(4, 2) / (2, 4): more threads than groups are asked for — the runner uses ONE thread per group unless teams are switched on (dv_runner_set "teams"; covered by the team tests below)"""
     from dynamic_vins_amd.backend import Runner
     from dynamic_vins_amd.pipeline import Pipeline
     S, frames = 4 if threads >= 2 else 3, 30

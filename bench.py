@@ -270,6 +270,8 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         for key in filter(None, args.debug_set.split(",")):
             assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
         runner = Runner([pipe], host_frames=args.host_frames)      # --host-frames: pinned host buffers, every frame's upload inside the timed region
+        if os.environ.get("BENCH_TRACKER_THREAD", "1") != "1":          # A/B: dynamic mode on the one-thread loop of round 4 instead of T2 beside T3
+            runner.set("tracker_thread", 0)
         runner.run(warm_ba * stride)
         it0 = runner.get(0)[2]                               # window-solve iterations spent in the warm-up
         gc.collect(); gc.freeze()

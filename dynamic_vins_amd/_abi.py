@@ -127,6 +127,7 @@ SIGNATURES = {
     "dv_ba_debug_dev_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_est_debug_hash_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_runner_get_row_log": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "dv_runner_get_frame_clock": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_runner_batch_rounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dv_runner_batch_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "dv_runner_set_dynamic": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),

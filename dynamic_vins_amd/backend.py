@@ -612,6 +612,12 @@ class Runner:
             return a.value, b.value
         return None
 
+    def frame_clock(self, i, which=0, cap=100000):
+        """host steady clock (seconds) at the end of every frame of sequence i so far (which = 1: at which its tracker thread delivered every frame); diagnostics"""
+        t = np.zeros(cap, np.float64); n = C.c_int(0)
+        self.lib.dv_runner_get_frame_clock(self.h, i, int(which), t.ctypes.data, cap, C.byref(n))
+        return t[: n.value].copy()
+
     def frames(self, i, cap=100000):
         """every frame handed to the back end: rows [t, px py pz qx qy qz qw, nonlinear]"""
         rows = np.zeros((cap, 9)); n = C.c_int(0)

@@ -187,8 +187,12 @@ int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& sc
     if (pend.pinned_bytes < up_bytes + dl_bytes) {
         if (pend.pinned) (void)hipHostFree(pend.pinned);
         pend.pinned = nullptr; pend.pinned_bytes = 0;
-        DV_CHECK(hipHostMalloc(&pend.pinned, 2 * (up_bytes + dl_bytes), hipHostMallocDefault));
-        pend.pinned_bytes = 2 * (up_bytes + dl_bytes);
+        // with a floor (4 MB ~ 16 objects x 11 frames with ~150 k points): the object problem GROWS over the first frames after the objects are initialised, and every
+        // hipHostFree / hipHostMalloc pair is a multi-millisecond call that holds runtime locks the tracker thread's launches wait for (seen as 7 ms frames at the
+        // start of the timed region of the dynamic bench line)
+        const size_t want = std::max<size_t>(2 * (up_bytes + dl_bytes), (size_t)4 << 20);
+        DV_CHECK(hipHostMalloc(&pend.pinned, want, hipHostMallocDefault));
+        pend.pinned_bytes = want;
     }
     if (!pend.ev) DV_CHECK(hipEventCreateWithFlags(&pend.ev, hipEventDisableTiming));
     struct HostView { uint8_t* p; uint8_t* data() { return p; } } host{ (uint8_t*)pend.pinned };
@@ -226,7 +230,7 @@ int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& sc
     double xc = 0;
     for (int f = 0; f < OS_NF; ++f) if (frame_has_box[f]) for (int k = 0; k < 7; ++k) xc += P->body_pose[7 * f + k] * P->body_pose[7 * f + k];
 
-    if (scratch.ensure(off) != hipSuccess) DV_FAIL("dv_obj_solve: out of device memory");
+    if (scratch.ensure(std::max<size_t>(off, (size_t)8 << 20)) != hipSuccess) DV_FAIL("dv_obj_solve: out of device memory");      // (floor: a hipFree + hipMalloc per growth step is a device-wide synchronisation)
     uint8_t* base = (uint8_t*)scratch.p;
     DV_CHECK(hipMemcpyAsync(base, host.data(), up_bytes, hipMemcpyHostToDevice, s));
     DV_CHECK(hipMemcpyAsync(base + o_x1, base + o_x0, 8 * 7 * (size_t)V, hipMemcpyDeviceToDevice, s));

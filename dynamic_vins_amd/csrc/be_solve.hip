@@ -378,10 +378,10 @@ void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s) { hipL
 #define BS_R 8
 #endif
 #ifdef BE_SOLVE_TS
-__device__ long long be_dbg_ts[32];
+__device__ long long be_dbg_ts[48];
 #define TS(k) do { if (threadIdx.x == 0) { be_dbg_ts[k] = wall_clock64(); if ((k) == 4) be_dbg_ts[30] = clock64(); if ((k) == 5) be_dbg_ts[31] = clock64(); } } while (0)
 #define TSW(k) do { if (threadIdx.x == SOL_THREADS - 64) be_dbg_ts[k] = wall_clock64(); } while (0)
-extern "C" int dv_debug_solve_ts(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(be_dbg_ts), sizeof(long long) * 32) == hipSuccess ? 0 : -1; }
+extern "C" int dv_debug_solve_ts(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(be_dbg_ts), sizeof(long long) * 48) == hipSuccess ? 0 : -1; }
 #else
 #define TS(k) do {} while (0)
 #define TSW(k) do {} while (0)
@@ -735,6 +735,15 @@ __device__ __forceinline__ void mf_diag_factor(mf_d4& T, const MfLds& m, int k, 
     if (c0 < 0 || c0 >= 8) mf_diag_substep<2>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
     if (c0 < 0 || c0 >= 12) mf_diag_substep<3>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
     *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(k, k, NB) * 256 + lane * 4) = Wt;      // W_k = L_kk^-1, result layout (the workgroup barrier behind this tile publishes it)
+    // ... and a second image in the PANEL's operand order (lane (rho, c) of a panel wave wants W[c][rho + 4 q], q = 0..3: here four consecutive doubles at lane * 4): the
+    // transposing read of the result-layout image is a 4-way bank conflict, and all sixteen waves issue it in the same instant behind barrier A — the panel phase was
+    // bound by the LDS pipe (0.8 us per step, phase stamps), not by its four MFMAs.  One wave pays the scattered WRITE once instead.  The image lives in the gather
+    // buffers of waves 12-15, idle during the factorisation (diagonal tiles belong to waves <= 10); one image at a time suffices: W_k is dead behind barrier B of step k.
+    {
+        double* wt = m.gat + 768;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wt[((((c & 3) << 4) + rho + 4 * r) << 2) + (c >> 2)] = Wt[r];
+    }
     __builtin_amdgcn_s_setprio(0);      // (the pivots are checked once, behind the last tile: ldlt_mf16)
 }
 // Three other forms of this tile were built and measured in round 5 (scripts/dbg/diag_bench.hip keeps them: rank-1 MFMA Gauss-Jordan in place, the same with the next
@@ -826,7 +835,7 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
     for (int i = tid; i < 16 * NB; i += SOL_THREADS) m.yv[i] = 0.0;
     if (tid == 0) *s_fail = 0;
 #ifdef BE_SOLVE_TS
-    if (tid == 0) { be_dbg_ts[19] = 0; be_dbg_ts[20] = 0; }
+    if (tid == 0) { be_dbg_ts[19] = 0; be_dbg_ts[20] = 0; be_dbg_ts[32] = 0; be_dbg_ts[33] = 0; be_dbg_ts[34] = 0; be_dbg_ts[35] = 0; }
 #endif
     lds_barrier();
     TS(4);
@@ -840,10 +849,10 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
 #endif
     // one panel tile: V = D^-1 W_k U, kept in the registers, stored as the factor's fragment, row n of L (the last block row) copied out as y
     auto panel = [&](mf_d4& T, int I, int k) {
-        const double* Wk = m.Tl + (size_t)mf_tix(k, k, NB) * 256;
-        double wf[4], ivr[4];
+        const mf_d4 wf = *reinterpret_cast<const mf_d4*>(m.gat + 768 + lane * 4);      // W_k[c][rho + 4 q], q = 0..3: the panel-order image (mf_diag_factor)
+        double ivr[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { wf[q] = Wk[((((c & 3) << 4) + rho + 4 * q) << 2) + (c >> 2)]; ivr[q] = m.iv[16 * k + rho + 4 * q]; }      // W[c][rho + 4q] from the result-layout image
+        for (int q = 0; q < 4; ++q) ivr[q] = m.iv[16 * k + rho + 4 * q];
         mf_d4 Y = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
         for (int q = 0; q < 4; ++q) Y = mf_mfma(wf[q], T[q], Y);
@@ -863,12 +872,22 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
         if (wave == k + 1) {
             // ---- the diagonal chain: slot 1 of this wave is tile (k+1, k) ----
             __builtin_amdgcn_s_setprio(3);
+#ifdef BE_SOLVE_TS
+            __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_c0 = wall_clock64();      // (lgkmcnt(0): dk has arrived)
+#endif
             panel(U[1], k + 1, k);
+#ifdef BE_SOLVE_TS
+            __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_c1 = wall_clock64();
+#endif
 #pragma unroll
             for (int q = 0; q < 4; ++q) U[0] = mf_mfma(U[1][q], dk[q] * U[1][q], U[0]);
+#ifdef BE_SOLVE_TS
+            asm volatile("s_nop 15\n\ts_nop 3\n\tv_mov_b64 %0, %0" : "+v"(U[0][0])); const long long t_c2 = wall_clock64();      // the last MFMA's result has landed
+#endif
             if (k + 2 < NB) lds_barrier();               // B (the last column has one tile below the diagonal, this wave's: nobody waits for a panel there)
 #ifdef BE_SOLVE_TS
             const long long t_u = wall_clock64();
+            if (lane == 0) { be_dbg_ts[32] += t_c0 - t_prev; be_dbg_ts[33] += t_c1 - t_c0; be_dbg_ts[34] += t_c2 - t_c1; be_dbg_ts[35] += t_u - t_c2; }
 #endif
             mf_diag(U[0], m, k + 1, NB, n, s_fail);
 #ifdef BE_SOLVE_TS
@@ -877,6 +896,11 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
             lds_barrier();                               // A
         } else {
             // ---- everybody else: panel tile of column k, then the trailing update ----
+#ifdef MF_EXPERIMENT_SKIP_MATES
+            // TIMING EXPERIMENT ONLY (wrong numbers): the SIMD-mates of the chain wave do nothing this step — an optimistic bound for a design that keeps the chain's SIMD to itself
+            const bool mate = ((wave & 3) == ((k + 1) & 3));
+            if (mate) { if (k + 2 < NB) lds_barrier(); lds_barrier(); continue; }
+#endif
 #pragma unroll
             for (int s = 1; s < MF_SLOTS; ++s) if (sJ[s] == k) panel(U[s], sI[s], k);
             if (k + 2 < NB) lds_barrier();               // B

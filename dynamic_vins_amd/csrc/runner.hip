@@ -5,11 +5,16 @@
 // One sequence (Pipeline of dynamic_vins_amd/pipeline.py, the order that overlaps the front end of frame k+1 with the back end of frame k on one host thread):
 //     collect tracking(k) -> feed IMU up to t_k -> dv_est_process_begin(k) [host bookkeeping + enqueue of the window solve]
 //     -> enqueue tracking(k+1) -> feed IMU up to t_k+1 -> dv_est_process_end(k) [wait, outlier rejection, slide]
+// A DYNAMIC sequence runs the reference's two threads literally (dv_runner_set "tracker_thread", default on): T2 = a tracker thread (TrackSemanticImage + InstsTrack of
+// frame after frame, collected into a small ring: the role of feature_queue, basic/feature_queue.h:19-73, blocking instead of dropping so that no frame is lost) beside
+// T3 = the estimator loop on the calling thread (pop, IMU, window solve, object branch, end).  Tracker and estimator share nothing but the ring: the tracker API touches
+// the context's tracker state and front-end streams, the estimator API its own state and the BA / object streams.
 // Many sequences on one GPU (config 4 of BASELINE.json, "batched"): the sequences of a GROUP run their begin phases back to back, dv_batch_enqueue launches the
 // iteration slots of all their window solves as one launch per stage, and while that runs the host turns to the next group; the end phases of a group follow when
 // its turn comes again.  `threads` host threads each drive their own groups (the reference runs one process — three threads — per sequence).
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -29,6 +34,8 @@ struct RSeq {
     std::vector<double> poses;          // [t, px py pz qx qy qz qw] per frame solved in the non-linear phase
     std::vector<unsigned long long> row_log;      // per frame handed to the back end: [frame index k, rows collected, FNV-1a of the rows' bytes, solver iterations] (dv_runner_get_row_log: diagnostics)
     unsigned long long cur_rows_hash = 0; int cur_k = -1;
+    std::vector<double> track_clock;    // tracker thread: host clock at which each frame was delivered into the ring (dv_runner_get_frame_clock with which = 1)
+    std::vector<double> end_clock;      // host clock (seconds, steady) at which each frame's dv_est_process_end returned (dv_runner_get_frame_clock: diagnostics)
     std::vector<double> frames9;        // [t, px py pz qx qy qz qw, nonlinear] of EVERY frame handed to the back end (what SaveBodyTrajectory writes)
     long long iterations = 0, frames = 0;
     std::string err;
@@ -37,6 +44,13 @@ struct RSeq {
     bool dynamic = false; dv_seq_dynamic dyn{};
     struct DynBuf { std::vector<dv_feat> rows; int n_rows = 0; std::vector<dv_inst_obs> insts; int n_insts = 0; std::vector<dv_feat> ifeats; int n_ifeats = 0; std::vector<double> pts; int n_pts = 0; bool valid = false; };
     DynBuf db[2]; int cur = 0;
+    // tracker thread (T2) -> estimator loop (T3): ring of collected frames.  ring_head = frame index of ring[ring_pos], ring_count frames are ready; tracked_next = the
+    // next frame the tracker will take.  Guarded by ring_mu; the tracker fills ring[(ring_pos + ring_count) % RING] outside the lock (the slot is not visible yet).
+    static constexpr int RING = 3;
+    DynBuf ring[RING]; int ring_pos = 0, ring_count = 0, ring_head = 0, tracked_next = 0; bool ring_failed = false;
+    int track_last = -1; bool track_stop = false, track_busy = false; std::thread tracker;      // the tracker thread lives as long as the runner (a thread's first HIP call costs milliseconds:
+                                                                                                // a thread per dv_runner_run put that into the first frames of every call); track_last = the last frame it may take
+    std::unique_ptr<std::mutex> ring_mu = std::make_unique<std::mutex>(); std::unique_ptr<std::condition_variable> ring_cv = std::make_unique<std::condition_variable>();
     long long detections = 0, object_features = 0, frames_with_objects = 0; int min_detections = 1 << 30;
 };
 }
@@ -64,6 +78,7 @@ struct dv_runner {
     bool teams = false;           // dv_runner_set "teams": several host threads per group.  First blamed for the round-4 trajectory defect, then cleared (the cause was the
                                   // accept decision's missing barrier, be_kernels.h be_accept_body); bit-identical to the single-thread run (tests/test_runner.py).
     int threads_requested = 1;
+    bool tracker_thread = true;   // dynamic sequences: the reference's T2 beside T3 (dv_runner_set "tracker_thread"); 0 = the one-thread loop of round 4 (dyn_begin), kept for A/B and as the bit-identity reference
     bool batch_front = true;      // dv_batch groups: the members' tracking in shared launches too (dv_batch_track_enqueue); dv_runner_set(runner, "batch_front", 0) keeps one set of launches per sequence
     std::string err; std::mutex err_mu;
 };
@@ -130,10 +145,65 @@ int dyn_begin(dv_runner* R, RSeq& s) {
     return 0;
 }
 
+// ---- dynamic mode on two threads ----
+// T2: tracks frames tracked_next .. track_last (inclusive; dv_runner_run moves the bound), each into the next free ring slot; parks while the ring is full (the reference's queue drops instead: 100 deep, never
+// reached by a tracker that is faster than its estimator — here nothing may be lost because the run must equal the one-thread loop frame for frame)
+void dyn_tracker_thread(dv_runner* R, RSeq& s) {
+    for (;;) {
+        int f, slot;
+        {
+            std::unique_lock<std::mutex> lk(*s.ring_mu);
+            s.track_busy = false; s.ring_cv->notify_all();
+            s.ring_cv->wait(lk, [&] { return s.track_stop || (!s.ring_failed && s.tracked_next <= s.track_last && s.ring_count < RSeq::RING); });
+            if (s.track_stop) return;
+            s.track_busy = true;
+            f = s.tracked_next; slot = (s.ring_pos + s.ring_count) % RSeq::RING;
+        }
+        RSeq::DynBuf& b = s.ring[slot];
+        const bool bad = dyn_enqueue(R, s, f) || dyn_collect(R, s, b);
+        {
+            std::lock_guard<std::mutex> lk(*s.ring_mu);
+            if (bad) s.ring_failed = true;
+            else { if (s.ring_count == 0) s.ring_head = f; ++s.ring_count; ++s.tracked_next; s.track_clock.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count()); }
+        }
+        s.ring_cv->notify_all();
+    }
+}
+// T3, first half of a step: frame k from the ring -> IMU -> window solve -> object branch -> IMU up to k+1 (the same estimator calls in the same order as dyn_begin)
+int dyn_begin_threaded(dv_runner* R, RSeq& s) {
+    const int k = s.next;
+    if (k >= s.in.n_frames) { s.err = "sequence exhausted"; set_err(R, s.err); return -1; }
+    RSeq::DynBuf* bp;
+    {
+        std::unique_lock<std::mutex> lk(*s.ring_mu);
+        s.ring_cv->wait(lk, [&] { return s.ring_count > 0 || s.ring_failed; });
+        if (s.ring_failed) return -1;
+        if (s.ring_head != k) { s.err = "internal: the tracker ring is out of step with the estimator"; set_err(R, s.err); return -1; }
+        bp = &s.ring[s.ring_pos];
+    }
+    RSeq::DynBuf& b = *bp;
+    const double t = s.in.times[k];
+    s.n_rows = b.n_rows;
+    if (seq_feed_imu(R, s, t)) return -1;
+    const int rc = dv_est_process_dynamic_begin_ego(s.ctx, b.rows.data(), b.n_rows, t);
+    if (rc < 0) return fail(R, s, "dv_est_process_dynamic_begin_ego");
+    if (rc > 0) { s.err = "IMU stream does not cover the frame"; set_err(R, s.err); return -1; }
+    if (dv_est_process_dynamic_attach(s.ctx, b.n_insts ? b.insts.data() : nullptr, b.n_insts, b.n_ifeats ? b.ifeats.data() : nullptr, b.n_pts ? b.pts.data() : nullptr)) return fail(R, s, "dv_est_process_dynamic_attach");
+    s.detections += b.n_insts; s.object_features += b.n_ifeats; s.frames_with_objects += b.n_insts > 0; s.min_detections = std::min(s.min_detections, b.n_insts);
+    {   // the estimator has taken what it needs of the slot (rows, detections, feature rows and points are copied into its own tables by the two calls above)
+        std::lock_guard<std::mutex> lk(*s.ring_mu);
+        b.valid = false; s.ring_pos = (s.ring_pos + 1) % RSeq::RING; --s.ring_count; ++s.ring_head;
+    }
+    s.ring_cv->notify_all();
+    if (k + 1 < s.in.n_frames && seq_feed_imu(R, s, s.in.times[k + 1])) return -1;
+    s.pending = true; s.pending_t = t;
+    return 0;
+}
+
 // first half of a step: everything up to and including the enqueue of frame k's window solve and of frame k+1's tracking.  own_front = false: the caller enqueues
 // the tracking of the group's frames itself, in shared launches (group_round), and feeds the IMU samples of frame k+1 afterwards.
 int seq_begin(dv_runner* R, RSeq& s, bool own_front = true) {
-    if (s.dynamic) return dyn_begin(R, s);
+    if (s.dynamic) return R->tracker_thread ? dyn_begin_threaded(R, s) : dyn_begin(R, s);
     const int k = s.next;
     if (k >= s.in.n_frames) { s.err = "sequence exhausted"; set_err(R, s.err); return -1; }
     if (!s.enqueued) { if (!own_front) { s.err = "internal: frame not enqueued"; set_err(R, s.err); return -1; } if (seq_enqueue(R, s, k)) return -1; }
@@ -181,6 +251,7 @@ int seq_end(dv_runner* R, RSeq& s) {
     if (dv_est_process_end(s.ctx, &s.last)) return fail(R, s, "dv_est_process_end");
     s.pending = false;
     s.row_log.push_back((unsigned long long)s.cur_k); s.row_log.push_back((unsigned long long)s.n_rows); s.row_log.push_back(s.cur_rows_hash); s.row_log.push_back((unsigned long long)s.last.iterations);
+    s.end_clock.push_back(std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count());
     s.frames9.push_back(s.pending_t);
     for (int i = 0; i < 7; ++i) s.frames9.push_back(s.last.window[10][i]);
     s.frames9.push_back((double)s.last.nonlinear);
@@ -290,6 +361,10 @@ dv_runner* dv_runner_create(dv_ctx* const* ctxs, const dv_seq_input* seqs, int n
 
 void dv_runner_destroy(dv_runner* R) {
     if (!R) return;
+    for (auto& s : R->seqs) if (s.tracker.joinable()) {
+        { std::lock_guard<std::mutex> lk(*s.ring_mu); s.track_stop = true; }
+        s.ring_cv->notify_all(); s.tracker.join();
+    }
     for (auto& g : R->groups) if (g.batch) dv_batch_destroy(g.batch);      // (the contexts stay the caller's)
     delete R;
 }
@@ -301,6 +376,16 @@ int dv_runner_run(dv_runner* R, int n_rounds, double* wall_seconds) {
     for (auto& s : R->seqs) if (s.next + n_rounds > s.in.n_frames) { R->err = "dv_runner_run: a sequence has fewer frames left than rounds asked"; return -1; }
     const auto t0 = std::chrono::steady_clock::now();
     int rc = 0;
+    // T2 of every dynamic sequence: may track up to ONE frame past what this call hands to the back end (as the one-thread loop does)
+    if (R->tracker_thread && n_rounds > 0)
+        for (auto& s : R->seqs) if (s.dynamic) {
+            {
+                std::lock_guard<std::mutex> lk(*s.ring_mu);
+                s.ring_failed = false; s.track_last = std::min(s.next + n_rounds, s.in.n_frames - 1);
+                if (!s.tracker.joinable()) s.tracker = std::thread(dyn_tracker_thread, R, std::ref(s));
+            }
+            s.ring_cv->notify_all();
+        }
     auto drive = [&](int first, int step) -> int {          // one host thread: its groups, round after round
         for (int r = 0; r < n_rounds; ++r) for (size_t gi = first; gi < R->groups.size(); gi += step) if (group_round(R, R->groups[gi])) return -1;
         for (size_t gi = first; gi < R->groups.size(); gi += step) if (group_drain(R, R->groups[gi])) return -1;
@@ -327,6 +412,14 @@ int dv_runner_run(dv_runner* R, int n_rounds, double* wall_seconds) {
         for (auto& t : th) t.join();
         for (int v : rcs) if (v) rc = -1;
     }
+    // the call ends when every tracker has delivered its last frame of this call (or has failed); an estimator-side failure takes the bound back so that a parked tracker stays parked
+    if (R->tracker_thread && n_rounds > 0)
+        for (auto& s : R->seqs) if (s.dynamic) {
+            std::unique_lock<std::mutex> lk(*s.ring_mu);
+            if (rc) s.track_last = s.tracked_next - 1;
+            s.ring_cv->wait(lk, [&] { return !s.track_busy && (s.ring_failed || s.tracked_next > s.track_last || s.ring_count >= RSeq::RING); });
+            if (s.ring_failed && !rc) rc = -1;
+        }
     for (auto& s : R->seqs) (void)dv_sync(s.ctx);
     if (wall_seconds) *wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return rc;
@@ -351,6 +444,17 @@ int dv_runner_get_frames(dv_runner* R, int seq, double* rows9, int cap, int* n_r
     const int n = (int)(s.frames9.size() / 9);
     if (n_rows) *n_rows = n;
     if (rows9) std::memcpy(rows9, s.frames9.data(), sizeof(double) * 9 * (size_t)std::min(n, std::max(cap, 0)));
+    return 0;
+}
+
+int dv_runner_get_frame_clock(dv_runner* R, int seq, int which, double* seconds, int cap, int* n_out) {
+    if (!R || seq < 0 || seq >= (int)R->seqs.size()) return -1;
+    RSeq& s = R->seqs[seq];
+    std::lock_guard<std::mutex> lk(*s.ring_mu);
+    const std::vector<double>& v = which == 1 ? s.track_clock : s.end_clock;
+    const int n = (int)v.size();
+    if (n_out) *n_out = n;
+    if (seconds) std::memcpy(seconds, v.data(), sizeof(double) * (size_t)std::min(n, std::max(cap, 0)));
     return 0;
 }
 
@@ -397,6 +501,7 @@ int dv_runner_set_dynamic(dv_runner* R, int seq, const dv_seq_dynamic* dyn) {
     if (dyn->inv_mask && dyn->mask_mem != s.in.mem) { R->err = "dv_runner_set_dynamic: mask_mem must equal the frames' mem (dv_track_stereo_enqueue takes frames and mask from one memory kind)"; return -1; }
     s.dynamic = true; s.dyn = *dyn;
     for (auto& b : s.db) { b.rows.resize(DV_MAX_FEATS); b.insts.resize(64); b.ifeats.resize(64 * 256); b.pts.resize((size_t)3 * 65536); b.valid = false; }
+    for (auto& b : s.ring) { b.rows.resize(DV_MAX_FEATS); b.insts.resize(64); b.ifeats.resize(64 * 256); b.pts.resize((size_t)3 * 65536); b.valid = false; }
     return 0;
 }
 int dv_runner_dynamic_stats(dv_runner* R, int seq, long long* detections, long long* object_features, long long* frames_with_objects, int* min_detections) {
@@ -411,6 +516,10 @@ int dv_runner_dynamic_stats(dv_runner* R, int seq, long long* detections, long l
 int dv_runner_set(dv_runner* R, const char* key, int value) {
     if (!R || !key) return -1;
     if (std::strcmp(key, "batch_front") == 0) { R->batch_front = value != 0; runner_layout(R); return 0; }      // (teams need the shared front end)
+    if (std::strcmp(key, "tracker_thread") == 0) {          // dynamic sequences: T2 beside T3 (default) or the one-thread loop; before the first dv_runner_run
+        for (auto& s : R->seqs) if (s.next != 0 || s.enqueued || s.pending || s.tracked_next != 0) { R->err = "dv_runner_set: tracker_thread must be chosen before the first dv_runner_run"; return -1; }
+        R->tracker_thread = value != 0; return 0;
+    }
     if (std::strcmp(key, "teams") == 0) { R->teams = value != 0; runner_layout(R); return 0; }                  // before the first dv_runner_run; see dv_runner::teams
     R->err = std::string("dv_runner_set: unknown key ") + key;
     return -1;

@@ -484,6 +484,9 @@ int dv_runner_get(dv_runner* runner, int seq, dv_est_state* last, double* poses8
 int dv_runner_get_frames(dv_runner* runner, int seq, double* rows9, int cap, int* n_rows);
 /* diagnostics: per frame handed to the back end [frame index, rows collected from the tracker, FNV-1a hash of those rows' bytes, solver iterations] — two runs of the same
  * sequence must agree entry by entry; where they first differ says whether the tracker's output or only the solve moved (raw mode) */
+/* diagnostics: the host's steady clock (seconds) at the end of every frame handed to the back end so far (which = 0), or at which the tracker thread of a dynamic sequence
+ * delivered every frame (which = 1): per-frame pacing of a run without cutting it into calls */
+int dv_runner_get_frame_clock(dv_runner* runner, int seq, int which, double* seconds, int cap, int* n_out);
 int dv_runner_get_row_log(dv_runner* runner, int seq, unsigned long long* rows4, int cap, int* n_rows);
 int dv_runner_batch_rounds(dv_runner* runner, long long* batched_rounds, long long* single_rounds);      /* dv_batch_info summed over the groups */
 int dv_runner_batch_timing(dv_runner* runner, int on, double* out3, long long* rounds, int* windows);      /* dv_batch_timing of the runner's groups, averaged */

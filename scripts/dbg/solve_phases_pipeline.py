@@ -16,14 +16,14 @@ extra = []
 for k in range(N):
     pipe.step()
     torch.cuda.synchronize()
-    ts = (C.c_longlong * 32)()
+    ts = (C.c_longlong * 48)()
     lib.dv_debug_solve_ts(ts)
-    t = np.array(ts[:32], dtype=np.int64)
+    t = np.array(ts[:48], dtype=np.int64)
     if k >= 20: rows.append([(t[b] - t[a]) / 100.0 for a, b, _ in seqp])
-    if k >= 20: extra.append([t[16] / 100.0, t[17] / 100.0, t[18] / 100.0, t[19] / 100.0, t[20] / 100.0])
+    if k >= 20: extra.append([t[16] / 100.0, t[17] / 100.0, t[18] / 100.0, t[19] / 100.0, t[20] / 100.0, t[32] / 100.0, t[33] / 100.0, t[34] / 100.0, t[35] / 100.0])
 r = np.array(rows)
 for i, (_, _, name) in enumerate(seqp):
     print(f"{name:26s} mean {r[:, i].mean():7.2f}  min {r[:, i].min():7.2f}  max {r[:, i].max():7.2f}")
 e = np.array(extra)
-for i, name in enumerate(["mf16: load + diag tile 0", "mf16: panels (sum over steps)", "mf16: updates + next diag (sum)", "mf16: diag tiles 1.. (owner wave, sum)", "mf16: owner's update before its diag (sum)"]):
+for i, name in enumerate(["mf16: load + diag tile 0", "mf16: panels (sum over steps)", "mf16: updates + next diag (sum)", "mf16: diag tiles 1.. (owner wave, sum)", "mf16: owner's update before its diag (sum)", "  chain: barrier A -> dk arrived (sum)", "  chain: panel of (k+1, k) (sum)", "  chain: own diagonal update, result landed (sum)", "  chain: barrier B (sum)"]):
     print(f"{name:44s} mean {e[:, i].mean():7.2f}")

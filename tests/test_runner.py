@@ -142,8 +142,12 @@ def test_runner_shared_front_end_launches_leave_the_same_bits():
             p.ctx.close()
 
 
-def test_runner_dynamic_mode_equals_the_python_dynamic_pipeline():
-    """dv_runner_set_dynamic: the reference's dynamic loop per frame in C++ (TrackSemanticImage + InstsTrack enqueued together, collect, the three-phase back end with
+@pytest.mark.parametrize("tracker_thread,calls", [(1, (29,)), (0, (29,)), (1, (7, 1, 13, 8))])
+def test_runner_dynamic_mode_equals_the_python_dynamic_pipeline(tracker_thread, calls):
+    """tracker_thread 1 (default): the reference's T2 / T3 — a tracker thread filling a ring of collected frames beside the estimator loop (system/main.cpp:178-330,
+    :394-404, basic/feature_queue.h); 0: the one-thread loop.  Both, and a run cut into several dv_runner_run calls (the tracker thread ends and restarts at every call,
+    one frame ahead), must leave the same bits as the Python pipeline.
+    dv_runner_set_dynamic: the reference's dynamic loop per frame in C++ (TrackSemanticImage + InstsTrack enqueued together, collect, the three-phase back end with
     the object branch beside the window solve) must leave EXACTLY what pipeline.DynamicPipeline leaves: ego window states, trajectory, object states, and what the
     object branch was fed — objects in every frame, extra points from the disparity map on the device"""
     from dynamic_vins_amd.backend import Runner
@@ -154,7 +158,10 @@ def test_runner_dynamic_mode_equals_the_python_dynamic_pipeline():
     kw = dict(max_cnt=150, min_dist=20, max_iters=8, use_det3d=1, mask_morphology_size=5)
     a, b = DynamicPipeline(seq, **kw), DynamicPipeline(seq, **kw)
     runner = Runner([a], group_size=0, threads=1)
-    runner.run(frames - 1)
+    runner.set("tracker_thread", tracker_thread)
+    assert sum(calls) == frames - 1
+    for n in calls:
+        runner.run(n)
     for _ in range(frames - 1):
         b.step()
     st, poses, iters, fr = runner.get(0)

@@ -76,6 +76,9 @@ struct BeMargArgs {
     double* imu_w;                // [465] whitened Jacobian (15 x 30) and residual (15) of the IMU factor (0,1): written by the extra block of be_marg_lm, read by be_marg_finish
     double* c0_out;               // optional second home of c0 (the device-resident prior of the estimator)
     const int32_t* lm_sel;        // optional: landmark b of the launch is lm[lm_sel[b]] (marginalization straight out of the solved window)
+    // be_marg_finish on the matrix cores (round 5): the dropped block's elimination and the 82-pivot factorisation behind c0 as ONE 16-wide LDL^T (be_mf16.h) of the system
+    // [dropped dims, padded to whole tiles | kept dims | right-hand side]: mf16 != 0 and its tile plan (be_mf16_plan for mf_n = 16 ceil(m / 16) + D - m) in mf_plan
+    uint8_t mf_plan[64]; int32_t mf16, mf_n;
 };
 
 // yaw-gauge fix after a solve (Estimator::Double2vector, estimator.cpp:1111-1154): rotates the solved window back to the yaw and
@@ -200,7 +203,7 @@ void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s);
 void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s);      // be_accept + be_gauge in one launch (estimator path)
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s);      // spec: reduce the candidate's set (or, after a failed / invalid step, rebuild x's with the new mu)
 static_assert(offsetof(BeSolveArgs, ldl_col0) % 4 == 0, "the MF16 plan is read as dwords");
-bool be_mf16_plan(int n, uint8_t* plan);      // false: the tiles of an n x n system (+ right-hand-side row) do not fit (n > 175): the generic form is used
+bool be_mf16_plan(int n, uint8_t* plan, bool check_solve_lds = true);      // false: the tiles of an n x n system (+ right-hand-side row) do not fit (n > 175): the generic form is used
 int  be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s);        // spec: decide on the pending candidate first (be_accept_kernel's rule)
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);
 // batched forms: n_win independent windows per launch (argument tables in HBM, window index in the grid); be_api.hip enqueues them for a dv_batch

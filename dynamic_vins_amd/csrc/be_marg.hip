@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 #include <cfloat>
 #include "be_kernels.h"
+#include "be_mf16.h"
 #include "dev_once.h"
 
 using namespace be;
@@ -494,6 +495,72 @@ __device__ __forceinline__ void be_marg_finish_body(const BeMargArgs& a) {
         __syncthreads();
     }
     MTS(11);
+    if (a.mf16 && a.c0_mode == 0) {
+        // ---------------- elimination of the dropped block AND c0 as ONE rank-revealing LDL^T, 16 wide, on the f64 matrix cores (be_mf16.h; round 5) ----------------
+        // Extended system, e = 0 .. mf_n: [dropped dims 0..m-1, padded with identity rows to 16 mt | kept dims | right-hand side (row mf_n, as in the window solve: row n of L
+        // comes out as y = D^-1 L^-1 b) | identity padding].  After the first mt block columns the trailing tiles ARE A' (and its right-hand-side row b'): every wave writes
+        // its share to global memory from its registers (after_update, k = mt - 1) and the factorisation simply goes on — its remaining pivots are the LDL^T of A', so
+        // c0 = b'^T A'^+ b' = sum y_k^2 d_k over the kept pivots.  Pivots <= 1e-8 are skipped (1 / d := 0) exactly as the 4-wide panel form below does.
+        // One factorisation of 7 x 7 tiles (D = 97, m = 15) instead of 4 + 21 panel steps of three barriers each.
+        const int mt = (m + 15) >> 4, mf_n = a.mf_n, NBm = (mf_n + 16) >> 4, e_k0 = 16 * mt;
+        const int lane = tid & 63, wv = mf_wave(), cc = lane & 15, rr = lane >> 4;
+        double* mfv = imu_ws + 960;
+        MfLds mf; mf.Tl = sm; mf.gat = mfv; mf.dv = mf.gat + 1024; mf.iv = mf.dv + 16 * NBm; mf.yv = mf.iv + 16 * NBm;
+        __shared__ int s_mf_fail;
+        auto edim = [&](int e) { return e < e_k0 ? (e < m ? e : -2) : (e < e_k0 + n ? m + (e - e_k0) : (e == mf_n ? -1 : -2)); };      // dim of the D x D system | -1 right-hand side | -2 padding
+        auto ext = [&](int ei, int ej) -> double {
+            const int di = edim(ei), dj = edim(ej);
+            const bool real_i = di >= 0, real_j = dj >= 0;
+            const double va = A[(real_i ? di : 0) * D + (real_j ? dj : 0)], vb = bv[real_i ? di : (real_j ? dj : 0)];
+            return (real_i && real_j) ? va : ((di == -1 && real_j) || (dj == -1 && real_i)) ? vb : (di == -1 && dj == -1) ? MF_RHO : (ei == ej ? 1.0 : 0.0);
+        };
+        int sI[MF_SLOTS], sJ[MF_SLOTS];
+        mf_slots(a.mf_plan, wv, NBm, sI, sJ);
+        mf_d4 U[MF_SLOTS];
+#pragma unroll
+        for (int s = 0; s < MF_SLOTS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? ext(16 * sI[s] + cc, 16 * sJ[s] + rr + 4 * r) : 0.0;
+        __syncthreads();                                  // every tile is in registers: the LDS image of A, b is dead, the factor's fragments take its place
+        for (int i = tid; i < 16 * NBm; i += MG_THREADS) mf.yv[i] = 0.0;
+        if (tid == 0) s_mf_fail = 0;
+        __syncthreads();
+        MTS(13);
+        auto dump = [&](int k) {
+            if (k != mt - 1) return;
+#pragma unroll
+            for (int s = 0; s < MF_SLOTS; ++s) {
+                if (sI[s] < mt || sJ[s] < mt) continue;   // (wave-uniform)
+                const int ei = 16 * sI[s] + cc, ki = ei - e_k0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ej = 16 * sJ[s] + rr + 4 * r, kj = ej - e_k0;
+                    if (kj < 0 || kj >= n) continue;
+                    const double v = U[s][r];
+                    if (ki < n) {                          // A': the lower triangle is the truth, mirrored (a diagonal tile holds both halves; they agree to rounding only)
+                        if (ki >= kj) { a.outA[(size_t)ki * n + kj] = v; if (ki != kj) a.outA[(size_t)kj * n + ki] = v; }
+                    } else if (ei == mf_n) a.outb[kj] = v;   // b': the right-hand-side row
+                }
+            }
+        };
+        mf16_factor_core<true>(U, a.mf_plan, mf_n, mf, &s_mf_fail, dump);
+        MTS(15);
+        if (wv == 0) {                                    // D of the dropped block -> smallest pivot / clamp flag; c0 and the rank from the kept pivots (fixed order: lane-strided, wave tree)
+            double dmin = DBL_MAX, c0p = 0.0; int bad = 0, rk = 0;
+            for (int e = lane; e < m; e += 64) { const double d = mf.dv[e]; dmin = fmin(dmin, d); bad |= !(d > 1e-8); }
+            for (int k = lane; k < n; k += 64) { const double y = mf.yv[e_k0 + k], d = mf.dv[e_k0 + k]; c0p += y * y * d; rk += mf.iv[e_k0 + k] != 0.0; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { dmin = fmin(dmin, __shfl_xor(dmin, o)); bad |= __shfl_xor(bad, o); rk += __shfl_xor(rk, o); }
+            c0p = wave_sum_f64(c0p);
+            if (lane == 0) {
+                const double mp = fmin(misc[0], dmin);
+                a.out_scalars[0] = c0p; a.out_scalars[1] = mp; a.out_scalars[2] = (bad || misc[1] != 0.0) ? 1.0 : 0.0; a.out_scalars[3] = (double)rk;
+                if (a.c0_out) a.c0_out[0] = c0p;
+            }
+        }
+        MTS(16);
+        return;
+    }
     // ---------------- eliminate the dropped pose / speed-bias dims [0, m): right-looking LDL^T in panels of <= 4 columns on the LOWER
     // triangle of the whole system (A is bitwise symmetric by construction: commuting products summed in one order), with b as an extra
     // row.  (A) thread 0 factors the pivot block, (B) one thread per row below forms its panel entries and updates b, (C) all threads
@@ -747,7 +814,7 @@ void be_launch_reject(const BeRejectArgs& a, hipStream_t s) { if (a.nlm > 0) hip
 void be_launch_gauge(const BeGaugeArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_gauge_kernel, dim3(1), dim3(256), 0, s, a); }
 void be_launch_accept_gauge(const BeSolveArgs& sa, const BeGaugeArgs& ga, hipStream_t s) { hipLaunchKernelGGL(be_accept_gauge_kernel, dim3(1), dim3(256), 0, s, sa, ga); }
 
-static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16 + 960) * sizeof(double); }
+static size_t finish_smem(int D, int n) { return ((size_t)D * D + D + std::max((size_t)n * n, (size_t)1024) + n + 16 + 960 + 1024 + 3 * 16 * MF_MAXNB) * sizeof(double); }      // A | b | W2 | y | misc | IMU factor | MF16: gather buffers, D, 1 / D, y
 static size_t lm_smem() { return std::max((size_t)(MG_MAXF + 2) * 54, (size_t)1024) * sizeof(double); }
 int be_marg_chunks(int nlm) { return (nlm + MG_CH - 1) / MG_CH; }
 int be_marg_part() { return MG_PART; }

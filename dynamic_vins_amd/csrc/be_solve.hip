@@ -24,6 +24,7 @@
 #include "be_kernels.h"
 #include "dev_once.h"
 #include "wave_dpp.h"
+#include "be_mf16.h"
 
 using namespace be;
 
@@ -399,11 +400,6 @@ __device__ __forceinline__ double block_sum(double v, double* red) {     // fixe
     return s;
 }
 
-// Barrier for exchanges that live in LDS only: s_waitcnt lgkmcnt(0) + s_barrier without the workgroup fence of __syncthreads(), which also drains vmcnt —
-// global loads requested ahead of the barrier stay in flight across it (that is the point: operands of a later phase are fetched behind the reductions of
-// this one).  NOT a substitute where other threads' global stores must become visible.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 // N sums with ONE LDS exchange (two barriers) instead of N: red must hold 16 * N doubles
 template <int N>
 __device__ __forceinline__ void block_sum_n(double (&v)[N], double* red) {
@@ -470,13 +466,6 @@ __device__ __forceinline__ void gemv_hd(const double* Hd, int n, const double* x
     __syncthreads();
     if (tid < n) y[tid] = (scratch[tid] + scratch[192 + tid]) + (scratch[384 + tid] + scratch[576 + tid]) + scratch[768 + tid];
     __syncthreads();
-}
-
-__device__ __forceinline__ double fast_rcp(double d) {      // v_rcp_f64 + two Newton steps (full precision, half the latency of a division)
-    double r = __builtin_amdgcn_rcp(d);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-    return r;
 }
 
 // Panel-blocked right-looking LDL^T of the (scaled, damped) reduced camera system.  Every thread owns NSLOT 4x4
@@ -636,121 +625,6 @@ __device__ __forceinline__ bool ldlt_blocked(const double* __restrict__ Sc, cons
 }
 
 
-__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// MF16 — the same LDL^T re-blocked 16 wide on the f64 matrix cores (v_mfma_f64_16x16x4_f64).
-// Every experiment of rounds 1-2 ended at the same per-step cost (~1.2 us per barrier-separated 4-pivot step, 42 steps): so the steps become 11 sixteen-pivot
-// steps.  The (n+1) x (n+1) system — row n carries the right-hand side, so the forward substitution is part of the factorisation and row n of L is
-// y = D^-1 L^-1 rhs — is cut into 16 x 16 tiles; tile (I, J), I >= J, lives TRANSPOSED in the registers of one wave in the MFMA result layout
-// (lane l, register r: U[(l >> 4) + 4 r][l & 15] = A[16 I + (l & 15)][16 J + (l >> 4) + 4 r]).  In that layout a tile is, without any data movement,
-//   * the B operand for a product that sums over its row index, and
-//   * the A operand of its transpose,
-// which is exactly what the two tile operations need:
-//   panel    V_I = X_I^T = D^-1 W_k U_Ik                 A = W_k = L_kk^-1 (fragment read transposed from LDS), B = the tile's registers
-//   update   U_IJ -= X_J D X_I^T = V_J^T (D V_I)          A = the stored fragment of V_J, B = the stored fragment of V_I scaled by d  (4 MFMAs per tile)
-// The fragments V_I stay in LDS as the factor (L_Ik^T); the diagonal slots hold W_k.  Diagonal tile (one wave, ~1 us): four 4-pivot sub-steps; the four pivot
-// rows are gathered through LDS, the 4x4 pivot block reaches every lane by row_newbcast, every lane runs the pivot chain and, by symmetry, the forward
-// substitution of ITS column (lane c holds A[p..p+3][c] = A[c][p..p+3]); ONE MFMA applies the rank-4 update to the tile and a second one the same elementary
-// block transformation to W (Gauss-Jordan: W <- L_q^-1 W), so that W_k = L_kk^-1 comes out of the factorisation.  Tile ownership (be_mf16_plan): wave j owns
-// diagonal tile j and only off-diagonal tiles of columns < j, so the wave that factors diagonal k+1 has no other tile to update in step k.
-// Two workgroup barriers per 16 pivots.  Same solution as ldlt_wavecol to rounding (different summation order): parity by tolerance (iteration sequences, 1e-6).
-#define MF_SLOTS 5
-#define MF_MAXNB 11
-#define MF_RHO 1e300
-typedef double mf_d4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ mf_d4 mf_mfma(double a, double b, mf_d4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-__device__ __forceinline__ int mf_tix(int I, int J, int NB) { return J * NB - (J * (J - 1)) / 2 + (I - J); }
-template <int LANE> __device__ __forceinline__ double mf_rowbc(double v) { return dpp_f64<0x150 + LANE, 0xf>(v); }      // row_newbcast:LANE (gfx90a+): lane LANE of every 16-lane row to the whole row
-__device__ __forceinline__ double mf_sel4(int rho, double v0, double v1, double v2, double v3) {      // v[rho] as three selects (a nested ?: chain is compiled into exec-mask branches)
-    const bool b0 = (rho & 1) != 0, b1 = (rho & 2) != 0;
-    const double t0 = b0 ? v1 : v0, t1 = b0 ? v3 : v2;
-    return b1 ? t1 : t0;
-}
-// (Round 5: hardware wave h runs on SIMD h & 3 (measured, scripts/dbg/diag_bench.hip: trailing-update MFMAs on waves 4, 8, 12 stretch a diagonal tile on wave 0 from
-//  1.52 to 2.11 us, the same load on the other twelve waves does nothing).  Dealing the plan's logical waves to the SIMDs in blocks of four — the chain wave's
-//  SIMD-mates are then its index neighbours, idle or nearly so — changed the kernel by nothing measurable (61.7 against 61.6 us, diagonal tiles 1.85 against 1.90 us):
-//  the mates that remain still own the tiles of the next columns.  Left at the identity.)
-__device__ __forceinline__ int mf_wave() { return __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); }
-struct MfLds { double* Tl; double* gat; double* dv; double* iv; double* yv; };      // tiles | per-wave gather buffers (64 each) | D | 1 / D | y (then the running right-hand side of the back substitution)
-
-// one 4-pivot sub-step of the diagonal tile.  c0: local index of the right-hand-side row (or -1); yk: this block's 16 entries of y.
-// The instruction stream of this one wave IS the critical path of the factorisation (~10 cycles per instruction in this mix of dependent fp64, LDS and MFMA
-// operations), so everything that is not arithmetic is kept out of it: the pivot block comes from the gather buffer by same-address (broadcast) LDS reads next
-// to the column reads, selections are flat v_cndmask pairs, D / 1/D / y leave through single masked 32-byte stores, the pivot check runs once per tile.
-template <int Q>
-__device__ __forceinline__ void mf_diag_substep(mf_d4& T, mf_d4& Wt, double* gat, double* dv16, double* iv16, int c0, double* yk) {
-    constexpr int P = 4 * Q;
-    const int lane = threadIdx.x & 63, c = lane & 15, rho = lane >> 4;
-    gat[lane] = T[Q];                                   // rows P .. P+3 sit in register Q of the four 16-lane rows
-    wave_lds_sync();
-    const double g0 = gat[c], g1 = gat[16 + c], g2 = gat[32 + c], g3 = gat[48 + c];      // g_m = A[P + m][c] (= A[c][P + m])
-    const double d0 = gat[P], a10 = gat[16 + P], a11 = gat[16 + P + 1], a20 = gat[32 + P], a21 = gat[32 + P + 1], a22 = gat[32 + P + 2];
-    const double a30 = gat[48 + P], a31 = gat[48 + P + 1], a32 = gat[48 + P + 2], a33 = gat[48 + P + 3];
-    wave_lds_sync();
-    const double i0 = fast_rcp(d0);
-    const double l10 = a10 * i0, l20 = a20 * i0, l30 = a30 * i0;
-    const double d1 = __builtin_fma(-l10, a10, a11), i1 = fast_rcp(d1);
-    const double t21 = __builtin_fma(-l20, a10, a21), t31 = __builtin_fma(-l30, a10, a31);
-    const double l21 = t21 * i1, l31 = t31 * i1;
-    const double d2 = __builtin_fma(-l21, t21, __builtin_fma(-l20, a20, a22)), i2 = fast_rcp(d2);
-    const double t32 = __builtin_fma(-l31, t21, __builtin_fma(-l30, a20, a32));
-    const double l32 = t32 * i2;
-    const double d3 = __builtin_fma(-l32, t32, __builtin_fma(-l31, t31, __builtin_fma(-l30, a30, a33))), i3 = fast_rcp(d3);
-    // this lane's column, read as row c of the panel: p = (L D)[c][P..P+3], x = L[c][P..P+3]; only the strictly lower part of L counts
-    const double p0 = g0, p1 = __builtin_fma(-p0, l10, g1);
-    const double p2 = __builtin_fma(-p1, l21, __builtin_fma(-p0, l20, g2));
-    const double p3 = __builtin_fma(-p2, l32, __builtin_fma(-p1, l31, __builtin_fma(-p0, l30, g3)));
-    const double lh0 = c > P ? p0 * i0 : 0.0, lh1 = c > P + 1 ? p1 * i1 : 0.0, lh2 = c > P + 2 ? p2 * i2 : 0.0, lh3 = c > P + 3 ? p3 * i3 : 0.0;
-    // T -= Lhat (D Lhat)^T: rank 4, the whole tile in one instruction.  Only the A operand is masked: the unmasked columns of B reach finished columns of the
-    // tile only, which are never read again.
-    T = mf_mfma(-mf_sel4(rho, lh0, lh1, lh2, lh3), mf_sel4(rho, p0, p1, p2, p3), T);
-    // W <- L_q^-1 W with L_q^-1 = I - Lhat W_qq embedded in columns P .. P+3 (W_qq = inverse of the unit lower 4x4 pivot block)
-    const double w20 = __builtin_fma(l21, l10, -l20), w31 = __builtin_fma(l32, l21, -l31);
-    const double w30 = __builtin_fma(-l32, w20, __builtin_fma(l31, l10, -l30));      // -l30 + l31 l10 + l32 l20 - l32 l21 l10
-    const double z0 = -__builtin_fma(lh3, w30, __builtin_fma(lh2, w20, __builtin_fma(-lh1, l10, lh0)));
-    const double z1 = -__builtin_fma(lh3, w31, __builtin_fma(-lh2, l21, lh1));
-    const double z2 = -__builtin_fma(-lh3, l32, lh2);
-    const double wq = Wt[Q];
-    Wt = mf_mfma(mf_sel4(rho, z0, z1, z2, -lh3), wq, Wt);
-    if (lane == 0) {
-        mf_d4 dd = { d0, d1, d2, d3 }, ii = { i0, i1, i2, i3 };
-        *reinterpret_cast<mf_d4*>(dv16 + P) = dd; *reinterpret_cast<mf_d4*>(iv16 + P) = ii;
-    }
-    if (lane == c0) { mf_d4 yy = { lh0, lh1, lh2, lh3 }; *reinterpret_cast<mf_d4*>(yk + P) = yy; }      // row c0 of L_kk = this block's share of y (zero from column c0 on: lh is masked)
-}
-__device__ __forceinline__ void mf_diag_factor(mf_d4& T, const MfLds& m, int k, int NB, int n, int* s_fail) {
-    const int lane = threadIdx.x & 63, c = lane & 15, rho = lane >> 4, wave = mf_wave();
-    __builtin_amdgcn_s_setprio(3);
-    mf_d4 Wt;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Wt[r] = (rho + 4 * r == c) ? 1.0 : 0.0;
-    double* gat = m.gat + wave * 64;
-    const int nv = n - 16 * k, c0 = (nv >= 0 && nv < 16) ? nv : -1;      // nv: rows of this tile that belong to the n x n system
-    // The tile that holds the right-hand-side row (the last one: c0 >= 0) ends with that row and identity padding: a sub-step whose four pivots all lie behind the
-    // row (4 Q > c0) touches nothing that is read again — W stays the identity there, y is zero-initialised, the pivot check below looks at c < nv only — and is
-    // skipped (n = 165: two of the last tile's four sub-steps, ~1.1 us per solve).
-    mf_diag_substep<0>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
-    if (c0 < 0 || c0 >= 4) mf_diag_substep<1>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
-    if (c0 < 0 || c0 >= 8) mf_diag_substep<2>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
-    if (c0 < 0 || c0 >= 12) mf_diag_substep<3>(T, Wt, gat, m.dv + 16 * k, m.iv + 16 * k, c0, m.yv + 16 * k);
-    *reinterpret_cast<mf_d4*>(m.Tl + (size_t)mf_tix(k, k, NB) * 256 + lane * 4) = Wt;      // W_k = L_kk^-1, result layout (the workgroup barrier behind this tile publishes it)
-    // ... and a second image in the PANEL's operand order (lane (rho, c) of a panel wave wants W[c][rho + 4 q], q = 0..3: here four consecutive doubles at lane * 4): the
-    // transposing read of the result-layout image is a 4-way bank conflict, and all sixteen waves issue it in the same instant behind barrier A — the panel phase was
-    // bound by the LDS pipe (0.8 us per step, phase stamps), not by its four MFMAs.  One wave pays the scattered WRITE once instead.  The image lives in the gather
-    // buffers of waves 12-15, idle during the factorisation (diagonal tiles belong to waves <= 10); one image at a time suffices: W_k is dead behind barrier B of step k.
-    {
-        double* wt = m.gat + 768;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wt[((((c & 3) << 4) + rho + 4 * r) << 2) + (c >> 2)] = Wt[r];
-    }
-    __builtin_amdgcn_s_setprio(0);      // (the pivots are checked once, behind the last tile: ldlt_mf16)
-}
-// Three other forms of this tile were built and measured in round 5 (scripts/dbg/diag_bench.hip keeps them: rank-1 MFMA Gauss-Jordan in place, the same with the next
-// reciprocal formed in the MFMA's shadow, column per lane on v_fmac_f64 DPP row_newbcast): 1.65 / 1.62 / 1.76 us per tile against 1.52 us for the form above, alone on
-// its SIMD — an MFMA result takes ~200 cycles to reach a VALU consumer, and DP-ALU DPP operations issue at half rate.  What the measurements DID show: trailing-update
-// MFMAs on the chain wave's own SIMD stretch the tile to 2.11 us (the figure seen inside the kernel); mf_wave() below deals with that.
-__device__ __forceinline__ void mf_diag(mf_d4& T, const MfLds& m, int k, int NB, int n, int* s_fail) { mf_diag_factor(T, m, k, NB, n, s_fail); }
 // tile entries: the raw Schur-complement entry is requested early (mf_prefetch, before the scaling phase: the loads' round trip hides behind it) and finished
 // (scaled, damped; right-hand side as row / column n; identity padding behind it) when the factorisation starts
 __device__ __forceinline__ double mf_raw(const double* __restrict__ Sc, int n, int i, int j) {
@@ -766,14 +640,6 @@ __device__ __forceinline__ double mf_finish(double raw, const double* v_s, const
     const double body = s_hi * s_lo * raw + (i == j ? mu * d_hi * d_hi : 0.0);
     const double row_n = lo == n ? MF_RHO : s_lo * rhs[lc];
     return hi < n ? body : (hi == n ? row_n : (hi == lo ? 1.0 : 0.0));
-}
-__device__ __forceinline__ void mf_slots(const uint8_t* plan, int wave, int NB, int (&sI)[5], int (&sJ)[5]) {
-    sI[0] = sJ[0] = wave < NB ? wave : -1;
-    // the wave's four plan bytes as ONE dword through the scalar path (the plan sits in the kernel arguments / the constant-space table, `wave` is an SGPR); byte
-    // loads have no scalar form on gfx950 and came back as four dependent vector loads in front of everything that needs the slots (~2 us per use)
-    const uint32_t w4 = reinterpret_cast<const uint32_t*>(plan)[wave];
-#pragma unroll
-    for (int s = 1; s < 5; ++s) { const int b = (int)((w4 >> (8 * (s - 1))) & 0xFFu); sI[s] = b == 0xFF ? -1 : (b >> 4); sJ[s] = b == 0xFF ? -1 : (b & 15); }
 }
 __device__ __forceinline__ void mf_prefetch(const double* __restrict__ Sc, const uint8_t* plan, int n, mf_d4 (&U)[5]) {
     const int lane = threadIdx.x & 63, wave = mf_wave(), c = lane & 15, rho = lane >> 4;
@@ -896,11 +762,6 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
             lds_barrier();                               // A
         } else {
             // ---- everybody else: panel tile of column k, then the trailing update ----
-#ifdef MF_EXPERIMENT_SKIP_MATES
-            // TIMING EXPERIMENT ONLY (wrong numbers): the SIMD-mates of the chain wave do nothing this step — an optimistic bound for a design that keeps the chain's SIMD to itself
-            const bool mate = ((wave & 3) == ((k + 1) & 3));
-            if (mate) { if (k + 2 < NB) lds_barrier(); lds_barrier(); continue; }
-#endif
 #pragma unroll
             for (int s = 1; s < MF_SLOTS; ++s) if (sJ[s] == k) panel(U[s], sI[s], k);
             if (k + 2 < NB) lds_barrier();               // B
@@ -1083,9 +944,9 @@ static size_t solve_smem_mf16(int n) {
 // loop), to a wave >= NB, or to a wave w with J < w: then the wave that factors diagonal tile k+1 behind the update of step k has no other active tile (its
 // off-diagonal tiles lie in columns <= k).  Every column's tiles go to DIFFERENT waves (one panel tile per wave and step), the waves whose eligibility ends
 // first are used first (earliest deadline first: wave w < NB is useless from column w on).  Feasible for every n <= 175 (checked exhaustively).
-bool be_mf16_plan(int n, uint8_t* plan /* [16][4] */) {
+bool be_mf16_plan(int n, uint8_t* plan /* [16][4] */, bool check_solve_lds) {
     const int NB = (n + 16) >> 4, W = SOL_THREADS / 64;
-    if (NB > MF_MAXNB || solve_smem_mf16(n) > 160 * 1024 - 512) return false;
+    if (NB > MF_MAXNB || (check_solve_lds && solve_smem_mf16(n) > 160 * 1024 - 512)) return false;
     int load[SOL_THREADS / 64] = { 0 };
     std::memset(plan, 0xFF, (size_t)W * 4);
     for (int j = 1; j < NB; ++j) plan[j * 4 + load[j]++] = (uint8_t)((j << 4) | (j - 1));      // slot 1 of wave j: tile (j, j-1), the one its diagonal tile waits for

@@ -175,9 +175,9 @@ static int marg_args(dv_ctx* ctx, const MargPlan& pl, const BeState* x, double g
     ma.c0_mode = 0;
     {   // the finish kernel's factorisation on the matrix cores where the tiles fit (every window the estimator builds: D = 97, m = 15 -> 7 x 7 tiles)
         const int mt = (pl.m + 15) / 16, mf_n = 16 * mt + (pl.D - pl.m), NB = (mf_n + 16) >> 4;
-        const size_t room = (size_t)pl.D * pl.D + pl.D + std::max((size_t)(pl.D - pl.m) * (pl.D - pl.m), (size_t)1024);      // A | b | W2 of the LDS image: the tiles take their place once they are in registers
+        const size_t room = (size_t)pl.D * pl.D + pl.D + std::max((size_t)(pl.D - pl.m) * (pl.D - pl.m), (size_t)1024);      // A | b | W2 of the LDS image: the factor's fragments and the staged A', b' tiles take their place once the tiles are in registers
         ma.mf16 = 0; ma.mf_n = mf_n;
-        if (pl.m > 0 && pl.D > pl.m && (size_t)NB * (NB + 1) / 2 * 256 <= room && be_mf16_plan(mf_n, ma.mf_plan, false) && !std::getenv("DVINS_MARG_GENERIC")) ma.mf16 = 1;
+        if (pl.m > 0 && pl.D > pl.m && 2 * ((size_t)NB * (NB + 1) / 2 * 256) <= room && be_mf16_plan(mf_n, ma.mf_plan, false) && !std::getenv("DVINS_MARG_GENERIC")) ma.mf16 = 1;
     }
     return 0;
 }

@@ -517,34 +517,36 @@ __device__ __forceinline__ void be_marg_finish_body(const BeMargArgs& a) {
         int sI[MF_SLOTS], sJ[MF_SLOTS];
         mf_slots(a.mf_plan, wv, NBm, sI, sJ);
         mf_d4 U[MF_SLOTS];
+        // (hoisting the row index out of the register loop was tried: 0.7 us less here, 48 spilled VGPRs and 3.4 us more in the factorisation loop)
 #pragma unroll
         for (int s = 0; s < MF_SLOTS; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) U[s][r] = sI[s] >= 0 ? ext(16 * sI[s] + cc, 16 * sJ[s] + rr + 4 * r) : 0.0;
-        __syncthreads();                                  // every tile is in registers: the LDS image of A, b is dead, the factor's fragments take its place
-        for (int i = tid; i < 16 * NBm; i += MG_THREADS) mf.yv[i] = 0.0;
+        for (int i = tid; i < 16 * NBm; i += MG_THREADS) mf.yv[i] = 0.0;      // (the MF16 vectors lie behind the IMU workspace: no alias with A)
         if (tid == 0) s_mf_fail = 0;
-        __syncthreads();
+        __syncthreads();                                  // every tile is in registers: the LDS image of A, b is dead, the factor's fragments take its place
         MTS(13);
+        // A', b' leave the registers at the one moment they exist (after_update, k = mt - 1) — into a staging image in LDS behind the factor's fragments (the place of A's
+        // tail and of W2), two 32-byte stores per tile: address arithmetic and scattered global stores at that point cost 144 spilled VGPRs and stalled the chain wave on
+        // its own store queue (67 us against 62 for the panel form).  The image goes to global memory behind the factorisation, coalesced.
+        double* stage = sm + (size_t)NBm * (NBm + 1) / 2 * 256;
         auto dump = [&](int k) {
             if (k != mt - 1) return;
 #pragma unroll
-            for (int s = 0; s < MF_SLOTS; ++s) {
-                if (sI[s] < mt || sJ[s] < mt) continue;   // (wave-uniform)
-                const int ei = 16 * sI[s] + cc, ki = ei - e_k0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int ej = 16 * sJ[s] + rr + 4 * r, kj = ej - e_k0;
-                    if (kj < 0 || kj >= n) continue;
-                    const double v = U[s][r];
-                    if (ki < n) {                          // A': the lower triangle is the truth, mirrored (a diagonal tile holds both halves; they agree to rounding only)
-                        if (ki >= kj) { a.outA[(size_t)ki * n + kj] = v; if (ki != kj) a.outA[(size_t)kj * n + ki] = v; }
-                    } else if (ei == mf_n) a.outb[kj] = v;   // b': the right-hand-side row
-                }
-            }
+            for (int s = 0; s < MF_SLOTS; ++s)
+                if (sI[s] >= mt && sJ[s] >= mt) *reinterpret_cast<mf_d4*>(stage + (size_t)mf_tix(sI[s], sJ[s], NBm) * 256 + lane * 4) = U[s];
         };
         mf16_factor_core<true>(U, a.mf_plan, mf_n, mf, &s_mf_fail, dump);
         MTS(15);
+        // A' (lower triangle of the staged tiles is the truth, mirrored: a diagonal tile holds both halves and they agree to rounding only) and b' (the right-hand-side row)
+        auto staged = [&](int ei, int ej) {               // entry (ei, ej), ei >= ej, of the extended system as staged: result layout, lane (ej & 3, ei & 15), register (ej & 15) >> 2
+            return stage[(size_t)mf_tix(ei >> 4, ej >> 4, NBm) * 256 + (((((ej & 3) << 4) + (ei & 15)) << 2) + ((ej & 15) >> 2))];
+        };
+        for (int e = tid; e < n * n + n; e += MG_THREADS) {
+            if (e >= n * n) { const int kj = e - n * n; a.outb[kj] = staged(mf_n, e_k0 + kj); continue; }
+            const int ki = e / n, kj = e - ki * n, hi = ki > kj ? ki : kj, lo = ki > kj ? kj : ki;
+            a.outA[e] = staged(e_k0 + hi, e_k0 + lo);
+        }
         if (wv == 0) {                                    // D of the dropped block -> smallest pivot / clamp flag; c0 and the rank from the kept pivots (fixed order: lane-strided, wave tree)
             double dmin = DBL_MAX, c0p = 0.0; int bad = 0, rk = 0;
             for (int e = lane; e < m; e += 64) { const double d = mf.dv[e]; dmin = fmin(dmin, d); bad |= !(d > 1e-8); }

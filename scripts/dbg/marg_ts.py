@@ -12,8 +12,8 @@ lib = _abi.load()
 lib.dv_debug_marg_ts.argtypes = [C.POINTER(C.c_longlong)]
 seqp = [(0, 1, "lm: tables + geometry"), (1, 2, "lm: residual blocks"), (2, 3, "lm: matrix-core sums (waves 0-4)"), (2, 20, "  setup"), (20, 21, "  loop"), (21, 3, "  stores"), (3, 4, "lm: w rows (pose columns)"), (4, 5, "lm: per-frame blocks"), (0, 5, "lm: total (block 0)"),
         (6, 7, "sum: loads + rank term (mfma)"), (6, 22, "  index setup"), (22, 23, "  loads, adds, products"), (23, 7, "  rest"), (7, 18, "sum: gather + store"), (5, 6, "lm end -> sum start"), (18, 8, "sum end -> finish start"),
-        (8, 9, "finish: load sum"), (9, 10, "finish: prior"), (10, 11, "finish: imu"), (11, 13, "finish: eliminate dropped block"), (13, 14, "finish: store A'"), (14, 15, "finish: store b'"),
-        (15, 16, "finish: c0"), (8, 16, "finish: total"), (0, 16, "marginalization: total")]
+        (8, 9, "finish: load sum"), (9, 10, "finish: prior"), (10, 11, "finish: imu"), (11, 13, "finish: eliminate dropped block | MF16: tiles from LDS to registers"), (13, 15, "finish: store A', b' | MF16: factorisation (incl. A', b' out of the registers)"),
+        (15, 16, "finish: c0 | MF16: scalars"), (8, 16, "finish: total"), (0, 16, "marginalization: total")]
 rows = []
 for k in range(N):
     pipe.step()

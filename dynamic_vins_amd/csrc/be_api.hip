@@ -2,6 +2,7 @@
 // tables, enqueues the fixed kernel schedule of the trust-region loop on the ctx's BA stream (no host round trip
 // between iterations: every kernel is predicated on the device-resident BeCtl) and downloads the solved states.
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include "dv_ctx.h"
@@ -628,7 +629,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
 // part: 3 launches per iteration and window — run on the batch's stream as ONE launch per stage for all windows (argument tables in HBM, window index in
 // the grid).  Per round: S event waits (uploads done), 3 x iterations launches, one event, S event waits (tails).
 struct dv_batch {
-    std::vector<dv_ctx*> members;
+    std::vector<dv_ctx*> members; int index = 0;          // index: creation order in the process (dv_group_stream_create)
     hipStream_t stream = nullptr; hipEvent_t ev_slots = nullptr;
     DevBuf tab; void* tab_pinned = nullptr; size_t tab_bytes = 0;      // [S] BeEvalArgs | [S] BeSolveArgs | [S] BeGaugeArgs | [S] BeRejectArgs | [S] BeMargArgs
     long long batched_rounds = 0, single_rounds = 0;
@@ -644,6 +645,16 @@ struct dv_batch {
 // dv_destroy of a member: the batch forgets it (a destroyed ctx must never be reached through B->members); threads waiting in dv_batch_arrive
 // for a round this member will never join are released with an error
 DvFrontBatch*& be_batch_front(dv_batch* B) { return B->front; }
+int be_batch_index(dv_batch* B) { return B->index; }
+hipError_t dv_group_stream_create(hipStream_t* s, int group_index) {
+    const char* e = std::getenv("DVINS_CU_PARTITIONS");
+    const int P = e ? std::atoi(e) : 0;
+    if (P < 2 || P > 32 || 256 % P) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    uint32_t mask[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    const int per = 256 / P, g = group_index % P;
+    for (int b = g * per; b < (g + 1) * per; ++b) mask[b >> 5] |= 1u << (b & 31);
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+}
 const std::vector<dv_ctx*>& be_batch_members(dv_batch* B) { return B->members; }
 void be_batch_detach(dv_ctx* ctx) {
     dv_batch* B = ctx->batch;
@@ -804,7 +815,8 @@ dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n) {
     if (hipSetDevice(ctxs[0]->cfg.device) != hipSuccess) { dv_set_error(nullptr, "dv_batch_create: hipSetDevice failed"); return nullptr; }
     dv_batch* B = new dv_batch();
     B->members.assign(ctxs, ctxs + n);
-    bool ok = hipStreamCreateWithFlags(&B->stream, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&B->ev_slots, hipEventDisableTiming) == hipSuccess
+    { static std::atomic<int> next_index{0}; B->index = next_index.fetch_add(1); }
+    bool ok = dv_group_stream_create(&B->stream, B->index) == hipSuccess && hipEventCreateWithFlags(&B->ev_slots, hipEventDisableTiming) == hipSuccess
               && hipEventCreateWithFlags(&B->ev_state, hipEventDisableTiming) == hipSuccess;
     const size_t bytes = (size_t)n * (sizeof(BeEvalArgs) + sizeof(BeSolveArgs) + sizeof(BeGaugeArgs) + sizeof(BeRejectArgs) + sizeof(BeMargArgs));
     B->tab_bytes = bytes;

@@ -267,6 +267,9 @@ template <bool FULL>
 __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL, 1, BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm)); }
 // batched form (several independent windows in one launch: blockIdx.y = window, argument table in HBM): four landmarks per workgroup
 #define EV_LPB_BATCH 4
+// (Round 5: the full evaluation holds 222 VGPRs — two workgroups per CU, 512 resident GPU-wide, so 16 windows (1232 workgroups of ~40 us) need 2.4 occupancy rounds: that, not
+//  traffic, is what its 86 us per 16 windows is.  Capping the registers with amdgpu_waves_per_eu(3 / 4) buys the occupancy with 109 / 203 spilled VGPRs and loses:
+//  16 sequences 5969 -> 5880 / 5852 frames/s, 64 sequences 8285 -> 8121 / 7772; profiles/r05_experiments/eval_waves_ab.txt.)
 template <bool FULL>
 __global__ __launch_bounds__(EV_THREADS) void be_eval_batch_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
     const DV_CONSTANT BeEvalArgs& a = *reinterpret_cast<const DV_CONSTANT BeEvalArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));

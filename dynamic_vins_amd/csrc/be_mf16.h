@@ -158,7 +158,7 @@ __device__ __forceinline__ void mf16_factor_core(mf_d4 (&U)[MF_SLOTS], const uin
     mf_slots(plan, wave, NB, sI, sJ);
     if (wave == 0) mf_diag_factor<RR>(U[0], m, 0, NB, n, s_fail);
     lds_barrier();                                       // A: W_0 published
-    auto panel = [&](mf_d4& T, int I, int k) {
+    auto panel = [&](mf_d4& T, int I, int k) -> mf_d4 {      // returns W_k U (before the division by D)
         const mf_d4 wf = *reinterpret_cast<const mf_d4*>(m.gat + 768 + lane * 4);
         double ivr[4];
 #pragma unroll
@@ -166,6 +166,7 @@ __device__ __forceinline__ void mf16_factor_core(mf_d4 (&U)[MF_SLOTS], const uin
         mf_d4 Y = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
         for (int q = 0; q < 4; ++q) Y = mf_mfma(wf[q], T[q], Y);
+        const mf_d4 Y0 = Y;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Y[r] *= ivr[r];
         T = Y;
@@ -174,16 +175,14 @@ __device__ __forceinline__ void mf16_factor_core(mf_d4 (&U)[MF_SLOTS], const uin
 #pragma unroll
             for (int r = 0; r < 4; ++r) m.yv[16 * k + rho + 4 * r] = Y[r];
         }
+        return Y0;
     };
     for (int k = 0; k + 1 < NB; ++k) {
-        double dk[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dk[q] = -m.dv[16 * k + rho + 4 * q];
         if (wave == k + 1) {
             __builtin_amdgcn_s_setprio(3);
-            panel(U[1], k + 1, k);
+            const mf_d4 Y0 = panel(U[1], k + 1, k);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) U[0] = mf_mfma(U[1][q], dk[q] * U[1][q], U[0]);
+            for (int q = 0; q < 4; ++q) U[0] = mf_mfma(U[1][q], -Y0[q], U[0]);      // D V = W U: no read of D on the chain (a skipped pivot has V = 0 there: its product vanishes as before)
             after_update(k);
             if (k + 2 < NB) lds_barrier();               // B
             mf_diag_factor<RR>(U[0], m, k + 1, NB, n, s_fail);
@@ -192,6 +191,9 @@ __device__ __forceinline__ void mf16_factor_core(mf_d4 (&U)[MF_SLOTS], const uin
 #pragma unroll
             for (int s = 1; s < MF_SLOTS; ++s) if (sJ[s] == k) panel(U[s], sI[s], k);
             if (k + 2 < NB) lds_barrier();               // B
+            double dk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dk[q] = -m.dv[16 * k + rho + 4 * q];
 #pragma unroll
             for (int s = 0; s < MF_SLOTS; ++s) if (sJ[s] > k) {
                 const mf_d4 a = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(sJ[s], k, NB) * 256 + lane * 4);

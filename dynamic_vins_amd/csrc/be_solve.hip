@@ -714,7 +714,7 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
     if (tid == 0) be_dbg_ts[16] = t_prev - be_dbg_ts[4];      // load + first diagonal tile
 #endif
     // one panel tile: V = D^-1 W_k U, kept in the registers, stored as the factor's fragment, row n of L (the last block row) copied out as y
-    auto panel = [&](mf_d4& T, int I, int k) {
+    auto panel = [&](mf_d4& T, int I, int k) -> mf_d4 {      // returns W_k U (the panel BEFORE the division by D): -(W U) is what d V is, without waiting for D
         const mf_d4 wf = *reinterpret_cast<const mf_d4*>(m.gat + 768 + lane * 4);      // W_k[c][rho + 4 q], q = 0..3: the panel-order image (mf_diag_factor)
         double ivr[4];
 #pragma unroll
@@ -722,6 +722,7 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
         mf_d4 Y = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
         for (int q = 0; q < 4; ++q) Y = mf_mfma(wf[q], T[q], Y);
+        const mf_d4 Y0 = Y;
 #pragma unroll
         for (int r = 0; r < 4; ++r) Y[r] *= ivr[r];
         T = Y;
@@ -730,23 +731,23 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
 #pragma unroll
             for (int r = 0; r < 4; ++r) m.yv[16 * k + rho + 4 * r] = Y[r];      // row n of L: y
         }
+        return Y0;
     };
     for (int k = 0; k + 1 < NB; ++k) {
-        double dk[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) dk[q] = -m.dv[16 * k + rho + 4 * q];
         if (wave == k + 1) {
             // ---- the diagonal chain: slot 1 of this wave is tile (k+1, k) ----
             __builtin_amdgcn_s_setprio(3);
 #ifdef BE_SOLVE_TS
-            __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_c0 = wall_clock64();      // (lgkmcnt(0): dk has arrived)
+            const long long t_c0 = wall_clock64();
 #endif
-            panel(U[1], k + 1, k);
+            const mf_d4 Y0 = panel(U[1], k + 1, k);
 #ifdef BE_SOLVE_TS
             __builtin_amdgcn_s_waitcnt(0xc07f); const long long t_c1 = wall_clock64();
 #endif
+            // own diagonal tile -= V D V^T with D V = W U = Y0 straight from the panel's accumulator: the chain neither reads D (an LDS round trip behind barrier A, 0.19 us
+            // per step by the stamps) nor multiplies by it
 #pragma unroll
-            for (int q = 0; q < 4; ++q) U[0] = mf_mfma(U[1][q], dk[q] * U[1][q], U[0]);
+            for (int q = 0; q < 4; ++q) U[0] = mf_mfma(U[1][q], -Y0[q], U[0]);
 #ifdef BE_SOLVE_TS
             asm volatile("s_nop 15\n\ts_nop 3\n\tv_mov_b64 %0, %0" : "+v"(U[0][0])); const long long t_c2 = wall_clock64();      // the last MFMA's result has landed
 #endif
@@ -768,6 +769,9 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
 #ifdef BE_SOLVE_TS
             { const long long t = wall_clock64(); acc_panel += t - t_prev; t_prev = t; }
 #endif
+            double dk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dk[q] = -m.dv[16 * k + rho + 4 * q];
 #pragma unroll
             for (int s = 0; s < MF_SLOTS; ++s) if (sJ[s] > k) {
                 const mf_d4 a = *reinterpret_cast<const mf_d4*>(m.Tl + (size_t)mf_tix(sJ[s], k, NB) * 256 + lane * 4);

@@ -139,6 +139,7 @@ int be_solve_fused(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFuse
 void be_batch_detach(dv_ctx* ctx);          // dv_destroy: leave the dv_batch this ctx is a member of
 struct DvFrontBatch;                        // the front-end half of a dv_batch (dvins_api.hip): stream, event, job tables of the shared tracking launches
 DvFrontBatch*& be_batch_front(struct dv_batch* B);
+int be_batch_index(struct dv_batch* B);
 const std::vector<dv_ctx*>& be_batch_members(struct dv_batch* B);
 void dv_front_batch_release(DvFrontBatch* F);
 void* be_staging_factors(dv_ctx* ctx, int* cap);      // where the next solve's upload reads its factor table (pinned); nullptr if the workspace cannot be set up
@@ -211,6 +212,10 @@ struct dv_ctx {
 };
 
 void dv_set_error(dv_ctx* ctx, const std::string& msg);
+// Stream of a dv_batch group.  DVINS_CU_PARTITIONS=P (experiment, off by default): group g's streams get the CU mask of partition g mod P — bits [256 g / P, 256 (g + 1) / P) of
+// the 256-bit mask, i.e. (mask bit i = CU i / 8 of XCD i mod 8: scripts/dbg/cumask_probe.hip) the same 32 / P CUs of EVERY XCD — so that the groups' kernels do not
+// compete for CUs with each other: a be_solve_batch workgroup needs a whole CU (157 KB of LDS, 16 waves of 128 VGPRs) and has to wait for one to drain completely.
+hipError_t dv_group_stream_create(hipStream_t* s, int group_index);
 
 #define DV_CHECK(expr)                                                                   \
     do {                                                                                 \

@@ -409,7 +409,7 @@ extern "C" int dv_batch_track_enqueue(dv_batch* B, const dv_track_job* jobs, int
     DvFrontBatch*& Fp = be_batch_front(B);
     if (!Fp) {
         Fp = new DvFrontBatch();
-        DV_CHECK(hipStreamCreateWithFlags(&Fp->stream, hipStreamNonBlocking));
+        DV_CHECK(std::getenv("DVINS_CU_PARTITION_FRONT") ? dv_group_stream_create(&Fp->stream, be_batch_index(B)) : hipStreamCreateWithFlags(&Fp->stream, hipStreamNonBlocking));
         DV_CHECK(hipEventCreateWithFlags(&Fp->done, hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) DV_CHECK(hipEventCreateWithFlags(&Fp->ev_copy[k], hipEventDisableTiming));
     }

@@ -100,7 +100,8 @@ def main():
     ap.add_argument("--group-size", type=int, default=0, help="with --sequences --batched --runner cpp: sequences per dv_batch group (default: four groups, one host thread each; two groups below 8 sequences)")
     ap.add_argument("--no-batch-front", action="store_true", help="with --sequences --batched: one set of tracking launches per sequence instead of dv_batch_track_enqueue (A/B)")
     ap.add_argument("--runner-threads", type=int, default=0, help="with --sequences: host threads driving the groups (default and maximum: one per group)")
-    ap.add_argument("--teams", action="store_true", help="opt-in: several host threads per dv_batch group (--runner-threads = a multiple of the group count); bit-identical to one thread per group in tests/test_runner.py")
+    ap.add_argument("--teams", action="store_true", help="(default since round 5) several host threads per dv_batch group: --runner-threads = a multiple of the group count, default two per group")
+    ap.add_argument("--no-teams", action="store_true", help="with --sequences --batched: one host thread per dv_batch group (the default until round 4)")
     ap.add_argument("--sequence-threads", action="store_true", help="with --sequences: one host thread per sequence instead of one interleaving thread")
     ap.add_argument("--blocks", type=int, default=2, help="consecutive timed blocks of --steps frames (the first is `value`; all are listed in config.block_values)")
     ap.add_argument("--timing-block", type=int, default=1, help="which block the instrumented (per-kernel HIP events) pass times")

@@ -75,7 +75,7 @@ struct dv_runner {
     struct Group { std::vector<int> members; dv_batch* batch = nullptr; bool pending = false; std::unique_ptr<SpinBarrier> bar; };
     std::vector<Group> groups;
     int threads = 1, threads_per_group = 1;      // threads > groups: every dv_batch group is driven by threads / groups host threads that split its members' host phases (runner_team)
-    bool teams = false;           // dv_runner_set "teams": several host threads per group.  First blamed for the round-4 trajectory defect, then cleared (the cause was the
+    bool teams = true;            // dv_runner_set "teams" (on by default since round 5: 100 of 100 runs of 16 sequences in four groups on eight threads bit-identical to the single-thread run, profiles/r05_experiments): several host threads per group.  First blamed for the round-4 trajectory defect, then cleared (the cause was the
                                   // accept decision's missing barrier, be_kernels.h be_accept_body); bit-identical to the single-thread run (tests/test_runner.py).
     int threads_requested = 1;
     bool tracker_thread = true;   // dynamic sequences: the reference's T2 beside T3 (dv_runner_set "tracker_thread"); 0 = the one-thread loop of round 4 (dyn_begin), kept for A/B and as the bit-identity reference

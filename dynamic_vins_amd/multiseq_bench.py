@@ -149,15 +149,14 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
         gsz = args.group_size if getattr(args, "group_size", 0) > 0 else ((S + 3) // 4 if S >= 8 else ((S + 1) // 2 if S >= 4 else S))
     n_groups = (S + gsz - 1) // gsz if gsz > 0 else S
     threads = getattr(args, "runner_threads", 0)
-    teams = bool(getattr(args, "teams", False))
-    if threads <= 0:          # default: ONE host thread per dv_batch group; --teams (opt-in) lets several threads share a group's host phases
-        threads = n_groups if gsz > 1 else 1
+    teams = gsz > 1 and not bool(getattr(args, "no_teams", False))
+    if threads <= 0:          # default: TWO host threads per dv_batch group (a team splits its members' host phases; --no-teams: one thread per group)
+        threads = (2 * n_groups if teams else n_groups) if gsz > 1 else 1
     if not teams:
         threads = min(threads, n_groups)
     args.runner_threads = threads
     runner = Runner(pipes, group_size=gsz, threads=max(1, threads))
-    if teams:
-        runner.set("teams", 1)
+    runner.set("teams", 1 if teams else 0)
     if getattr(args, "no_batch_front", False):
         runner.set("batch_front", 0)
     runner.run(warm_ba)

@@ -17,7 +17,7 @@ def make(n_seq, frames, w=752, h=480):
 
 @pytest.mark.parametrize("group_size,threads", [(0, 1), (3, 1), (2, 2), (4, 2), (2, 4)])
 def test_runner_equals_python_pipeline(group_size, threads):
-    """(4, 2) / (2, 4): more threads than groups are asked for — the runner uses ONE thread per group unless teams are switched on (dv_runner_set "teams"; covered by the team tests below)"""
+    """(4, 2) / (2, 4): more threads than groups are asked for — teams of two host threads per group (the default since round 5; dv_runner_set "teams" 0 = one thread per group)"""
     from dynamic_vins_amd.backend import Runner
     from dynamic_vins_amd.pipeline import Pipeline
     S, frames = 4 if threads >= 2 else 3, 30
@@ -46,8 +46,7 @@ def _trajectories(group_size, threads, S, frames, keys=(), teams=False):
         for k in keys:
             assert p.ctx.lib.dv_debug_set(p.ctx.h, k.encode(), 1) == 0, k
     r = Runner(pipes, group_size=group_size, threads=threads)
-    if teams:
-        r.set("teams", 1)
+    r.set("teams", 1 if teams else 0)
     r.run(frames - 1)
     out = [r.frames(i) for i in range(S)]
     r.close()

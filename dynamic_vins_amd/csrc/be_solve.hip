@@ -36,7 +36,15 @@ extern "C" int dv_debug_red_ts(long long* out) { return hipMemcpyFromSymbol(out,
 #define RTS(k) do {} while (0)
 #endif
 #define RED_THREADS 448          // 7 waves: waves 0-5 = rows of a 6x6 pose block (lane = landmark), wave 6 = the block's IMU / prior terms
-#define RED_PAIRS (BE_NF * BE_NF)
+#define RED_PAIRS (BE_NF * (BE_NF + 1) / 2)          // pose block pairs (fi >= fj): the landmark sums are bitwise symmetric (rho * (wi * wj); the direct terms are one stored value read from
+                                                      // either side), so the upper blocks are mirrored stores instead of a second pass over the same packet rows (round 5: 121 -> 66 pair blocks)
+#define FIN_PAIRS (BE_NF * BE_NF)                      // be_shard_finalize_kernel keeps one block per ordered pair (the exchange vector carries the full 66 x 66 images)
+__device__ __forceinline__ void red_pair(int bx, int& fi, int& fj) {      // bx = fi (fi + 1) / 2 + fj, fj <= fi
+    fi = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
+    while (fi * (fi + 1) / 2 > bx) --fi;
+    while ((fi + 1) * (fi + 2) / 2 <= bx) ++fi;
+    fj = bx - fi * (fi + 1) / 2;
+}
 
 // IMU + prior part of Hd(i, j)  (everything that is not a landmark sum).  rc: the frames of every IMU factor and the prior's header
 // fields, staged in LDS by the caller (they were dependent global loads per factor and entry)
@@ -144,7 +152,8 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
     if (threadIdx.x == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
     __shared__ int s_pci[6], s_pcj[6];      // pair blocks: prior index of the block's six row / column pose entries (fetched with the tables above: one round trip)
     if (bx < RED_PAIRS && threadIdx.x >= 65 && threadIdx.x < 77) {
-        const int fi = bx / BE_NF, fj = bx - fi * BE_NF, t = threadIdx.x - 65;
+        int fi, fj; red_pair(bx, fi, fj);
+        const int t = threadIdx.x - 65;
         const int f = t < 6 ? fi : fj, c0 = f < a.dims.nframes ? a.dims.pose_col[f] : -1;
         const int v = c0 >= 0 ? a.prior_col[c0 + (t < 6 ? t : t - 6)] : -1;
         if (t < 6) s_pci[t] = v; else s_pcj[t - 6] = v;
@@ -152,7 +161,8 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
     if (bx < RED_PAIRS && (threadIdx.x >> 6) == 2) {
         // pair block (fi, fj): the landmarks whose factors touch BOTH poses, compacted in ascending order by one wave (ballot + prefix count) — for two
         // frames of an 11-frame window that is a fraction of the landmarks (observed in ~6 frames each); every other packet row would contribute zeros
-        const int fi = bx / BE_NF, fj = bx - fi * BE_NF, lane = threadIdx.x & 63;
+        int fi, fj; red_pair(bx, fi, fj);
+        const int lane = threadIdx.x & 63;
         const int lo = a.sh.on ? a.sh.lo : 0, hi = a.sh.on ? a.sh.hi : nlm;
         int base = 0;
         // all observation masks requested up front (16 x 64 lanes covers BE_MAX_LM): with the load inside the ballot loop every 64 landmarks cost one
@@ -178,7 +188,7 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
     if (bx == 0) RTS(0);
     if (bx == RED_PAIRS + 3) RTS(8);
     if (bx < RED_PAIRS) {
-        const int fi = bx / BE_NF, fj = bx - fi * BE_NF;
+        int fi, fj; red_pair(bx, fi, fj);
         if (fi >= a.dims.nframes || fj >= a.dims.nframes) return;
         const int ci0 = a.dims.pose_col[fi], cj0 = a.dims.pose_col[fj];
         if (ci0 < 0 || cj0 < 0) return;
@@ -240,8 +250,9 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
                 double sv = S[0], hv = H[0];
 #pragma unroll
                 for (int q = 1; q < 6; ++q) if (lane == q) { sv = S[q]; hv = H[q]; }
-                const int e = (fi * 6 + ci) * 66 + fj * 6 + lane;
+                const int e = (fi * 6 + ci) * 66 + fj * 6 + lane, et = (fj * 6 + lane) * 66 + fi * 6 + ci;
                 a.sh.xsend[BE_XS_S + e] = sv; a.sh.xsend[BE_XS_H + e] = hv;
+                if (!diag) { a.sh.xsend[BE_XS_S + et] = sv; a.sh.xsend[BE_XS_H + et] = hv; }
             } else if (diag && lane == 6) { a.sh.xsend[BE_XS_G + fi * 6 + ci] = G; a.sh.xsend[BE_XS_GS + fi * 6 + ci] = GS; }
             return;
         }
@@ -253,6 +264,10 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
             const double hd = hv + s_dh[ci * 6 + lane];
             Hd[(size_t)i * n + j] = hd;
             if ((j >> 2) <= (i >> 2)) Sc[blk_pos(i, j, (n + 3) >> 2)] = hd - sv;
+            if (!diag) {                                  // the mirrored entry (the IMU / prior part is symmetric as well: the same sums in the same order with the roles swapped)
+                Hd[(size_t)j * n + i] = hd;
+                if ((i >> 2) <= (j >> 2)) Sc[blk_pos(j, i, (n + 3) >> 2)] = hd - sv;
+            }
         } else if (diag && lane == 6) {
             const int i = ci0 + ci;
             gvec[i] = G + s_dg[ci];
@@ -317,7 +332,7 @@ __global__ __launch_bounds__(FIN_THREADS) void be_shard_finalize_kernel(BeSolveA
     else if (!c.need_eval && !c.chol_fail) return;
     const int n = a.dims.nstate, nlm = a.dims.nlm, W = a.sh.world, len = a.sh.len, cap = a.sh.cap;
     const double* xr = a.sh.xrecv;
-    if (blockIdx.x < RED_PAIRS) {
+    if (blockIdx.x < FIN_PAIRS) {
         const int fi = blockIdx.x / BE_NF, fj = blockIdx.x - fi * BE_NF;
         if (fi >= a.dims.nframes || fj >= a.dims.nframes) return;
         const int ci0 = a.dims.pose_col[fi], cj0 = a.dims.pose_col[fj];
@@ -346,7 +361,7 @@ __global__ __launch_bounds__(FIN_THREADS) void be_shard_finalize_kernel(BeSolveA
         }
         return;
     }
-    const int row = blockIdx.x - RED_PAIRS;
+    const int row = blockIdx.x - FIN_PAIRS;
     double* pk = const_cast<double*>(a.packets[set]);
     for (int l = threadIdx.x; l < nlm; l += FIN_THREADS) {
         const int r = l / cap, k = l - r * cap;
@@ -358,7 +373,7 @@ __global__ __launch_bounds__(FIN_THREADS) void be_shard_finalize_kernel(BeSolveA
     }
 }
 void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s) {
-    hipLaunchKernelGGL(be_shard_finalize_kernel, dim3(RED_PAIRS + BE_XS_NROWS + 1), dim3(FIN_THREADS), 0, s, a, spec);
+    hipLaunchKernelGGL(be_shard_finalize_kernel, dim3(FIN_PAIRS + BE_XS_NROWS + 1), dim3(FIN_THREADS), 0, s, a, spec);
 }
 // cost-only exchange (the slot that ends with be_accept): phase 0 packs the owned candidate costs, phase 1 scatters the gathered ones
 __global__ __launch_bounds__(FIN_THREADS) void be_shard_cost_kernel(BeSolveArgs a, int phase) {

@@ -144,6 +144,7 @@ SIGNATURES = {
     "dv_dist_init_peer": (C.c_int, [_ctx, C.c_void_p]),
     "dv_dist_rccl_ranks": (C.c_int, [_ctx, C.POINTER(C.c_int)]),
     "dv_dist_shutdown": (C.c_int, [_ctx]),
+    "dv_dist_exchange_bytes": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dv_dist_info": (C.c_int, [_ctx, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]),
     "dv_allreduce_reduced_system": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
 }

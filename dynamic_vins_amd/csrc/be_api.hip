@@ -301,7 +301,7 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculat
     auto exchange_cost = [&]() -> int {
         if (!sharded) return 0;
         be_launch_shard_cost(pd.sa, 0, s);
-        if (be_exchange(ctx, (size_t)pd.sa.sh.cap, s)) return -1;
+        if (be_exchange(ctx, 8, s)) return -1;          // one partial sum per rank (padded to 64 bytes)
         be_launch_shard_cost(pd.sa, 1, s);
         return 0;
     };
@@ -312,6 +312,13 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculat
         be_dbg_stage(ctx, it, 2, s);
         if (last) { eval(BE_EVAL_CAND_COST); be_dbg_stage(ctx, it, 3, s); if (exchange_cost()) return -1; if (!(pd.fuse_accept_gauge && !kt && it == slots - 1)) accept(); }      // (fused: be_enqueue_tail launches accept + gauge as one kernel)
         else { eval(BE_EVAL_CAND_FULL); be_dbg_stage(ctx, it, 3, s); reduce(1); be_dbg_stage(ctx, it, 4, s); if (exchange_system(1)) return -1; }
+    }
+    if (sharded && (!speculative || slots > 0)) {
+        // every rank has moved its own landmarks only: one gather of the inverse depths of x behind the pass's last accept decision (whatever reads the whole state —
+        // the gauge kernel's download, the outlier test, the marginalization, a spare-slot pass — comes behind it on the stream)
+        be_launch_shard_depth(pd.sa, 0, s);
+        if (be_exchange(ctx, (size_t)pd.sa.sh.cap, s)) return -1;
+        be_launch_shard_depth(pd.sa, 1, s);
     }
     return 0;
 }
@@ -479,8 +486,9 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
         sh.on = 1; sh.rank = dd.rank; sh.world = dd.world;
         sh.cap = std::max(1, (P->nlm + dd.world - 1) / dd.world);
         sh.lo = std::min(P->nlm, dd.rank * sh.cap); sh.hi = std::min(P->nlm, sh.lo + sh.cap);
-        sh.len = BE_XS_LEN(sh.cap);
+        sh.len = BE_XS_LEN;
         sh.xsend = (double*)dd.xsend.p; sh.xrecv = (const double*)dd.xrecv.p;
+        sh.qf[0] = (double*)dd.qf.p; sh.qf[1] = sh.qf[0] + BE_QF_LEN;
         ea.lm_lo = sh.lo; ea.lm_hi = sh.hi;
     }
     for (int k = 0; k < 2; ++k) { ea.packets[k] = w.packets[k]; ea.imu_out[k] = w.imu_out[k]; ea.prior_out[k] = w.prior_out[k]; }
@@ -508,7 +516,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
         std::memcpy(r.ric, fused->rej_ric, sizeof(r.ric)); std::memcpy(r.tic, fused->rej_tic, sizeof(r.tic));
         pd.rej_on = true;
     }
-    pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.fuse_accept_gauge = fused != nullptr && !ctx->batch; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
+    pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.fuse_accept_gauge = fused != nullptr && !ctx->batch && !sh.on /* sharded: the last accept decision must stand before the gather of the inverse depths */; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
     pd.want_raw_pose = fused && fused->want_raw_pose;
     if (fused) { std::memcpy(pd.gauge_R0, fused->R0, sizeof(pd.gauge_R0)); std::memcpy(pd.gauge_ypr0, fused->ypr0, sizeof(pd.gauge_ypr0)); std::memcpy(pd.gauge_P0, fused->P0, sizeof(pd.gauge_P0)); }
     pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = 1 - w.prior_cur;
@@ -942,7 +950,14 @@ int dv_ba_eval(dv_ctx* ctx, const dv_ba_problem* P, int* n_out, double* cost, do
     DV_CHECK(hipMemcpyAsync(pc.data(), w.prior_out[0], 8, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipStreamSynchronize(s));
     if (be_dist_check(ctx)) return -1;
-    if (cost) { double c = 0; for (int l = 0; l < P->nlm; ++l) c += lcost[l]; for (int k = 0; k < P->nimu; ++k) c += io[(size_t)k * IMU_OUT_STRIDE]; c += pc[0]; *cost = c; }
+    if (cost) {
+        double c = 0;
+        if (pd.sa.sh.on) {          // sharded window: the landmark costs of the other ranks are known as their rank-ordered sum only (form scalar 10 of set 0)
+            double lc = 0; DV_CHECK(hipMemcpy(&lc, pd.sa.sh.qf[0] + BE_QF_A + 10, 8, hipMemcpyDeviceToHost)); c = lc;
+        } else for (int l = 0; l < P->nlm; ++l) c += lcost[l];
+        for (int k = 0; k < P->nimu; ++k) c += io[(size_t)k * IMU_OUT_STRIDE];
+        c += pc[0]; *cost = c;
+    }
     if (g) for (int i = 0; i < n; ++i) g[i] = gv[i] - gv[n + i];
     if (S) for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) {          // unpack the block-packed lower triangle (be_solve.hip: blk_pos)
         const int bi = i >> 2, bj = j >> 2;

@@ -8,21 +8,30 @@
 
 // Landmark-sharded window (north_star: "all-reduce of the reduced camera-pose Hessian"): rank r of `world` owns the landmarks [lo, hi)
 // (contiguous, cap = ceil(nlm / world) each).  Every rank evaluates and Schur-reduces only its own landmarks; IMU factors and the prior are evaluated
-// on every rank (identical bits, no exchange).  One exchange vector per rank and linearisation:
-//   [XS_S, +66*66)   sum_l rho_l w_l w_l^T over the owned landmarks, indexed (frame * 6 + comp) x (frame * 6 + comp)
-//   [XS_H, +66*66)   sum_l D_l (the landmarks' direct pose-pose terms)
-//   [XS_G, +66), [XS_GS, +66)   gradient parts
-//   [XS_ROWS, +BE_XS_NROWS * cap)   rows H, G, COST, W[66] of the owned packets: what be_solve needs of EVERY landmark (back substitution, norms)
-//   [.., +cap)       the owned candidate costs
-// The vectors are all-gathered and summed IN RANK ORDER by be_shard_finalize_kernel, so every rank holds the same bits and takes the same decisions.
-#define BE_XS_S 0
-#define BE_XS_H (66 * 66)
-#define BE_XS_G (2 * 66 * 66)
-#define BE_XS_GS (BE_XS_G + 66)
-#define BE_XS_ROWS (BE_XS_GS + 66)
-#define BE_XS_NROWS (BE_PK_W + 66)
-#define BE_XS_LEN(cap) (BE_XS_ROWS + (BE_XS_NROWS + 1) * (cap))
-struct BeShard { int32_t on, rank, world, lo, hi, cap, len, pad; double* xsend; const double* xrecv; };
+// on every rank (identical bits, no exchange).  Round 5: the exchange no longer depends on the number of landmarks.  What the trust-region step needs of
+// the landmarks it does not own are SUMS — norms of the Gauss-Newton / gradient / dogleg steps, the model cost change — and every one of them is a
+// quadratic form in the pose step of the same iteration: with v = s_p y_p (the pose part of the Gauss-Newton step), a landmark's step is
+//     dl = (cg alpha - cn rho) g + cn rho (w . v),   alpha = s^2 / d^2,  rho = 1 / (h + mu / alpha)
+// so that  sum dl^2, sum h dl^2, sum dl g, sum dl (w . delta_p), ...  are  scalar + vector . v + v^T matrix v  with weights known at reduce time.
+// One exchange vector per rank and linearisation, BE_XS_LEN doubles (99 KB) whatever the window holds:
+//   M(k), k = 0..4   66 lower block pairs (fi >= fj) x 36:  sum rho w w^T | sum D (direct pose-pose terms) | sum rho^2/alpha w w^T | sum h rho^2 w w^T | sum rho^2 w w^T
+//   V(k), k = 0..7   66 each:  sum g_p | sum rho g w | sum rho^2/alpha g w | sum alpha g w | sum h alpha rho g w | sum h rho^2 g w | sum alpha rho g w | sum rho^2 g w
+//   A                16 scalars: sum alpha g^2, rho^2/alpha g^2, rho g^2, h alpha^2 g^2, h alpha rho g^2, h rho^2 g^2, alpha^2 g^2, alpha rho g^2, rho^2 g^2, x^2, cost; max |g|
+// all-gathered and summed IN RANK ORDER by be_shard_finalize_kernel (identical bits on every rank -> identical decisions -> the same number of exchanges);
+// every rank back-substitutes, norms and moves its OWN landmarks only (be_solve_shard_kernel); the candidate costs travel as one partial sum per rank; the
+// inverse depths are gathered once, behind the last iteration slot.
+#define BE_XS_MSZ (66 * 36)
+#define BE_XS_M(k) ((k) * BE_XS_MSZ)
+#define BE_XS_V(k) (5 * BE_XS_MSZ + (k) * 66)
+#define BE_XS_A (5 * BE_XS_MSZ + 8 * 66)
+#define BE_XS_LEN (BE_XS_A + 16)
+#define BE_XS_BUF ((BE_XS_LEN > BE_MAX_LM + 16 ? BE_XS_LEN : BE_MAX_LM + 16))      // doubles: the exchange buffers also carry the final gather of the inverse depths (cap <= BE_MAX_LM)
+// the summed coefficients as be_solve_shard_kernel reads them (per linearisation set): full 66 x 66 images of S, C2 (rho^2/alpha), C6 (h rho^2), C9 (rho^2) | 7 vectors (V(1..7)) | the scalars
+#define BE_QF_M(k) ((k) * 4356)
+#define BE_QF_V(k) (4 * 4356 + (k) * 66)
+#define BE_QF_A (4 * 4356 + 7 * 66)
+#define BE_QF_LEN (BE_QF_A + 16)
+struct BeShard { int32_t on, rank, world, lo, hi, cap, len, pad; double* xsend; const double* xrecv; double* qf[2]; };
 
 struct BeEvalArgs {
     const BeCtl* ctl;
@@ -216,8 +225,9 @@ void be_launch_accept_gauge_batch(const BeSolveArgs* stab, const BeGaugeArgs* gt
 void be_launch_reject_batch(const BeRejectArgs* tab, int n, int max_nlm, hipStream_t s);
 size_t be_marg_finish_smem(int D, int n);
 int be_launch_marg_batch(const BeMargArgs* tab, int n, int max_nlm, int any_imu, int max_D, size_t max_finish_bytes, hipStream_t s);
-void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s);   // after the exchange of a reduce: rank-ordered sums -> Hd / Sc / gvec, packet rows, candidate costs
-void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s);      // cost-only exchange: phase 0 packs the owned candidate costs, phase 1 scatters all of them
+void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s);   // after the exchange of a reduce: rank-ordered sums -> Hd / Sc / gvec and the form coefficients qf
+void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s);      // cost-only exchange: phase 0 sums the owned candidate costs into one double, phase 1 leaves the rank-ordered total in cand_cost
+void be_launch_shard_depth(const BeSolveArgs& a, int phase, hipStream_t s);     // behind the last slot: phase 0 packs the owned inverse depths of x, phase 1 scatters the gathered ranges
 void be_launch_proj_op(const BeFactor* fac, int n, const double* pose_i, const double* pose_j, const double* ex0, const double* ex1,
                        const double* lambda, const double* td, double* out, hipStream_t s);
 void be_launch_imu_op(const BeImu* m, double g_norm, const double* par, double* out, hipStream_t s);

@@ -67,9 +67,10 @@ static std::string rccl_err(int rc) { return g_rccl.GetErrorString ? g_rccl.GetE
 
 int be_dist_buffers(dv_ctx* ctx) {
     DvDist& d = ctx->dist;
-    const size_t len = 8 * (size_t)BE_XS_LEN(BE_MAX_LM);
+    const size_t len = 8 * (size_t)BE_XS_BUF;
     DV_CHECK(d.xsend.ensure(len));
     DV_CHECK(d.xrecv.ensure(len * (size_t)d.world));
+    DV_CHECK(d.qf.ensure(8 * 2 * (size_t)BE_QF_LEN));
     if (d.transport == 2 && !d.h_send) {
         DV_CHECK(hipHostMalloc(&d.h_send, len, hipHostMallocDefault));
         DV_CHECK(hipHostMalloc(&d.h_recv, len * (size_t)d.world, hipHostMallocDefault));
@@ -80,7 +81,7 @@ void be_dist_release(dv_ctx* ctx) {
     DvDist& d = ctx->dist;
     if (d.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(d.comm);
     d.comm = nullptr;
-    d.xsend.release(); d.xrecv.release();
+    d.xsend.release(); d.xrecv.release(); d.qf.release();
     if (d.h_send) (void)hipHostFree(d.h_send);
     if (d.h_recv) (void)hipHostFree(d.h_recv);
     for (int r = 0; r < 64; ++r) { if (d.peer_win[r] && d.peer_win[r] != d.win) (void)hipIpcCloseMemHandle(d.peer_win[r]); d.peer_win[r] = nullptr; }
@@ -215,7 +216,7 @@ int dv_dist_peer_prepare(dv_ctx* ctx, int rank, int world, uint8_t handle[64]) {
     DV_CHECK(hipSetDevice(ctx->cfg.device));
     be_dist_release(ctx);
     DvDist& d = ctx->dist;
-    d.rank = rank; d.world = world; d.win_slot = (size_t)BE_XS_LEN(BE_MAX_LM);
+    d.rank = rank; d.world = world; d.win_slot = (size_t)BE_XS_BUF;
     const size_t bytes = peer_flag_off(d.win_slot, world) + (2 * (size_t)world + 1) * 8 + 256;
     // fine-grained: remote writes and the local polling loads must be coherent inside a running kernel, not only at kernel boundaries
     // (no coarse-grained fall-back: in-kernel polling of remotely written flags is not coherent there — spurious time-outs or stale vectors)
@@ -263,6 +264,14 @@ int dv_dist_shutdown(dv_ctx* ctx) {
     return 0;
 }
 
+int dv_dist_exchange_bytes(dv_ctx* ctx, int n_landmarks, long long* system_bytes, long long* cost_bytes, long long* depth_bytes) {
+    if (!ctx) return -1;
+    const int world = ctx->dist.world > 0 ? ctx->dist.world : 1;
+    if (system_bytes) *system_bytes = 8ll * BE_XS_LEN;                                   // per rank and linearisation: independent of the number of landmarks
+    if (cost_bytes) *cost_bytes = 64;                                                     // one partial sum per rank (padded)
+    if (depth_bytes) *depth_bytes = 8ll * std::max(1, (n_landmarks + world - 1) / world);   // once per solve, behind the last iteration slot
+    return 0;
+}
 int dv_dist_info(dv_ctx* ctx, int* rank, int* world, int* transport, long long* exchanges) {
     if (!ctx) return -1;
     if (rank) *rank = ctx->dist.rank;
@@ -280,7 +289,7 @@ int dv_allreduce_reduced_system(dv_ctx* ctx, double* S_g, int n) {
     if (!S_g || n < 1) DV_FAIL("dv_allreduce_reduced_system: null argument");
     if (d.transport == 0) { if (d.world == 1) return 0; DV_FAIL("dv_allreduce_reduced_system: dv_dist_init_* was not called"); }
     if (ctx->be.pend->active) DV_FAIL("dv_allreduce_reduced_system: a solve is in flight");
-    if ((size_t)n > (size_t)BE_XS_LEN(BE_MAX_LM)) DV_FAIL("dv_allreduce_reduced_system: n exceeds the exchange buffer");
+    if ((size_t)n > (size_t)BE_XS_BUF) DV_FAIL("dv_allreduce_reduced_system: n exceeds the exchange buffer");
     DV_CHECK(hipSetDevice(ctx->cfg.device));
     hipStream_t s = ctx->be_stream;
     std::vector<double> all((size_t)n * d.world);

@@ -38,7 +38,6 @@ extern "C" int dv_debug_red_ts(long long* out) { return hipMemcpyFromSymbol(out,
 #define RED_THREADS 448          // 7 waves: waves 0-5 = rows of a 6x6 pose block (lane = landmark), wave 6 = the block's IMU / prior terms
 #define RED_PAIRS (BE_NF * (BE_NF + 1) / 2)          // pose block pairs (fi >= fj): the landmark sums are bitwise symmetric (rho * (wi * wj); the direct terms are one stored value read from
                                                       // either side), so the upper blocks are mirrored stores instead of a second pass over the same packet rows (round 5: 121 -> 66 pair blocks)
-#define FIN_PAIRS (BE_NF * BE_NF)                      // be_shard_finalize_kernel keeps one block per ordered pair (the exchange vector carries the full 66 x 66 images)
 __device__ __forceinline__ void red_pair(int bx, int& fi, int& fj) {      // bx = fi (fi + 1) / 2 + fj, fj <= fi
     fi = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
     while (fi * (fi + 1) / 2 > bx) --fi;
@@ -135,7 +134,7 @@ __device__ __forceinline__ double wave_sum(double v) { return wave_sum_f64(v); }
 // blocks [0, 121): pose block (fi, fj) of the reduced system — landmark sums read the transposed packets coalesced
 //                  (lane = landmark), wave-tree reduced; blocks [121, ..): every entry that has no landmark term.
 #define DV_CONSTANT __attribute__((address_space(4)))
-template <class ARGS>
+template <bool SHARD, class ARGS>
 __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
@@ -163,7 +162,7 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
         // frames of an 11-frame window that is a fraction of the landmarks (observed in ~6 frames each); every other packet row would contribute zeros
         int fi, fj; red_pair(bx, fi, fj);
         const int lane = threadIdx.x & 63;
-        const int lo = a.sh.on ? a.sh.lo : 0, hi = a.sh.on ? a.sh.hi : nlm;
+        const int lo = SHARD ? a.sh.lo : 0, hi = SHARD ? a.sh.hi : nlm;
         int base = 0;
         // all observation masks requested up front (16 x 64 lanes covers BE_MAX_LM): with the load inside the ballot loop every 64 landmarks cost one
         // dependent round trip (five for a 300-landmark window) on the path every other wave of the block waits for
@@ -197,7 +196,7 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
         // the IMU / prior part of the block's 36 entries (and 6 gradient entries) is a chain of dependent global loads (column maps ->
         // factor / prior indices -> values): the seventh wave walks it WHILE the other six stream the landmark packets
         __shared__ double s_dh[36], s_dg[6];
-        if (ci == 6 && !a.sh.on) {
+        if (ci == 6 && !SHARD) {
 #ifdef BE_RED_TS
             if (bx == 0 && lane == 0) be_red_ts[16] = wall_clock64();
 #endif
@@ -208,6 +207,8 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
 #endif
         }
         double S[6] = {0, 0, 0, 0, 0, 0}, H[6] = {0, 0, 0, 0, 0, 0}, G = 0, GS = 0;
+        // sharded window: the weighted images of w w^T and g w behind the quadratic forms of be_solve_shard_kernel (be_kernels.h)
+        double T2[6] = {0, 0, 0, 0, 0, 0}, T6[6] = {0, 0, 0, 0, 0, 0}, T9[6] = {0, 0, 0, 0, 0, 0}, B2 = 0, B4 = 0, B5 = 0, B6 = 0, B8 = 0, B9 = 0;
         const int e_wi = BE_PK_W + fi * 6 + ci, e_wj = BE_PK_W + fj * 6;
         const int e_dd = BE_PK_DD + fi * 36 + ci * 6;
         const int e_da_i = BE_PK_DA + fj * 36 + ci * 6;                 // anchor == fi : row ci of block (anchor, fj)
@@ -222,11 +223,20 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
             const double wi = BE_PK(pk, e_wi, l);
 #pragma unroll
             for (int q = 0; q < 6; ++q) S[q] += rho * (wi * BE_PK(pk, e_wj + q, l));      // rho * (wi * wj): bitwise symmetric
+            const double al = SHARD ? (s * s) / d2 : 0.0, w2 = SHARD ? rho * rho / al : 0.0, w6 = h * (rho * rho), w9 = rho * rho;
+            if (SHARD) {
+#pragma unroll
+                for (int q = 0; q < 6; ++q) { const double wp = wi * BE_PK(pk, e_wj + q, l); T2[q] += w2 * wp; T6[q] += w6 * wp; T9[q] += w9 * wp; }
+            }
             if (diag) {
 #pragma unroll
                 for (int q = 0; q < 6; ++q) H[q] += BE_PK(pk, e_dd + q, l);
                 G += BE_PK(pk, BE_PK_GP + fi * 6 + ci, l);
                 GS += rho * (wi * BE_PK(pk, BE_PK_G, l));
+                if (SHARD) {
+                    const double gw = BE_PK(pk, BE_PK_G, l) * wi;
+                    B2 += w2 * gw; B4 += al * gw; B5 += (h * al * rho) * gw; B6 += w6 * gw; B8 += (al * rho) * gw; B9 += w9 * gw;
+                }
             } else {
                 const int anc = a.lm[l].anchor;
                 if (anc == fi) {
@@ -242,18 +252,26 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
 #pragma unroll
         for (int q = 0; q < 6; ++q) { S[q] = wave_sum(S[q]); H[q] = wave_sum(H[q]); }
         if (diag) { G = wave_sum(G); GS = wave_sum(GS); }
+        if (SHARD) {
+#pragma unroll
+            for (int q = 0; q < 6; ++q) { T2[q] = wave_sum(T2[q]); T6[q] = wave_sum(T6[q]); T9[q] = wave_sum(T9[q]); }
+            if (diag) { B2 = wave_sum(B2); B4 = wave_sum(B4); B5 = wave_sum(B5); B6 = wave_sum(B6); B8 = wave_sum(B8); B9 = wave_sum(B9); }
+        }
         __syncthreads();
         if (bx == 0) RTS(2);
         if (ci == 6) return;
-        if (a.sh.on) {            // sharded window: the partial landmark sums go to the exchange vector; be_shard_finalize_kernel adds the ranks up and the dense part in
+        if (SHARD) {              // sharded window: the partial landmark sums go to the exchange vector (lower block pair bx, row ci, column lane); be_shard_finalize_kernel adds the ranks up and the dense part in
             if (lane < 6) {
-                double sv = S[0], hv = H[0];
+                double v0 = S[0], v1 = H[0], v2 = T2[0], v3 = T6[0], v4 = T9[0];
 #pragma unroll
-                for (int q = 1; q < 6; ++q) if (lane == q) { sv = S[q]; hv = H[q]; }
-                const int e = (fi * 6 + ci) * 66 + fj * 6 + lane, et = (fj * 6 + lane) * 66 + fi * 6 + ci;
-                a.sh.xsend[BE_XS_S + e] = sv; a.sh.xsend[BE_XS_H + e] = hv;
-                if (!diag) { a.sh.xsend[BE_XS_S + et] = sv; a.sh.xsend[BE_XS_H + et] = hv; }
-            } else if (diag && lane == 6) { a.sh.xsend[BE_XS_G + fi * 6 + ci] = G; a.sh.xsend[BE_XS_GS + fi * 6 + ci] = GS; }
+                for (int q = 1; q < 6; ++q) if (lane == q) { v0 = S[q]; v1 = H[q]; v2 = T2[q]; v3 = T6[q]; v4 = T9[q]; }
+                const int e = bx * 36 + ci * 6 + lane;
+                a.sh.xsend[BE_XS_M(0) + e] = v0; a.sh.xsend[BE_XS_M(1) + e] = v1; a.sh.xsend[BE_XS_M(2) + e] = v2; a.sh.xsend[BE_XS_M(3) + e] = v3; a.sh.xsend[BE_XS_M(4) + e] = v4;
+            } else if (diag && lane == 6) {
+                const int e = fi * 6 + ci;
+                a.sh.xsend[BE_XS_V(0) + e] = G; a.sh.xsend[BE_XS_V(1) + e] = GS; a.sh.xsend[BE_XS_V(2) + e] = B2; a.sh.xsend[BE_XS_V(3) + e] = B4;
+                a.sh.xsend[BE_XS_V(4) + e] = B5; a.sh.xsend[BE_XS_V(5) + e] = B6; a.sh.xsend[BE_XS_V(6) + e] = B8; a.sh.xsend[BE_XS_V(7) + e] = B9;
+            }
             return;
         }
         if (lane < 6) {
@@ -278,16 +296,41 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
     }
     const int eb = bx - RED_PAIRS;
     const int n_dense = (n * n + n + RED_THREADS - 1) / RED_THREADS;
-    if (eb >= n_dense) {          // sharded window only: pack the rows be_solve reads of every landmark, and the candidate costs, for the owned range
-        const int row = eb - n_dense, cap = a.sh.cap;
-        double* dst = a.sh.xsend + BE_XS_ROWS + (size_t)row * cap;
-        for (int k = threadIdx.x; k < cap; k += RED_THREADS) {
-            const int l = a.sh.lo + k;
-            dst[k] = l < a.sh.hi ? (row < BE_XS_NROWS ? BE_PK(pk, row, l) : a.cand_cost[l]) : 0.0;
+    if (eb >= n_dense) {          // sharded window only (one block): the scalar sums over the owned landmarks, fixed order (strided partial sums, block tree), and the owned Jacobi scales
+        if (!SHARD) return;
+        __shared__ double s_red[7][13];
+        const double* xst = reinterpret_cast<const double*>((spec && c.pending) ? a.cand : a.x) + offsetof(BeState, inv_depth) / sizeof(double);
+        double acc[13];          // [12]: the owned candidate costs (a speculative linearisation carries the costs its accept decision will sum: the cost-only exchange belongs to the last slot alone)
+#pragma unroll
+        for (int k = 0; k < 13; ++k) acc[k] = 0.0;
+        for (int l = a.sh.lo + (int)threadIdx.x; l < a.sh.hi; l += RED_THREADS) {
+            const double h = BE_PK(pk, BE_PK_H, l), g = BE_PK(pk, BE_PK_G, l);
+            const double s = c.first ? 1.0 / (1.0 + sqrt(h)) : a.scale_l[l];
+            if (c.first) a.scale_l[l] = s;
+            double d2 = h * s * s; d2 = fmin(fmax(d2, 1e-6), 1e32);
+            const double rho = 1.0 / (h + mu * d2 / (s * s)), al = (s * s) / d2, g2 = g * g, x0 = xst[l];
+            acc[0] += al * g2; acc[1] += (rho * rho / al) * g2; acc[2] += rho * g2; acc[3] += (h * al * al) * g2; acc[4] += (h * al * rho) * g2; acc[5] += (h * (rho * rho)) * g2;
+            acc[6] += (al * al) * g2; acc[7] += (al * rho) * g2; acc[8] += (rho * rho) * g2; acc[9] += x0 * x0; acc[10] += BE_PK(pk, BE_PK_COST, l); acc[11] = fmax(acc[11], fabs(g)); acc[12] += a.cand_cost[l];
+        }
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc[k] = wave_sum(acc[k]);
+        acc[12] = wave_sum(acc[12]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc[11] = fmax(acc[11], __shfl_xor(acc[11], o));
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) s_red[threadIdx.x >> 6][k] = acc[k];
+        }
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            double v = 0.0;
+            if (threadIdx.x < 11 || threadIdx.x == 12) for (int w = 0; w < RED_THREADS / 64; ++w) v += s_red[w][threadIdx.x];
+            else if (threadIdx.x == 11) for (int w = 0; w < RED_THREADS / 64; ++w) v = fmax(v, s_red[w][11]);
+            a.sh.xsend[BE_XS_A + threadIdx.x] = v;
         }
         return;
     }
-    if (eb == 0 && c.first && !a.sh.on)
+    if (eb == 0 && c.first && !SHARD)
         for (int l = threadIdx.x; l < nlm; l += RED_THREADS) a.scale_l[l] = 1.0 / (1.0 + sqrt(BE_PK(pk, BE_PK_H, l)));
     const int t = eb * RED_THREADS + threadIdx.x;
     if (t < n * n) {
@@ -304,12 +347,13 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
     if (bx == RED_PAIRS + 3) RTS(9);
 }
 
-__global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, int spec) { be_reduce_body(a, spec, blockIdx.x); }
+__global__ __launch_bounds__(RED_THREADS) void be_reduce_kernel(BeSolveArgs a, int spec) { be_reduce_body<false>(a, spec, blockIdx.x); }
+__global__ __launch_bounds__(RED_THREADS) void be_reduce_shard_kernel(BeSolveArgs a, int spec) { be_reduce_body<true>(a, spec, blockIdx.x); }
 __global__ __launch_bounds__(RED_THREADS) void be_reduce_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) {      // blockIdx.y = window
     const DV_CONSTANT BeSolveArgs& a = *reinterpret_cast<const DV_CONSTANT BeSolveArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));      // the table through the constant (scalar, invariant) path
     const int n = a.dims.nstate;
     if ((int)blockIdx.x >= RED_PAIRS + (n * n + n + RED_THREADS - 1) / RED_THREADS) return;
-    be_reduce_body(a, spec, blockIdx.x);
+    be_reduce_body<false>(a, spec, blockIdx.x);
 }
 void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s) {
     hipLaunchKernelGGL(be_reduce_batch_kernel, dim3(RED_PAIRS + (max_n * max_n + max_n + RED_THREADS - 1) / RED_THREADS, n_win), dim3(RED_THREADS), 0, s, tab_dev, spec);
@@ -317,12 +361,13 @@ void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, in
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s) {
     const int n = a.dims.nstate;
     const int total = n * n + n;
-    hipLaunchKernelGGL(be_reduce_kernel, dim3(RED_PAIRS + (total + RED_THREADS - 1) / RED_THREADS + (a.sh.on ? BE_XS_NROWS + 1 : 0)), dim3(RED_THREADS), 0, s, a, spec);
+    if (a.sh.on) hipLaunchKernelGGL(be_reduce_shard_kernel, dim3(RED_PAIRS + (total + RED_THREADS - 1) / RED_THREADS + 1), dim3(RED_THREADS), 0, s, a, spec);
+    else hipLaunchKernelGGL(be_reduce_kernel, dim3(RED_PAIRS + (total + RED_THREADS - 1) / RED_THREADS), dim3(RED_THREADS), 0, s, a, spec);
 }
 
-// Sharded window, after the all-gather of the exchange vectors: sums the ranks' partial landmark sums in RANK ORDER (identical bits on every rank), adds the
-// IMU / prior part, and writes Hd / Sc / gvec of the set be_reduce_kernel worked on; copies every landmark's H, G, COST, W rows into the packets and the
-// candidate costs into cand_cost.  Same predicate as be_reduce_kernel, so an idle slot leaves the previous system untouched.
+// Sharded window, after the all-gather of the exchange vectors: sums the ranks' partial sums in RANK ORDER (identical bits on every rank), adds the IMU / prior part, writes
+// Hd / Sc / gvec of the set be_reduce worked on (upper blocks mirrored) and the summed form coefficients (qf of that set) for be_solve_shard_kernel.  Same predicate as
+// be_reduce_kernel, so an idle slot leaves the previous system untouched.
 #define FIN_THREADS 256
 __global__ __launch_bounds__(FIN_THREADS) void be_shard_finalize_kernel(BeSolveArgs a, int spec) {
     const BeCtl c = *a.ctl;
@@ -330,63 +375,95 @@ __global__ __launch_bounds__(FIN_THREADS) void be_shard_finalize_kernel(BeSolveA
     int set = c.cur;
     if (spec && c.pending) set ^= 1;
     else if (!c.need_eval && !c.chol_fail) return;
-    const int n = a.dims.nstate, nlm = a.dims.nlm, W = a.sh.world, len = a.sh.len, cap = a.sh.cap;
+    const int n = a.dims.nstate, W = a.sh.world, len = a.sh.len, t = threadIdx.x;
     const double* xr = a.sh.xrecv;
-    if (blockIdx.x < FIN_PAIRS) {
-        const int fi = blockIdx.x / BE_NF, fj = blockIdx.x - fi * BE_NF;
-        if (fi >= a.dims.nframes || fj >= a.dims.nframes) return;
-        const int ci0 = a.dims.pose_col[fi], cj0 = a.dims.pose_col[fj];
-        if (ci0 < 0 || cj0 < 0) return;
+    double* qf = a.sh.qf[set];
+    auto rsum = [&](int e) { double v = 0.0; for (int r = 0; r < W; ++r) v += xr[(size_t)r * len + e]; return v; };
+    if (blockIdx.x < RED_PAIRS) {
+        int fi, fj; red_pair(blockIdx.x, fi, fj);
+        const bool in_win = fi < a.dims.nframes && fj < a.dims.nframes;
+        const int ci0 = in_win ? a.dims.pose_col[fi] : -1, cj0 = in_win ? a.dims.pose_col[fj] : -1;
+        const bool valid = ci0 >= 0 && cj0 >= 0;      // (be_reduce writes the exchange vector for such pairs only: the rest of the 66-space is zero)
+        if (t < 36) {          // the form matrices in the 66-space (frame * 6 + component), mirrored
+            const int ci = t / 6, q = t - ci * 6, e = blockIdx.x * 36 + t, i66 = fi * 6 + ci, j66 = fj * 6 + q;
+            const double v0 = valid ? rsum(BE_XS_M(0) + e) : 0.0, v2 = valid ? rsum(BE_XS_M(2) + e) : 0.0, v3 = valid ? rsum(BE_XS_M(3) + e) : 0.0, v4 = valid ? rsum(BE_XS_M(4) + e) : 0.0;
+            qf[BE_QF_M(0) + i66 * 66 + j66] = v0; qf[BE_QF_M(1) + i66 * 66 + j66] = v2; qf[BE_QF_M(2) + i66 * 66 + j66] = v3; qf[BE_QF_M(3) + i66 * 66 + j66] = v4;
+            if (fi != fj) { qf[BE_QF_M(0) + j66 * 66 + i66] = v0; qf[BE_QF_M(1) + j66 * 66 + i66] = v2; qf[BE_QF_M(2) + j66 * 66 + i66] = v3; qf[BE_QF_M(3) + j66 * 66 + i66] = v4; }
+        } else if (fi == fj && t >= 64 && t < 70) {
+            const int e = fi * 6 + (t - 64);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) qf[BE_QF_V(k) + e] = valid ? rsum(BE_XS_V(k + 1) + e) : 0.0;
+        }
+        if (!valid) return;
         __shared__ int s_ifi[BE_WIN + 1], s_ifj[BE_WIN + 1], s_pr[2];
-        if ((int)threadIdx.x < a.dims.nimu) { s_ifi[threadIdx.x] = a.imu[threadIdx.x].fi; s_ifj[threadIdx.x] = a.imu[threadIdx.x].fj; }
-        if (threadIdx.x == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
+        if (t < a.dims.nimu) { s_ifi[t] = a.imu[t].fi; s_ifj[t] = a.imu[t].fj; }
+        if (t == 64) { s_pr[0] = a.prior->valid; s_pr[1] = a.prior->n; }
         __syncthreads();
         const RedCtx rc{ s_ifi, s_ifj, s_pr[0], s_pr[1] };
-        const int t = threadIdx.x;
         if (t < 36) {
-            const int ci = t / 6, q = t - ci * 6, e = (fi * 6 + ci) * 66 + fj * 6 + q;
-            double sv = 0.0, hv = 0.0;
-            for (int r = 0; r < W; ++r) { sv += xr[(size_t)r * len + BE_XS_S + e]; hv += xr[(size_t)r * len + BE_XS_H + e]; }
+            const int ci = t / 6, q = t - ci * 6, e = blockIdx.x * 36 + t;
+            const double sv = rsum(BE_XS_M(0) + e), hv = rsum(BE_XS_M(1) + e);
             const int i = ci0 + ci, j = cj0 + q;
             const double hd = hv + red_dense_h(a, rc, a.imu_out[set], i, j);
             a.Hd[set][(size_t)i * n + j] = hd;
             if ((j >> 2) <= (i >> 2)) a.Sc[set][blk_pos(i, j, (n + 3) >> 2)] = hd - sv;
+            if (fi != fj) {
+                a.Hd[set][(size_t)j * n + i] = hd;
+                if ((i >> 2) <= (j >> 2)) a.Sc[set][blk_pos(j, i, (n + 3) >> 2)] = hd - sv;
+            }
         } else if (fi == fj && t >= 64 && t < 70) {
-            const int ci = t - 64;
-            double G = 0.0, GS = 0.0;
-            for (int r = 0; r < W; ++r) { G += xr[(size_t)r * len + BE_XS_G + fi * 6 + ci]; GS += xr[(size_t)r * len + BE_XS_GS + fi * 6 + ci]; }
-            const int i = ci0 + ci;
-            a.gvec[set][i] = G + red_dense_g(a, rc, a.imu_out[set], a.prior_out[set], i);
-            a.gvec[set][n + i] = GS;
+            const int ci = t - 64, i = ci0 + ci;
+            a.gvec[set][i] = rsum(BE_XS_V(0) + fi * 6 + ci) + red_dense_g(a, rc, a.imu_out[set], a.prior_out[set], i);
+            a.gvec[set][n + i] = rsum(BE_XS_V(1) + fi * 6 + ci);
         }
         return;
     }
-    const int row = blockIdx.x - FIN_PAIRS;
-    double* pk = const_cast<double*>(a.packets[set]);
-    for (int l = threadIdx.x; l < nlm; l += FIN_THREADS) {
-        const int r = l / cap, k = l - r * cap;
-        const double v = xr[(size_t)r * len + BE_XS_ROWS + (size_t)row * cap + k];
-        if (row < BE_XS_NROWS) {
-            BE_PK(pk, row, l) = v;
-            if (row == BE_PK_H && c.first) a.scale_l[l] = 1.0 / (1.0 + sqrt(v));
-        } else const_cast<double*>(a.cand_cost)[l] = v;
+    if (t < 16) {              // the scalars (entry 11: a maximum)
+        double v = 0.0;
+        if (t == 11) for (int r = 0; r < W; ++r) v = fmax(v, xr[(size_t)r * len + BE_XS_A + 11]);
+        else v = rsum(BE_XS_A + t);
+        qf[BE_QF_A + t] = v;
+    }
+    if (spec && c.pending) {   // the candidate's costs for the decision the next solve takes: the rank-ordered total in the first landmark slot, zeros in the others (be_shard_cost_kernel's convention)
+        double* cc = const_cast<double*>(a.cand_cost);
+        for (int l = t; l < a.dims.nlm; l += FIN_THREADS) cc[l] = l == 0 ? rsum(BE_XS_A + 12) : 0.0;
     }
 }
 void be_launch_shard_finalize(const BeSolveArgs& a, int spec, hipStream_t s) {
-    hipLaunchKernelGGL(be_shard_finalize_kernel, dim3(FIN_PAIRS + BE_XS_NROWS + 1), dim3(FIN_THREADS), 0, s, a, spec);
+    hipLaunchKernelGGL(be_shard_finalize_kernel, dim3(RED_PAIRS + 1), dim3(FIN_THREADS), 0, s, a, spec);
 }
-// cost-only exchange (the slot that ends with be_accept): phase 0 packs the owned candidate costs, phase 1 scatters the gathered ones
+// cost-only exchange (the slot that ends with be_accept): phase 0 sums the owned candidate costs in a fixed order into ONE double; phase 1 adds the ranks' partial sums in
+// rank order and leaves the total in the first landmark slot of cand_cost, zeros in the others — the accept decision's own summation tree then yields the same bits on every rank
 __global__ __launch_bounds__(FIN_THREADS) void be_shard_cost_kernel(BeSolveArgs a, int phase) {
     const BeCtl c = *a.ctl;
     if (c.done || !c.pending) return;
-    const int cap = a.sh.cap;
+    const int t = threadIdx.x;
     if (phase == 0) {
-        for (int k = threadIdx.x; k < cap; k += FIN_THREADS) { const int l = a.sh.lo + k; a.sh.xsend[k] = l < a.sh.hi ? a.cand_cost[l] : 0.0; }
+        __shared__ double s_w[FIN_THREADS / 64];
+        double v = 0.0;
+        for (int l = a.sh.lo + t; l < a.sh.hi; l += FIN_THREADS) v += a.cand_cost[l];
+        v = wave_sum(v);
+        if ((t & 63) == 0) s_w[t >> 6] = v;
+        __syncthreads();
+        if (t == 0) { double tot = 0.0; for (int w = 0; w < FIN_THREADS / 64; ++w) tot += s_w[w]; a.sh.xsend[0] = tot; }
+        else if (t < 8) a.sh.xsend[t] = 0.0;
     } else {
-        for (int l = threadIdx.x; l < a.dims.nlm; l += FIN_THREADS) { const int r = l / cap; const_cast<double*>(a.cand_cost)[l] = a.sh.xrecv[(size_t)r * cap + (l - r * cap)]; }
+        double* cc = const_cast<double*>(a.cand_cost);
+        for (int l = t; l < a.dims.nlm; l += FIN_THREADS) {
+            double v = 0.0;
+            if (l == 0) for (int r = 0; r < a.sh.world; ++r) v += a.sh.xrecv[(size_t)r * 8];
+            cc[l] = v;
+        }
     }
 }
 void be_launch_shard_cost(const BeSolveArgs& a, int phase, hipStream_t s) { hipLaunchKernelGGL(be_shard_cost_kernel, dim3(1), dim3(FIN_THREADS), 0, s, a, phase); }
+// behind the last iteration slot: every rank holds the solved inverse depths of its own landmarks only; phase 0 packs them, phase 1 scatters the gathered ranges into x
+__global__ __launch_bounds__(FIN_THREADS) void be_shard_depth_kernel(BeSolveArgs a, int phase) {
+    const int cap = a.sh.cap;
+    if (phase == 0) { for (int k = threadIdx.x; k < cap; k += FIN_THREADS) { const int l = a.sh.lo + k; a.sh.xsend[k] = l < a.sh.hi ? a.x->inv_depth[l] : 0.0; } }
+    else for (int l = threadIdx.x; l < a.dims.nlm; l += FIN_THREADS) { const int r = l / cap; if (r != a.sh.rank) a.x->inv_depth[l] = a.sh.xrecv[(size_t)r * cap + (l - r * cap)]; }
+}
+void be_launch_shard_depth(const BeSolveArgs& a, int phase, hipStream_t s) { hipLaunchKernelGGL(be_shard_depth_kernel, dim3(1), dim3(FIN_THREADS), 0, s, a, phase); }
 
 // ---------------------------------------------------------------------------------------------
 #define SOL_THREADS 1024
@@ -942,11 +1019,18 @@ __device__ __forceinline__ void bs_rows(const double* Lm, int kt, int lane, doub
 // (99.2 vs 95.2 us; the by-value kernel arguments stopped being treated as invariant scalar loads).
 template <int NSLOT, bool MF16>
 __global__ __launch_bounds__(SOL_THREADS) void be_solve_kernel(BeSolveArgs a, int spec) {
+    constexpr bool SHARD = false;
 #include "be_solve_body.inc"
 }
 template <int NSLOT, bool MF16>
 __global__ __launch_bounds__(SOL_THREADS) void be_solve_batch_kernel(const BeSolveArgs* __restrict__ tab, int spec) {      // one workgroup per window
     const BeSolveArgs& a = tab[blockIdx.x];
+    constexpr bool SHARD = false;
+#include "be_solve_body.inc"
+}
+// one window sharded by landmark (be_kernels.h BeShard): the same step on every rank, landmark sums from the exchanged forms, the rank's own landmarks moved
+__global__ __launch_bounds__(SOL_THREADS) void be_solve_shard_kernel(BeSolveArgs a, int spec) {
+    constexpr int NSLOT = 1; constexpr bool MF16 = true, SHARD = true;
 #include "be_solve_body.inc"
 }
 
@@ -989,6 +1073,13 @@ int be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)solve_smem(BE_MAX_STATE)) != hipSuccess) return 1;
             return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ? 1 : 0; })) return -1;      // 160 KB per workgroup less the kernel's static arrays
     const int nbr = (a.dims.nstate + 3) / 4;
+    if (a.sh.on) {
+        if (!a.ldl_mf16 || solve_smem_mf16(a.dims.nstate) > 160 * 1024 - 1024) return -2;          // (the sharded step exists on the MF16 factorisation only: every window the estimator builds; its static LDS is 0.7 KB)
+        static DevOnce once_s;
+        if (once_s.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_shard_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024) != hipSuccess ? 1 : 0; })) return -1;
+        hipLaunchKernelGGL(be_solve_shard_kernel, dim3(1), dim3(SOL_THREADS), solve_smem_mf16(a.dims.nstate), s, a, spec);
+        return 0;
+    }
     if (a.ldl_mf16) hipLaunchKernelGGL((be_solve_kernel<1, true>), dim3(1), dim3(SOL_THREADS), solve_smem_mf16(a.dims.nstate), s, a, spec);
     else if (nbr * (nbr + 1) / 2 <= SOL_THREADS) hipLaunchKernelGGL((be_solve_kernel<1, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);
     else hipLaunchKernelGGL((be_solve_kernel<2, false>), dim3(1), dim3(SOL_THREADS), solve_smem(a.dims.nstate), s, a, spec);

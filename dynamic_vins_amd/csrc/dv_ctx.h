@@ -164,7 +164,7 @@ struct DvDist {
     int rank = 0, world = 1;
     void* comm = nullptr;         // ncclComm_t
     dv_allgather_fn fn = nullptr; void* user = nullptr;
-    DevBuf xsend, xrecv; void* h_send = nullptr; void* h_recv = nullptr;
+    DevBuf xsend, xrecv, qf; void* h_send = nullptr; void* h_recv = nullptr;      // qf: the summed form coefficients, one image per linearisation set (2 x BE_QF_LEN doubles)
     long long exchanges = 0;
     // transport 3: the window this rank exposes to its peers (hipIpc): [2 parities][world][slot] doubles, then [2][world] sequence flags, then a time-out flag;
     // peer_win[r] = rank r's window as mapped into this process (own window for r == rank)

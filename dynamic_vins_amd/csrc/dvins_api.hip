@@ -192,6 +192,8 @@ void dv_destroy(dv_ctx* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     be_batch_detach(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->last_done && ctx->last_front && ctx->last_front != ctx->stream) (void)hipEventSynchronize(ctx->last_done);      // a frame tracked on a dv_batch's front-end stream may still be in flight
+    if (ctx->be_stream) (void)hipStreamSynchronize(ctx->be_stream);
     for (auto& t : ctx->timers) for (auto& p : t.pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,
                        &ctx->left[0].buf, &ctx->left[1].buf, &ctx->right.buf, &ctx->leftc[0].buf, &ctx->leftc[1].buf, &ctx->rightc.buf, &ctx->opA.buf, &ctx->opB.buf, &ctx->undist_buf[0], &ctx->undist_buf[1] }) b->release();

@@ -168,6 +168,14 @@ def dist_info(ctx):
     return dict(rank=r.value, world=w.value, transport={0: "none", 1: "rccl", 2: "host", 3: "peer"}[t.value], exchanges=e.value, rccl_ranks=n.value)
 
 
+def exchange_bytes(ctx, n_landmarks):
+    """bytes one rank contributes to the exchanges of a sharded window solve: (system: per linearisation, independent of the landmark count; cost: per cost-only slot; depth: once per solve)"""
+    import ctypes as C
+    a, b, c = C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+    ctx.lib.dv_dist_exchange_bytes(ctx.h, int(n_landmarks), C.byref(a), C.byref(b), C.byref(c))
+    return dict(system=a.value, cost=b.value, depth=c.value)
+
+
 def whole_job_rate(units_per_rank, world, seconds_max):
     """BASELINE metric for N ranks: units all ranks processed / max-over-ranks time"""
     return world * units_per_rank / seconds_max

@@ -68,14 +68,14 @@ def run_shard_bench(args, rank, world, local_rank):
         p2.ctx.close()
         dt = times[0]
         cap = max(1, -(-n_lm // world))
-        xlen = 2 * 66 * 66 + 132 + 70 * cap
+        xb = dict(system=12424 * 8, cost=64, depth=8 * cap)      # dv_dist_exchange_bytes: per linearisation (independent of the landmark count) | per cost-only slot | once per solve
         out = {"metric": "stereo frames/sec (track+BA)", "value": round(args.steps / dt, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": warm_ba,
                "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"synthetic {w}x{h} stereo @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "") + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame",
                           "mode": "raw", "config": args.config, "git_head": git_head(),
                           "parallelism": f"ONE sequence; its window solve sharded by landmark over {world} rank(s): {info['transport']} all-gather + rank-ordered sum per linearisation; front end replicated",
                           "transport": info["transport"], "rccl_ranks": info["rccl_ranks"], "landmarks_in_window": n_lm, "landmarks_per_rank": cap, "exchanges_per_frame": round(info["exchanges"] / frames_total, 2),
-                          "exchange_bytes_per_rank": 8 * xlen, "all_ranks_same_trajectory_bits": bool(same), "ate_rmse_m_vs_ground_truth": round(ate, 5),
+                          "exchange_bytes_per_rank": xb["system"], "exchange_bytes_detail": xb, "all_ranks_same_trajectory_bits": bool(same), "ate_rmse_m_vs_ground_truth": round(ate, 5),
                           "second_block_value": round(args.steps / times[1], 2),
                           "unsharded_value_same_process": round(args.steps / plain_times[0], 2), "unsharded_second_block_value": round(args.steps / plain_times[1], 2),
                           "max_abs_position_diff_vs_unsharded_m": plain_digest},

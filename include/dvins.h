@@ -230,6 +230,9 @@ int dv_dist_peer_prepare(dv_ctx* ctx, int rank, int world, uint8_t handle[64]);
 int dv_dist_init_peer(dv_ctx* ctx, const uint8_t* handles /* [world][64], rank order */);
 int dv_dist_rccl_ranks(dv_ctx* ctx, int* n);                                             /* ncclCommCount of the communicator behind dv_dist_init_rccl (0: other transport) */
 int dv_dist_shutdown(dv_ctx* ctx);
+/* what one rank contributes to the exchanges of a sharded window solve (bytes): `system` once per linearisation — the partial reduced camera system and the coefficients of the
+ * quadratic forms the trust-region step needs of the landmarks it does not own: 12 424 doubles whatever the window holds —, `cost` once per cost-only slot, `depth` once per solve */
+int dv_dist_exchange_bytes(dv_ctx* ctx, int n_landmarks, long long* system_bytes, long long* cost_bytes, long long* depth_bytes);
 int dv_dist_info(dv_ctx* ctx, int* rank, int* world, int* transport, long long* exchanges);
 /* operator form of the exchange: S_g (host, n doubles — this rank's partial [S | g | cost], e.g. of dv_ba_eval on the rank's share of the landmarks)
  * is replaced by the rank-ordered sum over all ranks */

@@ -41,6 +41,10 @@ def test_world_one_sharded_path_matches_plain(gpu_ctx_factory, oracle, transport
         assert np.abs(a.pose - b.pose).max() < 1e-12 and np.abs(a.inv_depth - b.inv_depth).max(initial=0.0) < 1e-12
         assert np.isclose(sa.final_cost, sb.final_cost, rtol=1e-12)
     assert dv_dist.dist_info(shard)["exchanges"] > 0
+    # round 5: the per-linearisation exchange does not grow with the window (<= 110 KB at L = 1000) — partial reduced system + quadratic-form coefficients
+    for L in (0, 254, 1000):
+        eb = dv_dist.exchange_bytes(shard, L)
+        assert eb["system"] == 12424 * 8 <= 110 * 1024 and eb["cost"] == 64 and eb["depth"] == 8 * max(1, L)
     assert shard.lib.dv_dist_shutdown(shard.h) == 0
     # after shutdown the ctx solves unsharded again
     ref = ba_gen.make_window(oracle, seed=2, with_prior=True)

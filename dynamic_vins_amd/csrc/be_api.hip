@@ -672,6 +672,7 @@ void be_batch_detach(dv_ctx* ctx) {
         B->members.erase(std::remove(B->members.begin(), B->members.end(), ctx), B->members.end());
         ctx->batch = nullptr;
         if (B->stream) (void)hipStreamSynchronize(B->stream);
+        dv_front_batch_sync(B->front);
         if (ctx->be_stream_own) { ctx->be_stream = ctx->be_stream_own; ctx->be_stream_own = nullptr; }
         if (B->arrived > 0) { B->last_rc = -1; B->arrived = 0; ++B->generation; dv_set_error(nullptr, "dv_batch_arrive: a member was destroyed during the round"); }
     }

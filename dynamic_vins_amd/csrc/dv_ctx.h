@@ -142,6 +142,7 @@ DvFrontBatch*& be_batch_front(struct dv_batch* B);
 int be_batch_index(struct dv_batch* B);
 const std::vector<dv_ctx*>& be_batch_members(struct dv_batch* B);
 void dv_front_batch_release(DvFrontBatch* F);
+void dv_front_batch_sync(DvFrontBatch* F);
 void* be_staging_factors(dv_ctx* ctx, int* cap);      // where the next solve's upload reads its factor table (pinned); nullptr if the workspace cannot be set up
 int be_solve_fused_begin(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused);       // upload + enqueue everything, returns immediately
 int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, BeFused* fused);      // sync + collect

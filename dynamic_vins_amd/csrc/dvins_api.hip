@@ -192,7 +192,8 @@ void dv_destroy(dv_ctx* ctx) {
     (void)hipSetDevice(ctx->cfg.device);
     be_batch_detach(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    if (ctx->last_done && ctx->last_front && ctx->last_front != ctx->stream) (void)hipEventSynchronize(ctx->last_done);      // a frame tracked on a dv_batch's front-end stream may still be in flight
+    // (a frame tracked on a dv_batch's front-end stream: be_batch_detach above / dv_batch_destroy drain that stream — its event belongs to the batch and may be gone by now,
+    //  so it is NOT waited on here: doing so crashed dv_destroy behind dv_runner_destroy, round 5)
     if (ctx->be_stream) (void)hipStreamSynchronize(ctx->be_stream);
     for (auto& t : ctx->timers) for (auto& p : t.pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     for (DevBuf* b : { &ctx->state_block, &ctx->cand_buf, &ctx->hw_buf, &ctx->mask_buf, &ctx->out_buf, &ctx->s0, &ctx->s1, &ctx->s2, &ctx->s3, &ctx->s4,
@@ -394,6 +395,7 @@ struct DvFrontBatch {
     DevBuf tab[2]; void* tab_pinned[2] = { nullptr, nullptr }; size_t tab_bytes = 0; int parity = 0; bool copy_used[2] = { false, false };
     long long rounds = 0, members_batched = 0, members_single = 0;
 };
+void dv_front_batch_sync(DvFrontBatch* F) { if (F && F->stream) (void)hipStreamSynchronize(F->stream); }      // be_batch_detach: a member leaves while one of its frames may be in flight on the group's front-end stream
 void dv_front_batch_release(DvFrontBatch* F) {
     if (!F) return;
     if (F->stream) { (void)hipStreamSynchronize(F->stream); (void)hipStreamDestroy(F->stream); }

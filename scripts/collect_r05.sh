@@ -7,6 +7,7 @@
 #      16 / 32 / 64 sequences, 21 KITTI-size sequences, 16 without teams — each multi-sequence line behind the ATE gate and the two-member bit-identity check
 # The script REFUSES to finish (exit 4) if the digest in the PMC file it wrote differs from the sources' digest, or if the default line's roofline.traffic is null.
 set -e
+trap 'echo "collect: failed at line $LINENO"' ERR
 TAG=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out

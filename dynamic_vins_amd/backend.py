@@ -513,6 +513,12 @@ class Runner:
                 import torch
                 frames = [(f[0].cpu().pin_memory(), f[1].cpu().pin_memory()) for f in frames]
                 assert all(a.is_contiguous() and b.is_contiguous() for a, b in frames)
+                # one throw-away DMA out of every pinned buffer: the FIRST transfer from a freshly pinned page range pays its mapping (seen as an intermittent 40 - 80 ms stall in the
+                # first timed block when only the warm-up's frames had been uploaded before); the per-frame upload itself stays inside whatever times dv_runner_run
+                scratch = torch.empty_like(q.frames[0][0])
+                for a, b in frames:
+                    scratch.copy_(a, non_blocking=True); scratch.copy_(b, non_blocking=True)
+                torch.cuda.synchronize()
                 self._keep.append(frames)
             L = (C.c_void_p * len(frames))(*[f[0].data_ptr() for f in frames]); R = (C.c_void_p * len(frames))(*[f[1].data_ptr() for f in frames])
             t = np.ascontiguousarray(q.times[first_frame:], np.float64)

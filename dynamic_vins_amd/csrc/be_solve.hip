@@ -888,6 +888,21 @@ __device__ __forceinline__ bool ldlt_mf16(mf_d4 (&U)[MF_SLOTS], const uint8_t* p
 #endif
     return *s_fail == 0;
 }
+// sum over the four 16-lane rows of a wave (lanes c, 16 + c, 32 + c, 48 + c), the result in every lane, on the VALU: v_permlane32_swap folds the upper half onto the lower,
+// v_permlane16_swap the odd rows onto the even ones (gfx950) — (r0 + r2) + (r1 + r3) — instead of a round trip through the wave's gather buffer (write, wave sync, four reads,
+// wave sync).  Round 5: the two such sums per tile and step were the back substitution's "known yield" of the earlier rounds.
+#ifndef MF_BS_PERMLANE
+#define MF_BS_PERMLANE 1
+#endif
+typedef unsigned mf_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double mf_rows4_sum(double v) {
+    mf_u2 a = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    mf_u2 b = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    const double t = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    a = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(t), (unsigned)__double2loint(t), false, false);
+    b = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(t), (unsigned)__double2hiint(t), false, false);
+    return __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+}
 // block back substitution L^T x = y on the tiles: per block row i (last to first) x_i = W_i^T y_i (every wave that needs it forms it itself: 4 FMAs per lane and
 // one exchange through its gather buffer), then every tile (i, k) of that block row takes its share out of y_k.  One barrier per 16 unknowns.
 __device__ __forceinline__ void bs_mf16(const uint8_t* plan, int n, const MfLds& m, double* v_x) {
@@ -905,10 +920,13 @@ __device__ __forceinline__ void bs_mf16(const uint8_t* plan, int n, const MfLds&
             double part = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) part = __builtin_fma(Wi[r], m.yv[16 * i + rho + 4 * r], part);
-            gat[lane] = part;
-            wave_lds_sync();
-            double xi = (gat[c] + gat[16 + c]) + (gat[32 + c] + gat[48 + c]);      // (W_i^T y_i)[c], in every 16-lane row
-            wave_lds_sync();
+            double xi = MF_BS_PERMLANE ? mf_rows4_sum(part) : 0.0;                 // (W_i^T y_i)[c], in every 16-lane row
+            if (!MF_BS_PERMLANE) {
+                gat[lane] = part;
+                wave_lds_sync();
+                xi = (gat[c] + gat[16 + c]) + (gat[32 + c] + gat[48 + c]);
+                wave_lds_sync();
+            }
             if (i == IB && c >= c0) xi = 0.0;                                     // the right-hand-side row and the padding are not unknowns
             if (wave == 0 && rho == 0 && 16 * i + c < n) v_x[16 * i + c] = xi;
 #pragma unroll
@@ -921,10 +939,13 @@ __device__ __forceinline__ void bs_mf16(const uint8_t* plan, int n, const MfLds&
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { const int C = rho + 4 * q; acc = __builtin_fma(V[((((c & 3) << 4) + C) << 2) + (c >> 2)], gat[C], acc); }
                 wave_lds_sync();
-                gat[lane] = acc;
-                wave_lds_sync();
-                const double t = (gat[c] + gat[16 + c]) + (gat[32 + c] + gat[48 + c]);
-                wave_lds_sync();
+                double t = MF_BS_PERMLANE ? mf_rows4_sum(acc) : 0.0;
+                if (!MF_BS_PERMLANE) {
+                    gat[lane] = acc;
+                    wave_lds_sync();
+                    t = (gat[c] + gat[16 + c]) + (gat[32 + c] + gat[48 + c]);
+                    wave_lds_sync();
+                }
                 if (rho == 0) m.yv[16 * sJ[s] + c] -= t;
             }
         }

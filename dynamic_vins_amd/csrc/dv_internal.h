@@ -35,6 +35,7 @@ struct DvTrackState {
     int*      n_feat;        // device scalar: current number of features
     int*      n_tracked;     // device scalar: features that survived temporal LK
     uint32_t* next_id;       // InstFeat::global_id_count
+    unsigned short* lk_order;   // scratch of dv_launch_lk_track: the points of the launch in position order
 };
 
 struct GfttTileArgs {
@@ -91,7 +92,7 @@ int  dv_launch_gftt_select_multi(const GfttSelectArgs* tab_dev, int n_jobs, hipS
 struct DvLkJob { DvPyr A, B; const float2* pts_a; const int* n_dev; float2* pts_b; uint8_t* status; float add_x, add_y; int use_add, pad; };
 void dv_launch_lk_track_multi(const DvLkJob* jobs_dev, int n_jobs, int n_max, int flow_back, float dist_thresh, hipStream_t s);
 void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max,
-                        int flow_back, float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s);
+                        int flow_back, float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s, unsigned short* order_scratch = nullptr);      // order_scratch ([n_max] ushort, device): track the points in position order, XCD-aware (lk.hip lk_order_kernel)
 void dv_launch_lk_track_offset(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back,
                                float dist_thresh, float add_x, float add_y, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_finalize_offset(const DvTrackState& tr, const dv_cam& cam0, const dv_cam& cam1, int stereo, double dt, int n_max, double off_x, double off_y,

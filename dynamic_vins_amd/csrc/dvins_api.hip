@@ -169,7 +169,7 @@ dv_ctx* dv_create(const dv_config* cfg) {
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
     size_t o_last = take(N * 8), o_cur = take(N * 8), o_lk = take(N * 8), o_lks = take(N), o_ids = take(N * 4), o_cnt = take(N * 4),
            o_pun = take(N * 8), o_prun = take(N * 8), o_prv = take(N), o_trk = take(N), o_rp = take(N * 8), o_rs = take(N),
-           o_scal = take(64);
+           o_scal = take(64), o_ord = take(N * 2);
     if ((e = ctx->state_block.ensure(off)) != hipSuccess) return fail("hipMalloc(state)", e);
     uint8_t* base = (uint8_t*)ctx->state_block.p;
     ctx->tr.last_pts = (float2*)(base + o_last); ctx->tr.curr_pts = (float2*)(base + o_cur); ctx->tr.lk_pts = (float2*)(base + o_lk);
@@ -177,6 +177,7 @@ dv_ctx* dv_create(const dv_config* cfg) {
     ctx->tr.prev_un = (float2*)(base + o_pun); ctx->tr.prev_run = (float2*)(base + o_prun); ctx->tr.prev_rvalid = base + o_prv;
     ctx->tr.tracked = base + o_trk; ctx->tr.right_pts = (float2*)(base + o_rp); ctx->tr.right_status = base + o_rs;
     ctx->tr.n_feat = (int*)(base + o_scal); ctx->tr.n_tracked = ctx->tr.n_feat + 1; ctx->tr.next_id = (uint32_t*)(ctx->tr.n_feat + 2);
+    ctx->tr.lk_order = (unsigned short*)(base + o_ord);
     ctx->n_cand = ctx->tr.n_feat + 3; ctx->max_ord = (unsigned*)(ctx->tr.n_feat + 4); ctx->err_flag = ctx->tr.n_feat + 5;
     if ((e = ctx->out_buf.ensure(N * sizeof(dv_feat) + 256)) != hipSuccess) return fail("hipMalloc(out)", e);
     ctx->out_dev = (dv_feat*)ctx->out_buf.p; ctx->nout_dev = (int*)((uint8_t*)ctx->out_buf.p + N * sizeof(dv_feat));
@@ -310,7 +311,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
             dv_launch_lk_cuda_track(ctx->leftc[ctx->cur ^ 1].pyr, ctx->leftc[ctx->cur].pyr, ctx->tr.last_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_temporal, ctx->tr.lk_pts, ctx->tr.lk_status, s);
         else
             dv_launch_lk_track(Lp.pyr, L.pyr, ctx->tr.last_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_temporal, ctx->tr.lk_pts,
-                               ctx->tr.lk_status, s);
+                               ctx->tr.lk_status, s, ctx->tr.lk_order);
     }
     {
         StageScope sc(ctx, "compact");
@@ -344,7 +345,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
             dv_launch_lk_cuda_track(ctx->leftc[ctx->cur].pyr, ctx->rightc.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_stereo, ctx->tr.right_pts, ctx->tr.right_status, s);
         else
             dv_launch_lk_track(L.pyr, ctx->right.pyr, ctx->tr.curr_pts, ctx->tr.n_feat, c.max_cnt, c.flow_back, dist_stereo,
-                               ctx->tr.right_pts, ctx->tr.right_status, s);
+                               ctx->tr.right_pts, ctx->tr.right_status, s, ctx->tr.lk_order);
     }
     {
         StageScope sc(ctx, "finalize");

@@ -408,13 +408,40 @@ __device__ __forceinline__ void lk_track_point(const DvPyr& A, const DvPyr& B, c
     if (lane == 0) { pts_b[p] = next; status[p] = st ? 1 : 0; }
     LKADD(6, 1); LKADD(7, LKNOW() - lk_p0); LKMAX(3, LKNOW() - lk_p0);
 }
+// Position order of the points of one launch (round 5): rank of every point under the key (row, column) of its pixel, ties by index — order[rank] = point.  One workgroup,
+// rank by counting (n <= 1024: n LDS broadcast reads per thread).  lk_track_kernel deals the SORTED points to the XCDs in contiguous ranges (workgroup b runs on XCD b & 7):
+// an XCD's waves then read one horizontal band of the two pyramids instead of all of both (points arrive in track order: by age, not by position — PMC: 5.4 MB fetched per
+// launch for 1.6 MB of tiles, the pyramids pulled into up to eight L2s).  Which workgroup tracks which point changes, nothing else: results are bit-identical.
+__global__ __launch_bounds__(1024) void lk_order_kernel(const float2* __restrict__ pts, const int* __restrict__ n_dev, int n_host, unsigned short* __restrict__ order) {
+    __shared__ unsigned key[1024];
+    const int n = min(n_dev ? *n_dev : n_host, 1024), t = threadIdx.x;
+    if (t < n) {
+        const float2 q = pts[t];
+        const int yi = min(max((int)q.y, 0), 8191), xi = min(max((int)q.x, 0), 8191);      // (NaN / out-of-image positions: clamped — any key is a valid order)
+        key[t] = ((unsigned)yi << 13) | (unsigned)xi;
+    }
+    __syncthreads();
+    if (t < n) {
+        const unsigned k = key[t];
+        int r = 0;
+        for (int j = 0; j < n; ++j) { const unsigned kj = key[j]; r += (kj < k || (kj == k && j < t)) ? 1 : 0; }
+        order[r] = (unsigned short)t;
+    }
+}
 __global__ __launch_bounds__(64) void lk_track_kernel(DvPyr A, DvPyr B, const float2* __restrict__ pts_a, const int* __restrict__ n_dev,
                                                       int n_host, int flow_back, float dist_thresh, double eps_sq,
-                                                      float2* __restrict__ pts_b, uint8_t* __restrict__ status, float add_x, float add_y, int use_add) {
+                                                      float2* __restrict__ pts_b, uint8_t* __restrict__ status, float add_x, float add_y, int use_add,
+                                                      const unsigned short* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) uint8_t sI[IT_ROWS * IT_PITCH];
     __shared__ __attribute__((aligned(16))) uint8_t sJ[JT_ROWS * JT_PITCH];
-    const int p = blockIdx.x, lane = threadIdx.x;
+    const int lane = threadIdx.x;
     const int n = n_dev ? *n_dev : n_host;
+    int p = blockIdx.x;
+    if (order) {           // XCD b & 7 takes the sorted positions [(b & 7) per, (b & 7) per + per): one-to-one from the padded grid onto [0, 8 per)
+        const int per = (n + 7) >> 3, L = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+        if (((int)blockIdx.x >> 3) >= per || L >= n) return;
+        p = order[L];
+    }
     if (p >= n) return;
     // the level descriptors are indexed by the pass loop: from LDS (a dynamic index into the by-value argument structs makes the compiler copy them to scratch,
     // i.e. a memory round trip per pass)
@@ -442,16 +469,19 @@ void dv_launch_lk_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, i
 }
 
 void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back,
-                        float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s) {
+                        float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s, unsigned short* order_scratch) {
     if (n_max <= 0) return;
     const double eps = 0.01;   // TermCriteria default / feature_utils.cpp:52; OpenCV squares it
-    hipLaunchKernelGGL(lk_track_kernel, dim3(n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status, 0.f, 0.f, 0);
+    const bool ordered = order_scratch && n_max <= 1024;          // position-sorted points, XCD-aware (lk_order_kernel)
+    if (ordered) hipLaunchKernelGGL(lk_order_kernel, dim3(1), dim3(1024), 0, s, pts_a, n_dev, n_max, order_scratch);
+    hipLaunchKernelGGL(lk_track_kernel, dim3(ordered ? (n_max + 7) & ~7 : n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status, 0.f, 0.f, 0,
+                       ordered ? order_scratch : nullptr);
 }
 void dv_launch_lk_track_offset(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back,
                                float dist_thresh, float add_x, float add_y, float2* pts_b, uint8_t* status, hipStream_t s) {
     if (n_max <= 0) return;
     const double eps = 0.01;
-    hipLaunchKernelGGL(lk_track_kernel, dim3(n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status, add_x, add_y, 1);
+    hipLaunchKernelGGL(lk_track_kernel, dim3(n_max), dim3(64), 0, s, A, B, pts_a, n_dev, n_max, flow_back, dist_thresh, eps * eps, pts_b, status, add_x, add_y, 1, nullptr);
 }
 void dv_launch_lk_track_multi(const DvLkJob* jobs_dev, int n_jobs, int n_max, int flow_back, float dist_thresh, hipStream_t s) {
     if (n_jobs <= 0 || n_max <= 0) return;

@@ -101,21 +101,34 @@ __device__ __forceinline__ void pyr_down_tile(const uint8_t* __restrict__ src, i
 __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src0, const uint8_t* __restrict__ src1,
                                                        int sw, int sh, int spitch,
                                                        uint8_t* __restrict__ dst0, uint8_t* __restrict__ dst1, int dw, int dh, int dpitch,
-                                                       uint8_t* __restrict__ copy0, uint8_t* __restrict__ copy1, int cpitch, int rn_even) {
-    pyr_down_tile(blockIdx.z ? src1 : src0, sw, sh, spitch, blockIdx.z ? dst1 : dst0, dw, dh, dpitch, blockIdx.z ? copy1 : copy0, cpitch, blockIdx.x, blockIdx.y, rn_even);
+                                                       uint8_t* __restrict__ copy0, uint8_t* __restrict__ copy1, int cpitch, int rn_even, int tx_n, int ty_n, int n_img) {
+    // XCD-aware tile order (round 5).  Workgroups are dealt to the 8 XCDs round robin by their flat index, so with tile = block the horizontal neighbours of a tile — which
+    // share its source lines: a 132-byte tile row straddles two or three 128-byte lines — sat on eight different L2s and every line was fetched from HBM up to three times
+    // (PMC: 4.3 MB per launch for 1.6 MB).  Here XCD x takes a CONTIGUOUS range of the row-major tile order (image, tile row, tile column): neighbours meet in one L2.
+    // The grid is one-dimensional and padded to a multiple of 8 (8 * per blocks): flat index f -> tile (f & 7) * per + (f >> 3) is then one-to-one onto [0, 8 per).
+    const int total = tx_n * ty_n * n_img, flat = blockIdx.x, per = (int)gridDim.x >> 3;
+    const int L = (flat & 7) * per + (flat >> 3);
+    if (L >= total) return;
+    const int img = L / (tx_n * ty_n), rem = L - img * tx_n * ty_n, ty = rem / tx_n, tx = rem - ty * tx_n;
+    pyr_down_tile(img ? src1 : src0, sw, sh, spitch, img ? dst1 : dst0, dw, dh, dpitch, img ? copy1 : copy0, cpitch, tx, ty, rn_even);
 }
 // the same level step for several independent image pairs in ONE launch (the per-object ROI pyramids of dynamic mode: blockIdx.z = 2 * job + image); the grid
 // covers the largest job, tiles outside a smaller one end at once
-__global__ __launch_bounds__(256) void pyr_down_multi_kernel(const DvPyrJob* __restrict__ jobs) {
-    const DvPyrJob j = jobs[blockIdx.z >> 1];
-    if ((int)blockIdx.x * PT_W >= j.dw || (int)blockIdx.y * PT_H >= j.dh) return;
-    const int img = blockIdx.z & 1;
+__global__ __launch_bounds__(256) void pyr_down_multi_kernel(const DvPyrJob* __restrict__ jobs, int tx_n, int ty_n, int n_z) {
+    // the XCD-aware tile order of pyr_down_kernel over (plane z = 2 * job + image, tile row, tile column): one-dimensional grid padded to a multiple of 8
+    const int total = tx_n * ty_n * n_z, per = (int)gridDim.x >> 3, L = ((int)blockIdx.x & 7) * per + ((int)blockIdx.x >> 3);
+    if (L >= total) return;
+    const int z = L / (tx_n * ty_n), rem = L - z * tx_n * ty_n, ty = rem / tx_n, tx = rem - ty * tx_n;
+    const DvPyrJob j = jobs[z >> 1];
+    if (tx * PT_W >= j.dw || ty * PT_H >= j.dh) return;
+    const int img = z & 1;
     if (img && !j.src1) return;
-    pyr_down_tile(img ? j.src1 : j.src0, j.sw, j.sh, j.spitch, img ? j.dst1 : j.dst0, j.dw, j.dh, j.dpitch, img ? j.cpy1 : j.cpy0, j.cpitch, blockIdx.x, blockIdx.y);
+    pyr_down_tile(img ? j.src1 : j.src0, j.sw, j.sh, j.spitch, img ? j.dst1 : j.dst0, j.dw, j.dh, j.dpitch, img ? j.cpy1 : j.cpy0, j.cpitch, tx, ty);
 }
 void dv_launch_pyr_down_multi(const DvPyrJob* jobs_dev, int n_jobs, int max_dw, int max_dh, hipStream_t s) {
     if (n_jobs <= 0) return;
-    hipLaunchKernelGGL(pyr_down_multi_kernel, dim3((max_dw + PT_W - 1) / PT_W, (max_dh + PT_H - 1) / PT_H, 2 * n_jobs), dim3(256), 0, s, jobs_dev);
+    const int tx_n = (max_dw + PT_W - 1) / PT_W, ty_n = (max_dh + PT_H - 1) / PT_H, n_z = 2 * n_jobs, per = (tx_n * ty_n * n_z + 7) / 8;
+    hipLaunchKernelGGL(pyr_down_multi_kernel, dim3(8 * per), dim3(256), 0, s, jobs_dev, tx_n, ty_n, n_z);
 }
 
 // BORDER_REFLECT_101 apron of every level of one or two pyramids in ONE launch (blockIdx.y = level, blockIdx.z = image): with it no LK tile touches the
@@ -165,8 +178,8 @@ void dv_launch_pyr_apron(const DvPyr& a, const DvPyr* b, hipStream_t s) {
 void dv_launch_pyr_down2(const uint8_t* src0, const uint8_t* src1, int sw, int sh, int spitch, uint8_t* dst0, uint8_t* dst1,
                          int dpitch, uint8_t* copy0, uint8_t* copy1, int cpitch, hipStream_t s, int rn_even) {
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    dim3 grid((dw + PT_W - 1) / PT_W, (dh + PT_H - 1) / PT_H, src1 ? 2 : 1);
-    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src0, src1, sw, sh, spitch, dst0, dst1, dw, dh, dpitch, copy0, copy1, cpitch, rn_even);
+    const int tx_n = (dw + PT_W - 1) / PT_W, ty_n = (dh + PT_H - 1) / PT_H, n_img = src1 ? 2 : 1, per = (tx_n * ty_n * n_img + 7) / 8;
+    hipLaunchKernelGGL(pyr_down_kernel, dim3(8 * per), dim3(256), 0, s, src0, src1, sw, sh, spitch, dst0, dst1, dw, dh, dpitch, copy0, copy1, cpitch, rn_even, tx_n, ty_n, n_img);
 }
 
 

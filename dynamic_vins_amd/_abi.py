@@ -98,6 +98,7 @@ SIGNATURES = {
     "dv_undistort_lines": (C.c_int, [_ctx, C.POINTER(dv_cam), C.c_void_p, C.c_int, C.c_void_p]),
     "dv_est_change_sensor_type": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "dv_est_get_latest": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dv_est_get_extrinsics": (C.c_int, [_ctx, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dv_est_get_landmarks": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_inst_config": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int]),
     "dv_inst_reset": (C.c_int, [_ctx]),

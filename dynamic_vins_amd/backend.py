@@ -33,7 +33,7 @@ class dv_ba_prior(C.Structure):
 
 class dv_ba_problem(C.Structure):
     _fields_ = [("nframes", C.c_int32), ("nlm", C.c_int32), ("nfac", C.c_int32), ("nimu", C.c_int32),
-                ("use_imu", C.c_int32), ("plane_kind", C.c_int32), ("max_iters", C.c_int32), ("reserved", C.c_int32),
+                ("use_imu", C.c_int32), ("plane_kind", C.c_int32), ("max_iters", C.c_int32), ("free_blocks", C.c_int32),
                 ("g_norm", C.c_double),
                 ("pose", C.c_void_p), ("speed_bias", C.c_void_p), ("ex_pose", C.c_void_p), ("td", C.c_void_p), ("inv_depth", C.c_void_p),
                 ("factors", C.c_void_p), ("landmarks", C.c_void_p), ("imu", C.c_void_p),
@@ -52,7 +52,7 @@ class WindowProblem:
     The struct layout is shared by the oracle's dvo_ba_problem, so the same object drives both."""
 
     def __init__(self, pose, speed_bias, ex_pose, td, inv_depth, factors, landmarks, imu, use_imu=1, plane_kind=0, max_iters=8,
-                 g_norm=9.81, prior=None, prior_A=None, prior_b=None):
+                 g_norm=9.81, prior=None, prior_A=None, prior_b=None, free_blocks=0):
         self.pose = np.ascontiguousarray(pose, np.float64).copy()
         self.speed_bias = np.ascontiguousarray(speed_bias, np.float64).copy()
         self.ex_pose = np.ascontiguousarray(ex_pose, np.float64).copy()
@@ -68,6 +68,7 @@ class WindowProblem:
         p = dv_ba_problem()
         p.nframes, p.nlm, p.nfac, p.nimu = len(self.pose), len(self.landmarks), len(self.factors), len(self.imu)
         p.use_imu, p.plane_kind, p.max_iters, p.g_norm = use_imu, plane_kind, max_iters, g_norm
+        p.free_blocks = free_blocks          # bit 0: para_ex_pose free (estimate_extrinsic), bit 1: para_td free (estimate_td)
         self.c = p
         self._bind()
 
@@ -85,7 +86,7 @@ class WindowProblem:
 
     def clone(self):
         q = WindowProblem(self.pose, self.speed_bias, self.ex_pose, self.td[0], self.inv_depth, self.factors, self.landmarks, self.imu,
-                          self.c.use_imu, self.c.plane_kind, self.c.max_iters, self.c.g_norm, self.prior, self.prior_A, self.prior_b)
+                          self.c.use_imu, self.c.plane_kind, self.c.max_iters, self.c.g_norm, self.prior, self.prior_A, self.prior_b, self.c.free_blocks)
         return q
 
 
@@ -296,7 +297,7 @@ class dv_est_config(C.Structure):
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),
                 ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
                 ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2),
-                ("dynamic", C.c_int32), ("use_det3d", C.c_int32), ("instance_init_min_num", C.c_int32), ("pad_", C.c_int32), ("static_inst_threshold", C.c_double),
+                ("dynamic", C.c_int32), ("use_det3d", C.c_int32), ("instance_init_min_num", C.c_int32), ("estimate", C.c_int32), ("static_inst_threshold", C.c_double),
                 ("use_line", C.c_int32), ("line_min_obs", C.c_int32), ("line_sqrt_info", C.c_double * 4)]
 
 
@@ -312,9 +313,10 @@ class Estimator:
 
     def __init__(self, ctx, use_imu=1, stereo=1, plane_constraint=0, max_iters=8, keyframe_parallax=10.0, init_depth=5.0, g_norm=9.81, td=0.0,
                  acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None, dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0,
-                 use_line=0, line_min_obs=5, line_sqrt_info=(0.0, 0.0, 0.0, 0.0)):
+                 use_line=0, line_min_obs=5, line_sqrt_info=(0.0, 0.0, 0.0, 0.0), estimate=0):
         self.ctx = ctx
         c = dv_est_config()
+        c.estimate = estimate          # bit 0: estimate_extrinsic 1, bit 1: estimate_td 1
         c.use_imu, c.stereo, c.plane_constraint, c.max_iters = use_imu, stereo, plane_constraint, max_iters
         c.keyframe_parallax, c.init_depth, c.g_norm, c.td = keyframe_parallax, init_depth, g_norm, td
         c.acc_n, c.gyr_n, c.acc_w, c.gyr_w = acc_n, gyr_n, acc_w, gyr_w
@@ -335,6 +337,12 @@ class Estimator:
         if rc < 0:
             raise DvinsError(self.ctx.lib.dv_last_error(self.ctx.h).decode())
         return rc
+
+    def extrinsics(self):
+        """(ric[2, 3, 3], tic[2, 3], td) as the last solve left them"""
+        ric, tic, td = np.zeros(18), np.zeros(6), C.c_double(0)
+        self._check(self.ctx.lib.dv_est_get_extrinsics(self.ctx.h, ric.ctypes.data, tic.ctypes.data, C.addressof(td)))
+        return ric.reshape(2, 3, 3), tic.reshape(2, 3), td.value
 
     def InputIMU(self, t, acc, gyr):
         a = np.ascontiguousarray(acc, np.float64)

@@ -274,10 +274,12 @@ static int be_enqueue_slots(dv_ctx* ctx, BePending& pd, int slots, bool speculat
     auto eval = [&](int mode) {
         if (kt) { StageScope k(ctx, mode == BE_EVAL_CAND_COST ? "k_be_eval_cost" : "k_be_eval_full", s); be_launch_eval(pd.ea, mode, s); }
         else be_launch_eval(pd.ea, mode, s);
+        be_launch_eval_ext(pd.ea, pd.xt, mode, s);      // (free extrinsic / td blocks only)
     };
     auto reduce = [&](int spec) {
         if (kt) { StageScope k(ctx, "k_be_reduce", s); be_launch_reduce(pd.sa, spec, s); }
         else be_launch_reduce(pd.sa, spec, s);
+        be_launch_reduce_ext(pd.sa, spec, s);
     };
     auto solve = [&](int spec) {
         if (kt) { StageScope k(ctx, "k_be_solve", s); return be_launch_solve(pd.sa, spec, s); }
@@ -411,6 +413,14 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
         if (!pose_const) { d.pose_col[f] = col; for (int k = 0; k < 6; ++k) { col_kind[col] = 0; col_frame[col] = f; col_comp[col] = k; ++col; } }
         if (P->use_imu) { d.sb_col[f] = col; for (int k = 0; k < 9; ++k) { col_kind[col] = 1; col_frame[col] = f; col_comp[col] = k; ++col; } }
     }
+    // free extrinsic / td blocks (estimator.cpp:87-100; dv_ba_problem::free_blocks): their columns follow the frames' (ceres' reduced program keeps the insertion order of
+    // AddBodyParameterBlock: poses and speed-biases, the extrinsics, td); ext entry q = 0..5 ex0, 6..11 ex1, 12 td
+    BeExt xt{};
+    for (int q = 0; q <= BE_NX; ++q) xt.xcol[q] = -1;
+    if (P->free_blocks & ~3) DV_FAIL("dv_ba_solve: unknown bits in free_blocks");
+    if (P->free_blocks & 1) for (int cidx = 0; cidx < 2; ++cidx) for (int k = 0; k < 6; ++k) { xt.xcol[6 * cidx + k] = col; col_kind[col] = 2; col_frame[col] = 100 + cidx; col_comp[col] = k; ++col; }
+    if (P->free_blocks & 2) { xt.xcol[12] = col; col_kind[col] = 3; col_frame[col] = 102; col_comp[col] = 0; ++col; }
+    xt.on = (P->free_blocks & 3) ? 1 : 0;
     d.nstate = col;
     d.pad = 0;
     const bool has_prior = P->prior && P->prior->valid;
@@ -429,6 +439,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
             const BePriorBlock pb = ph.blocks[b];
             int c0 = -1;
             if (pb.type == 0) c0 = d.pose_col[pb.idx]; else if (pb.type == 1) c0 = d.sb_col[pb.idx];
+            else if (pb.type == 2) c0 = xt.xcol[6 * pb.idx]; else if (pb.type == 3) c0 = xt.xcol[12];
             if (c0 >= 0) for (int k = 0; k < pb.size_local; ++k) prior_col[c0 + k] = pb.off + k;
         }
     }
@@ -480,6 +491,13 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     ea.ctl = w.ctl; ea.x = w.x; ea.cand = w.cand; ea.fac = w.fac; ea.lm = w.lm; ea.imu = w.imu; ea.prior = w.prior; ea.priorA = w.priorA; ea.priorb = w.priorb;
     ea.dims = d; ea.g_norm = P->g_norm; ea.cand_cost = w.cand_cost; ea.lm_obs = w.lm_obs; ea.prior_c0 = w.prior_c0 + w.prior_cur;
     ea.lm_lo = 0; ea.lm_hi = P->nlm;
+    if (P->free_blocks & 3) {
+        if (ctx->dist.transport != 0) DV_FAIL("dv_ba_solve: free extrinsic / td blocks are not built for the landmark-sharded window");
+        if (xt.on) {
+            DV_CHECK(w.xpk_buf.ensure(2 * 8 * (size_t)BX_SIZE * BE_PK_STRIDE));
+            xt.xpk[0] = (double*)w.xpk_buf.p; xt.xpk[1] = xt.xpk[0] + (size_t)BX_SIZE * BE_PK_STRIDE;
+        }
+    }
     BeShard sh{};
     if (ctx->dist.transport != 0) {        // landmark-sharded window: contiguous ranges of cap = ceil(nlm / world) landmarks
         const DvDist& dd = ctx->dist;
@@ -498,10 +516,10 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     for (int k = 0; k < 2; ++k) { sa.packets[k] = w.packets[k]; sa.imu_out[k] = w.imu_out[k]; sa.prior_out[k] = w.prior_out[k]; sa.Hd[k] = w.Hd[k]; sa.Sc[k] = w.Sc[k]; sa.gvec[k] = w.gvec[k]; }
     sa.scale_p = w.scale_p; sa.diag_p = w.diag_p; sa.grad_p = w.grad_p; sa.gn_p = w.gn_p; sa.scale_l = w.scale_l; sa.diag_l = w.diag_l; sa.grad_l = w.grad_l; sa.gn_l = w.gn_l;
     sa.prior_col = w.prior_col; sa.col_kind = w.col_kind; sa.col_frame = w.col_frame; sa.col_comp = w.col_comp;
-    sa.xnorm2_extra = P->x_norm2_extra; sa.sh = sh;
+    sa.xnorm2_extra = P->x_norm2_extra; sa.sh = sh; sa.xt = xt;
     // the 16-wide MFMA factorisation (be_solve.hip MF16) wherever the system fits its tile budget (n <= 175: every window the estimator builds); "ldl_generic" selects the 4-wide panel form
     sa.ldl_mf16 = 0;
-    if (!w.ldl_generic) {
+    if (!w.ldl_generic && !(P->free_blocks & 3)) {      // (free extrinsic / td blocks: the generic form carries the ext entries)
         uint8_t plan[64];
         if (be_mf16_plan(d.nstate, plan)) { std::memcpy(sa.ldl_col0, plan, sizeof(plan)); sa.ldl_mf16 = 1; }
     }
@@ -514,15 +532,17 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
         BeRejectArgs& r = pd.rej;
         r.st = w.cand; r.fac = w.fac; r.lm = w.lm; r.nlm = P->nlm; r.nframes = P->nframes; r.focal = fused->rej_focal; r.flags = w.rej_pinned;
         std::memcpy(r.ric, fused->rej_ric, sizeof(r.ric)); std::memcpy(r.tic, fused->rej_tic, sizeof(r.tic));
+        r.ex_from_state = (P->free_blocks & 1) ? 1 : 0; r.pad = 0;
         pd.rej_on = true;
     }
+    pd.xt = xt; pd.copy_ex_td = (P->free_blocks & 3) != 0;
     pd.ea = ea; pd.sa = sa; pd.fused_present = fused != nullptr; pd.fuse_accept_gauge = fused != nullptr && !ctx->batch && !sh.on /* sharded: the last accept decision must stand before the gather of the inverse depths */; pd.max_iters = P->max_iters; pd.g_norm = P->g_norm; pd.nframes = P->nframes; pd.use_imu = P->use_imu; pd.nlm = P->nlm;
     pd.want_raw_pose = fused && fused->want_raw_pose;
     if (fused) { std::memcpy(pd.gauge_R0, fused->R0, sizeof(pd.gauge_R0)); std::memcpy(pd.gauge_ypr0, fused->ypr0, sizeof(pd.gauge_ypr0)); std::memcpy(pd.gauge_P0, fused->P0, sizeof(pd.gauge_P0)); }
     pd.do_marg = do_marg; pd.state_bytes = state_bytes; pd.nxt = 1 - w.prior_cur;
     if (eval_only) {        // dv_ba_eval: one evaluation + assembly of the reduced camera system at the given states (mu = 0)
-        be_launch_eval(ea, BE_EVAL_X, s);
-        be_launch_reduce(sa, 0, s);
+        be_launch_eval(ea, BE_EVAL_X, s); be_launch_eval_ext(ea, xt, BE_EVAL_X, s);
+        be_launch_reduce(sa, 0, s); be_launch_reduce_ext(sa, 0, s);
         if (sh.on) { if (be_exchange(ctx, (size_t)sh.len, s)) return -1; be_launch_shard_finalize(sa, 0, s); }
         DV_CHECK(hipGetLastError());
         return 0;
@@ -600,6 +620,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
     }
     for (int f = 0; f < P->nframes; ++f) { std::memcpy(P->pose + 7 * f, hx->pose[f], 56); if (P->use_imu) std::memcpy(P->speed_bias + 9 * f, hx->sb[f], 72); }
     if (P->nlm) std::memcpy(P->inv_depth, hx->inv_depth, 8 * (size_t)P->nlm);
+    if (pd.copy_ex_td) { std::memcpy(P->ex_pose, hx->ex, 14 * 8); P->td[0] = hx->td; }      // free blocks: para_ex_pose / para_td as the solve left them
     if (w.debug_hash_log && fused && w.dbg_pinned) {      // what the device holds when the round is over: x (raw solution), the candidate buffer (gauge-fixed copy), the control block
         be_dbg_hash(w.x, pd.state_bytes & ~(size_t)7, w.dbg_pinned + 3, s);
         be_dbg_hash(w.cand, pd.state_bytes & ~(size_t)7, w.dbg_pinned + 4, s);

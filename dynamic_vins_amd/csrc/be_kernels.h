@@ -33,6 +33,22 @@
 #define BE_QF_LEN (BE_QF_A + 16)
 struct BeShard { int32_t on, rank, world, lo, hi, cap, len, pad; double* xsend; const double* xrecv; double* qf[2]; };
 
+// Free extrinsic / td blocks in the window solve (estimate_extrinsic 1, estimate_td 1: Estimator::AddBodyParameterBlock, estimator.cpp:87-100 — para_ex_pose[0..1] stay
+// variable once openExEstimation is set, para_td while |Vs[0]| >= 0.2).  No shipped YAML switches them on, so they live BESIDE the default path instead of inside it: the
+// packets, be_eval, be_reduce and the MF16 solve are untouched (same bits, same speed); with a free block the solve takes the generic factorisation (n up to 178) and two
+// more launches per linearisation fill the 13 extra columns of the reduced system:
+//   be_eval_ext    per landmark: the factors again WITH their extrinsic / td Jacobians (proj_factor<true, true>) -> one "ext packet" per landmark, transposed like the packets:
+//                  ux[13] = J_x^T J_l | gx[13] = J_x^T r | XX[13][13] = J_x^T J_x | XP[13][66] = J_x^T J_pose      (x = ex0 (6), ex1 (6), td (1): local index q)
+//   be_reduce_ext  behind be_reduce (which has written the prior's part of every non pose x pose entry): adds the landmark sums into rows / columns xcol[q] of Hd, Sc, gvec
+// be_solve (generic form only) carries the 13 extra entries through every product with the landmarks' coupling rows and forms the candidate's ex / td blocks.
+#define BE_NX 13
+#define BX_W 0
+#define BX_G 13
+#define BX_XX 26
+#define BX_XP 195
+#define BX_SIZE 1056              // 1053 used
+struct BeExt { int32_t on, pad; int32_t xcol[BE_NX + 1]; double* xpk[2]; };      // xcol[q]: column of ext entry q in the reduced system, -1 = that block is constant
+
 struct BeEvalArgs {
     const BeCtl* ctl;
     const BeState* x; const BeState* cand;
@@ -66,6 +82,7 @@ struct BeSolveArgs {
     uint8_t ldl_col0[64]; int32_t ldl_mf16, ldl_pad;      // ldl_mf16 != 0: the 16-wide MFMA factorisation, its tile plan (be_mf16_plan, [16 waves][4 slots]) in ldl_col0; 0: the generic 4-wide panel form
     BeShard sh;             // landmark sharding (on = 0: the whole window lives here)
     double xnorm2_extra;    // squared norm of inert free blocks (line blocks under zero sqrt_info) that count in the parameter-tolerance test
+    BeExt xt;               // free extrinsic / td blocks (on = 0: constant, the default)
 };
 
 struct BeMargArgs {
@@ -103,7 +120,7 @@ struct BeGaugeArgs {
 // OutliersRejection (vio_util.cpp:381-430) on the device, behind the gauge fix: mean reprojection error of every landmark of the problem over its residual blocks at
 // the gauge-fixed states; flag[l] = 1 if it exceeds 3 px (x focal).  The same expressions in the same order as the estimator's host loop (est_host.hip
 // reject_outliers): bit-identical decisions.  ric / tic: the camera extrinsics as the host will hold them after Double2vector.
-struct BeRejectArgs { const BeState* st; const BeFactor* fac; const BeLm* lm; int nlm, nframes; double ric[2][9], tic[2][3], focal; uint8_t* flags; };
+struct BeRejectArgs { const BeState* st; const BeFactor* fac; const BeLm* lm; int nlm, nframes; double ric[2][9], tic[2][3], focal; uint8_t* flags; int ex_from_state, pad; };      // ex_from_state: free extrinsics — ric / tic are the SOLVED blocks of st (what Double2vector hands the host), not the arguments
 void be_launch_reject(const BeRejectArgs& a, hipStream_t s);
 
 #if defined(__HIPCC__)
@@ -215,6 +232,8 @@ static_assert(offsetof(BeSolveArgs, ldl_col0) % 4 == 0, "the MF16 plan is read a
 bool be_mf16_plan(int n, uint8_t* plan, bool check_solve_lds = true);      // false: the tiles of an n x n system (+ right-hand-side row) do not fit (n > 175): the generic form is used
 int  be_launch_solve(const BeSolveArgs& a, int spec, hipStream_t s);        // spec: decide on the pending candidate first (be_accept_kernel's rule)
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s);
+void be_launch_eval_ext(const BeEvalArgs& a, const BeExt& xt, int mode, hipStream_t s);      // behind be_launch_eval (full modes only)
+void be_launch_reduce_ext(const BeSolveArgs& a, int spec, hipStream_t s);                    // behind be_launch_reduce
 // batched forms: n_win independent windows per launch (argument tables in HBM, window index in the grid); be_api.hip enqueues them for a dv_batch
 void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s);
 void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s);

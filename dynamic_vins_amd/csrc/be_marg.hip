@@ -777,8 +777,13 @@ __device__ __forceinline__ void be_reject_body(const BeRejectArgs& a, const int 
         const m33 R = qR(qnormalized(mkq(p[6], p[3], p[4], p[5])));
         Rs[tid] = R; RsT[tid] = tr(R); Ps[tid] = mk3(p[0], p[1], p[2]);
     }
+    if (a.ex_from_state) {      // free extrinsic blocks: arrays_to_states on the solved para_ex_pose
+        if (tid == 32) { const double* p = a.st->ex[0]; ric0 = qR(qnormalized(mkq(p[6], p[3], p[4], p[5]))); }
+        if (tid == 33 || tid == 34) { const int c = tid - 33; const double* p = a.st->ex[c]; ricT[c] = tr(qR(qnormalized(mkq(p[6], p[3], p[4], p[5])))); tic[c] = mk3(p[0], p[1], p[2]); }
+    } else {
     if (tid == 32) { for (int k = 0; k < 9; ++k) ric0.m[k] = a.ric[0][k]; }
     if (tid == 33 || tid == 34) { const int c = tid - 33; m33 r; for (int k = 0; k < 9; ++k) r.m[k] = a.ric[c][k]; ricT[c] = tr(r); tic[c] = mk3(a.tic[c][0], a.tic[c][1], a.tic[c][2]); }
+    }
     __syncthreads();
     if (l >= a.nlm) return;
     const BeLm L = a.lm[l];

@@ -83,6 +83,7 @@ struct BePending {        // a solve that has been enqueued and not yet collecte
     hipEvent_t ev_state_ext = nullptr;   // member of a dv_batch round with shared tail launches: the batch's event replaces BeWork::ev_state for this frame
     bool fuse_accept_gauge = false;      // estimator path outside a dv_batch: the last slot's accept decision rides in the gauge kernel (be_accept_gauge_kernel)
     bool active = false, trivial = false, do_marg = false, fused_present = false, marg_in_flight = false, marg_check_due = false; int scal_slot = 0, check_slot = 0; size_t state_bytes = 0; int nxt = 0; MargPlan pl;
+    BeExt xt{}; bool copy_ex_td = false;      // free extrinsic / td blocks of this solve (be_kernels.h); copy_ex_td: hand the solved blocks back through dv_ba_problem::ex_pose / td
     BeEvalArgs ea; BeSolveArgs sa; int max_iters = 0, nframes = 0, use_imu = 0, nlm = 0; double g_norm = 0, gauge_R0[9], gauge_ypr0[3], gauge_P0[3];
     std::chrono::steady_clock::time_point t_begin, t_up, t_enq;
 };
@@ -100,6 +101,7 @@ struct BeWork {
     int32_t* prior_col = nullptr; int32_t* col_kind = nullptr; int32_t* col_frame = nullptr; int32_t* col_comp = nullptr;
     int fac_cap = 0;
     DevBuf marg_buf;       // per-landmark slabs of the marginalization (sized on demand)
+    DevBuf xpk_buf;        // ext packets of both linearisation sets (free extrinsic / td blocks, be_ext.hip): allocated by the first solve that frees one
     void* pinned = nullptr; size_t pinned_bytes = 0;      // host staging: mirror of the device's upload region + download area
     size_t up_ctl = 0, up_x = 0, up_imu = 0, up_prior = 0, up_idx = 0, up_mt = 0, up_lm = 0, up_fac = 0, dl_off = 0;
     double* priorA_buf[2] = { nullptr, nullptr }; double* priorb_buf[2] = { nullptr, nullptr }; int prior_cur = 0;      // double-buffered prior (A', b')

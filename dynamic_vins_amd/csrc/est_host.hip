@@ -174,6 +174,7 @@ struct dv_estimator {
     std::vector<double> dt_buf[kWin + 1]; std::vector<d3> la_buf[kWin + 1], av_buf[kWin + 1];
     std::vector<std::shared_ptr<Preint>> frame_pre;        // all_image_frame pre-integrations (initialisation only)
     bool nonlinear = false, margin_old = true;
+    bool open_ex = false;          // Estimator::openExEstimation (estimator.h:173): sticky until ClearState (estimator.cpp:632)
     dv_ba_prior prior{}; const double* prior_dev_A = nullptr; const double* prior_dev_b = nullptr;      // header on the host, A' / b' device-resident
     m33 back_R0; d3 back_P0;
     dv_ba_summary last{};
@@ -210,7 +211,7 @@ struct dv_estimator {
         for (int i = 0; i <= kWin; ++i) { Rs[i] = eye3(); Ps[i] = Vs[i] = Bas[i] = Bgs[i] = mk3(0, 0, 0); pre[i].reset(); dt_buf[i].clear(); la_buf[i].clear(); av_buf[i].clear(); headers[i] = 0; }
         lms.clear(); lm_index.clear(); imu_buf.clear(); frame_pre.clear(); tmp_pre.reset();
         prior = dv_ba_prior{}; prior_dev_A = prior_dev_b = nullptr;
-        prev_time = -1; cur_time = 0; first_imu = false; init_pose = false; frame = 0; nonlinear = false; acc_0 = gyr_0 = mk3(0, 0, 0);
+        prev_time = -1; cur_time = 0; first_imu = false; init_pose = false; frame = 0; nonlinear = false; open_ex = false; acc_0 = gyr_0 = mk3(0, 0, 0);
         for (int k = 0; k < 2; ++k) { for (int i = 0; i < 9; ++i) ric[k].m[i] = cfg.ric[k][i]; tic[k] = mk3(cfg.tic[k][0], cfg.tic[k][1], cfg.tic[k][2]); }
         td = cfg.td; g = mk3(0, 0, cfg.g_norm);
         lines.clear(); lines.min_obs = cfg.line_min_obs > 0 ? cfg.line_min_obs : 5; pending_lines.clear(); para_line.clear(); line_last = dv_ba_summary{};
@@ -450,6 +451,11 @@ struct dv_estimator {
           if (cfg.use_imu) for (int i = 0; i < frame; ++i) { if (pre[i + 1]->sum_dt > 10.0) continue; dv_ba_imu r; pre[i + 1]->fill(r, i, i + 1); imu.push_back(r); ctx->be.sqrt_hint.push_back(pre[i + 1]->sqrt_info()); }
           prior_dev_A = prior.valid ? ctx->be.priorA_buf[ctx->be.prior_cur] : nullptr; prior_dev_b = prior.valid ? ctx->be.priorb_buf[ctx->be.prior_cur] : nullptr;
           P = make_problem(frame + 1);
+          {   // AddBodyParameterBlock (estimator.cpp:87-100): which of para_ex_pose / para_td this solve may move
+              const double v0 = norm(Vs[0]);
+              if (((cfg.estimate & 1) && frame == kWin && v0 > 0.2) || open_ex) { open_ex = true; P.free_blocks |= 1; }
+              if ((cfg.estimate & 2) && !(v0 < 0.2)) P.free_blocks |= 2;
+          }
           if (cfg.use_line) {          // Vector2double's line part + AddLineResidualBlock under zero weights: the blocks only count in |x| (see dv_ba_problem::x_norm2_extra)
               lines.get_orth(Rs, Ps, ric[0], tic[0], para_line);
               double sq = 0; for (double v : para_line) sq += v * v;
@@ -722,6 +728,7 @@ int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg) {
     if (!ctx) return -1;
     if (!cfg) DV_FAIL("dv_est_create: null config");
     if (!cfg->stereo) DV_FAIL("dv_est_create: monocular initialisation is out of scope (every BASELINE config is stereo)");
+    if (cfg->estimate & ~3) DV_FAIL("dv_est_create: estimate: bit 0 estimate_extrinsic 1, bit 1 estimate_td 1 (estimate_extrinsic 2, the from-scratch calibration, is not built)");
     delete ctx->est;
     ctx->est = new dv_estimator(*cfg);
     return 0;
@@ -795,6 +802,18 @@ int dv_est_get_latest(dv_ctx* ctx, double* t, double* P3o, double* Q4o, double* 
     if (P3o) { P3o[0] = E.latest_P.x; P3o[1] = E.latest_P.y; P3o[2] = E.latest_P.z; }
     if (Q4o) { Q4o[0] = q.x; Q4o[1] = q.y; Q4o[2] = q.z; Q4o[3] = q.w; }
     if (V3o) { V3o[0] = E.latest_V.x; V3o[1] = E.latest_V.y; V3o[2] = E.latest_V.z; }
+    return 0;
+}
+// body.ric / body.tic / body.td as Double2vector left them (what pubOdometry writes to the extrinsic file when estimate_extrinsic is on, utils/io/visualization.cpp:94-118)
+int dv_est_get_extrinsics(dv_ctx* ctx, double* ric18, double* tic6, double* td) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_get_extrinsics: call dv_est_create first");
+    const dv_estimator& E = *ctx->est;
+    for (int c = 0; c < 2; ++c) {
+        if (ric18) std::memcpy(ric18 + 9 * c, E.ric[c].m, 72);
+        if (tic6) { tic6[3 * c] = E.tic[c].x; tic6[3 * c + 1] = E.tic[c].y; tic6[3 * c + 2] = E.tic[c].z; }
+    }
+    if (td) *td = E.td;
     return 0;
 }
 // feat_manager.point_landmarks as the point-cloud publishers read them (utils/io/visualization.cpp:214-249)

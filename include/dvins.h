@@ -183,12 +183,16 @@ typedef struct dv_ba_prior {
 
 typedef struct dv_ba_problem {
     int32_t nframes, nlm, nfac, nimu;     /* frames in the window (frame+1), landmarks, residual blocks, IMU factors */
-    int32_t use_imu, plane_kind /* 0 none, 1 PoseConstraint with IMU (dz=0), 2 vision-only (dy=0) */, max_iters, reserved;
+    int32_t use_imu, plane_kind /* 0 none, 1 PoseConstraint with IMU (dz=0), 2 vision-only (dy=0) */, max_iters;
+    int32_t free_blocks; /* bit 0: para_ex_pose[0..1] are NOT SetParameterBlockConstant (estimate_extrinsic 1 once openExEstimation is set), bit 1: para_td is not
+                            (estimate_td 1 while |Vs[0]| >= 0.2) — Estimator::AddBodyParameterBlock, estimator/estimator.cpp:87-100.  0 in every shipped configuration.
+                            Their columns follow the frames' in the reduced system (6 + 6 + 1); such a solve takes the generic factorisation and two more launches
+                            per linearisation (csrc/be_ext.hip); not available on a landmark-sharded window */
     double g_norm;
     double* pose;        /* [nframes][7] x y z qx qy qz qw   (para_pose, in/out) */
     double* speed_bias;  /* [nframes][9]                      (para_speed_bias, in/out; ignored if !use_imu) */
-    double* ex_pose;     /* [2][7]                            (para_ex_pose, constant: estimate_extrinsic 0) */
-    double* td;          /* [1]                               (para_td, constant: estimate_td 0) */
+    double* ex_pose;     /* [2][7]                            (para_ex_pose; in/out when free_blocks bit 0 is set, else constant) */
+    double* td;          /* [1]                               (para_td; in/out when free_blocks bit 1 is set, else constant) */
     double* inv_depth;   /* [nlm]                             (para_point_features, in/out) */
     const dv_ba_factor* factors; const dv_ba_lm* landmarks; const dv_ba_imu* imu;
     const dv_ba_prior* prior; const double* prior_A; const double* prior_b;     /* prior may be NULL */
@@ -208,7 +212,8 @@ int dv_ba_solve(dv_ctx* ctx, dv_ba_problem* problem, dv_ba_summary* summary);
 
 /* One evaluation at the given states (what one ceres Evaluate() pass + the Schur elimination produce): total cost, the reduced
  * camera system S = H_pp - sum_l w_l w_l^T / h_l (n x n, row-major, symmetric) and its right-hand side g = g_p - sum_l w_l g_l / h_l.
- * Column order: per frame, 6 pose columns (if the pose is free) then 9 speed-bias columns (if use_imu); *n = their count.
+ * Column order: per frame, 6 pose columns (if the pose is free) then 9 speed-bias columns (if use_imu); then, if free (free_blocks), 6 + 6 extrinsic columns and the td
+ * column; *n = their count (<= 178).
  * The sum over landmarks, IMU factors and the prior is linear, so a window sharded BY LANDMARK over several GPUs (IMU factors
  * and prior on one rank) is assembled by adding the per-rank [S | g | cost] — the all-reduce of SURVEY 8(e)
  * (dynamic_vins_amd/dist.py:allreduce_reduced_system). cost, S, g may be NULL. */
@@ -375,7 +380,9 @@ typedef struct dv_est_config {          /* para (estimator/vio_parameters.cpp:19
     int32_t dynamic;                    /* 1: dv_est_process_dynamic* run the InstanceManager */
     int32_t use_det3d;                  /* use_det3d: objects are initialised from 3-D detections */
     int32_t instance_init_min_num;      /* instance_init_min_num (viode.yaml:135: 4) */
-    int32_t pad_;
+    int32_t estimate;                   /* bit 0: cfg::is_estimate_ex == 1 (estimate_extrinsic 1: the extrinsics are optimised around the configured ones from the first full window with
+                                           |Vs[0]| > 0.2 on — openExEstimation, estimator.cpp:87-95,632), bit 1: cfg::is_estimate_td (estimate_td 1, :98-100).  estimate_extrinsic 2
+                                           (no initial guess: CalibrationExRotation, estimator.cpp:1426-1445) is not built.  0 in every shipped YAML */
     double static_inst_threshold;       /* static_inst_threshold: scene-flow norm above which an object counts as moving (default 10) */
     /* line mode (cfg::use_line): line landmarks in FeatureManager, TriangulateLineMono, OptimizationWithOnlyLine, AddLineResidualBlock (estimator.cpp:224-253,345-395) */
     int32_t use_line, line_min_obs;     /* use_line ; line_min_obs (default 5, vio_parameters.cpp:47-54) */
@@ -435,6 +442,9 @@ int dv_est_change_sensor_type(dv_ctx* ctx, int use_imu, int use_stereo);
 /* latest_time / latest_P / latest_Q (qx qy qz qw) / latest_V: the newest frame's state propagated by every IMU sample fed since — FastPredictIMU inside
  * InputIMU and UpdateLatestStates (estimator.cpp:729-742,1376-1418): what PubLatestOdometry publishes on `imu_propagate`.  Returns 1 while not initialised. */
 int dv_est_get_latest(dv_ctx* ctx, double* t, double* P3, double* Q4, double* V3);
+/* body.ric / body.tic (row-major rotations, translations of cam0 / cam1) and body.td as the last Double2vector left them: the configured values unless dv_est_config::estimate
+ * frees them (what pubOdometry writes out when estimate_extrinsic is on, utils/io/visualization.cpp:94-118).  Any pointer may be NULL. */
+int dv_est_get_extrinsics(dv_ctx* ctx, double* ric18, double* tic6, double* td);
 /* Health of the marginalization (MarginalizationInfo::marginalize, factor/marginalization_factor.cpp:284-304).  The reference zeroes the eigenvalues
  * <= 1e-8 of A_mm silently; the device skips the LDL^T pivots <= 1e-8 (also negative ones) — the same pseudo-inverse whenever the deficient directions
  * are single columns (a landmark without information), order dependent otherwise.  So the event is counted and readable:

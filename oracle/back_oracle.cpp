@@ -239,6 +239,7 @@ struct Config {
     ImuNoise noise{ 0.1, 0.01, 0.001, 1e-4 };
     M3 ric[2]; V3 tic[2];
     int use_line = 0, line_min_obs = 5; double line_sqrt_info[4] = { 0, 0, 0, 0 };      // cfg::use_line, para::kLineMinObs, lineProjectionFactor::sqrt_info (never assigned in the reference: zero)
+    int estimate = 0;      // bit 0 cfg::is_estimate_ex (1: optimise the extrinsics around the initial guess; 2 = calibrate from scratch is not restated), bit 1 cfg::is_estimate_td
     int dynamic = 0, use_det3d = 0, instance_init_min_num = 4; double static_inst_threshold = 10.0;      // cfg::slam == kDynamic, use_det3d, para::kInstanceInitMinNum, kStaticInstThreshold
 };
 
@@ -248,7 +249,7 @@ struct Estimator {
     M3 ric[2]; V3 tic[2]; V3 Ps[kWin + 1], Vs[kWin + 1], Bas[kWin + 1], Bgs[kWin + 1]; M3 Rs[kWin + 1];
     V3 g; double td = 0; double headers[kWin + 1] = { 0 };
     double para_ex_pose[2][7], para_pose[kWin + 1][7], para_speed_bias[kWin + 1][9], para_feature[1000][1], para_td[1][1];
-    int frame = 0;
+    int frame = 0; bool open_ex_estimation = false;      // Estimator::openExEstimation (estimator.h:173; reset by ClearState, estimator.cpp:632)
     std::list<Landmark> lms;                   // FeatureManager::point_landmarks
     int last_track_num = 0, new_feature_num = 0, long_track_num = 0;
     std::deque<std::pair<double, V3>> acc_buf, gyr_buf;
@@ -268,7 +269,7 @@ struct Estimator {
     explicit Estimator(const Config& c) : cfg(c) { clear(); set_parameter(); }
     void clear() {
         for (int i = 0; i <= kWin; ++i) { Rs[i] = M3::identity(); Ps[i] = Vs[i] = Bas[i] = Bgs[i] = V3(); pre[i].reset(); dt_buf[i].clear(); la_buf[i].clear(); av_buf[i].clear(); headers[i] = 0; }
-        lms.clear(); acc_buf.clear(); gyr_buf.clear(); all_frames.clear(); tmp_pre.reset(); last_marg.reset();
+        lms.clear(); acc_buf.clear(); gyr_buf.clear(); all_frames.clear(); tmp_pre.reset(); last_marg.reset(); open_ex_estimation = false;
         prev_time = -1; cur_time = 0; first_imu = false; init_first_pose = false; frame = 0; nonlinear = false;
         line_landmarks.clear(); pending_lines.clear();
         im = oim::InstanceManager();
@@ -665,8 +666,13 @@ struct Estimator {
             if (cfg.use_imu) prob.AddParameterBlock(para_speed_bias[i], 9);
         }
         if (!cfg.use_imu) prob.SetConstant(para_pose[0]);
-        for (int i = 0; i < 2; ++i) { prob.AddParameterBlock(para_ex_pose[i], 7, kPose); prob.SetConstant(para_ex_pose[i]); }      // estimate_extrinsic: 0 in every config
-        prob.AddParameterBlock(para_td[0], 1); prob.SetConstant(para_td[0]);                                                         // estimate_td: 0
+        for (int i = 0; i < 2; ++i) {          // AddBodyParameterBlock, estimator.cpp:87-95 (estimate_extrinsic is 0 in every shipped config)
+            prob.AddParameterBlock(para_ex_pose[i], 7, kPose);
+            if (((cfg.estimate & 1) && frame == kWin && Vs[0].norm() > 0.2) || open_ex_estimation) open_ex_estimation = true;
+            else prob.SetConstant(para_ex_pose[i]);
+        }
+        prob.AddParameterBlock(para_td[0], 1);          // :98-100 (estimate_td: 0 in every shipped config)
+        if (!(cfg.estimate & 2) || Vs[0].norm() < 0.2) prob.SetConstant(para_td[0]);
         if (last_marg && last_marg->valid) prob.AddResidualBlock(std::make_shared<MargCost>(last_marg.get()), kNoLoss, last_marg->keep_addr);
         if (cfg.use_imu)
             for (int i = 0; i < frame; ++i) {
@@ -946,8 +952,8 @@ int dvo_ba_solve(dvo_ba_problem* P, dvo_ba_summary* S) {
         if (P->use_imu) prob.AddParameterBlock(P->speed_bias + 9 * i, 9);
     }
     if (!P->use_imu) prob.SetConstant(P->pose);
-    for (int i = 0; i < 2; ++i) { prob.AddParameterBlock(P->ex_pose + 7 * i, 7, kPose); prob.SetConstant(P->ex_pose + 7 * i); }
-    prob.AddParameterBlock(P->td, 1); prob.SetConstant(P->td);
+    for (int i = 0; i < 2; ++i) { prob.AddParameterBlock(P->ex_pose + 7 * i, 7, kPose); if (!(P->free_blocks & 1)) prob.SetConstant(P->ex_pose + 7 * i); }
+    prob.AddParameterBlock(P->td, 1); if (!(P->free_blocks & 2)) prob.SetConstant(P->td);
     MargInfo mi;
     if (P->prior && P->prior->valid) {
         const int n = P->prior->n;
@@ -1105,7 +1111,7 @@ dvo_estimator* dvo_estimator_create(const dvo_be_config* c) {
     cfg.min_parallax = c->keyframe_parallax / kFocalLength; cfg.init_depth = c->init_depth; cfg.g_norm = c->g_norm; cfg.td = c->td;
     cfg.noise = ImuNoise{ c->acc_n, c->gyr_n, c->acc_w, c->gyr_w };
     for (int k = 0; k < 2; ++k) { for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) cfg.ric[k](i, j) = c->ric[k][i * 3 + j]; cfg.tic[k][i] = c->tic[k][i]; } }
-    cfg.dynamic = c->dynamic; cfg.use_det3d = c->use_det3d; cfg.instance_init_min_num = c->instance_init_min_num; cfg.static_inst_threshold = c->static_inst_threshold;
+    cfg.dynamic = c->dynamic; cfg.use_det3d = c->use_det3d; cfg.instance_init_min_num = c->instance_init_min_num; cfg.static_inst_threshold = c->static_inst_threshold; cfg.estimate = c->estimate;
     cfg.use_line = c->use_line; cfg.line_min_obs = c->line_min_obs; for (int k = 0; k < 4; ++k) cfg.line_sqrt_info[k] = c->line_sqrt_info[k];
     return new dvo_estimator{ new Estimator(cfg) };
 }
@@ -1130,6 +1136,10 @@ int dvo_estimator_get_lines(dvo_estimator* e, dvo_line_landmark* out, int cap, i
         std::memcpy(o.plucker, l.line_plucker, 48); for (int c = 0; c < 3; ++c) { o.ptw1[c] = l.ptw1[c]; o.ptw2[c] = l.ptw2[c]; }
     }
     *n_out = k; return 0;
+}
+void dvo_estimator_get_extrinsics(dvo_estimator* e, double* ric18, double* tic6, double* td) {
+    for (int c = 0; c < 2; ++c) { for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) ric18[9 * c + 3 * i + j] = e->e->ric[c](i, j); tic6[3 * c + i] = e->e->tic[c][i]; } }
+    *td = e->e->td;
 }
 void dvo_estimator_destroy(dvo_estimator* e) { if (e) { delete e->e; delete e; } }
 void dvo_estimator_input_imu(dvo_estimator* e, double t, const double* acc, const double* gyr) { e->e->input_imu(t, P3(acc), P3(gyr)); }

@@ -191,7 +191,7 @@ typedef struct dvo_ba_imu { double sum_dt, dp[3], dq[4], dv[3], lin_ba[3], lin_b
 typedef struct dvo_ba_prior_block { int32_t type, idx, off, size_local; } dvo_ba_prior_block;
 typedef struct dvo_ba_prior { int32_t valid, n, nblocks, pad; double c0; dvo_ba_prior_block blocks[16]; double x0[16][9]; } dvo_ba_prior;
 typedef struct dvo_ba_problem {
-    int32_t nframes, nlm, nfac, nimu, use_imu, plane_kind, max_iters, reserved;
+    int32_t nframes, nlm, nfac, nimu, use_imu, plane_kind, max_iters, free_blocks;      /* free_blocks: bit 0 para_ex_pose not SetParameterBlockConstant, bit 1 para_td (estimator.cpp:88-100) */
     double g_norm;
     double *pose, *speed_bias, *ex_pose, *td, *inv_depth;
     const dvo_ba_factor* factors; const dvo_ba_lm* landmarks; const dvo_ba_imu* imu;
@@ -212,7 +212,7 @@ typedef struct dvo_be_config {       /* para (estimator/vio_parameters.cpp:19-83
     double init_depth, g_norm, td;
     double acc_n, gyr_n, acc_w, gyr_w;
     double ric[2][9], tic[2][3];     /* body_T_cam0 / body_T_cam1 rotation (row-major) and translation */
-    int dynamic, use_det3d, instance_init_min_num, pad_;      /* cfg::slam == kDynamic; use_det3d; para::kInstanceInitMinNum */
+    int dynamic, use_det3d, instance_init_min_num, estimate;      /* cfg::slam == kDynamic; use_det3d; para::kInstanceInitMinNum; estimate: bit 0 cfg::is_estimate_ex, bit 1 cfg::is_estimate_td */
     double static_inst_threshold;    /* para::kStaticInstThreshold */
     int use_line, line_min_obs;      /* cfg::use_line, para::kLineMinObs */
     double line_sqrt_info[4];        /* lineProjectionFactor::sqrt_info, row-major 2x2 (the reference never assigns it: zero) */
@@ -260,6 +260,7 @@ int dvo_estimator_process_dynamic(dvo_estimator*, const dvo_feat* feats, int n, 
                                   const double* points, dvo_be_state* out);
 int dvo_fit_box_ransac(const double* pts, int n, const double* dims3, unsigned long long seed, double* out3);      /* vio_util.cpp:209-264, seeded (inst_manager.h) */
 int dvo_fit_box_camera(const double* pts, int n, const double* dims3, double* out3);                                /* vio_util.cpp:274-332 */
+void dvo_estimator_get_extrinsics(dvo_estimator*, double* ric18, double* tic6, double* td);      /* body.ric / tic / td after the last Double2vector */
 int dvo_estimator_set_lines(dvo_estimator* e, const dvo_line_row* lines, int n);      /* frame.features.lines of the next process call */
 int dvo_estimator_get_lines(dvo_estimator* e, dvo_line_landmark* out, int cap, int* n_out);
 int dvo_estimator_get_instances(dvo_estimator*, dvo_inst_state* out, int cap, int* n_out, double* summary4);

@@ -33,7 +33,11 @@ def small_rot(v):
 
 
 def make_window(oracle, seed=1, nframes=11, nlm=120, use_imu=1, max_iters=8, pix_sigma=0.4, with_prior=False, dt_frame=0.1,
-                pose_noise=(0.03, 0.01), depth_noise=0.08, stereo_ratio=0.8, plane_kind=0, outlier_ratio=0.0):
+                pose_noise=(0.03, 0.01), depth_noise=0.08, stereo_ratio=0.8, plane_kind=0, outlier_ratio=0.0,
+                feat_vel=False, td_true=0.0, ex_noise=(0.0, 0.0), free_blocks=0, prior_ex_scale=0.01):
+    """feat_vel: the factors carry the features' image velocities (what the td Jacobian needs); td_true: the observations were taken td_true seconds late
+    (x + v td_true: the factor undoes it with the td being estimated); ex_noise: (metres, radians) perturbation of the extrinsics handed to the solve;
+    free_blocks: dv_ba_problem::free_blocks (bit 0 extrinsics, bit 1 td).  The defaults draw the same random numbers as before these options existed."""
     rng = np.random.default_rng(seed)
     traj = sim.Trajectory()
     t0 = 2.0 + 0.37 * seed
@@ -49,6 +53,12 @@ def make_window(oracle, seed=1, nframes=11, nlm=120, use_imu=1, max_iters=8, pix
         Pc = ric[cam].T @ (R_wb[k].T @ (P - p_wb[k]) - tic[cam])
         return Pc[:2] / Pc[2], Pc[2]
 
+    def proj_vel(k, cam, P, h=1e-4):          # image velocity of the projection (normalised plane, per second)
+        def at(t):
+            Pc = ric[cam].T @ (traj.R(t).T @ (P - traj.p(t)) - tic[cam])
+            return Pc[:2] / Pc[2]
+        return (at(times[k] + h) - at(times[k] - h)) / (2 * h)
+
     factors, lms, inv_depth = [], [], []
     tries = 0
     while len(lms) < nlm and tries < 20000:
@@ -63,21 +73,25 @@ def make_window(oracle, seed=1, nframes=11, nlm=120, use_imu=1, max_iters=8, pix
             if zl < 0.5 or zr < 0.5 or np.abs(xl).max() > 0.8 or np.abs(xr).max() > 0.8:
                 ok = False
                 break
-            obs.append((xl + rng.normal(0, pix_sigma / f, 2), xr + rng.normal(0, pix_sigma / f, 2), rng.uniform() < stereo_ratio))
+            obs.append([xl + rng.normal(0, pix_sigma / f, 2), xr + rng.normal(0, pix_sigma / f, 2), rng.uniform() < stereo_ratio, np.zeros(2), np.zeros(2)])
+            if feat_vel:
+                obs[-1][3], obs[-1][4] = proj_vel(k, 0, P), proj_vel(k, 1, P)
+                obs[-1][0] = obs[-1][0] + obs[-1][3] * td_true
+                obs[-1][1] = obs[-1][1] + obs[-1][4] * td_true
         if not ok or len(obs) < 4:
             continue
         li = len(lms)
         first = len(factors)
         mask = 0
-        pi = obs[0][0]
+        pi, vi = obs[0][0], obs[0][3]
         if rng.uniform() < outlier_ratio:
-            obs[-1] = (obs[-1][0] + rng.normal(0, 30 / f, 2), obs[-1][1], obs[-1][2])
+            obs[-1][0] = obs[-1][0] + rng.normal(0, 30 / f, 2)
         for o, k in zip(obs, range(s, e + 1)):
             mask |= 1 << k
             if k != s:
-                factors.append((pi[0], pi[1], o[0][0], o[0][1], 0, 0, 0, 0, 0, 0, 0, li, s, k, (0, 0)))
+                factors.append((pi[0], pi[1], o[0][0], o[0][1], vi[0], vi[1], o[3][0], o[3][1], 0, 0, 0, li, s, k, (0, 0)))
             if o[2]:
-                factors.append((pi[0], pi[1], o[1][0], o[1][1], 0, 0, 0, 0, 0, 0, 1 if k != s else 2, li, s, k, (0, 0)))
+                factors.append((pi[0], pi[1], o[1][0], o[1][1], vi[0], vi[1], o[4][0], o[4][1], 0, 0, 1 if k != s else 2, li, s, k, (0, 0)))
         lms.append((first, len(factors) - first, s, mask))
         _, z = proj(s, 0, P)
         inv_depth.append(1.0 / (z * (1 + rng.normal(0, depth_noise))))
@@ -98,6 +112,9 @@ def make_window(oracle, seed=1, nframes=11, nlm=120, use_imu=1, max_iters=8, pix
     for c in range(2):
         ex[c, :3] = tic[c]
         ex[c, 3:] = quat_xyzw(ric[c])
+        if ex_noise[0] or ex_noise[1]:
+            ex[c, :3] += rng.normal(0, ex_noise[0], 3)
+            ex[c, 3:] = quat_xyzw(ric[c] @ small_rot(rng.normal(0, ex_noise[1], 3)))
     # IMU pre-integration with the oracle's IntegrationBase restatement
     imu = np.zeros(nframes - 1 if use_imu else 0, IMU_DTYPE)
     if use_imu:
@@ -144,7 +161,7 @@ def make_window(oracle, seed=1, nframes=11, nlm=120, use_imu=1, max_iters=8, pix
             off += sz
         n = off
         M = rng.normal(0, 1, (n + 10, n)) * 30.0
-        M[:, -13:] *= 0.01
+        M[:, -13:] *= prior_ex_scale          # the extrinsic / td columns of the prior (weak by default: the blocks are constants of the solve)
         A = M.T @ M
         # a near-null direction, like the gauge freedom of a real prior
         v = rng.normal(0, 1, n)
@@ -159,7 +176,7 @@ def make_window(oracle, seed=1, nframes=11, nlm=120, use_imu=1, max_iters=8, pix
         b = np.ascontiguousarray(b)
         prior.c0 = oracle.lib.dvo_prior_c0(A.ctypes.data, b.ctypes.data, n)
     return WindowProblem(pose, sb, ex, 0.0, np.array(inv_depth), factors, lms, imu, use_imu=use_imu, plane_kind=plane_kind, max_iters=max_iters,
-                         prior=prior, prior_A=A, prior_b=b)
+                         prior=prior, prior_A=A, prior_b=b, free_blocks=free_blocks)
 
 
 def oracle_solve(oracle, prob):

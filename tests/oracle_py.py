@@ -328,7 +328,7 @@ class dvo_be_config(C.Structure):
                 ("keyframe_parallax", C.c_double), ("init_depth", C.c_double), ("g_norm", C.c_double), ("td", C.c_double),
                 ("acc_n", C.c_double), ("gyr_n", C.c_double), ("acc_w", C.c_double), ("gyr_w", C.c_double),
                 ("ric", (C.c_double * 9) * 2), ("tic", (C.c_double * 3) * 2),
-                ("dynamic", C.c_int), ("use_det3d", C.c_int), ("instance_init_min_num", C.c_int), ("pad_", C.c_int), ("static_inst_threshold", C.c_double),
+                ("dynamic", C.c_int), ("use_det3d", C.c_int), ("instance_init_min_num", C.c_int), ("estimate", C.c_int), ("static_inst_threshold", C.c_double),
                 ("use_line", C.c_int), ("line_min_obs", C.c_int), ("line_sqrt_info", C.c_double * 4)]
 
 
@@ -340,8 +340,9 @@ class dvo_be_state(C.Structure):
 
 def make_be_config(cls, use_imu=1, stereo=1, plane_constraint=0, max_iters=8, keyframe_parallax=10.0, init_depth=5.0,
                    g_norm=9.81, td=0.0, acc_n=0.1, gyr_n=0.01, acc_w=0.001, gyr_w=1e-4, ric=None, tic=None,
-                   dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0, use_line=0, line_min_obs=5, line_sqrt_info=(0.0, 0.0, 0.0, 0.0)):
+                   dynamic=0, use_det3d=0, instance_init_min_num=4, static_inst_threshold=10.0, use_line=0, line_min_obs=5, line_sqrt_info=(0.0, 0.0, 0.0, 0.0), estimate=0):
     c = cls()
+    c.estimate = estimate
     c.use_line, c.line_min_obs = use_line, line_min_obs
     for i in range(4):
         c.line_sqrt_info[i] = float(line_sqrt_info[i])
@@ -383,6 +384,12 @@ class OracleEstimator:
 
     def window(self):
         return np.array([list(r) for r in self.state.window])
+
+    def extrinsics(self):
+        ric, tic, td = np.zeros(18), np.zeros(6), C.c_double(0)
+        self.lib.dvo_estimator_get_extrinsics.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.dvo_estimator_get_extrinsics(self.h, _p(ric), _p(tic), C.addressof(td))
+        return ric.reshape(2, 3, 3), tic.reshape(2, 3), td.value
 
     def process_dynamic(self, rows, t, insts, inst_feats, points):
         L = self.lib

@@ -220,8 +220,12 @@ inline Config ReadConfig(const std::string& config_path, int device = 0, const s
     }
     if (y.has("static_inst_threshold")) e.static_inst_threshold = y.num("static_inst_threshold");
     c.static_inst_as_background = y.integer("static_inst_as_background", 0) != 0;
-    if (e.use_imu && (y.integer("estimate_extrinsic", 0) != 0 || y.integer("estimate_td", 0) != 0))
-        throw std::runtime_error("dvins: estimate_extrinsic / estimate_td != 0 are not on the accelerated path (every shipped config sets 0)");
+    e.estimate = 0;                         // parameters.cpp:82-99: both switches are forced to 0 without an IMU
+    if (e.use_imu) {
+        const int ex = y.integer("estimate_extrinsic", 0);
+        if (ex == 2) throw std::runtime_error("dvins: estimate_extrinsic 2 (calibration without an initial guess, estimator.cpp:1426-1445) is not on the accelerated path");
+        e.estimate = (ex == 1 ? 1 : 0) | (y.integer("estimate_td", 0) != 0 ? 2 : 0);
+    }
     for (int k = 0; k < 2; ++k) for (int i = 0; i < 9; ++i) e.ric[k][i] = (i % 4 == 0) ? 1.0 : 0.0;
     const std::string dir = dir_of(config_path);
     if (c.dataset_type == "kitti" && y.has("kitti_calib_path")) {

@@ -165,3 +165,42 @@ def test_estimator_with_free_extrinsics_and_td_tracks_oracle(gpu_ctx_factory, or
     assert moved_ex == bool(estimate & 1) and moved_td == bool(estimate & 2)
     if estimate & 1:
         assert np.abs(to - np.array([sim.T_IC0, sim.T_IC1])).max() < 0.05          # (it stays with the simulator's extrinsics)
+
+
+def test_free_blocks_inside_a_dv_batch(gpu_ctx_factory):
+    """A dv_batch member whose solve frees the extrinsics takes the generic factorisation, so the round it is in falls back to the members' own launches (be_api.hip
+    batch_enqueue_impl: mixed kernel variants): every member, the free one and the constant ones beside it, still produces exactly what it produces alone."""
+    from dynamic_vins_amd import sim
+    from dynamic_vins_amd.backend import Batch, Estimator
+    from tests.test_batch import NOISE, make_inputs
+    S, frames, dtf = 3, 24, 0.1
+    kws = [dict(use_imu=1, stereo=1, max_iters=8, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], estimate=3 if i == 0 else 0, **NOISE) for i in range(S)]
+    single = [Estimator(gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5), **kws[i]) for i in range(S)]
+    batched = [Estimator(gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5), **kws[i]) for i in range(S)]
+    inputs = [make_inputs(i, 0.37 * i, 1) for i in range(S)]
+    batch = Batch([e.ctx for e in batched])
+    imu = [sim.imu_stream(tr, T0 - 0.05, T0 + frames * dtf + 0.2, 200.0, **NOISE) for tr, _, T0 in inputs]
+    k = [0] * S
+    for f in range(frames):
+        rows = []
+        for i, (tr, fs, T0) in enumerate(inputs):
+            t = T0 + f * dtf
+            ts, acc, gyr = imu[i]
+            while k[i] < len(ts) and ts[k[i]] <= t + 0.06:
+                single[i].InputIMU(ts[k[i]], acc[k[i]], gyr[k[i]]); batched[i].InputIMU(ts[k[i]], acc[k[i]], gyr[k[i]]); k[i] += 1
+            rows.append((fs.frame(t), t))
+        ref = [single[i].ProcessMeasurements(*rows[i])[1] for i in range(S)]
+        ref = [(s.frame, s.nonlinear, s.iterations, s.initial_cost, s.final_cost) for s in ref]
+        for i in range(S):
+            assert batched[i].ProcessMeasurementsBegin(*rows[i]) == 0
+        batch.enqueue()
+        for i in range(S):
+            sb = batched[i].ProcessMeasurementsEnd()
+            assert (sb.frame, sb.nonlinear, sb.iterations, sb.initial_cost, sb.final_cost) == ref[i], f"frame {f}, member {i}"
+            assert np.array_equal(batched[i].window(), single[i].window()), f"frame {f}, member {i}"
+            for a, b in zip(batched[i].extrinsics(), single[i].extrinsics()):
+                assert np.array_equal(a, b)
+    assert np.abs(batched[0].extrinsics()[1] - np.array([sim.T_IC0, sim.T_IC1])).max() > 1e-6 and np.array_equal(batched[1].extrinsics()[1], np.array([sim.T_IC0, sim.T_IC1]))
+    info = batch.info()
+    assert info["single_rounds"] >= 10, info          # (openExEstimation opens with the first full window: every steady-state round of this batch ran on the members' own launches)
+    batch.close()

@@ -38,12 +38,14 @@ extern "C" int dv_debug_red_ts(long long* out) { return hipMemcpyFromSymbol(out,
 #define RED_THREADS 448          // 7 waves: waves 0-5 = rows of a 6x6 pose block (lane = landmark), wave 6 = the block's IMU / prior terms
 #define RED_PAIRS (BE_NF * (BE_NF + 1) / 2)          // pose block pairs (fi >= fj): the landmark sums are bitwise symmetric (rho * (wi * wj); the direct terms are one stored value read from
                                                       // either side), so the upper blocks are mirrored stores instead of a second pass over the same packet rows (round 5: 121 -> 66 pair blocks)
-__device__ __forceinline__ void red_pair(int bx, int& fi, int& fj) {      // bx = fi (fi + 1) / 2 + fj, fj <= fi
-    fi = (int)((sqrtf(8.0f * (float)bx + 1.0f) - 1.0f) * 0.5f);
-    while (fi * (fi + 1) / 2 > bx) --fi;
-    while ((fi + 1) * (fi + 2) / 2 <= bx) ++fi;
-    fj = bx - fi * (fi + 1) / 2;
-}
+// Which pair a block takes decides what its XCD's L2 must hold: blocks are dealt to the 8 XCDs round-robin (bx % 8), and pair (fi, fj) streams the coupling rows W of both
+// frames and the direct-term rows of one of them.  With the pairs in triangular order an XCD met 10 of the 11 frames (81 frame row-sets fetched into the eight L2s for 11
+// that exist); the table below is a partition of the 66 pairs into eight classes of 8 - 9 pairs over 4 - 6 frames each (37 row-sets; found by annealing,
+// scripts/dbg/red_pair_partition.py).  Which block computes a pair changes no bit of the result.  Entry = fi * 16 + fj.
+__device__ const unsigned char RED_PAIR_TAB[RED_PAIRS] = {
+    150, 152, 51, 132, 98, 166, 170, 112, 147, 85, 68, 65, 32, 168, 49, 167, 118, 153, 66, 129, 96, 130, 165, 144, 33, 148, 67, 48, 102, 162, 161, 0, 97,
+    133, 50, 16, 101, 134, 17, 119, 99, 84, 114, 64, 80, 100, 163, 160, 145, 149, 115, 131, 82, 164, 81, 151, 113, 117, 116, 128, 34, 136, 83, 169, 146, 135 };
+__device__ __forceinline__ void red_pair(int bx, int& fi, int& fj) { const int t = RED_PAIR_TAB[bx]; fi = t >> 4; fj = t & 15; }      // fj <= fi
 
 // IMU + prior part of Hd(i, j)  (everything that is not a landmark sum).  rc: the frames of every IMU factor and the prior's header
 // fields, staged in LDS by the caller (they were dependent global loads per factor and entry)
@@ -294,8 +296,17 @@ __device__ __forceinline__ void be_reduce_body(const ARGS& a, int spec, int bx) 
         if (bx == 0) RTS(3);
         return;
     }
-    const int eb = bx - RED_PAIRS;
+    int eb = bx - RED_PAIRS;
     const int n_dense = (n * n + n + RED_THREADS - 1) / RED_THREADS;
+    if (eb < n_dense) {
+        // the dense blocks walk the matrix row by row: with block b on XCD b % 8 every L2 fetched nearly all of the IMU blocks' output and of the prior (8 x 129 KB for one
+        // window).  Renumbered so that the blocks one XCD receives cover a CONTIGUOUS range of rows: the frames of that range, their two IMU factors, their rows of A'
+        const int cls = bx & 7;
+        int start = 0;
+#pragma unroll
+        for (int y = 0; y < 8; ++y) { const int e0 = (y - RED_PAIRS) & 7; if (y < cls && n_dense > e0) start += (n_dense - e0 + 7) >> 3; }
+        eb = start + ((eb - ((cls - RED_PAIRS) & 7)) >> 3);          // bijection on [0, n_dense)
+    }
     if (eb >= n_dense) {          // sharded window only (one block): the scalar sums over the owned landmarks, fixed order (strided partial sums, block tree), and the owned Jacobi scales
         if (!SHARD) return;
         __shared__ double s_red[7][13];
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_batch_kernel(const BeSo
     be_reduce_body<false>(a, spec, blockIdx.x);
 }
 void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s) {
-    hipLaunchKernelGGL(be_reduce_batch_kernel, dim3(RED_PAIRS + (max_n * max_n + max_n + RED_THREADS - 1) / RED_THREADS, n_win), dim3(RED_THREADS), 0, s, tab_dev, spec);
+    hipLaunchKernelGGL(be_reduce_batch_kernel, dim3((RED_PAIRS + (max_n * max_n + max_n + RED_THREADS - 1) / RED_THREADS + 7) & ~7, n_win), dim3(RED_THREADS), 0, s, tab_dev, spec);      // (x a multiple of 8: a block's XCD is blockIdx.x % 8 in every window, as RED_PAIR_TAB assumes)
 }
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s) {
     const int n = a.dims.nstate;

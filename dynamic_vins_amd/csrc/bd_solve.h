@@ -32,7 +32,15 @@ struct BdArgs {
     const unsigned char* active;            // V: block has at least one residual (ceres drops the others from the program)
     double xnorm2_const;                    // squared norm of the parameter blocks that are in the ceres program but never move
     double* out;                            // iterations, successful, termination, initial_cost, final_cost
+    // round 5: the kernel initialises its own working set (x1 <- x0, H / vec zeroed: two enqueued operations less in front of it) and, with lds != 0, keeps x0 | x1 | H0 | H1 | vec
+    // in LDS for the whole solve (bd_lds_bytes(V) of dynamic shared memory): every phase of an iteration used to start with a round trip to L2 for what the previous phase
+    // of the SAME workgroup had just stored.  Same arithmetic in the same order: same bits.  h_x / h_out: optional pinned-host destinations of the result (V x 7 states,
+    // the 5 summary scalars) written by the kernel itself — the two download copies behind it go away.
+    int lds, pad;
+    double* h_x; double* h_out;
 };
+inline size_t bd_lds_bytes(int V) { return sizeof(double) * (size_t)(14 + 2 * BD_HSTRIDE + 30) * (size_t)V; }
+constexpr size_t BD_LDS_MAX = 96 * 1024;
 
 __device__ __forceinline__ constexpr int tri(int i, int j) { return i * (i + 1) / 2 + j; }      // i >= j
 
@@ -120,10 +128,17 @@ __device__ __forceinline__ bool gn6(const double* H, const double* g, const doub
 
 template <class Prob>
 __global__ __launch_bounds__(BD_THREADS) void bd_solve_kernel(Prob prob, BdArgs a) {
-    __shared__ double s_red[4 * BD_NW];
+    __shared__ double s_red[5 * BD_NW];          // block_sum<5> is the widest exchange (it used to be 4 * BD_NW: the fifth value's partials were written past the array — harmless while nothing
+                                                  // else lived in LDS, the first state block of the LDS-resident working set otherwise)
+    extern __shared__ __attribute__((aligned(16))) double bd_lds[];
     const int tid = threadIdx.x, V = a.V;
-    double* xb[2] = { a.x0, a.x1 }; double* Hb[2] = { a.H0, a.H1 };
-    double* scale = a.vec; double* diag = a.vec + 6 * (size_t)V; double* grad = a.vec + 12 * (size_t)V; double* gn = a.vec + 18 * (size_t)V; double* delta = a.vec + 24 * (size_t)V;
+    double* xb[2] = { a.x0, a.x1 }; double* Hb[2] = { a.H0, a.H1 }; double* vecp = a.vec;
+    if (a.lds) { xb[0] = bd_lds; xb[1] = xb[0] + 7 * (size_t)V; Hb[0] = xb[1] + 7 * (size_t)V; Hb[1] = Hb[0] + (size_t)BD_HSTRIDE * V; vecp = Hb[1] + (size_t)BD_HSTRIDE * V; }
+    for (int i = tid; i < 7 * V; i += BD_THREADS) { const double v = a.x0[i]; xb[0][i] = v; xb[1][i] = v; }
+    for (int i = tid; i < BD_HSTRIDE * V; i += BD_THREADS) { Hb[0][i] = 0.0; Hb[1][i] = 0.0; }
+    for (int i = tid; i < 30 * V; i += BD_THREADS) vecp[i] = 0.0;
+    __syncthreads();
+    double* scale = vecp; double* diag = vecp + 6 * (size_t)V; double* grad = vecp + 12 * (size_t)V; double* gn = vecp + 18 * (size_t)V; double* delta = vecp + 24 * (size_t)V;
     int cur = 0;
 
     // initial evaluation, Jacobi scaling (fixed for the whole solve), |x|
@@ -263,8 +278,11 @@ __global__ __launch_bounds__(BD_THREADS) void bd_solve_kernel(Prob prob, BdArgs 
         }
     }
     __syncthreads();
-    if (cur == 1) for (int i = tid; i < 7 * V; i += BD_THREADS) a.x0[i] = a.x1[i];
-    if (tid == 0) { a.out[0] = iterations; a.out[1] = successful; a.out[2] = termination; a.out[3] = initial_cost; a.out[4] = x_cost; }
+    if (cur == 1 || a.lds || a.h_x) for (int i = tid; i < 7 * V; i += BD_THREADS) { const double v = xb[cur][i]; if (cur == 1 || a.lds) a.x0[i] = v; if (a.h_x) a.h_x[i] = v; }
+    if (tid == 0) {
+        const double o5[5] = { (double)iterations, (double)successful, (double)termination, initial_cost, x_cost };
+        for (int k = 0; k < 5; ++k) { a.out[k] = o5[k]; if (a.h_out) a.h_out[k] = o5[k]; }
+    }
 }
 
 

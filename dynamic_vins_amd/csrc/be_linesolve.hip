@@ -126,8 +126,7 @@ extern "C" int dv_line_solve(dv_ctx* ctx, dv_line_problem* P, dv_ba_summary* sum
     uint8_t* base = (uint8_t*)ctx->s1.p;
     hipStream_t s = ctx->be_stream;
     DV_CHECK(hipMemcpyAsync(base, host.data(), up_bytes, hipMemcpyHostToDevice, s));
-    DV_CHECK(hipMemcpyAsync(base + o_x1, base + o_x0, 8 * 7 * (size_t)V, hipMemcpyDeviceToDevice, s));
-    DV_CHECK(hipMemsetAsync(base + o_H0, 0, o_out - o_H0, s));
+    // (x1 <- x0 and the zeroing of H | vec: the kernel's own first phase, bd_solve.h)
     BdArgs a{};
     a.V = V; a.max_iters = P->max_iters;
     a.x0 = (double*)(base + o_x0); a.x1 = (double*)(base + o_x1); a.H0 = (double*)(base + o_H0); a.H1 = (double*)(base + o_H1); a.vec = (double*)(base + o_vec);

@@ -23,6 +23,7 @@
 #include "be_math.h"
 #include "be_obj_dev.h"
 #include "bd_solve.h"
+#include "dev_once.h"
 
 using namespace be;
 
@@ -233,9 +234,7 @@ int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& sc
     if (scratch.ensure(std::max<size_t>(off, (size_t)8 << 20)) != hipSuccess) DV_FAIL("dv_obj_solve: out of device memory");      // (floor: a hipFree + hipMalloc per growth step is a device-wide synchronisation)
     uint8_t* base = (uint8_t*)scratch.p;
     DV_CHECK(hipMemcpyAsync(base, host.data(), up_bytes, hipMemcpyHostToDevice, s));
-    DV_CHECK(hipMemcpyAsync(base + o_x1, base + o_x0, 8 * 7 * (size_t)V, hipMemcpyDeviceToDevice, s));
-    DV_CHECK(hipMemsetAsync(base + o_H0, 0, o_out - o_H0, s));
-    BdArgs a{};
+    BdArgs a{};          // (x1 <- x0 and the zeroing of H | vec are the kernel's own first phase: two enqueued operations less in front of it)
     a.V = V; a.max_iters = P->max_iters;
     a.x0 = (double*)(base + o_x0); a.x1 = (double*)(base + o_x1); a.H0 = (double*)(base + o_H0); a.H1 = (double*)(base + o_H1); a.vec = (double*)(base + o_vec);
     a.active = base + o_act; a.xnorm2_const = xc; a.out = (double*)(base + o_out);
@@ -243,14 +242,18 @@ int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& sc
     pr.n_obj = n_obj; pr.nblk = nblk; pr.npts = npts; pr.plane_kind = P->plane_kind;
     pr.dims0 = (const double*)(base + o_dims0); pr.body = (const double*)(base + o_body); pr.rbc = (const double*)(base + o_rbc); pr.pt = (const double*)(base + o_pt);
     pr.pt_start = (const int*)(base + o_start); pr.box_R = (const double*)(base + o_boxR); pr.box_dims = (const double*)(base + o_boxd); pr.has_box = base + o_hasb;
+    // the solved states and the summary reach the pinned buffer with the kernel's completion (written by the kernel itself over PCIe): no download copies behind it
+    uint8_t* dl = (uint8_t*)pend.pinned + up_bytes;
+    a.h_x = (double*)dl; a.h_out = (double*)(dl + 8 * 7 * (size_t)V);
+    const size_t lds = bd_lds_bytes(V);
+    a.lds = lds <= BD_LDS_MAX ? 1 : 0;          // up to 10 objects the whole working set lives in LDS (bd_solve.h); larger problems keep it in HBM
     {
+        static DevOnce once;
+        if (once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(bd_solve_kernel<ObjProb>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BD_LDS_MAX) != hipSuccess ? 1 : 0; })) DV_FAIL("dv_obj_solve: cannot set the dynamic LDS size");
         StageScope sc(ctx, "obj_solve", s);
-        hipLaunchKernelGGL(bd_solve_kernel<ObjProb>, dim3(1), dim3(BD_THREADS), 0, s, pr, a);
+        hipLaunchKernelGGL(bd_solve_kernel<ObjProb>, dim3(1), dim3(BD_THREADS), a.lds ? lds : 0, s, pr, a);
     }
     DV_CHECK(hipGetLastError());
-    uint8_t* dl = (uint8_t*)pend.pinned + up_bytes;
-    DV_CHECK(hipMemcpyAsync(dl, a.x0, 8 * 7 * (size_t)V, hipMemcpyDeviceToHost, s));
-    DV_CHECK(hipMemcpyAsync(dl + 8 * 7 * (size_t)V, a.out, 64, hipMemcpyDeviceToHost, s));
     DV_CHECK(hipEventRecord(pend.ev, s));
     pend.active = true; pend.V = V; pend.nblk = nblk; pend.n_obj = n_obj; pend.up_bytes = up_bytes; pend.stream = s;
     return 0;

@@ -660,6 +660,7 @@ int be_solve_fused_end(dv_ctx* ctx, dv_ba_problem* P, dv_ba_summary* summary, Be
 struct dv_batch {
     std::vector<dv_ctx*> members; int index = 0;          // index: creation order in the process (dv_group_stream_create)
     hipStream_t stream = nullptr; hipEvent_t ev_slots = nullptr;
+    hipStream_t solve_stream = nullptr; std::vector<hipEvent_t> ev_x;      // DVINS_SOLVE_CUS: the solve launches of a round on a stream of their own (reserved CUs), chained to `stream` by events
     DevBuf tab; void* tab_pinned = nullptr; size_t tab_bytes = 0;      // [S] BeEvalArgs | [S] BeSolveArgs | [S] BeGaugeArgs | [S] BeRejectArgs | [S] BeMargArgs
     long long batched_rounds = 0, single_rounds = 0;
     DvFrontBatch* front = nullptr;                // the members' front ends in shared launches (dv_batch_track_enqueue, dvins_api.hip)
@@ -675,7 +676,25 @@ struct dv_batch {
 // for a round this member will never join are released with an error
 DvFrontBatch*& be_batch_front(dv_batch* B) { return B->front; }
 int be_batch_index(dv_batch* B) { return B->index; }
+// DVINS_SOLVE_CUS=k (experiment; measured SLOWER and left off: 16 sequences 6.75 -> 3.1 k frames/s, 64 sequences 9.7 -> 6.0 k — the two cross-stream edges per
+// iteration slot cost more than the solve's wait for a free CU; profiles/r05_experiments/solve_cus_and_eval_split_ab.txt): k CUs of every XCD are kept for the single-workgroup
+// window solves of the dv_batch groups (a be_solve_batch workgroup
+// needs a whole CU — 157 KB of LDS — and otherwise waits until one drains of the wide grids' workgroups); every group stream and front-end stream gets the complement.
+// CU mask bit i = CU i / 8 of XCD i % 8 (scripts/dbg/cumask_probe.hip).
+static int dv_solve_cus() { static int k = -1; if (k < 0) { const char* e = std::getenv("DVINS_SOLVE_CUS"); k = e ? std::atoi(e) : 0; if (k < 0 || k > 16) k = 0; } return k; }
+hipError_t dv_solve_stream_create(hipStream_t* s) {
+    const int k = dv_solve_cus();
+    if (!k) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    uint32_t mask[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (int b = 0; b < 8 * k; ++b) mask[b >> 5] |= 1u << (b & 31);
+    return hipExtStreamCreateWithCUMask(s, 8, mask);
+}
 hipError_t dv_group_stream_create(hipStream_t* s, int group_index) {
+    if (const int k = dv_solve_cus()) {
+        uint32_t mask[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        for (int b = 8 * k; b < 256; ++b) mask[b >> 5] |= 1u << (b & 31);
+        return hipExtStreamCreateWithCUMask(s, 8, mask);
+    }
     const char* e = std::getenv("DVINS_CU_PARTITIONS");
     const int P = e ? std::atoi(e) : 0;
     if (P < 2 || P > 32 || 256 % P) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
@@ -766,6 +785,12 @@ static int batch_enqueue_impl(dv_batch* B) {
         auto dbg_all = [&](int kind) { for (dv_ctx* c : M) be_dbg_stage(c, it, kind, s); };
         if (head) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_X, s); dbg_all(0); be_launch_reduce_batch(dsa, S, max_n, 0, s); dbg_all(1); }
         if (timed) { (void)hipEventRecord(B->tev[0], s); B->t_windows = S; }
+        if (B->solve_stream) {          // (experiment: the solve on the reserved CUs — two cross-stream edges per slot)
+            hipEvent_t e0 = B->ev_x[(2 * it) % B->ev_x.size()], e1 = B->ev_x[(2 * it + 1) % B->ev_x.size()];
+            DV_CHECK(hipEventRecord(e0, s)); DV_CHECK(hipStreamWaitEvent(B->solve_stream, e0, 0));
+            if (be_launch_solve_batch(dsa, S, max_n, head ? 0 : 1, B->solve_stream)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
+            DV_CHECK(hipEventRecord(e1, B->solve_stream)); DV_CHECK(hipStreamWaitEvent(s, e1, 0));
+        } else
         if (be_launch_solve_batch(dsa, S, max_n, head ? 0 : 1, s)) DV_FAIL("dv_batch_enqueue: cannot set dynamic LDS size");
         dbg_all(2);
         if (last) { be_launch_eval_batch(dea, S, max_grid, BE_EVAL_CAND_COST, s); dbg_all(3); }      // (its accept decision rides in the tail's first launch)
@@ -848,6 +873,10 @@ dv_batch* dv_batch_create(dv_ctx* const* ctxs, int n) {
     { static std::atomic<int> next_index{0}; B->index = next_index.fetch_add(1); }
     bool ok = dv_group_stream_create(&B->stream, B->index) == hipSuccess && hipEventCreateWithFlags(&B->ev_slots, hipEventDisableTiming) == hipSuccess
               && hipEventCreateWithFlags(&B->ev_state, hipEventDisableTiming) == hipSuccess;
+    if (ok && dv_solve_cus()) {
+        ok = dv_solve_stream_create(&B->solve_stream) == hipSuccess;
+        for (int i = 0; ok && i < 32; ++i) { hipEvent_t e = nullptr; ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; if (ok) B->ev_x.push_back(e); }
+    }
     const size_t bytes = (size_t)n * (sizeof(BeEvalArgs) + sizeof(BeSolveArgs) + sizeof(BeGaugeArgs) + sizeof(BeRejectArgs) + sizeof(BeMargArgs));
     B->tab_bytes = bytes;
     ok = ok && B->tab.ensure(bytes) == hipSuccess && hipHostMalloc(&B->tab_pinned, bytes, hipHostMallocDefault) == hipSuccess;
@@ -866,6 +895,8 @@ void dv_batch_destroy(dv_batch* B) {
     if (B->stream) (void)hipStreamSynchronize(B->stream);
     { std::lock_guard<std::mutex> lk(B->mu); for (dv_ctx* c : B->members) if (c->batch == B) { c->batch = nullptr; if (c->be_stream_own) { c->be_stream = c->be_stream_own; c->be_stream_own = nullptr; } } B->members.clear(); }
     if (B->front) { dv_front_batch_release(B->front); B->front = nullptr; }
+    if (B->solve_stream) { (void)hipStreamSynchronize(B->solve_stream); (void)hipStreamDestroy(B->solve_stream); }
+    for (hipEvent_t e : B->ev_x) (void)hipEventDestroy(e);
     if (B->stream) (void)hipStreamDestroy(B->stream);
     if (B->ev_slots) (void)hipEventDestroy(B->ev_slots);
     if (B->ev_state) (void)hipEventDestroy(B->ev_state);

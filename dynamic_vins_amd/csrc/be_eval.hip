@@ -15,6 +15,7 @@
 //                    MarginalizationFactor, factor/marginalization_factor.cpp:350-396).
 // COST-only variant (candidate points of the trust-region loop): residuals only.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "be_kernels.h"
 #include "wave_dpp.h"
 
@@ -44,7 +45,10 @@ __device__ __forceinline__ int be_eval_block_of(int bx, int nlm) {
 // LPB = landmarks per workgroup: 1 (the single-window launch: 256 threads sum one landmark's packet, lowest latency) or 4 (the batched launch: one WAVE per landmark
 // — only L.count <= 22 lanes of a workgroup do the factor arithmetic and the kernel's 214 VGPRs allow two workgroups per CU, so with one landmark per workgroup a CU
 // worked on 2 landmarks at a time; with four it works on 8 and the frame geometry is formed once for all four).  Same arithmetic, same order per landmark.
-template <bool FULL, int LPB, class ARGS>
+// PART: 0 every block kind; 1 the landmark blocks alone, 2 the IMU / prior blocks alone (the batched path from 12 windows per launch on, be_launch_eval_batch: the IMU factor's
+// single-thread evaluation is what holds 222 VGPRs — the landmark branch alone compiles to 176 — so a launch of its own for the handful of IMU / prior blocks lets the landmark
+// launch keep a third workgroup per CU)
+template <bool FULL, int LPB, class ARGS, int PART = 0>
 __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
     const BeCtl c = *a.ctl;
     if (c.done) return;
@@ -66,11 +70,12 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
     __shared__ int s_fj_all[LPB][BE_MAX_OBS_FACTORS], s_two_all[LPB][BE_MAX_OBS_FACTORS];
     __shared__ int s_flist_all[LPB][BE_NF][2];      // per observing frame: the (<= 2: left cam, right cam) two-frame factors whose frame j it is
     __shared__ double s_cost_all[LPB][BE_MAX_OBS_FACTORS];
-    __shared__ double s_imu[450 + 450 + 32];
+    __shared__ double s_imu[PART == 1 ? 1 : 450 + 450 + 32];
     if (b == 0) ETS(0);
     if (b == nlm) ETS(8);
     if (b == nlm + nimu) ETS(16);
     if (bg < ngrp) {
+      if constexpr (PART != 2) {
         // ------------------------------- landmark(s) -------------------------------
         double (*Jb)[28] = Jb_all[wsel]; int* s_fj = s_fj_all[wsel]; int* s_two = s_two_all[wsel]; int (*s_flist)[2] = s_flist_all[wsel]; double* s_cost = s_cost_all[wsel];
         const bool valid = b < nlm && !(b < a.lm_lo || b >= a.lm_hi);      // (sharded window: another rank's landmark)
@@ -169,7 +174,9 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
             BE_PK(o_packets, e, b) = v;
         }
         if (b == 0) ETS(3);
+      }
     } else if (b < nlm + nimu) {
+      if constexpr (PART != 1) {
         // ------------------------------- IMU factor -------------------------------
         const int lane = threadIdx.x;                         // (all EV_THREADS threads of the workgroup)
         const int k = b - nlm;
@@ -211,7 +218,9 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
             o[31 + e] = s;
         }
         if (b == nlm) ETS(12);
+      }
     } else {
+      if constexpr (PART != 1) {
         // ------------------------------- prior -------------------------------
         const int lane = threadIdx.x;
         const BePriorHdr* p = a.prior;
@@ -260,6 +269,7 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
         }
         if (FULL) for (int i = lane; i < n; i += EV_THREADS) o_prior[1 + i] = a.priorb[i] + Adx[i];
         ETS(19);
+      }
     }
 }
 
@@ -277,8 +287,31 @@ __global__ __launch_bounds__(EV_THREADS) void be_eval_batch_kernel(const BeEvalA
     if ((int)blockIdx.x >= ngrp + a.dims.nimu + 1) return;
     be_eval_body<FULL, EV_LPB_BATCH, DV_CONSTANT BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, ngrp));      // (grid x is a multiple of 8: the XCD of a block is blockIdx.x % 8 as in the single-window launch)
 }
+// the two launches of the split form: grid x = landmark workgroups resp. IMU + prior blocks of the largest window
+__global__ __launch_bounds__(EV_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void be_eval_batch_lm_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
+    const DV_CONSTANT BeEvalArgs& a = *reinterpret_cast<const DV_CONSTANT BeEvalArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));
+    const int ngrp = (a.dims.nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH;
+    if ((int)blockIdx.x >= ngrp) return;
+    be_eval_body<true, EV_LPB_BATCH, DV_CONSTANT BeEvalArgs, 1>(a, mode, be_eval_block_of(blockIdx.x, ngrp));
+}
+__global__ __launch_bounds__(EV_THREADS) void be_eval_batch_rest_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
+    const DV_CONSTANT BeEvalArgs& a = *reinterpret_cast<const DV_CONSTANT BeEvalArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));
+    const int ngrp = (a.dims.nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH;
+    if ((int)blockIdx.x >= a.dims.nimu + 1) return;
+    be_eval_body<true, EV_LPB_BATCH, DV_CONSTANT BeEvalArgs, 2>(a, mode, ngrp + (int)blockIdx.x);
+}
 int be_eval_batch_blocks(int nlm, int nimu) { return (nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH + nimu + 1; }
 void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s) {      // max_grid = max over the windows of be_eval_batch_blocks
+    // DVINS_EVAL_SPLIT: 1 always, 0 never; default: from 12 windows per launch on — with 16 windows the launch is 1232 workgroups (2.4 occupancy rounds at two per CU) and the
+    // third workgroup per CU pays for the extra launch (64 sequences: 9.6 -> 10.0 k frames/s); a group of 4 windows (308 workgroups) fits one round either way and only pays
+    // (16 sequences: 6.75 -> 6.3 k).  profiles/r05_experiments/solve_cus_and_eval_split_ab.txt
+    static const int split_env = [] { const char* e = std::getenv("DVINS_EVAL_SPLIT"); return e ? std::atoi(e) : -1; }();
+    const bool split = split_env < 0 ? n_win >= 12 : split_env != 0;
+    if (split && mode != BE_EVAL_CAND_COST) {          // (max_grid bounds both parts)
+        hipLaunchKernelGGL(be_eval_batch_rest_kernel, dim3(BE_WIN + 1, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+        hipLaunchKernelGGL(be_eval_batch_lm_kernel, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+        return;
+    }
     if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_batch_kernel<true>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
     else hipLaunchKernelGGL(be_eval_batch_kernel<false>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
 }

@@ -414,7 +414,7 @@ extern "C" int dv_batch_track_enqueue(dv_batch* B, const dv_track_job* jobs, int
     DvFrontBatch*& Fp = be_batch_front(B);
     if (!Fp) {
         Fp = new DvFrontBatch();
-        DV_CHECK(std::getenv("DVINS_CU_PARTITION_FRONT") ? dv_group_stream_create(&Fp->stream, be_batch_index(B)) : hipStreamCreateWithFlags(&Fp->stream, hipStreamNonBlocking));
+        DV_CHECK((std::getenv("DVINS_CU_PARTITION_FRONT") || std::getenv("DVINS_SOLVE_CUS")) ? dv_group_stream_create(&Fp->stream, be_batch_index(B)) : hipStreamCreateWithFlags(&Fp->stream, hipStreamNonBlocking));
         DV_CHECK(hipEventCreateWithFlags(&Fp->done, hipEventDisableTiming));
         for (int k = 0; k < 2; ++k) DV_CHECK(hipEventCreateWithFlags(&Fp->ev_copy[k], hipEventDisableTiming));
     }
@@ -446,13 +446,16 @@ extern "C" int dv_batch_track_enqueue(dv_batch* B, const dv_track_job* jobs, int
     const int w = ref->width, h = ref->height; const bool stereo = ref->stereo != 0;
     hipStream_t s = F.stream;
     // ---- per member: the checks and the lazily created resources of dv_track_stereo_enqueue ----
+    // (a member's `cur` flips here because everything below addresses its pyramids through it; a failure further down — table growth, the upload, an LDS attribute — flips it
+    //  back, so that no member is left with the wrong current pyramid and no pending frame: ADVICE r4)
+    struct CurGuard { std::vector<dv_ctx*> flipped; bool committed = false; ~CurGuard() { if (!committed) for (dv_ctx* c : flipped) c->cur ^= 1; } } cur_guard;
     int n_max = 0;
     for (int i : M) {
         const dv_track_job& j = jobs[i]; dv_ctx* c = mem[j.member];
         if (c->pending) { dv_set_error(ctx, "dv_batch_track_enqueue: a member's previous frame was not collected"); return -1; }
         if (ensure_hw(c, c->cfg.min_dist) || ensure_cand(c, w, h)) { dv_set_error(ctx, c->err); return -1; }
         if (c->last_front && c->last_front != s && c->last_done) DV_CHECK(hipStreamWaitEvent(s, c->last_done, 0));      // its previous frame ran on its own stream
-        c->cur ^= 1;
+        c->cur ^= 1; cur_guard.flipped.push_back(c);
         DV_CHECK(c->left[c->cur].alloc(w, h, 3));
         if (stereo) DV_CHECK(c->right.alloc(w, h, 3));
         n_max = std::max(n_max, c->cfg.max_cnt);
@@ -543,6 +546,7 @@ extern "C" int dv_batch_track_enqueue(dv_batch* B, const dv_track_job* jobs, int
         c->last_done = F.done; c->last_front = s;
         c->prev_time = j.t; c->have_prev = true; c->pending = true;
     }
+    cur_guard.committed = true;
     F.rounds++; F.members_batched += S;
     return 0;
 }

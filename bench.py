@@ -222,7 +222,7 @@ def main():
             dyn = measure(a2, cfg, rank, world, local_rank, want_roofline=False)
         if rank == 0 and dyn is not None:
             dc = dyn["config"]
-            out["config"]["dynamic_line"] = {"value": dyn["value"], "unit": "frames/s", "ms_per_step": dyn["ms_per_step"], "timed_region_s": dyn["timed_region_s"], "warmup": dyn["warmup"], "block_values": dc["block_values"],
+            out["config"]["dynamic_line"] = {"value": dyn["value"], "unit": "frames/s", "ms_per_step": dyn["ms_per_step"], "timed_region_s": dyn["timed_region_s"], "warmup": dyn["warmup"], "block_values": dc["block_values"], "block_step_ms": dc.get("block_step_ms"),
                                              "ate_rmse_m_vs_oracle": dc["ate_rmse_m_vs_oracle"], "ate_rmse_m_vs_ground_truth": dc["ate_rmse_m_vs_ground_truth"],
                                              "workload": dc["workload"], "dynamic": dc.get("dynamic"), "host_loop": dc.get("host_loop"), "solver_iterations_per_frame": dc["solver_iterations_per_frame"],
                                              "cpu_baseline_value": None if dyn["cpu_baseline"] is None else dyn["cpu_baseline"]["value"], "target_frames_per_s": 500}
@@ -297,6 +297,16 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 dv_dist.barrier()
             times.append(time.perf_counter() - t0)
             frame_ms.append({"p50": None, "p95": None, "max": None, "t_since_start_s": round(t0 - T_PROCESS_START, 2), "note": "C++ host loop: one call per block, no per-step host clock"})
+        try:          # per-frame end clocks of the C++ loop (dv_runner_get_frame_clock: host clock at every frame's end, the run is not cut): where inside a block the time went
+            clk = np.asarray(runner.frame_clock(0), dtype=np.float64)
+            for _b in range(blocks):
+                a = (warm_ba + _b * args.steps) * stride
+                dd = np.diff(clk[a - 1:a + args.steps * stride]) * 1e3
+                if len(dd):
+                    frame_ms[len(frame_ms) - blocks + _b].update(p50=round(float(np.median(dd)), 3), p95=round(float(np.percentile(dd, 95)), 3), max=round(float(dd.max()), 3),
+                                                                 first_two=[round(float(v), 3) for v in dd[:2]], note="C++ host loop: frame-end clocks of dv_runner (one call per block)")
+        except Exception as e:      # (diagnostics only)
+            frame_ms[-1]["note"] = "frame clocks unavailable: %s" % e
         st, poses, iters_all, _fr = runner.get(0)
         pipe.poses, pipe.pose_times = [q for q in poses[:, 1:8]], [float(t) for t in poses[:, 0]]
         pipe.est.state, pipe.rows = st, np.zeros(runner.last_rows)

@@ -1,0 +1,29 @@
+"""debug: the dynamic bench line cut into blocks as the driver's command cuts it (--steps 20 --warmup 5: 32 warm-up frames, two timed blocks of 20): wall time of every
+dv_runner_run call and the per-frame end clocks (dv_runner_get_frame_clock) around the cuts.  usage: python scripts/dbg/dyn_block_clock.py [warm] [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+import numpy as np, torch
+from dynamic_vins_amd import sim
+from dynamic_vins_amd.backend import Runner
+from dynamic_vins_amd.pipeline import DynamicPipeline, DynamicSequence
+warm = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+N = warm + 3 * K
+seq = DynamicSequence(1280, 720, sim.ZED, N + 2, rate=20.0, device="cuda:0", boxes=("escort", 4))
+pipe = DynamicPipeline(seq, max_cnt=250, min_dist=25, max_iters=10, device=0, mask_morphology_size=5)
+r = Runner([pipe])
+r.run(warm)
+walls = []
+for b in range(3):
+    torch.cuda.synchronize(); pipe.ctx.sync()
+    t0 = time.perf_counter(); r.run(K); pipe.ctx.sync(); torch.cuda.synchronize(); walls.append(time.perf_counter() - t0)
+clk = np.asarray(r.frame_clock(0)); tc = np.asarray(r.frame_clock(0, 1))
+d = np.diff(clk) * 1e3
+print("blocks of %d frames behind %d warm-up frames: " % (K, warm) + " ".join("%.2f ms = %.0f frames/s" % (1e3 * w, K / w) for w in walls))
+for b in range(3):
+    a = warm + b * K
+    print("block %d frames %d..%d end-to-end deltas (ms): " % (b, a, a + K - 1) + " ".join("%.2f" % v for v in d[a - 1:a + K - 1]))
+    print("   first frame of the block: run() call start -> frame end %.2f ms" % ((clk[a] - clk[a - 1]) * 1e3))
+print("frames > 1.6 ms:", [(int(i + 1), round(float(v), 2)) for i, v in enumerate(d) if v > 1.6 and i + 1 >= 12])
+r.close(); pipe.ctx.close()

@@ -102,3 +102,17 @@ def test_feat_row_dtype_roundtrip():
     a["left"][:, 0] = [0.5, 0.25, 0.125]
     b = np.frombuffer(a.tobytes(), FEAT_DTYPE)
     assert (b["id"] == a["id"]).all() and (b["left"] == a["left"]).all()
+
+
+def test_reduce_pair_table_is_a_partition_of_the_pose_pairs():
+    """be_reduce deals its 66 pose-pair blocks to the 8 XCDs through RED_PAIR_TAB (be_solve.hip): the table must hold every pair fi >= fj of the 11 window frames exactly once
+    (a missing pair would leave a block of the reduced camera system unwritten), and the point of it — few frames per XCD class — must survive edits."""
+    import re
+    src = open(os.path.join(ROOT, "dynamic_vins_amd", "csrc", "be_solve.hip")).read()
+    m = re.search(r"RED_PAIR_TAB\[RED_PAIRS\]\s*=\s*\{([^}]*)\}", src)
+    assert m, "RED_PAIR_TAB not found"
+    tab = [int(v) for v in m.group(1).replace("\n", " ").split(",") if v.strip()]
+    pairs = [(t >> 4, t & 15) for t in tab]
+    assert len(tab) == 66 and sorted(pairs) == sorted((i, j) for i in range(11) for j in range(i + 1))
+    per_xcd = [len({f for bx in range(x, 66, 8) for f in pairs[bx]}) for x in range(8)]
+    assert max(per_xcd) <= 6 and sum(per_xcd) <= 40, per_xcd          # (81 with the pairs in triangular order)

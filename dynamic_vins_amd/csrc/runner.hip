@@ -209,15 +209,19 @@ int seq_begin(dv_runner* R, RSeq& s, bool own_front = true) {
     if (!s.enqueued) { if (!own_front) { s.err = "internal: frame not enqueued"; set_err(R, s.err); return -1; } if (seq_enqueue(R, s, k)) return -1; }
     if (dv_track_stereo_collect(s.ctx, s.rows.data(), &s.n_rows)) return fail(R, s, "dv_track_stereo_collect");
     s.enqueued = false;
-    {   // what the back end is about to be handed: frame index + a hash of the collected rows
-        unsigned long long h = 1469598103934665603ull; const unsigned char* p = reinterpret_cast<const unsigned char*>(s.rows.data());
-        for (size_t i = 0, n = (size_t)s.n_rows * sizeof(dv_feat); i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
+    // what the back end is handed: frame index + a hash of the collected rows (row log: the bit-identity checks compare it run against run).  Taken BEHIND the enqueue of the
+    // window solve — a byte-serial FNV over 32 KB was 20 - 25 us on the path between two frames' solves — and over 64-bit words
+    auto hash_rows = [&]() {
+        static_assert(sizeof(dv_feat) % 8 == 0, "rows are hashed as 64-bit words");
+        unsigned long long h = 1469598103934665603ull; const unsigned long long* p = reinterpret_cast<const unsigned long long*>(s.rows.data());
+        for (size_t i = 0, n = (size_t)s.n_rows * sizeof(dv_feat) / 8; i < n; ++i) { h ^= p[i]; h *= 1099511628211ull; }
         s.cur_rows_hash = h; s.cur_k = k;
-    }
+    };
     const double t = s.in.times[k];
     const int stride = s.in.ba_stride > 1 ? s.in.ba_stride : 1;
     if (stride > 1 && (k % stride) != 0) {      // tracked only: outside KITTI the reference pushes a frame to feature_queue when cnt % 2 == 0, cnt counting tracked frames from 0 (system/main.cpp:181,300-312): frames 0, 2, 4, ...
         if (own_front && k + 1 < s.in.n_frames && seq_enqueue(R, s, k + 1)) return -1;
+        hash_rows();
         ++s.next; s.skipped = true;
         return 0;
     }
@@ -227,6 +231,7 @@ int seq_begin(dv_runner* R, RSeq& s, bool own_front = true) {
     if (rc < 0) return fail(R, s, "dv_est_process_begin");
     if (rc > 0) { s.err = "IMU stream does not cover the frame"; set_err(R, s.err); return -1; }
     if (own_front && k + 1 < s.in.n_frames) { if (seq_enqueue(R, s, k + 1) || seq_feed_imu(R, s, s.in.times[k + 1])) return -1; }
+    hash_rows();
     s.pending = true; s.pending_t = t;
     return 0;
 }

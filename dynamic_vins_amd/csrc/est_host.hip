@@ -217,7 +217,7 @@ struct dv_estimator {
         lines.clear(); lines.min_obs = cfg.line_min_obs > 0 ? cfg.line_min_obs : 5; pending_lines.clear(); para_line.clear(); line_last = dv_ba_summary{};
         im.clear(); im.cfg.use_det3d = cfg.use_det3d; im.cfg.init_min_num = cfg.instance_init_min_num; im.cfg.static_threshold = cfg.static_inst_threshold;
         im.cfg.plane_kind = cfg.plane_constraint ? (cfg.use_imu ? 1 : 2) : 0; im.cfg.max_iters = cfg.max_iters;
-        std::memset(para_pose_ref, 0, sizeof(para_pose_ref)); obj_last = dv_ba_summary{}; dyn_frame = false;
+        std::memset(para_pose_ref, 0, sizeof(para_pose_ref)); obj_last = dv_ba_summary{}; dyn_frame = false; dyn_tail_deferred = false;
         latest_valid = false; latest_time = 0; latest_P = latest_V = latest_Ba = latest_Bg = latest_acc_0 = latest_gyr_0 = mk3(0, 0, 0); latest_Q = mkq(1, 0, 0, 0);
     }
     dvi::BodyView body_view() const { return dvi::BodyView{ Rs, Ps, ric, tic, headers, td, frame }; }
@@ -652,6 +652,7 @@ struct dv_estimator {
     // solve enqueued just before is in flight on the BA stream.
     int dynamic_branch(dv_ctx* ctx, const dv_inst_obs* insts, int n_insts, const dv_feat* inst_feats, const double* points) {
         HostScope h(ctx, "h_dynamic");
+        flush_dyn_tail(ctx);          // the previous frame's object tail (see BodySnap)
         const dvi::BodyView B = body_view();
         { HostScope h1(ctx, "h_dyn_push"); im.push_back(frame, B, insts, n_insts, inst_feats, points); }
         { HostScope h1(ctx, "h_dyn_propagate"); im.propagate_pose(B); }
@@ -671,6 +672,26 @@ struct dv_estimator {
     // second half of the object branch (InstanceManager::GetOptimizationParameters + OutliersRejection, estimator_insts.cpp:804, estimator.cpp:1615): needs the object
     // solve's result and still the PRE-optimisation body states, so it runs at the top of process_image_end, before the window solve's result is applied
     dv_obj_problem OP{}; bool obj_solved = false;
+    // The object branch's tail of a frame — ManageTriangulatePoint + SlideWindow on the body window BEFORE it slides, the per-frame clean-up on the slid window
+    // (estimator.cpp:1653-1676) — reads nothing the next frame's ego branch writes and writes nothing it reads: it is kept back, with snapshots of the two body views it needs,
+    // and runs at the top of the next frame's object branch, i.e. beside that frame's window solve instead of in front of it (45 us of the host path the GPU waits for).
+    // Anything that looks at the objects before that (dv_est_get_instances, a reset) runs it first: same calls on the same data in the same order.
+    struct BodySnap {
+        m33 Rs[kWin + 1]; d3 Ps[kWin + 1]; m33 ric[2]; d3 tic[2]; double headers[kWin + 1]; double td = 0; int frame = 0;
+        dvi::BodyView view() const { return dvi::BodyView{ Rs, Ps, ric, tic, headers, td, frame }; }
+    };
+    BodySnap snap_pre, snap_post; bool dyn_tail_deferred = false, dyn_tail_margin_old = false;
+    void snap_body(BodySnap& b) const {
+        for (int i = 0; i <= kWin; ++i) { b.Rs[i] = Rs[i]; b.Ps[i] = Ps[i]; b.headers[i] = headers[i]; }
+        for (int c = 0; c < 2; ++c) { b.ric[c] = ric[c]; b.tic[c] = tic[c]; }
+        b.td = td; b.frame = frame;
+    }
+    void flush_dyn_tail(dv_ctx* ctx) {
+        if (!dyn_tail_deferred) return;
+        dyn_tail_deferred = false;
+        { HostScope h1(ctx, "h_dyn_slide"); const dvi::BodyView B = snap_pre.view(); im.manage_triangulate_point(B); im.slide_window(B, dyn_tail_margin_old); }
+        { HostScope h1(ctx, "h_dyn_finish_frame"); im.finish_frame(snap_post.view()); }
+    }
     int dynamic_branch_finish(dv_ctx* ctx) {
         HostScope h(ctx, "h_dynamic_finish");
         { HostScope h1(ctx, "h_dyn_solve_wait"); if (obj_solved && be_obj_solve_end(ctx, &OP, &obj_last, ctx->obj_pend)) return -1; }
@@ -712,9 +733,9 @@ struct dv_estimator {
         if (optimization_end(ctx)) return -1;
         if (dyn_frame) im.touch_in_main_optimization();      // AddInstanceParameterBlock / im.GetOptimizationParameters inside Estimator::Optimization
         { HostScope h(ctx, "h_reject"); reject_outliers(); if (cfg.use_line) lines.remove_outliers(Rs, Ps, ric[0], tic[0]); }
-        if (dyn_frame) { HostScope h1(ctx, "h_dyn_slide"); const dvi::BodyView B = body_view(); im.manage_triangulate_point(B); im.slide_window(B, margin_old); }      // estimator.cpp:1653-1658, BEFORE the body window slides
+        if (dyn_frame) { flush_dyn_tail(ctx); snap_body(snap_pre); dyn_tail_margin_old = margin_old; }      // estimator.cpp:1653-1658 sees the body window BEFORE it slides ...
         { HostScope h(ctx, "h_slide"); slide_window(); }
-        if (dyn_frame) { HostScope h1(ctx, "h_dyn_finish_frame"); im.finish_frame(body_view()); }                                                                                 // estimator.cpp:1663-1676, on the slid window
+        if (dyn_frame) { snap_body(snap_post); dyn_tail_deferred = true; }                                     // ... and :1663-1676 the slid one: both kept back (flush_dyn_tail)
         erase_if([](const Lm& l) { return l.solve_flag == 2; });      // RemoveFailures
         update_latest_states();          // unconditional in the reference (estimator.cpp:1688); the IMU replay inside is empty in vision-only mode
         return 0;
@@ -900,6 +921,7 @@ int dv_est_get_instances(dv_ctx* ctx, dv_inst_state* out, int cap, int* n_out, d
     if (!ctx->est) DV_FAIL("dv_est_get_instances: call dv_est_create first");
     if (!n_out || cap < 0 || (cap > 0 && !out)) DV_FAIL("dv_est_get_instances: bad argument");
     dv_estimator& E = *ctx->est;
+    E.flush_dyn_tail(ctx);
     int k = 0;
     for (auto& kv : E.im.insts) {
         if (k >= cap) break;

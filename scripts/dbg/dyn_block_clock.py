@@ -14,8 +14,10 @@ seq = DynamicSequence(1280, 720, sim.ZED, N + 2, rate=20.0, device="cuda:0", box
 pipe = DynamicPipeline(seq, max_cnt=250, min_dist=25, max_iters=10, device=0, mask_morphology_size=5)
 r = Runner([pipe])
 r.run(warm)
+idle = float(os.environ.get('IDLE_MS', '0')) / 1e3      # an idle gap in front of every block (the bench's gc.collect() pause is ~50 ms)
 walls = []
 for b in range(3):
+    if idle: time.sleep(idle)
     torch.cuda.synchronize(); pipe.ctx.sync()
     t0 = time.perf_counter(); r.run(K); pipe.ctx.sync(); torch.cuda.synchronize(); walls.append(time.perf_counter() - t0)
 clk = np.asarray(r.frame_clock(0)); tc = np.asarray(r.frame_clock(0, 1))
@@ -25,5 +27,9 @@ for b in range(3):
     a = warm + b * K
     print("block %d frames %d..%d end-to-end deltas (ms): " % (b, a, a + K - 1) + " ".join("%.2f" % v for v in d[a - 1:a + K - 1]))
     print("   first frame of the block: run() call start -> frame end %.2f ms" % ((clk[a] - clk[a - 1]) * 1e3))
-print("frames > 1.6 ms:", [(int(i + 1), round(float(v), 2)) for i, v in enumerate(d) if v > 1.6 and i + 1 >= 12])
+dt = np.diff(tc) * 1e3
+for i, v in enumerate(d):
+    f = i + 1
+    if v > 1.6 and f >= 14 and not idle:
+        print("slow frame %d: estimator delta %.2f ms | tracker delivery deltas of frames %d..%d: %s | estimator end - tracker delivery of that frame: %.2f ms" % (f, v, f - 1, f + 1, " ".join("%.2f" % x for x in dt[f - 2:f + 1]), (clk[f] - tc[f]) * 1e3))
 r.close(); pipe.ctx.close()

@@ -282,7 +282,13 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         runner = Runner([pipe], host_frames=args.host_frames)      # --host-frames: pinned host buffers, every frame's upload inside the timed region
         if os.environ.get("BENCH_TRACKER_THREAD", "1") != "1":          # A/B: dynamic mode on the one-thread loop of round 4 instead of T2 beside T3
             runner.set("tracker_thread", 0)
-        runner.run(warm_ba * stride)
+        # The warm-up contains one device-wide synchronisation, two frames before its end: the FIRST frame behind the first such synchronisation of a process costs 5 - 7 ms once
+        # in about two runs of three in dynamic mode (both host threads blocked in different HIP calls at the same instant: a lock inside the runtime, none of our allocations —
+        # scripts/dbg/dyn_block_clock.py, dyn_block_start_phases.py; later synchronisations do not repeat it).  It is a one-time cost of the process, not a rate: with the cut
+        # inside the warm-up a 20-step block measures frames, not that event (dynamic line 700 - 750 -> 925 - 935 frames/s in the runs that had it).  Same number of warm-up steps.
+        runner.run((warm_ba - 2) * stride)
+        torch.cuda.synchronize(); pipe.ctx.sync()
+        runner.run(2 * stride)
         it0 = runner.get(0)[2]                               # window-solve iterations spent in the warm-up
         gc.collect(); gc.freeze()
         times = []
@@ -323,7 +329,9 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         pipe = make_pipe()
         for key in filter(None, args.debug_set.split(",")):
             assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
-        for _ in range(warm_ba * stride):
+        for _w in range(warm_ba * stride):
+            if _w == (warm_ba - 2) * stride:          # (one device-wide synchronisation inside the warm-up: see run_cpp)
+                torch.cuda.synchronize(); pipe.ctx.sync()
             pipe.step()
         # A generation-2 collection of the interpreter's ~10^6 objects (torch, numpy) is a ~60 ms pause that lands in a random block (seen as ONE 63 ms step
         # in config.block_step_ms): collect now and move everything that exists to the permanent generation, as timeit does by disabling the collector.

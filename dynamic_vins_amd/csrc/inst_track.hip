@@ -265,13 +265,18 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
     StageScope sc_all(ctx, "inst_track", s);
     if (n_dets > 0) {
         // masks: one pinned staging area, one H2D per object (sources are pageable caller memory)
+        // (sized for two full frames of mask pixels from the start: the detections' rectangles GROW as objects come closer, and every growth step of these two buffers was a
+        //  hipHostFree + hipHostMalloc resp. two stream synchronisations + hipFree + hipMalloc — 5 - 8 ms during which the estimator thread's HIP calls wait for the runtime's
+        //  locks too; seen as one 6 ms frame somewhere in the first frames of the dynamic bench line's timed region in every second run)
+        const size_t mask_floor = 2 * (size_t)align_up(W, 16) * H + 4096;
         if (T.pinned_in_bytes < mask_bytes) {
             if (T.pinned_in) (void)hipHostFree(T.pinned_in);
             T.pinned_in = nullptr; T.pinned_in_bytes = 0;
-            DV_CHECK(hipHostMalloc(&T.pinned_in, mask_bytes * 2 + 4096, hipHostMallocDefault));
-            T.pinned_in_bytes = mask_bytes * 2 + 4096;
+            const size_t want = std::max(mask_bytes * 2 + 4096, mask_floor);
+            DV_CHECK(hipHostMalloc(&T.pinned_in, want, hipHostMallocDefault));
+            T.pinned_in_bytes = want;
         }
-        if (T.mask_all.bytes < mask_bytes) { DV_CHECK(hipStreamSynchronize(s)); DV_CHECK(hipStreamSynchronize(T.xstream)); DV_CHECK(T.mask_all.ensure(mask_bytes * 2 + 4096)); }
+        if (T.mask_all.bytes < mask_bytes) { DV_CHECK(hipStreamSynchronize(s)); DV_CHECK(hipStreamSynchronize(T.xstream)); DV_CHECK(T.mask_all.ensure(std::max(mask_bytes * 2 + 4096, mask_floor))); }
         // output area
         if (T.out_cap_slots < T.slots.size()) {
             const size_t cap = std::max<size_t>(8, T.slots.size() * 2);

@@ -462,3 +462,50 @@ def test_aux_golden_reproduced_by_the_oracle(oracle):
     s = G.o_line_solve(oracle.lib, p)
     assert [s.iterations, s.successful, s.termination] == g["line_summary"][:3].astype(int).tolist()
     assert np.allclose(p.orth, g["line_orth_out"], rtol=0, atol=1e-9) and np.isclose(s.final_cost, g["line_summary"][4], rtol=1e-10)
+
+
+def test_window_solve_free_blocks_of_the_oracle(oracle):
+    """dvo_ba_problem::free_blocks (Estimator::AddBodyParameterBlock, estimator.cpp:87-100: which of para_ex_pose / para_td are not SetParameterBlockConstant): a constant
+    block never moves (bit for bit), a free one does, and more freedom can only lower the minimum the same problem converges to."""
+    kw = dict(seed=31, with_prior=True, feat_vel=True, td_true=0.02, ex_noise=(0.01, 0.005), prior_ex_scale=1.0, max_iters=60)
+    final = {}
+    for fb in (0, 1, 2, 3):
+        p = ba_gen.make_window(oracle, free_blocks=fb, **kw)
+        ex0, td0 = p.ex_pose.copy(), p.td[0]
+        s = ba_gen.oracle_solve(oracle, p)
+        assert s.termination == 1 and s.final_cost < s.initial_cost
+        assert np.array_equal(p.ex_pose, ex0) == (not fb & 1) and (p.td[0] == td0) == (not fb & 2)
+        if fb & 1:
+            assert np.allclose(np.linalg.norm(p.ex_pose[:, 3:], axis=1), 1.0, atol=1e-12)          # PoseLocalParameterization keeps the quaternions normalised
+        final[fb] = s.final_cost
+    assert final[3] <= final[1] * (1 + 1e-9) <= final[0] * (1 + 1e-9) and final[3] <= final[2] * (1 + 1e-9) <= final[0] * (1 + 1e-9)
+
+
+def test_open_ex_estimation_rule_of_the_oracle_estimator(oracle):
+    """openExEstimation (estimator.cpp:87-95,632): with estimate_extrinsic 1 the extrinsics stay exactly the configured ones until the first FULL window whose oldest speed exceeds
+    0.2 m/s, move from then on, and never move with the switch off; td moves only with estimate_td 1."""
+    from dynamic_vins_amd import sim
+    noise = dict(acc_n=0.02, gyr_n=0.002, acc_w=2e-4, gyr_w=2e-5)
+    moved = {}
+    for estimate in (0, 1, 2):
+        traj = sim.Trajectory()
+        fs = sim.FeatureSim(traj, sim.EUROC, 752, 480, sim.room_points(2000), max_cnt=100, pix_sigma=0.3, seed=5)
+        tic = [np.asarray(sim.T_IC0) + 0.005, np.asarray(sim.T_IC1) - 0.005]
+        est = oracle.estimator(use_imu=1, stereo=1, max_iters=6, ric=[sim.R_IC, sim.R_IC], tic=tic, estimate=estimate, **noise)
+        ts, acc, gyr = sim.imu_stream(traj, 0.95, 1.0 + 16 * 0.1 + 0.2, 200.0, **noise)
+        k, first_ex, first_td = 0, None, None
+        for f in range(16):
+            t = 1.0 + 0.1 * f
+            while k < len(ts) and ts[k] <= t + 0.06:
+                est.input_imu(ts[k], acc[k], gyr[k]); k += 1
+            rc, st = est.process(fs.frame(t), t)
+            assert rc == 0
+            _, tt, td = est.extrinsics()
+            if first_ex is None and not np.array_equal(tt, np.array(tic)):
+                first_ex = (f, st.frame)
+            if first_td is None and td != 0.0:
+                first_td = f
+        moved[estimate] = (first_ex, first_td)
+    assert moved[0] == (None, None)
+    assert moved[1][0] is not None and moved[1][0][1] == 10 and moved[1][0][0] >= 10 and moved[1][1] is None          # not before the window is full
+    assert moved[2][0] is None and moved[2][1] is not None

@@ -41,7 +41,7 @@ int main(int argc, char** argv) {
             std::printf("width=%d\nheight=%d\nmax_cnt=%d\nmin_dist=%d\nflow_back=%d\nstereo=%d\nmask_morphology_size=%d\n", f.width, f.height, f.max_cnt, f.min_dist, f.flow_back, f.stereo, f.mask_morphology_size);
             std::printf("max_dynamic_cnt=%d\nmin_dynamic_dist=%d\nuse_det3d=%d\nundistort_input=%d\nstatic_inst_as_background=%d\nbaseline=%.17g\n", c.max_dynamic_cnt, c.min_dynamic_dist, c.use_det3d, c.undistort_input, (int)c.static_inst_as_background, c.baseline);
             std::printf("use_imu=%d\nplane_constraint=%d\nmax_iters=%d\nkeyframe_parallax=%.17g\ninit_depth=%.17g\ng_norm=%.17g\ntd=%.17g\n", e.use_imu, e.plane_constraint, e.max_iters, e.keyframe_parallax, e.init_depth, e.g_norm, e.td);
-            std::printf("acc_n=%.17g\ngyr_n=%.17g\nacc_w=%.17g\ngyr_w=%.17g\n", e.acc_n, e.gyr_n, e.acc_w, e.gyr_w);
+            std::printf("acc_n=%.17g\ngyr_n=%.17g\nacc_w=%.17g\ngyr_w=%.17g\nestimate=%d\n", e.acc_n, e.gyr_n, e.acc_w, e.gyr_w, e.estimate);
             std::printf("est_dynamic=%d\nest_use_det3d=%d\ninstance_init_min_num=%d\nstatic_inst_threshold=%.17g\nuse_line=%d\nline_min_obs=%d\n", e.dynamic, e.use_det3d, e.instance_init_min_num, e.static_inst_threshold, e.use_line, e.line_min_obs);
             for (int k = 0; k < 2; ++k) { const dv_cam& m = k ? f.cam1 : f.cam0; std::printf("cam%d=%.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", k, m.fx, m.fy, m.cx, m.cy, m.k1, m.k2, m.p1, m.p2); }
             for (int k = 0; k < 2; ++k) { std::printf("ric%d=", k); for (int i = 0; i < 9; ++i) std::printf("%.17g ", e.ric[k][i]); std::printf("\ntic%d=%.17g %.17g %.17g\n", k, e.tic[k][0], e.tic[k][1], e.tic[k][2]); }

@@ -52,6 +52,28 @@ def shim_config(exe, path):
     return dict(ln.split("=", 1) for ln in out.splitlines())
 
 
+def test_estimate_extrinsic_and_td_keys_reach_the_estimator_config(shim_exe, tmp_path):
+    """utils/parameters.cpp:82-99: estimate_extrinsic / estimate_td are read only with an IMU; 1 frees the blocks around the configured extrinsics (dv_est_config::estimate bit 0 / 1),
+    estimate_extrinsic 2 (calibration without an initial guess) is refused by the shim"""
+    import shutil
+    src = os.path.join(ROOT, "tests", "golden", "config")
+    for f in os.listdir(src):
+        if os.path.isfile(os.path.join(src, f)):
+            shutil.copy(os.path.join(src, f), tmp_path / f)
+    base = open(os.path.join(src, "zed_like.yaml")).read()
+    assert "estimate_extrinsic: 0" in base and "estimate_td: 0" in base and "\nimu: 1" in base
+    for ex, td, imu, want in ((0, 0, 1, "0"), (1, 0, 1, "1"), (0, 1, 1, "2"), (1, 1, 1, "3"), (1, 1, 0, "0"), (2, 0, 1, None)):
+        txt = base.replace("estimate_extrinsic: 0", "estimate_extrinsic: %d" % ex).replace("estimate_td: 0", "estimate_td: %d" % td).replace("\nimu: 1", "\nimu: %d" % imu)
+        path = tmp_path / "zed_like.yaml"
+        path.write_text(txt)
+        c = shim_config(shim_exe, str(path))
+        if want is None:
+            assert isinstance(c, str) and "estimate_extrinsic 2" in c, c
+        else:
+            assert not isinstance(c, str), c
+            assert c["estimate"] == want and c["use_imu"] == str(imu), (ex, td, imu, c["estimate"])
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="the reference's config tree is not on this machine")
 def test_every_shipped_yaml_constructs_the_shim_config(shim_exe):
     files = shipped_yamls()

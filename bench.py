@@ -513,7 +513,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 "second_block_ms_per_step": round(times[1] / args.steps * 1e3, 4), "second_block_value": round(dv_dist.whole_job_rate(args.steps, world, times[1]), 2),
                 "block_values": [round(dv_dist.whole_job_rate(args.steps, world, t), 2) for t in times],
                 "block_step_ms": frame_ms[: len(times)],
-                "warmup_requested": args.warmup, "git_head": git_head(),
+                "warmup_requested": args.warmup, "git_head": git_head(), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "host_loop": ("C++ (dv_runner)" if args.host_loop == "cpp" else "Python (pipeline.py)"),
                 "frames": ("pinned host buffers: the upload of every frame (2 x %d bytes, hipMemcpy2DAsync on the tracking stream) is inside the timed region" % (w * h)) if args.host_frames else "resident in HBM before the timed region",
                 "warmup_note": "at least 12 untimed BA frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"}

@@ -118,7 +118,7 @@ def run_multiseq_bench(args, rank, world, local_rank):
                "ms_per_step": round(dt / args.steps * 1e3, 4), "timed_region_s": round(dt, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{S} independent synthetic {w}x{h} stereo sequences per GPU @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "")
                                       + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame; a step = one frame of EVERY sequence",
-                          "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S,
+                          "mode": "raw", "config": args.config, "git_head": git_head(), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "sequences_per_gpu": S,
                           "parallelism": f"{S} sequences per GPU " + ("on one host thread each" if threaded else "interleaved by one host thread") + (", window solves batched (dv_batch: one launch per stage for all sequences)" if batch is not None else "") + f", own HIP streams, x {world} GPU(s); no collective",
                           "batch": (None if batch is None else batch.info()) if groups is None else dict(groups=2, **groups[0][1].info()),
                           "per_sequence_value": round(args.steps / dt, 2), "second_block_value": round(world * S * args.steps / times[1], 2),
@@ -249,7 +249,7 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
                "ms_per_step": round(dt / args.steps * 1e3, 4), "timed_region_s": round(dt, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": {"workload": f"{S} independent synthetic {w}x{h} stereo sequences per GPU @20 Hz" + (" + IMU @200 Hz" if cfg["use_imu"] else "")
                                       + f", max_cnt {cfg['max_cnt']}, min_dist {cfg['min_dist']}, {cfg['iters']} solver iterations, BA + marginalization on every frame; a step = one frame of EVERY sequence",
-                          "mode": "raw", "config": args.config, "git_head": git_head(), "sequences_per_gpu": S, "host_loop": "C++ (dv_runner)",
+                          "mode": "raw", "config": args.config, "git_head": git_head(), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "sequences_per_gpu": S, "host_loop": "C++ (dv_runner)",
                           "parallelism": f"{S} sequences per GPU, host loop in C++ on {max(1, getattr(args, 'runner_threads', 1))} thread(s)" + (f" ({max(1, getattr(args, 'runner_threads', 1)) // n_groups} per group)" if gsz > 1 and getattr(args, 'runner_threads', 1) > n_groups else "")
                                          + (f", window solves batched in dv_batch groups of {gsz} (one launch per stage for a group)" if gsz > 1 else ", every sequence on its own streams") + f", x {world} GPU(s); no collective",
                           "group_size": gsz, "runner_threads": max(1, getattr(args, "runner_threads", 1)), "host_threads_per_group": (max(1, threads) // n_groups if teams and gsz > 1 else 1), "teams": teams, "bit_identity": bit, "front_end_launches": dict(shared=not getattr(args, "no_batch_front", False) and gsz > 1, **runner.track_info()),

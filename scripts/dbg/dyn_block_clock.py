@@ -10,6 +10,16 @@ from dynamic_vins_amd.pipeline import DynamicPipeline, DynamicSequence
 warm = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 N = warm + 3 * K
+if os.environ.get('PRIMEQ'):          # make the runtime bring up its copy engines NOW: it creates an SDMA queue lazily (~6 ms, under a lock every other HIP call of the process waits for)
+    _n = int(os.environ['PRIMEQ'])      # the first time that many copies are in flight at once
+    _ss = [torch.cuda.Stream() for _ in range(_n)]
+    _h = [torch.empty(8 << 20, dtype=torch.uint8).pin_memory() for _ in range(_n)]
+    _d = [torch.empty(8 << 20, dtype=torch.uint8, device="cuda:0") for _ in range(_n)]
+    for _k in range(3):
+        for _s, _a, _b in zip(_ss, _h, _d):
+            with torch.cuda.stream(_s):
+                _b.copy_(_a, non_blocking=True); _a.copy_(_b, non_blocking=True)
+    torch.cuda.synchronize()
 seq = DynamicSequence(1280, 720, sim.ZED, N + 2, rate=20.0, device="cuda:0", boxes=("escort", 4))
 pipe = DynamicPipeline(seq, max_cnt=250, min_dist=25, max_iters=10, device=0, mask_morphology_size=5)
 r = Runner([pipe])

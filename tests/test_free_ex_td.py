@@ -204,3 +204,17 @@ def test_free_blocks_inside_a_dv_batch(gpu_ctx_factory):
     info = batch.info()
     assert info["single_rounds"] >= 10, info          # (openExEstimation opens with the first full window: every steady-state round of this batch ran on the members' own launches)
     batch.close()
+
+
+def test_unknown_bits_are_refused(ctx, oracle, gpu_ctx_factory):
+    from dynamic_vins_amd import sim
+    from dynamic_vins_amd.backend import Estimator, ba_solve
+    from dynamic_vins_amd.frontend import DvinsError
+    p = ba_gen.make_window(oracle, seed=38, nlm=40, max_iters=2)
+    p.c.free_blocks = 4
+    with pytest.raises(DvinsError, match="free_blocks"):
+        ba_solve(ctx, p)
+    p.c.free_blocks = 0
+    assert ba_solve(ctx, p).iterations >= 1          # the context is usable afterwards
+    with pytest.raises(DvinsError, match="estimate"):
+        Estimator(gpu_ctx_factory(width=64, height=64, max_cnt=10, min_dist=5), use_imu=1, stereo=1, max_iters=4, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], estimate=4)

@@ -60,6 +60,9 @@ SIGNATURES = {
     "dv_gftt": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f32p,
                           C.POINTER(C.c_int), C.c_int]),
     "dv_min_eigen": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
+    "dv_gftt_cuda": (C.c_int, [_ctx, _u8p, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, _f32p,
+                               C.POINTER(C.c_int), C.c_int]),
+    "dv_min_eigen_cuda": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_int]),
     "dv_viode_mask": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, _u8p, _u8p, C.c_void_p, C.c_void_p]),
     "dv_bgr2gray": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int]),
     "dv_remap": (C.c_int, [_ctx, _u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _u8p, C.c_int]),

@@ -38,6 +38,8 @@ struct DvTrackState {
     unsigned short* lk_order;   // scratch of dv_launch_lk_track: the points of the launch in position order
 };
 
+#define DV_GFTT_RULE_CPU 0
+#define DV_GFTT_RULE_CUDA 1
 struct GfttTileArgs {
     const uint8_t* img; int w, h, pitch;
     const uint8_t* in_mask; int mask_pitch;      // optional user mask (0 = excluded)
@@ -47,6 +49,7 @@ struct GfttTileArgs {
     int min_new;
     float* eig_out; int eig_pitch;               // optional: write the eigenvalue image (elements)
     DvCand* cand; int cand_cap; int* n_cand; unsigned* max_ord;
+    int rule;                                    // DV_GFTT_RULE_CPU (cv::goodFeaturesToTrack) | DV_GFTT_RULE_CUDA (cv::cuda::GoodFeaturesToTrackDetector: TrackImageNaive)
 };
 
 struct GfttSelectArgs {
@@ -57,6 +60,7 @@ struct GfttSelectArgs {
     DvTrackState tr; int has_tr;                                   // tracker epilogue: append corners, assign ids (1), or append and leave (old n_feat, accepted) in id_slot (2):
     int* err_flag;                                                 // the ids of several jobs drawing on ONE counter are handed out afterwards, in job order (dv_launch_gftt_assign_ids)
     int* id_slot;
+    int rule;                                                      // as GfttTileArgs::rule
 };
 
 struct dv_ctx;

@@ -318,6 +318,9 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
         dv_launch_compact(ctx->tr, naive ? mask_dev : nullptr, mask_pitch, naive ? 0 : 1, ctx->n_cand, ctx->max_ord, s);
     }
     const int min_new = naive ? 10 : 1;                   // Q23: instance_feature.cpp:353-356 vs background_tracker.cpp:82-90
+    // DetectNewFeature(img, use_gpu, ...): TrackImageNaive passes true (background_tracker.cpp:445) -> DetectShiTomasiCornersGpu (feature_utils.cpp:339-348),
+    // TrackSemanticImage passes false (:789) and TrackImage calls cv::goodFeaturesToTrack itself (:85)
+    const int gftt_rule = (mode == DV_MODE_NAIVE) ? DV_GFTT_RULE_CUDA : DV_GFTT_RULE_CPU;
     {
         StageScope sc(ctx, "gftt_eig");
         GfttTileArgs a{};
@@ -327,6 +330,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
         a.n_feat = ctx->tr.n_feat; a.max_cnt = c.max_cnt; a.min_new = min_new;
         a.eig_out = nullptr; a.eig_pitch = 0;
         a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord;
+        a.rule = gftt_rule;
         dv_launch_gftt_tile(a, s);
     }
     {
@@ -335,7 +339,7 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
         a.cand = (const DvCand*)ctx->cand_buf.p; a.n_cand = ctx->n_cand; a.cand_cap = ctx->cand_cap; a.max_ord = ctx->max_ord;
         a.w = w; a.h = h; a.quality = 0.01; a.min_dist = (double)c.min_dist;
         a.max_n_host = 0; a.n_feat = ctx->tr.n_feat; a.max_cnt = c.max_cnt; a.min_new = min_new;
-        a.out_xy = nullptr; a.n_out = nullptr; a.tr = ctx->tr; a.has_tr = 1; a.err_flag = ctx->err_flag;
+        a.out_xy = nullptr; a.n_out = nullptr; a.tr = ctx->tr; a.has_tr = 1; a.err_flag = ctx->err_flag; a.rule = gftt_rule;
         if (dv_launch_gftt_select(a, s)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
     }
     if (ctx->inst) DV_CHECK(hipEventRecord(ctx->ev_bg_select, s));
@@ -682,7 +686,7 @@ int dv_pyr_down_cuda(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, 
     return 0;
 }
 
-int dv_min_eigen(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem) {
+static int min_eigen_rule(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem, int rule) {
     if (!ctx) return -1;
     if (!img || !eig) DV_FAIL("dv_min_eigen: null argument");
     DV_CHECK(hipSetDevice(ctx->cfg.device));
@@ -694,7 +698,7 @@ int dv_min_eigen(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, floa
     DV_CHECK(hipMemsetAsync(ctx->n_cand, 0, 8, ctx->stream));     // n_cand + max_ord
     GfttTileArgs a{};
     a.img = d_img; a.w = w; a.h = h; a.pitch = pitch; a.eig_out = d_eig; a.eig_pitch = w;
-    a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord;
+    a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord; a.rule = rule;
     dv_launch_gftt_tile(a, ctx->stream);
     DV_CHECK(hipGetLastError());
     if (mem != DV_MEM_DEVICE) DV_CHECK(hipMemcpyAsync(eig, d_eig, (size_t)w * h * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -702,8 +706,11 @@ int dv_min_eigen(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, floa
     return 0;
 }
 
-int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w, int h, int stride, int max_n, double quality,
-            double min_dist, float* out_xy, int* n_out, int mem) {
+int dv_min_eigen(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem) { return min_eigen_rule(ctx, img, w, h, stride, eig, mem, DV_GFTT_RULE_CPU); }
+int dv_min_eigen_cuda(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem) { return min_eigen_rule(ctx, img, w, h, stride, eig, mem, DV_GFTT_RULE_CUDA); }
+
+static int gftt_rule_op(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w, int h, int stride, int max_n, double quality,
+                        double min_dist, float* out_xy, int* n_out, int mem, int rule) {
     if (!ctx) return -1;
     if (!img || !out_xy || !n_out) DV_FAIL("dv_gftt: null argument");
     if (!(quality > 0)) DV_FAIL("dv_gftt: qualityLevel must be > 0");
@@ -718,12 +725,12 @@ int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w,
     DV_CHECK(hipMemsetAsync(ctx->n_cand, 0, 12, ctx->stream));    // n_cand, max_ord, err_flag
     GfttTileArgs a{};
     a.img = d_img; a.w = w; a.h = h; a.pitch = pitch; a.in_mask = d_mask; a.mask_pitch = mpitch;
-    a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord;
+    a.cand = (DvCand*)ctx->cand_buf.p; a.cand_cap = ctx->cand_cap; a.n_cand = ctx->n_cand; a.max_ord = ctx->max_ord; a.rule = rule;
     dv_launch_gftt_tile(a, ctx->stream);
     GfttSelectArgs sa{};
     sa.cand = (const DvCand*)ctx->cand_buf.p; sa.n_cand = ctx->n_cand; sa.cand_cap = ctx->cand_cap; sa.max_ord = ctx->max_ord;
     sa.w = w; sa.h = h; sa.quality = quality; sa.min_dist = min_dist; sa.max_n_host = max_n; sa.n_feat = nullptr;
-    sa.out_xy = d_out; sa.n_out = d_n; sa.has_tr = 0; sa.err_flag = ctx->err_flag;
+    sa.out_xy = d_out; sa.n_out = d_n; sa.has_tr = 0; sa.err_flag = ctx->err_flag; sa.rule = rule;
     if (dv_launch_gftt_select(sa, ctx->stream)) DV_FAIL("gftt_select: cannot set dynamic LDS size");
     DV_CHECK(hipGetLastError());
     int n = 0, ef = 0;
@@ -735,6 +742,15 @@ int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w,
     DV_CHECK(hipStreamSynchronize(ctx->stream));
     *n_out = n;
     return 0;
+}
+
+int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w, int h, int stride, int max_n, double quality,
+            double min_dist, float* out_xy, int* n_out, int mem) {
+    return gftt_rule_op(ctx, img, mask_or_null, w, h, stride, max_n, quality, min_dist, out_xy, n_out, mem, DV_GFTT_RULE_CPU);
+}
+int dv_gftt_cuda(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w, int h, int stride, int max_n, double quality,
+                 double min_dist, float* out_xy, int* n_out, int mem) {
+    return gftt_rule_op(ctx, img, mask_or_null, w, h, stride, max_n, quality, min_dist, out_xy, n_out, mem, DV_GFTT_RULE_CUDA);
 }
 
 int dv_viode_mask(dv_ctx* ctx, const uint8_t* seg_bgr, int w, int h, int stride, const uint32_t* dyn_keys, int nkeys, uint8_t* merge_mask, uint8_t* inv_merge_mask,

@@ -57,6 +57,11 @@ __device__ __forceinline__ int gftt_xcd_tile(int lin, int nt) {
     for (int y = 0; y < xc; ++y) start += nt > y ? (nt - y + 7) >> 3 : 0;
     return start + k;
 }
+// RULE 0: cv::goodFeaturesToTrack's response map and masked maximum.  RULE 1: the response map and the UNMASKED maximum of cv::cuda::GoodFeaturesToTrackDetector
+// (cudaimgproc gftt.cpp / corners.cu; DetectShiTomasiCornersGpu, feature_utils.cpp:339-348 — TrackImageNaive's detector): the separable Sobel as a float
+// multiply-add chain over the taps in order, the nine products of a block accumulated in raster order by fused multiply-adds, the closed form in float
+// (choice D6: nvcc's default contraction, written out as fmaf here — the library is compiled with -ffp-contract=off).
+template <int RULE>
 __device__ __forceinline__ void gftt_tile_body(const GfttTileArgs& a, int tx, int ty) {
     __shared__ uint8_t s_img[IMG_H * IMG_PITCH];
     __shared__ float s_cov[3][COV_H][COV_W];
@@ -102,11 +107,18 @@ __device__ __forceinline__ void gftt_tile_body(const GfttTileArgs& a, int tx, in
             int a1 = p[-1], c1 = p[1];
             int a2 = p[IMG_PITCH - 1], b2 = p[IMG_PITCH], c2 = p[IMG_PITCH + 1];
             float d0 = (float)(c0 - a0), d1 = (float)(c1 - a1), d2 = (float)(c2 - a2);
-            float dx = (d0 + d2) * k1 + d1 * k2;
-            float s0 = (k1 * (float)a0 + k2 * (float)b0) + k1 * (float)c0;
-            float s2 = (k1 * (float)a2 + k2 * (float)b2) + k1 * (float)c2;
-            float dy = s2 - s0;
-            xx = dx * dx; xy = dx * dy; yy = dy * dy;
+            if (RULE == 0) {
+                float dx = (d0 + d2) * k1 + d1 * k2;
+                float s0 = (k1 * (float)a0 + k2 * (float)b0) + k1 * (float)c0;
+                float s2 = (k1 * (float)a2 + k2 * (float)b2) + k1 * (float)c2;
+                float dy = s2 - s0;
+                xx = dx * dx; xy = dx * dy; yy = dy * dy;
+            } else {      // the derivatives themselves (xx <- Dx, xy <- Dy): the block sums below need them, not their products
+                xx = fmaf(d2, k1, fmaf(d1, k2, d0 * k1));                                             // column chain over the exact row differences
+                const float r0 = fmaf((float)c0, k1, fmaf((float)b0, k2, (float)a0 * k1));      // row chains [1 2 1] * scale of the rows above and below
+                const float r2 = fmaf((float)c2, k1, fmaf((float)b2, k2, (float)a2 * k1));
+                xy = r2 - r0;                                                                          // column kernel [-1 0 1]: -r0, + 0 * r1, + r2
+            }
         }
         s_cov[0][r][c] = xx; s_cov[1][r][c] = xy; s_cov[2][r][c] = yy;
     }
@@ -117,16 +129,30 @@ __device__ __forceinline__ void gftt_tile_body(const GfttTileArgs& a, int tx, in
         int lx = x0 - 1 + c, ly = y0 - 1 + r;
         float e = -FLT_MAX;
         if (lx >= 0 && lx < w && ly >= 0 && ly < h) {
-            float bx[3];
+            if (RULE == 0) {
+                float bx[3];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                double rs0 = ((double)s_cov[k][r][c] + (double)s_cov[k][r][c + 1]) + (double)s_cov[k][r][c + 2];
-                double rs1 = ((double)s_cov[k][r + 1][c] + (double)s_cov[k][r + 1][c + 1]) + (double)s_cov[k][r + 1][c + 2];
-                double rs2 = ((double)s_cov[k][r + 2][c] + (double)s_cov[k][r + 2][c + 1]) + (double)s_cov[k][r + 2][c + 2];
-                bx[k] = (float)((rs0 + rs1) + rs2);
+                for (int k = 0; k < 3; ++k) {
+                    double rs0 = ((double)s_cov[k][r][c] + (double)s_cov[k][r][c + 1]) + (double)s_cov[k][r][c + 2];
+                    double rs1 = ((double)s_cov[k][r + 1][c] + (double)s_cov[k][r + 1][c + 1]) + (double)s_cov[k][r + 1][c + 2];
+                    double rs2 = ((double)s_cov[k][r + 2][c] + (double)s_cov[k][r + 2][c + 1]) + (double)s_cov[k][r + 2][c + 2];
+                    bx[k] = (float)((rs0 + rs1) + rs2);
+                }
+                float A = bx[0] * 0.5f, B = bx[1], C = bx[2] * 0.5f;
+                e = (A + C) - sqrtf((A - C) * (A - C) + B * B);
+            } else {      // cornerMinEigenVal_kernel: a += dx * dx; b += dx * dy; c += dy * dy over the block in raster order
+                float A = 0.f, B = 0.f, C = 0.f;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float dx = s_cov[0][r + i][c + j], dy = s_cov[1][r + i][c + j];
+                        A = fmaf(dx, dx, A); B = fmaf(dx, dy, B); C = fmaf(dy, dy, C);
+                    }
+                A *= 0.5f; C *= 0.5f;
+                const float d = A - C;
+                e = (A + C) - sqrtf(fmaf(d, d, B * B));
             }
-            float A = bx[0] * 0.5f, B = bx[1], C = bx[2] * 0.5f;
-            e = (A + C) - sqrtf((A - C) * (A - C) + B * B);
         }
         s_eig[r][c] = e;
     }
@@ -155,9 +181,10 @@ __device__ __forceinline__ void gftt_tile_body(const GfttTileArgs& a, int tx, in
                 }
             }
         }
+        if (RULE == 1) vmax = max(vmax, f2ord(v));      // cuda::minMax(eig_, 0, &maxVal): no mask
         if (!m) continue;
-        vmax = max(vmax, f2ord(v));
-        if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1 || v == 0.f) continue;
+        if (RULE == 0) vmax = max(vmax, f2ord(v));      // minMaxLoc(eig, 0, &maxVal, 0, 0, mask)
+        if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1 || (RULE == 0 && v == 0.f)) continue;
         float nb[8] = { s_eig[r][c], s_eig[r][c + 1], s_eig[r][c + 2], s_eig[r + 1][c], s_eig[r + 1][c + 2],
                         s_eig[r + 2][c], s_eig[r + 2][c + 1], s_eig[r + 2][c + 2] };
         float mx = nb[0], mn = nb[0];
@@ -182,9 +209,10 @@ __device__ __forceinline__ void gftt_tile_body(const GfttTileArgs& a, int tx, in
     __syncthreads();
     for (int i = tid; i < nc; i += 256) { const int k = s_base + i; if (k < a.cand_cap) a.cand[k] = s_cand[i]; }
 }
+template <int RULE>
 __global__ __launch_bounds__(256) void gftt_tile_kernel(GfttTileArgs a) {
     const int gx = gridDim.x, t = gftt_xcd_tile(blockIdx.y * gx + blockIdx.x, gridDim.x * gridDim.y);
-    gftt_tile_body(a, t % gx, t / gx);
+    gftt_tile_body<RULE>(a, t % gx, t / gx);
 }
 // several images of ONE size in one launch (the front ends of a dv_batch group): the launch's tiles are numbered image-major, and every XCD takes a contiguous
 // run of that sequence — whole images or raster runs of one
@@ -193,7 +221,7 @@ __global__ __launch_bounds__(256) void gftt_tile_multi_kernel(const GfttTileArgs
     const GfttTileArgs a = tab[job];
     const int tx = tt % gx, ty = tt / gx;
     if (tx * TW >= a.w || ty * TH >= a.h) return;      // (gx, gy) cover the largest image of the table: the objects' ROIs differ in size
-    gftt_tile_body(a, tx, ty);
+    gftt_tile_body<0>(a, tx, ty);      // shared launches exist for DV_MODE_RAW only
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -242,7 +270,7 @@ __device__ __forceinline__ void gftt_select_body(const GfttSelectArgs& a) {
     auto valid_bin = [&](const DvCand& c) -> int {
         float v = ord2f((unsigned)(c.key >> 32));
         if (!(v > thr)) return -1;
-        if (v < 0.f && !(c.min_nb > thr)) return -1;
+        if (a.rule == 0 && v < 0.f && !(c.min_nb > thr)) return -1;      // (rule 1, findCorners: eig > threshold and eig == max of the raw neighbourhood, nothing else)
         int b = (int)((v - thr) * bscale);
         return min(max(b, 0), SEL_BINS - 1);
     };
@@ -409,7 +437,8 @@ static size_t select_smem_bytes() {
 
 void dv_launch_gftt_tile(const GfttTileArgs& a, hipStream_t s) {
     dim3 grid((a.w + TW - 1) / TW, (a.h + TH - 1) / TH);
-    hipLaunchKernelGGL(gftt_tile_kernel, grid, dim3(256), 0, s, a);
+    if (a.rule == DV_GFTT_RULE_CUDA) hipLaunchKernelGGL(gftt_tile_kernel<1>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gftt_tile_kernel<0>, grid, dim3(256), 0, s, a);
 }
 
 void dv_launch_gftt_tile_multi(const GfttTileArgs* tab_dev, int n_jobs, int w, int h, hipStream_t s) {

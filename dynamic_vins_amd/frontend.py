@@ -191,18 +191,19 @@ class Context:
         self._check(self.lib.dv_pyr_down_cuda(self.h, _ptr(img), w, h, img.strides[0], _ptr(dst), DV_MEM_HOST))
         return dst
 
-    def gftt(self, img, max_n, quality, min_dist, mask=None):
+    def gftt(self, img, max_n, quality, min_dist, mask=None, rule="cpu"):
+        """rule "cpu": cv::goodFeaturesToTrack (dv_gftt); "cuda": cv::cuda::GoodFeaturesToTrackDetector, TrackImageNaive's detector (dv_gftt_cuda)"""
         h, w = img.shape
         out = np.zeros((_abi.DV_MAX_FEATS, 2), np.float32)
         n = C.c_int(0)
-        self._check(self.lib.dv_gftt(self.h, _ptr(img), _ptr(mask), w, h, img.strides[0], int(max_n), float(quality), float(min_dist),
+        self._check((self.lib.dv_gftt_cuda if rule == "cuda" else self.lib.dv_gftt)(self.h, _ptr(img), _ptr(mask), w, h, img.strides[0], int(max_n), float(quality), float(min_dist),
                                      _ptr(out), C.byref(n), DV_MEM_HOST))
         return out[: n.value].copy()
 
-    def min_eigen(self, img):
+    def min_eigen(self, img, rule="cpu"):
         h, w = img.shape
         eig = np.zeros((h, w), np.float32)
-        self._check(self.lib.dv_min_eigen(self.h, _ptr(img), w, h, img.strides[0], _ptr(eig), DV_MEM_HOST))
+        self._check((self.lib.dv_min_eigen_cuda if rule == "cuda" else self.lib.dv_min_eigen)(self.h, _ptr(img), w, h, img.strides[0], _ptr(eig), DV_MEM_HOST))
         return eig
 
     def viode_mask(self, seg_bgr, dyn_keys, want_keys=True):

@@ -112,6 +112,15 @@ int dv_gftt(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w,
             int max_n, double quality, double min_dist, float* out_xy, int* n_out, int mem);
 /* cv::cornerMinEigenVal(img, eig, 3, 3) (inside goodFeaturesToTrack) */
 int dv_min_eigen(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem);
+/* The reference's GPU corner detector, used by dv_track_stereo* where the reference uses it (DV_MODE_NAIVE only: DetectNewFeature(img, use_gpu = true, ...),
+ * front_end/background_tracker.cpp:445 -> front_end/instance_feature.cpp:372-379 -> DetectShiTomasiCornersGpu, front_end/feature_utils.cpp:339-348):
+ * cv::cuda::createGoodFeaturesToTrackDetector(CV_8UC1, max_n, quality, min_dist)->detect(img, out, mask).  Against dv_gftt: the response map is the GPU module's
+ * (float multiply-add chains, block sums inside the eigenvalue kernel), the quality threshold comes from the maximum over the WHOLE image (the CPU detector takes
+ * it under the mask), candidates are eig > threshold && eig == max of the raw 3 x 3 neighbourhood; the ordering and the minimum-distance grid are the same.
+ * dv_min_eigen_cuda: cv::cuda::createMinEigenValCorner(CV_8UC1, 3, 3)->compute.  Operator forms. */
+int dv_gftt_cuda(dv_ctx* ctx, const uint8_t* img, const uint8_t* mask_or_null, int w, int h, int stride,
+                 int max_n, double quality, double min_dist, float* out_xy, int* n_out, int mem);
+int dv_min_eigen_cuda(dv_ctx* ctx, const uint8_t* img, int w, int h, int stride, float* eig, int mem);
 /* cv::pyrDown (inside buildOpticalFlowPyramid); dst is ((w+1)/2) x ((h+1)/2), tightly packed */
 int dv_pyr_down(dv_ctx* ctx, const uint8_t* src, int w, int h, int stride, uint8_t* dst, int mem);
 /* VIODE segmentation image -> instance masks (VIODE::SetViodeMaskSimple / BuildViodeMask, utils/dataset/viode_utils.cpp:21-170).

@@ -28,7 +28,10 @@ void dvo_set_threads(int n);
  *   "lk_sums":   0 exact int64 window sums (D1) | 1 float accumulation in OpenCV's scalar (raster) order | 2 four float partial sums by x mod 4, combined (a 4-wide SIMD order)
  *   "box_sums":  0 3x3 covariance box sums in double, fixed order (D2) | 1 in float
  *   "f4_cpu_rule": 0 the reference's GPU tracker (cv::cuda::SparsePyrLKOpticalFlow restated, lk_cuda.cpp) where the reference uses it | 1 the CPU LK arithmetic with FeatureTrackByLKGpu's 1.0 px threshold
- *   "radius":    0 Ceres' dogleg radius rule (quality < 0.25: x 0.5; > 0.75: max(radius, 3 |step|)) | 1 the Levenberg-style reading (> 0.75: radius x 3) */
+ *   "radius":    0 Ceres' dogleg radius rule (quality < 0.25: x 0.5; > 0.75: max(radius, 3 |step|)) | 1 the Levenberg-style reading (> 0.75: radius x 3)
+ *   "f5_cpu_rule": 0 the reference's GPU corner detector (cv::cuda::GoodFeaturesToTrackDetector restated, gftt_cuda.cpp) in TrackImageNaive | 1 cv::goodFeaturesToTrack's rule there (rounds 1-5)
+ *   "gftt_cuda_fma": 0 the GPU detector's float chains contracted to fused multiply-adds (nvcc's default) | 1 no contraction
+ *   "gftt_cuda_tie": 0 corners of equal response in address-descending order | 1 ascending (the library's order is the kernel schedule) */
 void dvo_set_variant(const char* key, int value);
 int dvo_get_variant(const char* key);
 int dvo_get_threads(void);
@@ -98,6 +101,11 @@ void dvo_min_eigen(const uint8_t* img, int w, int h, float* eig);
 /* cv::goodFeaturesToTrack(img, out, max_n, quality, min_dist, mask) ; mask may be NULL */
 void dvo_gftt(const uint8_t* img, const uint8_t* mask, int w, int h, int max_n,
               double quality, double min_dist, float* out_xy, int* n_out);
+
+/* cv::cuda::createGoodFeaturesToTrackDetector(CV_8UC1, max_n, quality, min_dist)->detect(img, out, mask) (DetectShiTomasiCornersGpu, feature_utils.cpp:339-348)
+ * and its response map cuda::createMinEigenValCorner(CV_8UC1, 3, 3)->compute (gftt_cuda.cpp) */
+void dvo_gftt_cuda(const uint8_t* img, const uint8_t* mask, int w, int h, int max_n, double quality, double min_dist, float* out_xy, int* n_out);
+void dvo_min_eigen_cuda(const uint8_t* img, int w, int h, float* eig);
 
 /* cv::circle(mask, Point(cvRound(x),cvRound(y)), radius, 0, -1) for each point */
 void dvo_circle_mask(uint8_t* mask, int w, int h, const float* pts_xy, int n, int radius);

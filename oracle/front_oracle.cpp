@@ -41,14 +41,16 @@ static int g_threads = 1;      // dvo_set_threads: CPU-baseline timing only; res
 extern "C" void dvo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 extern "C" int dvo_get_threads() { return g_threads; }
 // sensitivity variants (dvo.h): process-wide switches, read by the stages they belong to
-int g_var_lk_sums = 0, g_var_box_sums = 0, g_var_radius = 0, g_var_f4_cpu = 0;      // "f4_cpu_rule" 1: naive / semantic modes track with the CPU arithmetic + the 1.0 px threshold (the substitution of rounds 1-3) instead of the GPU tracker (lk_cuda.cpp)
+int g_var_lk_sums = 0, g_var_box_sums = 0, g_var_radius = 0, g_var_f4_cpu = 0, g_var_f5_cpu = 0, g_var_gc_fma = 0, g_var_gc_tie = 0;      // "f4_cpu_rule" 1: naive / semantic modes track with the CPU arithmetic + the 1.0 px threshold (the substitution of rounds 1-3) instead of the GPU tracker (lk_cuda.cpp)
 extern "C" void dvo_set_variant(const char* key, int value) {
     const std::string k = key ? key : "";
     if (k == "lk_sums") g_var_lk_sums = value; else if (k == "box_sums") g_var_box_sums = value; else if (k == "radius") g_var_radius = value; else if (k == "f4_cpu_rule") g_var_f4_cpu = value;
+    else if (k == "f5_cpu_rule") g_var_f5_cpu = value; else if (k == "gftt_cuda_fma") g_var_gc_fma = value; else if (k == "gftt_cuda_tie") g_var_gc_tie = value;      // gftt_cuda.cpp
 }
 extern "C" int dvo_get_variant(const char* key) {
     const std::string k = key ? key : "";
-    return k == "lk_sums" ? g_var_lk_sums : k == "box_sums" ? g_var_box_sums : k == "radius" ? g_var_radius : k == "f4_cpu_rule" ? g_var_f4_cpu : -1;
+    return k == "lk_sums" ? g_var_lk_sums : k == "box_sums" ? g_var_box_sums : k == "radius" ? g_var_radius : k == "f4_cpu_rule" ? g_var_f4_cpu :
+           k == "f5_cpu_rule" ? g_var_f5_cpu : k == "gftt_cuda_fma" ? g_var_gc_fma : k == "gftt_cuda_tie" ? g_var_gc_tie : -1;
 }
 // A persistent worker pool standing in for OpenCV's parallel_for_ back end (the reference links OpenCV 3.4 built with a thread pool: calcOpticalFlowPyrLK runs
 // its LKTrackerInvoker over ranges of points, pyrDown / the corner response over ranges of rows).  Spawning std::threads per level — the round-2 form — cost
@@ -589,7 +591,12 @@ struct dvo_tracker {
         if (detect) {
             for (auto& p : curr_points) circle_zero(mask.data(), w, h, cv_round(p.x), cv_round(p.y), cfg.min_dist);
             std::vector<P2f> npts;
-            gftt(g0, mask.data(), w, h, n_max, 0.01, cfg.min_dist, npts);
+            if (mode == 1 && !g_var_f5_cpu) {                       // DetectNewFeature(img, use_gpu = true, ...) (background_tracker.cpp:445): the GPU detector (gftt_cuda.cpp); variant "f5_cpu_rule": the CPU detector (rounds 1-5)
+                npts.resize((size_t)std::max(n_max, 0)); int nn = 0;
+                dvo_gftt_cuda(g0, mask.data(), w, h, n_max, 0.01, cfg.min_dist, npts.empty() ? nullptr : &npts[0].x, &nn);
+                npts.resize((size_t)nn);
+            } else
+                gftt(g0, mask.data(), w, h, n_max, 0.01, cfg.min_dist, npts);
             for (auto& p : npts) { curr_points.push_back(p); ids.push_back(global_id_count++); track_cnt.push_back(1); }
         }
         undistort(cfg.cam0, curr_points, curr_un);

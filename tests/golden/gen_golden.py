@@ -263,9 +263,47 @@ def gen_aux(o):
     print("aux_kat.npz: obj", out["obj_a_summary"], out["obj_b_summary"], "line", out["line_summary"])
 
 
+def gen_gftt_cuda(o):
+    """5. gftt_cuda_kat.npz — the reference's GPU corner detector (row F5: cv::cuda::GoodFeaturesToTrackDetector as TrackImageNaive calls it, oracle/gftt_cuda.cpp):
+    response map, corners without / with a mask whose excluded region holds the strongest response (the threshold is NOT taken under the mask), and six frames of
+    TrackImageNaive rows (GPU tracker + GPU detector)."""
+    from dynamic_vins_amd import sim, synth
+    W, H = 128, 96
+    seq = synth.PlaneSequence(W, H, seed=0xD1CE, disparity=3.25, margin=48)
+    frames = [seq.frame(k) for k in range(6)]
+    img = frames[0][0].copy()
+    img[60:76, 90:106] = 0
+    img[68:76, 98:106] = 255                                     # a full-contrast corner: the strongest response of the frame by a wide margin
+    mask = np.full((H, W), 255, np.uint8)
+    mask[52:84, 82:114] = 0                                       # ... excluded by the mask
+    out = dict(img=img, mask=mask, left=np.array([f[0] for f in frames]), right=np.array([f[1] for f in frames]))
+    out["min_eigen"] = o.min_eigen(img, rule="cuda")
+    out["corners_nomask"] = o.gftt(img, 40, 0.01, 8, None, rule="cuda")
+    out["corners_mask"] = o.gftt(img, 1000, 0.01, 3, mask, rule="cuda")          # 383 corners: 1 % of the response of the excluded corner
+    out["corners_mask_cpu_rule"] = o.gftt(img, 1000, 0.01, 3, mask)                  # 459: 1 % of the strongest response under the mask
+    cam = sim.scaled_cam(sim.ZED, W, H, 1280, 720)
+    out["cam"] = np.array(sim.cam_tuple(cam))
+    trk = o.tracker(W, H, 30, 10, 1, 1, sim.cam_tuple(cam), sim.cam_tuple(cam))
+    tmask = np.full((H, W), 255, np.uint8)
+    tmask[30:60, 50:90] = 0
+    out["track_mask"] = tmask
+    rows = []
+    for k, (l, r) in enumerate(frames):
+        rw = trk.track_image(l, r, 1.0 + 0.05 * k, mask=tmask, mode=1)
+        pad = np.zeros(64, rw.dtype)
+        pad[: len(rw)] = rw
+        rows.append(pad)
+        out.setdefault("track_n", []).append(len(rw))
+    trk.close()
+    out["track_rows"] = np.array([r.view(np.uint8).reshape(64, 128) for r in rows])
+    out["track_n"] = np.array(out["track_n"])
+    np.savez_compressed(os.path.join(HERE, "gftt_cuda_kat.npz"), **out)
+    print("gftt_cuda_kat.npz: corners", len(out["corners_nomask"]), len(out["corners_mask"]), "cpu rule under the same mask", len(out["corners_mask_cpu_rule"]), "naive rows", out["track_n"])
+
+
 if __name__ == "__main__":
     import oracle_py
-    which = sys.argv[1:] or ["ate", "front", "back", "aux"]
+    which = sys.argv[1:] or ["ate", "front", "back", "aux", "gftt_cuda"]
     if "ate" in which:
         gen_ate()
         gen_associate()
@@ -276,3 +314,5 @@ if __name__ == "__main__":
         gen_back(o)
     if "aux" in which:
         gen_aux(o)
+    if "gftt_cuda" in which:
+        gen_gftt_cuda(o)

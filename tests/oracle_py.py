@@ -49,6 +49,8 @@ class Oracle:
         lib.dvo_track_by_lk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
         lib.dvo_gftt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.POINTER(C.c_int)]
         lib.dvo_min_eigen.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.dvo_gftt_cuda.argtypes = lib.dvo_gftt.argtypes
+        lib.dvo_min_eigen_cuda.argtypes = lib.dvo_min_eigen.argtypes
         lib.dvo_pyr_down.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.dvo_scharr.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.dvo_circle_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int]
@@ -117,21 +119,22 @@ class Oracle:
         self.lib.dvo_track_by_lk(_p(a), _p(b), w, h, _p(pts1), n, int(flow_back), dist_thresh, _p(pts2), _p(st))
         return pts2, st
 
-    def gftt(self, img, max_n, quality, min_dist, mask=None):
+    def gftt(self, img, max_n, quality, min_dist, mask=None, rule="cpu"):
+        """rule "cpu": cv::goodFeaturesToTrack; "cuda": cv::cuda::GoodFeaturesToTrackDetector (oracle/gftt_cuda.cpp)"""
         h, w = img.shape
         img = np.ascontiguousarray(img)
         if mask is not None:
             mask = np.ascontiguousarray(mask)
         out = np.zeros((max(h * w // 4, 16), 2), np.float32)
         n = C.c_int(0)
-        self.lib.dvo_gftt(_p(img), _p(mask), w, h, int(max_n), float(quality), float(min_dist), _p(out), C.byref(n))
+        (self.lib.dvo_gftt_cuda if rule == "cuda" else self.lib.dvo_gftt)(_p(img), _p(mask), w, h, int(max_n), float(quality), float(min_dist), _p(out), C.byref(n))
         return out[: n.value].copy()
 
-    def min_eigen(self, img):
+    def min_eigen(self, img, rule="cpu"):
         h, w = img.shape
         img = np.ascontiguousarray(img)
         eig = np.zeros((h, w), np.float32)
-        self.lib.dvo_min_eigen(_p(img), w, h, _p(eig))
+        (self.lib.dvo_min_eigen_cuda if rule == "cuda" else self.lib.dvo_min_eigen)(_p(img), w, h, _p(eig))
         return eig
 
     def circle_mask(self, mask, pts, radius):

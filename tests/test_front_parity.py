@@ -128,6 +128,61 @@ def test_gftt_empty_and_flat(ctx, oracle):
     assert len(ctx.gftt(img, 10, 0.01, 5, zero_mask)) == 0 == len(oracle.gftt(img, 10, 0.01, 5, zero_mask))
 
 
+@pytest.mark.parametrize("hw", [(240, 320), (480, 752), (375, 1242), (720, 1280), (65, 130), (16, 64), (17, 65)])
+def test_min_eigen_cuda_bit_exact(ctx, oracle, hw):
+    """cv::cuda::createMinEigenValCorner(CV_8UC1, 3, 3): the GPU detector's response map (row F5, oracle/gftt_cuda.cpp) — float multiply-add chains, bit for bit"""
+    img = _img(hw[0], hw[1], 11)
+    got = ctx.min_eigen(img, rule="cuda")
+    ref = oracle.min_eigen(img, rule="cuda")
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    assert not np.array_equal(ref.view(np.uint32), oracle.min_eigen(img).view(np.uint32))      # ... and not the CPU detector's map
+
+
+@pytest.mark.parametrize("hw,max_n,md", [((240, 320), 150, 15), ((480, 752), 150, 30), ((375, 1242), 250, 25), ((720, 1280), 250, 25), ((240, 320), 0, 8),
+                                         ((240, 320), 40, 4), ((240, 320), 500, 0)])
+def test_gftt_cuda_exact(ctx, oracle, hw, max_n, md):
+    """DetectShiTomasiCornersGpu (feature_utils.cpp:339-348): cv::cuda::GoodFeaturesToTrackDetector::detect, without and with a mask that hides the strongest corners
+    (the threshold is 1 % of the maximum over the whole image, not of the maximum under the mask)"""
+    img = _img(hw[0], hw[1], 5)
+    got = ctx.gftt(img, max_n, 0.01, md, rule="cuda")
+    ref = oracle.gftt(img, max_n if max_n > 0 else 1024, 0.01, md, rule="cuda")
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    mask = np.full(hw, 255, np.uint8)
+    top = oracle.gftt(img, 30, 0.01, max(md, 4), rule="cuda")
+    mask = oracle.circle_mask(mask, top, 12)                   # discs over the 30 strongest corners
+    mask[hw[0] // 3: hw[0] // 2, hw[1] // 4: hw[1] // 2] = 0
+    got = ctx.gftt(img, max_n, 0.01, md, mask, rule="cuda")
+    ref = oracle.gftt(img, max_n if max_n > 0 else 1024, 0.01, md, mask, rule="cuda")
+    assert got.shape == ref.shape and np.array_equal(got, ref)
+    assert len(got) > 0 and (mask[got[:, 1].astype(int), got[:, 0].astype(int)] != 0).all()
+
+
+def test_gftt_cuda_masked_720p_chunked_and_degenerate(ctx, oracle):
+    """720p with a low quality level (more surviving candidates than one LDS chunk holds), the tracker's analytic discs expressed as a mask, and the degenerate inputs"""
+    img = _img(720, 1280, 9)
+    rng = np.random.default_rng(2)
+    mask = np.full((720, 1280), 255, np.uint8)
+    mask[100:300, 200:700] = 0
+    pts = rng.uniform([0, 0], [1280, 720], (120, 2)).astype(np.float32)
+    mask = oracle.circle_mask(mask, pts, 25)
+    got = ctx.gftt(img, 1000, 0.001, 6, mask, rule="cuda")
+    ref = oracle.gftt(img, 1000, 0.001, 6, mask, rule="cuda")
+    assert np.array_equal(got, ref) and len(got) == 1000
+    flat = np.full((64, 96), 128, np.uint8)
+    assert len(ctx.gftt(flat, 10, 0.01, 5, rule="cuda")) == 0 == len(oracle.gftt(flat, 10, 0.01, 5, rule="cuda"))
+    small = _img(64, 96, 1)
+    zero_mask = np.zeros((64, 96), np.uint8)
+    assert len(ctx.gftt(small, 10, 0.01, 5, zero_mask, rule="cuda")) == 0 == len(oracle.gftt(small, 10, 0.01, 5, zero_mask, rule="cuda"))
+    # the strongest response hidden by the mask raises the threshold for everything else (the CPU detector's threshold would come from under the mask)
+    hot = small.copy()
+    hot[20:36, 40:56] = 0
+    hot[28:36, 48:56] = 255
+    m = np.full((64, 96), 255, np.uint8)
+    m[12:44, 32:64] = 0
+    a, b = ctx.gftt(hot, 500, 0.01, 2, m, rule="cuda"), oracle.gftt(hot, 500, 0.01, 2, m, rule="cuda")
+    assert np.array_equal(a, b) and len(a) < len(ctx.gftt(hot, 500, 0.01, 2, m))
+
+
 @pytest.mark.parametrize("radius", [0, 1, 4, 20, 25, 30])
 def test_circle_mask_bit_exact(ctx, oracle, radius):
     rng = np.random.default_rng(radius)
@@ -198,6 +253,33 @@ def test_track_image_naive_masked_bit_exact(gpu_ctx_factory, oracle):
         g = c.track_stereo(left, right, 0.1 * k, mask, DV_MODE_NAIVE)
         r = o.track_image(left, right, 0.1 * k, mask, naive=True)
         _rows_equal(g, r)
+
+
+def test_track_image_naive_720p_uses_the_gpu_detector(gpu_ctx_factory, oracle):
+    """TrackImageNaive at the headline size: temporal + right tracking by the GPU tracker's rule and NEW corners by the GPU detector's rule (DetectNewFeature(img, true, ...),
+    background_tracker.cpp:445) — rows bit for bit against the oracle, and different from what the CPU detector's rule (rounds 1-5) selects under the same mask."""
+    w, h, max_cnt, min_dist = 1280, 720, 250, 25
+    c = gpu_ctx_factory(width=w, height=h, max_cnt=max_cnt, min_dist=min_dist, cam0=_cam(ZED), cam1=_cam(ZED))
+    o = oracle.tracker(w, h, max_cnt, min_dist, 1, 1, ZED, ZED)
+    o_cpu = oracle.tracker(w, h, max_cnt, min_dist, 1, 1, ZED, ZED)
+    seq = synth.PlaneSequence(w, h, seed=8, disparity=9.5)
+    from dynamic_vins_amd.frontend import DV_MODE_NAIVE
+    differs = False
+    for k in range(4):
+        left, right = seq.frame(k)
+        mask = np.full((h, w), 255, np.uint8)
+        mask[200:520, 300 + 12 * k:760 + 12 * k] = 0
+        left, right = [np.where(mask == 0, im, (im.astype(np.float32) * 0.12 + 110).astype(np.uint8)) for im in (left, right)]      # a dim scene around a bright (masked) object
+        g = c.track_stereo(left, right, 0.05 * k, mask, DV_MODE_NAIVE)
+        r = o.track_image(left, right, 0.05 * k, mask, naive=True)
+        _rows_equal(g, r)
+        oracle.lib.dvo_set_variant(b"f5_cpu_rule", 1)
+        try:
+            rc = o_cpu.track_image(left, right, 0.05 * k, mask, naive=True)
+        finally:
+            oracle.lib.dvo_set_variant(b"f5_cpu_rule", 0)
+        differs = differs or len(rc) != len(r) or not np.array_equal(rc["left"], r["left"])
+    assert len(g) > 100 and differs
 
 
 @pytest.mark.parametrize("mode,erode_k", [(2, 0), (2, 7), (1, 5)])

@@ -41,6 +41,23 @@ def test_front_operators_match_golden(gpu_ctx_factory, front):
     assert np.array_equal(ctx.lift_projective(make_cam(*front["cam"]), front["lift_in"]).view(np.uint32), front["lift_out"].view(np.uint32))
 
 
+def test_gpu_detector_matches_golden(gpu_ctx_factory):
+    """row F5: cv::cuda::GoodFeaturesToTrackDetector's rule (dv_gftt_cuda / dv_min_eigen_cuda) and TrackImageNaive's rows against tests/golden/gftt_cuda_kat.npz"""
+    from dynamic_vins_amd.frontend import make_cam
+    g = np.load(os.path.join(G, "gftt_cuda_kat.npz"))
+    cam = make_cam(*g["cam"])
+    ctx = gpu_ctx_factory(width=128, height=96, max_cnt=30, min_dist=10, cam0=cam, cam1=cam)
+    assert np.array_equal(ctx.min_eigen(g["img"], rule="cuda").view(np.uint32), g["min_eigen"].view(np.uint32))
+    assert np.array_equal(ctx.gftt(g["img"], 40, 0.01, 8, None, rule="cuda"), g["corners_nomask"])
+    assert np.array_equal(ctx.gftt(g["img"], 1000, 0.01, 3, g["mask"], rule="cuda"), g["corners_mask"])
+    assert np.array_equal(ctx.gftt(g["img"], 1000, 0.01, 3, g["mask"]), g["corners_mask_cpu_rule"])
+    from dynamic_vins_amd.frontend import DV_MODE_NAIVE
+    for k in range(len(g["left"])):
+        rows = ctx.track_stereo(g["left"][k], g["right"][k], 1.0 + 0.05 * k, mask=g["track_mask"], mode=DV_MODE_NAIVE)
+        n = int(g["track_n"][k])
+        assert len(rows) == n and rows.tobytes() == g["track_rows"][k].tobytes()[: n * 128], f"frame {k}"
+
+
 def test_track_image_sequence_matches_golden(gpu_ctx_factory, front):
     from dynamic_vins_amd.frontend import make_cam
     cam = make_cam(*front["cam"])

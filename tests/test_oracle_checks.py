@@ -132,6 +132,62 @@ def test_gftt_properties(oracle, front):
     assert (q == mx[c[:, 1].astype(int), c[:, 0].astype(int)]).all()
 
 
+def test_gpu_detector_oracle_against_float_restatement_and_golden(oracle):
+    """Row F5, second half (oracle/gftt_cuda.cpp): cv::cuda::GoodFeaturesToTrackDetector as DetectShiTomasiCornersGpu calls it (feature_utils.cpp:339-348).
+    The response map against an independent float64 restatement of the formula; the committed vectors (bit patterns); the properties that separate it from the CPU
+    detector: the quality threshold comes from the maximum over the WHOLE image, every corner is a strict-threshold 3x3 maximum under the mask, strongest first,
+    minimum distance kept."""
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gftt_cuda_kat.npz"))
+    img, mask = g["img"], g["mask"]
+    eig = oracle.min_eigen(img, rule="cuda")
+    assert np.array_equal(eig.view(np.uint32), g["min_eigen"].view(np.uint32))
+    f = img.astype(np.float64)
+    h, w = f.shape
+    p = np.pad(f, 1, mode="reflect")
+    s = 1.0 / (255.0 * 12.0)
+    dx = ((p[0:h, 2:] - p[0:h, :-2]) + 2 * (p[1:h + 1, 2:] - p[1:h + 1, :-2]) + (p[2:h + 2, 2:] - p[2:h + 2, :-2])) * s
+    dy = ((p[2:, 0:w] - p[:-2, 0:w]) + 2 * (p[2:, 1:w + 1] - p[:-2, 1:w + 1]) + (p[2:, 2:w + 2] - p[:-2, 2:w + 2])) * s
+
+    def box(a):
+        q = np.pad(a, 1, mode="reflect")
+        return sum(q[i:i + h, j:j + w] for i in range(3) for j in range(3))
+    a, b, c = box(dx * dx) * 0.5, box(dx * dy), box(dy * dy) * 0.5
+    assert np.allclose(eig, (a + c) - np.sqrt((a - c) ** 2 + b * b), rtol=2e-4, atol=2e-7)
+    # the two detectors' maps are the same function in different float orders
+    assert np.abs(eig - oracle.min_eigen(img)).max() < 1e-6 * eig.max() + 1e-7
+    for key, m, n, md in (("corners_nomask", None, 40, 8), ("corners_mask", mask, 1000, 3)):
+        cn = oracle.gftt(img, n, 0.01, md, m, rule="cuda")
+        assert np.array_equal(cn, g[key])
+        xi, yi = cn[:, 0].astype(int), cn[:, 1].astype(int)
+        q = eig[yi, xi]
+        assert (np.diff(q) <= 0).all() and (q > np.float32(float(eig.max()) * 0.01)).all()                  # strongest first, strictly above 1 % of the GLOBAL maximum
+        assert (q == ndi.maximum_filter(eig, size=3, mode="nearest")[yi, xi]).all()                          # 3x3 maxima of the raw map
+        assert (xi >= 1).all() and (xi <= w - 2).all() and (yi >= 1).all() and (yi <= h - 2).all()
+        if m is not None:
+            assert (m[yi, xi] != 0).all()
+        d = np.linalg.norm(cn[:, None, :] - cn[None, :, :], axis=2) + 1e9 * np.eye(len(cn))
+        assert d.min() >= md
+    # the excluded region holds the strongest response: the GPU detector's threshold is 1 % of THAT, the CPU detector's 1 % of the strongest response under the mask
+    assert eig[mask == 0].max() > 5 * eig[mask != 0].max()
+    cpu = oracle.gftt(img, 1000, 0.01, 3, mask)
+    assert np.array_equal(cpu, g["corners_mask_cpu_rule"]) and len(cpu) > len(g["corners_mask"]) + 50
+    weakest_cpu = oracle.min_eigen(img)[cpu[:, 1].astype(int), cpu[:, 0].astype(int)].min()
+    assert weakest_cpu < 0.01 * eig.max() < q.min()
+    # degenerate inputs: a flat image and an all-zero mask give no corners; no minimum distance keeps the plain top-n
+    flat = np.full((40, 56), 77, np.uint8)
+    assert len(oracle.gftt(flat, 10, 0.01, 5, rule="cuda")) == 0
+    assert len(oracle.gftt(img, 10, 0.01, 5, np.zeros_like(img), rule="cuda")) == 0
+    top = oracle.gftt(img, 12, 0.01, 0, rule="cuda")
+    assert len(top) == 12 and (np.diff(eig[top[:, 1].astype(int), top[:, 0].astype(int)]) <= 0).all()
+    # TrackImageNaive rows (GPU tracker + GPU detector) are pinned too
+    cam = tuple(g["cam"])
+    trk = oracle.tracker(128, 96, 30, 10, 1, 1, cam, cam)
+    for k in range(len(g["left"])):
+        rows = trk.track_image(g["left"][k], g["right"][k], 1.0 + 0.05 * k, mask=g["track_mask"], mode=1)
+        assert len(rows) == int(g["track_n"][k]) and rows.tobytes() == g["track_rows"][k].tobytes()[: len(rows) * 128], k
+    trk.close()
+
+
 def test_lk_recovers_known_subpixel_shift(oracle):
     tex = synth.texture(160, 200, seed=77)
     xs, ys = np.meshgrid(np.arange(128, dtype=np.float64), np.arange(96, dtype=np.float64))

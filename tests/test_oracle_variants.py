@@ -102,3 +102,64 @@ def test_gpu_tracker_rule_against_the_cpu_rule_D4(oracle, sequence, mode):
     same, ate = compare(gpu_rule, cpu_rule)
     assert same > (0.5 if mode == 1 else 0.9), same          # naive mode re-tracks every feature with the other tracker every frame: positions drift apart by hundredths of a pixel
     assert ate < 1e-3, ate
+
+
+def run_masked(oracle, sequence, frames, mask, n, **variants):
+    """naive mode (TrackImageNaive) over prepared frames with a fixed inverse instance mask -> (rows per frame, positions of the newest frame)"""
+    cam, seq, _ = sequence
+    for k, v in variants.items():
+        oracle.lib.dvo_set_variant(k.encode(), int(v))
+    try:
+        camt = sim.cam_tuple(cam)
+        trk = oracle.tracker(W, H, 150, 20, 1, 1, camt, camt)
+        est = oracle.estimator(use_imu=1, stereo=1, max_iters=8, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], **seq.noise)
+        k_imu, poses, rows_all = 0, [], []
+        for k in range(n):
+            t = seq.times[k]
+            while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
+                est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
+            rows = trk.track_image(frames[k][0], frames[k][1], t, mask=mask, mode=1)
+            rc, st = est.process(rows, t)
+            assert rc == 0
+            rows_all.append(rows.copy())
+            if st.nonlinear:
+                poses.append(est.window()[10, :3].copy())
+        return rows_all, np.array(poses)
+    finally:
+        for k in variants:
+            oracle.lib.dvo_set_variant(k.encode(), 0)
+
+
+def test_gpu_detector_rule_and_its_declared_choices_D6(oracle, sequence):
+    """D6 (row F5): in naive mode the reference detects new corners with cv::cuda::GoodFeaturesToTrackDetector (DetectShiTomasiCornersGpu, feature_utils.cpp:339-348) — its own
+    float response map and a quality threshold taken over the WHOLE image instead of under the mask.  Rounds 1-5 ran cv::goodFeaturesToTrack's rule there without saying
+    so; round 6 restates the GPU detector (oracle/gftt_cuda.cpp).  Measured here: what that substitution was worth ("f5_cpu_rule"), and what each declaration inside the
+    restatement is worth (contraction of the float chains, order of equal responses).
+      * evenly textured scene (every frame holds more strong corners than max_cnt): the two detectors pick the same corners, frame for frame;
+      * a dim scene with one bright masked object — the case the two thresholds are made for: the GPU detector's threshold is 1 % of the OBJECT's strongest response,
+        the CPU detector's 1 % of the strongest background response: the CPU rule keeps ~150 features where the reference keeps 54 - 91, and the 26-frame
+        trajectories differ by 3 mm — more than north_star's 1 mm bar.  The substitution was NOT harmless; the restatement is what the reference does.
+      * the two declarations inside the restatement move nothing in either scene."""
+    n = 26
+    _, _, frames = sequence
+    full = np.full((H, W), 255, np.uint8)
+    canon = run_masked(oracle, sequence, frames, full, n)
+    for kw in (dict(f5_cpu_rule=1), dict(gftt_cuda_fma=1), dict(gftt_cuda_tie=1)):
+        same, ate = compare(canon, run_masked(oracle, sequence, frames, full, n, **kw))
+        assert same > 0.99 and ate < 1e-6, (kw, same, ate)
+    mask = full.copy()
+    mask[100:260, 200:420] = 0
+
+    def dim(img):
+        out = (img.astype(np.float32) * 0.12 + 110).astype(np.uint8)
+        out[mask == 0] = img[mask == 0]
+        return out
+    dimmed = [(dim(l), dim(r)) for l, r in frames]
+    canon = run_masked(oracle, sequence, dimmed, mask, n)
+    cpu_rule = run_masked(oracle, sequence, dimmed, mask, n, f5_cpu_rule=1)
+    assert len(cpu_rule[0][0]) > 2 * len(canon[0][0]) > 60, (len(cpu_rule[0][0]), len(canon[0][0]))
+    same, ate = compare(canon, cpu_rule)
+    assert same < 0.7 and 1e-3 < ate < 2e-2, (same, ate)
+    for kw in (dict(gftt_cuda_fma=1), dict(gftt_cuda_tie=1)):
+        same, ate = compare(canon, run_masked(oracle, sequence, dimmed, mask, n, **kw))
+        assert same > 0.99 and ate < 1e-6, (kw, same, ate)

@@ -243,15 +243,16 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
     w, h = cfg["w"], cfg["h"]
     stride = 2 if args.every_second_frame else 1
     warm_ba = max(args.warmup, 12)            # the estimator needs kWinSize+1 = 11 BA frames to initialise (estimator.cpp:1464-1483)
-    if args.mode == "dynamic" and os.environ.get("BENCH_DYN_WARM", "1") == "1":
-        # dynamic mode: the first ~20 frames behind the window fill are the frames in which the objects initialise (first object solves, first extra-point clouds, the trackers'
-        # tables reach their working size): one-time stalls of 2 - 7 ms fall there and a 20-step block (the driver's command) is then mostly that.  20 more untimed frames;
-        # every timed frame still runs all 10 iterations (they do until frame ~70).  BENCH_DYN_WARM=0: the 12-frame warm-up of the raw line
-        warm_ba += 20
-    if args.host_frames:
-        # uploads from pinned host memory: within their first ~30 frames ONE stall of 40 - 80 ms shows up intermittently (1 run in 3; not in the frames resident in HBM, not
-        # later) — a start-up cost of the transfer path, not a rate: the PCIe-inclusive line warms up 32 frames longer so that a 20-step block does not consist of it
-        warm_ba += 32
+    # Rounds 4-5 warmed the dynamic line 20 frames and the PCIe-inclusive line 32 frames longer and placed a device-wide synchronisation inside the warm-up, because one-time
+    # stalls of 5 - 9 ms (a copy queue the runtime brought up lazily; buffers created at the first solves) fell into the first timed block.  Round 6 removed the causes (no copy
+    # engine in the per-frame path: copy.hip, DV_MEM_PINNED; be_prepare at dv_est_create) and with them the special warm-ups: every line warms up max(--warmup, 12) frames.
+    # BENCH_DYN_WARM=1 / BENCH_HOST_WARM=1 bring the longer warm-ups back for A/B; `warmup_excluded` of the line says what the timed blocks leave out.
+    warm_extra = 0
+    if args.mode == "dynamic" and os.environ.get("BENCH_DYN_WARM", "0") == "1":
+        warm_extra = 20
+    if args.host_frames and os.environ.get("BENCH_HOST_WARM", "0") == "1":
+        warm_extra = 32
+    warm_ba += warm_extra
     n_frames = (warm_ba + max(2, args.blocks) * args.steps) * stride + 2
     cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
     dev = f"cuda:{local_rank}"
@@ -279,16 +280,11 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         pipe = make_pipe()
         for key in filter(None, args.debug_set.split(",")):
             assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
-        runner = Runner([pipe], host_frames=args.host_frames)      # --host-frames: pinned host buffers, every frame's upload inside the timed region
+        # --host-frames: pinned host buffers, every frame's trip over PCIe inside the timed region (BENCH_HOST_ENGINE=1: through the copy engine, hipMemcpy2DAsync, as in rounds 1-5)
+        runner = Runner([pipe], host_frames=("engine" if os.environ.get("BENCH_HOST_ENGINE", "0") == "1" else True) if args.host_frames else False)
         if os.environ.get("BENCH_TRACKER_THREAD", "1") != "1":          # A/B: dynamic mode on the one-thread loop of round 4 instead of T2 beside T3
             runner.set("tracker_thread", 0)
-        # The warm-up contains one device-wide synchronisation, two frames before its end: the FIRST frame behind the first such synchronisation of a process costs 5 - 7 ms once
-        # in about two runs of three in dynamic mode (both host threads blocked in different HIP calls at the same instant: a lock inside the runtime, none of our allocations —
-        # scripts/dbg/dyn_block_clock.py, dyn_block_start_phases.py; later synchronisations do not repeat it).  It is a one-time cost of the process, not a rate: with the cut
-        # inside the warm-up a 20-step block measures frames, not that event (dynamic line 700 - 750 -> 925 - 935 frames/s in the runs that had it).  Same number of warm-up steps.
-        runner.run((warm_ba - 2) * stride)
-        torch.cuda.synchronize(); pipe.ctx.sync()
-        runner.run(2 * stride)
+        runner.run(warm_ba * stride)
         it0 = runner.get(0)[2]                               # window-solve iterations spent in the warm-up
         gc.collect(); gc.freeze()
         times = []
@@ -308,9 +304,11 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
             for _b in range(blocks):
                 a = (warm_ba + _b * args.steps) * stride
                 dd = np.diff(clk[a - 1:a + args.steps * stride]) * 1e3
-                if len(dd):
-                    frame_ms[len(frame_ms) - blocks + _b].update(p50=round(float(np.median(dd)), 3), p95=round(float(np.percentile(dd, 95)), 3), max=round(float(dd.max()), 3),
-                                                                 first_two=[round(float(v), 3) for v in dd[:2]], note="C++ host loop: frame-end clocks of dv_runner (one call per block)")
+                if len(dd) > 1:      # dd[0] spans two dv_runner_run calls (the host's synchronisation, gc and barriers between the blocks: not a frame); the frames are dd[1:]
+                    fr = dd[1:]
+                    frame_ms[len(frame_ms) - blocks + _b].update(p50=round(float(np.median(fr)), 3), p95=round(float(np.percentile(fr, 95)), 3), max=round(float(fr.max()), 3),
+                                                                 first_two=[round(float(v), 3) for v in fr[:2]], inter_call_gap_ms=round(float(dd[0]), 3), frames_above_2ms=int((fr > 2.0).sum()),
+                                                                 note="C++ host loop: frame-end clocks of dv_runner (one call per block); the gap across the call boundary is inter_call_gap_ms, not part of p50 / p95 / max")
         except Exception as e:      # (diagnostics only)
             frame_ms[-1]["note"] = "frame clocks unavailable: %s" % e
         st, poses, iters_all, _fr = runner.get(0)
@@ -330,8 +328,6 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
         for key in filter(None, args.debug_set.split(",")):
             assert pipe.ctx.lib.dv_debug_set(pipe.ctx.h, key.encode(), 1) == 0, key
         for _w in range(warm_ba * stride):
-            if _w == (warm_ba - 2) * stride:          # (one device-wide synchronisation inside the warm-up: see run_cpp)
-                torch.cuda.synchronize(); pipe.ctx.sync()
             pipe.step()
         # A generation-2 collection of the interpreter's ~10^6 objects (torch, numpy) is a ~60 ms pause that lands in a random block (seen as ONE 63 ms step
         # in config.block_step_ms): collect now and move everything that exists to the permanent generation, as timeit does by disabling the collector.
@@ -515,7 +511,7 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 "block_step_ms": frame_ms[: len(times)],
                 "warmup_requested": args.warmup, "git_head": git_head(), "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "host_loop": ("C++ (dv_runner)" if args.host_loop == "cpp" else "Python (pipeline.py)"),
-                "frames": ("pinned host buffers: the upload of every frame (2 x %d bytes, hipMemcpy2DAsync on the tracking stream) is inside the timed region" % (w * h)) if args.host_frames else "resident in HBM before the timed region",
+                "frames": ("pinned host buffers: every frame (2 x %d bytes) crosses PCIe inside the timed region (%s)" % (w * h, "hipMemcpy2DAsync on the tracking stream" if os.environ.get("BENCH_HOST_ENGINE", "0") == "1" else "DV_MEM_PINNED: read in place by the pyramid kernel, no copy engine")) if args.host_frames else "resident in HBM before the timed region",
                 "warmup_note": "at least 12 untimed BA frames: the sliding window (11 frames) must be full before a step is a steady-state step (track + BA + marginalization)"}
         if dyn_info:
             conf["dynamic"] = dyn_info

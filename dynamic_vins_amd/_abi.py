@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVINS_HIP_LIB") or os.path.join(_HERE, "lib", "libdvins_hip.so")
 
-DV_MEM_HOST, DV_MEM_DEVICE = 0, 1
+DV_MEM_HOST, DV_MEM_DEVICE, DV_MEM_PINNED = 0, 1, 2      # PINNED: host memory pinned + mapped by the caller, read in place by the kernels
 DV_FMT_BGR = 0x100
 DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC = 0, 1, 2
 DV_MAX_FEATS = 1024

@@ -506,9 +506,10 @@ class Runner:
     objects (each owns its Context + Estimator and a SyntheticSequence whose frames are resident in HBM); the runner takes over driving them."""
 
     def __init__(self, pipes, group_size=0, threads=1, first_frame=0, host_frames=False):
-        """host_frames: the frames are handed over as PINNED HOST buffers (dv_seq_input::mem = DV_MEM_HOST): every frame's upload (hipMemcpy2DAsync on the tracking
-        stream) then lies inside whatever region times dv_runner_run — the PCIe-inclusive rate of bench.py's host_frames_line"""
-        from .frontend import DV_MEM_DEVICE, DV_MEM_HOST
+        """host_frames: the frames are handed over as PINNED HOST buffers: every frame's trip over PCIe then lies inside whatever region times dv_runner_run — the
+        PCIe-inclusive rate of bench.py's host_frames_line.  True / "pinned": dv_seq_input::mem = DV_MEM_PINNED, the pyramid kernel reads the frames in place (no copy
+        engine in the per-frame path); "engine": DV_MEM_HOST, one hipMemcpy2DAsync per image on the tracking stream (rounds 1-5)"""
+        from .frontend import DV_MEM_DEVICE, DV_MEM_HOST, DV_MEM_PINNED
         self.lib = pipes[0].ctx.lib
         self.pipes = list(pipes)
         n = len(pipes)
@@ -535,7 +536,7 @@ class Runner:
             self._keep += [L, R, t, it, ia, ig]
             a = arr[i]
             a.left, a.right, a.times = C.cast(L, C.c_void_p), C.cast(R, C.c_void_p), t.ctypes.data
-            a.n_frames, a.mem, a.stride, a.ba_stride = len(frames), (DV_MEM_HOST if host_frames else DV_MEM_DEVICE), 0, getattr(p, "ba_stride", 1)
+            a.n_frames, a.mem, a.stride, a.ba_stride = len(frames), (DV_MEM_DEVICE if not host_frames else DV_MEM_HOST if host_frames == "engine" else DV_MEM_PINNED), 0, getattr(p, "ba_stride", 1)
             a.imu_t, a.imu_acc, a.imu_gyr, a.n_imu = it.ctypes.data + 8 * k0, ia.ctypes.data + 24 * k0, ig.ctypes.data + 24 * k0, len(it) - k0
         self._arr = arr
         ctxs = (C.c_void_p * n)(*[p.ctx.h for p in pipes])

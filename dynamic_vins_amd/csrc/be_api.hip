@@ -61,6 +61,27 @@ static int be_ensure(dv_ctx* ctx, int nfac) {
     return 0;
 }
 
+// Everything the first frames of an estimator would otherwise create in the middle of the sequence: the work block and its pinned mirror (hipMalloc / hipHostMalloc),
+// the marginalization scratch, the side stream of the prior's constant, events, the pinned flag arrays, the kernels' code objects and LDS attributes — together a
+// 3 ms frame at the first window solve (scripts/dyn_cold_frames.py), where a 20 Hz estimator has 1 ms frames otherwise.  Called by dv_est_create.
+int be_prepare(dv_ctx* ctx, bool dynamic) {
+    BeWork& w = ctx->be;
+    DV_CHECK(hipSetDevice(ctx->cfg.device));
+    if (be_ensure(ctx, 0)) return -1;
+    {       // marg_args' sizing at its maximum (BE_MAX_LM landmarks anchored in the oldest frame, D = 178)
+        const size_t nlmax = (size_t)BE_MAX_LM, Dmax = 178;
+        DV_CHECK(w.marg_buf.ensure(8 * (nlmax * (size_t)be_marg_wstride((int)Dmax) + ((size_t)be_marg_chunks((int)nlmax) + 1) * be_marg_part() + Dmax * Dmax + Dmax + nlmax + 512)));
+    }
+    if (w.c0_side && !w.c0_stream) {
+        DV_CHECK(hipStreamCreateWithFlags(&w.c0_stream, hipStreamNonBlocking));
+        DV_CHECK(hipEventCreateWithFlags(&w.ev_margA, hipEventDisableTiming)); DV_CHECK(hipEventCreateWithFlags(&w.ev_c0, hipEventDisableTiming));
+    }
+    if (!w.rej_pinned) DV_CHECK(hipHostMalloc((void**)&w.rej_pinned, BE_MAX_LM, hipHostMallocDefault));
+    if (be_eval_prepare() || be_solve_prepare() || be_marg_prepare() || dv_copy_prepare()) DV_FAIL("be_prepare: cannot load the back end's kernels");
+    if (dynamic && be_obj_solve_prepare(ctx, ctx->obj_buf, ctx->obj_pend)) return -1;
+    return 0;
+}
+
 // 15x15: U upper-triangular with U^T U = cov^-1   (LLT(cov^-1).matrixL().transpose(), imu_factor.h:74-75; cached, Q8)
 static bool imu_sqrt_info(const double* cov, double* U) {
     double a[15][30];
@@ -367,7 +388,7 @@ static int be_enqueue_tail(dv_ctx* ctx, BePending& pd, hipStream_t s) {
         hipStream_t cs = side ? w.c0_stream : s;
         if (marg_enqueue(ctx, pd.pl, w.cand, pd.g_norm, w.priorA, w.priorb, w.priorA_buf[pd.nxt], w.priorb_buf[pd.nxt], w.marg_scal, w.prior_c0 + pd.nxt, s, side ? w.c0_stream : nullptr)) return -1;
         double* hscal = (double*)(hp + w.dl_off + sizeof(BeState) + sizeof(BeCtl)) + 4 * pd.scal_slot;      // two alternating host slots
-        DV_CHECK(hipMemcpyAsync(hscal, w.marg_scal, 32, hipMemcpyDeviceToHost, cs));
+        DV_CHECK(dv_copy_async(hscal, w.marg_scal, 32, cs));
         if (side) { DV_CHECK(hipEventRecord(w.ev_c0, cs)); w.c0_pending = true; }
         pd.marg_in_flight = true;
     }
@@ -474,7 +495,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     if (do_marg && !pl.empty) std::memcpy(hp + w.up_mt, pl.tab, sizeof(pl.tab));
     if (P->nlm) std::memcpy(hp + w.up_lm, P->landmarks, sizeof(BeLm) * (size_t)P->nlm);
     if (P->nfac && (const void*)P->factors != (const void*)(hp + w.up_fac)) std::memcpy(hp + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac);      // the estimator builds the table in place
-    DV_CHECK(hipMemcpyAsync(w.block.p, hp, w.up_fac + sizeof(BeFactor) * (size_t)P->nfac, hipMemcpyHostToDevice, s));
+    DV_CHECK(dv_copy_async(w.block.p, hp, w.up_fac + sizeof(BeFactor) * (size_t)P->nfac, s));      // (a kernel reading the pinned mirror: copy.hip)
     if (w.c0_pending) { DV_CHECK(hipStreamWaitEvent(s, w.ev_c0, 0)); w.c0_pending = false; }      // the previous frame's c0 (side stream) and its health scalars: before anything reads the prior's constant
     if (has_prior && !prior_on_device) {               // a prior handed over in host memory (the estimator's stays in HBM)
         if (!P->prior_A || !P->prior_b) DV_FAIL("dv_ba_solve: prior without A / b");
@@ -759,7 +780,7 @@ static int batch_enqueue_impl(dv_batch* B) {
     }
     const BeEvalArgs* dea = (const BeEvalArgs*)B->tab.p; const BeSolveArgs* dsa = (const BeSolveArgs*)(dea + cap);
     const BeGaugeArgs* dga = (const BeGaugeArgs*)(dsa + cap); const BeRejectArgs* drj = (const BeRejectArgs*)(dga + cap); const BeMargArgs* dma = (const BeMargArgs*)(drj + cap);
-    DV_CHECK(hipMemcpyAsync(B->tab.p, B->tab_pinned, B->tab_bytes, hipMemcpyHostToDevice, s));
+    DV_CHECK(dv_copy_async(B->tab.p, B->tab_pinned, B->tab_bytes, s));
     if (B->timing && B->tev_pending && hipEventQuery(B->tev[3]) == hipSuccess) {      // the previous round's three stages
         float ms;
         for (int k = 0; k < 3; ++k) if (hipEventElapsedTime(&ms, B->tev[k], B->tev[k + 1]) == hipSuccess) B->t_ms[k] += ms;

@@ -355,3 +355,6 @@ __global__ void be_imu_op_kernel(const BeImu* m, double g_norm, const double* pa
 void be_launch_imu_op(const BeImu* m, double g_norm, const double* par, double* out, hipStream_t s) {
     hipLaunchKernelGGL(be_imu_op_kernel, dim3(1), dim3(64), 0, s, m, g_norm, par, out);
 }
+
+// be_prepare (be_api.hip): the runtime loads a code object on the first launch of one of its kernels — asking for a kernel's attributes loads it now, at create time
+int be_eval_prepare() { hipFuncAttributes fa; return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(be_eval_kernel<true>)) == hipSuccess ? 0 : -1; }

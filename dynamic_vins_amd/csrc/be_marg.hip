@@ -867,3 +867,12 @@ int be_launch_marg(const BeMargArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(be_marg_finish_kernel, dim3(1), dim3(MG_THREADS), bytes, s, a);
     return 0;
 }
+
+int be_marg_prepare() {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(be_gauge_kernel)) != hipSuccess) return -1;
+    static DevOnce once;      // (the same attributes be_launch_marg sets on its first call)
+    return once.run([] {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_finish_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return 1;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(be_marg_lm_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ? 1 : 0; }) ? -1 : 0;
+}

@@ -233,7 +233,7 @@ int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& sc
 
     if (scratch.ensure(std::max<size_t>(off, (size_t)8 << 20)) != hipSuccess) DV_FAIL("dv_obj_solve: out of device memory");      // (floor: a hipFree + hipMalloc per growth step is a device-wide synchronisation)
     uint8_t* base = (uint8_t*)scratch.p;
-    DV_CHECK(hipMemcpyAsync(base, host.data(), up_bytes, hipMemcpyHostToDevice, s));
+    DV_CHECK(dv_copy_async(base, host.data(), up_bytes, s));      // pinned -> HBM by a kernel on the object stream (copy.hip)
     BdArgs a{};          // (x1 <- x0 and the zeroing of H | vec are the kernel's own first phase: two enqueued operations less in front of it)
     a.V = V; a.max_iters = P->max_iters;
     a.x0 = (double*)(base + o_x0); a.x1 = (double*)(base + o_x1); a.H0 = (double*)(base + o_H0); a.H1 = (double*)(base + o_H1); a.vec = (double*)(base + o_vec);
@@ -256,6 +256,19 @@ int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& sc
     DV_CHECK(hipGetLastError());
     DV_CHECK(hipEventRecord(pend.ev, s));
     pend.active = true; pend.V = V; pend.nblk = nblk; pend.n_obj = n_obj; pend.up_bytes = up_bytes; pend.stream = s;
+    return 0;
+}
+
+int be_obj_solve_prepare(dv_ctx* ctx, DevBuf& scratch, ObjPending& pend) {
+    if (!pend.pinned) {
+        const size_t want = (size_t)4 << 20;      // the floor of be_obj_solve_begin
+        DV_CHECK(hipHostMalloc(&pend.pinned, want, hipHostMallocDefault));
+        pend.pinned_bytes = want;
+    }
+    if (!pend.ev) DV_CHECK(hipEventCreateWithFlags(&pend.ev, hipEventDisableTiming));
+    if (scratch.ensure((size_t)8 << 20) != hipSuccess) DV_FAIL("dv_obj_solve: out of device memory");
+    static DevOnce once;
+    if (once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(bd_solve_kernel<ObjProb>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BD_LDS_MAX) != hipSuccess ? 1 : 0; })) DV_FAIL("dv_obj_solve: cannot set the dynamic LDS size");
     return 0;
 }
 

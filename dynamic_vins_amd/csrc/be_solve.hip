@@ -1131,3 +1131,10 @@ __global__ __launch_bounds__(256) void be_accept_kernel(BeSolveArgs a) { be_acce
 __global__ __launch_bounds__(256) void be_accept_batch_kernel(const BeSolveArgs* __restrict__ tab) { be_accept_body(tab[blockIdx.x]); }
 void be_launch_accept(const BeSolveArgs& a, hipStream_t s) { hipLaunchKernelGGL(be_accept_kernel, dim3(1), dim3(256), 0, s, a); }
 void be_launch_accept_batch(const BeSolveArgs* tab_dev, int n_win, hipStream_t s) { hipLaunchKernelGGL(be_accept_batch_kernel, dim3(n_win), dim3(256), 0, s, tab_dev); }
+
+int be_solve_prepare() {
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(be_reduce_kernel)) != hipSuccess) return -1;
+    static DevOnce once;
+    return once.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(be_solve_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512) != hipSuccess ? 1 : 0; }) ? -1 : 0;
+}

@@ -155,6 +155,8 @@ struct ObjPending {       // an object solve in flight (be_obj_solve_begin / _en
 };
 int be_obj_solve_begin(dv_ctx* ctx, dv_obj_problem* P, hipStream_t s, DevBuf& scratch, ObjPending& pend);
 int be_obj_solve_end(dv_ctx* ctx, dv_obj_problem* P, dv_ba_summary* summary, ObjPending& pend);
+int be_obj_solve_prepare(dv_ctx* ctx, DevBuf& scratch, ObjPending& pend);      // the buffers, event and kernel attribute be_obj_solve_begin would create on its first call
+int be_prepare(dv_ctx* ctx, bool dynamic);      // dv_est_create: everything the first window solve / marginalization / object solve would allocate or create lazily (a 3 ms frame otherwise)
 struct dv_estimator;
 void dv_est_destroy_internal(dv_estimator* e);
 struct dv_inst_tracker;

@@ -105,6 +105,7 @@ void dv_launch_finalize_offset(const DvTrackState& tr, const dv_cam& cam0, const
 void dv_launch_lk_cuda_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back, float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_lk_cuda_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters, int use_initial, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_gftt_tile(const GfttTileArgs& a, hipStream_t s);
+hipError_t dv_copy_async(void* dst, const void* src, size_t bytes, hipStream_t s);      // copy.hip: device <-> PINNED host (or device <-> device) as a kernel on s — no copy engine in the per-frame path
 int  dv_launch_gftt_select(const GfttSelectArgs& a, hipStream_t s);
 void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_pitch, int sort_by_cnt, int* n_cand,
                        unsigned* max_ord, hipStream_t s);

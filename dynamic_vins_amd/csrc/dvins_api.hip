@@ -255,6 +255,8 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     if (w != ctx->cfg.width || h != ctx->cfg.height) DV_FAIL("dv_track_stereo: image size differs from config (reference: std::terminate, main.cpp:95-99)");
     if (ctx->pending) DV_FAIL("dv_track_stereo_enqueue: previous frame not collected");
     if (mode != DV_MODE_RAW && mode != DV_MODE_NAIVE && mode != DV_MODE_SEMANTIC) DV_FAIL("dv_track_stereo: unknown mode");
+    if ((mem & 0xff) == DV_MEM_PINNED) mem = (mem & ~0xff) | DV_MEM_DEVICE;      // pinned + mapped host memory is device-addressable: the kernels read it in place
+    if ((mem & 0xff) != DV_MEM_HOST && (mem & 0xff) != DV_MEM_DEVICE) DV_FAIL("dv_track_stereo: unknown memory kind");
     DV_CHECK(hipSetDevice(ctx->cfg.device));
     const dv_config& c = ctx->cfg;
     const bool stereo = c.stereo && gray1;
@@ -492,7 +494,7 @@ extern "C" int dv_batch_track_enqueue(dv_batch* B, const dv_track_job* jobs, int
         PyrSet& L = c->left[c->cur]; PyrSet& Lp = c->left[c->cur ^ 1];
         const DvPyr& a = L.pyr; const DvPyr* b = stereo ? &c->right.pyr : nullptr;
         const int stride = j.stride > 0 ? j.stride : w;
-        const bool dev = j.mem == DV_MEM_DEVICE;
+        const bool dev = j.mem == DV_MEM_DEVICE || j.mem == DV_MEM_PINNED;      // (pinned + mapped host memory: read in place by the level-1 kernel, like HBM)
         if (!dev || a.levels == 1) {      // host frames: the upload IS the level-0 copy
             DV_CHECK(hipMemcpy2DAsync(a.L[0].p, a.L[0].pitch, j.gray0, stride, w, h, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
             if (b) DV_CHECK(hipMemcpy2DAsync(b->L[0].p, b->L[0].pitch, j.gray1, stride, w, h, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
@@ -532,7 +534,7 @@ extern "C" int dv_batch_track_enqueue(dv_batch* B, const dv_track_job* jobs, int
         f.err_in = c->err_flag; f.err_out = c->err_pinned;
         h_fin[k] = f;
     }
-    DV_CHECK(hipMemcpyAsync(F.tab[par].p, hp, total, hipMemcpyHostToDevice, s));
+    DV_CHECK(dv_copy_async(F.tab[par].p, hp, total, s));
     DV_CHECK(hipEventRecord(F.ev_copy[par], s)); F.copy_used[par] = true;
     // ---- the stages ----
     for (int l = 1; l < levels; ++l) dv_launch_pyr_down_multi((const DvPyrJob*)(dp + o_pyr) + (size_t)(l - 1) * S, S, lw[l], lh[l], s);

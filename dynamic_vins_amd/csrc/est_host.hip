@@ -752,7 +752,7 @@ int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg) {
     if (cfg->estimate & ~3) DV_FAIL("dv_est_create: estimate: bit 0 estimate_extrinsic 1, bit 1 estimate_td 1 (estimate_extrinsic 2, the from-scratch calibration, is not built)");
     delete ctx->est;
     ctx->est = new dv_estimator(*cfg);
-    return 0;
+    return be_prepare(ctx, cfg->dynamic != 0);      // nothing is allocated or created lazily in the middle of a sequence
 }
 // diagnostics (dv_debug_set "hash_log"): rows of six uint64 per window solve, see dv_estimator::hash_log
 int dv_est_debug_hash_log(dv_ctx* ctx, unsigned long long* rows6, int cap, int* n_rows) {

@@ -407,8 +407,8 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             }
         }
         if (na > 0) {
-            DV_CHECK(hipMemcpyAsync(T.mask_all.p, T.pinned_in, moff, hipMemcpyHostToDevice, s));
-            DV_CHECK(hipMemcpyAsync(T.arena.p, T.arena_pinned, arena_used, hipMemcpyHostToDevice, s));
+            DV_CHECK(dv_copy_async(T.mask_all.p, T.pinned_in, moff, s));
+            DV_CHECK(dv_copy_async(T.arena.p, T.arena_pinned, arena_used, s));
             if (T.xp_frame && n_xp > 0) {
                 // the reference starts a thread for this (dynamic_tracker.cpp:378): a side stream behind the mask + table uploads; the objects' tracking goes on meanwhile
                 DV_CHECK(hipEventRecord(T.ev_xin, s));
@@ -436,7 +436,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             j.add_x = (float)S.rx; j.add_y = (float)S.ry; j.use_add = 1;
             hj[n_temporal + k] = j;
         }
-        if (na > 0) DV_CHECK(hipMemcpyAsync(T.jobs.p, hj, (size_t)(n_temporal + (stereo ? na : 0)) * sizeof(DvLkJob), hipMemcpyHostToDevice, s));
+        if (na > 0) DV_CHECK(dv_copy_async(T.jobs.p, hj, (size_t)(n_temporal + (stereo ? na : 0)) * sizeof(DvLkJob), s));
         // ---- stage B ----
         dv_launch_lk_track_multi((const DvLkJob*)T.jobs.p, n_temporal, T.max_cnt, ctx->cfg.flow_back, 0.5f, s);
         // ---- stage C ----
@@ -459,7 +459,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
             S.out_valid = true; S.out_index = out_k++;
             T.out_order.push_back(S.id);
         }
-        if (out_k > 0) DV_CHECK(hipMemcpyAsync(T.out_pinned, T.out_buf.p, (size_t)out_k * slot_bytes, hipMemcpyDeviceToHost, s));
+        if (out_k > 0) DV_CHECK(dv_copy_async(T.out_pinned, T.out_buf.p, (size_t)out_k * slot_bytes, s));
     }
     // ---- ManageInstances (:499-514): objects unseen for more than one frame are dropped ----
     for (auto it = T.slots.begin(); it != T.slots.end();) {

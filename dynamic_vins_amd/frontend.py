@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _abi
-from ._abi import DvinsError, dv_cam, dv_config, dv_feat, DV_MEM_HOST, DV_MEM_DEVICE, DV_FMT_BGR, DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC
+from ._abi import DvinsError, dv_cam, dv_config, dv_feat, DV_MEM_HOST, DV_MEM_DEVICE, DV_MEM_PINNED, DV_FMT_BGR, DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC
 
 class dv_inst_det(C.Structure):
     _fields_ = [("track_id", C.c_uint32), ("class_id", C.c_int32), ("x", C.c_int32), ("y", C.c_int32), ("w", C.c_int32), ("h", C.c_int32),

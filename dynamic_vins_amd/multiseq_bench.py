@@ -159,9 +159,7 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
     runner.set("teams", 1 if teams else 0)
     if getattr(args, "no_batch_front", False):
         runner.set("batch_front", 0)
-    runner.run(warm_ba - 2)          # one device-wide synchronisation inside the warm-up (bench.py run_cpp: the first frame behind the first one of a process may cost milliseconds once)
-    torch.cuda.synchronize()
-    runner.run(2)
+    runner.run(warm_ba)          # (same cuts as the solo reference run of the bit-identity gate below: warm-up, block, block)
     if gsz > 1:
         runner.batch_timing(1)       # HIP events on the batch streams around one steady-state slot per round (dv_batch_timing)
     gc.collect(); gc.freeze()

@@ -23,6 +23,10 @@ extern "C" {
 
 #define DV_MEM_HOST   0
 #define DV_MEM_DEVICE 1
+/* dv_track_stereo* / dv_batch_track_enqueue / dv_seq_input::mem / dv_seq_dynamic::mask_mem: host memory the CALLER has pinned and mapped for the device
+ * (hipHostMalloc, or hipHostRegister with hipHostRegisterMapped).  The kernels read it over PCIe directly — no staging copy, no copy engine in the per-frame
+ * path; the buffers must stay unchanged until the frame is collected, as device buffers must. */
+#define DV_MEM_PINNED 2
 /* OR into `mem` of dv_track_stereo*: gray0 / gray1 point to 8-bit BGR frames (stride in bytes, >= 3 w); they are converted with
  * cv::cvtColor's fixed-point weights straight into pyramid level 0 (SemanticImage::SetGrayImageGpu, basic/semantic_image.cpp:103-118).
  * A mask, if given, is single-channel with stride w. */

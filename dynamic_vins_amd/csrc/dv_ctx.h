@@ -205,6 +205,10 @@ struct dv_ctx {
     // operator-level scratch
     PyrSet opA, opB; DevBuf s0, s1, s2, s3, s4;
     bool timing = false, kernel_timing = false, host_timing = false; std::deque<StageTimer> timers;   // deque: StageScope keeps pointers across emplace_back
+    // A dynamic sequence runs the tracker API (thread T2) and the estimator API (T3) on ONE ctx (runner.hip): the timer table is shared between them — every walk /
+    // growth of `timers` and every update of a timer's counters happens under timer_mu — and so is the error string (err_mu; dv_last_error hands out a
+    // per-thread copy)
+    std::mutex timer_mu, err_mu;
     // back end
     hipStream_t be_stream = nullptr; BeWork be;
     hipStream_t be_stream_own = nullptr;          // member of a dv_batch: be_stream IS the batch's stream (every BA launch and copy of the member is ordered on it); this is the ctx's own one, restored when it leaves
@@ -238,17 +242,23 @@ struct StageScope {
     StageScope(dv_ctx* ctx, const char* name, hipStream_t st = nullptr) : c(ctx), s(st ? st : ctx->stream) {
         if (!c->timing) return;
         t = dv_timer_for(c, name);
-        t->stream = s;
-        if (t->used == t->pool.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); t->pool.push_back({ a, b }); }
-        slot = t->used++;
-        (void)hipEventRecord(t->pool[slot].first, s);
+        hipEvent_t first;
+        {
+            std::lock_guard<std::mutex> lk(c->timer_mu);
+            t->stream = s;
+            if (t->used == t->pool.size()) { hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b); t->pool.push_back({ a, b }); }
+            slot = t->used++;
+            first = t->pool[slot].first; second = t->pool[slot].second;
+        }
+        (void)hipEventRecord(first, s);
     }
-    ~StageScope() { if (t) (void)hipEventRecord(t->pool[slot].second, s); }
+    ~StageScope() { if (t) (void)hipEventRecord(second, s); }
+    hipEvent_t second = nullptr;
 };
 // host wall-clock of a scope (std::chrono), accumulated under `name` next to the event timers ("h_*" names)
 struct HostScope {
     dv_ctx* c; StageTimer* t = nullptr; std::chrono::steady_clock::time_point t0;
     HostScope(dv_ctx* ctx, const char* name) : c(ctx) { if (!c->timing && !c->host_timing) return; t = dv_timer_for(c, name); t0 = std::chrono::steady_clock::now(); }
-    ~HostScope() { if (t) { t->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); t->count++; } }
+    ~HostScope() { if (t) { const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); std::lock_guard<std::mutex> lk(c->timer_mu); t->total_ms += ms; t->count++; } }
 };
 void dv_harvest_timers(dv_ctx* ctx, hipStream_t synced);      // harvests the timers recorded on `synced` (must be idle)

@@ -13,7 +13,7 @@ static std::string g_last_error;
 static std::mutex g_err_mutex;
 
 void dv_set_error(dv_ctx* ctx, const std::string& msg) {
-    if (ctx) ctx->err = msg;
+    if (ctx) { std::lock_guard<std::mutex> lk(ctx->err_mu); ctx->err = msg; }
     std::lock_guard<std::mutex> lk(g_err_mutex);
     g_last_error = msg;
 }
@@ -51,6 +51,7 @@ static int ensure_cand(dv_ctx* ctx, int w, int h) {
 }
 
 StageTimer* dv_timer_for(dv_ctx* ctx, const char* name) {
+    std::lock_guard<std::mutex> lk(ctx->timer_mu);
     for (auto& t : ctx->timers) if (t.name == name) return &t;
     ctx->timers.emplace_back();
     StageTimer& t = ctx->timers.back();
@@ -58,6 +59,7 @@ StageTimer* dv_timer_for(dv_ctx* ctx, const char* name) {
     return &t;
 }
 void dv_harvest_timers(dv_ctx* ctx, hipStream_t synced) {
+    std::lock_guard<std::mutex> lk(ctx->timer_mu);
     for (auto& t : ctx->timers) {
         if (t.stream != synced) continue;
         for (size_t i = 0; i < t.used; ++i) {
@@ -137,7 +139,12 @@ static int build_cuda_pyramids(dv_ctx* ctx, PyrSet& C0, PyrSet* C1, const DvPyr&
 extern "C" {
 
 const char* dv_last_error(dv_ctx* ctx) {
-    if (ctx) return ctx->err.c_str();
+    if (ctx) {      // a copy per calling thread: another thread of a dynamic sequence may be writing the ctx's string (valid until this thread's next call)
+        static thread_local std::string mine;
+        std::lock_guard<std::mutex> lk(ctx->err_mu);
+        mine = ctx->err;
+        return mine.c_str();
+    }
     std::lock_guard<std::mutex> lk(g_err_mutex);
     return g_last_error.c_str();
 }
@@ -239,9 +246,10 @@ int dv_sync(dv_ctx* ctx) {
 }
 
 int dv_timing_enable(dv_ctx* ctx, int on) { if (!ctx) return -1; ctx->host_timing = on == -1; ctx->timing = on > 0; ctx->kernel_timing = on >= 2; return 0; }      // -1: host wall-clock scopes only (no events, no extra syncs)
-int dv_timing_reset(dv_ctx* ctx) { if (!ctx) return -1; for (auto& t : ctx->timers) { t.total_ms = 0; t.count = 0; t.used = 0; } return 0; }
+int dv_timing_reset(dv_ctx* ctx) { if (!ctx) return -1; std::lock_guard<std::mutex> lk(ctx->timer_mu); for (auto& t : ctx->timers) { t.total_ms = 0; t.count = 0; t.used = 0; } return 0; }
 int dv_timing_get(dv_ctx* ctx, const char* name, double* total_ms, long long* count) {
     if (!ctx || !name) return -1;
+    std::lock_guard<std::mutex> lk(ctx->timer_mu);
     for (auto& t : ctx->timers) if (t.name == name) { if (total_ms) *total_ms = t.total_ms; if (count) *count = t.count; return 0; }
     if (total_ms) *total_ms = 0; if (count) *count = 0;
     return 0;

@@ -750,6 +750,8 @@ int dv_est_create(dv_ctx* ctx, const dv_est_config* cfg) {
     if (!cfg) DV_FAIL("dv_est_create: null config");
     if (!cfg->stereo) DV_FAIL("dv_est_create: monocular initialisation is out of scope (every BASELINE config is stereo)");
     if (cfg->estimate & ~3) DV_FAIL("dv_est_create: estimate: bit 0 estimate_extrinsic 1, bit 1 estimate_td 1 (estimate_extrinsic 2, the from-scratch calibration, is not built)");
+    if (cfg->estimate && cfg->dynamic)      // the reference's static-instance factors take para_ex_pose[0] / para_td (estimator.cpp:205); the object branch here builds its problem with constant extrinsics
+        DV_FAIL("dv_est_create: estimate != 0 (free extrinsic / td blocks) is not built for dynamic = 1: the object branch's factors carry no extrinsic / td Jacobians");
     delete ctx->est;
     ctx->est = new dv_estimator(*cfg);
     return be_prepare(ctx, cfg->dynamic != 0);      // nothing is allocated or created lazily in the middle of a sequence

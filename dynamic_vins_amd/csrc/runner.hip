@@ -240,8 +240,12 @@ int group_track(dv_runner* R, dv_runner::Group& g, int ahead) {
     std::vector<dv_track_job> jobs;
     for (size_t m = 0; m < g.members.size(); ++m) {
         RSeq& s = R->seqs[g.members[m]];
+        // `enqueued` first: in a team round thread 0 comes here (ahead = 0) while its teammates may still be inside seq_end of THEIR members, advancing s.next — every
+        // member is `enqueued` then (set by this thread in the previous round, two barriers ago) and its counters are not looked at.  Reading s.next before this test was a
+        // data race ThreadSanitizer reported (tests/host/runner_tsan.cpp); the value read was never used, so no result depended on it.
+        if (s.enqueued) continue;
         const int k = s.next + ahead - (s.skipped && ahead ? 1 : 0);      // (a track-only frame has already advanced s.next)
-        if (s.enqueued || k >= s.in.n_frames) continue;
+        if (k >= s.in.n_frames) continue;
         dv_track_job j{};
         j.member = (int)m; j.mem = s.in.mem; j.gray0 = s.in.left[k]; j.gray1 = s.in.right[k]; j.stride = s.stride; j.mode = DV_MODE_RAW; j.t = s.in.times[k]; j.mask = nullptr;
         jobs.push_back(j);

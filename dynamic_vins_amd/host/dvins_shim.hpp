@@ -769,11 +769,13 @@ public:
         right = std::move(right_.front().second); right_.pop_front();
         return true;
     }
-    size_t pending_left() const { return left_.size(); }
-    size_t pending_right() const { return right_.size(); }
-    int dropped_left = 0, dropped_right = 0;
+    // (under the lock, and atomic counters: a monitoring thread reads these beside the callbacks — unguarded reads of the deques' sizes were a data race ThreadSanitizer
+    //  reported, tests/host/shim_tsan.cpp)
+    size_t pending_left() const { std::lock_guard<std::mutex> lk(m_); return left_.size(); }
+    size_t pending_right() const { std::lock_guard<std::mutex> lk(m_); return right_.size(); }
+    std::atomic<int> dropped_left{0}, dropped_right{0};
 private:
-    std::mutex m_;
+    mutable std::mutex m_;
     std::deque<std::pair<double, Img>> left_, right_;
 };
 // FrameGate: which tracked frames reach the estimator (system/main.cpp:297-307): every frame on KITTI, every second one otherwise.

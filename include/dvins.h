@@ -395,7 +395,8 @@ typedef struct dv_est_config {          /* para (estimator/vio_parameters.cpp:19
     int32_t instance_init_min_num;      /* instance_init_min_num (viode.yaml:135: 4) */
     int32_t estimate;                   /* bit 0: cfg::is_estimate_ex == 1 (estimate_extrinsic 1: the extrinsics are optimised around the configured ones from the first full window with
                                            |Vs[0]| > 0.2 on — openExEstimation, estimator.cpp:87-95,632), bit 1: cfg::is_estimate_td (estimate_td 1, :98-100).  estimate_extrinsic 2
-                                           (no initial guess: CalibrationExRotation, estimator.cpp:1426-1445) is not built.  0 in every shipped YAML */
+                                           (no initial guess: CalibrationExRotation, estimator.cpp:1426-1445) is not built.  0 in every shipped YAML.  Refused together with dynamic = 1
+                                           (dv_est_create fails): the object branch's factors carry no extrinsic / td Jacobians (the reference's do, estimator.cpp:205) */
     double static_inst_threshold;       /* static_inst_threshold: scene-flow norm above which an object counts as moving (default 10) */
     /* line mode (cfg::use_line): line landmarks in FeatureManager, TriangulateLineMono, OptimizationWithOnlyLine, AddLineResidualBlock (estimator.cpp:224-253,345-395) */
     int32_t use_line, line_min_obs;     /* use_line ; line_min_obs (default 5, vio_parameters.cpp:47-54) */

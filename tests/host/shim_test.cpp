@@ -67,11 +67,11 @@ int main(int argc, char** argv) {
                 const bool ok = sync.TryPop(t0, l, t1, r);
                 if (ok) std::printf(" | %d %d %.3f %.3f", l, r, t0, t1); else std::printf(" | -");
             }
-            std::printf(" | dropped %d %d pending %zu %zu\n", sync.dropped_left, sync.dropped_right, sync.pending_left(), sync.pending_right());
+            std::printf(" | dropped %d %d pending %zu %zu\n", sync.dropped_left.load(), sync.dropped_right.load(), sync.pending_left(), sync.pending_right());
             StereoSync<int> s2;                                                      // a left image far older than every right image is dropped
             s2.PushLeft(2.000, 1); s2.PushLeft(2.100, 2); s2.PushRight(2.099, 7);
             const bool a = s2.TryPop(t0, l, t1, r); const bool b = s2.TryPop(t0, l, t1, r);
-            std::printf("%d %d %d %d %.3f dropped %d\n", (int)a, (int)b, l, r, t1, s2.dropped_left);
+            std::printf("%d %d %d %d %.3f dropped %d\n", (int)a, (int)b, l, r, t1, s2.dropped_left.load());
             FrameGate g, gk; gk.every_frame = true;
             for (int k = 0; k < 5; ++k) std::printf("%d%d ", (int)g.Pass(), (int)gk.Pass());
             std::printf("\n");

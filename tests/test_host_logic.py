@@ -17,8 +17,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.fixture(scope="module")
 def exe(tmp_path_factory):
     out = tmp_path_factory.mktemp("hl") / "host_logic_test"
-    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-ffp-contract=off", "-I", os.path.join(ROOT, "dynamic_vins_amd", "csrc"), "-o", str(out),
-                    os.path.join(ROOT, "tests", "host", "host_logic_test.cpp")], check=True)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-ffp-contract=off"] + os.environ.get("DVINS_CXX_SANITIZE", "").split()          # (tests/test_sanitizers.py: ASan + UBSan)
+                   + ["-I", os.path.join(ROOT, "dynamic_vins_amd", "csrc"), "-o", str(out), os.path.join(ROOT, "tests", "host", "host_logic_test.cpp")], check=True)
     return str(out)
 
 

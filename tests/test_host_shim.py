@@ -15,7 +15,7 @@ CFG = os.path.join(ROOT, "tests", "golden", "config", "zed_like.yaml")
 def shim_exe(tmp_path_factory):
     exe = str(tmp_path_factory.mktemp("shim") / "shim_test")
     lib = os.path.join(ROOT, "dynamic_vins_amd", "lib")
-    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "dynamic_vins_amd", "host"),
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Werror"] + os.environ.get("DVINS_CXX_SANITIZE", "").split() + ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "dynamic_vins_amd", "host"),
            os.path.join(ROOT, "tests", "host", "shim_test.cpp"), "-o", exe, "-L" + lib, "-ldvins_hip", "-Wl,-rpath," + lib, "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr

@@ -1,0 +1,56 @@
+"""Sanitizer builds of the CPU-side code (SURVEY 5 "sanitizers on the host shim").  CPU only — GPU AddressSanitizer is not available on this pool and
+nothing here loads the HIP runtime under a sanitizer.
+  * AddressSanitizer + UndefinedBehaviorSanitizer: the CPU oracle (`make -C oracle asan`, loaded into an interpreter started with LD_PRELOAD=libasan.so) under the
+    oracle's own checks, and the g++ builds of tests/host/*.cpp (the product's host-side geometry headers, the header shim's CPU commands) through their usual tests;
+  * ThreadSanitizer: the C++ runner's host machinery (runner.hip compiled as plain C++: spin barriers, teams, thread-per-group, the tracker thread + ring of a dynamic
+    sequence, the failure path) and the shim's concurrent surface (FeatureQueue, Estimator::InputIMU beside ProcessMeasurements and the getters, StereoSync) against a
+    stand-in C ABI that sleeps instead of launching (tests/host/stub_abi.cpp).
+Findings of the first run (round 6), fixed: group_track read a teammate's frame counter while that teammate advanced it (runner.hip; the value was unused);
+StereoSync::pending_left / pending_right / dropped_* read the deques unguarded (dvins_shim.hpp).  The whole CPU suite under ASan + UBSan: clean."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "tests", "host")
+
+
+def _lib(name):
+    p = subprocess.run(["gcc", "-print-file-name=" + name], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+@pytest.mark.skipif(_lib("libasan.so") is None, reason="no libasan in this toolchain")
+def test_oracle_and_host_cpp_under_asan_ubsan():
+    r = subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ)
+    env.update(LD_PRELOAD=_lib("libasan.so"), ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1",
+               DVO_LIB=os.path.join(ROOT, "oracle", "_build", "libdvins_oracle_asan.so"),
+               DVINS_CXX_SANITIZE="-g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined")
+    files = ["tests/test_oracle_checks.py", "tests/test_host_logic.py", "tests/test_host_shim.py", "tests/test_io_formats.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"] + files, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-4000:]
+    assert r.returncode == 0, tail
+    assert "AddressSanitizer" not in tail and "runtime error:" not in tail, tail
+    assert " passed" in r.stdout
+
+
+@pytest.mark.skipif(_lib("libtsan.so") is None, reason="no libtsan in this toolchain")
+def test_runner_and_shim_under_tsan():
+    r = subprocess.run(["make", "-s", "-C", HOST, "tsan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    env = dict(os.environ)
+    env["TSAN_OPTIONS"] = "halt_on_error=1:exitcode=66:second_deadlock_stack=1"
+    cfg = os.path.join(ROOT, "tests", "golden", "config", "zed_like.yaml")
+    runs = [([os.path.join(HOST, "_build", "runner_tsan"), "raw"], {}), ([os.path.join(HOST, "_build", "runner_tsan"), "dynamic"], {}),
+            ([os.path.join(HOST, "_build", "runner_tsan"), "fail"], {"DVSTUB_FAIL": "1:12"}), ([os.path.join(HOST, "_build", "shim_tsan"), cfg], {})]
+    for cmd, extra in runs:
+        e = dict(env); e.update(extra)
+        r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0 and "unexpected memory mapping" in r.stderr:
+            pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel")
+        assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (cmd, r.returncode, r.stdout[-1500:], r.stderr[-3000:])
+    assert "DIFFERENT" not in r.stdout

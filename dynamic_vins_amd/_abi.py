@@ -107,6 +107,7 @@ SIGNATURES = {
     "dv_inst_reset": (C.c_int, [_ctx]),
     "dv_inst_track_enqueue": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "dv_inst_set_disparity": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_double]),
+    "dv_inst_set_right_keys": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
     "dv_extra_points": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_inst_track_collect": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_est_get_instances": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
@@ -135,6 +136,7 @@ SIGNATURES = {
     "dv_runner_batch_rounds": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "dv_runner_batch_timing": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "dv_runner_set_dynamic": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "dv_runner_set_mask": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]),
     "dv_runner_dynamic_stats": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "dv_runner_set": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int]),
     "dv_runner_track_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),

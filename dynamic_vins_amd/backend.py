@@ -498,7 +498,8 @@ class dv_seq_input(C.Structure):
 
 class dv_seq_dynamic(C.Structure):
     _fields_ = [("inv_mask", C.c_void_p), ("mask_mem", C.c_int32), ("mode", C.c_int32), ("dets", C.c_void_p), ("n_dets", C.c_void_p), ("boxes3d", C.c_void_p), ("n_boxes3d", C.c_void_p),
-                ("disp", C.c_void_p), ("disp_mem", C.c_int32), ("disp_stride", C.c_int32), ("baseline", C.c_double)]
+                ("disp", C.c_void_p), ("disp_mem", C.c_int32), ("disp_stride", C.c_int32), ("baseline", C.c_double),
+                ("right_keys", C.c_void_p), ("right_keys_mem", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Runner:
@@ -577,6 +578,12 @@ class Runner:
         dyn.dets, dyn.n_dets = C.cast(det_ptrs, C.c_void_p), n_dets.ctypes.data
         dyn.boxes3d, dyn.n_boxes3d = C.cast(box_ptrs, C.c_void_p), n_boxes.ctypes.data
         dyn.disp, dyn.disp_mem, dyn.disp_stride, dyn.baseline = (C.cast(disps, C.c_void_p) if use_disp else None), DV_MEM_DEVICE, 0, float(q.baseline)
+        rk = getattr(q, "right_keys", None)          # VIODE-style sequences: per frame the uint32 key image of seg1 (host arrays)
+        if rk is not None:
+            rk = [np.ascontiguousarray(a, np.uint32) for a in rk[first_frame:]]
+            rkp = (C.c_void_p * nf)(*[a.ctypes.data for a in rk])
+            dyn.right_keys, dyn.right_keys_mem = C.cast(rkp, C.c_void_p), 0
+            self._keep += [rk, rkp]
         self._keep += [masks, det_ptrs, n_dets, box_ptrs, n_boxes, disps, dyn]
         if self.lib.dv_runner_set_dynamic(self.h, i, C.byref(dyn)) != 0:
             raise DvinsError(self.lib.dv_runner_error(self.h).decode())

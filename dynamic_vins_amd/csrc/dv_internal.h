@@ -93,7 +93,9 @@ void dv_launch_gftt_assign_ids(const GfttSelectArgs* tab_dev, int n_jobs, hipStr
 struct DvErodeJob { const uint8_t* src; uint8_t* tmp; uint8_t* dst; int w, h, spitch, tpitch, dpitch, k; };
 void dv_launch_erode_multi(const DvErodeJob* jobs_dev, int n_jobs, int w_max, int h_max, hipStream_t s);
 int  dv_launch_gftt_select_multi(const GfttSelectArgs* tab_dev, int n_jobs, hipStream_t s);
-struct DvLkJob { DvPyr A, B; const float2* pts_a; const int* n_dev; float2* pts_b; uint8_t* status; float add_x, add_y; int use_add, pad; };
+struct DvLkJob { DvPyr A, B; const float2* pts_a; const int* n_dev; float2* pts_b; uint8_t* status; float add_x, add_y; int use_add; uint32_t key; };      // key: the object's VIODE key (dv_launch_right_key_check)
+// VIODE: a right-image point survives TrackRightByPad only where seg1 carries the object's key (instance_feature.cpp:263-268); one workgroup per job of the stereo LK table
+void dv_launch_right_key_check(const DvLkJob* jobs_dev, int n_jobs, const uint32_t* key_img, int pitch_elems, int w, int h, hipStream_t s);
 void dv_launch_lk_track_multi(const DvLkJob* jobs_dev, int n_jobs, int n_max, int flow_back, float dist_thresh, hipStream_t s);
 void dv_launch_lk_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max,
                         int flow_back, float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s, unsigned short* order_scratch = nullptr);      // order_scratch ([n_max] ushort, device): track the points in position order, XCD-aware (lk.hip lk_order_kernel)

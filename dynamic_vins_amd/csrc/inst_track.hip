@@ -89,10 +89,11 @@ struct dv_inst_tracker {
     std::vector<unsigned> out_order;                            // ids written this frame, in output order
     // extra points from the frame's disparity map (dv_inst_set_disparity; extra_points.hip): the reference's second thread = a side stream
     const float* disp_user = nullptr; int disp_stride = 0, disp_mem = 0; double disp_baseline = 0; bool disp_next = false, xp_frame = false, xp_inflight = false;
+    const uint32_t* keys_user = nullptr; int keys_stride = 0, keys_mem = 0; bool keys_next = false; DevBuf keys_buf;      // VIODE: seg1's key image of the next frame (dv_inst_set_right_keys)
     DevBuf disp_buf, xp_pool; hipStream_t xstream = nullptr; hipEvent_t ev_xin = nullptr, ev_xdone = nullptr;
     void* xp_pinned = nullptr; size_t xp_cap_slots = 0;          // per output slot: count (64 bytes) + 3 * DV_XP_CAP doubles, written by the kernel straight into pinned memory
     ~dv_inst_tracker() {
-        disp_buf.release(); xp_pool.release();
+        disp_buf.release(); xp_pool.release(); keys_buf.release();
         if (xstream) { (void)hipStreamSynchronize(xstream); (void)hipStreamDestroy(xstream); }
         if (ev_xin) (void)hipEventDestroy(ev_xin);
         if (ev_xdone) (void)hipEventDestroy(ev_xdone);
@@ -433,7 +434,7 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         for (int k = 0; k < na && stereo; ++k) {
             Slot& S = *act[k];
             DvLkJob j{}; j.A = L; j.B = R; j.pts_a = S.tr.curr_pts; j.n_dev = S.tr.n_feat; j.pts_b = S.tr.right_pts; j.status = S.tr.right_status;
-            j.add_x = (float)S.rx; j.add_y = (float)S.ry; j.use_add = 1;
+            j.add_x = (float)S.rx; j.add_y = (float)S.ry; j.use_add = 1; j.key = S.id;
             hj[n_temporal + k] = j;
         }
         if (na > 0) DV_CHECK(dv_copy_async(T.jobs.p, hj, (size_t)(n_temporal + (stereo ? na : 0)) * sizeof(DvLkJob), s));
@@ -451,6 +452,15 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         }
         // ---- stage D ----
         if (stereo) dv_launch_lk_track_multi((const DvLkJob*)T.jobs.p + n_temporal, na, T.max_cnt, ctx->cfg.flow_back, 0.5f, s);
+        if (stereo && T.keys_next && na > 0) {          // cfg::dataset == kViode: the segmentation-key test of TrackRightByPad (instance_feature.cpp:263-268)
+            const uint32_t* kimg = T.keys_user; int kpitch = T.keys_stride / 4;
+            if (T.keys_mem != DV_MEM_DEVICE && T.keys_mem != DV_MEM_PINNED) {
+                DV_CHECK(T.keys_buf.ensure((size_t)W * H * 4));
+                DV_CHECK(hipMemcpy2DAsync(T.keys_buf.p, (size_t)W * 4, T.keys_user, (size_t)T.keys_stride, (size_t)W * 4, H, hipMemcpyHostToDevice, s));
+                kimg = (const uint32_t*)T.keys_buf.p; kpitch = W;
+            }
+            dv_launch_right_key_check((const DvLkJob*)T.jobs.p + n_temporal, na, kimg, kpitch, W, H, s);
+        }
         // ---- stage E: UndistortedPointsWithAddOffset + PtsVelocity + RightUndistortedPts + RightPtsVelocity + PostProcess -> rows ----
         if (na > 0) dv_launch_finalize_multi((const DvFinalizeJob*)((const uint8_t*)T.arena.p + fj_off), na, T.max_cnt, s);
         for (Slot* Sp : act) {
@@ -470,9 +480,22 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
         if (erase) { DV_CHECK(hipStreamSynchronize(s)); S.release(); it = T.slots.erase(it); } else ++it;
     }
     DV_CHECK(hipGetLastError());
+    T.keys_next = false;          // (the key image belongs to ONE frame, like the disparity map)
     if (T.xp_inflight) DV_CHECK(hipEventRecord(T.ev_xdone, T.xstream));
     DV_CHECK(hipEventRecord(T.done, s));
     T.last_time = T.cur_time; T.pending = true; T.frame_enqueued = true;
+    return 0;
+}
+
+// VIODE: the keys of SemanticImage::seg1 of the frame the NEXT dv_inst_track_enqueue processes (include/dvins.h)
+int dv_inst_set_right_keys(dv_ctx* ctx, const uint32_t* key_image, int stride_bytes, int mem) {
+    if (!ctx) return -1;
+    if (!ctx->inst) DV_FAIL("dv_inst_set_right_keys: call dv_inst_config first");
+    dv_inst_tracker& T = *ctx->inst;
+    if (!key_image) { T.keys_next = false; return 0; }
+    if (stride_bytes == 0) stride_bytes = 4 * ctx->cfg.width;
+    if (stride_bytes < 4 * ctx->cfg.width || (stride_bytes & 3)) DV_FAIL("dv_inst_set_right_keys: bad stride");
+    T.keys_user = key_image; T.keys_stride = stride_bytes; T.keys_mem = mem; T.keys_next = true;
     return 0;
 }
 

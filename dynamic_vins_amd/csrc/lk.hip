@@ -488,3 +488,20 @@ void dv_launch_lk_track_multi(const DvLkJob* jobs_dev, int n_jobs, int n_max, in
     const double eps = 0.01;
     hipLaunchKernelGGL(lk_track_multi_kernel, dim3(n_max, n_jobs), dim3(64), 0, s, jobs_dev, flow_back, dist_thresh, eps * eps);
 }
+
+// VIODE (cfg::dataset == kViode): InstFeat::TrackRightByPad keeps a right-image point only if the RIGHT camera's segmentation image carries the object's key at that
+// pixel — status[i] && VIODE::PixelToKey(right_points[i], img.seg1) != id -> 0 (front_end/instance_feature.cpp:263-268; cv::Mat::at(Point2f) rounds half to even).
+// One workgroup per job of the stereo LK table, behind that launch on the same stream; key_img = dv_viode_mask's key image of seg1.
+__global__ __launch_bounds__(64) void right_key_check_kernel(const DvLkJob* __restrict__ jobs, const uint32_t* __restrict__ key_img, int pitch, int w, int h) {
+    const DvLkJob j = jobs[blockIdx.x];
+    const int n = *j.n_dev;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        if (!j.status[i]) continue;
+        const float2 p = j.pts_b[i];
+        const int x = min(max(__float2int_rn(p.x), 0), w - 1), y = min(max(__float2int_rn(p.y), 0), h - 1);      // (InBorder has already put the point inside the image)
+        if (key_img[(size_t)y * pitch + x] != j.key) j.status[i] = 0;
+    }
+}
+void dv_launch_right_key_check(const DvLkJob* jobs_dev, int n_jobs, const uint32_t* key_img, int pitch_elems, int w, int h, hipStream_t s) {
+    if (n_jobs > 0 && key_img) hipLaunchKernelGGL(right_key_check_kernel, dim3(n_jobs), dim3(64), 0, s, jobs_dev, key_img, pitch_elems, w, h);
+}

@@ -52,6 +52,8 @@ struct RSeq {
                                                                                                 // a thread per dv_runner_run put that into the first frames of every call); track_last = the last frame it may take
     std::unique_ptr<std::mutex> ring_mu = std::make_unique<std::mutex>(); std::unique_ptr<std::condition_variable> ring_cv = std::make_unique<std::condition_variable>();
     long long detections = 0, object_features = 0, frames_with_objects = 0; int min_detections = 1 << 30;
+    // TrackImageNaive over the sequence (dv_runner_set_mask): per frame the inverse merged instance mask, and the tracking mode that takes it
+    const uint8_t* const* raw_mask = nullptr; int raw_mode = DV_MODE_RAW;
 };
 }
 namespace {
@@ -92,7 +94,7 @@ int fail(dv_runner* R, RSeq& s, const char* what) {
     return -1;
 }
 int seq_enqueue(dv_runner* R, RSeq& s, int k) {
-    if (dv_track_stereo_enqueue(s.ctx, s.in.left[k], s.in.right[k], s.w, s.h, s.stride, s.in.times[k], nullptr, DV_MODE_RAW, s.in.mem)) return fail(R, s, "dv_track_stereo_enqueue");
+    if (dv_track_stereo_enqueue(s.ctx, s.in.left[k], s.in.right[k], s.w, s.h, s.stride, s.in.times[k], s.raw_mask ? s.raw_mask[k] : nullptr, s.raw_mode, s.in.mem)) return fail(R, s, "dv_track_stereo_enqueue");
     s.enqueued = true;
     return 0;
 }
@@ -110,6 +112,7 @@ int dyn_enqueue(dv_runner* R, RSeq& s, int k) {
     // (frames and mask share `mem` in dv_track_stereo_enqueue: a device-resident sequence keeps both in HBM)
     if (dv_track_stereo_enqueue(s.ctx, s.in.left[k], s.in.right[k], s.w, s.h, s.stride, s.in.times[k], d.inv_mask ? d.inv_mask[k] : nullptr, mode, s.in.mem)) return fail(R, s, "dv_track_stereo_enqueue");
     if (d.disp && d.disp[k] && dv_inst_set_disparity(s.ctx, d.disp[k], d.disp_stride, d.disp_mem, d.baseline)) return fail(R, s, "dv_inst_set_disparity");
+    if (d.right_keys && d.right_keys[k] && dv_inst_set_right_keys(s.ctx, d.right_keys[k], 0, d.right_keys_mem)) return fail(R, s, "dv_inst_set_right_keys");
     if (dv_inst_track_enqueue(s.ctx, s.in.times[k], d.dets ? d.dets[k] : nullptr, d.n_dets ? d.n_dets[k] : 0, d.boxes3d ? d.boxes3d[k] : nullptr, d.n_boxes3d ? d.n_boxes3d[k] : 0)) return fail(R, s, "dv_inst_track_enqueue");
     s.enqueued = true;
     return 0;
@@ -127,6 +130,12 @@ int dyn_begin(dv_runner* R, RSeq& s) {
     if (!b.valid) { if (!s.enqueued && dyn_enqueue(R, s, k)) return -1; if (dyn_collect(R, s, b)) return -1; }
     const double t = s.in.times[k];
     s.n_rows = b.n_rows;
+    if (s.in.ba_stride > 1 && (k % s.in.ba_stride) != 0) {      // tracked only: both trackers have seen the frame, the back end has not (system/main.cpp:300-312: frames 0, 2, 4, ... outside KITTI)
+        if (k + 1 < s.in.n_frames) { if (dyn_enqueue(R, s, k + 1) || dyn_collect(R, s, s.db[s.cur ^ 1])) return -1; }
+        b.valid = false; s.cur ^= 1; ++s.next; s.skipped = true;
+        return 0;
+    }
+    s.skipped = false;
     if (seq_feed_imu(R, s, t)) return -1;
     // the window solve goes to the GPU with the background rows alone; then the next frame's tracking (thread T2 of the reference, independent of T3); then the object
     // branch of ProcessImage beside the window solve; then the next frame's rows are collected while the solve is still in flight
@@ -184,6 +193,13 @@ int dyn_begin_threaded(dv_runner* R, RSeq& s) {
     RSeq::DynBuf& b = *bp;
     const double t = s.in.times[k];
     s.n_rows = b.n_rows;
+    if (s.in.ba_stride > 1 && (k % s.in.ba_stride) != 0) {      // tracked only (see dyn_begin): the slot goes back to the tracker unread
+        { std::lock_guard<std::mutex> lk(*s.ring_mu); b.valid = false; s.ring_pos = (s.ring_pos + 1) % RSeq::RING; --s.ring_count; ++s.ring_head; }
+        s.ring_cv->notify_all();
+        ++s.next; s.skipped = true;
+        return 0;
+    }
+    s.skipped = false;
     if (seq_feed_imu(R, s, t)) return -1;
     const int rc = dv_est_process_dynamic_begin_ego(s.ctx, b.rows.data(), b.n_rows, t);
     if (rc < 0) return fail(R, s, "dv_est_process_dynamic_begin_ego");
@@ -247,7 +263,7 @@ int group_track(dv_runner* R, dv_runner::Group& g, int ahead) {
         const int k = s.next + ahead - (s.skipped && ahead ? 1 : 0);      // (a track-only frame has already advanced s.next)
         if (k >= s.in.n_frames) continue;
         dv_track_job j{};
-        j.member = (int)m; j.mem = s.in.mem; j.gray0 = s.in.left[k]; j.gray1 = s.in.right[k]; j.stride = s.stride; j.mode = DV_MODE_RAW; j.t = s.in.times[k]; j.mask = nullptr;
+        j.member = (int)m; j.mem = s.in.mem; j.gray0 = s.in.left[k]; j.gray1 = s.in.right[k]; j.stride = s.stride; j.mode = s.raw_mode; j.t = s.in.times[k]; j.mask = s.raw_mask ? s.raw_mask[k] : nullptr;      // (a masked / naive member keeps its own launches: dv_batch_track_enqueue)
         jobs.push_back(j);
     }
     if (jobs.empty()) return 0;
@@ -511,6 +527,18 @@ int dv_runner_set_dynamic(dv_runner* R, int seq, const dv_seq_dynamic* dyn) {
     s.dynamic = true; s.dyn = *dyn;
     for (auto& b : s.db) { b.rows.resize(DV_MAX_FEATS); b.insts.resize(64); b.ifeats.resize(64 * 256); b.pts.resize((size_t)3 * 65536); b.valid = false; }
     for (auto& b : s.ring) { b.rows.resize(DV_MAX_FEATS); b.insts.resize(64); b.ifeats.resize(64 * 256); b.pts.resize((size_t)3 * 65536); b.valid = false; }
+    return 0;
+}
+// slam_type naive over a sequence (system/main.cpp:263-265 FeatureTrack -> TrackImageNaive): per frame the inverse merged instance mask (0 = object) the tracker takes,
+// in the frames' memory kind; mode DV_MODE_NAIVE (or DV_MODE_RAW with inv_mask NULL to go back).  The estimator stays the raw one.  Before the first dv_runner_run.
+int dv_runner_set_mask(dv_runner* R, int seq, const uint8_t* const* inv_mask, int mask_mem, int mode) {
+    if (!R || seq < 0 || seq >= (int)R->seqs.size()) return -1;
+    RSeq& s = R->seqs[seq];
+    if (s.next != 0 || s.enqueued || s.pending) { R->err = "dv_runner_set_mask: the sequence has already started"; return -1; }
+    if (mode != DV_MODE_RAW && mode != DV_MODE_NAIVE) { R->err = "dv_runner_set_mask: mode must be DV_MODE_RAW or DV_MODE_NAIVE (DV_MODE_SEMANTIC belongs to dv_runner_set_dynamic)"; return -1; }
+    if (inv_mask && mask_mem != s.in.mem) { R->err = "dv_runner_set_mask: mask_mem must equal the frames' mem"; return -1; }
+    if (s.dynamic) { R->err = "dv_runner_set_mask: the sequence is dynamic (its mask travels in dv_seq_dynamic)"; return -1; }
+    s.raw_mask = inv_mask; s.raw_mode = mode;
     return 0;
 }
 int dv_runner_dynamic_stats(dv_runner* R, int seq, long long* detections, long long* object_features, long long* frames_with_objects, int* min_detections) {

@@ -117,6 +117,18 @@ class Context:
             ptr = int(disp)
         self._check(self.lib.dv_inst_set_disparity(self.h, ptr, int(stride_bytes), int(mem), float(baseline)))
 
+    def inst_set_right_keys(self, key_img, mem=DV_MEM_HOST):
+        """VIODE: the key image of seg1 (viode_mask(...)[2]: uint32 [h, w] numpy array, or a device pointer with mem=DV_MEM_DEVICE) of the frame the next inst_track_enqueue
+        processes: TrackRightByPad's segmentation-key test (front_end/instance_feature.cpp:263-268)"""
+        if key_img is None:
+            self._check(self.lib.dv_inst_set_right_keys(self.h, None, 0, 0))
+            return
+        if isinstance(key_img, np.ndarray):
+            self._keys_keep = np.ascontiguousarray(key_img, np.uint32)
+            self._check(self.lib.dv_inst_set_right_keys(self.h, self._keys_keep.ctypes.data, self._keys_keep.strides[0], DV_MEM_HOST))
+        else:
+            self._check(self.lib.dv_inst_set_right_keys(self.h, int(key_img), 0, int(mem)))
+
     def extra_points(self, mask, box_xy, disp, baseline, stage=0):
         """operator form: one object through InstFeat::DetectExtraPoints (stage 1) or the whole extra-point pipeline (stage 0) -> float64 [n, 3]"""
         mask = np.ascontiguousarray(mask, np.uint8); disp = np.ascontiguousarray(disp, np.float32)

@@ -10,9 +10,15 @@
 //   <sequence dir>/imu.csv            with `imu: 1`: EuRoC layout  t[ns], wx, wy, wz, ax, ay, az  (lines starting with # are comments)
 //   output: <output dir>/<seq>_<VIO|VO>_<raw|naive|dynamic>_<LinePoint|PointOnly>_Odometry.txt (utils/io/io_parameters.cpp:18-80), one line per frame handed to the
 //           back end: "<sec>.<nsec> px py pz qx qy qz qw" (output.cpp:199-227)
+//   <sequence dir>/segmentation0/*.png  <sequence dir>/segmentation1/*.png   dataset_type viode with slam_type naive / dynamic: the RGB label images of the two cameras
+//                                                                        (the bag's image0/1_segmentation_topic, utils/io/system_call_back.cpp:18-35), one per pair
 // Frame flow: every pair is tracked; every 2nd tracked pair goes to the back end unless dataset_type is kitti (system/main.cpp:300-307).
-// Scope: raw / naive tracking without masks (the detector, segmentation and stereo networks that feed dynamic mode are upstream of the path: SURVEY 2); a config
-// that asks for them is run on the background tracker alone and says so.
+// VIODE (config 3) needs no network in the reference and none here: segmentation image -> VIODE::SetViodeMaskSimple (naive) / SetViodeMaskAndRoi (dynamic)
+// (image_process/image_process.cpp:161-178, utils/dataset/viode_utils.cpp:21-218; dv_viode_mask does the per-pixel work) -> the inverse merged mask for TrackImageNaive
+// resp. TrackSemanticImage, and in dynamic mode one instance per key present (AddViodeInstances, front_end/dynamic_tracker.cpp:585-605: track_id = key, rect =
+// cv::Rect(min_pt, max_pt), ROI mask = the key's pixels) for InstsTrack, whose right-image points must carry the object's key in segmentation1
+// (front_end/instance_feature.cpp:263-268).  No disparity network: the objects get no extra points (SemanticImage::disp stays empty).
+// Other data sets' detector / segmentation / stereo networks are upstream of the path: such a config runs on the background tracker alone and says so.
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -30,7 +36,7 @@
 using namespace dynamic_vins;
 
 namespace {
-struct Gray { int w = 0, h = 0; std::vector<uint8_t> d; };
+struct Gray { int w = 0, h = 0; std::vector<uint8_t> d; std::vector<uint8_t> bgr; };      // bgr: filled for colour files when asked (segmentation images), B G R per pixel like cv::imread
 
 std::vector<std::string> list_images(const std::string& dir) {
     std::vector<std::string> out;
@@ -79,7 +85,7 @@ Gray read_pgm(const std::vector<uint8_t>& buf, const std::string& path) {
     return g;
 }
 // non-interlaced 8-bit PNG, colour type 0 (gray), 2 (RGB), 4 (gray + alpha), 6 (RGBA): what EuRoC / KITTI / VIODE ship
-Gray read_png(const std::vector<uint8_t>& buf, const std::string& path) {
+Gray read_png(const std::vector<uint8_t>& buf, const std::string& path, bool keep_colour = false) {
     static const uint8_t sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
     if (buf.size() < 33 || std::memcmp(buf.data(), sig, 8)) throw std::runtime_error("dvins_node: " + path + " is not a PNG");
     auto be32 = [&](size_t o) { return ((uint32_t)buf[o] << 24) | ((uint32_t)buf[o + 1] << 16) | ((uint32_t)buf[o + 2] << 8) | buf[o + 3]; };
@@ -101,6 +107,7 @@ Gray read_png(const std::vector<uint8_t>& buf, const std::string& path) {
     if (uncompress(raw.data(), &out_len, z.data(), (uLong)z.size()) != Z_OK || out_len != raw.size()) throw std::runtime_error("dvins_node: " + path + ": inflate failed");
     std::vector<uint8_t> prev(row, 0), cur(row);
     Gray g; g.w = w; g.h = h; g.d.resize((size_t)w * h);
+    if (keep_colour) g.bgr.resize((size_t)w * h * 3);
     for (int y = 0; y < h; ++y) {
         const uint8_t* in = raw.data() + (row + 1) * y; const int f = in[0];
         for (size_t x = 0; x < row; ++x) {
@@ -111,14 +118,20 @@ Gray read_png(const std::vector<uint8_t>& buf, const std::string& path) {
             cur[x] = (uint8_t)v;
         }
         for (int x = 0; x < w; ++x) g.d[(size_t)y * w + x] = ch <= 2 ? cur[(size_t)x * ch] : bgr2gray(cur[(size_t)x * ch], cur[(size_t)x * ch + 1], cur[(size_t)x * ch + 2]);
+        if (keep_colour) for (int x = 0; x < w; ++x) {
+            uint8_t* o = &g.bgr[((size_t)y * w + x) * 3];
+            if (ch <= 2) o[0] = o[1] = o[2] = cur[(size_t)x * ch]; else { o[0] = cur[(size_t)x * ch + 2]; o[1] = cur[(size_t)x * ch + 1]; o[2] = cur[(size_t)x * ch]; }
+        }
         prev.swap(cur);
     }
     return g;
 }
-Gray read_image(const std::string& path) {
+Gray read_image(const std::string& path, bool keep_colour = false) {
     const std::vector<uint8_t> buf = read_file(path);
-    return (buf.size() > 1 && buf[0] == 'P') ? read_pgm(buf, path) : read_png(buf, path);
+    if (buf.size() > 1 && buf[0] == 'P') { if (keep_colour) throw std::runtime_error("dvins_node: " + path + ": segmentation images must be PNG"); return read_pgm(buf, path); }
+    return read_png(buf, path, keep_colour);
 }
+constexpr int kMinInstSize = 8;          // a VIODE instance's rectangle must be at least this many pixels on both sides to be handed to the object tracker
 std::string stem(const std::string& path) {
     std::string s = path;
     while (s.size() > 1 && s.back() == '/') s.pop_back();
@@ -151,9 +164,15 @@ int main(int argc, char** argv) {
         const std::string cfg_path = pos[0], seq_dir = pos[1], out_dir = pos.size() > 2 ? pos[2] : ".";
         if (seq_name.empty()) seq_name = stem(seq_dir);
         Config cfg = ReadConfig(cfg_path, device, seq_name, kitti_calib);
-        if (cfg.dynamic) std::fprintf(stderr, "dvins_node: slam_type dynamic needs the detector / segmentation outputs (upstream of this path): running the background tracker without masks\n");
+        // dataset_type viode with slam_type naive / dynamic: everything the mode needs comes out of the segmentation images (cfg::is_input_seg, utils/parameters.cpp:59-64)
+        const bool viode = cfg.input_seg && !cfg.viode_dynamic_keys.empty();
+        if (cfg.input_seg && !viode) std::fprintf(stderr, "dvins_node: dataset_type viode with slam_type %s, but rgb_to_label_file / dynamic_label_id give no dynamic key: running without masks\n", cfg.slam_type.c_str());
+        if ((cfg.dynamic || cfg.naive) && !cfg.input_seg) std::fprintf(stderr, "dvins_node: slam_type %s on this data set needs the detector / segmentation outputs (upstream of this path): running the background tracker without masks\n", cfg.slam_type.c_str());
         if (cfg.est.use_line) std::fprintf(stderr, "dvins_node: use_line needs the LSD / LBD detector's segments (upstream of this path): running without lines\n");
-        cfg.est.dynamic = 0; cfg.est.use_line = 0;
+        const bool run_dynamic = cfg.dynamic && viode, run_naive = cfg.naive && viode;
+        if (viode && cfg.viode_dynamic_keys.size() > 64) throw std::runtime_error("dvins_node: more than 64 dynamic keys (dv_viode_mask takes at most 64)");
+        cfg.est.dynamic = run_dynamic ? 1 : 0; cfg.est.use_line = 0;
+        if (run_dynamic) cfg.est.use_det3d = 0;          // (no 3-D detector output in a VIODE directory; viode.yaml ships use_det3d: 0)
 
         std::vector<std::string> lf = list_images(seq_dir + "/left"), rf = list_images(seq_dir + "/right");
         if (lf.empty() || lf.size() != rf.size()) throw std::runtime_error("dvins_node: left/ and right/ must hold the same, non-zero number of images");
@@ -188,8 +207,64 @@ int main(int argc, char** argv) {
         dv_seq_input in{};
         in.left = lp.data(); in.right = rp.data(); in.times = times.data(); in.n_frames = n; in.mem = DV_MEM_HOST; in.stride = 0; in.ba_stride = cfg.every_frame ? 1 : 2;
         in.imu_t = imu_t.data(); in.imu_acc = imu_a.data(); in.imu_gyr = imu_g.data(); in.n_imu = (int)imu_t.size();
+
+        // ---- VIODE: thread T1's part of the frame (ImageProcessor::Run, image_process.cpp:161-178) for every pair, before the run ----
+        const int W = cfg.front.width, H = cfg.front.height;
+        std::vector<std::vector<uint8_t>> inv_mask;                       // img.inv_merge_mask per frame
+        std::vector<std::vector<uint32_t>> right_keys;                    // PixelToKey of every pixel of seg1
+        std::vector<std::vector<dv_inst_det>> dets; std::vector<std::vector<std::vector<uint8_t>>> det_masks;
+        std::vector<const uint8_t*> mask_ptr; std::vector<const uint32_t*> keys_ptr; std::vector<const dv_inst_det*> det_ptr; std::vector<int32_t> n_dets;
+        if (viode) {
+            const std::vector<std::string> s0 = list_images(seq_dir + "/segmentation0");
+            const std::vector<std::string> s1 = run_dynamic ? list_images(seq_dir + "/segmentation1") : std::vector<std::string>();
+            if ((int)s0.size() < n || (run_dynamic && (int)s1.size() < n)) throw std::runtime_error("dvins_node: segmentation0/ (and, in dynamic mode, segmentation1/) must hold one label image per pair");
+            const std::vector<uint32_t>& keys = cfg.viode_dynamic_keys; const int nk = (int)keys.size();
+            inv_mask.resize(n); right_keys.resize(n); dets.resize(n); det_masks.resize(n); mask_ptr.resize(n); keys_ptr.resize(n); det_ptr.resize(n); n_dets.assign(n, 0);
+            std::vector<uint8_t> merge((size_t)W * H); std::vector<uint32_t> kimg((size_t)W * H); std::vector<int32_t> boxes(4 * (size_t)nk);
+            for (int k = 0; k < n; ++k) {
+                const Gray seg = read_image(s0[k], true);
+                if (seg.w != W || seg.h != H) throw std::runtime_error("dvins_node: " + s0[k] + " is not image_width x image_height of the config");
+                inv_mask[k].resize((size_t)W * H);
+                if (dv_viode_mask(ctx, seg.bgr.data(), W, H, 3 * W, keys.data(), nk, merge.data(), inv_mask[k].data(), run_dynamic ? kimg.data() : nullptr, boxes.data()))
+                    throw std::runtime_error(std::string("dvins_node: dv_viode_mask: ") + dv_last_error(ctx));
+                mask_ptr[k] = inv_mask[k].data();
+                if (!run_dynamic) continue;
+                // VIODE::SetViodeMaskAndRoi (viode_utils.cpp:177-218): one Box2D per key present; ascending key (the reference walks an unordered_map)
+                for (int q = 0; q < nk; ++q) {
+                    const int r0 = boxes[4 * q], r1 = boxes[4 * q + 1], c0 = boxes[4 * q + 2], c1 = boxes[4 * q + 3];
+                    if (r1 < r0 || c1 < c0) continue;
+                    const int bw = c1 - c0, bh = r1 - r0;                        // cv::Rect(min_pt, max_pt): the max row / column is excluded
+                    if (bw < kMinInstSize || bh < kMinInstSize) continue;        // (declared deviation: see dynamic_vins_amd/viode.py detections())
+                    std::vector<uint8_t> m((size_t)bw * bh);
+                    for (int y = 0; y < bh; ++y) for (int x = 0; x < bw; ++x) m[(size_t)y * bw + x] = kimg[(size_t)(r0 + y) * W + c0 + x] == keys[q] ? 255 : 0;
+                    det_masks[k].push_back(std::move(m));
+                    dv_inst_det d{}; d.track_id = keys[q]; d.class_id = 0; d.x = c0; d.y = r0; d.w = bw; d.h = bh; d.points = nullptr; d.n_points = 0;
+                    dets[k].push_back(d);
+                }
+                for (size_t q = 0; q < dets[k].size(); ++q) dets[k][q].mask = det_masks[k][q].data();
+                det_ptr[k] = dets[k].empty() ? nullptr : dets[k].data(); n_dets[k] = (int)dets[k].size();
+                const Gray seg1 = read_image(s1[k], true);
+                if (seg1.w != W || seg1.h != H) throw std::runtime_error("dvins_node: " + s1[k] + " is not image_width x image_height of the config");
+                right_keys[k].resize((size_t)W * H);
+                std::vector<uint8_t> tmp_inv((size_t)W * H);
+                if (dv_viode_mask(ctx, seg1.bgr.data(), W, H, 3 * W, keys.data(), nk, merge.data(), tmp_inv.data(), right_keys[k].data(), boxes.data()))
+                    throw std::runtime_error(std::string("dvins_node: dv_viode_mask: ") + dv_last_error(ctx));
+                keys_ptr[k] = right_keys[k].data();
+            }
+            if (run_dynamic && dv_inst_config(ctx, cfg.max_dynamic_cnt, cfg.min_dynamic_dist, 0)) throw std::runtime_error(std::string("dvins_node: ") + dv_last_error(ctx));
+        }
+
         dv_runner* runner = dv_runner_create(&ctx, &in, 1, 0, 1);
         if (!runner) throw std::runtime_error(std::string("dvins_node: ") + dv_last_error(nullptr));
+        dv_seq_dynamic dyn{};
+        if (run_dynamic) {
+            dyn.inv_mask = mask_ptr.data(); dyn.mask_mem = DV_MEM_HOST; dyn.mode = DV_MODE_SEMANTIC;
+            dyn.dets = det_ptr.data(); dyn.n_dets = n_dets.data(); dyn.boxes3d = nullptr; dyn.n_boxes3d = nullptr; dyn.disp = nullptr; dyn.baseline = cfg.baseline;
+            dyn.right_keys = keys_ptr.data(); dyn.right_keys_mem = DV_MEM_HOST;
+            if (dv_runner_set_dynamic(runner, 0, &dyn)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));
+        } else if (run_naive) {
+            if (dv_runner_set_mask(runner, 0, mask_ptr.data(), DV_MEM_HOST, DV_MODE_NAIVE)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));
+        }
         double wall = 0;
         if (dv_runner_run(runner, n, &wall)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));
         int rows = 0;
@@ -202,6 +277,11 @@ int main(int argc, char** argv) {
         if (!out) throw std::runtime_error("dvins_node: cannot write " + out_path);
         for (int i = 0; i < rows; ++i) { std::array<double, 16> s{}; for (int k = 0; k < 7; ++k) s[k] = fr[9 * (size_t)i + 1 + k]; out << TumLine(fr[9 * (size_t)i], s) << "\n"; }
         std::printf("dvins_node: %d pairs tracked, %d frames through the back end in %.3f s (%.1f pairs/s) -> %s\n", n, rows, wall, n / std::max(wall, 1e-9), out_path.c_str());
+        if (run_dynamic) {
+            long long nd = 0, nf = 0, fo = 0; int mn = 0;
+            dv_runner_dynamic_stats(runner, 0, &nd, &nf, &fo, &mn);
+            std::printf("dvins_node: dynamic mode from the segmentation images: %lld detections, %lld object feature rows, %lld frames with objects\n", nd, nf, fo);
+        }
         dv_runner_destroy(runner);
         dv_destroy(ctx);
         return 0;

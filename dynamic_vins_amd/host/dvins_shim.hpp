@@ -29,6 +29,7 @@
 #include <cmath>
 #include <memory>
 #include <thread>
+#include <algorithm>
 #include <condition_variable>
 #include <cstdint>
 #include <cstdio>
@@ -91,6 +92,15 @@ public:
     double num(const std::string& k) const { return std::strtod(str(k).c_str(), nullptr); }
     double num(const std::string& k, double dflt) const { return has(k) ? num(k) : dflt; }
     int integer(const std::string& k, int dflt) const { return has(k) ? (int)std::lround(num(k)) : dflt; }
+    std::vector<int> int_list(const std::string& k) const {          // a flow sequence on one line: "dynamic_label_id: [241,242,243]"
+        std::vector<int> out;
+        if (!has(k)) return out;
+        std::string t = str(k);
+        for (char& c : t) if (c == '[' || c == ']' || c == ',') c = ' ';
+        std::istringstream is(t); double v;
+        while (is >> v) out.push_back((int)v);
+        return out;
+    }
     const std::vector<double>& matrix(const std::string& k) const {
         auto it = mats_.find(k);
         if (it == mats_.end()) throw std::runtime_error("dvins: config matrix missing: " + k);
@@ -174,7 +184,10 @@ struct Config {
     bool dynamic = false, naive = false, input_seg = false;
     bool every_frame = false;            // system/main.cpp:300-307: KITTI forwards every frame to the back end, every other dataset every second one
     int max_dynamic_cnt = 0, min_dynamic_dist = 0, use_det3d = 0, undistort_input = 0, only_frontend = 0;
-    bool static_inst_as_background = false;     // vio_parameters.cpp:69-71 -> estimator.cpp:1583, system/main.cpp:217-245
+    bool static_inst_as_background = true;      // vio_parameters.h:86 (default TRUE), vio_parameters.cpp:69-71 -> estimator.cpp:1583, system/main.cpp:217-245
+    // VIODE (utils/dataset/viode_utils.cpp:254-276 SetParameters): the keys VIODE::IsDynamic accepts — PixelToKey(r, g, b) = r * 1000000 + g * 1000 * b (sic) of every
+    // rgb_ids.txt line whose label id is one of dynamic_label_id; the first line of a key wins (unordered_map::insert).  Ascending.  Empty unless input_seg.
+    std::vector<uint32_t> viode_dynamic_keys; std::string rgb_to_label_file;
     double baseline = 0, max_solver_time = 0;
     std::map<std::string, std::string> topics;  // image0_topic, image1_topic, image0_segmentation_topic, image1_segmentation_topic, imu_topic
 };
@@ -219,7 +232,7 @@ inline Config ReadConfig(const std::string& config_path, int device = 0, const s
         e.instance_init_min_num = y.integer("instance_init_min_num", 4);
     }
     if (y.has("static_inst_threshold")) e.static_inst_threshold = y.num("static_inst_threshold");
-    c.static_inst_as_background = y.integer("static_inst_as_background", 0) != 0;
+    if (y.has("static_inst_as_background")) c.static_inst_as_background = y.integer("static_inst_as_background", 1) != 0;
     e.estimate = 0;                         // parameters.cpp:82-99: both switches are forced to 0 without an IMU
     if (e.use_imu) {
         const int ex = y.integer("estimate_extrinsic", 0);
@@ -248,6 +261,23 @@ inline Config ReadConfig(const std::string& config_path, int device = 0, const s
         }
     }
     for (const char* k : { "image0_topic", "image1_topic", "image0_segmentation_topic", "image1_segmentation_topic", "imu_topic" }) if (y.has(k)) c.topics[k] = y.str(k);
+    if (c.input_seg && y.has("rgb_to_label_file")) {          // VIODE::SetParameters: basic_dir + rgb_to_label_file; a file next to the config is accepted too (the reference's basic_dir is the author's home)
+        const std::string rel = y.str("rgb_to_label_file");
+        std::string path = y.str("basic_dir", "") + rel;
+        { std::string up = dir; for (int lvl = 0; lvl < 5 && !std::ifstream(path); ++lvl) { path = up + "/" + rel; up = dir_of(up); } }      // the config's directory, then its ancestors (the repository root the shipped files are relative to)
+        std::ifstream f(path);
+        if (!f) throw std::runtime_error("Can not open:" + path);                                   // ReadViodeRgbIds (viode_utils.cpp:225-227)
+        c.rgb_to_label_file = path;
+        const std::vector<int> dyn = y.int_list("dynamic_label_id");
+        std::map<uint32_t, int> key_to_id;
+        std::string line; std::getline(f, line);                                                    // the header line
+        while (std::getline(f, line)) {
+            int v[4] = { 0, 0, 0, 0 }; std::istringstream is(line); std::string tok;
+            for (int j = 0; j < 4 && std::getline(is, tok, ','); ++j) v[j] = std::atoi(tok.c_str());
+            key_to_id.insert({ (uint32_t)v[1] * 1000000u + (uint32_t)v[2] * 1000u * (uint32_t)v[3], v[0] });
+        }
+        for (const auto& kv : key_to_id) if (std::find(dyn.begin(), dyn.end(), kv.second) != dyn.end()) c.viode_dynamic_keys.push_back(kv.first);
+    }
     return c;
 }
 

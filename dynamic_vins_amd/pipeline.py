@@ -103,6 +103,8 @@ class Pipeline:
 
     def _finish(self, t):
         st = self.est.ProcessMeasurementsEnd()
+        if getattr(self, "keep_frame_rows", False):          # every frame handed to the back end, as the runner's dv_runner_get_frames keeps them (what SaveBodyTrajectory writes)
+            self.frame_rows.append((t, self.est.window()[10, :7].copy(), int(st.nonlinear)))
         if st.nonlinear:
             self.poses.append(self.est.window()[10, :7])
             self.pose_times.append(t)
@@ -207,7 +209,7 @@ class DynamicPipeline(Pipeline):
     as TrackSemanticImage's line thread delivers them (background_tracker.cpp:774-780, 809-817)."""
 
     def __init__(self, seq: DynamicSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, max_dynamic_cnt=50, min_dynamic_dist=5, use_det3d=1,
-                 static_inst_threshold=1.0, mask_morphology_size=0, segments=None, est_kw=None, extra_from_disparity=True):
+                 static_inst_threshold=1.0, mask_morphology_size=0, segments=None, est_kw=None, extra_from_disparity=True, ba_stride=1):
         from .frontend import DV_MODE_SEMANTIC
         self.extra_from_disparity = extra_from_disparity      # False: the detections' own `points` are handed through (the caller ran the extra-point pipeline)
         self.seq, self.host = seq, None
@@ -223,9 +225,10 @@ class DynamicPipeline(Pipeline):
         self.k_imu = self.next = 0
         self.enqueued = False
         self._prefetched = None
-        self.ba_stride = 1
+        self.ba_stride = ba_stride          # 2: every tracked frame goes through both trackers, every 2nd one to the back end (system/main.cpp:300-307: every data set but KITTI)
         self.last_state = None
         self.poses, self.pose_times = [], []
+        self.frame_rows, self.keep_frame_rows = [], False      # (t, [px py pz qx qy qz qw], nonlinear) of every frame handed to the back end when keep_frame_rows is set
         self.stat = dict(frames=0, frames_with_objects=0, object_detections=0, object_features=0, min_detections=10 ** 9)      # what the object branch was fed over the run
 
     def _enqueue(self, k):
@@ -233,6 +236,8 @@ class DynamicPipeline(Pipeline):
         self.ctx.track_stereo_enqueue(l.data_ptr(), r.data_ptr(), self.seq.times[k], self.seq.inv_mask_dev[k].data_ptr(), self.mode, DV_MEM_DEVICE)
         if self.extra_from_disparity:      # the extra points of the objects: DetectExtraPoints + ProcessExtraPoints on the device from the frame's disparity map
             self.ctx.inst_set_disparity(self.seq.disp_dev[k].data_ptr(), self.seq.baseline, DV_MEM_DEVICE)
+        if getattr(self.seq, "right_keys", None) is not None:      # VIODE: seg1's key image -> TrackRightByPad's segmentation-key test
+            self.ctx.inst_set_right_keys(self.seq.right_keys[k])
         self.ctx.inst_track_enqueue(self.seq.times[k], self.seq.dets[k], self.seq.boxes3d[k] if self.use_det3d else None)
         self.enqueued = True
 
@@ -255,6 +260,13 @@ class DynamicPipeline(Pipeline):
         rows, insts, ifeats, pts = pre
         self.enqueued = False
         t = s.times[k]
+        if self.ba_stride > 1 and (k % self.ba_stride) != 0:      # tracked only (both trackers keep their state up to date; system/main.cpp:300-312)
+            if k + 1 < len(s.frames):
+                self._enqueue(k + 1)
+                self._prefetched = self._collect()
+            self.next += 1
+            self.rows, self.insts, self.ifeats, self.ipts = rows, insts, ifeats, pts
+            return self.last_state if self.last_state is not None else self.est.state
         self._feed_imu(t)
         if self.segments is not None:
             self.lrows = self.line_rows(t)

@@ -496,8 +496,13 @@ typedef struct dv_seq_dynamic {
     const dv_inst_det* const* dets; const int32_t* n_dets;
     const dv_box3d* const* boxes3d; const int32_t* n_boxes3d;      /* may be NULL (no 3-D detector) */
     const float* const* disp; int32_t disp_mem, disp_stride /* bytes, 0 = 4 * width */; double baseline;      /* disp may be NULL: dv_inst_det::points are handed through */
+    const uint32_t* const* right_keys; int32_t right_keys_mem, reserved;      /* VIODE: per frame the key image of seg1 (dv_inst_set_right_keys), tightly packed; may be NULL */
 } dv_seq_dynamic;
 typedef struct dv_runner dv_runner;
+/* slam_type naive of a sequence (system/main.cpp:263-265: FeatureTrack -> TrackImageNaive): per frame [n_frames] the inverse merged instance mask (0 = object pixel;
+ * VIODE::SetViodeMaskSimple or the detector's SetBackgroundMask) in the frames' memory kind, tracked with `mode` = DV_MODE_NAIVE (GPU tracker's + GPU detector's rules).
+ * The back end stays the raw one.  Before the first dv_runner_run; a masked sequence inside a dv_batch group keeps its own tracking launches. */
+int dv_runner_set_mask(dv_runner* runner, int seq, const uint8_t* const* inv_mask, int mask_mem, int mode);
 int dv_runner_set_dynamic(dv_runner* runner, int seq, const dv_seq_dynamic* dyn);      /* before the first dv_runner_run; the sequence then runs outside dv_batch groups */
 /* what the object branch of a dynamic sequence was fed so far: detections, object feature rows, frames with at least one object, fewest detections in a frame */
 int dv_runner_dynamic_stats(dv_runner* runner, int seq, long long* detections, long long* object_features, long long* frames_with_objects, int* min_detections);
@@ -577,6 +582,11 @@ int dv_inst_track_enqueue(dv_ctx* ctx, double t, const dv_inst_det* dets, int n_
  * host or device memory (a device map must stay valid until dv_inst_track_collect); baseline = cam_s.baseline (utils/camera_model.h:38); fx0, fy0, cx0, cy0 = cam0 of the
  * config as float.  disp == NULL: back to the pass-through form.  Applies to the NEXT dv_inst_track_enqueue only. */
 int dv_inst_set_disparity(dv_ctx* ctx, const float* disp, int stride_bytes, int mem, double baseline);
+/* cfg::dataset == kViode: the keys (VIODE::PixelToKey; dv_viode_mask's key_image) of SemanticImage::seg1 — the RIGHT camera's segmentation image — of the frame the NEXT
+ * dv_inst_track_enqueue processes.  InstFeat::TrackRightByPad then keeps a right-image point only where that image carries the object's key (dv_inst_det::track_id):
+ * status[i] && VIODE::PixelToKey(right_points[i], img.seg1) != id -> 0 (front_end/instance_feature.cpp:263-268).  w x h uint32, stride in bytes (0 = 4 w), mem DV_MEM_*;
+ * host memory must stay valid until the frame is collected.  NULL: no test (KITTI / custom data sets).  Belongs to one frame, like the disparity map. */
+int dv_inst_set_right_keys(dv_ctx* ctx, const uint32_t* key_image, int stride_bytes, int mem);
 /* operator form of the same pipeline for one object (parity tests): mask = h rows of w bytes (host), (x, y) = Box2D::rect.tl().  stage 0: the whole pipeline (the segmented
  * cloud); stage 1: InstFeat::DetectExtraPoints alone (the sampled points before any filtering).  out_xyz: cap_out triples at most, the float results widened to double. */
 int dv_extra_points(dv_ctx* ctx, const uint8_t* mask, int x, int y, int w, int h, const float* disp, int stride_bytes, int mem, double baseline, int stage,

@@ -258,6 +258,9 @@ int dvo_insts_track(dvo_insts*, const uint8_t* gray0, const uint8_t* gray1, doub
 /* SemanticImage::disp (CV_32F, width x height of the tracker) of the NEXT dvo_insts_track call: the extra points of every visible object are then computed from it
  * (InstFeat::DetectExtraPoints + the PCL half of ProcessExtraPoints, extra_points.cpp) and dvo_inst_det::points is ignored.  baseline = cam_s.baseline.  The map is copied. */
 void dvo_insts_set_disparity(dvo_insts*, const float* disp, float baseline);
+/* VIODE: the keys (VIODE::PixelToKey, dvo_viode_mask's key image) of SemanticImage::seg1 of the NEXT dvo_insts_track call: TrackRightByPad drops a right-image point whose
+ * pixel does not carry the object's key (front_end/instance_feature.cpp:263-268).  NULL: no test (the other datasets).  The image is copied. */
+void dvo_insts_set_right_keys(dvo_insts*, const uint32_t* key_img);
 /* InstFeat::DetectExtraPoints (front_end/instance_feature.cpp:413-461) / the point-cloud half of InstsFeatManager::ProcessExtraPoints (front_end/dynamic_tracker.cpp:268-338) */
 int dvo_detect_extra_points(const uint8_t* mask, int cols, int rows, int box_x, int box_y, const float* disp, int disp_w, int disp_h,
                             float fx0, float fy0, float cx0, float cy0, float baseline, float* out_xyz, int cap);

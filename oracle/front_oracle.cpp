@@ -843,7 +843,15 @@ struct dvo_insts {
     std::map<unsigned, OInstFeat> instances;
     double curr_time = 0, last_time = 0;
     std::vector<float> disp; float baseline = 0; bool have_disp = false;      // curr_img.disp of the next frame (dvo_insts_set_disparity)
+    std::vector<uint32_t> right_keys; bool have_keys = false;                 // PixelToKey of every pixel of curr_img.seg1 of the next frame (dvo_insts_set_right_keys): cfg::dataset == kViode
 };
+// VIODE: TrackRightByPad keeps a right-image point only if the segmentation image of the RIGHT camera carries the object's key there
+// (instance_feature.cpp:263-268: status[i] && VIODE::PixelToKey(right_points[i], img.seg1) != id -> 0; Mat::at(Point2f) rounds like cvRound)
+void dvo_insts_set_right_keys(dvo_insts* M, const uint32_t* key_img) {
+    const size_t n = (size_t)M->bg->cfg.width * M->bg->cfg.height;
+    M->have_keys = key_img != nullptr;
+    if (key_img) M->right_keys.assign(key_img, key_img + n);
+}
 void dvo_insts_set_disparity(dvo_insts* M, const float* disp, float baseline) {
     const size_t n = (size_t)M->bg->cfg.width * M->bg->cfg.height;
     M->have_disp = disp != nullptr;
@@ -954,6 +962,9 @@ int dvo_insts_track(dvo_insts* M, const uint8_t* gray0, const uint8_t* gray1, do
                 for (size_t i = 0; i < padded.size(); ++i) padded[i] = { inst.curr_points[i].x + (float)inst.rx, inst.curr_points[i].y + (float)inst.ry };
                 std::vector<uint8_t> status(padded.size());
                 track_by_lk(gray0, gray1, W, H, padded.data(), (int)padded.size(), cfg.flow_back != 0, 0.5f, inst.right_points.data(), status.data());
+                if (M->have_keys)                                          // cfg::dataset == DatasetType::kViode (instance_feature.cpp:263-268)
+                    for (size_t i = 0; i < status.size(); ++i)
+                        if (status[i] && M->right_keys[(size_t)cv_round(inst.right_points[i].y) * W + cv_round(inst.right_points[i].x)] != inst.id) status[i] = 0;
                 inst.right_ids = inst.ids;
                 reduce_vector(inst.right_points, status); reduce_vector(inst.right_ids, status);
             }                                                              // (empty curr_points: TrackRightByPad returns early and right_points / right_ids keep their old content)
@@ -970,6 +981,7 @@ int dvo_insts_track(dvo_insts* M, const uint8_t* gray0, const uint8_t* gray1, do
         if (inst.lost_num > 0) { inst.lost_num++; if (inst.lost_num > 3) erase = true; }
         if (erase) it = M->instances.erase(it); else ++it;
     }
+    M->have_keys = false;
     if (is_exist_inst) exec([&](OInstFeat& inst) {      // PostProcess (instance_feature.h:88-101)
         inst.last_points = inst.curr_points;
         inst.prev_id_pts = inst.curr_id_pts; inst.right_prev_id_pts = inst.right_curr_id_pts;

@@ -96,6 +96,7 @@ int dv_track_stereo_collect(dv_ctx* c, dv_feat* out, int* n_out) {
     return 0;
 }
 int dv_inst_set_disparity(dv_ctx* c, const float*, int, int, double) { Stub& s = S(c); s.trk_scratch++; return 0; }
+int dv_inst_set_right_keys(dv_ctx* c, const uint32_t*, int, int) { Stub& s = S(c); s.trk_scratch++; return 0; }
 int dv_inst_track_enqueue(dv_ctx* c, double, const dv_inst_det*, int, const dv_box3d*, int) {
     Stub& s = S(c); s.trk_scratch++;
     if (s.inst_pending) return violation("dv_inst_track_enqueue: previous frame not collected");

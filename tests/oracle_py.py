@@ -119,6 +119,16 @@ class Oracle:
         self.lib.dvo_track_by_lk(_p(a), _p(b), w, h, _p(pts1), n, int(flow_back), dist_thresh, _p(pts2), _p(st))
         return pts2, st
 
+    def viode_mask(self, seg_bgr, dyn_keys):
+        """VIODE::SetViodeMaskSimple / BuildViodeMask (utils/dataset/viode_utils.cpp:21-170) -> (merge_mask, inv_merge_mask, key image, boxes[nkeys, 4]): frontend.Context.viode_mask's twin"""
+        seg = np.ascontiguousarray(seg_bgr, np.uint8)
+        h, w, _ = seg.shape
+        keys = np.ascontiguousarray(dyn_keys, np.uint32)
+        merge, inv, kimg, boxes = np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint8), np.zeros((h, w), np.uint32), np.zeros((len(keys), 4), np.int32)
+        self.lib.dvo_viode_mask.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.lib.dvo_viode_mask(_p(seg), w, h, seg.strides[0], _p(keys), len(keys), _p(merge), _p(inv), _p(kimg), _p(boxes))
+        return merge, inv, kimg, boxes
+
     def gftt(self, img, max_n, quality, min_dist, mask=None, rule="cpu"):
         """rule "cpu": cv::goodFeaturesToTrack; "cuda": cv::cuda::GoodFeaturesToTrackDetector (oracle/gftt_cuda.cpp)"""
         h, w = img.shape
@@ -299,6 +309,12 @@ class OracleInsts:
         d = None if disp is None else np.ascontiguousarray(disp, np.float32)
         self.lib.dvo_insts_set_disparity.argtypes = [C.c_void_p, C.c_void_p, C.c_float]
         self.lib.dvo_insts_set_disparity(self.h, _p(d), float(baseline))
+
+    def set_right_keys(self, key_img):
+        """VIODE: the key image (oracle.viode_mask(...)[2]) of seg1 of the next track() call: TrackRightByPad's segmentation-key test (instance_feature.cpp:263-268)"""
+        k = None if key_img is None else np.ascontiguousarray(key_img, np.uint32)
+        self.lib.dvo_insts_set_right_keys.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.dvo_insts_set_right_keys(self.h, _p(k))
 
     def track(self, g0, g1, t, dets, boxes3d, inst_dtype, box_dtype):
         g0 = np.ascontiguousarray(g0); g1 = np.ascontiguousarray(g1) if g1 is not None else None

@@ -105,3 +105,48 @@ def test_dynamic_pipeline_without_det3d(oracle):
     stats, ate = run(oracle, 640, 360, 30, 150, 20, 8, use_det3d=0)
     b = bars(stats)
     assert stats["max_dp"] < b[0] and stats["obj_p"] < b[1], stats
+
+
+@pytest.mark.parametrize("blank_key", [False, True])
+def test_viode_right_key_test_rows_bit_identical(oracle, blank_key):
+    """cfg::dataset == kViode: InstFeat::TrackRightByPad keeps a right-image point only where seg1 carries the object's key (front_end/instance_feature.cpp:263-268).
+    dv_inst_set_right_keys (a kernel behind the stereo LK of the objects) against the oracle's dvo_insts_set_right_keys: background and object rows bit-identical every
+    frame; with one object's key wiped from seg1 that object keeps NO right observation on either side while the others keep theirs."""
+    from dynamic_vins_amd import viode
+    from dynamic_vins_amd.frontend import Context, DV_MEM_DEVICE, DV_MODE_SEMANTIC, make_cam
+    w, h, frames = 640, 360, 10
+    cam = sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    c = make_cam(*sim.cam_tuple(cam))
+    ctx = Context(width=w, height=h, max_cnt=150, min_dist=20, cam0=c, cam1=c, mask_morphology_size=5)
+    seq = viode.ViodeSequence(w, h, cam, frames, ctx, rate=20.0)
+    ctx.inst_config(50, 5, 0)
+    victim = int(seq.dyn_keys[1])
+    camt = sim.cam_tuple(cam)
+    trk = oracle.tracker(w, h, 150, 20, 1, 1, camt, camt)
+    oin = oracle.insts(trk, 50, 5, 0)
+    right_obs = {int(k): 0 for k in seq.dyn_keys}
+    for k in range(frames):
+        t = seq.times[k]
+        keys = seq.right_keys[k].copy()
+        if blank_key:
+            keys[keys == victim] = 12345
+        l, r = seq.frames[k]
+        ctx.track_stereo_enqueue(l.data_ptr(), r.data_ptr(), t, seq.inv_mask_dev[k].data_ptr(), DV_MODE_SEMANTIC, DV_MEM_DEVICE)
+        ctx.inst_set_right_keys(keys)
+        ctx.inst_track_enqueue(t, seq.dets[k], None)
+        rows = ctx.track_stereo_collect()
+        insts, ifeats, pts = ctx.inst_track_collect()
+        left, right = seq.host_frame(k)
+        rows_o = trk.track_image(left, right, t, mask=seq.inv_mask[k], mode=2, erode_k=5)
+        oin.set_right_keys(keys)
+        io, fo, po = oin.track(left, right, t, seq.dets[k], None, dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
+        rows_equal(rows, rows_o, f"frame {k} background")
+        assert np.array_equal(io["id"], insts["id"]) and np.array_equal(io["n_feats"], insts["n_feats"]), k
+        rows_equal(ifeats, fo, f"frame {k} objects")
+        for o in io:
+            f = fo[o["first_feat"]: o["first_feat"] + o["n_feats"]]
+            right_obs[int(o["id"])] += int(f["has_right"].sum())
+    ctx.close()
+    others = [v for k_, v in right_obs.items() if k_ != victim]
+    assert min(others) > 5 * frames, right_obs
+    assert (right_obs[victim] == 0) if blank_key else (right_obs[victim] > 5 * frames), right_obs

@@ -171,6 +171,115 @@ def test_node_trajectory_file_equals_the_python_pipeline(tmp_path):
     assert sum(1 for ln in got if not ln.endswith("0.000000 0.000000 0.000000 0.000000 0.000000 0.000000 1.000000")) >= frames // 2 - 12      # the solved part is not the identity
 
 
+def _viode_setup(tmp_path, frames, w=640, h=360):
+    """a VIODE-layout directory written from the synthetic renderer (dynamic_vins_amd/viode.py) + the context that produced its masks"""
+    from dynamic_vins_amd import sim
+    from dynamic_vins_amd.frontend import Context, make_cam
+    from dynamic_vins_amd.viode import ViodeSequence
+    cam = sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    c = make_cam(*sim.cam_tuple(cam))
+    masker = Context(width=w, height=h, max_cnt=150, min_dist=20, cam0=c, cam1=c)
+    seq = ViodeSequence(w, h, cam, frames, masker, rate=20.0, t0=0.0)
+    masker.close()
+    sd = tmp_path / "city_day_3_high"
+    cfg = seq.write(str(sd), est=dict(max_cnt=150, min_dist=20, iters=8, morph=5, static_inst_threshold=10.0))
+    return seq, sd, cfg
+
+
+@pytest.mark.gpu
+def test_node_viode_dynamic_mode_from_files_equals_the_python_pipeline_and_the_oracle(tmp_path, oracle):
+    """config 3 (VIODE, slam_type dynamic) end to end FROM FILES: left / right / segmentation0 / segmentation1 PNGs + imu.csv + the VIODE keys of the YAML (rgb_to_label_file,
+    dynamic_label_id) -> dvins_node: dv_viode_mask (masks, key images, boxes; track_id = key) -> TrackSemanticImage + InstsTrack with the segmentation-key test of the right
+    image -> the dynamic back end on every 2nd pair -> <seq>_VIO_dynamic_PointOnly_Odometry.txt.  The file must equal the Python dynamic pipeline's lines byte for byte, and
+    the oracle (tracker mode 2 + instance tracker + dynamic estimator fed from the oracle's own viode_mask) must agree to 1e-5 m.
+    Reference: system/main.cpp:196-215, image_process/image_process.cpp:161-178, utils/dataset/viode_utils.cpp:21-218, front_end/dynamic_tracker.cpp:585-605."""
+    from dynamic_vins_amd import dynsim, io_formats, sim, viode
+    from dynamic_vins_amd.pipeline import DynamicPipeline
+    frames = 64
+    seq, sd, cfg = _viode_setup(tmp_path, frames)
+    assert min(len(d) for d in seq.dets) >= 2 and len(seq.dyn_keys) == 3
+    out = subprocess.run([NODE, cfg, str(sd), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "dynamic mode from the segmentation images" in out.stdout
+    got = open(tmp_path / "city_day_3_high_VIO_dynamic_PointOnly_Odometry.txt").read().splitlines()
+    # ---- the same through the Python dynamic pipeline (ctypes on the same C ABI), every 2nd pair to the back end ----
+    ekw = dict(keyframe_parallax=10.0, g_norm=9.81007, instance_init_min_num=4)
+    pipe = DynamicPipeline(seq, max_cnt=150, min_dist=20, max_iters=8, use_det3d=0, static_inst_threshold=10.0, mask_morphology_size=5, extra_from_disparity=False, ba_stride=2, est_kw=ekw)
+    want = []
+    for k in range(frames):
+        pipe.step()
+        if k % 2 == 0:
+            want.append(io_formats.trajectory_line(seq.times[k], pipe.est.window()[10, :7]))
+    Id, _ = pipe.est.instances()
+    assert pipe.stat["object_features"] > 10 * frames // 2 and len(Id) >= 2, pipe.stat
+    hip_traj = np.array([p[:3] for p in pipe.poses])
+    pipe.ctx.close()
+    assert len(got) == len(want) == frames // 2
+    assert got == want, [i for i, (a, b) in enumerate(zip(got, want)) if a != b][:5]
+    # ---- the oracle from the same files' content: its own viode_mask, its own trackers and estimator ----
+    camt = sim.cam_tuple(seq.cam)
+    trk = oracle.tracker(seq.w, seq.h, 150, 20, 1, 1, camt, camt)
+    oin = oracle.insts(trk, 50, 5, 0)
+    est = oracle.estimator(use_imu=1, stereo=1, max_iters=8, ric=seq.rig["est_ric"], tic=seq.rig["est_tic"], dynamic=1, use_det3d=0, static_inst_threshold=10.0, instance_init_min_num=4,
+                           keyframe_parallax=10.0, g_norm=9.81007, **seq.noise)
+    k_imu, o_traj = 0, []
+    for k in range(frames):
+        t = seq.times[k]
+        left, right = seq.host_frame(k)
+        _, inv, kimg, bx = oracle.viode_mask(seq.seg0[k], seq.dyn_keys)
+        assert np.array_equal(inv, seq.inv_mask[k])
+        dets = viode.detections(kimg, bx, seq.dyn_keys)
+        rows = trk.track_image(left, right, t, mask=inv, mode=2, erode_k=5)
+        oin.set_right_keys(oracle.viode_mask(seq.seg1[k], seq.dyn_keys)[2])
+        io, fo, po = oin.track(left, right, t, dets, None, dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
+        if k % 2:
+            continue
+        while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
+            est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
+        rc, so = est.process_dynamic(rows, t, io, fo, po)
+        assert rc == 0
+        if so.nonlinear:
+            o_traj.append(est.window()[10, :3].copy())
+    o_traj = np.array(o_traj)
+    assert len(o_traj) == len(hip_traj) >= frames // 2 - 12
+    assert np.abs(o_traj - hip_traj).max() < 1e-5, np.abs(o_traj - hip_traj).max()
+
+
+@pytest.mark.gpu
+def test_node_viode_naive_mode_from_files(tmp_path):
+    """viode.yaml as SHIPPED says slam_type naive: segmentation0 -> VIODE::SetViodeMaskSimple -> TrackImageNaive (GPU tracker's and GPU detector's rules) with the inverse mask
+    -> the raw back end.  The node's file must equal the Python pipeline's lines (dv_runner_set_mask vs per-frame ctypes calls)."""
+    from dynamic_vins_amd import io_formats
+    from dynamic_vins_amd.backend import Estimator
+    from dynamic_vins_amd.frontend import DV_MODE_NAIVE
+    frames = 40
+    seq, sd, cfg = _viode_setup(tmp_path, frames)
+    text = open(cfg).read().replace('slam_type: "dynamic"', 'slam_type: "naive"')
+    open(cfg, "w").write(text)
+    out = subprocess.run([NODE, cfg, str(sd), str(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = open(tmp_path / "city_day_3_high_VIO_naive_PointOnly_Odometry.txt").read().splitlines()
+    from dynamic_vins_amd.frontend import Context, make_cam
+    from dynamic_vins_amd import sim
+    c = make_cam(*sim.cam_tuple(seq.cam))
+    ctx = Context(width=seq.w, height=seq.h, max_cnt=150, min_dist=20, cam0=c, cam1=c, mask_morphology_size=5)
+    est = Estimator(ctx, use_imu=1, stereo=1, max_iters=8, ric=seq.rig["est_ric"], tic=seq.rig["est_tic"], keyframe_parallax=10.0, g_norm=9.81007, **seq.noise)
+    k_imu, want = 0, []
+    for k in range(frames):
+        t = seq.times[k]
+        l, r = seq.host_frame(k)
+        rows = ctx.track_stereo(l, r, t, seq.inv_mask[k], DV_MODE_NAIVE)
+        if k % 2:
+            continue
+        while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
+            est.InputIMU(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
+        rc, st = est.ProcessMeasurements(rows, t)
+        assert rc == 0
+        want.append(io_formats.trajectory_line(t, est.window()[10, :7]))
+    ctx.close()
+    assert got == want, [i for i, (a, b) in enumerate(zip(got, want)) if a != b][:5]
+
+
 REF_SRC = "/root/reference/dynamic_vins/src"
 
 

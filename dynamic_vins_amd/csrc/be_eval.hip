@@ -83,7 +83,7 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
         BeLm L{}; if (valid) L = a.lm[b];
         be_frame_geom_dev(st, a.dims.nframes, fg, ric, tic, (int)threadIdx.x);
         if (LPB == 1) { if (lane >= 64 && lane < 64 + 2 * BE_NF) s_flist[(lane - 64) >> 1][(lane - 64) & 1] = -1; }
-        else if (lane >= 40 && lane < 40 + 2 * BE_NF) s_flist[(lane - 40) >> 1][(lane - 40) & 1] = -1;
+        else if (lane >= TPL - 2 * BE_NF) s_flist[(lane - (TPL - 2 * BE_NF)) >> 1][(lane - (TPL - 2 * BE_NF)) & 1] = -1;      // (the last 22 lanes of the landmark's group: TPL >= 32)
         __syncthreads();
         if (b == 0) ETS(1);
         const double lambda = valid ? st->inv_depth[b] : 1.0;
@@ -115,8 +115,11 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
         // observation mask: pose f is touched by this landmark iff f is its anchor or a frame with a two-frame factor.  Only those frames' GP / DD / DA slots are
         // written (the rest were 8-byte stores of zeros: 40 % of the packet's 7.4 KB and of the 4x write amplification PMC showed) — be_reduce reads them under
         // the same mask.
-        const int wl = lane & 63;                                     // every wave forms the mask by itself: lane f votes for frame f
-        const int obs = (int)__ballot(wl < a.dims.nframes && (wl == anchor || s_flist[wl < BE_NF ? wl : 0][0] >= 0 || s_flist[wl < BE_NF ? wl : 0][1] >= 0));
+        // every wave forms the mask by itself: lane f (of the landmark's group inside the wave) votes for frame f.  TPL = 32: a wave holds TWO landmarks, each reads its half
+        constexpr int GL = TPL < 64 ? TPL : 64;                       // lanes of one landmark inside a wave
+        const int wl = lane & (GL - 1);
+        const unsigned long long votes = __ballot(wl < a.dims.nframes && (wl == anchor || s_flist[wl < BE_NF ? wl : 0][0] >= 0 || s_flist[wl < BE_NF ? wl : 0][1] >= 0));
+        const int obs = (int)((votes >> (((int)threadIdx.x & 63) & ~(GL - 1))) & ((1ull << BE_NF) - 1));
         if (lane == 0 && mode != BE_EVAL_CAND_COST) a.lm_obs[b] = obs;
         for (int e = lane; e < BE_PK_SIZE; e += TPL) {
             if (e >= BE_PK_GP && e < BE_PK_DA + BE_NF * 36) {
@@ -275,45 +278,54 @@ __device__ __forceinline__ void be_eval_body(const ARGS& a, int mode, int bg) {
 
 template <bool FULL>
 __global__ __launch_bounds__(EV_THREADS) void be_eval_kernel(BeEvalArgs a, int mode) { be_eval_body<FULL, 1, BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, a.dims.nlm)); }
-// batched form (several independent windows in one launch: blockIdx.y = window, argument table in HBM): four landmarks per workgroup
-#define EV_LPB_BATCH 4
-// (Round 5: the full evaluation holds 222 VGPRs — two workgroups per CU, 512 resident GPU-wide, so 16 windows (1232 workgroups of ~40 us) need 2.4 occupancy rounds: that, not
-//  traffic, is what its 86 us per 16 windows is.  Capping the registers with amdgpu_waves_per_eu(3 / 4) buys the occupancy with 109 / 203 spilled VGPRs and loses:
+// batched form (several independent windows in one launch: blockIdx.y = window, argument table in HBM): LPB landmarks per workgroup.
+// LPB 4 (rounds 4-5): one wave per landmark — at most 22 of its 64 lanes evaluate a factor, and 16 windows are 1232 workgroups of ~40 us against 512 - 768 resident
+// (the kernel holds 168 - 222 VGPRs: two or three workgroups per CU): 1.6 - 2.4 occupancy rounds, which is what its 73 - 86 us per 16 windows were (round 5's counters:
+// not bandwidth).  LPB 8 (round 6, default): 32 threads per landmark, TWO landmarks per wave — the factor phase runs on twice the lanes, the launch is HALF the
+// workgroups (616 for 16 windows: one round) and every packet entry is still summed by ONE thread over the same factors in the same order: the same bits.
+// DVINS_EVAL_LPB=4 selects the old form (A/B).
+// (Round 5: capping the registers with amdgpu_waves_per_eu(3 / 4) on the whole evaluation buys the occupancy with 109 / 203 spilled VGPRs and loses:
 //  16 sequences 5969 -> 5880 / 5852 frames/s, 64 sequences 8285 -> 8121 / 7772; profiles/r05_experiments/eval_waves_ab.txt.)
-template <bool FULL>
+static int ev_lpb() { static const int v = [] { const char* e = std::getenv("DVINS_EVAL_LPB"); return (e && std::atoi(e) == 4) ? 4 : 8; }(); return v; }
+template <bool FULL, int LPB>
 __global__ __launch_bounds__(EV_THREADS) void be_eval_batch_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
     const DV_CONSTANT BeEvalArgs& a = *reinterpret_cast<const DV_CONSTANT BeEvalArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));
-    const int ngrp = (a.dims.nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH;
+    const int ngrp = (a.dims.nlm + LPB - 1) / LPB;
     if ((int)blockIdx.x >= ngrp + a.dims.nimu + 1) return;
-    be_eval_body<FULL, EV_LPB_BATCH, DV_CONSTANT BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, ngrp));      // (grid x is a multiple of 8: the XCD of a block is blockIdx.x % 8 as in the single-window launch)
+    be_eval_body<FULL, LPB, DV_CONSTANT BeEvalArgs>(a, mode, be_eval_block_of(blockIdx.x, ngrp));      // (grid x is a multiple of 8: the XCD of a block is blockIdx.x % 8 as in the single-window launch)
 }
 // the two launches of the split form: grid x = landmark workgroups resp. IMU + prior blocks of the largest window
+template <int LPB>
 __global__ __launch_bounds__(EV_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void be_eval_batch_lm_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
     const DV_CONSTANT BeEvalArgs& a = *reinterpret_cast<const DV_CONSTANT BeEvalArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));
-    const int ngrp = (a.dims.nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH;
+    const int ngrp = (a.dims.nlm + LPB - 1) / LPB;
     if ((int)blockIdx.x >= ngrp) return;
-    be_eval_body<true, EV_LPB_BATCH, DV_CONSTANT BeEvalArgs, 1>(a, mode, be_eval_block_of(blockIdx.x, ngrp));
+    be_eval_body<true, LPB, DV_CONSTANT BeEvalArgs, 1>(a, mode, be_eval_block_of(blockIdx.x, ngrp));
 }
+template <int LPB>
 __global__ __launch_bounds__(EV_THREADS) void be_eval_batch_rest_kernel(const BeEvalArgs* __restrict__ tab, int mode) {
     const DV_CONSTANT BeEvalArgs& a = *reinterpret_cast<const DV_CONSTANT BeEvalArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));
-    const int ngrp = (a.dims.nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH;
+    const int ngrp = (a.dims.nlm + LPB - 1) / LPB;
     if ((int)blockIdx.x >= a.dims.nimu + 1) return;
-    be_eval_body<true, EV_LPB_BATCH, DV_CONSTANT BeEvalArgs, 2>(a, mode, ngrp + (int)blockIdx.x);
+    be_eval_body<true, LPB, DV_CONSTANT BeEvalArgs, 2>(a, mode, ngrp + (int)blockIdx.x);
 }
-int be_eval_batch_blocks(int nlm, int nimu) { return (nlm + EV_LPB_BATCH - 1) / EV_LPB_BATCH + nimu + 1; }
-void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s) {      // max_grid = max over the windows of be_eval_batch_blocks
-    // DVINS_EVAL_SPLIT: 1 always, 0 never; default: from 12 windows per launch on — with 16 windows the launch is 1232 workgroups (2.4 occupancy rounds at two per CU) and the
-    // third workgroup per CU pays for the extra launch (64 sequences: 9.6 -> 10.0 k frames/s); a group of 4 windows (308 workgroups) fits one round either way and only pays
-    // (16 sequences: 6.75 -> 6.3 k).  profiles/r05_experiments/solve_cus_and_eval_split_ab.txt
-    static const int split_env = [] { const char* e = std::getenv("DVINS_EVAL_SPLIT"); return e ? std::atoi(e) : -1; }();
-    const bool split = split_env < 0 ? n_win >= 12 : split_env != 0;
+int be_eval_batch_blocks(int nlm, int nimu) { const int lpb = ev_lpb(); return (nlm + lpb - 1) / lpb + nimu + 1; }
+template <int LPB>
+static void launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, bool split, hipStream_t s) {
     if (split && mode != BE_EVAL_CAND_COST) {          // (max_grid bounds both parts)
-        hipLaunchKernelGGL(be_eval_batch_rest_kernel, dim3(BE_WIN + 1, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
-        hipLaunchKernelGGL(be_eval_batch_lm_kernel, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+        hipLaunchKernelGGL(be_eval_batch_rest_kernel<LPB>, dim3(BE_WIN + 1, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+        hipLaunchKernelGGL(be_eval_batch_lm_kernel<LPB>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
         return;
     }
-    if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL(be_eval_batch_kernel<true>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
-    else hipLaunchKernelGGL(be_eval_batch_kernel<false>, dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+    if (mode != BE_EVAL_CAND_COST) hipLaunchKernelGGL((be_eval_batch_kernel<true, LPB>), dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+    else hipLaunchKernelGGL((be_eval_batch_kernel<false, LPB>), dim3((max_grid + 7) & ~7, n_win), dim3(EV_THREADS), 0, s, tab_dev, mode);
+}
+void be_launch_eval_batch(const BeEvalArgs* tab_dev, int n_win, int max_grid, int mode, hipStream_t s) {      // max_grid = max over the windows of be_eval_batch_blocks
+    // DVINS_EVAL_SPLIT: 1 always, 0 never; default: from 12 windows per launch on — the IMU / prior blocks in a launch of their own let the landmark launch hold fewer registers
+    // (64 sequences: 9.6 -> 10.0 k frames/s in round 5; a group of 4 windows only pays for the extra launch: 6.75 -> 6.3 k).  profiles/r05_experiments/solve_cus_and_eval_split_ab.txt
+    static const int split_env = [] { const char* e = std::getenv("DVINS_EVAL_SPLIT"); return e ? std::atoi(e) : -1; }();
+    const bool split = split_env < 0 ? n_win >= 12 : split_env != 0;
+    if (ev_lpb() == 4) launch_eval_batch<4>(tab_dev, n_win, max_grid, mode, split, s); else launch_eval_batch<8>(tab_dev, n_win, max_grid, mode, split, s);
 }
 void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s) {
     const int grid = a.dims.nlm + a.dims.nimu + 1;

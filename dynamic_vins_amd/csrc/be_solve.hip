@@ -21,6 +21,7 @@
 #include <cfloat>
 #include <algorithm>
 #include <cstring>
+#include <cstdlib>
 #include "be_kernels.h"
 #include "dev_once.h"
 #include "wave_dpp.h"
@@ -366,8 +367,22 @@ __global__ __launch_bounds__(RED_THREADS) void be_reduce_batch_kernel(const BeSo
     if ((int)blockIdx.x >= RED_PAIRS + (n * n + n + RED_THREADS - 1) / RED_THREADS) return;
     be_reduce_body<false>(a, spec, blockIdx.x);
 }
+// the same body capped at 80 VGPRs (5 of them spilled, 24 B of scratch per lane): THREE 7-wave workgroups per CU instead of two — 16 windows are 2048 workgroups against 512
+// resident at 96 VGPRs (four occupancy rounds of ~15 us: what the launch's 66 us were in round 5), 768 with the cap.  Used from 12 windows per launch on (be_launch_reduce_batch).
+__global__ __launch_bounds__(RED_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void be_reduce_batch_occ_kernel(const BeSolveArgs* __restrict__ tab, int spec) {
+    const DV_CONSTANT BeSolveArgs& a = *reinterpret_cast<const DV_CONSTANT BeSolveArgs*>(reinterpret_cast<uintptr_t>(tab + blockIdx.y));
+    const int n = a.dims.nstate;
+    if ((int)blockIdx.x >= RED_PAIRS + (n * n + n + RED_THREADS - 1) / RED_THREADS) return;
+    be_reduce_body<false>(a, spec, blockIdx.x);
+}
 void be_launch_reduce_batch(const BeSolveArgs* tab_dev, int n_win, int max_n, int spec, hipStream_t s) {
-    hipLaunchKernelGGL(be_reduce_batch_kernel, dim3((RED_PAIRS + (max_n * max_n + max_n + RED_THREADS - 1) / RED_THREADS + 7) & ~7, n_win), dim3(RED_THREADS), 0, s, tab_dev, spec);      // (x a multiple of 8: a block's XCD is blockIdx.x % 8 in every window, as RED_PAIR_TAB assumes)
+    // measured (round 6, one box): 64 sequences (groups of 16 windows) 10167 / 10547 -> 10458 / 11121 frames/s with the cap; 16 sequences (groups of 4: 512 workgroups, one round either
+    // way) 7245 -> 7187: the cap only pays when a launch exceeds the resident set — from 12 windows per launch on, like the evaluation's split.  DVINS_REDUCE_OCC=0 / 1 forces it.
+    static const int occ_env = [] { const char* e = std::getenv("DVINS_REDUCE_OCC"); return e ? (e[0] != '0' ? 1 : 0) : -1; }();
+    const bool occ = occ_env < 0 ? n_win >= 12 : occ_env != 0;
+    const dim3 grid((RED_PAIRS + (max_n * max_n + max_n + RED_THREADS - 1) / RED_THREADS + 7) & ~7, n_win);      // (x a multiple of 8: a block's XCD is blockIdx.x % 8 in every window, as RED_PAIR_TAB assumes)
+    if (occ) hipLaunchKernelGGL(be_reduce_batch_occ_kernel, grid, dim3(RED_THREADS), 0, s, tab_dev, spec);
+    else hipLaunchKernelGGL(be_reduce_batch_kernel, grid, dim3(RED_THREADS), 0, s, tab_dev, spec);
 }
 void be_launch_reduce(const BeSolveArgs& a, int spec, hipStream_t s) {
     const int n = a.dims.nstate;

@@ -389,6 +389,12 @@ class Estimator:
     def AttachInstances(self, insts, inst_feats, points):
         return self._check(self.ctx.lib.dv_est_process_dynamic_attach(self.ctx.h, *self._dyn_args(insts, inst_feats, points)))
 
+    def static_instances(self, cap=256):
+        """InstanceManager::GetOutputInstInfo as FeatureTrack reads it (system/main.cpp:194,217-245): ids reported static at the last dynamic frame's snapshot"""
+        ids = np.zeros(cap, np.uint32); n = C.c_int(0)
+        self._check(self.ctx.lib.dv_est_get_static_instances(self.ctx.h, ids.ctypes.data, cap, C.byref(n)))
+        return ids[: n.value].copy()
+
     def instances(self, cap=64):
         """Estimator::im.instances (ascending id) -> (INSTSTATE_DTYPE array, [iterations, termination, initial_cost, final_cost] of the last object solve)"""
         from .dynsim import INSTSTATE_DTYPE
@@ -499,7 +505,7 @@ class dv_seq_input(C.Structure):
 class dv_seq_dynamic(C.Structure):
     _fields_ = [("inv_mask", C.c_void_p), ("mask_mem", C.c_int32), ("mode", C.c_int32), ("dets", C.c_void_p), ("n_dets", C.c_void_p), ("boxes3d", C.c_void_p), ("n_boxes3d", C.c_void_p),
                 ("disp", C.c_void_p), ("disp_mem", C.c_int32), ("disp_stride", C.c_int32), ("baseline", C.c_double),
-                ("right_keys", C.c_void_p), ("right_keys_mem", C.c_int32), ("reserved", C.c_int32)]
+                ("right_keys", C.c_void_p), ("right_keys_mem", C.c_int32), ("static_as_background", C.c_int32)]
 
 
 class Runner:
@@ -578,6 +584,7 @@ class Runner:
         dyn.dets, dyn.n_dets = C.cast(det_ptrs, C.c_void_p), n_dets.ctypes.data
         dyn.boxes3d, dyn.n_boxes3d = C.cast(box_ptrs, C.c_void_p), n_boxes.ctypes.data
         dyn.disp, dyn.disp_mem, dyn.disp_stride, dyn.baseline = (C.cast(disps, C.c_void_p) if use_disp else None), DV_MEM_DEVICE, 0, float(q.baseline)
+        dyn.static_as_background = 1 if getattr(p, "static_as_background", False) else 0
         rk = getattr(q, "right_keys", None)          # VIODE-style sequences: per frame the uint32 key image of seg1 (host arrays)
         if rk is not None:
             rk = [np.ascontiguousarray(a, np.uint32) for a in rk[first_frame:]]

@@ -51,3 +51,14 @@ hipError_t dv_copy_async(void* dst, const void* src, size_t bytes, hipStream_t s
 }
 
 int dv_copy_prepare() { hipFuncAttributes fa; return hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(dv_copy_kernel)) == hipSuccess ? 0 : -1; }
+
+// FeatureTrack's static-instance unmasking (system/main.cpp:217-245): the ROI mask lives in pinned host memory and is read in place
+__global__ __launch_bounds__(256) void dv_unmask_kernel(uint8_t* __restrict__ inv_mask, int pitch, int W, int H, int x0, int y0, int w, int h, const uint8_t* __restrict__ roi) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+    if (c >= w || r >= h) return;
+    const int x = x0 + c, y = y0 + r;
+    if (x < W && y < H && roi[(size_t)r * w + c] >= 1) inv_mask[(size_t)y * pitch + x] = 255;
+}
+void dv_launch_unmask(uint8_t* inv_mask, int pitch, int W, int H, int x0, int y0, int w, int h, const uint8_t* roi_mask, hipStream_t s) {
+    if (w > 0 && h > 0) hipLaunchKernelGGL(dv_unmask_kernel, dim3((w + 255) / 256, h), dim3(256), 0, s, inv_mask, pitch, W, H, x0, y0, w, h, roi_mask);
+}

@@ -195,6 +195,10 @@ struct dv_ctx {
     DevBuf cand_buf; int cand_cap = 0; int* n_cand = nullptr; unsigned* max_ord = nullptr; int* err_flag = nullptr;
     DevBuf hw_buf; int hw_radius = -1;
     DevBuf mask_buf;
+    // dv_track_unmask_static: the ROI masks of the static instances of the next frame, staged in pinned memory at the call (rect + offset into unmask_pinned), applied by a
+    // kernel behind the mask's upload in dv_track_stereo_enqueue
+    struct UnmaskJob { int x, y, w, h; size_t off; };
+    std::vector<UnmaskJob> unmask; void* unmask_pinned = nullptr; size_t unmask_pinned_bytes = 0;
     DevBuf undist_buf[2]; bool undist[2] = { false, false }; int undist_w = 0, undist_h = 0;      // cfg::is_undistort_input: fixed-point maps per camera (map1 | map2)
     DevBuf out_buf; dv_feat* out_dev = nullptr; int* nout_dev = nullptr;
     dv_feat* out_pinned = nullptr; int* nout_pinned = nullptr; int* err_pinned = nullptr;

@@ -107,6 +107,8 @@ void dv_launch_finalize_offset(const DvTrackState& tr, const dv_cam& cam0, const
 void dv_launch_lk_cuda_track(const DvPyr& A, const DvPyr& B, const float2* pts_a, const int* n_dev, int n_max, int flow_back, float dist_thresh, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_lk_cuda_generic(const DvPyr& A, const DvPyr& B, const float2* pts_a, int n, int max_level, int iters, int use_initial, float2* pts_b, uint8_t* status, hipStream_t s);
 void dv_launch_gftt_tile(const GfttTileArgs& a, hipStream_t s);
+// system/main.cpp:217-245: inv_mask(y0 + r, x0 + c) = 255 where roi_mask(r, c) >= 1 (a static instance's pixels become background); roi_mask: w x h bytes in PINNED host memory, read in place
+void dv_launch_unmask(uint8_t* inv_mask, int pitch, int W, int H, int x0, int y0, int w, int h, const uint8_t* roi_mask, hipStream_t s);
 hipError_t dv_copy_async(void* dst, const void* src, size_t bytes, hipStream_t s);      // copy.hip: device <-> PINNED host (or device <-> device) as a kernel on s — no copy engine in the per-frame path
 int  dv_launch_gftt_select(const GfttSelectArgs& a, hipStream_t s);
 void dv_launch_compact(const DvTrackState& tr, const uint8_t* in_mask, int mask_pitch, int sort_by_cnt, int* n_cand,

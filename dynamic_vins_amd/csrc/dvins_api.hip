@@ -219,6 +219,7 @@ void dv_destroy(dv_ctx* ctx) {
     if (ctx->obj_stream) (void)hipStreamDestroy(ctx->obj_stream);
     if (ctx->be_stream) (void)hipStreamDestroy(ctx->be_stream);
     if (ctx->out_pinned) (void)hipHostFree(ctx->out_pinned);
+    if (ctx->unmask_pinned) (void)hipHostFree(ctx->unmask_pinned);
     if (ctx->done) (void)hipEventDestroy(ctx->done);
     if (ctx->ev_pyr) (void)hipEventDestroy(ctx->ev_pyr);
     if (ctx->ev_bg_select) (void)hipEventDestroy(ctx->ev_bg_select);
@@ -304,6 +305,18 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
             mask_dev = (const uint8_t*)ctx->mask_buf.p;
         }
     }
+    if (!ctx->unmask.empty()) {          // system/main.cpp:217-245: the static instances' pixels leave the merged mask (inv_merge_mask = 255 there) before anything reads it
+        if (!mask_dev) { ctx->unmask.clear(); DV_FAIL("dv_track_unmask_static: the frame carries no mask"); }
+        if (mask_dev != (const uint8_t*)ctx->mask_buf.p) {          // the caller's device buffer is not written to: work on a copy
+            const int mp = align_up(w, 16);
+            DV_CHECK(ctx->mask_buf.ensure((size_t)mp * h));
+            DV_CHECK(hipMemcpy2DAsync(ctx->mask_buf.p, mp, mask_dev, mask_pitch, w, h, hipMemcpyDeviceToDevice, s));
+            mask_dev = (const uint8_t*)ctx->mask_buf.p; mask_pitch = mp;
+        }
+        for (const dv_ctx::UnmaskJob& j : ctx->unmask)
+            dv_launch_unmask((uint8_t*)ctx->mask_buf.p, mask_pitch, w, h, j.x, j.y, j.w, j.h, (const uint8_t*)ctx->unmask_pinned + j.off, s);
+        ctx->unmask.clear();
+    }
     const bool naive = (mode != DV_MODE_RAW);            // naive and semantic share the InstFeat code path (mask test, no sort, >= 10 new)
     if (naive && mask_dev && c.mask_morphology_size > 0) {       // ErodeMask (background_tracker.cpp:408-416,764-768)
         const int ep = align_up(w, 16);
@@ -371,6 +384,35 @@ int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gr
     DV_CHECK(hipEventRecord(ctx->done, s));
     ctx->last_done = ctx->done; ctx->last_front = s;
     ctx->prev_time = t; ctx->have_prev = true; ctx->pending = true;
+    return 0;
+}
+
+int dv_track_unmask_static(dv_ctx* ctx, const dv_inst_det* dets, int n_dets, const uint32_t* static_ids, int n_static) {
+    if (!ctx) return -1;
+    ctx->unmask.clear();
+    if (n_static <= 0 || n_dets <= 0) return 0;
+    if (!dets || !static_ids) DV_FAIL("dv_track_unmask_static: null argument");
+    if (ctx->pending) DV_FAIL("dv_track_unmask_static: call it before dv_track_stereo_enqueue of the frame it belongs to");
+    size_t need = 0;
+    for (int i = 0; i < n_dets; ++i) if (std::find(static_ids, static_ids + n_static, dets[i].track_id) != static_ids + n_static) need += ((size_t)dets[i].w * dets[i].h + 15) / 16 * 16;
+    if (!need) return 0;
+    if (ctx->unmask_pinned_bytes < need) {
+        DV_CHECK(hipStreamSynchronize(ctx->stream));          // (a previous frame's kernels may still read the old staging area)
+        if (ctx->unmask_pinned) (void)hipHostFree(ctx->unmask_pinned);
+        ctx->unmask_pinned = nullptr; ctx->unmask_pinned_bytes = 0;
+        const size_t want = std::max<size_t>(2 * need, (size_t)ctx->cfg.width * ctx->cfg.height);      // (a frame's worth from the start: the rectangles grow as objects come closer)
+        DV_CHECK(hipHostMalloc(&ctx->unmask_pinned, want, hipHostMallocDefault));
+        ctx->unmask_pinned_bytes = want;
+    } else if (ctx->last_done && ctx->last_done == ctx->done) DV_CHECK(hipEventSynchronize(ctx->done));      // the previous frame's unmask kernels have read the staging area (a no-op wait in the usual case: that frame was collected)
+    size_t off = 0;
+    for (int i = 0; i < n_dets; ++i) {
+        const dv_inst_det& d = dets[i];
+        if (std::find(static_ids, static_ids + n_static, d.track_id) == static_ids + n_static) continue;
+        if (!d.mask || d.w <= 0 || d.h <= 0 || d.x < 0 || d.y < 0 || d.x + d.w > ctx->cfg.width || d.y + d.h > ctx->cfg.height) { ctx->unmask.clear(); DV_FAIL("dv_track_unmask_static: bad detection rectangle / mask"); }
+        std::memcpy((uint8_t*)ctx->unmask_pinned + off, d.mask, (size_t)d.w * d.h);
+        ctx->unmask.push_back({ d.x, d.y, d.w, d.h, off });
+        off += ((size_t)d.w * d.h + 15) / 16 * 16;
+    }
     return 0;
 }
 

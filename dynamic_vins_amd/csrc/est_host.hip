@@ -654,7 +654,7 @@ struct dv_estimator {
         HostScope h(ctx, "h_dynamic");
         flush_dyn_tail(ctx);          // the previous frame's object tail (see BodySnap)
         const dvi::BodyView B = body_view();
-        { HostScope h1(ctx, "h_dyn_push"); im.push_back(frame, B, insts, n_insts, inst_feats, points); }
+        { HostScope h1(ctx, "h_dyn_push"); im.push_back(frame, B, insts, n_insts, inst_feats, points); im.set_output_inst_info(); }
         { HostScope h1(ctx, "h_dyn_propagate"); im.propagate_pose(B); }
         { HostScope h1(ctx, "h_dyn_triangulate"); im.triangulate(B); }
         { HostScope h1(ctx, "h_dyn_initial"); im.initial_instance(B); im.initial_velocity(B); im.set_dynamic_or_static(B); }
@@ -936,6 +936,16 @@ int dv_est_get_instances(dv_ctx* ctx, dv_inst_state* out, int cap, int* n_out, d
     }
     *n_out = k;
     if (summary4) { summary4[0] = E.obj_last.iterations; summary4[1] = E.obj_last.termination; summary4[2] = E.obj_last.initial_cost; summary4[3] = E.obj_last.final_cost; }
+    return 0;
+}
+int dv_est_get_static_instances(dv_ctx* ctx, uint32_t* ids, int cap, int* n_out) {
+    if (!ctx) return -1;
+    if (!ctx->est) DV_FAIL("dv_est_get_static_instances: call dv_est_create first");
+    if (!n_out || cap < 0 || (cap > 0 && !ids)) DV_FAIL("dv_est_get_static_instances: bad argument");
+    const std::vector<uint32_t>& v = ctx->est->im.static_out;
+    const int n = std::min((int)v.size(), cap);
+    for (int i = 0; i < n; ++i) ids[i] = v[i];
+    *n_out = n;
     return 0;
 }
 int dv_est_process_end(dv_ctx* ctx, dv_est_state* out) {

@@ -133,7 +133,16 @@ struct InstMgr {
     std::map<unsigned, Inst> insts;      // ascending id = the canonical visiting order
     InstCfg cfg; int tracking_num = 0, frame = 0; uint64_t seq = 0;
 
-    void clear() { insts.clear(); tracking_num = 0; frame = 0; seq = 0; }
+    void clear() { insts.clear(); tracking_num = 0; frame = 0; seq = 0; static_out.clear(); }
+    // ---- SetOutputInstInfo (estimator_insts.cpp:967-990), as far as the front end reads it back: the ids of the instances InstExec visits (initialised and tracking) that
+    // are_static at this point — right behind PushBack (estimator.cpp:1579-1586), i.e. with the flags the PREVIOUS frame's SetDynamicOrStatic left.  system/main.cpp:217-245
+    // takes the pixels of those instances out of the merged mask (para::is_static_inst_as_background, default true: vio_parameters.h:86).
+    std::vector<uint32_t> static_out;
+    void set_output_inst_info() {
+        static_out.clear();
+        if (tracking_num < 1) return;
+        for (auto& kv : insts) { if (!kv.second.is_initial || !kv.second.is_tracking) continue; if (kv.second.is_static) static_out.push_back(kv.first); }
+    }
 
     // ---- PushBack (estimator_insts.cpp:54-170) ----
     void push_back(int frame_id, const BodyView& B, const dv_inst_obs* in, int n_in, const dv_feat* feats, const double* points) {

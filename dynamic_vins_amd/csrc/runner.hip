@@ -52,6 +52,12 @@ struct RSeq {
                                                                                                 // a thread per dv_runner_run put that into the first frames of every call); track_last = the last frame it may take
     std::unique_ptr<std::mutex> ring_mu = std::make_unique<std::mutex>(); std::unique_ptr<std::condition_variable> ring_cv = std::make_unique<std::condition_variable>();
     long long detections = 0, object_features = 0, frames_with_objects = 0; int min_detections = 1 << 30;
+    // para::is_static_inst_as_background (dv_seq_dynamic::static_as_background): FeatureTrack takes the pixels of the instances the estimator reported static out of the merged
+    // mask (system/main.cpp:194,217-245).  In the reference T2 reads whatever T3 published last — a race whose outcome depends on the threads' timing; here the tracking of
+    // frame f uses the snapshot of the newest back-end frame <= f - 2 (what the one-thread loop sees when it enqueues frame f: the object branch of frame f - 1 comes behind
+    // that enqueue), in every host layout.  snaps / est_passed are guarded by ring_mu.
+    struct StaticSnap { int frame = -1; std::vector<uint32_t> ids; };
+    bool static_unmask = false; StaticSnap snaps[4]; int snap_next = 0, est_passed = -1;
     // TrackImageNaive over the sequence (dv_runner_set_mask): per frame the inverse merged instance mask, and the tracking mode that takes it
     const uint8_t* const* raw_mask = nullptr; int raw_mode = DV_MODE_RAW;
 };
@@ -105,10 +111,27 @@ int seq_feed_imu(dv_runner* R, RSeq& s, double t) {
     }
     return 0;
 }
+// the estimator loop has passed frame k (its object branch ran, or the frame was track-only): publish the static-instance snapshot the tracker of frame >= k + 2 reads
+int dyn_passed(dv_runner* R, RSeq& s, int k, bool with_snapshot) {
+    uint32_t ids[256]; int n = 0;
+    if (s.static_unmask && with_snapshot && dv_est_get_static_instances(s.ctx, ids, 256, &n)) return fail(R, s, "dv_est_get_static_instances");
+    {
+        std::lock_guard<std::mutex> lk(*s.ring_mu);
+        if (s.static_unmask && with_snapshot) { RSeq::StaticSnap& sn = s.snaps[s.snap_next]; s.snap_next = (s.snap_next + 1) % 4; sn.frame = k; sn.ids.assign(ids, ids + n); }
+        s.est_passed = k;
+    }
+    s.ring_cv->notify_all();
+    return 0;
+}
 // ---- dynamic mode: TrackSemanticImage + InstsTrack of frame k (one enqueue), their collect, and the three-phase back end ----
 int dyn_enqueue(dv_runner* R, RSeq& s, int k) {
     const dv_seq_dynamic& d = s.dyn;
     const int mode = d.mode ? d.mode : DV_MODE_SEMANTIC;
+    if (s.static_unmask && d.inv_mask && d.dets && d.n_dets && d.n_dets[k] > 0) {
+        std::vector<uint32_t> ids;
+        { std::lock_guard<std::mutex> lk(*s.ring_mu); int best = -1; for (const RSeq::StaticSnap& sn : s.snaps) if (sn.frame >= 0 && sn.frame <= k - 2 && sn.frame > best) { best = sn.frame; ids = sn.ids; } }
+        if (dv_track_unmask_static(s.ctx, d.dets[k], d.n_dets[k], ids.data(), (int)ids.size())) return fail(R, s, "dv_track_unmask_static");
+    }
     // (frames and mask share `mem` in dv_track_stereo_enqueue: a device-resident sequence keeps both in HBM)
     if (dv_track_stereo_enqueue(s.ctx, s.in.left[k], s.in.right[k], s.w, s.h, s.stride, s.in.times[k], d.inv_mask ? d.inv_mask[k] : nullptr, mode, s.in.mem)) return fail(R, s, "dv_track_stereo_enqueue");
     if (d.disp && d.disp[k] && dv_inst_set_disparity(s.ctx, d.disp[k], d.disp_stride, d.disp_mem, d.baseline)) return fail(R, s, "dv_inst_set_disparity");
@@ -133,7 +156,7 @@ int dyn_begin(dv_runner* R, RSeq& s) {
     if (s.in.ba_stride > 1 && (k % s.in.ba_stride) != 0) {      // tracked only: both trackers have seen the frame, the back end has not (system/main.cpp:300-312: frames 0, 2, 4, ... outside KITTI)
         if (k + 1 < s.in.n_frames) { if (dyn_enqueue(R, s, k + 1) || dyn_collect(R, s, s.db[s.cur ^ 1])) return -1; }
         b.valid = false; s.cur ^= 1; ++s.next; s.skipped = true;
-        return 0;
+        return dyn_passed(R, s, k, false);
     }
     s.skipped = false;
     if (seq_feed_imu(R, s, t)) return -1;
@@ -145,6 +168,7 @@ int dyn_begin(dv_runner* R, RSeq& s) {
     if (k + 1 < s.in.n_frames && dyn_enqueue(R, s, k + 1)) return -1;
     if (dv_est_process_dynamic_attach(s.ctx, b.n_insts ? b.insts.data() : nullptr, b.n_insts, b.n_ifeats ? b.ifeats.data() : nullptr, b.n_pts ? b.pts.data() : nullptr)) return fail(R, s, "dv_est_process_dynamic_attach");
     s.detections += b.n_insts; s.object_features += b.n_ifeats; s.frames_with_objects += b.n_insts > 0; s.min_detections = std::min(s.min_detections, b.n_insts);
+    if (dyn_passed(R, s, k, true)) return -1;
     if (k + 1 < s.in.n_frames) {
         if (seq_feed_imu(R, s, s.in.times[k + 1])) return -1;
         if (dyn_collect(R, s, s.db[s.cur ^ 1])) return -1;
@@ -163,7 +187,8 @@ void dyn_tracker_thread(dv_runner* R, RSeq& s) {
         {
             std::unique_lock<std::mutex> lk(*s.ring_mu);
             s.track_busy = false; s.ring_cv->notify_all();
-            s.ring_cv->wait(lk, [&] { return s.track_stop || (!s.ring_failed && s.tracked_next <= s.track_last && s.ring_count < RSeq::RING); });
+            s.ring_cv->wait(lk, [&] { return s.track_stop || (!s.ring_failed && s.tracked_next <= s.track_last && s.ring_count < RSeq::RING &&
+                                                                  (!s.static_unmask || s.tracked_next < 2 || s.est_passed >= s.tracked_next - 2)); });      // (the static-instance snapshot of frame f - 2 must exist)
             if (s.track_stop) return;
             s.track_busy = true;
             f = s.tracked_next; slot = (s.ring_pos + s.ring_count) % RSeq::RING;
@@ -197,7 +222,7 @@ int dyn_begin_threaded(dv_runner* R, RSeq& s) {
         { std::lock_guard<std::mutex> lk(*s.ring_mu); b.valid = false; s.ring_pos = (s.ring_pos + 1) % RSeq::RING; --s.ring_count; ++s.ring_head; }
         s.ring_cv->notify_all();
         ++s.next; s.skipped = true;
-        return 0;
+        return dyn_passed(R, s, k, false);
     }
     s.skipped = false;
     if (seq_feed_imu(R, s, t)) return -1;
@@ -211,6 +236,7 @@ int dyn_begin_threaded(dv_runner* R, RSeq& s) {
         b.valid = false; s.ring_pos = (s.ring_pos + 1) % RSeq::RING; --s.ring_count; ++s.ring_head;
     }
     s.ring_cv->notify_all();
+    if (dyn_passed(R, s, k, true)) return -1;
     if (k + 1 < s.in.n_frames && seq_feed_imu(R, s, s.in.times[k + 1])) return -1;
     s.pending = true; s.pending_t = t;
     return 0;
@@ -524,7 +550,7 @@ int dv_runner_set_dynamic(dv_runner* R, int seq, const dv_seq_dynamic* dyn) {
     for (auto& g : R->groups) if (g.batch) for (int i : g.members) if (i == seq) { R->err = "dv_runner_set_dynamic: a dynamic sequence cannot be a member of a dv_batch group (create the runner with group_size 0 for it)"; return -1; }
     if (!s.ctx->inst) { R->err = "dv_runner_set_dynamic: call dv_inst_config on the sequence's context first"; return -1; }
     if (dyn->inv_mask && dyn->mask_mem != s.in.mem) { R->err = "dv_runner_set_dynamic: mask_mem must equal the frames' mem (dv_track_stereo_enqueue takes frames and mask from one memory kind)"; return -1; }
-    s.dynamic = true; s.dyn = *dyn;
+    s.dynamic = true; s.dyn = *dyn; s.static_unmask = dyn->static_as_background != 0;
     for (auto& b : s.db) { b.rows.resize(DV_MAX_FEATS); b.insts.resize(64); b.ifeats.resize(64 * 256); b.pts.resize((size_t)3 * 65536); b.valid = false; }
     for (auto& b : s.ring) { b.rows.resize(DV_MAX_FEATS); b.insts.resize(64); b.ifeats.resize(64 * 256); b.pts.resize((size_t)3 * 65536); b.valid = false; }
     return 0;

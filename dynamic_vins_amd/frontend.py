@@ -117,6 +117,21 @@ class Context:
             ptr = int(disp)
         self._check(self.lib.dv_inst_set_disparity(self.h, ptr, int(stride_bytes), int(mem), float(baseline)))
 
+    def track_unmask_static(self, dets, static_ids):
+        """FeatureTrack, system/main.cpp:217-245 (para::is_static_inst_as_background): for the NEXT track_stereo_enqueue (which must carry a mask) the pixels of the frame's
+        detections whose track_id the estimator reported static leave the merged instance mask.  dets: the frame's detection dicts (rect, mask)."""
+        ids = np.ascontiguousarray(static_ids, np.uint32)
+        if not len(ids) or not len(dets):
+            self._check(self.lib.dv_track_unmask_static(self.h, None, 0, None, 0))
+            return
+        arr = (dv_inst_det * len(dets))()
+        keep = []
+        for k, d in enumerate(dets):
+            m = np.ascontiguousarray(d["mask"], np.uint8); keep.append(m)
+            x, y, w, h = [int(v) for v in d["rect"]]
+            arr[k].track_id, arr[k].x, arr[k].y, arr[k].w, arr[k].h, arr[k].mask = int(d["track_id"]), x, y, w, h, m.ctypes.data
+        self._check(self.lib.dv_track_unmask_static(self.h, C.addressof(arr), len(dets), ids.ctypes.data, len(ids)))
+
     def inst_set_right_keys(self, key_img, mem=DV_MEM_HOST):
         """VIODE: the key image of seg1 (viode_mask(...)[2]: uint32 [h, w] numpy array, or a device pointer with mem=DV_MEM_DEVICE) of the frame the next inst_track_enqueue
         processes: TrackRightByPad's segmentation-key test (front_end/instance_feature.cpp:263-268)"""

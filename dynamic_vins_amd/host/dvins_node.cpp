@@ -261,6 +261,7 @@ int main(int argc, char** argv) {
             dyn.inv_mask = mask_ptr.data(); dyn.mask_mem = DV_MEM_HOST; dyn.mode = DV_MODE_SEMANTIC;
             dyn.dets = det_ptr.data(); dyn.n_dets = n_dets.data(); dyn.boxes3d = nullptr; dyn.n_boxes3d = nullptr; dyn.disp = nullptr; dyn.baseline = cfg.baseline;
             dyn.right_keys = keys_ptr.data(); dyn.right_keys_mem = DV_MEM_HOST;
+            dyn.static_as_background = cfg.static_inst_as_background ? 1 : 0;      // (vio_parameters.h:86: on unless the YAML says static_inst_as_background: 0)
             if (dv_runner_set_dynamic(runner, 0, &dyn)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));
         } else if (run_naive) {
             if (dv_runner_set_mask(runner, 0, mask_ptr.data(), DV_MEM_HOST, DV_MODE_NAIVE)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));

@@ -209,7 +209,8 @@ class DynamicPipeline(Pipeline):
     as TrackSemanticImage's line thread delivers them (background_tracker.cpp:774-780, 809-817)."""
 
     def __init__(self, seq: DynamicSequence, max_cnt=250, min_dist=25, max_iters=10, device=0, use_imu=1, max_dynamic_cnt=50, min_dynamic_dist=5, use_det3d=1,
-                 static_inst_threshold=1.0, mask_morphology_size=0, segments=None, est_kw=None, extra_from_disparity=True, ba_stride=1):
+                 static_inst_threshold=1.0, mask_morphology_size=0, segments=None, est_kw=None, extra_from_disparity=True, ba_stride=1,
+                 static_as_background=False):
         from .frontend import DV_MODE_SEMANTIC
         self.extra_from_disparity = extra_from_disparity      # False: the detections' own `points` are handed through (the caller ran the extra-point pipeline)
         self.seq, self.host = seq, None
@@ -228,11 +229,20 @@ class DynamicPipeline(Pipeline):
         self.ba_stride = ba_stride          # 2: every tracked frame goes through both trackers, every 2nd one to the back end (system/main.cpp:300-307: every data set but KITTI)
         self.last_state = None
         self.poses, self.pose_times = [], []
+        # para::is_static_inst_as_background (reference default: true): before tracking frame f the pixels of the instances the estimator reported static leave the merged mask
+        # (system/main.cpp:194,217-245).  The reference reads that report across threads without an order; here: the snapshot of the newest back-end frame <= f - 2 (runner.hip)
+        self.static_as_background, self.static_snaps = static_as_background, []
         self.frame_rows, self.keep_frame_rows = [], False      # (t, [px py pz qx qy qz qw], nonlinear) of every frame handed to the back end when keep_frame_rows is set
         self.stat = dict(frames=0, frames_with_objects=0, object_detections=0, object_features=0, min_detections=10 ** 9)      # what the object branch was fed over the run
 
+    def static_ids_for(self, k):
+        best = [s for s in self.static_snaps if s[0] <= k - 2]
+        return best[-1][1] if best else np.zeros(0, np.uint32)
+
     def _enqueue(self, k):
         l, r = self.seq.frames[k]
+        if self.static_as_background and len(self.seq.dets[k]):
+            self.ctx.track_unmask_static(self.seq.dets[k], self.static_ids_for(k))
         self.ctx.track_stereo_enqueue(l.data_ptr(), r.data_ptr(), self.seq.times[k], self.seq.inv_mask_dev[k].data_ptr(), self.mode, DV_MEM_DEVICE)
         if self.extra_from_disparity:      # the extra points of the objects: DetectExtraPoints + ProcessExtraPoints on the device from the frame's disparity map
             self.ctx.inst_set_disparity(self.seq.disp_dev[k].data_ptr(), self.seq.baseline, DV_MEM_DEVICE)
@@ -280,6 +290,8 @@ class DynamicPipeline(Pipeline):
         if k + 1 < len(s.frames):
             self._enqueue(k + 1)
         self.est.AttachInstances(insts, ifeats, pts)
+        if self.static_as_background:
+            self.static_snaps = (self.static_snaps + [(k, self.est.static_instances())])[-4:]
         if k + 1 < len(s.frames):
             self._feed_imu(s.times[k + 1])
             if not defer_end:

@@ -59,6 +59,19 @@ def detections(key_img, boxes, dyn_keys, min_size=MIN_INST_SIZE):
     return dets
 
 
+def unmask_static(inv_mask, dets, static_ids):
+    """FeatureTrack, system/main.cpp:217-245, on the host (the oracle side of the parity tests; the product does this on the device: dv_track_unmask_static): the ROI-mask pixels
+    of every detection whose track_id is in static_ids become background (inv_merge_mask 255)"""
+    out = np.array(inv_mask, np.uint8, copy=True)
+    ids = set(int(i) for i in static_ids)
+    for d in dets:
+        if int(d["track_id"]) in ids:
+            x, y, w, h = [int(v) for v in d["rect"]]
+            roi = out[y:y + h, x:x + w]
+            roi[np.asarray(d["mask"])[: roi.shape[0], : roi.shape[1]] >= 1] = 255
+    return out
+
+
 # ---- a VIODE-layout sequence directory from the synthetic renderer ----
 
 def object_colour(obj_id):

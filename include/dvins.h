@@ -89,6 +89,13 @@ int dv_track_stereo(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gray1, int
 int dv_track_stereo_enqueue(dv_ctx* ctx, const uint8_t* gray0, const uint8_t* gray1, int w, int h, int stride,
                             double t, const uint8_t* mask_or_null, int mode, int mem);
 int dv_track_stereo_collect(dv_ctx* ctx, dv_feat* out, int* n_out);
+struct dv_inst_det;
+/* para::is_static_inst_as_background (default true, estimator/vio_parameters.h:86) — FeatureTrack, system/main.cpp:217-245: before TrackSemanticImage the pixels of
+ * every visible instance the estimator reported static (dv_est_get_static_instances) are taken OUT of the merged instance mask, so the background tracker may pick
+ * features on parked objects: merge_mask(row + rect.y, col + rect.x) = 0 where the instance's ROI mask is set, inv_merge_mask = ~merge_mask.
+ * For the NEXT dv_track_stereo_enqueue (which must carry a mask): dets = the frame's detections (rect + ROI mask, host memory, valid until that call), static_ids =
+ * the estimator's list.  Detections whose track_id is not in the list are left alone; n_static 0 cancels.  The caller's mask is not written to. */
+int dv_track_unmask_static(dv_ctx* ctx, const struct dv_inst_det* dets, int n_dets, const uint32_t* static_ids, int n_static);
 
 /* ---- front end: operator-level entries ---- */
 /* cv::calcOpticalFlowPyrLK(img_a,img_b,pts_a,pts_b,status,err,Size(21,21),max_level,
@@ -496,7 +503,10 @@ typedef struct dv_seq_dynamic {
     const dv_inst_det* const* dets; const int32_t* n_dets;
     const dv_box3d* const* boxes3d; const int32_t* n_boxes3d;      /* may be NULL (no 3-D detector) */
     const float* const* disp; int32_t disp_mem, disp_stride /* bytes, 0 = 4 * width */; double baseline;      /* disp may be NULL: dv_inst_det::points are handed through */
-    const uint32_t* const* right_keys; int32_t right_keys_mem, reserved;      /* VIODE: per frame the key image of seg1 (dv_inst_set_right_keys), tightly packed; may be NULL */
+    const uint32_t* const* right_keys; int32_t right_keys_mem;      /* VIODE: per frame the key image of seg1 (dv_inst_set_right_keys), tightly packed; may be NULL */
+    int32_t static_as_background;      /* para::is_static_inst_as_background (vio_parameters.h:86: the reference's default is 1): before tracking frame f the pixels of the instances the
+                                          estimator reported static leave the merged mask (dv_est_get_static_instances of the newest back-end frame <= f - 2 -> dv_track_unmask_static;
+                                          system/main.cpp:194,217-245).  The reference reads that report across threads without an order; the lag of two frames is this runner's, in every layout */
 } dv_seq_dynamic;
 typedef struct dv_runner dv_runner;
 /* slam_type naive of a sequence (system/main.cpp:263-265: FeatureTrack -> TrackImageNaive): per frame [n_frames] the inverse merged instance mask (0 = object pixel;
@@ -610,6 +620,10 @@ int dv_est_process_dynamic_attach(dv_ctx* ctx, const dv_inst_obs* insts, int n_i
 /* Estimator::im.instances after the last processed frame (ascending id); *n_out = number written (<= cap); summary4 (may be NULL): iterations,
  * termination, initial and final cost of the last object solve */
 int dv_est_get_instances(dv_ctx* ctx, dv_inst_state* out, int cap, int* n_out, double* summary4);
+/* InstanceManager::GetOutputInstInfo as far as the front end reads it (estimator_insts.cpp:967-990; system/main.cpp:194,217-245): the ids of the initialised, tracked
+ * instances that were is_static when the LAST dynamic frame took its snapshot — right behind PushBack (estimator.cpp:1579-1586), so with the flags the frame before
+ * left.  Ascending.  The tracker side of the feedback is dv_track_unmask_static. */
+int dv_est_get_static_instances(dv_ctx* ctx, uint32_t* ids, int cap, int* n_out);
 
 /* ---- measurement hooks (used by bench.py; HIP-event timing on the ctx's own stream) ---- */
 /* names: "pyr","lk_temporal","compact","gftt_eig","gftt_select","lk_stereo","frame" */

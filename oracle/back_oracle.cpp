@@ -868,6 +868,7 @@ struct Estimator {
         if (dyn) {               // estimator.cpp:1562-1622
             const oim::Body b = body();
             im.PushBack(b, (unsigned)frame, *instances);
+            im.SetOutputInstInfo();          // para::is_static_inst_as_background (estimator.cpp:1583-1586; default true, vio_parameters.h:86)
             im.PropagatePose(b);
             im.Triangulate(b);
             im.InitialInstance(b);
@@ -1175,6 +1176,13 @@ int dvo_estimator_process_dynamic(dvo_estimator* e, const dvo_feat* feats, int n
     }
     if (!E.process(feats, n, t, &in)) return 1;
     fill_state(E, out);
+    return 0;
+}
+int dvo_estimator_get_static_instances(dvo_estimator* e, uint32_t* ids, int cap, int* n_out) {          // InstanceManager::GetOutputInstInfo, the is_static ids (system/main.cpp:194,217-245)
+    const std::vector<uint32_t>& v = e->e->im.insts_output_static;
+    const int n = std::min((int)v.size(), cap);
+    for (int i = 0; i < n; ++i) ids[i] = v[i];
+    *n_out = n;
     return 0;
 }
 int dvo_estimator_get_instances(dvo_estimator* e, dvo_inst_state* out, int cap, int* n_out, double* summary4) {

@@ -275,6 +275,9 @@ void dvo_estimator_get_extrinsics(dvo_estimator*, double* ric18, double* tic6, d
 int dvo_estimator_set_lines(dvo_estimator* e, const dvo_line_row* lines, int n);      /* frame.features.lines of the next process call */
 int dvo_estimator_get_lines(dvo_estimator* e, dvo_line_landmark* out, int cap, int* n_out);
 int dvo_estimator_get_instances(dvo_estimator*, dvo_inst_state* out, int cap, int* n_out, double* summary4);
+/* InstanceManager::GetOutputInstInfo (estimator_insts.cpp:967-990) as FeatureTrack reads it (system/main.cpp:194,217-245): ids of the initialised, tracked instances that
+ * were is_static at the last frame's snapshot (right behind PushBack), ascending */
+int dvo_estimator_get_static_instances(dvo_estimator*, uint32_t* ids, int cap, int* n_out);
 
 #ifdef __cplusplus
 }

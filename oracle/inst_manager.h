@@ -322,6 +322,13 @@ struct InstanceManager {   // estimator/estimator_insts.h
     std::map<unsigned, Instance> instances;      // canonical: ascending id (reference: unordered_map)
     Params para; int tracking_num = 0, frame = 0; uint64_t seq = 0; dvo_ba_summary last_summary{};
 
+    // SetOutputInstInfo (:967-990) as far as the front end reads it back (system/main.cpp:194,217-245): the ids of the instances InstExec visits that are is_static
+    std::vector<uint32_t> insts_output_static;
+    void SetOutputInstInfo() {
+        insts_output_static.clear();
+        if (tracking_num < 1) return;
+        InstExec([this](unsigned, Instance& inst) { if (inst.is_static) insts_output_static.push_back(inst.id); });
+    }
     template <class F> void InstExec(F function, bool exec_all = false) {
         if (tracking_num < 1) return;
         for (auto& kv : instances) { if (!exec_all && (!kv.second.is_initial || !kv.second.is_tracking)) continue; function(kv.first, kv.second); }

@@ -20,12 +20,13 @@ extern "C" void dvstub_new_run();
 namespace {
 struct Seq {
     std::vector<const uint8_t*> left, right; std::vector<double> times, imu_t, imu_a, imu_g;
-    std::vector<const uint8_t*> masks; std::vector<const dv_inst_det*> dets; std::vector<int32_t> n_dets;
+    std::vector<const uint8_t*> masks; std::vector<const dv_inst_det*> dets; std::vector<int32_t> n_dets; dv_inst_det one_det{};
     dv_seq_input in{}; dv_seq_dynamic dyn{};
 };
 void make_seq(Seq& q, int frames, int id) {
     static uint8_t pixel[4096];
-    for (int k = 0; k < frames; ++k) { q.left.push_back(pixel + (id * 64 + k) % 4000); q.right.push_back(pixel + (id * 64 + k + 7) % 4000); q.times.push_back(1.0 + 0.05 * k); q.masks.push_back(pixel + k % 100); q.dets.push_back(nullptr); q.n_dets.push_back(0); }
+    for (int k = 0; k < frames; ++k) { q.left.push_back(pixel + (id * 64 + k) % 4000); q.right.push_back(pixel + (id * 64 + k + 7) % 4000); q.times.push_back(1.0 + 0.05 * k); q.masks.push_back(pixel + k % 100); q.dets.push_back(&q.one_det); q.n_dets.push_back(1); }
+    q.one_det.track_id = 10; q.one_det.w = q.one_det.h = 4; q.one_det.mask = pixel;
     for (int i = 0; i < frames * 10 + 20; ++i) { q.imu_t.push_back(0.9 + 0.005 * i); for (int c = 0; c < 3; ++c) { q.imu_a.push_back(0.01 * i + c + id); q.imu_g.push_back(0.02 * i - c); } }
     q.in.left = q.left.data(); q.in.right = q.right.data(); q.in.times = q.times.data(); q.in.n_frames = frames; q.in.mem = DV_MEM_DEVICE; q.in.stride = 0; q.in.ba_stride = 1;
     q.in.imu_t = q.imu_t.data(); q.in.imu_acc = q.imu_a.data(); q.in.imu_gyr = q.imu_g.data(); q.in.n_imu = (int)q.imu_t.size();
@@ -33,10 +34,10 @@ void make_seq(Seq& q, int frames, int id) {
 }
 struct Log { std::vector<double> frames; std::vector<unsigned long long> rows; long long iterations = 0; };
 // one runner over n sequences in the given layout; `cuts` = the dv_runner_run calls; -> per-sequence logs (empty on failure)
-int run_layout(int n, int frames, int group, int threads, int teams, int dynamic, int tracker_thread, const std::vector<int>& cuts, std::vector<Log>& out, bool expect_fail = false) {
+int run_layout(int n, int frames, int group, int threads, int teams, int dynamic, int tracker_thread, const std::vector<int>& cuts, std::vector<Log>& out, bool expect_fail = false, int static_bg = 0, int ba_stride = 1) {
     std::vector<Seq> seqs(n); std::vector<dv_ctx*> ctxs; std::vector<dv_seq_input> in;
     dvstub_new_run();
-    for (int i = 0; i < n; ++i) { make_seq(seqs[i], frames, i); ctxs.push_back(dvstub_ctx(64, 48, dynamic)); in.push_back(seqs[i].in); }
+    for (int i = 0; i < n; ++i) { make_seq(seqs[i], frames, i); seqs[i].in.ba_stride = ba_stride; seqs[i].dyn.static_as_background = static_bg; ctxs.push_back(dvstub_ctx(64, 48, dynamic)); in.push_back(seqs[i].in); }
     dv_runner* R = dv_runner_create(ctxs.data(), in.data(), n, group, threads);
     if (!R) { std::fprintf(stderr, "dv_runner_create failed\n"); return 2; }
     dv_runner_set(R, "teams", teams);
@@ -92,6 +93,16 @@ int main(int argc, char** argv) {
             const bool ok = same(ref, got);
             if (!ok) bad++;
             std::printf("layout '%s': %s\n", l.name, ok ? "same logs" : "DIFFERENT");
+        }
+        // the static-instance feedback (T3 -> T2 with a lag of two frames) and the every-2nd-frame flow: the tracker waits for the estimator's snapshot, the hand-over must not depend on the layout
+        for (int stride = 1; stride <= 2; ++stride) {
+            if (run_layout(n, frames, 0, 1, 0, 1, 0, { frames }, ref, false, 1, stride)) return 2;
+            for (const L& l : layouts) {
+                if (run_layout(n, frames, 0, l.threads, 0, 1, l.tracker, l.cuts, got, false, 1, stride)) return 2;
+                const bool ok = same(ref, got);
+                if (!ok) bad++;
+                std::printf("static feedback, ba_stride %d, layout '%s': %s\n", stride, l.name, ok ? "same logs" : "DIFFERENT");
+            }
         }
     } else if (mode == "fail") {          // DVSTUB_FAIL=<ctx>:<frame> is set by the caller: the run must return an error, not hang, in every layout
         std::vector<Log> got;

@@ -8,6 +8,7 @@
 //   * deterministic outputs (functions of the frame index and of what the call was handed) after a short sleep, so that every threading layout of the runner must
 //     produce the same logs as its single-thread loop.
 // DVSTUB_FAIL="<ctx index>:<frame>" makes dv_est_process_begin of that context fail at that frame: the failure path through the team barriers.
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdlib>
@@ -23,7 +24,7 @@ namespace {
 struct Stub {
     int index = 0;
     // tracker domain
-    int trk_scratch = 0; bool trk_pending = false; int trk_frame = 0; double trk_t = 0; unsigned long long trk_in = 0;
+    int trk_scratch = 0; bool trk_pending = false; int trk_frame = 0; double trk_t = 0; unsigned long long trk_in = 0, unmask_hash = 0;
     bool inst_pending = false; int inst_frame = 0;
     // estimator domain
     int est_scratch = 0; bool begun = false, ego_begun = false; int est_frame = 0; unsigned long long est_hash = 0; double est_t = 0;
@@ -81,7 +82,8 @@ int dv_sync(dv_ctx*) { return 0; }
 int dv_track_stereo_enqueue(dv_ctx* c, const uint8_t* g0, const uint8_t* g1, int, int, int, double t, const uint8_t* mask, int mode, int) {
     Stub& s = S(c); s.trk_scratch++;
     if (s.trk_pending) return violation("dv_track_stereo_enqueue: previous frame not collected");
-    s.trk_pending = true; s.trk_t = t; s.trk_in = mix(mix(mix((unsigned long long)(uintptr_t)g0, (unsigned long long)(uintptr_t)g1), (unsigned long long)(uintptr_t)mask), (unsigned long long)mode);
+    s.trk_pending = true; s.trk_t = t; s.trk_in = mix(mix(mix(mix((unsigned long long)(uintptr_t)g0, (unsigned long long)(uintptr_t)g1), (unsigned long long)(uintptr_t)mask), (unsigned long long)mode), s.unmask_hash);
+    s.unmask_hash = 0;
     work(30);
     return 0;
 }
@@ -97,6 +99,12 @@ int dv_track_stereo_collect(dv_ctx* c, dv_feat* out, int* n_out) {
 }
 int dv_inst_set_disparity(dv_ctx* c, const float*, int, int, double) { Stub& s = S(c); s.trk_scratch++; return 0; }
 int dv_inst_set_right_keys(dv_ctx* c, const uint32_t*, int, int) { Stub& s = S(c); s.trk_scratch++; return 0; }
+int dv_track_unmask_static(dv_ctx* c, const dv_inst_det*, int, const uint32_t* ids, int n) {          // the ids travel into the next frame's input hash: every layout must hand over the same list
+    Stub& s = S(c); s.trk_scratch++;
+    if (s.trk_pending) return violation("dv_track_unmask_static: behind the frame's enqueue");
+    s.unmask_hash = 0x51ed; for (int i = 0; i < n; ++i) s.unmask_hash = mix(s.unmask_hash, ids[i]);
+    return 0;
+}
 int dv_inst_track_enqueue(dv_ctx* c, double, const dv_inst_det*, int, const dv_box3d*, int) {
     Stub& s = S(c); s.trk_scratch++;
     if (s.inst_pending) return violation("dv_inst_track_enqueue: previous frame not collected");
@@ -166,6 +174,13 @@ int dv_est_process(dv_ctx* c, const dv_feat* rows, int n, double t, dv_est_state
     return dv_est_process_end(c, out);
 }
 int dv_est_set_lines(dv_ctx* c, const dv_line_row*, int) { S(c).est_scratch++; return 0; }
+int dv_est_get_static_instances(dv_ctx* c, uint32_t* ids, int cap, int* n) {          // "static" instances as a function of the frames processed so far
+    Stub& s = S(c); s.est_scratch++;
+    const int k = std::min(cap, s.est_frame % 3);
+    for (int i = 0; i < k; ++i) ids[i] = (uint32_t)(10 + (s.est_frame + i) % 3);
+    *n = k;
+    return 0;
+}
 
 // ---------------- dv_batch: the shared launches touch every member ----------------
 struct dv_batch { std::vector<dv_ctx*> m; long long rounds = 0, track_rounds = 0, members = 0; };

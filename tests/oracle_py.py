@@ -420,6 +420,13 @@ class OracleEstimator:
                                              _p(points) if len(points) else None, C.byref(self.state))
         return rc, self.state
 
+    def static_instances(self, cap=256):
+        """ids the estimator reported static at its last dynamic frame (InstanceManager::GetOutputInstInfo, is_static; system/main.cpp:194,217-245)"""
+        ids = np.zeros(cap, np.uint32); n = C.c_int(0)
+        self.lib.dvo_estimator_get_static_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+        self.lib.dvo_estimator_get_static_instances(self.h, _p(ids), cap, C.byref(n))
+        return ids[: n.value].copy()
+
     def instances(self, dtype, cap=64):
         L = self.lib
         L.dvo_estimator_get_instances.restype = C.c_int

@@ -22,26 +22,37 @@ def rows_equal(a, b, what):
     assert np.array_equal(a["right"].view(np.uint64), b["right"].view(np.uint64)), what
 
 
-def run(oracle, w, h, frames, max_cnt, min_dist, iters, use_det3d=1, morph=0, drop=()):
+def run(oracle, w, h, frames, max_cnt, min_dist, iters, use_det3d=1, morph=0, drop=(), static_bg=False):
+    from dynamic_vins_amd import viode
     from dynamic_vins_amd.pipeline import DynamicPipeline, DynamicSequence
     cam = sim.ZED if (w, h) == (1280, 720) else sim.scaled_cam(sim.ZED, w, h, 1280, 720)
     seq = DynamicSequence(w, h, cam, frames, rate=20.0)
     for k in drop:                       # frames where the detector saw nothing
         seq.dets[k], seq.boxes3d[k] = [], np.zeros(0, dynsim.BOX3D_DTYPE)
-    pipe = DynamicPipeline(seq, max_cnt=max_cnt, min_dist=min_dist, max_iters=iters, use_det3d=use_det3d, mask_morphology_size=morph)
+    pipe = DynamicPipeline(seq, max_cnt=max_cnt, min_dist=min_dist, max_iters=iters, use_det3d=use_det3d, mask_morphology_size=morph, static_as_background=static_bg)
+    snaps = []
     camt = sim.cam_tuple(cam)
     trk = oracle.tracker(w, h, max_cnt, min_dist, 1, 1, camt, camt)
     oin = oracle.insts(trk, 50, 5, use_det3d)
     est = oracle.estimator(use_imu=1, stereo=1, max_iters=iters, ric=[sim.R_IC, sim.R_IC], tic=[sim.T_IC0, sim.T_IC1], dynamic=1, use_det3d=use_det3d, static_inst_threshold=1.0, **seq.noise)
     k_imu = 0
-    stats = dict(obj_rows=0, objs=set(), initial=0, solved=0, max_dp=0.0, obj_p=0.0, obj_q=0.0, iter_mismatch=0)
+    stats = dict(obj_rows=0, objs=set(), initial=0, solved=0, max_dp=0.0, obj_p=0.0, obj_q=0.0, iter_mismatch=0, unmasked_px=0, unmasked_frames=0, bg_rows_on_objects=0)
     for k in range(frames):
         t = seq.times[k]
         sd = pipe.step()
         while k_imu < len(seq.imu_t) and seq.imu_t[k_imu] <= t + 0.006:
             est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
         left, right = seq.host_frame(k)
-        rows_o = trk.track_image(left, right, t, mask=seq.inv_mask[k], mode=2, erode_k=morph)
+        mask_o = seq.inv_mask[k]
+        if static_bg:          # FeatureTrack (system/main.cpp:217-245) on the oracle side: the estimator's report of the newest back-end frame <= k - 2, applied on the host
+            best = [sn for sn in snaps if sn[0] <= k - 2]
+            mask_o = viode.unmask_static(seq.inv_mask[k], seq.dets[k], best[-1][1] if best else [])
+            px = int(((seq.inv_mask[k] == 0) & (mask_o == 255)).sum())
+            stats["unmasked_px"] += px; stats["unmasked_frames"] += int(px > 0)
+        rows_o = trk.track_image(left, right, t, mask=mask_o, mode=2, erode_k=morph)
+        if static_bg and len(rows_o):          # background features that sit on (unmasked) object pixels
+            u, v = np.rint(rows_o["left"][:, 3]).astype(int).clip(0, w - 1), np.rint(rows_o["left"][:, 4]).astype(int).clip(0, h - 1)
+            stats["bg_rows_on_objects"] += int((seq.inv_mask[k][v, u] == 0).sum())
         oin.set_disparity(seq.disp_host(k), seq.baseline)          # the extra points: DetectExtraPoints + ProcessExtraPoints from the same disparity map on both sides
         io, fo, po = oin.track(left, right, t, seq.dets[k], seq.boxes3d[k] if use_det3d else None, dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
         rows_equal(pipe.rows, rows_o, f"frame {k} background")
@@ -54,6 +65,9 @@ def run(oracle, w, h, frames, max_cnt, min_dist, iters, use_det3d=1, morph=0, dr
         stats["obj_rows"] += len(fo); stats["objs"].update(int(i) for i in io["id"])
         rc, so = est.process_dynamic(rows_o, t, io, fo, po)
         assert rc == 0
+        if static_bg:
+            snaps = (snaps + [(k, est.static_instances())])[-4:]
+            assert np.array_equal(snaps[-1][1], pipe.est.static_instances()), f"frame {k}: static report {snaps[-1][1]} vs {pipe.est.static_instances()}"
         assert (sd.frame, sd.nonlinear, sd.margin_old, sd.n_landmarks, sd.n_long) == (so.frame, so.nonlinear, so.margin_old, so.n_landmarks, so.n_long), f"frame {k}"
         assert iterations_agree(sd, so), f"frame {k}: iterations {sd.iterations} vs {so.iterations}, costs {sd.initial_cost} vs {so.initial_cost}"
         stats["iter_mismatch"] += int(sd.iterations != so.iterations)
@@ -99,6 +113,19 @@ def test_dynamic_pipeline_bench_workload_1280(oracle):
     assert stats["obj_rows"] > 500 and stats["solved"] > 3, stats
     b = bars(stats)
     assert stats["max_dp"] < b[0] and stats["obj_p"] < max(b[1], 5e-5) and stats["obj_q"] < max(b[2], 5e-6), stats      # (round 2: one window solve of this run ended an iteration apart: ego 6e-6 m, objects follow)
+
+
+def test_static_instances_leave_the_merged_mask(oracle):
+    """para::is_static_inst_as_background (vio_parameters.h:86: the reference's DEFAULT): FeatureTrack takes the pixels of the instances the estimator reported static out of
+    the merged mask before TrackSemanticImage (system/main.cpp:194,217-245; InstanceManager::SetOutputInstInfo, estimator_insts.cpp:967-990 behind PushBack).  The scene's
+    slow boxes are reported static for a while; their pixels are unmasked with the runner's deterministic two-frame lag, the background tracker then picks features on them.
+    dv_est_get_static_instances + dv_track_unmask_static (a kernel on the tracking stream) against the oracle's report + a host-side unmask: reports identical every frame,
+    background and object rows bit-identical, the usual state bars."""
+    stats, ate = run(oracle, 640, 360, 44, 150, 20, 8, static_bg=True)
+    assert stats["unmasked_frames"] >= 8 and stats["unmasked_px"] > 50000 and stats["bg_rows_on_objects"] > 20, stats
+    b = bars(stats)
+    assert stats["max_dp"] < b[0] and stats["obj_p"] < b[1] and stats["obj_q"] < b[2], stats
+    assert stats["iter_mismatch"] <= 2, stats
 
 
 def test_dynamic_pipeline_without_det3d(oracle):

@@ -204,7 +204,8 @@ def test_node_viode_dynamic_mode_from_files_equals_the_python_pipeline_and_the_o
     got = open(tmp_path / "city_day_3_high_VIO_dynamic_PointOnly_Odometry.txt").read().splitlines()
     # ---- the same through the Python dynamic pipeline (ctypes on the same C ABI), every 2nd pair to the back end ----
     ekw = dict(keyframe_parallax=10.0, g_norm=9.81007, instance_init_min_num=4)
-    pipe = DynamicPipeline(seq, max_cnt=150, min_dist=20, max_iters=8, use_det3d=0, static_inst_threshold=10.0, mask_morphology_size=5, extra_from_disparity=False, ba_stride=2, est_kw=ekw)
+    pipe = DynamicPipeline(seq, max_cnt=150, min_dist=20, max_iters=8, use_det3d=0, static_inst_threshold=10.0, mask_morphology_size=5, extra_from_disparity=False, ba_stride=2, est_kw=ekw,
+                           static_as_background=True)          # (the YAML does not switch it off: the reference's default)
     want = []
     for k in range(frames):
         pipe.step()
@@ -222,13 +223,15 @@ def test_node_viode_dynamic_mode_from_files_equals_the_python_pipeline_and_the_o
     oin = oracle.insts(trk, 50, 5, 0)
     est = oracle.estimator(use_imu=1, stereo=1, max_iters=8, ric=seq.rig["est_ric"], tic=seq.rig["est_tic"], dynamic=1, use_det3d=0, static_inst_threshold=10.0, instance_init_min_num=4,
                            keyframe_parallax=10.0, g_norm=9.81007, **seq.noise)
-    k_imu, o_traj = 0, []
+    k_imu, o_traj, snaps = 0, [], []
     for k in range(frames):
         t = seq.times[k]
         left, right = seq.host_frame(k)
         _, inv, kimg, bx = oracle.viode_mask(seq.seg0[k], seq.dyn_keys)
         assert np.array_equal(inv, seq.inv_mask[k])
         dets = viode.detections(kimg, bx, seq.dyn_keys)
+        best = [sn for sn in snaps if sn[0] <= k - 2]
+        inv = viode.unmask_static(inv, dets, best[-1][1] if best else [])          # FeatureTrack, system/main.cpp:217-245
         rows = trk.track_image(left, right, t, mask=inv, mode=2, erode_k=5)
         oin.set_right_keys(oracle.viode_mask(seq.seg1[k], seq.dyn_keys)[2])
         io, fo, po = oin.track(left, right, t, dets, None, dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
@@ -238,6 +241,7 @@ def test_node_viode_dynamic_mode_from_files_equals_the_python_pipeline_and_the_o
             est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
         rc, so = est.process_dynamic(rows, t, io, fo, po)
         assert rc == 0
+        snaps = (snaps + [(k, est.static_instances())])[-4:]
         if so.nonlinear:
             o_traj.append(est.window()[10, :3].copy())
     o_traj = np.array(o_traj)

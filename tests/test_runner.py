@@ -141,6 +141,37 @@ def test_runner_shared_front_end_launches_leave_the_same_bits():
             p.ctx.close()
 
 
+@pytest.mark.parametrize("tracker_thread,calls,stride", [(1, (43,), 1), (0, (43,), 1), (1, (9, 1, 20, 13), 1), (1, (43,), 2), (0, (20, 23), 2)])
+def test_runner_static_feedback_and_frame_stride_equal_the_python_pipeline(tracker_thread, calls, stride):
+    """the T3 -> T2 feedback of para::is_static_inst_as_background (dv_seq_dynamic::static_as_background: the estimator's static report of the newest back-end frame <= f - 2
+    unmasks frame f's static instances, system/main.cpp:194,217-245) and the every-2nd-frame flow of a dynamic sequence (dv_seq_input::ba_stride 2, system/main.cpp:300-312)
+    on the C++ runner — tracker thread beside the estimator loop or the one-thread loop, one call or several — leave exactly what the Python pipeline leaves."""
+    from dynamic_vins_amd.backend import Runner
+    from dynamic_vins_amd.pipeline import DynamicPipeline, DynamicSequence
+    w, h, frames = 640, 360, 44
+    cam = sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    seq = DynamicSequence(w, h, cam, frames, rate=20.0)          # default boxes: two of them are reported static for a stretch of the sequence
+    kw = dict(max_cnt=150, min_dist=20, max_iters=8, use_det3d=1, static_as_background=True, ba_stride=stride)
+    a, b = DynamicPipeline(seq, **kw), DynamicPipeline(seq, **kw)
+    runner = Runner([a], group_size=0, threads=1)
+    runner.set("tracker_thread", tracker_thread)
+    assert sum(calls) == frames - 1
+    for n in calls:
+        runner.run(n)
+    reports = 0
+    for _ in range(frames - 1):
+        b.step()
+        reports += int(len(b.static_snaps) > 0 and len(b.static_snaps[-1][1]) > 0)
+    st, poses, iters, fr = runner.get(0)
+    assert np.array_equal(np.ctypeslib.as_array(st.window), b.est.window())
+    want = np.array(b.poses)
+    assert len(poses) == len(want) and np.array_equal(poses[:, 1:], want)
+    Ia, _ = a.est.instances(); Ib, _ = b.est.instances()
+    assert Ia.tobytes() == Ib.tobytes()
+    assert reports >= (8 if stride == 1 else 3), reports          # the feedback really acted
+    runner.close(); a.ctx.close(); b.ctx.close()
+
+
 @pytest.mark.parametrize("tracker_thread,calls", [(1, (29,)), (0, (29,)), (1, (7, 1, 13, 8))])
 def test_runner_dynamic_mode_equals_the_python_dynamic_pipeline(tracker_thread, calls):
     """tracker_thread 1 (default): the reference's T2 / T3 — a tracker thread filling a ring of collected frames beside the estimator loop (system/main.cpp:178-330,

@@ -535,6 +535,16 @@ public:
     void SetDisparity(const float* disp, int stride_bytes, double baseline, bool device = false) {
         detail::check(ctx_, dv_inst_set_disparity(ctx_, disp, stride_bytes, device ? DV_MEM_DEVICE : DV_MEM_HOST, baseline), "SetDisparity");
     }
+    // cfg::dataset == kViode: the keys of SemanticImage::seg1 (VIODE::PixelToKey per pixel, dv_viode_mask's key image) of the frame the next InstsTrack processes —
+    // TrackRightByPad keeps a right-image point only where seg1 carries the object's key (front_end/instance_feature.cpp:263-268)
+    void SetRightKeys(const uint32_t* key_image, int stride_bytes = 0, bool device = false) {
+        detail::check(ctx_, dv_inst_set_right_keys(ctx_, key_image, stride_bytes, device ? DV_MEM_DEVICE : DV_MEM_HOST), "SetRightKeys");
+    }
+    // SetEstimatedInstancesInfo(estimator->im.GetOutputInstInfo()) + the unmasking of FeatureTrack (system/main.cpp:194,217-245; para::is_static_inst_as_background):
+    // call BEFORE the frame's TrackSemanticImage with the frame's detections and Estimator::StaticInstances() — the pixels of the static ones leave the merged mask
+    void UnmaskStaticInstances(const std::vector<dv_inst_det>& dets, const std::vector<uint32_t>& static_ids) {
+        detail::check(ctx_, dv_track_unmask_static(ctx_, dets.empty() ? nullptr : dets.data(), (int)dets.size(), static_ids.empty() ? nullptr : static_ids.data(), (int)static_ids.size()), "UnmaskStaticInstances");
+    }
     void InstsTrack(double time, const std::vector<dv_inst_det>& dets, const std::vector<dv_box3d>& boxes3d = {}) {
         detail::check(ctx_, dv_inst_track_enqueue(ctx_, time, dets.empty() ? nullptr : dets.data(), (int)dets.size(), boxes3d.empty() ? nullptr : boxes3d.data(), (int)boxes3d.size()), "InstsTrack");
         pending_ = true;
@@ -645,6 +655,13 @@ public:
     std::vector<dv_inst_state> Instances() {
         std::vector<dv_inst_state> v(64); int n = 0;
         detail::check(ctx_, dv_est_get_instances(ctx_, v.data(), (int)v.size(), &n, nullptr), "Instances");
+        v.resize(n); return v;
+    }
+    // estimator->im.GetOutputInstInfo() as FeatureTrack uses it (system/main.cpp:194,217-245): the ids of the instances reported static by the last dynamic frame
+    std::vector<uint32_t> StaticInstances() {
+        std::lock_guard<std::mutex> lk(process_mutex_);
+        std::vector<uint32_t> v(256); int n = 0;
+        detail::check(ctx_, dv_est_get_static_instances(ctx_, v.data(), (int)v.size(), &n), "StaticInstances");
         v.resize(n); return v;
     }
     // Estimator::ChangeSensorType (estimator.cpp:697-726)

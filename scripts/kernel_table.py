@@ -25,7 +25,7 @@ for name, title in (("pmc_traffic", "default line"), ("pmc_traffic_batched", "32
     print("| kernel | fetch MB | write MB | traffic MB | algorithmic MB | ratio |"); print("|---|---|---|---|---|---|")
     w = j.get("windows_per_launch", 1)
     for k, v in sorted(j["kernels"].items(), key=lambda kv: -kv[1]["traffic_bytes"]):
-        base = k.replace("_batch_kernel", "_kernel")
+        base = k.replace("_batch_occ_kernel", "_kernel").replace("_batch_lm_kernel", "_kernel<true>").replace("_batch_kernel", "_kernel")      # (round 6: be_reduce_batch_occ_kernel, be_eval_batch_lm_kernel<8>)
         alg = next((a for n, a in ALG.items() if base.startswith(n)), None)
         alg = None if alg is None else alg * (w if "_batch" in k else 1)
         print("| `%s` | %.2f | %.2f | %.2f | %s | %s |" % (k, v["fetch_bytes_x2"] / 1e6, v["write_bytes"] / 1e6, v["traffic_bytes"] / 1e6, "–" if alg is None else "%.1f" % alg, "–" if alg is None else "%.1f ×" % (v["traffic_bytes"] / 1e6 / alg)))

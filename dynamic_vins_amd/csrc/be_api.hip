@@ -703,6 +703,10 @@ int be_batch_index(dv_batch* B) { return B->index; }
 // needs a whole CU — 157 KB of LDS — and otherwise waits until one drains of the wide grids' workgroups); every group stream and front-end stream gets the complement.
 // CU mask bit i = CU i / 8 of XCD i % 8 (scripts/dbg/cumask_probe.hip).
 static int dv_solve_cus() { static int k = -1; if (k < 0) { const char* e = std::getenv("DVINS_SOLVE_CUS"); k = e ? std::atoi(e) : 0; if (k < 0 || k > 16) k = 0; } return k; }
+// CAVEAT on the two experiments below: hipExtStreamCreateWithCUMask has no flags argument — its streams are default-flag (blocking) streams that synchronise
+// implicitly with the NULL stream, while every other stream of the library is hipStreamNonBlocking; PyTorch's default stream IS the NULL stream.  The "measured slower" of
+// DESIGN_HISTORY (round 5) therefore includes whatever that implicit ordering cost in a process that also renders on torch's default stream; CU partitioning is recorded as
+// "slower in bench.py", not as rejected in general.
 hipError_t dv_solve_stream_create(hipStream_t* s) {
     const int k = dv_solve_cus();
     if (!k) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);

@@ -141,6 +141,29 @@ def test_runner_shared_front_end_launches_leave_the_same_bits():
             p.ctx.close()
 
 
+def test_pinned_host_frames_read_in_place_give_the_same_bits():
+    """DV_MEM_PINNED (dv_seq_input::mem): caller-pinned host frames are read IN PLACE by the pyramid kernel over PCIe — no staging copy, no copy engine.  The runner fed pinned
+    frames, pageable-style DV_MEM_HOST frames (hipMemcpy2DAsync) and HBM-resident frames must leave the same rows and states, bit for bit."""
+    from dynamic_vins_amd.backend import Runner
+    from dynamic_vins_amd.pipeline import Pipeline, SyntheticSequence
+    w, h, frames = 752, 480, 26
+    cam = sim.scaled_cam(sim.ZED, w, h, 1280, 720)
+    seq = SyntheticSequence(w, h, cam, frames, rate=20.0)
+    outs = []
+    for hf in (False, True, "engine"):
+        p = Pipeline(seq, max_cnt=150, min_dist=30, max_iters=8, use_imu=1)
+        r = Runner([p], host_frames=hf)
+        r.run(frames - 1)
+        st, poses, iters, fr = r.get(0)
+        outs.append((np.ctypeslib.as_array(st.window).copy(), poses.copy(), r.frames(0).copy(), r.row_log(0).copy() if hasattr(r, "row_log") else None))
+        r.close(); p.ctx.close()
+    for o in outs[1:]:
+        assert np.array_equal(o[0], outs[0][0]) and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+        if o[3] is not None:
+            assert np.array_equal(o[3], outs[0][3])
+    assert len(outs[0][1]) >= frames - 13
+
+
 @pytest.mark.parametrize("tracker_thread,calls,stride", [(1, (43,), 1), (0, (43,), 1), (1, (9, 1, 20, 13), 1), (1, (43,), 2), (0, (20, 23), 2)])
 def test_runner_static_feedback_and_frame_stride_equal_the_python_pipeline(tracker_thread, calls, stride):
     """the T3 -> T2 feedback of para::is_static_inst_as_background (dv_seq_dynamic::static_as_background: the estimator's static report of the newest back-end frame <= f - 2

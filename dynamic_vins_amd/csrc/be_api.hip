@@ -79,6 +79,11 @@ int be_prepare(dv_ctx* ctx, bool dynamic) {
     if (!w.rej_pinned) DV_CHECK(hipHostMalloc((void**)&w.rej_pinned, BE_MAX_LM, hipHostMallocDefault));
     if (be_eval_prepare() || be_solve_prepare() || be_marg_prepare() || dv_copy_prepare()) DV_FAIL("be_prepare: cannot load the back end's kernels");
     if (dynamic && be_obj_solve_prepare(ctx, ctx->obj_buf, ctx->obj_pend)) return -1;
+    // the scratch memory of the queues the back end launches on (see dv_warm_stream), then everything above has happened before the first frame
+    if (dv_warm_stream(ctx->be_stream) || (w.c0_stream && dv_warm_stream(w.c0_stream)) || (dynamic && ctx->obj_stream && dv_warm_stream(ctx->obj_stream))) DV_FAIL("be_prepare: warm-up launch failed");
+    DV_CHECK(hipStreamSynchronize(ctx->be_stream));
+    if (w.c0_stream) DV_CHECK(hipStreamSynchronize(w.c0_stream));
+    if (dynamic && ctx->obj_stream) DV_CHECK(hipStreamSynchronize(ctx->obj_stream));
     return 0;
 }
 

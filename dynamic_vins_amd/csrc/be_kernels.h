@@ -221,6 +221,7 @@ __device__ __forceinline__ void be_accept_body(const BeSolveArgs& a) {
 #define BE_EVAL_CAND_FULL 2 // full evaluation at cand into set cur ^ 1 + costs (runs if pending)
 void be_launch_eval(const BeEvalArgs& a, int mode, hipStream_t s);
 int  be_launch_marg(const BeMargArgs& a, hipStream_t s);
+int  dv_warm_stream(hipStream_t s);      // copy.hip: one dispatch with ~150 B of scratch per lane (the queue's scratch memory is allocated at create time, not at the first window solve)
 int  be_eval_prepare(); int be_solve_prepare(); int be_marg_prepare(); int dv_copy_prepare();      // load the code objects / set the LDS attributes at create time (be_prepare)
 int  be_launch_marg_c0(const BeMargArgs& a, hipStream_t s);      // the c0 = b'^T A'^+ b' part alone (BeMargArgs::c0_mode is set to 2)
 int  be_marg_chunks(int nlm);      // workgroups of be_marg_lm for nlm landmarks

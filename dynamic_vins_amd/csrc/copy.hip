@@ -62,3 +62,20 @@ __global__ __launch_bounds__(256) void dv_unmask_kernel(uint8_t* __restrict__ in
 void dv_launch_unmask(uint8_t* inv_mask, int pitch, int W, int H, int x0, int y0, int w, int h, const uint8_t* roi_mask, hipStream_t s) {
     if (w > 0 && h > 0) hipLaunchKernelGGL(dv_unmask_kernel, dim3((w + 255) / 256, h), dim3(256), 0, s, inv_mask, pitch, W, H, x0, y0, w, h, roi_mask);
 }
+
+// A queue's first dispatch of a kernel that needs scratch (private-segment) memory makes the runtime allocate that memory for the queue — a device allocation plus a queue
+// reconfiguration, 1 - 2 ms when the device is busy or its memory is held by other processes — and a later kernel with a LARGER per-lane need repeats it.  be_solve (28 B per
+// lane), the gauge kernels (80 B) and the batched solve (132 B) would pay it in the middle of a sequence: at the first window solve (seen as a 3.7 ms frame from a cold process
+// beside a busy session, tests/test_frame_gaps.py).  One trivial kernel with ~150 B per lane per stream at create time pays it there.
+__global__ void dv_scratch_warm_kernel(int* out, int n) {
+    int a[36];          // 144 B per lane (+ what the compiler adds): at least what any kernel of the per-frame path needs (batched solve 132 B); NOT much more — the runtime treats very
+                        // large scratch requests as use-once and frees them behind the dispatch
+    for (int i = 0; i < 36; ++i) a[i] = i * n + (int)threadIdx.x;
+    int acc = 0;
+    for (int i = 0; i < 36; ++i) acc += a[(i * 7 + n + (int)threadIdx.x) % 36];      // dynamic indexing keeps the array in scratch
+    if (n == -12345) *out = acc;
+}
+int dv_warm_stream(hipStream_t s) {
+    hipLaunchKernelGGL(dv_scratch_warm_kernel, dim3(1), dim3(64), 0, s, (int*)nullptr, 3);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}

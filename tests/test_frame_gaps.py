@@ -39,5 +39,6 @@ def test_no_long_frame_in_a_cold_dynamic_sequence(cut):
         if r["max_after_frame_2_ms"] < 3.0 and r["p95_ms"] < 2.0:
             break
     best = min(runs, key=lambda q: q["max_after_frame_2_ms"])
-    assert best["max_after_frame_2_ms"] < 3.0, [q["gaps_ms"] for q in runs]
-    assert best["p95_ms"] < 2.0, [q["gaps_ms"] for q in runs]
+    long_frames = [[(i, g) for i, g in enumerate(q["gaps_ms"]) if g is not None and g > 1.6] for q in runs]
+    assert best["max_after_frame_2_ms"] < 3.0, long_frames
+    assert best["p95_ms"] < 2.0, long_frames

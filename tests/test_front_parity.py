@@ -324,6 +324,43 @@ def test_error_behaviour(ctx):
         ctx.track_stereo(_img(100, 100, 1), None, 0.0, w=100, h=100)   # size mismatch (reference: std::terminate)
 
 
+def test_error_behaviour_of_the_round6_entries(gpu_ctx_factory):
+    """every new entry point refuses what it cannot do and leaves the context usable: an unknown memory kind, the static-instance unmasking without a mask / behind the frame's
+    enqueue / with a rectangle outside the image, a key image without an object tracker or with a bad stride, the GPU detector's argument checks"""
+    import ctypes as C
+    from dynamic_vins_amd import DvinsError
+    from dynamic_vins_amd.frontend import DV_MODE_SEMANTIC
+    w, h = 160, 120
+    ctx = gpu_ctx_factory(width=w, height=h, max_cnt=40, min_dist=10, cam0=_cam(ZED), cam1=_cam(ZED))
+    img = _img(h, w, 3)
+    with pytest.raises(DvinsError, match="memory kind"):
+        ctx.track_stereo(img, img, 0.0, None, 0, 7)
+    with pytest.raises(DvinsError):
+        ctx.gftt(img, 10, 0.0, 5, rule="cuda")                    # qualityLevel must be > 0 (the CUDA detector asserts the same)
+    with pytest.raises(DvinsError):
+        ctx.inst_set_right_keys(np.zeros((h, w), np.uint32))      # no object tracker configured
+    det = dict(track_id=5, rect=(10, 10, 20, 20), mask=np.full((20, 20), 255, np.uint8))
+    ctx.track_unmask_static([det], [5])
+    with pytest.raises(DvinsError, match="no mask"):
+        ctx.track_stereo(img, img, 0.0, None, DV_MODE_SEMANTIC)   # the unmasking was asked for a frame that carries no mask
+    bad = dict(track_id=5, rect=(150, 110, 20, 20), mask=np.full((20, 20), 255, np.uint8))
+    with pytest.raises(DvinsError, match="rectangle"):
+        ctx.track_unmask_static([bad], [5])
+    # an id that is not static, or no ids at all: nothing is staged, the frame runs as usual; and a staged unmask really clears the mask for the tracker
+    mask = np.full((h, w), 255, np.uint8); mask[10:30, 10:30] = 0
+    ctx.track_unmask_static([det], [6]); a = ctx.track_stereo(img, img, 0.0, mask, DV_MODE_SEMANTIC)
+    ctx.reset()
+    ctx.track_unmask_static([det], [5]); b = ctx.track_stereo(img, img, 0.0, mask, DV_MODE_SEMANTIC)
+    ctx.reset()
+    c = ctx.track_stereo(img, img, 0.0, np.full((h, w), 255, np.uint8), DV_MODE_SEMANTIC)
+    inside = lambda r: int(((r["left"][:, 3] >= 10) & (r["left"][:, 3] < 30) & (r["left"][:, 4] >= 10) & (r["left"][:, 4] < 30)).sum())
+    assert inside(a) == 0 and b.tobytes() == c.tobytes()          # unmasked == no object at all
+    ctx.inst_config(20, 5, 0)
+    with pytest.raises(DvinsError, match="stride"):
+        ctx._check(ctx.lib.dv_inst_set_right_keys(ctx.h, np.zeros((h, w), np.uint32).ctypes.data, 6, 0))
+    ctx.inst_set_right_keys(None)
+
+
 def test_instance_tracker_bit_exact(gpu_ctx_factory, oracle):
     """one object instance through InstsFeatManager::InstsTrack (row F10): a textured box drifting and growing over a
     moving background; ROI crops of changing size, eroded instance mask, box offset, right-image tracking"""

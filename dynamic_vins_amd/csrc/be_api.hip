@@ -427,6 +427,18 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     if (be_ensure(ctx, P->nfac)) return -1;
     BeWork& w = ctx->be;
     hipStream_t s = ctx->be_stream;
+    // ---- the bulk of the upload FIRST: landmark and factor tables (nine tenths of the bytes) are complete when the call begins (the estimator builds the factors in the pinned
+    // mirror itself), so their staging copy — 15 of the 19 us the whole upload takes over PCIe, on the path between two frames' solves — runs while the host still works out the
+    // column layout, the IMU records and the marginalization plan below; the head of the region (control block, states, IMU, prior header, index tables) follows at the end.
+    // Measured (profiles/r06_experiments/upload_split_ab.json, 100-step blocks interleaved on one box): +0.1 - 0.7 %, i.e. noise level — the BA stream is still busy with the
+    // previous frame's marginalization when the early copy arrives; kept because it cannot lose ----
+    static const bool split_upload = [] { const char* e = std::getenv("DVINS_UPLOAD_SPLIT"); return !(e && e[0] == '0'); }();      // 0: one copy at the end (rounds 1 - 5; A/B)
+    {
+        uint8_t* hp0 = (uint8_t*)w.pinned;
+        if (P->nlm) std::memcpy(hp0 + w.up_lm, P->landmarks, sizeof(BeLm) * (size_t)P->nlm);
+        if (P->nfac && (const void*)P->factors != (const void*)(hp0 + w.up_fac)) std::memcpy(hp0 + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac);      // the estimator builds the table in place
+        if (split_upload) DV_CHECK(dv_copy_async((uint8_t*)w.block.p + w.up_lm, hp0 + w.up_lm, (w.up_fac - w.up_lm) + sizeof(BeFactor) * (size_t)P->nfac, s));
+    }
     // ---- column layout of the reduced system ----
     BeDims d{};
     d.nframes = P->nframes; d.nlm = P->nlm; d.nfac = P->nfac; d.nimu = P->nimu; d.use_imu = P->use_imu; d.plane_kind = P->plane_kind;
@@ -498,9 +510,7 @@ static int be_begin_impl(dv_ctx* ctx, dv_ba_problem* P, BeFused* fused, bool eva
     std::memcpy(hp + w.up_prior, &ph, sizeof(ph));
     std::memcpy(hp + w.up_idx, idx.data(), 4 * idx.size());
     if (do_marg && !pl.empty) std::memcpy(hp + w.up_mt, pl.tab, sizeof(pl.tab));
-    if (P->nlm) std::memcpy(hp + w.up_lm, P->landmarks, sizeof(BeLm) * (size_t)P->nlm);
-    if (P->nfac && (const void*)P->factors != (const void*)(hp + w.up_fac)) std::memcpy(hp + w.up_fac, P->factors, sizeof(BeFactor) * (size_t)P->nfac);      // the estimator builds the table in place
-    DV_CHECK(dv_copy_async(w.block.p, hp, w.up_fac + sizeof(BeFactor) * (size_t)P->nfac, s));      // (a kernel reading the pinned mirror: copy.hip)
+    DV_CHECK(dv_copy_async(w.block.p, hp, split_upload ? w.up_lm : w.up_fac + sizeof(BeFactor) * (size_t)P->nfac, s));      // the head of the upload region (the landmark / factor tables went first, see the top); kernels reading the pinned mirror: copy.hip
     if (w.c0_pending) { DV_CHECK(hipStreamWaitEvent(s, w.ev_c0, 0)); w.c0_pending = false; }      // the previous frame's c0 (side stream) and its health scalars: before anything reads the prior's constant
     if (has_prior && !prior_on_device) {               // a prior handed over in host memory (the estimator's stays in HBM)
         if (!P->prior_A || !P->prior_b) DV_FAIL("dv_ba_solve: prior without A / b");

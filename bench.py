@@ -268,7 +268,8 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
     def make_pipe():
         if args.mode == "dynamic":
             return DynamicPipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"], mask_morphology_size=args.erode,
-                                   extra_from_disparity=os.environ.get("BENCH_DYN_PASSTHROUGH", "0") != "1")      # (debug A/B: 1 = the detections' own points are handed through, no extra-point kernels)
+                                   extra_from_disparity=os.environ.get("BENCH_DYN_PASSTHROUGH", "0") != "1",
+                                   static_as_background=os.environ.get("BENCH_DYN_STATIC_BG", "1") == "1")      # para::is_static_inst_as_background: the reference's default is true (vio_parameters.h:86)      # (debug A/B: 1 = the detections' own points are handed through, no extra-point kernels)
         return Pipeline(seq, max_cnt=cfg["max_cnt"], min_dist=cfg["min_dist"], max_iters=cfg["iters"], device=local_rank, use_imu=cfg["use_imu"],
                         host_frames=args.host_frames and args.host_loop != "cpp", ba_stride=stride)      # (the C++ runner pins its own host copies: backend.Runner)
 
@@ -366,7 +367,8 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
     dyn_info = None
     if args.mode == "dynamic":
         I, S = pipe.est.instances()
-        dyn_info = dict(objects_tracked=int(len(I)), objects_initialised=int(I["is_initial"].sum()) if len(I) else 0,
+        dyn_info = dict(static_inst_as_background=bool(getattr(pipe, "static_as_background", False)), objects_static_at_the_end=int(I["is_static"].sum()) if len(I) else 0,
+                        objects_tracked=int(len(I)), objects_initialised=int(I["is_initial"].sum()) if len(I) else 0,
                         object_features_per_frame=int(len(pipe.ifeats)), object_solve_iterations=int(S[0]),
                         over_the_run=dict(frames=pipe.stat["frames"], frames_with_objects=pipe.stat["frames_with_objects"],
                                           detections_per_frame=round(pipe.stat["object_detections"] / max(pipe.stat["frames"], 1), 2), min_detections_in_a_frame=int(pipe.stat["min_detections"]),
@@ -451,6 +453,8 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 est = o.estimator(**kw)
             nf = min((frames_wanted + 12) * stride, n_frames)
             host = [seq.host_frame(k) for k in range(nf)]
+            static_bg, snaps = args.mode == "dynamic" and os.environ.get("BENCH_DYN_STATIC_BG", "1") == "1", []
+            from dynamic_vins_amd import _abi, viode
             k_imu, t_fe, t_be, counted, poses, ptimes = 0, 0.0, 0.0, 0, [], []
             for k in range(nf):
                 t = seq.times[k]
@@ -458,7 +462,11 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                     est.input_imu(seq.imu_t[k_imu], seq.imu_a[k_imu], seq.imu_g[k_imu]); k_imu += 1
                 a = time.perf_counter()
                 if args.mode == "dynamic":
-                    rows = trk.track_image(host[k][0], host[k][1], t, mask=seq.inv_mask[k], mode=2, erode_k=args.erode)
+                    mask_k = seq.inv_mask[k]
+                    if static_bg:          # FeatureTrack, system/main.cpp:217-245: the estimator's static report of the newest back-end frame <= k - 2 (choice T1)
+                        best = [sn for sn in snaps if sn[0] <= k - _abi.DV_STATIC_REPORT_LAG]
+                        mask_k = viode.unmask_static(mask_k, seq.dets[k], best[-1][1] if best else [])
+                    rows = trk.track_image(host[k][0], host[k][1], t, mask=mask_k, mode=2, erode_k=args.erode)
                     oin.set_disparity(seq.disp_host(k), seq.baseline)
                     io, fo, po = oin.track(host[k][0], host[k][1], t, seq.dets[k], seq.boxes3d[k], dynsim.INSTOBS_DTYPE, dynsim.BOX3D_DTYPE)
                 else:
@@ -468,6 +476,8 @@ def measure(args, cfg, rank, world, local_rank, want_roofline=True):
                 st = None
                 if do_ba:
                     rc, st = est.process_dynamic(rows, t, io, fo, po) if args.mode == "dynamic" else est.process(rows, t)
+                    if static_bg:
+                        snaps = (snaps + [(k, est.static_instances())])[-4:]
                 c = time.perf_counter()
                 if st is not None and st.nonlinear:
                     poses.append(est.window()[10, :3].copy()); ptimes.append(t)

@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DVINS_HIP_LIB") or os.path.join(_HERE, "lib", "libdvins_hip.so")
 
+import os as _os
+DV_STATIC_REPORT_LAG = int(_os.environ.get("DVINS_STATIC_LAG", "2"))      # include/dvins.h (choice T1); the environment override is for experiments and must match the library's
 DV_MEM_HOST, DV_MEM_DEVICE, DV_MEM_PINNED = 0, 1, 2      # PINNED: host memory pinned + mapped by the caller, read in place by the kernels
 DV_FMT_BGR = 0x100
 DV_MODE_RAW, DV_MODE_NAIVE, DV_MODE_SEMANTIC = 0, 1, 2

@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -24,6 +25,8 @@
 #include "dv_ctx.h"
 
 namespace {
+// choice T1: DV_STATIC_REPORT_LAG (DVINS_STATIC_LAG in the environment: experiments only — the Python pipeline and the parity harness read the same variable)
+int static_lag() { static const int v = [] { const char* e = std::getenv("DVINS_STATIC_LAG"); const int k = e ? std::atoi(e) : DV_STATIC_REPORT_LAG; return k >= 1 && k <= 3 ? k : DV_STATIC_REPORT_LAG; }(); return v; }
 struct RSeq {
     dv_ctx* ctx = nullptr; dv_seq_input in{};
     int next = 0, k_imu = 0, w = 0, h = 0, stride = 0;
@@ -129,7 +132,7 @@ int dyn_enqueue(dv_runner* R, RSeq& s, int k) {
     const int mode = d.mode ? d.mode : DV_MODE_SEMANTIC;
     if (s.static_unmask && d.inv_mask && d.dets && d.n_dets && d.n_dets[k] > 0) {
         std::vector<uint32_t> ids;
-        { std::lock_guard<std::mutex> lk(*s.ring_mu); int best = -1; for (const RSeq::StaticSnap& sn : s.snaps) if (sn.frame >= 0 && sn.frame <= k - 2 && sn.frame > best) { best = sn.frame; ids = sn.ids; } }
+        { std::lock_guard<std::mutex> lk(*s.ring_mu); int best = -1; for (const RSeq::StaticSnap& sn : s.snaps) if (sn.frame >= 0 && sn.frame <= k - static_lag() && sn.frame > best) { best = sn.frame; ids = sn.ids; } }
         if (dv_track_unmask_static(s.ctx, d.dets[k], d.n_dets[k], ids.data(), (int)ids.size())) return fail(R, s, "dv_track_unmask_static");
     }
     // (frames and mask share `mem` in dv_track_stereo_enqueue: a device-resident sequence keeps both in HBM)
@@ -188,7 +191,7 @@ void dyn_tracker_thread(dv_runner* R, RSeq& s) {
             std::unique_lock<std::mutex> lk(*s.ring_mu);
             s.track_busy = false; s.ring_cv->notify_all();
             s.ring_cv->wait(lk, [&] { return s.track_stop || (!s.ring_failed && s.tracked_next <= s.track_last && s.ring_count < RSeq::RING &&
-                                                                  (!s.static_unmask || s.tracked_next < 2 || s.est_passed >= s.tracked_next - 2)); });      // (the static-instance snapshot of frame f - 2 must exist)
+                                                                  (!s.static_unmask || s.tracked_next < static_lag() || s.est_passed >= s.tracked_next - static_lag())); });      // (the static-instance snapshot of frame f - lag must exist)
             if (s.track_stop) return;
             s.track_busy = true;
             f = s.tracked_next; slot = (s.ring_pos + s.ring_count) % RSeq::RING;

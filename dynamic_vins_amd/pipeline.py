@@ -236,7 +236,8 @@ class DynamicPipeline(Pipeline):
         self.stat = dict(frames=0, frames_with_objects=0, object_detections=0, object_features=0, min_detections=10 ** 9)      # what the object branch was fed over the run
 
     def static_ids_for(self, k):
-        best = [s for s in self.static_snaps if s[0] <= k - 2]
+        from ._abi import DV_STATIC_REPORT_LAG
+        best = [s for s in self.static_snaps if s[0] <= k - DV_STATIC_REPORT_LAG]
         return best[-1][1] if best else np.zeros(0, np.uint32)
 
     def _enqueue(self, k):

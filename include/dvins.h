@@ -508,6 +508,8 @@ typedef struct dv_seq_dynamic {
                                           estimator reported static leave the merged mask (dv_est_get_static_instances of the newest back-end frame <= f - 2 -> dv_track_unmask_static;
                                           system/main.cpp:194,217-245).  The reference reads that report across threads without an order; the lag of two frames is this runner's, in every layout */
 } dv_seq_dynamic;
+/* choice T1: the static-instance report applied to frame f is that of the newest back-end frame <= f - DV_STATIC_REPORT_LAG */
+#define DV_STATIC_REPORT_LAG 2
 typedef struct dv_runner dv_runner;
 /* slam_type naive of a sequence (system/main.cpp:263-265: FeatureTrack -> TrackImageNaive): per frame [n_frames] the inverse merged instance mask (0 = object pixel;
  * VIODE::SetViodeMaskSimple or the detector's SetBackgroundMask) in the frames' memory kind, tracked with `mode` = DV_MODE_NAIVE (GPU tracker's + GPU detector's rules).

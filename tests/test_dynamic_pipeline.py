@@ -5,6 +5,8 @@ on the same frames, masks, detections and IMU stream.  Bars: background rows AND
 patterns of the normalised points / velocities), object tables identical (ids, 3-D box association, extra points), estimator flags / counts identical,
 ego window within 1e-5 m, object states within the tolerances of tests/test_dynamic_parity.py."""
 import numpy as np
+
+from dynamic_vins_amd import _abi
 import pytest
 
 from tests.conftest import iterations_agree
@@ -45,7 +47,7 @@ def run(oracle, w, h, frames, max_cnt, min_dist, iters, use_det3d=1, morph=0, dr
         left, right = seq.host_frame(k)
         mask_o = seq.inv_mask[k]
         if static_bg:          # FeatureTrack (system/main.cpp:217-245) on the oracle side: the estimator's report of the newest back-end frame <= k - 2, applied on the host
-            best = [sn for sn in snaps if sn[0] <= k - 2]
+            best = [sn for sn in snaps if sn[0] <= k - _abi.DV_STATIC_REPORT_LAG]
             mask_o = viode.unmask_static(seq.inv_mask[k], seq.dets[k], best[-1][1] if best else [])
             px = int(((seq.inv_mask[k] == 0) & (mask_o == 255)).sum())
             stats["unmasked_px"] += px; stats["unmasked_frames"] += int(px > 0)

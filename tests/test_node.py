@@ -9,6 +9,8 @@ import subprocess
 import zlib
 
 import numpy as np
+
+from dynamic_vins_amd import _abi
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -230,7 +232,7 @@ def test_node_viode_dynamic_mode_from_files_equals_the_python_pipeline_and_the_o
         _, inv, kimg, bx = oracle.viode_mask(seq.seg0[k], seq.dyn_keys)
         assert np.array_equal(inv, seq.inv_mask[k])
         dets = viode.detections(kimg, bx, seq.dyn_keys)
-        best = [sn for sn in snaps if sn[0] <= k - 2]
+        best = [sn for sn in snaps if sn[0] <= k - _abi.DV_STATIC_REPORT_LAG]
         inv = viode.unmask_static(inv, dets, best[-1][1] if best else [])          # FeatureTrack, system/main.cpp:217-245
         rows = trk.track_image(left, right, t, mask=inv, mode=2, erode_k=5)
         oin.set_right_keys(oracle.viode_mask(seq.seg1[k], seq.dyn_keys)[2])

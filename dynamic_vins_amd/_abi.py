@@ -110,6 +110,8 @@ SIGNATURES = {
     "dv_inst_track_enqueue": (C.c_int, [_ctx, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "dv_inst_set_disparity": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_double]),
     "dv_inst_set_right_keys": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int]),
+    "dv_pinned_alloc": (C.c_void_p, [C.c_size_t]),
+    "dv_pinned_free": (None, [C.c_void_p]),
     "dv_track_unmask_static": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "dv_est_get_static_instances": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "dv_extra_points": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

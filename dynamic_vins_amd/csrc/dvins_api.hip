@@ -138,6 +138,13 @@ static int build_cuda_pyramids(dv_ctx* ctx, PyrSet& C0, PyrSet* C1, const DvPyr&
 
 extern "C" {
 
+void* dv_pinned_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { dv_set_error(nullptr, "dv_pinned_alloc: hipHostMalloc failed"); return nullptr; }
+    return p;
+}
+void dv_pinned_free(void* p) { if (p) (void)hipHostFree(p); }
+
 const char* dv_last_error(dv_ctx* ctx) {
     if (ctx) {      // a copy per calling thread: another thread of a dynamic sequence may be writing the ctx's string (valid until this thread's next call)
         static thread_local std::string mine;

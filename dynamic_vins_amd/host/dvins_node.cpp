@@ -131,6 +131,12 @@ Gray read_image(const std::string& path, bool keep_colour = false) {
     if (buf.size() > 1 && buf[0] == 'P') { if (keep_colour) throw std::runtime_error("dvins_node: " + path + ": segmentation images must be PNG"); return read_pgm(buf, path); }
     return read_png(buf, path, keep_colour);
 }
+struct Pinned {          // dv_pinned_alloc / dv_pinned_free (hipHostMalloc behind the C ABI: the node itself does not link the HIP runtime)
+    uint8_t* p = nullptr;
+    explicit Pinned(size_t bytes) { p = bytes ? static_cast<uint8_t*>(dv_pinned_alloc(bytes)) : nullptr; }
+    ~Pinned() { if (p) dv_pinned_free(p); }
+    Pinned(const Pinned&) = delete; Pinned& operator=(const Pinned&) = delete;
+};
 constexpr int kMinInstSize = 8;          // a VIODE instance's rectangle must be at least this many pixels on both sides to be handed to the object tracker
 std::string stem(const std::string& path) {
     std::string s = path;
@@ -202,14 +208,31 @@ int main(int argc, char** argv) {
         dv_ctx* ctx = dv_create(&cfg.front);
         if (!ctx) throw std::runtime_error(std::string("dvins_node: ") + dv_last_error(nullptr));
         if (dv_est_create(ctx, &cfg.est)) throw std::runtime_error(std::string("dvins_node: ") + dv_last_error(ctx));
+        // Everything the device reads per frame — frames, inverse masks, key images — lives in ONE pinned, device-mapped arena (dv_pinned_alloc) and is handed over as
+        // DV_MEM_PINNED: the kernels read it in place over PCIe, no staging copy and no copy engine in the per-frame path.  If the arena cannot be had (a very long sequence),
+        // the buffers stay pageable and travel as DV_MEM_HOST (hipMemcpy2DAsync per frame).
+        const int W = cfg.front.width, H = cfg.front.height;
+        const size_t px = (size_t)W * H;
+        const bool want_masks = viode, want_keys = run_dynamic;
+        const size_t arena_bytes = (size_t)n * px * (2 + (want_masks ? 1 : 0) + (want_keys ? 4 : 0));
+        Pinned arena(arena_bytes);
+        const int mem = arena.p ? DV_MEM_PINNED : DV_MEM_HOST;
+        if (!arena.p) std::fprintf(stderr, "dvins_node: %zu MB of pinned memory are not available: pageable buffers (DV_MEM_HOST)\n", arena_bytes >> 20);
         std::vector<const uint8_t*> lp(n), rp(n);
-        for (int k = 0; k < n; ++k) { lp[k] = L[k].d.data(); rp[k] = R[k].d.data(); }
+        for (int k = 0; k < n; ++k) {
+            if (arena.p) {
+                uint8_t* a = arena.p + (size_t)k * 2 * px;
+                std::memcpy(a, L[k].d.data(), px); std::memcpy(a + px, R[k].d.data(), px);
+                lp[k] = a; rp[k] = a + px; L[k].d.clear(); L[k].d.shrink_to_fit(); R[k].d.clear(); R[k].d.shrink_to_fit();
+            } else { lp[k] = L[k].d.data(); rp[k] = R[k].d.data(); }
+        }
+        uint8_t* mask_arena = arena.p ? arena.p + (size_t)n * 2 * px : nullptr;
+        uint32_t* key_arena = (arena.p && want_keys) ? reinterpret_cast<uint32_t*>(arena.p + (size_t)n * (2 + (want_masks ? 1 : 0)) * px) : nullptr;
         dv_seq_input in{};
-        in.left = lp.data(); in.right = rp.data(); in.times = times.data(); in.n_frames = n; in.mem = DV_MEM_HOST; in.stride = 0; in.ba_stride = cfg.every_frame ? 1 : 2;
+        in.left = lp.data(); in.right = rp.data(); in.times = times.data(); in.n_frames = n; in.mem = mem; in.stride = 0; in.ba_stride = cfg.every_frame ? 1 : 2;
         in.imu_t = imu_t.data(); in.imu_acc = imu_a.data(); in.imu_gyr = imu_g.data(); in.n_imu = (int)imu_t.size();
 
         // ---- VIODE: thread T1's part of the frame (ImageProcessor::Run, image_process.cpp:161-178) for every pair, before the run ----
-        const int W = cfg.front.width, H = cfg.front.height;
         std::vector<std::vector<uint8_t>> inv_mask;                       // img.inv_merge_mask per frame
         std::vector<std::vector<uint32_t>> right_keys;                    // PixelToKey of every pixel of seg1
         std::vector<std::vector<dv_inst_det>> dets; std::vector<std::vector<std::vector<uint8_t>>> det_masks;
@@ -224,10 +247,10 @@ int main(int argc, char** argv) {
             for (int k = 0; k < n; ++k) {
                 const Gray seg = read_image(s0[k], true);
                 if (seg.w != W || seg.h != H) throw std::runtime_error("dvins_node: " + s0[k] + " is not image_width x image_height of the config");
-                inv_mask[k].resize((size_t)W * H);
-                if (dv_viode_mask(ctx, seg.bgr.data(), W, H, 3 * W, keys.data(), nk, merge.data(), inv_mask[k].data(), run_dynamic ? kimg.data() : nullptr, boxes.data()))
+                uint8_t* inv_k = mask_arena ? mask_arena + (size_t)k * px : (inv_mask[k].resize(px), inv_mask[k].data());
+                if (dv_viode_mask(ctx, seg.bgr.data(), W, H, 3 * W, keys.data(), nk, merge.data(), inv_k, run_dynamic ? kimg.data() : nullptr, boxes.data()))
                     throw std::runtime_error(std::string("dvins_node: dv_viode_mask: ") + dv_last_error(ctx));
-                mask_ptr[k] = inv_mask[k].data();
+                mask_ptr[k] = inv_k;
                 if (!run_dynamic) continue;
                 // VIODE::SetViodeMaskAndRoi (viode_utils.cpp:177-218): one Box2D per key present; ascending key (the reference walks an unordered_map)
                 for (int q = 0; q < nk; ++q) {
@@ -245,11 +268,11 @@ int main(int argc, char** argv) {
                 det_ptr[k] = dets[k].empty() ? nullptr : dets[k].data(); n_dets[k] = (int)dets[k].size();
                 const Gray seg1 = read_image(s1[k], true);
                 if (seg1.w != W || seg1.h != H) throw std::runtime_error("dvins_node: " + s1[k] + " is not image_width x image_height of the config");
-                right_keys[k].resize((size_t)W * H);
-                std::vector<uint8_t> tmp_inv((size_t)W * H);
-                if (dv_viode_mask(ctx, seg1.bgr.data(), W, H, 3 * W, keys.data(), nk, merge.data(), tmp_inv.data(), right_keys[k].data(), boxes.data()))
+                uint32_t* keys_k = key_arena ? key_arena + (size_t)k * px : (right_keys[k].resize(px), right_keys[k].data());
+                std::vector<uint8_t> tmp_inv(px);
+                if (dv_viode_mask(ctx, seg1.bgr.data(), W, H, 3 * W, keys.data(), nk, merge.data(), tmp_inv.data(), keys_k, boxes.data()))
                     throw std::runtime_error(std::string("dvins_node: dv_viode_mask: ") + dv_last_error(ctx));
-                keys_ptr[k] = right_keys[k].data();
+                keys_ptr[k] = keys_k;
             }
             if (run_dynamic && dv_inst_config(ctx, cfg.max_dynamic_cnt, cfg.min_dynamic_dist, 0)) throw std::runtime_error(std::string("dvins_node: ") + dv_last_error(ctx));
         }
@@ -258,13 +281,13 @@ int main(int argc, char** argv) {
         if (!runner) throw std::runtime_error(std::string("dvins_node: ") + dv_last_error(nullptr));
         dv_seq_dynamic dyn{};
         if (run_dynamic) {
-            dyn.inv_mask = mask_ptr.data(); dyn.mask_mem = DV_MEM_HOST; dyn.mode = DV_MODE_SEMANTIC;
+            dyn.inv_mask = mask_ptr.data(); dyn.mask_mem = mem; dyn.mode = DV_MODE_SEMANTIC;
             dyn.dets = det_ptr.data(); dyn.n_dets = n_dets.data(); dyn.boxes3d = nullptr; dyn.n_boxes3d = nullptr; dyn.disp = nullptr; dyn.baseline = cfg.baseline;
-            dyn.right_keys = keys_ptr.data(); dyn.right_keys_mem = DV_MEM_HOST;
+            dyn.right_keys = keys_ptr.data(); dyn.right_keys_mem = mem;
             dyn.static_as_background = cfg.static_inst_as_background ? 1 : 0;      // (vio_parameters.h:86: on unless the YAML says static_inst_as_background: 0)
             if (dv_runner_set_dynamic(runner, 0, &dyn)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));
         } else if (run_naive) {
-            if (dv_runner_set_mask(runner, 0, mask_ptr.data(), DV_MEM_HOST, DV_MODE_NAIVE)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));
+            if (dv_runner_set_mask(runner, 0, mask_ptr.data(), mem, DV_MODE_NAIVE)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));
         }
         double wall = 0;
         if (dv_runner_run(runner, n, &wall)) throw std::runtime_error(std::string("dvins_node: ") + dv_runner_error(runner));

@@ -16,6 +16,7 @@
  */
 #ifndef DVINS_H
 #define DVINS_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -27,6 +28,9 @@ extern "C" {
  * (hipHostMalloc, or hipHostRegister with hipHostRegisterMapped).  The kernels read it over PCIe directly — no staging copy, no copy engine in the per-frame
  * path; the buffers must stay unchanged until the frame is collected, as device buffers must. */
 #define DV_MEM_PINNED 2
+/* pinned + device-mapped host memory for DV_MEM_PINNED buffers, for hosts that do not link the HIP runtime themselves (hipHostMalloc / hipHostFree); NULL on failure */
+void* dv_pinned_alloc(size_t bytes);
+void dv_pinned_free(void* p);
 /* OR into `mem` of dv_track_stereo*: gray0 / gray1 point to 8-bit BGR frames (stride in bytes, >= 3 w); they are converted with
  * cv::cvtColor's fixed-point weights straight into pyramid level 0 (SemanticImage::SetGrayImageGpu, basic/semantic_image.cpp:103-118).
  * A mask, if given, is single-channel with stride w. */

@@ -222,6 +222,8 @@ int dv_track_stereo(dv_ctx* c, const uint8_t* g0, const uint8_t* g1, int w, int 
     if (dv_track_stereo_enqueue(c, g0, g1, w, h, stride, t, mask, mode, mem)) return -1;
     return dv_track_stereo_collect(c, out, n_out);
 }
+void* dv_pinned_alloc(size_t n) { return std::malloc(n); }
+void dv_pinned_free(void* p) { std::free(p); }
 int dv_inst_config(dv_ctx* c, int, int, int) { S(c).trk_scratch++; return 0; }
 int dv_undistort_lines(dv_ctx*, const dv_cam*, const float*, int, double*) { return 0; }
 int dv_set_undistort_maps(dv_ctx* c, int, const int16_t*, const uint16_t*, int, int) { S(c).trk_scratch++; return 0; }

@@ -18,7 +18,7 @@ def header_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     src = re.sub(r"//[^\n]*", "", src)
-    names = re.findall(r"^\s*(?:const\s+char\s*\*|dv_ctx\s*\*|dv_batch\s*\*|dv_runner\s*\*|int|void)\s+(dv_[a-z0-9_]+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|dv_ctx\s*\*|dv_batch\s*\*|dv_runner\s*\*|void\s*\*|int|void)\s*(dv_[a-z0-9_]+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 

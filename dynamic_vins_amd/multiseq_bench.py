@@ -150,8 +150,9 @@ def run_cpp_runner(args, cfg, seqs, pipes, rank, world, local_rank, dev):
     n_groups = (S + gsz - 1) // gsz if gsz > 0 else S
     threads = getattr(args, "runner_threads", 0)
     teams = gsz > 1 and not bool(getattr(args, "no_teams", False))
-    if threads <= 0:          # default: TWO host threads per dv_batch group (a team splits its members' host phases; --no-teams: one thread per group)
-        threads = (2 * n_groups if teams else n_groups) if gsz > 1 else 1
+    if threads <= 0:          # default: TWO host threads per dv_batch group (a team splits its members' host phases; --no-teams: one thread per group); EIGHT for groups of 16 and more
+        # (round 6, scripts/dbg/ab_threads.sh on one box, twice: 64 sequences 9346 / 9484 with 8 threads, 9906 / 9730 with 16, 10 015 / 10 141 with 32; 16 sequences in groups of 4: no difference)
+        threads = ((8 if gsz >= 16 else 2) * n_groups if teams else n_groups) if gsz > 1 else 1
     if not teams:
         threads = min(threads, n_groups)
     args.runner_threads = threads

@@ -264,7 +264,23 @@ struct Estimator {
     std::list<LineLandmark> line_landmarks;    // FeatureManager::line_landmarks
     std::vector<dvo_line_row> pending_lines; double para_line_features[1000][4];
     oim::InstanceManager im;                   // Estimator::im (estimator.h)
-    oim::Body body() { return oim::Body{ Rs, Ps, ric, tic, headers, td, frame, para_pose }; }
+    // variant "obj_perturb" 1000 + n (sensitivity only, dvo.h): the WHOLE object branch (triangulation, initialisation, solve, outlier tests) sees body positions moved by
+    // n x 1e-7 m, a pattern keyed to the frame's time stamp so that a frame keeps its offset while the window slides — what the ego-state difference between two correct
+    // window solves (4e-7 m between the HIP path and this oracle) is worth to the objects through the closed loop pose -> landmark depths -> world points -> pose
+    V3 Ps_pert[kWin + 1]; double para_pert[kWin + 1][7];
+    oim::Body body() {
+        const int np = dvo_get_variant("obj_perturb");
+        if (np >= 1000) {
+            for (int f = 0; f <= kWin; ++f) {
+                std::memcpy(para_pert[f], para_pose[f], sizeof(para_pert[f]));
+                const double d[3] = { std::sin(37.0 * headers[f] + 0.3), std::sin(37.0 * headers[f] + 2.6), std::sin(37.0 * headers[f] + 4.9) }, a = 1e-7 * (np - 1000);
+                Ps_pert[f] = Ps[f]; Ps_pert[f].x += a * d[0]; Ps_pert[f].y += a * d[1]; Ps_pert[f].z += a * d[2];
+                for (int c = 0; c < 3; ++c) para_pert[f][c] += a * d[c];
+            }
+            return oim::Body{ Rs, Ps_pert, ric, tic, headers, td, frame, para_pert };
+        }
+        return oim::Body{ Rs, Ps, ric, tic, headers, td, frame, para_pose };
+    }
 
     explicit Estimator(const Config& c) : cfg(c) { clear(); set_parameter(); }
     void clear() {

@@ -31,7 +31,10 @@ void dvo_set_threads(int n);
  *   "radius":    0 Ceres' dogleg radius rule (quality < 0.25: x 0.5; > 0.75: max(radius, 3 |step|)) | 1 the Levenberg-style reading (> 0.75: radius x 3)
  *   "f5_cpu_rule": 0 the reference's GPU corner detector (cv::cuda::GoodFeaturesToTrackDetector restated, gftt_cuda.cpp) in TrackImageNaive | 1 cv::goodFeaturesToTrack's rule there (rounds 1-5)
  *   "gftt_cuda_fma": 0 the GPU detector's float chains contracted to fused multiply-adds (nvcc's default) | 1 no contraction
- *   "gftt_cuda_tie": 0 corners of equal response in address-descending order | 1 ascending (the library's order is the kernel schedule) */
+ *   "gftt_cuda_tie": 0 corners of equal response in address-descending order | 1 ascending (the library's order is the kernel schedule)
+ *   "obj_point_order": 0 the object solve's point blocks in the reference's order | 1 reversed (summation order only: what rounding noise is worth to the object states)
+ *   "obj_perturb": 0 < n < 1000 moves the world points the object solve reads by n x 1e-7 m (per-frame input noise); 1000 + n moves the body positions the WHOLE object branch sees by
+ *                  n x 1e-7 m, keyed to the frame's time stamp (what the ego-state difference between two correct window solves is worth to the objects: tests/tools/obj_sensitivity.py) */
 void dvo_set_variant(const char* key, int value);
 int dvo_get_variant(const char* key);
 int dvo_get_threads(void);

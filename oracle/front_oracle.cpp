@@ -41,16 +41,19 @@ static int g_threads = 1;      // dvo_set_threads: CPU-baseline timing only; res
 extern "C" void dvo_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
 extern "C" int dvo_get_threads() { return g_threads; }
 // sensitivity variants (dvo.h): process-wide switches, read by the stages they belong to
-int g_var_lk_sums = 0, g_var_box_sums = 0, g_var_radius = 0, g_var_f4_cpu = 0, g_var_f5_cpu = 0, g_var_gc_fma = 0, g_var_gc_tie = 0;      // "f4_cpu_rule" 1: naive / semantic modes track with the CPU arithmetic + the 1.0 px threshold (the substitution of rounds 1-3) instead of the GPU tracker (lk_cuda.cpp)
+int g_var_lk_sums = 0, g_var_box_sums = 0, g_var_radius = 0, g_var_f4_cpu = 0, g_var_f5_cpu = 0, g_var_gc_fma = 0, g_var_gc_tie = 0, g_var_obj_order = 0, g_var_obj_perturb = 0, g_var_obj_dump = 0;      // "f4_cpu_rule" 1: naive / semantic modes track with the CPU arithmetic + the 1.0 px threshold (the substitution of rounds 1-3) instead of the GPU tracker (lk_cuda.cpp)
 extern "C" void dvo_set_variant(const char* key, int value) {
     const std::string k = key ? key : "";
     if (k == "lk_sums") g_var_lk_sums = value; else if (k == "box_sums") g_var_box_sums = value; else if (k == "radius") g_var_radius = value; else if (k == "f4_cpu_rule") g_var_f4_cpu = value;
     else if (k == "f5_cpu_rule") g_var_f5_cpu = value; else if (k == "gftt_cuda_fma") g_var_gc_fma = value; else if (k == "gftt_cuda_tie") g_var_gc_tie = value;      // gftt_cuda.cpp
+    else if (k == "obj_point_order") g_var_obj_order = value;      // obj_solve.cpp
+    else if (k == "obj_perturb") g_var_obj_perturb = value;        // inst_manager.h
+    else if (k == "obj_dump") g_var_obj_dump = value;              // inst_manager.h (a test hook, not a variant of the arithmetic)
 }
 extern "C" int dvo_get_variant(const char* key) {
     const std::string k = key ? key : "";
     return k == "lk_sums" ? g_var_lk_sums : k == "box_sums" ? g_var_box_sums : k == "radius" ? g_var_radius : k == "f4_cpu_rule" ? g_var_f4_cpu :
-           k == "f5_cpu_rule" ? g_var_f5_cpu : k == "gftt_cuda_fma" ? g_var_gc_fma : k == "gftt_cuda_tie" ? g_var_gc_tie : -1;
+           k == "f5_cpu_rule" ? g_var_f5_cpu : k == "gftt_cuda_fma" ? g_var_gc_fma : k == "gftt_cuda_tie" ? g_var_gc_tie : k == "obj_point_order" ? g_var_obj_order : k == "obj_perturb" ? g_var_obj_perturb : k == "obj_dump" ? g_var_obj_dump : -1;
 }
 // A persistent worker pool standing in for OpenCV's parallel_for_ back end (the reference links OpenCV 3.4 built with a thread pool: calcOpticalFlowPyrLK runs
 // its LKTrackerInvoker over ranges of points, pyrDown / the corner response over ranges of rows).  Spawning std::threads per level — the round-2 form — cost

@@ -13,6 +13,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <cstring>
 #include <list>
 #include <map>
@@ -533,8 +536,24 @@ struct InstanceManager {   // estimator/estimator_insts.h
             dvo_obj_problem P{};
             P.n_obj = (int)objs.size(); P.n_boxes = (int)boxes.size(); P.n_points = (int)points.size(); P.max_iters = para.KNumIter; P.plane_kind = para.plane_kind;
             P.state = st.data(); P.dims = dm.data(); P.body_pose = &body.para_pose[0][0];
+            // variant "obj_perturb" n (sensitivity only, dvo.h): the world points the enclose factors read are moved by n x 1e-7 m (a fixed pattern) — the size of the ego-state
+            // difference between two correct implementations of the window solve (marginalization forms), which reaches the objects through p_w; tests/tools/obj_sensitivity.py
+            if (const int np = dvo_get_variant("obj_perturb"); np > 0 && np < 1000)
+                for (size_t i = 0; i < points.size(); ++i) for (int c = 0; c < 3; ++c) points[i].p_w[c] += 1e-7 * np * std::sin(1.7 * (double)i + 2.3 * c + 0.37 * seq);
             for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) P.R_bc[r * 3 + c] = body.ric[0](r, c);
             P.boxes = boxes.data(); P.points = points.data();
+            // hook "obj_dump" (tests/tools/obj_problem_dump.py; not a variant of the arithmetic): while set, the problem as it enters the solve is written under $DVO_OBJ_DUMP_DIR —
+            // fixtures for the operator-level comparison of dv_obj_solve with dvo_obj_solve on problems a real sequence produced (tests/test_obj_sequence_problems.py)
+            if (dvo_get_variant("obj_dump") > 0) {
+                const char* dir = std::getenv("DVO_OBJ_DUMP_DIR");
+                const std::string path = std::string(dir ? dir : "/tmp") + "/obj_" + std::to_string((long long)seq) + ".bin";
+                if (FILE* f = std::fopen(path.c_str(), "wb")) {
+                    const int32_t hdr[6] = { P.n_obj, P.n_boxes, P.n_points, P.max_iters, P.plane_kind, (int32_t)seq };
+                    std::fwrite(hdr, 4, 6, f); std::fwrite(st.data(), 8, st.size(), f); std::fwrite(dm.data(), 8, dm.size(), f); std::fwrite(P.body_pose, 8, 77, f); std::fwrite(P.R_bc, 8, 9, f);
+                    std::fwrite(boxes.data(), sizeof(dvo_obj_box), boxes.size(), f); std::fwrite(points.data(), sizeof(dvo_obj_point), points.size(), f);
+                    std::fclose(f);
+                }
+            }
             dvo_obj_solve(&P, &last_summary);
             for (size_t o = 0; o < objs.size(); ++o) { std::memcpy(objs[o]->para_state, &st[o * 77], 77 * 8); std::memcpy(objs[o]->para_box, &dm[o * 3], 24); }
         }

@@ -78,8 +78,12 @@ extern "C" int dvo_obj_solve(dvo_obj_problem* P, dvo_ba_summary* S) {
         prob.AddResidualBlock(std::make_shared<DimsCost>(b.dims), kHuber1, { P->dims + 3 * (size_t)b.obj });
         prob.AddResidualBlock(std::make_shared<OrientationCost>(b.R_cioi, P->R_bc), kNoLoss, { body.data() + 7 * b.frame, state(b.obj, b.frame) });
     }
-    for (int i = 0; i < P->n_points; ++i) {
-        const dvo_obj_point& p = P->points[i];
+    // variant "obj_point_order" 1 (sensitivity only, dvo.h): the point blocks join the problem in REVERSE order — same parameter blocks in the same order, same residual
+    // blocks, a different (equally valid) summation order of J^T J and J^T r.  What that is worth over a long dynamic run: tests/tools/obj_sensitivity.py
+    const bool rev = dvo_get_variant("obj_point_order") == 1;
+    if (rev) for (int i = 0; i < P->n_points; ++i) prob.AddParameterBlock(state(P->points[i].obj, P->points[i].frame), 7, pose_kind);
+    for (int k = 0; k < P->n_points; ++k) {
+        const dvo_obj_point& p = P->points[rev ? P->n_points - 1 - k : k];
         prob.AddParameterBlock(state(p.obj, p.frame), 7, pose_kind);
         prob.AddResidualBlock(std::make_shared<EncloseCost>(p.p_w, dims0.data() + 3 * (size_t)p.obj), kHuber1, { state(p.obj, p.frame) });
     }

@@ -1,4 +1,4 @@
-"""Long-run parity: what the 30 - 44-frame parity tests cannot say.  scripts/longrun_parity.py runs images -> tracker -> estimator on the HIP path
+"""Long-run parity: what the 30 - 44-frame parity tests cannot say.  tests/tools/longrun_parity.py runs images -> tracker -> estimator on the HIP path
 and on the oracle for hundreds of frames and counts, per frame: bit-identity of the rows handed from the front end to the back end, equality of the estimator's flags /
 counts, and how often a window solve ended a different number of iterations apart (tests/conftest.py::iterations_agree's +-1 allowance: the prior's constant c0 carries
 rounding noise that moves only Ceres' RELATIVE function-tolerance test).
@@ -17,7 +17,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
 FULL = os.environ.get("DVINS_LONGRUN", "0") == "1"
 
 

@@ -74,11 +74,13 @@ Gray read_pgm(const std::vector<uint8_t>& buf, const std::string& path) {
     };
     const std::string magic = token();
     if (magic != "P5" && magic != "P6") throw std::runtime_error("dvins_node: " + path + " is not a binary PGM / PPM");
-    Gray g; g.w = std::stoi(token()); g.h = std::stoi(token());
-    if (std::stoi(token()) != 255) throw std::runtime_error("dvins_node: " + path + ": only 8-bit images");
+    auto number = [&]() { const std::string t = token(); try { return std::stoi(t); } catch (const std::exception&) { throw std::runtime_error("dvins_node: " + path + ": bad PGM / PPM header"); } };
+    Gray g; g.w = number(); g.h = number();
+    if (number() != 255) throw std::runtime_error("dvins_node: " + path + ": only 8-bit images");
     ++p;
     const size_t ch = magic == "P5" ? 1 : 3;
-    if (buf.size() - p < (size_t)g.w * g.h * ch) throw std::runtime_error("dvins_node: " + path + " is truncated");
+    if (g.w <= 0 || g.h <= 0 || g.w > 65535 || g.h > 65535) throw std::runtime_error("dvins_node: " + path + ": bad image size");
+    if (p > buf.size() || buf.size() - p < (size_t)g.w * g.h * ch) throw std::runtime_error("dvins_node: " + path + " is truncated");
     g.d.resize((size_t)g.w * g.h);
     if (ch == 1) std::memcpy(g.d.data(), buf.data() + p, g.d.size());
     else for (size_t i = 0; i < g.d.size(); ++i) g.d[i] = bgr2gray(buf[p + 3 * i], buf[p + 3 * i + 1], buf[p + 3 * i + 2]);
@@ -94,14 +96,16 @@ Gray read_png(const std::vector<uint8_t>& buf, const std::string& path, bool kee
     for (size_t o = 8; o + 12 <= buf.size();) {
         const uint32_t len = be32(o); const char* tag = (const char*)&buf[o + 4];
         if (o + 12 + len > buf.size()) break;
-        if (!std::memcmp(tag, "IHDR", 4)) { w = (int)be32(o + 8); h = (int)be32(o + 12); depth = buf[o + 16]; ctype = buf[o + 17]; interlace = buf[o + 20]; }
+        if (!std::memcmp(tag, "IHDR", 4)) { if (len < 13) throw std::runtime_error("dvins_node: " + path + ": short IHDR chunk"); w = (int)be32(o + 8); h = (int)be32(o + 12); depth = buf[o + 16]; ctype = buf[o + 17]; interlace = buf[o + 20]; }
         else if (!std::memcmp(tag, "IDAT", 4)) z.insert(z.end(), buf.begin() + o + 8, buf.begin() + o + 8 + len);
         else if (!std::memcmp(tag, "IEND", 4)) break;
         o += 12 + len;
     }
     const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
-    if (!w || !h || depth != 8 || !ch || interlace) throw std::runtime_error("dvins_node: " + path + ": only non-interlaced 8-bit gray / RGB(A) PNGs");
+    if (w <= 0 || h <= 0 || depth != 8 || !ch || interlace) throw std::runtime_error("dvins_node: " + path + ": only non-interlaced 8-bit gray / RGB(A) PNGs");
     const size_t row = (size_t)w * ch;
+    // the header is input like any other: deflate expands at most ~1032 : 1, so a size the compressed stream cannot fill is refused BEFORE anything of that size is allocated
+    if (w > 65535 || h > 65535 || (row + 1) * (size_t)h > z.size() * 1032 + 1024) throw std::runtime_error("dvins_node: " + path + ": image size and compressed data do not fit together");
     std::vector<uint8_t> raw((row + 1) * h);
     uLongf out_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &out_len, z.data(), (uLong)z.size()) != Z_OK || out_len != raw.size()) throw std::runtime_error("dvins_node: " + path + ": inflate failed");

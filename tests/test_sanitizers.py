@@ -54,3 +54,39 @@ def test_runner_and_shim_under_tsan():
             pytest.skip("ThreadSanitizer cannot map its shadow memory on this kernel")
         assert r.returncode == 0 and "ThreadSanitizer" not in r.stderr, (cmd, r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     assert "DIFFERENT" not in r.stdout
+
+
+@pytest.mark.skipif(_lib("libasan.so") is None, reason="no libasan in this toolchain")
+def test_node_image_decoders_on_malformed_files_under_asan(tmp_path):
+    """dvins_node's PGM / PNG readers face files from outside.  A mutation run under ASan + UBSan (2169 truncated / bit-flipped / header-edited images; 3974 YAML / calibration
+    files and 974 feature files through the shim's parsers: clean) found two defects in round 6, both fixed: a PGM cut right behind its header read past the buffer
+    (`buf.size() - p` wrapped), and a PNG whose IHDR claims a size its compressed stream cannot fill allocated (and cleared) that size — tens of gigabytes from a 500-byte file.
+    The deterministic cases below are the regression: each must end in the node's own error (exit 1, "dvins_node: ..."), never in a sanitizer report, and quickly."""
+    import struct
+    import numpy as np
+    from tests.test_node import write_pgm, write_png
+    r = subprocess.run(["make", "-s", "-C", HOST, "_build/dvins_node_asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    exe = os.path.join(HOST, "_build", "dvins_node_asan")
+    rng = np.random.default_rng(7)
+    write_png(tmp_path / "g.png", rng.integers(0, 256, (19, 23), dtype=np.uint8)); write_png(tmp_path / "a.png", rng.integers(0, 256, (9, 13, 4), dtype=np.uint8), filters=(4, 3))
+    write_pgm(tmp_path / "p.pgm", rng.integers(0, 256, (7, 9), dtype=np.uint8))
+    png, pgm = open(tmp_path / "g.png", "rb").read(), open(tmp_path / "p.pgm", "rb").read()
+    hdr = pgm.index(b"255") + 3
+    cases = {"pgm_cut_behind_header.pgm": pgm[:hdr], "pgm_cut_in_header.pgm": pgm[:5], "pgm_half.pgm": pgm[: hdr + 20], "pgm_negative.pgm": b"P5\n-1 -1\n255\n" + pgm[hdr + 1:],
+             "pgm_huge.pgm": b"P5\n70000 70000\n255\n" + pgm[hdr + 1:], "png_short_ihdr.png": png[:8] + struct.pack(">I", 3) + png[12:], "png_cut.png": png[: len(png) // 2],
+             "png_ihdr_at_the_end.png": png + struct.pack(">I", 0) + b"IHDR"}
+    for w, h in [(0, 5), (5, 0), (0x7FFFFFFF, 1), (1, 0x7FFFFFFF), (0xFFFFFFFF, 0xFFFFFFFF), (65536, 65536), (65535, 65535), (23, 1000000)]:
+        cases["png_%x_%x.png" % (w, h)] = png[:16] + struct.pack(">II", w, h) + png[24:]
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    ok = subprocess.run([exe, "--decode", str(tmp_path / "g.png"), str(tmp_path / "a.png"), str(tmp_path / "p.pgm")], env=env, capture_output=True, text=True, timeout=60)
+    assert ok.returncode == 0 and len(ok.stdout.splitlines()) == 3, ok.stdout + ok.stderr[-2000:]
+    for name, data in cases.items():
+        open(tmp_path / name, "wb").write(data)
+        r = subprocess.run([exe, "--decode", str(tmp_path / name)], env=env, capture_output=True, text=True, errors="replace", timeout=20)
+        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, (name, r.stderr[-2500:])
+        if name == "png_ihdr_at_the_end.png":          # bytes behind IEND are not read: decodes like the original
+            assert r.returncode == 0 and r.stdout == ok.stdout.splitlines()[0] + "\n", (name, r.returncode, r.stdout)
+            continue
+        assert r.returncode == 1 and "dvins_node" in (r.stdout + r.stderr), (name, r.returncode, r.stdout[-300:], r.stderr[-300:])
+

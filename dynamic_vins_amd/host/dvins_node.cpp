@@ -190,8 +190,9 @@ int main(int argc, char** argv) {
         std::vector<Gray> L(n), R(n);
         for (int k = 0; k < n; ++k) {
             L[k] = read_image(lf[k]); R[k] = read_image(rf[k]);
-            if (L[k].w != cfg.front.width || L[k].h != cfg.front.height || R[k].w != L[k].w || R[k].h != L[k].h)      // (system/main.cpp:95-99 enforces the configured size)
-                throw std::runtime_error("dvins_node: " + lf[k] + " is not image_width x image_height of the config");
+            const bool left_ok = L[k].w == cfg.front.width && L[k].h == cfg.front.height;      // (system/main.cpp:95-99 enforces the configured size)
+            if (!left_ok || R[k].w != L[k].w || R[k].h != L[k].h)
+                throw std::runtime_error("dvins_node: " + (left_ok ? rf[k] : lf[k]) + " is not image_width x image_height of the config");
         }
         std::vector<double> times(n);
         { std::ifstream tf(seq_dir + "/times.txt"); double t = 0.0; for (int k = 0; k < n; ++k) { if (tf && (tf >> times[k])) continue; times[k] = t; t += 0.05; } }      // Dataloader::LoadStereo: time += 0.05

@@ -90,3 +90,40 @@ def test_node_image_decoders_on_malformed_files_under_asan(tmp_path):
             continue
         assert r.returncode == 1 and "dvins_node" in (r.stdout + r.stderr), (name, r.returncode, r.stdout[-300:], r.stderr[-300:])
 
+
+@pytest.mark.skipif(_lib("libasan.so") is None, reason="no libasan in this toolchain")
+def test_node_parse_path_under_asan_up_to_the_missing_device(tmp_path):
+    """the node's whole input side — YAML config + camera file, directory listing, every image of the pairs (PGM left, PNG right), imu.csv with comment / short / ns-stamped lines,
+    times.txt — under ASan + UBSan on a CPU box: everything is read and checked BEFORE dv_create, which then fails loudly (no device).  With a GPU the run goes through."""
+    import numpy as np
+    import torch
+    from tests.test_node import CAM, CFG, write_pgm, write_png
+    r = subprocess.run(["make", "-s", "-C", HOST, "_build/dvins_node_asan"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    w, h, n = 64, 48, 5
+    rng = np.random.default_rng(3)
+    sd = tmp_path / "seq"
+    (sd / "left").mkdir(parents=True); (sd / "right").mkdir()
+    for k in range(n):
+        write_pgm(sd / "left" / f"{k:06d}.pgm", rng.integers(0, 256, (h, w), dtype=np.uint8)); write_png(sd / "right" / f"{k:06d}.png", rng.integers(0, 256, (h, w), dtype=np.uint8))
+    with open(sd / "imu.csv", "w") as f:
+        f.write("#timestamp [ns],w_x,w_y,w_z,a_x,a_y,a_z\n\n1403636579758555392,0.1,0.2,0.3,9.8,0.0,0.1\n0.05,0,0\nnot,a,number,at,all,x,y\n")
+        for i in range(40):
+            f.write("%.6f,0.0,0.0,0.0,0.0,0.0,9.81\n" % (0.005 * i))
+    open(sd / "times.txt", "w").write("".join("%.3f\n" % (0.05 * k) for k in range(n)))
+    (tmp_path / "cfg").mkdir()
+    open(tmp_path / "cfg" / "node.yaml", "w").write(CFG.format(w=w, h=h))
+    open(tmp_path / "cfg" / "cam.yaml", "w").write(CAM.format(w=w, h=h, k1=-0.1, k2=0.01, p1=0.0, p2=0.0, fx=35.0, fy=35.0, cx=32.0, cy=24.0))
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    exe = os.path.join(HOST, "_build", "dvins_node_asan")
+    r = subprocess.run([exe, str(tmp_path / "cfg" / "node.yaml"), str(sd), str(tmp_path)], env=env, capture_output=True, text=True, errors="replace", timeout=300)
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-3000:]
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout[-500:] + r.stderr[-500:]
+    else:
+        assert r.returncode == 1 and "dvins_node:" in (r.stdout + r.stderr), (r.returncode, r.stdout[-500:], r.stderr[-500:])
+    # a right image of another size is refused by name, a missing imu.csv likewise
+    write_png(sd / "right" / "000002.png", rng.integers(0, 256, (h, w + 2), dtype=np.uint8))
+    r = subprocess.run([exe, str(tmp_path / "cfg" / "node.yaml"), str(sd), str(tmp_path)], env=env, capture_output=True, text=True, errors="replace", timeout=300)
+    assert r.returncode == 1 and "000002.png" in (r.stdout + r.stderr) and "AddressSanitizer" not in r.stderr, (r.returncode, r.stdout[-300:], r.stderr[-800:])
+

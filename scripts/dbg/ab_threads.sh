@@ -17,3 +17,11 @@ run s64_t32 --sequences 64 --runner-threads 32
 run s64_g8_t16 --sequences 64 --group-size 8 --runner-threads 16
 run s64_g8_t32 --sequences 64 --group-size 8 --runner-threads 32
 done
+# second sweep (another box): group sizes for 16 sequences, threads for 32 sequences
+# run s16_g4_t8 --sequences 16
+# run s16_g8_t8 --sequences 16 --group-size 8 --runner-threads 8
+# run s16_g16_t8 --sequences 16 --group-size 16 --runner-threads 8
+# run s32_g8_t8 --sequences 32
+# run s32_g8_t16 --sequences 32 --runner-threads 16
+# run s32_g8_t32 --sequences 32 --runner-threads 32
+# run s32_g16_t16 --sequences 32 --group-size 16 --runner-threads 16

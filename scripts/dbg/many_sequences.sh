@@ -10,3 +10,5 @@ for ln in sys.stdin:
 run s128_g16_t64 --sequences 128 --group-size 16 --runner-threads 64 --steps 40
 run s128_default --sequences 128 --steps 40
 run s96_g16_t48 --sequences 96 --group-size 16 --runner-threads 48 --steps 40
+run s256_default --sequences 256 --steps 40
+run s128_g32_t64 --sequences 128 --runner-threads 64 --steps 40
